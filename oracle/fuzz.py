@@ -1,0 +1,132 @@
+"""Seeded generators of pileup text for parity tests.  TEST INFRASTRUCTURE ONLY.
+
+``fuzz_line`` produces single lines that exercise the grammar corners listed in
+SURVEY.md A.1 (caret runs, indel tails that collide, length mismatches, exotic
+bytes, lower-case reference, depth 0 ...).  ``synth_pileup`` produces a small
+well-formed genome-wide pileup in the shape SURVEY.md 8(d) describes, on the
+host, for sizes the Python oracle finishes in seconds.
+"""
+
+import random
+
+_QUAL_LO, _QUAL_HI = 33, 74
+
+
+def _bases_token(rng, ref_like=True):
+    r = rng.random()
+    if r < 0.45:
+        return rng.choice(".,")
+    if r < 0.75:
+        return rng.choice("ACGTNacgtn")
+    if r < 0.80:
+        return "*"
+    if r < 0.86:
+        return "^" + chr(rng.randint(33, 126)) + rng.choice(".,ACGTacgt")
+    if r < 0.91:
+        return rng.choice(".,ACGT") + "$"
+    if r < 0.97:
+        k = rng.randint(1, 12)
+        return rng.choice(".,ACGT") + rng.choice("+-") + str(k) + "".join(rng.choice("ACGTNacgtn") for _ in range(k))
+    return rng.choice("#<>*")
+
+
+def _adversarial(rng):
+    """Strings that are not valid samtools output but that the reference still
+    has a defined answer for."""
+    pool = [
+        "^^.A", "^+2AC.", "^$.$", ".^", "^", "^^", "^^^", ".+3A-1C.", ".+2A-1CG.", "+1+1AA.", ".-2+1A.",
+        "..+9AC", ".+1A2C", ".+A.", "+1$A", ".+0A", "-0", "+", "-", "+-1A.", ".+12ACGTACGTACGTA,",
+        ".+1^A,C", ".^+1A", "$$$", ".$+1A,", "+2^AC..", "+1^", ".,+3AC", "+007ACGTACG.", "1.2,", ".+2A^B-1C,,,",
+        "..-1^", "+1+", "+1-", "^-1A.", ".+1", ".-", "+99999999999999999999A.", "..+1A+1", "[]_`\\", "{|}~",
+        "Rr.,", "*#<>", "....^~a", ",,,,$", "a+1gc-2tta",
+    ]
+    s = rng.choice(pool)
+    if rng.random() < 0.5:
+        s = "".join(_bases_token(rng) for _ in range(rng.randint(0, 6))) + s
+    if rng.random() < 0.5:
+        s = s + "".join(_bases_token(rng) for _ in range(rng.randint(0, 6)))
+    return s
+
+
+def fuzz_line(rng, chrom="chrF"):
+    """One pileup line (str, no newline) plus nothing else; may be malformed."""
+    pos = rng.randint(1, 5_000_000)
+    ref = rng.choice("ACGTNacgtnRY*")
+    mode = rng.random()
+    if mode < 0.04:
+        return "%s\t%d\t%s\t0\t*\t*" % (chrom, pos, ref)
+    if mode < 0.06:
+        return "%s\t%d\t%s\t0" % (chrom, pos, ref)
+    if mode < 0.08:
+        return "%s\t%d\t%s\t%d" % (chrom, pos, ref, rng.randint(1, 9))      # 4 fields, depth>0 -> empty record
+    if mode < 0.30:
+        bases = _adversarial(rng)
+    else:
+        depth_t = rng.choice([1, 2, 3, 5, 8, 13, 30, 30, 30, 64, 65, 130, 300])
+        bases = "".join(_bases_token(rng) for _ in range(depth_t))
+    # quality string: usually one char per surviving base, sometimes off by a few
+    approx = sum(1 for c in bases if c in ".,ACGTNacgtn*#<>")
+    qlen = max(0, approx + rng.choice([0, 0, 0, 0, 0, 0, -2, -1, 1, 3]))
+    if rng.random() < 0.03:
+        qlen = 0
+    quals = "".join(chr(rng.randint(_QUAL_LO, _QUAL_HI)) for _ in range(qlen))
+    depth = rng.choice([approx, approx, approx, max(1, approx + 1), 1])
+    sep = "\t" if rng.random() < 0.93 else rng.choice([" ", "\t\t", " \t", "\x0b", "\x1f"])
+    fields = [chrom, str(pos), ref, str(max(depth, 1)), bases]
+    if qlen > 0 or rng.random() < 0.5:
+        fields.append(quals)
+    line = sep.join(f for f in fields)
+    if rng.random() < 0.03:
+        line = line + rng.choice([" ", "\t", "  "])
+    return line
+
+
+def synth_pileup(seed, genome_len=4000, contigs=("synth_chr1",), mean_depth=30, n_sites=60,
+                 carrier_frac=0.3, skip_frac=0.01, site_margin=1):
+    """Small well-formed pileup.  Returns (text bytes, reference {contig: str},
+    site list [(contig bytes, pos)], sorted)."""
+    rng = random.Random(seed)
+    lines = []
+    refs = {}
+    sites = []
+    for contig in contigs:
+        ref = "".join(rng.choice("ACGT") for _ in range(genome_len))
+        refs[contig] = ref
+        lo, hi = site_margin, genome_len - site_margin + 1
+        chosen = sorted(rng.sample(range(lo, hi), min(n_sites, hi - lo)))
+        alts = {p: rng.choice([b for b in "ACGT" if b != ref[p - 1]]) for p in chosen}
+        carried = {p for p in chosen if rng.random() < carrier_frac}
+        sites.extend((contig.encode(), p) for p in chosen)
+        for pos in range(1, genome_len + 1):
+            if rng.random() < skip_frac:
+                continue                                   # uncovered position: no line
+            depth = max(0, int(rng.gauss(mean_depth, mean_depth ** 0.5)))
+            if depth == 0:
+                continue
+            r = ref[pos - 1]
+            toks = []
+            quals = []
+            for _ in range(depth):
+                fwd = rng.random() < 0.5
+                if pos in carried and rng.random() < 0.97:
+                    b = alts[pos]
+                    t = b if fwd else b.lower()
+                elif rng.random() < 0.005:
+                    b = rng.choice([x for x in "ACGT" if x != r])
+                    t = b if fwd else b.lower()
+                elif rng.random() < 0.0005:
+                    t = "*"
+                else:
+                    t = "." if fwd else ","
+                if rng.random() < 1 / 150:
+                    t = "^" + chr(33 + rng.randint(0, 42)) + t
+                if rng.random() < 1e-3:
+                    k = rng.randint(1, 3)
+                    seq = "".join(rng.choice("ACGT") for _ in range(k))
+                    t += rng.choice("+-") + str(k) + (seq if fwd else seq.lower())
+                if rng.random() < 1 / 150:
+                    t += "$"
+                toks.append(t)
+                quals.append(chr(33 + min(41, max(2, int(round(rng.gauss(35, 5)))))))
+            lines.append("%s\t%d\t%s\t%d\t%s\t%s\n" % (contig, pos, r, depth, "".join(toks), "".join(quals)))
+    return "".join(lines).encode(), refs, sorted(sites)

@@ -1,0 +1,414 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under ``tests/golden/`` by running the REAL
+reference (``/root/reference/snppipeline``) in the build container.
+
+Run from the repo root:  ``python oracle/gen_golden.py``
+
+The reference is imported in place (never copied, no bytecode written).
+``snppipeline.pileup`` imports natively; ``utils``/``filter_regions``/
+``call_consensus`` need ``Bio`` and ``vcf`` (PyVCF3), which are not installed,
+so minimal stand-in modules are registered in ``sys.modules`` — enough for the
+functions exercised here to run their own arithmetic:
+``vcf.Reader`` yields objects with ``CHROM``/``POS`` parsed from the data lines
+(all the reference ever reads from it on these paths), ``SeqIO.write`` captures
+the sequence string that ``call_consensus`` built.
+
+Outputs (committed):
+  tests/golden/pileup_vectors.json.gz   strip / Record / caller vectors, whole-file runs
+  tests/golden/steps_vectors.json.gz    region, merge, distance vectors
+  tests/golden/fixtures/...             the reference's bundled ExpectedResults files
+                                        that pin the path (data files, some gzipped)
+"""
+
+import argparse
+import doctest
+import gzip
+import io
+import json
+import os
+import random
+import shutil
+import sys
+import tarfile
+import tempfile
+import types
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+
+def install_stubs():
+    captured = {}
+
+    bio = types.ModuleType("Bio")
+    seqio = types.ModuleType("Bio.SeqIO")
+    seqm = types.ModuleType("Bio.Seq")
+    recm = types.ModuleType("Bio.SeqRecord")
+
+    class Seq(str):
+        pass
+
+    class SeqRecord(object):
+        def __init__(self, seq, id="", description=""):
+            self.seq, self.id, self.description = seq, id, description
+
+    def write(records, handle, fmt):
+        for r in records:
+            captured["last"] = (r.id, str(r.seq))
+            handle.write(">%s\n" % r.id)
+        return len(records)
+
+    def parse(handle, fmt):
+        name, chunks = None, []
+        for line in handle:
+            if line.startswith(">"):
+                if name is not None:
+                    yield SeqRecord(Seq("".join(chunks)), id=name)
+                name, chunks = line[1:].split()[0], []
+            else:
+                chunks.append(line.strip())
+        if name is not None:
+            yield SeqRecord(Seq("".join(chunks)), id=name)
+
+    seqio.write, seqio.parse = write, parse
+    seqm.Seq, recm.SeqRecord = Seq, SeqRecord
+    bio.SeqIO, bio.Seq, bio.SeqRecord = seqio, seqm, recm
+
+    vcf = types.ModuleType("vcf")
+
+    class _Rec(object):
+        def __init__(self, chrom, pos):
+            self.CHROM, self.POS = chrom, pos
+
+    class Reader(object):
+        def __init__(self, fsock=None, **kw):
+            self._f = fsock
+
+        def __iter__(self):
+            for line in self._f:
+                if line.startswith("#") or not line.strip():
+                    continue
+                f = line.split("\t")
+                yield _Rec(f[0], int(f[1]))
+
+    vcf.Reader = Reader
+    for name, mod in [("Bio", bio), ("Bio.SeqIO", seqio), ("Bio.Seq", seqm), ("Bio.SeqRecord", recm), ("vcf", vcf)]:
+        sys.modules[name] = mod
+    return captured
+
+
+def counter_items(c):
+    return sorted([k, v] for k, v in c.items())
+
+
+PARAM_SETS = [
+    [0, 0.6, 1, 0, 0.0],      # CLI defaults (cfsan_snp_pipeline.py:397-401)
+    [0, 0.6, 3, 0, 0.0],      # pipeline conf (snppipeline.conf:249)
+    [15, 0.9, 5, 2, 0.1],     # strict set from SURVEY 8(d)
+    [20, 0.75, 2, 1, 0.25],
+    [0, 1.0, 0, 0, 0.5],
+]
+
+
+def record_vector(pileup, line, with_calls=True):
+    """Run the reference Record (+ callers) on one line for every parameter set."""
+    out = {"line": line, "by_q": {}}
+    for q in sorted({p[0] for p in PARAM_SETS}):
+        try:
+            r = pileup.Record(line, q)
+        except Exception as e:                      # IndexError / ValueError paths
+            out["by_q"][str(q)] = {"error": type(e).__name__}
+            continue
+        d = {
+            "chrom": r.chrom, "pos": r.position, "ref": r.reference_base, "raw": r.raw_depth,
+            "good": r.good_depth, "fwd": r.forward_good_depth, "rev": r.reverse_good_depth,
+            "total_hist": counter_items(r.base_good_depth),
+            "fwd_hist": counter_items(r.forward_base_good_depth),
+            "rev_hist": counter_items(r.reverse_base_good_depth),
+            "ranked": r.most_common_good_bases,
+            "calls": [],
+        }
+        if with_calls:
+            for p in PARAM_SETS:
+                if p[0] != q:
+                    continue
+                caller = pileup.ConsensusCaller(p[1], p[2], p[3], p[4])
+                base, failed = caller.call_consensus(r)
+                d["calls"].append({"params": p, "base": base, "failed": failed})
+        out["by_q"][str(q)] = d
+    return out
+
+
+def gen_pileup_vectors(captured):
+    from snppipeline import pileup
+    from oracle import fuzz
+
+    res = doctest.testmod(pileup)
+    assert res.failed == 0, res
+    vec = {"reference_doctests": {"attempted": res.attempted, "failed": res.failed}}
+
+    # --- strip vectors: doctest examples (pileup.py:294-309), SURVEY A.1 probes, fuzz
+    strip_in = [".,.actg,,,", "^K.,.^Fa,,,^K", "$.,.$*$*,,,*", ".,.+10AAAAAAAAAAa,,,", "+2TT.,.+10AAAAAAAAAAa,,,+2GC",
+                ".,.-10AAAAAAAAAAa,,,", "-2TT.,.-10AAAAAAAAAAa,,,-2GC", "^Kc-2TT..$a+10AAAAAAAAAAa,,*,-2GC",
+                "^^.A", "^+2AC.", "^$.$", "..+9AC", ".-1A+1C.", ".+1A2C", ".+A.", "+1$A", ".+3A-1C.", ".+2A-1CG.",
+                "+1+1AA.", ".-2+1A.", "", "^", "+", "5", "+5", "$"]
+    rng = random.Random(1234)
+    alphabet = "^^^++--$$0123456789.,.,ACGTacgt*"
+    for _ in range(6000):
+        strip_in.append("".join(rng.choice(alphabet) for _ in range(rng.randint(0, 24))))
+    for _ in range(1500):
+        strip_in.append(fuzz._adversarial(rng))
+    vec["strip"] = [[s, pileup.Record._strip_unwanted_base_patterns(s)] for s in strip_in]
+
+    # --- record vectors: doctest records (pileup.py:98-184, 513-548) + fuzz
+    lines = [
+        "NC_011149.1\t42\tG\t9\taaAaA+6TAAGAG..+5AAGAG.,\t21G1G-111",
+        "ID\t628640\tA\t20\t**.,,.,.............\t22E?;9HF;H8EDGHHI?GH",
+        "gi|197247352|ref|NC_011149.1|\t4663812\tT\t0",
+        "ID\t1\tA\t20\tTTccAAGG\t22E?;9HF;H8EDGHHI?GH",
+        "ID\t1\tA\t20\tTTtccAAAGG\t22E?;9HF;H8EDGHHI?GH",
+        "ID\t42\tG\t14\taaaaAAAA...,,,\t00001111222333",
+        "ID\t42\tG\t14\taAAAAAAA...,,,\t00001111222333",
+        "ID\t42\tG\t14\taaaAAAAA...,,,\t00001111222333",
+        "ID\t42\tG\t14\taaaAAA....,,,,\t00011122223333",
+        "ID\t42\tg\t14\taaaAAA....,,,,\t00011122223333",
+        "ID\t42\tg\t0",
+        "ID\t7\tG\t4\t**..\tIIII",
+        "ID\t7\tN\t3\t...\tIII",
+        "ID\t7\tA\t2\t.\tII",
+        "ID\t7\tA\t5\t.....\tIII",
+    ]
+    rng = random.Random(77)
+    for _ in range(4200):
+        lines.append(fuzz.fuzz_line(rng))
+    vec["records"] = [record_vector(pileup, ln) for ln in lines]
+
+    # --- float-threshold table: cons < depth * freq for the stock frequencies (pileup.py:564)
+    thr = {}
+    for f in (0.6, 0.75, 0.9, 1.0, 0.51):
+        thr[repr(f)] = [min(k for k in range(0, d + 2) if not (k < d * f)) for d in range(0, 400)]
+    vec["freq_threshold"] = thr
+
+    # --- whole-file runs through the reference's own call_consensus driver
+    from snppipeline import call_consensus as cc
+    from snppipeline import utils as ref_utils
+    runs = []
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    try:
+        for seed, kw, pset in [
+            (11, dict(genome_len=3000, n_sites=80), PARAM_SETS[1]),
+            (12, dict(genome_len=2500, n_sites=60, contigs=("ctgB", "ctgA", "ctgAA")), PARAM_SETS[2]),
+            (13, dict(genome_len=1500, n_sites=40, mean_depth=9), PARAM_SETS[0]),
+            (14, dict(genome_len=1200, n_sites=50, mean_depth=70), PARAM_SETS[3]),
+        ]:
+            data, refs, sites = fuzz.synth_pileup(seed, **kw)
+            rng = random.Random(seed)
+            # snplist: sites (+ some positions that have no pileup line, + one duplicate)
+            snps = list(sites)
+            snps.append((sites[0][0], 10_000_000))
+            snps.sort()
+            excluded = sorted(rng.sample(sites, max(1, len(sites) // 7)))
+            extra_excl = [(sites[0][0], 5), (sites[0][0], 6)]       # excluded but not in snplist
+            sdir = os.path.join(tmp, "sample%d" % seed)
+            os.makedirs(sdir)
+            ppath = os.path.join(sdir, "reads.all.pileup")
+            with open(ppath, "wb") as f:
+                f.write(data)
+            lpath = os.path.join(tmp, "snplist%d.txt" % seed)
+            with open(lpath, "w") as f:
+                for c, p in snps:
+                    f.write("%s\t%d\t1\tx\n" % (c.decode(), p))
+            epath = os.path.join(sdir, "excl.vcf")
+            with open(epath, "w") as f:
+                f.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n")
+                for c, p in excluded + extra_excl:
+                    f.write("%s\t%d\t.\tA\tC\t.\tPASS\t.\tGT\t1/1\n" % (c.decode(), p))
+            for use_excl in (False, True):
+                args = argparse.Namespace(
+                    snpListFile=lpath, allPileupFile=ppath, consensusFile=os.path.join(sdir, "consensus.fasta"),
+                    excludeFile=epath if use_excl else None, forceFlag=True, vcfFileName=None, vcfRefName="x",
+                    vcfAllPos=False, vcfPreserveRefCase=False, vcfFailedSnpGt=".", minBaseQual=pset[0],
+                    minConsFreq=pset[1], minConsDpth=pset[2], minConsStrdDpth=pset[3], minConsStrdBias=pset[4])
+                ref_utils.log_verbosity = 0
+                sink = io.StringIO()
+                old = sys.stdout
+                sys.stdout = sink
+                try:
+                    cc.call_consensus(args)
+                finally:
+                    sys.stdout = old
+                sid, seq = captured["last"]
+                runs.append({
+                    "seed": seed, "kw": {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()},
+                    "params": pset, "snplist": [[c.decode(), p] for c, p in snps],
+                    "excluded": [[c.decode(), p] for c, p in excluded + extra_excl] if use_excl else [],
+                    "sample": sid, "consensus": seq,
+                })
+    finally:
+        shutil.rmtree(tmp)
+    vec["runs"] = runs
+    return vec
+
+
+def gen_steps_vectors():
+    from snppipeline import filter_regions as fr
+    from snppipeline import utils as ru
+
+    assert doctest.testmod(fr).failed == 0
+    vec = {}
+    rng = random.Random(5)
+    dense = []
+    fixed = [(3, 1000, []), (3, 1000, [1, 2, 3, 1001]), (3, 1000, [1, 20, 30, 1000]), (3, 1000, [1, 20, 30, 40, 1000]),
+             (3, 1000, [1, 20, 30, 40, 501, 600, 1000, 1500]), (3, 1000, [1, 2, 3, 1000, 1500, 3001, 3002, 3003, 4000])]
+    for m, w, s in fixed:
+        dense.append({"m": m, "w": w, "snps": s, "out": [list(t) for t in fr.find_dense_regions(m, w, s)]})
+    for _ in range(400):
+        n = rng.randint(0, 60)
+        span = rng.choice([200, 2000, 20000])
+        s = sorted(rng.randint(1, span) for _ in range(n))       # duplicates allowed
+        m, w = rng.choice([(3, 1000), (2, 125), (1, 15), (5, 50), (1, 1)])
+        dense.append({"m": m, "w": w, "snps": s, "out": [list(t) for t in fr.find_dense_regions(m, w, s)]})
+    vec["find_dense_regions"] = dense
+
+    merges = []
+    for _ in range(400):
+        regs = []
+        for _ in range(rng.randint(0, 14)):
+            a = rng.randint(0, 300)
+            regs.append((a, a + rng.randint(0, 40)))
+        merges.append({"in": [list(r) for r in regs], "out": [list(r) for r in ru.merge_regions(list(regs))]})
+    vec["merge_regions"] = merges
+
+    inreg = []
+    for _ in range(300):
+        regs = ru.merge_regions([(a, a + rng.randint(0, 10)) for a in (rng.randint(0, 100) for _ in range(rng.randint(0, 6)))])
+        p = rng.randint(0, 115)
+        inreg.append({"pos": p, "regions": [list(r) for r in regs], "out": bool(ru.in_region(p, regs))})
+    vec["in_region"] = inreg
+
+    dist = []
+    alpha = "ACGTacgt-NnRY*"
+    for _ in range(500):
+        n = rng.randint(0, 90)
+        a = "".join(rng.choice(alpha) for _ in range(n))
+        b = "".join(rng.choice(alpha) for _ in range(n))
+        dist.append({"a": a, "b": b, "d": ru.calculate_sequence_distance(a, b)})
+    vec["sequence_distance"] = dist
+
+    # collect_dense_regions with a stand-in reader (objects with CHROM/POS)
+    class R(object):
+        def __init__(self, c, p):
+            self.CHROM, self.POS = c, p
+    coll = []
+    for _ in range(120):
+        lens = {"c1": rng.choice([900, 1000, 1001, 5000, 50000]), "c2": 30000}
+        samples = []
+        for s in range(rng.randint(1, 4)):
+            recs = []
+            for _ in range(rng.randint(0, 40)):
+                c = rng.choice(["c1", "c1", "c2", "c3"])
+                recs.append([c, rng.randint(1, lens.get(c, 60000))])
+            samples.append(recs)
+        edge = rng.choice([500, 100, 1])
+        rules = rng.choice([([3, 2, 1], [1000, 125, 15]), ([3], [1000]), ([1], [5])])
+        bad = {}
+        for recs in samples:
+            fr.collect_dense_regions([R(c, p) for c, p in recs], bad, lens, edge, rules[0], rules[1])
+        merged = {c: [list(r) for r in ru.merge_regions(v)] for c, v in bad.items()}
+        coll.append({"lens": lens, "samples": samples, "edge": edge, "max_snps": rules[0], "windows": rules[1], "out": merged})
+    vec["collect_all"] = coll
+
+    # snplist writer
+    d = {("chrB", 5): ["s1"], ("chrA", 100): ["s2", "s1"], ("chrA", 20): ["s3"], ("chrAA", 3): ["s1", "s2", "s3"]}
+    tmp = tempfile.mkdtemp()
+    try:
+        p = os.path.join(tmp, "snplist.txt")
+        ru.write_list_of_snps(p, d)
+        with open(p) as f:
+            vec["snplist_writer"] = {"in": [[k[0], k[1], v] for k, v in d.items()], "out": f.read()}
+        vec["snplist_reader"] = [list(t) for t in ru.read_snp_position_list(p)]
+    finally:
+        shutil.rmtree(tmp)
+    return vec
+
+
+def copy_fixtures():
+    """Data files from the reference's bundled ExpectedResults trees."""
+    src = os.path.join(REF, "snppipeline", "data")
+    dst = os.path.join(GOLD, "fixtures")
+    if os.path.isdir(dst):
+        shutil.rmtree(dst)
+    keep_top = ("snplist.txt", "snplist_preserved.txt", "snpma.fasta", "snpma_preserved.fasta",
+                "snp_distance_matrix.tsv", "snp_distance_matrix_preserved.tsv",
+                "snp_distance_pairwise.tsv", "snp_distance_pairwise_preserved.tsv",
+                "referenceSNP.fasta", "referenceSNP_preserved.fasta", "metrics.tsv")
+    keep_sample = ("var.flt.vcf", "var.flt_preserved.vcf", "var.flt_removed.vcf", "consensus.fasta",
+                   "consensus_preserved.fasta", "consensus.vcf", "consensus_preserved.vcf", "metrics")
+    for ds in ("lambdaVirus", "agona", "listeria"):
+        exp = os.path.join(src, ds + "ExpectedResults")
+        out = os.path.join(dst, ds)
+        os.makedirs(out)
+        buf = io.BytesIO()
+        with tarfile.open(fileobj=buf, mode="w") as tar:
+            for name in keep_top:
+                p = os.path.join(exp, name)
+                if os.path.isfile(p):
+                    tar.add(p, arcname=name)
+            sdir = os.path.join(exp, "samples")
+            for s in sorted(os.listdir(sdir)):
+                for name in keep_sample:
+                    p = os.path.join(sdir, s, name)
+                    if os.path.isfile(p):
+                        tar.add(p, arcname="samples/%s/%s" % (s, name))
+        with open(os.path.join(out, "expected.tar.xz"), "wb") as f:
+            import lzma
+            f.write(lzma.compress(buf.getvalue(), preset=9))
+        # contig ids + lengths of the reference FASTA (filter_regions only needs these)
+        inp = os.path.join(src, ds + "Inputs", "reference")
+        lens = {}
+        if os.path.isdir(inp):
+            for fn in os.listdir(inp):
+                name, n = None, 0
+                with open(os.path.join(inp, fn)) as f:
+                    for line in f:
+                        if line.startswith(">"):
+                            if name is not None:
+                                lens[name] = n
+                            name, n = line[1:].split()[0], 0
+                        else:
+                            n += len(line.strip())
+                if name is not None:
+                    lens[name] = n
+        sl = os.path.join(src, ds + "Inputs", "sampleList")
+        meta = {"contig_lengths": lens}
+        if os.path.isfile(sl):
+            meta["sampleList"] = open(sl).read().split()
+        with open(os.path.join(out, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+    shutil.copy(os.path.join(src, "lambdaVirusInputs", "reference", "lambda_virus.fasta"), os.path.join(dst, "lambdaVirus"))
+
+
+def dump(name, obj):
+    raw = json.dumps(obj, separators=(",", ":"), sort_keys=True).encode()
+    with open(os.path.join(GOLD, name), "wb") as f:
+        with gzip.GzipFile(fileobj=f, mode="wb", mtime=0) as g:
+            g.write(raw)
+    print(name, len(raw), "bytes raw")
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    captured = install_stubs()
+    dump("pileup_vectors.json.gz", gen_pileup_vectors(captured))
+    dump("steps_vectors.json.gz", gen_steps_vectors())
+    copy_fixtures()
+
+
+if __name__ == "__main__":
+    main()

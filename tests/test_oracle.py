@@ -1,0 +1,130 @@
+"""The CPU oracle against vectors produced by the real reference
+(oracle/gen_golden.py) and against the reference's bundled ExpectedResults."""
+import os
+
+import pytest
+
+from oracle import pileup_oracle as po
+from oracle import steps_oracle as so
+
+
+def test_reference_doctests_were_green(pileup_vectors):
+    d = pileup_vectors["reference_doctests"]
+    assert d["failed"] == 0 and d["attempted"] >= 79
+
+
+def test_strip_vectors(pileup_vectors):
+    for raw, want in pileup_vectors["strip"]:
+        assert po.strip_bases(raw.encode()).decode() == want, raw
+
+
+def _hist(d):
+    return sorted([chr(k), v] for k, v in d.items())
+
+
+def test_record_and_caller_vectors(pileup_vectors):
+    n_calls = 0
+    for v in pileup_vectors["records"]:
+        line = v["line"].encode()
+        for q, want in v["by_q"].items():
+            q = int(q)
+            if "error" in want:
+                with pytest.raises((IndexError, ValueError)) as ei:
+                    po.parse_record(po.split_fields(line), q)
+                assert type(ei.value).__name__ == want["error"], v["line"]
+                continue
+            r = po.parse_record(po.split_fields(line), q)
+            assert (r.chrom.decode(), r.position, r.reference_base.decode(), r.raw_depth) == \
+                (want["chrom"], want["pos"], want["ref"], want["raw"]), v["line"]
+            assert (r.good_depth, r.forward_good_depth, r.reverse_good_depth) == (want["good"], want["fwd"], want["rev"]), v["line"]
+            assert _hist(r.base_good_depth) == want["total_hist"], v["line"]
+            assert _hist(r.forward_base_good_depth) == want["fwd_hist"], v["line"]
+            assert _hist(r.reverse_base_good_depth) == want["rev_hist"], v["line"]
+            ranked = None if r.most_common_good_bases is None else [chr(b) for b in r.most_common_good_bases]
+            assert ranked == want["ranked"], v["line"]
+            for c in want["calls"]:
+                p = po.CallerParams(*c["params"])
+                base, mask = po.call_record(r, p)
+                names = po.filter_names(p)
+                failed = [names[i] for i in range(6) if mask >> i & 1] or None
+                assert (chr(base), failed) == (c["base"], c["failed"]), (v["line"], c["params"])
+                n_calls += 1
+    assert n_calls > 15000
+
+
+def test_float_threshold_table(pileup_vectors):
+    for f, table in pileup_vectors["freq_threshold"].items():
+        f = float(f)
+        for d, k in enumerate(table):
+            assert min(x for x in range(d + 2) if not (x < d * f)) == k
+
+
+def test_whole_file_runs(pileup_vectors):
+    from oracle import fuzz
+    for run in pileup_vectors["runs"]:
+        kw = dict(run["kw"])
+        if "contigs" in kw:
+            kw["contigs"] = tuple(kw["contigs"])
+        data, _, _ = fuzz.synth_pileup(run["seed"], **kw)
+        snps = [(c.encode(), p) for c, p in run["snplist"]]
+        excl = {(c.encode(), p) for c, p in run["excluded"]}
+        cons, _ = po.call_consensus_sites(data, snps, excl, po.CallerParams(*run["params"]))
+        assert cons.decode() == run["consensus"], run["seed"]
+
+
+def test_universal_newlines_and_blank_lines():
+    data = b"c 1 A 1 . I\r\nc 2 A 1 . I\rc 3 A 1 . I\nc 4 A 1 . I"
+    assert [ln for _, ln in po.iter_lines(data)] == [b"c 1 A 1 . I", b"c 2 A 1 . I", b"c 3 A 1 . I", b"c 4 A 1 . I"]
+    with pytest.raises(ValueError):
+        list(po.scan_sites(b"c 1 A 1 . I\n\nc 2 A 1 . I\n", {(b"c", 2)}, 0))
+
+
+def test_steps_vectors(steps_vectors):
+    for v in steps_vectors["find_dense_regions"]:
+        assert [list(t) for t in so.find_dense_regions(v["m"], v["w"], v["snps"])] == v["out"]
+    for v in steps_vectors["merge_regions"]:
+        assert [list(t) for t in so.merge_regions([tuple(r) for r in v["in"]])] == v["out"]
+    for v in steps_vectors["in_region"]:
+        assert so.in_region(v["pos"], [tuple(r) for r in v["regions"]]) == v["out"]
+    for v in steps_vectors["sequence_distance"]:
+        assert so.sequence_distance(v["a"], v["b"]) == v["d"]
+    for v in steps_vectors["collect_all"]:
+        samples = [("s%d" % i, [tuple(r) for r in recs]) for i, recs in enumerate(v["samples"])]
+        got = so.bad_regions(samples, v["lens"], v["edge"], v["max_snps"], v["windows"], mode="all")
+        assert {c: [list(r) for r in regs] for c, regs in got.items()} == v["out"]
+    w = steps_vectors["snplist_writer"]
+    merged = sorted(((c, p), names) for c, p, names in w["in"])
+    assert so.snplist_text(merged) == w["out"]
+
+
+def _vcf_sites(path):
+    out = []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("#") or not line.strip():
+                continue
+            c, p = line.split("\t")[:2]
+            out.append((c, int(p)))
+    return out
+
+
+@pytest.mark.parametrize("ds", ["lambdaVirus", "agona", "listeria"])
+def test_bundled_fixtures(fixture_trees, ds):
+    root, meta = fixture_trees[ds]
+    sdirs = sorted(os.listdir(os.path.join(root, "samples")))
+    samples = [(os.path.join(root, "samples", s), s, _vcf_sites(os.path.join(root, "samples", s, "var.flt.vcf"))) for s in sdirs]
+    merged, _ = so.merge_sites(samples)
+    assert so.snplist_text(merged) == open(os.path.join(root, "snplist.txt")).read()
+
+    bad = so.bad_regions([(n, recs) for _, n, recs in samples], meta["contig_lengths"], 500, [3, 2, 1], [1000, 125, 15])
+    pres = [(d, n, [k for k in recs if not so.in_region(k[1], bad[k[0]])]) for d, n, recs in samples]
+    merged_p, _ = so.merge_sites(pres)
+    assert so.snplist_text(merged_p) == open(os.path.join(root, "snplist_preserved.txt")).read()
+
+    for suffix in ("", "_preserved"):
+        seqs = so.parse_snpma(open(os.path.join(root, "snpma%s.fasta" % suffix)).read())
+        ids, d = so.distance_tables(seqs)
+        assert so.matrix_text(ids, d) == open(os.path.join(root, "snp_distance_matrix%s.tsv" % suffix)).read()
+        pw = os.path.join(root, "snp_distance_pairwise%s.tsv" % suffix)
+        if os.path.isfile(pw):
+            assert so.pairwise_text(ids, d) == open(pw).read()
