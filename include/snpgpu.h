@@ -1,0 +1,211 @@
+/* snpgpu.h — C ABI of the MI355X (gfx950) hot path of the CFSAN SNP Pipeline.
+ *
+ * The reference (CFSAN-Biostatistics/snp-pipeline v2.2.1) is pure Python and has
+ * no FFI; its operator boundary is the `cfsan_snp_pipeline <subcommand>` CLI
+ * (snppipeline/cfsan_snp_pipeline.py:309-457).  The Python host layer in
+ * snp_pipeline_amd/ mirrors that CLI and calls the entry points below through
+ * ctypes.  Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative SNPGPU_E_* code on failure;
+ *    a message is available from snpgpu_last_error(ctx).  Nothing throws.
+ *  - `*_dev` functions take DEVICE pointers, enqueue work on the context's
+ *    stream and return without synchronising; the others take HOST pointers and
+ *    are synchronous.  The caller owns every buffer it passes.
+ *  - a context is bound to one (process, device) and is not thread-safe.
+ *  - there is no CPU fallback: without a gfx950 device snpgpu_ctx_create fails.
+ */
+#ifndef SNPGPU_H
+#define SNPGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNPGPU_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------- */
+#define SNPGPU_OK            0
+#define SNPGPU_E_HIP        -1   /* HIP runtime error (message has the hipError string) */
+#define SNPGPU_E_ARG        -2   /* invalid argument */
+#define SNPGPU_E_NOMEM      -3
+#define SNPGPU_E_PILEUP     -4   /* malformed pileup text; see snpgpu_scan_status */
+#define SNPGPU_E_UNSUPPORTED -5  /* input the reference accepts but this build refuses (reported loudly) */
+
+/* ---- failed-filter bits, in the order pileup.py:564-584 appends them and
+ *      call_consensus.py:165-168 appends "Region" ------------------------- */
+#define SNPGPU_F_RAWDPTH  0x01
+#define SNPGPU_F_VARFREQ  0x02
+#define SNPGPU_F_DEPTH    0x04
+#define SNPGPU_F_STRDPTH  0x08
+#define SNPGPU_F_STRBIAS  0x10
+#define SNPGPU_F_REGION   0x20
+
+/* ---- site flags --------------------------------------------------------- */
+#define SNPGPU_SITE_IN_SNPLIST 0x01   /* position is in snplist.txt (call_consensus.py:146) */
+#define SNPGPU_SITE_EXCLUDED   0x02   /* position is in the -e exclude VCF (call_consensus.py:121) */
+
+/* ---- per-site status ---------------------------------------------------- */
+#define SNPGPU_ST_NO_LINE      0   /* no pileup line for this position: '-' (call_consensus.py:187) */
+#define SNPGPU_ST_OK           1
+#define SNPGPU_ST_SHORT_LINE   2   /* < 4 fields: IndexError in pileup.py:224-225 */
+#define SNPGPU_ST_BAD_DEPTH    3   /* depth field is not [0-9]+: ValueError in pileup.py:225 */
+#define SNPGPU_ST_NO_QUALS     4   /* depth > 0 and exactly 5 fields: IndexError in pileup.py:237 */
+#define SNPGPU_ST_MULTI_REF    5   /* reference-base field longer than one byte (unsupported) */
+
+typedef struct snpgpu_ctx snpgpu_ctx;
+typedef struct snpgpu_siteset snpgpu_siteset;
+
+/* ConsensusCaller parameters, pileup.py:433-465 (+ Reader's min_base_quality, pileup.py:384). */
+typedef struct snpgpu_caller_params {
+    int32_t min_base_quality;       /* -q, default 0   */
+    int32_t min_cons_depth;         /* -D, default 1   */
+    int32_t min_cons_strand_depth;  /* -d, default 0   */
+    int32_t reserved;
+    double  min_cons_freq;          /* -c, default 0.6 */
+    double  min_cons_strand_bias;   /* -b, default 0.0 */
+} snpgpu_caller_params;
+
+/* Everything pileup.Record exposes for one position (pileup.py:58-94), with the
+ * histograms as a ranked list (count descending, byte ascending, pileup.py:263-266).
+ * 128 bytes per site.  Enough to write consensus.vcf rows (vcf_writer.py:295-379). */
+#define SNPGPU_MAX_SYMS 8
+typedef struct snpgpu_site_counts {
+    uint32_t raw_depth;             /* Record.raw_depth */
+    uint32_t good_depth;            /* Record.good_depth */
+    uint32_t fwd_good_depth;        /* Record.forward_good_depth */
+    uint32_t rev_good_depth;        /* Record.reverse_good_depth */
+    uint32_t n_symbols;             /* distinct upper-cased symbols with good depth (may exceed 8) */
+    uint8_t  ref_base;              /* Record.reference_base, case preserved */
+    uint8_t  cons_base;             /* ConsensusCaller.call_consensus()[0] */
+    uint8_t  filters;               /* SNPGPU_F_* mask, incl. REGION */
+    uint8_t  status;                /* SNPGPU_ST_* */
+    uint8_t  sym[SNPGPU_MAX_SYMS];  /* most_common_good_bases[0..8) */
+    uint32_t total[SNPGPU_MAX_SYMS];/* base_good_depth[sym] */
+    uint32_t fwd[SNPGPU_MAX_SYMS];  /* forward_base_good_depth[sym] */
+    uint32_t rev[SNPGPU_MAX_SYMS];  /* reverse_base_good_depth[sym] */
+} snpgpu_site_counts;
+
+/* Result words of one pileup scan (device-written, 4 x u64). */
+#define SNPGPU_SCAN_STATUS_WORDS 4
+/*  [0] first malformed line: ((byte offset + 1) << 8) | code, or UINT64_MAX when clean
+ *        code 1: line has < 2 fields      (ValueError at pileup.py:425)
+ *        code 2: position is not [0-9]+   (ValueError at pileup.py:426)
+ *        code 3: byte >= 0x80 in the file (non-ASCII pileup: unsupported)
+ *  [1] number of lines seen, [2] number of lines that matched a site, [3] sum of the depth column over
+ *      well-formed lines (collect_metrics.py:325-340 by-product; 0 unless requested) */
+
+/* ---- context ------------------------------------------------------------ */
+int  snpgpu_abi_version(void);
+int  snpgpu_ctx_create(int device, snpgpu_ctx **out);
+void snpgpu_ctx_destroy(snpgpu_ctx *ctx);
+const char *snpgpu_last_error(const snpgpu_ctx *ctx);
+/* Run on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the context's own. */
+int  snpgpu_ctx_set_stream(snpgpu_ctx *ctx, void *hip_stream);
+int  snpgpu_ctx_sync(snpgpu_ctx *ctx);
+/* Kernel-only elapsed time helpers (HIP events recorded on the context's stream). */
+int  snpgpu_timer_start(snpgpu_ctx *ctx);
+int  snpgpu_timer_stop_ms(snpgpu_ctx *ctx, float *out_ms);   /* synchronises on the stop event */
+
+/* ---- site set: the (chrom,pos) set handed to pileup.Reader (pileup.py:396-403) ----
+ * contig_names: concatenated names, contig_name_off[n_contigs+1]; names must be sorted bytewise and unique.
+ * site_keys: (contig_index << 32) | position, strictly increasing; site_flags: SNPGPU_SITE_* per key.
+ * All HOST pointers; the set is copied to the device (bitmap + rank directory). */
+int  snpgpu_siteset_create(snpgpu_ctx *ctx, const uint8_t *contig_names, const uint32_t *contig_name_off,
+                           uint32_t n_contigs, const uint64_t *site_keys, const uint8_t *site_flags,
+                           uint32_t n_sites, snpgpu_siteset **out);
+void snpgpu_siteset_destroy(snpgpu_siteset *ss);
+uint32_t snpgpu_siteset_size(const snpgpu_siteset *ss);
+
+/* ---- call_consensus: pileup.Reader + Record + ConsensusCaller + the mapping in
+ *      call_consensus.py:161-188, for ONE sample ------------------------------------------------
+ * d_pileup: raw ASCII of reads.all.pileup in device memory (any alignment).
+ * d_out_base[n_sites]:    the byte call_consensus.py writes to the FASTA for that key ('-' when a filter failed,
+ *                         the base is '*', or the position has no line).
+ * d_out_filters[n_sites]: SNPGPU_F_* mask (0 when the position has no line).
+ * d_out_counts[n_sites]:  nullable.
+ * d_status[4]:            SNPGPU_SCAN_STATUS_WORDS u64.
+ * want_depth_sum: also accumulate status[3] (costs one integer parse per line). */
+int  snpgpu_call_consensus_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const void *d_pileup, size_t nbytes,
+                               const snpgpu_caller_params *params, uint8_t *d_out_base, uint8_t *d_out_filters,
+                               snpgpu_site_counts *d_out_counts, uint64_t *d_status, int want_depth_sum);
+/* Many samples resident in one device buffer; sample i is bytes [h_offsets[i], h_offsets[i+1]).
+ * Outputs are [n_samples][n_sites] row-major; d_status is [n_samples][4]. */
+int  snpgpu_call_consensus_batch_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const void *d_pileups,
+                                     const uint64_t *h_offsets, uint32_t n_samples,
+                                     const snpgpu_caller_params *params, uint8_t *d_out_base,
+                                     uint8_t *d_out_filters, uint64_t *d_status);
+/* Host-buffer form (copies the pileup to the device, runs, copies results back, synchronous).
+ * Returns SNPGPU_E_PILEUP when the scan found a malformed line (status words still filled). */
+int  snpgpu_call_consensus(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *pileup, size_t nbytes,
+                           const snpgpu_caller_params *params, uint8_t *out_base, uint8_t *out_filters,
+                           snpgpu_site_counts *out_counts, uint64_t *out_status, int want_depth_sum);
+
+/* ---- snp_matrix / distance: utils.calculate_sequence_distance (utils.py:1135-1165) over all pairs
+ *      (distance.py:93-98) ----------------------------------------------------------------------
+ * The samples x sites matrix is packed 4 bits per site, planar per 32-site word:
+ *   packed[row][word] = uint32[4] { valid (upper(c) in ACGT), code bit1, code bit0, lower-case flag }
+ * with A=0 C=1 G=2 T=3.  words = ceil(n_sites / 32). */
+size_t snpgpu_packed_row_bytes(uint32_t n_sites);
+int  snpgpu_pack_matrix_dev(snpgpu_ctx *ctx, const uint8_t *d_symbols, uint32_t n_rows, uint32_t n_sites,
+                            size_t row_stride, void *d_packed);
+/* d_out is a full n x n int32 matrix.  Only the 128x128 tiles t of the upper triangle with
+ * t % tile_nranks == tile_rank are computed; each is written together with its mirror image.
+ * Entries of other tiles are left untouched. */
+int  snpgpu_distance_packed_dev(snpgpu_ctx *ctx, const void *d_packed, uint32_t n_rows, uint32_t n_sites,
+                                uint32_t tile_rank, uint32_t tile_nranks, int32_t *d_out);
+/* Host form: symbols is n_rows x n_sites bytes (row-major, the sequences of snpma.fasta); out is n x n int32. */
+int  snpgpu_distance(snpgpu_ctx *ctx, const uint8_t *symbols, uint32_t n_rows, uint32_t n_sites, int32_t *out);
+
+/* ---- filter_regions: find_dense_regions (filter_regions.py:17-71) + utils.merge_regions
+ *      (utils.py:1267-1282) + utils.in_region (utils.py:1314-1318) -----------------------------
+ * Positions are grouped in segments (one per (sample, contig)); seg_off[n_segs+1]; the positions of a segment
+ * may come in any order (they are sorted on the device, filter_regions.py:425).  For every rule r the candidate window (p[i], p[i+max_snps[r]]) is emitted when
+ * p[i] + window[r] - 1 >= p[i+max_snps[r]].  out_start/out_end receive the candidates (capacity
+ * n_pos * n_rules), out_seg their segment; *out_n the count.  Host pointers, synchronous. */
+int  snpgpu_dense_windows(snpgpu_ctx *ctx, const int64_t *positions, const uint32_t *seg_off, uint32_t n_segs,
+                          const int32_t *max_snps, const int32_t *window, uint32_t n_rules,
+                          int64_t *out_start, int64_t *out_end, uint32_t *out_seg, uint32_t *out_n);
+/* Merge intervals per group (group ids ascending, intervals need not be sorted): sort by (group,start,end),
+ * running max of end, join when start <= last_end + 1.  Outputs capacity n.  Host pointers, synchronous. */
+int  snpgpu_merge_regions(snpgpu_ctx *ctx, const uint32_t *group, const int64_t *start, const int64_t *end,
+                          uint32_t n, uint32_t *out_group, int64_t *out_start, int64_t *out_end, uint32_t *out_n);
+/* in_region for many positions: regions per group must be merged (disjoint, sorted); reg_off[n_groups+1].
+ * out_flag[i] = 1 when positions[i] lies in a region of pos_group[i] (inclusive ends). */
+int  snpgpu_in_regions(snpgpu_ctx *ctx, const uint32_t *pos_group, const int64_t *positions, uint32_t n_pos,
+                       const uint32_t *reg_off, const int64_t *reg_start, const int64_t *reg_end,
+                       uint32_t n_groups, uint8_t *out_flag);
+
+/* ---- merge_sites: union of (CHROM,POS) over samples (merge_sites.py:91-117) -----------------------
+ * keys[i] = (contig_index << 32) | pos, sample_of_key[i] = sample index in sorted-dir order (ascending runs).
+ * Outputs: unique keys ascending, CSR offsets (n_unique+1) and the carrier sample indices in ascending
+ * order per key, duplicates of (key, sample) collapsed (the reference builds a set per sample).
+ * Capacities: out_unique[n], out_off[n+1], out_carrier[n].  Host pointers, synchronous. */
+int  snpgpu_merge_sites(snpgpu_ctx *ctx, const uint64_t *keys, const uint32_t *sample_of_key, size_t n,
+                        uint64_t *out_unique, uint32_t *out_off, uint32_t *out_carrier,
+                        uint32_t *out_n_unique, uint32_t *out_n_carrier);
+
+/* ---- synthetic pileups for bench/tests, generated on the device --------------------
+ * Fills d_out with the text of one sample's pileup over a single contig and returns its length in *out_nbytes
+ * (synchronous; d_out capacity in bytes; d_out == NULL only queries the length).  d_site_alt[genome_len+1]: 0 or the ALT base at each 1-based position. */
+typedef struct snpgpu_synth_params {
+    uint64_t seed;
+    uint32_t sample;
+    uint32_t genome_len;
+    float    mean_depth;
+    float    carrier_p_same_clade;
+    float    carrier_p_other_clade;
+    uint32_t n_clades;
+    char     contig[32];
+} snpgpu_synth_params;
+int  snpgpu_synth_reference_dev(snpgpu_ctx *ctx, uint64_t seed, uint32_t genome_len, uint8_t *d_ref /* genome_len+1 */);
+int  snpgpu_synth_pileup_dev(snpgpu_ctx *ctx, const snpgpu_synth_params *p, const uint8_t *d_ref,
+                             const uint8_t *d_site_alt, uint8_t *d_out, size_t capacity, size_t *out_nbytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNPGPU_H */

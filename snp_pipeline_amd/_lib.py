@@ -1,0 +1,93 @@
+"""ctypes binding of libsnpgpu.so (include/snpgpu.h).  There is no CPU fallback: if the library is missing
+or no gfx950 device is visible, the calls raise."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsnpgpu.so")
+
+MAX_SYMS = 8
+SCAN_STATUS_WORDS = 4
+
+F_RAWDPTH, F_VARFREQ, F_DEPTH, F_STRDPTH, F_STRBIAS, F_REGION = 1, 2, 4, 8, 16, 32
+SITE_IN_SNPLIST, SITE_EXCLUDED = 1, 2
+ST_NO_LINE, ST_OK, ST_SHORT_LINE, ST_BAD_DEPTH, ST_NO_QUALS, ST_MULTI_REF = 0, 1, 2, 3, 4, 5
+E_HIP, E_ARG, E_NOMEM, E_PILEUP, E_UNSUPPORTED = -1, -2, -3, -4, -5
+
+
+class CallerParams(C.Structure):
+    _fields_ = [("min_base_quality", C.c_int32), ("min_cons_depth", C.c_int32),
+                ("min_cons_strand_depth", C.c_int32), ("reserved", C.c_int32),
+                ("min_cons_freq", C.c_double), ("min_cons_strand_bias", C.c_double)]
+
+
+class SiteCounts(C.Structure):
+    _fields_ = [("raw_depth", C.c_uint32), ("good_depth", C.c_uint32), ("fwd_good_depth", C.c_uint32),
+                ("rev_good_depth", C.c_uint32), ("n_symbols", C.c_uint32), ("ref_base", C.c_uint8),
+                ("cons_base", C.c_uint8), ("filters", C.c_uint8), ("status", C.c_uint8),
+                ("sym", C.c_uint8 * MAX_SYMS), ("total", C.c_uint32 * MAX_SYMS),
+                ("fwd", C.c_uint32 * MAX_SYMS), ("rev", C.c_uint32 * MAX_SYMS)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("sample", C.c_uint32), ("genome_len", C.c_uint32),
+                ("mean_depth", C.c_float), ("carrier_p_same_clade", C.c_float),
+                ("carrier_p_other_clade", C.c_float), ("n_clades", C.c_uint32), ("contig", C.c_char * 32)]
+
+
+assert C.sizeof(SiteCounts) == 128 and C.sizeof(CallerParams) == 32
+
+# name -> (restype, argtypes); every exported symbol of include/snpgpu.h
+_P = C.c_void_p
+SIGNATURES = {
+    "snpgpu_abi_version": (C.c_int, []),
+    "snpgpu_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "snpgpu_ctx_destroy": (None, [_P]),
+    "snpgpu_last_error": (C.c_char_p, [_P]),
+    "snpgpu_ctx_set_stream": (C.c_int, [_P, _P]),
+    "snpgpu_ctx_sync": (C.c_int, [_P]),
+    "snpgpu_timer_start": (C.c_int, [_P]),
+    "snpgpu_timer_stop_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "snpgpu_siteset_create": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, C.c_uint32, C.POINTER(_P)]),
+    "snpgpu_siteset_destroy": (None, [_P]),
+    "snpgpu_siteset_size": (C.c_uint32, [_P]),
+    "snpgpu_call_consensus_dev": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(CallerParams), _P, _P, _P, _P, C.c_int]),
+    "snpgpu_call_consensus_batch_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(CallerParams), _P, _P, _P]),
+    "snpgpu_call_consensus": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(CallerParams), _P, _P, _P, _P, C.c_int]),
+    "snpgpu_packed_row_bytes": (C.c_size_t, [C.c_uint32]),
+    "snpgpu_pack_matrix_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_size_t, _P]),
+    "snpgpu_distance_packed_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
+    "snpgpu_distance": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P]),
+    "snpgpu_dense_windows": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_uint32)]),
+    "snpgpu_merge_regions": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_uint32)]),
+    "snpgpu_in_regions": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, _P, C.c_uint32, _P]),
+    "snpgpu_merge_sites": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "snpgpu_synth_reference_dev": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P]),
+    "snpgpu_synth_pileup_dev": (C.c_int, [_P, C.POINTER(SynthParams), _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+}
+
+_lib = None
+
+
+class SnpGpuError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "snpgpu error %d: %s" % (code, message))
+        self.code = code
+
+
+def load():
+    """Load libsnpgpu.so.  torch is imported first so that the HIP runtime torch ships (same SONAME) is the one
+    and only runtime in the process — device pointers of torch tensors are then valid for our kernels."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -m snp_pipeline_amd.build` (there is no CPU fallback)" % LIB_PATH)
+    import torch  # noqa: F401  (side effect: loads libamdhip64)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,663 @@
+// K1 pileup scan (line index + site match) and K2 per-site wavefront consensus caller.
+//
+// Replaces, for one sample:
+//   pileup.Reader.__iter__            snppipeline/pileup.py:408-429   -> k_scan_pileup
+//   pileup.Record._init_from_split_line  pileup.py:209-274            -> k_call_sites
+//   pileup.Record._strip_unwanted_base_patterns  pileup.py:276-325    -> k_call_sites (mask algebra, see below)
+//   pileup.ConsensusCaller.call_consensus  pileup.py:492-590          -> k_call_sites (tail)
+//   call_consensus.py:161-188 (Region filter, '-' mapping, last line wins, missing -> '-')
+//
+// k_scan_pileup is the HBM-bound kernel: every byte of the raw ASCII pileup is read exactly once with 16-byte
+// coalesced loads, staged through LDS, newline-indexed with SWAR, and only the first two fields of each line are
+// parsed.  A matching line publishes (its offset + 1) with atomicMax into site_line[site]; the maximum implements
+// "the last duplicate line wins" (call_consensus.py:171-176).  k_call_sites then runs one 64-lane wavefront per
+// site over that line.  The three regex passes of the reference become 64-bit mask algebra on wave ballots
+// (scalar ALU work on gfx950: one ballot == one SGPR pair).
+#include "internal.h"
+
+// ------------------------------------------------------------------------------------------------
+//                                           K1: scan
+// ------------------------------------------------------------------------------------------------
+#define SCAN_THREADS 256
+#define SCAN_TILE 16384                      // bytes per tile
+#define SCAN_HALO 256                        // bytes staged past the tile for the fields of its last lines
+#define SCAN_MAXL (SCAN_TILE / 4)            // a valid line has >= 4 bytes ("a 1\n")
+#define SCAN_CHUNKS (SCAN_TILE / 16)         // 16-byte chunks per tile
+#define SCAN_CPT (SCAN_CHUNKS / SCAN_THREADS)
+
+#define SCAN_ERR_FEW_FIELDS 1
+#define SCAN_ERR_BAD_POS 2
+#define SCAN_ERR_NON_ASCII 3
+
+struct ScanArgs {
+    const uint8_t *base;     // 16-byte aligned pointer at or below the first byte of the file
+    uint64_t lo, hi;         // the file is base[lo, hi)
+    uint64_t n_tiles;
+    uint64_t *site_line;     // n_sites
+    uint64_t *status;        // SNPGPU_SCAN_STATUS_WORDS
+    int want_depth;
+};
+
+__device__ __forceinline__ uint32_t swar_eq_mask(uint32_t w, uint32_t pat) {
+    uint32_t x = w ^ pat;                                   // zero byte <=> match
+    uint32_t y = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;     // bit 7 of each byte set <=> byte non-zero
+    return ~y & 0x80808080u;                                // exact per byte
+}
+
+__device__ __forceinline__ void report_scan_error(uint64_t *status, uint64_t file_off, uint32_t code) {
+    atomicMin((unsigned long long *)&status[0], (unsigned long long)(((file_off + 1) << 8) | code));
+}
+
+// Bytewise lexicographic compare of a line field (read through getb) with contig name c.
+template <typename GetB>
+__device__ int cmp_name(const SiteSetDev &ss, uint32_t c, int64_t p0, uint32_t len, GetB getb) {
+    uint32_t a = ss.name_off[c], nl = ss.name_off[c + 1] - a;
+    uint32_t m = len < nl ? len : nl;
+    for (uint32_t k = 0; k < m; ++k) {
+        int d = (int)getb(p0 + k) - (int)ss.names[a + k];
+        if (d) return d;
+    }
+    return (int)len - (int)nl;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_pileup(ScanArgs a, SiteSetDev ss) {
+    __shared__ uint4 tile4[(16 + SCAN_TILE + SCAN_HALO) / 16];
+    __shared__ uint16_t lstart[SCAN_MAXL];
+    __shared__ uint32_t n_lines_sh;
+    __shared__ uint32_t hint_sh;
+    __shared__ unsigned long long depth_sh;
+    uint8_t *tile = (uint8_t *)tile4 + 16;                  // tile[-16 .. SCAN_TILE+SCAN_HALO)
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) hint_sh = 0;
+
+    for (uint64_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        const uint64_t t0 = t * SCAN_TILE;                  // offset of the tile relative to a.base
+        if (tid == 0) { n_lines_sh = 0; depth_sh = 0; }
+        // ---- stage [t0-16, t0+TILE+HALO) into LDS; bytes outside [lo,hi) read as '\n' ----------
+        uint4 regs[SCAN_CPT];
+        uint32_t hi_bits = 0;
+        auto load_chunk = [&](int64_t rel) -> uint4 {       // rel: chunk offset relative to t0 (multiple of 16)
+            int64_t ab = (int64_t)t0 + rel;
+            uint4 v = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+            if (ab + 16 <= (int64_t)a.lo || ab >= (int64_t)a.hi || ab < 0) return v;
+            v = *(const uint4 *)(a.base + ab);
+            if (ab < (int64_t)a.lo || ab + 16 > (int64_t)a.hi) {     // edge chunk: blank the outside bytes
+                uint8_t *pb = (uint8_t *)&v;
+                for (int j = 0; j < 16; ++j)
+                    if (ab + j < (int64_t)a.lo || ab + j >= (int64_t)a.hi) pb[j] = 10;
+            }
+            return v;
+        };
+#pragma unroll
+        for (int i = 0; i < SCAN_CPT; ++i) {
+            uint32_t c = i * SCAN_THREADS + tid;
+            regs[i] = load_chunk((int64_t)c * 16);
+            hi_bits |= (regs[i].x | regs[i].y | regs[i].z | regs[i].w);
+            tile4[1 + c] = regs[i];
+        }
+        if (tid < SCAN_HALO / 16) tile4[1 + SCAN_CHUNKS + tid] = load_chunk((int64_t)SCAN_TILE + tid * 16);
+        if (tid == SCAN_THREADS - 1) tile4[0] = load_chunk(-16);
+        if (hi_bits & 0x80808080u) report_scan_error(a.status, t0 > a.lo ? t0 - a.lo : 0, SCAN_ERR_NON_ASCII);
+        __syncthreads();
+
+        // ---- line starts: s is a start iff byte s-1 ends a terminator ('\n', or '\r' not followed by '\n') ----
+#pragma unroll
+        for (int i = 0; i < SCAN_CPT; ++i) {
+            uint32_t c = i * SCAN_THREADS + tid;
+            int32_t cb = (int32_t)c * 16;                   // chunk offset in the tile
+            uint32_t w[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
+            uint32_t prev = tile[cb - 1];
+            uint32_t cr_any = (prev == 13u);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cr_any |= swar_eq_mask(w[k], 0x0D0D0D0Du);
+            if (!cr_any) {
+                // fast path: starts are the bytes right after a '\n' in [cb-1, cb+15)
+                if (prev == 10u) {
+                    uint64_t s_abs = t0 + cb;
+                    if (s_abs >= a.lo && s_abs < a.hi) {
+                        uint32_t idx = atomicAdd(&n_lines_sh, 1u);
+                        if (idx < SCAN_MAXL) lstart[idx] = (uint16_t)cb;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t z = swar_eq_mask(w[k], 0x0A0A0A0Au);
+                    while (z) {
+                        int byte = (__ffs(z) - 1) >> 3;
+                        z &= z - 1;
+                        int s = cb + k * 4 + byte + 1;
+                        if (s >= cb + 16) break;            // belongs to the next chunk (seen there as prev)
+                        uint64_t s_abs = t0 + s;
+                        if (s_abs >= a.lo && s_abs < a.hi) {
+                            uint32_t idx = atomicAdd(&n_lines_sh, 1u);
+                            if (idx < SCAN_MAXL) lstart[idx] = (uint16_t)s;
+                        }
+                    }
+                }
+            } else {
+                for (int j = 0; j < 16; ++j) {              // rare: '\r' present, byte loop on the LDS copy
+                    int s = cb + j;
+                    uint32_t pv = tile[s - 1], cv = tile[s];
+                    bool st = (pv == 10u) || (pv == 13u && cv != 10u);
+                    uint64_t s_abs = t0 + s;
+                    if (st && s_abs >= a.lo && s_abs < a.hi) {
+                        uint32_t idx = atomicAdd(&n_lines_sh, 1u);
+                        if (idx < SCAN_MAXL) lstart[idx] = (uint16_t)s;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t n_lines = n_lines_sh;
+        if (n_lines > SCAN_MAXL) {                          // only possible with lines shorter than 4 bytes
+            if (tid == 0) report_scan_error(a.status, t0 > a.lo ? t0 - a.lo : 0, SCAN_ERR_FEW_FIELDS);
+            n_lines = SCAN_MAXL;
+        }
+
+        // ---- parse "chrom pos" of every line that starts in this tile --------------------------
+        auto getb = [&](int64_t p) -> uint32_t {            // p relative to t0
+            if (p < SCAN_TILE + SCAN_HALO) return tile[p];
+            uint64_t ab = t0 + (uint64_t)p;
+            return ab < a.hi ? a.base[ab] : 10u;
+        };
+        uint32_t hits = 0;
+        unsigned long long depth_acc = 0;
+        for (uint32_t j = tid; j < n_lines; j += SCAN_THREADS) {
+            int64_t s = lstart[j];
+            const uint64_t file_off = t0 + (uint64_t)s - a.lo;
+            int64_t p = s;
+            uint32_t c = getb(p);
+            while (is_ws(c) && !is_term(c)) c = getb(++p);
+            if (is_term(c)) { report_scan_error(a.status, file_off, SCAN_ERR_FEW_FIELDS); continue; }
+            int64_t f0 = p;
+            while (!is_ws(c)) c = getb(++p);
+            uint32_t f0len = (uint32_t)(p - f0);
+            while (is_ws(c) && !is_term(c)) c = getb(++p);
+            if (is_term(c)) { report_scan_error(a.status, file_off, SCAN_ERR_FEW_FIELDS); continue; }
+            uint64_t pos = 0;
+            bool ok = true;
+            while (!is_ws(c)) {
+                if (is_digit(c)) { pos = pos * 10 + (c - 48u); if (pos > 0xFFFFFFFFull) pos = 0x100000000ull; }
+                else ok = false;
+                c = getb(++p);
+            }
+            if (!ok) { report_scan_error(a.status, file_off, SCAN_ERR_BAD_POS); continue; }
+            if (a.want_depth) {                             // 4th column, collect_metrics.py:325-340 by-product
+                while (is_ws(c) && !is_term(c)) c = getb(++p);
+                while (!is_ws(c)) c = getb(++p);            // reference base field
+                while (is_ws(c) && !is_term(c)) c = getb(++p);
+                unsigned long long d = 0;
+                bool dok = !is_ws(c);
+                while (!is_ws(c)) { if (is_digit(c)) d = d * 10 + (c - 48u); else dok = false; c = getb(++p); }
+                if (dok) depth_acc += d;
+            }
+            if (ss.n_contigs == 0 || pos > 0xFFFFFFFFull) continue;
+            // contig lookup: last hit first, then binary search over the sorted name table
+            uint32_t cid = hint_sh;
+            if (cid >= ss.n_contigs || cmp_name(ss, cid, f0, f0len, getb) != 0) {
+                int lo_i = 0, hi_i = (int)ss.n_contigs - 1;
+                cid = 0xFFFFFFFFu;
+                while (lo_i <= hi_i) {
+                    int mid = (lo_i + hi_i) >> 1;
+                    int d = cmp_name(ss, (uint32_t)mid, f0, f0len, getb);
+                    if (d == 0) { cid = (uint32_t)mid; break; }
+                    if (d < 0) hi_i = mid - 1; else lo_i = mid + 1;
+                }
+                if (cid == 0xFFFFFFFFu) continue;
+                hint_sh = cid;                              // benign race: only a hint
+            }
+            if ((uint32_t)pos > ss.max_pos[cid]) continue;
+            uint64_t bit = ss.bit_off[cid] + (uint32_t)pos;
+            uint32_t word = ss.bitmap[bit >> 5];
+            uint32_t sh = (uint32_t)(bit & 31);
+            if (!((word >> sh) & 1u)) continue;
+            uint32_t site = ss.rank[bit >> 5] + __popc(word & ((1u << sh) - 1u));
+            atomicMax((unsigned long long *)&a.site_line[site], (unsigned long long)(file_off + 1));
+            ++hits;
+        }
+        if (hits) atomicAdd((unsigned long long *)&a.status[2], (unsigned long long)hits);
+        if (a.want_depth && depth_acc) atomicAdd(&depth_sh, depth_acc);
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd((unsigned long long *)&a.status[1], (unsigned long long)n_lines);
+            if (a.want_depth && depth_sh) atomicAdd((unsigned long long *)&a.status[3], depth_sh);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+//                                   K2: one wavefront per site
+// ------------------------------------------------------------------------------------------------
+#define CALL_WAVES 4
+#define CALL_LBUF 4224          // bytes of a line staged in LDS (lines longer than this take the serial path)
+#define CALL_LMAX 2048          // longest bases field handled by the wave-parallel path
+#define HIST_BINS 384           // [fwd | rev | neither] x 128 upper-cased symbols
+
+struct CallArgs {
+    const uint8_t *buf;         // first byte of the file
+    uint64_t nbytes;
+    const uint64_t *site_line;
+    const uint8_t *site_flags;
+    uint32_t n_sites;
+    snpgpu_caller_params prm;
+    uint8_t *out_base;
+    uint8_t *out_filters;
+    snpgpu_site_counts *out_counts;   // nullable
+};
+
+struct WaveLds {
+    uint8_t line[CALL_LBUF];
+    uint8_t s1[CALL_LMAX + 64];
+    uint32_t hist[HIST_BINS];
+    uint32_t fs[6], fe[6];
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t mbcnt(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+__device__ __forceinline__ uint64_t low_mask(uint32_t n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }   // bits [0,n)
+__device__ __forceinline__ uint32_t sat_add(uint32_t x, uint32_t y) { uint32_t s = x + y; return (s < x || s > (1u << 30)) ? (1u << 30) : s; }
+__device__ __forceinline__ uint32_t sat_mul10_add(uint32_t x, uint32_t d) { return x >= (1u << 26) ? (1u << 30) : x * 10u + d; }
+
+// histogram bin of a surviving base byte (after '.'/',' substitution): strand class * 128 + upper(byte)
+__device__ __forceinline__ uint32_t hist_bin(uint32_t c) {
+    uint32_t strand = c <= 0x5Au ? 0u : (c >= 0x61u ? 1u : 2u);      // pileup.py:269-270
+    return strand * 128u + (to_upper(c) & 127u);             // bytes >= 0x80 are rejected by the scan
+}
+
+// Serial, streaming restatement of the same automaton for one lane: used for lines too long for the LDS path.
+__device__ void call_serial(const uint8_t *g, uint64_t bs, uint64_t be, uint64_t qs, uint64_t qe, int minq,
+                            uint32_t ref_up, uint32_t ref_lo, uint32_t *hist, uint32_t &good) {
+    bool caret_skip = false, in_run = false;
+    uint32_t pending = 0, acc = 0, debt = 0;
+    uint64_t kept = 0, qlen = qe - qs;
+    auto ordinary = [&](uint32_t c) {
+        if (debt) { --debt; return; }
+        if (c == '$') return;
+        uint64_t i = kept++;
+        if (i >= qlen) return;
+        if ((int)g[qs + i] - 33 < minq) return;
+        if (c == '.') c = ref_up; else if (c == ',') c = ref_lo;
+        hist[hist_bin(c)] += 1;
+        ++good;
+    };
+    for (uint64_t p = bs; p < be; ++p) {
+        uint32_t c = g[p];
+        if (caret_skip) { caret_skip = false; continue; }
+        if (c == '^' && p + 1 < be) { caret_skip = true; continue; }
+        if (pending) {
+            uint32_t ps = pending;
+            pending = 0;
+            if (is_digit(c)) { in_run = true; acc = c - 48u; continue; }
+            ordinary(ps);
+        }
+        if (in_run) {
+            if (is_digit(c)) { acc = sat_mul10_add(acc, c - 48u); continue; }
+            debt = sat_add(debt, acc);
+            in_run = false;
+        }
+        if (c == '+' || c == '-') { pending = c; continue; }
+        ordinary(c);
+    }
+    if (pending) ordinary(pending);
+}
+
+__global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
+    __shared__ WaveLds lds[CALL_WAVES];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    WaveLds &L = lds[wave];
+    const uint64_t lt = low_mask(lane);                     // lanes below me
+
+    for (uint32_t site = blockIdx.x * CALL_WAVES + wave; site < a.n_sites; site += gridDim.x * CALL_WAVES) {
+        const uint64_t lv = a.site_line[site];
+        const uint32_t sflags = a.site_flags[site];
+        uint32_t status = SNPGPU_ST_NO_LINE, filters = 0, cons = '-', out_b = '-';
+        uint32_t raw_depth = 0, good = 0, nfwd = 0, nrev = 0, nsym = 0, ref = 0;
+        bool have_hist = false;
+        if (lv != 0) {
+            const uint64_t ls = lv - 1;
+            // ---- stage the line in LDS and tokenise it (fields 0..5) with ballots --------------
+            for (uint32_t i = lane; i < HIST_BINS; i += 64) L.hist[i] = 0;
+            if (lane < 6) { L.fs[lane] = 0xFFFFFFFFu; L.fe[lane] = 0xFFFFFFFFu; }
+            uint32_t nfields = 0, line_len = 0;
+            bool prev_ws = true;
+            for (uint64_t k = 0;; k += 64) {
+                uint64_t p = ls + k + lane;
+                uint32_t c = p < a.nbytes ? a.buf[p] : 10u;
+                if (k + lane < CALL_LBUF) L.line[k + lane] = (uint8_t)c;
+                uint64_t T = __ballot(is_term(c));
+                uint64_t valid = T ? low_mask((uint32_t)__ffsll((long long)T)) : ~0ull;   // up to and incl. the terminator
+                uint64_t W = __ballot(is_ws(c)) & valid;
+                uint64_t prevW = (W << 1) | (prev_ws ? 1ull : 0ull);
+                uint64_t starts = ~W & prevW & valid;
+                uint64_t ends = W & ~prevW & valid;
+                uint32_t before = nfields + __popcll(starts & lt);
+                if ((starts >> lane) & 1) { if (before < 6) L.fs[before] = (uint32_t)(k + lane); }
+                if ((ends >> lane) & 1) { if (before >= 1 && before <= 6) L.fe[before - 1] = (uint32_t)(k + lane); }
+                nfields += __popcll(starts);
+                prev_ws = (W >> 63) & 1;
+                if (T) { line_len = (uint32_t)(k + __ffsll((long long)T) - 1); break; }
+                if (k + 64 > 0xFFFFFF00ull) break;
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            status = SNPGPU_ST_OK;
+            const uint8_t *gl = a.buf + ls;                 // line bytes in global memory
+            auto lb = [&](uint32_t off) -> uint32_t { return off < CALL_LBUF ? L.line[off] : (uint32_t)gl[off]; };
+            if (nfields < 4) status = SNPGPU_ST_SHORT_LINE;
+            else if (L.fe[2] - L.fs[2] != 1) status = SNPGPU_ST_MULTI_REF;
+            else {
+                ref = lb(L.fs[2]);
+                uint32_t ds = L.fs[3], de = L.fe[3];
+                uint64_t dv = 0;
+                bool dok = de > ds;
+                for (uint32_t q = ds; q < de; ++q) {         // uniform loop, a handful of digits
+                    uint32_t c = lb(q);
+                    if (is_digit(c)) { dv = dv * 10 + (c - 48u); if (dv > 0xFFFFFFFFull) dv = 0xFFFFFFFFull; }
+                    else dok = false;
+                }
+                if (!dok) status = SNPGPU_ST_BAD_DEPTH;
+                else {
+                    raw_depth = (uint32_t)dv;
+                    if (raw_depth != 0 && nfields == 5) status = SNPGPU_ST_NO_QUALS;
+                }
+            }
+            if (status == SNPGPU_ST_OK && raw_depth != 0 && nfields >= 6) {
+                have_hist = true;
+                const uint32_t bs = L.fs[4], be = L.fe[4], qs = L.fs[5], qe = L.fe[5];
+                const uint32_t L0 = be - bs, qlen = qe - qs;
+                const uint32_t ref_up = to_upper(ref), ref_lo = to_lower(ref);
+                const int minq = a.prm.min_base_quality;
+                if (line_len <= CALL_LBUF && L0 <= CALL_LMAX) {
+                    // ---- pass A: '^' + next byte (pileup.py:312).  Openers are the carets at even distance from
+                    //      the start of their caret run; a run start is never itself consumed except through the
+                    //      carry at a chunk boundary.  Run membership by parity class uses the carry chain of a
+                    //      64-bit add. -----------------------------------------------------------------------
+                    uint32_t n1 = 0;
+                    bool carry_consumed = false;
+                    for (uint32_t k = 0; k < L0; k += 64) {
+                        uint32_t i = k + lane;
+                        bool v = i < L0;
+                        uint32_t c = v ? L.line[bs + i] : 0u;
+                        uint64_t V = low_mask(L0 - k);
+                        uint64_t C = __ballot(v && c == '^');
+                        uint64_t S = C & ~(C << 1);
+                        const uint64_t EVEN = 0x5555555555555555ull;
+                        uint64_t Se = S & EVEN, So = S & ~EVEN;
+                        if (carry_consumed && (C & 1ull)) { Se &= ~1ull; So |= 1ull; }   // run continues from the previous chunk with flipped parity
+                        uint64_t Me = C & ~(C + Se), Mo = C & ~(C + So);
+                        uint64_t openers = (Me & EVEN) | (Mo & ~EVEN);
+                        if (carry_consumed && (C & 1ull) == 0) { /* byte 0 consumed, not a caret: nothing else changes */ }
+                        uint64_t consumed = (openers << 1) | (carry_consumed ? 1ull : 0ull);
+                        carry_consumed = (openers >> 63) & 1ull;
+                        if (k + 64 >= L0) openers &= ~(1ull << (L0 - 1 - k));          // a trailing lone '^' stays
+                        uint64_t keep = V & ~(openers | consumed);
+                        if ((keep >> lane) & 1) L.s1[n1 + __popcll(keep & lt)] = (uint8_t)c;
+                        n1 += __popcll(keep);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0);
+                    __builtin_amdgcn_wave_barrier();
+                    // ---- pass B: indel markers with additive debt (pileup.py:315-320), '$' (pileup.py:323),
+                    //      quality pairing (pileup.py:248-250), substitution + histogram (pileup.py:255-274) ----
+                    uint32_t kept = 0, debt = 0, acc = 0;
+                    bool in_run = false;
+                    uint64_t carry_md = 0;
+                    for (uint32_t k = 0; k < n1; k += 64) {
+                        uint32_t i = k + lane;
+                        bool v = i < n1;
+                        uint32_t c = v ? L.s1[i] : 0u;
+                        uint32_t nx = (i + 1 < n1) ? L.s1[i + 1] : 0u;
+                        uint32_t nvalid = n1 - k < 64 ? n1 - k : 64;
+                        uint64_t V = low_mask(nvalid);
+                        uint64_t Ms = __ballot(v && (c == '+' || c == '-') && is_digit(nx));
+                        uint64_t Dg = __ballot(v && is_digit(c));
+                        uint64_t Del = 0, Md = 0;
+                        if (Ms || in_run || debt) {
+                            uint64_t St = ((Ms << 1) | carry_md) & Dg;
+                            Md = Dg & ~(Dg + St);
+                            uint32_t cur = 0;
+                            while (true) {
+                                if (in_run) {
+                                    uint64_t rest = cur < 64 ? (~Md >> cur) : 1ull;
+                                    uint32_t run_len = rest ? (uint32_t)__ffsll((long long)rest) - 1 : 64 - cur;
+                                    for (uint32_t q = 0; q < run_len; ++q) acc = sat_mul10_add(acc, (uint32_t)L.s1[k + cur + q] - 48u);
+                                    cur += run_len;
+                                    if (cur >= nvalid && k + 64 < n1) break;            // run may continue in the next chunk
+                                    debt = sat_add(debt, acc);
+                                    acc = 0;
+                                    in_run = false;
+                                    if (cur >= nvalid) break;
+                                }
+                                uint64_t ms_rest = cur < 64 ? (Ms >> cur) : 0ull;
+                                uint32_t m = ms_rest ? cur + (uint32_t)__ffsll((long long)ms_rest) - 1 : 64;
+                                uint32_t seg_end = m < nvalid ? m : nvalid;
+                                uint32_t seg_len = seg_end - cur;
+                                uint32_t eat = debt < seg_len ? debt : seg_len;
+                                Del |= low_mask(cur + eat) & ~low_mask(cur);
+                                debt -= eat;
+                                cur = m;
+                                if (cur >= nvalid) break;
+                                cur += 1;                                               // the sign
+                                in_run = true;
+                                acc = 0;
+                            }
+                        }
+                        carry_md = ((Ms | Md) >> 63) & 1ull;
+                        uint64_t keep = V & ~Ms & ~Md & ~Del & ~__ballot(c == '$');
+                        uint32_t gi = kept + __popcll(keep & lt);
+                        bool is_good = ((keep >> lane) & 1) && gi < qlen && ((int)L.line[qs + gi] - 33 >= minq);
+                        kept += __popcll(keep);
+                        if (c == '.') c = ref_up; else if (c == ',') c = ref_lo;
+                        uint32_t bin = is_good ? hist_bin(c) : 0xFFFFu;
+                        uint64_t rem = __ballot(is_good);
+                        good += __popcll(rem);
+                        while (rem) {                                                   // one LDS update per distinct bin
+                            uint32_t leader = (uint32_t)__ffsll((long long)rem) - 1;
+                            uint32_t kb = __builtin_amdgcn_readlane(bin, leader);
+                            uint64_t same = __ballot(bin == kb);
+                            if (lane == leader) L.hist[kb] += __popcll(same);
+                            rem &= ~same;
+                        }
+                    }
+                } else {
+                    if (lane == 0) call_serial(gl, bs, be, qs, qe, minq, ref_up, ref_lo, L.hist, good);
+                    good = __builtin_amdgcn_readfirstlane(good);
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+
+        // ---- rank the histogram and apply the caller's filters (pileup.py:550-588) ---------------
+        uint32_t t0 = 0, t1 = 0, f0 = 0, f1 = 0, r0 = 0, r1 = 0;
+        if (have_hist) {
+            f0 = L.hist[lane]; f1 = L.hist[lane + 64];
+            r0 = L.hist[128 + lane]; r1 = L.hist[192 + lane];
+            t0 = f0 + r0 + L.hist[256 + lane]; t1 = f1 + r1 + L.hist[320 + lane];
+            nfwd = 0; nrev = 0;
+            uint32_t sf = f0 + f1, sr = r0 + r1;
+            for (int o = 32; o; o >>= 1) { sf += __shfl_xor(sf, o); sr += __shfl_xor(sr, o); }
+            nfwd = sf; nrev = sr;
+            nsym = __popcll(__ballot(t0 != 0)) + __popcll(__ballot(t1 != 0));
+        }
+        uint8_t top_sym[SNPGPU_MAX_SYMS];
+        uint32_t top_t[SNPGPU_MAX_SYMS], top_f[SNPGPU_MAX_SYMS], top_r[SNPGPU_MAX_SYMS];
+        const int want_top = a.out_counts ? SNPGPU_MAX_SYMS : 1;
+#pragma unroll
+        for (int r = 0; r < SNPGPU_MAX_SYMS; ++r) { top_sym[r] = 0; top_t[r] = top_f[r] = top_r[r] = 0; }
+        if (status == SNPGPU_ST_OK) {
+            if (good == 0) { filters = SNPGPU_F_RAWDPTH; cons = '-'; }
+            else {
+#pragma unroll
+                for (int r = 0; r < SNPGPU_MAX_SYMS; ++r) {
+                    if (r >= want_top) break;
+                    // key: count descending, then byte ascending (pileup.py:265)
+                    uint64_t k0 = t0 ? ((uint64_t)t0 << 8) | (255u - lane) : 0ull;
+                    uint64_t k1 = t1 ? ((uint64_t)t1 << 8) | (255u - (lane + 64)) : 0ull;
+                    uint64_t best = k0 > k1 ? k0 : k1;
+                    for (int o = 32; o; o >>= 1) { uint64_t other = __shfl_xor((unsigned long long)best, o); best = other > best ? other : best; }
+                    if (best == 0) break;
+                    uint32_t sym = 255u - (uint32_t)(best & 255u);
+                    uint32_t owner = sym & 63u;
+                    uint32_t tf = sym < 64 ? f0 : f1, tr = sym < 64 ? r0 : r1;
+                    top_sym[r] = (uint8_t)sym;
+                    top_t[r] = (uint32_t)(best >> 8);
+                    top_f[r] = __builtin_amdgcn_readlane(tf, owner);
+                    top_r[r] = __builtin_amdgcn_readlane(tr, owner);
+                    if (lane == owner) { if (sym < 64) t0 = 0; else t1 = 0; }
+                }
+                cons = top_sym[0];
+                const uint32_t n = top_t[0], nf = top_f[0], nr = top_r[0];
+                // CPython compares int < float exactly; one IEEE double multiply, no contraction (pileup.py:564, 580-582)
+                if ((double)n < (double)good * a.prm.min_cons_freq) filters |= SNPGPU_F_VARFREQ;
+                if ((int64_t)n < (int64_t)a.prm.min_cons_depth) filters |= SNPGPU_F_DEPTH;
+                if ((int64_t)nf < (int64_t)a.prm.min_cons_strand_depth || (int64_t)nr < (int64_t)a.prm.min_cons_strand_depth) filters |= SNPGPU_F_STRDPTH;
+                const double bias = (double)n * a.prm.min_cons_strand_bias;
+                if ((double)nf < bias || (double)nr < bias) filters |= SNPGPU_F_STRBIAS;
+                if (cons == to_upper(ref)) cons = ref;
+            }
+            if (sflags & SNPGPU_SITE_EXCLUDED) filters |= SNPGPU_F_REGION;
+            out_b = (filters || cons == '*') ? '-' : cons;                                // call_consensus.py:169-176
+        }
+        if (lane == 0) {
+            a.out_base[site] = (uint8_t)out_b;
+            a.out_filters[site] = (uint8_t)filters;
+            if (a.out_counts) {
+                snpgpu_site_counts oc;
+                oc.raw_depth = raw_depth; oc.good_depth = good; oc.fwd_good_depth = nfwd; oc.rev_good_depth = nrev;
+                oc.n_symbols = nsym; oc.ref_base = (uint8_t)ref; oc.cons_base = (uint8_t)cons;
+                oc.filters = (uint8_t)filters; oc.status = (uint8_t)status;
+#pragma unroll
+                for (int r = 0; r < SNPGPU_MAX_SYMS; ++r) { oc.sym[r] = top_sym[r]; oc.total[r] = top_t[r]; oc.fwd[r] = top_f[r]; oc.rev[r] = top_r[r]; }
+                a.out_counts[site] = oc;
+            } else if (status > SNPGPU_ST_OK) {
+                a.out_filters[site] = (uint8_t)(0x80u | status);                          // error marker when no counts buffer
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+//                                           host API
+// ------------------------------------------------------------------------------------------------
+static int enqueue_sample(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *d_pileup, size_t nbytes,
+                          const snpgpu_caller_params *prm, uint8_t *d_out_base, uint8_t *d_out_filters,
+                          snpgpu_site_counts *d_out_counts, uint64_t *d_status, int want_depth) {
+    hipStream_t st = ctx->stream;
+    const uint32_t n_sites = ss->n_sites;
+    static const uint64_t status_init[SNPGPU_SCAN_STATUS_WORDS] = {~0ull, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(d_status, status_init, sizeof status_init, hipMemcpyHostToDevice, st));
+    if (n_sites) HIP_TRY(ctx, hipMemsetAsync(ss->site_line, 0, 8ull * n_sites, st));
+    if (nbytes) {
+        ScanArgs sa;
+        uintptr_t addr = (uintptr_t)d_pileup;
+        sa.base = (const uint8_t *)(addr & ~(uintptr_t)15);
+        sa.lo = addr & 15;
+        sa.hi = sa.lo + nbytes;
+        sa.n_tiles = (sa.hi + SCAN_TILE - 1) / SCAN_TILE;
+        sa.site_line = ss->site_line;
+        sa.status = d_status;
+        sa.want_depth = want_depth;
+        uint64_t max_blocks = (uint64_t)ctx->n_cu * 8;
+        unsigned grid = (unsigned)(sa.n_tiles < max_blocks ? sa.n_tiles : max_blocks);
+        k_scan_pileup<<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
+    }
+    if (n_sites) {
+        CallArgs ca;
+        ca.buf = d_pileup;
+        ca.nbytes = nbytes;
+        ca.site_line = ss->site_line;
+        ca.site_flags = ss->dev.flags;
+        ca.n_sites = n_sites;
+        ca.prm = *prm;
+        ca.out_base = d_out_base;
+        ca.out_filters = d_out_filters;
+        ca.out_counts = d_out_counts;
+        uint32_t blocks = (n_sites + CALL_WAVES - 1) / CALL_WAVES;
+        uint32_t max_blocks = (uint32_t)ctx->n_cu * 16;
+        k_call_sites<<<blocks < max_blocks ? blocks : max_blocks, CALL_WAVES * 64, 0, st>>>(ca);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return SNPGPU_OK;
+}
+
+extern "C" {
+
+int snpgpu_call_consensus_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const void *d_pileup, size_t nbytes,
+                              const snpgpu_caller_params *params, uint8_t *d_out_base, uint8_t *d_out_filters,
+                              snpgpu_site_counts *d_out_counts, uint64_t *d_status, int want_depth_sum) {
+    if (!ctx || !ss || !params || !d_status || (nbytes && !d_pileup)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (ss->n_sites && (!d_out_base || !d_out_filters)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return enqueue_sample(ctx, ss, (const uint8_t *)d_pileup, nbytes, params, d_out_base, d_out_filters, d_out_counts, d_status, want_depth_sum);
+}
+
+int snpgpu_call_consensus_batch_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const void *d_pileups,
+                                    const uint64_t *h_offsets, uint32_t n_samples,
+                                    const snpgpu_caller_params *params, uint8_t *d_out_base,
+                                    uint8_t *d_out_filters, uint64_t *d_status) {
+    if (!ctx || !ss || !params || !d_status || !h_offsets) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint8_t *p = (const uint8_t *)d_pileups;
+    for (uint32_t i = 0; i < n_samples; ++i) {
+        if (h_offsets[i + 1] < h_offsets[i]) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "offsets must be non-decreasing");
+        size_t off = (size_t)i * ss->n_sites;
+        int rc = enqueue_sample(ctx, ss, p + h_offsets[i], h_offsets[i + 1] - h_offsets[i], params,
+                                d_out_base + off, d_out_filters + off, nullptr,
+                                d_status + (size_t)i * SNPGPU_SCAN_STATUS_WORDS, 0);
+        if (rc) return rc;
+    }
+    return SNPGPU_OK;
+}
+
+int snpgpu_call_consensus(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *pileup, size_t nbytes,
+                          const snpgpu_caller_params *params, uint8_t *out_base, uint8_t *out_filters,
+                          snpgpu_site_counts *out_counts, uint64_t *out_status, int want_depth_sum) {
+    if (!ctx || !ss || !params || !out_status || (nbytes && !pileup)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = ss->n_sites;
+    size_t o_base = (nbytes + 255) / 256 * 256;
+    size_t o_filt = o_base + (n + 255) / 256 * 256;
+    size_t o_stat = o_filt + (n + 255) / 256 * 256;
+    size_t o_cnt = o_stat + 256;
+    size_t total = o_cnt + (out_counts ? sizeof(snpgpu_site_counts) * (size_t)n : 0) + 256;
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, total);
+    if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+    char *b = (char *)d;
+    int rc = SNPGPU_OK;
+    hipStream_t st = ctx->stream;
+#define CC_TRY(expr)                                                                                    \
+    do {                                                                                                \
+        hipError_t e2_ = (expr);                                                                        \
+        if (e2_ != hipSuccess) {                                                                        \
+            hipFree(d);                                                                                 \
+            return snpgpu_set_error(ctx, SNPGPU_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e2_)); \
+        }                                                                                               \
+    } while (0)
+    if (nbytes) CC_TRY(hipMemcpyAsync(b, pileup, nbytes, hipMemcpyHostToDevice, st));
+    rc = enqueue_sample(ctx, ss, (const uint8_t *)b, nbytes, params, (uint8_t *)(b + o_base), (uint8_t *)(b + o_filt),
+                        out_counts ? (snpgpu_site_counts *)(b + o_cnt) : nullptr, (uint64_t *)(b + o_stat), want_depth_sum);
+    if (rc) { hipFree(d); return rc; }
+    if (n) {
+        CC_TRY(hipMemcpyAsync(out_base, b + o_base, n, hipMemcpyDeviceToHost, st));
+        CC_TRY(hipMemcpyAsync(out_filters, b + o_filt, n, hipMemcpyDeviceToHost, st));
+        if (out_counts) CC_TRY(hipMemcpyAsync(out_counts, b + o_cnt, sizeof(snpgpu_site_counts) * (size_t)n, hipMemcpyDeviceToHost, st));
+    }
+    CC_TRY(hipMemcpyAsync(out_status, b + o_stat, 8 * SNPGPU_SCAN_STATUS_WORDS, hipMemcpyDeviceToHost, st));
+    CC_TRY(hipStreamSynchronize(st));
+#undef CC_TRY
+    hipFree(d);
+    if (out_status[0] != ~0ull) {
+        unsigned code = (unsigned)(out_status[0] & 0xFF);
+        unsigned long long off = (unsigned long long)(out_status[0] >> 8) - 1;
+        const char *what = code == SCAN_ERR_FEW_FIELDS ? "line has fewer than 2 fields" :
+                           code == SCAN_ERR_BAD_POS ? "position field is not an unsigned decimal integer" :
+                           code == SCAN_ERR_NON_ASCII ? "non-ASCII byte" : "malformed line";
+        return snpgpu_set_error(ctx, code == SCAN_ERR_NON_ASCII ? SNPGPU_E_UNSUPPORTED : SNPGPU_E_PILEUP,
+                                "pileup: %s at byte offset %llu", what, off);
+    }
+    return SNPGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,198 @@
+// K4-pack + K5: samples x sites matrix packed 4 bits/site, and the all-pairs SNP distance.
+//
+// Replaces utils.calculate_sequence_distance (snppipeline/utils.py:1135-1165) called for every pair by
+// distance.calculate_snp_distances (snppipeline/distance.py:93-98):  a site counts for a pair iff, after
+// upper-casing, both bytes are in {A,C,G,T} and they differ.
+//
+// Packed layout (HBM): packed[row][word] = uint4 { valid, code_hi, code_lo, lower } for 32 consecutive sites,
+// bit i = site 32*word + i;  A=0 C=1 G=2 T=3.  Per pair and word:
+//      mismatches += popcount( ((xh ^ yh) | (xl ^ yl)) & xv & yv )            (6 VALU ops per 32 site-compares)
+// This is integer VALU + LDS work (no MFMA): a 128x128 block of pairs per workgroup, 8x8 pairs per lane,
+// operands staged through LDS in slabs of DIST_KW words.
+#include "internal.h"
+
+#define DIST_TILE 128
+#define DIST_KW 8
+#define DIST_THREADS 256
+
+extern "C" size_t snpgpu_packed_row_bytes(uint32_t n_sites) { return (size_t)((n_sites + 31) / 32) * 16; }
+
+// One wavefront packs 64 consecutive sites of one row: coalesced byte loads, four ballots.
+__global__ __launch_bounds__(256) void k_pack_matrix(const uint8_t *sym, uint32_t n_rows, uint32_t n_sites, size_t stride,
+                                                     uint4 *packed, uint32_t words) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t groups_per_row = (words + 1) / 2;
+    const uint64_t total = (uint64_t)n_rows * groups_per_row;
+    for (uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < total; g += (uint64_t)gridDim.x * 4) {
+        uint32_t row = (uint32_t)(g / groups_per_row);
+        uint32_t grp = (uint32_t)(g % groups_per_row);
+        uint32_t site = grp * 64 + lane;
+        uint32_t c = site < n_sites ? sym[(size_t)row * stride + site] : 0u;
+        uint32_t u = to_upper(c);
+        bool v = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
+        bool hi = (u == 'G') | (u == 'T');
+        bool lo = (u == 'C') | (u == 'T');
+        uint64_t V = __ballot(v), H = __ballot(v && hi), Lo = __ballot(v && lo), Lc = __ballot(c != u);
+        if (lane < 2) {
+            uint32_t w = grp * 2 + lane;
+            if (w < words) {
+                uint32_t sh = lane * 32;
+                packed[(size_t)row * words + w] = make_uint4((uint32_t)(V >> sh), (uint32_t)(H >> sh), (uint32_t)(Lo >> sh), (uint32_t)(Lc >> sh));
+            }
+        }
+    }
+}
+
+struct DistArgs {
+    const uint4 *packed;
+    uint32_t n, words, n_tiles;     // n_tiles = ceil(n / DIST_TILE)
+    uint32_t tile_rank, tile_nranks;
+    uint64_t total_tiles;           // n_tiles * (n_tiles + 1) / 2
+    int32_t *out;
+};
+
+__device__ __forceinline__ void tile_coords(uint64_t t, uint32_t nt, uint32_t &bi, uint32_t &bj) {
+    // row-major enumeration of the upper triangle: row b starts at b*nt - b*(b-1)/2
+    double fn = (double)nt + 0.5;
+    int64_t b = (int64_t)(fn - sqrt(fn * fn - 2.0 * (double)t));
+    if (b < 0) b = 0;
+    if (b >= nt) b = nt - 1;
+    auto start = [&](int64_t r) { return (uint64_t)r * nt - (uint64_t)r * (uint64_t)(r - 1) / 2; };
+    while (b > 0 && start(b) > t) --b;
+    while (b + 1 < (int64_t)nt && start(b + 1) <= t) ++b;
+    bi = (uint32_t)b;
+    bj = (uint32_t)(b + (t - start(b)));
+}
+
+__global__ __launch_bounds__(DIST_THREADS) void k_distance(DistArgs a) {
+    __shared__ uint4 xs[DIST_KW][DIST_TILE];
+    __shared__ uint4 ys[DIST_KW][DIST_TILE];
+    const uint32_t tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    for (uint64_t g = blockIdx.x;; g += gridDim.x) {
+        uint64_t t = (uint64_t)a.tile_rank + g * a.tile_nranks;
+        if (t >= a.total_tiles) break;
+        uint32_t bi, bj;
+        tile_coords(t, a.n_tiles, bi, bj);
+        const uint32_t r0 = bi * DIST_TILE, c0 = bj * DIST_TILE;
+        int32_t acc[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = 0;
+
+        for (uint32_t k0 = 0; k0 < a.words; k0 += DIST_KW) {
+            __syncthreads();
+            // stage 128 rows x DIST_KW words of both operands: consecutive lanes walk the words of a row
+#pragma unroll
+            for (int e = 0; e < DIST_TILE * DIST_KW / DIST_THREADS; ++e) {
+                uint32_t idx = e * DIST_THREADS + tid;
+                uint32_t kk = idx % DIST_KW, rr = idx / DIST_KW;
+                uint32_t w = k0 + kk;
+                uint4 zx = make_uint4(0, 0, 0, 0), zy = zx;
+                if (w < a.words) {
+                    if (r0 + rr < a.n) zx = a.packed[(size_t)(r0 + rr) * a.words + w];
+                    if (c0 + rr < a.n) zy = a.packed[(size_t)(c0 + rr) * a.words + w];
+                }
+                xs[kk][rr] = zx;
+                ys[kk][rr] = zy;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < DIST_KW; ++kk) {
+                uint4 x[8], y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = xs[kk][ty + 16 * i];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = ys[kk][tx + 16 * j];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        uint32_t d = ((x[i].y ^ y[j].y) | (x[i].z ^ y[j].z)) & x[i].x & y[j].x;
+                        acc[i][j] += __popc(d);
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t r = r0 + ty + 16 * i;
+            if (r >= a.n) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint32_t c = c0 + tx + 16 * j;
+                if (c >= a.n) continue;
+                a.out[(size_t)r * a.n + c] = acc[i][j];
+                if (bi != bj) a.out[(size_t)c * a.n + r] = acc[i][j];
+            }
+        }
+    }
+}
+
+extern "C" {
+
+int snpgpu_pack_matrix_dev(snpgpu_ctx *ctx, const uint8_t *d_symbols, uint32_t n_rows, uint32_t n_sites,
+                           size_t row_stride, void *d_packed) {
+    if (!ctx) return SNPGPU_E_ARG;
+    if (n_rows == 0 || n_sites == 0) return SNPGPU_OK;
+    if (!d_symbols || !d_packed || row_stride < n_sites) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "bad pack arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t words = (n_sites + 31) / 32;
+    uint64_t groups = (uint64_t)n_rows * ((words + 1) / 2);
+    uint64_t blocks = (groups + 3) / 4, cap = (uint64_t)ctx->n_cu * 32;
+    k_pack_matrix<<<(unsigned)(blocks < cap ? blocks : cap), 256, 0, ctx->stream>>>(d_symbols, n_rows, n_sites, row_stride, (uint4 *)d_packed, words);
+    HIP_TRY(ctx, hipGetLastError());
+    return SNPGPU_OK;
+}
+
+int snpgpu_distance_packed_dev(snpgpu_ctx *ctx, const void *d_packed, uint32_t n_rows, uint32_t n_sites,
+                               uint32_t tile_rank, uint32_t tile_nranks, int32_t *d_out) {
+    if (!ctx) return SNPGPU_E_ARG;
+    if (tile_nranks == 0 || tile_rank >= tile_nranks) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "bad tile rank %u of %u", tile_rank, tile_nranks);
+    if (n_rows == 0) return SNPGPU_OK;
+    if (!d_out || (n_sites && !d_packed)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null distance argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DistArgs a;
+    a.packed = (const uint4 *)d_packed;
+    a.n = n_rows;
+    a.words = (n_sites + 31) / 32;
+    a.n_tiles = (n_rows + DIST_TILE - 1) / DIST_TILE;
+    a.tile_rank = tile_rank;
+    a.tile_nranks = tile_nranks;
+    a.total_tiles = (uint64_t)a.n_tiles * (a.n_tiles + 1) / 2;
+    a.out = d_out;
+    uint64_t mine = a.total_tiles > tile_rank ? (a.total_tiles - tile_rank + tile_nranks - 1) / tile_nranks : 0;
+    if (mine == 0) return SNPGPU_OK;
+    uint64_t cap = (uint64_t)ctx->n_cu * 64;
+    k_distance<<<(unsigned)(mine < cap ? mine : cap), DIST_THREADS, 0, ctx->stream>>>(a);
+    HIP_TRY(ctx, hipGetLastError());
+    return SNPGPU_OK;
+}
+
+int snpgpu_distance(snpgpu_ctx *ctx, const uint8_t *symbols, uint32_t n_rows, uint32_t n_sites, int32_t *out) {
+    if (!ctx) return SNPGPU_E_ARG;
+    if (n_rows == 0) return SNPGPU_OK;
+    if (!out || (n_sites && !symbols)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null distance argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t sym_bytes = (size_t)n_rows * n_sites;
+    size_t o_pack = (sym_bytes + 255) / 256 * 256;
+    size_t pack_bytes = snpgpu_packed_row_bytes(n_sites) * n_rows;
+    size_t o_out = o_pack + (pack_bytes + 255) / 256 * 256;
+    size_t out_bytes = (size_t)n_rows * n_rows * 4;
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, o_out + out_bytes + 256);
+    if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+    char *b = (char *)d;
+    hipStream_t st = ctx->stream;
+    int rc = SNPGPU_OK;
+    hipError_t he = hipSuccess;
+    if (sym_bytes) he = hipMemcpyAsync(b, symbols, sym_bytes, hipMemcpyHostToDevice, st);
+    if (he == hipSuccess && n_sites) rc = snpgpu_pack_matrix_dev(ctx, (const uint8_t *)b, n_rows, n_sites, n_sites, b + o_pack);
+    if (he == hipSuccess && rc == SNPGPU_OK) rc = snpgpu_distance_packed_dev(ctx, b + o_pack, n_rows, n_sites, 0, 1, (int32_t *)(b + o_out));
+    if (he == hipSuccess && rc == SNPGPU_OK) he = hipMemcpyAsync(out, b + o_out, out_bytes, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (he != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_HIP, "distance failed: %s", hipGetErrorString(he));
+    return rc;
+}
+
+}  // extern "C"

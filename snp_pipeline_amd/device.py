@@ -1,0 +1,290 @@
+"""Python face of the C ABI: a ``Device`` owns one snpgpu context; all arithmetic of the hot path runs in the
+HIP kernels behind it.  Nothing here computes a result on the CPU — arrays are only marshalled.
+
+Device-memory plumbing (allocation, streams, collectives) is torch's; host buffers are numpy.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import CallerParams, SiteCounts, SnpGpuError  # noqa: F401  (re-exported)
+
+COUNTS_DTYPE = np.dtype([
+    ("raw_depth", "<u4"), ("good_depth", "<u4"), ("fwd_good_depth", "<u4"), ("rev_good_depth", "<u4"),
+    ("n_symbols", "<u4"), ("ref_base", "u1"), ("cons_base", "u1"), ("filters", "u1"), ("status", "u1"),
+    ("sym", "u1", (L.MAX_SYMS,)), ("total", "<u4", (L.MAX_SYMS,)), ("fwd", "<u4", (L.MAX_SYMS,)),
+    ("rev", "<u4", (L.MAX_SYMS,))])
+assert COUNTS_DTYPE.itemsize == 128
+
+_SCAN_CODES = {1: "line has fewer than 2 fields", 2: "position field is not an unsigned decimal integer",
+               3: "non-ASCII byte in pileup"}
+
+
+class PileupFormatError(ValueError):
+    """The pileup text is malformed in a way that makes the reference raise (pileup.py:425-426, 224-237)."""
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def make_params(min_base_quality=0, min_cons_freq=0.6, min_cons_depth=1, min_cons_strand_depth=0,
+                min_cons_strand_bias=0.0):
+    return CallerParams(int(min_base_quality), int(min_cons_depth), int(min_cons_strand_depth), 0,
+                        float(min_cons_freq), float(min_cons_strand_bias))
+
+
+class SiteSet(object):
+    """The (chrom, pos) set handed to pileup.Reader (pileup.py:396-403), resident on the device."""
+
+    def __init__(self, device, keys, flags):
+        """keys: sequence of (chrom: bytes, pos: int); flags: parallel sequence of SITE_* bit masks.
+        Duplicated keys are merged (flags OR-ed).  ``index_of`` maps each input key to its device slot
+        (-1 for positions that cannot occur in a pileup: negative or >= 2**32)."""
+        self.device = device
+        contigs = sorted({k[0] for k in keys})
+        cid = {c: i for i, c in enumerate(contigs)}
+        n = len(keys)
+        packed = np.empty(n, dtype=np.uint64)
+        ok = np.ones(n, dtype=bool)
+        for i, (c, p) in enumerate(keys):
+            if 0 <= p < (1 << 32):
+                packed[i] = (cid[c] << 32) | p
+            else:
+                packed[i] = 0
+                ok[i] = False
+        fl = np.asarray(flags, dtype=np.uint8).reshape(n) if n else np.zeros(0, np.uint8)
+        uniq, inv = np.unique(packed[ok], return_inverse=True)
+        ufl = np.zeros(len(uniq), dtype=np.uint8)
+        np.bitwise_or.at(ufl, inv, fl[ok])
+        self.index_of = np.full(n, -1, dtype=np.int64)
+        self.index_of[ok] = inv
+        self.contigs = contigs
+        self.keys = np.ascontiguousarray(uniq, dtype=np.uint64)
+        self.flags = np.ascontiguousarray(ufl)
+        names = b"".join(contigs)
+        offs = np.zeros(len(contigs) + 1, dtype=np.uint32)
+        if contigs:
+            offs[1:] = np.cumsum([len(c) for c in contigs])
+        self._names = np.frombuffer(names, dtype=np.uint8) if names else np.zeros(0, np.uint8)
+        self._offs = offs
+        h = C.c_void_p()
+        device._check(device.lib.snpgpu_siteset_create(
+            device.ctx, _ptr(self._names), _ptr(self._offs), len(contigs), _ptr(self.keys), _ptr(self.flags),
+            len(self.keys), C.byref(h)))
+        self.handle = h
+
+    def __len__(self):
+        return len(self.keys)
+
+    def key_tuples(self):
+        return [(self.contigs[int(k) >> 32], int(k) & 0xFFFFFFFF) for k in self.keys]
+
+    def close(self):
+        if self.handle:
+            self.device.lib.snpgpu_siteset_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ConsensusResult(object):
+    __slots__ = ("bases", "filters", "counts", "status", "n_lines", "n_matched", "depth_sum")
+
+    def __init__(self, bases, filters, counts, status):
+        self.bases, self.filters, self.counts, self.status = bases, filters, counts, status
+        self.n_lines, self.n_matched, self.depth_sum = int(status[1]), int(status[2]), int(status[3])
+
+
+class Device(object):
+    def __init__(self, index=None):
+        self.lib = L.load()
+        if index is None:
+            index = int(os.environ.get("SNPGPU_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        self.index = index
+        h = C.c_void_p()
+        rc = self.lib.snpgpu_ctx_create(index, C.byref(h))
+        if rc != 0:
+            raise SnpGpuError(rc, "no usable gfx950 device %d (the HIP path has no CPU fallback)" % index)
+        self.ctx = h
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.snpgpu_last_error(self.ctx)
+            raise SnpGpuError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+    def close(self):
+        if self.ctx:
+            self.lib.snpgpu_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def use_torch_stream(self):
+        """Enqueue on torch's current stream so torch.cuda events / collectives order with our kernels."""
+        import torch
+        self._check(self.lib.snpgpu_ctx_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def sync(self):
+        self._check(self.lib.snpgpu_ctx_sync(self.ctx))
+
+    def timer_start(self):
+        self._check(self.lib.snpgpu_timer_start(self.ctx))
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        self._check(self.lib.snpgpu_timer_stop_ms(self.ctx, C.byref(ms)))
+        return ms.value
+
+    # ---- call_consensus ------------------------------------------------------------------------
+    def siteset(self, keys, flags):
+        return SiteSet(self, keys, flags)
+
+    @staticmethod
+    def raise_scan_status(status):
+        w0 = int(status[0])
+        if w0 != 0xFFFFFFFFFFFFFFFF:
+            code, off = w0 & 0xFF, (w0 >> 8) - 1
+            raise PileupFormatError("pileup: %s at byte offset %d" % (_SCAN_CODES.get(code, "malformed line"), off))
+
+    def call_consensus(self, siteset, pileup, params, want_counts=False, want_depth_sum=False):
+        """pileup: bytes-like (host).  Returns ConsensusResult over siteset.keys order."""
+        buf = np.frombuffer(pileup, dtype=np.uint8)
+        n = len(siteset)
+        bases = np.empty(n, dtype=np.uint8)
+        filters = np.empty(n, dtype=np.uint8)
+        counts = np.zeros(n, dtype=COUNTS_DTYPE) if want_counts else None
+        status = np.zeros(L.SCAN_STATUS_WORDS, dtype=np.uint64)
+        rc = self.lib.snpgpu_call_consensus(self.ctx, siteset.handle, _ptr(buf) if len(buf) else None, len(buf),
+                                            C.byref(params), _ptr(bases), _ptr(filters), _ptr(counts), _ptr(status),
+                                            1 if want_depth_sum else 0)
+        if rc in (L.E_PILEUP, L.E_UNSUPPORTED) and int(status[0]) != 0xFFFFFFFFFFFFFFFF:
+            self.raise_scan_status(status)
+        self._check(rc)
+        res = ConsensusResult(bases, filters, counts, status)
+        self.raise_site_status(res)
+        return res
+
+    @staticmethod
+    def raise_site_status(res):
+        """Per-line failures that make the reference raise while building a Record."""
+        if res.counts is not None:
+            bad = np.nonzero(res.counts["status"] > L.ST_OK)[0]
+            code = int(res.counts["status"][bad[0]]) if len(bad) else 0
+        else:
+            bad = np.nonzero(res.filters & 0x80)[0]
+            code = int(res.filters[bad[0]] & 0x7F) if len(bad) else 0
+        if len(bad):
+            what = {L.ST_SHORT_LINE: "IndexError: line has fewer than 4 fields",
+                    L.ST_BAD_DEPTH: "ValueError: depth field is not an unsigned decimal integer",
+                    L.ST_NO_QUALS: "IndexError: depth > 0 but no quality field",
+                    L.ST_MULTI_REF: "unsupported: reference-base field longer than one byte"}.get(code, "malformed line")
+            raise PileupFormatError("pileup line for site #%d: %s" % (int(bad[0]), what))
+
+    def call_consensus_dev(self, siteset, d_pileup_ptr, nbytes, params, d_bases, d_filters, d_status, d_counts=None,
+                           want_depth_sum=False):
+        """All arguments are device pointers (ints); asynchronous on the context's stream."""
+        self._check(self.lib.snpgpu_call_consensus_dev(
+            self.ctx, siteset.handle, C.c_void_p(d_pileup_ptr), nbytes, C.byref(params), C.c_void_p(d_bases),
+            C.c_void_p(d_filters), C.c_void_p(d_counts) if d_counts else None, C.c_void_p(d_status),
+            1 if want_depth_sum else 0))
+
+    def call_consensus_batch_dev(self, siteset, d_pileups_ptr, offsets, params, d_bases, d_filters, d_status):
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._check(self.lib.snpgpu_call_consensus_batch_dev(
+            self.ctx, siteset.handle, C.c_void_p(d_pileups_ptr), _ptr(offs), len(offs) - 1, C.byref(params),
+            C.c_void_p(d_bases), C.c_void_p(d_filters), C.c_void_p(d_status)))
+
+    # ---- distance ------------------------------------------------------------------------------
+    def packed_row_bytes(self, n_sites):
+        return int(self.lib.snpgpu_packed_row_bytes(n_sites))
+
+    def distance(self, symbols):
+        """symbols: (n, s) uint8 array of sequence bytes.  Returns (n, n) int32."""
+        sym = np.ascontiguousarray(symbols, dtype=np.uint8)
+        n, s = sym.shape
+        out = np.zeros((n, n), dtype=np.int32)
+        self._check(self.lib.snpgpu_distance(self.ctx, _ptr(sym) if sym.size else None, n, s, _ptr(out)))
+        return out
+
+    def pack_matrix_dev(self, d_symbols, n_rows, n_sites, row_stride, d_packed):
+        self._check(self.lib.snpgpu_pack_matrix_dev(self.ctx, C.c_void_p(d_symbols), n_rows, n_sites, row_stride,
+                                                    C.c_void_p(d_packed)))
+
+    def distance_packed_dev(self, d_packed, n_rows, n_sites, d_out, tile_rank=0, tile_nranks=1):
+        self._check(self.lib.snpgpu_distance_packed_dev(self.ctx, C.c_void_p(d_packed), n_rows, n_sites, tile_rank,
+                                                        tile_nranks, C.c_void_p(d_out)))
+
+    # ---- filter_regions ------------------------------------------------------------------------
+    def dense_windows(self, positions, seg_off, max_snps, windows):
+        pos = np.ascontiguousarray(positions, dtype=np.int64)
+        seg = np.ascontiguousarray(seg_off, dtype=np.uint32)
+        ms = np.ascontiguousarray(max_snps, dtype=np.int32)
+        ws = np.ascontiguousarray(windows, dtype=np.int32)
+        cap = max(1, len(pos) * max(1, len(ms)))
+        o_s, o_e, o_g = np.empty(cap, np.int64), np.empty(cap, np.int64), np.empty(cap, np.uint32)
+        n = C.c_uint32()
+        self._check(self.lib.snpgpu_dense_windows(self.ctx, _ptr(pos), _ptr(seg), len(seg) - 1, _ptr(ms), _ptr(ws),
+                                                  len(ms), _ptr(o_s), _ptr(o_e), _ptr(o_g), C.byref(n)))
+        return o_s[:n.value], o_e[:n.value], o_g[:n.value]
+
+    def merge_regions(self, group, start, end):
+        g = np.ascontiguousarray(group, dtype=np.uint32)
+        s = np.ascontiguousarray(start, dtype=np.int64)
+        e = np.ascontiguousarray(end, dtype=np.int64)
+        m = len(g)
+        og, os_, oe = np.empty(max(m, 1), np.uint32), np.empty(max(m, 1), np.int64), np.empty(max(m, 1), np.int64)
+        n = C.c_uint32()
+        self._check(self.lib.snpgpu_merge_regions(self.ctx, _ptr(g), _ptr(s), _ptr(e), m, _ptr(og), _ptr(os_), _ptr(oe),
+                                                  C.byref(n)))
+        return og[:n.value], os_[:n.value], oe[:n.value]
+
+    def in_regions(self, pos_group, positions, reg_off, reg_start, reg_end):
+        pg = np.ascontiguousarray(pos_group, dtype=np.uint32)
+        ps = np.ascontiguousarray(positions, dtype=np.int64)
+        ro = np.ascontiguousarray(reg_off, dtype=np.uint32)
+        rs = np.ascontiguousarray(reg_start, dtype=np.int64)
+        re_ = np.ascontiguousarray(reg_end, dtype=np.int64)
+        out = np.zeros(len(ps), dtype=np.uint8)
+        self._check(self.lib.snpgpu_in_regions(self.ctx, _ptr(pg), _ptr(ps), len(ps), _ptr(ro), _ptr(rs), _ptr(re_),
+                                               len(ro) - 1, _ptr(out)))
+        return out.astype(bool)
+
+    # ---- merge_sites ---------------------------------------------------------------------------
+    def merge_sites(self, keys, sample_of_key):
+        k = np.ascontiguousarray(keys, dtype=np.uint64)
+        s = np.ascontiguousarray(sample_of_key, dtype=np.uint32)
+        m = len(k)
+        uniq, off, car = np.empty(max(m, 1), np.uint64), np.zeros(m + 1, np.uint32), np.empty(max(m, 1), np.uint32)
+        nu, nc = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.snpgpu_merge_sites(self.ctx, _ptr(k), _ptr(s), m, _ptr(uniq), _ptr(off), _ptr(car),
+                                                C.byref(nu), C.byref(nc)))
+        return uniq[:nu.value], off[:nu.value + 1], car[:nc.value]
+
+    # ---- synthetic pileups ---------------------------------------------------------------------
+    def synth_reference_dev(self, seed, genome_len, d_ref):
+        self._check(self.lib.snpgpu_synth_reference_dev(self.ctx, seed, genome_len, C.c_void_p(d_ref)))
+
+    def synth_pileup_dev(self, seed, sample, genome_len, d_ref, d_site_alt, d_out, capacity, contig=b"synth_chr1",
+                         mean_depth=30.0, p_same=0.15, p_other=0.02, n_clades=10):
+        p = L.SynthParams(seed, sample, genome_len, mean_depth, p_same, p_other, n_clades, contig)
+        nbytes = C.c_size_t()
+        self._check(self.lib.snpgpu_synth_pileup_dev(self.ctx, C.byref(p), C.c_void_p(d_ref),
+                                                     C.c_void_p(d_site_alt) if d_site_alt else None,
+                                                     C.c_void_p(d_out) if d_out else None, capacity, C.byref(nbytes)))
+        return nbytes.value
+
+
+_default = None
+
+
+def default_device():
+    global _default
+    if _default is None:
+        _default = Device()
+    return _default

@@ -1,0 +1,238 @@
+"""filter_regions subcommand: drop SNPs at contig edges and in abnormally dense windows.
+
+Host mirror of snppipeline/filter_regions.py (filter_regions :74, filter_regions_across_samples :205,
+filter_regions_per_sample :300, collect_dense_regions :386, write_outgroup_... :431,
+write_preserved_and_removed_vcf_files :460).  File handling, freshness and the error protocol live here; the
+arithmetic — dense-window test, interval merge, position-in-region classification — runs in the HIP kernels
+behind ``Device.dense_windows / merge_regions / in_regions`` (csrc/regions.hip).
+"""
+from __future__ import print_function
+
+import os
+import shutil
+import sys
+
+import numpy as np
+
+from . import utils
+
+UNKNOWN_CONTIG_LENGTH = sys.maxsize          # filter_regions.py:417 fallback for contigs missing from the FASTA
+
+
+def _edge_intervals(length, edge_length):
+    if length <= 2 * edge_length:
+        return [(0, length)]
+    return [(0, edge_length), (length - edge_length, length)]
+
+
+def compute_bad_regions(dev, samples, contig_lengths, edge_length, max_snps_list, window_list, per_sample=False):
+    """samples: list (one per non-outgroup sample) of [(contig, pos), ...] in file order.
+
+    Returns, for mode all, {contig: [(start, end), ...]} merged; for per_sample=True a list of such dicts.
+    Every interval comes from the device: candidates from the dense-window kernel, the union from the merge
+    kernel.  The host only lays out segments and the contig-edge intervals (parameters, not data)."""
+    # group ids: mode all -> contig; mode each -> (sample, contig)
+    group_of = {}
+    groups = []
+
+    def gid(sample_idx, contig):
+        key = (sample_idx if per_sample else -1, contig)
+        if key not in group_of:
+            group_of[key] = len(groups)
+            groups.append(key)
+        return group_of[key]
+
+    seg_positions, seg_group = [], []
+    for si, sites in enumerate(samples):
+        by_contig = {}
+        for contig, pos in sites:
+            by_contig.setdefault(contig, []).append(pos)
+        for contig, plist in by_contig.items():
+            seg_positions.append(plist)
+            seg_group.append(gid(si, contig))
+    g_list, s_list, e_list = [], [], []
+    for (si, contig), g in sorted(group_of.items(), key=lambda kv: kv[1]):
+        for a, b in _edge_intervals(contig_lengths.get(contig, UNKNOWN_CONTIG_LENGTH), edge_length):
+            g_list.append(g), s_list.append(a), e_list.append(b)
+    if seg_positions:
+        seg_off = np.zeros(len(seg_positions) + 1, dtype=np.uint32)
+        seg_off[1:] = np.cumsum([len(p) for p in seg_positions])
+        flat = np.fromiter((p for plist in seg_positions for p in plist), dtype=np.int64, count=int(seg_off[-1]))
+        cs, ce, cseg = dev.dense_windows(flat, seg_off, max_snps_list, window_list)
+        seg_group_arr = np.asarray(seg_group, dtype=np.uint32)
+        g_all = np.concatenate([np.asarray(g_list, dtype=np.uint32), seg_group_arr[cseg]])
+        s_all = np.concatenate([np.asarray(s_list, dtype=np.int64), cs])
+        e_all = np.concatenate([np.asarray(e_list, dtype=np.int64), ce])
+    else:
+        g_all, s_all, e_all = (np.asarray(g_list, dtype=np.uint32), np.asarray(s_list, dtype=np.int64),
+                               np.asarray(e_list, dtype=np.int64))
+    mg, ms, me = dev.merge_regions(g_all, s_all, e_all)
+    if per_sample:
+        out = [dict() for _ in samples]
+        for g, a, b in zip(mg, ms, me):
+            si, contig = groups[int(g)]
+            out[si].setdefault(contig, []).append((int(a), int(b)))
+        return out
+    out = {}
+    for g, a, b in zip(mg, ms, me):
+        out.setdefault(groups[int(g)][1], []).append((int(a), int(b)))
+    return out
+
+
+def classify_records(dev, sites, regions):
+    """sites: [(contig, pos)]; regions: {contig: merged [(start, end)]}.  Returns a bool array, True = removed."""
+    if not sites:
+        return np.zeros(0, dtype=bool)
+    contigs = sorted(regions)
+    cid = {c: i for i, c in enumerate(contigs)}
+    reg_off = np.zeros(len(contigs) + 1, dtype=np.uint32)
+    rs, re_ = [], []
+    for i, c in enumerate(contigs):
+        rs.extend(a for a, _ in regions[c])
+        re_.extend(b for _, b in regions[c])
+        reg_off[i + 1] = len(rs)
+    pos_group = np.fromiter((cid[c] for c, _ in sites), dtype=np.uint32, count=len(sites))   # KeyError like bad_regions_dict[contig]
+    positions = np.fromiter((p for _, p in sites), dtype=np.int64, count=len(sites))
+    return dev.in_regions(pos_group, positions, reg_off, rs, re_)
+
+
+_STRUCTURED = ("##INFO=", "##FORMAT=", "##FILTER=", "##ALT=", "##contig=")
+
+
+def reorder_header(header_lines):
+    """Header as PyVCF3's Writer re-emits a Reader template: plain ``##key=value`` lines, then INFO, FORMAT,
+    FILTER, ALT, contig, then the ``#CHROM`` line (pinned by the lambda var.flt_preserved.vcf fixtures)."""
+    plain = [h for h in header_lines if h.startswith("##") and not h.startswith(_STRUCTURED)]
+    out = list(plain)
+    for prefix in ("##INFO=", "##FORMAT=", "##FILTER=", "##ALT=", "##contig="):
+        out.extend(h for h in header_lines if h.startswith(prefix))
+    out.extend(h for h in header_lines if h.startswith("#") and not h.startswith("##"))
+    return out
+
+
+def _write_vcf(path, header, data_lines):
+    with open(path, "w") as f:
+        f.writelines(header)
+        f.writelines(data_lines)
+
+
+def write_outgroup_preserved_and_removed_vcf_files(vcf_file_path, header):
+    preserved = vcf_file_path[:-4] + "_preserved.vcf"
+    removed = vcf_file_path[:-4] + "_removed.vcf"
+    try:
+        _write_vcf(removed, reorder_header(header), [])
+    except (IOError, OSError):
+        if os.path.exists(removed):
+            os.remove(removed)
+        utils.sample_error("Error: Cannot create the file for removed SNPs: %s." % removed, continue_possible=True)
+        return
+    shutil.copyfile(vcf_file_path, preserved)
+
+
+def write_preserved_and_removed_vcf_files(vcf_file_path, header, data_lines, removed_flags):
+    preserved = vcf_file_path[:-4] + "_preserved.vcf"
+    removed = vcf_file_path[:-4] + "_removed.vcf"
+    hdr = reorder_header(header)
+    try:
+        _write_vcf(preserved, hdr, [ln for ln, r in zip(data_lines, removed_flags) if not r])
+    except (IOError, OSError):
+        if os.path.exists(preserved):
+            os.remove(preserved)
+        utils.sample_error("Error: Cannot create the file for preserved SNPs: %s." % preserved, continue_possible=True)
+        return
+    try:
+        _write_vcf(removed, hdr, [ln for ln, r in zip(data_lines, removed_flags) if r])
+    except (IOError, OSError):
+        if os.path.exists(removed):
+            os.remove(removed)
+        utils.sample_error("Error: Cannot create the file for removed SNPs: %s." % removed, continue_possible=True)
+
+
+def filter_regions(args):
+    """Entry point of ``cfsan_snp_pipeline filter_regions`` (cfsan_snp_pipeline.py:309-324)."""
+    utils.print_log_header()
+    utils.print_arguments(args)
+
+    sample_directories_list_path = args.sampleDirsFile
+    ref_fasta_path = args.refFastaFile
+    force_flag = args.forceFlag
+    vcf_file_name = args.vcfFileName
+    edge_length = args.edgeLength
+    window_size_list = args.windowSizeList
+    max_num_snps_list = args.maxSnpsList
+    out_group_list_path = args.outGroupFile
+    filter_across_samples = args.mode == "all"
+
+    if utils.verify_non_empty_input_files("File of sample directories", [sample_directories_list_path]) > 0:
+        utils.global_error(None)
+    with open(sample_directories_list_path, "r") as f:
+        dirs = [line.rstrip() for line in f]
+    sorted_dirs = sorted(d for d in dirs if d)
+    list_of_vcf_files = [os.path.join(d, vcf_file_name) for d in sorted_dirs]
+    bad = utils.verify_non_empty_input_files("VCF file", list_of_vcf_files)
+    if bad == len(list_of_vcf_files):
+        utils.global_error("Error: all %d VCF files were missing or empty." % bad)
+    elif bad > 0:
+        utils.sample_error("Error: %d VCF files were missing or empty." % bad, continue_possible=True)
+    if utils.verify_non_empty_input_files("Reference file", [ref_fasta_path]) > 0:
+        utils.global_error(None)
+
+    outgroup = []
+    if out_group_list_path is not None:
+        if utils.verify_non_empty_input_files("File of outgroup samples", [out_group_list_path]) > 0:
+            utils.global_error(None)
+        try:
+            with open(out_group_list_path, "r") as f:
+                outgroup = sorted(line.rstrip() for line in f)
+        except (IOError, OSError):
+            utils.global_error("Error: Cannot open the file containing the list of outgroup samples!")
+    try:
+        contig_length_dict = utils.read_fasta_lengths(ref_fasta_path)
+    except (IOError, OSError, UnicodeDecodeError):
+        utils.global_error("Error: cannot open the reference fastq file, or fail to read the contigs in the reference fastq file.")
+
+    # ---- which samples need a rebuild (filter_regions.py:246-256 / :339-350) -------------------------------
+    common_inputs = [ref_fasta_path] + ([out_group_list_path] if out_group_list_path else [])
+    if filter_across_samples:
+        common_inputs = common_inputs + list_of_vcf_files
+    need_rebuild = {}
+    for vcf_path in list_of_vcf_files:
+        inputs = common_inputs if filter_across_samples else common_inputs + [vcf_path]
+        need_rebuild[vcf_path] = (force_flag
+                                  or utils.target_needs_rebuild(inputs, vcf_path[:-4] + "_preserved.vcf")
+                                  or utils.target_needs_rebuild(inputs, vcf_path[:-4] + "_removed.vcf"))
+    if not any(need_rebuild.values()):
+        utils.verbose_print("All preserved and removed vcf files are already freshly built.  Use the -f option to force a rebuild.")
+        return
+
+    # ---- read the VCFs (mode all reads every sample; mode each only those being rebuilt) ---------------------
+    from .device import default_device
+    dev = default_device()
+    parsed = []          # (vcf_path, header, data_lines, sites)
+    for vcf_path in list_of_vcf_files:
+        if not filter_across_samples and not need_rebuild[vcf_path]:
+            continue
+        try:
+            header, data_lines, sites = utils.read_vcf_sites(vcf_path)
+        except (IOError, OSError):
+            utils.sample_error("Error: Cannot open the input vcf file: %s." % vcf_path, continue_possible=True)
+            continue
+        sample_id = utils.sample_id_from_file(vcf_path)
+        utils.verbose_print("Processing sample %s" % sample_id)
+        if sample_id in outgroup:
+            if filter_across_samples or need_rebuild[vcf_path]:
+                write_outgroup_preserved_and_removed_vcf_files(vcf_path, header)
+            continue
+        parsed.append((vcf_path, header, data_lines, sites))
+
+    site_lists = [p[3] for p in parsed]
+    if filter_across_samples:
+        regions = compute_bad_regions(dev, site_lists, contig_length_dict, edge_length, max_num_snps_list, window_size_list)
+        for vcf_path, header, data_lines, sites in parsed:
+            if need_rebuild[vcf_path]:
+                write_preserved_and_removed_vcf_files(vcf_path, header, data_lines, classify_records(dev, sites, regions))
+    else:
+        per_sample = compute_bad_regions(dev, site_lists, contig_length_dict, edge_length, max_num_snps_list,
+                                         window_size_list, per_sample=True)
+        for (vcf_path, header, data_lines, sites), regions in zip(parsed, per_sample):
+            write_preserved_and_removed_vcf_files(vcf_path, header, data_lines, classify_records(dev, sites, regions))

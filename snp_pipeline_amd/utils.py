@@ -1,0 +1,275 @@
+"""Host-side conventions of the hot subcommands: logging banner, error/exit protocol, make-style freshness,
+and the small text codecs (snplist, VCF CHROM/POS, FASTA) the five steps share.
+
+Mirrors the subset of snppipeline/utils.py the hot path uses (names and behaviour kept so a maintainer can
+diff them): verbose_print :49, print_log_header :85, print_arguments :130, global_error :542,
+sample_error :575, handle_global_exception :629, handle_sample_exception :675, verify_*_input_files :754/:804,
+target_needs_rebuild :977, write_list_of_snps :1056, read_snp_position_list :1073,
+convert_vcf_file_to_snp_set :1113, sample_id_from_file :469.  No arithmetic of the path lives here.
+"""
+from __future__ import print_function
+
+import os
+import platform
+import sys
+import time
+import traceback
+
+__version__ = "2.2.1"            # the reference version whose CLI/formats this build reproduces
+
+log_verbosity = 0
+
+
+def set_logging_verbosity(args):
+    global log_verbosity
+    log_verbosity = args.verbose
+
+
+def verbose_print(*args):
+    if log_verbosity > 0:
+        print(*args)
+
+
+def timestamp():
+    return time.strftime('%Y-%m-%d %H:%M:%S', time.localtime())
+
+
+def program_name():
+    return os.path.basename(sys.argv[0])
+
+
+def program_name_with_command():
+    program = os.path.basename(sys.argv[0])
+    if program == "cfsan_snp_pipeline" and len(sys.argv) > 1:
+        program += " " + sys.argv[1]
+    return program
+
+
+def command_line_short():
+    return "%s %s" % (program_name(), " ".join(sys.argv[1:]))
+
+
+def command_line_long():
+    return " ".join(sys.argv)
+
+
+def _ram_mbytes():
+    try:
+        return os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") // (1024 * 1024)
+    except (ValueError, OSError, AttributeError):
+        return 0
+
+
+def print_log_header(classpath=False):
+    verbose_print("# Command           : %s" % command_line_long())
+    verbose_print("# Working Directory : %s" % os.getcwd())
+    env = os.environ.get
+    pbs, sge, sge_task = env("PBS_JOBID"), env("JOB_ID"), env("SGE_TASK_ID")
+    slurm_array, slurm_job, slurm_task = env("SLURM_ARRAY_JOB_ID"), env("SLURM_JOBID"), env("SLURM_ARRAY_TASK_ID")
+    if sge_task == "undefined":
+        sge_task = None
+    if pbs:
+        verbose_print("# Job ID            : %s" % pbs)
+    elif sge and sge_task:
+        verbose_print("# Job ID            : %s[%s]" % (sge, sge_task))
+    elif sge:
+        verbose_print("# Job ID            : %s" % sge)
+    elif slurm_array and slurm_task:
+        verbose_print("# Job ID            : %s[%s]" % (slurm_array, slurm_task))
+    elif slurm_job:
+        verbose_print("# Job ID            : %s" % slurm_job)
+    verbose_print("# Hostname          : %s" % platform.node())
+    verbose_print("# RAM               : %s MB" % format(_ram_mbytes(), ",d"))
+    if classpath:
+        verbose_print("# CLASSPATH         : %s" % os.environ.get("CLASSPATH"))
+    verbose_print("# Python Version    : %s" % sys.version.replace("\n", " "))
+    verbose_print("# Program Version   : %s %s" % (program_name_with_command(), __version__))
+    verbose_print("")
+    verbose_print("# %s %s" % (timestamp(), command_line_short()))
+
+
+def print_arguments(args):
+    verbose_print("Options:")
+    options = vars(args)
+    for key in sorted(options):
+        if key in ("subparser_name", "func", "excepthook"):
+            continue
+        verbose_print("    %s=%s" % (key, options[key]))
+    verbose_print("")
+
+
+# ---- error / exit protocol (exit 100 = stop the pipeline, 98 = this sample failed, continue) -----------------
+def _append_error_log(lines):
+    path = os.environ.get("errorOutputFile")
+    if path:
+        with open(path, "a") as err_log:
+            for line in lines:
+                print(line, file=err_log)
+
+
+def report_error(message):
+    if message is not None:
+        _append_error_log([message])
+    sys.stdout.flush()
+    if message:
+        print(message, file=sys.stderr)
+
+
+def global_error(message):
+    lines = ["%s failed." % program_name_with_command()]
+    if message:
+        lines.append(message)
+    lines.append("=" * 80)
+    _append_error_log(lines)
+    sys.stdout.flush()
+    if message:
+        print(message, file=sys.stderr)
+    sys.exit(100)
+
+
+def _stop_on_sample_error():
+    v = os.environ.get("StopOnSampleError")
+    return v is None or v == "true"
+
+
+def sample_error(message, continue_possible=False):
+    stop = _stop_on_sample_error()
+    first = "%s failed." % program_name_with_command() if (stop or not continue_possible) else "%s" % program_name_with_command()
+    _append_error_log([first, message, "=" * 80])
+    sys.stdout.flush()
+    print(message, file=sys.stderr)
+    if stop:
+        sys.exit(100)
+    if not continue_possible:
+        sys.exit(98)
+
+
+def _log_exception(exc_type, exc_value, exc_traceback):
+    path = os.environ.get("errorOutputFile")
+    if path:
+        entries = traceback.extract_tb(exc_traceback)
+        file_name, line_number, function_name, code_text = entries[-1] if entries else ("?", 0, "?", "")
+        _append_error_log([
+            "Error detected while running %s." % program_name_with_command(), "",
+            "The command line was:", "    %s" % command_line_short(), "",
+            "%s exception in function %s at line %d in file %s" % (exc_type.__name__, function_name, line_number, file_name),
+            "    %s" % code_text, "=" * 80])
+    sys.stdout.flush()
+    traceback.print_exception(exc_type, exc_value, exc_traceback)
+
+
+def handle_global_exception(exc_type, exc_value, exc_traceback):
+    _log_exception(exc_type, exc_value, exc_traceback)
+    sys.exit(100)
+
+
+def handle_sample_exception(exc_type, exc_value, exc_traceback):
+    _log_exception(exc_type, exc_value, exc_traceback)
+    sys.exit(100 if _stop_on_sample_error() else 98)
+
+
+def _dispatch_error(err_messages, error_handler, continue_possible):
+    if error_handler not in ("global", "sample", None):
+        raise ValueError("Invalid error_handler: %s" % repr(error_handler))
+    if err_messages:
+        text = "\n".join(err_messages)
+        if error_handler == "global":
+            global_error(text)
+        elif error_handler == "sample":
+            sample_error(text, continue_possible=continue_possible)
+        else:
+            report_error(text)
+    return len(err_messages)
+
+
+def verify_existing_input_files(error_prefix, file_list, error_handler=None, continue_possible=False):
+    bad = ["%s %s does not exist." % (error_prefix, p) for p in file_list if not os.path.isfile(p)]
+    return _dispatch_error(bad, error_handler, continue_possible)
+
+
+def verify_non_empty_input_files(error_prefix, file_list, error_handler=None, continue_possible=False, empty_ok=False):
+    bad = []
+    for p in file_list:
+        if not os.path.isfile(p):
+            bad.append("%s %s does not exist." % (error_prefix, p))
+        elif not empty_ok and os.path.getsize(p) == 0:
+            bad.append("%s %s is empty." % (error_prefix, p))
+    return _dispatch_error(bad, error_handler, continue_possible)
+
+
+def target_needs_rebuild(source_files, target_file):
+    """make-style freshness: rebuild when the target is missing/empty or any existing source is newer."""
+    if not os.path.isfile(target_file) or os.path.getsize(target_file) == 0:
+        return True
+    target_mtime = os.stat(target_file).st_mtime
+    return any(os.path.isfile(s) and os.stat(s).st_mtime > target_mtime for s in source_files)
+
+
+def sample_id_from_file(file_path):
+    return os.path.basename(os.path.dirname(os.path.abspath(file_path)))
+
+
+# ---- text codecs ------------------------------------------------------------------------------------------------
+def write_list_of_snps(file_path, keys, carrier_lists):
+    """snplist.txt: ``chrom\\tpos\\tcount\\tname...``; keys already in (chrom, pos) order."""
+    with open(file_path, "w") as f:
+        for (chrom, pos), names in zip(keys, carrier_lists):
+            f.write("%s\t%d\t%d\t%s\n" % (chrom, pos, len(names), "\t".join(names)))
+
+
+def read_snp_position_list(snp_list_file_path):
+    """[(chrom, pos)] in file order; a malformed line raises (ValueError) exactly where the reference does."""
+    snp_list = list()
+    with open(snp_list_file_path, "r") as snp_list_file_object:
+        for line in snp_list_file_object:
+            chrom, pos = line.split()[0:2]
+            snp_list.append((chrom, int(pos)))
+    return snp_list
+
+
+def read_vcf_sites(vcf_file_path):
+    """(CHROM, POS) of every data record, in file order (what the reference reads through PyVCF3's Reader in
+    utils.py:1127 and filter_regions.py:408-410), plus the raw lines.  Returns (header_lines, data_lines, sites)."""
+    header, data, sites = [], [], []
+    with open(vcf_file_path, "r") as f:
+        for line in f:
+            if line.startswith("#"):
+                header.append(line)
+                continue
+            if not line.strip():
+                continue
+            fields = line.split("\t", 2)
+            if len(fields) < 2:
+                fields = line.split(None, 2)
+            sites.append((fields[0], int(fields[1])))
+            data.append(line)
+    return header, data, sites
+
+
+def convert_vcf_file_to_snp_set(vcf_file_path):
+    return set(read_vcf_sites(vcf_file_path)[2])
+
+
+def read_fasta_lengths(path):
+    """{record id: sequence length} as Bio.SeqIO.parse yields them (id = first word of the header)."""
+    lengths = {}
+    name, n = None, 0
+    with open(path, "r") as f:
+        for line in f:
+            if line.startswith(">"):
+                if name is not None:
+                    lengths[name] = n
+                words = line[1:].split()
+                name, n = (words[0] if words else ""), 0
+            elif name is not None:
+                n += len("".join(line.split()))
+    if name is not None:
+        lengths[name] = n
+    return lengths
+
+
+def write_fasta_record(handle, record_id, sequence, width=60):
+    """Bio.SeqIO's FASTA writer layout: ``>id`` then the sequence wrapped at 60 columns."""
+    handle.write(">%s\n" % record_id)
+    for i in range(0, len(sequence), width):
+        handle.write(sequence[i:i + width] + "\n")

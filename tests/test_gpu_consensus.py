@@ -1,0 +1,243 @@
+"""HIP pileup scan + consensus caller (through the C ABI) against the golden vectors and the oracle."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import fuzz
+from oracle import pileup_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def d():
+    from tests.gpu_util import get_device
+    return get_device()
+
+
+def _names(mask, p):
+    names = po.filter_names(p)
+    return [names[i] for i in range(6) if mask >> i & 1] or None
+
+
+def test_golden_record_vectors(d, pileup_vectors):
+    """Every fuzzed line the real reference parsed: counts, ranking, consensus and filter list."""
+    from snp_pipeline_amd import _lib as L
+    from tests.gpu_util import gpu_consensus
+    recs = pileup_vectors["records"]
+    param_sets = sorted({tuple(c["params"]) for v in recs for q in v["by_q"].values() if "calls" in q for c in q["calls"]})
+    checked = 0
+    for params in param_sets:
+        p = po.CallerParams(*params)
+        q = str(params[0])
+        good = [v for v in recs if "error" not in v["by_q"][q]]
+        data = ("\n".join(v["line"] for v in good) + "\n").encode()
+        last = {}
+        for v in good:
+            w = v["by_q"][q]
+            last[(w["chrom"].encode(), w["pos"])] = w
+        keys = sorted(last)
+        _, res, ss = gpu_consensus(d, data, keys, [], p)
+        for slot, key in enumerate(ss.key_tuples()):
+            w = last[key]
+            c = res.counts[slot]
+            call = [x for x in w["calls"] if tuple(x["params"]) == params][0]
+            assert c["status"] == L.ST_OK, w
+            assert (c["raw_depth"], c["good_depth"], c["fwd_good_depth"], c["rev_good_depth"]) == (w["raw"], w["good"], w["fwd"], w["rev"]), w
+            assert chr(c["cons_base"]) == call["base"], (key, call)
+            assert _names(int(c["filters"]), p) == call["failed"], (key, call)
+            ranked = w["ranked"] or []
+            assert c["n_symbols"] == len(ranked)
+            tot, fw, rv = dict(map(tuple, w["total_hist"])), dict(map(tuple, w["fwd_hist"])), dict(map(tuple, w["rev_hist"]))
+            for r, sym in enumerate(ranked[:L.MAX_SYMS]):
+                assert chr(c["sym"][r]) == sym
+                assert (c["total"][r], c["fwd"][r], c["rev"][r]) == (tot[sym], fw.get(sym, 0), rv.get(sym, 0)), (key, sym)
+            checked += 1
+    assert checked > 15000
+
+
+def test_golden_error_lines_raise(d, pileup_vectors):
+    from snp_pipeline_amd.device import PileupFormatError
+    from tests.gpu_util import gpu_consensus
+    bad = [v for v in pileup_vectors["records"] if "error" in v["by_q"]["0"]]
+    assert bad
+    for v in bad[:40]:
+        f = po.split_fields(v["line"].encode())
+        with pytest.raises(PileupFormatError):
+            gpu_consensus(d, (v["line"] + "\n").encode(), [(f[0], int(f[1]))], [], po.CallerParams())
+
+
+def test_golden_whole_file_runs(d, pileup_vectors):
+    from tests.gpu_util import gpu_consensus
+    for run in pileup_vectors["runs"]:
+        kw = dict(run["kw"])
+        if "contigs" in kw:
+            kw["contigs"] = tuple(kw["contigs"])
+        data, _, _ = fuzz.synth_pileup(run["seed"], **kw)
+        snps = [(c.encode(), p) for c, p in run["snplist"]]
+        excl = [(c.encode(), p) for c, p in run["excluded"]]
+        cons, _, _ = gpu_consensus(d, data, snps, excl, po.CallerParams(*run["params"]))
+        assert cons.decode() == run["consensus"], run["seed"]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fuzz_lines_vs_oracle(d, seed):
+    """Fresh fuzz (not in the golden file), incl. long lines that span many 64-byte chunks."""
+    from tests.gpu_util import check_against_oracle
+    rng = random.Random(seed)
+    lines, keys = [], []
+    pos = 0
+    while len(lines) < 1500:
+        ln = fuzz.fuzz_line(rng)
+        f = po.split_fields(ln.encode())
+        try:
+            po.parse_record(f, 0)
+        except (IndexError, ValueError):
+            continue
+        pos += 1
+        f[1] = str(pos).encode()                     # unique ascending positions
+        lines.append(b"\t".join(f))
+        keys.append((f[0], pos))
+    data = b"\n".join(lines) + b"\n"
+    for p in (po.CallerParams(), po.CallerParams(15, 0.9, 5, 2, 0.1), po.CallerParams(30, 0.75, 2, 1, 0.25)):
+        check_against_oracle(d, data, keys, keys[::9], p)
+
+
+def _long_line(rng, chrom, pos, depth):
+    toks = "".join(fuzz._bases_token(rng) for _ in range(depth))
+    approx = sum(1 for c in toks if c in ".,ACGTNacgtn*#<>")
+    quals = "".join(chr(rng.randint(33, 74)) for _ in range(approx + rng.choice([0, 0, -3, 5])))
+    return ("%s\t%d\t%s\t%d\t%s\t%s" % (chrom, pos, rng.choice("ACGTn"), depth, toks, quals)).encode()
+
+
+def test_long_lines_both_paths(d):
+    """Bases fields around and beyond the LDS limit (2048 B): wave-parallel and serial device paths."""
+    from tests.gpu_util import check_against_oracle
+    rng = random.Random(99)
+    lines, keys = [], []
+    for i, depth in enumerate([60, 63, 64, 65, 127, 128, 129, 500, 900, 1100, 1300, 1500, 2500, 6000, 20000]):
+        lines.append(_long_line(rng, "deep", i + 1, depth))
+        keys.append((b"deep", i + 1))
+    data = b"\n".join(lines) + b"\n"
+    check_against_oracle(d, data, keys, [], po.CallerParams(10, 0.6, 3, 0, 0.0))
+
+
+def test_terminators_blank_and_missing_lines(d):
+    from snp_pipeline_amd.device import PileupFormatError
+    from tests.gpu_util import check_against_oracle, gpu_consensus
+    body = [b"c1\t5\tA\t3\t..,\tIII", b"c1\t6\tC\t3\tTTt\tIII", b"c2\t5\tG\t2\t.$,\tII", b"c1\t9\tT\t0\t*\t*"]
+    keys = [(b"c1", 5), (b"c1", 6), (b"c1", 7), (b"c2", 5), (b"c1", 9), (b"zz", 1)]
+    for sep, tail in ((b"\n", b"\n"), (b"\r\n", b"\r\n"), (b"\r", b"\r"), (b"\n", b""), (b"\r\n", b"")):
+        check_against_oracle(d, sep.join(body) + tail, keys, [(b"c1", 6)], po.CallerParams())
+    # duplicate position: the last line wins (call_consensus.py:171-176)
+    dup = b"c1\t5\tA\t3\tGGG\tIII\nc1\t5\tA\t3\tTTT\tIII\n"
+    cons, _, _ = gpu_consensus(d, dup, [(b"c1", 5)], [], po.CallerParams())
+    assert cons == b"T"
+    # empty pileup, empty site list
+    cons, _, _ = gpu_consensus(d, b"", keys, [], po.CallerParams())
+    assert cons == b"-" * len(keys)
+    cons, res, _ = gpu_consensus(d, body[0] + b"\n", [], [], po.CallerParams())
+    assert cons == b"" and res.n_lines == 1
+    # blank line / one-field line / non-numeric position make the reference raise ValueError (pileup.py:425-426)
+    for bad in (b"c1\t5\tA\t1\t.\tI\n\nc1\t6\tA\t1\t.\tI\n", b"c1\n", b"c1\tx5\tA\t1\t.\tI\n", b"   \n"):
+        with pytest.raises(PileupFormatError):
+            gpu_consensus(d, bad, keys, [], po.CallerParams())
+
+
+@pytest.mark.parametrize("seed,kw", [(21, dict(genome_len=6000, n_sites=150)),
+                                      (22, dict(genome_len=3000, n_sites=90, contigs=("NODE_2", "NODE_10", "NODE_1", "N"))),
+                                      (23, dict(genome_len=20000, n_sites=400, mean_depth=12))])
+def test_synthetic_files_vs_oracle(d, seed, kw):
+    from tests.gpu_util import check_against_oracle
+    data, _, sites = fuzz.synth_pileup(seed, **kw)
+    rng = random.Random(seed)
+    snps = sorted(sites + [(sites[0][0], 99_999_999), (b"absent_contig", 3)])
+    excl = rng.sample(sites, len(sites) // 5) + [(sites[0][0], 17)]
+    res = check_against_oracle(d, data, snps, excl, po.CallerParams(0, 0.6, 3, 0, 0.0))
+    assert res.n_lines == data.count(b"\n")
+    check_against_oracle(d, data, snps, [], po.CallerParams(15, 0.9, 5, 2, 0.1))
+
+
+def test_depth_sum_byproduct(d):
+    from snp_pipeline_amd import device as dev
+    data, _, sites = fuzz.synth_pileup(5, genome_len=5000, n_sites=20)
+    want = sum(int(po.split_fields(ln)[3]) for _, ln in po.iter_lines(data))
+    ss = d.siteset(sites, [1] * len(sites))
+    res = d.call_consensus(ss, data, dev.make_params(), want_depth_sum=True)
+    assert res.depth_sum == want
+
+
+def test_device_pointer_api_unaligned_and_batch(d):
+    """Device-resident pileups at odd offsets inside one buffer, batch entry point, torch stream."""
+    import torch
+    from snp_pipeline_amd import device as dev
+    from snp_pipeline_amd import _lib as L
+    d.use_torch_stream()
+    samples = [fuzz.synth_pileup(30 + i, genome_len=4000, n_sites=70)[0] for i in range(3)]
+    _, _, sites = fuzz.synth_pileup(30, genome_len=4000, n_sites=70)
+    keys = sorted(set(sites) | {(b"synth_chr1", p) for p in range(1, 4000, 37)})
+    ss = d.siteset(keys, [L.SITE_IN_SNPLIST] * len(keys))
+    offs = [3]
+    for s in samples:
+        offs.append(offs[-1] + len(s) + 5)           # odd gaps => unaligned starts
+    blob = np.full(offs[-1] + 64, ord("#"), dtype=np.uint8)
+    starts = []
+    for i, s in enumerate(samples):
+        blob[offs[i]:offs[i] + len(s)] = np.frombuffer(s, dtype=np.uint8)
+        starts.append(offs[i])
+    t = torch.from_numpy(blob).cuda()
+    n = len(ss)
+    p = po.CallerParams(0, 0.6, 3, 0, 0.0)
+    prm = dev.make_params(0, 0.6, 3, 0, 0.0)
+    for i, s in enumerate(samples):
+        bases = torch.empty(n, dtype=torch.uint8, device="cuda")
+        filt = torch.empty(n, dtype=torch.uint8, device="cuda")
+        status = torch.empty(4, dtype=torch.int64, device="cuda")
+        d.call_consensus_dev(ss, t.data_ptr() + starts[i], len(s), prm, bases.data_ptr(), filt.data_ptr(), status.data_ptr())
+        torch.cuda.synchronize()
+        want, _ = po.call_consensus_sites(s, ss.key_tuples(), set(), p)
+        assert bytes(bases.cpu().numpy()) == want
+        assert int(status[0].item()) == -1
+    # contiguous batch
+    cat = np.concatenate([np.frombuffer(s, dtype=np.uint8) for s in samples])
+    boffs = np.cumsum([0] + [len(s) for s in samples]).astype(np.uint64)
+    tc = torch.from_numpy(cat).cuda()
+    bases = torch.empty((3, n), dtype=torch.uint8, device="cuda")
+    filt = torch.empty((3, n), dtype=torch.uint8, device="cuda")
+    status = torch.empty((3, 4), dtype=torch.int64, device="cuda")
+    d.call_consensus_batch_dev(ss, tc.data_ptr(), boffs, prm, bases.data_ptr(), filt.data_ptr(), status.data_ptr())
+    torch.cuda.synchronize()
+    for i, s in enumerate(samples):
+        want, _ = po.call_consensus_sites(s, ss.key_tuples(), set(), p)
+        assert bytes(bases[i].cpu().numpy()) == want
+    d.sync()
+
+
+def test_device_generated_pileup_vs_oracle(d):
+    """The on-device generator feeds both the HIP path and the oracle (bytes copied back)."""
+    import torch
+    from snp_pipeline_amd import device as dev
+    from snp_pipeline_amd import _lib as L
+    G = 120_000
+    ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda")
+    d.use_torch_stream()
+    d.synth_reference_dev(7, G, ref.data_ptr())
+    torch.cuda.synchronize()
+    refh = ref.cpu().numpy()
+    rng = np.random.default_rng(3)
+    pos = np.sort(rng.choice(np.arange(501, G - 500), size=1500, replace=False))
+    alt = np.zeros(G + 1, dtype=np.uint8)
+    for p_ in pos:
+        alt[p_] = rng.choice([b for b in b"ACGT" if b != refh[p_]])
+    alt_d = torch.from_numpy(alt).cuda()
+    for sample in (0, 13):
+        nbytes = d.synth_pileup_dev(11, sample, G, ref.data_ptr(), alt_d.data_ptr(), 0, 0)
+        out = torch.empty(nbytes + 16, dtype=torch.uint8, device="cuda")
+        n2 = d.synth_pileup_dev(11, sample, G, ref.data_ptr(), alt_d.data_ptr(), out.data_ptr(), nbytes + 16)
+        assert n2 == nbytes
+        data = bytes(out[:nbytes].cpu().numpy())
+        assert data.count(b"\n") > 0.9 * G and 60 < nbytes / G < 120
+        keys = [(b"synth_chr1", int(p_)) for p_ in pos]
+        from tests.gpu_util import check_against_oracle
+        check_against_oracle(d, data, keys, keys[::11], po.CallerParams(0, 0.6, 3, 0, 0.0))
