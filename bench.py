@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the post-alignment hot path on MI355X, one process per GPU.
+
+A *step* is one pass of the hot path over one batch of synthetic samples already resident in HBM:
+    call_consensus (pileup scan + per-site caller) for this rank's B samples
+    -> pack the B x S consensus matrix 4 bits/site -> all-gather of packed rows over RCCL (N > 1)
+    -> all-pairs SNP distance over the (N*B) x S matrix, 128x128 tiles dealt cyclically to ranks.
+Workload = BASELINE.json configs[3] shape per GPU (5 Mbp reference, 30x pileups, 50 k SNP sites), B samples per
+rank (weak scaling: the node-level run of configs[3] is 8 ranks x 125 samples; the default B keeps the default
+run within minutes).  value = consensus bases called per second, whole job.
+
+The same JSON line carries
+  roofline      the pileup-scan kernel: algorithmic bytes (= pileup text bytes, each read once) / its average launch
+                duration measured with HIP events recorded on the launch stream inside the timed region;
+  cpu_baseline  the CPU oracle (a statement-for-statement Python port of the reference's loop structure) on the
+                first samples of the same batch, 1 core, rank 0, N=1 only;
+  secondary     pairwise SNP distances/s of the distance kernel alone at BASELINE configs[4] shape
+                (10 000 x 200 000), timed separately after the K steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--samples", type=int, default=24, help="samples per rank resident in HBM")
+    ap.add_argument("--genome", type=int, default=5_000_000)
+    ap.add_argument("--sites", type=int, default=50_000)
+    ap.add_argument("--depth", type=float, default=30.0)
+    ap.add_argument("--dist-samples", type=int, default=10_000)
+    ap.add_argument("--dist-sites", type=int, default=200_000)
+    ap.add_argument("--dist-reps", type=int, default=2)
+    ap.add_argument("--cpu-samples", type=int, default=3, help="samples timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--skip-secondary", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from snp_pipeline_amd import _lib as L
+    from snp_pipeline_amd import device as dev
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    d = dev.Device(local_rank)
+    d.use_torch_stream()
+
+    G, S, B = args.genome, args.sites, args.samples
+    # ---- synthetic inputs: reference seed 1, sites seed 2, pileups seed 3 -----------------------
+    ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda")
+    d.synth_reference_dev(1, G, ref.data_ptr())
+    torch.cuda.synchronize()
+    refh = ref.cpu().numpy()
+    rng = np.random.default_rng(2)
+    pos = np.sort(rng.choice(np.arange(501, G - 499, dtype=np.int64), size=S, replace=False))
+    n_clustered = S // 100                                   # 1 % of the sites in clusters of 4 within 100 bp
+    for c in range(0, n_clustered - 3, 4):
+        base = pos[c * 25 % (S - 4)]
+        pos[c:c + 4] = base + np.array([0, 17, 41, 83])
+    pos = np.unique(np.clip(pos, 501, G - 500))
+    S = len(pos)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    code = np.searchsorted(acgt, refh[pos])
+    alt_host = np.zeros(G + 1, dtype=np.uint8)
+    alt_host[pos] = acgt[(code + 1 + rng.integers(0, 3, size=S)) % 4]
+    alt = torch.from_numpy(alt_host).cuda()
+
+    sizes = []
+    for i in range(B):
+        sizes.append(d.synth_pileup_dev(3, rank * B + i, G, ref.data_ptr(), alt.data_ptr(), 0, 0, mean_depth=args.depth))
+    offs = np.zeros(B + 1, dtype=np.uint64)
+    for i, n in enumerate(sizes):
+        offs[i + 1] = offs[i] + ((n + 255) // 256) * 256
+    pile = torch.empty(int(offs[-1]) + 256, dtype=torch.uint8, device="cuda")
+    for i in range(B):
+        n = d.synth_pileup_dev(3, rank * B + i, G, ref.data_ptr(), alt.data_ptr(), pile.data_ptr() + int(offs[i]),
+                               sizes[i], mean_depth=args.depth)
+        assert n == sizes[i]
+    torch.cuda.synchronize()
+    pile_bytes = int(sum(sizes))
+
+    keys = [(b"synth_chr1", int(p)) for p in pos]
+    ss = d.siteset(keys, [L.SITE_IN_SNPLIST] * S)
+    prm = dev.make_params(0, 0.6, 3, 0, 0.0)                  # pipeline defaults (snppipeline.conf:249)
+
+    bases = torch.empty((B, S), dtype=torch.uint8, device="cuda")
+    filt = torch.empty((B, S), dtype=torch.uint8, device="cuda")
+    status = torch.empty((B, 4), dtype=torch.int64, device="cuda")
+    row_bytes = d.packed_row_bytes(S)
+    packed = torch.empty((B, row_bytes), dtype=torch.uint8, device="cuda")
+    packed_all = torch.empty((world * B, row_bytes), dtype=torch.uint8, device="cuda") if world > 1 else packed
+    dmat = torch.zeros((world * B, world * B), dtype=torch.int32, device="cuda")
+
+    def step():
+        # one launch pair (scan, call) per sample; sample i is bytes [offs[i], offs[i] + sizes[i])
+        for i in range(B):
+            d.call_consensus_dev(ss, pile.data_ptr() + int(offs[i]), sizes[i], prm, bases[i].data_ptr(),
+                                 filt[i].data_ptr(), status[i].data_ptr())
+        d.pack_matrix_dev(bases.data_ptr(), B, S, S, packed.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(packed_all, packed)
+        d.distance_packed_dev(packed_all.data_ptr(), world * B, S, dmat.data_ptr(), rank, world)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    d.kernel_timing(True)
+    d.kernel_time_ms(0), d.kernel_time_ms(1), d.kernel_time_ms(2)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    scan_ms, scan_n = d.kernel_time_ms(0)
+    call_ms, call_n = d.kernel_time_ms(1)
+    dist_ms, dist_n = d.kernel_time_ms(2)
+    d.kernel_timing(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    st = status.cpu().numpy()
+    if (st[:, 0] != -1).any():
+        raise SystemExit("scan reported a malformed pileup: %r" % st[:, 0])
+    if (filt.cpu().numpy() & 0x80).any():
+        raise SystemExit("caller reported a malformed line")
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * B * S / (elapsed / args.steps)
+    scan_avg_ms = scan_ms / max(scan_n, 1)
+    algo_bytes = pile_bytes / B                                # per launch: one sample's pileup text
+    achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
+
+    out = {
+        "metric": "consensus_bases_called_per_sec", "value": value, "unit": "bases/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3] shape per GPU: %d samples/GPU x %d bp x %gx pileups, %d SNP sites; "
+                               "step = scan+call per sample, 4-bit pack, all-gather, all-pairs distance"
+                               % (B, G, args.depth, S),
+                   "samples_per_gpu": B, "genome_bp": G, "mean_depth": args.depth, "snp_sites": S,
+                   "pileup_bytes_per_gpu": pile_bytes, "caller": "q0 c0.6 D3 d0 b0",
+                   "parallelism": "samples sharded, %d rank(s)" % world},
+        "genome_bp_per_sec": world * B * G / (elapsed / args.steps),
+        "pileup_gb_per_sec": world * pile_bytes / (elapsed / args.steps) / 1e9,
+        "roofline": {"kernel": "k_scan_pileup", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},
+        "kernels_ms_per_step": {"k_scan_pileup": scan_ms / args.steps, "k_call_sites": call_ms / args.steps,
+                                "k_distance": dist_ms / args.steps},
+    }
+
+    # ---- secondary metric: the distance kernel alone at configs[4] shape ------------------------------------------
+    if not args.skip_secondary:
+        n2, s2 = args.dist_samples, args.dist_sites
+        g = torch.Generator(device="cuda")
+        g.manual_seed(3)
+        lut = torch.tensor(list(b"ACGT-"), dtype=torch.uint8, device="cuda")
+        probs = torch.tensor([.24, .24, .24, .24, .04], device="cuda")
+        sym = torch.empty((n2, s2), dtype=torch.uint8, device="cuda")
+        chunk = max(1, (1 << 28) // s2)
+        for r0 in range(0, n2, chunk):
+            r1 = min(n2, r0 + chunk)
+            idx = torch.multinomial(probs, (r1 - r0) * s2, replacement=True, generator=g)
+            sym[r0:r1] = lut[idx].view(r1 - r0, s2)
+            del idx
+        pk = torch.empty((n2, d.packed_row_bytes(s2)), dtype=torch.uint8, device="cuda")
+        d.pack_matrix_dev(sym.data_ptr(), n2, s2, s2, pk.data_ptr())
+        del sym
+        dm = torch.zeros((n2, n2), dtype=torch.int32, device="cuda")
+        d.distance_packed_dev(pk.data_ptr(), n2, s2, dm.data_ptr(), rank, world)      # warm-up
+        barrier()
+        d.kernel_timing(True)
+        d.kernel_time_ms(2)
+        t1 = time.perf_counter()
+        for _ in range(args.dist_reps):
+            d.distance_packed_dev(pk.data_ptr(), n2, s2, dm.data_ptr(), rank, world)
+        barrier()
+        el2 = (time.perf_counter() - t1) / args.dist_reps
+        k_ms, k_n = d.kernel_time_ms(2)
+        d.kernel_timing(False)
+        if world > 1:
+            tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el2 = float(tt.item())
+        pairs = n2 * (n2 - 1) / 2
+        # 6 VALU lane-ops per 32 site-compares; VALU peak = 256 CU x 128 lanes x 2.4 GHz
+        valu_peak = 256 * 128 * 2.4e9
+        out["secondary"] = {
+            "metric": "pairwise_snp_distances_per_sec", "value": pairs / el2, "unit": "pairs/s",
+            "site_compares_per_sec": pairs * s2 / el2, "seconds": el2,
+            "config": {"workload": "BASELINE configs[4] shape: %d samples x %d sites, random ACGT- matrix" % (n2, s2)},
+            "kernel_ms": k_ms / max(k_n, 1),
+            "valu_frac_of_peak": (pairs * s2 / 32 * 6 / el2) / valu_peak,
+        }
+        del pk, dm
+
+    # ---- CPU baseline: the oracle on the first samples of the batch, one core, rank 0, N = 1 ---------------------
+    if rank == 0 and world == 1 and args.cpu_samples > 0:
+        from oracle import pileup_oracle as po
+        ncpu = min(args.cpu_samples, B)
+        snps = [(b"synth_chr1", int(p)) for p in pos]
+        p = po.CallerParams(0, 0.6, 3, 0, 0.0)
+        gpu_rows = bases[:ncpu].cpu().numpy()
+        t_cpu = 0.0
+        ok = True
+        for i in range(ncpu):
+            data = bytes(pile[int(offs[i]):int(offs[i]) + sizes[i]].cpu().numpy())
+            t1 = time.perf_counter()
+            cons, _ = po.call_consensus_sites(data, snps, set(), p)
+            t_cpu += time.perf_counter() - t1
+            ok = ok and (cons == bytes(gpu_rows[i]))
+        out["cpu_baseline"] = {
+            "value": ncpu * S / t_cpu, "unit": "bases/s", "cores": 1, "kind": "port",
+            "sample": "%d of the same synthetic samples (%d bp x %gx, %d sites each), call_consensus path only, "
+                      "pure-Python oracle" % (ncpu, G, args.depth, S),
+            "seconds": t_cpu, "genome_bp_per_sec": ncpu * G / t_cpu, "matches_gpu": bool(ok),
+        }
+        if not ok:
+            raise SystemExit("GPU consensus differs from the CPU oracle")
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -103,12 +103,20 @@ int  snpgpu_abi_version(void);
 int  snpgpu_ctx_create(int device, snpgpu_ctx **out);
 void snpgpu_ctx_destroy(snpgpu_ctx *ctx);
 const char *snpgpu_last_error(const snpgpu_ctx *ctx);
-/* Run on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the context's own. */
+/* Run on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL is HIP's default stream.
+ * snpgpu_ctx_reset_stream goes back to the context's own non-blocking stream. */
 int  snpgpu_ctx_set_stream(snpgpu_ctx *ctx, void *hip_stream);
+int  snpgpu_ctx_reset_stream(snpgpu_ctx *ctx);
 int  snpgpu_ctx_sync(snpgpu_ctx *ctx);
 /* Kernel-only elapsed time helpers (HIP events recorded on the context's stream). */
 int  snpgpu_timer_start(snpgpu_ctx *ctx);
 int  snpgpu_timer_stop_ms(snpgpu_ctx *ctx, float *out_ms);   /* synchronises on the stop event */
+
+/* Per-kernel timing for bench.py: when enabled, HIP events are recorded on the stream around every launch of
+ * the scan (0), per-site caller (1) and distance (2) kernels; snpgpu_ctx_kernel_time_ms synchronises, returns the
+ * summed elapsed time and the number of launches of that kernel since the last query, and clears them. */
+int  snpgpu_ctx_kernel_timing(snpgpu_ctx *ctx, int enable);
+int  snpgpu_ctx_kernel_time_ms(snpgpu_ctx *ctx, int kernel, float *total_ms, uint32_t *launches);
 
 /* ---- site set: the (chrom,pos) set handed to pileup.Reader (pileup.py:396-403) ----
  * contig_names: concatenated names, contig_name_off[n_contigs+1]; names must be sorted bytewise and unique.

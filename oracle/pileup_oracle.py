@@ -38,6 +38,15 @@ def iter_lines(data):
     newlines: ``\\n``, ``\\r\\n`` and a lone ``\\r`` all end a line), without the
     terminator."""
     n = len(data)
+    if b"\r" not in data:                     # common case: plain '\n' files
+        start = 0
+        while start < n:
+            end = data.find(b"\n", start)
+            if end < 0:
+                end = n
+            yield start, data[start:end]
+            start = end + 1
+        return
     start = 0
     i = 0
     while i < n:
@@ -220,8 +229,10 @@ def scan_sites(data, wanted, min_base_quality):
     """pileup.py:423-429: yield a Record for every line whose (chrom,pos) is in
     ``wanted`` (a set of (bytes,int)); every line must split into >= 2 fields
     with an integer second field, as in the reference."""
+    # bytes.split() knows the ASCII separators except FS/GS/RS/US; fall back to the explicit splitter for those
+    exotic = any(c in data for c in (b"\x1c", b"\x1d", b"\x1e", b"\x1f"))
     for _, line in iter_lines(data):
-        f = split_fields(line)
+        f = split_fields(line) if exotic else line.split()
         chrom, pos = f[:2]                 # ValueError on short lines, like the reference
         if (chrom, int(pos)) in wanted:
             yield parse_record(f, min_base_quality)

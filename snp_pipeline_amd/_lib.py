@@ -45,9 +45,12 @@ SIGNATURES = {
     "snpgpu_ctx_destroy": (None, [_P]),
     "snpgpu_last_error": (C.c_char_p, [_P]),
     "snpgpu_ctx_set_stream": (C.c_int, [_P, _P]),
+    "snpgpu_ctx_reset_stream": (C.c_int, [_P]),
     "snpgpu_ctx_sync": (C.c_int, [_P]),
     "snpgpu_timer_start": (C.c_int, [_P]),
     "snpgpu_timer_stop_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "snpgpu_ctx_kernel_timing": (C.c_int, [_P, C.c_int]),
+    "snpgpu_ctx_kernel_time_ms": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "snpgpu_siteset_create": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, C.c_uint32, C.POINTER(_P)]),
     "snpgpu_siteset_destroy": (None, [_P]),
     "snpgpu_siteset_size": (C.c_uint32, [_P]),

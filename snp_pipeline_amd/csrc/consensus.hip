@@ -560,7 +560,9 @@ static int enqueue_sample(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8
         sa.want_depth = want_depth;
         uint64_t max_blocks = (uint64_t)ctx->n_cu * 8;
         unsigned grid = (unsigned)(sa.n_tiles < max_blocks ? sa.n_tiles : max_blocks);
+        hipEvent_t ta = snpgpu_time_begin(ctx);
         k_scan_pileup<<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
+        snpgpu_time_end(ctx, SNPGPU_K_SCAN, ta);
     }
     if (n_sites) {
         CallArgs ca;
@@ -575,7 +577,9 @@ static int enqueue_sample(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8
         ca.out_counts = d_out_counts;
         uint32_t blocks = (n_sites + CALL_WAVES - 1) / CALL_WAVES;
         uint32_t max_blocks = (uint32_t)ctx->n_cu * 16;
+        hipEvent_t ta = snpgpu_time_begin(ctx);
         k_call_sites<<<blocks < max_blocks ? blocks : max_blocks, CALL_WAVES * 64, 0, st>>>(ca);
+        snpgpu_time_end(ctx, SNPGPU_K_CALL, ta);
     }
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;

@@ -35,7 +35,53 @@ int snpgpu_scratch(snpgpu_ctx *ctx, size_t bytes, void **out) {
     return SNPGPU_OK;
 }
 
+static hipEvent_t take_event(snpgpu_ctx *ctx) {
+    if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+hipEvent_t snpgpu_time_begin(snpgpu_ctx *ctx) {
+    if (!ctx->time_kernels) return nullptr;
+    hipEvent_t a = take_event(ctx);
+    (void)hipEventRecord(a, ctx->stream);
+    return a;
+}
+
+void snpgpu_time_end(snpgpu_ctx *ctx, int kernel, hipEvent_t a) {
+    if (!a) return;
+    hipEvent_t b = take_event(ctx);
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->timed.push_back({kernel, a, b});
+}
+
 extern "C" {
+
+int snpgpu_ctx_kernel_timing(snpgpu_ctx *ctx, int enable) {
+    if (!ctx) return SNPGPU_E_ARG;
+    ctx->time_kernels = enable != 0;
+    return SNPGPU_OK;
+}
+
+int snpgpu_ctx_kernel_time_ms(snpgpu_ctx *ctx, int kernel, float *total_ms, uint32_t *launches) {
+    if (!ctx || !total_ms || !launches) return SNPGPU_E_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float sum = 0;
+    uint32_t n = 0;
+    std::vector<snpgpu_ctx::Timed> keep;
+    for (auto &t : ctx->timed) {
+        if (t.kernel != kernel) { keep.push_back(t); continue; }
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { sum += ms; ++n; }
+        ctx->event_pool.push_back(t.a);
+        ctx->event_pool.push_back(t.b);
+    }
+    ctx->timed.swap(keep);
+    *total_ms = sum;
+    *launches = n;
+    return SNPGPU_OK;
+}
 
 int snpgpu_abi_version(void) { return SNPGPU_ABI_VERSION; }
 
@@ -65,6 +111,8 @@ void snpgpu_ctx_destroy(snpgpu_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) hipFree(ctx->scratch);
+    for (auto &t : ctx->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    for (auto e : ctx->event_pool) hipEventDestroy(e);
     if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
@@ -76,7 +124,14 @@ const char *snpgpu_last_error(const snpgpu_ctx *ctx) { return ctx ? ctx->err.c_s
 int snpgpu_ctx_set_stream(snpgpu_ctx *ctx, void *hip_stream) {
     if (!ctx) return SNPGPU_E_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;      // NULL is HIP's legacy default stream (what torch uses by default)
+    return SNPGPU_OK;
+}
+
+int snpgpu_ctx_reset_stream(snpgpu_ctx *ctx) {
+    if (!ctx) return SNPGPU_E_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = ctx->own_stream;
     return SNPGPU_OK;
 }
 

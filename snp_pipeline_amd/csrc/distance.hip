@@ -163,7 +163,9 @@ int snpgpu_distance_packed_dev(snpgpu_ctx *ctx, const void *d_packed, uint32_t n
     uint64_t mine = a.total_tiles > tile_rank ? (a.total_tiles - tile_rank + tile_nranks - 1) / tile_nranks : 0;
     if (mine == 0) return SNPGPU_OK;
     uint64_t cap = (uint64_t)ctx->n_cu * 64;
+    hipEvent_t ta = snpgpu_time_begin(ctx);
     k_distance<<<(unsigned)(mine < cap ? mine : cap), DIST_THREADS, 0, ctx->stream>>>(a);
+    snpgpu_time_end(ctx, SNPGPU_K_DISTANCE, ta);
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;
 }

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/snpgpu.h"
 
@@ -18,7 +19,19 @@ struct snpgpu_ctx {
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     int n_cu = 256;
+    // optional per-kernel timing (bench): event pairs recorded around selected launches
+    bool time_kernels = false;
+    struct Timed { int kernel; hipEvent_t a, b; };
+    std::vector<Timed> timed;
+    std::vector<hipEvent_t> event_pool;
 };
+
+#define SNPGPU_K_SCAN 0
+#define SNPGPU_K_CALL 1
+#define SNPGPU_K_DISTANCE 2
+// RAII-less helpers: call begin before the launch and end right after it (no-ops unless timing is enabled)
+hipEvent_t snpgpu_time_begin(snpgpu_ctx *ctx);
+void snpgpu_time_end(snpgpu_ctx *ctx, int kernel, hipEvent_t a);
 
 // Device-side view of a site set.
 struct SiteSetDev {

@@ -133,6 +133,15 @@ class Device(object):
     def sync(self):
         self._check(self.lib.snpgpu_ctx_sync(self.ctx))
 
+    def kernel_timing(self, enable):
+        self._check(self.lib.snpgpu_ctx_kernel_timing(self.ctx, 1 if enable else 0))
+
+    def kernel_time_ms(self, kernel):
+        """(total ms, launches) of kernel 0=scan 1=call 2=distance since the last query."""
+        ms, n = C.c_float(), C.c_uint32()
+        self._check(self.lib.snpgpu_ctx_kernel_time_ms(self.ctx, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def timer_start(self):
         self._check(self.lib.snpgpu_timer_start(self.ctx))
 
