@@ -1,4 +1,4 @@
-// K1 pileup scan (line index + site match) and K2 per-site wavefront consensus caller.
+// K2 per-site wavefront consensus caller, and the call_consensus entry points (K1, the scan, is scan.hip).
 //
 // Replaces, for one sample:
 //   pileup.Reader.__iter__            snppipeline/pileup.py:408-429   -> k_scan_pileup
@@ -15,215 +15,12 @@
 // (scalar ALU work on gfx950: one ballot == one SGPR pair).
 #include "internal.h"
 
-// ------------------------------------------------------------------------------------------------
-//                                           K1: scan
-// ------------------------------------------------------------------------------------------------
-#define SCAN_THREADS 256
-#define SCAN_TILE 16384                      // bytes per tile
-#define SCAN_HALO 256                        // bytes staged past the tile for the fields of its last lines
-#define SCAN_MAXL (SCAN_TILE / 4)            // a valid line has >= 4 bytes ("a 1\n")
-#define SCAN_CHUNKS (SCAN_TILE / 16)         // 16-byte chunks per tile
-#define SCAN_CPT (SCAN_CHUNKS / SCAN_THREADS)
+int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *d_pileup, size_t nbytes,
+                        uint64_t *d_status, int want_depth);      // scan.hip
 
 #define SCAN_ERR_FEW_FIELDS 1
 #define SCAN_ERR_BAD_POS 2
 #define SCAN_ERR_NON_ASCII 3
-
-struct ScanArgs {
-    const uint8_t *base;     // 16-byte aligned pointer at or below the first byte of the file
-    uint64_t lo, hi;         // the file is base[lo, hi)
-    uint64_t n_tiles;
-    uint64_t *site_line;     // n_sites
-    uint64_t *status;        // SNPGPU_SCAN_STATUS_WORDS
-    int want_depth;
-};
-
-__device__ __forceinline__ uint32_t swar_eq_mask(uint32_t w, uint32_t pat) {
-    uint32_t x = w ^ pat;                                   // zero byte <=> match
-    uint32_t y = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;     // bit 7 of each byte set <=> byte non-zero
-    return ~y & 0x80808080u;                                // exact per byte
-}
-
-__device__ __forceinline__ void report_scan_error(uint64_t *status, uint64_t file_off, uint32_t code) {
-    atomicMin((unsigned long long *)&status[0], (unsigned long long)(((file_off + 1) << 8) | code));
-}
-
-// Bytewise lexicographic compare of a line field (read through getb) with contig name c.
-template <typename GetB>
-__device__ int cmp_name(const SiteSetDev &ss, uint32_t c, int64_t p0, uint32_t len, GetB getb) {
-    uint32_t a = ss.name_off[c], nl = ss.name_off[c + 1] - a;
-    uint32_t m = len < nl ? len : nl;
-    for (uint32_t k = 0; k < m; ++k) {
-        int d = (int)getb(p0 + k) - (int)ss.names[a + k];
-        if (d) return d;
-    }
-    return (int)len - (int)nl;
-}
-
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_pileup(ScanArgs a, SiteSetDev ss) {
-    __shared__ uint4 tile4[(16 + SCAN_TILE + SCAN_HALO) / 16];
-    __shared__ uint16_t lstart[SCAN_MAXL];
-    __shared__ uint32_t n_lines_sh;
-    __shared__ uint32_t hint_sh;
-    __shared__ unsigned long long depth_sh;
-    uint8_t *tile = (uint8_t *)tile4 + 16;                  // tile[-16 .. SCAN_TILE+SCAN_HALO)
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) hint_sh = 0;
-
-    for (uint64_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
-        const uint64_t t0 = t * SCAN_TILE;                  // offset of the tile relative to a.base
-        if (tid == 0) { n_lines_sh = 0; depth_sh = 0; }
-        // ---- stage [t0-16, t0+TILE+HALO) into LDS; bytes outside [lo,hi) read as '\n' ----------
-        uint4 regs[SCAN_CPT];
-        uint32_t hi_bits = 0;
-        auto load_chunk = [&](int64_t rel) -> uint4 {       // rel: chunk offset relative to t0 (multiple of 16)
-            int64_t ab = (int64_t)t0 + rel;
-            uint4 v = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
-            if (ab + 16 <= (int64_t)a.lo || ab >= (int64_t)a.hi || ab < 0) return v;
-            v = *(const uint4 *)(a.base + ab);
-            if (ab < (int64_t)a.lo || ab + 16 > (int64_t)a.hi) {     // edge chunk: blank the outside bytes
-                uint8_t *pb = (uint8_t *)&v;
-                for (int j = 0; j < 16; ++j)
-                    if (ab + j < (int64_t)a.lo || ab + j >= (int64_t)a.hi) pb[j] = 10;
-            }
-            return v;
-        };
-#pragma unroll
-        for (int i = 0; i < SCAN_CPT; ++i) {
-            uint32_t c = i * SCAN_THREADS + tid;
-            regs[i] = load_chunk((int64_t)c * 16);
-            hi_bits |= (regs[i].x | regs[i].y | regs[i].z | regs[i].w);
-            tile4[1 + c] = regs[i];
-        }
-        if (tid < SCAN_HALO / 16) tile4[1 + SCAN_CHUNKS + tid] = load_chunk((int64_t)SCAN_TILE + tid * 16);
-        if (tid == SCAN_THREADS - 1) tile4[0] = load_chunk(-16);
-        if (hi_bits & 0x80808080u) report_scan_error(a.status, t0 > a.lo ? t0 - a.lo : 0, SCAN_ERR_NON_ASCII);
-        __syncthreads();
-
-        // ---- line starts: s is a start iff byte s-1 ends a terminator ('\n', or '\r' not followed by '\n') ----
-#pragma unroll
-        for (int i = 0; i < SCAN_CPT; ++i) {
-            uint32_t c = i * SCAN_THREADS + tid;
-            int32_t cb = (int32_t)c * 16;                   // chunk offset in the tile
-            uint32_t w[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
-            uint32_t prev = tile[cb - 1];
-            uint32_t cr_any = (prev == 13u);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) cr_any |= swar_eq_mask(w[k], 0x0D0D0D0Du);
-            if (!cr_any) {
-                // fast path: starts are the bytes right after a '\n' in [cb-1, cb+15)
-                if (prev == 10u) {
-                    uint64_t s_abs = t0 + cb;
-                    if (s_abs >= a.lo && s_abs < a.hi) {
-                        uint32_t idx = atomicAdd(&n_lines_sh, 1u);
-                        if (idx < SCAN_MAXL) lstart[idx] = (uint16_t)cb;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    uint32_t z = swar_eq_mask(w[k], 0x0A0A0A0Au);
-                    while (z) {
-                        int byte = (__ffs(z) - 1) >> 3;
-                        z &= z - 1;
-                        int s = cb + k * 4 + byte + 1;
-                        if (s >= cb + 16) break;            // belongs to the next chunk (seen there as prev)
-                        uint64_t s_abs = t0 + s;
-                        if (s_abs >= a.lo && s_abs < a.hi) {
-                            uint32_t idx = atomicAdd(&n_lines_sh, 1u);
-                            if (idx < SCAN_MAXL) lstart[idx] = (uint16_t)s;
-                        }
-                    }
-                }
-            } else {
-                for (int j = 0; j < 16; ++j) {              // rare: '\r' present, byte loop on the LDS copy
-                    int s = cb + j;
-                    uint32_t pv = tile[s - 1], cv = tile[s];
-                    bool st = (pv == 10u) || (pv == 13u && cv != 10u);
-                    uint64_t s_abs = t0 + s;
-                    if (st && s_abs >= a.lo && s_abs < a.hi) {
-                        uint32_t idx = atomicAdd(&n_lines_sh, 1u);
-                        if (idx < SCAN_MAXL) lstart[idx] = (uint16_t)s;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        uint32_t n_lines = n_lines_sh;
-        if (n_lines > SCAN_MAXL) {                          // only possible with lines shorter than 4 bytes
-            if (tid == 0) report_scan_error(a.status, t0 > a.lo ? t0 - a.lo : 0, SCAN_ERR_FEW_FIELDS);
-            n_lines = SCAN_MAXL;
-        }
-
-        // ---- parse "chrom pos" of every line that starts in this tile --------------------------
-        auto getb = [&](int64_t p) -> uint32_t {            // p relative to t0
-            if (p < SCAN_TILE + SCAN_HALO) return tile[p];
-            uint64_t ab = t0 + (uint64_t)p;
-            return ab < a.hi ? a.base[ab] : 10u;
-        };
-        uint32_t hits = 0;
-        unsigned long long depth_acc = 0;
-        for (uint32_t j = tid; j < n_lines; j += SCAN_THREADS) {
-            int64_t s = lstart[j];
-            const uint64_t file_off = t0 + (uint64_t)s - a.lo;
-            int64_t p = s;
-            uint32_t c = getb(p);
-            while (is_ws(c) && !is_term(c)) c = getb(++p);
-            if (is_term(c)) { report_scan_error(a.status, file_off, SCAN_ERR_FEW_FIELDS); continue; }
-            int64_t f0 = p;
-            while (!is_ws(c)) c = getb(++p);
-            uint32_t f0len = (uint32_t)(p - f0);
-            while (is_ws(c) && !is_term(c)) c = getb(++p);
-            if (is_term(c)) { report_scan_error(a.status, file_off, SCAN_ERR_FEW_FIELDS); continue; }
-            uint64_t pos = 0;
-            bool ok = true;
-            while (!is_ws(c)) {
-                if (is_digit(c)) { pos = pos * 10 + (c - 48u); if (pos > 0xFFFFFFFFull) pos = 0x100000000ull; }
-                else ok = false;
-                c = getb(++p);
-            }
-            if (!ok) { report_scan_error(a.status, file_off, SCAN_ERR_BAD_POS); continue; }
-            if (a.want_depth) {                             // 4th column, collect_metrics.py:325-340 by-product
-                while (is_ws(c) && !is_term(c)) c = getb(++p);
-                while (!is_ws(c)) c = getb(++p);            // reference base field
-                while (is_ws(c) && !is_term(c)) c = getb(++p);
-                unsigned long long d = 0;
-                bool dok = !is_ws(c);
-                while (!is_ws(c)) { if (is_digit(c)) d = d * 10 + (c - 48u); else dok = false; c = getb(++p); }
-                if (dok) depth_acc += d;
-            }
-            if (ss.n_contigs == 0 || pos > 0xFFFFFFFFull) continue;
-            // contig lookup: last hit first, then binary search over the sorted name table
-            uint32_t cid = hint_sh;
-            if (cid >= ss.n_contigs || cmp_name(ss, cid, f0, f0len, getb) != 0) {
-                int lo_i = 0, hi_i = (int)ss.n_contigs - 1;
-                cid = 0xFFFFFFFFu;
-                while (lo_i <= hi_i) {
-                    int mid = (lo_i + hi_i) >> 1;
-                    int d = cmp_name(ss, (uint32_t)mid, f0, f0len, getb);
-                    if (d == 0) { cid = (uint32_t)mid; break; }
-                    if (d < 0) hi_i = mid - 1; else lo_i = mid + 1;
-                }
-                if (cid == 0xFFFFFFFFu) continue;
-                hint_sh = cid;                              // benign race: only a hint
-            }
-            if ((uint32_t)pos > ss.max_pos[cid]) continue;
-            uint64_t bit = ss.bit_off[cid] + (uint32_t)pos;
-            uint32_t word = ss.bitmap[bit >> 5];
-            uint32_t sh = (uint32_t)(bit & 31);
-            if (!((word >> sh) & 1u)) continue;
-            uint32_t site = ss.rank[bit >> 5] + __popc(word & ((1u << sh) - 1u));
-            atomicMax((unsigned long long *)&a.site_line[site], (unsigned long long)(file_off + 1));
-            ++hits;
-        }
-        if (hits) atomicAdd((unsigned long long *)&a.status[2], (unsigned long long)hits);
-        if (a.want_depth && depth_acc) atomicAdd(&depth_sh, depth_acc);
-        __syncthreads();
-        if (tid == 0) {
-            atomicAdd((unsigned long long *)&a.status[1], (unsigned long long)n_lines);
-            if (a.want_depth && depth_sh) atomicAdd((unsigned long long *)&a.status[3], depth_sh);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 //                                   K2: one wavefront per site
@@ -545,24 +342,10 @@ static int enqueue_sample(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8
                           snpgpu_site_counts *d_out_counts, uint64_t *d_status, int want_depth) {
     hipStream_t st = ctx->stream;
     const uint32_t n_sites = ss->n_sites;
-    static const uint64_t status_init[SNPGPU_SCAN_STATUS_WORDS] = {~0ull, 0, 0, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(d_status, status_init, sizeof status_init, hipMemcpyHostToDevice, st));
     if (n_sites) HIP_TRY(ctx, hipMemsetAsync(ss->site_line, 0, 8ull * n_sites, st));
-    if (nbytes) {
-        ScanArgs sa;
-        uintptr_t addr = (uintptr_t)d_pileup;
-        sa.base = (const uint8_t *)(addr & ~(uintptr_t)15);
-        sa.lo = addr & 15;
-        sa.hi = sa.lo + nbytes;
-        sa.n_tiles = (sa.hi + SCAN_TILE - 1) / SCAN_TILE;
-        sa.site_line = ss->site_line;
-        sa.status = d_status;
-        sa.want_depth = want_depth;
-        uint64_t max_blocks = (uint64_t)ctx->n_cu * 8;
-        unsigned grid = (unsigned)(sa.n_tiles < max_blocks ? sa.n_tiles : max_blocks);
-        hipEvent_t ta = snpgpu_time_begin(ctx);
-        k_scan_pileup<<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
-        snpgpu_time_end(ctx, SNPGPU_K_SCAN, ta);
+    {
+        int rc = snpgpu_enqueue_scan(ctx, ss, d_pileup, nbytes, d_status, want_depth);
+        if (rc) return rc;
     }
     if (n_sites) {
         CallArgs ca;

@@ -220,7 +220,9 @@ int snpgpu_siteset_create(snpgpu_ctx *ctx, const uint8_t *contig_names, const ui
     size_t o_flag = align_up(o_rank + 4 * n_words, 256);
     size_t o_line = align_up(o_flag + (n_sites ? n_sites : 1), 256);
     size_t o_keys = align_up(o_line + 8ull * (n_sites ? n_sites : 1), 256);
-    size_t total = o_keys + 8ull * (n_sites ? n_sites : 1);
+    size_t o_queue = align_up(o_keys + 8ull * (n_sites ? n_sites : 1), 256);
+    size_t o_ctl = o_queue + 8ull * SNPGPU_SLOW_QUEUE_CAP;
+    size_t total = o_ctl + 256;
 
     snpgpu_siteset *ss = new snpgpu_siteset();
     ss->ctx = ctx;
@@ -274,9 +276,12 @@ int snpgpu_siteset_create(snpgpu_ctx *ctx, const uint8_t *contig_names, const ui
     ss->dev.bitmap = (const uint32_t *)(b + o_bmap);
     ss->dev.rank = (const uint32_t *)(b + o_rank);
     ss->dev.flags = (const uint8_t *)(b + o_flag);
+    ss->dev.n_words = n_words;
     ss->dev.n_contigs = n_contigs;
     ss->dev.n_sites = n_sites;
     ss->site_line = (uint64_t *)(b + o_line);
+    ss->slow_queue = (uint64_t *)(b + o_queue);
+    ss->slow_ctl = (uint32_t *)(b + o_ctl);
     *out = ss;
     return SNPGPU_OK;
 }

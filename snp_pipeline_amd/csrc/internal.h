@@ -26,6 +26,7 @@ struct snpgpu_ctx {
     std::vector<hipEvent_t> event_pool;
 };
 
+#define SNPGPU_SLOW_QUEUE_CAP (1u << 20)
 #define SNPGPU_K_SCAN 0
 #define SNPGPU_K_CALL 1
 #define SNPGPU_K_DISTANCE 2
@@ -42,6 +43,7 @@ struct SiteSetDev {
     const uint32_t *bitmap;     // one bit per (contig, pos <= max_pos)
     const uint32_t *rank;       // per bitmap word: number of set bits in earlier words == index into keys
     const uint8_t *flags;       // n_sites
+    uint64_t n_words;           // dwords in bitmap / rank
     uint32_t n_contigs;
     uint32_t n_sites;
 };
@@ -52,6 +54,8 @@ struct snpgpu_siteset {
     void *blob = nullptr;       // one allocation backing every device array
     uint64_t total_bits = 0;
     uint64_t *site_line = nullptr;   // n_sites scratch: (offset+1) of the last matching line
+    uint64_t *slow_queue = nullptr;  // SNPGPU_SLOW_QUEUE_CAP file offsets of lines the fast scan path left over
+    uint32_t *slow_ctl = nullptr;    // [0] queue length, [1] overflow flag
     uint32_t n_sites = 0;
 };
 

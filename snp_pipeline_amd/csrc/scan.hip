@@ -1,0 +1,584 @@
+// K1: pileup scan — newline index, "chrom pos" parse of every line, site match.
+//
+// Replaces pileup.Reader.__iter__ with a position set (snppipeline/pileup.py:422-429): for every line of the
+// genome-wide pileup, split on whitespace, take (chrom, int(pos)) and test membership in the site set.  A matching
+// line publishes (file offset + 1) with atomicMax into site_line[site]; the maximum implements "the last duplicate
+// line wins" (call_consensus.py:171-176).
+//
+// HBM-bound by design: every byte is fetched once, 16 bytes per lane, straight into LDS (global_load_lds_dwordx4,
+// no VGPR round trip), double buffered so the next tile streams in while the current one is parsed.  The unit of
+// work is ONE WAVEFRONT and one 4 KiB tile: there is no workgroup barrier anywhere, the 16 waves of a CU run as
+// independent streams and hide each other's LDS / L2 latency.  Per tile:
+//   A  wait for the tile's LDS-DMA, issue the DMA of the wave's next tile
+//   B  each lane scans four 16-byte chunks for '\n' (SWAR + v_dot4_u32_u8 gathers the byte flags into bits);
+//      a DPP prefix sum over the wave turns the per-lane counts into a list of line starts in LDS
+//   C  one lane per line: compare the first L bytes with the wave's current contig name (dword compares, L and the
+//      name are wave-uniform), find the end of the position field with a SWAR "byte <= 0x20" mask, convert the
+//      digits with SWAR multiplies, probe the site bitmap (L2 resident).  Anything unusual — other contig, odd
+//      whitespace, '\r', long names, > 10 digits — takes an exact byte-wise parser.
+#include <stdlib.h>
+
+#include "internal.h"
+
+#define SCAN_WAVES 4                         // consumer waves per workgroup (one 4 KiB sub-tile each)
+#define SCAN_THREADS ((SCAN_WAVES + 1) * 64) // + one loader wave
+#define SCAN_TILE 4096                       // bytes per consumer wave
+#define SCAN_BTILE (SCAN_WAVES * SCAN_TILE)  // bytes per workgroup tile
+#define SCAN_HALO 128                        // bytes staged past the tile for the first fields of its last lines
+#define SCAN_STAGE_CHUNKS ((16 + SCAN_BTILE + SCAN_HALO) / 16)  // [x0-16, x0+BTILE+HALO) in 16-byte chunks
+#define SCAN_STAGE_ROUNDS ((SCAN_STAGE_CHUNKS + 63) / 64)
+#define SCAN_LIST_CAP 192                    // line starts held in LDS per pass (a tile with more makes extra passes)
+#define SCAN_HINT_WORDS 12                   // contig names up to 44 bytes take the fast compare
+
+#define SCAN_ERR_FEW_FIELDS 1
+#define SCAN_ERR_BAD_POS 2
+#define SCAN_ERR_NON_ASCII 3
+
+struct ScanArgs {
+    const uint8_t *base;     // 16-byte aligned pointer at or below the first byte of the file
+    uint64_t lo, hi;         // the file is base[lo, hi)
+    uint64_t n_btiles;
+    uint64_t *site_line;     // n_sites
+    uint64_t *status;        // SNPGPU_SCAN_STATUS_WORDS
+    uint64_t *queue;         // file offsets of lines left to the exact parser
+    uint32_t *ctl;           // [0] queue length, [1] queue overflowed
+    uint32_t q_cap;
+    int want_depth;
+    unsigned long long *dbg; // optional: per-phase cycle totals (tuning builds only)
+};
+
+struct BlockShared {
+    uint4 tile4[2][SCAN_STAGE_CHUNKS];       // double buffer, filled by the loader wave
+    uint16_t lstart[SCAN_WAVES][SCAN_LIST_CAP];
+    uint32_t hint_w[SCAN_WAVES][SCAN_HINT_WORDS];   // each consumer wave's current contig name, zero padded
+};
+
+__device__ __forceinline__ void report_scan_error(uint64_t *status, uint64_t file_off, uint32_t code) {
+    atomicMin((unsigned long long *)&status[0], (unsigned long long)(((file_off + 1) << 8) | code));
+}
+
+struct TileView {
+    const uint8_t *tile;     // LDS copy, valid for [-16, lds_limit)
+    const uint8_t *base;     // global
+    uint64_t t0, hi;
+    int64_t lds_limit;
+    __device__ __forceinline__ uint32_t get(int64_t p) const {
+        if (p < lds_limit) return tile[p];
+        uint64_t ab = t0 + (uint64_t)p;
+        return ab < hi ? base[ab] : 10u;
+    }
+};
+
+// Bytewise lexicographic compare of a line field with contig name c.
+__device__ int cmp_name(const SiteSetDev &ss, uint32_t c, const TileView &tv, int64_t p0, uint32_t len) {
+    uint32_t a = ss.name_off[c], nl = ss.name_off[c + 1] - a;
+    uint32_t m = len < nl ? len : nl;
+    for (uint32_t k = 0; k < m; ++k) {
+        int d = (int)tv.get(p0 + k) - (int)ss.names[a + k];
+        if (d) return d;
+    }
+    return (int)len - (int)nl;
+}
+
+__device__ __noinline__ uint32_t find_contig(const SiteSetDev &ss, TileView tv, int64_t f0, uint32_t f0len) {
+    int lo_i = 0, hi_i = (int)ss.n_contigs - 1;
+    while (lo_i <= hi_i) {
+        int mid = (lo_i + hi_i) >> 1;
+        int d = cmp_name(ss, (uint32_t)mid, tv, f0, f0len);
+        if (d == 0) return (uint32_t)mid;
+        if (d < 0) hi_i = mid - 1; else lo_i = mid + 1;
+    }
+    return 0xFFFFFFFFu;
+}
+
+// Exact byte-wise parse of "chrom pos [ref depth]" (any whitespace, any length).
+struct SlowLine {
+    uint32_t err;            // 0 or SCAN_ERR_*
+    uint32_t f0len;
+    int64_t f0;
+    uint64_t pos;
+    unsigned long long depth;
+};
+__device__ __noinline__ SlowLine parse_line_slow(TileView tv, int64_t s, int want_depth) {
+    SlowLine r;
+    r.err = 0; r.f0len = 0; r.f0 = s; r.pos = 0; r.depth = 0;
+    int64_t p = s;
+    uint32_t c = tv.get(p);
+    while (is_ws(c) && !is_term(c)) c = tv.get(++p);
+    if (is_term(c)) { r.err = SCAN_ERR_FEW_FIELDS; return r; }
+    const int64_t f0 = p;
+    while (!is_ws(c)) c = tv.get(++p);
+    const uint32_t f0len = (uint32_t)(p - f0);
+    while (is_ws(c) && !is_term(c)) c = tv.get(++p);
+    if (is_term(c)) { r.err = SCAN_ERR_FEW_FIELDS; return r; }
+    uint64_t pos = 0;
+    bool ok = true;
+    while (!is_ws(c)) {
+        if (is_digit(c)) { pos = pos * 10 + (c - 48u); if (pos > 0xFFFFFFFFull) pos = 0x100000000ull; }
+        else ok = false;
+        c = tv.get(++p);
+    }
+    if (!ok) { r.err = SCAN_ERR_BAD_POS; return r; }
+    r.f0 = f0; r.f0len = f0len; r.pos = pos;
+    if (want_depth) {                                       // 4th column, collect_metrics.py:325-340 by-product
+        while (is_ws(c) && !is_term(c)) c = tv.get(++p);
+        while (!is_ws(c)) c = tv.get(++p);                  // reference base field
+        while (is_ws(c) && !is_term(c)) c = tv.get(++p);
+        unsigned long long dd = 0;
+        bool dok = !is_ws(c);
+        while (!is_ws(c)) { if (is_digit(c)) dd = dd * 10 + (c - 48u); else dok = false; c = tv.get(++p); }
+        if (dok) r.depth = dd;
+    }
+    return r;
+}
+
+__device__ __forceinline__ uint32_t four_digits(uint32_t x) {      // x: 4 bytes 0..9, lowest address most significant
+    uint32_t t = (x * 10u + (x >> 8)) & 0x00FF00FFu;
+    return (t & 0xFFu) * 100u + (t >> 16);
+}
+
+// 0x80 in every byte of w equal to the byte replicated in pat (ASCII input: no carry between bytes)
+__device__ __forceinline__ uint32_t eq_flags(uint32_t w, uint32_t pat) { return ~((w ^ pat) + 0x7F7F7F7Fu) & 0x80808080u; }
+// 0x80 in every byte of w that is <= 0x20 (ASCII input)
+__device__ __forceinline__ uint32_t le20_flags(uint32_t w) { return ~(w + 0x5F5F5F5Fu) & 0x80808080u; }
+// 16 byte flags (0x80 per byte) of a 16-byte chunk -> 16 bits (v_dot4_u32_u8 with weights 1,2,4,8 / 16..128)
+__device__ __forceinline__ uint32_t flags_to_bits16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
+    uint32_t lo = __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false);
+    lo = __builtin_amdgcn_udot4(f1, 0x80402010u, lo, false);
+    uint32_t hi = __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false);
+    hi = __builtin_amdgcn_udot4(f3, 0x80402010u, hi, false);
+    return (lo >> 7) | ((hi >> 7) << 8);
+}
+
+// 16 bytes of LDS starting at any byte offset, as four dwords.  A byte-misaligned ds_read_b128 is executed as slowly
+// as sixteen byte reads, so read five ALIGNED dwords and funnel-shift them (v_alignbyte_b32).
+__device__ __forceinline__ void lds_window16(const uint8_t *tile, int off, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+    const uint32_t *pw = (const uint32_t *)(tile + (off & ~3));
+    const uint32_t a0 = pw[0], a1 = pw[1], a2 = pw[2], a3 = pw[3], a4 = pw[4];
+    const uint32_t sh = (uint32_t)off & 3u;
+    o0 = __builtin_amdgcn_alignbyte(a1, a0, sh);
+    o1 = __builtin_amdgcn_alignbyte(a2, a1, sh);
+    o2 = __builtin_amdgcn_alignbyte(a3, a2, sh);
+    o3 = __builtin_amdgcn_alignbyte(a4, a3, sh);
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (no LDS traffic).
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+struct Hint {                // the wave's current contig (all members wave-uniform); the name itself is in LDS
+    uint32_t len, cid, max_pos;
+    uint64_t bit_off;
+};
+
+__device__ __noinline__ Hint load_hint(const SiteSetDev &ss, uint32_t cid, uint32_t *hint_w, uint32_t lane) {
+    Hint h;
+    h.cid = 0xFFFFFFFFu; h.len = 0; h.max_pos = 0; h.bit_off = 0;
+    if (cid < ss.n_contigs) {
+        const uint32_t off = ss.name_off[cid], len = ss.name_off[cid + 1] - off;
+        h.cid = cid; h.len = len; h.max_pos = ss.max_pos[cid]; h.bit_off = ss.bit_off[cid];
+        if (lane < SCAN_HINT_WORDS) {
+            uint32_t w = 0;
+            for (uint32_t j = 0; j < 4; ++j) { uint32_t i = lane * 4 + j; if (i < len) w |= (uint32_t)ss.names[off + i] << (8 * j); }
+            hint_w[lane] = w;
+        }
+    } else if (lane < SCAN_HINT_WORDS) hint_w[lane] = 0;
+    return h;
+}
+
+// 0x80 in every byte of w in 0x0A..0x0D ('\n' '\v' '\f' '\r'; ASCII input).  Three ops per dword; whether a flagged
+// byte really is '\n' is checked when its line start is emitted.
+__device__ __forceinline__ uint32_t term_flags(uint32_t w) { return (w + 0x76767676u) & ~(w + 0x72727272u) & 0x80808080u; }
+
+// Workgroup = SCAN_WAVES consumer waves + 1 loader wave.  The loader streams block tile i+1 (SCAN_WAVES x 4 KiB
+// + halo) into the idle LDS buffer with LDS-DMA while the consumers parse block tile i; one barrier per block tile
+// swaps the buffers.  Only the loader ever waits on the DMA (vmcnt), so the fetch of the next tile overlaps the
+// whole parse of the current one, and every workgroup keeps 16 KiB in flight all the time.
+//
+// kExact = false: the hot kernel.  Straight-line fast path only; a line that does not fit it is pushed (its file
+//                 offset) on a small device queue and finished by k_scan_queue with the exact parser.
+// kExact = true:  every line goes through the exact parser (used when the depth column is wanted, and as the
+//                 fallback when the queue overflowed).
+template <int kMode, bool kExact>   // kMode 0 = full; 1 = stage only, 2/3 = line index only, 3/4 = no loads (ablation)
+__global__ __launch_bounds__(SCAN_THREADS, kExact ? 2 : 4) void k_scan_pileup(ScanArgs a, SiteSetDev ss) {
+    __shared__ BlockShared sh;
+    if (kExact && !a.want_depth && a.ctl[1] == 0) return;    // fallback pass: only when the slow-line queue overflowed
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = wave == SCAN_WAVES;
+    const uint32_t *bitmap = ss.bitmap, *rank = ss.rank;
+    uint32_t hits = 0, lines_seen = 0, any_hi = 0;
+    unsigned long long depth_acc = 0;
+    Hint hint{};
+    if (!loader) hint = load_hint(ss, 0, sh.hint_w[wave], lane);
+    uint64_t win_base = 0xFFFFFFFFFFFFFF00ull;           // bitmap window [win_base, win_base + 64) dwords; starts empty
+    uint32_t win_word = 0, win_rank = 0;
+    unsigned long long tB = 0, tL = 0, tC = 0, tW = 0, tLd = 0, tmark = 0;
+#define TICK(acc) do { if (kMode == 5) { unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tmark; tmark = now_; } } while (0)
+    if (kMode == 5) tmark = __builtin_readcyclecounter();
+
+    // A block tile is "interior" when [x0-16, x0+BTILE+HALO) lies inside the file: it can be streamed as is.
+    auto interior = [&](uint64_t tt) { uint64_t x0 = tt * SCAN_BTILE; return x0 >= a.lo + 16 && x0 + SCAN_BTILE + SCAN_HALO <= a.hi; };
+    // Loader: LDS-DMA, global_load_lds_dwordx4 writes 64 lanes x 16 B straight into LDS (LDS address = M0 + lane*16).
+    auto stage_async = [&](uint64_t tt, int buf) {
+        const uint8_t *g = a.base + tt * SCAN_BTILE - 16 + (size_t)lane * 16;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)&sh.tile4[buf][0]);
+#pragma unroll
+        for (int r = 0; r < SCAN_STAGE_ROUNDS; ++r) {
+            if (r * 64 + lane < SCAN_STAGE_CHUNKS) {
+                const uint8_t *gp = g + (size_t)r * 1024;
+                const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + r * 1024);
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m0v) : "memory");
+            }
+        }
+    };
+    // First / last block tiles: byte loads, bytes outside [lo,hi) read as '\n'.
+    auto stage_edge = [&](uint64_t tt, int buf) {
+        const int64_t x0 = (int64_t)(tt * SCAN_BTILE) - 16;
+#pragma nounroll
+        for (uint32_t e = lane; e < SCAN_STAGE_CHUNKS; e += 64) {
+            uint32_t d[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int64_t idx = x0 + (int64_t)e * 16 + 4 * k + j;
+                    uint32_t bb = (idx >= (int64_t)a.lo && idx < (int64_t)a.hi) ? (uint32_t)a.base[idx] : 10u;
+                    d[k] |= bb << (8 * j);
+                }
+            sh.tile4[buf][e] = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+    };
+    auto stage = [&](uint64_t tt, int buf) { if (interior(tt)) stage_async(tt, buf); else stage_edge(tt, buf); };
+
+    int cur = 0;
+    if (loader && blockIdx.x < a.n_btiles) {
+        stage(blockIdx.x, 0);
+        if (kMode == 3 || kMode == 4) stage(blockIdx.x, 1);  // ablation: parse the same tile over and over, no further loads
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    for (uint64_t bt = blockIdx.x; bt < a.n_btiles; bt += gridDim.x, cur ^= 1) {
+        if (loader) {
+            const uint64_t nb = bt + gridDim.x;
+            if (nb < a.n_btiles && kMode != 3 && kMode != 4) stage(nb, cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            TICK(tLd);
+        } else {
+            const uint64_t t0 = bt * SCAN_BTILE + (uint64_t)wave * SCAN_TILE;   // offset of my sub-tile relative to a.base
+            const bool edge = !interior(bt);
+            const uint8_t *tile = (const uint8_t *)&sh.tile4[cur][1] + wave * SCAN_TILE;   // tile[-16 .. SCAN_TILE+SCAN_HALO)
+            const uint4 *tile16 = &sh.tile4[cur][1 + wave * (SCAN_TILE / 16)];
+            uint16_t *lstart = sh.lstart[wave];
+            const uint32_t *hint_w = sh.hint_w[wave];
+            do {                                                // one pass; `break` leaves the tile early
+                if (kMode == 1) { hits += tile[lane]; break; }
+                // ---- B: terminator flags of four 16-byte chunks per lane (chunk i*64+lane: conflict-free LDS reads) ----
+                // bit 16*i + b of S: byte b of chunk i*64+lane is in 0x0A..0x0D; a line starts at the next byte.
+                // Straight-line code: no branch depends on the data unless the tile holds '\v' '\f' or '\r'.
+                uint64_t S;
+                uint32_t exo = 0;                                   // 0x80 where a byte is in 0x0B..0x0D
+                {
+                    uint32_t bits[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint4 v = tile16[i * 64 + lane];
+                        any_hi |= v.x | v.y | v.z | v.w;
+                        exo |= ((v.x + 0x75757575u) & ~(v.x + 0x72727272u)) | ((v.y + 0x75757575u) & ~(v.y + 0x72727272u)) |
+                               ((v.z + 0x75757575u) & ~(v.z + 0x72727272u)) | ((v.w + 0x75757575u) & ~(v.w + 0x72727272u));
+                        bits[i] = flags_to_bits16(term_flags(v.x), term_flags(v.y), term_flags(v.z), term_flags(v.w));
+                    }
+                    S = (uint64_t)(bits[0] | (bits[1] << 16)) | ((uint64_t)(bits[2] | (bits[3] << 16)) << 32);
+                }
+                // The last byte of the sub-tile (lane 63, chunk 3, byte 15) starts a line in the NEXT sub-tile, which
+                // sees it as its byte -1; byte 0 starts a line iff the byte before it ends a terminator.
+                if (lane == 63) S &= ~(1ull << 63);
+                const uint32_t pv0 = tile[-1], cv0 = tile[0];
+                bool s0 = (lane == 0) && (pv0 == 10u || (pv0 == 13u && cv0 != 10u));
+                if (__ballot((exo & 0x80808080u) != 0 || ((lane == 0) && (pv0 - 11u <= 2u)))) {
+                    S = 0;                                          // rare: '\r' (or '\v' '\f'): exact byte-wise index
+#pragma nounroll
+                    for (int i = 0; i < 4; ++i)
+#pragma nounroll
+                        for (int b = 0; b < 16; ++b) {
+                            const int q = (i * 64 + (int)lane) * 16 + b;
+                            const uint32_t cv = tile[q], nx = tile[q + 1];
+                            if (cv == 10u || (cv == 13u && nx != 10u)) S |= 1ull << (16 * i + b);
+                        }
+                    if (lane == 63) S &= ~(1ull << 63);
+                }
+                if (edge) {                                         // starts must lie inside the file
+#pragma nounroll
+                    for (int i = 0; i < 4; ++i)
+#pragma nounroll
+                        for (int b = 0; b < 16; ++b) {
+                            const uint64_t st = t0 + (uint64_t)((i * 64 + (int)lane) * 16 + b + 1);
+                            if (st < a.lo || st >= a.hi) S &= ~(1ull << (16 * i + b));
+                        }
+                    s0 = s0 && t0 >= a.lo && t0 < a.hi;
+                }
+                const uint32_t cnt = (uint32_t)__popcll(S) + (s0 ? 1u : 0u);
+                const uint32_t incl = wave_inclusive_sum(cnt);
+                const uint32_t n_lines = __builtin_amdgcn_readlane(incl, 63);
+                const uint32_t base = incl - cnt;
+                lines_seen += (lane == 0) ? n_lines : 0;
+                if (kMode == 2 || kMode == 3) { hits += base; break; }
+                TICK(tB);
+
+                for (uint32_t pass0 = 0; pass0 < n_lines; pass0 += SCAN_LIST_CAP) {
+                    {   // list of the line starts [pass0, pass0 + CAP): two predicated slots, a loop only for lanes
+                        // with three or more starts in their 64 bytes (lines shorter than ~21 bytes)
+                        uint64_t s_bits = S;
+                        uint32_t idx = base - pass0;                // slots below 0 wrap to huge values and are skipped
+                        if (s0 && idx < SCAN_LIST_CAP) lstart[idx] = 0;
+                        idx += s0 ? 1u : 0u;
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const uint32_t bpos = (uint32_t)__ffsll((long long)s_bits) - 1;     // 0xFFFFFFFF when empty
+                            const bool have = s_bits != 0;
+                            if (have && idx < SCAN_LIST_CAP) lstart[idx] = (uint16_t)((((bpos >> 4) * 64 + lane) << 4) + (bpos & 15) + 1);
+                            idx += have ? 1u : 0u;
+                            s_bits &= s_bits - 1;
+                        }
+                        if (__ballot(s_bits != 0)) {
+                            while (s_bits) {
+                                const uint32_t bpos = (uint32_t)__ffsll((long long)s_bits) - 1;
+                                s_bits &= s_bits - 1;
+                                if (idx < SCAN_LIST_CAP) lstart[idx] = (uint16_t)((((bpos >> 4) * 64 + lane) << 4) + (bpos & 15) + 1);
+                                ++idx;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    TICK(tL);
+                    const uint32_t n_here = n_lines - pass0 < SCAN_LIST_CAP ? n_lines - pass0 : SCAN_LIST_CAP;
+                    // ---- C: one lane per line ------------------------------------------------------------------
+                    if (!kExact) {
+                        // Straight-line predicated code for "name SEP digits SEP"; a line that does not fit (other
+                        // contig, odd whitespace, > 10 digits, long name ...) is queued for the exact parser.
+                        // the hint is wave-uniform; say so (it came back from a call in VGPRs)
+                        const uint32_t L = __builtin_amdgcn_readfirstlane(hint.len);
+                        const uint32_t h_cid = __builtin_amdgcn_readfirstlane(hint.cid);
+                        const uint32_t h_max = __builtin_amdgcn_readfirstlane(hint.max_pos);
+                        const uint64_t h_off = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(hint.bit_off >> 32)) << 32) |
+                                               __builtin_amdgcn_readfirstlane((uint32_t)hint.bit_off);
+                        const bool hint_ok = h_cid != 0xFFFFFFFFu && L >= 1 && L <= 4 * SCAN_HINT_WORDS - 4;
+                        const uint32_t nw = (L + 3) >> 2;                               // dwords of the name
+                        for (uint32_t j0 = 0; j0 < n_here; j0 += 64) {
+                            const uint32_t j = j0 + lane;
+                            const bool active = j < n_here;
+                            const uint32_t s = active ? lstart[j] : 0u;
+                            const uint8_t *p = tile + s;
+                            bool fast = false;
+                            uint64_t pos = 0;
+                            if (hint_ok) {                                               // uniform
+                                uint32_t w[SCAN_HINT_WORDS];
+                                lds_window16(tile, (int)s, w[0], w[1], w[2], w[3]);
+                                if (nw > 4) lds_window16(tile, (int)s + 16, w[4], w[5], w[6], w[7]);        // uniform
+                                if (nw > 8) lds_window16(tile, (int)s + 32, w[8], w[9], w[10], w[11]);      // uniform
+                                uint32_t bad = 0;
+#pragma unroll
+                                for (int k = 0; k < SCAN_HINT_WORDS; ++k)
+                                    if ((uint32_t)k < nw) {                              // uniform
+                                        const uint32_t nb = L - 4 * k;                  // bytes of the name in this dword (uniform)
+                                        const uint32_t mk = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+                                        bad |= (w[k] ^ hint_w[k]) & mk;
+                                    }
+                                const uint32_t c1 = p[L];                                // the separator after the name
+                                uint4 q1;
+                                lds_window16(tile, (int)(s + L + 1), q1.x, q1.y, q1.z, q1.w);      // digits + separator
+                                // first byte <= 0x20 in the 16-byte window = number of digits
+                                const uint32_t ctl = flags_to_bits16(le20_flags(q1.x), le20_flags(q1.y), le20_flags(q1.z), le20_flags(q1.w));
+                                uint32_t nd = (uint32_t)__ffs((int)ctl) - 1u;            // ctl == 0 -> 0xFFFFFFFF
+                                bad |= (nd - 1u > 9u) ? 1u : 0u;
+                                nd = nd > 10u ? 10u : nd;
+                                uint4 q;
+                                lds_window16(tile, (int)(s + L + 1 + nd) - 15, q.x, q.y, q.z, q.w);  // the digits end at byte 14 of this window
+                                const uint32_t c2 = q.w >> 24;
+                                // separators of the fast path: TAB or space after the name; TAB, space or '\n' after the digits
+                                bad |= (c1 != 9u && c1 != 32u) ? 1u : 0u;
+                                bad |= (c2 != 9u && c2 != 32u && c2 != 10u) ? 1u : 0u;
+                                const uint32_t first = 15u - nd;                          // window index of the first digit (5..14)
+                                uint32_t x1 = q.y ^ 0x30303030u, x2 = q.z ^ 0x30303030u, x3 = (q.w ^ 0x30303030u) & 0x00FFFFFFu;
+                                const uint32_t d1 = first > 4 ? first - 4 : 0, d2 = first > 8 ? first - 8 : 0, d3 = first > 12 ? first - 12 : 0;
+                                x1 = d1 >= 4 ? 0u : x1 & (0xFFFFFFFFu << (8 * d1));
+                                x2 = d2 >= 4 ? 0u : x2 & (0xFFFFFFFFu << (8 * d2));
+                                x3 = x3 & (0xFFFFFFFFu << (8 * d3));
+                                bad |= (((x1 + 0x76767676u) | x1) | ((x2 + 0x76767676u) | x2) | ((x3 + 0x76767676u) | x3)) & 0x80808080u;
+                                pos = ((uint64_t)(four_digits(x1) * 10000u + four_digits(x2))) * 1000ull + four_digits(x3 << 8);
+                                fast = bad == 0;
+                            }
+                            const uint64_t off1 = t0 + (uint64_t)s - a.lo + 1;
+                            if (active && !fast) {                                       // rare: leave it to k_scan_queue
+                                const uint32_t qi = atomicAdd(&a.ctl[0], 1u);
+                                if (qi < a.q_cap) a.queue[qi] = off1 - 1; else a.ctl[1] = 1u;
+                            }
+                            const bool probe = active && fast && pos <= (uint64_t)h_max;
+                            // Site bitmap probe without touching memory: the wave keeps a 64-dword window of the
+                            // bitmap (and of its rank directory) in two VGPRs, one dword per lane; a pileup is
+                            // position sorted, so a window (2048 positions) serves ~40 tiles before it is refilled
+                            // with two coalesced 256-byte loads.  Lookup = ds_bpermute (cross-lane, no LDS memory).
+                            const uint64_t bit = h_off + (uint32_t)pos;
+                            const uint64_t wi = bit >> 5;
+                            uint32_t word = 0, rk = 0;
+                            bool done = !probe;
+                            for (;;) {
+                                const uint64_t rel = wi - win_base;
+                                const int sel = (int)(((uint32_t)rel & 63u) << 2);
+                                const uint32_t w_ = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)win_word);
+                                const uint32_t r_ = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)win_rank);
+                                if (!done && rel < 64) { word = w_; rk = r_; done = true; }
+                                const uint64_t miss = __ballot(!done);
+                                if (!miss) break;
+                                const uint32_t src = (uint32_t)__ffsll((long long)miss) - 1;
+                                win_base = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(wi >> 32), src) << 32) |
+                                           __builtin_amdgcn_readlane((uint32_t)wi, src);
+                                const bool inb = win_base + lane < ss.n_words;
+                                win_word = inb ? bitmap[win_base + lane] : 0u;
+                                win_rank = inb ? rank[win_base + lane] : 0u;
+                            }
+                            const uint32_t shf = (uint32_t)(bit & 31);
+                            if ((word >> shf) & 1u) {
+                                const uint32_t site = rk + __popc(word & ((1u << shf) - 1u));
+                                atomicMax((unsigned long long *)&a.site_line[site], (unsigned long long)off1);
+                                ++hits;
+                            }
+                        }
+                    } else {
+                        TileView tv{tile, a.base, t0, a.hi, (int64_t)(SCAN_BTILE + SCAN_HALO) - (int64_t)wave * SCAN_TILE};
+                        for (uint32_t j = lane; j < n_here; j += 64) {
+                            const uint32_t s = lstart[j];
+                            const uint64_t file_off = t0 + (uint64_t)s - a.lo;
+                            SlowLine sl = parse_line_slow(tv, s, a.want_depth);
+                            if (sl.err) { report_scan_error(a.status, file_off, sl.err); continue; }
+                            depth_acc += sl.depth;
+                            const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, sl.f0, sl.f0len) : 0xFFFFFFFFu;
+                            if (cid == 0xFFFFFFFFu || sl.pos > (uint64_t)ss.max_pos[cid]) continue;
+                            const uint64_t bit = ss.bit_off[cid] + (uint32_t)sl.pos;
+                            const uint32_t word = bitmap[bit >> 5];
+                            const uint32_t shf = (uint32_t)(bit & 31);
+                            if (!((word >> shf) & 1u)) continue;
+                            const uint32_t site = rank[bit >> 5] + __popc(word & ((1u << shf) - 1u));
+                            atomicMax((unsigned long long *)&a.site_line[site], (unsigned long long)(file_off + 1));
+                            ++hits;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    TICK(tC);
+                }
+            } while (false);
+        }
+        __syncthreads();
+        TICK(tW);
+    }
+    if (kMode == 5 && lane == 0 && a.dbg) {
+        atomicAdd(&a.dbg[loader ? 5 : 0], tB); atomicAdd(&a.dbg[loader ? 6 : 1], tL); atomicAdd(&a.dbg[loader ? 7 : 2], tC);
+        atomicAdd(&a.dbg[loader ? 8 : 3], tW); atomicAdd(&a.dbg[loader ? 9 : 4], tLd);
+    }
+    // a byte >= 0x80 anywhere in this wave's share of the file (checked once: the answers are void anyway)
+    if (__ballot((any_hi & 0x80808080u) != 0) && lane == 0) report_scan_error(a.status, 0, SCAN_ERR_NON_ASCII);
+    // ---- totals: one atomic per wave -------------------------------------------------------------------
+    for (int o = 32; o; o >>= 1) { hits += __shfl_xor(hits, o); lines_seen += __shfl_xor(lines_seen, o); }
+    if (lane == 0) {
+        if (hits) atomicAdd((unsigned long long *)&a.status[2], (unsigned long long)hits);
+        if (lines_seen) atomicAdd((unsigned long long *)&a.status[1], (unsigned long long)lines_seen);
+    }
+    if (a.want_depth) {
+        for (int o = 32; o; o >>= 1) depth_acc += __shfl_xor(depth_acc, o);
+        if (lane == 0 && depth_acc) atomicAdd((unsigned long long *)&a.status[3], depth_acc);
+    }
+}
+
+// The exact parser over the queued lines (one lane per line, bytes read straight from global memory).
+__global__ __launch_bounds__(256) void k_scan_queue(ScanArgs a, SiteSetDev ss) {
+    const uint32_t n = a.ctl[0];
+    if (n == 0 || a.ctl[1] != 0) return;                    // nothing queued, or overflow: the exact pass redoes the file
+    TileView tv{nullptr, a.base + a.lo, 0, a.hi - a.lo, 0}; // lds_limit 0: every byte comes from global memory
+    uint32_t hits = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t off = a.queue[i];
+        SlowLine sl = parse_line_slow(tv, (int64_t)off, 0);
+        if (sl.err) { report_scan_error(a.status, off, sl.err); continue; }
+        const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, sl.f0, sl.f0len) : 0xFFFFFFFFu;
+        if (cid == 0xFFFFFFFFu || sl.pos > (uint64_t)ss.max_pos[cid]) continue;
+        const uint64_t bit = ss.bit_off[cid] + (uint32_t)sl.pos;
+        const uint32_t word = ss.bitmap[bit >> 5];
+        const uint32_t shf = (uint32_t)(bit & 31);
+        if (!((word >> shf) & 1u)) continue;
+        const uint32_t site = ss.rank[bit >> 5] + __popc(word & ((1u << shf) - 1u));
+        atomicMax((unsigned long long *)&a.site_line[site], (unsigned long long)(off + 1));
+        ++hits;
+    }
+    if (hits) atomicAdd((unsigned long long *)&a.status[2], (unsigned long long)hits);
+}
+
+// status words + queue control for one sample; when the queue overflowed, resets the counters the exact pass recounts
+__global__ void k_scan_init(uint64_t *status, uint32_t *ctl, int phase) {
+    if (phase == 0) { status[0] = ~0ull; status[1] = status[2] = status[3] = 0; ctl[0] = ctl[1] = 0; }
+    else if (ctl[1] != 0) { status[1] = status[2] = 0; }
+}
+
+int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *d_pileup, size_t nbytes,
+                        uint64_t *d_status, int want_depth) {
+    hipStream_t st = ctx->stream;
+    k_scan_init<<<1, 1, 0, st>>>(d_status, ss->slow_ctl, 0);
+    if (!nbytes) return SNPGPU_OK;
+    ScanArgs sa;
+    uintptr_t addr = (uintptr_t)d_pileup;
+    sa.base = (const uint8_t *)(addr & ~(uintptr_t)15);
+    sa.lo = addr & 15;
+    sa.hi = sa.lo + nbytes;
+    sa.n_btiles = (sa.hi + SCAN_BTILE - 1) / SCAN_BTILE;
+    sa.site_line = ss->site_line;
+    sa.status = d_status;
+    sa.want_depth = want_depth;
+    sa.queue = ss->slow_queue;
+    sa.q_cap = SNPGPU_SLOW_QUEUE_CAP;
+    sa.ctl = ss->slow_ctl;
+    sa.dbg = nullptr;
+    static int blocks_per_cu = -1, mode = 0;
+    if (blocks_per_cu < 0) {                                // tuning knobs (development only)
+        const char *b = getenv("SNPGPU_SCAN_BLOCKS_PER_CU"), *m = getenv("SNPGPU_SCAN_MODE");
+        blocks_per_cu = b ? atoi(b) : 2;
+        mode = m ? atoi(m) : 0;
+    }
+    uint64_t max_blocks = (uint64_t)ctx->n_cu * blocks_per_cu;
+    unsigned grid = (unsigned)(sa.n_btiles < max_blocks ? sa.n_btiles : max_blocks);
+    uint64_t exact_max = (uint64_t)ctx->n_cu * 2;
+    unsigned grid_exact = (unsigned)(sa.n_btiles < exact_max ? sa.n_btiles : exact_max);
+    hipEvent_t ta = snpgpu_time_begin(ctx);
+    if (want_depth) {
+        k_scan_pileup<0, true><<<grid_exact, SCAN_THREADS, 0, st>>>(sa, ss->dev);
+    } else {
+        if (mode == 1) k_scan_pileup<1, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
+        else if (mode == 2) k_scan_pileup<2, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
+        else if (mode == 3) k_scan_pileup<3, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
+        else if (mode == 4) k_scan_pileup<4, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
+        else if (mode == 6) k_scan_pileup<6, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
+        else if (mode == 5) {                              // phase timing: cycle totals go to the queue tail
+            sa.dbg = (unsigned long long *)(ss->slow_queue + SNPGPU_SLOW_QUEUE_CAP - 16);
+            (void)hipMemsetAsync(sa.dbg, 0, 128, st);
+            k_scan_pileup<5, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
+            unsigned long long h[10];
+            (void)hipMemcpyAsync(h, sa.dbg, 80, hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            fprintf(stderr, "scan phases (cycles summed over waves): consumer B %llu list %llu C %llu barrier %llu | loader load+wait %llu barrier %llu | blocks %u\n",
+                    h[0], h[1], h[2], h[3], h[9], h[8], grid);
+        }
+        else k_scan_pileup<0, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
+    }
+    snpgpu_time_end(ctx, SNPGPU_K_SCAN, ta);
+    if (!want_depth) {
+        k_scan_queue<<<ctx->n_cu, 256, 0, st>>>(sa, ss->dev);
+        k_scan_init<<<1, 1, 0, st>>>(d_status, ss->slow_ctl, 1);
+        k_scan_pileup<0, true><<<grid_exact, SCAN_THREADS, 0, st>>>(sa, ss->dev);   // returns at once unless the queue overflowed
+    }
+    return SNPGPU_OK;
+}

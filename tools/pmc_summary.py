@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc counter_collection CSVs: per kernel name, mean counter value per dispatch."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(list))
+for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            name = row.get("Kernel_Name", "?").split("(")[0][:60]
+            acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for name in sorted(acc):
+    print(name)
+    for c in sorted(acc[name]):
+        v = acc[name][c]
+        print("    %-28s n=%-4d mean=%.4g" % (c, len(v), sum(v) / len(v)))
