@@ -151,6 +151,10 @@ int  snpgpu_call_consensus_batch_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, 
 int  snpgpu_call_consensus(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *pileup, size_t nbytes,
                            const snpgpu_caller_params *params, uint8_t *out_base, uint8_t *out_filters,
                            snpgpu_site_counts *out_counts, uint64_t *out_status, int want_depth_sum);
+/* After a call_consensus on `ss`: for every site, 1 + the byte offset of the pileup line that was used (0 = no
+ * line).  consensus.vcf rows are written in pileup order (call_consensus.py:161-180), which this recovers.
+ * out_line_off[n_sites] is a HOST pointer; synchronous. */
+int  snpgpu_siteset_line_offsets(snpgpu_ctx *ctx, const snpgpu_siteset *ss, uint64_t *out_line_off);
 
 /* ---- snp_matrix / distance: utils.calculate_sequence_distance (utils.py:1135-1165) over all pairs
  *      (distance.py:93-98) ----------------------------------------------------------------------

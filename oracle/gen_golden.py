@@ -394,6 +394,40 @@ def copy_fixtures():
     shutil.copy(os.path.join(src, "lambdaVirusInputs", "reference", "lambda_virus.fasta"), os.path.join(dst, "lambdaVirus"))
 
 
+CLI_LINES = [
+    "filter_regions dirs.txt ref.fasta",
+    "filter_regions -f -n var.flt.vcf dirs.txt ref.fasta --edge_length 500 --window_size 1000 125 15 --max_snp 3 2 1 --mode all",
+    "filter_regions dirs.txt ref.fasta -l 10 -w 100 -m 2 -g outgroup.txt -M each -v 0",
+    "merge_sites dirs.txt dirs.filtered",
+    "merge_sites -f -n var.flt_preserved.vcf -o snplist_preserved.txt --maxsnps 1000 dirs.txt dirs.filtered",
+    "call_consensus reads.all.pileup",
+    "call_consensus -f -l snplist.txt -o s/consensus.fasta --vcfRefName ref.fasta --minConsFreq 0.6 --minConsDpth 3 --vcfFileName consensus.vcf s/reads.all.pileup",
+    "call_consensus -l snplist_preserved.txt -o s/consensus_preserved.fasta -e s/var.flt_removed.vcf -q 15 -c 0.9 -D 5 -d 2 -b 0.1 --vcfFailedSnpGt 1 --vcfPreserveRefCase s/reads.all.pileup",
+    "snp_matrix dirs.txt",
+    "snp_matrix -f -c consensus_preserved.fasta -o snpma_preserved.fasta dirs.txt",
+    "distance snpma.fasta",
+    "distance -f -p pairs.tsv -m matrix.tsv snpma.fasta",
+]
+
+
+def gen_cli_vectors():
+    """argparse results of the reference's own parser for the five hot subcommands."""
+    import types as _t
+    jr = _t.ModuleType("jobrunner")                      # orchestration only (run.py); never called here
+    jr.JobRunner = object
+    jr.JobRunnerException = Exception
+    sys.modules.setdefault("jobrunner", jr)
+    from snppipeline import cfsan_snp_pipeline as ref_cli
+    out = []
+    for line in CLI_LINES:
+        ns = vars(ref_cli.parse_command_line(line))
+        clean = {k: v for k, v in ns.items() if k not in ("func", "excepthook")}
+        clean["excepthook"] = ns["excepthook"].__name__ if ns.get("excepthook") else None
+        clean["func"] = ns["func"].__name__
+        out.append({"line": line, "args": clean})
+    return out
+
+
 def dump(name, obj):
     raw = json.dumps(obj, separators=(",", ":"), sort_keys=True).encode()
     with open(os.path.join(GOLD, name), "wb") as f:
@@ -407,6 +441,7 @@ def main():
     captured = install_stubs()
     dump("pileup_vectors.json.gz", gen_pileup_vectors(captured))
     dump("steps_vectors.json.gz", gen_steps_vectors())
+    dump("cli_vectors.json.gz", gen_cli_vectors())
     copy_fixtures()
 
 

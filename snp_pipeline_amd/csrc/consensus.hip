@@ -379,6 +379,15 @@ int snpgpu_call_consensus_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const v
     return enqueue_sample(ctx, ss, (const uint8_t *)d_pileup, nbytes, params, d_out_base, d_out_filters, d_out_counts, d_status, want_depth_sum);
 }
 
+int snpgpu_siteset_line_offsets(snpgpu_ctx *ctx, const snpgpu_siteset *ss, uint64_t *out_line_off) {
+    if (!ctx || !ss || (ss->n_sites && !out_line_off)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (!ss->n_sites) return SNPGPU_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(out_line_off, ss->site_line, 8ull * ss->n_sites, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SNPGPU_OK;
+}
+
 int snpgpu_call_consensus_batch_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const void *d_pileups,
                                     const uint64_t *h_offsets, uint32_t n_samples,
                                     const snpgpu_caller_params *params, uint8_t *d_out_base,

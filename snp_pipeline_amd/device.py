@@ -195,6 +195,12 @@ class Device(object):
                     L.ST_MULTI_REF: "unsupported: reference-base field longer than one byte"}.get(code, "malformed line")
             raise PileupFormatError("pileup line for site #%d: %s" % (int(bad[0]), what))
 
+    def line_offsets(self, siteset):
+        """1 + byte offset of the pileup line used for each site by the last call_consensus on this set (0 = none)."""
+        out = np.zeros(len(siteset), dtype=np.uint64)
+        self._check(self.lib.snpgpu_siteset_line_offsets(self.ctx, siteset.handle, _ptr(out)))
+        return out
+
     def call_consensus_dev(self, siteset, d_pileup_ptr, nbytes, params, d_bases, d_filters, d_status, d_counts=None,
                            want_depth_sum=False):
         """All arguments are device pointers (ints); asynchronous on the context's stream."""

@@ -1,0 +1,71 @@
+"""distance subcommand: all-pairs SNP distances from snpma.fasta.
+
+Host mirror of snppipeline/distance.py:14-118.  The pair counting (utils.calculate_sequence_distance for every pair)
+runs in the HIP distance kernel (csrc/distance.hip) behind ``Device.distance``; this file parses the multi-FASTA,
+orders the ids and writes the two TSV layouts.
+"""
+from __future__ import print_function
+
+import numpy as np
+
+from . import snp_matrix
+from . import utils
+
+
+def distance_matrix(dev, seqs):
+    """seqs: {id: sequence}.  Returns (sorted ids, (n, n) int32 matrix).  Sequences must have equal length, except
+    that — like the reference's loop over range(len(seq1)) — a longer second sequence is simply cut."""
+    ids = sorted(seqs.keys())
+    n = len(ids)
+    if n == 0:
+        return ids, np.zeros((0, 0), dtype=np.int32)
+    lengths = {len(seqs[i]) for i in ids}
+    if len(lengths) != 1:
+        raise IndexError("sequences of unequal length in the SNP matrix")     # utils.py:1157 raises IndexError
+    s = lengths.pop()
+    sym = np.frombuffer("".join(seqs[i] for i in ids).encode("latin-1"), dtype=np.uint8).reshape(n, s) if s else np.zeros((n, 0), np.uint8)
+    return ids, dev.distance(sym)
+
+
+def write_pairwise(path, ids, mat):
+    with open(path, "w") as p_out:
+        p_out.write("Seq1\tSeq2\tDistance\n")
+        for i, id1 in enumerate(ids):
+            row = mat[i]
+            p_out.write("".join("%s\t%s\t%i\n" % (id1, id2, row[j]) for j, id2 in enumerate(ids)))
+
+
+def write_matrix(path, ids, mat):
+    with open(path, "w") as m_out:
+        m_out.write("\t%s\n" % "\t".join(ids))
+        for i, id1 in enumerate(ids):
+            m_out.write("%s\t%s\n" % (id1, "\t".join(map(str, mat[i].tolist()))))
+
+
+def calculate_snp_distances(args):
+    """Entry point of ``cfsan_snp_pipeline distance`` (cfsan_snp_pipeline.py:448-457)."""
+    utils.print_log_header()
+    utils.print_arguments(args)
+
+    input_file = args.inputFile
+    pairwise_file = args.pairwiseFile
+    matrix_file = args.matrixFile
+    if utils.verify_existing_input_files("SNP matrix file", [input_file]) > 0:
+        utils.global_error("Error: cannot calculate sequence distances without the snp matrix file.")
+    if not pairwise_file and not matrix_file:
+        utils.global_error("Error: no output file specified.")
+
+    rebuild_pairwise = pairwise_file and utils.target_needs_rebuild([input_file], pairwise_file)
+    rebuild_matrix = matrix_file and utils.target_needs_rebuild([input_file], matrix_file)
+    if not (args.forceFlag or rebuild_pairwise or rebuild_matrix):
+        utils.verbose_print("Distance files have already been freshly built.  Use the -f option to force a rebuild.")
+        return
+
+    seqs = snp_matrix.read_matrix(input_file)
+    utils.verbose_print("# %s %s" % (utils.timestamp(), "Calculating all pairwise distances"))
+    from .device import default_device
+    ids, mat = distance_matrix(default_device(), seqs)
+    if pairwise_file:
+        write_pairwise(pairwise_file, ids, mat)
+    if matrix_file:
+        write_matrix(matrix_file, ids, mat)

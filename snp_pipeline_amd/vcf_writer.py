@@ -1,0 +1,101 @@
+"""consensus.vcf writer (the reference's vcf_writer.SingleSampleWriter, snppipeline/vcf_writer.py:92-134, 295-435).
+
+Every number in a row (SDP, RD, AD[], RDF, RDR, ADF[], ADR[], ALT order, FT) is a by-product of the per-site
+caller kernel (``snpgpu_site_counts``); this file only lays the text out.  Header layout follows what PyVCF3's
+Writer emits for the reference's template: plain ``##key=value`` lines, INFO, FORMAT, FILTER, ``#CHROM``
+(pinned by the lambda consensus*.vcf fixtures, which the reference's own test compares modulo fileDate/source).
+"""
+from __future__ import print_function
+
+import datetime
+
+import numpy as np
+
+from . import _lib as L
+from . import utils
+
+FORMAT_IDS = "GT:SDP:RD:AD:RDF:RDR:ADF:ADR:FT"
+_FORMAT_LINES = [
+    '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
+    '##FORMAT=<ID=SDP,Number=1,Type=Integer,Description="Raw read depth">',
+    '##FORMAT=<ID=RD,Number=1,Type=Integer,Description="Depth of reference-supporting bases">',
+    '##FORMAT=<ID=AD,Number=A,Type=Integer,Description="Depth of variant-supporting bases (comma-separated depth per alt allele)">',
+    '##FORMAT=<ID=RDF,Number=1,Type=Integer,Description="Depth of reference-supporting bases on forward strand">',
+    '##FORMAT=<ID=RDR,Number=1,Type=Integer,Description="Depth of reference-supporting bases on reverse strand">',
+    '##FORMAT=<ID=ADF,Number=A,Type=Integer,Description="Depth of variant-supporting bases on forward strand (comma-separated depth per alt allele)">',
+    '##FORMAT=<ID=ADR,Number=A,Type=Integer,Description="Depth of variant-supporting bases on reverse strand (comma-separated depth per alt allele)">',
+    '##FORMAT=<ID=FT,Number=1,Type=String,Description="Genotype filters using the same codes as the FILTER data element">',
+]
+
+
+def filter_descriptions(min_cons_freq, min_cons_depth, min_cons_strand_depth, min_cons_strand_bias):
+    """Names in failed-filter bit order (pileup.py:467-490) + Region (call_consensus.py:156)."""
+    return [
+        ("RawDpth", "No read depth"),
+        ("VarFreq" + str(int(100 * min_cons_freq)), "Variant base frequency below %.2f" % min_cons_freq),
+        ("Depth" + str(min_cons_depth), "Less than %i supporting reads" % min_cons_depth),
+        ("StrDpth" + str(min_cons_strand_depth), "Less than %i variant-supporing reads on at least one strand" % min_cons_strand_depth),
+        ("StrBias" + str(int(100 * min_cons_strand_bias)), "Fraction of variant supporting reads below %.2f on one strand" % min_cons_strand_bias),
+        ("Region", "Position is in dense region of snps or near the end of the contig."),
+    ]
+
+
+def header_lines(sample_id, filters, reference, now=None):
+    now = now or datetime.datetime.now()
+    out = ["##fileformat=VCFv4.2", now.strftime("##fileDate=%Y%m%d"), "##source=CFSAN SNP-Pipeline %s" % utils.__version__,
+           "##reference=%s" % reference,
+           '##INFO=<ID=NS,Number=1,Type=Integer,Description="Number of samples with data">']
+    out.extend(_FORMAT_LINES)
+    out.append('##FILTER=<ID=PASS,Description="All filters passed">')
+    out.extend('##FILTER=<ID=%s,Description="%s">' % (n, d) for n, d in filters)
+    out.append("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s" % sample_id)
+    return out
+
+
+def row_from_counts(chrom, pos, c, filter_names, preserve_ref_case, failed_snp_gt):
+    """One VCF data line from a snpgpu_site_counts record (vcf_writer.py:295-379)."""
+    ref = chr(int(c["ref_base"]))
+    upper_ref = ref.upper()
+    if not preserve_ref_case:
+        ref = upper_ref
+    mask = int(c["filters"])
+    failed = [filter_names[i] for i in range(6) if mask >> i & 1]
+    n_sym = int(c["n_symbols"])
+    if n_sym > L.MAX_SYMS:
+        raise ValueError("%s:%d has %d distinct symbols; the device record keeps %d" % (chrom, pos, n_sym, L.MAX_SYMS))
+    syms = [chr(int(c["sym"][r])) for r in range(n_sym)]
+    total = {s: int(c["total"][r]) for r, s in enumerate(syms)}
+    fwd = {s: int(c["fwd"][r]) for r, s in enumerate(syms)}
+    rev = {s: int(c["rev"][r]) for r, s in enumerate(syms)}
+    if int(c["good_depth"]) == 0:                       # most_common_good_bases is None
+        alt, gt, ad, adf, adr = [], ".", "0", "0", "0"
+    else:
+        alt = [s for s in syms if s != upper_ref]
+        if not alt:
+            gt, ad, adf, adr = "0", "0", "0", "0"
+        else:
+            gt = "0" if syms[0] == upper_ref else "1"
+            ad = ",".join(str(total[s]) for s in alt)
+            adf = ",".join(str(fwd.get(s, 0)) for s in alt)
+            adr = ",".join(str(rev.get(s, 0)) for s in alt)
+        if failed:
+            gt = "." if failed_snp_gt == "." else ("0" if failed_snp_gt == "0" else "1")
+    ft = ";".join(failed) if failed else "PASS"
+    data = ":".join([gt, str(int(c["raw_depth"])), str(total.get(upper_ref, 0)), ad, str(fwd.get(upper_ref, 0)),
+                     str(rev.get(upper_ref, 0)), adf, adr, ft])
+    return "\t".join([chrom, str(pos), ".", ref, ",".join(alt) if alt else ".", ".", ft, "NS=1", FORMAT_IDS, data])
+
+
+def write_consensus_vcf(path, sample_id, args, siteset, result, line_offsets):
+    """Rows for every parsed position (snplist and exclude positions that have a pileup line), in pileup order."""
+    filters = filter_descriptions(args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
+    names = [n for n, _ in filters]
+    keys = siteset.key_tuples()
+    have = np.nonzero(result.counts["status"] == L.ST_OK)[0]
+    order = have[np.argsort(line_offsets[have], kind="stable")]
+    with open(path, "w") as f:
+        f.write("\n".join(header_lines(sample_id, filters, args.vcfRefName)) + "\n")
+        for slot in order:
+            chrom, pos = keys[int(slot)]
+            f.write(row_from_counts(chrom.decode("ascii"), pos, result.counts[int(slot)], names,
+                                    args.vcfPreserveRefCase, args.vcfFailedSnpGt) + "\n")

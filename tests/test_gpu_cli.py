@@ -1,0 +1,181 @@
+"""The five hot subcommands end to end (CLI -> host mirror -> C ABI -> HIP kernels) against the reference's bundled
+ExpectedResults trees and, for call_consensus (no pileup ships with the reference), against the oracle."""
+import filecmp
+import os
+import shutil
+
+import pytest
+
+from oracle import fuzz
+from oracle import pileup_oracle as po
+from oracle import vcf_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _argv(monkeypatch):
+    monkeypatch.setattr("sys.argv", ["cfsan_snp_pipeline", "test"])
+
+
+def _run(line):
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    args = cli.parse_command_line(line)
+    args.verbose = 0
+    assert cli.run_command_from_args(args) == 0
+
+
+def _work_tree(tmp_path, fixture_root, meta, dataset):
+    """Copy the fixture samples into a scratch work dir; returns (work dir, sample dirs file, reference fasta)."""
+    work = str(tmp_path / "work")
+    shutil.copytree(os.path.join(fixture_root, "samples"), os.path.join(work, "samples"))
+    dirs = sorted(os.path.join(work, "samples", s) for s in os.listdir(os.path.join(work, "samples")))
+    dirs_file = os.path.join(work, "sampleDirectories.txt")
+    with open(dirs_file, "w") as f:
+        f.write("\n".join(reversed(dirs)) + "\n")                 # deliberately unsorted
+    ref = os.path.join(work, "reference.fasta")
+    if dataset == "lambdaVirus":
+        from tests.conftest import GOLD
+        shutil.copy(os.path.join(GOLD, "fixtures", "lambdaVirus", "lambda_virus.fasta"), ref)
+    else:
+        with open(ref, "w") as f:
+            lens = meta["contig_lengths"] or {"contig_missing_from_this_checkout": 100}
+            for name, n in lens.items():
+                f.write(">%s\n" % name)
+                for i in range(0, n, 60000):
+                    f.write("N" * min(60000, n - i) + "\n")
+    return work, dirs_file, ref
+
+
+@pytest.mark.parametrize("ds", ["lambdaVirus", "agona", "listeria"])
+def test_filter_merge_matrix_distance_on_bundled_trees(tmp_path, fixture_trees, ds):
+    root, meta = fixture_trees[ds]
+    work, dirs_file, ref = _work_tree(tmp_path, root, meta, ds)
+    samples = sorted(os.listdir(os.path.join(work, "samples")))
+    # remove the expected outputs that the commands below must recreate
+    for s in samples:
+        for name in ("var.flt_preserved.vcf", "var.flt_removed.vcf"):
+            p = os.path.join(work, "samples", s, name)
+            if os.path.exists(p):
+                os.remove(p)
+    # step 5: filter_regions with the pipeline's default parameters (snppipeline.conf:211)
+    _run("filter_regions -n var.flt.vcf %s %s --edge_length 500 --window_size 1000 125 15 --max_snp 3 2 1 --mode all" % (dirs_file, ref))
+    for s in samples:
+        for name in ("var.flt_preserved.vcf", "var.flt_removed.vcf"):
+            want = os.path.join(root, "samples", s, name)
+            if os.path.exists(want):
+                assert filecmp.cmp(os.path.join(work, "samples", s, name), want, shallow=False), (s, name)
+    # steps 6.1 / 6.2: merge_sites
+    _run("merge_sites -n var.flt.vcf -o %s/snplist.txt %s %s.OrigVCF.filtered" % (work, dirs_file, dirs_file))
+    _run("merge_sites -n var.flt_preserved.vcf -o %s/snplist_preserved.txt %s %s.PresVCF.filtered" % (work, dirs_file, dirs_file))
+    assert filecmp.cmp(work + "/snplist.txt", root + "/snplist.txt", shallow=False)
+    assert filecmp.cmp(work + "/snplist_preserved.txt", root + "/snplist_preserved.txt", shallow=False)
+    assert open(dirs_file + ".OrigVCF.filtered").read() == open(dirs_file).read()
+    # steps 8.x: snp_matrix from the bundled consensus files, steps 11.x: distance
+    for suffix in ("", "_preserved"):
+        have_cons = all(os.path.exists(os.path.join(work, "samples", s, "consensus%s.fasta" % suffix)) for s in samples)
+        snpma = "%s/snpma%s.fasta" % (work, suffix)
+        if have_cons:
+            _run("snp_matrix -c consensus%s.fasta -o %s %s.OrigVCF.filtered" % (suffix, snpma, dirs_file))
+            assert filecmp.cmp(snpma, "%s/snpma%s.fasta" % (root, suffix), shallow=False)
+        else:
+            shutil.copy("%s/snpma%s.fasta" % (root, suffix), snpma)
+        _run("distance -p %s/pairs%s.tsv -m %s/matrix%s.tsv %s" % (work, suffix, work, suffix, snpma))
+        assert filecmp.cmp("%s/matrix%s.tsv" % (work, suffix), "%s/snp_distance_matrix%s.tsv" % (root, suffix), shallow=False)
+        pw = "%s/snp_distance_pairwise%s.tsv" % (root, suffix)
+        if os.path.exists(pw):
+            assert filecmp.cmp("%s/pairs%s.tsv" % (work, suffix), pw, shallow=False)
+    # freshness: a second run without -f leaves the outputs alone
+    before = os.stat(work + "/snplist.txt").st_mtime_ns
+    _run("merge_sites -n var.flt.vcf -o %s/snplist.txt %s %s.OrigVCF.filtered" % (work, dirs_file, dirs_file))
+    assert os.stat(work + "/snplist.txt").st_mtime_ns == before
+
+
+def test_filter_regions_mode_each_and_outgroup(tmp_path, fixture_trees):
+    from oracle import steps_oracle as so
+    from snp_pipeline_amd import utils
+    root, meta = fixture_trees["lambdaVirus"]
+    work, dirs_file, ref = _work_tree(tmp_path, root, meta, "lambdaVirus")
+    og = os.path.join(work, "outgroup.txt")
+    with open(og, "w") as f:
+        f.write("sample2\n")
+    _run("filter_regions -f %s %s -l 500 -w 1000 125 15 -m 3 2 1 -M each -g %s" % (dirs_file, ref, og))
+    lens = meta["contig_lengths"]
+    for s in sorted(os.listdir(os.path.join(work, "samples"))):
+        d = os.path.join(work, "samples", s)
+        header, data, sites = utils.read_vcf_sites(os.path.join(d, "var.flt.vcf"))
+        pres = utils.read_vcf_sites(os.path.join(d, "var.flt_preserved.vcf"))[2]
+        rem = utils.read_vcf_sites(os.path.join(d, "var.flt_removed.vcf"))[2]
+        if s == "sample2":
+            assert filecmp.cmp(os.path.join(d, "var.flt.vcf"), os.path.join(d, "var.flt_preserved.vcf"), shallow=False) and rem == []
+            continue
+        bad = so.bad_regions([(s, sites)], lens, 500, [3, 2, 1], [1000, 125, 15], mode="each")[s]
+        assert rem == [k for k in sites if so.in_region(k[1], bad[k[0]])]
+        assert pres == [k for k in sites if not so.in_region(k[1], bad[k[0]])]
+
+
+def test_call_consensus_cli_vs_oracle(tmp_path):
+    """call_consensus subcommand on synthetic pileups: consensus.fasta and consensus.vcf against the oracle."""
+    work = tmp_path
+    for seed, kw, extra in ((41, dict(genome_len=5000, n_sites=120), ""),
+                            (42, dict(genome_len=2500, n_sites=70, contigs=("ctgB", "ctgA")), " -q 15 -c 0.9 -D 5 -d 2 -b 0.1 --vcfFailedSnpGt 1")):
+        data, _, sites = fuzz.synth_pileup(seed, **kw)
+        sdir = work / ("sample%d" % seed)
+        sdir.mkdir()
+        (sdir / "reads.all.pileup").write_bytes(data)
+        snps = sorted(sites + [(sites[0][0], 77_000_000)])
+        excl = sites[::6] + [(sites[0][0], 9)]
+        with open(str(work / ("snplist%d.txt" % seed)), "w") as f:
+            for c, p in snps:
+                f.write("%s\t%d\t1\tsampleX\n" % (c.decode(), p))
+        with open(str(sdir / "var.flt_removed.vcf"), "w") as f:
+            f.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n")
+            for c, p in excl:
+                f.write("%s\t%d\t.\tA\tC\t.\tPASS\t.\tGT\t1/1\n" % (c.decode(), p))
+        params = po.CallerParams(15, 0.9, 5, 2, 0.1) if extra else po.CallerParams(0, 0.6, 3, 0, 0.0)
+        base_flags = extra if extra else " --minConsFreq 0.6 --minConsDpth 3"
+        _run("call_consensus -l %s/snplist%d.txt -o %s/consensus.fasta -e %s/var.flt_removed.vcf --vcfRefName ref.fasta "
+             "--vcfFileName consensus.vcf%s %s/reads.all.pileup" % (work, seed, sdir, sdir, base_flags, sdir))
+        want, detail = po.call_consensus_sites(data, snps, set(excl), params)
+        want_fa = ">sample%d\n" % seed + "".join(want.decode()[i:i + 60] + "\n" for i in range(0, len(want), 60))
+        assert (sdir / "consensus.fasta").read_text() == want_fa
+        names = po.filter_names(params)
+        rows = []
+        for _, line in po.iter_lines(data):                            # pileup order, one row per parsed position
+            f = line.split()
+            key = (f[0], int(f[1]))
+            if key in detail:
+                rec, base, mask = detail[key]
+                failed = [names[i] for i in range(6) if mask >> i & 1] or None
+                rows.append(vo.vcf_row(rec, failed, "1" if extra else "."))
+        got = [ln for ln in (sdir / "consensus.vcf").read_text().split("\n") if ln and not ln.startswith("#")]
+        assert got == rows
+    # empty snplist: exit 0, FASTA with only the header line (regression_tests.sh:3156-3207)
+    (work / "empty.txt").write_text("")
+    _run("call_consensus -f -l %s/empty.txt -o %s/empty.fasta %s/sample41/reads.all.pileup" % (work, work, work))
+    assert (work / "empty.fasta").read_text() == ">sample41\n"
+
+
+def test_call_consensus_cli_error_paths(tmp_path, monkeypatch):
+    """Missing snplist -> exit 100 always; missing pileup -> 100 / 98 by StopOnSampleError; corrupt snplist -> exception hook."""
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    log = tmp_path / "error.log"
+    monkeypatch.setenv("errorOutputFile", str(log))
+    pile = tmp_path / "s1" / "reads.all.pileup"
+    pile.parent.mkdir()
+    pile.write_bytes(b"c\t1\tA\t1\t.\tI\n")
+    monkeypatch.setenv("StopOnSampleError", "false")
+    with pytest.raises(SystemExit) as ei:
+        _run("call_consensus -l %s/absent.txt -o %s/c.fasta %s" % (tmp_path, tmp_path, pile))
+    assert ei.value.code == 100 and "cannot call consensus without the snplist file" in log.read_text()
+    (tmp_path / "snplist.txt").write_text("c\t1\t1\ts1\n")
+    with pytest.raises(SystemExit) as ei:
+        _run("call_consensus -l %s/snplist.txt -o %s/c.fasta %s/absent.pileup" % (tmp_path, tmp_path, tmp_path))
+    assert ei.value.code == 98
+    monkeypatch.delenv("StopOnSampleError")
+    with pytest.raises(SystemExit) as ei:
+        _run("call_consensus -l %s/snplist.txt -o %s/c.fasta %s/absent.pileup" % (tmp_path, tmp_path, tmp_path))
+    assert ei.value.code == 100
+    (tmp_path / "corrupt.txt").write_text("c\tnot_a_number\n")
+    with pytest.raises(ValueError):
+        _run("call_consensus -f -l %s/corrupt.txt -o %s/c.fasta %s" % (tmp_path, tmp_path, pile))

@@ -128,3 +128,15 @@ def test_bundled_fixtures(fixture_trees, ds):
         pw = os.path.join(root, "snp_distance_pairwise%s.tsv" % suffix)
         if os.path.isfile(pw):
             assert so.pairwise_text(ids, d) == open(pw).read()
+
+
+def test_vcf_row_known_answers():
+    """The reference's own doctest answers for consensus.vcf rows (vcf_writer.py:400-429)."""
+    from oracle import vcf_oracle as vo
+    r = po.parse_record([b"ID", b"42", b"G", b"0", b"", b""], 15)
+    assert vo.vcf_row(r, ["Fail"], ".").split("\t") == ["ID", "42", ".", "G", ".", ".", "Fail", "NS=1", vo.FORMAT_IDS, ".:0:0:0:0:0:0:0:Fail"]
+    r = po.parse_record([b"ID", b"42", b"G", b"14", b"aaaaAAAA...,,,", b"00001111222333"], 15)
+    assert vo.vcf_row(r, None, ".").split("\t") == ["ID", "42", ".", "G", "A", ".", "PASS", "NS=1", vo.FORMAT_IDS, "1:14:6:8:3:3:4:4:PASS"]
+    r = po.parse_record([b"ID", b"42", b"G", b"23", b"TttaaAAAcCC.......,,,,,", b"00011111222333333333333"], 15)
+    assert vo.vcf_row(r, None, ".").split("\t") == ["ID", "42", ".", "G", "A,C,T", ".", "PASS", "NS=1", vo.FORMAT_IDS,
+                                                    "0:23:12:5,3,3:7:5:3,2,1:2,1,2:PASS"]
