@@ -54,6 +54,7 @@ def main():
     import torch.distributed as dist
     from snp_pipeline_amd import _lib as L
     from snp_pipeline_amd import device as dev
+    from snp_pipeline_amd import sharding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -109,7 +110,6 @@ def main():
     status = torch.empty((B, 4), dtype=torch.int64, device="cuda")
     row_bytes = d.packed_row_bytes(S)
     packed = torch.empty((B, row_bytes), dtype=torch.uint8, device="cuda")
-    packed_all = torch.empty((world * B, row_bytes), dtype=torch.uint8, device="cuda") if world > 1 else packed
     dmat = torch.zeros((world * B, world * B), dtype=torch.int32, device="cuda")
 
     def step():
@@ -118,8 +118,7 @@ def main():
             d.call_consensus_dev(ss, pile.data_ptr() + int(offs[i]), sizes[i], prm, bases[i].data_ptr(),
                                  filt[i].data_ptr(), status[i].data_ptr())
         d.pack_matrix_dev(bases.data_ptr(), B, S, S, packed.data_ptr())
-        if world > 1:
-            dist.all_gather_into_tensor(packed_all, packed)
+        packed_all = sharding.all_gather_rows(packed, world * B)         # C2: RCCL all-gather over xGMI when world > 1
         d.distance_packed_dev(packed_all.data_ptr(), world * B, S, dmat.data_ptr(), rank, world)
 
     def barrier():

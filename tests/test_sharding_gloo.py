@@ -1,0 +1,89 @@
+"""The N > 1 path on CPU: two gloo ranks shard samples, exchange site lists and matrix rows, split the distance
+tiles, and must reproduce the single-process answer.  (The kernels themselves are covered by the -m gpu tests; here
+the per-rank arithmetic is the oracle's.)"""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import steps_oracle as so
+from snp_pipeline_amd import sharding
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _np_tile(sym, bi, bj):
+    t = sharding.DIST_TILE
+    a, b = sym[bi * t:(bi + 1) * t], sym[bj * t:(bj + 1) * t]
+    valid = np.isin(sym, np.frombuffer(b"ACGT", dtype=np.uint8))
+    va, vb = valid[bi * t:(bi + 1) * t], valid[bj * t:(bj + 1) * t]
+    return ((a[:, None, :] != b[None, :, :]) & va[:, None, :] & vb[None, :, :]).sum(axis=2).astype(np.int32)
+
+
+def _worker(rank, world, port, n_samples, n_sites, seed, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(seed)
+        # every rank derives the same global inputs, then only touches its own shard
+        site_sets = [np.unique(rng.integers(1, 5000, size=rng.integers(0, 60))).astype(np.int64) for _ in range(n_samples)]
+        sym = rng.choice(np.frombuffer(b"ACGT-n", dtype=np.uint8), size=(n_samples, n_sites)).astype(np.uint8)
+        lo, hi = sharding.shard_bounds(n_samples, rank, world)
+        # C1: variable-length all-gather of site keys, then the same merge everywhere
+        mine = np.concatenate([site_sets[i] for i in range(lo, hi)] + [np.zeros(0, np.int64)])
+        owner = np.concatenate([np.full(len(site_sets[i]), i, np.int64) for i in range(lo, hi)] + [np.zeros(0, np.int64)])
+        keys, counts = sharding.all_gather_varlen(torch.from_numpy(mine))
+        owners, _ = sharding.all_gather_varlen(torch.from_numpy(owner))
+        assert sum(counts) == sum(len(s) for s in site_sets)
+        merged = {}
+        for k, o in zip(keys.tolist(), owners.tolist()):
+            merged.setdefault(k, []).append(o)
+        want, _ = so.merge_sites([("d%03d" % i, i, [("c", int(p)) for p in site_sets[i]]) for i in range(n_samples)])
+        assert [(("c", k), merged[k]) for k in sorted(merged)] == want
+        # C2: all-gather of this rank's rows
+        full = sharding.all_gather_rows(torch.from_numpy(sym[lo:hi].copy()), n_samples)
+        assert np.array_equal(full.numpy(), sym)
+        # distance tiles dealt cyclically, partial matrices summed
+        part = np.zeros((n_samples, n_samples), dtype=np.int32)
+        t = sharding.DIST_TILE
+        for bi, bj in sharding.tiles_of_rank(n_samples, rank, world):
+            blk = _np_tile(full.numpy(), bi, bj)
+            part[bi * t:bi * t + blk.shape[0], bj * t:bj * t + blk.shape[1]] = blk
+            if bi != bj:
+                part[bj * t:bj * t + blk.shape[1], bi * t:bi * t + blk.shape[0]] = blk.T
+        total = sharding.sum_partial_distances(torch.from_numpy(part)).numpy()
+        if rank == 0:
+            np.save(os.path.join(out_dir, "dist.npy"), total)
+            np.save(os.path.join(out_dir, "sym.npy"), sym)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_pipeline_matches_single_process(tmp_path):
+    n_samples, n_sites = 261, 300                   # 3 x 3 tile grid, uneven shards (131 + 130)
+    mp.spawn(_worker, args=(2, _free_port(), n_samples, n_sites, 5, str(tmp_path)), nprocs=2, join=True)
+    total = np.load(str(tmp_path / "dist.npy"))
+    sym = np.load(str(tmp_path / "sym.npy"))
+    seqs = [bytes(r).decode() for r in sym]
+    for i, j in [(0, 1), (5, 200), (130, 131), (260, 0), (128, 255), (17, 17)]:
+        assert total[i, j] == (0 if i == j else so.sequence_distance(seqs[i], seqs[j]))
+    assert np.array_equal(total, total.T) and not total.diagonal().any()
+
+
+def test_shard_bounds_and_tiles():
+    assert [sharding.shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert [sharding.shard_bounds(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    tiles = sharding.upper_tiles(300)
+    assert tiles == [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+    got = sorted(t for r in range(4) for t in sharding.tiles_of_rank(300, r, 4))
+    assert got == sorted(tiles)
+    assert sharding.all_gather_varlen(torch.arange(3))[1] == [3]
