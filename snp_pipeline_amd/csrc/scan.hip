@@ -496,6 +496,306 @@ __global__ __launch_bounds__(SCAN_THREADS, kExact ? 2 : 4) void k_scan_pileup(Sc
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The hot kernel: barrier-free ring.  One loader wave keeps a ring of SCAN_RING self-contained 4 KiB (+halo) slots
+// full with LDS-DMA, always SCAN_DEPTH+1 tiles in flight (counted vmcnt, so a slot is published the moment its own
+// DMA has landed); SCAN_WAVES consumer waves take tiles n = w, w+4, ... from slot n % SCAN_RING, parse them (phases
+// B and C above, fast path only) and hand the slot back.  Hand-off is an LDS word per slot (tile sequence number + 1
+// when full, 0 when free); nobody ever waits at a workgroup barrier, so a slow consumer stalls neither the loader
+// nor its siblings.
+#define SCAN_RING 8
+#define SCAN_DEPTH 3                         // tiles in flight behind the newest one
+#define SCAN_DMA_PER_TILE ((SCAN_WTILE_CHUNKS + 63) / 64)
+#define SCAN_WTILE_CHUNKS ((16 + SCAN_TILE + SCAN_HALO) / 16)
+
+struct RingShared {
+    uint4 slot[SCAN_RING][SCAN_WTILE_CHUNKS];
+    uint32_t ready[SCAN_RING];
+    uint16_t lstart[SCAN_WAVES][SCAN_LIST_CAP];
+    uint32_t hint_w[SCAN_WAVES][SCAN_HINT_WORDS];
+};
+
+__device__ __forceinline__ uint32_t lds_load_volatile(const uint32_t *p) { return *(const volatile uint32_t *)p; }
+__device__ __forceinline__ void lds_store_volatile(uint32_t *p, uint32_t v) { *(volatile uint32_t *)p = v; }
+
+__global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_ring(ScanArgs a, SiteSetDev ss) {
+    __shared__ RingShared sh;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = wave == SCAN_WAVES;
+    const uint32_t *bitmap = ss.bitmap, *rank = ss.rank;
+    uint32_t hits = 0, lines_seen = 0, any_hi = 0;
+    if (threadIdx.x < SCAN_RING) sh.ready[threadIdx.x] = 0;
+    Hint hint{};
+    if (!loader) hint = load_hint(ss, 0, sh.hint_w[wave], lane);
+    __syncthreads();                                          // the only barrier: ring flags initialised
+
+    // tile sequence of this workgroup: rounds of SCAN_WAVES consecutive 4 KiB tiles, round r at (r*gridDim + block)
+    const uint64_t n_tiles = a.n_btiles;                      // here: number of 4 KiB tiles
+    auto tile_of = [&](uint32_t n) { return ((uint64_t)(n / SCAN_WAVES) * gridDim.x + blockIdx.x) * SCAN_WAVES + (n % SCAN_WAVES); };
+    uint32_t total = 0;                                       // tiles of this workgroup
+    {
+        const uint64_t per_round = (uint64_t)gridDim.x * SCAN_WAVES;
+        const uint64_t first = (uint64_t)blockIdx.x * SCAN_WAVES;
+        if (first < n_tiles) {
+            const uint64_t full_rounds = (n_tiles - first) / per_round;       // rounds whose first tile exists
+            const uint64_t last_first = first + full_rounds * per_round;
+            total = (uint32_t)(full_rounds * SCAN_WAVES);
+            if (last_first < n_tiles) total += (uint32_t)((n_tiles - last_first) < SCAN_WAVES ? (n_tiles - last_first) : SCAN_WAVES);
+        }
+    }
+    auto interior = [&](uint64_t tt) { uint64_t x0 = tt * SCAN_TILE; return x0 >= a.lo + 16 && x0 + SCAN_TILE + SCAN_HALO <= a.hi; };
+
+    if (loader) {
+        uint32_t n_pub = 0;                                   // next tile to publish
+        for (uint32_t n = 0; n < total; ++n) {
+            const uint32_t slot = n % SCAN_RING;
+            while (lds_load_volatile(&sh.ready[slot]) != 0) __builtin_amdgcn_s_sleep(2);      // slot handed back?
+            const uint64_t tt = tile_of(n);
+            if (interior(tt)) {
+                const uint8_t *g = a.base + tt * SCAN_TILE - 16 + (size_t)lane * 16;
+                const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)&sh.slot[slot][0]);
+#pragma unroll
+                for (int r = 0; r < SCAN_DMA_PER_TILE; ++r) {
+                    // SCAN_DMA_PER_TILE wave-instructions per tile (the last one with a partial exec mask): the
+                    // counted vmcnt below relies on this count being exact
+                    const uint8_t *gp = g + (size_t)r * 1024;             // chunk r*64 + lane of the slot
+                    const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + r * 1024);
+                    if (r * 64 + lane < SCAN_WTILE_CHUNKS)
+                        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m0v) : "memory");
+                }
+                // tiles n-DEPTH and older have landed once at most DEPTH tiles' worth of DMA is outstanding
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SCAN_DEPTH * SCAN_DMA_PER_TILE) : "memory");
+                while (n_pub + SCAN_DEPTH <= n) { lds_store_volatile(&sh.ready[n_pub % SCAN_RING], n_pub + 1); ++n_pub; }
+            } else {                                          // first / last tiles: byte loads, outside bytes read as '\n'
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                while (n_pub < n) { lds_store_volatile(&sh.ready[n_pub % SCAN_RING], n_pub + 1); ++n_pub; }
+                const int64_t x0 = (int64_t)(tt * SCAN_TILE) - 16;
+#pragma nounroll
+                for (uint32_t e = lane; e < SCAN_WTILE_CHUNKS; e += 64) {
+                    uint32_t d[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            int64_t idx = x0 + (int64_t)e * 16 + 4 * k + j;
+                            uint32_t bb = (idx >= (int64_t)a.lo && idx < (int64_t)a.hi) ? (uint32_t)a.base[idx] : 10u;
+                            d[k] |= bb << (8 * j);
+                        }
+                    sh.slot[slot][e] = make_uint4(d[0], d[1], d[2], d[3]);
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                lds_store_volatile(&sh.ready[slot], n + 1);
+                n_pub = n + 1;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        while (n_pub < total) { lds_store_volatile(&sh.ready[n_pub % SCAN_RING], n_pub + 1); ++n_pub; }
+    } else {
+        uint64_t win_base = 0xFFFFFFFFFFFFFF00ull;           // bitmap window [win_base, win_base + 64) dwords; starts empty
+        uint32_t win_word = 0, win_rank = 0;
+        uint16_t *lstart = sh.lstart[wave];
+        const uint32_t *hint_w = sh.hint_w[wave];
+        for (uint32_t n = wave; n < total; n += SCAN_WAVES) {
+            const uint32_t slot = n % SCAN_RING;
+            while (lds_load_volatile(&sh.ready[slot]) != n + 1) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            const uint64_t tt = tile_of(n);
+            const uint64_t t0 = tt * SCAN_TILE;
+            const bool edge = !interior(tt);
+            const uint8_t *tile = (const uint8_t *)&sh.slot[slot][1];
+            const uint4 *tile16 = &sh.slot[slot][1];
+            do {                                                // one pass; `break` leaves the tile early
+                
+                // ---- B: terminator flags of four 16-byte chunks per lane (chunk i*64+lane: conflict-free LDS reads) ----
+                // bit 16*i + b of S: byte b of chunk i*64+lane is in 0x0A..0x0D; a line starts at the next byte.
+                // Straight-line code: no branch depends on the data unless the tile holds '\v' '\f' or '\r'.
+                uint64_t S;
+                uint32_t exo = 0;                                   // 0x80 where a byte is in 0x0B..0x0D
+                {
+                    uint32_t bits[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint4 v = tile16[i * 64 + lane];
+                        any_hi |= v.x | v.y | v.z | v.w;
+                        exo |= ((v.x + 0x75757575u) & ~(v.x + 0x72727272u)) | ((v.y + 0x75757575u) & ~(v.y + 0x72727272u)) |
+                               ((v.z + 0x75757575u) & ~(v.z + 0x72727272u)) | ((v.w + 0x75757575u) & ~(v.w + 0x72727272u));
+                        bits[i] = flags_to_bits16(term_flags(v.x), term_flags(v.y), term_flags(v.z), term_flags(v.w));
+                    }
+                    S = (uint64_t)(bits[0] | (bits[1] << 16)) | ((uint64_t)(bits[2] | (bits[3] << 16)) << 32);
+                }
+                // The last byte of the sub-tile (lane 63, chunk 3, byte 15) starts a line in the NEXT sub-tile, which
+                // sees it as its byte -1; byte 0 starts a line iff the byte before it ends a terminator.
+                if (lane == 63) S &= ~(1ull << 63);
+                const uint32_t pv0 = tile[-1], cv0 = tile[0];
+                bool s0 = (lane == 0) && (pv0 == 10u || (pv0 == 13u && cv0 != 10u));
+                if (__ballot((exo & 0x80808080u) != 0 || ((lane == 0) && (pv0 - 11u <= 2u)))) {
+                    S = 0;                                          // rare: '\r' (or '\v' '\f'): exact byte-wise index
+#pragma nounroll
+                    for (int i = 0; i < 4; ++i)
+#pragma nounroll
+                        for (int b = 0; b < 16; ++b) {
+                            const int q = (i * 64 + (int)lane) * 16 + b;
+                            const uint32_t cv = tile[q], nx = tile[q + 1];
+                            if (cv == 10u || (cv == 13u && nx != 10u)) S |= 1ull << (16 * i + b);
+                        }
+                    if (lane == 63) S &= ~(1ull << 63);
+                }
+                if (edge) {                                         // starts must lie inside the file
+#pragma nounroll
+                    for (int i = 0; i < 4; ++i)
+#pragma nounroll
+                        for (int b = 0; b < 16; ++b) {
+                            const uint64_t st = t0 + (uint64_t)((i * 64 + (int)lane) * 16 + b + 1);
+                            if (st < a.lo || st >= a.hi) S &= ~(1ull << (16 * i + b));
+                        }
+                    s0 = s0 && t0 >= a.lo && t0 < a.hi;
+                }
+                const uint32_t cnt = (uint32_t)__popcll(S) + (s0 ? 1u : 0u);
+                const uint32_t incl = wave_inclusive_sum(cnt);
+                const uint32_t n_lines = __builtin_amdgcn_readlane(incl, 63);
+                const uint32_t base = incl - cnt;
+                lines_seen += (lane == 0) ? n_lines : 0;
+                
+                
+
+                for (uint32_t pass0 = 0; pass0 < n_lines; pass0 += SCAN_LIST_CAP) {
+                    {   // list of the line starts [pass0, pass0 + CAP): two predicated slots, a loop only for lanes
+                        // with three or more starts in their 64 bytes (lines shorter than ~21 bytes)
+                        uint64_t s_bits = S;
+                        uint32_t idx = base - pass0;                // slots below 0 wrap to huge values and are skipped
+                        if (s0 && idx < SCAN_LIST_CAP) lstart[idx] = 0;
+                        idx += s0 ? 1u : 0u;
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const uint32_t bpos = (uint32_t)__ffsll((long long)s_bits) - 1;     // 0xFFFFFFFF when empty
+                            const bool have = s_bits != 0;
+                            if (have && idx < SCAN_LIST_CAP) lstart[idx] = (uint16_t)((((bpos >> 4) * 64 + lane) << 4) + (bpos & 15) + 1);
+                            idx += have ? 1u : 0u;
+                            s_bits &= s_bits - 1;
+                        }
+                        if (__ballot(s_bits != 0)) {
+                            while (s_bits) {
+                                const uint32_t bpos = (uint32_t)__ffsll((long long)s_bits) - 1;
+                                s_bits &= s_bits - 1;
+                                if (idx < SCAN_LIST_CAP) lstart[idx] = (uint16_t)((((bpos >> 4) * 64 + lane) << 4) + (bpos & 15) + 1);
+                                ++idx;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    
+                    const uint32_t n_here = n_lines - pass0 < SCAN_LIST_CAP ? n_lines - pass0 : SCAN_LIST_CAP;
+                    // ---- C: one lane per line ------------------------------------------------------------------
+                    {
+                        // Straight-line predicated code for "name SEP digits SEP"; a line that does not fit (other
+                        // contig, odd whitespace, > 10 digits, long name ...) is queued for the exact parser.
+                        // the hint is wave-uniform; say so (it came back from a call in VGPRs)
+                        const uint32_t L = __builtin_amdgcn_readfirstlane(hint.len);
+                        const uint32_t h_cid = __builtin_amdgcn_readfirstlane(hint.cid);
+                        const uint32_t h_max = __builtin_amdgcn_readfirstlane(hint.max_pos);
+                        const uint64_t h_off = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(hint.bit_off >> 32)) << 32) |
+                                               __builtin_amdgcn_readfirstlane((uint32_t)hint.bit_off);
+                        const bool hint_ok = h_cid != 0xFFFFFFFFu && L >= 1 && L <= 4 * SCAN_HINT_WORDS - 4;
+                        const uint32_t nw = (L + 3) >> 2;                               // dwords of the name
+                        for (uint32_t j0 = 0; j0 < n_here; j0 += 64) {
+                            const uint32_t j = j0 + lane;
+                            const bool active = j < n_here;
+                            const uint32_t s = active ? lstart[j] : 0u;
+                            const uint8_t *p = tile + s;
+                            bool fast = false;
+                            uint64_t pos = 0;
+                            if (hint_ok) {                                               // uniform
+                                uint32_t w[SCAN_HINT_WORDS];
+                                lds_window16(tile, (int)s, w[0], w[1], w[2], w[3]);
+                                if (nw > 4) lds_window16(tile, (int)s + 16, w[4], w[5], w[6], w[7]);        // uniform
+                                if (nw > 8) lds_window16(tile, (int)s + 32, w[8], w[9], w[10], w[11]);      // uniform
+                                uint32_t bad = 0;
+#pragma unroll
+                                for (int k = 0; k < SCAN_HINT_WORDS; ++k)
+                                    if ((uint32_t)k < nw) {                              // uniform
+                                        const uint32_t nb = L - 4 * k;                  // bytes of the name in this dword (uniform)
+                                        const uint32_t mk = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+                                        bad |= (w[k] ^ hint_w[k]) & mk;
+                                    }
+                                const uint32_t c1 = p[L];                                // the separator after the name
+                                uint4 q1;
+                                lds_window16(tile, (int)(s + L + 1), q1.x, q1.y, q1.z, q1.w);      // digits + separator
+                                // first byte <= 0x20 in the 16-byte window = number of digits
+                                const uint32_t ctl = flags_to_bits16(le20_flags(q1.x), le20_flags(q1.y), le20_flags(q1.z), le20_flags(q1.w));
+                                uint32_t nd = (uint32_t)__ffs((int)ctl) - 1u;            // ctl == 0 -> 0xFFFFFFFF
+                                bad |= (nd - 1u > 9u) ? 1u : 0u;
+                                nd = nd > 10u ? 10u : nd;
+                                uint4 q;
+                                lds_window16(tile, (int)(s + L + 1 + nd) - 15, q.x, q.y, q.z, q.w);  // the digits end at byte 14 of this window
+                                const uint32_t c2 = q.w >> 24;
+                                // separators of the fast path: TAB or space after the name; TAB, space or '\n' after the digits
+                                bad |= (c1 != 9u && c1 != 32u) ? 1u : 0u;
+                                bad |= (c2 != 9u && c2 != 32u && c2 != 10u) ? 1u : 0u;
+                                const uint32_t first = 15u - nd;                          // window index of the first digit (5..14)
+                                uint32_t x1 = q.y ^ 0x30303030u, x2 = q.z ^ 0x30303030u, x3 = (q.w ^ 0x30303030u) & 0x00FFFFFFu;
+                                const uint32_t d1 = first > 4 ? first - 4 : 0, d2 = first > 8 ? first - 8 : 0, d3 = first > 12 ? first - 12 : 0;
+                                x1 = d1 >= 4 ? 0u : x1 & (0xFFFFFFFFu << (8 * d1));
+                                x2 = d2 >= 4 ? 0u : x2 & (0xFFFFFFFFu << (8 * d2));
+                                x3 = x3 & (0xFFFFFFFFu << (8 * d3));
+                                bad |= (((x1 + 0x76767676u) | x1) | ((x2 + 0x76767676u) | x2) | ((x3 + 0x76767676u) | x3)) & 0x80808080u;
+                                pos = ((uint64_t)(four_digits(x1) * 10000u + four_digits(x2))) * 1000ull + four_digits(x3 << 8);
+                                fast = bad == 0;
+                            }
+                            const uint64_t off1 = t0 + (uint64_t)s - a.lo + 1;
+                            if (active && !fast) {                                       // rare: leave it to k_scan_queue
+                                const uint32_t qi = atomicAdd(&a.ctl[0], 1u);
+                                if (qi < a.q_cap) a.queue[qi] = off1 - 1; else a.ctl[1] = 1u;
+                            }
+                            const bool probe = active && fast && pos <= (uint64_t)h_max;
+                            // Site bitmap probe without touching memory: the wave keeps a 64-dword window of the
+                            // bitmap (and of its rank directory) in two VGPRs, one dword per lane; a pileup is
+                            // position sorted, so a window (2048 positions) serves ~40 tiles before it is refilled
+                            // with two coalesced 256-byte loads.  Lookup = ds_bpermute (cross-lane, no LDS memory).
+                            const uint64_t bit = h_off + (uint32_t)pos;
+                            const uint64_t wi = bit >> 5;
+                            uint32_t word = 0, rk = 0;
+                            bool done = !probe;
+                            for (;;) {
+                                const uint64_t rel = wi - win_base;
+                                const int sel = (int)(((uint32_t)rel & 63u) << 2);
+                                const uint32_t w_ = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)win_word);
+                                const uint32_t r_ = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)win_rank);
+                                if (!done && rel < 64) { word = w_; rk = r_; done = true; }
+                                const uint64_t miss = __ballot(!done);
+                                if (!miss) break;
+                                const uint32_t src = (uint32_t)__ffsll((long long)miss) - 1;
+                                win_base = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(wi >> 32), src) << 32) |
+                                           __builtin_amdgcn_readlane((uint32_t)wi, src);
+                                const bool inb = win_base + lane < ss.n_words;
+                                win_word = inb ? bitmap[win_base + lane] : 0u;
+                                win_rank = inb ? rank[win_base + lane] : 0u;
+                            }
+                            const uint32_t shf = (uint32_t)(bit & 31);
+                            if ((word >> shf) & 1u) {
+                                const uint32_t site = rk + __popc(word & ((1u << shf) - 1u));
+                                atomicMax((unsigned long long *)&a.site_line[site], (unsigned long long)off1);
+                                ++hits;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    
+                }
+            } while (false);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of the slot has returned
+            lds_store_volatile(&sh.ready[slot], 0);
+        }
+    }
+    // a byte >= 0x80 anywhere in this wave's share of the file (checked once: the answers are void anyway)
+    if (__ballot((any_hi & 0x80808080u) != 0) && lane == 0) report_scan_error(a.status, 0, SCAN_ERR_NON_ASCII);
+    for (int o = 32; o; o >>= 1) { hits += __shfl_xor(hits, o); lines_seen += __shfl_xor(lines_seen, o); }
+    if (lane == 0) {
+        if (hits) atomicAdd((unsigned long long *)&a.status[2], (unsigned long long)hits);
+        if (lines_seen) atomicAdd((unsigned long long *)&a.status[1], (unsigned long long)lines_seen);
+    }
+}
+
 // The exact parser over the queued lines (one lane per line, bytes read straight from global memory).
 __global__ __launch_bounds__(256) void k_scan_queue(ScanArgs a, SiteSetDev ss) {
     const uint32_t n = a.ctl[0];
@@ -546,7 +846,7 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t
     static int blocks_per_cu = -1, mode = 0;
     if (blocks_per_cu < 0) {                                // tuning knobs (development only)
         const char *b = getenv("SNPGPU_SCAN_BLOCKS_PER_CU"), *m = getenv("SNPGPU_SCAN_MODE");
-        blocks_per_cu = b ? atoi(b) : 2;
+        blocks_per_cu = b ? atoi(b) : 3;
         mode = m ? atoi(m) : 0;
     }
     uint64_t max_blocks = (uint64_t)ctx->n_cu * blocks_per_cu;
@@ -572,7 +872,14 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t
             fprintf(stderr, "scan phases (cycles summed over waves): consumer B %llu list %llu C %llu barrier %llu | loader load+wait %llu barrier %llu | blocks %u\n",
                     h[0], h[1], h[2], h[3], h[9], h[8], grid);
         }
-        else k_scan_pileup<0, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
+        else if (mode == 7) k_scan_pileup<0, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);   // barrier version
+        else {
+            ScanArgs ra = sa;
+            ra.n_btiles = (sa.hi + SCAN_TILE - 1) / SCAN_TILE;          // 4 KiB tiles
+            uint64_t want = (ra.n_btiles + SCAN_WAVES - 1) / SCAN_WAVES;
+            unsigned rgrid = (unsigned)(want < max_blocks ? want : max_blocks);
+            k_scan_ring<<<rgrid, SCAN_THREADS, 0, st>>>(ra, ss->dev);
+        }
     }
     snpgpu_time_end(ctx, SNPGPU_K_SCAN, ta);
     if (!want_depth) {
