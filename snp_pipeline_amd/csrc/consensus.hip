@@ -118,9 +118,13 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
             if (lane < 6) { L.fs[lane] = 0xFFFFFFFFu; L.fe[lane] = 0xFFFFFFFFu; }
             uint32_t nfields = 0, line_len = 0;
             bool prev_ws = true;
+            // the first 192 bytes are requested at once (one memory round trip covers a typical 30x line)
+            const uint32_t pre0 = ls + lane < a.nbytes ? a.buf[ls + lane] : 10u;
+            const uint32_t pre1 = ls + 64 + lane < a.nbytes ? a.buf[ls + 64 + lane] : 10u;
+            const uint32_t pre2 = ls + 128 + lane < a.nbytes ? a.buf[ls + 128 + lane] : 10u;
             for (uint64_t k = 0;; k += 64) {
                 uint64_t p = ls + k + lane;
-                uint32_t c = p < a.nbytes ? a.buf[p] : 10u;
+                uint32_t c = k == 0 ? pre0 : (k == 64 ? pre1 : (k == 128 ? pre2 : (p < a.nbytes ? a.buf[p] : 10u)));
                 if (k + lane < CALL_LBUF) L.line[k + lane] = (uint8_t)c;
                 uint64_t T = __ballot(is_term(c));
                 uint64_t valid = T ? low_mask((uint32_t)__ffsll((long long)T)) : ~0ull;   // up to and incl. the terminator

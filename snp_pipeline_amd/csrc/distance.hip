@@ -48,6 +48,7 @@ struct DistArgs {
     uint32_t n, words, n_tiles;     // n_tiles = ceil(n / DIST_TILE)
     uint32_t tile_rank, tile_nranks;
     uint64_t total_tiles;           // n_tiles * (n_tiles + 1) / 2
+    uint32_t k_parts, k_chunk;      // split-K: the words are cut in k_parts ranges of k_chunk words (small matrices)
     int32_t *out;
 };
 
@@ -64,13 +65,20 @@ __device__ __forceinline__ void tile_coords(uint64_t t, uint32_t nt, uint32_t &b
     bj = (uint32_t)(b + (t - start(b)));
 }
 
+// kSplit: a few tiles only (small sample counts): every tile is shared by k_parts workgroups, each sums its range of
+// words and adds it to the (zeroed) output with integer atomics — the result does not depend on the order.
+template <bool kSplit>
 __global__ __launch_bounds__(DIST_THREADS) void k_distance(DistArgs a) {
     __shared__ uint4 xs[DIST_KW][DIST_TILE];
     __shared__ uint4 ys[DIST_KW][DIST_TILE];
     const uint32_t tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    for (uint64_t g = blockIdx.x;; g += gridDim.x) {
+    for (uint64_t gg = blockIdx.x;; gg += gridDim.x) {
+        const uint64_t g = kSplit ? gg / a.k_parts : gg;
+        const uint32_t part = kSplit ? (uint32_t)(gg % a.k_parts) : 0;
         uint64_t t = (uint64_t)a.tile_rank + g * a.tile_nranks;
         if (t >= a.total_tiles) break;
+        const uint32_t k_begin = kSplit ? part * a.k_chunk : 0;
+        const uint32_t k_end = kSplit ? (k_begin + a.k_chunk < a.words ? k_begin + a.k_chunk : a.words) : a.words;
         uint32_t bi, bj;
         tile_coords(t, a.n_tiles, bi, bj);
         const uint32_t r0 = bi * DIST_TILE, c0 = bj * DIST_TILE;
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(DIST_THREADS) void k_distance(DistArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = 0;
 
-        for (uint32_t k0 = 0; k0 < a.words; k0 += DIST_KW) {
+        for (uint32_t k0 = k_begin; k0 < k_end; k0 += DIST_KW) {
             __syncthreads();
             // stage 128 rows x DIST_KW words of both operands: consecutive lanes walk the words of a row
 #pragma unroll
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(DIST_THREADS) void k_distance(DistArgs a) {
                 uint32_t kk = idx % DIST_KW, rr = idx / DIST_KW;
                 uint32_t w = k0 + kk;
                 uint4 zx = make_uint4(0, 0, 0, 0), zy = zx;
-                if (w < a.words) {
+                if (w < k_end) {
                     if (r0 + rr < a.n) zx = a.packed[(size_t)(r0 + rr) * a.words + w];
                     if (c0 + rr < a.n) zy = a.packed[(size_t)(c0 + rr) * a.words + w];
                 }
@@ -121,9 +129,30 @@ __global__ __launch_bounds__(DIST_THREADS) void k_distance(DistArgs a) {
             for (int j = 0; j < 8; ++j) {
                 uint32_t c = c0 + tx + 16 * j;
                 if (c >= a.n) continue;
-                a.out[(size_t)r * a.n + c] = acc[i][j];
-                if (bi != bj) a.out[(size_t)c * a.n + r] = acc[i][j];
+                if (kSplit) {
+                    if (acc[i][j]) {
+                        atomicAdd(&a.out[(size_t)r * a.n + c], acc[i][j]);
+                        if (bi != bj) atomicAdd(&a.out[(size_t)c * a.n + r], acc[i][j]);
+                    }
+                } else {
+                    a.out[(size_t)r * a.n + c] = acc[i][j];
+                    if (bi != bj) a.out[(size_t)c * a.n + r] = acc[i][j];
+                }
             }
+        }
+    }
+}
+
+// zero the tiles (and mirror images) a rank owns, before a split-K accumulation
+__global__ __launch_bounds__(DIST_THREADS) void k_distance_zero(DistArgs a) {
+    for (uint64_t g = blockIdx.x;; g += gridDim.x) {
+        uint64_t t = (uint64_t)a.tile_rank + g * a.tile_nranks;
+        if (t >= a.total_tiles) break;
+        uint32_t bi, bj;
+        tile_coords(t, a.n_tiles, bi, bj);
+        for (uint32_t e = threadIdx.x; e < DIST_TILE * DIST_TILE; e += DIST_THREADS) {
+            uint32_t r = bi * DIST_TILE + e / DIST_TILE, c = bj * DIST_TILE + e % DIST_TILE;
+            if (r < a.n && c < a.n) { a.out[(size_t)r * a.n + c] = 0; a.out[(size_t)c * a.n + r] = 0; }
         }
     }
 }
@@ -163,8 +192,20 @@ int snpgpu_distance_packed_dev(snpgpu_ctx *ctx, const void *d_packed, uint32_t n
     uint64_t mine = a.total_tiles > tile_rank ? (a.total_tiles - tile_rank + tile_nranks - 1) / tile_nranks : 0;
     if (mine == 0) return SNPGPU_OK;
     uint64_t cap = (uint64_t)ctx->n_cu * 64;
+    a.k_parts = 1;
+    a.k_chunk = a.words;
     hipEvent_t ta = snpgpu_time_begin(ctx);
-    k_distance<<<(unsigned)(mine < cap ? mine : cap), DIST_THREADS, 0, ctx->stream>>>(a);
+    if (mine < (uint64_t)ctx->n_cu && a.words >= 4 * DIST_KW) {        // too few tiles to fill the chip: split the word range
+        uint64_t parts = ((uint64_t)ctx->n_cu * 2 + mine - 1) / mine;
+        uint64_t max_parts = a.words / (2 * DIST_KW);
+        if (parts > max_parts) parts = max_parts;
+        a.k_chunk = (uint32_t)(((a.words + parts - 1) / parts + DIST_KW - 1) / DIST_KW * DIST_KW);
+        a.k_parts = (a.words + a.k_chunk - 1) / a.k_chunk;
+        k_distance_zero<<<(unsigned)mine, DIST_THREADS, 0, ctx->stream>>>(a);
+        k_distance<true><<<(unsigned)(mine * a.k_parts), DIST_THREADS, 0, ctx->stream>>>(a);
+    } else {
+        k_distance<false><<<(unsigned)(mine < cap ? mine : cap), DIST_THREADS, 0, ctx->stream>>>(a);
+    }
     snpgpu_time_end(ctx, SNPGPU_K_DISTANCE, ta);
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;

@@ -497,114 +497,120 @@ __global__ __launch_bounds__(SCAN_THREADS, kExact ? 2 : 4) void k_scan_pileup(Sc
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The hot kernel: barrier-free ring.  One loader wave keeps a ring of SCAN_RING self-contained 4 KiB (+halo) slots
-// full with LDS-DMA, always SCAN_DEPTH+1 tiles in flight (counted vmcnt, so a slot is published the moment its own
-// DMA has landed); SCAN_WAVES consumer waves take tiles n = w, w+4, ... from slot n % SCAN_RING, parse them (phases
-// B and C above, fast path only) and hand the slot back.  Hand-off is an LDS word per slot (tile sequence number + 1
-// when full, 0 when free); nobody ever waits at a workgroup barrier, so a slow consumer stalls neither the loader
-// nor its siblings.
-#define SCAN_RING 8
-#define SCAN_DEPTH 3                         // tiles in flight behind the newest one
-#define SCAN_DMA_PER_TILE ((SCAN_WTILE_CHUNKS + 63) / 64)
+// The hot kernel.  Every wavefront is an independent stream: it owns SCAN_NBUF LDS slots of one 4 KiB tile (+ halo),
+// requests tile k+1 with LDS-DMA (global_load_lds_dwordx4, 64 lanes x 16 B straight into LDS, no VGPR round trip)
+// before it parses tile k, and waits for its own DMA with a counted s_waitcnt — no workgroup barrier, no flags, no
+// polling.  The DMA goes through inline asm on purpose: hipcc orders every LDS read behind a *tracked* LDS-DMA with
+// vmcnt(0), which would serialise fetch and parse; the steady-state parse issues no other vector-memory load (the
+// site bitmap is probed through a register window), so the explicit counted wait is the only one on the path.
+#define SCAN_NBUF 2
 #define SCAN_WTILE_CHUNKS ((16 + SCAN_TILE + SCAN_HALO) / 16)
+#define SCAN_DMA_PER_TILE ((SCAN_WTILE_CHUNKS + 63) / 64)
 
-struct RingShared {
-    uint4 slot[SCAN_RING][SCAN_WTILE_CHUNKS];
-    uint32_t ready[SCAN_RING];
-    uint16_t lstart[SCAN_WAVES][SCAN_LIST_CAP];
-    uint32_t hint_w[SCAN_WAVES][SCAN_HINT_WORDS];
+struct WaveSlots {
+    uint4 slot[SCAN_NBUF][SCAN_WTILE_CHUNKS];
+    uint16_t lstart[SCAN_LIST_CAP];
+    uint32_t hint_w[SCAN_HINT_WORDS];
+    uint32_t hint_m[SCAN_HINT_WORDS];
+};
+struct WaveBlockShared {
+    WaveSlots w[SCAN_WAVES];
+    uint4 digit_mask[16];
 };
 
-__device__ __forceinline__ uint32_t lds_load_volatile(const uint32_t *p) { return *(const volatile uint32_t *)p; }
-__device__ __forceinline__ void lds_store_volatile(uint32_t *p, uint32_t v) { *(volatile uint32_t *)p = v; }
-
-__global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_ring(ScanArgs a, SiteSetDev ss) {
-    __shared__ RingShared sh;
+__global__ __launch_bounds__(SCAN_WAVES * 64, 4) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
+    __shared__ WaveBlockShared sh;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool loader = wave == SCAN_WAVES;
+    WaveSlots &ws = sh.w[wave];
     const uint32_t *bitmap = ss.bitmap, *rank = ss.rank;
     uint32_t hits = 0, lines_seen = 0, any_hi = 0;
-    if (threadIdx.x < SCAN_RING) sh.ready[threadIdx.x] = 0;
-    Hint hint{};
-    if (!loader) hint = load_hint(ss, 0, sh.hint_w[wave], lane);
-    __syncthreads();                                          // the only barrier: ring flags initialised
-
-    // tile sequence of this workgroup: rounds of SCAN_WAVES consecutive 4 KiB tiles, round r at (r*gridDim + block)
-    const uint64_t n_tiles = a.n_btiles;                      // here: number of 4 KiB tiles
-    auto tile_of = [&](uint32_t n) { return ((uint64_t)(n / SCAN_WAVES) * gridDim.x + blockIdx.x) * SCAN_WAVES + (n % SCAN_WAVES); };
-    uint32_t total = 0;                                       // tiles of this workgroup
-    {
-        const uint64_t per_round = (uint64_t)gridDim.x * SCAN_WAVES;
-        const uint64_t first = (uint64_t)blockIdx.x * SCAN_WAVES;
-        if (first < n_tiles) {
-            const uint64_t full_rounds = (n_tiles - first) / per_round;       // rounds whose first tile exists
-            const uint64_t last_first = first + full_rounds * per_round;
-            total = (uint32_t)(full_rounds * SCAN_WAVES);
-            if (last_first < n_tiles) total += (uint32_t)((n_tiles - last_first) < SCAN_WAVES ? (n_tiles - last_first) : SCAN_WAVES);
+    if (threadIdx.x < 16) {                                   // digit_mask[nd]: byte masks keeping the last nd bytes of window bytes 4..14
+        const uint32_t nd = threadIdx.x > 10 ? 10 : threadIdx.x, first = 15u - nd;
+        uint32_t m[3];
+        for (int g = 0; g < 3; ++g) {
+            uint32_t v = 0;
+            for (uint32_t bb = 0; bb < 4; ++bb) { uint32_t idx = 4 + 4 * g + bb; if (idx >= first && idx <= 14) v |= 0xFFu << (8 * bb); }
+            m[g] = v;
         }
+        sh.digit_mask[threadIdx.x] = make_uint4(m[0], m[1], m[2], 0);
     }
-    auto interior = [&](uint64_t tt) { uint64_t x0 = tt * SCAN_TILE; return x0 >= a.lo + 16 && x0 + SCAN_TILE + SCAN_HALO <= a.hi; };
+    Hint hint = load_hint(ss, 0, ws.hint_w, lane);
+    __syncthreads();                                          // the only barrier: digit_mask table visible
 
-    if (loader) {
-        uint32_t n_pub = 0;                                   // next tile to publish
-        for (uint32_t n = 0; n < total; ++n) {
-            const uint32_t slot = n % SCAN_RING;
-            while (lds_load_volatile(&sh.ready[slot]) != 0) __builtin_amdgcn_s_sleep(2);      // slot handed back?
-            const uint64_t tt = tile_of(n);
-            if (interior(tt)) {
-                const uint8_t *g = a.base + tt * SCAN_TILE - 16 + (size_t)lane * 16;
-                const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)&sh.slot[slot][0]);
+    const uint64_t n_tiles = a.n_btiles;                      // here: number of 4 KiB tiles
+    const uint64_t gwave = (uint64_t)blockIdx.x * SCAN_WAVES + wave, n_waves = (uint64_t)gridDim.x * SCAN_WAVES;
+    auto interior = [&](uint64_t tt) { uint64_t x0 = tt * SCAN_TILE; return x0 >= a.lo + 16 && x0 + SCAN_TILE + SCAN_HALO <= a.hi; };
+    // request tile tt into slot `buf`; returns the number of DMA wave-instructions now in flight for it (0: staged synchronously)
+    auto request = [&](uint64_t tt, int buf) -> uint32_t {
+        if (interior(tt)) {
+            const uint8_t *g = a.base + tt * SCAN_TILE - 16 + (size_t)lane * 16;
+            const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)&ws.slot[buf][0]);
 #pragma unroll
-                for (int r = 0; r < SCAN_DMA_PER_TILE; ++r) {
-                    // SCAN_DMA_PER_TILE wave-instructions per tile (the last one with a partial exec mask): the
-                    // counted vmcnt below relies on this count being exact
-                    const uint8_t *gp = g + (size_t)r * 1024;             // chunk r*64 + lane of the slot
-                    const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + r * 1024);
-                    if (r * 64 + lane < SCAN_WTILE_CHUNKS)
-                        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m0v) : "memory");
-                }
-                // tiles n-DEPTH and older have landed once at most DEPTH tiles' worth of DMA is outstanding
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SCAN_DEPTH * SCAN_DMA_PER_TILE) : "memory");
-                while (n_pub + SCAN_DEPTH <= n) { lds_store_volatile(&sh.ready[n_pub % SCAN_RING], n_pub + 1); ++n_pub; }
-            } else {                                          // first / last tiles: byte loads, outside bytes read as '\n'
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                while (n_pub < n) { lds_store_volatile(&sh.ready[n_pub % SCAN_RING], n_pub + 1); ++n_pub; }
-                const int64_t x0 = (int64_t)(tt * SCAN_TILE) - 16;
-#pragma nounroll
-                for (uint32_t e = lane; e < SCAN_WTILE_CHUNKS; e += 64) {
-                    uint32_t d[4] = {0, 0, 0, 0};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            int64_t idx = x0 + (int64_t)e * 16 + 4 * k + j;
-                            uint32_t bb = (idx >= (int64_t)a.lo && idx < (int64_t)a.hi) ? (uint32_t)a.base[idx] : 10u;
-                            d[k] |= bb << (8 * j);
-                        }
-                    sh.slot[slot][e] = make_uint4(d[0], d[1], d[2], d[3]);
-                }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                lds_store_volatile(&sh.ready[slot], n + 1);
-                n_pub = n + 1;
+            for (int r = 0; r < SCAN_DMA_PER_TILE; ++r) {
+                const uint8_t *gp = g + (size_t)r * 1024;                 // chunk r*64 + lane of the slot
+                const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + r * 1024);
+                if (r * 64 + lane < SCAN_WTILE_CHUNKS)                     // the last instruction has a partial exec mask
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m0v) : "memory");
             }
+            return SCAN_DMA_PER_TILE;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        while (n_pub < total) { lds_store_volatile(&sh.ready[n_pub % SCAN_RING], n_pub + 1); ++n_pub; }
-    } else {
-        uint64_t win_base = 0xFFFFFFFFFFFFFF00ull;           // bitmap window [win_base, win_base + 64) dwords; starts empty
-        uint32_t win_word = 0, win_rank = 0;
-        uint16_t *lstart = sh.lstart[wave];
-        const uint32_t *hint_w = sh.hint_w[wave];
-        for (uint32_t n = wave; n < total; n += SCAN_WAVES) {
-            const uint32_t slot = n % SCAN_RING;
-            while (lds_load_volatile(&sh.ready[slot]) != n + 1) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-            const uint64_t tt = tile_of(n);
+        // first / last tiles of the file: byte loads, bytes outside [lo,hi) read as '\n'
+        const int64_t x0 = (int64_t)(tt * SCAN_TILE) - 16;
+#pragma nounroll
+        for (uint32_t e = lane; e < SCAN_WTILE_CHUNKS; e += 64) {
+            uint32_t d[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int64_t idx = x0 + (int64_t)e * 16 + 4 * k + j;
+                    uint32_t bb = (idx >= (int64_t)a.lo && idx < (int64_t)a.hi) ? (uint32_t)a.base[idx] : 10u;
+                    d[k] |= bb << (8 * j);
+                }
+            ws.slot[buf][e] = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+        return 0;
+    };
+
+    uint64_t win_base = 0xFFFFFFFFFFFFFF00ull;               // bitmap window [win_base, win_base + 64) dwords; starts empty
+    uint32_t win_word = 0, win_rank = 0;
+    uint16_t *lstart = ws.lstart;
+    const uint32_t *hint_w = ws.hint_w;
+    const uint32_t *hint_m = ws.hint_m;
+        // the wave's contig hint (uniform): name words / byte masks of the first 16 bytes live in registers
+        const uint32_t L = __builtin_amdgcn_readfirstlane(hint.len);
+        const uint32_t h_max = __builtin_amdgcn_readfirstlane(hint.max_pos);
+        const uint64_t h_off = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(hint.bit_off >> 32)) << 32) |
+                               __builtin_amdgcn_readfirstlane((uint32_t)hint.bit_off);
+        const uint32_t hint_bad = (__builtin_amdgcn_readfirstlane(hint.cid) != 0xFFFFFFFFu && L >= 1 && L <= 4 * SCAN_HINT_WORDS - 4) ? 0u : 1u;
+        const bool hint_long = L > 15;
+        uint32_t hw[4], hm[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            hw[k] = hint_w[k];
+            const uint32_t nb = L > 4u * k ? L - 4u * k : 0u;
+            hm[k] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+        }
+        if (lane < SCAN_HINT_WORDS) {
+            const uint32_t nb = L > 4u * lane ? L - 4u * lane : 0u;
+            ws.hint_m[lane] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+        }
+
+    uint32_t dma_next = 0;                                    // DMA instructions in flight for the tile after the current one
+    if (gwave < n_tiles) (void)request(gwave, 0);
+    if (gwave + n_waves < n_tiles) dma_next = request(gwave + n_waves, 1);
+    int cur = 0;
+    for (uint64_t tt = gwave; tt < n_tiles; tt += n_waves, cur ^= 1) {
+        // the current tile's DMA has landed when only the next tile's requests are still outstanding
+        if (dma_next) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SCAN_DMA_PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        {
             const uint64_t t0 = tt * SCAN_TILE;
             const bool edge = !interior(tt);
-            const uint8_t *tile = (const uint8_t *)&sh.slot[slot][1];
-            const uint4 *tile16 = &sh.slot[slot][1];
+            const uint8_t *tile = (const uint8_t *)&ws.slot[cur][1];
+            const uint4 *tile16 = &ws.slot[cur][1];
             do {                                                // one pass; `break` leaves the tile early
                 
                 // ---- B: terminator flags of four 16-byte chunks per lane (chunk i*64+lane: conflict-free LDS reads) ----
@@ -688,66 +694,48 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_ring(ScanArgs a, SiteS
                     const uint32_t n_here = n_lines - pass0 < SCAN_LIST_CAP ? n_lines - pass0 : SCAN_LIST_CAP;
                     // ---- C: one lane per line ------------------------------------------------------------------
                     {
-                        // Straight-line predicated code for "name SEP digits SEP"; a line that does not fit (other
-                        // contig, odd whitespace, > 10 digits, long name ...) is queued for the exact parser.
-                        // the hint is wave-uniform; say so (it came back from a call in VGPRs)
-                        const uint32_t L = __builtin_amdgcn_readfirstlane(hint.len);
-                        const uint32_t h_cid = __builtin_amdgcn_readfirstlane(hint.cid);
-                        const uint32_t h_max = __builtin_amdgcn_readfirstlane(hint.max_pos);
-                        const uint64_t h_off = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(hint.bit_off >> 32)) << 32) |
-                                               __builtin_amdgcn_readfirstlane((uint32_t)hint.bit_off);
-                        const bool hint_ok = h_cid != 0xFFFFFFFFu && L >= 1 && L <= 4 * SCAN_HINT_WORDS - 4;
-                        const uint32_t nw = (L + 3) >> 2;                               // dwords of the name
+                        // Straight-line code for "name SEP digits SEP" with as little scalar/exec traffic as possible:
+                        // every test lands in one per-lane `bad` word; a line that does not fit (other contig, odd
+                        // whitespace, > 10 digits, long name ...) is queued for the exact parser.
                         for (uint32_t j0 = 0; j0 < n_here; j0 += 64) {
                             const uint32_t j = j0 + lane;
                             const bool active = j < n_here;
                             const uint32_t s = active ? lstart[j] : 0u;
-                            const uint8_t *p = tile + s;
-                            bool fast = false;
-                            uint64_t pos = 0;
-                            if (hint_ok) {                                               // uniform
-                                uint32_t w[SCAN_HINT_WORDS];
-                                lds_window16(tile, (int)s, w[0], w[1], w[2], w[3]);
-                                if (nw > 4) lds_window16(tile, (int)s + 16, w[4], w[5], w[6], w[7]);        // uniform
-                                if (nw > 8) lds_window16(tile, (int)s + 32, w[8], w[9], w[10], w[11]);      // uniform
-                                uint32_t bad = 0;
-#pragma unroll
-                                for (int k = 0; k < SCAN_HINT_WORDS; ++k)
-                                    if ((uint32_t)k < nw) {                              // uniform
-                                        const uint32_t nb = L - 4 * k;                  // bytes of the name in this dword (uniform)
-                                        const uint32_t mk = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
-                                        bad |= (w[k] ^ hint_w[k]) & mk;
-                                    }
-                                const uint32_t c1 = p[L];                                // the separator after the name
-                                uint4 q1;
-                                lds_window16(tile, (int)(s + L + 1), q1.x, q1.y, q1.z, q1.w);      // digits + separator
-                                // first byte <= 0x20 in the 16-byte window = number of digits
-                                const uint32_t ctl = flags_to_bits16(le20_flags(q1.x), le20_flags(q1.y), le20_flags(q1.z), le20_flags(q1.w));
-                                uint32_t nd = (uint32_t)__ffs((int)ctl) - 1u;            // ctl == 0 -> 0xFFFFFFFF
-                                bad |= (nd - 1u > 9u) ? 1u : 0u;
-                                nd = nd > 10u ? 10u : nd;
-                                uint4 q;
-                                lds_window16(tile, (int)(s + L + 1 + nd) - 15, q.x, q.y, q.z, q.w);  // the digits end at byte 14 of this window
-                                const uint32_t c2 = q.w >> 24;
-                                // separators of the fast path: TAB or space after the name; TAB, space or '\n' after the digits
-                                bad |= (c1 != 9u && c1 != 32u) ? 1u : 0u;
-                                bad |= (c2 != 9u && c2 != 32u && c2 != 10u) ? 1u : 0u;
-                                const uint32_t first = 15u - nd;                          // window index of the first digit (5..14)
-                                uint32_t x1 = q.y ^ 0x30303030u, x2 = q.z ^ 0x30303030u, x3 = (q.w ^ 0x30303030u) & 0x00FFFFFFu;
-                                const uint32_t d1 = first > 4 ? first - 4 : 0, d2 = first > 8 ? first - 8 : 0, d3 = first > 12 ? first - 12 : 0;
-                                x1 = d1 >= 4 ? 0u : x1 & (0xFFFFFFFFu << (8 * d1));
-                                x2 = d2 >= 4 ? 0u : x2 & (0xFFFFFFFFu << (8 * d2));
-                                x3 = x3 & (0xFFFFFFFFu << (8 * d3));
-                                bad |= (((x1 + 0x76767676u) | x1) | ((x2 + 0x76767676u) | x2) | ((x3 + 0x76767676u) | x3)) & 0x80808080u;
-                                pos = ((uint64_t)(four_digits(x1) * 10000u + four_digits(x2))) * 1000ull + four_digits(x3 << 8);
-                                fast = bad == 0;
+                            uint32_t bad = hint_bad;                                     // uniform: no usable hint
+                            // name: masked dword compare (masks are zero past the name)
+                            uint32_t w0, w1, w2, w3;
+                            lds_window16(tile, (int)s, w0, w1, w2, w3);
+                            bad |= ((w0 ^ hw[0]) & hm[0]) | ((w1 ^ hw[1]) & hm[1]) | ((w2 ^ hw[2]) & hm[2]) | ((w3 ^ hw[3]) & hm[3]);
+                            if (hint_long) {                                             // uniform: names of 16..44 bytes
+                                uint32_t v0, v1, v2, v3;
+                                lds_window16(tile, (int)s + 16, v0, v1, v2, v3);
+                                bad |= ((v0 ^ hint_w[4]) & hint_m[4]) | ((v1 ^ hint_w[5]) & hint_m[5]) | ((v2 ^ hint_w[6]) & hint_m[6]) | ((v3 ^ hint_w[7]) & hint_m[7]);
+                                lds_window16(tile, (int)s + 32, v0, v1, v2, v3);
+                                bad |= ((v0 ^ hint_w[8]) & hint_m[8]) | ((v1 ^ hint_w[9]) & hint_m[9]) | ((v2 ^ hint_w[10]) & hint_m[10]) | ((v3 ^ hint_w[11]) & hint_m[11]);
                             }
+                            const uint32_t c1 = tile[s + L];                             // the separator after the name
+                            uint4 q1;
+                            lds_window16(tile, (int)(s + L + 1), q1.x, q1.y, q1.z, q1.w);       // digits + separator
+                            // first byte <= 0x20 in the 16-byte window = number of digits (1..10 on the fast path)
+                            const uint32_t ctl = flags_to_bits16(le20_flags(q1.x), le20_flags(q1.y), le20_flags(q1.z), le20_flags(q1.w));
+                            const uint32_t nd_raw = (uint32_t)__ffs((int)ctl) - 1u;      // ctl == 0 -> 0xFFFFFFFF
+                            bad |= (uint32_t)(nd_raw - 1u > 9u);
+                            const uint32_t nd = nd_raw > 10u ? 10u : nd_raw;
+                            uint4 q;
+                            lds_window16(tile, (int)(s + L + 1 + nd) - 15, q.x, q.y, q.z, q.w);  // the digits end at byte 14 of this window
+                            const uint4 dm = sh.digit_mask[nd];                          // keeps the nd digit bytes of q.y q.z q.w
+                            const uint32_t c2 = q.w >> 24;
+                            // separators of the fast path: TAB or space after the name; TAB, space or '\n' after the digits
+                            bad |= min(c1 ^ 9u, c1 ^ 32u) | min(min(c2 ^ 9u, c2 ^ 32u), c2 ^ 10u);
+                            const uint32_t x1 = (q.y ^ 0x30303030u) & dm.x, x2 = (q.z ^ 0x30303030u) & dm.y, x3 = (q.w ^ 0x30303030u) & dm.z;
+                            bad |= (((x1 + 0x76767676u) | x1) | ((x2 + 0x76767676u) | x2) | ((x3 + 0x76767676u) | x3)) & 0x80808080u;
+                            const uint64_t pos = ((uint64_t)(four_digits(x1) * 10000u + four_digits(x2))) * 1000ull + four_digits(x3 << 8);
                             const uint64_t off1 = t0 + (uint64_t)s - a.lo + 1;
-                            if (active && !fast) {                                       // rare: leave it to k_scan_queue
+                            if (active && bad != 0) {                                    // rare: leave it to k_scan_queue
                                 const uint32_t qi = atomicAdd(&a.ctl[0], 1u);
                                 if (qi < a.q_cap) a.queue[qi] = off1 - 1; else a.ctl[1] = 1u;
                             }
-                            const bool probe = active && fast && pos <= (uint64_t)h_max;
+                            const bool probe = active && bad == 0 && pos <= (uint64_t)h_max;
                             // Site bitmap probe without touching memory: the wave keeps a 64-dword window of the
                             // bitmap (and of its rank directory) in two VGPRs, one dword per lane; a pileup is
                             // position sorted, so a window (2048 positions) serves ~40 tiles before it is refilled
@@ -783,9 +771,18 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_ring(ScanArgs a, SiteS
                     
                 }
             } while (false);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of the slot has returned
-            lds_store_volatile(&sh.ready[slot], 0);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this slot has returned: it can be refilled
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t t2 = tt + 2 * n_waves;
+        const bool has_next = tt + n_waves < n_tiles;
+        // the slot just parsed receives tile k+2; afterwards "next" is tile k+1 (already requested into the other slot)
+        uint32_t dma_k2 = 0;
+        if (t2 < n_tiles) dma_k2 = request(t2, cur);
+        // after this point the outstanding requests are: tile k+1 (if DMA) then tile k+2 (if DMA).  The wait at the
+        // top of the next iteration must leave only tile k+2's in flight:
+        dma_next = has_next ? dma_k2 : 0;
+        if (has_next && t2 < n_tiles && dma_k2 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // k+2 was staged synchronously
     }
     // a byte >= 0x80 anywhere in this wave's share of the file (checked once: the answers are void anyway)
     if (__ballot((any_hi & 0x80808080u) != 0) && lane == 0) report_scan_error(a.status, 0, SCAN_ERR_NON_ASCII);
@@ -846,7 +843,7 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t
     static int blocks_per_cu = -1, mode = 0;
     if (blocks_per_cu < 0) {                                // tuning knobs (development only)
         const char *b = getenv("SNPGPU_SCAN_BLOCKS_PER_CU"), *m = getenv("SNPGPU_SCAN_MODE");
-        blocks_per_cu = b ? atoi(b) : 3;
+        blocks_per_cu = b ? atoi(b) : 4;
         mode = m ? atoi(m) : 0;
     }
     uint64_t max_blocks = (uint64_t)ctx->n_cu * blocks_per_cu;
@@ -878,7 +875,7 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t
             ra.n_btiles = (sa.hi + SCAN_TILE - 1) / SCAN_TILE;          // 4 KiB tiles
             uint64_t want = (ra.n_btiles + SCAN_WAVES - 1) / SCAN_WAVES;
             unsigned rgrid = (unsigned)(want < max_blocks ? want : max_blocks);
-            k_scan_ring<<<rgrid, SCAN_THREADS, 0, st>>>(ra, ss->dev);
+            k_scan_wave<<<rgrid, SCAN_WAVES * 64, 0, st>>>(ra, ss->dev);
         }
     }
     snpgpu_time_end(ctx, SNPGPU_K_SCAN, ta);
