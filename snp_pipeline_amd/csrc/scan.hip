@@ -5,28 +5,29 @@
 // line publishes (file offset + 1) with atomicMax into site_line[site]; the maximum implements "the last duplicate
 // line wins" (call_consensus.py:171-176).
 //
-// HBM-bound by design: every byte is fetched once, 16 bytes per lane, straight into LDS (global_load_lds_dwordx4,
-// no VGPR round trip), double buffered so the next tile streams in while the current one is parsed.  The unit of
-// work is ONE WAVEFRONT and one 4 KiB tile: there is no workgroup barrier anywhere, the 16 waves of a CU run as
-// independent streams and hide each other's LDS / L2 latency.  Per tile:
-//   A  wait for the tile's LDS-DMA, issue the DMA of the wave's next tile
-//   B  each lane scans four 16-byte chunks for '\n' (SWAR + v_dot4_u32_u8 gathers the byte flags into bits);
+// Every wavefront is an independent stream over 4 KiB tiles: it owns two LDS slots, requests tile k+1 with LDS-DMA
+// (global_load_lds_dwordx4: 64 lanes x 16 B straight into LDS, no VGPR round trip) before it parses tile k, and waits
+// for its own DMA with a counted s_waitcnt — no workgroup barrier, no flags, no polling.  The DMA goes through inline
+// asm on purpose: hipcc orders every LDS read behind a *tracked* LDS-DMA with vmcnt(0), which would serialise fetch
+// and parse; the steady-state parse issues no other vector-memory load (the site bitmap is probed through a
+// register window), so the explicit counted wait is the only one on the path.  Per tile:
+//   B  each lane scans four 16-byte chunks for line terminators (SWAR, v_dot4_u32_u8 gathers byte flags into bits);
 //      a DPP prefix sum over the wave turns the per-lane counts into a list of line starts in LDS
-//   C  one lane per line: compare the first L bytes with the wave's current contig name (dword compares, L and the
-//      name are wave-uniform), find the end of the position field with a SWAR "byte <= 0x20" mask, convert the
-//      digits with SWAR multiplies, probe the site bitmap (L2 resident).  Anything unusual — other contig, odd
-//      whitespace, '\r', long names, > 10 digits — takes an exact byte-wise parser.
+//   C  one lane per line, straight-line code: masked dword compare with the wave's current contig name, SWAR
+//      "<= 0x20" mask + ffs for the digit count, SWAR decimal conversion, site probe by ds_bpermute into a 64-dword
+//      register window of the bitmap / rank directory.
+// A line that does not fit the fast path (other contig, odd whitespace, '\r', > 10 digits, long names) is pushed on
+// a device queue and finished by k_scan_queue with an exact byte-wise parser; if the queue overflows, the kExact
+// instantiation (every line through the exact parser) redoes the file.  kExact also serves the depth-column sum.
 #include <stdlib.h>
 
 #include "internal.h"
 
-#define SCAN_WAVES 4                         // consumer waves per workgroup (one 4 KiB sub-tile each)
-#define SCAN_THREADS ((SCAN_WAVES + 1) * 64) // + one loader wave
-#define SCAN_TILE 4096                       // bytes per consumer wave
-#define SCAN_BTILE (SCAN_WAVES * SCAN_TILE)  // bytes per workgroup tile
+#define SCAN_TILE 4096                       // bytes per wave tile
 #define SCAN_HALO 128                        // bytes staged past the tile for the first fields of its last lines
-#define SCAN_STAGE_CHUNKS ((16 + SCAN_BTILE + SCAN_HALO) / 16)  // [x0-16, x0+BTILE+HALO) in 16-byte chunks
-#define SCAN_STAGE_ROUNDS ((SCAN_STAGE_CHUNKS + 63) / 64)
+#define SCAN_NBUF 2                          // LDS slots per wave: tile k is parsed while tile k+1 streams in
+#define SCAN_WTILE_CHUNKS ((16 + SCAN_TILE + SCAN_HALO) / 16)   // [t0-16, t0+TILE+HALO) in 16-byte chunks
+#define SCAN_DMA_PER_TILE ((SCAN_WTILE_CHUNKS + 63) / 64)       // global_load_lds wave-instructions per tile
 #define SCAN_LIST_CAP 192                    // line starts held in LDS per pass (a tile with more makes extra passes)
 #define SCAN_HINT_WORDS 12                   // contig names up to 44 bytes take the fast compare
 
@@ -37,20 +38,29 @@
 struct ScanArgs {
     const uint8_t *base;     // 16-byte aligned pointer at or below the first byte of the file
     uint64_t lo, hi;         // the file is base[lo, hi)
-    uint64_t n_btiles;
+    uint64_t n_tiles;        // 4 KiB tiles
     uint64_t *site_line;     // n_sites
     uint64_t *status;        // SNPGPU_SCAN_STATUS_WORDS
     uint64_t *queue;         // file offsets of lines left to the exact parser
     uint32_t *ctl;           // [0] queue length, [1] queue overflowed
     uint32_t q_cap;
     int want_depth;
-    unsigned long long *dbg; // optional: per-phase cycle totals (tuning builds only)
+    uint32_t chunk_tiles;    // tiles per work ticket
+    uint32_t *ticket;        // next chunk to hand out (starts at 0; chunk c < n_waves belongs to wave c)
+    uint64_t *totals;        // per-wave {lines, matched, depth sum}: same-address atomics from thousands of waves
+                             // serialise at ~12 ns each and stall the loads of the waves still running
+    unsigned long long *dbg; // optional: per-wave timing records (tuning only)
 };
 
-struct BlockShared {
-    uint4 tile4[2][SCAN_STAGE_CHUNKS];       // double buffer, filled by the loader wave
-    uint16_t lstart[SCAN_WAVES][SCAN_LIST_CAP];
-    uint32_t hint_w[SCAN_WAVES][SCAN_HINT_WORDS];   // each consumer wave's current contig name, zero padded
+struct WaveSlots {
+    uint4 slot[SCAN_NBUF][SCAN_WTILE_CHUNKS];
+    uint16_t lstart[SCAN_LIST_CAP];
+    uint32_t hint_w[SCAN_HINT_WORDS];        // the wave's current contig name, zero padded
+    uint32_t hint_m[SCAN_HINT_WORDS];        // byte masks of the name (zero past its end)
+};
+struct ScanShared {                          // dynamic LDS: the table, then one WaveSlots per wave of the workgroup
+    uint4 digit_mask[16];                    // [nd]: keeps the last nd bytes of window bytes 4..14
+    WaveSlots w[1];
 };
 
 __device__ __forceinline__ void report_scan_error(uint64_t *status, uint64_t file_off, uint32_t code) {
@@ -197,335 +207,25 @@ __device__ __noinline__ Hint load_hint(const SiteSetDev &ss, uint32_t cid, uint3
 // byte really is '\n' is checked when its line start is emitted.
 __device__ __forceinline__ uint32_t term_flags(uint32_t w) { return (w + 0x76767676u) & ~(w + 0x72727272u) & 0x80808080u; }
 
-// Workgroup = SCAN_WAVES consumer waves + 1 loader wave.  The loader streams block tile i+1 (SCAN_WAVES x 4 KiB
-// + halo) into the idle LDS buffer with LDS-DMA while the consumers parse block tile i; one barrier per block tile
-// swaps the buffers.  Only the loader ever waits on the DMA (vmcnt), so the fetch of the next tile overlaps the
-// whole parse of the current one, and every workgroup keeps 16 KiB in flight all the time.
-//
-// kExact = false: the hot kernel.  Straight-line fast path only; a line that does not fit it is pushed (its file
-//                 offset) on a small device queue and finished by k_scan_queue with the exact parser.
-// kExact = true:  every line goes through the exact parser (used when the depth column is wanted, and as the
-//                 fallback when the queue overflowed).
-template <int kMode, bool kExact>   // kMode 0 = full; 1 = stage only, 2/3 = line index only, 3/4 = no loads (ablation)
-__global__ __launch_bounds__(SCAN_THREADS, kExact ? 2 : 4) void k_scan_pileup(ScanArgs a, SiteSetDev ss) {
-    __shared__ BlockShared sh;
+#define SCAN_HINT_NONE 0xFFFFFFFFu           // no usable hint
+#define SCAN_HINT_ABSENT 0xFFFFFFFEu         // the name is known NOT to be a contig of the site set
+
+template <bool kExact, int kTime>
+__global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
+    extern __shared__ uint4 scan_lds[];
+    ScanShared &sh = *(ScanShared *)scan_lds;
     if (kExact && !a.want_depth && a.ctl[1] == 0) return;    // fallback pass: only when the slow-line queue overflowed
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool loader = wave == SCAN_WAVES;
-    const uint32_t *bitmap = ss.bitmap, *rank = ss.rank;
-    uint32_t hits = 0, lines_seen = 0, any_hi = 0;
-    unsigned long long depth_acc = 0;
-    Hint hint{};
-    if (!loader) hint = load_hint(ss, 0, sh.hint_w[wave], lane);
-    uint64_t win_base = 0xFFFFFFFFFFFFFF00ull;           // bitmap window [win_base, win_base + 64) dwords; starts empty
-    uint32_t win_word = 0, win_rank = 0;
-    unsigned long long tB = 0, tL = 0, tC = 0, tW = 0, tLd = 0, tmark = 0;
-#define TICK(acc) do { if (kMode == 5) { unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tmark; tmark = now_; } } while (0)
-    if (kMode == 5) tmark = __builtin_readcyclecounter();
-
-    // A block tile is "interior" when [x0-16, x0+BTILE+HALO) lies inside the file: it can be streamed as is.
-    auto interior = [&](uint64_t tt) { uint64_t x0 = tt * SCAN_BTILE; return x0 >= a.lo + 16 && x0 + SCAN_BTILE + SCAN_HALO <= a.hi; };
-    // Loader: LDS-DMA, global_load_lds_dwordx4 writes 64 lanes x 16 B straight into LDS (LDS address = M0 + lane*16).
-    auto stage_async = [&](uint64_t tt, int buf) {
-        const uint8_t *g = a.base + tt * SCAN_BTILE - 16 + (size_t)lane * 16;
-        const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)&sh.tile4[buf][0]);
-#pragma unroll
-        for (int r = 0; r < SCAN_STAGE_ROUNDS; ++r) {
-            if (r * 64 + lane < SCAN_STAGE_CHUNKS) {
-                const uint8_t *gp = g + (size_t)r * 1024;
-                const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + r * 1024);
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m0v) : "memory");
-            }
-        }
-    };
-    // First / last block tiles: byte loads, bytes outside [lo,hi) read as '\n'.
-    auto stage_edge = [&](uint64_t tt, int buf) {
-        const int64_t x0 = (int64_t)(tt * SCAN_BTILE) - 16;
-#pragma nounroll
-        for (uint32_t e = lane; e < SCAN_STAGE_CHUNKS; e += 64) {
-            uint32_t d[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int64_t idx = x0 + (int64_t)e * 16 + 4 * k + j;
-                    uint32_t bb = (idx >= (int64_t)a.lo && idx < (int64_t)a.hi) ? (uint32_t)a.base[idx] : 10u;
-                    d[k] |= bb << (8 * j);
-                }
-            sh.tile4[buf][e] = make_uint4(d[0], d[1], d[2], d[3]);
-        }
-    };
-    auto stage = [&](uint64_t tt, int buf) { if (interior(tt)) stage_async(tt, buf); else stage_edge(tt, buf); };
-
-    int cur = 0;
-    if (loader && blockIdx.x < a.n_btiles) {
-        stage(blockIdx.x, 0);
-        if (kMode == 3 || kMode == 4) stage(blockIdx.x, 1);  // ablation: parse the same tile over and over, no further loads
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    for (uint64_t bt = blockIdx.x; bt < a.n_btiles; bt += gridDim.x, cur ^= 1) {
-        if (loader) {
-            const uint64_t nb = bt + gridDim.x;
-            if (nb < a.n_btiles && kMode != 3 && kMode != 4) stage(nb, cur ^ 1);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            TICK(tLd);
-        } else {
-            const uint64_t t0 = bt * SCAN_BTILE + (uint64_t)wave * SCAN_TILE;   // offset of my sub-tile relative to a.base
-            const bool edge = !interior(bt);
-            const uint8_t *tile = (const uint8_t *)&sh.tile4[cur][1] + wave * SCAN_TILE;   // tile[-16 .. SCAN_TILE+SCAN_HALO)
-            const uint4 *tile16 = &sh.tile4[cur][1 + wave * (SCAN_TILE / 16)];
-            uint16_t *lstart = sh.lstart[wave];
-            const uint32_t *hint_w = sh.hint_w[wave];
-            do {                                                // one pass; `break` leaves the tile early
-                if (kMode == 1) { hits += tile[lane]; break; }
-                // ---- B: terminator flags of four 16-byte chunks per lane (chunk i*64+lane: conflict-free LDS reads) ----
-                // bit 16*i + b of S: byte b of chunk i*64+lane is in 0x0A..0x0D; a line starts at the next byte.
-                // Straight-line code: no branch depends on the data unless the tile holds '\v' '\f' or '\r'.
-                uint64_t S;
-                uint32_t exo = 0;                                   // 0x80 where a byte is in 0x0B..0x0D
-                {
-                    uint32_t bits[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const uint4 v = tile16[i * 64 + lane];
-                        any_hi |= v.x | v.y | v.z | v.w;
-                        exo |= ((v.x + 0x75757575u) & ~(v.x + 0x72727272u)) | ((v.y + 0x75757575u) & ~(v.y + 0x72727272u)) |
-                               ((v.z + 0x75757575u) & ~(v.z + 0x72727272u)) | ((v.w + 0x75757575u) & ~(v.w + 0x72727272u));
-                        bits[i] = flags_to_bits16(term_flags(v.x), term_flags(v.y), term_flags(v.z), term_flags(v.w));
-                    }
-                    S = (uint64_t)(bits[0] | (bits[1] << 16)) | ((uint64_t)(bits[2] | (bits[3] << 16)) << 32);
-                }
-                // The last byte of the sub-tile (lane 63, chunk 3, byte 15) starts a line in the NEXT sub-tile, which
-                // sees it as its byte -1; byte 0 starts a line iff the byte before it ends a terminator.
-                if (lane == 63) S &= ~(1ull << 63);
-                const uint32_t pv0 = tile[-1], cv0 = tile[0];
-                bool s0 = (lane == 0) && (pv0 == 10u || (pv0 == 13u && cv0 != 10u));
-                if (__ballot((exo & 0x80808080u) != 0 || ((lane == 0) && (pv0 - 11u <= 2u)))) {
-                    S = 0;                                          // rare: '\r' (or '\v' '\f'): exact byte-wise index
-#pragma nounroll
-                    for (int i = 0; i < 4; ++i)
-#pragma nounroll
-                        for (int b = 0; b < 16; ++b) {
-                            const int q = (i * 64 + (int)lane) * 16 + b;
-                            const uint32_t cv = tile[q], nx = tile[q + 1];
-                            if (cv == 10u || (cv == 13u && nx != 10u)) S |= 1ull << (16 * i + b);
-                        }
-                    if (lane == 63) S &= ~(1ull << 63);
-                }
-                if (edge) {                                         // starts must lie inside the file
-#pragma nounroll
-                    for (int i = 0; i < 4; ++i)
-#pragma nounroll
-                        for (int b = 0; b < 16; ++b) {
-                            const uint64_t st = t0 + (uint64_t)((i * 64 + (int)lane) * 16 + b + 1);
-                            if (st < a.lo || st >= a.hi) S &= ~(1ull << (16 * i + b));
-                        }
-                    s0 = s0 && t0 >= a.lo && t0 < a.hi;
-                }
-                const uint32_t cnt = (uint32_t)__popcll(S) + (s0 ? 1u : 0u);
-                const uint32_t incl = wave_inclusive_sum(cnt);
-                const uint32_t n_lines = __builtin_amdgcn_readlane(incl, 63);
-                const uint32_t base = incl - cnt;
-                lines_seen += (lane == 0) ? n_lines : 0;
-                if (kMode == 2 || kMode == 3) { hits += base; break; }
-                TICK(tB);
-
-                for (uint32_t pass0 = 0; pass0 < n_lines; pass0 += SCAN_LIST_CAP) {
-                    {   // list of the line starts [pass0, pass0 + CAP): two predicated slots, a loop only for lanes
-                        // with three or more starts in their 64 bytes (lines shorter than ~21 bytes)
-                        uint64_t s_bits = S;
-                        uint32_t idx = base - pass0;                // slots below 0 wrap to huge values and are skipped
-                        if (s0 && idx < SCAN_LIST_CAP) lstart[idx] = 0;
-                        idx += s0 ? 1u : 0u;
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) {
-                            const uint32_t bpos = (uint32_t)__ffsll((long long)s_bits) - 1;     // 0xFFFFFFFF when empty
-                            const bool have = s_bits != 0;
-                            if (have && idx < SCAN_LIST_CAP) lstart[idx] = (uint16_t)((((bpos >> 4) * 64 + lane) << 4) + (bpos & 15) + 1);
-                            idx += have ? 1u : 0u;
-                            s_bits &= s_bits - 1;
-                        }
-                        if (__ballot(s_bits != 0)) {
-                            while (s_bits) {
-                                const uint32_t bpos = (uint32_t)__ffsll((long long)s_bits) - 1;
-                                s_bits &= s_bits - 1;
-                                if (idx < SCAN_LIST_CAP) lstart[idx] = (uint16_t)((((bpos >> 4) * 64 + lane) << 4) + (bpos & 15) + 1);
-                                ++idx;
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    TICK(tL);
-                    const uint32_t n_here = n_lines - pass0 < SCAN_LIST_CAP ? n_lines - pass0 : SCAN_LIST_CAP;
-                    // ---- C: one lane per line ------------------------------------------------------------------
-                    if (!kExact) {
-                        // Straight-line predicated code for "name SEP digits SEP"; a line that does not fit (other
-                        // contig, odd whitespace, > 10 digits, long name ...) is queued for the exact parser.
-                        // the hint is wave-uniform; say so (it came back from a call in VGPRs)
-                        const uint32_t L = __builtin_amdgcn_readfirstlane(hint.len);
-                        const uint32_t h_cid = __builtin_amdgcn_readfirstlane(hint.cid);
-                        const uint32_t h_max = __builtin_amdgcn_readfirstlane(hint.max_pos);
-                        const uint64_t h_off = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(hint.bit_off >> 32)) << 32) |
-                                               __builtin_amdgcn_readfirstlane((uint32_t)hint.bit_off);
-                        const bool hint_ok = h_cid != 0xFFFFFFFFu && L >= 1 && L <= 4 * SCAN_HINT_WORDS - 4;
-                        const uint32_t nw = (L + 3) >> 2;                               // dwords of the name
-                        for (uint32_t j0 = 0; j0 < n_here; j0 += 64) {
-                            const uint32_t j = j0 + lane;
-                            const bool active = j < n_here;
-                            const uint32_t s = active ? lstart[j] : 0u;
-                            const uint8_t *p = tile + s;
-                            bool fast = false;
-                            uint64_t pos = 0;
-                            if (hint_ok) {                                               // uniform
-                                uint32_t w[SCAN_HINT_WORDS];
-                                lds_window16(tile, (int)s, w[0], w[1], w[2], w[3]);
-                                if (nw > 4) lds_window16(tile, (int)s + 16, w[4], w[5], w[6], w[7]);        // uniform
-                                if (nw > 8) lds_window16(tile, (int)s + 32, w[8], w[9], w[10], w[11]);      // uniform
-                                uint32_t bad = 0;
-#pragma unroll
-                                for (int k = 0; k < SCAN_HINT_WORDS; ++k)
-                                    if ((uint32_t)k < nw) {                              // uniform
-                                        const uint32_t nb = L - 4 * k;                  // bytes of the name in this dword (uniform)
-                                        const uint32_t mk = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
-                                        bad |= (w[k] ^ hint_w[k]) & mk;
-                                    }
-                                const uint32_t c1 = p[L];                                // the separator after the name
-                                uint4 q1;
-                                lds_window16(tile, (int)(s + L + 1), q1.x, q1.y, q1.z, q1.w);      // digits + separator
-                                // first byte <= 0x20 in the 16-byte window = number of digits
-                                const uint32_t ctl = flags_to_bits16(le20_flags(q1.x), le20_flags(q1.y), le20_flags(q1.z), le20_flags(q1.w));
-                                uint32_t nd = (uint32_t)__ffs((int)ctl) - 1u;            // ctl == 0 -> 0xFFFFFFFF
-                                bad |= (nd - 1u > 9u) ? 1u : 0u;
-                                nd = nd > 10u ? 10u : nd;
-                                uint4 q;
-                                lds_window16(tile, (int)(s + L + 1 + nd) - 15, q.x, q.y, q.z, q.w);  // the digits end at byte 14 of this window
-                                const uint32_t c2 = q.w >> 24;
-                                // separators of the fast path: TAB or space after the name; TAB, space or '\n' after the digits
-                                bad |= (c1 != 9u && c1 != 32u) ? 1u : 0u;
-                                bad |= (c2 != 9u && c2 != 32u && c2 != 10u) ? 1u : 0u;
-                                const uint32_t first = 15u - nd;                          // window index of the first digit (5..14)
-                                uint32_t x1 = q.y ^ 0x30303030u, x2 = q.z ^ 0x30303030u, x3 = (q.w ^ 0x30303030u) & 0x00FFFFFFu;
-                                const uint32_t d1 = first > 4 ? first - 4 : 0, d2 = first > 8 ? first - 8 : 0, d3 = first > 12 ? first - 12 : 0;
-                                x1 = d1 >= 4 ? 0u : x1 & (0xFFFFFFFFu << (8 * d1));
-                                x2 = d2 >= 4 ? 0u : x2 & (0xFFFFFFFFu << (8 * d2));
-                                x3 = x3 & (0xFFFFFFFFu << (8 * d3));
-                                bad |= (((x1 + 0x76767676u) | x1) | ((x2 + 0x76767676u) | x2) | ((x3 + 0x76767676u) | x3)) & 0x80808080u;
-                                pos = ((uint64_t)(four_digits(x1) * 10000u + four_digits(x2))) * 1000ull + four_digits(x3 << 8);
-                                fast = bad == 0;
-                            }
-                            const uint64_t off1 = t0 + (uint64_t)s - a.lo + 1;
-                            if (active && !fast) {                                       // rare: leave it to k_scan_queue
-                                const uint32_t qi = atomicAdd(&a.ctl[0], 1u);
-                                if (qi < a.q_cap) a.queue[qi] = off1 - 1; else a.ctl[1] = 1u;
-                            }
-                            const bool probe = active && fast && pos <= (uint64_t)h_max;
-                            // Site bitmap probe without touching memory: the wave keeps a 64-dword window of the
-                            // bitmap (and of its rank directory) in two VGPRs, one dword per lane; a pileup is
-                            // position sorted, so a window (2048 positions) serves ~40 tiles before it is refilled
-                            // with two coalesced 256-byte loads.  Lookup = ds_bpermute (cross-lane, no LDS memory).
-                            const uint64_t bit = h_off + (uint32_t)pos;
-                            const uint64_t wi = bit >> 5;
-                            uint32_t word = 0, rk = 0;
-                            bool done = !probe;
-                            for (;;) {
-                                const uint64_t rel = wi - win_base;
-                                const int sel = (int)(((uint32_t)rel & 63u) << 2);
-                                const uint32_t w_ = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)win_word);
-                                const uint32_t r_ = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)win_rank);
-                                if (!done && rel < 64) { word = w_; rk = r_; done = true; }
-                                const uint64_t miss = __ballot(!done);
-                                if (!miss) break;
-                                const uint32_t src = (uint32_t)__ffsll((long long)miss) - 1;
-                                win_base = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(wi >> 32), src) << 32) |
-                                           __builtin_amdgcn_readlane((uint32_t)wi, src);
-                                const bool inb = win_base + lane < ss.n_words;
-                                win_word = inb ? bitmap[win_base + lane] : 0u;
-                                win_rank = inb ? rank[win_base + lane] : 0u;
-                            }
-                            const uint32_t shf = (uint32_t)(bit & 31);
-                            if ((word >> shf) & 1u) {
-                                const uint32_t site = rk + __popc(word & ((1u << shf) - 1u));
-                                atomicMax((unsigned long long *)&a.site_line[site], (unsigned long long)off1);
-                                ++hits;
-                            }
-                        }
-                    } else {
-                        TileView tv{tile, a.base, t0, a.hi, (int64_t)(SCAN_BTILE + SCAN_HALO) - (int64_t)wave * SCAN_TILE};
-                        for (uint32_t j = lane; j < n_here; j += 64) {
-                            const uint32_t s = lstart[j];
-                            const uint64_t file_off = t0 + (uint64_t)s - a.lo;
-                            SlowLine sl = parse_line_slow(tv, s, a.want_depth);
-                            if (sl.err) { report_scan_error(a.status, file_off, sl.err); continue; }
-                            depth_acc += sl.depth;
-                            const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, sl.f0, sl.f0len) : 0xFFFFFFFFu;
-                            if (cid == 0xFFFFFFFFu || sl.pos > (uint64_t)ss.max_pos[cid]) continue;
-                            const uint64_t bit = ss.bit_off[cid] + (uint32_t)sl.pos;
-                            const uint32_t word = bitmap[bit >> 5];
-                            const uint32_t shf = (uint32_t)(bit & 31);
-                            if (!((word >> shf) & 1u)) continue;
-                            const uint32_t site = rank[bit >> 5] + __popc(word & ((1u << shf) - 1u));
-                            atomicMax((unsigned long long *)&a.site_line[site], (unsigned long long)(file_off + 1));
-                            ++hits;
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    TICK(tC);
-                }
-            } while (false);
-        }
-        __syncthreads();
-        TICK(tW);
-    }
-    if (kMode == 5 && lane == 0 && a.dbg) {
-        atomicAdd(&a.dbg[loader ? 5 : 0], tB); atomicAdd(&a.dbg[loader ? 6 : 1], tL); atomicAdd(&a.dbg[loader ? 7 : 2], tC);
-        atomicAdd(&a.dbg[loader ? 8 : 3], tW); atomicAdd(&a.dbg[loader ? 9 : 4], tLd);
-    }
-    // a byte >= 0x80 anywhere in this wave's share of the file (checked once: the answers are void anyway)
-    if (__ballot((any_hi & 0x80808080u) != 0) && lane == 0) report_scan_error(a.status, 0, SCAN_ERR_NON_ASCII);
-    // ---- totals: one atomic per wave -------------------------------------------------------------------
-    for (int o = 32; o; o >>= 1) { hits += __shfl_xor(hits, o); lines_seen += __shfl_xor(lines_seen, o); }
-    if (lane == 0) {
-        if (hits) atomicAdd((unsigned long long *)&a.status[2], (unsigned long long)hits);
-        if (lines_seen) atomicAdd((unsigned long long *)&a.status[1], (unsigned long long)lines_seen);
-    }
-    if (a.want_depth) {
-        for (int o = 32; o; o >>= 1) depth_acc += __shfl_xor(depth_acc, o);
-        if (lane == 0 && depth_acc) atomicAdd((unsigned long long *)&a.status[3], depth_acc);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The hot kernel.  Every wavefront is an independent stream: it owns SCAN_NBUF LDS slots of one 4 KiB tile (+ halo),
-// requests tile k+1 with LDS-DMA (global_load_lds_dwordx4, 64 lanes x 16 B straight into LDS, no VGPR round trip)
-// before it parses tile k, and waits for its own DMA with a counted s_waitcnt — no workgroup barrier, no flags, no
-// polling.  The DMA goes through inline asm on purpose: hipcc orders every LDS read behind a *tracked* LDS-DMA with
-// vmcnt(0), which would serialise fetch and parse; the steady-state parse issues no other vector-memory load (the
-// site bitmap is probed through a register window), so the explicit counted wait is the only one on the path.
-#define SCAN_NBUF 2
-#define SCAN_WTILE_CHUNKS ((16 + SCAN_TILE + SCAN_HALO) / 16)
-#define SCAN_DMA_PER_TILE ((SCAN_WTILE_CHUNKS + 63) / 64)
-
-struct WaveSlots {
-    uint4 slot[SCAN_NBUF][SCAN_WTILE_CHUNKS];
-    uint16_t lstart[SCAN_LIST_CAP];
-    uint32_t hint_w[SCAN_HINT_WORDS];
-    uint32_t hint_m[SCAN_HINT_WORDS];
-};
-struct WaveBlockShared {
-    WaveSlots w[SCAN_WAVES];
-    uint4 digit_mask[16];
-};
-
-__global__ __launch_bounds__(SCAN_WAVES * 64, 4) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
-    __shared__ WaveBlockShared sh;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveSlots &ws = sh.w[wave];
     const uint32_t *bitmap = ss.bitmap, *rank = ss.rank;
     uint32_t hits = 0, lines_seen = 0, any_hi = 0;
-    if (threadIdx.x < 16) {                                   // digit_mask[nd]: byte masks keeping the last nd bytes of window bytes 4..14
+    unsigned long long depth_acc = 0;
+    unsigned long long t_a = 0, t_b = 0, t_c = 0, t_mark = kTime >= 2 ? __builtin_readcyclecounter() : 0;
+    const unsigned long long rt_start = kTime ? __builtin_amdgcn_s_memrealtime() : 0;    // 100 MHz wall clock
+    unsigned long long rt_prologue = 0, rt_first = 0;
+#define WTICK(acc) do { if (kTime >= 2) { unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - t_mark; t_mark = now_; } } while (0)
+    if (threadIdx.x < 16) {
         const uint32_t nd = threadIdx.x > 10 ? 10 : threadIdx.x, first = 15u - nd;
         uint32_t m[3];
         for (int g = 0; g < 3; ++g) {
@@ -535,11 +235,11 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 4) void k_scan_wave(ScanArgs a, Si
         }
         sh.digit_mask[threadIdx.x] = make_uint4(m[0], m[1], m[2], 0);
     }
-    Hint hint = load_hint(ss, 0, ws.hint_w, lane);
     __syncthreads();                                          // the only barrier: digit_mask table visible
 
-    const uint64_t n_tiles = a.n_btiles;                      // here: number of 4 KiB tiles
-    const uint64_t gwave = (uint64_t)blockIdx.x * SCAN_WAVES + wave, n_waves = (uint64_t)gridDim.x * SCAN_WAVES;
+    const uint64_t n_tiles = a.n_tiles;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint64_t gwave = (uint64_t)blockIdx.x * waves_per_block + wave, n_waves = (uint64_t)gridDim.x * waves_per_block;
     auto interior = [&](uint64_t tt) { uint64_t x0 = tt * SCAN_TILE; return x0 >= a.lo + 16 && x0 + SCAN_TILE + SCAN_HALO <= a.hi; };
     // request tile tt into slot `buf`; returns the number of DMA wave-instructions now in flight for it (0: staged synchronously)
     auto request = [&](uint64_t tt, int buf) -> uint32_t {
@@ -578,39 +278,77 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 4) void k_scan_wave(ScanArgs a, Si
     uint16_t *lstart = ws.lstart;
     const uint32_t *hint_w = ws.hint_w;
     const uint32_t *hint_m = ws.hint_m;
-        // the wave's contig hint (uniform): name words / byte masks of the first 16 bytes live in registers
-        const uint32_t L = __builtin_amdgcn_readfirstlane(hint.len);
-        const uint32_t h_max = __builtin_amdgcn_readfirstlane(hint.max_pos);
-        const uint64_t h_off = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(hint.bit_off >> 32)) << 32) |
-                               __builtin_amdgcn_readfirstlane((uint32_t)hint.bit_off);
-        const uint32_t hint_bad = (__builtin_amdgcn_readfirstlane(hint.cid) != 0xFFFFFFFFu && L >= 1 && L <= 4 * SCAN_HINT_WORDS - 4) ? 0u : 1u;
-        const bool hint_long = L > 15;
-        uint32_t hw[4], hm[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            hw[k] = hint_w[k];
-            const uint32_t nb = L > 4u * k ? L - 4u * k : 0u;
-            hm[k] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
-        }
+    // the wave's contig hint (wave-uniform): length, probe parameters, and the first 16 name bytes + masks in registers
+    uint32_t L = 0, h_max = 0, hint_bad = 1, hw[4] = {0, 0, 0, 0}, hm[4] = {0, 0, 0, 0};
+    uint64_t h_off = 0;
+    bool hint_long = false, hint_present = false;
+    auto adopt = [&](Hint h) {                                // h came back from a call in VGPRs: make it uniform
+        L = __builtin_amdgcn_readfirstlane(h.len);
+        const uint32_t cid = __builtin_amdgcn_readfirstlane(h.cid);
+        h_max = __builtin_amdgcn_readfirstlane(h.max_pos);
+        h_off = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(h.bit_off >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)h.bit_off);
+        hint_present = cid < SCAN_HINT_ABSENT;
+        hint_bad = (cid != SCAN_HINT_NONE && L >= 1 && L <= 4 * SCAN_HINT_WORDS - 4) ? 0u : 1u;
+        hint_long = L > 15;
         if (lane < SCAN_HINT_WORDS) {
             const uint32_t nb = L > 4u * lane ? L - 4u * lane : 0u;
             ws.hint_m[lane] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            hw[k] = ws.hint_w[k];
+            const uint32_t nb = L > 4u * k ? L - 4u * k : 0u;
+            hm[k] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+        }
+    };
+    if (!kExact) adopt(load_hint(ss, 0, ws.hint_w, lane));
 
+    // Work distribution: the file is cut into chunks of a.chunk_tiles contiguous tiles.  Chunk w is wave w's first one;
+    // after that a wave draws tickets from a device counter — the workgroups of a launch are not spread evenly over
+    // the CUs, so equal static shares would leave most of the chip waiting for the CUs that got more waves.  The ticket
+    // for the next chunk is drawn when a chunk is started and first looked at when its last tile has been requested, so
+    // the atomic's round trip is never waited for.  Tiles inside a chunk are consecutive: a pileup is sorted, so the
+    // contig hint and the bitmap window usually survive from one tile to the next.
+    const uint64_t chunk = a.chunk_tiles, n_chunks = (n_tiles + chunk - 1) / chunk;
+    if (gwave >= n_chunks) {
+        if (lane == 0) a.totals[3 * gwave] = a.totals[3 * gwave + 1] = a.totals[3 * gwave + 2] = 0;
+        return;
+    }
+    uint64_t s_tile = gwave * chunk, s_end = s_tile + chunk < n_tiles ? s_tile + chunk : n_tiles;
+    uint32_t drawn = 0;
+    bool dry = a.ticket == nullptr;                           // static shares: one chunk per wave
+    if (!dry && lane == 0) drawn = atomicAdd(a.ticket, 1u);
+    const uint64_t kNoTile = ~0ull;
+    auto next_tile = [&]() -> uint64_t {
+        if (s_tile == s_end) {
+            if (dry) return kNoTile;
+            const uint64_t c = n_waves + __builtin_amdgcn_readfirstlane(drawn);
+            if (c >= n_chunks) { dry = true; return kNoTile; }
+            if (lane == 0) drawn = atomicAdd(a.ticket, 1u);
+            s_tile = c * chunk;
+            s_end = s_tile + chunk < n_tiles ? s_tile + chunk : n_tiles;
+        }
+        return s_tile++;
+    };
+    uint64_t tt = next_tile(), t_nxt = next_tile();
     uint32_t dma_next = 0;                                    // DMA instructions in flight for the tile after the current one
-    if (gwave < n_tiles) (void)request(gwave, 0);
-    if (gwave + n_waves < n_tiles) dma_next = request(gwave + n_waves, 1);
+    (void)request(tt, 0);
+    if (t_nxt != kNoTile) dma_next = request(t_nxt, 1);
     int cur = 0;
-    for (uint64_t tt = gwave; tt < n_tiles; tt += n_waves, cur ^= 1) {
+    bool first_tile = true;
+    if (kTime) rt_prologue = __builtin_amdgcn_s_memrealtime();
+    for (; tt != kNoTile; cur ^= 1) {
         // the current tile's DMA has landed when only the next tile's requests are still outstanding
         if (dma_next) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SCAN_DMA_PER_TILE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        WTICK(t_a);
         {
             const uint64_t t0 = tt * SCAN_TILE;
             const bool edge = !interior(tt);
-            const uint8_t *tile = (const uint8_t *)&ws.slot[cur][1];
+            const uint8_t *tile = (const uint8_t *)&ws.slot[cur][1];   // tile[-16 .. SCAN_TILE+SCAN_HALO)
             const uint4 *tile16 = &ws.slot[cur][1];
+            uint32_t mismatch_at = 0xFFFFFFFFu;                      // line start of a lane whose name did not match the hint
             do {                                                // one pass; `break` leaves the tile early
                 
                 // ---- B: terminator flags of four 16-byte chunks per lane (chunk i*64+lane: conflict-free LDS reads) ----
@@ -662,8 +400,6 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 4) void k_scan_wave(ScanArgs a, Si
                 const uint32_t n_lines = __builtin_amdgcn_readlane(incl, 63);
                 const uint32_t base = incl - cnt;
                 lines_seen += (lane == 0) ? n_lines : 0;
-                
-                
 
                 for (uint32_t pass0 = 0; pass0 < n_lines; pass0 += SCAN_LIST_CAP) {
                     {   // list of the line starts [pass0, pass0 + CAP): two predicated slots, a loop only for lanes
@@ -690,8 +426,8 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 4) void k_scan_wave(ScanArgs a, Si
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
-                    
                     const uint32_t n_here = n_lines - pass0 < SCAN_LIST_CAP ? n_lines - pass0 : SCAN_LIST_CAP;
+                    if (!kExact) {
                     // ---- C: one lane per line ------------------------------------------------------------------
                     {
                         // Straight-line code for "name SEP digits SEP" with as little scalar/exec traffic as possible:
@@ -714,6 +450,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 4) void k_scan_wave(ScanArgs a, Si
                                 bad |= ((v0 ^ hint_w[8]) & hint_m[8]) | ((v1 ^ hint_w[9]) & hint_m[9]) | ((v2 ^ hint_w[10]) & hint_m[10]) | ((v3 ^ hint_w[11]) & hint_m[11]);
                             }
                             const uint32_t c1 = tile[s + L];                             // the separator after the name
+                            if (active && (bad | min(c1 ^ 9u, c1 ^ 32u)) != 0) mismatch_at = s;    // another contig?
                             uint4 q1;
                             lds_window16(tile, (int)(s + L + 1), q1.x, q1.y, q1.z, q1.w);       // digits + separator
                             // first byte <= 0x20 in the 16-byte window = number of digits (1..10 on the fast path)
@@ -735,7 +472,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 4) void k_scan_wave(ScanArgs a, Si
                                 const uint32_t qi = atomicAdd(&a.ctl[0], 1u);
                                 if (qi < a.q_cap) a.queue[qi] = off1 - 1; else a.ctl[1] = 1u;
                             }
-                            const bool probe = active && bad == 0 && pos <= (uint64_t)h_max;
+                            const bool probe = active && bad == 0 && hint_present && pos <= (uint64_t)h_max;
                             // Site bitmap probe without touching memory: the wave keeps a 64-dword window of the
                             // bitmap (and of its rank directory) in two VGPRs, one dword per lane; a pileup is
                             // position sorted, so a window (2048 positions) serves ~40 tiles before it is refilled
@@ -767,30 +504,79 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 4) void k_scan_wave(ScanArgs a, Si
                             }
                         }
                     }
+                    } else {
+                        TileView tv{tile, a.base, t0, a.hi, (int64_t)(SCAN_TILE + SCAN_HALO)};
+                        for (uint32_t j = lane; j < n_here; j += 64) {
+                            const uint32_t s = lstart[j];
+                            const uint64_t file_off = t0 + (uint64_t)s - a.lo;
+                            SlowLine sl = parse_line_slow(tv, s, a.want_depth);
+                            if (sl.err) { report_scan_error(a.status, file_off, sl.err); continue; }
+                            depth_acc += sl.depth;
+                            const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, sl.f0, sl.f0len) : 0xFFFFFFFFu;
+                            if (cid == 0xFFFFFFFFu || sl.pos > (uint64_t)ss.max_pos[cid]) continue;
+                            const uint64_t bit = ss.bit_off[cid] + (uint32_t)sl.pos;
+                            const uint32_t word = bitmap[bit >> 5];
+                            const uint32_t shf = (uint32_t)(bit & 31);
+                            if (!((word >> shf) & 1u)) continue;
+                            const uint32_t site = rank[bit >> 5] + __popc(word & ((1u << shf) - 1u));
+                            atomicMax((unsigned long long *)&a.site_line[site], (unsigned long long)(file_off + 1));
+                            ++hits;
+                        }
+                    }
                     __builtin_amdgcn_wave_barrier();
-                    
                 }
             } while (false);
+            // A line of another contig was seen: make that contig the wave's hint (rare: once per contig change).  The
+            // lines that failed meanwhile are in the queue, so this only affects speed.
+            if (!kExact) {
+                const uint64_t mm = __ballot(mismatch_at != 0xFFFFFFFFu);
+                if (mm) {
+                    const uint32_t s1 = __builtin_amdgcn_readlane(mismatch_at, (uint32_t)__ffsll((long long)mm) - 1);
+                    uint32_t len = 0;
+                    while (len < 4 * SCAN_HINT_WORDS && __builtin_amdgcn_readfirstlane((uint32_t)tile[s1 + len]) > 0x20u) ++len;
+                    if (len >= 1 && len <= 4 * SCAN_HINT_WORDS - 4) {
+                        TileView tv{tile, a.base, t0, a.hi, (int64_t)(SCAN_TILE + SCAN_HALO)};
+                        const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, (int64_t)s1, len) : 0xFFFFFFFFu;
+                        if (cid != 0xFFFFFFFFu) adopt(load_hint(ss, cid, ws.hint_w, lane));
+                        else {                                       // not a contig of the site set: remember the name itself
+                            if (lane < SCAN_HINT_WORDS) {
+                                uint32_t w = 0;
+                                for (uint32_t j = 0; j < 4; ++j) { uint32_t i = lane * 4 + j; if (i < len) w |= (uint32_t)tile[s1 + i] << (8 * j); }
+                                ws.hint_w[lane] = w;
+                            }
+                            Hint h;
+                            h.len = len; h.cid = SCAN_HINT_ABSENT; h.max_pos = 0; h.bit_off = 0;
+                            adopt(h);
+                        }
+                    }
+                }
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this slot has returned: it can be refilled
         __builtin_amdgcn_wave_barrier();
-        const uint64_t t2 = tt + 2 * n_waves;
-        const bool has_next = tt + n_waves < n_tiles;
-        // the slot just parsed receives tile k+2; afterwards "next" is tile k+1 (already requested into the other slot)
-        uint32_t dma_k2 = 0;
-        if (t2 < n_tiles) dma_k2 = request(t2, cur);
-        // after this point the outstanding requests are: tile k+1 (if DMA) then tile k+2 (if DMA).  The wait at the
-        // top of the next iteration must leave only tile k+2's in flight:
-        dma_next = has_next ? dma_k2 : 0;
-        if (has_next && t2 < n_tiles && dma_k2 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // k+2 was staged synchronously
+        WTICK(t_b);
+        // the slot just parsed receives the tile after next; the outstanding requests are then the next tile's (older)
+        // and these, and the next top-of-loop wait leaves exactly these in flight
+        const uint64_t t_new = next_tile();
+        dma_next = t_new != kNoTile ? request(t_new, cur) : 0;
+        tt = t_nxt;
+        t_nxt = t_new;
+        WTICK(t_c);
+        if (kTime && first_tile) { rt_first = __builtin_amdgcn_s_memrealtime(); first_tile = false; }
     }
+    if (kTime && lane == 0 && a.dbg) {                        // per-wave record for tools/scan_waves.py
+        unsigned long long *rec = a.dbg + 8 * gwave;
+        rec[0] = rt_start; rec[1] = __builtin_amdgcn_s_memrealtime();
+        rec[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);   // XCC_ID, HW_ID
+        rec[3] = t_a; rec[4] = t_b; rec[5] = t_c; rec[6] = rt_prologue; rec[7] = rt_first;
+    }
+#undef WTICK
     // a byte >= 0x80 anywhere in this wave's share of the file (checked once: the answers are void anyway)
     if (__ballot((any_hi & 0x80808080u) != 0) && lane == 0) report_scan_error(a.status, 0, SCAN_ERR_NON_ASCII);
     for (int o = 32; o; o >>= 1) { hits += __shfl_xor(hits, o); lines_seen += __shfl_xor(lines_seen, o); }
-    if (lane == 0) {
-        if (hits) atomicAdd((unsigned long long *)&a.status[2], (unsigned long long)hits);
-        if (lines_seen) atomicAdd((unsigned long long *)&a.status[1], (unsigned long long)lines_seen);
-    }
+    if (kExact && a.want_depth)
+        for (int o = 32; o; o >>= 1) depth_acc += __shfl_xor(depth_acc, o);
+    if (lane == 0) { a.totals[3 * gwave] = lines_seen; a.totals[3 * gwave + 1] = hits; a.totals[3 * gwave + 2] = depth_acc; }
 }
 
 // The exact parser over the queued lines (one lane per line, bytes read straight from global memory).
@@ -816,73 +602,101 @@ __global__ __launch_bounds__(256) void k_scan_queue(ScanArgs a, SiteSetDev ss) {
     if (hits) atomicAdd((unsigned long long *)&a.status[2], (unsigned long long)hits);
 }
 
-// status words + queue control for one sample; when the queue overflowed, resets the counters the exact pass recounts
-__global__ void k_scan_init(uint64_t *status, uint32_t *ctl, int phase) {
-    if (phase == 0) { status[0] = ~0ull; status[1] = status[2] = status[3] = 0; ctl[0] = ctl[1] = 0; }
-    else if (ctl[1] != 0) { status[1] = status[2] = 0; }
+// status words + queue control for one sample (phase 0); sums of the per-wave totals after the fast pass (phase 1:
+// dropped when the queue overflowed, because the exact pass recounts) and after the exact pass (phase 2)
+__global__ void k_scan_init(uint64_t *status, uint32_t *ctl, const uint64_t *totals, uint32_t n_waves, int phase, int want_depth) {
+    __shared__ unsigned long long part[3][4];
+    if (phase == 0) {
+        if (threadIdx.x == 0) { status[0] = ~0ull; status[1] = status[2] = status[3] = 0; ctl[0] = ctl[1] = 0; ctl[16] = ctl[32] = 0; }
+        return;
+    }
+    const bool overflow = ctl[1] != 0;
+    if (phase == 1 && overflow) { if (threadIdx.x == 0) status[1] = status[2] = 0; return; }
+    if (phase == 2 && !overflow && !want_depth) return;
+    unsigned long long v[3] = {0, 0, 0};
+    for (uint32_t w = threadIdx.x; w < n_waves; w += blockDim.x)
+        for (int k = 0; k < 3; ++k) v[k] += totals[3 * w + k];
+    for (int k = 0; k < 3; ++k) {
+        for (int o = 32; o; o >>= 1) v[k] += __shfl_xor(v[k], o);
+        if ((threadIdx.x & 63) == 0) part[k][threadIdx.x >> 6] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) status[1 + threadIdx.x] += part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
 }
 
 int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *d_pileup, size_t nbytes,
                         uint64_t *d_status, int want_depth) {
     hipStream_t st = ctx->stream;
-    k_scan_init<<<1, 1, 0, st>>>(d_status, ss->slow_ctl, 0);
+    k_scan_init<<<1, 64, 0, st>>>(d_status, ss->slow_ctl, nullptr, 0, 0, 0);
     if (!nbytes) return SNPGPU_OK;
     ScanArgs sa;
     uintptr_t addr = (uintptr_t)d_pileup;
     sa.base = (const uint8_t *)(addr & ~(uintptr_t)15);
     sa.lo = addr & 15;
     sa.hi = sa.lo + nbytes;
-    sa.n_btiles = (sa.hi + SCAN_BTILE - 1) / SCAN_BTILE;
+    sa.n_tiles = (sa.hi + SCAN_TILE - 1) / SCAN_TILE;
     sa.site_line = ss->site_line;
     sa.status = d_status;
     sa.want_depth = want_depth;
     sa.queue = ss->slow_queue;
-    sa.q_cap = SNPGPU_SLOW_QUEUE_CAP;
+    // the tail of the queue allocation holds the per-wave totals (3 words x up to 4096 waves) and, in the tuning
+    // modes, the per-wave timing records (8 words each)
+    sa.q_cap = SNPGPU_SLOW_QUEUE_CAP - 65536;
+    sa.totals = ss->slow_queue + SNPGPU_SLOW_QUEUE_CAP - 16384;
     sa.ctl = ss->slow_ctl;
     sa.dbg = nullptr;
-    static int blocks_per_cu = -1, mode = 0;
+    static int blocks_per_cu = -1, mode = 0, chunk_tiles = 0, waves = 16;
     if (blocks_per_cu < 0) {                                // tuning knobs (development only)
-        const char *b = getenv("SNPGPU_SCAN_BLOCKS_PER_CU"), *m = getenv("SNPGPU_SCAN_MODE");
-        blocks_per_cu = b ? atoi(b) : 4;
+        const char *b = getenv("SNPGPU_SCAN_BLOCKS_PER_CU"), *m = getenv("SNPGPU_SCAN_MODE"), *c = getenv("SNPGPU_SCAN_CHUNK"),
+                   *w = getenv("SNPGPU_SCAN_WAVES");
+        blocks_per_cu = b && atoi(b) > 0 ? atoi(b) : 1;
         mode = m ? atoi(m) : 0;
+        if (c && atoi(c) > 0) chunk_tiles = atoi(c);
+        if (w && atoi(w) >= 1 && atoi(w) <= 16) waves = atoi(w);
+        for (auto f : {(const void *)k_scan_wave<false, 0>, (const void *)k_scan_wave<false, 1>, (const void *)k_scan_wave<false, 2>,
+                       (const void *)k_scan_wave<true, 0>})
+            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    uint64_t max_blocks = (uint64_t)ctx->n_cu * blocks_per_cu;
-    unsigned grid = (unsigned)(sa.n_btiles < max_blocks ? sa.n_btiles : max_blocks);
-    uint64_t exact_max = (uint64_t)ctx->n_cu * 2;
-    unsigned grid_exact = (unsigned)(sa.n_btiles < exact_max ? sa.n_btiles : exact_max);
+    // Exactly blocks_per_cu workgroups fit on a CU (the LDS request is padded to make sure) and the grid is
+    // n_cu * blocks_per_cu, so every CU runs the same number of waves and equal static shares finish together.
+    const size_t lds_need = sizeof(ScanShared) - sizeof(WaveSlots) + (size_t)waves * sizeof(WaveSlots);
+    const size_t lds_pad = (size_t)(160 * 1024) / (blocks_per_cu + 1) + 1024;
+    const size_t lds = lds_need > lds_pad ? lds_need : lds_pad;
+    const uint64_t max_waves = (uint64_t)ctx->n_cu * blocks_per_cu * waves;
+    uint64_t chunk = chunk_tiles ? (uint64_t)chunk_tiles : (sa.n_tiles + max_waves - 1) / max_waves;   // 0: static shares
+    if (chunk < 1) chunk = 1;
+    sa.chunk_tiles = (uint32_t)chunk;
+    sa.ticket = chunk_tiles ? ss->slow_ctl + 16 : nullptr;
+    const uint64_t n_chunks = (sa.n_tiles + chunk - 1) / chunk, want = (n_chunks + waves - 1) / waves;
+    const uint64_t cap = (uint64_t)ctx->n_cu * blocks_per_cu;
+    const unsigned grid = (unsigned)(want < cap ? want : cap), threads = (unsigned)waves * 64;
+    const uint32_t n_waves = grid * (unsigned)waves;
     hipEvent_t ta = snpgpu_time_begin(ctx);
     if (want_depth) {
-        k_scan_pileup<0, true><<<grid_exact, SCAN_THREADS, 0, st>>>(sa, ss->dev);
-    } else {
-        if (mode == 1) k_scan_pileup<1, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
-        else if (mode == 2) k_scan_pileup<2, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
-        else if (mode == 3) k_scan_pileup<3, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
-        else if (mode == 4) k_scan_pileup<4, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
-        else if (mode == 6) k_scan_pileup<6, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
-        else if (mode == 5) {                              // phase timing: cycle totals go to the queue tail
-            sa.dbg = (unsigned long long *)(ss->slow_queue + SNPGPU_SLOW_QUEUE_CAP - 16);
-            (void)hipMemsetAsync(sa.dbg, 0, 128, st);
-            k_scan_pileup<5, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);
-            unsigned long long h[10];
-            (void)hipMemcpyAsync(h, sa.dbg, 80, hipMemcpyDeviceToHost, st);
+        k_scan_wave<true, 0><<<grid, threads, lds, st>>>(sa, ss->dev);
+    } else if (mode == 8 || mode == 9) {                    // tuning: per-wave time stamps (9) + phase cycle counts (8)
+        sa.dbg = (unsigned long long *)(ss->slow_queue + SNPGPU_SLOW_QUEUE_CAP - 65536);
+        if (mode == 8) k_scan_wave<false, 2><<<grid, threads, lds, st>>>(sa, ss->dev);
+        else k_scan_wave<false, 1><<<grid, threads, lds, st>>>(sa, ss->dev);
+        if (const char *path = getenv("SNPGPU_SCAN_DUMP")) {
+            const size_t nrec = (size_t)n_waves * 8;
+            unsigned long long *recs = (unsigned long long *)malloc(nrec * 8);
             (void)hipStreamSynchronize(st);
-            fprintf(stderr, "scan phases (cycles summed over waves): consumer B %llu list %llu C %llu barrier %llu | loader load+wait %llu barrier %llu | blocks %u\n",
-                    h[0], h[1], h[2], h[3], h[9], h[8], grid);
+            (void)hipMemcpy(recs, sa.dbg, nrec * 8, hipMemcpyDeviceToHost);
+            if (FILE *f = fopen(path, "wb")) { fwrite(recs, 8, nrec, f); fclose(f); }
+            free(recs);
         }
-        else if (mode == 7) k_scan_pileup<0, false><<<grid, SCAN_THREADS, 0, st>>>(sa, ss->dev);   // barrier version
-        else {
-            ScanArgs ra = sa;
-            ra.n_btiles = (sa.hi + SCAN_TILE - 1) / SCAN_TILE;          // 4 KiB tiles
-            uint64_t want = (ra.n_btiles + SCAN_WAVES - 1) / SCAN_WAVES;
-            unsigned rgrid = (unsigned)(want < max_blocks ? want : max_blocks);
-            k_scan_wave<<<rgrid, SCAN_WAVES * 64, 0, st>>>(ra, ss->dev);
-        }
+        sa.dbg = nullptr;
+    } else {
+        k_scan_wave<false, 0><<<grid, threads, lds, st>>>(sa, ss->dev);
     }
     snpgpu_time_end(ctx, SNPGPU_K_SCAN, ta);
     if (!want_depth) {
         k_scan_queue<<<ctx->n_cu, 256, 0, st>>>(sa, ss->dev);
-        k_scan_init<<<1, 1, 0, st>>>(d_status, ss->slow_ctl, 1);
-        k_scan_pileup<0, true><<<grid_exact, SCAN_THREADS, 0, st>>>(sa, ss->dev);   // returns at once unless the queue overflowed
+        k_scan_init<<<1, 256, 0, st>>>(d_status, ss->slow_ctl, sa.totals, n_waves, 1, 0);
+        if (sa.ticket) sa.ticket = ss->slow_ctl + 32;
+        k_scan_wave<true, 0><<<grid, threads, lds, st>>>(sa, ss->dev);   // returns at once unless the queue overflowed
     }
+    k_scan_init<<<1, 256, 0, st>>>(d_status, ss->slow_ctl, sa.totals, n_waves, 2, want_depth);
     return SNPGPU_OK;
 }

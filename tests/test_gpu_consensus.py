@@ -241,3 +241,26 @@ def test_device_generated_pileup_vs_oracle(d):
         keys = [(b"synth_chr1", int(p_)) for p_ in pos]
         from tests.gpu_util import check_against_oracle
         check_against_oracle(d, data, keys, keys[::11], po.CallerParams(0, 0.6, 3, 0, 0.0))
+
+
+def test_contig_changes_and_contigs_outside_the_site_set(d):
+    """A genome-wide pileup walks through every contig; the scan kernel's per-wave contig hint must follow it —
+    contigs with sites, contigs without any site, names longer than the 16-byte register compare and names longer
+    than the hint itself (those lines take the exact parser)."""
+    from snp_pipeline_amd.device import PileupFormatError
+    from tests.gpu_util import check_against_oracle, gpu_consensus
+    names = ("ctgA", "ctg_without_sites_1", "NODE_17_length_48211_cov_31.5", "b", "ctg_without_sites_2",
+             "x" * 60, "ctgA2")
+    data, _, sites = fuzz.synth_pileup(31, genome_len=2500, n_sites=40, contigs=names)
+    snps = [k for k in sites if b"without" not in k[0]]
+    res = check_against_oracle(d, data, snps, snps[::7], po.CallerParams(0, 0.6, 3, 0, 0.0))
+    assert res.n_lines == data.count(b"\n")
+    # no site at all on the contigs of the file / an empty site set
+    check_against_oracle(d, data, [(b"elsewhere", 5)], [], po.CallerParams())
+    cons, res, _ = gpu_consensus(d, data, [], [], po.CallerParams())
+    assert cons == b"" and res.n_lines == data.count(b"\n")
+    # a malformed position on a contig without sites still raises, as pileup.py:426 does for every line
+    bad = data.replace(b"ctg_without_sites_2\t1200\t", b"ctg_without_sites_2\t12o0\t")
+    assert bad != data
+    with pytest.raises(PileupFormatError):
+        gpu_consensus(d, bad, snps, [], po.CallerParams())
