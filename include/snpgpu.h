@@ -140,10 +140,13 @@ uint32_t snpgpu_siteset_size(const snpgpu_siteset *ss);
 int  snpgpu_call_consensus_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const void *d_pileup, size_t nbytes,
                                const snpgpu_caller_params *params, uint8_t *d_out_base, uint8_t *d_out_filters,
                                snpgpu_site_counts *d_out_counts, uint64_t *d_status, int want_depth_sum);
-/* Many samples resident in one device buffer; sample i is bytes [h_offsets[i], h_offsets[i+1]).
- * Outputs are [n_samples][n_sites] row-major; d_status is [n_samples][4]. */
+/* Many samples resident in one device buffer: ONE scan launch and ONE call launch serve up to 256 samples (the
+ * waves of the scan are dealt to the samples in proportion to their sizes), which is what the throughput figures
+ * are quoted on.  Sample i is bytes [h_offsets[i], h_offsets[i] + h_sizes[i]) of d_pileups; h_sizes == NULL means
+ * the samples are packed back to back, h_sizes[i] = h_offsets[i+1] - h_offsets[i] (h_offsets then has n_samples + 1
+ * entries).  Outputs are [n_samples][n_sites] row-major; d_status is [n_samples][4]. */
 int  snpgpu_call_consensus_batch_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const void *d_pileups,
-                                     const uint64_t *h_offsets, uint32_t n_samples,
+                                     const uint64_t *h_offsets, const uint64_t *h_sizes, uint32_t n_samples,
                                      const snpgpu_caller_params *params, uint8_t *d_out_base,
                                      uint8_t *d_out_filters, uint64_t *d_status);
 /* Host-buffer form (copies the pileup to the device, runs, copies results back, synchronous).

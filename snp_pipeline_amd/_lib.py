@@ -55,7 +55,7 @@ SIGNATURES = {
     "snpgpu_siteset_destroy": (None, [_P]),
     "snpgpu_siteset_size": (C.c_uint32, [_P]),
     "snpgpu_call_consensus_dev": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(CallerParams), _P, _P, _P, _P, C.c_int]),
-    "snpgpu_call_consensus_batch_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(CallerParams), _P, _P, _P]),
+    "snpgpu_call_consensus_batch_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint32, C.POINTER(CallerParams), _P, _P, _P]),
     "snpgpu_call_consensus": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(CallerParams), _P, _P, _P, _P, C.c_int]),
     "snpgpu_siteset_line_offsets": (C.c_int, [_P, _P, _P]),
     "snpgpu_packed_row_bytes": (C.c_size_t, [C.c_uint32]),

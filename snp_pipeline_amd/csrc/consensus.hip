@@ -15,9 +15,6 @@
 // (scalar ALU work on gfx950: one ballot == one SGPR pair).
 #include "internal.h"
 
-int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *d_pileup, size_t nbytes,
-                        uint64_t *d_status, int want_depth);      // scan.hip
-
 #define SCAN_ERR_FEW_FIELDS 1
 #define SCAN_ERR_BAD_POS 2
 #define SCAN_ERR_NON_ASCII 3
@@ -31,8 +28,8 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t
 #define HIST_BINS 384           // [fwd | rev | neither] x 128 upper-cased symbols
 
 struct CallArgs {
-    const uint8_t *buf;         // first byte of the file
-    uint64_t nbytes;
+    const SampleDev *samples;   // the batch; outputs and site_line are [n_samples][n_sites] row-major
+    uint32_t n_samples;
     const uint64_t *site_line;
     const uint8_t *site_flags;
     uint32_t n_sites;
@@ -105,9 +102,14 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
     WaveLds &L = lds[wave];
     const uint64_t lt = low_mask(lane);                     // lanes below me
 
-    for (uint32_t site = blockIdx.x * CALL_WAVES + wave; site < a.n_sites; site += gridDim.x * CALL_WAVES) {
+    const uint64_t n_work = (uint64_t)a.n_samples * a.n_sites;
+    for (uint64_t site = (uint64_t)blockIdx.x * CALL_WAVES + wave; site < n_work; site += (uint64_t)gridDim.x * CALL_WAVES) {
+        const uint32_t sample = (uint32_t)(site / a.n_sites);
+        const SampleDev sd = a.samples[sample];
+        const uint8_t *buf = sd.buf;
+        const uint64_t nbytes = sd.nbytes;
         const uint64_t lv = a.site_line[site];
-        const uint32_t sflags = a.site_flags[site];
+        const uint32_t sflags = a.site_flags[site - (uint64_t)sample * a.n_sites];
         uint32_t status = SNPGPU_ST_NO_LINE, filters = 0, cons = '-', out_b = '-';
         uint32_t raw_depth = 0, good = 0, nfwd = 0, nrev = 0, nsym = 0, ref = 0;
         bool have_hist = false;
@@ -119,12 +121,12 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
             uint32_t nfields = 0, line_len = 0;
             bool prev_ws = true;
             // the first 192 bytes are requested at once (one memory round trip covers a typical 30x line)
-            const uint32_t pre0 = ls + lane < a.nbytes ? a.buf[ls + lane] : 10u;
-            const uint32_t pre1 = ls + 64 + lane < a.nbytes ? a.buf[ls + 64 + lane] : 10u;
-            const uint32_t pre2 = ls + 128 + lane < a.nbytes ? a.buf[ls + 128 + lane] : 10u;
+            const uint32_t pre0 = ls + lane < nbytes ? buf[ls + lane] : 10u;
+            const uint32_t pre1 = ls + 64 + lane < nbytes ? buf[ls + 64 + lane] : 10u;
+            const uint32_t pre2 = ls + 128 + lane < nbytes ? buf[ls + 128 + lane] : 10u;
             for (uint64_t k = 0;; k += 64) {
                 uint64_t p = ls + k + lane;
-                uint32_t c = k == 0 ? pre0 : (k == 64 ? pre1 : (k == 128 ? pre2 : (p < a.nbytes ? a.buf[p] : 10u)));
+                uint32_t c = k == 0 ? pre0 : (k == 64 ? pre1 : (k == 128 ? pre2 : (p < nbytes ? buf[p] : 10u)));
                 if (k + lane < CALL_LBUF) L.line[k + lane] = (uint8_t)c;
                 uint64_t T = __ballot(is_term(c));
                 uint64_t valid = T ? low_mask((uint32_t)__ffsll((long long)T)) : ~0ull;   // up to and incl. the terminator
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_wave_barrier();
             status = SNPGPU_ST_OK;
-            const uint8_t *gl = a.buf + ls;                 // line bytes in global memory
+            const uint8_t *gl = buf + ls;                 // line bytes in global memory
             auto lb = [&](uint32_t off) -> uint32_t { return off < CALL_LBUF ? L.line[off] : (uint32_t)gl[off]; };
             if (nfields < 4) status = SNPGPU_ST_SHORT_LINE;
             else if (L.fe[2] - L.fs[2] != 1) status = SNPGPU_ST_MULTI_REF;
@@ -341,35 +343,62 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
 // ------------------------------------------------------------------------------------------------
 //                                           host API
 // ------------------------------------------------------------------------------------------------
-static int enqueue_sample(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *d_pileup, size_t nbytes,
-                          const snpgpu_caller_params *prm, uint8_t *d_out_base, uint8_t *d_out_filters,
-                          snpgpu_site_counts *d_out_counts, uint64_t *d_status, int want_depth) {
+struct SampleIO { const uint8_t *d_pileup; size_t nbytes; uint64_t *d_status; };
+
+// Scan + call for up to SNPGPU_SCAN_MAX_BATCH samples: one scan launch and one call launch for all of them.
+// d_site_line == nullptr: the rows live in the context's scratch; outputs are [n][n_sites] row-major.
+static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleIO *io, uint32_t n,
+                         const snpgpu_caller_params *prm, uint8_t *d_out_base, uint8_t *d_out_filters,
+                         snpgpu_site_counts *d_out_counts, uint64_t *d_site_line, int want_depth) {
     hipStream_t st = ctx->stream;
     const uint32_t n_sites = ss->n_sites;
-    if (n_sites) HIP_TRY(ctx, hipMemsetAsync(ss->site_line, 0, 8ull * n_sites, st));
+    const size_t ws_bytes = (snpgpu_scan_workspace_bytes(ctx, n) + 255) / 256 * 256;
+    const size_t rows_bytes = d_site_line ? 0 : 8ull * n_sites * n;
+    void *ws = nullptr;
     {
-        int rc = snpgpu_enqueue_scan(ctx, ss, d_pileup, nbytes, d_status, want_depth);
+        int rc = snpgpu_scratch(ctx, ws_bytes + rows_bytes + 256, &ws);
+        if (rc) return rc;
+    }
+    if (!d_site_line) d_site_line = (uint64_t *)((char *)ws + ws_bytes);
+    if (n_sites) HIP_TRY(ctx, hipMemsetAsync(d_site_line, 0, 8ull * n_sites * n, st));
+    std::vector<SampleDev> samples(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        samples[i].buf = io[i].d_pileup;
+        samples[i].nbytes = io[i].nbytes;
+        samples[i].status = io[i].d_status;
+        samples[i].wave0 = samples[i].n_waves = 0;
+    }
+    {
+        int rc = snpgpu_enqueue_scan(ctx, ss, samples, ws, d_site_line, want_depth);
         if (rc) return rc;
     }
     if (n_sites) {
         CallArgs ca;
-        ca.buf = d_pileup;
-        ca.nbytes = nbytes;
-        ca.site_line = ss->site_line;
+        ca.samples = (const SampleDev *)ws;
+        ca.n_samples = n;
+        ca.site_line = d_site_line;
         ca.site_flags = ss->dev.flags;
         ca.n_sites = n_sites;
         ca.prm = *prm;
         ca.out_base = d_out_base;
         ca.out_filters = d_out_filters;
         ca.out_counts = d_out_counts;
-        uint32_t blocks = (n_sites + CALL_WAVES - 1) / CALL_WAVES;
-        uint32_t max_blocks = (uint32_t)ctx->n_cu * 16;
+        const uint64_t blocks = ((uint64_t)n_sites * n + CALL_WAVES - 1) / CALL_WAVES;
+        const uint64_t max_blocks = (uint64_t)ctx->n_cu * 16;
         hipEvent_t ta = snpgpu_time_begin(ctx);
-        k_call_sites<<<blocks < max_blocks ? blocks : max_blocks, CALL_WAVES * 64, 0, st>>>(ca);
+        k_call_sites<<<(unsigned)(blocks < max_blocks ? blocks : max_blocks), CALL_WAVES * 64, 0, st>>>(ca);
         snpgpu_time_end(ctx, SNPGPU_K_CALL, ta);
     }
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;
+}
+
+static int enqueue_sample(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *d_pileup, size_t nbytes,
+                          const snpgpu_caller_params *prm, uint8_t *d_out_base, uint8_t *d_out_filters,
+                          snpgpu_site_counts *d_out_counts, uint64_t *d_status, int want_depth) {
+    SampleIO io{d_pileup, nbytes, d_status};
+    // the single-sample forms keep the line offsets in the site set, where snpgpu_siteset_line_offsets finds them
+    return enqueue_group(ctx, ss, &io, 1, prm, d_out_base, d_out_filters, d_out_counts, ss->site_line, want_depth);
 }
 
 extern "C" {
@@ -393,18 +422,31 @@ int snpgpu_siteset_line_offsets(snpgpu_ctx *ctx, const snpgpu_siteset *ss, uint6
 }
 
 int snpgpu_call_consensus_batch_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const void *d_pileups,
-                                    const uint64_t *h_offsets, uint32_t n_samples,
+                                    const uint64_t *h_offsets, const uint64_t *h_sizes, uint32_t n_samples,
                                     const snpgpu_caller_params *params, uint8_t *d_out_base,
                                     uint8_t *d_out_filters, uint64_t *d_status) {
     if (!ctx || !ss || !params || !d_status || !h_offsets) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint8_t *p = (const uint8_t *)d_pileups;
-    for (uint32_t i = 0; i < n_samples; ++i) {
-        if (h_offsets[i + 1] < h_offsets[i]) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "offsets must be non-decreasing");
-        size_t off = (size_t)i * ss->n_sites;
-        int rc = enqueue_sample(ctx, ss, p + h_offsets[i], h_offsets[i + 1] - h_offsets[i], params,
-                                d_out_base + off, d_out_filters + off, nullptr,
-                                d_status + (size_t)i * SNPGPU_SCAN_STATUS_WORDS, 0);
+    if (!h_sizes)
+        for (uint32_t i = 0; i < n_samples; ++i)
+            if (h_offsets[i + 1] < h_offsets[i]) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "offsets must be non-decreasing");
+    // groups of samples share one scan launch and one call launch; the line-offset rows of a group (8 bytes per
+    // sample and site) live in scratch, so the group is also bounded by 1 GiB of rows
+    uint32_t group = SNPGPU_SCAN_MAX_BATCH;
+    if (ss->n_sites) {
+        const uint64_t by_mem = (1ull << 30) / (8ull * ss->n_sites);
+        if (by_mem < group) group = by_mem ? (uint32_t)by_mem : 1;
+    }
+    std::vector<SampleIO> io;
+    for (uint32_t i0 = 0; i0 < n_samples; i0 += group) {
+        const uint32_t n = n_samples - i0 < group ? n_samples - i0 : group;
+        io.resize(n);
+        for (uint32_t k = 0; k < n; ++k)
+            io[k] = SampleIO{p + h_offsets[i0 + k], (size_t)(h_sizes ? h_sizes[i0 + k] : h_offsets[i0 + k + 1] - h_offsets[i0 + k]),
+                             d_status + (size_t)(i0 + k) * SNPGPU_SCAN_STATUS_WORDS};
+        const size_t off = (size_t)i0 * ss->n_sites;
+        int rc = enqueue_group(ctx, ss, io.data(), n, params, d_out_base + off, d_out_filters + off, nullptr, nullptr, 0);
         if (rc) return rc;
     }
     return SNPGPU_OK;

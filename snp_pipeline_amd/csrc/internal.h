@@ -59,6 +59,18 @@ struct snpgpu_siteset {
     uint32_t n_sites = 0;
 };
 
+// One pileup of a batch, as the scan and call kernels see it.
+struct SampleDev {
+    const uint8_t *buf;         // first byte of the file (device memory, any alignment)
+    uint64_t nbytes;
+    uint64_t *status;           // SNPGPU_SCAN_STATUS_WORDS
+    uint32_t wave0, n_waves;    // the scan launch's waves [wave0, wave0 + n_waves) work on this sample
+};
+size_t snpgpu_scan_workspace_bytes(const snpgpu_ctx *ctx, uint32_t n_samples);
+int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<SampleDev> &h_samples, void *workspace,
+                        uint64_t *d_site_line, int want_depth);
+#define SNPGPU_SCAN_MAX_BATCH 256   // samples per scan launch (each gets at least ~16 of the 4096 waves)
+
 int snpgpu_set_error(snpgpu_ctx *ctx, int code, const char *fmt, ...);
 int snpgpu_scratch(snpgpu_ctx *ctx, size_t bytes, void **out);
 

@@ -36,21 +36,38 @@
 #define SCAN_ERR_NON_ASCII 3
 
 struct ScanArgs {
-    const uint8_t *base;     // 16-byte aligned pointer at or below the first byte of the file
-    uint64_t lo, hi;         // the file is base[lo, hi)
-    uint64_t n_tiles;        // 4 KiB tiles
-    uint64_t *site_line;     // n_sites
-    uint64_t *status;        // SNPGPU_SCAN_STATUS_WORDS
-    uint64_t *queue;         // file offsets of lines left to the exact parser
+    const SampleDev *samples; // one launch covers a batch of pileups; each wave works inside exactly one of them
+    uint32_t n_samples;
+    uint32_t n_sites;
+    uint64_t *site_line;     // [n_samples][n_sites]
+    uint64_t *queue;         // (sample << 40 | file offset) of lines left to the exact parser
     uint32_t *ctl;           // [0] queue length, [1] queue overflowed
     uint32_t q_cap;
     int want_depth;
-    uint32_t chunk_tiles;    // tiles per work ticket
-    uint32_t *ticket;        // next chunk to hand out (starts at 0; chunk c < n_waves belongs to wave c)
     uint64_t *totals;        // per-wave {lines, matched, depth sum}: same-address atomics from thousands of waves
                              // serialise at ~12 ns each and stall the loads of the waves still running
     unsigned long long *dbg; // optional: per-wave timing records (tuning only)
 };
+// the part of a sample's description the parse loop works with (wave-uniform)
+struct ScanFile {
+    const uint8_t *base;     // 16-byte aligned pointer at or below the first byte of the file
+    uint64_t lo, hi;         // the file is base[lo, hi)
+    uint64_t *site_line;     // this sample's row
+    uint64_t *status;        // this sample's SNPGPU_SCAN_STATUS_WORDS
+    uint64_t sample;         // index << 40, OR-ed into queue entries
+};
+__device__ __forceinline__ ScanFile scan_file(const ScanArgs &a, uint32_t i) {
+    const SampleDev sd = a.samples[i];
+    ScanFile f;
+    const uintptr_t addr = (uintptr_t)sd.buf;
+    f.base = (const uint8_t *)(addr & ~(uintptr_t)15);
+    f.lo = addr & 15;
+    f.hi = f.lo + sd.nbytes;
+    f.site_line = a.site_line + (size_t)i * a.n_sites;
+    f.status = sd.status;
+    f.sample = (uint64_t)i << 40;
+    return f;
+}
 
 struct WaveSlots {
     uint4 slot[SCAN_NBUF][SCAN_WTILE_CHUNKS];
@@ -215,6 +232,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     extern __shared__ uint4 scan_lds[];
     ScanShared &sh = *(ScanShared *)scan_lds;
     if (kExact && !a.want_depth && a.ctl[1] == 0) return;    // fallback pass: only when the slow-line queue overflowed
+    if ((uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) >= a.samples[a.n_samples].wave0) return;   // spare wave
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveSlots &ws = sh.w[wave];
@@ -237,14 +255,22 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     }
     __syncthreads();                                          // the only barrier: digit_mask table visible
 
-    const uint64_t n_tiles = a.n_tiles;
-    const uint32_t waves_per_block = blockDim.x >> 6;
-    const uint64_t gwave = (uint64_t)blockIdx.x * waves_per_block + wave, n_waves = (uint64_t)gridDim.x * waves_per_block;
-    auto interior = [&](uint64_t tt) { uint64_t x0 = tt * SCAN_TILE; return x0 >= a.lo + 16 && x0 + SCAN_TILE + SCAN_HALO <= a.hi; };
+    const uint64_t gwave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    // my sample: the host dealt the waves of the launch to the samples in proportion to their sizes
+    uint32_t si = 0;
+    {
+        uint32_t lo_i = 0, hi_i = a.n_samples;                // last sample whose first wave is <= gwave
+        while (hi_i - lo_i > 1) { const uint32_t mid = (lo_i + hi_i) >> 1; if (a.samples[mid].wave0 <= gwave) lo_i = mid; else hi_i = mid; }
+        si = __builtin_amdgcn_readfirstlane(lo_i);
+    }
+    const uint32_t s_wave0 = __builtin_amdgcn_readfirstlane(a.samples[si].wave0), s_waves = __builtin_amdgcn_readfirstlane(a.samples[si].n_waves);
+    const ScanFile f = scan_file(a, si);
+    const uint64_t n_tiles = (f.hi + SCAN_TILE - 1) / SCAN_TILE;
+    auto interior = [&](uint64_t tt) { uint64_t x0 = tt * SCAN_TILE; return x0 >= f.lo + 16 && x0 + SCAN_TILE + SCAN_HALO <= f.hi; };
     // request tile tt into slot `buf`; returns the number of DMA wave-instructions now in flight for it (0: staged synchronously)
     auto request = [&](uint64_t tt, int buf) -> uint32_t {
         if (interior(tt)) {
-            const uint8_t *g = a.base + tt * SCAN_TILE - 16 + (size_t)lane * 16;
+            const uint8_t *g = f.base + tt * SCAN_TILE - 16 + (size_t)lane * 16;
             const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)&ws.slot[buf][0]);
 #pragma unroll
             for (int r = 0; r < SCAN_DMA_PER_TILE; ++r) {
@@ -265,7 +291,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     int64_t idx = x0 + (int64_t)e * 16 + 4 * k + j;
-                    uint32_t bb = (idx >= (int64_t)a.lo && idx < (int64_t)a.hi) ? (uint32_t)a.base[idx] : 10u;
+                    uint32_t bb = (idx >= (int64_t)f.lo && idx < (int64_t)f.hi) ? (uint32_t)f.base[idx] : 10u;
                     d[k] |= bb << (8 * j);
                 }
             ws.slot[buf][e] = make_uint4(d[0], d[1], d[2], d[3]);
@@ -303,36 +329,16 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     };
     if (!kExact) adopt(load_hint(ss, 0, ws.hint_w, lane));
 
-    // Work distribution: the file is cut into chunks of a.chunk_tiles contiguous tiles.  Chunk w is wave w's first one;
-    // after that a wave draws tickets from a device counter — the workgroups of a launch are not spread evenly over
-    // the CUs, so equal static shares would leave most of the chip waiting for the CUs that got more waves.  The ticket
-    // for the next chunk is drawn when a chunk is started and first looked at when its last tile has been requested, so
-    // the atomic's round trip is never waited for.  Tiles inside a chunk are consecutive: a pileup is sorted, so the
-    // contig hint and the bitmap window usually survive from one tile to the next.
-    const uint64_t chunk = a.chunk_tiles, n_chunks = (n_tiles + chunk - 1) / chunk;
-    if (gwave >= n_chunks) {
-        if (lane == 0) a.totals[3 * gwave] = a.totals[3 * gwave + 1] = a.totals[3 * gwave + 2] = 0;
-        return;
-    }
-    uint64_t s_tile = gwave * chunk, s_end = s_tile + chunk < n_tiles ? s_tile + chunk : n_tiles;
-    uint32_t drawn = 0;
-    bool dry = a.ticket == nullptr;                           // static shares: one chunk per wave
-    if (!dry && lane == 0) drawn = atomicAdd(a.ticket, 1u);
+    // Every wave takes one contiguous run of its sample's tiles: a pileup is sorted, so the contig hint and the bitmap
+    // window survive from one tile to the next.  Shares are static and equal; the launcher makes sure every CU holds
+    // the same number of waves.  (Drawing work tickets from a device counter was measured and rejected: same-address
+    // atomics cost ~12 ns each, device-wide, and stall the loads queued behind them.)
+    const uint64_t me = gwave - s_wave0, per = n_tiles / s_waves, rem = n_tiles % s_waves;
+    const uint64_t t_first = me * per + (me < rem ? me : rem), t_end = t_first + per + (me < rem ? 1 : 0);
     const uint64_t kNoTile = ~0ull;
-    auto next_tile = [&]() -> uint64_t {
-        if (s_tile == s_end) {
-            if (dry) return kNoTile;
-            const uint64_t c = n_waves + __builtin_amdgcn_readfirstlane(drawn);
-            if (c >= n_chunks) { dry = true; return kNoTile; }
-            if (lane == 0) drawn = atomicAdd(a.ticket, 1u);
-            s_tile = c * chunk;
-            s_end = s_tile + chunk < n_tiles ? s_tile + chunk : n_tiles;
-        }
-        return s_tile++;
-    };
-    uint64_t tt = next_tile(), t_nxt = next_tile();
+    uint64_t tt = t_first < t_end ? t_first : kNoTile, t_nxt = t_first + 1 < t_end ? t_first + 1 : kNoTile;
     uint32_t dma_next = 0;                                    // DMA instructions in flight for the tile after the current one
-    (void)request(tt, 0);
+    if (tt != kNoTile) (void)request(tt, 0);
     if (t_nxt != kNoTile) dma_next = request(t_nxt, 1);
     int cur = 0;
     bool first_tile = true;
@@ -391,9 +397,9 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
 #pragma nounroll
                         for (int b = 0; b < 16; ++b) {
                             const uint64_t st = t0 + (uint64_t)((i * 64 + (int)lane) * 16 + b + 1);
-                            if (st < a.lo || st >= a.hi) S &= ~(1ull << (16 * i + b));
+                            if (st < f.lo || st >= f.hi) S &= ~(1ull << (16 * i + b));
                         }
-                    s0 = s0 && t0 >= a.lo && t0 < a.hi;
+                    s0 = s0 && t0 >= f.lo && t0 < f.hi;
                 }
                 const uint32_t cnt = (uint32_t)__popcll(S) + (s0 ? 1u : 0u);
                 const uint32_t incl = wave_inclusive_sum(cnt);
@@ -467,10 +473,10 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             const uint32_t x1 = (q.y ^ 0x30303030u) & dm.x, x2 = (q.z ^ 0x30303030u) & dm.y, x3 = (q.w ^ 0x30303030u) & dm.z;
                             bad |= (((x1 + 0x76767676u) | x1) | ((x2 + 0x76767676u) | x2) | ((x3 + 0x76767676u) | x3)) & 0x80808080u;
                             const uint64_t pos = ((uint64_t)(four_digits(x1) * 10000u + four_digits(x2))) * 1000ull + four_digits(x3 << 8);
-                            const uint64_t off1 = t0 + (uint64_t)s - a.lo + 1;
+                            const uint64_t off1 = t0 + (uint64_t)s - f.lo + 1;
                             if (active && bad != 0) {                                    // rare: leave it to k_scan_queue
                                 const uint32_t qi = atomicAdd(&a.ctl[0], 1u);
-                                if (qi < a.q_cap) a.queue[qi] = off1 - 1; else a.ctl[1] = 1u;
+                                if (qi < a.q_cap) a.queue[qi] = f.sample | (off1 - 1); else a.ctl[1] = 1u;
                             }
                             const bool probe = active && bad == 0 && hint_present && pos <= (uint64_t)h_max;
                             // Site bitmap probe without touching memory: the wave keeps a 64-dword window of the
@@ -499,18 +505,18 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             const uint32_t shf = (uint32_t)(bit & 31);
                             if ((word >> shf) & 1u) {
                                 const uint32_t site = rk + __popc(word & ((1u << shf) - 1u));
-                                atomicMax((unsigned long long *)&a.site_line[site], (unsigned long long)off1);
+                                atomicMax((unsigned long long *)&f.site_line[site], (unsigned long long)off1);
                                 ++hits;
                             }
                         }
                     }
                     } else {
-                        TileView tv{tile, a.base, t0, a.hi, (int64_t)(SCAN_TILE + SCAN_HALO)};
+                        TileView tv{tile, f.base, t0, f.hi, (int64_t)(SCAN_TILE + SCAN_HALO)};
                         for (uint32_t j = lane; j < n_here; j += 64) {
                             const uint32_t s = lstart[j];
-                            const uint64_t file_off = t0 + (uint64_t)s - a.lo;
+                            const uint64_t file_off = t0 + (uint64_t)s - f.lo;
                             SlowLine sl = parse_line_slow(tv, s, a.want_depth);
-                            if (sl.err) { report_scan_error(a.status, file_off, sl.err); continue; }
+                            if (sl.err) { report_scan_error(f.status, file_off, sl.err); continue; }
                             depth_acc += sl.depth;
                             const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, sl.f0, sl.f0len) : 0xFFFFFFFFu;
                             if (cid == 0xFFFFFFFFu || sl.pos > (uint64_t)ss.max_pos[cid]) continue;
@@ -519,7 +525,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             const uint32_t shf = (uint32_t)(bit & 31);
                             if (!((word >> shf) & 1u)) continue;
                             const uint32_t site = rank[bit >> 5] + __popc(word & ((1u << shf) - 1u));
-                            atomicMax((unsigned long long *)&a.site_line[site], (unsigned long long)(file_off + 1));
+                            atomicMax((unsigned long long *)&f.site_line[site], (unsigned long long)(file_off + 1));
                             ++hits;
                         }
                     }
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                     uint32_t len = 0;
                     while (len < 4 * SCAN_HINT_WORDS && __builtin_amdgcn_readfirstlane((uint32_t)tile[s1 + len]) > 0x20u) ++len;
                     if (len >= 1 && len <= 4 * SCAN_HINT_WORDS - 4) {
-                        TileView tv{tile, a.base, t0, a.hi, (int64_t)(SCAN_TILE + SCAN_HALO)};
+                        TileView tv{tile, f.base, t0, f.hi, (int64_t)(SCAN_TILE + SCAN_HALO)};
                         const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, (int64_t)s1, len) : 0xFFFFFFFFu;
                         if (cid != 0xFFFFFFFFu) adopt(load_hint(ss, cid, ws.hint_w, lane));
                         else {                                       // not a contig of the site set: remember the name itself
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
         WTICK(t_b);
         // the slot just parsed receives the tile after next; the outstanding requests are then the next tile's (older)
         // and these, and the next top-of-loop wait leaves exactly these in flight
-        const uint64_t t_new = next_tile();
+        const uint64_t t_new = t_nxt != kNoTile && t_nxt + 1 < t_end ? t_nxt + 1 : kNoTile;
         dma_next = t_new != kNoTile ? request(t_new, cur) : 0;
         tt = t_nxt;
         t_nxt = t_new;
@@ -572,7 +578,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     }
 #undef WTICK
     // a byte >= 0x80 anywhere in this wave's share of the file (checked once: the answers are void anyway)
-    if (__ballot((any_hi & 0x80808080u) != 0) && lane == 0) report_scan_error(a.status, 0, SCAN_ERR_NON_ASCII);
+    if (__ballot((any_hi & 0x80808080u) != 0) && lane == 0) report_scan_error(f.status, 0, SCAN_ERR_NON_ASCII);
     for (int o = 32; o; o >>= 1) { hits += __shfl_xor(hits, o); lines_seen += __shfl_xor(lines_seen, o); }
     if (kExact && a.want_depth)
         for (int o = 32; o; o >>= 1) depth_acc += __shfl_xor(depth_acc, o);
@@ -582,13 +588,13 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
 // The exact parser over the queued lines (one lane per line, bytes read straight from global memory).
 __global__ __launch_bounds__(256) void k_scan_queue(ScanArgs a, SiteSetDev ss) {
     const uint32_t n = a.ctl[0];
-    if (n == 0 || a.ctl[1] != 0) return;                    // nothing queued, or overflow: the exact pass redoes the file
-    TileView tv{nullptr, a.base + a.lo, 0, a.hi - a.lo, 0}; // lds_limit 0: every byte comes from global memory
-    uint32_t hits = 0;
+    if (n == 0 || a.ctl[1] != 0) return;                    // nothing queued, or overflow: the exact pass redoes the files
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint64_t off = a.queue[i];
+        const uint64_t e = a.queue[i], off = e & ((1ull << 40) - 1);
+        const ScanFile f = scan_file(a, (uint32_t)(e >> 40));
+        TileView tv{nullptr, f.base + f.lo, 0, f.hi - f.lo, 0};   // lds_limit 0: every byte comes from global memory
         SlowLine sl = parse_line_slow(tv, (int64_t)off, 0);
-        if (sl.err) { report_scan_error(a.status, off, sl.err); continue; }
+        if (sl.err) { report_scan_error(f.status, off, sl.err); continue; }
         const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, sl.f0, sl.f0len) : 0xFFFFFFFFu;
         if (cid == 0xFFFFFFFFu || sl.pos > (uint64_t)ss.max_pos[cid]) continue;
         const uint64_t bit = ss.bit_off[cid] + (uint32_t)sl.pos;
@@ -596,26 +602,29 @@ __global__ __launch_bounds__(256) void k_scan_queue(ScanArgs a, SiteSetDev ss) {
         const uint32_t shf = (uint32_t)(bit & 31);
         if (!((word >> shf) & 1u)) continue;
         const uint32_t site = ss.rank[bit >> 5] + __popc(word & ((1u << shf) - 1u));
-        atomicMax((unsigned long long *)&a.site_line[site], (unsigned long long)(off + 1));
-        ++hits;
+        atomicMax((unsigned long long *)&f.site_line[site], (unsigned long long)(off + 1));
+        atomicAdd((unsigned long long *)&f.status[2], 1ull);
     }
-    if (hits) atomicAdd((unsigned long long *)&a.status[2], (unsigned long long)hits);
 }
 
-// status words + queue control for one sample (phase 0); sums of the per-wave totals after the fast pass (phase 1:
-// dropped when the queue overflowed, because the exact pass recounts) and after the exact pass (phase 2)
-__global__ void k_scan_init(uint64_t *status, uint32_t *ctl, const uint64_t *totals, uint32_t n_waves, int phase, int want_depth) {
+// One workgroup per sample.  Phase 0: status words (+ queue control) before the scan.  Phase 1: add the per-wave
+// totals of the fast pass — dropped when the queue overflowed, because the exact pass recounts.  Phase 2: add the
+// totals of the exact pass (when it ran).
+__global__ __launch_bounds__(256) void k_scan_init(const SampleDev *samples, uint32_t *ctl, const uint64_t *totals, int phase, int want_depth) {
     __shared__ unsigned long long part[3][4];
+    const SampleDev sd = samples[blockIdx.x];
+    uint64_t *status = sd.status;
     if (phase == 0) {
-        if (threadIdx.x == 0) { status[0] = ~0ull; status[1] = status[2] = status[3] = 0; ctl[0] = ctl[1] = 0; ctl[16] = ctl[32] = 0; }
+        if (threadIdx.x == 0) { status[0] = ~0ull; status[1] = status[2] = status[3] = 0; }
+        if (threadIdx.x == 0 && blockIdx.x == 0) ctl[0] = ctl[1] = 0;
         return;
     }
     const bool overflow = ctl[1] != 0;
     if (phase == 1 && overflow) { if (threadIdx.x == 0) status[1] = status[2] = 0; return; }
     if (phase == 2 && !overflow && !want_depth) return;
     unsigned long long v[3] = {0, 0, 0};
-    for (uint32_t w = threadIdx.x; w < n_waves; w += blockDim.x)
-        for (int k = 0; k < 3; ++k) v[k] += totals[3 * w + k];
+    for (uint32_t w = threadIdx.x; w < sd.n_waves; w += blockDim.x)
+        for (int k = 0; k < 3; ++k) v[k] += totals[3 * (size_t)(sd.wave0 + w) + k];
     for (int k = 0; k < 3; ++k) {
         for (int o = 32; o; o >>= 1) v[k] += __shfl_xor(v[k], o);
         if ((threadIdx.x & 63) == 0) part[k][threadIdx.x >> 6] = v[k];
@@ -624,53 +633,85 @@ __global__ void k_scan_init(uint64_t *status, uint32_t *ctl, const uint64_t *tot
     if (threadIdx.x < 3) status[1 + threadIdx.x] += part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
 }
 
-int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *d_pileup, size_t nbytes,
-                        uint64_t *d_status, int want_depth) {
+size_t snpgpu_scan_workspace_bytes(const snpgpu_ctx *ctx, uint32_t n_samples) {
+    return ((size_t)(n_samples + 1) * sizeof(SampleDev) + 255) / 256 * 256 + 3 * 8 * (size_t)ctx->n_cu * 2 * 16 + 256;
+}
+
+// Scans a batch of pileups with one launch.  h_samples[i].buf/nbytes/status are filled by the caller; the wave shares are
+// dealt here.  d_site_line is [n][n_sites] and must be zero.  `workspace` holds snpgpu_scan_workspace_bytes().
+int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<SampleDev> &h_samples, void *workspace,
+                        uint64_t *d_site_line, int want_depth) {
     hipStream_t st = ctx->stream;
-    k_scan_init<<<1, 64, 0, st>>>(d_status, ss->slow_ctl, nullptr, 0, 0, 0);
-    if (!nbytes) return SNPGPU_OK;
-    ScanArgs sa;
-    uintptr_t addr = (uintptr_t)d_pileup;
-    sa.base = (const uint8_t *)(addr & ~(uintptr_t)15);
-    sa.lo = addr & 15;
-    sa.hi = sa.lo + nbytes;
-    sa.n_tiles = (sa.hi + SCAN_TILE - 1) / SCAN_TILE;
-    sa.site_line = ss->site_line;
-    sa.status = d_status;
-    sa.want_depth = want_depth;
-    sa.queue = ss->slow_queue;
-    // the tail of the queue allocation holds the per-wave totals (3 words x up to 4096 waves) and, in the tuning
-    // modes, the per-wave timing records (8 words each)
-    sa.q_cap = SNPGPU_SLOW_QUEUE_CAP - 65536;
-    sa.totals = ss->slow_queue + SNPGPU_SLOW_QUEUE_CAP - 16384;
-    sa.ctl = ss->slow_ctl;
-    sa.dbg = nullptr;
-    static int blocks_per_cu = -1, mode = 0, chunk_tiles = 0, waves = 16;
+    const uint32_t n = (uint32_t)h_samples.size();
+    if (!n) return SNPGPU_OK;
+    static int blocks_per_cu = -1, mode = 0, waves = 16;
     if (blocks_per_cu < 0) {                                // tuning knobs (development only)
-        const char *b = getenv("SNPGPU_SCAN_BLOCKS_PER_CU"), *m = getenv("SNPGPU_SCAN_MODE"), *c = getenv("SNPGPU_SCAN_CHUNK"),
-                   *w = getenv("SNPGPU_SCAN_WAVES");
-        blocks_per_cu = b && atoi(b) > 0 ? atoi(b) : 1;
+        const char *b = getenv("SNPGPU_SCAN_BLOCKS_PER_CU"), *m = getenv("SNPGPU_SCAN_MODE"), *w = getenv("SNPGPU_SCAN_WAVES");
+        blocks_per_cu = b && atoi(b) > 0 && atoi(b) <= 2 ? atoi(b) : 1;
         mode = m ? atoi(m) : 0;
-        if (c && atoi(c) > 0) chunk_tiles = atoi(c);
         if (w && atoi(w) >= 1 && atoi(w) <= 16) waves = atoi(w);
         for (auto f : {(const void *)k_scan_wave<false, 0>, (const void *)k_scan_wave<false, 1>, (const void *)k_scan_wave<false, 2>,
                        (const void *)k_scan_wave<true, 0>})
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    // Exactly blocks_per_cu workgroups fit on a CU (the LDS request is padded to make sure) and the grid is
-    // n_cu * blocks_per_cu, so every CU runs the same number of waves and equal static shares finish together.
+    // Exactly blocks_per_cu workgroups fit on a CU (the LDS request is padded to make sure) and a full grid is
+    // n_cu * blocks_per_cu, so every CU runs the same number of waves and equal shares finish together.
     const size_t lds_need = sizeof(ScanShared) - sizeof(WaveSlots) + (size_t)waves * sizeof(WaveSlots);
     const size_t lds_pad = (size_t)(160 * 1024) / (blocks_per_cu + 1) + 1024;
     const size_t lds = lds_need > lds_pad ? lds_need : lds_pad;
     const uint64_t max_waves = (uint64_t)ctx->n_cu * blocks_per_cu * waves;
-    uint64_t chunk = chunk_tiles ? (uint64_t)chunk_tiles : (sa.n_tiles + max_waves - 1) / max_waves;   // 0: static shares
-    if (chunk < 1) chunk = 1;
-    sa.chunk_tiles = (uint32_t)chunk;
-    sa.ticket = chunk_tiles ? ss->slow_ctl + 16 : nullptr;
-    const uint64_t n_chunks = (sa.n_tiles + chunk - 1) / chunk, want = (n_chunks + waves - 1) / waves;
-    const uint64_t cap = (uint64_t)ctx->n_cu * blocks_per_cu;
-    const unsigned grid = (unsigned)(want < cap ? want : cap), threads = (unsigned)waves * 64;
-    const uint32_t n_waves = grid * (unsigned)waves;
+    if (n > max_waves) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "too many samples for one scan launch");
+    // deal the waves to the samples in proportion to their tile counts (at least one each)
+    std::vector<uint64_t> tiles(n);
+    uint64_t total_tiles = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t lo = (uintptr_t)h_samples[i].buf & 15;
+        tiles[i] = (lo + h_samples[i].nbytes + SCAN_TILE - 1) / SCAN_TILE;
+        total_tiles += tiles[i];
+    }
+    uint64_t budget = total_tiles < max_waves ? total_tiles : max_waves, used = 0;
+    if (budget < n) budget = n;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t w = total_tiles ? budget * tiles[i] / total_tiles : 0;
+        h_samples[i].n_waves = (uint32_t)(w ? w : 1);
+        used += h_samples[i].n_waves;
+    }
+    while (used < budget) {                                 // leftovers go where a wave's share is largest
+        uint32_t best = 0;
+        double worst = -1;
+        for (uint32_t i = 0; i < n; ++i) { double r = (double)tiles[i] / h_samples[i].n_waves; if (r > worst) { worst = r; best = i; } }
+        if (worst <= 1.0) break;
+        ++h_samples[best].n_waves;
+        ++used;
+    }
+    while (used > max_waves) {                              // only when many samples were rounded up to one wave
+        uint32_t best = 0;
+        for (uint32_t i = 0; i < n; ++i) if (h_samples[i].n_waves > h_samples[best].n_waves) best = i;
+        --h_samples[best].n_waves;
+        --used;
+    }
+    uint32_t w0 = 0;
+    for (uint32_t i = 0; i < n; ++i) { h_samples[i].wave0 = w0; w0 += h_samples[i].n_waves; }
+    SampleDev sentinel{};
+    sentinel.wave0 = w0;
+    h_samples.push_back(sentinel);
+    SampleDev *d_samples = (SampleDev *)workspace;
+    HIP_TRY(ctx, hipMemcpyAsync(d_samples, h_samples.data(), (size_t)(n + 1) * sizeof(SampleDev), hipMemcpyHostToDevice, st));
+    h_samples.pop_back();
+
+    ScanArgs sa;
+    sa.samples = d_samples;
+    sa.n_samples = n;
+    sa.n_sites = ss->n_sites;
+    sa.site_line = d_site_line;
+    sa.want_depth = want_depth;
+    sa.queue = ss->slow_queue;
+    sa.q_cap = SNPGPU_SLOW_QUEUE_CAP - 65536;               // the tail holds the tuning modes' per-wave records
+    sa.ctl = ss->slow_ctl;
+    sa.totals = (uint64_t *)((char *)workspace + ((size_t)(n + 1) * sizeof(SampleDev) + 255) / 256 * 256);
+    sa.dbg = nullptr;
+    const unsigned grid = (unsigned)((w0 + waves - 1) / waves), threads = (unsigned)waves * 64;
+    k_scan_init<<<n, 256, 0, st>>>(d_samples, ss->slow_ctl, sa.totals, 0, 0);
     hipEvent_t ta = snpgpu_time_begin(ctx);
     if (want_depth) {
         k_scan_wave<true, 0><<<grid, threads, lds, st>>>(sa, ss->dev);
@@ -679,11 +720,11 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t
         if (mode == 8) k_scan_wave<false, 2><<<grid, threads, lds, st>>>(sa, ss->dev);
         else k_scan_wave<false, 1><<<grid, threads, lds, st>>>(sa, ss->dev);
         if (const char *path = getenv("SNPGPU_SCAN_DUMP")) {
-            const size_t nrec = (size_t)n_waves * 8;
+            const size_t nrec = (size_t)w0 * 8;
             unsigned long long *recs = (unsigned long long *)malloc(nrec * 8);
             (void)hipStreamSynchronize(st);
             (void)hipMemcpy(recs, sa.dbg, nrec * 8, hipMemcpyDeviceToHost);
-            if (FILE *f = fopen(path, "wb")) { fwrite(recs, 8, nrec, f); fclose(f); }
+            if (FILE *fp = fopen(path, "wb")) { fwrite(recs, 8, nrec, fp); fclose(fp); }
             free(recs);
         }
         sa.dbg = nullptr;
@@ -693,10 +734,10 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t
     snpgpu_time_end(ctx, SNPGPU_K_SCAN, ta);
     if (!want_depth) {
         k_scan_queue<<<ctx->n_cu, 256, 0, st>>>(sa, ss->dev);
-        k_scan_init<<<1, 256, 0, st>>>(d_status, ss->slow_ctl, sa.totals, n_waves, 1, 0);
-        if (sa.ticket) sa.ticket = ss->slow_ctl + 32;
+        k_scan_init<<<n, 256, 0, st>>>(d_samples, ss->slow_ctl, sa.totals, 1, 0);
         k_scan_wave<true, 0><<<grid, threads, lds, st>>>(sa, ss->dev);   // returns at once unless the queue overflowed
     }
-    k_scan_init<<<1, 256, 0, st>>>(d_status, ss->slow_ctl, sa.totals, n_waves, 2, want_depth);
+    k_scan_init<<<n, 256, 0, st>>>(d_samples, ss->slow_ctl, sa.totals, 2, want_depth);
+    HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;
 }

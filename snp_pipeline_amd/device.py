@@ -209,11 +209,20 @@ class Device(object):
             C.c_void_p(d_filters), C.c_void_p(d_counts) if d_counts else None, C.c_void_p(d_status),
             1 if want_depth_sum else 0))
 
-    def call_consensus_batch_dev(self, siteset, d_pileups_ptr, offsets, params, d_bases, d_filters, d_status):
+    def call_consensus_batch_dev(self, siteset, d_pileups_ptr, offsets, params, d_bases, d_filters, d_status, sizes=None):
+        """One scan launch + one call launch for the whole batch.  Sample i is bytes [offsets[i], offsets[i] + sizes[i])
+        of the device buffer; without `sizes` the samples are packed and offsets has one entry more than samples."""
         offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if sizes is None:
+            n, sz = len(offs) - 1, None
+        else:
+            sz = np.ascontiguousarray(sizes, dtype=np.uint64)
+            n = len(sz)
+            if len(offs) < n:
+                raise ValueError("offsets shorter than sizes")
         self._check(self.lib.snpgpu_call_consensus_batch_dev(
-            self.ctx, siteset.handle, C.c_void_p(d_pileups_ptr), _ptr(offs), len(offs) - 1, C.byref(params),
-            C.c_void_p(d_bases), C.c_void_p(d_filters), C.c_void_p(d_status)))
+            self.ctx, siteset.handle, C.c_void_p(d_pileups_ptr), _ptr(offs), _ptr(sz) if sz is not None else None, n,
+            C.byref(params), C.c_void_p(d_bases), C.c_void_p(d_filters), C.c_void_p(d_status)))
 
     # ---- distance ------------------------------------------------------------------------------
     def packed_row_bytes(self, n_sites):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Development helper: time k_scan_pileup / k_call_sites on a few device-generated samples.
-Usage: python tools/scan_tune.py [n_samples] [genome_len]   (knobs via SNPGPU_SCAN_* env vars)"""
+"""Development helper: time k_scan_wave / k_call_sites on a few device-generated samples.
+Usage: python tools/scan_tune.py [n_samples] [genome_len] [batch]   (knobs via SNPGPU_SCAN_* env vars)
+"batch": all samples through one call of the batch entry point (one scan launch, one call launch)."""
 import os
 import sys
 
@@ -37,7 +38,15 @@ def main():
     filt = torch.empty((B, S), dtype=torch.uint8, device="cuda")
     status = torch.empty((B, 4), dtype=torch.int64, device="cuda")
 
+    batch = len(sys.argv) > 3 and sys.argv[3] == "batch"
+    ptrs = [t.data_ptr() for t in bufs]
+    base = min(ptrs)
+    offs = np.array([p - base for p in ptrs], dtype=np.uint64)
+
     def run():
+        if batch:
+            d.call_consensus_batch_dev(ss, base, offs, prm, bases.data_ptr(), filt.data_ptr(), status.data_ptr(), sizes=sizes)
+            return
         for i in range(B):
             d.call_consensus_dev(ss, bufs[i].data_ptr(), sizes[i], prm, bases[i].data_ptr(), filt[i].data_ptr(), status[i].data_ptr())
     run()
@@ -51,6 +60,8 @@ def main():
     cm, cn = d.kernel_time_ms(1)
     st = status.cpu().numpy()
     gbs = sum(sizes) * 3 / (sm * 1e-3) / 1e9
+    if batch:
+        sn, cn = sn * B, cn * B
     print("variant waves=%s blocks=%s : scan %.3f ms/sample  %.0f GB/s (%.1f%% of 8 TB/s) | call %.3f ms/sample | lines %d matched %d err %s | checksum %d"
           % (os.environ.get("SNPGPU_SCAN_WAVES", "-"), os.environ.get("SNPGPU_SCAN_BLOCKS_PER_CU", "-"), sm / sn, gbs, gbs / 80,
              cm / cn, st[0, 1], st[0, 2], st[0, 0] != -1, int(bases.to(torch.int64).sum().item())))
