@@ -13,6 +13,8 @@
 // "the last duplicate line wins" (call_consensus.py:171-176).  k_call_sites then runs one 64-lane wavefront per
 // site over that line.  The three regex passes of the reference become 64-bit mask algebra on wave ballots
 // (scalar ALU work on gfx950: one ballot == one SGPR pair).
+#include <stdlib.h>
+
 #include "internal.h"
 
 #define SCAN_ERR_FEW_FIELDS 1
@@ -37,6 +39,9 @@ struct CallArgs {
     uint8_t *out_base;
     uint8_t *out_filters;
     snpgpu_site_counts *out_counts;   // nullable
+    uint64_t *todo;             // k_call_lanes: sites left to k_call_sites; k_call_sites: nullable, work only on these
+    uint32_t *todo_n;
+    int exp;                    // tuning only: stop k_call_lanes after phase N
 };
 
 struct WaveLds {
@@ -102,14 +107,47 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
     WaveLds &L = lds[wave];
     const uint64_t lt = low_mask(lane);                     // lanes below me
 
-    const uint64_t n_work = (uint64_t)a.n_samples * a.n_sites;
-    for (uint64_t site = (uint64_t)blockIdx.x * CALL_WAVES + wave; site < n_work; site += (uint64_t)gridDim.x * CALL_WAVES) {
-        const uint32_t sample = (uint32_t)(site / a.n_sites);
-        const SampleDev sd = a.samples[sample];
-        const uint8_t *buf = sd.buf;
-        const uint64_t nbytes = sd.nbytes;
-        const uint64_t lv = a.site_line[site];
-        const uint32_t sflags = a.site_flags[site - (uint64_t)sample * a.n_sites];
+    // Software pipeline over the wave's sites: the kernel is a chain of dependent memory round trips per site
+    // (line offset -> line bytes), so the offset of the site after next and the first 192 bytes of the next site's line
+    // (one round trip covers a typical 30x line) are requested before the current site is worked on.
+    const uint64_t n_work = a.todo ? (uint64_t)*a.todo_n : (uint64_t)a.n_samples * a.n_sites;
+    const uint64_t stride = (uint64_t)gridDim.x * CALL_WAVES;
+    struct SiteRef { uint64_t site; uint64_t lv; uint32_t sflags; const uint8_t *buf; uint64_t nbytes; };
+    auto fetch_ref = [&](uint64_t idx) -> SiteRef {
+        SiteRef r{0, 0, 0, nullptr, 0};
+        if (idx < n_work) {
+            const uint64_t s = a.todo ? a.todo[idx] : idx;
+            const uint32_t sample = (uint32_t)(s / a.n_sites);
+            r.site = s;
+            r.lv = a.site_line[s];
+            r.sflags = a.site_flags[s - (uint64_t)sample * a.n_sites];
+            r.buf = a.samples[sample].buf;
+            r.nbytes = a.samples[sample].nbytes;
+        }
+        return r;
+    };
+    auto fetch_head = [&](const SiteRef &r, uint32_t &h0, uint32_t &h1, uint32_t &h2) {
+        h0 = h1 = h2 = 10u;
+        if (r.lv != 0) {
+            const uint64_t ls = r.lv - 1;
+            if (ls + lane < r.nbytes) h0 = r.buf[ls + lane];
+            if (ls + 64 + lane < r.nbytes) h1 = r.buf[ls + 64 + lane];
+            if (ls + 128 + lane < r.nbytes) h2 = r.buf[ls + 128 + lane];
+        }
+    };
+    uint64_t idx = (uint64_t)blockIdx.x * CALL_WAVES + wave;
+    SiteRef cur = fetch_ref(idx), nxt = fetch_ref(idx + stride);
+    uint32_t pre0, pre1, pre2;
+    fetch_head(cur, pre0, pre1, pre2);
+    for (; idx < n_work; idx += stride) {
+        const SiteRef after = fetch_ref(idx + 2 * stride);
+        const uint64_t site = cur.site;
+        uint32_t nh0, nh1, nh2;
+        fetch_head(nxt, nh0, nh1, nh2);
+        const uint8_t *buf = cur.buf;
+        const uint64_t nbytes = cur.nbytes;
+        const uint64_t lv = cur.lv;
+        const uint32_t sflags = cur.sflags;
         uint32_t status = SNPGPU_ST_NO_LINE, filters = 0, cons = '-', out_b = '-';
         uint32_t raw_depth = 0, good = 0, nfwd = 0, nrev = 0, nsym = 0, ref = 0;
         bool have_hist = false;
@@ -120,10 +158,6 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
             if (lane < 6) { L.fs[lane] = 0xFFFFFFFFu; L.fe[lane] = 0xFFFFFFFFu; }
             uint32_t nfields = 0, line_len = 0;
             bool prev_ws = true;
-            // the first 192 bytes are requested at once (one memory round trip covers a typical 30x line)
-            const uint32_t pre0 = ls + lane < nbytes ? buf[ls + lane] : 10u;
-            const uint32_t pre1 = ls + 64 + lane < nbytes ? buf[ls + 64 + lane] : 10u;
-            const uint32_t pre2 = ls + 128 + lane < nbytes ? buf[ls + 128 + lane] : 10u;
             for (uint64_t k = 0;; k += 64) {
                 uint64_t p = ls + k + lane;
                 uint32_t c = k == 0 ? pre0 : (k == 64 ? pre1 : (k == 128 ? pre2 : (p < nbytes ? buf[p] : 10u)));
@@ -142,8 +176,7 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
                 if (T) { line_len = (uint32_t)(k + __ffsll((long long)T) - 1); break; }
                 if (k + 64 > 0xFFFFFF00ull) break;
             }
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_wave_barrier();               // LDS is in order within a wave: no counter wait needed
             status = SNPGPU_ST_OK;
             const uint8_t *gl = buf + ls;                 // line bytes in global memory
             auto lb = [&](uint32_t off) -> uint32_t { return off < CALL_LBUF ? L.line[off] : (uint32_t)gl[off]; };
@@ -198,7 +231,6 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
                         if ((keep >> lane) & 1) L.s1[n1 + __popcll(keep & lt)] = (uint8_t)c;
                         n1 += __popcll(keep);
                     }
-                    __builtin_amdgcn_s_waitcnt(0);
                     __builtin_amdgcn_wave_barrier();
                     // ---- pass B: indel markers with additive debt (pileup.py:315-320), '$' (pileup.py:323),
                     //      quality pairing (pileup.py:248-250), substitution + histogram (pileup.py:255-274) ----
@@ -266,7 +298,6 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
                     if (lane == 0) call_serial(gl, bs, be, qs, qe, minq, ref_up, ref_lo, L.hist, good);
                     good = __builtin_amdgcn_readfirstlane(good);
                 }
-                __builtin_amdgcn_s_waitcnt(0);
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -337,6 +368,248 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
                 a.out_filters[site] = (uint8_t)(0x80u | status);                          // error marker when no counts buffer
             }
         }
+        cur = nxt;
+        nxt = after;
+        pre0 = nh0; pre1 = nh1; pre2 = nh2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+//                         K2 fast path: one LANE per site, 64 sites per wave
+// ------------------------------------------------------------------------------------------------
+// k_call_sites spends ~1000 wave instructions on one ~90-byte line.  Here every lane owns a site: the 256 aligned
+// bytes around its line go to a private LDS slot (16-byte loads, slot stride 65 dwords: conflict free), then the lanes
+// walk their lines in lockstep over aligned dwords — a serial tokeniser (str.split() field boundaries packed into two
+// 64-bit registers) and the same left-to-right automaton as call_serial, with the per-symbol counts in byte lanes of
+// two 64-bit registers ('*' A C G N T x forward/reverse; a line of <= 256 bytes cannot overflow them).  That is ~50
+// wave instructions per site.  Whatever does not fit — a line longer than the window, a malformed line, any other
+// symbol, a sign that is not an indel marker — is appended to a list for k_call_sites, which remains the reference
+// implementation of the caller on the device (and the only one when per-site counts are requested).
+#define LANES_WAVES 2
+#define LANES_WIN 256           // bytes staged per site, from the 16-byte aligned address at or below the line start
+#define LANES_STRIDE 65         // dwords between slots
+
+struct LanesLds {
+    uint32_t slot[LANES_WAVES][64 * LANES_STRIDE];
+    uint8_t cls[256];           // byte after '.'/',' substitution -> rank of its symbol among "*ACGNT" | reverse << 3; 0xFF: other
+};
+
+__global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
+    __shared__ LanesLds S;
+    for (uint32_t c = threadIdx.x; c < 256; c += blockDim.x) {
+        const uint32_t u = to_upper(c);
+        uint32_t k = u == '*' ? 0u : u == 'A' ? 1u : u == 'C' ? 2u : u == 'G' ? 3u : u == 'N' ? 4u : u == 'T' ? 5u : 0xFFu;
+        if (k != 0xFFu && c >= 0x61u) k |= 8u;               // pileup.py:269-270: >= 'a' is the reverse strand
+        S.cls[c] = (uint8_t)k;
+    }
+    __syncthreads();
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *slot = &S.slot[wave][lane * LANES_STRIDE];
+    const uint8_t *slot_b = (const uint8_t *)slot;
+    const uint64_t n_work = (uint64_t)a.n_samples * a.n_sites;
+    const uint64_t n_groups = (n_work + 63) / 64;
+    const int minq = a.prm.min_base_quality;
+
+    for (uint64_t grp = (uint64_t)blockIdx.x * LANES_WAVES + wave; grp < n_groups; grp += (uint64_t)gridDim.x * LANES_WAVES) {
+        const uint64_t site = grp * 64 + lane;
+        const bool valid = site < n_work;
+        uint64_t lv = 0;
+        uint32_t sflags = 0;
+        uintptr_t addr = 0, end = 0;
+        if (valid) {
+            const uint32_t sample = (uint32_t)(site / a.n_sites);
+            lv = a.site_line[site];
+            sflags = a.site_flags[site - (uint64_t)sample * a.n_sites];
+            const uintptr_t b = (uintptr_t)a.samples[sample].buf;
+            end = b + a.samples[sample].nbytes;
+            addr = b + (lv - 1);
+        }
+        const bool has = lv != 0;
+        // ---- stage [al, al + 256) of every lane's line; bytes at or past the end of the file read as '\n' -------------
+        const uintptr_t al = addr & ~(uintptr_t)15;
+        const uint32_t o = (uint32_t)(addr & 15);              // the line starts at byte o of the slot
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint4 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uintptr_t x = al + 16u * (8 * half + r);
+                v[r] = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+                if (has && x < end) v[r] = *(const uint4 *)x;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uintptr_t x = al + 16u * (8 * half + r);
+                if (__ballot(has && x < end && x + 16 > end)) {            // the file ends inside this chunk (rare)
+                    uint32_t w[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+#pragma unroll
+                        for (int bb = 0; bb < 4; ++bb)
+                            if (x + 4 * d + bb >= end) w[d] = (w[d] & ~(0xFFu << (8 * bb))) | (0x0Au << (8 * bb));
+                    v[r] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                uint32_t *dst = slot + 4 * (8 * half + r);
+                dst[0] = v[r].x; dst[1] = v[r].y; dst[2] = v[r].z; dst[3] = v[r].w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                       // a lane only ever reads its own slot
+
+        if (a.exp == 1) continue;
+        // ---- tokenise: str.split() boundaries of the first fields (pileup.py:206), one byte per step ------------------
+        uint64_t starts = 0, ends = 0;                         // byte k: start / end (exclusive) of field k, k < 8
+        uint32_t nf = 0, line_end = 0;
+        bool prev_ws = true, done = !has;
+        {
+            uint32_t w = slot[0];
+            for (uint32_t t = 0; t < LANES_WIN / 4; ++t) {
+                const uint32_t wn = t + 1 < LANES_WIN / 4 ? slot[t + 1] : 0x0A0A0A0Au;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t p = 4 * t + k, c = (w >> (8 * k)) & 0xFFu;
+                    const bool act = !done && p >= o;
+                    const bool ws = is_ws(c);
+                    const bool st = act && !ws && prev_ws, en = act && ws && !prev_ws;
+                    starts |= (uint64_t)(st ? p : 0u) << (8 * (nf < 7 ? nf : 7));
+                    nf += st ? 1u : 0u;
+                    ends |= (uint64_t)(en ? p : 0u) << (8 * (nf - 1 < 7 ? nf - 1 : 7));
+                    if (act) prev_ws = ws;
+                    if (act && is_term(c)) { done = true; line_end = p; }
+                }
+                w = wn;
+                if (!__ballot(!done)) break;
+            }
+        }
+        if (a.exp == 2) { if (nf == 77) a.out_base[site] = (uint8_t)line_end; continue; }
+        bool punt = has && !done;                              // no terminator inside the window: long line
+        auto fs = [&](int k) -> uint32_t { return (uint32_t)(starts >> (8 * k)) & 0xFFu; };
+        auto fe = [&](int k) -> uint32_t { return (uint32_t)(ends >> (8 * k)) & 0xFFu; };
+        // reference base and depth (pileup.py:224-225); anything odd goes to k_call_sites, which knows the error codes
+        uint32_t ref = 0, raw_depth = 0;
+        if (has && !punt) {
+            if (nf < 4 || nf == 5 || fe(2) - fs(2) != 1 || fe(3) - fs(3) > 9 || fe(3) <= fs(3)) punt = true;
+            else {
+                ref = slot_b[fs(2)];
+                for (uint32_t q = fs(3); q < fe(3); ++q) {
+                    const uint32_t c = slot_b[q];
+                    if (!is_digit(c)) punt = true;
+                    raw_depth = raw_depth * 10u + (c - 48u);
+                }
+            }
+        }
+        // ---- bases + qualities (pileup.py:237-274) -------------------------------------------------------------------
+        uint64_t cnt_f = 0, cnt_r = 0;                         // byte lanes: '*' A C G N T
+        uint32_t good = 0;
+        const bool parse = has && !punt && raw_depth != 0 && nf >= 6;
+        {
+            const uint32_t bs = parse ? fs(4) : 0u, be = parse ? fe(4) : 0u, qs = fs(5), qlen = parse ? fe(5) - fs(5) : 0u;
+            const uint32_t ref_up = to_upper(ref), ref_lo = to_lower(ref);
+            uint32_t t_lo = bs >> 2, t_hi = (be + 3) >> 2;
+            for (int off = 32; off; off >>= 1) { t_lo = min(t_lo, (uint32_t)__shfl_xor((int)t_lo, off)); t_hi = max(t_hi, (uint32_t)__shfl_xor((int)t_hi, off)); }
+            if (!__ballot(parse)) t_hi = t_lo;
+            // The automaton of call_serial, written as straight-line selects (a divergent branch costs more scalar work
+            // than the few VALU ops it would skip).  Quality bytes are consumed in order, so they come from a dword
+            // window that is refilled ahead of use; the symbol classes of a dword's four bytes are requested while the
+            // previous dword is being worked on.
+            bool caret_skip = false, in_run = false, pending = false;
+            uint32_t acc = 0, debt = 0, kept = 0;
+            uint32_t w = t_lo < t_hi ? slot[t_lo] : 0u;
+            uint32_t qd = qs >> 2;                                 // dword index of the quality window
+            uint32_t qw = slot[qd & 63u], qw_next = slot[(qd + 1) & 63u];
+            auto subst = [&](uint32_t c) -> uint32_t { return c == '.' ? ref_up : (c == ',' ? ref_lo : c); };
+            uint32_t cl4[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) cl4[k] = S.cls[subst((w >> (8 * k)) & 0xFFu)];
+            for (uint32_t t = t_lo; t < t_hi; ++t) {
+                const uint32_t wn = t + 1 < LANES_WIN / 4 ? slot[t + 1] : 0u;
+                uint32_t cn4[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) cn4[k] = S.cls[subst((wn >> (8 * k)) & 0xFFu)];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t p = 4 * t + k, c = (w >> (8 * k)) & 0xFFu;
+                    const bool act = p >= bs && p < be;
+                    const bool isd = is_digit(c), sign = c == '+' || c == '-';
+                    const bool live = act && !caret_skip && !(c == '^' && p + 1 < be);
+                    caret_skip = act ? (!caret_skip && c == '^' && p + 1 < be) : caret_skip;
+                    // a pending sign: followed by a digit it opens a marker, otherwise it was an ordinary byte
+                    const bool open = live && pending && isd, plain_sign = live && pending && !isd;
+                    punt = punt || (plain_sign && debt == 0);      // ... that survives as a symbol: not ours
+                    debt -= (plain_sign && debt != 0) ? 1u : 0u;
+                    pending = live ? false : pending;
+                    // the digit run of a marker; its value joins the debt when the run ends
+                    const bool more = live && !open && in_run && isd, close = live && !open && in_run && !isd;
+                    acc = open ? c - 48u : (more ? sat_mul10_add(acc, c - 48u) : acc);
+                    debt = close ? sat_add(debt, acc) : debt;
+                    in_run = open ? true : (close ? false : in_run);
+                    const bool rest = live && !open && !more;
+                    pending = (rest && sign) ? true : pending;
+                    const bool ordinary = rest && !sign;
+                    const bool owed = ordinary && debt != 0;
+                    debt -= owed ? 1u : 0u;
+                    const bool emit = ordinary && !owed && c != '$';
+                    // the quality this base pairs with (zip truncation: none past the end of the quality field)
+                    const uint32_t qi = qs + kept;
+                    if (__ballot((qi >> 2) != qd)) {                 // some lane's window moves on (every few steps)
+                        const bool adv = (qi >> 2) != qd;
+                        qw = adv ? qw_next : qw;
+                        qd += adv ? 1u : 0u;
+                        qw_next = slot[(qd + 1) & 63u];
+                    }
+                    const uint32_t qv = (qw >> (8 * (qi & 3u))) & 0xFFu;
+                    const bool goodb = emit && kept < qlen && (int)qv - 33 >= minq;
+                    kept += emit ? 1u : 0u;
+                    good += goodb ? 1u : 0u;
+                    const uint32_t cl = cl4[k];
+                    punt = punt || (goodb && cl == 0xFFu);
+                    const uint64_t one = (goodb && cl != 0xFFu) ? 1ull << (8 * (cl & 7u)) : 0ull;
+                    cnt_f += (cl & 8u) ? 0ull : one;
+                    cnt_r += (cl & 8u) ? one : 0ull;
+                }
+                w = wn;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) cl4[k] = cn4[k];
+            }
+            if (parse && pending && !debt) punt = true;        // a trailing sign survives as a symbol
+        }
+        if (a.exp == 3) { if (good == 7777) a.out_base[site] = (uint8_t)(cnt_f + cnt_r); continue; }
+        // ---- the caller (pileup.py:550-588) --------------------------------------------------------------------------
+        uint32_t filters = 0, cons = '-';
+        if (has && !punt) {
+            if (good == 0) filters = SNPGPU_F_RAWDPTH;
+            else {
+                const uint64_t tot = cnt_f + cnt_r;            // per byte lane <= 253: no carry between lanes
+                uint32_t n = 0, bk = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 6; ++k) {             // count descending, byte ascending (pileup.py:265)
+                    const uint32_t tk = (uint32_t)(tot >> (8 * k)) & 0xFFu;
+                    if (tk > n) { n = tk; bk = k; }
+                }
+                cons = bk == 0 ? '*' : bk == 1 ? 'A' : bk == 2 ? 'C' : bk == 3 ? 'G' : bk == 4 ? 'N' : 'T';
+                const uint32_t nfw = (uint32_t)(cnt_f >> (8 * bk)) & 0xFFu, nrv = (uint32_t)(cnt_r >> (8 * bk)) & 0xFFu;
+                if ((double)n < (double)good * a.prm.min_cons_freq) filters |= SNPGPU_F_VARFREQ;
+                if ((int64_t)n < (int64_t)a.prm.min_cons_depth) filters |= SNPGPU_F_DEPTH;
+                if ((int64_t)nfw < (int64_t)a.prm.min_cons_strand_depth || (int64_t)nrv < (int64_t)a.prm.min_cons_strand_depth) filters |= SNPGPU_F_STRDPTH;
+                const double bias = (double)n * a.prm.min_cons_strand_bias;
+                if ((double)nfw < bias || (double)nrv < bias) filters |= SNPGPU_F_STRBIAS;
+                if (cons == to_upper(ref)) cons = ref;
+            }
+            if (sflags & SNPGPU_SITE_EXCLUDED) filters |= SNPGPU_F_REGION;
+        }
+        if (valid && !punt) {
+            a.out_base[site] = (uint8_t)((filters || cons == '*') ? '-' : cons);           // call_consensus.py:169-176
+            a.out_filters[site] = (uint8_t)filters;
+        }
+        // ---- leftovers: one atomic per wave ---------------------------------------------------------------------------
+        const uint64_t pm = __ballot(punt);
+        if (pm) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(a.todo_n, (uint32_t)__popcll(pm));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (punt) a.todo[base + __popcll(pm & low_mask(lane))] = site;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -354,12 +627,15 @@ static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const Sample
     const uint32_t n_sites = ss->n_sites;
     const size_t ws_bytes = (snpgpu_scan_workspace_bytes(ctx, n) + 255) / 256 * 256;
     const size_t rows_bytes = d_site_line ? 0 : 8ull * n_sites * n;
+    const size_t todo_bytes = d_out_counts ? 0 : 8ull * n_sites * n + 256;     // leftovers of k_call_lanes + their count
     void *ws = nullptr;
     {
-        int rc = snpgpu_scratch(ctx, ws_bytes + rows_bytes + 256, &ws);
+        int rc = snpgpu_scratch(ctx, ws_bytes + rows_bytes + todo_bytes + 256, &ws);
         if (rc) return rc;
     }
     if (!d_site_line) d_site_line = (uint64_t *)((char *)ws + ws_bytes);
+    uint32_t *d_todo_n = (uint32_t *)((char *)ws + ws_bytes + rows_bytes);
+    uint64_t *d_todo = (uint64_t *)((char *)ws + ws_bytes + rows_bytes + 256);
     if (n_sites) HIP_TRY(ctx, hipMemsetAsync(d_site_line, 0, 8ull * n_sites * n, st));
     std::vector<SampleDev> samples(n);
     for (uint32_t i = 0; i < n; ++i) {
@@ -383,10 +659,33 @@ static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const Sample
         ca.out_base = d_out_base;
         ca.out_filters = d_out_filters;
         ca.out_counts = d_out_counts;
-        const uint64_t blocks = ((uint64_t)n_sites * n + CALL_WAVES - 1) / CALL_WAVES;
+        const uint64_t n_work = (uint64_t)n_sites * n;
+        const uint64_t blocks = (n_work + CALL_WAVES - 1) / CALL_WAVES;
         const uint64_t max_blocks = (uint64_t)ctx->n_cu * 16;
+        const unsigned grid = (unsigned)(blocks < max_blocks ? blocks : max_blocks);
+        ca.todo = nullptr;
+        ca.todo_n = nullptr;
+        static int exp_mode = -1;
+        if (exp_mode < 0) { const char *e = getenv("SNPGPU_CALL_EXP"); exp_mode = e ? atoi(e) : 0; }
+        ca.exp = exp_mode;
         hipEvent_t ta = snpgpu_time_begin(ctx);
-        k_call_sites<<<(unsigned)(blocks < max_blocks ? blocks : max_blocks), CALL_WAVES * 64, 0, st>>>(ca);
+        if (d_out_counts) {
+            k_call_sites<<<grid, CALL_WAVES * 64, 0, st>>>(ca);      // per-site counts: the wave-per-site kernel does it all
+        } else {
+            // one lane per site for every ordinary line, then one wave per site for whatever that kernel left over
+            ca.todo = d_todo;
+            ca.todo_n = d_todo_n;
+            HIP_TRY(ctx, hipMemsetAsync(d_todo_n, 0, 4, st));
+            const uint64_t lblocks = ((n_work + 63) / 64 + LANES_WAVES - 1) / LANES_WAVES, lmax = (uint64_t)ctx->n_cu * 8;
+            k_call_lanes<<<(unsigned)(lblocks < lmax ? lblocks : lmax), LANES_WAVES * 64, 0, st>>>(ca);
+            k_call_sites<<<grid, CALL_WAVES * 64, 0, st>>>(ca);
+            if (exp_mode == 9) {                                     // tuning: how many sites were left over
+                uint32_t left = 0;
+                (void)hipMemcpyAsync(&left, d_todo_n, 4, hipMemcpyDeviceToHost, st);
+                (void)hipStreamSynchronize(st);
+                fprintf(stderr, "k_call_lanes left %u of %llu sites to k_call_sites\n", left, (unsigned long long)n_work);
+            }
+        }
         snpgpu_time_end(ctx, SNPGPU_K_CALL, ta);
     }
     HIP_TRY(ctx, hipGetLastError());

@@ -46,4 +46,8 @@ def check_against_oracle(d, data, snp_list, excluded, p):
             assert c["total"][r] == rec.base_good_depth[sym]
             assert c["fwd"][r] == rec.forward_base_good_depth.get(sym, 0)
             assert c["rev"][r] == rec.reverse_base_good_depth.get(sym, 0)
+    # the throughput path (no per-site counts: one lane per site, leftovers by the wave-per-site kernel) must agree
+    got2, res2, _ = gpu_consensus(d, data, snp_list, excluded, p, want_counts=False)
+    assert got2 == want
+    assert bytes(res2.bases) == bytes(res.bases) and bytes(res2.filters) == bytes(res.filters)
     return res

@@ -54,6 +54,9 @@ def test_golden_record_vectors(d, pileup_vectors):
                 assert chr(c["sym"][r]) == sym
                 assert (c["total"][r], c["fwd"][r], c["rev"][r]) == (tot[sym], fw.get(sym, 0), rv.get(sym, 0)), (key, sym)
             checked += 1
+        # the lane-per-site kernel on the same lines (no per-site counts requested)
+        cons2, res2, _ = gpu_consensus(d, data, keys, [], p, want_counts=False)
+        assert bytes(res2.bases) == bytes(res.bases) and bytes(res2.filters) == bytes(res.filters)
     assert checked > 15000
 
 
