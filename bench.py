@@ -159,6 +159,20 @@ def main():
     algo_bytes = pile_bytes * args.steps / max(scan_n, 1)       # per launch: the rank's whole batch of pileup text
     achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
 
+    # HBM traffic of one scan launch from the committed PMC passes (rocprofv3 cannot run inside this process); only
+    # quoted when it was measured on this very workload
+    traffic = None
+    traffic_note = None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1", "pmc_traffic.json")) as f:
+            pt = json.load(f)
+        w = pt["workload"]
+        if (w["samples_per_gpu"], w["genome_bp"], w["mean_depth"], w["snp_sites"]) == (B, G, args.depth, S):
+            traffic = pt["traffic_bytes_per_launch"]
+            traffic_note = "profiles/r1/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    except (OSError, KeyError, ValueError):
+        pass
+
     out = {
         "metric": "consensus_bases_called_per_sec", "value": value, "unit": "bases/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -172,7 +186,7 @@ def main():
         "genome_bp_per_sec": world * B * G / (elapsed / args.steps),
         "pileup_gb_per_sec": world * pile_bytes / (elapsed / args.steps) / 1e9,
         "roofline": {"kernel": "k_scan_wave", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},
         "kernels_ms_per_step": {"k_scan_wave": scan_ms / args.steps, "k_call_sites": call_ms / args.steps,
                                 "k_distance": dist_ms / args.steps},

@@ -457,34 +457,63 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
         __builtin_amdgcn_wave_barrier();                       // a lane only ever reads its own slot
 
         if (a.exp == 1) continue;
-        // ---- tokenise: str.split() boundaries of the first fields (pileup.py:206), one byte per step ------------------
-        uint64_t starts = 0, ends = 0;                         // byte k: start / end (exclusive) of field k, k < 8
-        uint32_t nf = 0, line_end = 0;
-        bool prev_ws = true, done = !has;
-        {
-            uint32_t w = slot[0];
-            for (uint32_t t = 0; t < LANES_WIN / 4; ++t) {
-                const uint32_t wn = t + 1 < LANES_WIN / 4 ? slot[t + 1] : 0x0A0A0A0Au;
+        // ---- tokenise (pileup.py:206): per-lane 256-bit masks of the str.split() separators and of the terminator
+        //      candidates, built 4 bytes per step with SWAR compares; the field boundaries are bit scans on the masks ----
+        uint64_t Wm[4] = {0, 0, 0, 0}, Tm[4] = {0, 0, 0, 0};
+        bool done = !has;
 #pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    const uint32_t p = 4 * t + k, c = (w >> (8 * k)) & 0xFFu;
-                    const bool act = !done && p >= o;
-                    const bool ws = is_ws(c);
-                    const bool st = act && !ws && prev_ws, en = act && ws && !prev_ws;
-                    starts |= (uint64_t)(st ? p : 0u) << (8 * (nf < 7 ? nf : 7));
-                    nf += st ? 1u : 0u;
-                    ends |= (uint64_t)(en ? p : 0u) << (8 * (nf - 1 < 7 ? nf - 1 : 7));
-                    if (act) prev_ws = ws;
-                    if (act && is_term(c)) { done = true; line_end = p; }
+        for (int blk = 0; blk < LANES_WIN / 64; ++blk) {
+            if (!__ballot(!done)) break;
+            uint32_t mw[2] = {0, 0}, mt[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                uint32_t w = slot[16 * blk + j];
+                if (blk == 0 && j < 4) {                         // bytes before the line start read as spaces
+                    const uint32_t nb = o > 4u * j ? min(o - 4u * j, 4u) : 0u;
+                    const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+                    w = (w & ~m) | (0x20202020u & m);
                 }
-                w = wn;
-                if (!__ballot(!done)) break;
+                const uint32_t ge14 = w + 0x72727272u;           // bit 7 of a byte: byte >= 14 (input is ASCII)
+                const uint32_t f_ws = (((w + 0x77777777u) & ~ge14) | ((w + 0x64646464u) & ~(w + 0x5F5F5F5Fu))) & 0x80808080u;   // 9..13, 28..32
+                const uint32_t f_t = (w + 0x76767676u) & ~ge14 & 0x80808080u;                                                 // 10..13
+                mw[j >> 3] |= __builtin_amdgcn_udot4(f_ws >> 7, 0x08040201u, 0u, false) << (4 * (j & 7));
+                mt[j >> 3] |= __builtin_amdgcn_udot4(f_t >> 7, 0x08040201u, 0u, false) << (4 * (j & 7));
+            }
+            Wm[blk] = (uint64_t)mw[0] | ((uint64_t)mw[1] << 32);
+            Tm[blk] = (uint64_t)mt[0] | ((uint64_t)mt[1] << 32);
+            done = done || Tm[blk] != 0;
+        }
+        // first set bit at or after `pos` (256: none); inv: scan the complement
+        auto scan_from = [&](const uint64_t (&M)[4], bool inv, uint32_t pos) -> uint32_t {
+            uint32_t r = 256;
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                uint64_t m = inv ? ~M[j] : M[j];
+                const uint32_t pj = pos >> 6;
+                m = pj > (uint32_t)j ? 0ull : (pj == (uint32_t)j ? m & (~0ull << (pos & 63u)) : m);
+                if (m) r = 64u * j + (uint32_t)__builtin_ctzll(m);
+            }
+            return r;
+        };
+        const uint32_t line_end = scan_from(Tm, false, 0);      // candidates are bytes 10..13; 11 and 12 are checked below
+        uint32_t nf = 0, f_s[6], f_e[6];
+        {
+            uint32_t pos = o;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const uint32_t st = scan_from(Wm, true, pos);
+                const uint32_t en = scan_from(Wm, false, st < 256 ? st : 255u);
+                const bool found = st < line_end;
+                nf += found ? 1u : 0u;
+                f_s[k] = st; f_e[k] = en;
+                pos = found ? (en < 256 ? en : 255u) : 255u;
             }
         }
         if (a.exp == 2) { if (nf == 77) a.out_base[site] = (uint8_t)line_end; continue; }
-        bool punt = has && !done;                              // no terminator inside the window: long line
-        auto fs = [&](int k) -> uint32_t { return (uint32_t)(starts >> (8 * k)) & 0xFFu; };
-        auto fe = [&](int k) -> uint32_t { return (uint32_t)(ends >> (8 * k)) & 0xFFu; };
+        bool punt = has && line_end >= 256;                    // no terminator inside the window: long line
+        if (has && !punt) { const uint32_t tc = slot_b[line_end]; punt = tc == 11u || tc == 12u; }
+        auto fs = [&](int k) -> uint32_t { return f_s[k]; };
+        auto fe = [&](int k) -> uint32_t { return f_e[k]; };
         // reference base and depth (pileup.py:224-225); anything odd goes to k_call_sites, which knows the error codes
         uint32_t ref = 0, raw_depth = 0;
         if (has && !punt) {

@@ -239,10 +239,11 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     const uint32_t *bitmap = ss.bitmap, *rank = ss.rank;
     uint32_t hits = 0, lines_seen = 0, any_hi = 0;
     unsigned long long depth_acc = 0;
-    unsigned long long t_a = 0, t_b = 0, t_c = 0, t_mark = kTime >= 2 ? __builtin_readcyclecounter() : 0;
-    const unsigned long long rt_start = kTime ? __builtin_amdgcn_s_memrealtime() : 0;    // 100 MHz wall clock
+    unsigned long long t_a = 0, t_b = 0, t_c = 0, t_mark = kTime == 2 ? __builtin_readcyclecounter() : 0;
+    constexpr bool kStamp = kTime == 1 || kTime == 2;
+    const unsigned long long rt_start = kStamp ? __builtin_amdgcn_s_memrealtime() : 0;    // 100 MHz wall clock
     unsigned long long rt_prologue = 0, rt_first = 0;
-#define WTICK(acc) do { if (kTime >= 2) { unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - t_mark; t_mark = now_; } } while (0)
+#define WTICK(acc) do { if (kTime == 2) { unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - t_mark; t_mark = now_; } } while (0)
     if (threadIdx.x < 16) {
         const uint32_t nd = threadIdx.x > 10 ? 10 : threadIdx.x, first = 15u - nd;
         uint32_t m[3];
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     if (t_nxt != kNoTile) dma_next = request(t_nxt, 1);
     int cur = 0;
     bool first_tile = true;
-    if (kTime) rt_prologue = __builtin_amdgcn_s_memrealtime();
+    if (kStamp) rt_prologue = __builtin_amdgcn_s_memrealtime();
     for (; tt != kNoTile; cur ^= 1) {
         // the current tile's DMA has landed when only the next tile's requests are still outstanding
         if (dma_next) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SCAN_DMA_PER_TILE) : "memory");
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
             const uint4 *tile16 = &ws.slot[cur][1];
             uint32_t mismatch_at = 0xFFFFFFFFu;                      // line start of a lane whose name did not match the hint
             do {                                                // one pass; `break` leaves the tile early
-                
+                if (kTime == 3) { any_hi |= tile16[lane].x; break; }   // tuning: stream only, no parsing
                 // ---- B: terminator flags of four 16-byte chunks per lane (chunk i*64+lane: conflict-free LDS reads) ----
                 // bit 16*i + b of S: byte b of chunk i*64+lane is in 0x0A..0x0D; a line starts at the next byte.
                 // Straight-line code: no branch depends on the data unless the tile holds '\v' '\f' or '\r'.
@@ -568,9 +569,9 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
         tt = t_nxt;
         t_nxt = t_new;
         WTICK(t_c);
-        if (kTime && first_tile) { rt_first = __builtin_amdgcn_s_memrealtime(); first_tile = false; }
+        if (kStamp && first_tile) { rt_first = __builtin_amdgcn_s_memrealtime(); first_tile = false; }
     }
-    if (kTime && lane == 0 && a.dbg) {                        // per-wave record for tools/scan_waves.py
+    if (kStamp && lane == 0 && a.dbg) {                        // per-wave record for tools/scan_waves.py
         unsigned long long *rec = a.dbg + 8 * gwave;
         rec[0] = rt_start; rec[1] = __builtin_amdgcn_s_memrealtime();
         rec[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);   // XCC_ID, HW_ID
@@ -651,7 +652,7 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<S
         mode = m ? atoi(m) : 0;
         if (w && atoi(w) >= 1 && atoi(w) <= 16) waves = atoi(w);
         for (auto f : {(const void *)k_scan_wave<false, 0>, (const void *)k_scan_wave<false, 1>, (const void *)k_scan_wave<false, 2>,
-                       (const void *)k_scan_wave<true, 0>})
+                       (const void *)k_scan_wave<false, 3>, (const void *)k_scan_wave<true, 0>})
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     // Exactly blocks_per_cu workgroups fit on a CU (the LDS request is padded to make sure) and a full grid is
@@ -715,6 +716,8 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<S
     hipEvent_t ta = snpgpu_time_begin(ctx);
     if (want_depth) {
         k_scan_wave<true, 0><<<grid, threads, lds, st>>>(sa, ss->dev);
+    } else if (mode == 7) {                                 // tuning: LDS-DMA streaming rate without any parsing
+        k_scan_wave<false, 3><<<grid, threads, lds, st>>>(sa, ss->dev);
     } else if (mode == 8 || mode == 9) {                    // tuning: per-wave time stamps (9) + phase cycle counts (8)
         sa.dbg = (unsigned long long *)(ss->slow_queue + SNPGPU_SLOW_QUEUE_CAP - 65536);
         if (mode == 8) k_scan_wave<false, 2><<<grid, threads, lds, st>>>(sa, ss->dev);
