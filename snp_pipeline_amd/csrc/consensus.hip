@@ -374,6 +374,25 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
     }
 }
 
+// 128-bit per-lane masks for k_call_lanes
+struct M128 { uint64_t lo, hi; };
+__device__ __forceinline__ M128 m_make(const uint32_t (&w)[4]) { return M128{(uint64_t)w[0] | ((uint64_t)w[1] << 32), (uint64_t)w[2] | ((uint64_t)w[3] << 32)}; }
+__device__ __forceinline__ M128 m_and(M128 a, M128 b) { return M128{a.lo & b.lo, a.hi & b.hi}; }
+__device__ __forceinline__ M128 m_or(M128 a, M128 b) { return M128{a.lo | b.lo, a.hi | b.hi}; }
+__device__ __forceinline__ M128 m_andn(M128 a, M128 b) { return M128{a.lo & ~b.lo, a.hi & ~b.hi}; }     // a & ~b
+__device__ __forceinline__ M128 m_not(M128 a) { return M128{~a.lo, ~a.hi}; }
+__device__ __forceinline__ bool m_any(M128 a) { return (a.lo | a.hi) != 0; }
+__device__ __forceinline__ M128 m_shl1(M128 a) { return M128{a.lo << 1, (a.hi << 1) | (a.lo >> 63)}; }
+__device__ __forceinline__ M128 m_add(M128 a, M128 b) { const uint64_t lo = a.lo + b.lo; return M128{lo, a.hi + b.hi + (lo < a.lo ? 1ull : 0ull)}; }
+__device__ __forceinline__ M128 m_below(uint32_t n) {                                                  // bits [0, n), n <= 128
+    return M128{n >= 64 ? ~0ull : ((1ull << n) - 1ull), n >= 128 ? ~0ull : (n > 64 ? ((1ull << (n - 64)) - 1ull) : 0ull)};
+}
+__device__ __forceinline__ M128 m_bit(uint32_t i) { return M128{i < 64 ? 1ull << i : 0ull, (i >= 64 && i < 128) ? 1ull << (i - 64) : 0ull}; }   // i >= 128: empty
+__device__ __forceinline__ bool m_test(M128 a, uint32_t i) { return (((i & 64u) ? a.hi : a.lo) >> (i & 63u) & 1ull) != 0; }   // bit i mod 128
+__device__ __forceinline__ uint32_t m_ctz(M128 a) { return a.lo ? (uint32_t)__builtin_ctzll(a.lo) : (a.hi ? 64u + (uint32_t)__builtin_ctzll(a.hi) : 128u); }
+__device__ __forceinline__ uint32_t m_popc(M128 a) { return (uint32_t)__popcll(a.lo) + (uint32_t)__popcll(a.hi); }
+__device__ __forceinline__ M128 m_clear_lowest(M128 a) { return a.lo ? M128{a.lo & (a.lo - 1), a.hi} : M128{0, a.hi & (a.hi - 1)}; }
+
 // ------------------------------------------------------------------------------------------------
 //                         K2 fast path: one LANE per site, 64 sites per wave
 // ------------------------------------------------------------------------------------------------
@@ -391,7 +410,7 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
 
 struct LanesLds {
     uint32_t slot[LANES_WAVES][64 * LANES_STRIDE];
-    uint8_t cls[256];           // byte after '.'/',' substitution -> rank of its symbol among "*ACGNT" | reverse << 3; 0xFF: other
+    uint8_t cls[256];           // byte -> rank of its symbol among "*ACGNT" (6: '.' / ',') | reverse << 3; 0xFF: other
 };
 
 __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
@@ -400,6 +419,8 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
         const uint32_t u = to_upper(c);
         uint32_t k = u == '*' ? 0u : u == 'A' ? 1u : u == 'C' ? 2u : u == 'G' ? 3u : u == 'N' ? 4u : u == 'T' ? 5u : 0xFFu;
         if (k != 0xFFu && c >= 0x61u) k |= 8u;               // pileup.py:269-270: >= 'a' is the reverse strand
+        if (c == '.') k = 6u;                                // the reference base, forward strand (lane 6 of cnt_f)
+        if (c == ',') k = 14u;                               // ... reverse strand (lane 6 of cnt_r)
         S.cls[c] = (uint8_t)k;
     }
     __syncthreads();
@@ -528,79 +549,164 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
             }
         }
         // ---- bases + qualities (pileup.py:237-274) -------------------------------------------------------------------
-        uint64_t cnt_f = 0, cnt_r = 0;                         // byte lanes: '*' A C G N T
+        // The bases field (<= 128 bytes here) is handled as per-lane 128-bit masks in field coordinates: byte classes by
+        // SWAR compares + dot4, caret pairs by the carry chains of two 128-bit adds (as k_call_sites does on ballots),
+        // indel markers by a short serial walk over the '+'/'-' bytes (none on most lines), and only the surviving bytes
+        // are then looked at one by one for the counts.
+        uint64_t cnt_f = 0, cnt_r = 0;                         // byte lanes: '*' A C G N T, lane 6: '.' (fwd) / ',' (rev)
         uint32_t good = 0;
-        const bool parse = has && !punt && raw_depth != 0 && nf >= 6;
+        bool parse = has && !punt && raw_depth != 0 && nf >= 6;
+        if (parse && fe(4) - fs(4) > 128u) { punt = true; parse = false; }
         {
-            const uint32_t bs = parse ? fs(4) : 0u, be = parse ? fe(4) : 0u, qs = fs(5), qlen = parse ? fe(5) - fs(5) : 0u;
-            const uint32_t ref_up = to_upper(ref), ref_lo = to_lower(ref);
-            uint32_t t_lo = bs >> 2, t_hi = (be + 3) >> 2;
-            for (int off = 32; off; off >>= 1) { t_lo = min(t_lo, (uint32_t)__shfl_xor((int)t_lo, off)); t_hi = max(t_hi, (uint32_t)__shfl_xor((int)t_hi, off)); }
-            if (!__ballot(parse)) t_hi = t_lo;
-            // The automaton of call_serial, written as straight-line selects (a divergent branch costs more scalar work
-            // than the few VALU ops it would skip).  Quality bytes are consumed in order, so they come from a dword
-            // window that is refilled ahead of use; the symbol classes of a dword's four bytes are requested while the
-            // previous dword is being worked on.
-            bool caret_skip = false, in_run = false, pending = false;
-            uint32_t acc = 0, debt = 0, kept = 0;
-            uint32_t w = t_lo < t_hi ? slot[t_lo] : 0u;
-            uint32_t qd = qs >> 2;                                 // dword index of the quality window
-            uint32_t qw = slot[qd & 63u], qw_next = slot[(qd + 1) & 63u];
-            auto subst = [&](uint32_t c) -> uint32_t { return c == '.' ? ref_up : (c == ',' ? ref_lo : c); };
-            uint32_t cl4[4];
+            const uint32_t bs = parse ? fs(4) : 0u, L0 = parse ? fe(4) - fs(4) : 0u, qs = fs(5), qlen = parse ? fe(5) - fs(5) : 0u;
+            uint32_t maxL = L0;
+            for (int off = 32; off; off >>= 1) maxL = max(maxL, (uint32_t)__shfl_xor((int)maxL, off));
+            maxL = __builtin_amdgcn_readfirstlane(maxL);
+            const uint32_t nd = (maxL + 3) >> 2;                 // dwords of the longest field in the wave
+            const M128 V = m_below(L0);
+            // -- byte classes: NOT '^', NOT sign, NOT '$' (a cleared bit = match), digits
+            uint32_t nC[4] = {0, 0, 0, 0}, nP[4] = {0, 0, 0, 0}, nS[4] = {0, 0, 0, 0}, dG[4] = {0, 0, 0, 0};
+            {
+                const uint32_t sh = bs & 3u;
+                uint32_t lo = slot[bs >> 2];
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) cl4[k] = S.cls[subst((w >> (8 * k)) & 0xFFu)];
-            for (uint32_t t = t_lo; t < t_hi; ++t) {
-                const uint32_t wn = t + 1 < LANES_WIN / 4 ? slot[t + 1] : 0u;
-                uint32_t cn4[4];
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) cn4[k] = S.cls[subst((wn >> (8 * k)) & 0xFFu)];
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    const uint32_t p = 4 * t + k, c = (w >> (8 * k)) & 0xFFu;
-                    const bool act = p >= bs && p < be;
-                    const bool isd = is_digit(c), sign = c == '+' || c == '-';
-                    const bool live = act && !caret_skip && !(c == '^' && p + 1 < be);
-                    caret_skip = act ? (!caret_skip && c == '^' && p + 1 < be) : caret_skip;
-                    // a pending sign: followed by a digit it opens a marker, otherwise it was an ordinary byte
-                    const bool open = live && pending && isd, plain_sign = live && pending && !isd;
-                    punt = punt || (plain_sign && debt == 0);      // ... that survives as a symbol: not ours
-                    debt -= (plain_sign && debt != 0) ? 1u : 0u;
-                    pending = live ? false : pending;
-                    // the digit run of a marker; its value joins the debt when the run ends
-                    const bool more = live && !open && in_run && isd, close = live && !open && in_run && !isd;
-                    acc = open ? c - 48u : (more ? sat_mul10_add(acc, c - 48u) : acc);
-                    debt = close ? sat_add(debt, acc) : debt;
-                    in_run = open ? true : (close ? false : in_run);
-                    const bool rest = live && !open && !more;
-                    pending = (rest && sign) ? true : pending;
-                    const bool ordinary = rest && !sign;
-                    const bool owed = ordinary && debt != 0;
-                    debt -= owed ? 1u : 0u;
-                    const bool emit = ordinary && !owed && c != '$';
-                    // the quality this base pairs with (zip truncation: none past the end of the quality field)
-                    const uint32_t qi = qs + kept;
-                    if (__ballot((qi >> 2) != qd)) {                 // some lane's window moves on (every few steps)
-                        const bool adv = (qi >> 2) != qd;
-                        qw = adv ? qw_next : qw;
-                        qd += adv ? 1u : 0u;
-                        qw_next = slot[(qd + 1) & 63u];
-                    }
-                    const uint32_t qv = (qw >> (8 * (qi & 3u))) & 0xFFu;
-                    const bool goodb = emit && kept < qlen && (int)qv - 33 >= minq;
-                    kept += emit ? 1u : 0u;
-                    good += goodb ? 1u : 0u;
-                    const uint32_t cl = cl4[k];
-                    punt = punt || (goodb && cl == 0xFFu);
-                    const uint64_t one = (goodb && cl != 0xFFu) ? 1ull << (8 * (cl & 7u)) : 0ull;
-                    cnt_f += (cl & 8u) ? 0ull : one;
-                    cnt_r += (cl & 8u) ? one : 0ull;
+                for (uint32_t j = 0; j < 32; ++j) {
+                    if (j >= nd) break;
+                    const uint32_t hi = slot[(bs >> 2) + j + 1];
+                    const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                    lo = hi;
+                    const uint32_t ne_c = ((w ^ 0x5E5E5E5Eu) + 0x7F7F7F7Fu) & 0x80808080u;
+                    const uint32_t ne_p = ((w ^ 0x2B2B2B2Bu) + 0x7F7F7F7Fu) & ((w ^ 0x2D2D2D2Du) + 0x7F7F7F7Fu) & 0x80808080u;
+                    const uint32_t ne_s = ((w ^ 0x24242424u) + 0x7F7F7F7Fu) & 0x80808080u;
+                    const uint32_t dg = ((w + 0x50505050u) ^ (w + 0x46464646u)) & 0x80808080u;     // '0'..'9'
+                    const uint32_t pos = (4 * j) & 31u;
+                    nC[j >> 3] |= (__builtin_amdgcn_udot4(ne_c, 0x08040201u, 0u, false) >> 7) << pos;
+                    nP[j >> 3] |= (__builtin_amdgcn_udot4(ne_p, 0x08040201u, 0u, false) >> 7) << pos;
+                    nS[j >> 3] |= (__builtin_amdgcn_udot4(ne_s, 0x08040201u, 0u, false) >> 7) << pos;
+                    dG[j >> 3] |= (__builtin_amdgcn_udot4(dg, 0x08040201u, 0u, false) >> 7) << pos;
                 }
-                w = wn;
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) cl4[k] = cn4[k];
             }
-            if (parse && pending && !debt) punt = true;        // a trailing sign survives as a symbol
+            const M128 C = m_andn(V, m_make(nC)), PM = m_andn(V, m_make(nP)), DL = m_andn(V, m_make(nS)), D = m_and(V, m_make(dG));
+            // -- '^' + next byte (pileup.py:312): openers are the carets at even distance from the start of their run
+            const M128 EVEN{0x5555555555555555ull, 0x5555555555555555ull};
+            const M128 S0 = m_andn(C, m_shl1(C));
+            const M128 Me = m_andn(C, m_add(C, m_and(S0, EVEN))), Mo = m_andn(C, m_add(C, m_andn(S0, EVEN)));
+            M128 openers = m_or(m_and(Me, EVEN), m_andn(Mo, EVEN));
+            openers = m_andn(openers, m_bit(L0 - 1));            // a trailing lone '^' stays (L0 == 0: no bit)
+            const M128 K1 = m_andn(V, m_or(openers, m_shl1(openers)));
+            // -- indel markers with additive debt (pileup.py:315-320), walked sign by sign
+            M128 Ms{0, 0}, Md{0, 0}, Del{0, 0};
+            M128 P = m_and(PM, K1);
+            if (__ballot(m_any(P))) {
+                uint32_t debt = 0, prev_end = 0;
+                auto settle = [&](uint32_t upto) {                 // the debt eats ordinary bytes in [prev_end, upto)
+                    M128 O = m_and(m_andn(m_andn(K1, Ms), Md), m_andn(m_below(upto), m_below(prev_end)));
+                    const uint32_t avail = m_popc(O), eat = debt < avail ? debt : avail;
+                    M128 rest = O;
+                    for (uint32_t t = 0; __ballot(t < eat); ++t) if (t < eat) rest = m_clear_lowest(rest);
+                    Del = m_or(Del, m_andn(O, rest));
+                    debt -= eat;
+                };
+                while (__ballot(m_any(P))) {
+                    const bool on = m_any(P);
+                    const uint32_t i = on ? m_ctz(P) : 0u;
+                    if (on) P = m_clear_lowest(P);
+                    const uint32_t nk = m_ctz(m_andn(K1, m_below(i + 1)));            // the next byte that survived the carets
+                    const bool marker = on && nk < 128u && m_test(D, nk);
+                    const uint32_t e = m_ctz(m_andn(m_andn(K1, D), m_below(nk)));      // 128: the digits run to the end
+                    const M128 run = m_and(m_and(K1, m_below(e)), marker ? m_not(m_below(nk)) : M128{0, 0});
+                    uint32_t count = 0;
+                    {
+                        M128 r = run;
+                        while (__ballot(m_any(r))) {
+                            if (m_any(r)) { count = sat_mul10_add(count, (uint32_t)slot_b[(bs + m_ctz(r)) & 0xFFu] - 48u); r = m_clear_lowest(r); }
+                        }
+                    }
+                    if (__ballot(marker && debt != 0)) { if (marker) settle(i); }
+                    if (marker) {
+                        Ms = m_or(Ms, m_bit(i));
+                        Md = m_or(Md, run);
+                        // ordinary bytes between the previous marker and this sign were settled above (or there was no debt)
+                        debt = sat_add(debt, count);
+                        prev_end = e;
+                    }
+                }
+                if (__ballot(debt != 0)) settle(128);
+                punt = punt || m_any(m_andn(m_andn(m_and(PM, K1), Ms), Del));         // a sign that survives as a symbol: not ours
+            }
+            const M128 K = m_andn(m_andn(m_andn(m_andn(K1, Ms), Md), Del), DL);
+            // -- pair with qualities (zip truncation, pileup.py:248-250) and count
+            const int thr = 33 + minq;
+            const uint32_t kept_total = m_popc(K);
+            // all qualities pass and none is missing?  Then every kept byte is a good base.
+            bool allq = kept_total <= qlen;
+            if (thr > 0) {
+                if (thr > 128) allq = allq && kept_total == 0;
+                else {
+                    const uint32_t addc = (uint32_t)(128 - thr) * 0x01010101u;       // bit 7 of a byte after the add: byte >= thr
+                    const uint32_t shq = qs & 3u;
+                    uint32_t lo = slot[(qs >> 2) & 63u];
+                    uint32_t maxQ = parse ? (kept_total < qlen ? kept_total : qlen) : 0u;
+                    for (int off = 32; off; off >>= 1) maxQ = max(maxQ, (uint32_t)__shfl_xor((int)maxQ, off));
+                    const uint32_t nq = (__builtin_amdgcn_readfirstlane(maxQ) + 3) >> 2;
+                    const uint32_t need = kept_total < qlen ? kept_total : qlen;      // qualities that matter
+                    for (uint32_t j = 0; j < nq; ++j) {
+                        const uint32_t hi = slot[((qs >> 2) + j + 1) & 63u];
+                        const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, shq);
+                        lo = hi;
+                        const uint32_t nb = need > 4 * j ? min(need - 4 * j, 4u) : 0u;
+                        const uint32_t m = nb >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * nb)) - 1u));
+                        allq = allq && ((~(w + addc)) & m) == 0;
+                    }
+                }
+            }
+            const bool pair_any = __ballot(parse && !allq) != 0;
+            {
+                const uint32_t sh = bs & 3u;
+                uint32_t lo = slot[bs >> 2];
+                uint32_t kept = 0;
+                uint32_t qd = qs >> 2, qw = 0, qw_next = 0;
+                if (pair_any) { qw = slot[qd & 63u]; qw_next = slot[(qd + 1) & 63u]; }
+                for (uint32_t j = 0; j < nd; ++j) {
+                    const uint32_t hi = slot[(bs >> 2) + j + 1];
+                    const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                    lo = hi;
+                    const uint32_t k4 = (uint32_t)(((j & 16u) ? K.hi : K.lo) >> ((4 * j) & 63u)) & 15u;
+                    uint32_t cl4[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) cl4[k] = S.cls[(w >> (8 * k)) & 0xFFu];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const bool emit = (k4 >> k) & 1u;
+                        bool goodb = emit;
+                        if (pair_any) {
+                            const uint32_t qi = qs + kept;
+                            if (__ballot((qi >> 2) != qd)) {
+                                const bool adv = (qi >> 2) != qd;
+                                qw = adv ? qw_next : qw;
+                                qd += adv ? 1u : 0u;
+                                qw_next = slot[(qd + 1) & 63u];
+                            }
+                            const uint32_t qv = (qw >> (8 * (qi & 3u))) & 0xFFu;
+                            goodb = emit && kept < qlen && (int)qv >= thr;
+                            kept += emit ? 1u : 0u;
+                        }
+                        const uint32_t cl = cl4[k];
+                        good += goodb ? 1u : 0u;
+                        punt = punt || (goodb && cl == 0xFFu);
+                        const uint32_t shf = 8u * (cl & 7u);
+                        cnt_f += (uint64_t)((goodb && cl < 8u) ? 1u : 0u) << shf;
+                        cnt_r += (uint64_t)((goodb && (cl & 0xF8u) == 8u) ? 1u : 0u) << shf;
+                    }
+                }
+            }
+            // '.' and ',' stand for the reference base on the forward / reverse strand (pileup.py:255-258)
+            const uint32_t ndot = (uint32_t)(cnt_f >> 48) & 0xFFu, ncom = (uint32_t)(cnt_r >> 48) & 0xFFu;
+            const uint32_t kr = S.cls[to_upper(ref) & 0xFFu];
+            const bool ref_ok = kr >= 1u && kr <= 5u;             // A C G N T in either case
+            punt = punt || (!ref_ok && (ndot | ncom) != 0);
+            cnt_f = (cnt_f & 0x0000FFFFFFFFFFFFull) + ((uint64_t)ndot << (8 * (kr & 7u)));
+            cnt_r = (cnt_r & 0x0000FFFFFFFFFFFFull) + ((uint64_t)ncom << (8 * (kr & 7u)));
         }
         if (a.exp == 3) { if (good == 7777) a.out_base[site] = (uint8_t)(cnt_f + cnt_r); continue; }
         // ---- the caller (pileup.py:550-588) --------------------------------------------------------------------------

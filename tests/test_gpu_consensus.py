@@ -267,3 +267,49 @@ def test_contig_changes_and_contigs_outside_the_site_set(d):
     assert bad != data
     with pytest.raises(PileupFormatError):
         gpu_consensus(d, bad, snps, [], po.CallerParams())
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_lane_kernel_alphabet_stress(d, seed):
+    """Dense carets, indel markers, '$', digits and short / long quality strings over the alphabet the lane-per-site
+    kernel keeps for itself (other symbols go to the wave-per-site kernel): both device paths against the oracle."""
+    from tests.gpu_util import check_against_oracle
+    rng = random.Random(seed)
+    alphabet = ".,.,.,ACGTNacgtn*" + "^$+-0123456789"
+    lines, keys = [], []
+    for pos in range(1, 1501):
+        n = rng.choice([1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 120, 128])
+        dense = rng.random() < 0.5
+        toks = []
+        while len(toks) < n:
+            r = rng.random()
+            if dense and r < 0.15:
+                toks.append("^" * rng.randint(1, 4))
+            elif dense and r < 0.30:
+                k = rng.randint(0, 12)
+                toks.append(rng.choice("+-") + (str(k) if rng.random() < 0.8 else "") + "".join(rng.choice("ACGTNacgtn") for _ in range(rng.randint(0, 4))))
+            elif dense and r < 0.36:
+                toks.append(str(rng.randint(0, 99)))
+            elif r < 0.45 and dense:
+                toks.append("$")
+            else:
+                toks.append(rng.choice(alphabet if dense else ".,.,.,.,ACGTacgt^$"))
+        bases = "".join(toks)[:n]
+        qn = max(0, len(bases) + rng.choice([0, 0, 0, -3, 2, -len(bases)]))
+        quals = "".join(chr(33 + rng.choice([0, 5, 14, 15, 16, 30, 40, 41])) for _ in range(qn))
+        ref = rng.choice("ACGTNacgtn")
+        depth = rng.choice([len(bases), 1, 0]) if rng.random() < 0.2 else len(bases)
+        fields = ["ctgL", str(pos), ref, str(depth), bases] + ([quals] if quals or rng.random() < 0.5 else [])
+        lines.append(rng.choice(["\t", "\t", " "]).join(fields))
+        keys.append((b"ctgL", pos))
+    data = ("\n".join(lines) + "\n").encode()
+    for p in (po.CallerParams(0, 0.6, 1, 0, 0.0), po.CallerParams(15, 0.75, 3, 1, 0.25), po.CallerParams(16, 0.5, 1, 0, 0.0)):
+        ok_keys = []
+        for (_, ln), k in zip(po.iter_lines(data), keys):       # keep the lines the reference itself can parse
+            try:
+                po.parse_record(po.split_fields(ln), p.min_base_quality)
+                ok_keys.append(k)
+            except Exception:
+                pass
+        assert len(ok_keys) > 1000
+        check_against_oracle(d, data, ok_keys, ok_keys[::13], p)
