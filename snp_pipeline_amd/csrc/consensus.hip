@@ -432,37 +432,75 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
     const uint64_t n_groups = (n_work + 63) / 64;
     const int minq = a.prm.min_base_quality;
 
-    for (uint64_t grp = (uint64_t)blockIdx.x * LANES_WAVES + wave; grp < n_groups; grp += (uint64_t)gridDim.x * LANES_WAVES) {
+    // what a lane needs to know about its site; the next group's is requested before this group is worked on
+    struct LaneRef { uint64_t lv; uint32_t sflags; uintptr_t buf, end; };
+    auto fetch_ref = [&](uint64_t g) -> LaneRef {
+        LaneRef r{0, 0, 0, 0};
+        const uint64_t s = g * 64 + lane;
+        if (g < n_groups && s < n_work) {
+            const uint32_t sample = (uint32_t)(s / a.n_sites);
+            r.lv = a.site_line[s];
+            r.sflags = a.site_flags[s - (uint64_t)sample * a.n_sites];
+            r.buf = (uintptr_t)a.samples[sample].buf;
+            r.end = r.buf + a.samples[sample].nbytes;
+        }
+        return r;
+    };
+    const uint64_t g_stride = (uint64_t)gridDim.x * LANES_WAVES;
+    uint64_t grp = (uint64_t)blockIdx.x * LANES_WAVES + wave;
+    LaneRef nxt = fetch_ref(grp);
+    for (; grp < n_groups; grp += g_stride) {
+        const LaneRef cur = nxt;
+        nxt = fetch_ref(grp + g_stride);
         const uint64_t site = grp * 64 + lane;
         const bool valid = site < n_work;
-        uint64_t lv = 0;
-        uint32_t sflags = 0;
-        uintptr_t addr = 0, end = 0;
-        if (valid) {
-            const uint32_t sample = (uint32_t)(site / a.n_sites);
-            lv = a.site_line[site];
-            sflags = a.site_flags[site - (uint64_t)sample * a.n_sites];
-            const uintptr_t b = (uintptr_t)a.samples[sample].buf;
-            end = b + a.samples[sample].nbytes;
-            addr = b + (lv - 1);
-        }
+        const uint64_t lv = cur.lv;
+        const uint32_t sflags = cur.sflags;
+        const uintptr_t addr = cur.buf + (lv - 1), end = cur.end;
         const bool has = lv != 0;
-        // ---- stage [al, al + 256) of every lane's line; bytes at or past the end of the file read as '\n' -------------
+        // ---- stage the line: bytes [al, al + 128) of every lane first, [al + 128, al + 256) only for the lanes whose line
+        //      does not end in the first half (a 30x line is ~100 bytes; the fetch is random 128-byte DRAM accesses, so
+        //      bytes matter).  Bytes at or past the end of the file read as '\n'. ------------------------------------
         const uintptr_t al = addr & ~(uintptr_t)15;
         const uint32_t o = (uint32_t)(addr & 15);              // the line starts at byte o of the slot
+        auto stage_half = [&](int half, bool want) {
+            if (!__ballot(want && end - al < 2 * LANES_WIN)) {
+                // Eight neighbouring lanes fetch one site's 128 bytes, so that a wave instruction is 8 coalesced
+                // 128-byte reads (2 cache lines each) instead of 64 scattered 16-byte ones: the fetch is bound by
+                // the number of outstanding requests per CU, not by bytes.
+                const uint64_t wm = __ballot(want);
+                const uint32_t piece = lane & 7u;
+                uint4 v[8];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+                for (int r = 0; r < 8; ++r) {
+                    const uint32_t src = 8u * r + (lane >> 3);
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)(uint32_t)al);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)(uint32_t)(al >> 32));
+                    const uintptr_t x = (((uintptr_t)hi << 32) | lo) + 128u * half + 16u * piece;
+                    v[r] = make_uint4(0, 0, 0, 0);
+                    if ((wm >> src) & 1ull) v[r] = *(const uint4 *)x;
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const uint32_t src = 8u * r + (lane >> 3);
+                    if ((wm >> src) & 1ull) {
+                        uint32_t *dst = &S.slot[wave][src * LANES_STRIDE + 32 * half + 4 * piece];
+                        dst[0] = v[r].x; dst[1] = v[r].y; dst[2] = v[r].z; dst[3] = v[r].w;
+                    }
+                }
+                return;
+            }
             uint4 v[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const uintptr_t x = al + 16u * (8 * half + r);
                 v[r] = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
-                if (has && x < end) v[r] = *(const uint4 *)x;
+                if (want && x < end) v[r] = *(const uint4 *)x;
             }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const uintptr_t x = al + 16u * (8 * half + r);
-                if (__ballot(has && x < end && x + 16 > end)) {            // the file ends inside this chunk (rare)
+                if (__ballot(want && x < end && x + 16 > end)) {           // the file ends inside this chunk (rare)
                     uint32_t w[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
 #pragma unroll
                     for (int d = 0; d < 4; ++d)
@@ -471,11 +509,14 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
                             if (x + 4 * d + bb >= end) w[d] = (w[d] & ~(0xFFu << (8 * bb))) | (0x0Au << (8 * bb));
                     v[r] = make_uint4(w[0], w[1], w[2], w[3]);
                 }
-                uint32_t *dst = slot + 4 * (8 * half + r);
-                dst[0] = v[r].x; dst[1] = v[r].y; dst[2] = v[r].z; dst[3] = v[r].w;
+                if (want) {
+                    uint32_t *dst = slot + 4 * (8 * half + r);
+                    dst[0] = v[r].x; dst[1] = v[r].y; dst[2] = v[r].z; dst[3] = v[r].w;
+                }
             }
-        }
-        __builtin_amdgcn_wave_barrier();                       // a lane only ever reads its own slot
+        };
+        stage_half(0, has);
+        __builtin_amdgcn_wave_barrier();                       // LDS operations of a wave execute in order
 
         if (a.exp == 1) continue;
         // ---- tokenise (pileup.py:206): per-lane 256-bit masks of the str.split() separators and of the terminator
@@ -485,6 +526,8 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
 #pragma unroll
         for (int blk = 0; blk < LANES_WIN / 64; ++blk) {
             if (!__ballot(!done)) break;
+            if (blk == 2) { stage_half(1, !done); __builtin_amdgcn_wave_barrier(); }   // only the lines that are still open
+            const bool open = !done;                             // (the slots of the others hold stale bytes up there)
             uint32_t mw[2] = {0, 0}, mt[2] = {0, 0};
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -500,8 +543,8 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
                 mw[j >> 3] |= __builtin_amdgcn_udot4(f_ws >> 7, 0x08040201u, 0u, false) << (4 * (j & 7));
                 mt[j >> 3] |= __builtin_amdgcn_udot4(f_t >> 7, 0x08040201u, 0u, false) << (4 * (j & 7));
             }
-            Wm[blk] = (uint64_t)mw[0] | ((uint64_t)mw[1] << 32);
-            Tm[blk] = (uint64_t)mt[0] | ((uint64_t)mt[1] << 32);
+            Wm[blk] = open ? (uint64_t)mw[0] | ((uint64_t)mw[1] << 32) : ~0ull;     // past the end of a line: separators
+            Tm[blk] = open ? (uint64_t)mt[0] | ((uint64_t)mt[1] << 32) : 0ull;
             done = done || Tm[blk] != 0;
         }
         // first set bit at or after `pos` (256: none); inv: scan the complement
