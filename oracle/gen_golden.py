@@ -407,11 +407,13 @@ CLI_LINES = [
     "snp_matrix -f -c consensus_preserved.fasta -o snpma_preserved.fasta dirs.txt",
     "distance snpma.fasta",
     "distance -f -p pairs.tsv -m matrix.tsv snpma.fasta",
+    "snp_reference reference/lambda_virus.fasta",
+    "snp_reference -f -v 0 -l snplist_preserved.txt -o referenceSNP_preserved.fasta reference/lambda_virus.fasta",
 ]
 
 
 def gen_cli_vectors():
-    """argparse results of the reference's own parser for the five hot subcommands."""
+    """argparse results of the reference's own parser for the subcommands this build provides."""
     import types as _t
     jr = _t.ModuleType("jobrunner")                      # orchestration only (run.py); never called here
     jr.JobRunner = object
@@ -439,6 +441,9 @@ def dump(name, obj):
 def main():
     os.makedirs(GOLD, exist_ok=True)
     captured = install_stubs()
+    if sys.argv[1:] == ["--only", "cli"]:
+        dump("cli_vectors.json.gz", gen_cli_vectors())
+        return
     dump("pileup_vectors.json.gz", gen_pileup_vectors(captured))
     dump("steps_vectors.json.gz", gen_steps_vectors())
     dump("cli_vectors.json.gz", gen_cli_vectors())

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""``cfsan_snp_pipeline`` console entry for the five hot subcommands on MI355X.
+"""``cfsan_snp_pipeline`` console entry for the post-alignment subcommands on MI355X.
 
 Mirrors the argparse surface of snppipeline/cfsan_snp_pipeline.py for filter_regions (:309-324, list validation
-:530-543), merge_sites (:329-340), call_consensus (:345-410), snp_matrix (:429-443) and distance (:448-457): same
+:530-543), merge_sites (:329-340), call_consensus (:345-410), snp_matrix (:429-443), distance (:448-457) and snp_reference (:460-471): same
 flags, defaults, type validators, per-subcommand exception hook, exit codes and "finished" banner, plus the
 python-level helpers the reference's unit tests use (parse_command_line, parse_argument_list,
 run_command_from_args ...).  Every other subcommand belongs to the alignment stage or to orchestration and is not
@@ -13,10 +13,10 @@ from __future__ import absolute_import
 import argparse
 import sys
 
-from . import call_consensus, distance, filter_regions, merge_sites, snp_matrix, utils
+from . import call_consensus, distance, filter_regions, merge_sites, snp_matrix, snp_reference, utils
 from .utils import __version__, verbose_print
 
-NOT_PROVIDED = ("run", "data", "index_ref", "map_reads", "call_sites", "merge_vcfs", "snp_reference",
+NOT_PROVIDED = ("run", "data", "index_ref", "map_reads", "call_sites", "merge_vcfs",
                 "collect_metrics", "combine_metrics", "purge")
 
 
@@ -120,6 +120,15 @@ def parse_argument_list(argv):
     sub.add_argument("-m", "--matrix", dest="matrixFile", type=str, default=None, metavar="FILE", help="Relative or absolute path to the distance matrix output file.")
     _common(sub)
     sub.set_defaults(func=distance.calculate_snp_distances, excepthook=utils.handle_global_exception)
+
+    sub = subparsers.add_parser("snp_reference", help="Write reference bases at SNP locations to a fasta file", formatter_class=fmt,
+                                description="Write reference sequence bases at SNP locations to a fasta file.")
+    sub.add_argument(dest="referenceFile", type=str, help="Relative or absolute path to the reference bases file in fasta format")
+    sub.add_argument("-f", "--force", dest="forceFlag", action="store_true", help="Force processing even when result file already exists and is newer than inputs")
+    sub.add_argument("-l", "--snpListFile", dest="snpListFile", type=str, default="snplist.txt", metavar="FILE", help="Relative or absolute path to the SNP list file")
+    sub.add_argument("-o", "--output", dest="snpRefFile", type=str, default="referenceSNP.fasta", metavar="FILE", help="Output file.  Relative or absolute path to the SNP reference sequence file")
+    _common(sub)
+    sub.set_defaults(func=snp_reference.create_snp_reference_seq, excepthook=utils.handle_global_exception)
 
     for name in NOT_PROVIDED:
         sub = subparsers.add_parser(name, help="(not part of this build)", add_help=False)

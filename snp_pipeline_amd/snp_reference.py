@@ -1,0 +1,71 @@
+"""snp_reference subcommand: the reference bases at the snplist positions as a FASTA file.
+
+Host mirror of snppipeline/snp_reference.py:12-77 and utils.write_reference_snp_file (utils.py:1091-1110).  There is
+no arithmetic in this step — one byte gathered per site — so it stays on the host; it is here because
+referenceSNP.fasta is one of the top-level outputs the regression suite diffs.
+"""
+from __future__ import absolute_import
+
+from . import utils
+from .utils import verbose_print
+
+
+def read_fasta_sequences(path):
+    """{record id: sequence} the way Bio.SeqIO.to_dict(SeqIO.parse(path, "fasta")) sees the file: the id is the first
+    word of the header, the sequence is the data lines with all whitespace removed; a repeated id is an error."""
+    seqs = {}
+    name, parts = None, []
+    with open(path, "r") as f:
+        for line in f:
+            if line.startswith(">"):
+                if name is not None:
+                    seqs[name] = "".join(parts)
+                words = line[1:].split()
+                name, parts = (words[0] if words else ""), []
+                if name in seqs:
+                    raise ValueError("Duplicate key '%s'" % name)      # what SeqIO.to_dict raises
+            elif name is not None:
+                parts.append("".join(line.split()))
+    if name is not None:
+        seqs[name] = "".join(parts)
+    return seqs
+
+
+def write_reference_snp_file(reference_file_path, snp_list_file_path, snp_reference_file_path):
+    """utils.py:1091-1110: for every contig of the reference in sorted id order, the upper-cased reference bases at
+    the snplist positions of that contig, in snplist order (python indexing: position 0 reads the last base, a
+    position past the end raises IndexError)."""
+    with open(snp_list_file_path, "r") as snp_list_file:
+        position_list = [line.split()[0:2] for line in snp_list_file]
+    match_dict = read_fasta_sequences(reference_file_path)
+    by_contig = {}
+    for item in position_list:
+        chrom_id, pos = item                                  # a line with fewer than two fields raises, as in the reference
+        by_contig.setdefault(chrom_id, []).append(pos)
+    with open(snp_reference_file_path, "w") as out:
+        for ordered_id in sorted(match_dict.keys()):
+            seq = match_dict[ordered_id]
+            ref_str = "".join(seq[int(pos) - 1].upper() for pos in by_contig.get(ordered_id, ()))
+            utils.write_fasta_record(out, ordered_id, ref_str)
+
+
+def create_snp_reference_seq(args):
+    """args: referenceFile, snpListFile, snpRefFile, forceFlag (snp_reference.py:12-77)."""
+    utils.print_log_header()
+    utils.print_arguments(args)
+    reference_file = args.referenceFile
+    snp_list_file_path = args.snpListFile
+    snp_ref_seq_path = args.snpRefFile
+
+    bad_file_count = utils.verify_existing_input_files("Snplist file", [snp_list_file_path])
+    if bad_file_count > 0:
+        utils.global_error("Error: cannot create the snp reference sequence without the snplist file.")
+    bad_file_count = utils.verify_non_empty_input_files("Reference file", [reference_file])
+    if bad_file_count > 0:
+        utils.global_error("Error: cannot create the snp reference sequence without the reference fasta file.")
+
+    source_files = [reference_file, snp_list_file_path]
+    if args.forceFlag or utils.target_needs_rebuild(source_files, snp_ref_seq_path):
+        write_reference_snp_file(reference_file, snp_list_file_path, snp_ref_seq_path)
+    else:
+        verbose_print("SNP reference sequence %s has already been freshly built.  Use the -f option to force a rebuild." % snp_ref_seq_path)

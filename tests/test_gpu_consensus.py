@@ -313,3 +313,85 @@ def test_lane_kernel_alphabet_stress(d, seed):
                 pass
         assert len(ok_keys) > 1000
         check_against_oracle(d, data, ok_keys, ok_keys[::13], p)
+
+
+def test_full_size_samples_properties_and_spot_check(d):
+    """BASELINE configs[3] sample shape (5 Mbp x 30x, 50 k sites) — too big for the oracle, so: size-independent
+    properties (line count = newline count, matched count = sites with a line, batch = per-sample = counts path,
+    idempotence) plus the oracle on the very lines the device picked for 600 random sites."""
+    import torch
+    from snp_pipeline_amd import device as dev
+    from snp_pipeline_amd import _lib as L
+    G, S, B = 5_000_000, 50_000, 2
+    d.use_torch_stream()
+    ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda")
+    d.synth_reference_dev(1, G, ref.data_ptr())
+    refh = ref.cpu().numpy()
+    rng = np.random.default_rng(2)
+    pos = np.sort(rng.choice(np.arange(501, G - 499), size=S, replace=False))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    alt_h = np.zeros(G + 1, dtype=np.uint8)
+    alt_h[pos] = acgt[(np.searchsorted(acgt, refh[pos]) + 1 + rng.integers(0, 3, size=S)) % 4]
+    alt = torch.from_numpy(alt_h).cuda()
+    sizes = [d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), 0, 0) for i in range(B)]
+    offs = np.zeros(B, dtype=np.uint64)
+    offs[1] = (sizes[0] + 255) // 256 * 256 + 7                       # an odd start address for the second sample
+    pile = torch.full((int(offs[1]) + sizes[1] + 64,), 0x58, dtype=torch.uint8, device="cuda")
+    for i in range(B):
+        assert d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), pile.data_ptr() + int(offs[i]), sizes[i]) == sizes[i]
+    keys = [(b"synth_chr1", int(p_)) for p_ in pos]
+    ss = d.siteset(keys, [L.SITE_IN_SNPLIST] * S)
+    p = po.CallerParams(0, 0.6, 3, 0, 0.0)
+    prm = dev.make_params(p.min_base_quality, p.min_cons_freq, p.min_cons_depth, p.min_cons_strand_depth, p.min_cons_strand_bias)
+    bases = torch.zeros((B, S), dtype=torch.uint8, device="cuda")
+    filt = torch.zeros((B, S), dtype=torch.uint8, device="cuda")
+    status = torch.zeros((B, 4), dtype=torch.int64, device="cuda")
+    d.call_consensus_batch_dev(ss, pile.data_ptr(), offs, prm, bases.data_ptr(), filt.data_ptr(), status.data_ptr(),
+                               sizes=np.asarray(sizes, dtype=np.uint64))
+    torch.cuda.synchronize()
+    st = status.cpu().numpy()
+    assert (st[:, 0] == -1).all()
+    for i in range(B):
+        view = pile[int(offs[i]):int(offs[i]) + sizes[i]]
+        assert int(st[i, 1]) == int((view == 10).sum().item())          # lines seen = terminators in the file
+    # the same samples one at a time: plain path and counts path; rerun of the batch (idempotence)
+    for i in range(B):
+        b1 = torch.zeros(S, dtype=torch.uint8, device="cuda")
+        f1 = torch.zeros(S, dtype=torch.uint8, device="cuda")
+        s1 = torch.zeros(4, dtype=torch.int64, device="cuda")
+        d.call_consensus_dev(ss, pile.data_ptr() + int(offs[i]), sizes[i], prm, b1.data_ptr(), f1.data_ptr(), s1.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(b1, bases[i]) and torch.equal(f1, filt[i])
+        assert s1.cpu().numpy().tolist() == st[i].tolist()
+        line_off = d.line_offsets(ss)
+        assert int(st[i, 2]) == int(np.count_nonzero(line_off))         # matched lines = sites that got a line
+        assert ((bases[i].cpu().numpy() == 0x2D) | (line_off != 0)).all()
+        cbuf = torch.zeros(S * 128, dtype=torch.uint8, device="cuda")
+        b2 = torch.zeros(S, dtype=torch.uint8, device="cuda")
+        f2 = torch.zeros(S, dtype=torch.uint8, device="cuda")
+        d.call_consensus_dev(ss, pile.data_ptr() + int(offs[i]), sizes[i], prm, b2.data_ptr(), f2.data_ptr(), s1.data_ptr(),
+                             d_counts=cbuf.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(b2, bases[i]) and torch.equal(f2, filt[i])   # wave-per-site kernel = lane-per-site kernel
+        # the oracle on the lines the device picked
+        bh, fh = bases[i].cpu().numpy(), filt[i].cpu().numpy()
+        for slot in rng.choice(S, size=300, replace=False):
+            if line_off[slot] == 0:
+                assert bh[slot] == 0x2D and fh[slot] == 0
+                continue
+            a0 = int(offs[i]) + int(line_off[slot]) - 1
+            raw = bytes(pile[a0:a0 + 700].cpu().numpy())
+            line = raw[:raw.index(b"\n")]
+            if a0 > int(offs[i]):
+                assert int(pile[a0 - 1].item()) == 10                    # it is the start of a line
+            fields = po.split_fields(line)
+            assert (fields[0], int(fields[1])) == keys[slot]
+            base, mask = po.call_record(po.parse_record(fields, p.min_base_quality), p)
+            want = 0x2D if (mask or base == 0x2A) else base
+            assert (int(bh[slot]), int(fh[slot])) == (want, mask), line
+    b3 = torch.zeros((B, S), dtype=torch.uint8, device="cuda")
+    f3 = torch.zeros((B, S), dtype=torch.uint8, device="cuda")
+    d.call_consensus_batch_dev(ss, pile.data_ptr(), offs, prm, b3.data_ptr(), f3.data_ptr(), status.data_ptr(),
+                               sizes=np.asarray(sizes, dtype=np.uint64))
+    torch.cuda.synchronize()
+    assert torch.equal(b3, bases) and torch.equal(f3, filt)

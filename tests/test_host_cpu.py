@@ -134,3 +134,28 @@ def test_consensus_vcf_header_matches_lambda_fixture(fixture_trees):
     got = vcf_writer.header_lines("sample1", filters, "lambda_virus.fasta")
     skip = ("##fileDate", "##source")                           # the reference's test ignores these two (test_cfsan_snp_pipeline.py:173)
     assert [x for x in got if not x.startswith(skip)] == [x for x in want if not x.startswith(skip)]
+
+
+def test_snp_reference_matches_lambda_fixture(tmp_path, fixture_trees):
+    """referenceSNP.fasta / referenceSNP_preserved.fasta of the bundled lambda results, byte for byte, through the CLI
+    (snp_reference.py:12-77; the other two datasets ship no reference fasta)."""
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    from snp_pipeline_amd import snp_reference
+    tree, _ = fixture_trees["lambdaVirus"]
+    ref = os.path.join(os.path.dirname(__file__), "golden", "fixtures", "lambdaVirus", "lambda_virus.fasta")
+    for snplist, want in (("snplist.txt", "referenceSNP.fasta"), ("snplist_preserved.txt", "referenceSNP_preserved.fasta")):
+        out = str(tmp_path / want)
+        rc = cli.run_command_from_args(cli.parse_argument_list(
+            ["snp_reference", "-v", "0", "-l", os.path.join(tree, snplist), "-o", out, ref]))
+        assert rc == 0
+        assert open(out, "rb").read() == open(os.path.join(tree, want), "rb").read()
+    # python indexing of the reference: position 0 reads the last base, a position past the end raises
+    fa = tmp_path / "r.fasta"
+    fa.write_text(">c2 desc\nacgt\nTT\n>c1\nGGa\n")
+    sl = tmp_path / "s.txt"
+    sl.write_text("c2\t1\t1\tx\nc1\t3\t1\tx\nc2\t0\t1\tx\nzz\t9\t1\tx\nc2 6 1 x\n")
+    snp_reference.write_reference_snp_file(str(fa), str(sl), str(tmp_path / "o.fasta"))
+    assert (tmp_path / "o.fasta").read_text() == ">c1\nA\n>c2\nATT\n"
+    sl.write_text("c1\t4\t1\tx\n")
+    with pytest.raises(IndexError):
+        snp_reference.write_reference_snp_file(str(fa), str(sl), str(tmp_path / "o.fasta"))
