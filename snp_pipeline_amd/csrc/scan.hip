@@ -44,6 +44,7 @@ struct ScanArgs {
     uint32_t *ctl;           // [0] queue length, [1] queue overflowed
     uint32_t q_cap;
     int want_depth;
+    uint32_t share[4];       // relative tile share of a wave by its age rank on its SIMD (wave-in-block / 4)
     uint64_t *totals;        // per-wave {lines, matched, depth sum}: same-address atomics from thousands of waves
                              // serialise at ~12 ns each and stall the loads of the waves still running
     unsigned long long *dbg; // optional: per-wave timing records (tuning only)
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
         return 0;
     };
 
-    uint64_t win_base = 0xFFFFFFFFFFFFFF00ull;               // bitmap window [win_base, win_base + 64) dwords; starts empty
+    uint32_t win_base = 0xFFFFFF00u;                          // bitmap window [win_base, win_base + 64) dwords; starts empty
     uint32_t win_word = 0, win_rank = 0;
     uint16_t *lstart = ws.lstart;
     const uint32_t *hint_w = ws.hint_w;
@@ -334,8 +335,17 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     // window survive from one tile to the next.  Shares are static and equal; the launcher makes sure every CU holds
     // the same number of waves.  (Drawing work tickets from a device counter was measured and rejected: same-address
     // atomics cost ~12 ns each, device-wide, and stall the loads queued behind them.)
-    const uint64_t me = gwave - s_wave0, per = n_tiles / s_waves, rem = n_tiles % s_waves;
-    const uint64_t t_first = me * per + (me < rem ? me : rem), t_end = t_first + per + (me < rem ? 1 : 0);
+    // ... weighted by age: the SIMD issues oldest-first, so of the four waves it holds the oldest gets the most issue
+    // slots; with equal shares it finishes ~35 % before the youngest, which then runs alone at half the SIMD's rate.
+    // cum(x) = total weight of the launch's waves [0, x); a workgroup is 16 waves, wave w has age rank w / 4.
+    auto cum = [&](uint64_t x) -> uint64_t {
+        const uint32_t wpb = blockDim.x >> 6, r = (uint32_t)(x % wpb);
+        uint64_t c = 0, blk = 0;
+        for (uint32_t w = 0; w < wpb; ++w) { const uint32_t sw = a.share[(w * 4) / wpb]; blk += sw; c += w < r ? sw : 0; }
+        return (x / wpb) * blk + c;
+    };
+    const uint64_t c_lo = cum(s_wave0), c_span = cum((uint64_t)s_wave0 + s_waves) - c_lo;
+    const uint64_t t_first = n_tiles * (cum(gwave) - c_lo) / c_span, t_end = n_tiles * (cum(gwave + 1) - c_lo) / c_span;
     const uint64_t kNoTile = ~0ull;
     uint64_t tt = t_first < t_end ? t_first : kNoTile, t_nxt = t_first + 1 < t_end ? t_first + 1 : kNoTile;
     uint32_t dma_next = 0;                                    // DMA instructions in flight for the tile after the current one
@@ -360,17 +370,16 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                 if (kTime == 3) { any_hi |= tile16[lane].x; break; }   // tuning: stream only, no parsing
                 // ---- B: terminator flags of four 16-byte chunks per lane (chunk i*64+lane: conflict-free LDS reads) ----
                 // bit 16*i + b of S: byte b of chunk i*64+lane is in 0x0A..0x0D; a line starts at the next byte.
-                // Straight-line code: no branch depends on the data unless the tile holds '\v' '\f' or '\r'.
+                // Straight-line code.  That every flagged byte really is '\n' is checked on the list of line starts
+                // (one byte per line) instead of on every byte here; if one is not ('\r', '\v', '\f'), the tile is
+                // indexed again byte by byte with the universal-newline rules.
                 uint64_t S;
-                uint32_t exo = 0;                                   // 0x80 where a byte is in 0x0B..0x0D
                 {
                     uint32_t bits[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const uint4 v = tile16[i * 64 + lane];
                         any_hi |= v.x | v.y | v.z | v.w;
-                        exo |= ((v.x + 0x75757575u) & ~(v.x + 0x72727272u)) | ((v.y + 0x75757575u) & ~(v.y + 0x72727272u)) |
-                               ((v.z + 0x75757575u) & ~(v.z + 0x72727272u)) | ((v.w + 0x75757575u) & ~(v.w + 0x72727272u));
                         bits[i] = flags_to_bits16(term_flags(v.x), term_flags(v.y), term_flags(v.z), term_flags(v.w));
                     }
                     S = (uint64_t)(bits[0] | (bits[1] << 16)) | ((uint64_t)(bits[2] | (bits[3] << 16)) << 32);
@@ -380,8 +389,59 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                 if (lane == 63) S &= ~(1ull << 63);
                 const uint32_t pv0 = tile[-1], cv0 = tile[0];
                 bool s0 = (lane == 0) && (pv0 == 10u || (pv0 == 13u && cv0 != 10u));
-                if (__ballot((exo & 0x80808080u) != 0 || ((lane == 0) && (pv0 - 11u <= 2u)))) {
-                    S = 0;                                          // rare: '\r' (or '\v' '\f'): exact byte-wise index
+                uint32_t cnt, n_lines, base;
+                auto finish_index = [&]() {                         // edge tiles, per-lane counts, wave prefix sum
+                    if (edge) {                                     // starts must lie inside the file
+#pragma nounroll
+                        for (int i = 0; i < 4; ++i)
+#pragma nounroll
+                            for (int b = 0; b < 16; ++b) {
+                                const uint64_t st = t0 + (uint64_t)((i * 64 + (int)lane) * 16 + b + 1);
+                                if (st < f.lo || st >= f.hi) S &= ~(1ull << (16 * i + b));
+                            }
+                        s0 = s0 && t0 >= f.lo && t0 < f.hi;
+                    }
+                    cnt = (uint32_t)__popcll(S) + (s0 ? 1u : 0u);
+                    const uint32_t incl = wave_inclusive_sum(cnt);
+                    n_lines = __builtin_amdgcn_readlane(incl, 63);
+                    base = incl - cnt;
+                };
+                auto build_list = [&](uint32_t pass0) {
+                    // list of the line starts [pass0, pass0 + CAP): two predicated slots, a loop only for lanes
+                    // with three or more starts in their 64 bytes (lines shorter than ~21 bytes)
+                    uint64_t s_bits = S;
+                    uint32_t idx = base - pass0;                    // slots below 0 wrap to huge values and are skipped
+                    if (s0 && idx < SCAN_LIST_CAP) lstart[idx] = 0;
+                    idx += s0 ? 1u : 0u;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const uint32_t bpos = (uint32_t)__ffsll((long long)s_bits) - 1;         // 0xFFFFFFFF when empty
+                        const bool have = s_bits != 0;
+                        if (have && idx < SCAN_LIST_CAP) lstart[idx] = (uint16_t)((((bpos >> 4) * 64 + lane) << 4) + (bpos & 15) + 1);
+                        idx += have ? 1u : 0u;
+                        s_bits &= s_bits - 1;
+                    }
+                    if (__ballot(s_bits != 0)) {
+                        while (s_bits) {
+                            const uint32_t bpos = (uint32_t)__ffsll((long long)s_bits) - 1;
+                            s_bits &= s_bits - 1;
+                            if (idx < SCAN_LIST_CAP) lstart[idx] = (uint16_t)((((bpos >> 4) * 64 + lane) << 4) + (bpos & 15) + 1);
+                            ++idx;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                };
+                finish_index();
+                bool redo = n_lines > SCAN_LIST_CAP || __ballot((lane == 0) && (pv0 - 11u <= 2u)) != 0;
+                if (!redo) {
+                    build_list(0);
+                    bool odd = false;                               // a start that does not follow a '\n'
+                    for (uint32_t j = lane; j < n_lines; j += 64) odd = odd || tile[(int)lstart[j] - 1] != 10u;
+                    redo = __ballot(odd) != 0;
+                }
+                const bool listed = !redo;                          // the list of pass 0 is already in LDS
+                if (redo) {
+                    S = 0;                                          // rare: exact byte-wise index
 #pragma nounroll
                     for (int i = 0; i < 4; ++i)
 #pragma nounroll
@@ -391,48 +451,13 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             if (cv == 10u || (cv == 13u && nx != 10u)) S |= 1ull << (16 * i + b);
                         }
                     if (lane == 63) S &= ~(1ull << 63);
+                    s0 = (lane == 0) && (pv0 == 10u || (pv0 == 13u && cv0 != 10u));
+                    finish_index();
                 }
-                if (edge) {                                         // starts must lie inside the file
-#pragma nounroll
-                    for (int i = 0; i < 4; ++i)
-#pragma nounroll
-                        for (int b = 0; b < 16; ++b) {
-                            const uint64_t st = t0 + (uint64_t)((i * 64 + (int)lane) * 16 + b + 1);
-                            if (st < f.lo || st >= f.hi) S &= ~(1ull << (16 * i + b));
-                        }
-                    s0 = s0 && t0 >= f.lo && t0 < f.hi;
-                }
-                const uint32_t cnt = (uint32_t)__popcll(S) + (s0 ? 1u : 0u);
-                const uint32_t incl = wave_inclusive_sum(cnt);
-                const uint32_t n_lines = __builtin_amdgcn_readlane(incl, 63);
-                const uint32_t base = incl - cnt;
                 lines_seen += (lane == 0) ? n_lines : 0;
 
                 for (uint32_t pass0 = 0; pass0 < n_lines; pass0 += SCAN_LIST_CAP) {
-                    {   // list of the line starts [pass0, pass0 + CAP): two predicated slots, a loop only for lanes
-                        // with three or more starts in their 64 bytes (lines shorter than ~21 bytes)
-                        uint64_t s_bits = S;
-                        uint32_t idx = base - pass0;                // slots below 0 wrap to huge values and are skipped
-                        if (s0 && idx < SCAN_LIST_CAP) lstart[idx] = 0;
-                        idx += s0 ? 1u : 0u;
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) {
-                            const uint32_t bpos = (uint32_t)__ffsll((long long)s_bits) - 1;     // 0xFFFFFFFF when empty
-                            const bool have = s_bits != 0;
-                            if (have && idx < SCAN_LIST_CAP) lstart[idx] = (uint16_t)((((bpos >> 4) * 64 + lane) << 4) + (bpos & 15) + 1);
-                            idx += have ? 1u : 0u;
-                            s_bits &= s_bits - 1;
-                        }
-                        if (__ballot(s_bits != 0)) {
-                            while (s_bits) {
-                                const uint32_t bpos = (uint32_t)__ffsll((long long)s_bits) - 1;
-                                s_bits &= s_bits - 1;
-                                if (idx < SCAN_LIST_CAP) lstart[idx] = (uint16_t)((((bpos >> 4) * 64 + lane) << 4) + (bpos & 15) + 1);
-                                ++idx;
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
+                    if (!listed || pass0 != 0) build_list(pass0);
                     const uint32_t n_here = n_lines - pass0 < SCAN_LIST_CAP ? n_lines - pass0 : SCAN_LIST_CAP;
                     if (!kExact) {
                     // ---- C: one lane per line ------------------------------------------------------------------
@@ -485,23 +510,21 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             // position sorted, so a window (2048 positions) serves ~40 tiles before it is refilled
                             // with two coalesced 256-byte loads.  Lookup = ds_bpermute (cross-lane, no LDS memory).
                             const uint64_t bit = h_off + (uint32_t)pos;
-                            const uint64_t wi = bit >> 5;
+                            const uint32_t wi = (uint32_t)(bit >> 5);                   // < n_words, which fits 32 bits
                             uint32_t word = 0, rk = 0;
                             bool done = !probe;
                             for (;;) {
-                                const uint64_t rel = wi - win_base;
-                                const int sel = (int)(((uint32_t)rel & 63u) << 2);
+                                const uint32_t rel = wi - win_base;
+                                const int sel = (int)((rel & 63u) << 2);
                                 const uint32_t w_ = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)win_word);
                                 const uint32_t r_ = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)win_rank);
                                 if (!done && rel < 64) { word = w_; rk = r_; done = true; }
                                 const uint64_t miss = __ballot(!done);
                                 if (!miss) break;
-                                const uint32_t src = (uint32_t)__ffsll((long long)miss) - 1;
-                                win_base = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(wi >> 32), src) << 32) |
-                                           __builtin_amdgcn_readlane((uint32_t)wi, src);
-                                const bool inb = win_base + lane < ss.n_words;
-                                win_word = inb ? bitmap[win_base + lane] : 0u;
-                                win_rank = inb ? rank[win_base + lane] : 0u;
+                                win_base = __builtin_amdgcn_readlane(wi, (uint32_t)__ffsll((long long)miss) - 1);
+                                const bool inb = (uint64_t)win_base + lane < ss.n_words;
+                                win_word = inb ? bitmap[(uint64_t)win_base + lane] : 0u;
+                                win_rank = inb ? rank[(uint64_t)win_base + lane] : 0u;
                             }
                             const uint32_t shf = (uint32_t)(bit & 31);
                             if ((word >> shf) & 1u) {
@@ -646,8 +669,14 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<S
     const uint32_t n = (uint32_t)h_samples.size();
     if (!n) return SNPGPU_OK;
     static int blocks_per_cu = -1, mode = 0, waves = 16;
+    static int share[4] = {329, 282, 223, 169};            // measured: 1 / (finish time with equal shares), oldest first
     if (blocks_per_cu < 0) {                                // tuning knobs (development only)
         const char *b = getenv("SNPGPU_SCAN_BLOCKS_PER_CU"), *m = getenv("SNPGPU_SCAN_MODE"), *w = getenv("SNPGPU_SCAN_WAVES");
+        if (const char *sh = getenv("SNPGPU_SCAN_SHARE")) {
+            int v[4];
+            if (sscanf(sh, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0)
+                for (int g = 0; g < 4; ++g) share[g] = v[g];
+        }
         blocks_per_cu = b && atoi(b) > 0 && atoi(b) <= 2 ? atoi(b) : 1;
         mode = m ? atoi(m) : 0;
         if (w && atoi(w) >= 1 && atoi(w) <= 16) waves = atoi(w);
@@ -706,6 +735,7 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<S
     sa.n_sites = ss->n_sites;
     sa.site_line = d_site_line;
     sa.want_depth = want_depth;
+    for (int g = 0; g < 4; ++g) sa.share[g] = (waves == 16 && blocks_per_cu == 1) ? (uint32_t)share[g] : 1u;
     sa.queue = ss->slow_queue;
     sa.q_cap = SNPGPU_SLOW_QUEUE_CAP - 65536;               // the tail holds the tuning modes' per-wave records
     sa.ctl = ss->slow_ctl;
