@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--dist-reps", type=int, default=2)
     ap.add_argument("--cpu-samples", type=int, default=3, help="samples timed on the CPU oracle (0 = skip)")
     ap.add_argument("--skip-secondary", action="store_true")
+    ap.add_argument("--skip-aux", action="store_true", help="skip the device-copy ceiling and the K3/K4 timings")
     return ap.parse_args()
 
 
@@ -236,6 +237,48 @@ def main():
             "valu_frac_of_peak": (pairs * s2 / 32 * 6 / el2) / valu_peak,
         }
         del pk, dm
+
+    # ---- context figures (rank 0, N = 1): a measured device-copy ceiling and the small latency-bound steps ------------
+    if rank == 0 and world == 1 and not args.skip_aux:
+        src = torch.empty(1 << 28, dtype=torch.int32, device="cuda")
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        copy_s = (time.perf_counter() - t1) / 5
+        del src, dst
+        out["roofline"]["measured_copy_gbps_read_plus_write"] = 2 * (1 << 30) / copy_s / 1e9
+        # K3 / K4 at configs[3] scale: 1000 samples x ~1500 phase-1 SNP records each (host buffers in, host buffers out)
+        arng = np.random.default_rng(5)
+        n_s, per = 1000, 1500
+        samp_pos = [np.sort(arng.choice(pos, size=per, replace=False)) for _ in range(n_s)]
+        keys = np.concatenate(samp_pos).astype(np.uint64)              # contig 0
+        who = np.repeat(np.arange(n_s, dtype=np.uint32), per)
+        d.merge_sites(keys[:1000], who[:1000])                        # warm-up
+        t1 = time.perf_counter()
+        uniq, off_, car = d.merge_sites(keys, who)
+        t_merge = time.perf_counter() - t1
+        seg = np.arange(0, n_s * per + 1, per, dtype=np.uint32)
+        t1 = time.perf_counter()
+        ws_, we_, wg_ = d.dense_windows(keys.astype(np.int64), seg, [3, 2, 1], [1000, 125, 15])
+        t_dense = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        rg, rs_, re_ = d.merge_regions(np.zeros(len(ws_), np.uint32), ws_, we_)
+        t_mreg = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        inside = d.in_regions(np.zeros(len(keys), np.uint32), keys.astype(np.int64), [0, len(rs_)], rs_, re_)
+        t_inreg = time.perf_counter() - t1
+        out["aux_steps_ms"] = {
+            "workload": "%d samples x %d SNP records each, one contig of %d bp" % (n_s, per, G),
+            "merge_sites_union_and_carriers": t_merge * 1e3, "unique_sites": int(len(uniq)),
+            "dense_windows_3_rules": t_dense * 1e3, "windows": int(len(ws_)),
+            "merge_regions": t_mreg * 1e3, "regions": int(len(rs_)),
+            "in_regions": t_inreg * 1e3, "records_in_a_region": int(inside.sum()),
+            "note": "wall time of the host-buffer entry points (H2D + kernels + D2H); latency-bound, reported for completeness",
+        }
 
     # ---- CPU baseline: the oracle on the first samples of the batch, one core, rank 0, N = 1 ---------------------
     if rank == 0 and world == 1 and args.cpu_samples > 0:
