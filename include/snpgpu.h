@@ -163,7 +163,8 @@ int  snpgpu_siteset_line_offsets(snpgpu_ctx *ctx, const snpgpu_siteset *ss, uint
  *      (distance.py:93-98) ----------------------------------------------------------------------
  * The samples x sites matrix is packed 4 bits per site, planar per 32-site word:
  *   packed[row][word] = uint32[4] { valid (upper(c) in ACGT), code bit1, code bit0, lower-case flag }
- * with A=0 C=1 G=2 T=3.  words = ceil(n_sites / 32). */
+ * with A=0 C=1 G=2 T=3.  A row holds ceil(n_sites / 32) words rounded up to a multiple of 4 (64 bytes); the padding
+ * words are all zero (no valid site).  snpgpu_packed_row_bytes() is the row pitch. */
 size_t snpgpu_packed_row_bytes(uint32_t n_sites);
 int  snpgpu_pack_matrix_dev(snpgpu_ctx *ctx, const uint8_t *d_symbols, uint32_t n_rows, uint32_t n_sites,
                             size_t row_stride, void *d_packed);

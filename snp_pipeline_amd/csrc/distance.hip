@@ -6,16 +6,21 @@
 //
 // Packed layout (HBM): packed[row][word] = uint4 { valid, code_hi, code_lo, lower } for 32 consecutive sites,
 // bit i = site 32*word + i;  A=0 C=1 G=2 T=3.  Per pair and word:
-//      mismatches += popcount( ((xh ^ yh) | (xl ^ yl)) & xv & yv )            (6 VALU ops per 32 site-compares)
-// This is integer VALU + LDS work (no MFMA): a 128x128 block of pairs per workgroup, 8x8 pairs per lane,
-// operands staged through LDS in slabs of DIST_KW words.
+//      mismatches += popcount( ((xh ^ yh) | (xl ^ yl)) & xv & yv )
+// which gfx950 does in 4 VALU ops per 32 site-compares (v_xor, 2 x v_bitop3, v_bcnt).  A row is padded with zero words
+// to a multiple of DIST_KW words.  This is integer VALU + LDS work (no MFMA): a 128x128 block of pairs per workgroup,
+// 8x8 pairs per lane; slabs of DIST_KW words of both operands stream into a double-buffered LDS area with LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no LDS store instructions) one slab ahead of the arithmetic, one
+// barrier per slab.  Slot s of row r holds word s ^ ((r >> 2) & 3) of the slab, which makes the 16 rows a wave reads at
+// once fall into 16 different bank groups.
 #include "internal.h"
 
 #define DIST_TILE 128
-#define DIST_KW 8
+#define DIST_KW 4                // words (of 32 sites) per slab
 #define DIST_THREADS 256
 
-extern "C" size_t snpgpu_packed_row_bytes(uint32_t n_sites) { return (size_t)((n_sites + 31) / 32) * 16; }
+static inline uint32_t padded_words(uint32_t n_sites) { return ((n_sites + 31) / 32 + DIST_KW - 1) / DIST_KW * DIST_KW; }
+extern "C" size_t snpgpu_packed_row_bytes(uint32_t n_sites) { return (size_t)padded_words(n_sites) * 16; }
 
 // One wavefront packs 64 consecutive sites of one row: coalesced byte loads, four ballots.
 __global__ __launch_bounds__(256) void k_pack_matrix(const uint8_t *sym, uint32_t n_rows, uint32_t n_sites, size_t stride,
@@ -68,16 +73,17 @@ __device__ __forceinline__ void tile_coords(uint64_t t, uint32_t nt, uint32_t &b
 // kSplit: a few tiles only (small sample counts): every tile is shared by k_parts workgroups, each sums its range of
 // words and adds it to the (zeroed) output with integer atomics — the result does not depend on the order.
 template <bool kSplit>
-__global__ __launch_bounds__(DIST_THREADS) void k_distance(DistArgs a) {
-    __shared__ uint4 xs[DIST_KW][DIST_TILE];
-    __shared__ uint4 ys[DIST_KW][DIST_TILE];
+__global__ __launch_bounds__(DIST_THREADS, 3) void k_distance(DistArgs a) {
+    // [buffer][operand][row][slot]; a wave's 64 DMA lanes fill 64 consecutive 16-byte slots
+    __shared__ uint4 slab[2][2][DIST_TILE][DIST_KW];
     const uint32_t tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (uint64_t gg = blockIdx.x;; gg += gridDim.x) {
         const uint64_t g = kSplit ? gg / a.k_parts : gg;
         const uint32_t part = kSplit ? (uint32_t)(gg % a.k_parts) : 0;
         uint64_t t = (uint64_t)a.tile_rank + g * a.tile_nranks;
         if (t >= a.total_tiles) break;
-        const uint32_t k_begin = kSplit ? part * a.k_chunk : 0;
+        const uint32_t k_begin = kSplit ? part * a.k_chunk : 0;                      // multiples of DIST_KW
         const uint32_t k_end = kSplit ? (k_begin + a.k_chunk < a.words ? k_begin + a.k_chunk : a.words) : a.words;
         uint32_t bi, bj;
         tile_coords(t, a.n_tiles, bi, bj);
@@ -88,36 +94,48 @@ __global__ __launch_bounds__(DIST_THREADS) void k_distance(DistArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = 0;
 
-        for (uint32_t k0 = k_begin; k0 < k_end; k0 += DIST_KW) {
-            __syncthreads();
-            // stage 128 rows x DIST_KW words of both operands: consecutive lanes walk the words of a row
+        // DMA: chunk p = e * 256 + tid of an operand's slab is slot (p & 3) of row (p >> 2).  Rows past the matrix read
+        // the last row instead (their pairs are never stored).
+        uint32_t row_of[2][DIST_TILE * DIST_KW / DIST_THREADS], kk_of[DIST_TILE * DIST_KW / DIST_THREADS];
 #pragma unroll
-            for (int e = 0; e < DIST_TILE * DIST_KW / DIST_THREADS; ++e) {
-                uint32_t idx = e * DIST_THREADS + tid;
-                uint32_t kk = idx % DIST_KW, rr = idx / DIST_KW;
-                uint32_t w = k0 + kk;
-                uint4 zx = make_uint4(0, 0, 0, 0), zy = zx;
-                if (w < k_end) {
-                    if (r0 + rr < a.n) zx = a.packed[(size_t)(r0 + rr) * a.words + w];
-                    if (c0 + rr < a.n) zy = a.packed[(size_t)(c0 + rr) * a.words + w];
+        for (int e = 0; e < DIST_TILE * DIST_KW / DIST_THREADS; ++e) {
+            const uint32_t p = e * DIST_THREADS + tid, rr = p >> 2;
+            kk_of[e] = (p & 3u) ^ ((rr >> 2) & 3u);
+            row_of[0][e] = r0 + rr < a.n ? r0 + rr : a.n - 1;
+            row_of[1][e] = c0 + rr < a.n ? c0 + rr : a.n - 1;
+        }
+        auto request = [&](uint32_t k0, int buf) {
+#pragma unroll
+            for (int op = 0; op < 2; ++op)
+#pragma unroll
+                for (int e = 0; e < DIST_TILE * DIST_KW / DIST_THREADS; ++e) {
+                    const uint4 *gp = a.packed + ((size_t)row_of[op][e] * a.words + (k0 + kk_of[e]));
+                    const uint32_t m0v = __builtin_amdgcn_readfirstlane(
+                        (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)&slab[buf][op][0][0]) + (e * DIST_THREADS + wave * 64) * 16);
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m0v) : "memory");
                 }
-                xs[kk][rr] = zx;
-                ys[kk][rr] = zy;
-            }
-            __syncthreads();
+        };
+        __syncthreads();                                            // the previous tile's last slab has been read
+        request(k_begin, 0);
+        int buf = 0;
+        for (uint32_t k0 = k_begin; k0 < k_end; k0 += DIST_KW, buf ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // my part of this slab has landed ...
+            __syncthreads();                                        // ... everybody's has, and slab k0 - KW has been read
+            if (k0 + DIST_KW < k_end) request(k0 + DIST_KW, buf ^ 1);
 #pragma unroll
             for (int kk = 0; kk < DIST_KW; ++kk) {
                 uint4 x[8], y[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] = xs[kk][ty + 16 * i];
+                for (int i = 0; i < 8; ++i) { const uint32_t r = ty + 16 * i; x[i] = slab[buf][0][r][kk ^ ((r >> 2) & 3u)]; }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) y[j] = ys[kk][tx + 16 * j];
+                for (int j = 0; j < 8; ++j) { const uint32_t c = tx + 16 * j; y[j] = slab[buf][1][c][kk ^ ((c >> 2) & 3u)]; }
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        uint32_t d = ((x[i].y ^ y[j].y) | (x[i].z ^ y[j].z)) & x[i].x & y[j].x;
-                        acc[i][j] += __popc(d);
+                        // ((xh ^ yh) | (xl ^ yl)) & xv & yv as v_xor + two 3-input bit ops (truth tables 0xBE, 0x80)
+                        const uint32_t u = __builtin_amdgcn_bitop3_b32(x[i].y, y[j].y, x[i].z ^ y[j].z, 0xBE);
+                        acc[i][j] += __popc(__builtin_amdgcn_bitop3_b32(u, x[i].x, y[j].x, 0x80));
                     }
             }
         }
@@ -165,7 +183,7 @@ int snpgpu_pack_matrix_dev(snpgpu_ctx *ctx, const uint8_t *d_symbols, uint32_t n
     if (n_rows == 0 || n_sites == 0) return SNPGPU_OK;
     if (!d_symbols || !d_packed || row_stride < n_sites) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "bad pack arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    uint32_t words = (n_sites + 31) / 32;
+    uint32_t words = padded_words(n_sites);                 // the padding words come out all zero (no valid site)
     uint64_t groups = (uint64_t)n_rows * ((words + 1) / 2);
     uint64_t blocks = (groups + 3) / 4, cap = (uint64_t)ctx->n_cu * 32;
     k_pack_matrix<<<(unsigned)(blocks < cap ? blocks : cap), 256, 0, ctx->stream>>>(d_symbols, n_rows, n_sites, row_stride, (uint4 *)d_packed, words);
@@ -183,7 +201,7 @@ int snpgpu_distance_packed_dev(snpgpu_ctx *ctx, const void *d_packed, uint32_t n
     DistArgs a;
     a.packed = (const uint4 *)d_packed;
     a.n = n_rows;
-    a.words = (n_sites + 31) / 32;
+    a.words = padded_words(n_sites);
     a.n_tiles = (n_rows + DIST_TILE - 1) / DIST_TILE;
     a.tile_rank = tile_rank;
     a.tile_nranks = tile_nranks;
