@@ -395,3 +395,51 @@ def test_full_size_samples_properties_and_spot_check(d):
                                sizes=np.asarray(sizes, dtype=np.uint64))
     torch.cuda.synchronize()
     assert torch.equal(b3, bases) and torch.equal(f3, filt)
+
+
+def test_batch_groups_empty_and_tiny_samples(d):
+    """More samples than one scan launch takes (groups of 256), with empty, one-line and unterminated samples mixed in,
+    at odd offsets inside one buffer: every row equals the per-sample host call and the oracle."""
+    import torch
+    from snp_pipeline_amd import device as dev
+    rng = random.Random(77)
+    base, _, sites = fuzz.synth_pileup(41, genome_len=400, n_sites=25)
+    keys = sorted(sites)
+    lines = base.split(b"\n")[:-1]
+    samples = []
+    for i in range(300):
+        kind = i % 6
+        if kind == 0:
+            samples.append(b"")
+        elif kind == 1:
+            samples.append(rng.choice(lines) + b"\n")
+        elif kind == 2:
+            samples.append(b"\n".join(rng.sample(lines, 40)))               # no terminator at the end of the file
+        else:
+            pick = sorted(rng.sample(range(len(lines)), rng.randint(50, len(lines))))
+            samples.append(b"\n".join(lines[j] for j in pick) + b"\n")
+    p = po.CallerParams(0, 0.6, 3, 0, 0.0)
+    prm = dev.make_params(p.min_base_quality, p.min_cons_freq, p.min_cons_depth, p.min_cons_strand_depth, p.min_cons_strand_bias)
+    ss = d.siteset(keys, [1] * len(keys))
+    offs, blob = [], bytearray()
+    for sm in samples:
+        blob += b"Z" * rng.randint(0, 5)                                     # junk between samples, odd alignment
+        offs.append(len(blob))
+        blob += sm
+    blob += b"ZZZZ"
+    t = torch.from_numpy(np.frombuffer(bytes(blob), dtype=np.uint8).copy()).cuda()
+    n, S = len(samples), len(keys)
+    bases = torch.zeros((n, S), dtype=torch.uint8, device="cuda")
+    filt = torch.zeros((n, S), dtype=torch.uint8, device="cuda")
+    status = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    d.use_torch_stream()
+    d.call_consensus_batch_dev(ss, t.data_ptr(), np.asarray(offs, dtype=np.uint64), prm, bases.data_ptr(), filt.data_ptr(),
+                               status.data_ptr(), sizes=np.asarray([len(sm) for sm in samples], dtype=np.uint64))
+    torch.cuda.synchronize()
+    bh, st = bases.cpu().numpy(), status.cpu().numpy()
+    order = [ss.index_of[i] for i in range(S)]
+    for i, sm in enumerate(samples):
+        want, _ = po.call_consensus_sites(sm, keys, set(), p)
+        got = bytes(int(bh[i, j]) for j in order)
+        assert got == want, i
+        assert st[i, 0] == -1 and st[i, 1] == len(list(po.iter_lines(sm))), i
