@@ -75,6 +75,7 @@ struct WaveSlots {
     uint16_t lstart[SCAN_LIST_CAP];
     uint32_t hint_w[SCAN_HINT_WORDS];        // the wave's current contig name, zero padded
     uint32_t hint_m[SCAN_HINT_WORDS];        // byte masks of the name (zero past its end)
+    uint32_t lay[16];                        // scan_layout() of the current (name, digit count)
 };
 struct ScanShared {                          // dynamic LDS: the table, then one WaveSlots per wave of the workgroup
     uint4 digit_mask[16];                    // [nd]: keeps the last nd bytes of window bytes 4..14
@@ -188,6 +189,41 @@ __device__ __forceinline__ void lds_window16(const uint8_t *tile, int off, uint3
     o1 = __builtin_amdgcn_alignbyte(a2, a1, sh);
     o2 = __builtin_amdgcn_alignbyte(a3, a2, sh);
     o3 = __builtin_amdgcn_alignbyte(a4, a3, sh);
+}
+
+// 24 bytes of LDS starting at any byte offset (may be negative), as six dwords
+__device__ __forceinline__ void lds_window24(const uint8_t *tile, int off, uint32_t (&o)[6]) {
+    const uint32_t *pw = (const uint32_t *)(tile + (off & ~3));
+    uint32_t a[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) a[k] = pw[k];
+    const uint32_t sh = (uint32_t)off & 3u;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = __builtin_amdgcn_alignbyte(a[k + 1], a[k], sh);
+}
+
+// What the one-window parse expects to see in the 24 bytes that END with the separator after the position, for a contig
+// name of L bytes and positions of g digits:  [.. junk ..][name, L][sep][digits, g][sep].  lay[0..5] name bytes in place,
+// lay[6..11] their byte masks, lay[12..14] byte masks of the digits in dwords 3..5.  One lane per dword.
+__device__ __noinline__ void scan_layout(uint32_t *lay, const uint32_t *hint_w, uint32_t L, uint32_t g, uint32_t lane) {
+    if (lane < 6) {
+        uint32_t w = 0, m = 0;
+        for (uint32_t k = 0; k < L; ++k) {
+            const uint32_t b = 22u - g - L + k;                   // window byte of name byte k
+            if ((b >> 2) == lane) {
+                w |= ((hint_w[k >> 2] >> (8 * (k & 3))) & 0xFFu) << (8 * (b & 3));
+                m |= 0xFFu << (8 * (b & 3));
+            }
+        }
+        lay[lane] = w;
+        lay[6 + lane] = m;
+    }
+    if (lane < 3) {
+        uint32_t m = 0;
+        for (uint32_t b = 23u - g; b <= 22u; ++b)
+            if ((b >> 2) == lane + 3) m |= 0xFFu << (8 * (b & 3));
+        lay[12 + lane] = m;
+    }
 }
 
 // Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (no LDS traffic).
@@ -329,6 +365,21 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
             hm[k] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
         }
     };
+    // One-window parse: positions of a sorted pileup have the same number of digits g for long stretches, so with the
+    // name length L known the whole "name SEP digits SEP" prefix sits at a fixed place in the 24 bytes that end with the
+    // second separator.  A line whose position has another digit count fails the separator / digit tests (exactly: the
+    // tests pass iff the count is g), goes to the queue, and resets g; the general path then recalibrates it.
+    uint32_t g = 0, nw[6] = {0, 0, 0, 0, 0, 0}, nm[6] = {0, 0, 0, 0, 0, 0}, dmk[3] = {0, 0, 0};
+    bool fastc = false;
+    auto relayout = [&]() {
+        fastc = hint_bad == 0 && g >= 1 && g <= 10 && L + g + 2 <= 24;
+        if (!fastc) return;
+        scan_layout(ws.lay, ws.hint_w, L, g, lane);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { nw[k] = ws.lay[k]; nm[k] = ws.lay[6 + k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dmk[k] = ws.lay[12 + k];
+    };
     if (!kExact) adopt(load_hint(ss, 0, ws.hint_w, lane));
 
     // Every wave takes one contiguous run of its sample's tiles: a pileup is sorted, so the contig hint and the bitmap
@@ -469,7 +520,34 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             const uint32_t j = j0 + lane;
                             const bool active = j < n_here;
                             const uint32_t s = active ? lstart[j] : 0u;
-                            uint32_t bad = hint_bad;                                     // uniform: no usable hint
+                            uint32_t bad, c1, pos;
+                            bool big;
+                            uint32_t nd_seen = 0;                                        // digits of this line's position (0: unknown)
+                            const bool fast_round = fastc;
+                            if (fast_round) {
+                                uint32_t w[6];
+                                lds_window24(tile, (int)s + (int)(L + g) - 22, w);       // ends with the second separator
+                                c1 = tile[s + L];                                        // the separator after the name
+                                bad = ((w[0] ^ nw[0]) & nm[0]) | ((w[1] ^ nw[1]) & nm[1]) | ((w[2] ^ nw[2]) & nm[2]) |
+                                      ((w[3] ^ nw[3]) & nm[3]) | ((w[4] ^ nw[4]) & nm[4]) | ((w[5] ^ nw[5]) & nm[5]);
+                                const uint32_t sep1 = min(c1 ^ 9u, c1 ^ 32u);
+                                if (active && (bad | sep1) != 0) mismatch_at = s;        // another contig?
+                                else if (active) nd_seen = g;
+                                const uint32_t c2 = w[5] >> 24;
+                                bad |= sep1 | min(min(c2 ^ 9u, c2 ^ 32u), c2 ^ 10u);
+                                const uint32_t x3 = (w[3] ^ 0x30303030u) & dmk[0], x4 = (w[4] ^ 0x30303030u) & dmk[1], x5 = (w[5] ^ 0x30303030u) & dmk[2];
+                                bad |= (((x3 + 0x76767676u) | x3) | ((x4 + 0x76767676u) | x4) | ((x5 + 0x76767676u) | x5)) & 0x80808080u;
+                                // decimal value: v_dot4_u32_u8 with weights 100, 10, 1 over three digits, the fourth added on top
+                                // (24-bit multiplies: v_mad_u32_u24 is full rate, the 32-bit multiplies are quarter rate)
+                                const uint32_t f3 = __umul24(__builtin_amdgcn_udot4(x3, 0x00010A64u, 0u, false), 10u) + (x3 >> 24);
+                                const uint32_t f4 = __umul24(__builtin_amdgcn_udot4(x4, 0x00010A64u, 0u, false), 10u) + (x4 >> 24);
+                                const uint32_t hi7 = __umul24(f3, 10000u) + f4;          // the first g - 3 digits (< 10^7)
+                                // positions past 2^32 - 1 cannot be in the site set: 4294966 * 1000 + 999 still fits 32 bits
+                                big = hi7 > 4294966u;
+                                pos = __umul24(hi7, 1000u) + __builtin_amdgcn_udot4(x5, 0x00010A64u, 0u, false);
+                                if (__ballot(active && bad != 0 && nd_seen != 0)) { g = 0; fastc = false; }   // a digit count changed
+                            } else {
+                            bad = hint_bad;                                              // uniform: no usable hint
                             // name: masked dword compare (masks are zero past the name)
                             uint32_t w0, w1, w2, w3;
                             lds_window16(tile, (int)s, w0, w1, w2, w3);
@@ -481,7 +559,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                 lds_window16(tile, (int)s + 32, v0, v1, v2, v3);
                                 bad |= ((v0 ^ hint_w[8]) & hint_m[8]) | ((v1 ^ hint_w[9]) & hint_m[9]) | ((v2 ^ hint_w[10]) & hint_m[10]) | ((v3 ^ hint_w[11]) & hint_m[11]);
                             }
-                            const uint32_t c1 = tile[s + L];                             // the separator after the name
+                            c1 = tile[s + L];                                            // the separator after the name
                             if (active && (bad | min(c1 ^ 9u, c1 ^ 32u)) != 0) mismatch_at = s;    // another contig?
                             uint4 q1;
                             lds_window16(tile, (int)(s + L + 1), q1.x, q1.y, q1.z, q1.w);       // digits + separator
@@ -498,18 +576,22 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             bad |= min(c1 ^ 9u, c1 ^ 32u) | min(min(c2 ^ 9u, c2 ^ 32u), c2 ^ 10u);
                             const uint32_t x1 = (q.y ^ 0x30303030u) & dm.x, x2 = (q.z ^ 0x30303030u) & dm.y, x3 = (q.w ^ 0x30303030u) & dm.z;
                             bad |= (((x1 + 0x76767676u) | x1) | ((x2 + 0x76767676u) | x2) | ((x3 + 0x76767676u) | x3)) & 0x80808080u;
-                            const uint64_t pos = ((uint64_t)(four_digits(x1) * 10000u + four_digits(x2))) * 1000ull + four_digits(x3 << 8);
+                            const uint64_t pos64 = ((uint64_t)(four_digits(x1) * 10000u + four_digits(x2))) * 1000ull + four_digits(x3 << 8);
+                            big = pos64 > 0xFFFFFFFFull;
+                            pos = (uint32_t)pos64;
+                            nd_seen = bad == 0 ? nd : 0u;
+                            }
                             const uint64_t off1 = t0 + (uint64_t)s - f.lo + 1;
                             if (active && bad != 0) {                                    // rare: leave it to k_scan_queue
                                 const uint32_t qi = atomicAdd(&a.ctl[0], 1u);
                                 if (qi < a.q_cap) a.queue[qi] = f.sample | (off1 - 1); else a.ctl[1] = 1u;
                             }
-                            const bool probe = active && bad == 0 && hint_present && pos <= (uint64_t)h_max;
+                            const bool probe = active && bad == 0 && hint_present && !big && pos <= h_max;
                             // Site bitmap probe without touching memory: the wave keeps a 64-dword window of the
                             // bitmap (and of its rank directory) in two VGPRs, one dword per lane; a pileup is
                             // position sorted, so a window (2048 positions) serves ~40 tiles before it is refilled
                             // with two coalesced 256-byte loads.  Lookup = ds_bpermute (cross-lane, no LDS memory).
-                            const uint64_t bit = h_off + (uint32_t)pos;
+                            const uint64_t bit = h_off + pos;
                             const uint32_t wi = (uint32_t)(bit >> 5);                   // < n_words, which fits 32 bits
                             uint32_t word = 0, rk = 0;
                             bool done = !probe;
@@ -525,12 +607,20 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                 const bool inb = (uint64_t)win_base + lane < ss.n_words;
                                 win_word = inb ? bitmap[(uint64_t)win_base + lane] : 0u;
                                 win_rank = inb ? rank[(uint64_t)win_base + lane] : 0u;
+                                // consume the two loads here: otherwise hipcc waits for them at the top of the loop with
+                                // vmcnt(0) on every round, which also waits for the next tile's LDS-DMA it knows nothing of
+                                asm volatile("" : "+v"(win_word), "+v"(win_rank));
                             }
                             const uint32_t shf = (uint32_t)(bit & 31);
                             if ((word >> shf) & 1u) {
                                 const uint32_t site = rk + __popc(word & ((1u << shf) - 1u));
                                 atomicMax((unsigned long long *)&f.site_line[site], (unsigned long long)off1);
                                 ++hits;
+                            }
+                            if (!fast_round) {                                           // the general path calibrates the digit count
+                                const uint64_t okm = __ballot(active && nd_seen != 0);
+                                const uint32_t g_new = okm ? __builtin_amdgcn_readlane(nd_seen, (uint32_t)__ffsll((long long)okm) - 1) : 0u;
+                                if (g_new != g) { g = g_new; relayout(); }
                             }
                         }
                     }
@@ -567,6 +657,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                     if (len >= 1 && len <= 4 * SCAN_HINT_WORDS - 4) {
                         TileView tv{tile, f.base, t0, f.hi, (int64_t)(SCAN_TILE + SCAN_HALO)};
                         const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, (int64_t)s1, len) : 0xFFFFFFFFu;
+                        g = 0; fastc = false;                        // the next round calibrates against the new name
                         if (cid != 0xFFFFFFFFu) adopt(load_hint(ss, cid, ws.hint_w, lane));
                         else {                                       // not a contig of the site set: remember the name itself
                             if (lane < SCAN_HINT_WORDS) {
