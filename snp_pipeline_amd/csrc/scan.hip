@@ -523,7 +523,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             uint32_t bad, c1, pos;
                             bool big;
                             uint32_t nd_seen = 0;                                        // digits of this line's position (0: unknown)
-                            const bool fast_round = fastc;
+                            const bool fast_round = __builtin_amdgcn_readfirstlane((uint32_t)fastc) != 0;    // wave-uniform: a scalar branch
                             if (fast_round) {
                                 uint32_t w[6];
                                 lds_window24(tile, (int)s + (int)(L + g) - 22, w);       // ends with the second separator
@@ -593,24 +593,29 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             // with two coalesced 256-byte loads.  Lookup = ds_bpermute (cross-lane, no LDS memory).
                             const uint64_t bit = h_off + pos;
                             const uint32_t wi = (uint32_t)(bit >> 5);                   // < n_words, which fits 32 bits
-                            uint32_t word = 0, rk = 0;
-                            bool done = !probe;
-                            for (;;) {
-                                const uint32_t rel = wi - win_base;
-                                const int sel = (int)((rel & 63u) << 2);
-                                const uint32_t w_ = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)win_word);
-                                const uint32_t r_ = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)win_rank);
-                                if (!done && rel < 64) { word = w_; rk = r_; done = true; }
-                                const uint64_t miss = __ballot(!done);
-                                if (!miss) break;
-                                win_base = __builtin_amdgcn_readlane(wi, (uint32_t)__ffsll((long long)miss) - 1);
-                                const bool inb = (uint64_t)win_base + lane < ss.n_words;
-                                win_word = inb ? bitmap[(uint64_t)win_base + lane] : 0u;
-                                win_rank = inb ? rank[(uint64_t)win_base + lane] : 0u;
-                                // consume the two loads here: otherwise hipcc waits for them at the top of the loop with
-                                // vmcnt(0) on every round, which also waits for the next tile's LDS-DMA it knows nothing of
-                                asm volatile("" : "+v"(win_word), "+v"(win_rank));
+                            uint32_t rel = wi - win_base;
+                            uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rel & 63u) << 2), (int)win_word);
+                            uint32_t rk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rel & 63u) << 2), (int)win_rank);
+                            bool got = probe && rel < 64;
+                            if (__ballot(probe && rel >= 64)) {                         // rare: some lane is outside the window
+                                bool done = got || !probe;
+                                for (;;) {
+                                    const uint64_t miss = __ballot(!done);
+                                    if (!miss) break;
+                                    win_base = __builtin_amdgcn_readlane(wi, (uint32_t)__ffsll((long long)miss) - 1);
+                                    const bool inb = (uint64_t)win_base + lane < ss.n_words;
+                                    win_word = inb ? bitmap[(uint64_t)win_base + lane] : 0u;
+                                    win_rank = inb ? rank[(uint64_t)win_base + lane] : 0u;
+                                    // consume the two loads here: otherwise hipcc waits for them at the top of the loop with
+                                    // vmcnt(0) on every round, which also waits for the next tile's LDS-DMA it knows nothing of
+                                    asm volatile("" : "+v"(win_word), "+v"(win_rank));
+                                    rel = wi - win_base;
+                                    const uint32_t w_ = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rel & 63u) << 2), (int)win_word);
+                                    const uint32_t r_ = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rel & 63u) << 2), (int)win_rank);
+                                    if (!done && rel < 64) { word = w_; rk = r_; done = true; got = true; }
+                                }
                             }
+                            if (!got) word = 0;
                             const uint32_t shf = (uint32_t)(bit & 31);
                             if ((word >> shf) & 1u) {
                                 const uint32_t site = rk + __popc(word & ((1u << shf) - 1u));
