@@ -62,9 +62,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, args.gpus))
+    # functional test hook (not a measurement mode): all ranks on one GPU over gloo, to exercise the N > 1 code path on
+    # a single-GPU box
+    if os.environ.get("SNPGPU_BENCH_TEST_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("SNPGPU_BENCH_TEST_ONE_GPU") == "1":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     d = dev.Device(local_rank)
     d.use_torch_stream()
 
