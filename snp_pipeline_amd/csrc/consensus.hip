@@ -41,7 +41,6 @@ struct CallArgs {
     snpgpu_site_counts *out_counts;   // nullable
     uint64_t *todo;             // k_call_lanes: sites left to k_call_sites; k_call_sites: nullable, work only on these
     uint32_t *todo_n;
-    int exp;                    // tuning only: stop k_call_lanes after phase N
 };
 
 struct WaveLds {
@@ -518,7 +517,6 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
         stage_half(0, has);
         __builtin_amdgcn_wave_barrier();                       // LDS operations of a wave execute in order
 
-        if (a.exp == 1) continue;
         // ---- tokenise (pileup.py:206): per-lane 256-bit masks of the str.split() separators and of the terminator
         //      candidates, built 4 bytes per step with SWAR compares; the field boundaries are bit scans on the masks ----
         uint64_t Wm[4] = {0, 0, 0, 0}, Tm[4] = {0, 0, 0, 0};
@@ -573,7 +571,6 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
                 pos = found ? (en < 256 ? en : 255u) : 255u;
             }
         }
-        if (a.exp == 2) { if (nf == 77) a.out_base[site] = (uint8_t)line_end; continue; }
         bool punt = has && line_end >= 256;                    // no terminator inside the window: long line
         if (has && !punt) { const uint32_t tc = slot_b[line_end]; punt = tc == 11u || tc == 12u; }
         auto fs = [&](int k) -> uint32_t { return f_s[k]; };
@@ -751,7 +748,6 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
             cnt_f = (cnt_f & 0x0000FFFFFFFFFFFFull) + ((uint64_t)ndot << (8 * (kr & 7u)));
             cnt_r = (cnt_r & 0x0000FFFFFFFFFFFFull) + ((uint64_t)ncom << (8 * (kr & 7u)));
         }
-        if (a.exp == 3) { if (good == 7777) a.out_base[site] = (uint8_t)(cnt_f + cnt_r); continue; }
         // ---- the caller (pileup.py:550-588) --------------------------------------------------------------------------
         uint32_t filters = 0, cons = '-';
         if (has && !punt) {
@@ -843,9 +839,6 @@ static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const Sample
         const unsigned grid = (unsigned)(blocks < max_blocks ? blocks : max_blocks);
         ca.todo = nullptr;
         ca.todo_n = nullptr;
-        static int exp_mode = -1;
-        if (exp_mode < 0) { const char *e = getenv("SNPGPU_CALL_EXP"); exp_mode = e ? atoi(e) : 0; }
-        ca.exp = exp_mode;
         hipEvent_t ta = snpgpu_time_begin(ctx);
         if (d_out_counts) {
             k_call_sites<<<grid, CALL_WAVES * 64, 0, st>>>(ca);      // per-site counts: the wave-per-site kernel does it all
@@ -857,12 +850,6 @@ static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const Sample
             const uint64_t lblocks = ((n_work + 63) / 64 + LANES_WAVES - 1) / LANES_WAVES, lmax = (uint64_t)ctx->n_cu * 8;
             k_call_lanes<<<(unsigned)(lblocks < lmax ? lblocks : lmax), LANES_WAVES * 64, 0, st>>>(ca);
             k_call_sites<<<grid, CALL_WAVES * 64, 0, st>>>(ca);
-            if (exp_mode == 9) {                                     // tuning: how many sites were left over
-                uint32_t left = 0;
-                (void)hipMemcpyAsync(&left, d_todo_n, 4, hipMemcpyDeviceToHost, st);
-                (void)hipStreamSynchronize(st);
-                fprintf(stderr, "k_call_lanes left %u of %llu sites to k_call_sites\n", left, (unsigned long long)n_work);
-            }
         }
         snpgpu_time_end(ctx, SNPGPU_K_CALL, ta);
     }
