@@ -150,7 +150,11 @@ def test_terminators_blank_and_missing_lines(d):
 
 @pytest.mark.parametrize("seed,kw", [(21, dict(genome_len=6000, n_sites=150)),
                                       (22, dict(genome_len=3000, n_sites=90, contigs=("NODE_2", "NODE_10", "NODE_1", "N"))),
-                                      (23, dict(genome_len=20000, n_sites=400, mean_depth=12))])
+                                      (23, dict(genome_len=20000, n_sites=400, mean_depth=12)),
+                                      # bases fields of 64..128 bytes (two mask words in the lane kernel) and lines past
+                                      # its 256-byte window (wave-per-site kernel)
+                                      (24, dict(genome_len=2500, n_sites=120, mean_depth=70)),
+                                      (25, dict(genome_len=1500, n_sites=100, mean_depth=140))])
 def test_synthetic_files_vs_oracle(d, seed, kw):
     from tests.gpu_util import check_against_oracle
     data, _, sites = fuzz.synth_pileup(seed, **kw)
