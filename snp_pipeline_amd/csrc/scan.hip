@@ -5,20 +5,27 @@
 // line publishes (file offset + 1) with atomicMax into site_line[site]; the maximum implements "the last duplicate
 // line wins" (call_consensus.py:171-176).
 //
-// Every wavefront is an independent stream over 4 KiB tiles: it owns two LDS slots, requests tile k+1 with LDS-DMA
-// (global_load_lds_dwordx4: 64 lanes x 16 B straight into LDS, no VGPR round trip) before it parses tile k, and waits
-// for its own DMA with a counted s_waitcnt — no workgroup barrier, no flags, no polling.  The DMA goes through inline
-// asm on purpose: hipcc orders every LDS read behind a *tracked* LDS-DMA with vmcnt(0), which would serialise fetch
-// and parse; the steady-state parse issues no other vector-memory load (the site bitmap is probed through a
-// register window), so the explicit counted wait is the only one on the path.  Per tile:
+// One launch serves a batch of pileups; every wavefront is an independent stream over a contiguous run of 4 KiB tiles
+// of ONE sample (shares dealt by the host, weighted by the wave's age rank on its SIMD).  A wave owns two LDS slots,
+// requests tile k+2 with LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B straight into LDS, no VGPR round trip) as
+// soon as tile k is parsed, and waits for its own DMA with a counted s_waitcnt — no workgroup barrier, no flags, no
+// polling.  The DMA goes through inline asm on purpose: hipcc orders every LDS read behind a *tracked* LDS-DMA with
+// vmcnt(0), which would serialise fetch and parse; the steady-state parse issues no other vector-memory load (the
+// site bitmap is probed through a register window), so the explicit counted wait is the only one on the path.
+// Per tile:
 //   B  each lane scans four 16-byte chunks for line terminators (SWAR, v_dot4_u32_u8 gathers byte flags into bits);
-//      a DPP prefix sum over the wave turns the per-lane counts into a list of line starts in LDS
-//   C  one lane per line, straight-line code: masked dword compare with the wave's current contig name, SWAR
-//      "<= 0x20" mask + ffs for the digit count, SWAR decimal conversion, site probe by ds_bpermute into a 64-dword
-//      register window of the bitmap / rank directory.
-// A line that does not fit the fast path (other contig, odd whitespace, '\r', > 10 digits, long names) is pushed on
-// a device queue and finished by k_scan_queue with an exact byte-wise parser; if the queue overflows, the kExact
-// instantiation (every line through the exact parser) redoes the file.  kExact also serves the depth-column sum.
+//      a DPP prefix sum over the wave turns the per-lane counts into a list of line starts in LDS; every start is then
+//      checked to follow a '\n' (else the tile is indexed again byte by byte with the universal-newline rules)
+//   C  one lane per line.  One-window form: with the name length L and the digit count g of the positions known, the
+//      24 bytes that end with the separator after the position hold "name SEP digits SEP" at fixed places — masked
+//      compares, SWAR digit test, dot4 decimal conversion.  General form (calibrates g, handles long names): name
+//      window, digit window, SWAR "<= 0x20" mask + ffs for the digit count.  Then the site probe by ds_bpermute into a
+//      64-dword register window of the bitmap / rank directory.
+// A line that fits neither (other contig, another digit count, odd whitespace, > 10 digits, names > 44 bytes) is
+// pushed on a device queue and finished by k_scan_queue with an exact byte-wise parser; if the queue overflows, the
+// kExact instantiation (every line through the exact parser) redoes the batch.  kExact also serves the depth-column
+// sum.  Line and match counts leave the kernel through per-wave slots (k_scan_init adds them up per sample):
+// same-address atomics from thousands of waves cost ~12 ns each and stall the loads behind them.
 #include <stdlib.h>
 
 #include "internal.h"
@@ -166,8 +173,6 @@ __device__ __forceinline__ uint32_t four_digits(uint32_t x) {      // x: 4 bytes
     return (t & 0xFFu) * 100u + (t >> 16);
 }
 
-// 0x80 in every byte of w equal to the byte replicated in pat (ASCII input: no carry between bytes)
-__device__ __forceinline__ uint32_t eq_flags(uint32_t w, uint32_t pat) { return ~((w ^ pat) + 0x7F7F7F7Fu) & 0x80808080u; }
 // 0x80 in every byte of w that is <= 0x20 (ASCII input)
 __device__ __forceinline__ uint32_t le20_flags(uint32_t w) { return ~(w + 0x5F5F5F5Fu) & 0x80808080u; }
 // 16 byte flags (0x80 per byte) of a 16-byte chunk -> 16 bits (v_dot4_u32_u8 with weights 1,2,4,8 / 16..128)
