@@ -46,7 +46,18 @@ def parse_args():
     ap.add_argument("--cpu-samples", type=int, default=3, help="samples timed on the CPU oracle (0 = skip)")
     ap.add_argument("--skip-secondary", action="store_true")
     ap.add_argument("--skip-aux", action="store_true", help="skip the device-copy ceiling and the K3/K4 timings")
+    ap.add_argument("--skip-cpu-parallel", action="store_true", help="skip the one-process-per-sample CPU baseline")
     return ap.parse_args()
+
+
+def _oracle_worker(job):
+    """One call_consensus of the CPU oracle in its own process (bench cpu_baseline.parallel)."""
+    path, positions = job
+    from oracle import pileup_oracle as po
+    with open(path, "rb") as f:
+        data = f.read()
+    cons, _ = po.call_consensus_sites(data, [(b"synth_chr1", p) for p in positions], set(), po.CallerParams(0, 0.6, 3, 0, 0.0))
+    return cons
 
 
 def main():
@@ -311,6 +322,31 @@ def main():
         }
         if not ok:
             raise SystemExit("GPU consensus differs from the CPU oracle")
+        # the reference runs one call_consensus process per sample (xargs -P / run.py:710): the same samples again, one
+        # oracle process each, for the host's parallel rate
+        if ncpu > 1 and not args.skip_cpu_parallel:
+            import multiprocessing as mp
+            import tempfile
+            tmpdir = tempfile.mkdtemp(prefix="snpbench_")
+            paths = []
+            for i in range(ncpu):
+                path = os.path.join(tmpdir, "s%d.pileup" % i)
+                with open(path, "wb") as f:
+                    f.write(bytes(pile[int(offs[i]):int(offs[i]) + sizes[i]].cpu().numpy()))
+                paths.append(path)
+            ctx_mp = mp.get_context("spawn")                     # no fork of a process that holds a HIP context
+            t1 = time.perf_counter()
+            with ctx_mp.Pool(ncpu) as pool:
+                res = pool.map(_oracle_worker, [(pth, [int(x) for x in pos]) for pth in paths])
+            t_par = time.perf_counter() - t1
+            for pth in paths:
+                os.remove(pth)
+            os.rmdir(tmpdir)
+            out["cpu_baseline"]["parallel"] = {
+                "value": ncpu * S / t_par, "unit": "bases/s", "processes": ncpu, "host_cores": os.cpu_count(),
+                "seconds": t_par, "matches_gpu": bool(all(r == bytes(gpu_rows[i]) for i, r in enumerate(res))),
+                "note": "one oracle process per sample incl. process start and file read, as the reference's xargs -P does",
+            }
 
     if rank == 0:
         print(json.dumps(out))
