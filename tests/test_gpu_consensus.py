@@ -159,7 +159,9 @@ def test_synthetic_files_vs_oracle(d, seed, kw):
     from tests.gpu_util import check_against_oracle
     data, _, sites = fuzz.synth_pileup(seed, **kw)
     rng = random.Random(seed)
-    snps = sorted(sites + [(sites[0][0], 99_999_999), (b"absent_contig", 3)])
+    # plus the positions around every power of ten (the scan's one-window parse recalibrates its digit count there)
+    edges = [(sites[0][0], p10 + dlt) for p10 in (10, 100, 1000, 10000) for dlt in (-1, 0, 1)]
+    snps = sorted(set(sites + edges + [(sites[0][0], 99_999_999), (b"absent_contig", 3)]))
     excl = rng.sample(sites, len(sites) // 5) + [(sites[0][0], 17)]
     res = check_against_oracle(d, data, snps, excl, po.CallerParams(0, 0.6, 3, 0, 0.0))
     assert res.n_lines == data.count(b"\n")
