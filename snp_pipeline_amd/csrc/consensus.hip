@@ -39,8 +39,10 @@ struct CallArgs {
     uint8_t *out_base;
     uint8_t *out_filters;
     snpgpu_site_counts *out_counts;   // nullable
-    uint64_t *todo;             // k_call_lanes: sites left to k_call_sites; k_call_sites: nullable, work only on these
+    uint64_t *todo;             // k_call_lanes: sites it leaves to the next kernel; k_call_sites: nullable, work only on these
     uint32_t *todo_n;
+    const uint64_t *in_todo;    // k_call_lanes: nullable, work only on these sites
+    const uint32_t *in_todo_n;
 };
 
 struct WaveLds {
@@ -373,24 +375,42 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
     }
 }
 
-// 128-bit per-lane masks for k_call_lanes
-struct M128 { uint64_t lo, hi; };
-__device__ __forceinline__ M128 m_make(const uint32_t (&w)[4]) { return M128{(uint64_t)w[0] | ((uint64_t)w[1] << 32), (uint64_t)w[2] | ((uint64_t)w[3] << 32)}; }
-__device__ __forceinline__ M128 m_and(M128 a, M128 b) { return M128{a.lo & b.lo, a.hi & b.hi}; }
-__device__ __forceinline__ M128 m_or(M128 a, M128 b) { return M128{a.lo | b.lo, a.hi | b.hi}; }
-__device__ __forceinline__ M128 m_andn(M128 a, M128 b) { return M128{a.lo & ~b.lo, a.hi & ~b.hi}; }     // a & ~b
-__device__ __forceinline__ M128 m_not(M128 a) { return M128{~a.lo, ~a.hi}; }
-__device__ __forceinline__ bool m_any(M128 a) { return (a.lo | a.hi) != 0; }
-__device__ __forceinline__ M128 m_shl1(M128 a) { return M128{a.lo << 1, (a.hi << 1) | (a.lo >> 63)}; }
-__device__ __forceinline__ M128 m_add(M128 a, M128 b) { const uint64_t lo = a.lo + b.lo; return M128{lo, a.hi + b.hi + (lo < a.lo ? 1ull : 0ull)}; }
-__device__ __forceinline__ M128 m_below(uint32_t n) {                                                  // bits [0, n), n <= 128
-    return M128{n >= 64 ? ~0ull : ((1ull << n) - 1ull), n >= 128 ? ~0ull : (n > 64 ? ((1ull << (n - 64)) - 1ull) : 0ull)};
+// 64*N-bit per-lane masks for k_call_lanes (N = 2 or 4)
+template <int N> struct BM { uint64_t w[N]; };
+#define BM_FOR _Pragma("unroll") for (int k_ = 0; k_ < N; ++k_)
+template <int N> __device__ __forceinline__ BM<N> m_fill(uint64_t v) { BM<N> r; BM_FOR r.w[k_] = v; return r; }
+template <int N> __device__ __forceinline__ BM<N> m_make(const uint32_t (&w)[2 * N]) { BM<N> r; BM_FOR r.w[k_] = (uint64_t)w[2 * k_] | ((uint64_t)w[2 * k_ + 1] << 32); return r; }
+template <int N> __device__ __forceinline__ BM<N> m_and(BM<N> a, BM<N> b) { BM_FOR a.w[k_] &= b.w[k_]; return a; }
+template <int N> __device__ __forceinline__ BM<N> m_or(BM<N> a, BM<N> b) { BM_FOR a.w[k_] |= b.w[k_]; return a; }
+template <int N> __device__ __forceinline__ BM<N> m_andn(BM<N> a, BM<N> b) { BM_FOR a.w[k_] &= ~b.w[k_]; return a; }   // a & ~b
+template <int N> __device__ __forceinline__ BM<N> m_not(BM<N> a) { BM_FOR a.w[k_] = ~a.w[k_]; return a; }
+template <int N> __device__ __forceinline__ bool m_any(BM<N> a) { uint64_t o = 0; BM_FOR o |= a.w[k_]; return o != 0; }
+template <int N> __device__ __forceinline__ BM<N> m_shl1(BM<N> a) { BM<N> r; BM_FOR r.w[k_] = (a.w[k_] << 1) | (k_ ? a.w[k_ ? k_ - 1 : 0] >> 63 : 0ull); return r; }
+template <int N> __device__ __forceinline__ BM<N> m_add(BM<N> a, BM<N> b) {
+    uint64_t c = 0;
+    BM_FOR { const uint64_t s0 = a.w[k_] + b.w[k_], s1 = s0 + c; c = (s0 < a.w[k_] || s1 < s0) ? 1ull : 0ull; a.w[k_] = s1; }
+    return a;
 }
-__device__ __forceinline__ M128 m_bit(uint32_t i) { return M128{i < 64 ? 1ull << i : 0ull, (i >= 64 && i < 128) ? 1ull << (i - 64) : 0ull}; }   // i >= 128: empty
-__device__ __forceinline__ bool m_test(M128 a, uint32_t i) { return (((i & 64u) ? a.hi : a.lo) >> (i & 63u) & 1ull) != 0; }   // bit i mod 128
-__device__ __forceinline__ uint32_t m_ctz(M128 a) { return a.lo ? (uint32_t)__builtin_ctzll(a.lo) : (a.hi ? 64u + (uint32_t)__builtin_ctzll(a.hi) : 128u); }
-__device__ __forceinline__ uint32_t m_popc(M128 a) { return (uint32_t)__popcll(a.lo) + (uint32_t)__popcll(a.hi); }
-__device__ __forceinline__ M128 m_clear_lowest(M128 a) { return a.lo ? M128{a.lo & (a.lo - 1), a.hi} : M128{0, a.hi & (a.hi - 1)}; }
+template <int N> __device__ __forceinline__ BM<N> m_below(uint32_t n) {                               // bits [0, n), n <= 64 N
+    BM<N> r;
+    BM_FOR r.w[k_] = n >= 64u * (k_ + 1) ? ~0ull : (n > 64u * k_ ? ((1ull << (n - 64u * k_)) - 1ull) : 0ull);
+    return r;
+}
+template <int N> __device__ __forceinline__ BM<N> m_bit(uint32_t i) { BM<N> r; BM_FOR r.w[k_] = (i >> 6) == (uint32_t)k_ ? 1ull << (i & 63u) : 0ull; return r; }   // i >= 64 N: empty
+template <int N> __device__ __forceinline__ uint64_t m_word(BM<N> a, uint32_t idx) { uint64_t r = a.w[0]; BM_FOR if (idx == (uint32_t)k_) r = a.w[k_]; return r; }
+template <int N> __device__ __forceinline__ bool m_test(BM<N> a, uint32_t i) { return ((m_word(a, (i >> 6) & (N - 1)) >> (i & 63u)) & 1ull) != 0; }   // bit i mod 64 N
+template <int N> __device__ __forceinline__ uint32_t m_ctz(BM<N> a) {                                 // 64 N: empty
+    uint32_t r = 64u * N;
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) if (a.w[k]) r = 64u * k + (uint32_t)__builtin_ctzll(a.w[k]);
+    return r;
+}
+template <int N> __device__ __forceinline__ uint32_t m_popc(BM<N> a) { uint32_t r = 0; BM_FOR r += (uint32_t)__popcll(a.w[k_]); return r; }
+template <int N> __device__ __forceinline__ BM<N> m_clear_lowest(BM<N> a) {
+    bool done = false;
+    BM_FOR if (!done && a.w[k_]) { a.w[k_] &= a.w[k_] - 1; done = true; }
+    return a;
+}
 
 // ------------------------------------------------------------------------------------------------
 //                         K2 fast path: one LANE per site, 64 sites per wave
@@ -403,17 +423,24 @@ __device__ __forceinline__ M128 m_clear_lowest(M128 a) { return a.lo ? M128{a.lo
 // wave instructions per site.  Whatever does not fit — a line longer than the window, a malformed line, any other
 // symbol, a sign that is not an indel marker — is appended to a list for k_call_sites, which remains the reference
 // implementation of the caller on the device (and the only one when per-site counts are requested).
-#define LANES_WAVES 2
-#define LANES_WIN 256           // bytes staged per site, from the 16-byte aligned address at or below the line start
-#define LANES_STRIDE 65         // dwords between slots
-
+// Two instantiations: a 256-byte window (lines of up to ~110x coverage; bases field <= 128 bytes, two mask words; two
+// waves per workgroup) over all sites, then a 512-byte window (bases field <= 255 bytes, four mask words; one wave per
+// workgroup because of the LDS it needs) over what the first one left, then k_call_sites over what that one left.
+template <int kWin, int kWaves>
 struct LanesLds {
-    uint32_t slot[LANES_WAVES][64 * LANES_STRIDE];
+    uint32_t slot[kWaves][64 * (kWin / 4 + 1)];   // slot stride kWin/4 + 1 dwords: odd, conflict free
     uint8_t cls[256];           // byte -> rank of its symbol among "*ACGNT" (6: '.' / ',') | reverse << 3; 0xFF: other
 };
 
-__global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
-    __shared__ LanesLds S;
+template <int kWin, int kWords, int kWaves>
+__global__ __launch_bounds__(kWaves * 64) void k_call_lanes(CallArgs a) {
+    constexpr int LANES_WIN = kWin;               // bytes staged per site, from the 16-byte aligned address at or below the line start
+    constexpr int LANES_STRIDE = kWin / 4 + 1;    // dwords between slots
+    constexpr int LANES_WAVES = kWaves;
+    constexpr uint32_t kBits = 64u * kWords;      // mask width = longest bases field in bytes ...
+    constexpr uint32_t kMaxField = kBits > 255u ? 255u : kBits;   // ... but the counts live in byte lanes
+    typedef BM<kWords> M;
+    __shared__ LanesLds<kWin, kWaves> S;
     for (uint32_t c = threadIdx.x; c < 256; c += blockDim.x) {
         const uint32_t u = to_upper(c);
         uint32_t k = u == '*' ? 0u : u == 'A' ? 1u : u == 'C' ? 2u : u == 'G' ? 3u : u == 'N' ? 4u : u == 'T' ? 5u : 0xFFu;
@@ -427,17 +454,19 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *slot = &S.slot[wave][lane * LANES_STRIDE];
     const uint8_t *slot_b = (const uint8_t *)slot;
-    const uint64_t n_work = (uint64_t)a.n_samples * a.n_sites;
+    const uint64_t n_work = a.in_todo ? (uint64_t)*a.in_todo_n : (uint64_t)a.n_samples * a.n_sites;
     const uint64_t n_groups = (n_work + 63) / 64;
     const int minq = a.prm.min_base_quality;
 
     // what a lane needs to know about its site; the next group's is requested before this group is worked on
-    struct LaneRef { uint64_t lv; uint32_t sflags; uintptr_t buf, end; };
+    struct LaneRef { uint64_t site; uint64_t lv; uint32_t sflags; uintptr_t buf, end; };
     auto fetch_ref = [&](uint64_t g) -> LaneRef {
-        LaneRef r{0, 0, 0, 0};
-        const uint64_t s = g * 64 + lane;
-        if (g < n_groups && s < n_work) {
+        LaneRef r{0, 0, 0, 0, 0};
+        const uint64_t idx = g * 64 + lane;
+        if (g < n_groups && idx < n_work) {
+            const uint64_t s = a.in_todo ? a.in_todo[idx] : idx;
             const uint32_t sample = (uint32_t)(s / a.n_sites);
+            r.site = s;
             r.lv = a.site_line[s];
             r.sflags = a.site_flags[s - (uint64_t)sample * a.n_sites];
             r.buf = (uintptr_t)a.samples[sample].buf;
@@ -451,8 +480,8 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
     for (; grp < n_groups; grp += g_stride) {
         const LaneRef cur = nxt;
         nxt = fetch_ref(grp + g_stride);
-        const uint64_t site = grp * 64 + lane;
-        const bool valid = site < n_work;
+        const uint64_t site = cur.site;
+        const bool valid = grp * 64 + lane < n_work;
         const uint64_t lv = cur.lv;
         const uint32_t sflags = cur.sflags;
         const uintptr_t addr = cur.buf + (lv - 1), end = cur.end;
@@ -463,7 +492,7 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
         const uintptr_t al = addr & ~(uintptr_t)15;
         const uint32_t o = (uint32_t)(addr & 15);              // the line starts at byte o of the slot
         auto stage_half = [&](int half, bool want) {
-            if (!__ballot(want && end - al < 2 * LANES_WIN)) {
+            if (!__ballot(want && end - al < (uintptr_t)LANES_WIN + 16)) {
                 // Eight neighbouring lanes fetch one site's 128 bytes, so that a wave instruction is 8 coalesced
                 // 128-byte reads (2 cache lines each) instead of 64 scattered 16-byte ones: the fetch is bound by
                 // the number of outstanding requests per CU, not by bytes.
@@ -519,12 +548,14 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
 
         // ---- tokenise (pileup.py:206): per-lane 256-bit masks of the str.split() separators and of the terminator
         //      candidates, built 4 bytes per step with SWAR compares; the field boundaries are bit scans on the masks ----
-        uint64_t Wm[4] = {0, 0, 0, 0}, Tm[4] = {0, 0, 0, 0};
+        uint64_t Wm[LANES_WIN / 64], Tm[LANES_WIN / 64];
+#pragma unroll
+        for (int q = 0; q < LANES_WIN / 64; ++q) { Wm[q] = 0; Tm[q] = 0; }
         bool done = !has;
 #pragma unroll
         for (int blk = 0; blk < LANES_WIN / 64; ++blk) {
             if (!__ballot(!done)) break;
-            if (blk == 2) { stage_half(1, !done); __builtin_amdgcn_wave_barrier(); }   // only the lines that are still open
+            if (blk >= 2 && (blk & 1) == 0) { stage_half(blk / 2, !done); __builtin_amdgcn_wave_barrier(); }   // only the lines that are still open
             const bool open = !done;                             // (the slots of the others hold stale bytes up there)
             uint32_t mw[2] = {0, 0}, mt[2] = {0, 0};
 #pragma unroll
@@ -545,12 +576,12 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
             Tm[blk] = open ? (uint64_t)mt[0] | ((uint64_t)mt[1] << 32) : 0ull;
             done = done || Tm[blk] != 0;
         }
-        // first set bit at or after `pos` (256: none); inv: scan the complement
-        auto scan_from = [&](const uint64_t (&M)[4], bool inv, uint32_t pos) -> uint32_t {
-            uint32_t r = 256;
+        // first set bit at or after `pos` (LANES_WIN: none); inv: scan the complement
+        auto scan_from = [&](const uint64_t (&Mk)[LANES_WIN / 64], bool inv, uint32_t pos) -> uint32_t {
+            uint32_t r = LANES_WIN;
 #pragma unroll
-            for (int j = 3; j >= 0; --j) {
-                uint64_t m = inv ? ~M[j] : M[j];
+            for (int j = LANES_WIN / 64 - 1; j >= 0; --j) {
+                uint64_t m = inv ? ~Mk[j] : Mk[j];
                 const uint32_t pj = pos >> 6;
                 m = pj > (uint32_t)j ? 0ull : (pj == (uint32_t)j ? m & (~0ull << (pos & 63u)) : m);
                 if (m) r = 64u * j + (uint32_t)__builtin_ctzll(m);
@@ -564,14 +595,14 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 const uint32_t st = scan_from(Wm, true, pos);
-                const uint32_t en = scan_from(Wm, false, st < 256 ? st : 255u);
+                const uint32_t en = scan_from(Wm, false, st < (uint32_t)LANES_WIN ? st : LANES_WIN - 1u);
                 const bool found = st < line_end;
                 nf += found ? 1u : 0u;
                 f_s[k] = st; f_e[k] = en;
-                pos = found ? (en < 256 ? en : 255u) : 255u;
+                pos = found ? (en < (uint32_t)LANES_WIN ? en : LANES_WIN - 1u) : LANES_WIN - 1u;
             }
         }
-        bool punt = has && line_end >= 256;                    // no terminator inside the window: long line
+        bool punt = has && line_end >= (uint32_t)LANES_WIN;    // no terminator inside the window: long line
         if (has && !punt) { const uint32_t tc = slot_b[line_end]; punt = tc == 11u || tc == 12u; }
         auto fs = [&](int k) -> uint32_t { return f_s[k]; };
         auto fe = [&](int k) -> uint32_t { return f_e[k]; };
@@ -589,28 +620,30 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
             }
         }
         // ---- bases + qualities (pileup.py:237-274) -------------------------------------------------------------------
-        // The bases field (<= 128 bytes here) is handled as per-lane 128-bit masks in field coordinates: byte classes by
+        // The bases field (<= kMaxField bytes here) is handled as per-lane 64*kWords-bit masks in field coordinates: byte classes by
         // SWAR compares + dot4, caret pairs by the carry chains of two 128-bit adds (as k_call_sites does on ballots),
         // indel markers by a short serial walk over the '+'/'-' bytes (none on most lines), and only the surviving bytes
         // are then looked at one by one for the counts.
         uint64_t cnt_f = 0, cnt_r = 0;                         // byte lanes: '*' A C G N T, lane 6: '.' (fwd) / ',' (rev)
         uint32_t good = 0;
         bool parse = has && !punt && raw_depth != 0 && nf >= 6;
-        if (parse && fe(4) - fs(4) > 128u) { punt = true; parse = false; }
+        if (parse && fe(4) - fs(4) > kMaxField) { punt = true; parse = false; }
         {
             const uint32_t bs = parse ? fs(4) : 0u, L0 = parse ? fe(4) - fs(4) : 0u, qs = fs(5), qlen = parse ? fe(5) - fs(5) : 0u;
             uint32_t maxL = L0;
             for (int off = 32; off; off >>= 1) maxL = max(maxL, (uint32_t)__shfl_xor((int)maxL, off));
             maxL = __builtin_amdgcn_readfirstlane(maxL);
             const uint32_t nd = (maxL + 3) >> 2;                 // dwords of the longest field in the wave
-            const M128 V = m_below(L0);
+            const M V = m_below<kWords>(L0);
             // -- byte classes: NOT '^', NOT sign, NOT '$' (a cleared bit = match), digits
-            uint32_t nC[4] = {0, 0, 0, 0}, nP[4] = {0, 0, 0, 0}, nS[4] = {0, 0, 0, 0}, dG[4] = {0, 0, 0, 0};
+            uint32_t nC[2 * kWords], nP[2 * kWords], nS[2 * kWords], dG[2 * kWords];
+#pragma unroll
+            for (int q = 0; q < 2 * kWords; ++q) { nC[q] = 0; nP[q] = 0; nS[q] = 0; dG[q] = 0; }
             {
                 const uint32_t sh = bs & 3u;
                 uint32_t lo = slot[bs >> 2];
 #pragma unroll
-                for (uint32_t j = 0; j < 32; ++j) {
+                for (uint32_t j = 0; j < 16u * kWords; ++j) {
                     if (j >= nd) break;
                     const uint32_t hi = slot[(bs >> 2) + j + 1];
                     const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
@@ -626,23 +659,23 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
                     dG[j >> 3] |= (__builtin_amdgcn_udot4(dg, 0x08040201u, 0u, false) >> 7) << pos;
                 }
             }
-            const M128 C = m_andn(V, m_make(nC)), PM = m_andn(V, m_make(nP)), DL = m_andn(V, m_make(nS)), D = m_and(V, m_make(dG));
+            const M C = m_andn(V, m_make<kWords>(nC)), PM = m_andn(V, m_make<kWords>(nP)), DL = m_andn(V, m_make<kWords>(nS)), D = m_and(V, m_make<kWords>(dG));
             // -- '^' + next byte (pileup.py:312): openers are the carets at even distance from the start of their run
-            const M128 EVEN{0x5555555555555555ull, 0x5555555555555555ull};
-            const M128 S0 = m_andn(C, m_shl1(C));
-            const M128 Me = m_andn(C, m_add(C, m_and(S0, EVEN))), Mo = m_andn(C, m_add(C, m_andn(S0, EVEN)));
-            M128 openers = m_or(m_and(Me, EVEN), m_andn(Mo, EVEN));
-            openers = m_andn(openers, m_bit(L0 - 1));            // a trailing lone '^' stays (L0 == 0: no bit)
-            const M128 K1 = m_andn(V, m_or(openers, m_shl1(openers)));
+            const M EVEN = m_fill<kWords>(0x5555555555555555ull), ZERO = m_fill<kWords>(0ull);
+            const M S0 = m_andn(C, m_shl1(C));
+            const M Me = m_andn(C, m_add(C, m_and(S0, EVEN))), Mo = m_andn(C, m_add(C, m_andn(S0, EVEN)));
+            M openers = m_or(m_and(Me, EVEN), m_andn(Mo, EVEN));
+            openers = m_andn(openers, m_bit<kWords>(L0 - 1));            // a trailing lone '^' stays (L0 == 0: no bit)
+            const M K1 = m_andn(V, m_or(openers, m_shl1(openers)));
             // -- indel markers with additive debt (pileup.py:315-320), walked sign by sign
-            M128 Ms{0, 0}, Md{0, 0}, Del{0, 0};
-            M128 P = m_and(PM, K1);
+            M Ms = ZERO, Md = ZERO, Del = ZERO;
+            M P = m_and(PM, K1);
             if (__ballot(m_any(P))) {
                 uint32_t debt = 0, prev_end = 0;
                 auto settle = [&](uint32_t upto) {                 // the debt eats ordinary bytes in [prev_end, upto)
-                    M128 O = m_and(m_andn(m_andn(K1, Ms), Md), m_andn(m_below(upto), m_below(prev_end)));
+                    M O = m_and(m_andn(m_andn(K1, Ms), Md), m_andn(m_below<kWords>(upto), m_below<kWords>(prev_end)));
                     const uint32_t avail = m_popc(O), eat = debt < avail ? debt : avail;
-                    M128 rest = O;
+                    M rest = O;
                     for (uint32_t t = 0; __ballot(t < eat); ++t) if (t < eat) rest = m_clear_lowest(rest);
                     Del = m_or(Del, m_andn(O, rest));
                     debt -= eat;
@@ -651,30 +684,30 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
                     const bool on = m_any(P);
                     const uint32_t i = on ? m_ctz(P) : 0u;
                     if (on) P = m_clear_lowest(P);
-                    const uint32_t nk = m_ctz(m_andn(K1, m_below(i + 1)));            // the next byte that survived the carets
-                    const bool marker = on && nk < 128u && m_test(D, nk);
-                    const uint32_t e = m_ctz(m_andn(m_andn(K1, D), m_below(nk)));      // 128: the digits run to the end
-                    const M128 run = m_and(m_and(K1, m_below(e)), marker ? m_not(m_below(nk)) : M128{0, 0});
+                    const uint32_t nk = m_ctz(m_andn(K1, m_below<kWords>(i + 1 < kBits ? i + 1 : kBits)));            // the next byte that survived the carets
+                    const bool marker = on && nk < kBits && m_test(D, nk);
+                    const uint32_t e = m_ctz(m_andn(m_andn(K1, D), m_below<kWords>(nk)));      // kBits: the digits run to the end
+                    const M run = m_and(m_and(K1, m_below<kWords>(e)), marker ? m_not(m_below<kWords>(nk)) : ZERO);
                     uint32_t count = 0;
                     {
-                        M128 r = run;
+                        M r = run;
                         while (__ballot(m_any(r))) {
-                            if (m_any(r)) { count = sat_mul10_add(count, (uint32_t)slot_b[(bs + m_ctz(r)) & 0xFFu] - 48u); r = m_clear_lowest(r); }
+                            if (m_any(r)) { count = sat_mul10_add(count, (uint32_t)slot_b[(bs + m_ctz(r)) & (LANES_WIN - 1u)] - 48u); r = m_clear_lowest(r); }
                         }
                     }
                     if (__ballot(marker && debt != 0)) { if (marker) settle(i); }
                     if (marker) {
-                        Ms = m_or(Ms, m_bit(i));
+                        Ms = m_or(Ms, m_bit<kWords>(i));
                         Md = m_or(Md, run);
                         // ordinary bytes between the previous marker and this sign were settled above (or there was no debt)
                         debt = sat_add(debt, count);
                         prev_end = e;
                     }
                 }
-                if (__ballot(debt != 0)) settle(128);
+                if (__ballot(debt != 0)) settle(kBits);
                 punt = punt || m_any(m_andn(m_andn(m_and(PM, K1), Ms), Del));         // a sign that survives as a symbol: not ours
             }
-            const M128 K = m_andn(m_andn(m_andn(m_andn(K1, Ms), Md), Del), DL);
+            const M K = m_andn(m_andn(m_andn(m_andn(K1, Ms), Md), Del), DL);
             // -- pair with qualities (zip truncation, pileup.py:248-250) and count
             const int thr = 33 + minq;
             const uint32_t kept_total = m_popc(K);
@@ -685,13 +718,13 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
                 else {
                     const uint32_t addc = (uint32_t)(128 - thr) * 0x01010101u;       // bit 7 of a byte after the add: byte >= thr
                     const uint32_t shq = qs & 3u;
-                    uint32_t lo = slot[(qs >> 2) & 63u];
+                    uint32_t lo = slot[(qs >> 2) & (LANES_WIN / 4 - 1u)];
                     uint32_t maxQ = parse ? (kept_total < qlen ? kept_total : qlen) : 0u;
                     for (int off = 32; off; off >>= 1) maxQ = max(maxQ, (uint32_t)__shfl_xor((int)maxQ, off));
                     const uint32_t nq = (__builtin_amdgcn_readfirstlane(maxQ) + 3) >> 2;
                     const uint32_t need = kept_total < qlen ? kept_total : qlen;      // qualities that matter
                     for (uint32_t j = 0; j < nq; ++j) {
-                        const uint32_t hi = slot[((qs >> 2) + j + 1) & 63u];
+                        const uint32_t hi = slot[((qs >> 2) + j + 1) & (LANES_WIN / 4 - 1u)];
                         const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, shq);
                         lo = hi;
                         const uint32_t nb = need > 4 * j ? min(need - 4 * j, 4u) : 0u;
@@ -706,12 +739,12 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
                 uint32_t lo = slot[bs >> 2];
                 uint32_t kept = 0;
                 uint32_t qd = qs >> 2, qw = 0, qw_next = 0;
-                if (pair_any) { qw = slot[qd & 63u]; qw_next = slot[(qd + 1) & 63u]; }
+                if (pair_any) { qw = slot[qd & (LANES_WIN / 4 - 1u)]; qw_next = slot[(qd + 1) & (LANES_WIN / 4 - 1u)]; }
                 for (uint32_t j = 0; j < nd; ++j) {
                     const uint32_t hi = slot[(bs >> 2) + j + 1];
                     const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
                     lo = hi;
-                    const uint32_t k4 = (uint32_t)(((j & 16u) ? K.hi : K.lo) >> ((4 * j) & 63u)) & 15u;
+                    const uint32_t k4 = (uint32_t)(m_word(K, j >> 4) >> ((4 * j) & 63u)) & 15u;
                     uint32_t cl4[4];
 #pragma unroll
                     for (uint32_t k = 0; k < 4; ++k) cl4[k] = S.cls[(w >> (8 * k)) & 0xFFu];
@@ -725,7 +758,7 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void k_call_lanes(CallArgs a) {
                                 const bool adv = (qi >> 2) != qd;
                                 qw = adv ? qw_next : qw;
                                 qd += adv ? 1u : 0u;
-                                qw_next = slot[(qd + 1) & 63u];
+                                qw_next = slot[(qd + 1) & (LANES_WIN / 4 - 1u)];
                             }
                             const uint32_t qv = (qw >> (8 * (qi & 3u))) & 0xFFu;
                             goodb = emit && kept < qlen && (int)qv >= thr;
@@ -801,15 +834,17 @@ static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const Sample
     const uint32_t n_sites = ss->n_sites;
     const size_t ws_bytes = (snpgpu_scan_workspace_bytes(ctx, n) + 255) / 256 * 256;
     const size_t rows_bytes = d_site_line ? 0 : 8ull * n_sites * n;
-    const size_t todo_bytes = d_out_counts ? 0 : 8ull * n_sites * n + 256;     // leftovers of k_call_lanes + their count
+    const size_t list_bytes = (8ull * n_sites * n + 255) / 256 * 256;
+    const size_t todo_bytes = d_out_counts ? 0 : 2 * list_bytes + 256;          // leftovers of the two lane kernels + their counts
     void *ws = nullptr;
     {
         int rc = snpgpu_scratch(ctx, ws_bytes + rows_bytes + todo_bytes + 256, &ws);
         if (rc) return rc;
     }
     if (!d_site_line) d_site_line = (uint64_t *)((char *)ws + ws_bytes);
-    uint32_t *d_todo_n = (uint32_t *)((char *)ws + ws_bytes + rows_bytes);
+    uint32_t *d_todo_n = (uint32_t *)((char *)ws + ws_bytes + rows_bytes);      // [0]: after the 256-byte pass, [1]: after the 512-byte pass
     uint64_t *d_todo = (uint64_t *)((char *)ws + ws_bytes + rows_bytes + 256);
+    uint64_t *d_todo2 = (uint64_t *)((char *)ws + ws_bytes + rows_bytes + 256 + list_bytes);
     if (n_sites) HIP_TRY(ctx, hipMemsetAsync(d_site_line, 0, 8ull * n_sites * n, st));
     std::vector<SampleDev> samples(n);
     for (uint32_t i = 0; i < n; ++i) {
@@ -839,16 +874,27 @@ static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const Sample
         const unsigned grid = (unsigned)(blocks < max_blocks ? blocks : max_blocks);
         ca.todo = nullptr;
         ca.todo_n = nullptr;
+        ca.in_todo = nullptr;
+        ca.in_todo_n = nullptr;
         hipEvent_t ta = snpgpu_time_begin(ctx);
         if (d_out_counts) {
             k_call_sites<<<grid, CALL_WAVES * 64, 0, st>>>(ca);      // per-site counts: the wave-per-site kernel does it all
         } else {
-            // one lane per site for every ordinary line, then one wave per site for whatever that kernel left over
+            // one lane per site: a 256-byte window for every site, a 512-byte window for what that left (deeper pileups),
+            // then one wave per site for the rest
+            HIP_TRY(ctx, hipMemsetAsync(d_todo_n, 0, 8, st));
+            ca.in_todo = nullptr;
+            ca.in_todo_n = nullptr;
             ca.todo = d_todo;
             ca.todo_n = d_todo_n;
-            HIP_TRY(ctx, hipMemsetAsync(d_todo_n, 0, 4, st));
-            const uint64_t lblocks = ((n_work + 63) / 64 + LANES_WAVES - 1) / LANES_WAVES, lmax = (uint64_t)ctx->n_cu * 8;
-            k_call_lanes<<<(unsigned)(lblocks < lmax ? lblocks : lmax), LANES_WAVES * 64, 0, st>>>(ca);
+            const uint64_t lblocks = ((n_work + 63) / 64 + 1) / 2, lmax = (uint64_t)ctx->n_cu * 8;
+            k_call_lanes<256, 2, 2><<<(unsigned)(lblocks < lmax ? lblocks : lmax), 128, 0, st>>>(ca);
+            ca.in_todo = d_todo;
+            ca.in_todo_n = d_todo_n;
+            ca.todo = d_todo2;
+            ca.todo_n = d_todo_n + 1;
+            const uint64_t l2blocks = (n_work + 63) / 64, l2max = (uint64_t)ctx->n_cu * 4;
+            k_call_lanes<512, 4, 1><<<(unsigned)(l2blocks < l2max ? l2blocks : l2max), 64, 0, st>>>(ca);
             k_call_sites<<<grid, CALL_WAVES * 64, 0, st>>>(ca);
         }
         snpgpu_time_end(ctx, SNPGPU_K_CALL, ta);

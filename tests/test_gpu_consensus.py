@@ -284,7 +284,8 @@ def test_lane_kernel_alphabet_stress(d, seed):
     alphabet = ".,.,.,ACGTNacgtn*" + "^$+-0123456789"
     lines, keys = [], []
     for pos in range(1, 1501):
-        n = rng.choice([1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 120, 128])
+        # up to 128 bases: 256-byte window, two mask words; up to 255: 512-byte window, four mask words; more: wave kernel
+        n = rng.choice([1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 120, 128, 129, 150, 192, 200, 240, 255, 256, 300])
         dense = rng.random() < 0.5
         toks = []
         while len(toks) < n:
