@@ -5,9 +5,10 @@ A *step* is one pass of the hot path over one batch of synthetic samples already
     call_consensus (pileup scan + per-site caller) for this rank's B samples
     -> pack the B x S consensus matrix 4 bits/site -> all-gather of packed rows over RCCL (N > 1)
     -> all-pairs SNP distance over the (N*B) x S matrix, 128x128 tiles dealt cyclically to ranks.
-Workload = BASELINE.json configs[3] shape per GPU (5 Mbp reference, 30x pileups, 50 k SNP sites), B samples per
-rank (weak scaling: the node-level run of configs[3] is 8 ranks x 125 samples; the default B keeps the default
-run within minutes).  value = consensus bases called per second, whole job.
+Workload at N = 1: BASELINE.json configs[1] size (the Agona set: ~25 samples, ~5 Mbp reference; B = 24 samples per
+rank) with the synthetic pileups configs[3] specifies (30x depth, 50 k SNP sites) because the reference bundles no
+pileup files.  N > 1 is weak scaling: B samples per rank (the node-level run of configs[3] would be 8 ranks x 125
+samples, same per-sample work).  value = consensus bases called per second, whole job.
 
 The same JSON line carries
   roofline      the pileup-scan kernel: algorithmic bytes (= pileup text bytes, each read once) / its average launch
@@ -196,7 +197,8 @@ def main():
         "metric": "consensus_bases_called_per_sec", "value": value, "unit": "bases/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[3] shape per GPU: %d samples/GPU x %d bp x %gx pileups, %d SNP sites; "
+        "config": {"workload": "BASELINE configs[1] size (Agona-like: %d samples/GPU x %d bp reference) with the synthetic "
+                               "pileups configs[3] specifies (%gx depth, %d SNP sites; the reference bundles no pileups); "
                                "step = one batched scan launch + one call launch, 4-bit pack, all-gather, all-pairs distance"
                                % (B, G, args.depth, S),
                    "samples_per_gpu": B, "genome_bp": G, "mean_depth": args.depth, "snp_sites": S,

@@ -1,20 +1,63 @@
-import sys, time; sys.path.insert(0, "/root/repo")
-import torch
-from oracle import fuzz
-from snp_pipeline_amd import device as dev
-d = dev.default_device()
-one, _, sites = fuzz.synth_pileup(3, genome_len=40000, n_sites=300)
-parts, keys = [], []
-for i in range(12):
-    nm = b"contig_%02d" % i
-    parts.append(one.replace(b"synth_chr1", nm))
-    if i % 3 != 1: keys += [(nm, p) for _, p in sites]
-data = b"".join(parts)
-ss = d.siteset(keys, [1] * len(keys))
-prm = dev.make_params(0, 0.6, 3, 0, 0.0)
-res = d.call_consensus(ss, data, prm, want_counts=False)
-d.kernel_timing(True); d.kernel_time_ms(0); d.kernel_time_ms(1)
-t = time.time()
-for _ in range(5): res = d.call_consensus(ss, data, prm, want_counts=False)
-sm, sn = d.kernel_time_ms(0)
-print("multi-contig %d bytes: scan kernel %.3f ms (%.0f GB/s), host wall %.1f ms/call, lines %d" % (len(data), sm / sn, len(data) / (sm / sn * 1e-3) / 1e9, (time.time() - t) * 200, res.n_lines))
+#!/usr/bin/env python3
+"""Development helper: scan rate on samples made of many contigs (device-generated pieces with different contig names
+laid back to back), some of them without any site.  Usage: python tools/scan_multi_contig.py [n_contigs] [contig_len]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import torch
+    from snp_pipeline_amd import device as dev
+    C = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    G = int(sys.argv[2]) if len(sys.argv) > 2 else 125_000
+    B = 8
+    d = dev.Device(0)
+    d.use_torch_stream()
+    ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda")
+    d.synth_reference_dev(1, G, ref.data_ptr())
+    pos = np.sort(np.random.default_rng(2).choice(np.arange(51, G - 49), size=G // 100, replace=False))
+    alt_h = np.zeros(G + 1, dtype=np.uint8)
+    alt_h[pos] = ord("A")
+    alt = torch.from_numpy(alt_h).cuda()
+    names = [("NODE_%d_len_%d" % (c + 1, G)).encode() if c % 2 else ("ctg%03d" % c).encode() for c in range(C)]
+    keys = [(names[c], int(p)) for c in range(C) if c % 5 != 3 for p in pos]          # every fifth contig has no site
+    sizes = [[d.synth_pileup_dev(3, s * C + c, G, ref.data_ptr(), alt.data_ptr(), 0, 0, contig=names[c]) for c in range(C)] for s in range(B)]
+    total = sum(sum(x) for x in sizes)
+    buf = torch.empty(total + 64, dtype=torch.uint8, device="cuda")
+    offs, lens, o = [], [], 0
+    for s in range(B):
+        offs.append(o)
+        for c in range(C):
+            n = d.synth_pileup_dev(3, s * C + c, G, ref.data_ptr(), alt.data_ptr(), buf.data_ptr() + o, sizes[s][c], contig=names[c])
+            o += n
+        lens.append(o - offs[-1])
+    ss = d.siteset(keys, [1] * len(keys))
+    prm = dev.make_params(0, 0.6, 3, 0, 0.0)
+    S = len(keys)
+    bases = torch.empty((B, S), dtype=torch.uint8, device="cuda")
+    filt = torch.empty((B, S), dtype=torch.uint8, device="cuda")
+    status = torch.empty((B, 4), dtype=torch.int64, device="cuda")
+
+    def run():
+        d.call_consensus_batch_dev(ss, buf.data_ptr(), np.asarray(offs, dtype=np.uint64), prm, bases.data_ptr(), filt.data_ptr(),
+                                   status.data_ptr(), sizes=np.asarray(lens, dtype=np.uint64))
+    run()
+    torch.cuda.synchronize()
+    d.kernel_timing(True)
+    d.kernel_time_ms(0), d.kernel_time_ms(1)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    sm, sn = d.kernel_time_ms(0)
+    cm, cn = d.kernel_time_ms(1)
+    st = status.cpu().numpy()
+    print("%d samples x %d contigs x %d bp (%.2f GB): scan %.3f ms  %.0f GB/s | call %.3f ms | lines %d matched %d of %d sites, err %s"
+          % (B, C, G, total / 1e9, sm / sn, total / (sm / sn * 1e-3) / 1e9, cm / cn, st[0, 1], st[0, 2], S, (st[:, 0] != -1).any()))
+
+
+if __name__ == "__main__":
+    main()
