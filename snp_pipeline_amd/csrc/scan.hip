@@ -32,7 +32,9 @@
 
 #define SCAN_TILE 4096                       // bytes per wave tile
 #define SCAN_HALO 128                        // bytes staged past the tile for the first fields of its last lines
-#define SCAN_NBUF 2                          // LDS slots per wave: tile k is parsed while tile k+1 streams in
+#ifndef SCAN_NBUF
+#define SCAN_NBUF 2                          // LDS slots per wave: tile k is parsed while tiles k+1 .. k+NBUF-1 stream in
+#endif
 #define SCAN_WTILE_CHUNKS ((16 + SCAN_TILE + SCAN_HALO) / 16)   // [t0-16, t0+TILE+HALO) in 16-byte chunks
 #define SCAN_DMA_PER_TILE ((SCAN_WTILE_CHUNKS + 63) / 64)       // global_load_lds wave-instructions per tile
 #define SCAN_LIST_CAP 192                    // line starts held in LDS per pass (a tile with more makes extra passes)
@@ -397,23 +399,29 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     auto cum = [&](uint64_t x) -> uint64_t {
         const uint32_t wpb = blockDim.x >> 6, r = (uint32_t)(x % wpb);
         uint64_t c = 0, blk = 0;
-        for (uint32_t w = 0; w < wpb; ++w) { const uint32_t sw = a.share[(w * 4) / wpb]; blk += sw; c += w < r ? sw : 0; }
+        for (uint32_t w = 0; w < wpb; ++w) { const uint32_t sw = a.share[(w >> 2) & 3u]; blk += sw; c += w < r ? sw : 0; }
         return (x / wpb) * blk + c;
     };
     const uint64_t c_lo = cum(s_wave0), c_span = cum((uint64_t)s_wave0 + s_waves) - c_lo;
     const uint64_t t_first = n_tiles * (cum(gwave) - c_lo) / c_span, t_end = n_tiles * (cum(gwave + 1) - c_lo) / c_span;
     const uint64_t kNoTile = ~0ull;
-    uint64_t tt = t_first < t_end ? t_first : kNoTile, t_nxt = t_first + 1 < t_end ? t_first + 1 : kNoTile;
-    uint32_t dma_next = 0;                                    // DMA instructions in flight for the tile after the current one
-    if (tt != kNoTile) (void)request(tt, 0);
-    if (t_nxt != kNoTile) dma_next = request(t_nxt, 1);
+    // slot b holds tile t_first + b + k * NBUF; cnt[b] = DMA instructions requested for the tile now in slot b
+    uint64_t t_req = t_first;
+    uint32_t cnt[SCAN_NBUF];
+#pragma unroll
+    for (int b = 0; b < SCAN_NBUF; ++b) { cnt[b] = 0; if (t_req < t_end) cnt[b] = request(t_req++, b); }
     int cur = 0;
     bool first_tile = true;
     if (kStamp) rt_prologue = __builtin_amdgcn_s_memrealtime();
-    for (; tt != kNoTile; cur ^= 1) {
-        // the current tile's DMA has landed when only the next tile's requests are still outstanding
-        if (dma_next) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SCAN_DMA_PER_TILE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    for (uint64_t tt = t_first < t_end ? t_first : kNoTile; tt != kNoTile; tt = tt + 1 < t_end ? tt + 1 : kNoTile) {
+        // the current tile's DMA has landed when only the requests of the later tiles are still outstanding
+        uint32_t later = 0;
+#pragma unroll
+        for (int b = 0; b < SCAN_NBUF; ++b) later += b == cur ? 0u : cnt[b];
+        later = __builtin_amdgcn_readfirstlane(later);
+        if (later == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (later == SCAN_DMA_PER_TILE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SCAN_DMA_PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * SCAN_DMA_PER_TILE) : "memory");
         __builtin_amdgcn_wave_barrier();
         WTICK(t_a);
         {
@@ -686,12 +694,14 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this slot has returned: it can be refilled
         __builtin_amdgcn_wave_barrier();
         WTICK(t_b);
-        // the slot just parsed receives the tile after next; the outstanding requests are then the next tile's (older)
-        // and these, and the next top-of-loop wait leaves exactly these in flight
-        const uint64_t t_new = t_nxt != kNoTile && t_nxt + 1 < t_end ? t_nxt + 1 : kNoTile;
-        dma_next = t_new != kNoTile ? request(t_new, cur) : 0;
-        tt = t_nxt;
-        t_nxt = t_new;
+        // the slot just parsed receives the tile NBUF ahead
+        {
+            uint32_t c_new = 0;
+            if (t_req < t_end) c_new = request(t_req++, cur);
+#pragma unroll
+            for (int b = 0; b < SCAN_NBUF; ++b) if (b == cur) cnt[b] = c_new;
+            cur = cur + 1 == SCAN_NBUF ? 0 : cur + 1;
+        }
         WTICK(t_c);
         if (kStamp && first_tile) { rt_first = __builtin_amdgcn_s_memrealtime(); first_tile = false; }
     }
@@ -769,7 +779,7 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<S
     hipStream_t st = ctx->stream;
     const uint32_t n = (uint32_t)h_samples.size();
     if (!n) return SNPGPU_OK;
-    static int blocks_per_cu = -1, mode = 0, waves = 16;
+    static int blocks_per_cu = -1, mode = 0, waves = SCAN_NBUF == 2 ? 16 : 12;
     static int share[4] = {329, 282, 223, 169};            // measured: 1 / (finish time with equal shares), oldest first
     if (blocks_per_cu < 0) {                                // tuning knobs (development only)
         const char *b = getenv("SNPGPU_SCAN_BLOCKS_PER_CU"), *m = getenv("SNPGPU_SCAN_MODE"), *w = getenv("SNPGPU_SCAN_WAVES");
@@ -836,7 +846,7 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<S
     sa.n_sites = ss->n_sites;
     sa.site_line = d_site_line;
     sa.want_depth = want_depth;
-    for (int g = 0; g < 4; ++g) sa.share[g] = (waves == 16 && blocks_per_cu == 1) ? (uint32_t)share[g] : 1u;
+    for (int g = 0; g < 4; ++g) sa.share[g] = ((waves == 16 || waves == 12) && blocks_per_cu == 1) ? (uint32_t)share[g] : 1u;
     sa.queue = ss->slow_queue;
     sa.q_cap = SNPGPU_SLOW_QUEUE_CAP - 65536;               // the tail holds the tuning modes' per-wave records
     sa.ctl = ss->slow_ctl;
