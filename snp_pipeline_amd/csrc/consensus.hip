@@ -1,18 +1,18 @@
-// K2 per-site wavefront consensus caller, and the call_consensus entry points (K1, the scan, is scan.hip).
+// K2: the consensus caller (one wavefront per site, and one lane per site for the throughput path), and the
+// call_consensus entry points (K1, the scan, is scan.hip).
 //
-// Replaces, for one sample:
-//   pileup.Reader.__iter__            snppipeline/pileup.py:408-429   -> k_scan_pileup
-//   pileup.Record._init_from_split_line  pileup.py:209-274            -> k_call_sites
-//   pileup.Record._strip_unwanted_base_patterns  pileup.py:276-325    -> k_call_sites (mask algebra, see below)
-//   pileup.ConsensusCaller.call_consensus  pileup.py:492-590          -> k_call_sites (tail)
+// Replaces, for a batch of samples:
+//   pileup.Reader.__iter__            snppipeline/pileup.py:408-429   -> k_scan_wave (scan.hip)
+//   pileup.Record._init_from_split_line  pileup.py:209-274            -> k_call_lanes / k_call_sites
+//   pileup.Record._strip_unwanted_base_patterns  pileup.py:276-325    -> k_call_lanes / k_call_sites (mask algebra, see below)
+//   pileup.ConsensusCaller.call_consensus  pileup.py:492-590          -> k_call_lanes / k_call_sites (tail)
 //   call_consensus.py:161-188 (Region filter, '-' mapping, last line wins, missing -> '-')
 //
-// k_scan_pileup is the HBM-bound kernel: every byte of the raw ASCII pileup is read exactly once with 16-byte
-// coalesced loads, staged through LDS, newline-indexed with SWAR, and only the first two fields of each line are
-// parsed.  A matching line publishes (its offset + 1) with atomicMax into site_line[site]; the maximum implements
-// "the last duplicate line wins" (call_consensus.py:171-176).  k_call_sites then runs one 64-lane wavefront per
-// site over that line.  The three regex passes of the reference become 64-bit mask algebra on wave ballots
-// (scalar ALU work on gfx950: one ballot == one SGPR pair).
+// The scan leaves, per (sample, site), the offset + 1 of the last pileup line of that position (0: none).  k_call_sites
+// runs one 64-lane wavefront per site over that line: the three regex passes of the reference become 64-bit mask
+// algebra on wave ballots (scalar ALU work on gfx950: one ballot == one SGPR pair).  It is the complete caller
+// (per-site counts for consensus.vcf, any symbol, any line length).  k_call_lanes gives every LANE a site and does the
+// same algebra on per-lane bit masks; it serves the FASTA-only path and hands what it cannot do to k_call_sites.
 #include <stdlib.h>
 
 #include "internal.h"
