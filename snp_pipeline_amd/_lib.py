@@ -79,15 +79,25 @@ class SnpGpuError(RuntimeError):
         self.code = code
 
 
+TORCH_FREE_OK = False          # set by the console script: a CLI process never shares device pointers with torch
+loaded_without_torch = False
+
+
 def load():
     """Load libsnpgpu.so.  torch is imported first so that the HIP runtime torch ships (same SONAME) is the one
-    and only runtime in the process — device pointers of torch tensors are then valid for our kernels."""
-    global _lib
+    and only runtime in the process — device pointers of torch tensors are then valid for our kernels.  The console
+    script skips that (its processes never touch torch, and the import costs seconds per sample process) unless torch
+    is already loaded or SNPGPU_TORCH=1."""
+    global _lib, loaded_without_torch
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: run `python -m snp_pipeline_amd.build` (there is no CPU fallback)" % LIB_PATH)
-    import torch  # noqa: F401  (side effect: loads libamdhip64)
+    import sys
+    if "torch" in sys.modules or not TORCH_FREE_OK or os.environ.get("SNPGPU_TORCH") == "1":
+        import torch  # noqa: F401  (side effect: loads libamdhip64)
+    else:
+        loaded_without_torch = True
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -176,6 +176,10 @@ def run_command_from_line(line):
 
 
 def main():
+    """Console entry point.  A CLI process never exchanges device pointers with torch, so the HIP library is loaded
+    without importing it (seconds per sample process); see _lib.load()."""
+    from . import _lib
+    _lib.TORCH_FREE_OK = True
     return run_command_from_arg_list(sys.argv[1:])
 
 

@@ -127,6 +127,9 @@ class Device(object):
 
     def use_torch_stream(self):
         """Enqueue on torch's current stream so torch.cuda events / collectives order with our kernels."""
+        if L.loaded_without_torch:
+            raise RuntimeError("libsnpgpu.so was loaded with the system HIP runtime (console-script mode); import torch "
+                               "before snp_pipeline_amd to share streams and device pointers with it")
         import torch
         self._check(self.lib.snpgpu_ctx_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 

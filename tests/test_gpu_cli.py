@@ -179,3 +179,31 @@ def test_call_consensus_cli_error_paths(tmp_path, monkeypatch):
     (tmp_path / "corrupt.txt").write_text("c\tnot_a_number\n")
     with pytest.raises(ValueError):
         _run("call_consensus -f -l %s/corrupt.txt -o %s/c.fasta %s" % (tmp_path, tmp_path, pile))
+
+
+def test_console_script_subprocess_without_torch(tmp_path):
+    """bin/cfsan_snp_pipeline as run.py starts it: a separate process, which loads the HIP library without importing
+    torch (seconds saved per sample process) and writes the same FASTA."""
+    import subprocess
+    import sys
+    import time
+    data, _, sites = fuzz.synth_pileup(43, genome_len=4000, n_sites=90)
+    sdir = tmp_path / "sampleS"
+    sdir.mkdir()
+    (sdir / "reads.all.pileup").write_bytes(data)
+    with open(str(tmp_path / "snplist.txt"), "w") as f:
+        for c, p in sites:
+            f.write("%s\t%d\t1\tsampleS\n" % (c.decode(), p))
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "cfsan_snp_pipeline")
+    probe = ("import runpy, sys\n"
+             "sys.argv = ['cfsan_snp_pipeline', 'call_consensus', '-v', '0', '-l', %r, '-o', %r, '--minConsDpth', '3', %r]\n"
+             "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit as e:\n    assert not e.code, e.code\n"
+             "print('torch' in sys.modules)"
+             % (str(tmp_path / "snplist.txt"), str(sdir / "consensus.fasta"), str(sdir / "reads.all.pileup"), exe))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().endswith("False"), r.stdout[-500:]            # torch was never imported
+    want, _ = po.call_consensus_sites(data, sites, set(), po.CallerParams(0, 0.6, 3, 0, 0.0))
+    assert (sdir / "consensus.fasta").read_text() == ">sampleS\n" + "".join(want.decode()[i:i + 60] + "\n" for i in range(0, len(want), 60))
+    print("console script wall time %.2f s" % (time.time() - t0))
