@@ -405,22 +405,21 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     const uint64_t c_lo = cum(s_wave0), c_span = cum((uint64_t)s_wave0 + s_waves) - c_lo;
     const uint64_t t_first = n_tiles * (cum(gwave) - c_lo) / c_span, t_end = n_tiles * (cum(gwave + 1) - c_lo) / c_span;
     const uint64_t kNoTile = ~0ull;
-    // slot b holds tile t_first + b + k * NBUF; cnt[b] = DMA instructions requested for the tile now in slot b
+    // slot b holds tile t_first + b + k * NBUF; bit b of dma_mask: the tile now in slot b was requested by DMA (an edge
+    // tile is staged synchronously instead).  Wave-uniform scalars throughout.
     uint64_t t_req = t_first;
-    uint32_t cnt[SCAN_NBUF];
+    uint32_t dma_mask = 0;
 #pragma unroll
-    for (int b = 0; b < SCAN_NBUF; ++b) { cnt[b] = 0; if (t_req < t_end) cnt[b] = request(t_req++, b); }
-    int cur = 0;
+    for (int b = 0; b < SCAN_NBUF; ++b)
+        if (t_req < t_end) dma_mask |= (__builtin_amdgcn_readfirstlane(request(t_req++, b)) ? 1u : 0u) << b;
+    uint32_t cur = 0;
     bool first_tile = true;
     if (kStamp) rt_prologue = __builtin_amdgcn_s_memrealtime();
     for (uint64_t tt = t_first < t_end ? t_first : kNoTile; tt != kNoTile; tt = tt + 1 < t_end ? tt + 1 : kNoTile) {
         // the current tile's DMA has landed when only the requests of the later tiles are still outstanding
-        uint32_t later = 0;
-#pragma unroll
-        for (int b = 0; b < SCAN_NBUF; ++b) later += b == cur ? 0u : cnt[b];
-        later = __builtin_amdgcn_readfirstlane(later);
+        const uint32_t later = (uint32_t)__builtin_popcount(dma_mask & ~(1u << cur));
         if (later == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (later == SCAN_DMA_PER_TILE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SCAN_DMA_PER_TILE) : "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SCAN_DMA_PER_TILE) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * SCAN_DMA_PER_TILE) : "memory");
         __builtin_amdgcn_wave_barrier();
         WTICK(t_a);
@@ -695,13 +694,9 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
         __builtin_amdgcn_wave_barrier();
         WTICK(t_b);
         // the slot just parsed receives the tile NBUF ahead
-        {
-            uint32_t c_new = 0;
-            if (t_req < t_end) c_new = request(t_req++, cur);
-#pragma unroll
-            for (int b = 0; b < SCAN_NBUF; ++b) if (b == cur) cnt[b] = c_new;
-            cur = cur + 1 == SCAN_NBUF ? 0 : cur + 1;
-        }
+        dma_mask &= ~(1u << cur);
+        if (t_req < t_end) dma_mask |= (__builtin_amdgcn_readfirstlane(request(t_req++, (int)cur)) ? 1u : 0u) << cur;
+        cur = cur + 1 == SCAN_NBUF ? 0 : cur + 1;
         WTICK(t_c);
         if (kStamp && first_tile) { rt_first = __builtin_amdgcn_s_memrealtime(); first_tile = false; }
     }
