@@ -425,7 +425,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
         WTICK(t_a);
         {
             const uint64_t t0 = tt * SCAN_TILE;
-            const bool edge = !interior(tt);
+            const bool edge = ((dma_mask >> cur) & 1u) == 0;          // staged synchronously = not an interior tile
             const uint8_t *tile = (const uint8_t *)&ws.slot[cur][1];   // tile[-16 .. SCAN_TILE+SCAN_HALO)
             const uint4 *tile16 = &ws.slot[cur][1];
             uint32_t mismatch_at = 0xFFFFFFFFu;                      // line start of a lane whose name did not match the hint
@@ -499,7 +499,8 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                 if (!redo) {
                     build_list(0);
                     bool odd = false;                               // a start that does not follow a '\n'
-                    for (uint32_t j = lane; j < n_lines; j += 64) odd = odd || tile[(int)lstart[j] - 1] != 10u;
+                    if (n_lines <= 64) odd = lane < n_lines && tile[(int)lstart[lane] - 1] != 10u;
+                    else for (uint32_t j = lane; j < n_lines; j += 64) odd = odd || tile[(int)lstart[j] - 1] != 10u;
                     redo = __ballot(odd) != 0;
                 }
                 const bool listed = !redo;                          // the list of pass 0 is already in LDS
