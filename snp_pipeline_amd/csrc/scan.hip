@@ -443,7 +443,12 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                     for (int i = 0; i < 4; ++i) {
                         const uint4 v = tile16[i * 64 + lane];
                         any_hi |= v.x | v.y | v.z | v.w;
-                        bits[i] = flags_to_bits16(term_flags(v.x), term_flags(v.y), term_flags(v.z), term_flags(v.w));
+                        // the two SWAR adds on 8 bytes at a time (v_lshl_add_u64), the 3-input select per dword
+                        const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+                        const uint64_t la = lo + 0x7676767676767676ull, lb = lo + 0x7272727272727272ull;
+                        const uint64_t ha = hi + 0x7676767676767676ull, hb = hi + 0x7272727272727272ull;
+                        bits[i] = flags_to_bits16((uint32_t)la & ~(uint32_t)lb & 0x80808080u, (uint32_t)(la >> 32) & ~(uint32_t)(lb >> 32) & 0x80808080u,
+                                                  (uint32_t)ha & ~(uint32_t)hb & 0x80808080u, (uint32_t)(ha >> 32) & ~(uint32_t)(hb >> 32) & 0x80808080u);
                     }
                     S = (uint64_t)(bits[0] | (bits[1] << 16)) | ((uint64_t)(bits[2] | (bits[3] << 16)) << 32);
                 }
