@@ -845,7 +845,6 @@ static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const Sample
     uint32_t *d_todo_n = (uint32_t *)((char *)ws + ws_bytes + rows_bytes);      // [0]: after the 256-byte pass, [1]: after the 512-byte pass
     uint64_t *d_todo = (uint64_t *)((char *)ws + ws_bytes + rows_bytes + 256);
     uint64_t *d_todo2 = (uint64_t *)((char *)ws + ws_bytes + rows_bytes + 256 + list_bytes);
-    if (n_sites) HIP_TRY(ctx, hipMemsetAsync(d_site_line, 0, 8ull * n_sites * n, st));
     std::vector<SampleDev> samples(n);
     for (uint32_t i = 0; i < n; ++i) {
         samples[i].buf = io[i].d_pileup;
@@ -854,7 +853,8 @@ static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const Sample
         samples[i].wave0 = samples[i].n_waves = 0;
     }
     {
-        int rc = snpgpu_enqueue_scan(ctx, ss, samples, ws, d_site_line, want_depth);
+        // the scan's prepare kernel also zeroes the line-offset rows and the two leftover counters of the lane kernels
+        int rc = snpgpu_enqueue_scan(ctx, ss, samples, ws, d_site_line, want_depth, d_out_counts ? nullptr : d_todo_n, d_out_counts ? 0 : 2);
         if (rc) return rc;
     }
     if (n_sites) {
@@ -882,7 +882,6 @@ static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const Sample
         } else {
             // one lane per site: a 256-byte window for every site, a 512-byte window for what that left (deeper pileups),
             // then one wave per site for the rest
-            HIP_TRY(ctx, hipMemsetAsync(d_todo_n, 0, 8, st));
             ca.in_todo = nullptr;
             ca.in_todo_n = nullptr;
             ca.todo = d_todo;

@@ -68,7 +68,7 @@ struct SampleDev {
 };
 size_t snpgpu_scan_workspace_bytes(const snpgpu_ctx *ctx, uint32_t n_samples);
 int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<SampleDev> &h_samples, void *workspace,
-                        uint64_t *d_site_line, int want_depth);
+                        uint64_t *d_site_line, int want_depth, uint32_t *d_zero32, uint32_t n_zero32);
 #define SNPGPU_SCAN_MAX_BATCH 256   // samples per scan launch (each gets at least ~16 of the 4096 waves)
 
 int snpgpu_set_error(snpgpu_ctx *ctx, int code, const char *fmt, ...);

@@ -24,7 +24,7 @@
 // A line that fits neither (other contig, another digit count, odd whitespace, > 10 digits, names > 44 bytes) is
 // pushed on a device queue and finished by k_scan_queue with an exact byte-wise parser; if the queue overflows, the
 // kExact instantiation (every line through the exact parser) redoes the batch.  kExact also serves the depth-column
-// sum.  Line and match counts leave the kernel through per-wave slots (k_scan_init adds them up per sample):
+// sum.  Line and match counts leave the kernel through per-wave slots (k_scan_finish adds them up per sample):
 // same-address atomics from thousands of waves cost ~12 ns each and stall the loads behind them.
 #include <stdlib.h>
 
@@ -743,21 +743,30 @@ __global__ __launch_bounds__(256) void k_scan_queue(ScanArgs a, SiteSetDev ss) {
     }
 }
 
-// One workgroup per sample.  Phase 0: status words (+ queue control) before the scan.  Phase 1: add the per-wave
-// totals of the fast pass — dropped when the queue overflowed, because the exact pass recounts.  Phase 2: add the
-// totals of the exact pass (when it ran).
-__global__ __launch_bounds__(256) void k_scan_init(const SampleDev *samples, uint32_t *ctl, const uint64_t *totals, int phase, int want_depth) {
+// Before the scan, one launch: zero the line-offset rows of the batch, set every sample's status words, reset the queue
+// control words and whatever small counters the caller wants cleared (the leftover counts of the call kernels).
+__global__ __launch_bounds__(256) void k_scan_prepare(const SampleDev *samples, uint32_t n_samples, uint32_t *ctl, uint64_t *site_line,
+                                                      uint64_t n_rows_words, uint32_t *zero32, uint32_t n_zero32) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows_words; i += (uint64_t)gridDim.x * blockDim.x) site_line[i] = 0;
+    if (threadIdx.x == 0) {
+        for (uint32_t b = blockIdx.x; b < n_samples; b += gridDim.x) {
+            uint64_t *status = samples[b].status;
+            status[0] = ~0ull; status[1] = status[2] = status[3] = 0;
+        }
+        if (blockIdx.x == 0) {
+            ctl[0] = ctl[1] = 0;
+            for (uint32_t k = 0; k < n_zero32; ++k) zero32[k] = 0;
+        }
+    }
+}
+
+// After the scan, one workgroup per sample: add up the per-wave totals.  They are the fast pass's, or — when the queue
+// overflowed or the depth sum was asked for — the exact pass's, which then also replace what the queue kernel counted.
+__global__ __launch_bounds__(256) void k_scan_finish(const SampleDev *samples, const uint32_t *ctl, const uint64_t *totals) {
     __shared__ unsigned long long part[3][4];
     const SampleDev sd = samples[blockIdx.x];
     uint64_t *status = sd.status;
-    if (phase == 0) {
-        if (threadIdx.x == 0) { status[0] = ~0ull; status[1] = status[2] = status[3] = 0; }
-        if (threadIdx.x == 0 && blockIdx.x == 0) ctl[0] = ctl[1] = 0;
-        return;
-    }
     const bool overflow = ctl[1] != 0;
-    if (phase == 1 && overflow) { if (threadIdx.x == 0) status[1] = status[2] = 0; return; }
-    if (phase == 2 && !overflow && !want_depth) return;
     unsigned long long v[3] = {0, 0, 0};
     for (uint32_t w = threadIdx.x; w < sd.n_waves; w += blockDim.x)
         for (int k = 0; k < 3; ++k) v[k] += totals[3 * (size_t)(sd.wave0 + w) + k];
@@ -766,7 +775,11 @@ __global__ __launch_bounds__(256) void k_scan_init(const SampleDev *samples, uin
         if ((threadIdx.x & 63) == 0) part[k][threadIdx.x >> 6] = v[k];
     }
     __syncthreads();
-    if (threadIdx.x < 3) status[1 + threadIdx.x] += part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+    if (threadIdx.x < 3) {
+        const unsigned long long sum = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+        // [1] lines, [3] depth: only the wave kernels count them; [2] matches: the queue kernel added its own unless it was skipped
+        if (threadIdx.x == 1 && !overflow) status[2] += sum; else status[1 + threadIdx.x] = sum;
+    }
 }
 
 size_t snpgpu_scan_workspace_bytes(const snpgpu_ctx *ctx, uint32_t n_samples) {
@@ -774,9 +787,9 @@ size_t snpgpu_scan_workspace_bytes(const snpgpu_ctx *ctx, uint32_t n_samples) {
 }
 
 // Scans a batch of pileups with one launch.  h_samples[i].buf/nbytes/status are filled by the caller; the wave shares are
-// dealt here.  d_site_line is [n][n_sites] and must be zero.  `workspace` holds snpgpu_scan_workspace_bytes().
+// dealt here.  d_site_line is [n][n_sites] (zeroed here, together with the n_zero32 words at d_zero32).  `workspace` holds snpgpu_scan_workspace_bytes().
 int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<SampleDev> &h_samples, void *workspace,
-                        uint64_t *d_site_line, int want_depth) {
+                        uint64_t *d_site_line, int want_depth, uint32_t *d_zero32, uint32_t n_zero32) {
     hipStream_t st = ctx->stream;
     const uint32_t n = (uint32_t)h_samples.size();
     if (!n) return SNPGPU_OK;
@@ -854,7 +867,12 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<S
     sa.totals = (uint64_t *)((char *)workspace + ((size_t)(n + 1) * sizeof(SampleDev) + 255) / 256 * 256);
     sa.dbg = nullptr;
     const unsigned grid = (unsigned)((w0 + waves - 1) / waves), threads = (unsigned)waves * 64;
-    k_scan_init<<<n, 256, 0, st>>>(d_samples, ss->slow_ctl, sa.totals, 0, 0);
+    {
+        const uint64_t row_words = (uint64_t)n * ss->n_sites;
+        const uint64_t want_blocks = (row_words + 2047) / 2048 + 1, cap_blocks = (uint64_t)ctx->n_cu * 4;
+        k_scan_prepare<<<(unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks), 256, 0, st>>>(
+            d_samples, n, ss->slow_ctl, d_site_line, row_words, d_zero32, n_zero32);
+    }
     hipEvent_t ta = snpgpu_time_begin(ctx);
     if (want_depth) {
         k_scan_wave<true, 0><<<grid, threads, lds, st>>>(sa, ss->dev);
@@ -879,10 +897,9 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<S
     snpgpu_time_end(ctx, SNPGPU_K_SCAN, ta);
     if (!want_depth) {
         k_scan_queue<<<ctx->n_cu, 256, 0, st>>>(sa, ss->dev);
-        k_scan_init<<<n, 256, 0, st>>>(d_samples, ss->slow_ctl, sa.totals, 1, 0);
         k_scan_wave<true, 0><<<grid, threads, lds, st>>>(sa, ss->dev);   // returns at once unless the queue overflowed
     }
-    k_scan_init<<<n, 256, 0, st>>>(d_samples, ss->slow_ctl, sa.totals, 2, want_depth);
+    k_scan_finish<<<n, 256, 0, st>>>(d_samples, ss->slow_ctl, sa.totals);
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;
 }

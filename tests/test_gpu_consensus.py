@@ -450,3 +450,26 @@ def test_batch_groups_empty_and_tiny_samples(d):
         got = bytes(int(bh[i, j]) for j in order)
         assert got == want, i
         assert st[i, 0] == -1 and st[i, 1] == len(list(po.iter_lines(sm))), i
+
+
+def test_queue_overflow_takes_the_exact_pass(d):
+    """More lines than the slow-line queue holds (1 M) are separated by two TABs, which only the exact parser accepts: the
+    queue overflows and the exact instantiation of the scan redoes the file.  Counts, matches and calls must not change."""
+    from tests.gpu_util import gpu_consensus
+    n = 1_100_000
+    rng = random.Random(5)
+    keys = sorted({(b"ovf", rng.randrange(1, n + 1)) for _ in range(300)})
+    pos = np.arange(1, n + 1)
+    body = b"".join(b"ovf\t\t%d\tA\t2\t.,\tII\n" % p for p in range(1, n + 1))
+    cons, res, ss = gpu_consensus(d, body, keys, [], po.CallerParams(0, 0.6, 1, 0, 0.0), want_counts=False)
+    assert res.n_lines == n and res.n_matched == len(keys)
+    assert cons == b"A" * len(keys)
+    # the same file with ordinary separators (fast path) gives the same answer
+    cons2, res2, _ = gpu_consensus(d, body.replace(b"\t\t", b"\t"), keys, [], po.CallerParams(0, 0.6, 1, 0, 0.0), want_counts=False)
+    assert cons2 == cons and res2.n_lines == n and res2.n_matched == len(keys)
+    # and a malformed position far into the overflowing file is still reported
+    from snp_pipeline_amd.device import PileupFormatError
+    bad = body[:-20] + body[-20:].replace(b"\t\t11", b"\t\t1x")
+    assert bad != body
+    with pytest.raises(PileupFormatError):
+        gpu_consensus(d, bad, keys, [], po.CallerParams(0, 0.6, 1, 0, 0.0), want_counts=False)
