@@ -145,6 +145,66 @@ def record_vector(pileup, line, with_calls=True):
     return out
 
 
+def gen_file_runs(captured, specs, extra_sites=()):
+    """Whole files through the reference's own call_consensus driver.  specs: (seed, synth_pileup kwargs, params)."""
+    # --- whole-file runs through the reference's own call_consensus driver
+    from oracle import fuzz
+    from snppipeline import call_consensus as cc
+    from snppipeline import utils as ref_utils
+    runs = []
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    try:
+        for seed, kw, pset in specs:
+            data, refs, sites = fuzz.synth_pileup(seed, **kw)
+            rng = random.Random(seed)
+            # snplist: sites (+ some positions that have no pileup line, + one duplicate)
+            snps = list(sites)
+            snps.append((sites[0][0], 10_000_000))
+            if extra_sites:
+                snps = sorted(set(snps + [(sites[0][0], p) for p in extra_sites]))
+            snps.sort()
+            excluded = sorted(rng.sample(sites, max(1, len(sites) // 7)))
+            extra_excl = [(sites[0][0], 5), (sites[0][0], 6)]       # excluded but not in snplist
+            sdir = os.path.join(tmp, "sample%d" % seed)
+            os.makedirs(sdir)
+            ppath = os.path.join(sdir, "reads.all.pileup")
+            with open(ppath, "wb") as f:
+                f.write(data)
+            lpath = os.path.join(tmp, "snplist%d.txt" % seed)
+            with open(lpath, "w") as f:
+                for c, p in snps:
+                    f.write("%s\t%d\t1\tx\n" % (c.decode(), p))
+            epath = os.path.join(sdir, "excl.vcf")
+            with open(epath, "w") as f:
+                f.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n")
+                for c, p in excluded + extra_excl:
+                    f.write("%s\t%d\t.\tA\tC\t.\tPASS\t.\tGT\t1/1\n" % (c.decode(), p))
+            for use_excl in (False, True):
+                args = argparse.Namespace(
+                    snpListFile=lpath, allPileupFile=ppath, consensusFile=os.path.join(sdir, "consensus.fasta"),
+                    excludeFile=epath if use_excl else None, forceFlag=True, vcfFileName=None, vcfRefName="x",
+                    vcfAllPos=False, vcfPreserveRefCase=False, vcfFailedSnpGt=".", minBaseQual=pset[0],
+                    minConsFreq=pset[1], minConsDpth=pset[2], minConsStrdDpth=pset[3], minConsStrdBias=pset[4])
+                ref_utils.log_verbosity = 0
+                sink = io.StringIO()
+                old = sys.stdout
+                sys.stdout = sink
+                try:
+                    cc.call_consensus(args)
+                finally:
+                    sys.stdout = old
+                sid, seq = captured["last"]
+                runs.append({
+                    "seed": seed, "kw": {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()},
+                    "params": pset, "snplist": [[c.decode(), p] for c, p in snps],
+                    "excluded": [[c.decode(), p] for c, p in excluded + extra_excl] if use_excl else [],
+                    "sample": sid, "consensus": seq,
+                })
+    finally:
+        shutil.rmtree(tmp)
+    return runs
+
+
 def gen_pileup_vectors(captured):
     from snppipeline import pileup
     from oracle import fuzz
@@ -195,65 +255,14 @@ def gen_pileup_vectors(captured):
         thr[repr(f)] = [min(k for k in range(0, d + 2) if not (k < d * f)) for d in range(0, 400)]
     vec["freq_threshold"] = thr
 
-    # --- whole-file runs through the reference's own call_consensus driver
-    from snppipeline import call_consensus as cc
-    from snppipeline import utils as ref_utils
-    runs = []
-    tmp = tempfile.mkdtemp(prefix="golden_")
-    try:
-        for seed, kw, pset in [
-            (11, dict(genome_len=3000, n_sites=80), PARAM_SETS[1]),
-            (12, dict(genome_len=2500, n_sites=60, contigs=("ctgB", "ctgA", "ctgAA")), PARAM_SETS[2]),
-            (13, dict(genome_len=1500, n_sites=40, mean_depth=9), PARAM_SETS[0]),
-            (14, dict(genome_len=1200, n_sites=50, mean_depth=70), PARAM_SETS[3]),
-        ]:
-            data, refs, sites = fuzz.synth_pileup(seed, **kw)
-            rng = random.Random(seed)
-            # snplist: sites (+ some positions that have no pileup line, + one duplicate)
-            snps = list(sites)
-            snps.append((sites[0][0], 10_000_000))
-            snps.sort()
-            excluded = sorted(rng.sample(sites, max(1, len(sites) // 7)))
-            extra_excl = [(sites[0][0], 5), (sites[0][0], 6)]       # excluded but not in snplist
-            sdir = os.path.join(tmp, "sample%d" % seed)
-            os.makedirs(sdir)
-            ppath = os.path.join(sdir, "reads.all.pileup")
-            with open(ppath, "wb") as f:
-                f.write(data)
-            lpath = os.path.join(tmp, "snplist%d.txt" % seed)
-            with open(lpath, "w") as f:
-                for c, p in snps:
-                    f.write("%s\t%d\t1\tx\n" % (c.decode(), p))
-            epath = os.path.join(sdir, "excl.vcf")
-            with open(epath, "w") as f:
-                f.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n")
-                for c, p in excluded + extra_excl:
-                    f.write("%s\t%d\t.\tA\tC\t.\tPASS\t.\tGT\t1/1\n" % (c.decode(), p))
-            for use_excl in (False, True):
-                args = argparse.Namespace(
-                    snpListFile=lpath, allPileupFile=ppath, consensusFile=os.path.join(sdir, "consensus.fasta"),
-                    excludeFile=epath if use_excl else None, forceFlag=True, vcfFileName=None, vcfRefName="x",
-                    vcfAllPos=False, vcfPreserveRefCase=False, vcfFailedSnpGt=".", minBaseQual=pset[0],
-                    minConsFreq=pset[1], minConsDpth=pset[2], minConsStrdDpth=pset[3], minConsStrdBias=pset[4])
-                ref_utils.log_verbosity = 0
-                sink = io.StringIO()
-                old = sys.stdout
-                sys.stdout = sink
-                try:
-                    cc.call_consensus(args)
-                finally:
-                    sys.stdout = old
-                sid, seq = captured["last"]
-                runs.append({
-                    "seed": seed, "kw": {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()},
-                    "params": pset, "snplist": [[c.decode(), p] for c, p in snps],
-                    "excluded": [[c.decode(), p] for c, p in excluded + extra_excl] if use_excl else [],
-                    "sample": sid, "consensus": seq,
-                })
-    finally:
-        shutil.rmtree(tmp)
-    vec["runs"] = runs
+    vec["runs"] = gen_file_runs(captured, [
+        (11, dict(genome_len=3000, n_sites=80), PARAM_SETS[1]),
+        (12, dict(genome_len=2500, n_sites=60, contigs=("ctgB", "ctgA", "ctgAA")), PARAM_SETS[2]),
+        (13, dict(genome_len=1500, n_sites=40, mean_depth=9), PARAM_SETS[0]),
+        (14, dict(genome_len=1200, n_sites=50, mean_depth=70), PARAM_SETS[3]),
+    ])
     return vec
+
 
 
 def gen_steps_vectors():
@@ -443,6 +452,18 @@ def main():
     captured = install_stubs()
     if sys.argv[1:] == ["--only", "cli"]:
         dump("cli_vectors.json.gz", gen_cli_vectors())
+        return
+    if sys.argv[1:] == ["--only", "runs2"]:
+        # later additions: shapes the device kernels treat specially (512-byte lane window, long contig names,
+        # positions around the powers of ten), again through the reference's own driver
+        long_names = ("NODE_1_length_419034_cov_23.1", "scaffold_with_a_very_long_name_that_exceeds_44_bytes_000001", "c")
+        runs = gen_file_runs(captured, [
+            (15, dict(genome_len=900, n_sites=60, mean_depth=140), PARAM_SETS[0]),
+            (16, dict(genome_len=1500, n_sites=70, contigs=long_names), PARAM_SETS[1]),
+            (17, dict(genome_len=10400, n_sites=150), PARAM_SETS[2]),
+            (18, dict(genome_len=800, n_sites=50, mean_depth=220), PARAM_SETS[4]),
+        ], extra_sites=[p10 + d for p10 in (10, 100, 1000, 10000) for d in (-1, 0, 1)])
+        dump("pileup_runs2.json.gz", {"runs": runs})
         return
     dump("pileup_vectors.json.gz", gen_pileup_vectors(captured))
     dump("steps_vectors.json.gz", gen_steps_vectors())

@@ -72,16 +72,19 @@ def test_golden_error_lines_raise(d, pileup_vectors):
 
 
 def test_golden_whole_file_runs(d, pileup_vectors):
+    """Whole files that went through the reference's own call_consensus driver: the FASTA string, from both device paths."""
+    from tests.conftest import load_golden
     from tests.gpu_util import gpu_consensus
-    for run in pileup_vectors["runs"]:
+    for run in pileup_vectors["runs"] + load_golden("pileup_runs2.json.gz")["runs"]:
         kw = dict(run["kw"])
         if "contigs" in kw:
             kw["contigs"] = tuple(kw["contigs"])
         data, _, _ = fuzz.synth_pileup(run["seed"], **kw)
         snps = [(c.encode(), p) for c, p in run["snplist"]]
         excl = [(c.encode(), p) for c, p in run["excluded"]]
-        cons, _, _ = gpu_consensus(d, data, snps, excl, po.CallerParams(*run["params"]))
-        assert cons.decode() == run["consensus"], run["seed"]
+        for want_counts in (True, False):
+            cons, _, _ = gpu_consensus(d, data, snps, excl, po.CallerParams(*run["params"]), want_counts=want_counts)
+            assert cons.decode() == run["consensus"], (run["seed"], want_counts)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
