@@ -559,18 +559,27 @@ __global__ __launch_bounds__(kWaves * 64) void k_call_lanes(CallArgs a) {
             const bool open = !done;                             // (the slots of the others hold stale bytes up there)
             uint32_t mw[2] = {0, 0}, mt[2] = {0, 0};
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                uint32_t w = slot[16 * blk + j];
-                if (blk == 0 && j < 4) {                         // bytes before the line start read as spaces
-                    const uint32_t nb = o > 4u * j ? min(o - 4u * j, 4u) : 0u;
-                    const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
-                    w = (w & ~m) | (0x20202020u & m);
+            for (int jp = 0; jp < 8; ++jp) {                     // 8 bytes per step: the SWAR adds are 64-bit (v_lshl_add_u64)
+                uint32_t w2[2] = {slot[16 * blk + 2 * jp], slot[16 * blk + 2 * jp + 1]};
+                if (blk == 0 && jp < 2) {                        // bytes before the line start read as spaces
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t j = 2 * jp + h;
+                        const uint32_t nb = o > 4u * j ? min(o - 4u * j, 4u) : 0u;
+                        const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+                        w2[h] = (w2[h] & ~m) | (0x20202020u & m);
+                    }
                 }
-                const uint32_t ge14 = w + 0x72727272u;           // bit 7 of a byte: byte >= 14 (input is ASCII)
-                const uint32_t f_ws = (((w + 0x77777777u) & ~ge14) | ((w + 0x64646464u) & ~(w + 0x5F5F5F5Fu))) & 0x80808080u;   // 9..13, 28..32
-                const uint32_t f_t = (w + 0x76767676u) & ~ge14 & 0x80808080u;                                                 // 10..13
-                mw[j >> 3] |= __builtin_amdgcn_udot4(f_ws >> 7, 0x08040201u, 0u, false) << (4 * (j & 7));
-                mt[j >> 3] |= __builtin_amdgcn_udot4(f_t >> 7, 0x08040201u, 0u, false) << (4 * (j & 7));
+                const uint64_t W = (uint64_t)w2[0] | ((uint64_t)w2[1] << 32);
+                // bit 7 of a byte of W + (0x80 - t): byte >= t (input is ASCII)
+                const uint64_t ge9 = W + 0x7777777777777777ull, ge14 = W + 0x7272727272727272ull, ge10 = W + 0x7676767676767676ull;
+                const uint64_t ge28 = W + 0x6464646464646464ull, ge33 = W + 0x5F5F5F5F5F5F5F5Full;
+                const uint64_t f_ws = ((ge9 & ~ge14) | (ge28 & ~ge33)) & 0x8080808080808080ull;        // 9..13, 28..32
+                const uint64_t f_t = ge10 & ~ge14 & 0x8080808080808080ull;                              // 10..13
+                const uint32_t bw = __builtin_amdgcn_udot4((uint32_t)(f_ws >> 32), 0x80402010u, __builtin_amdgcn_udot4((uint32_t)f_ws, 0x08040201u, 0u, false), false) >> 7;
+                const uint32_t bt = __builtin_amdgcn_udot4((uint32_t)(f_t >> 32), 0x80402010u, __builtin_amdgcn_udot4((uint32_t)f_t, 0x08040201u, 0u, false), false) >> 7;
+                mw[jp >> 2] |= bw << (8 * (jp & 3));
+                mt[jp >> 2] |= bt << (8 * (jp & 3));
             }
             Wm[blk] = open ? (uint64_t)mw[0] | ((uint64_t)mw[1] << 32) : ~0ull;     // past the end of a line: separators
             Tm[blk] = open ? (uint64_t)mt[0] | ((uint64_t)mt[1] << 32) : 0ull;
