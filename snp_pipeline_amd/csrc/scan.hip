@@ -275,7 +275,8 @@ template <bool kExact, int kTime>
 __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     extern __shared__ uint4 scan_lds[];
     ScanShared &sh = *(ScanShared *)scan_lds;
-    if (kExact && !a.want_depth && a.ctl[1] == 0) return;    // fallback pass: only when the slow-line queue overflowed
+    constexpr bool kDepth = kTime == 4;                      // also add up the depth column (collect_metrics by-product)
+    if (kExact && a.ctl[1] == 0) return;                     // fallback pass: only when the slow-line queue overflowed
     if ((uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) >= a.samples[a.n_samples].wave0) return;   // spare wave
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -599,6 +600,27 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             pos = (uint32_t)pos64;
                             nd_seen = bad == 0 ? nd : 0u;
                             }
+                            if (kDepth) {
+                                // 4th column (collect_metrics.py:325-340 sums int(tokens[3]) over the lines that have one):
+                                // after the position's separator come one reference byte, a separator, 1..4 digits and a
+                                // separator or the end of the line.  Anything else sends the line to the exact parser.
+                                const uint32_t nd_here = nd_seen;                        // digits of the position (0: line is bad anyway)
+                                uint32_t d0, d1, d2, d3;
+                                lds_window16(tile, (int)(s + L + 1 + nd_here), d0, d1, d2, d3);   // [sep2][ref][sep][digits ...]
+                                (void)d2; (void)d3;
+                                const uint32_t c2d = d0 & 0xFFu, refb = (d0 >> 8) & 0xFFu, sepb = (d0 >> 16) & 0xFFu;
+                                const uint32_t x = (d0 >> 24) | (d1 << 8);               // the four bytes after that separator
+                                const uint32_t after4 = d1 >> 24;                        // ... and the fifth
+                                const uint32_t ctl4 = __builtin_amdgcn_udot4(le20_flags(x), 0x08040201u, 0u, false) >> 7;
+                                const uint32_t k = ctl4 ? (uint32_t)__ffs((int)ctl4) - 1u : 4u;  // digits before the first byte <= 0x20
+                                const uint32_t xm = (x ^ 0x30303030u) & (k >= 4 ? 0xFFFFFFFFu : ((1u << (8 * k)) - 1u));
+                                const bool digits_ok = ((((xm + 0x76767676u) | xm) & 0x80808080u) == 0) && k >= 1 && (k < 4 || after4 <= 0x20u);
+                                const bool shape_ok = refb > 0x20u && (sepb == 9u || sepb == 32u) && digits_ok;
+                                if (active && nd_here != 0 && c2d != 10u) {              // the line goes on after the position
+                                    if (shape_ok) depth_acc += four_digits(k >= 4 ? xm : xm << (8 * (4 - k)));
+                                    else bad |= 1u;                                      // exact parser: any ref field, any depth
+                                }
+                            }
                             const uint64_t off1 = t0 + (uint64_t)s - f.lo + 1;
                             if (active && bad != 0) {                                    // rare: leave it to k_scan_queue
                                 const uint32_t qi = atomicAdd(&a.ctl[0], 1u);
@@ -716,7 +738,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     // a byte >= 0x80 anywhere in this wave's share of the file (checked once: the answers are void anyway)
     if (__ballot((any_hi & 0x80808080u) != 0) && lane == 0) report_scan_error(f.status, 0, SCAN_ERR_NON_ASCII);
     for (int o = 32; o; o >>= 1) { hits += __shfl_xor(hits, o); lines_seen += __shfl_xor(lines_seen, o); }
-    if (kExact && a.want_depth)
+    if ((kExact && a.want_depth) || kDepth)
         for (int o = 32; o; o >>= 1) depth_acc += __shfl_xor(depth_acc, o);
     if (lane == 0) { a.totals[3 * gwave] = lines_seen; a.totals[3 * gwave + 1] = hits; a.totals[3 * gwave + 2] = depth_acc; }
 }
@@ -729,8 +751,9 @@ __global__ __launch_bounds__(256) void k_scan_queue(ScanArgs a, SiteSetDev ss) {
         const uint64_t e = a.queue[i], off = e & ((1ull << 40) - 1);
         const ScanFile f = scan_file(a, (uint32_t)(e >> 40));
         TileView tv{nullptr, f.base + f.lo, 0, f.hi - f.lo, 0};   // lds_limit 0: every byte comes from global memory
-        SlowLine sl = parse_line_slow(tv, (int64_t)off, 0);
+        SlowLine sl = parse_line_slow(tv, (int64_t)off, a.want_depth);
         if (sl.err) { report_scan_error(f.status, off, sl.err); continue; }
+        if (sl.depth) atomicAdd((unsigned long long *)&f.status[3], (unsigned long long)sl.depth);
         const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, sl.f0, sl.f0len) : 0xFFFFFFFFu;
         if (cid == 0xFFFFFFFFu || sl.pos > (uint64_t)ss.max_pos[cid]) continue;
         const uint64_t bit = ss.bit_off[cid] + (uint32_t)sl.pos;
@@ -777,8 +800,8 @@ __global__ __launch_bounds__(256) void k_scan_finish(const SampleDev *samples, c
     __syncthreads();
     if (threadIdx.x < 3) {
         const unsigned long long sum = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
-        // [1] lines, [3] depth: only the wave kernels count them; [2] matches: the queue kernel added its own unless it was skipped
-        if (threadIdx.x == 1 && !overflow) status[2] += sum; else status[1 + threadIdx.x] = sum;
+        // [1] lines: only the wave kernels count them; [2] matches, [3] depth: the queue kernel added its own unless it was skipped
+        if (threadIdx.x >= 1 && !overflow) status[1 + threadIdx.x] += sum; else status[1 + threadIdx.x] = sum;
     }
 }
 
@@ -806,7 +829,7 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<S
         mode = m ? atoi(m) : 0;
         if (w && atoi(w) >= 1 && atoi(w) <= 16) waves = atoi(w);
         for (auto f : {(const void *)k_scan_wave<false, 0>, (const void *)k_scan_wave<false, 1>, (const void *)k_scan_wave<false, 2>,
-                       (const void *)k_scan_wave<false, 3>, (const void *)k_scan_wave<true, 0>})
+                       (const void *)k_scan_wave<false, 3>, (const void *)k_scan_wave<false, 4>, (const void *)k_scan_wave<true, 0>})
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     // Exactly blocks_per_cu workgroups fit on a CU (the LDS request is padded to make sure) and a full grid is
@@ -875,7 +898,7 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<S
     }
     hipEvent_t ta = snpgpu_time_begin(ctx);
     if (want_depth) {
-        k_scan_wave<true, 0><<<grid, threads, lds, st>>>(sa, ss->dev);
+        k_scan_wave<false, 4><<<grid, threads, lds, st>>>(sa, ss->dev);  // the same parse + the 4th column
     } else if (mode == 7) {                                 // tuning: LDS-DMA streaming rate without any parsing
         k_scan_wave<false, 3><<<grid, threads, lds, st>>>(sa, ss->dev);
     } else if (mode == 8 || mode == 9) {                    // tuning: per-wave time stamps (9) + phase cycle counts (8)
@@ -895,10 +918,8 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<S
         k_scan_wave<false, 0><<<grid, threads, lds, st>>>(sa, ss->dev);
     }
     snpgpu_time_end(ctx, SNPGPU_K_SCAN, ta);
-    if (!want_depth) {
-        k_scan_queue<<<ctx->n_cu, 256, 0, st>>>(sa, ss->dev);
-        k_scan_wave<true, 0><<<grid, threads, lds, st>>>(sa, ss->dev);   // returns at once unless the queue overflowed
-    }
+    k_scan_queue<<<ctx->n_cu, 256, 0, st>>>(sa, ss->dev);
+    k_scan_wave<true, 0><<<grid, threads, lds, st>>>(sa, ss->dev);       // returns at once unless the queue overflowed
     k_scan_finish<<<n, 256, 0, st>>>(d_samples, ss->slow_ctl, sa.totals);
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;

@@ -164,8 +164,10 @@ class Device(object):
             code, off = w0 & 0xFF, (w0 >> 8) - 1
             raise PileupFormatError("pileup: %s at byte offset %d" % (_SCAN_CODES.get(code, "malformed line"), off))
 
-    def call_consensus(self, siteset, pileup, params, want_counts=False, want_depth_sum=False):
-        """pileup: bytes-like (host).  Returns ConsensusResult over siteset.keys order."""
+    def call_consensus(self, siteset, pileup, params, want_counts=False, want_depth_sum=False, check=True):
+        """pileup: bytes-like (host).  Returns ConsensusResult over siteset.keys order.  check=False: do not raise for
+        the per-site failures the reference raises on (malformed line at a listed position); the scan-level errors
+        (malformed chrom / position column anywhere in the file) always raise."""
         buf = np.frombuffer(pileup, dtype=np.uint8)
         n = len(siteset)
         bases = np.empty(n, dtype=np.uint8)
@@ -179,7 +181,8 @@ class Device(object):
             self.raise_scan_status(status)
         self._check(rc)
         res = ConsensusResult(bases, filters, counts, status)
-        self.raise_site_status(res)
+        if check:
+            self.raise_site_status(res)
         return res
 
     @staticmethod
