@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SNPGPU_ABI_VERSION 1
+#define SNPGPU_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------- */
 #define SNPGPU_OK            0
@@ -34,6 +34,7 @@ extern "C" {
 #define SNPGPU_E_NOMEM      -3
 #define SNPGPU_E_PILEUP     -4   /* malformed pileup text; see snpgpu_scan_status */
 #define SNPGPU_E_UNSUPPORTED -5  /* input the reference accepts but this build refuses (reported loudly) */
+#define SNPGPU_E_IO         -6   /* a pileup file could not be opened or read */
 
 /* ---- failed-filter bits, in the order pileup.py:564-584 appends them and
  *      call_consensus.py:165-168 appends "Region" ------------------------- */
@@ -100,6 +101,7 @@ typedef struct snpgpu_site_counts {
 
 /* ---- context ------------------------------------------------------------ */
 int  snpgpu_abi_version(void);
+int  snpgpu_device_count(void);   /* visible gfx950 devices (0 when there is no usable HIP runtime); creates no context */
 int  snpgpu_ctx_create(int device, snpgpu_ctx **out);
 void snpgpu_ctx_destroy(snpgpu_ctx *ctx);
 const char *snpgpu_last_error(const snpgpu_ctx *ctx);
@@ -149,11 +151,61 @@ int  snpgpu_call_consensus_batch_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, 
                                      const uint64_t *h_offsets, const uint64_t *h_sizes, uint32_t n_samples,
                                      const snpgpu_caller_params *params, uint8_t *d_out_base,
                                      uint8_t *d_out_filters, uint64_t *d_status);
-/* Host-buffer form (copies the pileup to the device, runs, copies results back, synchronous).
+/* Host-buffer form for one pileup (an mmap, bytes read elsewhere): streamed through the same pipeline as
+ * snpgpu_call_consensus_files below, synchronous.
  * Returns SNPGPU_E_PILEUP when the scan found a malformed line (status words still filled). */
 int  snpgpu_call_consensus(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *pileup, size_t nbytes,
                            const snpgpu_caller_params *params, uint8_t *out_base, uint8_t *out_filters,
                            snpgpu_site_counts *out_counts, uint64_t *out_status, int want_depth_sum);
+/* ---- streamed ingestion: pileup FILES -> consensus bytes --------------------------------------------------
+ * Replaces the reference's input side of call_consensus: the text-mode line iterator over the open pileup
+ * (pileup.py:408-429, driven from call_consensus.py:161) and the one-process-per-sample job array around it
+ * (run.py:704-718).  Reader threads pread() the files in chunks of whole 4 KiB scan tiles into pinned staging
+ * buffers, a copy stream moves each chunk into the file's device buffer, and the scan runs over the tiles that
+ * have landed while the rest of the file is still on its way; the exact parser's queue and the call step run
+ * when the file is complete.  Files alternate between device buffers, so the next file streams in during the
+ * tail of the previous one.  No file is ever resident in host memory as a whole.
+ *
+ * Outputs are [n_files][n_sites] row-major HOST arrays: out_base / out_filters as snpgpu_call_consensus_dev,
+ * out_counts (nullable) the per-site records, out_line_off (nullable) 1 + byte offset of the line used for
+ * each site (0 = none), out_status [n_files][4] the scan status words, out_rc (nullable) per file: 0,
+ * SNPGPU_E_IO (could not open / read: its outputs are void), SNPGPU_E_PILEUP or SNPGPU_E_UNSUPPORTED (malformed
+ * pileup: see its status words).  The return value is 0 unless the pipeline itself failed. */
+typedef struct snpgpu_stream_opts {      /* 0 = default everywhere */
+    uint32_t chunk_bytes;                /* bytes per host->device copy (default 8 MiB; rounded up to 4 KiB) */
+    uint32_t n_staging;                  /* pinned staging buffers (default: readers + 4) */
+    uint32_t n_readers;                  /* reader threads (default: 12 on a big host, fewer on a small one) */
+    uint32_t n_slots;                    /* device file buffers = files in flight (default 2) */
+    uint32_t want_depth_sum;             /* also accumulate status[3] (collect_metrics.py:325-340 by-product) */
+    uint32_t reserved[3];
+} snpgpu_stream_opts;
+typedef struct snpgpu_stream_stats {
+    uint64_t bytes;                      /* pileup bytes that went through */
+    uint64_t n_chunks;
+    double   seconds;                    /* wall time of the call */
+    double   seconds_waiting_for_readers;/* ... of which the issuing thread waited for a chunk to be read */
+    double   seconds_waiting_for_device; /* ... and for the device to finish a file */
+    uint32_t n_readers, n_staging, chunk_bytes, reserved;
+    double   reader_seconds_reading;     /* summed over the reader threads: inside pread / memcpy */
+    double   reader_seconds_waiting;     /* ... waiting for a staging buffer to be copied out */
+    double   seconds_enqueueing;         /* issuing thread: inside HIP enqueue calls (copies, events, kernels) */
+} snpgpu_stream_stats;
+int  snpgpu_call_consensus_files(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const char *const *paths, uint32_t n_files,
+                                 const snpgpu_caller_params *params, uint8_t *out_base, uint8_t *out_filters,
+                                 snpgpu_site_counts *out_counts, uint64_t *out_line_off, uint64_t *out_status,
+                                 int32_t *out_rc, const snpgpu_stream_opts *opts, snpgpu_stream_stats *stats);
+
+/* call_consensus --vcfAllPos (call_consensus.py:148-151, pileup.py:418-421): a Record for EVERY line of the pileup,
+ * whether its position is listed or not.  Synchronous; host outputs in file order: out_line_off[i] = 1 + byte offset of
+ * line i, out_line_flags[i] = SNPGPU_SITE_* of its position (0 when it is not in the site set), out_counts[i] its
+ * record (filters include REGION for excluded positions).  *out_n_lines is always set; when it exceeds `capacity`
+ * nothing else is written and the caller comes back with larger arrays (capacity 0 just counts the lines).
+ * out_status[4]: [0] first line whose chrom / position columns are malformed (else UINT64_MAX), [1] lines. */
+int  snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const char *path,
+                                const snpgpu_caller_params *params, uint64_t capacity, uint64_t *out_n_lines,
+                                uint64_t *out_line_off, uint8_t *out_line_flags, snpgpu_site_counts *out_counts,
+                                uint64_t *out_status);
+
 /* After a call_consensus on `ss`: for every site, 1 + the byte offset of the pileup line that was used (0 = no
  * line).  consensus.vcf rows are written in pileup order (call_consensus.py:161-180), which this recovers.
  * out_line_off[n_sites] is a HOST pointer; synchronous. */

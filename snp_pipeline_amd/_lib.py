@@ -12,7 +12,7 @@ SCAN_STATUS_WORDS = 4
 F_RAWDPTH, F_VARFREQ, F_DEPTH, F_STRDPTH, F_STRBIAS, F_REGION = 1, 2, 4, 8, 16, 32
 SITE_IN_SNPLIST, SITE_EXCLUDED = 1, 2
 ST_NO_LINE, ST_OK, ST_SHORT_LINE, ST_BAD_DEPTH, ST_NO_QUALS, ST_MULTI_REF = 0, 1, 2, 3, 4, 5
-E_HIP, E_ARG, E_NOMEM, E_PILEUP, E_UNSUPPORTED = -1, -2, -3, -4, -5
+E_HIP, E_ARG, E_NOMEM, E_PILEUP, E_UNSUPPORTED, E_IO = -1, -2, -3, -4, -5, -6
 
 
 class CallerParams(C.Structure):
@@ -35,12 +35,26 @@ class SynthParams(C.Structure):
                 ("carrier_p_other_clade", C.c_float), ("n_clades", C.c_uint32), ("contig", C.c_char * 32)]
 
 
+class StreamOpts(C.Structure):
+    _fields_ = [("chunk_bytes", C.c_uint32), ("n_staging", C.c_uint32), ("n_readers", C.c_uint32),
+                ("n_slots", C.c_uint32), ("want_depth_sum", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+class StreamStats(C.Structure):
+    _fields_ = [("bytes", C.c_uint64), ("n_chunks", C.c_uint64), ("seconds", C.c_double),
+                ("seconds_waiting_for_readers", C.c_double), ("seconds_waiting_for_device", C.c_double),
+                ("n_readers", C.c_uint32), ("n_staging", C.c_uint32), ("chunk_bytes", C.c_uint32),
+                ("reserved", C.c_uint32), ("reader_seconds_reading", C.c_double),
+                ("reader_seconds_waiting", C.c_double), ("seconds_enqueueing", C.c_double)]
+
+
 assert C.sizeof(SiteCounts) == 128 and C.sizeof(CallerParams) == 32
 
 # name -> (restype, argtypes); every exported symbol of include/snpgpu.h
 _P = C.c_void_p
 SIGNATURES = {
     "snpgpu_abi_version": (C.c_int, []),
+    "snpgpu_device_count": (C.c_int, []),
     "snpgpu_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "snpgpu_ctx_destroy": (None, [_P]),
     "snpgpu_last_error": (C.c_char_p, [_P]),
@@ -57,6 +71,10 @@ SIGNATURES = {
     "snpgpu_call_consensus_dev": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(CallerParams), _P, _P, _P, _P, C.c_int]),
     "snpgpu_call_consensus_batch_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint32, C.POINTER(CallerParams), _P, _P, _P]),
     "snpgpu_call_consensus": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(CallerParams), _P, _P, _P, _P, C.c_int]),
+    "snpgpu_call_consensus_files": (C.c_int, [_P, _P, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(CallerParams), _P, _P,
+                                              _P, _P, _P, _P, C.POINTER(StreamOpts), C.POINTER(StreamStats)]),
+    "snpgpu_call_all_lines_file": (C.c_int, [_P, _P, C.c_char_p, C.POINTER(CallerParams), C.c_uint64, C.POINTER(C.c_uint64),
+                                             _P, _P, _P, _P]),
     "snpgpu_siteset_line_offsets": (C.c_int, [_P, _P, _P]),
     "snpgpu_packed_row_bytes": (C.c_size_t, [C.c_uint32]),
     "snpgpu_pack_matrix_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_size_t, _P]),

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libsnpgpu.so")
-SOURCES = ["ctx.hip", "scan.hip", "consensus.hip", "distance.hip", "regions.hip", "synth.hip"]
+SOURCES = ["ctx.hip", "scan.hip", "consensus.hip", "stream.hip", "distance.hip", "regions.hip", "synth.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
          "-Wno-unused-result"]
 
@@ -23,13 +23,19 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def _flags():
+    # SNPGPU_TUNING=1 builds the development instantiations of the scan kernel (per-wave time stamps, stream-only mode)
+    # and their SNPGPU_SCAN_* environment knobs into a library for tools/; the product library never contains them.
+    return FLAGS + (["-DSNPGPU_TUNING"] if os.environ.get("SNPGPU_TUNING") == "1" else [])
+
+
 def _stamp():
     h = hashlib.sha256()
     for name in sorted(os.listdir(CSRC)) + ["../../include/snpgpu.h"]:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode())
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(_flags()).encode())
     return h.hexdigest()
 
 
@@ -46,7 +52,7 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + _flags() + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stdout))
@@ -54,7 +60,7 @@ def build(force=False, verbose=True):
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stdout)

@@ -2,12 +2,18 @@
 
 Host mirror of snppipeline/call_consensus.py:18-192.  Argument handling, input checks, freshness and the FASTA/VCF
 writers live here; reading the pileup, the per-position base counting and the caller's filters run in the HIP
-kernels (csrc/scan.hip, csrc/consensus.hip) behind ``Device.call_consensus``.
+kernels (csrc/scan.hip, csrc/consensus.hip) behind ``Device.call_consensus_files``: the pileup FILE is streamed to the
+device in chunks (csrc/stream.hip) and scanned while it arrives; it is never resident in host memory.
+
+``call_consensus_batch`` is the same step for every sample of a sampleDirsFile in ONE process: what run.py:704-718
+starts as an array of per-sample processes becomes one stream of files per visible GPU (samples dealt round-robin).
 """
 from __future__ import print_function
 
-import mmap
 import os
+import threading
+
+import numpy as np
 
 from . import _lib as L
 from . import device as devmod
@@ -15,20 +21,70 @@ from . import utils
 from . import vcf_writer
 
 
-def consensus_for_sample(dev, pileup_bytes, snp_list, excluded_positions, params, want_counts=False, extra_positions=None):
-    """snp_list: [(chrom str, pos int)] in snplist order; excluded_positions: set of the same.
-    Returns (consensus str in snplist order, SiteSet, ConsensusResult)."""
+def build_siteset(dev, snp_list, excluded_positions):
+    """snp_list: [(chrom str, pos int)] in snplist order; excluded_positions: set of the same.  Returns (SiteSet, the
+    number of snplist keys): slots [0, n) of ``index_of`` are the snplist positions in order."""
     keys = [(c.encode(), p) for c, p in snp_list]
     snps = set(keys)
     excl = {(c.encode(), p) for c, p in excluded_positions}
     extra = [k for k in sorted(excl) if k not in snps]
     all_keys = keys + extra
     flags = [(L.SITE_IN_SNPLIST if k in snps else 0) | (L.SITE_EXCLUDED if k in excl else 0) for k in all_keys]
-    ss = dev.siteset(all_keys, flags)
+    return dev.siteset(all_keys, flags), len(keys)
+
+
+def consensus_string(ss, n_keys, res):
+    idx = ss.index_of[:n_keys]
+    picked = np.where(idx >= 0, res.bases[np.maximum(idx, 0)], 0x2D).astype(np.uint8)
+    return picked.tobytes().decode("ascii")
+
+
+def consensus_for_sample(dev, pileup_bytes, snp_list, excluded_positions, params, want_counts=False):
+    """Host-buffer form (tests, bench): returns (consensus str in snplist order, SiteSet, ConsensusResult)."""
+    ss, n_keys = build_siteset(dev, snp_list, excluded_positions)
     res = dev.call_consensus(ss, pileup_bytes, params, want_counts=want_counts)
-    idx = ss.index_of[:len(keys)]
-    consensus = bytes(int(res.bases[i]) if i >= 0 else 0x2D for i in idx).decode("ascii")
-    return consensus, ss, res
+    return consensus_string(ss, n_keys, res), ss, res
+
+
+def _raise_as_reference(err):
+    """Re-raise a device-detected malformed pileup as the exception class the reference raises for it, so that the
+    error log names the same exception type (utils.handle_sample_exception prints ``exc_type.__name__``)."""
+    exc = getattr(err, "reference_exception", None)
+    if exc is None:
+        raise err
+    raise exc(str(err))
+
+
+class _Plan(object):
+    """Everything call_consensus.py:100-140 derives from the arguments of one sample."""
+
+    def __init__(self, args, all_pileup_file_path, consensus_file_path, exclude_file_path):
+        self.args = args
+        self.pileup_path = all_pileup_file_path
+        self.consensus_path = consensus_file_path
+        self.exclude_path = exclude_file_path
+        self.sample_name = os.path.basename(os.path.dirname(os.path.abspath(all_pileup_file_path)))
+        consensus_file_dir = os.path.dirname(os.path.abspath(consensus_file_path))
+        self.vcf_path = os.path.join(consensus_file_dir, args.vcfFileName) if args.vcfFileName else None
+        self.excluded = set()
+
+
+def _write_outputs(plan, dev, ss, n_keys, res):
+    args = plan.args
+    in_snplist = (ss.flags & L.SITE_IN_SNPLIST) != 0
+    utils.verbose_print("called consensus positions = %i" % int(((res.counts["status"] != L.ST_NO_LINE) & in_snplist).sum()))
+    if plan.vcf_path:
+        if args.vcfAllPos:
+            params = devmod.make_params(args.minBaseQual, args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
+            try:
+                line_off, _, counts = dev.call_all_lines(ss, plan.pileup_path, params, capacity=res.n_lines)
+            except devmod.PileupFormatError as err:
+                _raise_as_reference(err)
+            vcf_writer.write_all_positions_vcf(plan.vcf_path, plan.sample_name, args, plan.pileup_path, line_off, counts)
+        else:
+            vcf_writer.write_consensus_vcf(plan.vcf_path, plan.sample_name, args, ss, res, res.line_offsets)
+    with open(plan.consensus_path, "w") as fasta_file_object:
+        utils.write_fasta_record(fasta_file_object, plan.sample_name, consensus_string(ss, n_keys, res))
 
 
 def call_consensus(args):
@@ -38,12 +94,7 @@ def call_consensus(args):
 
     snp_list_file_path = args.snpListFile
     all_pileup_file_path = args.allPileupFile
-    sample_directory = os.path.dirname(os.path.abspath(all_pileup_file_path))
-    sample_name = os.path.basename(sample_directory)
-    consensus_file_path = args.consensusFile
-    consensus_file_dir = os.path.dirname(os.path.abspath(consensus_file_path))
-    vcf_file_name = args.vcfFileName
-    vcf_file_path = os.path.join(consensus_file_dir, vcf_file_name) if vcf_file_name else None
+    plan = _Plan(args, all_pileup_file_path, args.consensusFile, args.excludeFile)
 
     if utils.verify_existing_input_files("Snplist file", [snp_list_file_path]) > 0:
         utils.global_error("Error: cannot call consensus without the snplist file.")
@@ -51,37 +102,112 @@ def call_consensus(args):
         utils.sample_error("Error: cannot call consensus without the pileup file.", continue_possible=False)
     source_files = [snp_list_file_path, all_pileup_file_path]
 
-    exclude_file_path = args.excludeFile
-    if exclude_file_path:
-        if utils.verify_existing_input_files("Exclude file", [exclude_file_path]) > 0:
+    if plan.exclude_path:
+        if utils.verify_existing_input_files("Exclude file", [plan.exclude_path]) > 0:
             utils.sample_error("Error: cannot call consensus without the file of excluded positions.", continue_possible=False)
-        excluded_positions = utils.convert_vcf_file_to_snp_set(exclude_file_path)
-        source_files.append(exclude_file_path)
-    else:
-        excluded_positions = set()
+        plan.excluded = utils.convert_vcf_file_to_snp_set(plan.exclude_path)
+        source_files.append(plan.exclude_path)
 
-    if not args.forceFlag and not utils.target_needs_rebuild(source_files, consensus_file_path):
-        utils.verbose_print("Consensus call file %s has already been freshly built.  Use the -f option to force a rebuild." % consensus_file_path)
+    if not args.forceFlag and not utils.target_needs_rebuild(source_files, plan.consensus_path):
+        utils.verbose_print("Consensus call file %s has already been freshly built.  Use the -f option to force a rebuild." % plan.consensus_path)
         return
 
     snp_list = utils.read_snp_position_list(snp_list_file_path)
     utils.verbose_print("snp position list length = %d" % len(snp_list))
-    utils.verbose_print("excluded snps list length = %d" % len(excluded_positions))
-    utils.verbose_print("total snp position list length = %d" % (len(snp_list) + len(excluded_positions)))
-
-    if args.vcfAllPos and vcf_file_name:
-        utils.global_error("Error: --vcfAllPos is not provided by the MI355X build (diagnostic option of the reference).")
+    utils.verbose_print("excluded snps list length = %d" % len(plan.excluded))
+    utils.verbose_print("total snp position list length = %d" % (len(snp_list) + len(plan.excluded)))
 
     params = devmod.make_params(args.minBaseQual, args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
     dev = devmod.default_device()
-    with open(all_pileup_file_path, "rb") as f:
-        with mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
-            consensus, ss, res = consensus_for_sample(dev, mm, snp_list, excluded_positions, params, want_counts=True)
-    in_snplist = (ss.flags & L.SITE_IN_SNPLIST) != 0
-    utils.verbose_print("called consensus positions = %i" % int(((res.counts["status"] != L.ST_NO_LINE) & in_snplist).sum()))
+    ss, n_keys = build_siteset(dev, snp_list, plan.excluded)
+    results, rcs, _ = dev.call_consensus_files(ss, [all_pileup_file_path], params, want_counts=True, want_line_offsets=True)
+    try:
+        dev.raise_file_status(all_pileup_file_path, int(rcs[0]), results[0])
+    except devmod.PileupFormatError as err:
+        _raise_as_reference(err)
+    _write_outputs(plan, dev, ss, n_keys, results[0])
 
-    if vcf_file_name:
-        vcf_writer.write_consensus_vcf(vcf_file_path, sample_name, args, ss, res, dev.line_offsets(ss))
 
-    with open(consensus_file_path, "w") as fasta_file_object:
-        utils.write_fasta_record(fasta_file_object, sample_name, consensus)
+def call_consensus_batch(args):
+    """``cfsan_snp_pipeline call_consensus_batch`` — an extension of this build, not a reference subcommand: the
+    call_consensus step of run.py:704-718 for every sample directory listed in sampleDirsFile, in one process.  The
+    options are call_consensus's; ``-o`` / ``-e`` / ``--pileupName`` are file NAMES inside each sample directory (as the
+    ``{1}/...`` templates of run.py).  Samples are dealt round-robin to the visible GPUs, one host thread and one
+    stream of files per GPU.  A failing sample is reported as a sample error and the others still run."""
+    utils.print_log_header()
+    utils.print_arguments(args)
+    sample_directories_list_path = args.sampleDirsFile
+    if utils.verify_non_empty_input_files("File of sample directories", [sample_directories_list_path]) > 0:
+        utils.global_error(None)
+    with open(sample_directories_list_path, "r") as f:
+        sample_dirs = [line.rstrip() for line in f]
+    sample_dirs = [d for d in sample_dirs if d]
+    snp_list_file_path = args.snpListFile
+    if utils.verify_existing_input_files("Snplist file", [snp_list_file_path]) > 0:
+        utils.global_error("Error: cannot call consensus without the snplist file.")
+
+    plans, failed = [], 0
+    for d in sample_dirs:
+        plan = _Plan(args, os.path.join(d, args.pileupName), os.path.join(d, args.consensusFile),
+                     os.path.join(d, args.excludeFile) if args.excludeFile else None)
+        if utils.verify_non_empty_input_files("Pileup file", [plan.pileup_path]) > 0:
+            utils.sample_error("Error: cannot call consensus without the pileup file.", continue_possible=True)
+            failed += 1
+            continue
+        source_files = [snp_list_file_path, plan.pileup_path]
+        if plan.exclude_path:
+            if utils.verify_existing_input_files("Exclude file", [plan.exclude_path]) > 0:
+                utils.sample_error("Error: cannot call consensus without the file of excluded positions.", continue_possible=True)
+                failed += 1
+                continue
+            plan.excluded = utils.convert_vcf_file_to_snp_set(plan.exclude_path)
+            source_files.append(plan.exclude_path)
+        if not args.forceFlag and not utils.target_needs_rebuild(source_files, plan.consensus_path):
+            utils.verbose_print("Consensus call file %s has already been freshly built.  Use the -f option to force a rebuild." % plan.consensus_path)
+            continue
+        plans.append(plan)
+    if not plans:
+        return
+
+    snp_list = utils.read_snp_position_list(snp_list_file_path)
+    utils.verbose_print("snp position list length = %d" % len(snp_list))
+    params = devmod.make_params(args.minBaseQual, args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
+    pinned = os.environ.get("SNPGPU_DEVICE", os.environ.get("LOCAL_RANK"))
+    devices = [int(pinned)] if pinned is not None else list(range(max(1, devmod.device_count())))
+    devices = devices[:max(1, len(plans))]
+    errors = []                                   # (plan, exception) of samples that failed on the device
+    lock = threading.Lock()
+
+    def worker(dev_index, my_plans):
+        dev = devmod.Device(dev_index)
+        try:
+            # samples that share the site set (no per-sample exclude file) go through the device as one stream of files
+            groups = {}
+            for plan in my_plans:
+                groups.setdefault(frozenset(plan.excluded), []).append(plan)
+            for excluded, group in groups.items():
+                ss, n_keys = build_siteset(dev, snp_list, excluded)
+                results, rcs, _ = dev.call_consensus_files(ss, [p.pileup_path for p in group], params, want_counts=True,
+                                                           want_line_offsets=True)
+                for plan, rc, res in zip(group, rcs, results):
+                    try:
+                        dev.raise_file_status(plan.pileup_path, int(rc), res)
+                        with lock:                # the log lines of one sample stay together
+                            _write_outputs(plan, dev, ss, n_keys, res)
+                    except Exception as err:      # noqa: B902  (reported per sample below)
+                        with lock:
+                            errors.append((plan, err))
+                ss.close()
+        finally:
+            dev.close()
+
+    threads = [threading.Thread(target=worker, args=(dv, plans[i::len(devices)])) for i, dv in enumerate(devices)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for plan, err in errors:
+        utils.sample_error("Error: call_consensus failed for sample %s: %s: %s" % (plan.sample_name, type(err).__name__, err),
+                           continue_possible=True)
+    if failed or errors:
+        utils.verbose_print("%d of %d samples failed." % (failed + len(errors), len(sample_dirs)))

@@ -103,6 +103,28 @@ def parse_argument_list(argv):
     _common(sub)
     sub.set_defaults(func=call_consensus.call_consensus, excepthook=utils.handle_sample_exception)
 
+    # Extension of this build (no reference counterpart): call_consensus for all samples of a sampleDirsFile in one process
+    sub = subparsers.add_parser("call_consensus_batch", help="call_consensus for every sample directory, one process, all visible GPUs", formatter_class=fmt,
+                                description="Run the call_consensus step for every sample directory listed in sampleDirsFile in one process: the pileup files are streamed through the visible GPUs, samples dealt round-robin.  Options as call_consensus; file options are names inside each sample directory.")
+    sub.add_argument(dest="sampleDirsFile", type=str, help="Relative or absolute path to file containing a list of directories -- one per sample")
+    sub.add_argument("--pileupName", dest="pileupName", type=str, default="reads.all.pileup", metavar="NAME", help="File name of the genome-wide pileup file in each sample directory.")
+    sub.add_argument("-f", "--force", dest="forceFlag", action="store_true", help="Force processing even when result file already exists and is newer than inputs.")
+    sub.add_argument("-l", "--snpListFile", dest="snpListFile", type=str, default="snplist.txt", metavar="FILE", help="Relative or absolute path to the SNP list file across all samples.")
+    sub.add_argument("-e", "--excludeFile", dest="excludeFile", type=str, default=None, metavar="NAME", help="File name, in each sample directory, of the VCF file of positions to exclude.")
+    sub.add_argument("-o", "--output", dest="consensusFile", type=str, default="consensus.fasta", metavar="NAME", help="Output file name of the consensus fasta file in each sample directory.")
+    sub.add_argument("-q", "--minBaseQual", dest="minBaseQual", type=int, default=0, metavar="INT", help="Mimimum base quality score to count a read.")
+    sub.add_argument("-c", "--minConsFreq", dest="minConsFreq", type=_min_cons_freq, default=0.60, metavar="FREQ", help="Consensus frequency.")
+    sub.add_argument("-D", "--minConsDpth", dest="minConsDpth", type=int, default=1, metavar="INT", help="Consensus depth.")
+    sub.add_argument("-d", "--minConsStrdDpth", dest="minConsStrdDpth", type=int, default=0, metavar="INT", help="Consensus strand depth.")
+    sub.add_argument("-b", "--minConsStrdBias", dest="minConsStrdBias", type=_min_cons_strand_bias, default=0, metavar="FREQ", help="Strand bias.")
+    sub.add_argument("--vcfFileName", dest="vcfFileName", type=str, default=None, metavar="NAME", help="VCF Output file name.")
+    sub.add_argument("--vcfRefName", dest="vcfRefName", type=str, default="Unknown reference", metavar="NAME", help="Name of the reference file.  This is only used in the generated VCF file header.")
+    sub.add_argument("--vcfAllPos", dest="vcfAllPos", action="store_true", help="Flag to cause VCF file generation at all positions, not just the snp positions.")
+    sub.add_argument("--vcfPreserveRefCase", dest="vcfPreserveRefCase", action="store_true", help="Emit each reference base in uppercase/lowercase as it appears in the reference sequence file.")
+    sub.add_argument("--vcfFailedSnpGt", dest="vcfFailedSnpGt", type=str, default=".", choices=[".", "0", "1"], help="Controls the VCF file GT data element when a snp fails filters.")
+    _common(sub)
+    sub.set_defaults(func=call_consensus.call_consensus_batch, excepthook=utils.handle_global_exception)
+
     sub = subparsers.add_parser("snp_matrix", help="Create a matrix of SNPs", formatter_class=fmt,
                                 description="Create the SNP matrix containing the consensus base for each of the samples at the positions where high-confidence SNPs were found in any of the samples.")
     sub.add_argument(dest="sampleDirsFile", type=str, help="Relative or absolute path to file containing a list of directories -- one per sample")

@@ -17,10 +17,6 @@
 
 #include "internal.h"
 
-#define SCAN_ERR_FEW_FIELDS 1
-#define SCAN_ERR_BAD_POS 2
-#define SCAN_ERR_NON_ASCII 3
-
 // ------------------------------------------------------------------------------------------------
 //                                   K2: one wavefront per site
 // ------------------------------------------------------------------------------------------------
@@ -834,12 +830,82 @@ __global__ __launch_bounds__(kWaves * 64) void k_call_lanes(CallArgs a) {
 // ------------------------------------------------------------------------------------------------
 struct SampleIO { const uint8_t *d_pileup; size_t nbytes; uint64_t *d_status; };
 
-// Scan + call for up to SNPGPU_SCAN_MAX_BATCH samples: one scan launch and one call launch for all of them.
+// The call kernels over a scanned batch: d_table describes the (complete) files, d_site_line the scan's result.
+int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n,
+                        const snpgpu_caller_params *prm, const uint64_t *d_site_line, uint8_t *d_out_base,
+                        uint8_t *d_out_filters, snpgpu_site_counts *d_out_counts, uint32_t *d_todo_n, uint64_t *d_todo,
+                        uint64_t *d_todo2) {
+    hipStream_t st = ctx->stream;
+    const uint32_t n_sites = ss->n_sites;
+    if (!n_sites || !n) return SNPGPU_OK;
+    CallArgs ca;
+    ca.samples = d_table;
+    ca.n_samples = n;
+    ca.site_line = d_site_line;
+    ca.site_flags = ss->dev.flags;
+    ca.n_sites = n_sites;
+    ca.prm = *prm;
+    ca.out_base = d_out_base;
+    ca.out_filters = d_out_filters;
+    ca.out_counts = d_out_counts;
+    const uint64_t n_work = (uint64_t)n_sites * n;
+    const uint64_t blocks = (n_work + CALL_WAVES - 1) / CALL_WAVES;
+    const uint64_t max_blocks = (uint64_t)ctx->n_cu * 16;
+    const unsigned grid = (unsigned)(blocks < max_blocks ? blocks : max_blocks);
+    ca.todo = nullptr;
+    ca.todo_n = nullptr;
+    ca.in_todo = nullptr;
+    ca.in_todo_n = nullptr;
+    hipEvent_t ta = snpgpu_time_begin(ctx);
+    if (d_out_counts) {
+        k_call_sites<<<grid, CALL_WAVES * 64, 0, st>>>(ca);      // per-site counts: the wave-per-site kernel does it all
+    } else {
+        // one lane per site: a 256-byte window for every site, a 512-byte window for what that left (deeper pileups),
+        // then one wave per site for the rest
+        ca.todo = d_todo;
+        ca.todo_n = d_todo_n;
+        const uint64_t lblocks = ((n_work + 63) / 64 + 1) / 2, lmax = (uint64_t)ctx->n_cu * 8;
+        k_call_lanes<256, 2, 2><<<(unsigned)(lblocks < lmax ? lblocks : lmax), 128, 0, st>>>(ca);
+        ca.in_todo = d_todo;
+        ca.in_todo_n = d_todo_n;
+        ca.todo = d_todo2;
+        ca.todo_n = d_todo_n + 1;
+        const uint64_t l2blocks = (n_work + 63) / 64, l2max = (uint64_t)ctx->n_cu * 4;
+        k_call_lanes<512, 4, 1><<<(unsigned)(l2blocks < l2max ? l2blocks : l2max), 64, 0, st>>>(ca);
+        k_call_sites<<<grid, CALL_WAVES * 64, 0, st>>>(ca);
+    }
+    snpgpu_time_end(ctx, SNPGPU_K_CALL, ta);
+    HIP_TRY(ctx, hipGetLastError());
+    return SNPGPU_OK;
+}
+
+// Every line of one pileup as a "site" (--vcfAllPos): the complete caller over a list of line offsets.
+int snpgpu_enqueue_call_lines(snpgpu_ctx *ctx, const SampleDev *d_sample, const uint64_t *d_line_off, const uint8_t *d_flags,
+                              uint32_t n_lines, const snpgpu_caller_params *prm, uint8_t *d_out_base, uint8_t *d_out_filters,
+                              snpgpu_site_counts *d_out_counts) {
+    if (!n_lines) return SNPGPU_OK;
+    CallArgs ca;
+    ca.samples = d_sample;
+    ca.n_samples = 1;
+    ca.site_line = d_line_off;
+    ca.site_flags = d_flags;
+    ca.n_sites = n_lines;
+    ca.prm = *prm;
+    ca.out_base = d_out_base;
+    ca.out_filters = d_out_filters;
+    ca.out_counts = d_out_counts;
+    ca.todo = nullptr; ca.todo_n = nullptr; ca.in_todo = nullptr; ca.in_todo_n = nullptr;
+    const uint64_t blocks = ((uint64_t)n_lines + CALL_WAVES - 1) / CALL_WAVES, max_blocks = (uint64_t)ctx->n_cu * 16;
+    k_call_sites<<<(unsigned)(blocks < max_blocks ? blocks : max_blocks), CALL_WAVES * 64, 0, ctx->stream>>>(ca);
+    HIP_TRY(ctx, hipGetLastError());
+    return SNPGPU_OK;
+}
+
+// Scan + call for up to SNPGPU_SCAN_MAX_BATCH resident samples: one scan launch and one call launch for all of them.
 // d_site_line == nullptr: the rows live in the context's scratch; outputs are [n][n_sites] row-major.
 static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleIO *io, uint32_t n,
                          const snpgpu_caller_params *prm, uint8_t *d_out_base, uint8_t *d_out_filters,
                          snpgpu_site_counts *d_out_counts, uint64_t *d_site_line, int want_depth) {
-    hipStream_t st = ctx->stream;
     const uint32_t n_sites = ss->n_sites;
     const size_t ws_bytes = (snpgpu_scan_workspace_bytes(ctx, n) + 255) / 256 * 256;
     const size_t rows_bytes = d_site_line ? 0 : 8ull * n_sites * n;
@@ -856,59 +922,16 @@ static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const Sample
     uint64_t *d_todo2 = (uint64_t *)((char *)ws + ws_bytes + rows_bytes + 256 + list_bytes);
     std::vector<SampleDev> samples(n);
     for (uint32_t i = 0; i < n; ++i) {
+        samples[i] = SampleDev{};
         samples[i].buf = io[i].d_pileup;
         samples[i].nbytes = io[i].nbytes;
         samples[i].status = io[i].d_status;
-        samples[i].wave0 = samples[i].n_waves = 0;
     }
-    {
-        // the scan's prepare kernel also zeroes the line-offset rows and the two leftover counters of the lane kernels
-        int rc = snpgpu_enqueue_scan(ctx, ss, samples, ws, d_site_line, want_depth, d_out_counts ? nullptr : d_todo_n, d_out_counts ? 0 : 2);
-        if (rc) return rc;
-    }
-    if (n_sites) {
-        CallArgs ca;
-        ca.samples = (const SampleDev *)ws;
-        ca.n_samples = n;
-        ca.site_line = d_site_line;
-        ca.site_flags = ss->dev.flags;
-        ca.n_sites = n_sites;
-        ca.prm = *prm;
-        ca.out_base = d_out_base;
-        ca.out_filters = d_out_filters;
-        ca.out_counts = d_out_counts;
-        const uint64_t n_work = (uint64_t)n_sites * n;
-        const uint64_t blocks = (n_work + CALL_WAVES - 1) / CALL_WAVES;
-        const uint64_t max_blocks = (uint64_t)ctx->n_cu * 16;
-        const unsigned grid = (unsigned)(blocks < max_blocks ? blocks : max_blocks);
-        ca.todo = nullptr;
-        ca.todo_n = nullptr;
-        ca.in_todo = nullptr;
-        ca.in_todo_n = nullptr;
-        hipEvent_t ta = snpgpu_time_begin(ctx);
-        if (d_out_counts) {
-            k_call_sites<<<grid, CALL_WAVES * 64, 0, st>>>(ca);      // per-site counts: the wave-per-site kernel does it all
-        } else {
-            // one lane per site: a 256-byte window for every site, a 512-byte window for what that left (deeper pileups),
-            // then one wave per site for the rest
-            ca.in_todo = nullptr;
-            ca.in_todo_n = nullptr;
-            ca.todo = d_todo;
-            ca.todo_n = d_todo_n;
-            const uint64_t lblocks = ((n_work + 63) / 64 + 1) / 2, lmax = (uint64_t)ctx->n_cu * 8;
-            k_call_lanes<256, 2, 2><<<(unsigned)(lblocks < lmax ? lblocks : lmax), 128, 0, st>>>(ca);
-            ca.in_todo = d_todo;
-            ca.in_todo_n = d_todo_n;
-            ca.todo = d_todo2;
-            ca.todo_n = d_todo_n + 1;
-            const uint64_t l2blocks = (n_work + 63) / 64, l2max = (uint64_t)ctx->n_cu * 4;
-            k_call_lanes<512, 4, 1><<<(unsigned)(l2blocks < l2max ? l2blocks : l2max), 64, 0, st>>>(ca);
-            k_call_sites<<<grid, CALL_WAVES * 64, 0, st>>>(ca);
-        }
-        snpgpu_time_end(ctx, SNPGPU_K_CALL, ta);
-    }
-    HIP_TRY(ctx, hipGetLastError());
-    return SNPGPU_OK;
+    // the scan's prepare kernel also zeroes the line-offset rows and the two leftover counters of the lane kernels
+    int rc = snpgpu_enqueue_scan(ctx, ss, samples, ws, d_site_line, want_depth, d_out_counts ? nullptr : d_todo_n, d_out_counts ? 0 : 2);
+    if (rc) return rc;
+    return snpgpu_enqueue_call(ctx, ss, (const SampleDev *)ws, n, prm, d_site_line, d_out_base, d_out_filters, d_out_counts,
+                               d_todo_n, d_todo, d_todo2);
 }
 
 static int enqueue_sample(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *d_pileup, size_t nbytes,
@@ -966,56 +989,6 @@ int snpgpu_call_consensus_batch_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, c
         const size_t off = (size_t)i0 * ss->n_sites;
         int rc = enqueue_group(ctx, ss, io.data(), n, params, d_out_base + off, d_out_filters + off, nullptr, nullptr, 0);
         if (rc) return rc;
-    }
-    return SNPGPU_OK;
-}
-
-int snpgpu_call_consensus(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *pileup, size_t nbytes,
-                          const snpgpu_caller_params *params, uint8_t *out_base, uint8_t *out_filters,
-                          snpgpu_site_counts *out_counts, uint64_t *out_status, int want_depth_sum) {
-    if (!ctx || !ss || !params || !out_status || (nbytes && !pileup)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const uint32_t n = ss->n_sites;
-    size_t o_base = (nbytes + 255) / 256 * 256;
-    size_t o_filt = o_base + (n + 255) / 256 * 256;
-    size_t o_stat = o_filt + (n + 255) / 256 * 256;
-    size_t o_cnt = o_stat + 256;
-    size_t total = o_cnt + (out_counts ? sizeof(snpgpu_site_counts) * (size_t)n : 0) + 256;
-    void *d = nullptr;
-    hipError_t e = hipMalloc(&d, total);
-    if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
-    char *b = (char *)d;
-    int rc = SNPGPU_OK;
-    hipStream_t st = ctx->stream;
-#define CC_TRY(expr)                                                                                    \
-    do {                                                                                                \
-        hipError_t e2_ = (expr);                                                                        \
-        if (e2_ != hipSuccess) {                                                                        \
-            hipFree(d);                                                                                 \
-            return snpgpu_set_error(ctx, SNPGPU_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e2_)); \
-        }                                                                                               \
-    } while (0)
-    if (nbytes) CC_TRY(hipMemcpyAsync(b, pileup, nbytes, hipMemcpyHostToDevice, st));
-    rc = enqueue_sample(ctx, ss, (const uint8_t *)b, nbytes, params, (uint8_t *)(b + o_base), (uint8_t *)(b + o_filt),
-                        out_counts ? (snpgpu_site_counts *)(b + o_cnt) : nullptr, (uint64_t *)(b + o_stat), want_depth_sum);
-    if (rc) { hipFree(d); return rc; }
-    if (n) {
-        CC_TRY(hipMemcpyAsync(out_base, b + o_base, n, hipMemcpyDeviceToHost, st));
-        CC_TRY(hipMemcpyAsync(out_filters, b + o_filt, n, hipMemcpyDeviceToHost, st));
-        if (out_counts) CC_TRY(hipMemcpyAsync(out_counts, b + o_cnt, sizeof(snpgpu_site_counts) * (size_t)n, hipMemcpyDeviceToHost, st));
-    }
-    CC_TRY(hipMemcpyAsync(out_status, b + o_stat, 8 * SNPGPU_SCAN_STATUS_WORDS, hipMemcpyDeviceToHost, st));
-    CC_TRY(hipStreamSynchronize(st));
-#undef CC_TRY
-    hipFree(d);
-    if (out_status[0] != ~0ull) {
-        unsigned code = (unsigned)(out_status[0] & 0xFF);
-        unsigned long long off = (unsigned long long)(out_status[0] >> 8) - 1;
-        const char *what = code == SCAN_ERR_FEW_FIELDS ? "line has fewer than 2 fields" :
-                           code == SCAN_ERR_BAD_POS ? "position field is not an unsigned decimal integer" :
-                           code == SCAN_ERR_NON_ASCII ? "non-ASCII byte" : "malformed line";
-        return snpgpu_set_error(ctx, code == SCAN_ERR_NON_ASCII ? SNPGPU_E_UNSUPPORTED : SNPGPU_E_PILEUP,
-                                "pileup: %s at byte offset %llu", what, off);
     }
     return SNPGPU_OK;
 }

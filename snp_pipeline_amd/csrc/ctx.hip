@@ -85,6 +85,11 @@ int snpgpu_ctx_kernel_time_ms(snpgpu_ctx *ctx, int kernel, float *total_ms, uint
 
 int snpgpu_abi_version(void) { return SNPGPU_ABI_VERSION; }
 
+int snpgpu_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int snpgpu_ctx_create(int device, snpgpu_ctx **out) {
     if (!out) return SNPGPU_E_ARG;
     *out = nullptr;
@@ -110,6 +115,7 @@ void snpgpu_ctx_destroy(snpgpu_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    snpgpu_stream_pool_destroy(ctx);
     if (ctx->scratch) hipFree(ctx->scratch);
     for (auto &t : ctx->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (auto e : ctx->event_pool) hipEventDestroy(e);

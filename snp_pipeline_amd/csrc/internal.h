@@ -9,8 +9,12 @@
 
 #include "../../include/snpgpu.h"
 
+struct snpgpu_stream_pool;          // stream.hip: pinned staging ring, device file slots, copy stream
+void snpgpu_stream_pool_destroy(struct snpgpu_ctx *ctx);
+
 struct snpgpu_ctx {
     int device = 0;
+    snpgpu_stream_pool *pool = nullptr;
     hipStream_t stream = nullptr;       // stream work is enqueued on
     hipStream_t own_stream = nullptr;   // created by the context
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -65,10 +69,52 @@ struct SampleDev {
     uint64_t nbytes;
     uint64_t *status;           // SNPGPU_SCAN_STATUS_WORDS
     uint32_t wave0, n_waves;    // the scan launch's waves [wave0, wave0 + n_waves) work on this sample
+    uint32_t tile_lo, tile_hi;  // ... on its 4 KiB tiles [tile_lo, tile_hi): the whole file, or — while the file is still
+                                // streaming in from the host — the tiles whose bytes (and halo) have landed
 };
+#define SNPGPU_SCAN_TILE 4096
+#define SNPGPU_SCAN_HALO 128
+static inline uint64_t snpgpu_scan_tiles(const void *buf, uint64_t nbytes) {
+    return (((uintptr_t)buf & 15) + nbytes + SNPGPU_SCAN_TILE - 1) / SNPGPU_SCAN_TILE;
+}
+// The scan of a batch in pieces (scan.hip).  A batch is described by a device table of n SampleDev entries followed by a
+// sentinel whose wave0 is the number of waves of the launch; snpgpu_scan_deal fills wave0 / n_waves of a host table
+// (tile ranges already set) and returns that number.
+//   snpgpu_scan_begin   zero the line-offset rows, status words, queue control words (and n_zero32 caller words)
+//   snpgpu_scan_range   the fast pass over the tile ranges of `d_table`; counts are ADDED to the status words, so a file
+//                       may be scanned in several launches while it arrives (d_table entries then describe the part of
+//                       the file that has landed: nbytes = landed bytes, tile_hi * 4096 + 128 <= landed)
+//   snpgpu_scan_end     the exact parser over the queued lines, the exact pass when the queue overflowed; d_table must
+//                       describe the complete files
+size_t snpgpu_scan_totals_bytes(const snpgpu_ctx *ctx);
+uint32_t snpgpu_scan_deal(const snpgpu_ctx *ctx, SampleDev *h_table, uint32_t n, uint32_t min_tiles_per_wave);
+int snpgpu_scan_begin(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n, uint64_t *d_site_line,
+                      uint32_t *d_zero32, uint32_t n_zero32);
+int snpgpu_scan_range(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n, uint32_t n_waves,
+                      uint64_t *d_totals, uint64_t *d_site_line, int want_depth);
+int snpgpu_scan_end(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n, uint32_t n_waves,
+                    uint64_t *d_totals, uint64_t *d_site_line, int want_depth);
+// all of the above for files that are resident: `workspace` holds snpgpu_scan_workspace_bytes()
 size_t snpgpu_scan_workspace_bytes(const snpgpu_ctx *ctx, uint32_t n_samples);
 int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<SampleDev> &h_samples, void *workspace,
                         uint64_t *d_site_line, int want_depth, uint32_t *d_zero32, uint32_t n_zero32);
+// every line of a pileup (--vcfAllPos): line index + per-line site flags (scan.hip)
+size_t snpgpu_lines_workspace_words(uint64_t nbytes);
+int snpgpu_enqueue_lines_count(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, uint32_t *ws, uint32_t **d_total);
+int snpgpu_enqueue_lines_emit(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *d_buf, uint64_t nbytes, uint32_t *ws,
+                              uint64_t *d_line_off, uint8_t *d_flags, uint64_t n_lines, uint64_t *d_status);
+// ... and the wave-per-site call kernel over such a list (consensus.hip): "site" i is line i
+int snpgpu_enqueue_call_lines(snpgpu_ctx *ctx, const SampleDev *d_sample, const uint64_t *d_line_off, const uint8_t *d_flags,
+                              uint32_t n_lines, const snpgpu_caller_params *prm, uint8_t *d_out_base, uint8_t *d_out_filters,
+                              snpgpu_site_counts *d_out_counts);
+// the call kernels over a scanned batch (consensus.hip); d_todo_n: 2 zeroed words, d_todo / d_todo2: n * n_sites entries each
+int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n,
+                        const snpgpu_caller_params *prm, const uint64_t *d_site_line, uint8_t *d_out_base,
+                        uint8_t *d_out_filters, snpgpu_site_counts *d_out_counts, uint32_t *d_todo_n, uint64_t *d_todo,
+                        uint64_t *d_todo2);
+#define SCAN_ERR_FEW_FIELDS 1
+#define SCAN_ERR_BAD_POS 2
+#define SCAN_ERR_NON_ASCII 3
 #define SNPGPU_SCAN_MAX_BATCH 256   // samples per scan launch (each gets at least ~16 of the 4096 waves)
 
 int snpgpu_set_error(snpgpu_ctx *ctx, int code, const char *fmt, ...);

@@ -29,9 +29,10 @@
 #include <stdlib.h>
 
 #include "internal.h"
+#include "prims.h"
 
-#define SCAN_TILE 4096                       // bytes per wave tile
-#define SCAN_HALO 128                        // bytes staged past the tile for the first fields of its last lines
+#define SCAN_TILE SNPGPU_SCAN_TILE            // bytes per wave tile (4096)
+#define SCAN_HALO SNPGPU_SCAN_HALO            // bytes staged past the tile for the first fields of its last lines (128)
 #ifndef SCAN_NBUF
 #define SCAN_NBUF 2                          // LDS slots per wave: tile k is parsed while tiles k+1 .. k+NBUF-1 stream in
 #endif
@@ -39,10 +40,6 @@
 #define SCAN_DMA_PER_TILE ((SCAN_WTILE_CHUNKS + 63) / 64)       // global_load_lds wave-instructions per tile
 #define SCAN_LIST_CAP 192                    // line starts held in LDS per pass (a tile with more makes extra passes)
 #define SCAN_HINT_WORDS 12                   // contig names up to 44 bytes take the fast compare
-
-#define SCAN_ERR_FEW_FIELDS 1
-#define SCAN_ERR_BAD_POS 2
-#define SCAN_ERR_NON_ASCII 3
 
 struct ScanArgs {
     const SampleDev *samples; // one launch covers a batch of pileups; each wave works inside exactly one of them
@@ -233,17 +230,6 @@ __device__ __noinline__ void scan_layout(uint32_t *lay, const uint32_t *hint_w, 
     }
 }
 
-// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (no LDS traffic).
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
-    return v;
-}
-
 struct Hint {                // the wave's current contig (all members wave-uniform); the name itself is in LDS
     uint32_t len, cid, max_pos;
     uint64_t bit_off;
@@ -311,7 +297,9 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     }
     const uint32_t s_wave0 = __builtin_amdgcn_readfirstlane(a.samples[si].wave0), s_waves = __builtin_amdgcn_readfirstlane(a.samples[si].n_waves);
     const ScanFile f = scan_file(a, si);
-    const uint64_t n_tiles = (f.hi + SCAN_TILE - 1) / SCAN_TILE;
+    // the tiles of the sample this launch covers: all of them, or the part of a file that has landed so far
+    const uint64_t r_lo = __builtin_amdgcn_readfirstlane(a.samples[si].tile_lo);
+    const uint64_t n_tiles = __builtin_amdgcn_readfirstlane(a.samples[si].tile_hi) - r_lo;
     auto interior = [&](uint64_t tt) { uint64_t x0 = tt * SCAN_TILE; return x0 >= f.lo + 16 && x0 + SCAN_TILE + SCAN_HALO <= f.hi; };
     // request tile tt into slot `buf`; returns the number of DMA wave-instructions now in flight for it (0: staged synchronously)
     auto request = [&](uint64_t tt, int buf) -> uint32_t {
@@ -404,7 +392,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
         return (x / wpb) * blk + c;
     };
     const uint64_t c_lo = cum(s_wave0), c_span = cum((uint64_t)s_wave0 + s_waves) - c_lo;
-    const uint64_t t_first = n_tiles * (cum(gwave) - c_lo) / c_span, t_end = n_tiles * (cum(gwave + 1) - c_lo) / c_span;
+    const uint64_t t_first = r_lo + n_tiles * (cum(gwave) - c_lo) / c_span, t_end = r_lo + n_tiles * (cum(gwave + 1) - c_lo) / c_span;
     const uint64_t kNoTile = ~0ull;
     // slot b holds tile t_first + b + k * NBUF; bit b of dma_mask: the tile now in slot b was requested by DMA (an edge
     // tile is staged synchronously instead).  Wave-uniform scalars throughout.
@@ -783,13 +771,15 @@ __global__ __launch_bounds__(256) void k_scan_prepare(const SampleDev *samples, 
     }
 }
 
-// After the scan, one workgroup per sample: add up the per-wave totals.  They are the fast pass's, or — when the queue
-// overflowed or the depth sum was asked for — the exact pass's, which then also replace what the queue kernel counted.
-__global__ __launch_bounds__(256) void k_scan_finish(const SampleDev *samples, const uint32_t *ctl, const uint64_t *totals) {
+// After a scan launch, one workgroup per sample: add up the per-wave totals.  exact == 0: the fast pass's, ADDED to the
+// status words (a file may be scanned in several launches); exact == 1: the exact pass's — only when the queue
+// overflowed, and they then REPLACE what the fast passes and the queue kernel counted.
+__global__ __launch_bounds__(256) void k_scan_finish(const SampleDev *samples, const uint32_t *ctl, const uint64_t *totals, int exact) {
     __shared__ unsigned long long part[3][4];
     const SampleDev sd = samples[blockIdx.x];
     uint64_t *status = sd.status;
     const bool overflow = ctl[1] != 0;
+    if (exact && !overflow) return;
     unsigned long long v[3] = {0, 0, 0};
     for (uint32_t w = threadIdx.x; w < sd.n_waves; w += blockDim.x)
         for (int k = 0; k < 3; ++k) v[k] += totals[3 * (size_t)(sd.wave0 + w) + k];
@@ -800,113 +790,228 @@ __global__ __launch_bounds__(256) void k_scan_finish(const SampleDev *samples, c
     __syncthreads();
     if (threadIdx.x < 3) {
         const unsigned long long sum = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
-        // [1] lines: only the wave kernels count them; [2] matches, [3] depth: the queue kernel added its own unless it was skipped
-        if (threadIdx.x >= 1 && !overflow) status[1 + threadIdx.x] += sum; else status[1 + threadIdx.x] = sum;
+        // [1] lines: only the wave kernels count them; [2] matches, [3] depth: the queue kernel adds its own unless it is skipped
+        if (exact) status[1 + threadIdx.x] = sum; else status[1 + threadIdx.x] += sum;
     }
 }
 
-size_t snpgpu_scan_workspace_bytes(const snpgpu_ctx *ctx, uint32_t n_samples) {
-    return ((size_t)(n_samples + 1) * sizeof(SampleDev) + 255) / 256 * 256 + 3 * 8 * (size_t)ctx->n_cu * 2 * 16 + 256;
+// ------------------------------------------------------------------------------------------------
+//            every line of a pileup (call_consensus --vcfAllPos, pileup.py:418-421)
+// ------------------------------------------------------------------------------------------------
+// With chrom_position_set None the reference builds a Record from EVERY line.  Three small kernels give the call
+// kernel its work list: count the lines of every 16 KiB block, (prim scan of the counts,) emit 1 + the offset of every
+// line in file order, and look every line's (chrom, pos) up in the site set for its flags (a line of an excluded
+// position fails the Region filter, call_consensus.py:165-168).  A line ends with '\n', or with a '\r' that is not
+// followed by '\n' (universal newlines, as the scan); a start at the end of the file is no line.
+#define LINES_BLOCK 16384
+#define LINES_THREADS 256
+#define LINES_PER_THREAD (LINES_BLOCK / LINES_THREADS)
+
+template <bool kEmit>
+__global__ __launch_bounds__(LINES_THREADS) void k_lines_index(const uint8_t *buf, uint64_t nbytes, uint32_t *block_counts, uint64_t *line_off, uint64_t capacity) {
+    __shared__ uint32_t lds[17];
+    const uint64_t b0 = (uint64_t)blockIdx.x * LINES_BLOCK + (uint64_t)threadIdx.x * LINES_PER_THREAD;
+    // bit k of `starts`: a line starts at byte b0 + k
+    uint64_t starts = 0;
+    uint32_t prev = b0 == 0 ? 10u : (b0 - 1 < nbytes ? buf[b0 - 1] : 0u);
+    for (int k = 0; k < LINES_PER_THREAD; ++k) {
+        const uint64_t p = b0 + k;
+        if (p >= nbytes) break;
+        const uint32_t c = buf[p];
+        if (prev == 10u || (prev == 13u && c != 10u)) starts |= 1ull << k;
+        prev = c;
+    }
+    uint32_t total;
+    const uint32_t mine = (uint32_t)__popcll(starts);
+    const uint32_t ex = block_exclusive_sum(mine, lds, total);
+    if (!kEmit) {
+        if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+        return;
+    }
+    uint64_t idx = (uint64_t)block_counts[blockIdx.x] + ex;   // block_counts: exclusive scan of the counts (< 2^32 lines)
+    while (starts) {
+        const uint32_t k = (uint32_t)__ffsll((long long)starts) - 1;
+        starts &= starts - 1;
+        if (idx < capacity) line_off[idx] = b0 + k + 1;
+        ++idx;
+    }
 }
 
-// Scans a batch of pileups with one launch.  h_samples[i].buf/nbytes/status are filled by the caller; the wave shares are
-// dealt here.  d_site_line is [n][n_sites] (zeroed here, together with the n_zero32 words at d_zero32).  `workspace` holds snpgpu_scan_workspace_bytes().
-int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<SampleDev> &h_samples, void *workspace,
-                        uint64_t *d_site_line, int want_depth, uint32_t *d_zero32, uint32_t n_zero32) {
-    hipStream_t st = ctx->stream;
-    const uint32_t n = (uint32_t)h_samples.size();
-    if (!n) return SNPGPU_OK;
-    static int blocks_per_cu = -1, mode = 0, waves = SCAN_NBUF == 2 ? 16 : 12;
-    static int share[4] = {329, 282, 223, 169};            // measured: 1 / (finish time with equal shares), oldest first
-    if (blocks_per_cu < 0) {                                // tuning knobs (development only)
+// flags[i] = site flags of line i's (chrom, pos) when it is in the site set, else 0; malformed chrom / pos columns are
+// reported in status[0] as the scan does
+__global__ __launch_bounds__(256) void k_lines_flags(const uint8_t *buf, uint64_t nbytes, const uint64_t *line_off, uint64_t n_lines,
+                                                     SiteSetDev ss, uint8_t *flags, uint64_t *status) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lines; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t off = line_off[i] - 1;
+        TileView tv{nullptr, buf, 0, nbytes, 0};             // lds_limit 0: every byte comes from global memory
+        uint8_t f = 0;
+        SlowLine sl = parse_line_slow(tv, (int64_t)off, 0);
+        if (sl.err) report_scan_error(status, off, sl.err);
+        else {
+            const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, sl.f0, sl.f0len) : 0xFFFFFFFFu;
+            if (cid != 0xFFFFFFFFu && sl.pos <= (uint64_t)ss.max_pos[cid]) {
+                const uint64_t bit = ss.bit_off[cid] + (uint32_t)sl.pos;
+                const uint32_t word = ss.bitmap[bit >> 5], shf = (uint32_t)(bit & 31);
+                if ((word >> shf) & 1u) f = ss.flags[ss.rank[bit >> 5] + __popc(word & ((1u << shf) - 1u))];
+            }
+        }
+        flags[i] = f;
+    }
+}
+
+size_t snpgpu_lines_workspace_words(uint64_t nbytes) { return prim_scan_workspace_words((nbytes + LINES_BLOCK - 1) / LINES_BLOCK + 1) + (nbytes + LINES_BLOCK - 1) / LINES_BLOCK + 1; }
+
+// ws: snpgpu_lines_workspace_words(nbytes) words.  Leaves the number of lines in *d_total (a pointer into ws).
+int snpgpu_enqueue_lines_count(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, uint32_t *ws, uint32_t **d_total) {
+    const uint64_t nb = (nbytes + LINES_BLOCK - 1) / LINES_BLOCK;
+    if (nb > 0x7FFFFFFFull) return snpgpu_set_error(ctx, SNPGPU_E_UNSUPPORTED, "pileup too large for the line index");
+    uint32_t *counts = ws, *scan_ws = ws + nb + 1;
+    if (nb) k_lines_index<false><<<(unsigned)nb, LINES_THREADS, 0, ctx->stream>>>(d_buf, nbytes, counts, nullptr, 0);
+    prim_exclusive_scan_u32(ctx->stream, counts, counts, nb, scan_ws, d_total);
+    HIP_TRY(ctx, hipGetLastError());
+    return SNPGPU_OK;
+}
+
+// after snpgpu_enqueue_lines_count with the same ws: line offsets (+1) in file order and the flags of every line
+int snpgpu_enqueue_lines_emit(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *d_buf, uint64_t nbytes, uint32_t *ws,
+                              uint64_t *d_line_off, uint8_t *d_flags, uint64_t n_lines, uint64_t *d_status) {
+    const uint64_t nb = (nbytes + LINES_BLOCK - 1) / LINES_BLOCK;
+    if (nb) k_lines_index<true><<<(unsigned)nb, LINES_THREADS, 0, ctx->stream>>>(d_buf, nbytes, ws, d_line_off, n_lines);
+    if (n_lines) {
+        const uint64_t blocks = (n_lines + 255) / 256, cap = (uint64_t)ctx->n_cu * 8;
+        k_lines_flags<<<(unsigned)(blocks < cap ? blocks : cap), 256, 0, ctx->stream>>>(d_buf, nbytes, d_line_off, n_lines, ss->dev, d_flags, d_status);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return SNPGPU_OK;
+}
+
+size_t snpgpu_scan_totals_bytes(const snpgpu_ctx *ctx) { return 3 * 8 * (size_t)ctx->n_cu * 2 * 16 + 256; }
+size_t snpgpu_scan_workspace_bytes(const snpgpu_ctx *ctx, uint32_t n_samples) {
+    return ((size_t)(n_samples + 1) * sizeof(SampleDev) + 255) / 256 * 256 + snpgpu_scan_totals_bytes(ctx);
+}
+
+namespace {
+struct ScanConfig {
+    int blocks_per_cu = 1, mode = 0, waves = SCAN_NBUF == 2 ? 16 : 12;
+    int share[4] = {329, 282, 223, 169};                    // measured: 1 / (finish time with equal shares), oldest first
+    bool ready = false;
+};
+ScanConfig &scan_config() {
+    static ScanConfig c;
+    if (!c.ready) {
+#ifdef SNPGPU_TUNING                                        // development builds only (tools/): never in the product library
         const char *b = getenv("SNPGPU_SCAN_BLOCKS_PER_CU"), *m = getenv("SNPGPU_SCAN_MODE"), *w = getenv("SNPGPU_SCAN_WAVES");
         if (const char *sh = getenv("SNPGPU_SCAN_SHARE")) {
             int v[4];
             if (sscanf(sh, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0)
-                for (int g = 0; g < 4; ++g) share[g] = v[g];
+                for (int g = 0; g < 4; ++g) c.share[g] = v[g];
         }
-        blocks_per_cu = b && atoi(b) > 0 && atoi(b) <= 2 ? atoi(b) : 1;
-        mode = m ? atoi(m) : 0;
-        if (w && atoi(w) >= 1 && atoi(w) <= 16) waves = atoi(w);
-        for (auto f : {(const void *)k_scan_wave<false, 0>, (const void *)k_scan_wave<false, 1>, (const void *)k_scan_wave<false, 2>,
-                       (const void *)k_scan_wave<false, 3>, (const void *)k_scan_wave<false, 4>, (const void *)k_scan_wave<true, 0>})
+        c.blocks_per_cu = b && atoi(b) > 0 && atoi(b) <= 2 ? atoi(b) : 1;
+        c.mode = m ? atoi(m) : 0;
+        if (w && atoi(w) >= 1 && atoi(w) <= 16) c.waves = atoi(w);
+        for (auto f : {(const void *)k_scan_wave<false, 1>, (const void *)k_scan_wave<false, 2>, (const void *)k_scan_wave<false, 3>})
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+        for (auto f : {(const void *)k_scan_wave<false, 0>, (const void *)k_scan_wave<false, 4>, (const void *)k_scan_wave<true, 0>})
+            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        c.ready = true;
     }
-    // Exactly blocks_per_cu workgroups fit on a CU (the LDS request is padded to make sure) and a full grid is
-    // n_cu * blocks_per_cu, so every CU runs the same number of waves and equal shares finish together.
-    const size_t lds_need = sizeof(ScanShared) - sizeof(WaveSlots) + (size_t)waves * sizeof(WaveSlots);
-    const size_t lds_pad = (size_t)(160 * 1024) / (blocks_per_cu + 1) + 1024;
-    const size_t lds = lds_need > lds_pad ? lds_need : lds_pad;
-    const uint64_t max_waves = (uint64_t)ctx->n_cu * blocks_per_cu * waves;
-    if (n > max_waves) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "too many samples for one scan launch");
-    // deal the waves to the samples in proportion to their tile counts (at least one each)
-    std::vector<uint64_t> tiles(n);
-    uint64_t total_tiles = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint64_t lo = (uintptr_t)h_samples[i].buf & 15;
-        tiles[i] = (lo + h_samples[i].nbytes + SCAN_TILE - 1) / SCAN_TILE;
-        total_tiles += tiles[i];
-    }
-    uint64_t budget = total_tiles < max_waves ? total_tiles : max_waves, used = 0;
-    if (budget < n) budget = n;
-    for (uint32_t i = 0; i < n; ++i) {
-        uint64_t w = total_tiles ? budget * tiles[i] / total_tiles : 0;
-        h_samples[i].n_waves = (uint32_t)(w ? w : 1);
-        used += h_samples[i].n_waves;
-    }
-    while (used < budget) {                                 // leftovers go where a wave's share is largest
-        uint32_t best = 0;
-        double worst = -1;
-        for (uint32_t i = 0; i < n; ++i) { double r = (double)tiles[i] / h_samples[i].n_waves; if (r > worst) { worst = r; best = i; } }
-        if (worst <= 1.0) break;
-        ++h_samples[best].n_waves;
-        ++used;
-    }
-    while (used > max_waves) {                              // only when many samples were rounded up to one wave
-        uint32_t best = 0;
-        for (uint32_t i = 0; i < n; ++i) if (h_samples[i].n_waves > h_samples[best].n_waves) best = i;
-        --h_samples[best].n_waves;
-        --used;
-    }
-    uint32_t w0 = 0;
-    for (uint32_t i = 0; i < n; ++i) { h_samples[i].wave0 = w0; w0 += h_samples[i].n_waves; }
-    SampleDev sentinel{};
-    sentinel.wave0 = w0;
-    h_samples.push_back(sentinel);
-    SampleDev *d_samples = (SampleDev *)workspace;
-    HIP_TRY(ctx, hipMemcpyAsync(d_samples, h_samples.data(), (size_t)(n + 1) * sizeof(SampleDev), hipMemcpyHostToDevice, st));
-    h_samples.pop_back();
-
+    return c;
+}
+// Exactly blocks_per_cu workgroups fit on a CU (the LDS request is padded to make sure) and a full grid is
+// n_cu * blocks_per_cu, so every CU runs the same number of waves and equal shares finish together.
+size_t scan_lds_bytes(const ScanConfig &c) {
+    const size_t lds_need = sizeof(ScanShared) - sizeof(WaveSlots) + (size_t)c.waves * sizeof(WaveSlots);
+    const size_t lds_pad = (size_t)(160 * 1024) / (c.blocks_per_cu + 1) + 1024;
+    return lds_need > lds_pad ? lds_need : lds_pad;
+}
+ScanArgs scan_args(const snpgpu_siteset *ss, const ScanConfig &c, const SampleDev *d_table, uint32_t n, uint64_t *d_totals,
+                   uint64_t *d_site_line, int want_depth) {
     ScanArgs sa;
-    sa.samples = d_samples;
+    sa.samples = d_table;
     sa.n_samples = n;
     sa.n_sites = ss->n_sites;
     sa.site_line = d_site_line;
     sa.want_depth = want_depth;
-    for (int g = 0; g < 4; ++g) sa.share[g] = ((waves == 16 || waves == 12) && blocks_per_cu == 1) ? (uint32_t)share[g] : 1u;
+    for (int g = 0; g < 4; ++g) sa.share[g] = ((c.waves == 16 || c.waves == 12) && c.blocks_per_cu == 1) ? (uint32_t)c.share[g] : 1u;
     sa.queue = ss->slow_queue;
     sa.q_cap = SNPGPU_SLOW_QUEUE_CAP - 65536;               // the tail holds the tuning modes' per-wave records
     sa.ctl = ss->slow_ctl;
-    sa.totals = (uint64_t *)((char *)workspace + ((size_t)(n + 1) * sizeof(SampleDev) + 255) / 256 * 256);
+    sa.totals = d_totals;
     sa.dbg = nullptr;
-    const unsigned grid = (unsigned)((w0 + waves - 1) / waves), threads = (unsigned)waves * 64;
-    {
-        const uint64_t row_words = (uint64_t)n * ss->n_sites;
-        const uint64_t want_blocks = (row_words + 2047) / 2048 + 1, cap_blocks = (uint64_t)ctx->n_cu * 4;
-        k_scan_prepare<<<(unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks), 256, 0, st>>>(
-            d_samples, n, ss->slow_ctl, d_site_line, row_words, d_zero32, n_zero32);
+    return sa;
+}
+}  // namespace
+
+// Deals the waves of one launch to the samples of a host table in proportion to the tiles each has in its range (at
+// least one wave each, at least min_tiles_per_wave tiles per wave where the range allows it).  Returns the wave count.
+uint32_t snpgpu_scan_deal(const snpgpu_ctx *ctx, SampleDev *h, uint32_t n, uint32_t min_tiles_per_wave) {
+    const ScanConfig &c = scan_config();
+    const uint64_t max_waves = (uint64_t)ctx->n_cu * c.blocks_per_cu * c.waves;
+    if (!min_tiles_per_wave) min_tiles_per_wave = 1;
+    std::vector<uint64_t> tiles(n);
+    uint64_t total_tiles = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        tiles[i] = h[i].tile_hi - h[i].tile_lo;
+        total_tiles += tiles[i];
     }
+    uint64_t budget = total_tiles / min_tiles_per_wave, used = 0;
+    if (budget > max_waves) budget = max_waves;
+    if (budget < n) budget = n;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t w = total_tiles ? budget * tiles[i] / total_tiles : 0;
+        h[i].n_waves = (uint32_t)(w ? w : 1);
+        used += h[i].n_waves;
+    }
+    while (used < budget) {                                 // leftovers go where a wave's share is largest
+        uint32_t best = 0;
+        double worst = -1;
+        for (uint32_t i = 0; i < n; ++i) { double r = (double)tiles[i] / h[i].n_waves; if (r > worst) { worst = r; best = i; } }
+        if (worst <= 1.0) break;
+        ++h[best].n_waves;
+        ++used;
+    }
+    while (used > max_waves) {                              // only when many samples were rounded up to one wave
+        uint32_t best = 0;
+        for (uint32_t i = 0; i < n; ++i) if (h[i].n_waves > h[best].n_waves) best = i;
+        --h[best].n_waves;
+        --used;
+    }
+    uint32_t w0 = 0;
+    for (uint32_t i = 0; i < n; ++i) { h[i].wave0 = w0; w0 += h[i].n_waves; }
+    return w0;
+}
+
+int snpgpu_scan_begin(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n, uint64_t *d_site_line,
+                      uint32_t *d_zero32, uint32_t n_zero32) {
+    const uint64_t row_words = (uint64_t)n * ss->n_sites;
+    const uint64_t want_blocks = (row_words + 2047) / 2048 + 1, cap_blocks = (uint64_t)ctx->n_cu * 4;
+    k_scan_prepare<<<(unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks), 256, 0, ctx->stream>>>(
+        d_table, n, ss->slow_ctl, d_site_line, row_words, d_zero32, n_zero32);
+    HIP_TRY(ctx, hipGetLastError());
+    return SNPGPU_OK;
+}
+
+int snpgpu_scan_range(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n, uint32_t n_waves,
+                      uint64_t *d_totals, uint64_t *d_site_line, int want_depth) {
+    const ScanConfig &c = scan_config();
+    hipStream_t st = ctx->stream;
+    if (n > (uint64_t)ctx->n_cu * c.blocks_per_cu * c.waves) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "too many samples for one scan launch");
+    ScanArgs sa = scan_args(ss, c, d_table, n, d_totals, d_site_line, want_depth);
+    const size_t lds = scan_lds_bytes(c);
+    const unsigned grid = (unsigned)((n_waves + c.waves - 1) / c.waves), threads = (unsigned)c.waves * 64;
     hipEvent_t ta = snpgpu_time_begin(ctx);
     if (want_depth) {
         k_scan_wave<false, 4><<<grid, threads, lds, st>>>(sa, ss->dev);  // the same parse + the 4th column
-    } else if (mode == 7) {                                 // tuning: LDS-DMA streaming rate without any parsing
+#ifdef SNPGPU_TUNING
+    } else if (c.mode == 7) {                               // tuning: LDS-DMA streaming rate without any parsing
         k_scan_wave<false, 3><<<grid, threads, lds, st>>>(sa, ss->dev);
-    } else if (mode == 8 || mode == 9) {                    // tuning: per-wave time stamps (9) + phase cycle counts (8)
+    } else if (c.mode == 8 || c.mode == 9) {                // tuning: per-wave time stamps (9) + phase cycle counts (8)
         sa.dbg = (unsigned long long *)(ss->slow_queue + SNPGPU_SLOW_QUEUE_CAP - 65536);
-        if (mode == 8) k_scan_wave<false, 2><<<grid, threads, lds, st>>>(sa, ss->dev);
+        if (c.mode == 8) k_scan_wave<false, 2><<<grid, threads, lds, st>>>(sa, ss->dev);
         else k_scan_wave<false, 1><<<grid, threads, lds, st>>>(sa, ss->dev);
         if (const char *path = getenv("SNPGPU_SCAN_DUMP")) {
-            const size_t nrec = (size_t)w0 * 8;
+            const size_t nrec = (size_t)n_waves * 8;
             unsigned long long *recs = (unsigned long long *)malloc(nrec * 8);
             (void)hipStreamSynchronize(st);
             (void)hipMemcpy(recs, sa.dbg, nrec * 8, hipMemcpyDeviceToHost);
@@ -914,13 +1019,50 @@ int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<S
             free(recs);
         }
         sa.dbg = nullptr;
+#endif
     } else {
         k_scan_wave<false, 0><<<grid, threads, lds, st>>>(sa, ss->dev);
     }
     snpgpu_time_end(ctx, SNPGPU_K_SCAN, ta);
-    k_scan_queue<<<ctx->n_cu, 256, 0, st>>>(sa, ss->dev);
-    k_scan_wave<true, 0><<<grid, threads, lds, st>>>(sa, ss->dev);       // returns at once unless the queue overflowed
-    k_scan_finish<<<n, 256, 0, st>>>(d_samples, ss->slow_ctl, sa.totals);
+    k_scan_finish<<<n, 256, 0, st>>>(d_table, ss->slow_ctl, d_totals, 0);
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;
+}
+
+int snpgpu_scan_end(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n, uint32_t n_waves,
+                    uint64_t *d_totals, uint64_t *d_site_line, int want_depth) {
+    const ScanConfig &c = scan_config();
+    hipStream_t st = ctx->stream;
+    ScanArgs sa = scan_args(ss, c, d_table, n, d_totals, d_site_line, want_depth);
+    const unsigned grid = (unsigned)((n_waves + c.waves - 1) / c.waves), threads = (unsigned)c.waves * 64;
+    k_scan_queue<<<ctx->n_cu, 256, 0, st>>>(sa, ss->dev);
+    k_scan_wave<true, 0><<<grid, threads, scan_lds_bytes(c), st>>>(sa, ss->dev);   // returns at once unless the queue overflowed
+    k_scan_finish<<<n, 256, 0, st>>>(d_table, ss->slow_ctl, d_totals, 1);
+    HIP_TRY(ctx, hipGetLastError());
+    return SNPGPU_OK;
+}
+
+// Scans a batch of resident pileups with one launch.  h_samples[i].buf/nbytes/status are filled by the caller; tile
+// ranges and wave shares are set here.  d_site_line is [n][n_sites] (zeroed here, together with the n_zero32 words at
+// d_zero32).  `workspace` holds snpgpu_scan_workspace_bytes(); the device table stays at its start.
+int snpgpu_enqueue_scan(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<SampleDev> &h_samples, void *workspace,
+                        uint64_t *d_site_line, int want_depth, uint32_t *d_zero32, uint32_t n_zero32) {
+    const uint32_t n = (uint32_t)h_samples.size();
+    if (!n) return SNPGPU_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        h_samples[i].tile_lo = 0;
+        h_samples[i].tile_hi = (uint32_t)snpgpu_scan_tiles(h_samples[i].buf, h_samples[i].nbytes);
+    }
+    const uint32_t n_waves = snpgpu_scan_deal(ctx, h_samples.data(), n, 1);
+    SampleDev sentinel{};
+    sentinel.wave0 = n_waves;
+    h_samples.push_back(sentinel);
+    SampleDev *d_samples = (SampleDev *)workspace;
+    HIP_TRY(ctx, hipMemcpyAsync(d_samples, h_samples.data(), (size_t)(n + 1) * sizeof(SampleDev), hipMemcpyHostToDevice, ctx->stream));
+    h_samples.pop_back();
+    uint64_t *d_totals = (uint64_t *)((char *)workspace + ((size_t)(n + 1) * sizeof(SampleDev) + 255) / 256 * 256);
+    int rc = snpgpu_scan_begin(ctx, ss, d_samples, n, d_site_line, d_zero32, n_zero32);
+    if (rc == SNPGPU_OK) rc = snpgpu_scan_range(ctx, ss, d_samples, n, n_waves, d_totals, d_site_line, want_depth);
+    if (rc == SNPGPU_OK) rc = snpgpu_scan_end(ctx, ss, d_samples, n, n_waves, d_totals, d_site_line, want_depth);
+    return rc;
 }

@@ -1,0 +1,659 @@
+// Streamed ingestion for call_consensus: pileup files (or host buffers) -> consensus bytes, without ever waiting for a
+// whole file to be resident.
+//
+// Replaces the way the reference feeds pileup.Reader (snppipeline/pileup.py:408-429: a text-mode line iterator over the
+// open file, driven from call_consensus.py:161) and the one-process-per-sample job array around it (run.py:704-718).
+// A pileup is 0.4 GB of text per 5 Mbp x 30x sample: the 10 000-sample target is 4 TB that can only pass through HBM,
+// so the rate that matters end to end is the host link's, and the job of this file is to keep that link busy:
+//
+//   reader threads   pread() the file (page cache) in chunks of whole 4 KiB scan tiles into a ring of PINNED staging
+//                    buffers — a kernel-side memcpy of ~5 GB/s per thread, hence several threads
+//   copy stream      one hipMemcpyAsync per chunk, staging -> the file's device buffer ("slot"), event per chunk
+//   compute stream   waits for the chunk's event and scans the tiles that are now complete (tile + 128-byte halo inside
+//                    the landed bytes) with the batch scan kernel restricted to that tile range (scan.hip:
+//                    snpgpu_scan_range); lines the fast parser leaves to the exact parser are queued with their file
+//                    offsets and finished when the file is complete, as is the call step (snpgpu_enqueue_call), which
+//                    reads the lines the scan selected straight from the slot
+//   results          base / filter bytes (+ optional per-site counts and line offsets) come back through pinned buffers
+// Files alternate between n_slots device buffers, so file k+1 streams in while file k's tail (last tiles, queue, call,
+// results) runs.  Everything on the compute stream is in order, so all device scratch is shared between files.
+#include <errno.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "internal.h"
+
+namespace {
+
+inline size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Source {
+    const char *path = nullptr;     // a file ...
+    const uint8_t *mem = nullptr;   // ... or host memory
+    uint64_t size = 0;
+    int fd = -1;
+    int rc = SNPGPU_OK;
+};
+
+struct Job {
+    uint32_t file;
+    uint64_t off, len;
+    bool first, last;
+    uint32_t chunk;                 // index of the chunk inside its file
+};
+
+}  // namespace
+
+// Persistent per-context resources of the streaming path (pinned memory is expensive to allocate: keep it).
+struct snpgpu_stream_pool {
+    hipStream_t copy_stream = nullptr;      // chunks alternate between two copy streams: the set-up of one copy hides
+    hipStream_t copy_stream2 = nullptr;     // behind the transfer of the other
+    cpu_set_t near_cpus;                    // CPUs of the NUMA node the device hangs off (reader threads run there)
+    bool have_near_cpus = false;
+    size_t chunk_bytes = 0;
+    std::vector<void *> staging;            // pinned, chunk_bytes each
+    std::vector<hipEvent_t> ev_copy;        // the H2D copy out of staging[i] has completed
+    std::vector<void *> slot;               // device file buffers
+    size_t slot_bytes = 0;
+    std::vector<hipEvent_t> ev_done;        // the results of the file in slot i are in its pinned result block
+    std::vector<void *> result;             // pinned result blocks, one per slot
+    size_t result_bytes = 0;
+    std::vector<void *> table_host;         // pinned mirrors of the per-chunk sample tables, one per slot
+    size_t table_bytes = 0;
+};
+
+static void pool_free_host(std::vector<void *> &v) {
+    for (void *p : v) if (p) (void)hipHostFree(p);
+    v.clear();
+}
+
+void snpgpu_stream_pool_destroy(snpgpu_ctx *ctx) {
+    snpgpu_stream_pool *p = ctx->pool;
+    if (!p) return;
+    pool_free_host(p->staging);
+    pool_free_host(p->result);
+    pool_free_host(p->table_host);
+    for (void *d : p->slot) if (d) (void)hipFree(d);
+    for (auto e : p->ev_copy) (void)hipEventDestroy(e);
+    for (auto e : p->ev_done) (void)hipEventDestroy(e);
+    if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
+    if (p->copy_stream2) (void)hipStreamDestroy(p->copy_stream2);
+    delete p;
+    ctx->pool = nullptr;
+}
+
+namespace {
+
+int pool_ensure(snpgpu_ctx *ctx, size_t chunk_bytes, uint32_t n_staging, uint32_t n_slots, size_t slot_bytes, size_t result_bytes,
+                size_t table_bytes) {
+    if (!ctx->pool) ctx->pool = new snpgpu_stream_pool();
+    snpgpu_stream_pool *p = ctx->pool;
+    if (!p->copy_stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&p->copy_stream2, hipStreamNonBlocking));
+        // the CPUs next to the device: /sys/bus/pci/devices/<bdf>/local_cpulist (best effort)
+        char bdf[64] = {0};
+        if (hipDeviceGetPCIBusId(bdf, sizeof bdf, ctx->device) == hipSuccess) {
+            for (char *c = bdf; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+            char path[160];
+            snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+            if (FILE *fp = fopen(path, "r")) {
+                char line[1024] = {0};
+                if (fgets(line, sizeof line, fp)) {
+                    CPU_ZERO(&p->near_cpus);
+                    int n_set = 0;
+                    for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+                        int a = 0, b = 0;
+                        const int k = sscanf(tok, "%d-%d", &a, &b);
+                        if (k == 1) b = a;
+                        if (k >= 1) for (int c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET(c, &p->near_cpus); ++n_set; }
+                    }
+                    p->have_near_cpus = n_set > 0;
+                }
+                fclose(fp);
+            }
+        }
+    }
+    if (p->chunk_bytes != chunk_bytes) {
+        pool_free_host(p->staging);
+        p->chunk_bytes = chunk_bytes;
+    }
+    while (p->staging.size() < n_staging) {
+        void *h = nullptr;
+        hipError_t e = hipHostMalloc(&h, chunk_bytes, hipHostMallocDefault);
+        if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipHostMalloc(%zu) failed: %s", chunk_bytes, hipGetErrorString(e));
+        p->staging.push_back(h);
+    }
+    while (p->ev_copy.size() < p->staging.size()) {
+        hipEvent_t ev = nullptr;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        p->ev_copy.push_back(ev);
+    }
+    if (p->slot_bytes < slot_bytes || p->slot.size() < n_slots) {
+        for (void *d : p->slot) if (d) (void)hipFree(d);
+        p->slot.clear();
+        const size_t want = p->slot_bytes > slot_bytes ? p->slot_bytes : slot_bytes;
+        for (uint32_t i = 0; i < n_slots; ++i) {
+            void *d = nullptr;
+            hipError_t e = hipMalloc(&d, want);
+            if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipMalloc(%zu) for a pileup slot failed: %s", want, hipGetErrorString(e));
+            p->slot.push_back(d);
+        }
+        p->slot_bytes = want;
+    }
+    while (p->ev_done.size() < p->slot.size()) {
+        hipEvent_t ev = nullptr;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        p->ev_done.push_back(ev);
+    }
+    if (p->result_bytes < result_bytes || p->result.size() < p->slot.size()) {
+        pool_free_host(p->result);
+        for (size_t i = 0; i < p->slot.size(); ++i) {
+            void *h = nullptr;
+            hipError_t e = hipHostMalloc(&h, result_bytes, hipHostMallocDefault);
+            if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipHostMalloc(%zu) failed: %s", result_bytes, hipGetErrorString(e));
+            p->result.push_back(h);
+        }
+        p->result_bytes = result_bytes;
+    }
+    if (p->table_bytes < table_bytes || p->table_host.size() < p->slot.size()) {
+        pool_free_host(p->table_host);
+        for (size_t i = 0; i < p->slot.size(); ++i) {
+            void *h = nullptr;
+            hipError_t e = hipHostMalloc(&h, table_bytes, hipHostMallocDefault);
+            if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipHostMalloc(%zu) failed: %s", table_bytes, hipGetErrorString(e));
+            p->table_host.push_back(h);
+        }
+        p->table_bytes = table_bytes;
+    }
+    return SNPGPU_OK;
+}
+
+struct Outputs {
+    uint8_t *base, *filters;
+    snpgpu_site_counts *counts;     // nullable
+    uint64_t *line_off;             // nullable
+    uint64_t *status;
+    int32_t *rc;                    // nullable
+};
+
+// What the readers and the orchestrator share.
+struct Shared {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<uint8_t> filled;    // job j has been read into staging[j % R]
+    std::vector<int> job_err;       // errno of a failed read (0: fine)
+    int64_t freed = 0;              // jobs whose H2D copy has completed: their staging buffers can be refilled
+    uint64_t R = 1;                 // staging buffers in the ring
+    std::atomic<uint64_t> ns_reading{0}, ns_waiting{0};   // summed over the readers
+    bool abort = false;
+    std::atomic<uint64_t> next{0};
+};
+
+void reader_main(snpgpu_ctx *ctx, Shared *sh, const std::vector<Job> *jobs, std::vector<Source> *src) {
+    snpgpu_stream_pool *p = ctx->pool;
+    if (p->have_near_cpus) (void)sched_setaffinity(0, sizeof p->near_cpus, &p->near_cpus);   // this thread only; best effort
+    const uint64_t R = sh->R;
+    for (;;) {
+        const uint64_t j = sh->next.fetch_add(1);
+        if (j >= jobs->size()) return;
+        const Job &jb = (*jobs)[j];
+        const double t_w = now_s();
+        if (j >= R) {                                       // staging[j % R] is free once job j - R has been copied out of it
+            std::unique_lock<std::mutex> lk(sh->mu);         // (the issuing thread watches the copy events: readers never call HIP)
+            sh->cv.wait(lk, [&] { return sh->abort || sh->freed > (int64_t)(j - R); });
+            if (sh->abort) return;
+        }
+        const double t_r = now_s();
+        uint8_t *dst = (uint8_t *)p->staging[j % R];
+        Source &s = (*src)[jb.file];
+        int err = 0;
+        if (s.mem) {
+            memcpy(dst, s.mem + jb.off, jb.len);
+        } else if (s.fd >= 0) {
+            uint64_t got = 0;
+            while (got < jb.len) {
+                ssize_t r = pread(s.fd, dst + got, jb.len - got, (off_t)(jb.off + got));
+                if (r < 0) { if (errno == EINTR) continue; err = errno ? errno : EIO; break; }
+                if (r == 0) { err = EIO; break; }            // the file shrank under us
+                got += (uint64_t)r;
+            }
+            if (err) memset(dst + got, '\n', jb.len - got);
+        } else {
+            memset(dst, '\n', jb.len);                       // could not be opened: its result is void (rc says so)
+        }
+        sh->ns_waiting.fetch_add((uint64_t)((t_r - t_w) * 1e9));
+        sh->ns_reading.fetch_add((uint64_t)((now_s() - t_r) * 1e9));
+        {
+            std::lock_guard<std::mutex> lk(sh->mu);
+            sh->filled[j] = 1;
+            sh->job_err[j] = err;
+        }
+        sh->cv.notify_all();
+    }
+}
+
+struct DevScratch {                 // one carve-up of the context's scratch, shared by all files (the compute stream is in order)
+    SampleDev *tables;              // [n_slots][table entries]
+    size_t table_stride;            // bytes per slot
+    uint64_t *totals, *site_line, *todo, *todo2, *status;
+    uint32_t *todo_n;
+    uint8_t *base, *filters;
+    snpgpu_site_counts *counts;
+};
+
+// d_site_line: nullptr = in scratch; the single-pileup form passes the site set's own row, where
+// snpgpu_siteset_line_offsets finds it afterwards.
+int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &src, const snpgpu_caller_params *prm,
+               const Outputs &out, const snpgpu_stream_opts *opts, snpgpu_stream_stats *stats, uint64_t *d_site_line) {
+    const double t_start = now_s();
+    const uint32_t n_files = (uint32_t)src.size();
+    const uint32_t n_sites = ss->n_sites;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (!n_files) return SNPGPU_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t chunk = opts && opts->chunk_bytes ? opts->chunk_bytes : (size_t)16 << 20;
+    chunk = up(chunk < 65536 ? 65536 : chunk, SNPGPU_SCAN_TILE);
+    const int want_depth = opts && opts->want_depth_sum ? 1 : 0;
+
+    // ---- sources and jobs -------------------------------------------------------------------------------------
+    uint64_t max_size = 0, total_bytes = 0;
+    for (auto &s : src) {
+        if (s.path) {
+            s.fd = open(s.path, O_RDONLY | O_CLOEXEC);
+            struct stat stt;
+            if (s.fd < 0 || fstat(s.fd, &stt) != 0 || !S_ISREG(stt.st_mode)) {
+                if (s.fd >= 0) { close(s.fd); s.fd = -1; }
+                s.rc = SNPGPU_E_IO;
+                s.size = 0;
+            } else {
+                s.size = (uint64_t)stt.st_size;
+                (void)posix_fadvise(s.fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+            }
+        }
+        if (s.size > max_size) max_size = s.size;
+        total_bytes += s.size;
+    }
+    std::vector<Job> jobs;
+    std::vector<uint32_t> chunks_of(n_files);
+    uint32_t max_chunks = 1;
+    for (uint32_t f = 0; f < n_files; ++f) {
+        const uint64_t n = src[f].size;
+        const uint32_t nc = n ? (uint32_t)((n + chunk - 1) / chunk) : 1;   // an empty file still takes one (empty) job
+        chunks_of[f] = nc;
+        if (nc > max_chunks) max_chunks = nc;
+        for (uint32_t c = 0; c < nc; ++c) {
+            const uint64_t off = (uint64_t)c * chunk;
+            jobs.push_back(Job{f, off, n - off < chunk ? n - off : chunk, c == 0, c + 1 == nc, c});
+        }
+    }
+    const uint64_t J = jobs.size();
+
+    // ---- resources ----------------------------------------------------------------------------------------------
+    uint32_t n_readers = opts && opts->n_readers ? opts->n_readers : 0;
+    if (!n_readers) {
+        unsigned hc = std::thread::hardware_concurrency();
+        n_readers = hc >= 32 ? 8 : (hc >= 8 ? hc / 2 : (hc > 1 ? hc - 1 : 1));
+    }
+    if (n_readers > J) n_readers = (uint32_t)J;
+    uint32_t n_staging = opts && opts->n_staging ? opts->n_staging : n_readers + 4;
+    if (n_staging > J) n_staging = (uint32_t)J;
+    if (n_staging < 1) n_staging = 1;
+    uint32_t n_slots = opts && opts->n_slots ? opts->n_slots : 2;
+    if (n_slots > n_files) n_slots = n_files;
+    const size_t slot_bytes = up(max_size + SNPGPU_SCAN_TILE + 256, 4096);
+    const size_t r_base = 0, r_filt = up(r_base + n_sites, 256), r_stat = up(r_filt + n_sites, 256), r_line = r_stat + 256;
+    const size_t r_cnt = up(r_line + (out.line_off ? 8ull * n_sites : 0), 256);
+    const size_t result_bytes = r_cnt + (out.counts ? sizeof(snpgpu_site_counts) * (size_t)n_sites : 0) + 256;
+    const size_t table_bytes = up((size_t)(max_chunks + 1) * 2 * sizeof(SampleDev), 256);
+    {
+        int rc = pool_ensure(ctx, chunk, n_staging, n_slots, slot_bytes, result_bytes, table_bytes);
+        if (rc) { for (auto &s : src) if (s.fd >= 0) close(s.fd); return rc; }
+    }
+    snpgpu_stream_pool *p = ctx->pool;
+    const uint64_t R = p->staging.size() < n_staging ? p->staging.size() : n_staging;   // ring actually used
+    DevScratch ds;
+    {
+        const size_t list_bytes = up(8ull * n_sites, 256);
+        size_t o = 0;
+        const size_t o_tab = o; o += table_bytes * p->slot.size();
+        const size_t o_tot = o; o += up(snpgpu_scan_totals_bytes(ctx), 256);
+        const size_t o_line = o; o += list_bytes;
+        const size_t o_todon = o; o += 256;
+        const size_t o_todo = o; o += list_bytes;
+        const size_t o_todo2 = o; o += list_bytes;
+        const size_t o_base = o; o += up(n_sites, 256);
+        const size_t o_filt = o; o += up(n_sites, 256);
+        const size_t o_stat = o; o += 256;
+        const size_t o_cnt = o; o += out.counts ? up(sizeof(snpgpu_site_counts) * (size_t)n_sites, 256) : 0;
+        void *ws = nullptr;
+        int rc = snpgpu_scratch(ctx, o + 256, &ws);
+        if (rc) { for (auto &s : src) if (s.fd >= 0) close(s.fd); return rc; }
+        char *b = (char *)ws;
+        ds.tables = (SampleDev *)(b + o_tab); ds.table_stride = table_bytes;
+        ds.totals = (uint64_t *)(b + o_tot); ds.site_line = (uint64_t *)(b + o_line); ds.todo_n = (uint32_t *)(b + o_todon);
+        ds.todo = (uint64_t *)(b + o_todo); ds.todo2 = (uint64_t *)(b + o_todo2); ds.base = (uint8_t *)(b + o_base);
+        ds.filters = (uint8_t *)(b + o_filt); ds.status = (uint64_t *)(b + o_stat);
+        ds.counts = out.counts ? (snpgpu_site_counts *)(b + o_cnt) : nullptr;
+        if (d_site_line) ds.site_line = d_site_line;
+    }
+    hipStream_t st = ctx->stream;
+    // whatever the caller enqueued before on the compute stream is done before the slots are overwritten
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+
+    Shared sh;
+    sh.R = R;
+    sh.filled.assign(J, 0);
+    sh.job_err.assign(J, 0);
+    std::vector<std::thread> readers;
+    for (uint32_t i = 0; i < n_readers; ++i) readers.emplace_back(reader_main, ctx, &sh, &jobs, &src);
+
+    int rc = SNPGPU_OK;
+    double t_wait_read = 0, t_wait_gpu = 0, t_enqueue = 0;
+    auto harvest = [&](uint32_t f) -> int {                  // results of file f: pinned block -> the caller's arrays
+        const uint32_t slot = f % (uint32_t)p->slot.size();
+        const double t0 = now_s();
+        hipError_t e = hipEventSynchronize(p->ev_done[slot]);
+        t_wait_gpu += now_s() - t0;
+        if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_HIP, "waiting for the results of pileup %u failed: %s", f, hipGetErrorString(e));
+        const char *r = (const char *)p->result[slot];
+        if (n_sites) {
+            memcpy(out.base + (size_t)f * n_sites, r + r_base, n_sites);
+            memcpy(out.filters + (size_t)f * n_sites, r + r_filt, n_sites);
+            if (out.line_off) memcpy(out.line_off + (size_t)f * n_sites, r + r_line, 8ull * n_sites);
+            if (out.counts) memcpy(out.counts + (size_t)f * n_sites, r + r_cnt, sizeof(snpgpu_site_counts) * (size_t)n_sites);
+        }
+        uint64_t *stw = out.status + (size_t)f * SNPGPU_SCAN_STATUS_WORDS;
+        memcpy(stw, r + r_stat, 8 * SNPGPU_SCAN_STATUS_WORDS);
+        if (src[f].rc == SNPGPU_OK && stw[0] != ~0ull)
+            src[f].rc = (stw[0] & 0xFF) == SCAN_ERR_NON_ASCII ? SNPGPU_E_UNSUPPORTED : SNPGPU_E_PILEUP;
+        return SNPGPU_OK;
+    };
+#define ST_TRY(expr)                                                                                                \
+    do {                                                                                                            \
+        hipError_t e_ = (expr);                                                                                     \
+        if (e_ != hipSuccess) { rc = snpgpu_set_error(ctx, SNPGPU_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } \
+    } while (0)
+
+    {
+        uint32_t harvested = 0;                              // files [0, harvested) have been copied out
+        uint32_t cur_waves = 0;                              // waves of the final (whole-file) table entry of the current file
+        uint32_t tiles_done = 0;
+        int64_t copies_done = 0;                             // copies [0, copies_done) have completed (events polled in order)
+        for (uint64_t j = 0; j < J; ++j) {
+            const Job &jb = jobs[j];
+            const uint32_t f = jb.file, slot = f % (uint32_t)p->slot.size();
+            Source &s = src[f];
+            uint8_t *d_file = (uint8_t *)p->slot[slot];
+            SampleDev *h_tab = (SampleDev *)p->table_host[slot];
+            SampleDev *d_tab = (SampleDev *)((char *)ds.tables + ds.table_stride * slot);
+            const uint32_t nc = chunks_of[f];
+            if (jb.first) {
+                // the slot, its table mirror and its result block are free once the file that used them has been harvested
+                while (harvested + (uint32_t)p->slot.size() <= f) { rc = harvest(harvested); if (rc) goto done; ++harvested; }
+                // one table entry (+ sentinel) per chunk: the part of the file that has landed after chunk c, and the tiles
+                // that became complete with it; entry nc describes the whole file for the exact parser and the call step
+                const uint64_t n_tiles = snpgpu_scan_tiles(d_file, s.size);
+                uint32_t lo = 0;
+                for (uint32_t c = 0; c <= nc; ++c) {
+                    const bool whole = c + 1 >= nc;
+                    const uint64_t landed = whole ? s.size : (uint64_t)(c + 1) * chunk;
+                    SampleDev e{};
+                    e.buf = d_file;
+                    e.nbytes = landed;
+                    e.status = ds.status;
+                    e.tile_lo = c == nc ? 0 : lo;
+                    e.tile_hi = whole ? (uint32_t)n_tiles : (uint32_t)((landed - SNPGPU_SCAN_HALO) / SNPGPU_SCAN_TILE);
+                    if (c < nc) lo = e.tile_hi;
+                    SampleDev sent{};
+                    sent.wave0 = snpgpu_scan_deal(ctx, &e, 1, c == nc ? 1 : 8);
+                    h_tab[2 * c] = e;
+                    h_tab[2 * c + 1] = sent;
+                }
+                cur_waves = h_tab[2 * nc + 1].wave0;
+                tiles_done = 0;
+                ST_TRY(hipMemcpyAsync(d_tab, h_tab, (size_t)(nc + 1) * 2 * sizeof(SampleDev), hipMemcpyHostToDevice, st));
+                rc = snpgpu_scan_begin(ctx, ss, d_tab + 2 * nc, 1, ds.site_line, out.counts ? nullptr : ds.todo_n, out.counts ? 0 : 2);
+                if (rc) goto done;
+            }
+            {
+                // wait for the chunk to be read; meanwhile retire finished copies so that their buffers go back to the readers
+                const double t0 = now_s();
+                for (;;) {
+                    bool progress = false;
+                    while (copies_done < (int64_t)j && hipEventQuery(p->ev_copy[copies_done % R]) == hipSuccess) { ++copies_done; progress = true; }
+                    std::unique_lock<std::mutex> lk(sh.mu);
+                    if (progress) { sh.freed = copies_done; lk.unlock(); sh.cv.notify_all(); lk.lock(); }
+                    if (sh.filled[j]) break;
+                    sh.cv.wait_for(lk, std::chrono::microseconds(copies_done < (int64_t)j ? 20 : 2000), [&] { return sh.filled[j] != 0; });
+                    if (sh.filled[j]) break;
+                }
+                if (sh.job_err[j] && s.rc == SNPGPU_OK) s.rc = SNPGPU_E_IO;
+                t_wait_read += now_s() - t0;
+            }
+            const double t_e = now_s();
+            hipStream_t cs = (j & 1) ? p->copy_stream2 : p->copy_stream;
+            if (jb.len) ST_TRY(hipMemcpyAsync(d_file + jb.off, p->staging[j % R], jb.len, hipMemcpyHostToDevice, cs));
+            ST_TRY(hipEventRecord(p->ev_copy[j % R], cs));
+            ST_TRY(hipStreamWaitEvent(st, p->ev_copy[j % R], 0));
+            const SampleDev &e = h_tab[2 * jb.chunk];
+            if (e.tile_hi > tiles_done) {
+                rc = snpgpu_scan_range(ctx, ss, d_tab + 2 * jb.chunk, 1, h_tab[2 * jb.chunk + 1].wave0, ds.totals, ds.site_line, want_depth);
+                if (rc) goto done;
+                tiles_done = e.tile_hi;
+            }
+            if (jb.last) {
+                const SampleDev *d_whole = d_tab + 2 * nc;
+                rc = snpgpu_scan_end(ctx, ss, d_whole, 1, cur_waves, ds.totals, ds.site_line, want_depth);
+                if (rc == SNPGPU_OK)
+                    rc = snpgpu_enqueue_call(ctx, ss, d_whole, 1, prm, ds.site_line, ds.base, ds.filters, ds.counts, ds.todo_n, ds.todo, ds.todo2);
+                if (rc) goto done;
+                char *r = (char *)p->result[slot];
+                if (n_sites) {
+                    ST_TRY(hipMemcpyAsync(r + r_base, ds.base, n_sites, hipMemcpyDeviceToHost, st));
+                    ST_TRY(hipMemcpyAsync(r + r_filt, ds.filters, n_sites, hipMemcpyDeviceToHost, st));
+                    if (out.line_off) ST_TRY(hipMemcpyAsync(r + r_line, ds.site_line, 8ull * n_sites, hipMemcpyDeviceToHost, st));
+                    if (out.counts) ST_TRY(hipMemcpyAsync(r + r_cnt, ds.counts, sizeof(snpgpu_site_counts) * (size_t)n_sites, hipMemcpyDeviceToHost, st));
+                }
+                ST_TRY(hipMemcpyAsync(r + r_stat, ds.status, 8 * SNPGPU_SCAN_STATUS_WORDS, hipMemcpyDeviceToHost, st));
+                // (the next file that uses this slot is not started before this event has been waited for in harvest())
+                ST_TRY(hipEventRecord(p->ev_done[slot], st));
+            }
+            t_enqueue += now_s() - t_e;
+        }
+        while (harvested < n_files) { rc = harvest(harvested); if (rc) goto done; ++harvested; }
+    }
+done:
+#undef ST_TRY
+    {
+        std::lock_guard<std::mutex> lk(sh.mu);
+        if (rc) { sh.abort = true; sh.next.store(J); }
+    }
+    sh.cv.notify_all();
+    for (auto &t : readers) t.join();
+    if (rc) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamSynchronize(p->copy_stream2); (void)hipStreamSynchronize(st); }
+    for (auto &s : src) if (s.fd >= 0) { close(s.fd); s.fd = -1; }
+    if (out.rc) for (uint32_t f = 0; f < n_files; ++f) out.rc[f] = src[f].rc;
+    if (stats) {
+        stats->bytes = total_bytes;
+        stats->seconds = now_s() - t_start;
+        stats->seconds_waiting_for_readers = t_wait_read;
+        stats->seconds_waiting_for_device = t_wait_gpu;
+        stats->n_chunks = J;
+        stats->n_readers = n_readers;
+        stats->n_staging = (uint32_t)R;
+        stats->chunk_bytes = (uint32_t)chunk;
+        stats->reader_seconds_reading = sh.ns_reading.load() * 1e-9;
+        stats->reader_seconds_waiting = sh.ns_waiting.load() * 1e-9;
+        stats->seconds_enqueueing = t_enqueue;
+    }
+    return rc;
+}
+
+// Synchronous load of one file into device slot 0 (the --vcfAllPos path: a diagnostic option, no overlap needed).
+int load_file(snpgpu_ctx *ctx, const char *path, uint8_t **d_file, uint64_t *size) {
+    int fd = open(path, O_RDONLY | O_CLOEXEC);
+    struct stat stt;
+    if (fd < 0 || fstat(fd, &stt) != 0 || !S_ISREG(stt.st_mode)) {
+        if (fd >= 0) close(fd);
+        return snpgpu_set_error(ctx, SNPGPU_E_IO, "cannot open the pileup file %s", path);
+    }
+    const uint64_t n = (uint64_t)stt.st_size;
+    const size_t chunk = (size_t)8 << 20;
+    int rc = pool_ensure(ctx, chunk, 2, 1, up(n + SNPGPU_SCAN_TILE + 256, 4096), 256, 256);
+    if (rc) { close(fd); return rc; }
+    snpgpu_stream_pool *p = ctx->pool;
+    hipStream_t st = ctx->stream;
+    uint8_t *d = (uint8_t *)p->slot[0];
+    hipError_t he = hipStreamSynchronize(st);
+    uint64_t j = 0;
+    for (uint64_t off = 0; off < n && he == hipSuccess; off += chunk, ++j) {
+        const uint64_t len = n - off < chunk ? n - off : chunk;
+        if (j >= 2) he = hipEventSynchronize(p->ev_copy[j % 2]);
+        uint8_t *h = (uint8_t *)p->staging[j % 2];
+        uint64_t got = 0;
+        while (got < len) {
+            ssize_t r = pread(fd, h + got, len - got, (off_t)(off + got));
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) { close(fd); (void)hipStreamSynchronize(st); return snpgpu_set_error(ctx, SNPGPU_E_IO, "cannot read the pileup file %s", path); }
+            got += (uint64_t)r;
+        }
+        if (he == hipSuccess) he = hipMemcpyAsync(d + off, h, len, hipMemcpyHostToDevice, st);
+        if (he == hipSuccess) he = hipEventRecord(p->ev_copy[j % 2], st);
+    }
+    close(fd);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_HIP, "loading %s failed: %s", path, hipGetErrorString(he));
+    *d_file = d;
+    *size = n;
+    return SNPGPU_OK;
+}
+
+int scan_status_error(snpgpu_ctx *ctx, const uint64_t *status, const char *what_file) {
+    unsigned code = (unsigned)(status[0] & 0xFF);
+    unsigned long long off = (unsigned long long)(status[0] >> 8) - 1;
+    const char *what = code == SCAN_ERR_FEW_FIELDS ? "line has fewer than 2 fields" :
+                       code == SCAN_ERR_BAD_POS ? "position field is not an unsigned decimal integer" :
+                       code == SCAN_ERR_NON_ASCII ? "non-ASCII byte" : "malformed line";
+    return snpgpu_set_error(ctx, code == SCAN_ERR_NON_ASCII ? SNPGPU_E_UNSUPPORTED : SNPGPU_E_PILEUP,
+                            "pileup%s%s: %s at byte offset %llu", what_file ? " " : "", what_file ? what_file : "", what, off);
+}
+
+}  // namespace
+
+extern "C" {
+
+int snpgpu_call_consensus_files(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const char *const *paths, uint32_t n_files,
+                                const snpgpu_caller_params *params, uint8_t *out_base, uint8_t *out_filters,
+                                snpgpu_site_counts *out_counts, uint64_t *out_line_off, uint64_t *out_status,
+                                int32_t *out_rc, const snpgpu_stream_opts *opts, snpgpu_stream_stats *stats) {
+    if (!ctx || !ss || !params || !out_status || (n_files && !paths)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (ss->n_sites && n_files && (!out_base || !out_filters)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
+    std::vector<Source> src(n_files);
+    for (uint32_t f = 0; f < n_files; ++f) {
+        if (!paths[f]) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null path %u", f);
+        src[f].path = paths[f];
+    }
+    Outputs out{out_base, out_filters, out_counts, out_line_off, out_status, out_rc};
+    return run_stream(ctx, ss, src, params, out, opts, stats, nullptr);
+}
+
+// Host-buffer form for ONE pileup (an mmap, bytes read elsewhere): same pipeline, the readers memcpy instead of pread.
+// Synchronous.  Returns SNPGPU_E_PILEUP / SNPGPU_E_UNSUPPORTED when the scan found a malformed line (status words still filled).
+int snpgpu_call_consensus(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *pileup, size_t nbytes,
+                          const snpgpu_caller_params *params, uint8_t *out_base, uint8_t *out_filters,
+                          snpgpu_site_counts *out_counts, uint64_t *out_status, int want_depth_sum) {
+    if (!ctx || !ss || !params || !out_status || (nbytes && !pileup)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (ss->n_sites && (!out_base || !out_filters)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
+    static const uint8_t empty = 0;
+    std::vector<Source> src(1);
+    src[0].mem = nbytes ? pileup : &empty;
+    src[0].size = nbytes;
+    snpgpu_stream_opts o{};
+    o.want_depth_sum = want_depth_sum ? 1u : 0u;
+    Outputs out{out_base, out_filters, out_counts, nullptr, out_status, nullptr};
+    int rc = run_stream(ctx, ss, src, params, out, &o, nullptr, ss->site_line);
+    if (rc) return rc;
+    if (out_status[0] != ~0ull) return scan_status_error(ctx, out_status, nullptr);
+    return SNPGPU_OK;
+}
+
+// call_consensus --vcfAllPos (call_consensus.py:148-151, pileup.py:418-421): a Record for EVERY line of the pileup.
+// Synchronous, host outputs in file order: out_line_off[i] = 1 + byte offset of line i, out_line_flags[i] = SNPGPU_SITE_*
+// of its position (0 when it is not in the site set), out_counts[i] its record.  *out_n_lines is always set; when it
+// exceeds `capacity` nothing else is written and the caller comes back with larger arrays.  out_status: scan status words
+// ([0] = first line whose chrom / position columns are malformed, [1] = number of lines).
+int snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const char *path, const snpgpu_caller_params *params,
+                               uint64_t capacity, uint64_t *out_n_lines, uint64_t *out_line_off, uint8_t *out_line_flags,
+                               snpgpu_site_counts *out_counts, uint64_t *out_status) {
+    if (!ctx || !ss || !path || !params || !out_n_lines || !out_status) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (capacity && (!out_line_off || !out_line_flags || !out_counts)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint8_t *d_file = nullptr;
+    uint64_t nbytes = 0;
+    int rc = load_file(ctx, path, &d_file, &nbytes);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    const size_t ws_words = snpgpu_lines_workspace_words(nbytes);
+    // first the count alone (its workspace is all the scratch it needs) ...
+    void *scr = nullptr;
+    rc = snpgpu_scratch(ctx, up(4 * ws_words, 256) + 512, &scr);
+    if (rc) return rc;
+    uint32_t *d_total = nullptr;
+    rc = snpgpu_enqueue_lines_count(ctx, d_file, nbytes, (uint32_t *)scr, &d_total);
+    if (rc) return rc;
+    uint32_t n_lines = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n_lines, d_total, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    *out_n_lines = n_lines;
+    out_status[0] = ~0ull; out_status[1] = n_lines; out_status[2] = out_status[3] = 0;
+    if (n_lines > capacity || n_lines == 0) return SNPGPU_OK;
+    // ... then everything: the scratch may move, so the count is redone in the new place (cheap next to the call step)
+    size_t o = up(4 * ws_words, 256);
+    const size_t o_off = o; o += up(8ull * n_lines, 256);
+    const size_t o_flag = o; o += up(n_lines, 256);
+    const size_t o_base = o; o += up(n_lines, 256);
+    const size_t o_filt = o; o += up(n_lines, 256);
+    const size_t o_stat = o; o += 256;
+    const size_t o_samp = o; o += 256;
+    const size_t o_cnt = o; o += sizeof(snpgpu_site_counts) * (size_t)n_lines;
+    rc = snpgpu_scratch(ctx, o + 256, &scr);
+    if (rc) return rc;
+    char *b = (char *)scr;
+    rc = snpgpu_enqueue_lines_count(ctx, d_file, nbytes, (uint32_t *)b, &d_total);
+    if (rc) return rc;
+    uint64_t h_status[SNPGPU_SCAN_STATUS_WORDS] = {~0ull, n_lines, 0, 0};
+    SampleDev sd{};
+    sd.buf = d_file;
+    sd.nbytes = nbytes;
+    sd.status = (uint64_t *)(b + o_stat);
+    HIP_TRY(ctx, hipMemcpyAsync(b + o_stat, h_status, sizeof h_status, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(b + o_samp, &sd, sizeof sd, hipMemcpyHostToDevice, st));
+    rc = snpgpu_enqueue_lines_emit(ctx, ss, d_file, nbytes, (uint32_t *)b, (uint64_t *)(b + o_off), (uint8_t *)(b + o_flag), n_lines,
+                                   (uint64_t *)(b + o_stat));
+    if (rc == SNPGPU_OK)
+        rc = snpgpu_enqueue_call_lines(ctx, (const SampleDev *)(b + o_samp), (const uint64_t *)(b + o_off), (const uint8_t *)(b + o_flag),
+                                       n_lines, params, (uint8_t *)(b + o_base), (uint8_t *)(b + o_filt), (snpgpu_site_counts *)(b + o_cnt));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out_line_off, b + o_off, 8ull * n_lines, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(out_line_flags, b + o_flag, n_lines, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(out_counts, b + o_cnt, sizeof(snpgpu_site_counts) * (size_t)n_lines, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(out_status, b + o_stat, 8 * SNPGPU_SCAN_STATUS_WORDS, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    out_status[1] = n_lines;
+    if (out_status[0] != ~0ull) return scan_status_error(ctx, out_status, path);
+    return SNPGPU_OK;
+}
+
+}  // extern "C"

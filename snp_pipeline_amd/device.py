@@ -23,7 +23,23 @@ _SCAN_CODES = {1: "line has fewer than 2 fields", 2: "position field is not an u
 
 
 class PileupFormatError(ValueError):
-    """The pileup text is malformed in a way that makes the reference raise (pileup.py:425-426, 224-237)."""
+    """The pileup text is malformed in a way that makes the reference raise (pileup.py:425-426, 224-237).
+    ``reference_exception`` is the exception class the reference raises for the same input (ValueError or IndexError;
+    None where the reference does not raise and this build refuses the input); the CLI re-raises as that class so that
+    the error log names the same exception type."""
+
+    def __init__(self, message, reference_exception=ValueError):
+        ValueError.__init__(self, message)
+        self.reference_exception = reference_exception
+
+
+class PileupIOError(IOError):
+    """A pileup file could not be opened or read (the reference's open() fails the same way, pileup.py:405/417)."""
+
+
+# exception class of the reference per scan code (pileup.py:425 unpacking / :426 int()) and per site status
+# (pileup.py:224-225 IndexError, :225 ValueError, :237 IndexError); None: the reference accepts the input
+_SCAN_EXC = {1: ValueError, 2: ValueError, 3: None}
 
 
 def _ptr(a):
@@ -95,11 +111,12 @@ class SiteSet(object):
 
 
 class ConsensusResult(object):
-    __slots__ = ("bases", "filters", "counts", "status", "n_lines", "n_matched", "depth_sum")
+    __slots__ = ("bases", "filters", "counts", "status", "n_lines", "n_matched", "depth_sum", "line_offsets")
 
     def __init__(self, bases, filters, counts, status):
         self.bases, self.filters, self.counts, self.status = bases, filters, counts, status
         self.n_lines, self.n_matched, self.depth_sum = int(status[1]), int(status[2]), int(status[3])
+        self.line_offsets = None
 
 
 class Device(object):
@@ -162,7 +179,8 @@ class Device(object):
         w0 = int(status[0])
         if w0 != 0xFFFFFFFFFFFFFFFF:
             code, off = w0 & 0xFF, (w0 >> 8) - 1
-            raise PileupFormatError("pileup: %s at byte offset %d" % (_SCAN_CODES.get(code, "malformed line"), off))
+            raise PileupFormatError("pileup: %s at byte offset %d" % (_SCAN_CODES.get(code, "malformed line"), off),
+                                    _SCAN_EXC.get(code, ValueError))
 
     def call_consensus(self, siteset, pileup, params, want_counts=False, want_depth_sum=False, check=True):
         """pileup: bytes-like (host).  Returns ConsensusResult over siteset.keys order.  check=False: do not raise for
@@ -195,11 +213,76 @@ class Device(object):
             bad = np.nonzero(res.filters & 0x80)[0]
             code = int(res.filters[bad[0]] & 0x7F) if len(bad) else 0
         if len(bad):
-            what = {L.ST_SHORT_LINE: "IndexError: line has fewer than 4 fields",
-                    L.ST_BAD_DEPTH: "ValueError: depth field is not an unsigned decimal integer",
-                    L.ST_NO_QUALS: "IndexError: depth > 0 but no quality field",
-                    L.ST_MULTI_REF: "unsupported: reference-base field longer than one byte"}.get(code, "malformed line")
-            raise PileupFormatError("pileup line for site #%d: %s" % (int(bad[0]), what))
+            what, exc = {L.ST_SHORT_LINE: ("line has fewer than 4 fields", IndexError),
+                         L.ST_BAD_DEPTH: ("depth field is not an unsigned decimal integer", ValueError),
+                         L.ST_NO_QUALS: ("depth > 0 but no quality field", IndexError),
+                         L.ST_MULTI_REF: ("unsupported: reference-base field longer than one byte", None)
+                         }.get(code, ("malformed line", ValueError))
+            raise PileupFormatError("pileup line for site #%d: %s" % (int(bad[0]), what), exc)
+
+    def call_consensus_files(self, siteset, paths, params, want_counts=False, want_line_offsets=False,
+                             want_depth_sum=False, chunk_bytes=0, n_readers=0, n_staging=0, n_slots=0):
+        """Streamed ingestion of pileup FILES (snpgpu_call_consensus_files): reader threads -> pinned staging -> copy
+        stream -> scan of the tiles that have landed; no file is resident in host memory.
+        Returns (results, rcs, stats): one ConsensusResult per path (``.line_offsets`` set when asked for), the per-file
+        return codes (0, E_IO, E_PILEUP, E_UNSUPPORTED) and the StreamStats of the call.  Nothing is raised per file:
+        use ``raise_file_status``."""
+        n_files, n = len(paths), len(siteset)
+        enc = [os.fsencode(p) for p in paths]
+        arr = (C.c_char_p * max(n_files, 1))(*enc)
+        bases = np.empty((n_files, n), dtype=np.uint8)
+        filters = np.empty((n_files, n), dtype=np.uint8)
+        counts = np.zeros((n_files, n), dtype=COUNTS_DTYPE) if want_counts else None
+        line_off = np.zeros((n_files, n), dtype=np.uint64) if want_line_offsets else None
+        status = np.zeros((n_files, L.SCAN_STATUS_WORDS), dtype=np.uint64)
+        rcs = np.zeros(max(n_files, 1), dtype=np.int32)
+        opts = L.StreamOpts(int(chunk_bytes), int(n_staging), int(n_readers), int(n_slots), 1 if want_depth_sum else 0)
+        stats = L.StreamStats()
+        self._check(self.lib.snpgpu_call_consensus_files(
+            self.ctx, siteset.handle, arr, n_files, C.byref(params), _ptr(bases), _ptr(filters), _ptr(counts),
+            _ptr(line_off), _ptr(status), _ptr(rcs), C.byref(opts), C.byref(stats)))
+        results = []
+        for f in range(n_files):
+            r = ConsensusResult(bases[f], filters[f], counts[f] if want_counts else None, status[f])
+            r.line_offsets = line_off[f] if want_line_offsets else None
+            results.append(r)
+        return results, rcs[:n_files], stats
+
+    def call_all_lines(self, siteset, path, params, capacity=0):
+        """call_consensus --vcfAllPos: a record for EVERY line of the pileup file, in file order.
+        Returns (line_offsets + 1, line site flags, counts records).  Raises like the reference for malformed lines."""
+        n_lines = C.c_uint64()
+        status = np.zeros(L.SCAN_STATUS_WORDS, dtype=np.uint64)
+        while True:
+            cap = int(capacity)
+            off = np.zeros(max(cap, 1), dtype=np.uint64)
+            flags = np.zeros(max(cap, 1), dtype=np.uint8)
+            counts = np.zeros(max(cap, 1), dtype=COUNTS_DTYPE)
+            rc = self.lib.snpgpu_call_all_lines_file(self.ctx, siteset.handle, os.fsencode(path), C.byref(params), cap,
+                                                     C.byref(n_lines), _ptr(off), _ptr(flags), _ptr(counts), _ptr(status))
+            if rc == L.E_IO:
+                raise PileupIOError("cannot open or read the pileup file %s" % path)
+            if rc in (L.E_PILEUP, L.E_UNSUPPORTED) and int(status[0]) != 0xFFFFFFFFFFFFFFFF:
+                self.raise_scan_status(status)
+            self._check(rc)
+            if n_lines.value <= cap:
+                break
+            capacity = n_lines.value
+        n = n_lines.value
+        res = ConsensusResult(None, None, counts[:n], status)
+        self.raise_site_status(res)
+        return off[:n], flags[:n], counts[:n]
+
+    def raise_file_status(self, path, rc, res, check=True):
+        """Raise for one file of call_consensus_files the way call_consensus does for its single pileup."""
+        if rc == L.E_IO:
+            raise PileupIOError("cannot open or read the pileup file %s" % path)
+        if rc in (L.E_PILEUP, L.E_UNSUPPORTED):
+            self.raise_scan_status(res.status)
+        if rc != 0:
+            raise SnpGpuError(int(rc), "pileup %s" % path)
+        if check:
+            self.raise_site_status(res)
 
     def line_offsets(self, siteset):
         """1 + byte offset of the pileup line used for each site by the last call_consensus on this set (0 = none)."""
@@ -311,10 +394,57 @@ class Device(object):
 
 
 _default = None
+_slot_lock = None
+
+
+def device_count():
+    return int(L.load().snpgpu_device_count())
+
+
+def acquire_device_slot(n_devices, max_per_device=None, lock_dir=None):
+    """Device assignment for the reference's per-sample process array (run.py:709-710 starts up to max_cpu_cores
+    ``cfsan_snp_pipeline call_consensus`` processes at once, none of which knows about the others).  Every process
+    takes an advisory lock on one of ``n_devices x max_per_device`` slot files: the first free slot in a sweep that
+    prefers the least loaded device, or — when all are taken — a blocking wait on one of them.  So the processes spread
+    round-robin over the visible GPUs and at most ``max_per_device`` contexts exist per GPU at a time; the lock dies with
+    the process.  Returns (device index, open lock file)."""
+    import fcntl
+    import tempfile
+    if max_per_device is None:
+        max_per_device = int(os.environ.get("SNPGPU_MAX_PROCS_PER_DEVICE", "4"))
+    max_per_device = max(1, max_per_device)
+    lock_dir = lock_dir or os.environ.get("SNPGPU_LOCK_DIR") or os.path.join(tempfile.gettempdir(), "snpgpu-%d" % os.getuid())
+    os.makedirs(lock_dir, exist_ok=True)
+    start = os.getpid() % n_devices
+    order = [((start + i) % n_devices, j) for j in range(max_per_device) for i in range(n_devices)]
+
+    def open_slot(dev, j):
+        return open(os.path.join(lock_dir, "dev%d.slot%d" % (dev, j)), "a+")
+
+    for dev, j in order:                       # slot 0 of every device first, then slot 1 ...: least loaded device wins
+        f = open_slot(dev, j)
+        try:
+            fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)
+            return dev, f
+        except (IOError, OSError):
+            f.close()
+    dev, j = order[os.getpid() % len(order)]
+    f = open_slot(dev, j)
+    fcntl.flock(f, fcntl.LOCK_EX)              # everything is busy: queue up behind one slot
+    return dev, f
 
 
 def default_device():
-    global _default
+    """The process-wide device.  SNPGPU_DEVICE / LOCAL_RANK pin it; otherwise a console-script process takes a device
+    slot (see acquire_device_slot), anything else uses device 0."""
+    global _default, _slot_lock
     if _default is None:
+        pinned = os.environ.get("SNPGPU_DEVICE", os.environ.get("LOCAL_RANK"))
+        if pinned is None and L.TORCH_FREE_OK:
+            n = device_count()
+            if n > 0:
+                index, _slot_lock = acquire_device_slot(n)
+                _default = Device(index)
+                return _default
         _default = Device()
     return _default

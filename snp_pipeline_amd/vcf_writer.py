@@ -99,3 +99,28 @@ def write_consensus_vcf(path, sample_id, args, siteset, result, line_offsets):
             chrom, pos = keys[int(slot)]
             f.write(row_from_counts(chrom.decode("ascii"), pos, result.counts[int(slot)], names,
                                     args.vcfPreserveRefCase, args.vcfFailedSnpGt) + "\n")
+
+
+def write_all_positions_vcf(path, sample_id, args, pileup_path, line_offsets, counts):
+    """--vcfAllPos (call_consensus.py:148-151): one row per pileup LINE, in file order.  The numbers come from the
+    per-line records of ``Device.call_all_lines``; CHROM and POS are the first two fields of the line itself."""
+    import mmap
+    filters = filter_descriptions(args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
+    names = [n for n, _ in filters]
+    with open(path, "w") as f:
+        f.write("\n".join(header_lines(sample_id, filters, args.vcfRefName)) + "\n")
+        if len(line_offsets) == 0:
+            return
+        with open(pileup_path, "rb") as pf:
+            mm = mmap.mmap(pf.fileno(), 0, access=mmap.ACCESS_READ)
+            try:
+                for i in range(len(line_offsets)):
+                    start = int(line_offsets[i]) - 1
+                    fields = mm[start:start + 256].split(None, 2)
+                    if len(fields) < 3:                          # a very long contig name: take the whole line
+                        end = mm.find(b"\n", start)
+                        fields = mm[start:end if end >= 0 else len(mm)].split(None, 2)
+                    f.write(row_from_counts(fields[0].decode("ascii"), int(fields[1]), counts[i], names,
+                                            args.vcfPreserveRefCase, args.vcfFailedSnpGt) + "\n")
+            finally:
+                mm.close()

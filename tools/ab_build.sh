@@ -10,7 +10,7 @@ git -C "$root" archive "$rev" snp_pipeline_amd/csrc include | tar -x -C "$tmp"
 objs=""
 for f in "$tmp"/snp_pipeline_amd/csrc/*.hip; do
     o="$tmp/$(basename "$f" .hip).o"
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -c "$f" -o "$o" &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -DSNPGPU_TUNING -c "$f" -o "$o" &
     objs="$objs $o"
 done
 wait
