@@ -2,21 +2,24 @@
 """bench.py — throughput of the post-alignment hot path on MI355X, one process per GPU.
 
 A *step* is one pass of the hot path over one batch of synthetic samples already resident in HBM:
-    call_consensus (pileup scan + per-site caller) for this rank's B samples
-    -> pack the B x S consensus matrix 4 bits/site -> all-gather of packed rows over RCCL (N > 1)
-    -> all-pairs SNP distance over the (N*B) x S matrix, 128x128 tiles dealt cyclically to ranks.
-Workload at N = 1: BASELINE.json configs[1] size (the Agona set: ~25 samples, ~5 Mbp reference; B = 24 samples per
-rank) with the synthetic pileups configs[3] specifies (30x depth, 50 k SNP sites) because the reference bundles no
-pileup files.  N > 1 is weak scaling: B samples per rank (the node-level run of configs[3] would be 8 ranks x 125
-samples, same per-sample work).  value = consensus bases called per second, whole job.
+    C1  all-gather of every rank's per-sample SNP records (site keys) + the site union on the device (merge_sites)
+    call_consensus (pileup scan + per-site caller) for this rank's samples: one scan launch + one call launch
+    -> pack the consensus matrix 4 bits/site -> C2 all-gather of packed rows over RCCL (N > 1)
+    -> all-pairs SNP distance over the (N*B) x S matrix, 128x128 tiles dealt cyclically to ranks
+    -> row-band exchange (all-to-all): every rank ends with the complete distance rows of its band.
+Workload at N = 1: the per-GPU shard of BASELINE.json configs[3] — 125 samples (1000 / 8) x 5 Mbp x 30x synthetic
+pileups (54 GB of text resident in HBM), 50 k SNP sites, 1 500 SNP records per sample.  N > 1: weak scaling by default
+(125 samples per rank: N = 8 is configs[3] itself); `--scaling strong` keeps the total at --samples.  value = consensus
+bases called per second, whole job.
 
 The same JSON line carries
   roofline      the pileup-scan kernel: algorithmic bytes (= pileup text bytes, each read once) / its average launch
                 duration measured with HIP events recorded on the launch stream inside the timed region;
-  cpu_baseline  the CPU oracle (a statement-for-statement Python port of the reference's loop structure) on the
-                first samples of the same batch, 1 core, rank 0, N=1 only;
-  secondary     pairwise SNP distances/s of the distance kernel alone at BASELINE configs[4] shape
-                (10 000 x 200 000), timed separately after the K steps.
+  end_to_end    pileup FILES in the page cache -> consensus bytes on the host through the streamed ingestion, next to the
+                pinned host-to-device copy rate measured in the same process;
+  cpu_baseline  the CPU oracle (a statement-for-statement Python port of the reference's loop structure) on samples of
+                the same batch: 1 core, one process per sample on min(cores, 32) cores, and the distance loop; rank 0, N=1;
+  secondary     pairwise SNP distances/s of the distance step alone at BASELINE configs[4] shape (10 000 x 200 000).
 """
 import argparse
 import json
@@ -30,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+PROFILE_ROUND = "r2"
 
 
 def parse_args():
@@ -37,18 +41,23 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--samples", type=int, default=24, help="samples per rank resident in HBM")
+    ap.add_argument("--samples", type=int, default=125, help="samples per rank (weak scaling) or in total (strong scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--genome", type=int, default=5_000_000)
     ap.add_argument("--sites", type=int, default=50_000)
     ap.add_argument("--depth", type=float, default=30.0)
+    ap.add_argument("--vcf-records", type=int, default=1500, help="phase-1 SNP records per sample (input of the site merge, C1)")
     ap.add_argument("--dist-samples", type=int, default=10_000)
     ap.add_argument("--dist-sites", type=int, default=200_000)
     ap.add_argument("--dist-reps", type=int, default=2)
-    ap.add_argument("--cpu-samples", type=int, default=3, help="samples timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-samples", type=int, default=8, help="samples timed on the CPU oracle, one core (0 = skip the CPU baseline)")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="one-process-per-sample CPU leg: processes (0 = min(cores, 32))")
+    ap.add_argument("--cpu-dist-samples", type=int, default=60, help="rows of the CPU distance leg (x 50 000 sites)")
     ap.add_argument("--skip-secondary", action="store_true")
     ap.add_argument("--skip-aux", action="store_true", help="skip the device-copy ceiling and the K3/K4 timings")
     ap.add_argument("--skip-cpu-parallel", action="store_true", help="skip the one-process-per-sample CPU baseline")
     ap.add_argument("--e2e-files", type=int, default=16, help="pileup files streamed from the page cache for the end_to_end row (0 = skip)")
+    ap.add_argument("--dump", type=str, default=None, help="write this rank's results (site union, packed matrix, distance band) to DUMP.rankN.npz")
     return ap.parse_args()
 
 
@@ -62,25 +71,31 @@ def _oracle_worker(job):
     return cons
 
 
+def _scratch_dir(need_bytes):
+    """A directory on a regular file system with room for the pileup files (page cache), else tmpfs.  The FIRST read of
+    freshly written tmpfs pages is serialised in the kernel (~15 GB/s on the bench box whatever the thread count; later
+    passes, and every pass over ordinary page-cache files, are not), so tmpfs comes second."""
+    import shutil
+    import tempfile
+    for cand in (tempfile.gettempdir(), "/dev/shm"):
+        try:
+            if shutil.disk_usage(cand).free > 2 * need_bytes:
+                return cand
+        except OSError:
+            pass
+    return None
+
+
 def end_to_end(d, ss, prm, pile, offs, sizes, bases, n_files, S):
-    """Page-cache files -> FASTA bytes: the rate a run over more samples than fit in HBM proceeds at.  The files are
-    written first (page cache / tmpfs), one warm-up file goes through (pinned staging allocation), then all of them are
-    timed in one snpgpu_call_consensus_files call and compared with the resident results; the yardstick is a pinned
-    host-to-device copy measured in the same process."""
+    """Page-cache files -> consensus bytes: the rate a run over more samples than fit in HBM proceeds at.  The files are
+    written first, one warm-up file goes through (pinned staging allocation), then all of them are timed in one
+    snpgpu_call_consensus_files call and compared with the resident results; the yardstick is a pinned host-to-device
+    copy measured in the same process."""
     import shutil
     import tempfile
     import torch
     need = int(sum(sizes[:n_files])) + (64 << 20)
-    base_dir = None
-    # a regular file system first: the FIRST read of freshly written tmpfs pages is serialised in the kernel (~15 GB/s on
-    # the bench box whatever the thread count; every later pass, and every pass over ordinary page-cache files, is not)
-    for cand in (tempfile.gettempdir(), "/dev/shm"):
-        try:
-            if shutil.disk_usage(cand).free > 2 * need:
-                base_dir = cand
-                break
-        except OSError:
-            pass
+    base_dir = _scratch_dir(need)
     if base_dir is None:
         return {"skipped": "no room for %d bytes of pileup files" % need}
     tmpdir = tempfile.mkdtemp(prefix="snpbench_e2e_", dir=base_dir)
@@ -123,6 +138,172 @@ def end_to_end(d, ss, prm, pile, offs, sizes, bases, n_files, S):
         shutil.rmtree(tmpdir, ignore_errors=True)
 
 
+def _event_ms(torch, fn, reps=3):
+    """Device time of fn() (enqueued on torch's current stream) by events, best of reps."""
+    best = None
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ms = a.elapsed_time(b)
+        best = ms if best is None or ms < best else best
+    return best
+
+
+def aux_steps(d, pos, G):
+    """K3 / K4 at configs[3] scale (1000 samples x 1500 SNP records): device time of the _dev forms (device pointers, no
+    host synchronisation inside) and wall time of the host-pointer forms (staging + kernels + read-back)."""
+    import torch
+    arng = np.random.default_rng(5)
+    n_s, per = 1000, 1500
+    samp_pos = [np.sort(arng.choice(pos, size=per, replace=False)) for _ in range(n_s)]
+    keys = np.concatenate(samp_pos).astype(np.int64)                # contig 0
+    who = np.repeat(np.arange(n_s, dtype=np.int32), per)
+    m = len(keys)
+    tk, tw = torch.from_numpy(keys).cuda(), torch.from_numpy(who).cuda()
+    ou = torch.zeros(m, dtype=torch.int64, device="cuda")
+    oo = torch.zeros(m + 1, dtype=torch.int32, device="cuda")
+    oc = torch.zeros(m, dtype=torch.int32, device="cuda")
+    on = torch.zeros(4, dtype=torch.int32, device="cuda")
+    k_merge = _event_ms(torch, lambda: d.merge_sites_dev(tk.data_ptr(), tw.data_ptr(), m, ou.data_ptr(), oo.data_ptr(), oc.data_ptr(), on.data_ptr()))
+    n_unique = int(on[0])
+    seg = torch.arange(0, m + 1, per, dtype=torch.int32, device="cuda")
+    cap = 3 * m
+    ws_, we_ = torch.zeros(cap, dtype=torch.int64, device="cuda"), torch.zeros(cap, dtype=torch.int64, device="cuda")
+    wg_, wn = torch.zeros(cap, dtype=torch.int32, device="cuda"), torch.zeros(2, dtype=torch.int32, device="cuda")
+    k_dense = _event_ms(torch, lambda: d.dense_windows_dev(tk.data_ptr(), seg.data_ptr(), n_s, m, [3, 2, 1], [1000, 125, 15],
+                                                          ws_.data_ptr(), we_.data_ptr(), wg_.data_ptr(), wn.data_ptr()))
+    n_win = int(wn[0])
+    grp = torch.zeros(max(n_win, 1), dtype=torch.int32, device="cuda")
+    og = torch.zeros(max(n_win, 1), dtype=torch.int32, device="cuda")
+    os_, oe = torch.zeros(max(n_win, 1), dtype=torch.int64, device="cuda"), torch.zeros(max(n_win, 1), dtype=torch.int64, device="cuda")
+    mn = torch.zeros(2, dtype=torch.int32, device="cuda")
+    k_mreg = _event_ms(torch, lambda: d.merge_regions_dev(grp.data_ptr(), ws_.data_ptr(), we_.data_ptr(), n_win, og.data_ptr(), os_.data_ptr(),
+                                                          oe.data_ptr(), mn.data_ptr()))
+    n_reg = int(mn[0])
+    roff = torch.tensor([0, n_reg], dtype=torch.int32, device="cuda")
+    pg = torch.zeros(m, dtype=torch.int32, device="cuda")
+    flag = torch.zeros(m, dtype=torch.uint8, device="cuda")
+    k_inreg = _event_ms(torch, lambda: d.in_regions_dev(pg.data_ptr(), tk.data_ptr(), m, roff.data_ptr(), os_.data_ptr(), oe.data_ptr(), 1, flag.data_ptr()))
+    inside = int(flag.sum().item())
+    # host-pointer forms
+    hk, hw = keys.astype(np.uint64), who.astype(np.uint32)
+    d.merge_sites(hk[:1000], hw[:1000])
+    t1 = time.perf_counter()
+    uniq, _, _ = d.merge_sites(hk, hw)
+    t_merge = time.perf_counter() - t1
+    hseg = np.arange(0, m + 1, per, dtype=np.uint32)
+    t1 = time.perf_counter()
+    hs, he, _ = d.dense_windows(keys, hseg, [3, 2, 1], [1000, 125, 15])
+    t_dense = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    _, rs_, re_ = d.merge_regions(np.zeros(len(hs), np.uint32), hs, he)
+    t_mreg = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    hin = d.in_regions(np.zeros(m, np.uint32), keys, [0, len(rs_)], rs_, re_)
+    t_inreg = time.perf_counter() - t1
+    assert (len(uniq), len(hs), len(rs_), int(hin.sum())) == (n_unique, n_win, n_reg, inside)
+    return {
+        "workload": "%d samples x %d SNP records each, one contig of %d bp" % (n_s, per, G),
+        "device_ms": {"merge_sites_union_and_carriers": k_merge, "dense_windows_3_rules": k_dense, "merge_regions": k_mreg,
+                      "in_regions": k_inreg,
+                      "note": "_dev entry points: device pointers in and out, HIP events around the whole step, no host synchronisation inside"},
+        "host_form_wall_ms": {"merge_sites_union_and_carriers": t_merge * 1e3, "dense_windows_3_rules": t_dense * 1e3,
+                              "merge_regions": t_mreg * 1e3, "in_regions": t_inreg * 1e3,
+                              "note": "host-pointer entry points: pageable H2D + kernels + D2H, one synchronisation at the end"},
+        "unique_sites": n_unique, "windows": n_win, "regions": n_reg, "records_in_a_region": inside,
+    }
+
+
+def cpu_baseline(args, d, pile, offs, sizes, bases, pos, G, S, gpu_value, secondary):
+    """The CPU oracle — a statement-for-statement Python port of the reference's loops, pinned to the reference by the
+    golden vectors — on samples of the same batch.  Three legs, as BASELINE.md 3 plans: one core; one process per sample
+    on min(cores, 32) cores (what run.py:709-710 / xargs -P do); the distance loop (single process in the reference)."""
+    from oracle import pileup_oracle as po
+    from oracle import steps_oracle as so
+    B = len(sizes)
+    ncpu = min(args.cpu_samples, B)
+    snps = [(b"synth_chr1", int(p)) for p in pos]
+    p = po.CallerParams(0, 0.6, 3, 0, 0.0)
+    gpu_rows = bases[:max(ncpu, 1)].cpu().numpy()
+    t_cpu = 0.0
+    ok = True
+    for i in range(ncpu):
+        data = bytes(pile[int(offs[i]):int(offs[i]) + sizes[i]].cpu().numpy())
+        t1 = time.perf_counter()
+        cons, _ = po.call_consensus_sites(data, snps, set(), p)
+        t_cpu += time.perf_counter() - t1
+        ok = ok and (cons == bytes(gpu_rows[i]))
+    if not ok:
+        raise SystemExit("GPU consensus differs from the CPU oracle")
+    res = {
+        "value": ncpu * S / t_cpu, "unit": "bases/s", "cores": 1, "kind": "port",
+        "sample": "%d of the same synthetic samples (%d bp x %gx, %d sites each), call_consensus path only, pure-Python oracle"
+                  % (ncpu, G, args.depth, S),
+        "seconds": t_cpu, "genome_bp_per_sec": ncpu * G / t_cpu, "matches_gpu": True,
+        "gpu_over_cpu_1core": gpu_value / (ncpu * S / t_cpu),
+        "reference_probe": "BASELINE.md 2: the real reference measured 1.2e4 consensus bases/s and 1.19e6 genome-bp/s on 1 core "
+                           "(survey container, 200 kbp synthetic pileup)",
+    }
+    # the reference runs one call_consensus process per sample (xargs -P / run.py:710): one oracle process per sample on
+    # min(cores, 32) cores, files in the page cache
+    if not args.skip_cpu_parallel:
+        import multiprocessing as mp
+        import shutil
+        import tempfile
+        cores = os.cpu_count() or 1
+        nproc = args.cpu_procs or min(cores, 32)
+        nproc = max(1, min(nproc, B))
+        base_dir = _scratch_dir(int(sum(sizes[:nproc])))
+        if base_dir is not None:
+            tmpdir = tempfile.mkdtemp(prefix="snpbench_cpu_", dir=base_dir)
+            try:
+                paths = []
+                for i in range(nproc):
+                    path = os.path.join(tmpdir, "s%d.pileup" % i)
+                    with open(path, "wb") as f:
+                        f.write(pile[int(offs[i]):int(offs[i]) + sizes[i]].cpu().numpy().tobytes())
+                    paths.append(path)
+                rows = bases[:nproc].cpu().numpy()
+                ctx_mp = mp.get_context("spawn")                     # no fork of a process that holds a HIP context
+                t1 = time.perf_counter()
+                with ctx_mp.Pool(nproc) as pool:
+                    got = pool.map(_oracle_worker, [(pth, [int(x) for x in pos]) for pth in paths])
+                t_par = time.perf_counter() - t1
+            finally:
+                shutil.rmtree(tmpdir, ignore_errors=True)
+            res["parallel"] = {
+                "value": nproc * S / t_par, "unit": "bases/s", "processes": nproc, "host_cores": cores,
+                "seconds": t_par, "matches_gpu": bool(all(r == bytes(rows[i]) for i, r in enumerate(got))),
+                "gpu_over_cpu": gpu_value / (nproc * S / t_par),
+                "note": "one oracle process per sample incl. process start and file read, as the reference's xargs -P does; "
+                        "both steps are linear in samples, so the whole host's rate is this x cores / processes",
+            }
+    # distance: the reference's per-pair Python loop (utils.py:1135-1165, distance.py:93-98), single process
+    if args.cpu_dist_samples > 1:
+        rng = np.random.default_rng(3)
+        nd, sd = args.cpu_dist_samples, 50_000
+        sym = rng.choice(np.frombuffer(b"ACGT-", dtype=np.uint8), size=(nd, sd), p=[.24, .24, .24, .24, .04]).astype(np.uint8)
+        seqs = [bytes(r).decode() for r in sym]
+        t1 = time.perf_counter()
+        want = [[so.sequence_distance(seqs[i], seqs[j]) for j in range(i + 1, nd)] for i in range(nd)]
+        t_d = time.perf_counter() - t1
+        got = d.distance(sym)
+        same = all(got[i, j] == want[i][j - i - 1] for i in range(nd) for j in range(i + 1, nd))
+        if not same:
+            raise SystemExit("GPU distances differ from the CPU oracle")
+        pairs = nd * (nd - 1) / 2
+        res["distance"] = {
+            "value": pairs / t_d, "unit": "pairs/s", "cores": 1, "site_compares_per_sec": pairs * sd / t_d, "seconds": t_d,
+            "sample": "%d x %d random ACGT- matrix, all pairs, pure-Python oracle" % (nd, sd), "matches_gpu": True,
+            "gpu_over_cpu_site_compares": (secondary["site_compares_per_sec"] / (pairs * sd / t_d)) if secondary else None,
+            "reference_probe": "BASELINE.md 2: the real reference measured 1.1e7 site-compares/s on 1 core",
+        }
+    return res
+
+
 def main():
     args = parse_args()
     import torch
@@ -138,18 +319,28 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, args.gpus))
     # functional test hook (not a measurement mode): all ranks on one GPU over gloo, to exercise the N > 1 code path on
     # a single-GPU box
-    if os.environ.get("SNPGPU_BENCH_TEST_ONE_GPU") == "1":
+    one_gpu = os.environ.get("SNPGPU_BENCH_TEST_ONE_GPU") == "1"
+    if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    backend = None
     if world > 1:
-        if os.environ.get("SNPGPU_BENCH_TEST_ONE_GPU") == "1":
+        backend = "gloo" if one_gpu else "nccl"
+        if one_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     d = dev.Device(local_rank)
     d.use_torch_stream()
 
-    G, S, B = args.genome, args.sites, args.samples
+    G, S = args.genome, args.sites
+    if args.scaling == "weak":
+        n_total = world * args.samples
+        g0, g1 = rank * args.samples, (rank + 1) * args.samples
+    else:
+        n_total = args.samples
+        g0, g1 = sharding.shard_bounds(n_total, rank, world)
+    B = g1 - g0                                               # this rank's samples: global indices [g0, g1)
     # ---- synthetic inputs: reference seed 1, sites seed 2, pileups seed 3 -----------------------
     ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda")
     d.synth_reference_dev(1, G, ref.data_ptr())
@@ -171,13 +362,13 @@ def main():
 
     sizes = []
     for i in range(B):
-        sizes.append(d.synth_pileup_dev(3, rank * B + i, G, ref.data_ptr(), alt.data_ptr(), 0, 0, mean_depth=args.depth))
+        sizes.append(d.synth_pileup_dev(3, g0 + i, G, ref.data_ptr(), alt.data_ptr(), 0, 0, mean_depth=args.depth))
     offs = np.zeros(B + 1, dtype=np.uint64)
     for i, n in enumerate(sizes):
         offs[i + 1] = offs[i] + ((n + 255) // 256) * 256
     pile = torch.empty(int(offs[-1]) + 256, dtype=torch.uint8, device="cuda")
     for i in range(B):
-        n = d.synth_pileup_dev(3, rank * B + i, G, ref.data_ptr(), alt.data_ptr(), pile.data_ptr() + int(offs[i]),
+        n = d.synth_pileup_dev(3, g0 + i, G, ref.data_ptr(), alt.data_ptr(), pile.data_ptr() + int(offs[i]),
                                sizes[i], mean_depth=args.depth)
         assert n == sizes[i]
     torch.cuda.synchronize()
@@ -187,22 +378,48 @@ def main():
     ss = d.siteset(keys, [L.SITE_IN_SNPLIST] * S)
     prm = dev.make_params(0, 0.6, 3, 0, 0.0)                  # pipeline defaults (snppipeline.conf:249)
 
+    # phase-1 SNP records of every sample (what merge_sites reads from var.flt.vcf): a fixed subset of the sites per
+    # sample, keyed by the global sample index so that every rank can also tell what the union must be
+    recs = min(args.vcf_records, S)
+
+    def sample_records(g):
+        return np.sort(np.random.default_rng(1000 + g).choice(pos, size=recs, replace=False))
+
+    local_keys = torch.from_numpy(np.concatenate([sample_records(g) for g in range(g0, g1)] + [np.zeros(0, np.int64)]).astype(np.int64)).cuda()
+    local_samp = torch.from_numpy(np.repeat(np.arange(g0, g1, dtype=np.int32), recs)).cuda()
+    n_records = n_total * recs
+    u_keys = torch.zeros(max(n_records, 1), dtype=torch.int64, device="cuda")
+    u_off = torch.zeros(n_records + 1, dtype=torch.int32, device="cuda")
+    u_car = torch.zeros(max(n_records, 1), dtype=torch.int32, device="cuda")
+    u_n = torch.zeros(4, dtype=torch.int32, device="cuda")
+
     bases = torch.empty((B, S), dtype=torch.uint8, device="cuda")
     filt = torch.empty((B, S), dtype=torch.uint8, device="cuda")
-    status = torch.empty((B, 4), dtype=torch.int64, device="cuda")
+    status = torch.empty((max(B, 1), 4), dtype=torch.int64, device="cuda")
     row_bytes = d.packed_row_bytes(S)
     packed = torch.empty((B, row_bytes), dtype=torch.uint8, device="cuda")
-    dmat = torch.zeros((world * B, world * B), dtype=torch.int32, device="cuda")
-
+    bands = sharding.RowBands(n_total, world)
+    per = (n_total + world - 1) // world
+    packed_pad = torch.zeros((max(bands.n_padded, world * per), row_bytes), dtype=torch.uint8, device="cuda")
+    dmat = torch.zeros((bands.n_padded, bands.n_padded), dtype=torch.int32, device="cuda")
     sizes_np = np.asarray(sizes, dtype=np.uint64)
+    band_holder = [None]
 
     def step():
+        # C1: every rank's SNP records -> the same site union on every rank (the snplist)
+        keys_all, _ = sharding.all_gather_varlen(local_keys)
+        samp_all, _ = sharding.all_gather_varlen(local_samp)
+        d.merge_sites_dev(keys_all.data_ptr(), samp_all.data_ptr(), keys_all.numel(), u_keys.data_ptr(), u_off.data_ptr(),
+                          u_car.data_ptr(), u_n.data_ptr())
         # one scan launch and one call launch for the rank's whole batch; sample i is bytes [offs[i], offs[i] + sizes[i])
-        d.call_consensus_batch_dev(ss, pile.data_ptr(), offs[:B], prm, bases.data_ptr(), filt.data_ptr(), status.data_ptr(),
-                                   sizes=sizes_np)
-        d.pack_matrix_dev(bases.data_ptr(), B, S, S, packed.data_ptr())
-        packed_all = sharding.all_gather_rows(packed, world * B)         # C2: RCCL all-gather over xGMI when world > 1
-        d.distance_packed_dev(packed_all.data_ptr(), world * B, S, dmat.data_ptr(), rank, world)
+        if B:
+            d.call_consensus_batch_dev(ss, pile.data_ptr(), offs[:B], prm, bases.data_ptr(), filt.data_ptr(), status.data_ptr(),
+                                       sizes=sizes_np)
+            d.pack_matrix_dev(bases.data_ptr(), B, S, S, packed.data_ptr())
+        # C2: RCCL all-gather of the packed rows over xGMI when world > 1 (straight into the padded matrix)
+        sharding.all_gather_rows_into(packed, n_total, packed_pad)
+        d.distance_packed_dev(packed_pad.data_ptr(), bands.n_padded, S, dmat.data_ptr(), rank, world)
+        band_holder[0] = bands.exchange(dmat, rank)           # every rank: the complete rows of its band
 
     def barrier():
         torch.cuda.synchronize()
@@ -225,18 +442,29 @@ def main():
     dist_ms, dist_n = d.kernel_time_ms(2)
     d.kernel_timing(False)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    st = status.cpu().numpy()
-    if (st[:, 0] != -1).any():
-        raise SystemExit("scan reported a malformed pileup: %r" % st[:, 0])
-    if (filt.cpu().numpy() & 0x80).any():
-        raise SystemExit("caller reported a malformed line")
+    if B:
+        st = status[:B].cpu().numpy()
+        if (st[:, 0] != -1).any():
+            raise SystemExit("scan reported a malformed pileup: %r" % st[:, 0])
+        if (filt.cpu().numpy() & 0x80).any():
+            raise SystemExit("caller reported a malformed line")
+    want_union = len(np.unique(np.concatenate([sample_records(g) for g in range(n_total)]))) if n_total * recs <= 4_000_000 else None
+    if want_union is not None and int(u_n[0]) != want_union:
+        raise SystemExit("site union has %d keys, expected %d" % (int(u_n[0]), want_union))
+    if args.dump:
+        lo, hi = bands.band_rows(rank)
+        nu = int(u_n[0])
+        np.savez(args.dump + ".rank%d.npz" % rank, union=u_keys[:nu].cpu().numpy(), union_off=u_off[:nu + 1].cpu().numpy(),
+                 carriers=u_car[:int(u_n[1])].cpu().numpy(), packed=packed_pad[:n_total].cpu().numpy(),
+                 band=band_holder[0][:hi - lo, :n_total].cpu().numpy(), band_rows=np.array([lo, hi]), bases=bases.cpu().numpy(),
+                 first_sample=np.array([g0, g1]))
 
     ms_per_step = elapsed * 1e3 / args.steps
-    value = world * B * S / (elapsed / args.steps)
+    value = n_total * S / (elapsed / args.steps)
     scan_avg_ms = scan_ms / max(scan_n, 1)
     algo_bytes = pile_bytes * args.steps / max(scan_n, 1)       # per launch: the rank's whole batch of pileup text
     achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
@@ -245,39 +473,44 @@ def main():
     # quoted when it was measured on this very workload
     traffic = None
     traffic_note = None
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1", "pmc_traffic.json")) as f:
-            pt = json.load(f)
-        w = pt["workload"]
-        if (w["samples_per_gpu"], w["genome_bp"], w["mean_depth"], w["snp_sites"]) == (B, G, args.depth, S):
-            traffic = pt["traffic_bytes_per_launch"]
-            traffic_note = "profiles/r1/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-    except (OSError, KeyError, ValueError):
-        pass
+    for rnd in (PROFILE_ROUND, "r1"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
+                pt = json.load(f)
+            w = pt["workload"]
+            if (w["samples_per_gpu"], w["genome_bp"], w["mean_depth"], w["snp_sites"]) == (B, G, args.depth, S):
+                traffic = pt["traffic_bytes_per_launch"]
+                traffic_note = "profiles/%s/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % rnd
+                break
+        except (OSError, KeyError, ValueError):
+            pass
 
     out = {
         "metric": "consensus_bases_called_per_sec", "value": value, "unit": "bases/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1] size (Agona-like: %d samples/GPU x %d bp reference) with the synthetic "
-                               "pileups configs[3] specifies (%gx depth, %d SNP sites; the reference bundles no pileups); "
-                               "step = one batched scan launch + one call launch, 4-bit pack, all-gather, all-pairs distance"
-                               % (B, G, args.depth, S),
-                   "samples_per_gpu": B, "genome_bp": G, "mean_depth": args.depth, "snp_sites": S,
-                   "pileup_bytes_per_gpu": pile_bytes, "caller": "q0 c0.6 D3 d0 b0",
-                   "parallelism": "samples sharded, %d rank(s)" % world},
-        "genome_bp_per_sec": world * B * G / (elapsed / args.steps),
-        "pileup_gb_per_sec": world * pile_bytes / (elapsed / args.steps) / 1e9,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3] shard (%d samples%s x %d bp x %gx synthetic pileups, %d SNP sites, %d SNP records "
+                               "per sample; the reference bundles no pileups); step = site-record gather + site union, one batched "
+                               "scan launch + one call launch, 4-bit pack, row all-gather, all-pairs distance tiles, row-band exchange"
+                               % (args.samples, "/GPU" if args.scaling == "weak" else " in total", G, args.depth, S, recs),
+                   "samples_total": n_total, "samples_this_rank": B, "genome_bp": G, "mean_depth": args.depth, "snp_sites": S,
+                   "pileup_bytes_this_rank": pile_bytes, "caller": "q0 c0.6 D3 d0 b0",
+                   "parallelism": "samples sharded over %d rank(s)%s"
+                                  % (world, (", backend %s, world size %d" % (backend, dist.get_world_size())) if world > 1 else "")},
+        "genome_bp_per_sec": n_total * G / (elapsed / args.steps),
+        "pileup_gb_per_sec": (pile_bytes * n_total / max(B, 1)) / (elapsed / args.steps) / 1e9,
         "roofline": {"kernel": "k_scan_wave", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},
         "kernels_ms_per_step": {"k_scan_wave": scan_ms / args.steps, "k_call_sites": call_ms / args.steps,
                                 "k_distance": dist_ms / args.steps},
+        "site_union": {"records": n_records, "unique_sites": int(u_n[0]), "carriers": int(u_n[1])},
     }
 
-    # ---- secondary metric: the distance kernel alone at configs[4] shape ------------------------------------------
+    # ---- secondary metric: the distance step alone at configs[4] shape (kernel + row-band exchange) ------------------
     if not args.skip_secondary:
         n2, s2 = args.dist_samples, args.dist_sites
+        b2 = sharding.RowBands(n2, world)
         g = torch.Generator(device="cuda")
         g.manual_seed(3)
         lut = torch.tensor(list(b"ACGT-"), dtype=torch.uint8, device="cuda")
@@ -289,33 +522,39 @@ def main():
             idx = torch.multinomial(probs, (r1 - r0) * s2, replacement=True, generator=g)
             sym[r0:r1] = lut[idx].view(r1 - r0, s2)
             del idx
-        pk = torch.empty((n2, d.packed_row_bytes(s2)), dtype=torch.uint8, device="cuda")
+        pk = torch.zeros((b2.n_padded, d.packed_row_bytes(s2)), dtype=torch.uint8, device="cuda")
         d.pack_matrix_dev(sym.data_ptr(), n2, s2, s2, pk.data_ptr())
         del sym
-        dm = torch.zeros((n2, n2), dtype=torch.int32, device="cuda")
-        d.distance_packed_dev(pk.data_ptr(), n2, s2, dm.data_ptr(), rank, world)      # warm-up
+        dm = torch.zeros((b2.n_padded, b2.n_padded), dtype=torch.int32, device="cuda")
+
+        def dstep():
+            d.distance_packed_dev(pk.data_ptr(), b2.n_padded, s2, dm.data_ptr(), rank, world)
+            return b2.exchange(dm, rank) if world > 1 else dm
+
+        dstep()                                                  # warm-up
         barrier()
         d.kernel_timing(True)
         d.kernel_time_ms(2)
         t1 = time.perf_counter()
         for _ in range(args.dist_reps):
-            d.distance_packed_dev(pk.data_ptr(), n2, s2, dm.data_ptr(), rank, world)
+            dstep()
         barrier()
         el2 = (time.perf_counter() - t1) / args.dist_reps
         k_ms, k_n = d.kernel_time_ms(2)
         d.kernel_timing(False)
         if world > 1:
-            tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([el2], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el2 = float(tt.item())
         pairs = n2 * (n2 - 1) / 2
         # 4 VALU lane-ops per 32 site-compares (v_xor, 2 x v_bitop3, v_bcnt); integer VALU peak = 256 CU x 4 SIMD x 16 lanes
         # x 2.4 GHz
-        valu_peak = 256 * 64 * 2.4e9
+        valu_peak = 256 * 64 * 2.4e9 * world
         out["secondary"] = {
             "metric": "pairwise_snp_distances_per_sec", "value": pairs / el2, "unit": "pairs/s",
             "site_compares_per_sec": pairs * s2 / el2, "seconds": el2,
-            "config": {"workload": "BASELINE configs[4] shape: %d samples x %d sites, random ACGT- matrix" % (n2, s2)},
+            "config": {"workload": "BASELINE configs[4] shape: %d samples x %d sites, random ACGT- matrix; tiles dealt to %d rank(s)%s"
+                                   % (n2, s2, world, ", row-band exchange included" if world > 1 else "")},
             "kernel_ms": k_ms / max(k_n, 1),
             "valu_frac_of_peak": (pairs * s2 / 32 * 4 / el2) / valu_peak,
         }
@@ -334,87 +573,15 @@ def main():
         copy_s = (time.perf_counter() - t1) / 5
         del src, dst
         out["roofline"]["measured_copy_gbps_read_plus_write"] = 2 * (1 << 30) / copy_s / 1e9
-        # K3 / K4 at configs[3] scale: 1000 samples x ~1500 phase-1 SNP records each (host buffers in, host buffers out)
-        arng = np.random.default_rng(5)
-        n_s, per = 1000, 1500
-        samp_pos = [np.sort(arng.choice(pos, size=per, replace=False)) for _ in range(n_s)]
-        keys = np.concatenate(samp_pos).astype(np.uint64)              # contig 0
-        who = np.repeat(np.arange(n_s, dtype=np.uint32), per)
-        d.merge_sites(keys[:1000], who[:1000])                        # warm-up
-        t1 = time.perf_counter()
-        uniq, off_, car = d.merge_sites(keys, who)
-        t_merge = time.perf_counter() - t1
-        seg = np.arange(0, n_s * per + 1, per, dtype=np.uint32)
-        t1 = time.perf_counter()
-        ws_, we_, wg_ = d.dense_windows(keys.astype(np.int64), seg, [3, 2, 1], [1000, 125, 15])
-        t_dense = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        rg, rs_, re_ = d.merge_regions(np.zeros(len(ws_), np.uint32), ws_, we_)
-        t_mreg = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        inside = d.in_regions(np.zeros(len(keys), np.uint32), keys.astype(np.int64), [0, len(rs_)], rs_, re_)
-        t_inreg = time.perf_counter() - t1
-        out["aux_steps_ms"] = {
-            "workload": "%d samples x %d SNP records each, one contig of %d bp" % (n_s, per, G),
-            "merge_sites_union_and_carriers": t_merge * 1e3, "unique_sites": int(len(uniq)),
-            "dense_windows_3_rules": t_dense * 1e3, "windows": int(len(ws_)),
-            "merge_regions": t_mreg * 1e3, "regions": int(len(rs_)),
-            "in_regions": t_inreg * 1e3, "records_in_a_region": int(inside.sum()),
-            "note": "wall time of the host-buffer entry points (H2D + kernels + D2H); latency-bound, reported for completeness",
-        }
+        out["aux_steps_ms"] = aux_steps(d, pos, G)
 
     # ---- end to end: pileup FILES in the page cache -> consensus bytes on the host, through the streamed ingestion ----
-    if rank == 0 and world == 1 and args.e2e_files > 0:
+    if rank == 0 and world == 1 and args.e2e_files > 0 and B:
         out["end_to_end"] = end_to_end(d, ss, prm, pile, offs, sizes, bases, min(args.e2e_files, B), S)
 
-    # ---- CPU baseline: the oracle on the first samples of the batch, one core, rank 0, N = 1 ---------------------
-    if rank == 0 and world == 1 and args.cpu_samples > 0:
-        from oracle import pileup_oracle as po
-        ncpu = min(args.cpu_samples, B)
-        snps = [(b"synth_chr1", int(p)) for p in pos]
-        p = po.CallerParams(0, 0.6, 3, 0, 0.0)
-        gpu_rows = bases[:ncpu].cpu().numpy()
-        t_cpu = 0.0
-        ok = True
-        for i in range(ncpu):
-            data = bytes(pile[int(offs[i]):int(offs[i]) + sizes[i]].cpu().numpy())
-            t1 = time.perf_counter()
-            cons, _ = po.call_consensus_sites(data, snps, set(), p)
-            t_cpu += time.perf_counter() - t1
-            ok = ok and (cons == bytes(gpu_rows[i]))
-        out["cpu_baseline"] = {
-            "value": ncpu * S / t_cpu, "unit": "bases/s", "cores": 1, "kind": "port",
-            "sample": "%d of the same synthetic samples (%d bp x %gx, %d sites each), call_consensus path only, "
-                      "pure-Python oracle" % (ncpu, G, args.depth, S),
-            "seconds": t_cpu, "genome_bp_per_sec": ncpu * G / t_cpu, "matches_gpu": bool(ok),
-        }
-        if not ok:
-            raise SystemExit("GPU consensus differs from the CPU oracle")
-        # the reference runs one call_consensus process per sample (xargs -P / run.py:710): the same samples again, one
-        # oracle process each, for the host's parallel rate
-        if ncpu > 1 and not args.skip_cpu_parallel:
-            import multiprocessing as mp
-            import tempfile
-            tmpdir = tempfile.mkdtemp(prefix="snpbench_")
-            paths = []
-            for i in range(ncpu):
-                path = os.path.join(tmpdir, "s%d.pileup" % i)
-                with open(path, "wb") as f:
-                    f.write(bytes(pile[int(offs[i]):int(offs[i]) + sizes[i]].cpu().numpy()))
-                paths.append(path)
-            ctx_mp = mp.get_context("spawn")                     # no fork of a process that holds a HIP context
-            t1 = time.perf_counter()
-            with ctx_mp.Pool(ncpu) as pool:
-                res = pool.map(_oracle_worker, [(pth, [int(x) for x in pos]) for pth in paths])
-            t_par = time.perf_counter() - t1
-            for pth in paths:
-                os.remove(pth)
-            os.rmdir(tmpdir)
-            out["cpu_baseline"]["parallel"] = {
-                "value": ncpu * S / t_par, "unit": "bases/s", "processes": ncpu, "host_cores": os.cpu_count(),
-                "seconds": t_par, "matches_gpu": bool(all(r == bytes(gpu_rows[i]) for i, r in enumerate(res))),
-                "note": "one oracle process per sample incl. process start and file read, as the reference's xargs -P does",
-            }
+    # ---- CPU baseline: the oracle on samples of the batch; rank 0, N = 1 -----------------------------
+    if rank == 0 and world == 1 and args.cpu_samples > 0 and B:
+        out["cpu_baseline"] = cpu_baseline(args, d, pile, offs, sizes, bases, pos, G, S, value, out.get("secondary"))
 
     if rank == 0:
         print(json.dumps(out))

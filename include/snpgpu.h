@@ -229,32 +229,50 @@ int  snpgpu_distance_packed_dev(snpgpu_ctx *ctx, const void *d_packed, uint32_t 
 int  snpgpu_distance(snpgpu_ctx *ctx, const uint8_t *symbols, uint32_t n_rows, uint32_t n_sites, int32_t *out);
 
 /* ---- filter_regions: find_dense_regions (filter_regions.py:17-71) + utils.merge_regions
- *      (utils.py:1267-1282) + utils.in_region (utils.py:1314-1318) -----------------------------
- * Positions are grouped in segments (one per (sample, contig)); seg_off[n_segs+1]; the positions of a segment
- * may come in any order (they are sorted on the device, filter_regions.py:425).  For every rule r the candidate window (p[i], p[i+max_snps[r]]) is emitted when
- * p[i] + window[r] - 1 >= p[i+max_snps[r]].  out_start/out_end receive the candidates (capacity
- * n_pos * n_rules), out_seg their segment; *out_n the count.  Host pointers, synchronous. */
+ *      (utils.py:1267-1282) + utils.in_region (utils.py:1314-1318); merge_sites (merge_sites.py:91-117) ---------
+ * Hand-written sort / scan kernels (csrc/prims.h); each step comes as a host-pointer form (synchronous, one
+ * synchronisation at its end) and a `_dev` form (device pointers, asynchronous on the context's stream, counts left in
+ * device memory: d_out_n[0] = number of outputs, d_out_n[1] = error bits — 1: position outside [0, 2^40),
+ * 2: interval with start > end).  Output capacities are stated with each function.
+ *
+ * dense windows: positions are grouped in segments (one per (sample, contig)); seg_off[n_segs+1]; the positions of a
+ * segment may come in any order (they are sorted on the device, filter_regions.py:425).  For every rule r the candidate
+ * window (p[i], p[i+max_snps[r]]) is emitted when p[i] + window[r] - 1 >= p[i+max_snps[r]].  out_start/out_end receive the
+ * candidates (capacity n_pos * n_rules), out_seg their segment; order: by segment, position, rule.  At most 64 rules. */
 int  snpgpu_dense_windows(snpgpu_ctx *ctx, const int64_t *positions, const uint32_t *seg_off, uint32_t n_segs,
                           const int32_t *max_snps, const int32_t *window, uint32_t n_rules,
                           int64_t *out_start, int64_t *out_end, uint32_t *out_seg, uint32_t *out_n);
-/* Merge intervals per group (group ids ascending, intervals need not be sorted): sort by (group,start,end),
- * running max of end, join when start <= last_end + 1.  Outputs capacity n.  Host pointers, synchronous. */
+int  snpgpu_dense_windows_dev(snpgpu_ctx *ctx, const int64_t *d_positions, const uint32_t *d_seg_off, uint32_t n_segs,
+                              uint32_t n_pos, const int32_t *max_snps /* host */, const int32_t *window /* host */,
+                              uint32_t n_rules, int64_t *d_out_start, int64_t *d_out_end, uint32_t *d_out_seg,
+                              uint32_t *d_out_n /* 2 words */);
+/* Merge intervals per group (intervals in any order, start <= end): sort by (group,start,end), running max of end, join
+ * when start <= last_end + 1.  Output: merged regions ascending by (group, start); capacity n. */
 int  snpgpu_merge_regions(snpgpu_ctx *ctx, const uint32_t *group, const int64_t *start, const int64_t *end,
                           uint32_t n, uint32_t *out_group, int64_t *out_start, int64_t *out_end, uint32_t *out_n);
+int  snpgpu_merge_regions_dev(snpgpu_ctx *ctx, const uint32_t *d_group, const int64_t *d_start, const int64_t *d_end,
+                              uint32_t n, uint32_t *d_out_group, int64_t *d_out_start, int64_t *d_out_end,
+                              uint32_t *d_out_n /* 2 words */);
 /* in_region for many positions: regions per group must be merged (disjoint, sorted); reg_off[n_groups+1].
  * out_flag[i] = 1 when positions[i] lies in a region of pos_group[i] (inclusive ends). */
 int  snpgpu_in_regions(snpgpu_ctx *ctx, const uint32_t *pos_group, const int64_t *positions, uint32_t n_pos,
                        const uint32_t *reg_off, const int64_t *reg_start, const int64_t *reg_end,
                        uint32_t n_groups, uint8_t *out_flag);
+int  snpgpu_in_regions_dev(snpgpu_ctx *ctx, const uint32_t *d_pos_group, const int64_t *d_positions, uint32_t n_pos,
+                           const uint32_t *d_reg_off, const int64_t *d_reg_start, const int64_t *d_reg_end,
+                           uint32_t n_groups, uint8_t *d_out_flag);
 
-/* ---- merge_sites: union of (CHROM,POS) over samples (merge_sites.py:91-117) -----------------------
- * keys[i] = (contig_index << 32) | pos, sample_of_key[i] = sample index in sorted-dir order (ascending runs).
+/* merge_sites: union of (CHROM,POS) over samples (merge_sites.py:91-117).
+ * keys[i] = (contig_index << 32) | pos, sample_of_key[i] = sample index in sorted-dir order; records in any order.
  * Outputs: unique keys ascending, CSR offsets (n_unique+1) and the carrier sample indices in ascending
  * order per key, duplicates of (key, sample) collapsed (the reference builds a set per sample).
- * Capacities: out_unique[n], out_off[n+1], out_carrier[n].  Host pointers, synchronous. */
+ * Capacities: out_unique[n], out_off[n+1], out_carrier[n].  _dev: d_out_n[0] = unique keys, d_out_n[1] = carriers. */
 int  snpgpu_merge_sites(snpgpu_ctx *ctx, const uint64_t *keys, const uint32_t *sample_of_key, size_t n,
                         uint64_t *out_unique, uint32_t *out_off, uint32_t *out_carrier,
                         uint32_t *out_n_unique, uint32_t *out_n_carrier);
+int  snpgpu_merge_sites_dev(snpgpu_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_sample_of_key, uint32_t n,
+                            uint64_t *d_out_unique, uint32_t *d_out_off, uint32_t *d_out_carrier,
+                            uint32_t *d_out_n /* 2 words */);
 
 /* ---- synthetic pileups for bench/tests, generated on the device --------------------
  * Fills d_out with the text of one sample's pileup over a single contig and returns its length in *out_nbytes

@@ -84,6 +84,10 @@ SIGNATURES = {
     "snpgpu_merge_regions": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_uint32)]),
     "snpgpu_in_regions": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, _P, C.c_uint32, _P]),
     "snpgpu_merge_sites": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "snpgpu_dense_windows_dev": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, C.c_uint32, _P, _P, _P, _P]),
+    "snpgpu_merge_regions_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, _P, _P, _P]),
+    "snpgpu_in_regions_dev": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, _P, C.c_uint32, _P]),
+    "snpgpu_merge_sites_dev": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, _P, _P]),
     "snpgpu_synth_reference_dev": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P]),
     "snpgpu_synth_pileup_dev": (C.c_int, [_P, C.POINTER(SynthParams), _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
 }

@@ -4,9 +4,8 @@
 
 #include <vector>
 
-#include <hipcub/hipcub.hpp>
-
 #include "internal.h"
+#include "prims.h"
 
 int snpgpu_set_error(snpgpu_ctx *ctx, int code, const char *fmt, ...) {
     char buf[1024];
@@ -265,15 +264,17 @@ int snpgpu_siteset_create(snpgpu_ctx *ctx, const uint8_t *contig_names, const ui
     }
     // rank[w] = popcount of words < w
     k_popcount_words<<<(unsigned)((n_words + 255) / 256), 256, 0, st>>>((const uint32_t *)(b + o_bmap), (uint32_t *)(b + o_rank), n_words);
-    size_t tmp_bytes = 0;
-    SS_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (uint32_t *)(b + o_rank), (uint32_t *)(b + o_rank), (int)n_words, st));
-    void *tmp = nullptr;
-    SS_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-    hipError_t es = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, (uint32_t *)(b + o_rank), (uint32_t *)(b + o_rank), (int)n_words, st);
-    hipError_t ey = hipStreamSynchronize(st);
-    hipFree(tmp);
-    SS_TRY(es);
-    SS_TRY(ey);
+    {
+        void *scan_ws = nullptr;
+        if (snpgpu_scratch(ctx, 4 * prim_scan_workspace_words(n_words) + 256, &scan_ws) != SNPGPU_OK) {
+            hipFree(ss->blob);
+            delete ss;
+            return SNPGPU_E_NOMEM;
+        }
+        prim_exclusive_scan_u32(st, (const uint32_t *)(b + o_rank), (uint32_t *)(b + o_rank), n_words, (uint32_t *)scan_ws, nullptr);
+    }
+    SS_TRY(hipGetLastError());
+    SS_TRY(hipStreamSynchronize(st));
 #undef SS_TRY
     ss->dev.names = (const uint8_t *)(b + o_names);
     ss->dev.name_off = (const uint32_t *)(b + o_noff);

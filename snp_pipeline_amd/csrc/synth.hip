@@ -3,12 +3,12 @@
 //   <contig>\t<pos>\t<REF>\t<depth>\t<bases>\t<quals>\n   one line per covered position, ascending.
 // Counter-based RNG keyed by (seed, sample, position, read, draw), so the length pass and the write pass see
 // the same line and any host can regenerate the same bytes.
-#include <hipcub/hipcub.hpp>
 
 #include <math.h>
 #include <string.h>
 
 #include "internal.h"
+#include "prims.h"
 
 namespace {
 
@@ -135,6 +135,8 @@ __global__ void k_synth_write(SynthDev P, const uint8_t *ref, const uint8_t *alt
 
 }  // namespace
 
+struct U64Add { __device__ uint64_t operator()(const uint64_t &a, const uint64_t &b) const { return a + b; } };
+
 extern "C" {
 
 int snpgpu_synth_reference_dev(snpgpu_ctx *ctx, uint64_t seed, uint32_t genome_len, uint8_t *d_ref) {
@@ -167,23 +169,23 @@ int snpgpu_synth_pileup_dev(snpgpu_ctx *ctx, const snpgpu_synth_params *p, const
         term *= mean / (k + 1);
     }
     P.depth_cdf[255] = 2.0f;
+    // line lengths at d_len[1 ..], d_len[0] = 0: an inclusive prefix sum then leaves every line's offset in d_len[pos - 1]
+    // and the total in d_len[genome_len]
+    const uint64_t n_scan = (uint64_t)P.genome_len + 1;
+    const size_t len_bytes = (8ull * n_scan + 255) / 256 * 256;
     void *scratch = nullptr;
-    int rc = snpgpu_scratch(ctx, 8ull * (P.genome_len + 1), &scratch);
+    int rc = snpgpu_scratch(ctx, len_bytes + 8ull * prim_gscan_blocks(n_scan) + 256, &scratch);
     if (rc) return rc;
     uint64_t *d_len = (uint64_t *)scratch;
+    uint64_t *d_aggr = (uint64_t *)((char *)scratch + len_bytes);
     hipStream_t st = ctx->stream;
     unsigned blocks = (P.genome_len + 255) / 256;
-    HIP_TRY(ctx, hipMemsetAsync(d_len + P.genome_len, 0, 8, st));
-    k_synth_len<<<blocks, 256, 0, st>>>(P, d_ref, d_site_alt, d_len);
-    size_t tb = 0;
-    HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_len, d_len, (int)(P.genome_len + 1), st));
-    void *tmp = nullptr;
-    HIP_TRY(ctx, hipMalloc(&tmp, tb ? tb : 16));
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, d_len, d_len, (int)(P.genome_len + 1), st);
+    HIP_TRY(ctx, hipMemsetAsync(d_len, 0, 8, st));
+    k_synth_len<<<blocks, 256, 0, st>>>(P, d_ref, d_site_alt, d_len + 1);
+    prim_inclusive_scan<uint64_t, U64Add>(st, d_len, d_len, n_scan, d_aggr, U64Add());
     uint64_t total = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&total, d_len + P.genome_len, 8, hipMemcpyDeviceToHost, st);
+    hipError_t e = hipMemcpyAsync(&total, d_len + P.genome_len, 8, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(tmp);
     if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_HIP, "synth scan failed: %s", hipGetErrorString(e));
     *out_nbytes = (size_t)total;
     if (!d_out) return SNPGPU_OK;                      // size query

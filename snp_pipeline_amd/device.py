@@ -379,6 +379,30 @@ class Device(object):
                                                 C.byref(nu), C.byref(nc)))
         return uniq[:nu.value], off[:nu.value + 1], car[:nc.value]
 
+    # ---- device-pointer forms of the small steps (asynchronous; arguments are device pointers as ints) ---------
+    def dense_windows_dev(self, d_positions, d_seg_off, n_segs, n_pos, max_snps, windows, d_out_start, d_out_end, d_out_seg, d_out_n):
+        ms = np.ascontiguousarray(max_snps, dtype=np.int32)
+        ws = np.ascontiguousarray(windows, dtype=np.int32)
+        self._check(self.lib.snpgpu_dense_windows_dev(self.ctx, C.c_void_p(d_positions), C.c_void_p(d_seg_off), n_segs, n_pos,
+                                                      _ptr(ms), _ptr(ws), len(ms), C.c_void_p(d_out_start), C.c_void_p(d_out_end),
+                                                      C.c_void_p(d_out_seg), C.c_void_p(d_out_n)))
+
+    def merge_regions_dev(self, d_group, d_start, d_end, n, d_out_group, d_out_start, d_out_end, d_out_n):
+        self._check(self.lib.snpgpu_merge_regions_dev(self.ctx, C.c_void_p(d_group), C.c_void_p(d_start), C.c_void_p(d_end), n,
+                                                      C.c_void_p(d_out_group), C.c_void_p(d_out_start), C.c_void_p(d_out_end),
+                                                      C.c_void_p(d_out_n)))
+
+    def in_regions_dev(self, d_pos_group, d_positions, n_pos, d_reg_off, d_reg_start, d_reg_end, n_groups, d_out_flag):
+        self._check(self.lib.snpgpu_in_regions_dev(self.ctx, C.c_void_p(d_pos_group), C.c_void_p(d_positions), n_pos,
+                                                   C.c_void_p(d_reg_off), C.c_void_p(d_reg_start), C.c_void_p(d_reg_end), n_groups,
+                                                   C.c_void_p(d_out_flag)))
+
+    def merge_sites_dev(self, d_keys, d_samples, n, d_out_unique, d_out_off, d_out_carrier, d_out_n):
+        """Union of site keys straight from device tensors (the C1 all-gather of the sharded pipeline): d_out_n[0] unique
+        keys, d_out_n[1] carriers; capacities n, n + 1, n."""
+        self._check(self.lib.snpgpu_merge_sites_dev(self.ctx, C.c_void_p(d_keys), C.c_void_p(d_samples), n, C.c_void_p(d_out_unique),
+                                                    C.c_void_p(d_out_off), C.c_void_p(d_out_carrier), C.c_void_p(d_out_n)))
+
     # ---- synthetic pileups ---------------------------------------------------------------------
     def synth_reference_dev(self, seed, genome_len, d_ref):
         self._check(self.lib.snpgpu_synth_reference_dev(self.ctx, seed, genome_len, C.c_void_p(d_ref)))

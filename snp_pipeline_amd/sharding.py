@@ -5,8 +5,11 @@ The path shards by samples: each rank parses its own VCFs and sca
 communication.  There are exactly two exchange steps, both all-gathers:
   C1  the per-rank SNP site keys (variable length) -> every rank runs the same merge -> identical global snplist
   C2  the per-rank rows of the 4-bit packed consensus matrix -> every rank holds the full matrix
-The N x N distance is then dealt out in 128 x 128 tiles of the upper triangle, tile t to rank t % world, and the
-partial matrices are summed (each entry is written by exactly one rank).
+The N x N distance is then dealt out in 128 x 128 tiles of the upper triangle, tile t to rank t % world (balanced: every
+rank gets the same number of tiles whatever their row).  The combine is a ROW-BAND exchange: rank q ends up with the
+complete rows of its contiguous band of tile rows, and every computed tile travels exactly once to the owner of its row
+(and its transpose once to the owner of its column) in one all-to-all — N*N*4/world bytes per rank over seven parallel xGMI
+links, where summing the partial matrices with an all-reduce would move the whole N x N through every rank.
 """
 import torch
 import torch.distributed as dist
@@ -21,10 +24,18 @@ def shard_bounds(n_items, rank, world):
     return lo, min(n_items, lo + per)
 
 
+def _via_host(t):
+    """gloo moves host tensors only: the single-GPU functional tests of the N > 1 path stage through the host."""
+    return dist.is_initialized() and dist.get_backend() == "gloo" and t.is_cuda
+
+
 def all_gather_varlen(t):
     """All-gather of 1-D tensors whose lengths differ per rank.  Returns (concatenation in rank order, lengths)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return t, [int(t.numel())]
+    if _via_host(t):
+        out, counts = all_gather_varlen(t.cpu())
+        return out.to(t.device), counts
     world = dist.get_world_size()
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     counts = torch.zeros(world, dtype=torch.int64, device=t.device)
@@ -45,6 +56,8 @@ def all_gather_rows(rows, n_total):
     Returns the (n_total, row_bytes) matrix on every rank."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return rows
+    if _via_host(rows):
+        return all_gather_rows(rows.cpu(), n_total).to(rows.device)
     world = dist.get_world_size()
     per = (n_total + world - 1) // world
     width = rows.shape[1]
@@ -53,6 +66,28 @@ def all_gather_rows(rows, n_total):
     out = torch.empty((world * per, width), dtype=rows.dtype, device=rows.device)
     dist.all_gather_into_tensor(out, padded)
     return out[:n_total]
+
+
+def all_gather_rows_into(rows, n_total, out):
+    """As all_gather_rows, but straight into the first rows of `out` (at least max(n_total, world * ceil(n_total / world))
+    rows; the distance kernel wants the matrix padded to whole 128-row tiles, the padding rows stay zero)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        out[:rows.shape[0]].copy_(rows)
+        return out
+    world = dist.get_world_size()
+    per = (n_total + world - 1) // world
+    if _via_host(rows):
+        out[:n_total].copy_(all_gather_rows(rows.cpu(), n_total).to(rows.device))
+        return out
+    if rows.shape[0] == per:
+        padded = rows
+    else:
+        padded = torch.zeros((per, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        padded[:rows.shape[0]] = rows
+    dist.all_gather_into_tensor(out[:world * per], padded)
+    if world * per > n_total:
+        out[n_total:world * per].zero_()
+    return out
 
 
 def upper_tiles(n):
@@ -70,3 +105,71 @@ def sum_partial_distances(partial):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(partial, op=dist.ReduceOp.SUM)
     return partial
+
+
+class RowBands(object):
+    """Who computes which 128 x 128 tile, who owns which rows, and what travels where — a pure function of (n, world), so
+    every rank derives the whole exchange plan itself and no metadata is ever sent.
+
+    Tiles: upper triangle, tile t (row-major enumeration) computed by rank t % world, together with its mirror image.
+    Rows: tile rows in contiguous bands, band q = shard_bounds(n_tile_rows, q, world)."""
+
+    def __init__(self, n, world):
+        self.n, self.world = n, world
+        self.nt = (n + DIST_TILE - 1) // DIST_TILE
+        self.n_padded = self.nt * DIST_TILE
+        self.bands = [shard_bounds(self.nt, q, world) for q in range(world)]
+        owner_of_row = [0] * self.nt
+        for q, (lo, hi) in enumerate(self.bands):
+            for r in range(lo, hi):
+                owner_of_row[r] = q
+        # blocks[src][dst] = [(tile_row, tile_col)] of the full matrix that src computed and dst owns, in a fixed order
+        self._index = {}
+        self.blocks = [[[] for _ in range(world)] for _ in range(world)]
+        for t, (bi, bj) in enumerate(upper_tiles(n)):
+            src = t % world
+            self.blocks[src][owner_of_row[bi]].append((bi, bj))
+            if bi != bj:
+                self.blocks[src][owner_of_row[bj]].append((bj, bi))
+
+    def band_rows(self, rank):
+        """[lo, hi) matrix rows of the band of `rank` (clipped to n)."""
+        lo, hi = self.bands[rank]
+        return min(self.n, lo * DIST_TILE), min(self.n, hi * DIST_TILE)
+
+    def exchange(self, partial, rank):
+        """partial: this rank's (n_padded, n_padded) int32 matrix holding the tiles it computed (and their mirror images).
+        Returns the (band tile rows * 128, n_padded) band of complete rows this rank owns."""
+        nt, T, world = self.nt, DIST_TILE, self.world
+        lo, hi = self.bands[rank]
+        band = torch.zeros(((hi - lo) * T, self.n_padded), dtype=partial.dtype, device=partial.device)
+        p4 = partial.view(nt, T, nt, T)
+        b4 = band.view(max(hi - lo, 0), T, nt, T) if hi > lo else None
+        in_splits = [len(self.blocks[rank][dst]) for dst in range(world)]
+        out_splits = [len(self.blocks[src][rank]) for src in range(world)]
+        dev = partial.device
+        plan = self._index.get((rank, str(dev)))
+        if plan is None:                                                  # index tensors of this rank's plan, built once
+            send_list = [blk for dst in range(world) for blk in self.blocks[rank][dst]]
+            recv_list = [blk for src in range(world) for blk in self.blocks[src][rank]]
+            plan = tuple(torch.tensor(v, dtype=torch.int64, device=dev) for v in (
+                [b[0] for b in send_list], [b[1] for b in send_list], [b[0] - lo for b in recv_list], [b[1] for b in recv_list]))
+            self._index[(rank, str(dev))] = plan
+        rows, cols, rrows, rcols = plan
+        if rows.numel():
+            send = p4[rows, :, cols, :].contiguous()                      # (k, 128, 128)
+        else:
+            send = torch.zeros((0, T, T), dtype=partial.dtype, device=dev)
+        if world == 1 or not dist.is_initialized():
+            recv = send
+        else:
+            recv = torch.empty((sum(out_splits), T, T), dtype=partial.dtype, device=dev)
+            if _via_host(send):
+                recv_h = recv.cpu()
+                dist.all_to_all_single(recv_h, send.cpu(), out_splits, in_splits)
+                recv = recv_h.to(dev)
+            else:
+                dist.all_to_all_single(recv, send, out_splits, in_splits)
+        if rrows.numel():
+            b4[rrows, :, rcols, :] = recv
+        return band

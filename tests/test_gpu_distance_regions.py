@@ -131,3 +131,112 @@ def test_merge_sites_vs_oracle(d):
     assert got == merged
     u0, o0, c0 = d.merge_sites([], [])
     assert len(u0) == 0 and list(o0) == [0]
+
+
+def test_sort_scan_primitives_at_scale(d):
+    """The hand-written sort / scan path (csrc/prims.h) on inputs that span many tiles and merge passes: unsorted positions
+    in many segments, 10^5 random intervals in many groups (with unbounded ends), 3 x 10^5 site records — against numpy /
+    the oracle."""
+    rng = np.random.default_rng(11)
+    # dense windows: 300 segments of 0..3000 unsorted positions with duplicates, three rules
+    seg_sizes = rng.integers(0, 3000, size=300)
+    seg_sizes[7] = 0
+    seg_off = np.concatenate([[0], np.cumsum(seg_sizes)]).astype(np.uint32)
+    pos = rng.integers(1, 200_000, size=int(seg_off[-1])).astype(np.int64)
+    rules_m, rules_w = [3, 2, 1], [1000, 125, 15]
+    cs, ce, cg = d.dense_windows(pos, seg_off, rules_m, rules_w)
+    want = []
+    for sgi in range(300):
+        p_sorted = np.sort(pos[seg_off[sgi]:seg_off[sgi + 1]])
+        for i in range(len(p_sorted)):
+            for m, w in zip(rules_m, rules_w):
+                if i + m < len(p_sorted) and p_sorted[i] + w - 1 >= p_sorted[i + m]:
+                    want.append((int(p_sorted[i]), int(p_sorted[i + m]), sgi))
+    assert list(zip(cs.tolist(), ce.tolist(), cg.tolist())) == want
+    # already sorted input takes the copy path of the sort: same answer
+    pos_sorted = np.concatenate([np.sort(pos[seg_off[i]:seg_off[i + 1]]) for i in range(300)]).astype(np.int64)
+    cs2, ce2, cg2 = d.dense_windows(pos_sorted, seg_off, rules_m, rules_w)
+    assert cs2.tolist() == cs.tolist() and ce2.tolist() == ce.tolist() and cg2.tolist() == cg.tolist()
+    # merge_regions: 10^5 intervals, 40 groups, some reaching to the unknown-contig-length sentinel
+    n = 100_000
+    grp = rng.integers(0, 40, size=n).astype(np.uint32)
+    st = rng.integers(0, 3_000_000, size=n).astype(np.int64)
+    en = st + rng.integers(0, 60, size=n)
+    en[rng.integers(0, n, size=20)] = np.iinfo(np.int64).max
+    mg, ms, me = d.merge_regions(grp, st, en)
+    want = []
+    for g in range(40):
+        sel = grp == g
+        for a, b in so.merge_regions(sorted(zip(st[sel].tolist(), en[sel].tolist()))):
+            want.append((g, a, b))
+    assert list(zip(mg.tolist(), ms.tolist(), me.tolist())) == want
+    # in_regions against the merged list
+    reg_off = np.searchsorted(mg, np.arange(41)).astype(np.uint32)
+    q_g = rng.integers(0, 42, size=50_000).astype(np.uint32)
+    q_p = rng.integers(0, 3_000_100, size=50_000).astype(np.int64)
+    got = d.in_regions(q_g, q_p, reg_off, ms, me)
+    for k in rng.integers(0, 50_000, size=3000):
+        g, p = int(q_g[k]), int(q_p[k])
+        inside = g < 40 and any(a <= p <= b for a, b in zip(ms[reg_off[g]:reg_off[g + 1]].tolist(), me[reg_off[g]:reg_off[g + 1]].tolist()) if a <= p)
+        assert bool(got[k]) == inside
+    # merge_sites: 3 x 10^5 records of 700 samples over 2 contigs, shuffled, with duplicates
+    m = 300_000
+    keys = ((rng.integers(0, 2, size=m).astype(np.uint64) << np.uint64(32)) | rng.integers(1, 60_000, size=m).astype(np.uint64))
+    samp = rng.integers(0, 700, size=m).astype(np.uint32)
+    uniq, off, car = d.merge_sites(keys, samp)
+    pairs = np.unique(np.stack([keys, samp.astype(np.uint64)], axis=1), axis=0)
+    wu, wc = np.unique(pairs[:, 0], return_counts=True)
+    assert uniq.tolist() == wu.tolist()
+    assert off.tolist() == np.concatenate([[0], np.cumsum(wc)]).tolist()
+    assert car.tolist() == pairs[:, 1].tolist()
+
+
+def test_small_steps_device_pointer_forms(d):
+    """The _dev entry points (device pointers, asynchronous, counts in device memory) give what the host forms give."""
+    import torch
+    d.use_torch_stream()
+    rng = np.random.default_rng(12)
+    m = 50_000
+    keys = ((rng.integers(0, 3, size=m).astype(np.int64) << 32) | rng.integers(1, 20_000, size=m).astype(np.int64))
+    samp = rng.integers(0, 90, size=m).astype(np.int32)
+    uniq, off, car = d.merge_sites(keys.astype(np.uint64), samp.astype(np.uint32))
+    tk, ts = torch.from_numpy(keys).cuda(), torch.from_numpy(samp).cuda()
+    ou = torch.zeros(m, dtype=torch.int64, device="cuda")
+    oo = torch.zeros(m + 1, dtype=torch.int32, device="cuda")
+    oc = torch.zeros(m, dtype=torch.int32, device="cuda")
+    on = torch.zeros(4, dtype=torch.int32, device="cuda")
+    d.merge_sites_dev(tk.data_ptr(), ts.data_ptr(), m, ou.data_ptr(), oo.data_ptr(), oc.data_ptr(), on.data_ptr())
+    torch.cuda.synchronize()
+    nu, nc = int(on[0]), int(on[1])
+    assert (nu, nc) == (len(uniq), len(car))
+    assert ou[:nu].cpu().numpy().astype(np.uint64).tolist() == uniq.tolist()
+    assert oo[:nu + 1].cpu().numpy().tolist() == off.tolist() and oc[:nc].cpu().numpy().tolist() == car.tolist()
+    # dense windows + merge + in_regions chained on the device, no host round trip in between
+    seg_off = np.array([0, 4000, 4000, 9000, 15000], dtype=np.int32)
+    pos = rng.integers(1, 400_000, size=15000).astype(np.int64)
+    cs, ce, cg = d.dense_windows(pos, seg_off.astype(np.uint32), [3, 1], [1000, 15])
+    tp, tso = torch.from_numpy(pos).cuda(), torch.from_numpy(seg_off).cuda()
+    cap = 15000 * 2
+    ws_, we_ = torch.zeros(cap, dtype=torch.int64, device="cuda"), torch.zeros(cap, dtype=torch.int64, device="cuda")
+    wg_, wn = torch.zeros(cap, dtype=torch.int32, device="cuda"), torch.zeros(2, dtype=torch.int32, device="cuda")
+    d.dense_windows_dev(tp.data_ptr(), tso.data_ptr(), 4, 15000, [3, 1], [1000, 15], ws_.data_ptr(), we_.data_ptr(), wg_.data_ptr(), wn.data_ptr())
+    torch.cuda.synchronize()
+    k = int(wn[0])
+    assert int(wn[1]) == 0 and k == len(cs)
+    assert ws_[:k].cpu().tolist() == cs.tolist() and we_[:k].cpu().tolist() == ce.tolist() and wg_[:k].cpu().tolist() == cg.tolist()
+    mg, ms, me = d.merge_regions(cg, cs, ce)
+    og = torch.zeros(k, dtype=torch.int32, device="cuda")
+    os_, oe = torch.zeros(k, dtype=torch.int64, device="cuda"), torch.zeros(k, dtype=torch.int64, device="cuda")
+    mn = torch.zeros(2, dtype=torch.int32, device="cuda")
+    d.merge_regions_dev(wg_.data_ptr(), ws_.data_ptr(), we_.data_ptr(), k, og.data_ptr(), os_.data_ptr(), oe.data_ptr(), mn.data_ptr())
+    torch.cuda.synchronize()
+    r = int(mn[0])
+    assert r == len(mg) and og[:r].cpu().tolist() == mg.tolist() and os_[:r].cpu().tolist() == ms.tolist() and oe[:r].cpu().tolist() == me.tolist()
+    # error bits instead of exceptions
+    bad = torch.tensor([5, -1, 7], dtype=torch.int64, device="cuda")
+    so2 = torch.tensor([0, 3], dtype=torch.int32, device="cuda")
+    d.dense_windows_dev(bad.data_ptr(), so2.data_ptr(), 1, 3, [1], [15], ws_.data_ptr(), we_.data_ptr(), wg_.data_ptr(), wn.data_ptr())
+    torch.cuda.synchronize()
+    assert int(wn[1]) == 1
+    with pytest.raises(Exception):
+        d.dense_windows(np.array([5, -1, 7], dtype=np.int64), np.array([0, 3], dtype=np.uint32), [1], [15])

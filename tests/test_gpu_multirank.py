@@ -1,0 +1,71 @@
+"""The N > 1 path with the real kernels: bench.py's step under torch.distributed.run, all ranks on the one GPU of the test
+box (gloo moves the bytes; on an 8-GPU node the same code runs over RCCL).  The 2- and 3-rank runs must reproduce the 1-rank
+answer exactly: site union + carrier lists (C1), packed consensus matrix (C2), consensus rows, and the distance rows each rank
+ends up owning after the row-band exchange.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_bench(world, dump, extra):
+    args = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--scaling", "strong", "--skip-aux", "--e2e-files", "0",
+            "--cpu-samples", "0", "--dump", dump] + extra
+    env = dict(os.environ, SNPGPU_BENCH_TEST_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    if world == 1:
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_step_equals_single_rank(tmp_path, world):
+    n_total = 300                                                       # 3 x 3 distance tiles, uneven sample shards for 3 ranks
+    extra = ["--samples", str(n_total), "--genome", "40000", "--sites", "400", "--vcf-records", "60", "--dist-samples", "700",
+             "--dist-sites", "3000", "--dist-reps", "1"]
+    one = _run_bench(1, str(tmp_path / "one"), extra)
+    many = _run_bench(world, str(tmp_path / "many"), extra)
+    assert many["n_gpus"] == world and many["scaling"] == "strong" and "world size %d" % world in many["config"]["parallelism"]
+    assert many["site_union"] == one["site_union"]
+    assert many["secondary"]["value"] > 0
+    ref = np.load(str(tmp_path / "one.rank0.npz"))
+    assert tuple(ref["band_rows"]) == (0, n_total) and ref["band"].shape == (n_total, n_total)
+    full = ref["band"]
+    assert np.array_equal(full, full.T) and not full.diagonal().any() and full.max() > 0
+    covered = 0
+    for r in range(world):
+        got = np.load(str(tmp_path / ("many.rank%d.npz" % r)))
+        # C1: the same snplist (keys, carrier CSR) on every rank
+        for k in ("union", "union_off", "carriers"):
+            assert np.array_equal(got[k], ref[k]), (r, k)
+        # C2: the same packed matrix on every rank
+        assert np.array_equal(got["packed"], ref["packed"]), r
+        # this rank's consensus rows and distance rows
+        g0, g1 = got["first_sample"]
+        assert np.array_equal(got["bases"], ref["bases"][g0:g1])
+        lo, hi = got["band_rows"]
+        assert np.array_equal(got["band"], full[lo:hi]), r
+        covered += hi - lo
+    assert covered == n_total

@@ -52,17 +52,27 @@ def _worker(rank, world, port, n_samples, n_sites, seed, out_dir):
         # C2: all-gather of this rank's rows
         full = sharding.all_gather_rows(torch.from_numpy(sym[lo:hi].copy()), n_samples)
         assert np.array_equal(full.numpy(), sym)
-        # distance tiles dealt cyclically, partial matrices summed
-        part = np.zeros((n_samples, n_samples), dtype=np.int32)
+        # the same gather straight into a matrix padded to whole tiles
+        bands = sharding.RowBands(n_samples, world)
+        padded = torch.zeros((max(bands.n_padded, world * ((n_samples + world - 1) // world)), n_sites), dtype=torch.uint8)
+        sharding.all_gather_rows_into(torch.from_numpy(sym[lo:hi].copy()), n_samples, padded)
+        assert np.array_equal(padded[:n_samples].numpy(), sym) and not padded[n_samples:].any()
+        # distance tiles dealt cyclically; the row-band exchange leaves every rank with the complete rows of its band
+        part = np.zeros((bands.n_padded, bands.n_padded), dtype=np.int32)
         t = sharding.DIST_TILE
         for bi, bj in sharding.tiles_of_rank(n_samples, rank, world):
             blk = _np_tile(full.numpy(), bi, bj)
             part[bi * t:bi * t + blk.shape[0], bj * t:bj * t + blk.shape[1]] = blk
             if bi != bj:
                 part[bj * t:bj * t + blk.shape[1], bi * t:bi * t + blk.shape[0]] = blk.T
-        total = sharding.sum_partial_distances(torch.from_numpy(part)).numpy()
+        band = bands.exchange(torch.from_numpy(part), rank).numpy()
+        r0, r1 = bands.band_rows(rank)
+        np.save(os.path.join(out_dir, "band%d.npy" % rank), band[:r1 - r0, :n_samples])
+        np.save(os.path.join(out_dir, "rows%d.npy" % rank), np.array([r0, r1]))
+        # (the all-reduce combine of round 1 stays available and must agree)
+        total = sharding.sum_partial_distances(torch.from_numpy(part.copy())).numpy()[:n_samples, :n_samples]
+        assert np.array_equal(total[r0:r1], band[:r1 - r0, :n_samples])
         if rank == 0:
-            np.save(os.path.join(out_dir, "dist.npy"), total)
             np.save(os.path.join(out_dir, "sym.npy"), sym)
     finally:
         dist.destroy_process_group()
@@ -71,8 +81,14 @@ def _worker(rank, world, port, n_samples, n_sites, seed, out_dir):
 def test_two_rank_pipeline_matches_single_process(tmp_path):
     n_samples, n_sites = 261, 300                   # 3 x 3 tile grid, uneven shards (131 + 130)
     mp.spawn(_worker, args=(2, _free_port(), n_samples, n_sites, 5, str(tmp_path)), nprocs=2, join=True)
-    total = np.load(str(tmp_path / "dist.npy"))
     sym = np.load(str(tmp_path / "sym.npy"))
+    total = np.zeros((n_samples, n_samples), dtype=np.int32)
+    covered = 0
+    for r in range(2):
+        r0, r1 = np.load(str(tmp_path / ("rows%d.npy" % r)))
+        total[r0:r1] = np.load(str(tmp_path / ("band%d.npy" % r)))
+        covered += r1 - r0
+    assert covered == n_samples                         # the bands partition the rows
     seqs = [bytes(r).decode() for r in sym]
     for i, j in [(0, 1), (5, 200), (130, 131), (260, 0), (128, 255), (17, 17)]:
         assert total[i, j] == (0 if i == j else so.sequence_distance(seqs[i], seqs[j]))
@@ -87,3 +103,16 @@ def test_shard_bounds_and_tiles():
     got = sorted(t for r in range(4) for t in sharding.tiles_of_rank(300, r, 4))
     assert got == sorted(tiles)
     assert sharding.all_gather_varlen(torch.arange(3))[1] == [3]
+    # the exchange plan: every block of the full matrix travels exactly once, to the owner of its tile row
+    for n, w in ((261, 2), (1000, 8), (129, 3), (5, 4)):
+        rb = sharding.RowBands(n, w)
+        seen = {}
+        for src in range(w):
+            for dst in range(w):
+                for blk in rb.blocks[src][dst]:
+                    assert blk not in seen and rb.bands[dst][0] <= blk[0] < rb.bands[dst][1]
+                    seen[blk] = (src, dst)
+        assert len(seen) == rb.nt * rb.nt
+    # one rank: the exchange is the identity on the padded matrix
+    m = torch.arange(256 * 256, dtype=torch.int32).view(256, 256)
+    assert torch.equal(sharding.RowBands(200, 1).exchange(m, 0), m)
