@@ -130,3 +130,28 @@ def synth_pileup(seed, genome_len=4000, contigs=("synth_chr1",), mean_depth=30, 
                 quals.append(chr(33 + min(41, max(2, int(round(rng.gauss(35, 5)))))))
             lines.append("%s\t%d\t%s\t%d\t%s\t%s\n" % (contig, pos, r, depth, "".join(toks), "".join(quals)))
     return "".join(lines).encode(), refs, sorted(sites)
+
+
+def odd_depth_lines(seed, eol=b"\n", n=4000):
+    """A pileup whose lines exercise every shape the depth column can take: depths of 1 to 6 digits, two- and three-field
+    lines, a multi-byte reference field, doubled separators, a depth that is not a number, a line that ends after the depth."""
+    rng = random.Random(seed)
+    lines = []
+    for pos in range(1, n + 1):
+        r = rng.random()
+        depth = rng.choice([0, 1, 7, 30, 250, 999, 1000, 9999, 10000, 123456])
+        if r < 0.80:
+            lines.append(b"c9\t%d\tA\t%d\t%s\t%s" % (pos, depth, b"." * min(depth, 40), b"I" * min(depth, 40)))
+        elif r < 0.84:
+            lines.append(b"c9\t%d" % pos)
+        elif r < 0.88:
+            lines.append(b"c9\t%d\tA" % pos)
+        elif r < 0.92:
+            lines.append(b"c9\t%d\tACG\t%d\t...\tIII" % (pos, depth))
+        elif r < 0.95:
+            lines.append(b"c9\t%d\tA\t\t%d\t.\tI" % (pos, depth))
+        elif r < 0.98:
+            lines.append(b"c9 %d A %dx . I" % (pos, depth))
+        else:
+            lines.append(b"c9\t%d\tA\t%d" % (pos, depth))
+    return eol.join(lines) + eol

@@ -58,6 +58,9 @@ def install_stubs():
         def __init__(self, seq, id="", description=""):
             self.seq, self.id, self.description = seq, id, description
 
+        def __len__(self):
+            return len(self.seq)
+
     def write(records, handle, fmt):
         for r in records:
             captured["last"] = (r.id, str(r.seq))
@@ -65,6 +68,11 @@ def install_stubs():
         return len(records)
 
     def parse(handle, fmt):
+        if isinstance(handle, str):                     # SeqIO.parse also takes a path (collect_metrics.py:334)
+            with open(handle) as f:
+                for rec in parse(f, fmt):
+                    yield rec
+            return
         name, chunks = None, []
         for line in handle:
             if line.startswith(">"):
@@ -347,6 +355,59 @@ def gen_steps_vectors():
     return vec
 
 
+def gen_metrics_vectors():
+    """The depth-column sum of collect_metrics.py:325-340 (avePileupDepth), by running the reference's own
+    collect_metrics() on sample directories that hold nothing but a pileup; with a 1-base reference the printed
+    ``%.2f`` average is the sum itself.  Also missingPos (collect_metrics.py:109-128 counts the '-' of a FASTA record)."""
+    install_stubs()
+    from snppipeline import collect_metrics as cm
+    from oracle import fuzz
+    out = []
+    specs = [("synth", dict(seed=5, genome_len=5000, n_sites=20)), ("synth", dict(seed=6, genome_len=3000, n_sites=10, mean_depth=120)),
+             ("synth", dict(seed=7, genome_len=2500, n_sites=10, contigs=("NODE_2", "NODE_10"))),
+             ("odd", dict(seed=9, eol="\n")), ("odd", dict(seed=9, eol="\r\n")), ("odd", dict(seed=10, eol="\n"))]
+    old = os.environ.get("StopOnSampleError")
+    os.environ["StopOnSampleError"] = "false"
+    try:
+        for kind, kw in specs:
+            if kind == "synth":
+                k2 = dict(kw)
+                if "contigs" in k2:
+                    k2["contigs"] = tuple(k2["contigs"])
+                data = fuzz.synth_pileup(**k2)[0]
+            else:
+                data = fuzz.odd_depth_lines(kw["seed"], kw["eol"].encode())
+            tmp = tempfile.mkdtemp()
+            try:
+                sd = os.path.join(tmp, "samples", "s1")
+                os.makedirs(sd)
+                with open(os.path.join(sd, "reads.all.pileup"), "wb") as f:
+                    f.write(data)
+                ref = os.path.join(tmp, "ref.fasta")
+                with open(ref, "w") as f:
+                    f.write(">r\nA\n")
+                args = argparse.Namespace(referenceFile=ref, sampleDir=sd, consensusFastaFileName="consensus.fasta",
+                                          consensusPreservedFastaFileName="consensus_preserved.fasta", consensusVcfFileName="consensus.vcf",
+                                          consensusPreservedVcfFileName="consensus_preserved.vcf", maxSnps=-1,
+                                          metricsFile=os.path.join(sd, "metrics"), forceFlag=True, verbose=0, subparser_name="collect_metrics")
+                stdout = sys.stdout
+                sys.stdout = io.StringIO()
+                try:
+                    cm.collect_metrics(args)
+                finally:
+                    sys.stdout = stdout
+                props = dict(line.rstrip("\n").split("=", 1) for line in open(os.path.join(sd, "metrics")) if "=" in line)
+                out.append({"kind": kind, "kw": kw, "avePileupDepth": props["avePileupDepth"], "bytes": len(data)})
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+    finally:
+        if old is None:
+            os.environ.pop("StopOnSampleError", None)
+        else:
+            os.environ["StopOnSampleError"] = old
+    return {"depth_sum": out}
+
+
 def copy_fixtures():
     """Data files from the reference's bundled ExpectedResults trees."""
     src = os.path.join(REF, "snppipeline", "data")
@@ -401,6 +462,12 @@ def copy_fixtures():
         with open(os.path.join(out, "meta.json"), "w") as f:
             json.dump(meta, f, indent=1, sort_keys=True)
     shutil.copy(os.path.join(src, "lambdaVirusInputs", "reference", "lambda_virus.fasta"), os.path.join(dst, "lambdaVirus"))
+    # the listeria reference (3 MB of FASTA text) pins snp_reference on a second data set: kept xz-compressed
+    import lzma
+    with open(os.path.join(src, "listeriaInputs", "reference", "CFSAN023463.HGAP.draft.fasta"), "rb") as f:
+        raw = f.read()
+    with open(os.path.join(dst, "listeria", "CFSAN023463.HGAP.draft.fasta.xz"), "wb") as f:
+        f.write(lzma.compress(raw, preset=9))
 
 
 CLI_LINES = [
@@ -453,6 +520,12 @@ def main():
     if sys.argv[1:] == ["--only", "cli"]:
         dump("cli_vectors.json.gz", gen_cli_vectors())
         return
+    if sys.argv[1:] == ["--only", "fixtures"]:
+        copy_fixtures()
+        return
+    if sys.argv[1:] == ["--only", "metrics"]:
+        dump("metrics_vectors.json.gz", gen_metrics_vectors())
+        return
     if sys.argv[1:] == ["--only", "runs2"]:
         # later additions: shapes the device kernels treat specially (512-byte lane window, long contig names,
         # positions around the powers of ten), again through the reference's own driver
@@ -468,6 +541,7 @@ def main():
     dump("pileup_vectors.json.gz", gen_pileup_vectors(captured))
     dump("steps_vectors.json.gz", gen_steps_vectors())
     dump("cli_vectors.json.gz", gen_cli_vectors())
+    dump("metrics_vectors.json.gz", gen_metrics_vectors())
     copy_fixtures()
 
 

@@ -256,3 +256,16 @@ def call_consensus_sites(data, snp_list, excluded, p):
             called[key] = 0x2D if (mask or base == 0x2A) else base
         detail[key] = (rec, base, mask)
     return bytes(called.get(k, 0x2D) for k in snp_list), detail
+
+
+def depth_sum(data):
+    """collect_metrics.py:325-340: the sum of int(tokens[3]) over the lines that have one; a line with fewer fields or a
+    4th field that is not an integer is skipped.  (avePileupDepth is this sum / reference length, "%.2f".)"""
+    total = 0
+    for _, ln in iter_lines(data):
+        tokens = split_fields(ln)
+        try:
+            total += int(tokens[3].decode())
+        except (ValueError, IndexError):
+            pass
+    return total

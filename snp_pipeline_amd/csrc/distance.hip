@@ -209,6 +209,11 @@ int snpgpu_distance_packed_dev(snpgpu_ctx *ctx, const void *d_packed, uint32_t n
     a.out = d_out;
     uint64_t mine = a.total_tiles > tile_rank ? (a.total_tiles - tile_rank + tile_nranks - 1) / tile_nranks : 0;
     if (mine == 0) return SNPGPU_OK;
+    if (a.words == 0) {                                         // no sites at all: every distance of the rank's tiles is 0
+        k_distance_zero<<<(unsigned)(mine < (uint64_t)ctx->n_cu * 64 ? mine : (uint64_t)ctx->n_cu * 64), DIST_THREADS, 0, ctx->stream>>>(a);
+        HIP_TRY(ctx, hipGetLastError());
+        return SNPGPU_OK;
+    }
     uint64_t cap = (uint64_t)ctx->n_cu * 64;
     a.k_parts = 1;
     a.k_chunk = a.words;

@@ -13,17 +13,26 @@ from . import utils
 
 
 def distance_matrix(dev, seqs):
-    """seqs: {id: sequence}.  Returns (sorted ids, (n, n) int32 matrix).  Sequences must have equal length, except
-    that — like the reference's loop over range(len(seq1)) — a longer second sequence is simply cut."""
+    """seqs: {id: sequence}.  Returns (sorted ids, (n, n) int32 matrix).
+
+    Unequal lengths behave as in the reference: utils.calculate_sequence_distance (utils.py:1156-1158) walks
+    range(len(seq1)) for every pair of itertools.combinations(sorted ids) — a longer second sequence is simply cut, a shorter
+    one raises IndexError at seq2[pos].  So the lengths must be non-decreasing in sorted-id order, and a pair is compared over
+    the length of its first sequence: the shorter rows are padded with '-' (never counted) and the kernel does the rest."""
     ids = sorted(seqs.keys())
     n = len(ids)
     if n == 0:
         return ids, np.zeros((0, 0), dtype=np.int32)
-    lengths = {len(seqs[i]) for i in ids}
-    if len(lengths) != 1:
-        raise IndexError("sequences of unequal length in the SNP matrix")     # utils.py:1157 raises IndexError
-    s = lengths.pop()
-    sym = np.frombuffer("".join(seqs[i] for i in ids).encode("latin-1"), dtype=np.uint8).reshape(n, s) if s else np.zeros((n, 0), np.uint8)
+    lens = [len(seqs[i]) for i in ids]
+    for a, b in zip(lens, lens[1:]):
+        if b < a:
+            raise IndexError("string index out of range")                     # what seq2[pos] raises in utils.py:1158
+    s = lens[-1]
+    if s == 0:
+        return ids, np.zeros((n, n), dtype=np.int32)
+    sym = np.full((n, s), 0x2D, dtype=np.uint8)
+    for r, i in enumerate(ids):
+        sym[r, :lens[r]] = np.frombuffer(seqs[i].encode("latin-1"), dtype=np.uint8)
     return ids, dev.distance(sym)
 
 

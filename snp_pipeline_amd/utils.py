@@ -236,6 +236,10 @@ def read_vcf_sites(vcf_file_path):
             if line.startswith("#"):
                 header.append(line)
                 continue
+            if not header and line.strip():
+                # PyVCF3's Reader refuses a file that does not start with meta / header lines; the callers report that
+                # as "cannot open the input vcf file" (filter_regions.py:263-272)
+                raise IOError("%s is not a VCF file: data before the header" % vcf_file_path)
             if not line.strip():
                 continue
             fields = line.split("\t", 2)

@@ -171,18 +171,6 @@ def test_synthetic_files_vs_oracle(d, seed, kw):
     check_against_oracle(d, data, snps, [], po.CallerParams(15, 0.9, 5, 2, 0.1))
 
 
-def _ref_depth_sum(data):
-    """collect_metrics.py:325-340: int(tokens[3]) of every line that has one; anything else is skipped."""
-    total = 0
-    for _, ln in po.iter_lines(data):
-        tokens = po.split_fields(ln)
-        try:
-            total += int(tokens[3].decode())
-        except (ValueError, IndexError):
-            pass
-    return total
-
-
 def test_depth_sum_byproduct(d):
     """The sum of the depth column comes out of the same scan (fast path: 1..4 digit depths after a one-byte reference
     field; everything else through the exact parser), for the metrics step that re-reads the pileup in the reference."""
@@ -190,37 +178,20 @@ def test_depth_sum_byproduct(d):
     data, _, sites = fuzz.synth_pileup(5, genome_len=5000, n_sites=20)
     ss = d.siteset(sites, [1] * len(sites))
     res = d.call_consensus(ss, data, dev.make_params(), want_depth_sum=True)
-    assert res.depth_sum == _ref_depth_sum(data) > 0
+    assert res.depth_sum == po.depth_sum(data) > 0
     plain = d.call_consensus(ss, data, dev.make_params())
     assert bytes(plain.bases) == bytes(res.bases) and (plain.n_lines, plain.n_matched) == (res.n_lines, res.n_matched)
-    # odd lines: depths of 5+ digits, two- and three-field lines, a multi-byte reference field, doubled separators,
-    # a depth that is not a number (skipped by the reference), CR LF endings, deep and shallow lines mixed
-    rng = random.Random(9)
-    lines = []
-    for pos in range(1, 4001):
-        r = rng.random()
-        depth = rng.choice([0, 1, 7, 30, 250, 999, 1000, 9999, 10000, 123456])
-        if r < 0.80:
-            lines.append(b"c9\t%d\tA\t%d\t%s\t%s" % (pos, depth, b"." * min(depth, 40), b"I" * min(depth, 40)))
-        elif r < 0.84:
-            lines.append(b"c9\t%d" % pos)
-        elif r < 0.88:
-            lines.append(b"c9\t%d\tA" % pos)
-        elif r < 0.92:
-            lines.append(b"c9\t%d\tACG\t%d\t...\tIII" % (pos, depth))
-        elif r < 0.95:
-            lines.append(b"c9\t%d\tA\t\t%d\t.\tI" % (pos, depth))
-        elif r < 0.98:
-            lines.append(b"c9 %d A %dx . I" % (pos, depth))
-        else:
-            lines.append(b"c9\t%d\tA\t%d" % (pos, depth))
+    # odd lines (fuzz.odd_depth_lines: depths of 5+ digits, two- and three-field lines, a multi-byte reference field, doubled
+    # separators, a depth that is not a number, CR LF endings) — the very texts the reference's collect_metrics() summed for
+    # tests/golden/metrics_vectors.json.gz, which pins the oracle
+    n_odd = 4000
     for eol in (b"\n", b"\r\n"):
-        odd = eol.join(lines) + eol
+        odd = fuzz.odd_depth_lines(9, eol, n_odd)
         keys = [(b"c9", p_) for p_ in range(5, 4000, 37)]
         ss2 = d.siteset(keys, [1] * len(keys))
         got = d.call_consensus(ss2, odd, dev.make_params(), want_depth_sum=True, want_counts=False, check=False)
-        assert got.depth_sum == _ref_depth_sum(odd), eol
-        assert got.n_lines == len(lines)
+        assert got.depth_sum == po.depth_sum(odd), eol
+        assert got.n_lines == n_odd
 
 
 def test_device_pointer_api_unaligned_and_batch(d):

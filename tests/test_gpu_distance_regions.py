@@ -240,3 +240,29 @@ def test_small_steps_device_pointer_forms(d):
     assert int(wn[1]) == 1
     with pytest.raises(Exception):
         d.dense_windows(np.array([5, -1, 7], dtype=np.int64), np.array([0, 3], dtype=np.uint32), [1], [15])
+
+
+def test_distance_unequal_lengths_and_no_sites(d):
+    """utils.calculate_sequence_distance walks range(len(seq1)) (utils.py:1156-1158): a longer second sequence is cut, a
+    shorter one raises IndexError.  And a matrix without sites: all distances 0, nothing read."""
+    import torch
+    from snp_pipeline_amd import distance as dm
+    seqs = {"a": "ACGT", "b": "ACCTAA", "c": "TCGTAAGG", "b2": "aCGTAC"}
+    ids, mat = dm.distance_matrix(d, seqs)
+    assert ids == ["a", "b", "b2", "c"]
+    for i, x in enumerate(ids):
+        for j, y in enumerate(ids):
+            if i < j:
+                assert mat[i, j] == mat[j, i] == so.sequence_distance(seqs[x], seqs[y]), (x, y)
+    assert so.sequence_distance("ACGT", "TCGTAAGG") == 1
+    with pytest.raises(IndexError):
+        so.sequence_distance("ACGTA", "ACG")
+    with pytest.raises(IndexError):
+        dm.distance_matrix(d, {"a": "ACGTA", "b": "ACG"})
+    ids, mat = dm.distance_matrix(d, {"x": "", "y": ""})
+    assert mat.tolist() == [[0, 0], [0, 0]]
+    d.use_torch_stream()
+    out = torch.full((300, 300), 7, dtype=torch.int32, device="cuda")
+    d.distance_packed_dev(0, 300, 0, out.data_ptr())
+    torch.cuda.synchronize()
+    assert not bool(out.any().item())

@@ -1,0 +1,138 @@
+"""BASELINE.json configs[3] and configs[4] at their stated sizes on one MI355X.
+
+The oracle cannot run at these sizes, so the checks are the size-independent ones: symmetry, zero diagonal, numpy on random
+pairs and on the last (partial) tile row / column, tile split over ranks == the full run (distance); line counts = newline
+counts, matched lines = sites with a line, a 300-sample batch (two scan groups: 256 + 44) == a 125-sample batch (the per-GPU
+shard of configs[3], one group) == per-sample calls, and the oracle on the very lines the device picked (consensus).
+"""
+import numpy as np
+import pytest
+
+from oracle import pileup_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def d():
+    from tests.gpu_util import get_device
+    return get_device()
+
+
+def test_distance_10000_x_200000(d):
+    """configs[4]: 10 000 samples x 200 000 sites — a 79 x 79 tile grid whose last tile row / column is partial (16 rows)."""
+    import torch
+    d.use_torch_stream()
+    n, s = 10_000, 200_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    lut = torch.tensor(list(b"ACGTacgt-N"), dtype=torch.uint8, device="cuda")
+    probs = torch.tensor([.2, .2, .2, .2, .03, .03, .03, .03, .05, .03], device="cuda")
+    sym = torch.empty((n, s), dtype=torch.uint8, device="cuda")
+    chunk = (1 << 28) // s
+    for r0 in range(0, n, chunk):
+        r1 = min(n, r0 + chunk)
+        sym[r0:r1] = lut[torch.multinomial(probs, (r1 - r0) * s, replacement=True, generator=g)].view(r1 - r0, s)
+    # two rows made equal, two made maximally different, so that 0 and large values are both present off the diagonal
+    sym[17] = sym[4242]
+    pk = torch.empty((n, d.packed_row_bytes(s)), dtype=torch.uint8, device="cuda")
+    d.pack_matrix_dev(sym.data_ptr(), n, s, s, pk.data_ptr())
+    dm = torch.full((n, n), -1, dtype=torch.int32, device="cuda")
+    d.distance_packed_dev(pk.data_ptr(), n, s, dm.data_ptr())
+    torch.cuda.synchronize()
+    assert int(dm.min().item()) == 0 and int(dm.max().item()) < s
+    assert not bool(dm.diagonal().any().item())
+    assert bool(torch.equal(dm, dm.t()))
+    assert int(dm[17, 4242].item()) == 0
+    # numpy on 200 random pairs, on the partial last tile row / column, and on tile-boundary rows
+    rng = np.random.default_rng(1)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def np_dist(a, b):
+        ua, ub = a & 0xDF, b & 0xDF                          # upper-case letters; '-' (0x2D) stays outside ACGT either way
+        return int((np.isin(ua, acgt) & np.isin(ub, acgt) & (ua != ub)).sum())
+
+    pairs = [(int(i), int(j)) for i, j in rng.integers(0, n, size=(200, 2))]
+    pairs += [(n - 1, 0), (n - 1, n - 2), (9984, 9983), (9984, n - 1), (9999, 9984), (127, 128), (128, 255), (0, 9990)]
+    rows = sorted({i for pr in pairs for i in pr})
+    host = {i: sym[i].cpu().numpy() for i in rows}
+    for i, j in pairs:
+        assert int(dm[i, j].item()) == np_dist(host[i], host[j]), (i, j)
+    # the tiles split over three ranks, written into one zeroed matrix, are the full matrix
+    dm3 = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    for r in range(3):
+        d.distance_packed_dev(pk.data_ptr(), n, s, dm3.data_ptr(), r, 3)
+    torch.cuda.synchronize()
+    assert bool(torch.equal(dm3, dm))
+
+
+def test_configs3_shard_125_and_grouped_batch_300(d):
+    """configs[3] sample shape (5 Mbp x 30x, 50 k sites): 300 samples resident (130 GB) in one call = two scan groups."""
+    import torch
+    from snp_pipeline_amd import device as dev
+    from snp_pipeline_amd import _lib as L
+    G, S, B = 5_000_000, 50_000, 300
+    d.use_torch_stream()
+    ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda")
+    d.synth_reference_dev(1, G, ref.data_ptr())
+    refh = ref.cpu().numpy()
+    rng = np.random.default_rng(2)
+    pos = np.sort(rng.choice(np.arange(501, G - 499), size=S, replace=False))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    alt_h = np.zeros(G + 1, dtype=np.uint8)
+    alt_h[pos] = acgt[(np.searchsorted(acgt, refh[pos]) + 1 + rng.integers(0, 3, size=S)) % 4]
+    alt = torch.from_numpy(alt_h).cuda()
+    sizes = [d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), 0, 0) for i in range(B)]
+    offs = np.zeros(B, dtype=np.uint64)
+    for i in range(1, B):
+        offs[i] = offs[i - 1] + (sizes[i - 1] + 255) // 256 * 256 + (3 if i % 7 == 0 else 0)      # some odd start addresses
+    pile = torch.empty(int(offs[-1]) + sizes[-1] + 64, dtype=torch.uint8, device="cuda")
+    for i in range(B):
+        assert d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), pile.data_ptr() + int(offs[i]), sizes[i]) == sizes[i]
+    keys = [(b"synth_chr1", int(p_)) for p_ in pos]
+    ss = d.siteset(keys, [L.SITE_IN_SNPLIST] * S)
+    p = po.CallerParams(0, 0.6, 3, 0, 0.0)
+    prm = dev.make_params(p.min_base_quality, p.min_cons_freq, p.min_cons_depth, p.min_cons_strand_depth, p.min_cons_strand_bias)
+    sizes_np = np.asarray(sizes, dtype=np.uint64)
+    bases = torch.zeros((B, S), dtype=torch.uint8, device="cuda")
+    filt = torch.zeros((B, S), dtype=torch.uint8, device="cuda")
+    status = torch.zeros((B, 4), dtype=torch.int64, device="cuda")
+    d.call_consensus_batch_dev(ss, pile.data_ptr(), offs, prm, bases.data_ptr(), filt.data_ptr(), status.data_ptr(), sizes=sizes_np)
+    torch.cuda.synchronize()
+    st = status.cpu().numpy()
+    assert (st[:, 0] == -1).all()
+    assert not bool((filt & 0x80).any().item())
+    for i in range(B):
+        view = pile[int(offs[i]):int(offs[i]) + sizes[i]]
+        assert int(st[i, 1]) == int((view == 10).sum().item()), i          # lines seen = terminators in the file
+    called = (bases != 0x2D).sum(dim=1).cpu().numpy()
+    assert (st[:, 2] >= called).all() and (called > 0.9 * S).all()        # every called site had a line
+    # the per-GPU shard of configs[3] (125 samples, one scan group) gives the same rows
+    b125 = torch.zeros((125, S), dtype=torch.uint8, device="cuda")
+    f125 = torch.zeros((125, S), dtype=torch.uint8, device="cuda")
+    s125 = torch.zeros((125, 4), dtype=torch.int64, device="cuda")
+    d.call_consensus_batch_dev(ss, pile.data_ptr(), offs[:125], prm, b125.data_ptr(), f125.data_ptr(), s125.data_ptr(), sizes=sizes_np[:125])
+    torch.cuda.synchronize()
+    assert torch.equal(b125, bases[:125]) and torch.equal(f125, filt[:125]) and s125.cpu().numpy().tolist() == st[:125].tolist()
+    # single-sample calls around the group boundary and at the ends; the oracle on the lines the device picked
+    for i in (0, 124, 255, 256, 257, 299):
+        b1 = torch.zeros(S, dtype=torch.uint8, device="cuda")
+        f1 = torch.zeros(S, dtype=torch.uint8, device="cuda")
+        s1 = torch.zeros(4, dtype=torch.int64, device="cuda")
+        d.call_consensus_dev(ss, pile.data_ptr() + int(offs[i]), sizes[i], prm, b1.data_ptr(), f1.data_ptr(), s1.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(b1, bases[i]) and torch.equal(f1, filt[i]) and s1.cpu().numpy().tolist() == st[i].tolist()
+        line_off = d.line_offsets(ss)
+        assert int(st[i, 2]) == int(np.count_nonzero(line_off))
+        bh, fh = bases[i].cpu().numpy(), filt[i].cpu().numpy()
+        for slot in rng.choice(S, size=120, replace=False):
+            if line_off[slot] == 0:
+                assert bh[slot] == 0x2D and fh[slot] == 0
+                continue
+            a0 = int(offs[i]) + int(line_off[slot]) - 1
+            raw = bytes(pile[a0:a0 + 700].cpu().numpy())
+            fields = po.split_fields(raw[:raw.index(b"\n")])
+            assert (fields[0], int(fields[1])) == keys[slot]
+            base, mask = po.call_record(po.parse_record(fields, p.min_base_quality), p)
+            want = 0x2D if (mask or base == 0x2A) else base
+            assert (int(bh[slot]), int(fh[slot])) == (want, mask)

@@ -159,3 +159,106 @@ def test_snp_reference_matches_lambda_fixture(tmp_path, fixture_trees):
     sl.write_text("c1\t4\t1\tx\n")
     with pytest.raises(IndexError):
         snp_reference.write_reference_snp_file(str(fa), str(sl), str(tmp_path / "o.fasta"))
+
+
+def _counts_from_vcf_row(row):
+    """Invert one consensus.vcf data line into (chrom, pos, snpgpu_site_counts record, ranked symbols)."""
+    import numpy as np
+    from snp_pipeline_amd import _lib as L
+    from snp_pipeline_amd.device import COUNTS_DTYPE
+    f = row.split("\t")
+    chrom, pos, ref, alt_s, ft = f[0], int(f[1]), f[3], f[4], f[6]
+    assert f[2] == "." and f[5] == "." and f[7] == "NS=1" and f[8] == "GT:SDP:RD:AD:RDF:RDR:ADF:ADR:FT"
+    gt, sdp, rd, ad, rdf, rdr, adf, adr, ft2 = f[9].split(":")
+    assert ft2 == ft
+    alts = [] if alt_s == "." else alt_s.split(",")
+    tot = {a: int(x) for a, x in zip(alts, ad.split(","))} if alts else {}
+    fwd = {a: int(x) for a, x in zip(alts, adf.split(","))} if alts else {}
+    rev = {a: int(x) for a, x in zip(alts, adr.split(","))} if alts else {}
+    if not alts:
+        assert (ad, adf, adr) == ("0", "0", "0")
+    if int(rd) > 0:
+        tot[ref], fwd[ref], rev[ref] = int(rd), int(rdf), int(rdr)
+    ranked = sorted(tot, key=lambda s: (-tot[s], s))                 # pileup.py:263-266: count descending, byte ascending
+    assert [s for s in ranked if s != ref] == alts                   # ... which is the order the reference printed the ALTs in
+    c = np.zeros(1, dtype=COUNTS_DTYPE)[0]
+    c["raw_depth"], c["good_depth"] = int(sdp), sum(tot.values())
+    c["fwd_good_depth"], c["rev_good_depth"] = sum(fwd.values()), sum(rev.values())
+    c["n_symbols"], c["ref_base"], c["status"] = len(ranked), ord(ref), L.ST_OK
+    for r, s in enumerate(ranked):
+        c["sym"][r], c["total"][r], c["fwd"][r], c["rev"][r] = ord(s), tot[s], fwd[s], rev[s]
+    return chrom, pos, c, ranked, ft, gt
+
+
+def test_consensus_vcf_rows_and_fasta_of_the_lambda_fixtures(fixture_trees):
+    """Every data line of the eight bundled lambda consensus*.vcf files (the reference's own output on real reads): the host
+    writer and the oracle's row function reproduce it byte for byte from the counts it encodes, the GT / FT rules included,
+    and (counts -> FASTA character) agrees with the bundled consensus*.fasta (call_consensus.py:161-188)."""
+    from oracle import pileup_oracle as po
+    from oracle import vcf_oracle as vo
+    from snp_pipeline_amd import utils, vcf_writer
+    root, _ = fixture_trees["lambdaVirus"]
+    n_rows = 0
+    for suffix in ("", "_preserved"):
+        snplist = utils.read_snp_position_list(os.path.join(root, "snplist%s.txt" % suffix))
+        for s in sorted(os.listdir(os.path.join(root, "samples"))):
+            sdir = os.path.join(root, "samples", s)
+            lines = open(os.path.join(sdir, "consensus%s.vcf" % suffix)).read().split("\n")
+            names = [ln.split("ID=")[1].split(",")[0] for ln in lines if ln.startswith("##FILTER=") and "ID=PASS" not in ln]
+            assert names == ["RawDpth", "VarFreq60", "Depth3", "StrDpth0", "StrBias0", "Region"]
+            fasta = "".join(open(os.path.join(sdir, "consensus%s.fasta" % suffix)).read().split("\n")[1:])
+            assert len(fasta) == len(snplist)
+            called = {}
+            for row in lines:
+                if not row or row.startswith("#"):
+                    continue
+                chrom, pos, c, ranked, ft, gt = _counts_from_vcf_row(row)
+                mask = 0
+                for name in ([] if ft == "PASS" else ft.split(";")):
+                    mask |= 1 << names.index(name)
+                c["filters"] = mask
+                assert vcf_writer.row_from_counts(chrom, pos, c, names, False, ".") == row
+                rec = po.Record(chrom.encode(), pos, bytes([int(c["ref_base"])]), int(c["raw_depth"]), int(c["good_depth"]),
+                                int(c["fwd_good_depth"]), int(c["rev_good_depth"]),
+                                {int(c["sym"][r]): int(c["total"][r]) for r in range(len(ranked))},
+                                {int(c["sym"][r]): int(c["fwd"][r]) for r in range(len(ranked))},
+                                {int(c["sym"][r]): int(c["rev"][r]) for r in range(len(ranked))},
+                                [ord(x) for x in ranked] if ranked else None)
+                assert vo.vcf_row(rec, None if ft == "PASS" else ft.split(";"), ".") == row
+                # GT: '.' when a filter failed or nothing was counted, else 0 / 1 by whether the top symbol is the reference
+                assert gt == ("." if (mask or not ranked) else ("0" if ranked[0] == chr(int(c["ref_base"])) else "1"))
+                called[(chrom, pos)] = "-" if (mask or not ranked or ranked[0] == "*") else ranked[0]
+                n_rows += 1
+            want = "".join(called.get(key, "-") for key in snplist)
+            assert want == fasta, (s, suffix)
+            # consensus.vcf holds the snplist positions that have a pileup line; the preserved run adds the excluded ones
+            if not suffix:
+                assert set(called) <= set(snplist)
+    assert n_rows > 1200
+
+
+def test_snp_reference_matches_listeria_fixture(tmp_path, fixture_trees):
+    """The second data set that ships its reference: referenceSNP*.fasta of the listeria results (10 102 / 1 040 sites)."""
+    import lzma
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    tree, _ = fixture_trees["listeria"]
+    src = os.path.join(os.path.dirname(__file__), "golden", "fixtures", "listeria", "CFSAN023463.HGAP.draft.fasta.xz")
+    ref = tmp_path / "CFSAN023463.HGAP.draft.fasta"
+    ref.write_bytes(lzma.decompress(open(src, "rb").read()))
+    for snplist, want in (("snplist.txt", "referenceSNP.fasta"), ("snplist_preserved.txt", "referenceSNP_preserved.fasta")):
+        out = str(tmp_path / want)
+        assert cli.run_command_from_args(cli.parse_argument_list(
+            ["snp_reference", "-v", "0", "-l", os.path.join(tree, snplist), "-o", out, str(ref)])) == 0
+        assert open(out, "rb").read() == open(os.path.join(tree, want), "rb").read()
+
+
+def test_vcf_reader_refuses_a_file_without_header(tmp_path):
+    """PyVCF3's Reader refuses a file that does not start with header lines; filter_regions reports that as a sample error."""
+    from snp_pipeline_amd import utils
+    bad = tmp_path / "garbage.vcf"
+    bad.write_text("this is not a vcf\nchr\t12\n")
+    with pytest.raises(IOError):
+        utils.read_vcf_sites(str(bad))
+    ok = tmp_path / "ok.vcf"
+    ok.write_text("##fileformat=VCFv4.1\n#CHROM\tPOS\n\nc1\t5\t.\nc1\t9\t.\n")
+    assert utils.read_vcf_sites(str(ok))[2] == [("c1", 5), ("c1", 9)]

@@ -142,3 +142,22 @@ def test_vcf_row_known_answers():
     r = po.parse_record([b"ID", b"42", b"G", b"23", b"TttaaAAAcCC.......,,,,,", b"00011111222333333333333"], 15)
     assert vo.vcf_row(r, None, ".").split("\t") == ["ID", "42", ".", "G", "A,C,T", ".", "PASS", "NS=1", vo.FORMAT_IDS,
                                                     "0:23:12:5,3,3:7:5:3,2,1:2,1,2:PASS"]
+
+
+def test_depth_sum_against_the_reference_collect_metrics():
+    """avePileupDepth as the reference's own collect_metrics() printed it for pileups with every line shape (1-base
+    reference, so the printed average is the sum): pins oracle.depth_sum, which the GPU by-product is checked against."""
+    from tests.conftest import load_golden
+    from oracle import fuzz
+    vec = load_golden("metrics_vectors.json.gz")["depth_sum"]
+    assert len(vec) >= 6
+    for v in vec:
+        kw = dict(v["kw"])
+        if v["kind"] == "synth":
+            if "contigs" in kw:
+                kw["contigs"] = tuple(kw["contigs"])
+            data = fuzz.synth_pileup(**kw)[0]
+        else:
+            data = fuzz.odd_depth_lines(kw["seed"], kw["eol"].encode())
+        assert len(data) == v["bytes"]
+        assert "%.2f" % float(po.depth_sum(data)) == v["avePileupDepth"]
