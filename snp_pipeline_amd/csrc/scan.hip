@@ -207,8 +207,10 @@ __device__ __forceinline__ void lds_window24(const uint8_t *tile, int off, uint3
 }
 
 // What the one-window parse expects to see in the 24 bytes that END with the separator after the position, for a contig
-// name of L bytes and positions of g digits:  [.. junk ..][name, L][sep][digits, g][sep].  lay[0..5] name bytes in place,
-// lay[6..11] their byte masks, lay[12..14] byte masks of the digits in dwords 3..5.  One lane per dword.
+// name of L bytes and positions of g digits:  [.. junk ..][name, L][TAB][digits, g][TAB].  lay[0..5] name bytes and the two
+// TABs in place, lay[6..11] their byte masks, lay[12..14] byte masks of the digits in dwords 3..5.  One lane per dword.
+// (Only TAB-separated lines take the one-window parse — what samtools writes; a line with other whitespace there goes
+// through the general parse or the exact parser.)
 __device__ __noinline__ void scan_layout(uint32_t *lay, const uint32_t *hint_w, uint32_t L, uint32_t g, uint32_t lane) {
     if (lane < 6) {
         uint32_t w = 0, m = 0;
@@ -219,6 +221,9 @@ __device__ __noinline__ void scan_layout(uint32_t *lay, const uint32_t *hint_w, 
                 m |= 0xFFu << (8 * (b & 3));
             }
         }
+        const uint32_t seps[2] = {22u - g, 23u};                  // the separators after the name and after the digits
+        for (int q = 0; q < 2; ++q)
+            if ((seps[q] >> 2) == lane) { w |= 9u << (8 * (seps[q] & 3)); m |= 0xFFu << (8 * (seps[q] & 3)); }
         lay[lane] = w;
         lay[6 + lane] = m;
     }
@@ -366,9 +371,12 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     // second separator.  A line whose position has another digit count fails the separator / digit tests (exactly: the
     // tests pass iff the count is g), goes to the queue, and resets g; the general path then recalibrates it.
     uint32_t g = 0, nw[6] = {0, 0, 0, 0, 0, 0}, nm[6] = {0, 0, 0, 0, 0, 0}, dmk[3] = {0, 0, 0};
-    bool fastc = false;
+    bool fastc = false, name_split = false;
     auto relayout = [&]() {
-        fastc = hint_bad == 0 && g >= 1 && g <= 10 && L + g + 2 <= 24;
+        // names that do not fit in front of the digits (L > 22 - g) are checked in two pieces: their tail in the window,
+        // their first 16 bytes against the hint registers of the general parse (together: names up to 38 - g bytes)
+        fastc = hint_bad == 0 && g >= 1 && g <= 10 && L + g <= 38;
+        name_split = L + g > 22;
         if (!fastc) return;
         scan_layout(ws.lay, ws.hint_w, L, g, lane);
 #pragma unroll
@@ -492,10 +500,25 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                 bool redo = n_lines > SCAN_LIST_CAP || __ballot((lane == 0) && (pv0 - 11u <= 2u)) != 0;
                 if (!redo) {
                     build_list(0);
-                    bool odd = false;                               // a start that does not follow a '\n'
-                    if (n_lines <= 64) odd = lane < n_lines && tile[(int)lstart[lane] - 1] != 10u;
-                    else for (uint32_t j = lane; j < n_lines; j += 64) odd = odd || tile[(int)lstart[j] - 1] != 10u;
+                    // A start is proper when it follows a '\n'.  In a CR LF file every '\r' flags a second start, the '\n'
+                    // that follows it: such a phantom (it follows '\r' and IS '\n') is marked in the list (bit 15) and
+                    // skipped, so CR LF files keep the fast index.  Anything else ('\r' alone, '\v', '\f') is odd.
+                    bool odd = false;
+                    uint32_t phantoms = 0;
+                    for (uint32_t j = lane; j < n_lines; j += 64) {
+                        const uint32_t st = lstart[j];
+                        const uint32_t pv = tile[(int)st - 1], cv = tile[st];
+                        const bool ph = pv == 13u && cv == 10u;
+                        odd = odd || (pv != 10u && !ph);
+                        if (ph) { lstart[j] = (uint16_t)(st | 0x8000u); ++phantoms; }
+                        if (n_lines <= 64) break;
+                    }
                     redo = __ballot(odd) != 0;
+                    if (!redo && __ballot(phantoms != 0)) {
+                        for (int o = 32; o; o >>= 1) phantoms += __shfl_xor(phantoms, o);
+                        lines_seen -= (lane == 0) ? phantoms : 0;
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
                 const bool listed = !redo;                          // the list of pass 0 is already in LDS
                 if (redo) {
@@ -525,23 +548,27 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                         // whitespace, > 10 digits, long name ...) is queued for the exact parser.
                         for (uint32_t j0 = 0; j0 < n_here; j0 += 64) {
                             const uint32_t j = j0 + lane;
-                            const bool active = j < n_here;
-                            const uint32_t s = active ? lstart[j] : 0u;
-                            uint32_t bad, c1, pos;
+                            const uint32_t s_raw = j < n_here ? lstart[j] : 0x8000u;        // bit 15: the '\n' of a CR LF pair, no line
+                            const bool active = (s_raw >> 15) == 0;
+                            const uint32_t s = s_raw & 0x7FFFu;
+                            uint32_t bad, pos;
                             bool big;
                             uint32_t nd_seen = 0;                                        // digits of this line's position (0: unknown)
+                            bool tabs = true;
                             const bool fast_round = __builtin_amdgcn_readfirstlane((uint32_t)fastc) != 0;    // wave-uniform: a scalar branch
                             if (fast_round) {
                                 uint32_t w[6];
                                 lds_window24(tile, (int)s + (int)(L + g) - 22, w);       // ends with the second separator
-                                c1 = tile[s + L];                                        // the separator after the name
+                                // the name and both TABs in one masked compare per dword
                                 bad = ((w[0] ^ nw[0]) & nm[0]) | ((w[1] ^ nw[1]) & nm[1]) | ((w[2] ^ nw[2]) & nm[2]) |
                                       ((w[3] ^ nw[3]) & nm[3]) | ((w[4] ^ nw[4]) & nm[4]) | ((w[5] ^ nw[5]) & nm[5]);
-                                const uint32_t sep1 = min(c1 ^ 9u, c1 ^ 32u);
-                                if (active && (bad | sep1) != 0) mismatch_at = s;        // another contig?
+                                if (__builtin_amdgcn_readfirstlane((uint32_t)name_split)) {  // uniform: a long name's first 16 bytes
+                                    uint32_t v0, v1, v2, v3;
+                                    lds_window16(tile, (int)s, v0, v1, v2, v3);
+                                    bad |= ((v0 ^ hw[0]) & hm[0]) | ((v1 ^ hw[1]) & hm[1]) | ((v2 ^ hw[2]) & hm[2]) | ((v3 ^ hw[3]) & hm[3]);
+                                }
+                                if (active && bad != 0) mismatch_at = s;                 // another contig, or another digit count
                                 else if (active) nd_seen = g;
-                                const uint32_t c2 = w[5] >> 24;
-                                bad |= sep1 | min(min(c2 ^ 9u, c2 ^ 32u), c2 ^ 10u);
                                 const uint32_t x3 = (w[3] ^ 0x30303030u) & dmk[0], x4 = (w[4] ^ 0x30303030u) & dmk[1], x5 = (w[5] ^ 0x30303030u) & dmk[2];
                                 bad |= (((x3 + 0x76767676u) | x3) | ((x4 + 0x76767676u) | x4) | ((x5 + 0x76767676u) | x5)) & 0x80808080u;
                                 // decimal value: v_dot4_u32_u8 with weights 100, 10, 1 over three digits, the fourth added on top
@@ -566,7 +593,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                 lds_window16(tile, (int)s + 32, v0, v1, v2, v3);
                                 bad |= ((v0 ^ hint_w[8]) & hint_m[8]) | ((v1 ^ hint_w[9]) & hint_m[9]) | ((v2 ^ hint_w[10]) & hint_m[10]) | ((v3 ^ hint_w[11]) & hint_m[11]);
                             }
-                            c1 = tile[s + L];                                            // the separator after the name
+                            const uint32_t c1 = tile[s + L];                             // the separator after the name
                             if (active && (bad | min(c1 ^ 9u, c1 ^ 32u)) != 0) mismatch_at = s;    // another contig?
                             uint4 q1;
                             lds_window16(tile, (int)(s + L + 1), q1.x, q1.y, q1.z, q1.w);       // digits + separator
@@ -587,6 +614,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             big = pos64 > 0xFFFFFFFFull;
                             pos = (uint32_t)pos64;
                             nd_seen = bad == 0 ? nd : 0u;
+                            tabs = ((c1 ^ 9u) | (c2 ^ 9u)) == 0;                          // the one-window parse wants TABs
                             }
                             if (kDepth) {
                                 // 4th column (collect_metrics.py:325-340 sums int(tokens[3]) over the lines that have one):
@@ -651,7 +679,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                 ++hits;
                             }
                             if (!fast_round) {                                           // the general path calibrates the digit count
-                                const uint64_t okm = __ballot(active && nd_seen != 0);
+                                const uint64_t okm = __ballot(active && nd_seen != 0 && tabs);   // lines separated otherwise never calibrate it
                                 const uint32_t g_new = okm ? __builtin_amdgcn_readlane(nd_seen, (uint32_t)__ffsll((long long)okm) - 1) : 0u;
                                 if (g_new != g) { g = g_new; relayout(); }
                             }
@@ -660,6 +688,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                     } else {
                         TileView tv{tile, f.base, t0, f.hi, (int64_t)(SCAN_TILE + SCAN_HALO)};
                         for (uint32_t j = lane; j < n_here; j += 64) {
+                            if (lstart[j] & 0x8000u) continue;                          // the '\n' of a CR LF pair
                             const uint32_t s = lstart[j];
                             const uint64_t file_off = t0 + (uint64_t)s - f.lo;
                             SlowLine sl = parse_line_slow(tv, s, a.want_depth);
@@ -687,7 +716,15 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                     const uint32_t s1 = __builtin_amdgcn_readlane(mismatch_at, (uint32_t)__ffsll((long long)mm) - 1);
                     uint32_t len = 0;
                     while (len < 4 * SCAN_HINT_WORDS && __builtin_amdgcn_readfirstlane((uint32_t)tile[s1 + len]) > 0x20u) ++len;
-                    if (len >= 1 && len <= 4 * SCAN_HINT_WORDS - 4) {
+                    // the same name as the hint's? then only the digit count (or a separator) differed: recalibrate, no look-up
+                    bool same = hint_bad == 0 && len == L;
+                    if (same) {
+                        bool diff = false;
+                        for (uint32_t i = lane; i < len; i += 64) diff = diff || tile[s1 + i] != ((ws.hint_w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+                        same = __ballot(diff) == 0;
+                    }
+                    if (same) { g = 0; fastc = false; }
+                    else if (len >= 1 && len <= 4 * SCAN_HINT_WORDS - 4) {
                         TileView tv{tile, f.base, t0, f.hi, (int64_t)(SCAN_TILE + SCAN_HALO)};
                         const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, (int64_t)s1, len) : 0xFFFFFFFFu;
                         g = 0; fastc = false;                        // the next round calibrates against the new name

@@ -94,8 +94,8 @@ def test_files_any_chunking_equals_resident_and_oracle(d, tmp_path):
             assert r.depth_sum == sum(int(f[3]) for _, ln in po.iter_lines(datas[i]) for f in [ln.split()] if len(f) > 3)
     # ... and the oracle itself on the multi-chunk files
     excl = {k for k, fl in zip(ss.key_tuples(), ss.flags) if fl & L.SITE_EXCLUDED}
-    results, _, _ = d.call_consensus_files(ss, paths[:3], prm, chunk_bytes=65536, n_staging=4, n_readers=3)
-    for i in range(3):
+    results, _, _ = d.call_consensus_files(ss, paths[:5], prm, chunk_bytes=65536, n_staging=4, n_readers=3)
+    for i in range(5):
         want, _ = po.call_consensus_sites(datas[i], ss.key_tuples(), excl, p)
         assert bytes(results[i].bases) == want
 

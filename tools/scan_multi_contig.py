@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     import torch
+    from snp_pipeline_amd import _lib as L
+    if os.environ.get("SNPGPU_TUNE_LIB"):
+        L.LIB_PATH = os.path.abspath(os.environ["SNPGPU_TUNE_LIB"])
     from snp_pipeline_amd import device as dev
     C = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     G = int(sys.argv[2]) if len(sys.argv) > 2 else 125_000
