@@ -83,8 +83,26 @@ def _write_outputs(plan, dev, ss, n_keys, res):
             vcf_writer.write_all_positions_vcf(plan.vcf_path, plan.sample_name, args, plan.pileup_path, line_off, counts)
         else:
             vcf_writer.write_consensus_vcf(plan.vcf_path, plan.sample_name, args, ss, res, res.line_offsets)
+    consensus = consensus_string(ss, n_keys, res)
     with open(plan.consensus_path, "w") as fasta_file_object:
-        utils.write_fasta_record(fasta_file_object, plan.sample_name, consensus_string(ss, n_keys, res))
+        utils.write_fasta_record(fasta_file_object, plan.sample_name, consensus)
+    if getattr(args, "amdMetricsRefFasta", None):
+        _record_metrics(plan, res, consensus)
+
+
+def _record_metrics(plan, res, consensus):
+    """collect_metrics by-products: the reference re-reads the whole pileup in Python to sum its depth column
+    (collect_metrics.py:325-340) and re-reads the consensus FASTA to count its gaps (:109-128) — both fall out of this step.
+    They are recorded in the sample's metrics file under the names collect_metrics uses; when that file is newer than the
+    pileup / the FASTA, the reference's collect_metrics takes them from there (:318-321, :441-447) and skips the re-reads.
+    The preserved flow (an exclude file was given) records missingPosPreserved."""
+    args = plan.args
+    path = args.amdMetricsFile or os.path.join(os.path.dirname(os.path.abspath(plan.pileup_path)), "metrics")
+    updates = {("missingPosPreserved" if plan.exclude_path else "missingPos"): str(consensus.count("-"))}
+    reference_length = sum(utils.read_fasta_lengths(args.amdMetricsRefFasta).values())
+    if res.depth_sum > 0 and reference_length > 0:
+        updates["avePileupDepth"] = "%.2f" % (float(res.depth_sum) / float(reference_length))
+    utils.update_properties(path, updates)
 
 
 def call_consensus(args):
@@ -120,7 +138,8 @@ def call_consensus(args):
     params = devmod.make_params(args.minBaseQual, args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
     dev = devmod.default_device()
     ss, n_keys = build_siteset(dev, snp_list, plan.excluded)
-    results, rcs, _ = dev.call_consensus_files(ss, [all_pileup_file_path], params, want_counts=True, want_line_offsets=True)
+    results, rcs, _ = dev.call_consensus_files(ss, [all_pileup_file_path], params, want_counts=True, want_line_offsets=True,
+                                               want_depth_sum=bool(getattr(args, "amdMetricsRefFasta", None)))
     try:
         dev.raise_file_status(all_pileup_file_path, int(rcs[0]), results[0])
     except devmod.PileupFormatError as err:
@@ -188,7 +207,8 @@ def call_consensus_batch(args):
             for excluded, group in groups.items():
                 ss, n_keys = build_siteset(dev, snp_list, excluded)
                 results, rcs, _ = dev.call_consensus_files(ss, [p.pileup_path for p in group], params, want_counts=True,
-                                                           want_line_offsets=True)
+                                                           want_line_offsets=True,
+                                                           want_depth_sum=bool(getattr(args, "amdMetricsRefFasta", None)))
                 for plan, rc, res in zip(group, rcs, results):
                     try:
                         dev.raise_file_status(plan.pileup_path, int(rc), res)

@@ -100,6 +100,8 @@ def parse_argument_list(argv):
     sub.add_argument("--vcfAllPos", dest="vcfAllPos", action="store_true", help="Flag to cause VCF file generation at all positions, not just the snp positions.")
     sub.add_argument("--vcfPreserveRefCase", dest="vcfPreserveRefCase", action="store_true", help="Emit each reference base in uppercase/lowercase as it appears in the reference sequence file.")
     sub.add_argument("--vcfFailedSnpGt", dest="vcfFailedSnpGt", type=str, default=".", choices=[".", "0", "1"], help="Controls the VCF file GT data element when a snp fails filters.")
+    sub.add_argument("--amdMetricsRefFasta", dest="amdMetricsRefFasta", type=str, default=None, metavar="FILE", help="Extension of this build: reference fasta file; when given, the mean pileup depth (a by-product of the pileup scan) and the number of missing positions are recorded in the sample's metrics file, where the reference's collect_metrics reuses them instead of reading the pileup again.")
+    sub.add_argument("--amdMetricsFile", dest="amdMetricsFile", type=str, default=None, metavar="FILE", help="Extension of this build: the metrics file to update (default: metrics in the sample directory).")
     _common(sub)
     sub.set_defaults(func=call_consensus.call_consensus, excepthook=utils.handle_sample_exception)
 
@@ -122,6 +124,8 @@ def parse_argument_list(argv):
     sub.add_argument("--vcfAllPos", dest="vcfAllPos", action="store_true", help="Flag to cause VCF file generation at all positions, not just the snp positions.")
     sub.add_argument("--vcfPreserveRefCase", dest="vcfPreserveRefCase", action="store_true", help="Emit each reference base in uppercase/lowercase as it appears in the reference sequence file.")
     sub.add_argument("--vcfFailedSnpGt", dest="vcfFailedSnpGt", type=str, default=".", choices=[".", "0", "1"], help="Controls the VCF file GT data element when a snp fails filters.")
+    sub.add_argument("--amdMetricsRefFasta", dest="amdMetricsRefFasta", type=str, default=None, metavar="FILE", help="Extension of this build: reference fasta file; when given, the mean pileup depth (a by-product of the pileup scan) and the number of missing positions are recorded in the sample's metrics file, where the reference's collect_metrics reuses them instead of reading the pileup again.")
+    sub.add_argument("--amdMetricsFile", dest="amdMetricsFile", type=str, default=None, metavar="FILE", help="Extension of this build: the metrics file to update (default: metrics in the sample directory).")
     _common(sub)
     sub.set_defaults(func=call_consensus.call_consensus_batch, excepthook=utils.handle_global_exception)
 

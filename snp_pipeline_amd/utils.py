@@ -277,3 +277,25 @@ def write_fasta_record(handle, record_id, sequence, width=60):
     handle.write(">%s\n" % record_id)
     for i in range(0, len(sequence), width):
         handle.write(sequence[i:i + width] + "\n")
+
+
+# ---- the per-sample metrics file (name=value properties, utils.py:323-380 of the reference reads it back) ---------------
+def update_properties(prop_file_path, updates):
+    """Set ``name=value`` lines in a properties file, keeping every other line; the file is created when missing."""
+    lines = []
+    if os.path.isfile(prop_file_path):
+        with open(prop_file_path, "r") as f:
+            lines = f.read().split("\n")
+        if lines and lines[-1] == "":
+            lines.pop()
+    left = dict(updates)
+    out = []
+    for line in lines:
+        name = line.split("=", 1)[0].strip() if "=" in line and not line.lstrip().startswith("#") else None
+        if name in left:
+            out.append("%s=%s" % (name, left.pop(name)))
+        else:
+            out.append(line)
+    out.extend("%s=%s" % kv for kv in left.items())
+    with open(prop_file_path, "w") as f:
+        f.write("\n".join(out) + "\n")

@@ -207,3 +207,34 @@ def test_console_script_subprocess_without_torch(tmp_path):
     want, _ = po.call_consensus_sites(data, sites, set(), po.CallerParams(0, 0.6, 3, 0, 0.0))
     assert (sdir / "consensus.fasta").read_text() == ">sampleS\n" + "".join(want.decode()[i:i + 60] + "\n" for i in range(0, len(want), 60))
     print("console script wall time %.2f s" % (time.time() - t0))
+
+
+def test_call_consensus_records_metrics_byproducts(tmp_path):
+    """--amdMetricsRefFasta: avePileupDepth (depth-column sum of the scan / reference length, "%.2f", collect_metrics.py:325-340)
+    and missingPos / missingPosPreserved go to the sample's metrics file, other lines kept."""
+    data, ref, sites = fuzz.synth_pileup(47, genome_len=3000, n_sites=80)
+    sdir = tmp_path / "sampleM"
+    sdir.mkdir()
+    (sdir / "reads.all.pileup").write_bytes(data)
+    fa = tmp_path / "ref.fasta"
+    fa.write_text("".join(">%s some description\n%s\n" % (c.decode() if isinstance(c, bytes) else c, "\n".join(seq[i:i + 70] for i in range(0, len(seq), 70)))
+                          for c, seq in ref.items()))
+    ref_len = sum(len(seq) for seq in ref.values())
+    with open(str(tmp_path / "snplist.txt"), "w") as f:
+        for c, p in sites:
+            f.write("%s\t%d\t1\tsampleM\n" % (c.decode(), p))
+    (sdir / "metrics").write_text('sample="sampleM"\nmissingPos=999\n')
+    _run("call_consensus -v 0 -l %s/snplist.txt -o %s/consensus.fasta --minConsDpth 3 --amdMetricsRefFasta %s %s/reads.all.pileup" % (tmp_path, sdir, fa, sdir))
+    want, _ = po.call_consensus_sites(data, sites, set(), po.CallerParams(0, 0.6, 3, 0, 0.0))
+    props = dict(ln.split("=", 1) for ln in (sdir / "metrics").read_text().split("\n") if "=" in ln)
+    assert props == {"sample": '"sampleM"', "missingPos": str(want.count(b"-")), "avePileupDepth": "%.2f" % (po.depth_sum(data) / float(ref_len))}
+    # the preserved flow records its own key, in the file named by --amdMetricsFile
+    with open(str(sdir / "excl.vcf"), "w") as f:
+        f.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n")
+        for c, p in sites[::4]:
+            f.write("%s\t%d\t.\tA\tC\t.\tPASS\t.\tGT\t1/1\n" % (c.decode(), p))
+    _run("call_consensus -v 0 -l %s/snplist.txt -o %s/consensus_preserved.fasta -e %s/excl.vcf --minConsDpth 3 --amdMetricsRefFasta %s "
+         "--amdMetricsFile %s/m2 %s/reads.all.pileup" % (tmp_path, sdir, sdir, fa, tmp_path, sdir))
+    want2, _ = po.call_consensus_sites(data, sites, set(sites[::4]), po.CallerParams(0, 0.6, 3, 0, 0.0))
+    props2 = dict(ln.split("=", 1) for ln in (tmp_path / "m2").read_text().split("\n") if "=" in ln)
+    assert props2["missingPosPreserved"] == str(want2.count(b"-")) and "missingPos" not in props2

@@ -13,7 +13,8 @@ def test_cli_parser_matches_reference_parser():
     from snp_pipeline_amd import cfsan_snp_pipeline as cli
     for v in load_golden("cli_vectors.json.gz"):
         ns = vars(cli.parse_command_line(v["line"]))
-        got = {k: val for k, val in ns.items() if k not in ("func", "excepthook")}
+        # (the two --amdMetrics* options are extensions of this build: additive, absent from the reference's Namespace)
+        got = {k: val for k, val in ns.items() if k not in ("func", "excepthook") and not k.startswith("amd")}
         got["excepthook"] = ns["excepthook"].__name__
         got["func"] = ns["func"].__name__
         assert got == v["args"], v["line"]
@@ -262,3 +263,25 @@ def test_vcf_reader_refuses_a_file_without_header(tmp_path):
     ok = tmp_path / "ok.vcf"
     ok.write_text("##fileformat=VCFv4.1\n#CHROM\tPOS\n\nc1\t5\t.\nc1\t9\t.\n")
     assert utils.read_vcf_sites(str(ok))[2] == [("c1", 5), ("c1", 9)]
+
+
+def test_metrics_properties_update_and_missing_positions(tmp_path, fixture_trees):
+    """The metrics side file: name=value lines updated in place; missingPos is the number of '-' of the sample's consensus
+    record (collect_metrics.py:109-128) — checked against the bundled lambda metrics files."""
+    from snp_pipeline_amd import utils
+    path = tmp_path / "metrics"
+    utils.update_properties(str(path), {"avePileupDepth": "23.10", "missingPos": "4"})
+    assert path.read_text() == "avePileupDepth=23.10\nmissingPos=4\n"
+    path.write_text('sample="s1"\n# note\nmissingPos=9\nmachine=\n')
+    utils.update_properties(str(path), {"missingPos": "0", "avePileupDepth": "1.00"})
+    assert path.read_text() == 'sample="s1"\n# note\nmissingPos=0\nmachine=\navePileupDepth=1.00\n'
+    root, _ = fixture_trees["lambdaVirus"]
+    checked = 0
+    for s in sorted(os.listdir(os.path.join(root, "samples"))):
+        sdir = os.path.join(root, "samples", s)
+        props = dict(ln.rstrip("\n").split("=", 1) for ln in open(os.path.join(sdir, "metrics")) if "=" in ln)
+        for fasta, key in (("consensus.fasta", "missingPos"), ("consensus_preserved.fasta", "missingPosPreserved")):
+            seq = "".join(open(os.path.join(sdir, fasta)).read().split("\n")[1:])
+            assert str(seq.count("-")) == props[key].strip('"'), (s, key)
+            checked += 1
+    assert checked == 8

@@ -1,0 +1,30 @@
+#!/bin/sh
+# Round profile on the GPU box: the bench line, the rocprofv3 kernel trace of the same command, and the PMC passes
+# (FETCH_SIZE / WRITE_SIZE / SQ counters, separate runs) -> gpurun_out/<round>/ ; copy what is to be judged into profiles/<round>/.
+# Usage: sh tools/profile_round.sh r2
+round=${1:-r2}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/$round
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+short="--steps 5 --warmup 2 --cpu-samples 0 --skip-aux --e2e-files 0"
+pmc="--steps 3 --warmup 1 --cpu-samples 0 --skip-secondary --skip-aux --e2e-files 0"
+python $root/bench.py > "$out/bench_n1.json" 2> "$out/bench_n1.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python $root/bench.py $short > "$out/trace_bench.json" 2> "$out/trace.err"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python $root/bench.py $pmc > /dev/null 2> "$out/pmc_fetch.err"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python $root/bench.py $pmc > /dev/null 2> "$out/pmc_write.err"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d "$out/pmc_sq" -- python $root/bench.py $pmc > /dev/null 2> "$out/pmc_sq.err"
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d "$out/pmc_sq2" -- python $root/bench.py $pmc > /dev/null 2> "$out/pmc_sq2.err"
+cd "$root"
+python tools/pmc_summary.py "$out/pmc_fetch" > "$out/pmc_fetch_size_summary.txt"
+python tools/pmc_summary.py "$out/pmc_write" > "$out/pmc_write_size_summary.txt"
+python tools/pmc_summary.py "$out/pmc_sq" > "$out/pmc_sq_summary.txt"
+python tools/pmc_summary.py "$out/pmc_sq2" > "$out/pmc_sq2_summary.txt"
+find "$out/trace" -name "*kernel_stats.csv" -exec cp {} "$out/rocprofv3_kernel_stats_bench.csv" \;
+# keep the merge small: the raw per-dispatch CSVs stay on the box
+rm -rf "$out/trace" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_sq" "$out/pmc_sq2"
+ls -la "$out"
+head -12 "$out/rocprofv3_kernel_stats_bench.csv"
+grep -A3 "k_scan_wave<false, 0>" "$out/pmc_fetch_size_summary.txt" "$out/pmc_write_size_summary.txt" | head -20
+grep -A9 "k_scan_wave<false, 0>" "$out/pmc_sq_summary.txt" "$out/pmc_sq2_summary.txt" | head -40
+tail -c 1500 "$out/bench_n1.json"
