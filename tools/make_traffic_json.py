@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""profiles/<round>/pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE summaries and the bench line of the same round."""
+import json
+import re
+import sys
+
+rnd = sys.argv[1]
+base = "profiles/%s/" % rnd
+
+
+def mean_of(path, kernel, counter):
+    txt = open(path).read().split("\n")
+    for i, line in enumerate(txt):
+        if line.startswith(kernel):
+            for ln in txt[i + 1:i + 12]:
+                m = re.match(r"\s+%s\s+n=\d+\s+mean=(\S+)" % counter, ln)
+                if m:
+                    return float(m.group(1))
+    raise SystemExit("no %s for %s in %s" % (counter, kernel, path))
+
+
+bench = json.loads(open(base + "bench_n1.json").read().strip().split("\n")[-1])
+k = "void k_scan_wave<false, 0>"
+fetch_kb = mean_of(base + "pmc_fetch_size_summary.txt", k, "FETCH_SIZE")
+write_kb = mean_of(base + "pmc_write_size_summary.txt", k, "WRITE_SIZE")
+algo = bench["roofline"]["algorithmic_bytes_per_launch"]
+fetch_b, write_b = fetch_kb * 1024 * 2, write_kb * 1024
+out = {
+    "kernel": "k_scan_wave<false,0>",
+    "workload": {"samples_per_gpu": bench["config"]["samples_this_rank"], "genome_bp": bench["config"]["genome_bp"],
+                 "mean_depth": bench["config"]["mean_depth"], "snp_sites": bench["config"]["snp_sites"]},
+    "FETCH_SIZE_kb_per_launch": fetch_kb, "WRITE_SIZE_kb_per_launch": write_kb,
+    "corrections": "FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes (rocprofv3, gfx950); unit KB (x1024); FETCH_SIZE "
+                   "doubled as MI355X_MICROARCH.md prescribes for wide coalesced streaming reads (128-B requests tallied at 64 B); "
+                   "WRITE_SIZE uncalibrated, taken as reported",
+    "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b, "traffic_bytes_per_launch": fetch_b + write_b,
+    "algorithmic_bytes_per_launch": algo, "traffic_over_algorithmic": (fetch_b + write_b) / algo,
+}
+json.dump(out, open(base + "pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
