@@ -182,16 +182,12 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
             else {
                 ref = lb(L.fs[2]);
                 uint32_t ds = L.fs[3], de = L.fe[3];
-                uint64_t dv = 0;
-                bool dok = de > ds;
-                for (uint32_t q = ds; q < de; ++q) {         // uniform loop, a handful of digits
-                    uint32_t c = lb(q);
-                    if (is_digit(c)) { dv = dv * 10 + (c - 48u); if (dv > 0xFFFFFFFFull) dv = 0xFFFFFFFFull; }
-                    else dok = false;
-                }
-                if (!dok) status = SNPGPU_ST_BAD_DEPTH;
+                PyInt di;                                    // int(depth), pileup.py:225 ("+30" and "3_0" are integers too)
+                for (uint32_t q = ds; q < de; ++q) di.feed(lb(q));   // uniform loop, a handful of bytes
+                // (a negative depth is an integer for the reference as well; the 32-bit record cannot hold it: refused)
+                if (!di.ok() || (di.neg && di.v != 0)) status = SNPGPU_ST_BAD_DEPTH;
                 else {
-                    raw_depth = (uint32_t)dv;
+                    raw_depth = di.v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)di.v;
                     if (raw_depth != 0 && nfields == 5) status = SNPGPU_ST_NO_QUALS;
                 }
             }

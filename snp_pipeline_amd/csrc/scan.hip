@@ -146,23 +146,19 @@ __device__ __noinline__ SlowLine parse_line_slow(TileView tv, int64_t s, int wan
     const uint32_t f0len = (uint32_t)(p - f0);
     while (is_ws(c) && !is_term(c)) c = tv.get(++p);
     if (is_term(c)) { r.err = SCAN_ERR_FEW_FIELDS; return r; }
-    uint64_t pos = 0;
-    bool ok = true;
-    while (!is_ws(c)) {
-        if (is_digit(c)) { pos = pos * 10 + (c - 48u); if (pos > 0xFFFFFFFFull) pos = 0x100000000ull; }
-        else ok = false;
-        c = tv.get(++p);
-    }
-    if (!ok) { r.err = SCAN_ERR_BAD_POS; return r; }
+    PyInt pi;                                                   // int(pos), pileup.py:426: "+5" and "1_0" are integers too
+    while (!is_ws(c)) { pi.feed(c); c = tv.get(++p); }
+    if (!pi.ok()) { r.err = SCAN_ERR_BAD_POS; return r; }
+    // a negative position, or one past 2^32 - 1, cannot be in the site set
+    const uint64_t pos = (pi.neg && pi.v != 0) || pi.v > 0xFFFFFFFFull ? 0x100000000ull : pi.v;
     r.f0 = f0; r.f0len = f0len; r.pos = pos;
     if (want_depth) {                                       // 4th column, collect_metrics.py:325-340 by-product
         while (is_ws(c) && !is_term(c)) c = tv.get(++p);
         while (!is_ws(c)) c = tv.get(++p);                  // reference base field
         while (is_ws(c) && !is_term(c)) c = tv.get(++p);
-        unsigned long long dd = 0;
-        bool dok = !is_ws(c);
-        while (!is_ws(c)) { if (is_digit(c)) dd = dd * 10 + (c - 48u); else dok = false; c = tv.get(++p); }
-        if (dok) r.depth = dd;
+        PyInt di;                                               // int(tokens[3]) or skip the line (collect_metrics.py:330-333)
+        while (!is_ws(c)) { di.feed(c); c = tv.get(++p); }
+        if (di.ok()) r.depth = di.neg ? 0ull - di.v : di.v;     // sums are taken modulo 2^64: a negative depth subtracts
     }
     return r;
 }

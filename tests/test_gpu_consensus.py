@@ -490,3 +490,29 @@ def test_queue_overflow_takes_the_exact_pass(d):
     assert bad != body
     with pytest.raises(PileupFormatError):
         gpu_consensus(d, bad, keys, [], po.CallerParams(0, 0.6, 1, 0, 0.0), want_counts=False)
+
+
+def test_python_int_fields(d):
+    """int(pos) / int(depth) as CPython parses them (pileup.py:426, :223-225): an optional sign and single underscores between
+    digits are integers too; the one-window parse leaves such lines to the exact parser, which must agree with the oracle."""
+    from snp_pipeline_amd.device import PileupFormatError
+    from tests.gpu_util import check_against_oracle, gpu_consensus
+    body = [b"c1\t+5\tA\t3\t..,\tIII", b"c1\t1_0\tC\t+3\tTTt\tIII", b"c1\t0_1_2\tG\t1_0\t.$,.,.,.,.,\tIIIIIIIIII", b"c1\t-0\tT\t2\tgg\tII",
+             b"c1\t-7\tT\t2\tgg\tII", b"c1\t007\tT\t02\tcc\tII", b"c1\t99999999999\tA\t1\t.\tI", b"c1\t20\tA\t0_0\t*\t*"]
+    keys = [(b"c1", 5), (b"c1", 10), (b"c1", 12), (b"c1", 0), (b"c1", 7), (b"c1", 20), (b"c1", 99)]
+    data = b"\n".join(body) + b"\n"
+    res = check_against_oracle(d, data, keys, [(b"c1", 10)], po.CallerParams(0, 0.6, 1, 0, 0.0))
+    assert res.n_lines == len(body) and res.n_matched == 6
+    got = d.call_consensus(d.siteset(keys, [1] * len(keys)), data, __import__("snp_pipeline_amd.device", fromlist=["x"]).make_params(),
+                           want_depth_sum=True)
+    assert got.depth_sum == po.depth_sum(data) == 3 + 3 + 10 + 2 + 2 + 2 + 1 + 0
+    for bad in (b"c1\t5_\tA\t1\t.\tI\n", b"c1\t_5\tA\t1\t.\tI\n", b"c1\t+\tA\t1\t.\tI\n", b"c1\t5__0\tA\t1\t.\tI\n", b"c1\t++5\tA\t1\t.\tI\n",
+                b"c1\t5\tA\t1_\t.\tI\n", b"c1\t5\tA\t+\t.\tI\n"):
+        with pytest.raises(ValueError):
+            po.call_consensus_sites(bad, keys, set(), po.CallerParams())
+        with pytest.raises(PileupFormatError) as ei:
+            gpu_consensus(d, bad, keys, [], po.CallerParams())
+        assert ei.value.reference_exception is ValueError
+    # a negative depth is an integer for the reference; the 32-bit record cannot hold it: refused loudly (DESIGN 2)
+    with pytest.raises(PileupFormatError):
+        gpu_consensus(d, b"c1\t5\tA\t-3\t...\tIII\n", keys, [], po.CallerParams())
