@@ -81,6 +81,13 @@ def _write_outputs(plan, dev, ss, n_keys, res):
             except devmod.PileupFormatError as err:
                 _raise_as_reference(err)
             vcf_writer.write_all_positions_vcf(plan.vcf_path, plan.sample_name, args, plan.pileup_path, line_off, counts)
+        elif res.n_matched > int(np.count_nonzero(res.line_offsets)):
+            # a pileup that repeats a position: the reference writes a row for every matching LINE (call_consensus.py:178-180),
+            # the per-site result only knows the last one — take the rows from the all-lines pass, listed positions only
+            params = devmod.make_params(args.minBaseQual, args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
+            line_off, line_flags, counts = dev.call_all_lines(ss, plan.pileup_path, params, capacity=res.n_lines, check=False)
+            keep = np.nonzero(line_flags)[0]
+            vcf_writer.write_all_positions_vcf(plan.vcf_path, plan.sample_name, args, plan.pileup_path, line_off[keep], counts[keep])
         else:
             vcf_writer.write_consensus_vcf(plan.vcf_path, plan.sample_name, args, ss, res, res.line_offsets)
     consensus = consensus_string(ss, n_keys, res)

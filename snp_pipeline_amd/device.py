@@ -248,9 +248,10 @@ class Device(object):
             results.append(r)
         return results, rcs[:n_files], stats
 
-    def call_all_lines(self, siteset, path, params, capacity=0):
+    def call_all_lines(self, siteset, path, params, capacity=0, check=True):
         """call_consensus --vcfAllPos: a record for EVERY line of the pileup file, in file order.
-        Returns (line_offsets + 1, line site flags, counts records).  Raises like the reference for malformed lines."""
+        Returns (line_offsets + 1, line site flags, counts records).  Raises like the reference for malformed lines
+        (check=False: only for malformed chrom / position columns; the caller looks at the records it uses)."""
         n_lines = C.c_uint64()
         status = np.zeros(L.SCAN_STATUS_WORDS, dtype=np.uint64)
         while True:
@@ -269,8 +270,8 @@ class Device(object):
                 break
             capacity = n_lines.value
         n = n_lines.value
-        res = ConsensusResult(None, None, counts[:n], status)
-        self.raise_site_status(res)
+        if check:
+            self.raise_site_status(ConsensusResult(None, None, counts[:n], status))
         return off[:n], flags[:n], counts[:n]
 
     def raise_file_status(self, path, rc, res, check=True):

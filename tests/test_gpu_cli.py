@@ -238,3 +238,26 @@ def test_call_consensus_records_metrics_byproducts(tmp_path):
     want2, _ = po.call_consensus_sites(data, sites, set(sites[::4]), po.CallerParams(0, 0.6, 3, 0, 0.0))
     props2 = dict(ln.split("=", 1) for ln in (tmp_path / "m2").read_text().split("\n") if "=" in ln)
     assert props2["missingPosPreserved"] == str(want2.count(b"-")) and "missingPos" not in props2
+
+
+def test_consensus_vcf_rows_for_repeated_positions(tmp_path):
+    """A pileup that lists a position twice: the FASTA takes the last line (call_consensus.py:171-176), consensus.vcf gets a
+    row for every matching line in file order (:178-180)."""
+    lines = [b"c1\t5\tA\t3\tGGG\tIII", b"c1\t6\tC\t3\t...\tIII", b"c1\t5\tA\t4\tTTTt\tIIII", b"c1\t7\tG\t2\t..\tII", b"c1\t9\tG\t3\taaa\tIII",
+             b"c1\t9\tG\t1\t.\tI"]
+    data = b"\n".join(lines) + b"\n"
+    sdir = tmp_path / "dup"
+    sdir.mkdir()
+    (sdir / "reads.all.pileup").write_bytes(data)
+    (tmp_path / "snplist.txt").write_text("c1\t5\t1\tdup\nc1\t7\t1\tdup\nc1\t9\t1\tdup\n")
+    _run("call_consensus -v 0 -l %s/snplist.txt -o %s/consensus.fasta --vcfFileName consensus.vcf %s/reads.all.pileup" % (tmp_path, sdir, sdir))
+    assert (sdir / "consensus.fasta").read_text() == ">dup\nTGG\n"
+    params = po.CallerParams(0, 0.6, 1, 0, 0.0)
+    names = po.filter_names(params)
+    want = []
+    for ln in (lines[0], lines[2], lines[3], lines[4], lines[5]):
+        rec = po.parse_record(po.split_fields(ln), 0)
+        base, mask = po.call_record(rec, params)
+        want.append(vo.vcf_row(rec, [names[i] for i in range(6) if mask >> i & 1] or None, "."))
+    got = [x for x in (sdir / "consensus.vcf").read_text().split("\n") if x and not x.startswith("#")]
+    assert got == want
