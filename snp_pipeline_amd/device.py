@@ -426,15 +426,17 @@ def device_count():
     return int(L.load().snpgpu_device_count())
 
 
-def acquire_device_slot(n_devices, max_per_device=None, lock_dir=None):
+def acquire_device_slot(n_devices, max_per_device=None, lock_dir=None, poll_seconds=0.05):
     """Device assignment for the reference's per-sample process array (run.py:709-710 starts up to max_cpu_cores
     ``cfsan_snp_pipeline call_consensus`` processes at once, none of which knows about the others).  Every process
     takes an advisory lock on one of ``n_devices x max_per_device`` slot files: the first free slot in a sweep that
-    prefers the least loaded device, or — when all are taken — a blocking wait on one of them.  So the processes spread
-    round-robin over the visible GPUs and at most ``max_per_device`` contexts exist per GPU at a time; the lock dies with
-    the process.  Returns (device index, open lock file)."""
+    prefers the least loaded device (slot 0 of every device before slot 1 of any), or — while all are taken — it keeps
+    sweeping until a holder goes away.  So the processes spread round-robin over the visible GPUs and at most
+    ``max_per_device`` contexts exist per GPU at a time; the lock dies with the process.  Returns (device index, open
+    lock file)."""
     import fcntl
     import tempfile
+    import time
     if max_per_device is None:
         max_per_device = int(os.environ.get("SNPGPU_MAX_PROCS_PER_DEVICE", "4"))
     max_per_device = max(1, max_per_device)
@@ -442,21 +444,15 @@ def acquire_device_slot(n_devices, max_per_device=None, lock_dir=None):
     os.makedirs(lock_dir, exist_ok=True)
     start = os.getpid() % n_devices
     order = [((start + i) % n_devices, j) for j in range(max_per_device) for i in range(n_devices)]
-
-    def open_slot(dev, j):
-        return open(os.path.join(lock_dir, "dev%d.slot%d" % (dev, j)), "a+")
-
-    for dev, j in order:                       # slot 0 of every device first, then slot 1 ...: least loaded device wins
-        f = open_slot(dev, j)
-        try:
-            fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)
-            return dev, f
-        except (IOError, OSError):
-            f.close()
-    dev, j = order[os.getpid() % len(order)]
-    f = open_slot(dev, j)
-    fcntl.flock(f, fcntl.LOCK_EX)              # everything is busy: queue up behind one slot
-    return dev, f
+    while True:
+        for dev, j in order:
+            f = open(os.path.join(lock_dir, "dev%d.slot%d" % (dev, j)), "a+")
+            try:
+                fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)
+                return dev, f
+            except (IOError, OSError):
+                f.close()
+        time.sleep(poll_seconds)                   # everything is busy: look again shortly
 
 
 def default_device():

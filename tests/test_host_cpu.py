@@ -285,3 +285,64 @@ def test_metrics_properties_update_and_missing_positions(tmp_path, fixture_trees
             assert str(seq.count("-")) == props[key].strip('"'), (s, key)
             checked += 1
     assert checked == 8
+
+
+def test_device_slots_spread_processes(tmp_path):
+    """acquire_device_slot: what the array of per-sample CLI processes (run.py:709-710) uses to pick a GPU — slot 0 of every
+    device before slot 1 of any, never more than max_per_device holders per device, the lock gone with its holder."""
+    import multiprocessing as mp
+    from snp_pipeline_amd import device as dev
+    lock_dir = str(tmp_path / "locks")
+    held = [dev.acquire_device_slot(3, max_per_device=2, lock_dir=lock_dir) for _ in range(6)]
+    per_dev = {}
+    for d_, _ in held:
+        per_dev[d_] = per_dev.get(d_, 0) + 1
+    assert per_dev == {0: 2, 1: 2, 2: 2}
+    assert sorted(d_ for d_, _ in held[:3]) == [0, 1, 2]            # the first three processes land on three different GPUs
+    assert sorted(os.listdir(lock_dir)) == ["dev%d.slot%d" % (d_, j) for d_ in range(3) for j in range(2)]
+    # everything is taken: a seventh process waits, and gets the slot the moment a holder goes away
+    q = mp.get_context("spawn").Queue()
+    p = mp.get_context("spawn").Process(target=_slot_worker, args=(lock_dir, q))
+    p.start()
+    time.sleep(1.0)
+    assert q.empty()
+    gone = held.pop(2)
+    gone[1].close()
+    got = q.get(timeout=30)
+    p.join(30)
+    assert 0 <= got < 3
+    for _, f in held:
+        f.close()
+
+
+def _slot_worker(lock_dir, q):
+    from snp_pipeline_amd import device as dev
+    d_, f = dev.acquire_device_slot(3, max_per_device=2, lock_dir=lock_dir)
+    q.put(d_)
+    f.close()
+
+
+def test_call_consensus_batch_parser_and_all_positions_writer(tmp_path):
+    """The extension subcommand takes call_consensus's options; the --vcfAllPos writer lays out one row per line."""
+    import numpy as np
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    from snp_pipeline_amd import vcf_writer
+    ns = cli.parse_command_line("call_consensus_batch -l snplist.txt -o consensus_preserved.fasta -e var.flt_removed.vcf -q 15 -c 0.9 "
+                                "--vcfFileName consensus_preserved.vcf --pileupName reads.all.pileup dirs.txt")
+    assert (ns.sampleDirsFile, ns.consensusFile, ns.excludeFile, ns.minBaseQual, ns.minConsFreq, ns.pileupName) == \
+        ("dirs.txt", "consensus_preserved.fasta", "var.flt_removed.vcf", 15, 0.9, "reads.all.pileup")
+    assert ns.func.__name__ == "call_consensus_batch" and ns.vcfAllPos is False
+    one = cli.parse_command_line("call_consensus --amdMetricsRefFasta ref.fa x.pileup")
+    assert one.amdMetricsRefFasta == "ref.fa" and one.amdMetricsFile is None
+    pile = tmp_path / "p.pileup"
+    pile.write_bytes(b"c1\t5\tG\t2\t.A\tII\nlong_contig_name_%s\t77\ta\t0\t*\t*\n" % (b"x" * 300))
+    rows = [_counts_from_vcf_row("c1\t5\t.\tG\tA\t.\tPASS\tNS=1\tGT:SDP:RD:AD:RDF:RDR:ADF:ADR:FT\t1:2:1:1:1:0:1:0:PASS")[2],
+            _counts_from_vcf_row("z\t77\t.\tA\t.\t.\tRawDpth\tNS=1\tGT:SDP:RD:AD:RDF:RDR:ADF:ADR:FT\t.:0:0:0:0:0:0:0:RawDpth")[2]]
+    rows[1]["filters"] = 1
+    rows[1]["ref_base"] = ord("a")
+    args = cli.parse_command_line("call_consensus --vcfFileName v.vcf --vcfAllPos --vcfRefName r.fa x.pileup")
+    counts = np.array(rows)
+    vcf_writer.write_all_positions_vcf(str(tmp_path / "v.vcf"), "s1", args, str(pile), np.array([1, 1 + len(b"c1\t5\tG\t2\t.A\tII\n")], dtype=np.uint64), counts)
+    data = [x for x in (tmp_path / "v.vcf").read_text().split("\n") if x and not x.startswith("#")]
+    assert data[0] == "c1\t5\t.\tG\tA\t.\tPASS\tNS=1\tGT:SDP:RD:AD:RDF:RDR:ADF:ADR:FT\t1:2:1:1:1:0:1:0:PASS"   # a tie ranks A before G: GT 1
+    assert data[1].startswith("long_contig_name_" + "x" * 300 + "\t77\t.\tA\t.\t.\tRawDpth\t")
