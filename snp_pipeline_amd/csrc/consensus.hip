@@ -424,7 +424,7 @@ struct LanesLds {
     uint8_t cls[256];           // byte -> rank of its symbol among "*ACGNT" (6: '.' / ',') | reverse << 3; 0xFF: other
 };
 
-template <int kWin, int kWords, int kWaves>
+template <int kWin, int kWords, int kWaves, bool kCounts>
 __global__ __launch_bounds__(kWaves * 64) void k_call_lanes(CallArgs a) {
     constexpr int LANES_WIN = kWin;               // bytes staged per site, from the 16-byte aligned address at or below the line start
     constexpr int LANES_STRIDE = kWin / 4 + 1;    // dwords between slots
@@ -808,6 +808,42 @@ __global__ __launch_bounds__(kWaves * 64) void k_call_lanes(CallArgs a) {
         if (valid && !punt) {
             a.out_base[site] = (uint8_t)((filters || cons == '*') ? '-' : cons);           // call_consensus.py:169-176
             a.out_filters[site] = (uint8_t)filters;
+            if (kCounts) {
+                // the per-site record (consensus.vcf): everything pileup.Record exposes, ranked by count descending, byte
+                // ascending (pileup.py:263-266) — the byte lanes are already in byte order: '*' A C G N T
+                const uint64_t tot = cnt_f + cnt_r;
+                uint32_t syms[2] = {0, 0}, tt[8], tf[8], tr[8], nsym = 0;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { tt[r] = 0; tf[r] = 0; tr[r] = 0; }
+                uint64_t left = tot;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    uint32_t n = 0, bk = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < 6; ++k) {
+                        const uint32_t tk = (uint32_t)(left >> (8 * k)) & 0xFFu;
+                        if (tk > n) { n = tk; bk = k; }
+                    }
+                    if (n != 0) {
+                        const uint32_t sym = bk == 0 ? '*' : bk == 1 ? 'A' : bk == 2 ? 'C' : bk == 3 ? 'G' : bk == 4 ? 'N' : 'T';
+                        syms[r >> 2] |= sym << (8 * (r & 3));
+                        tt[r] = n;
+                        tf[r] = (uint32_t)(cnt_f >> (8 * bk)) & 0xFFu;
+                        tr[r] = (uint32_t)(cnt_r >> (8 * bk)) & 0xFFu;
+                        left &= ~(0xFFull << (8 * bk));
+                        ++nsym;
+                    }
+                }
+                const uint32_t nfwd = __builtin_amdgcn_udot4((uint32_t)cnt_f, 0x01010101u, 0u, false) + __builtin_amdgcn_udot4((uint32_t)(cnt_f >> 32), 0x00000101u, 0u, false);
+                const uint32_t nrev = __builtin_amdgcn_udot4((uint32_t)cnt_r, 0x01010101u, 0u, false) + __builtin_amdgcn_udot4((uint32_t)(cnt_r >> 32), 0x00000101u, 0u, false);
+                uint4 *rec = (uint4 *)&a.out_counts[site];
+                const uint32_t st = has ? (uint32_t)SNPGPU_ST_OK : (uint32_t)SNPGPU_ST_NO_LINE;
+                rec[0] = make_uint4(has ? raw_depth : 0u, good, nfwd, nrev);
+                rec[1] = make_uint4(nsym, (has ? ref : 0u) | (cons << 8) | (filters << 16) | (st << 24), syms[0], syms[1]);
+                rec[2] = make_uint4(tt[0], tt[1], tt[2], tt[3]); rec[3] = make_uint4(tt[4], tt[5], tt[6], tt[7]);
+                rec[4] = make_uint4(tf[0], tf[1], tf[2], tf[3]); rec[5] = make_uint4(tf[4], tf[5], tf[6], tf[7]);
+                rec[6] = make_uint4(tr[0], tr[1], tr[2], tr[3]); rec[7] = make_uint4(tr[4], tr[5], tr[6], tr[7]);
+            }
         }
         // ---- leftovers: one atomic per wave ---------------------------------------------------------------------------
         const uint64_t pm = __ballot(punt);
@@ -853,21 +889,21 @@ int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleD
     ca.in_todo = nullptr;
     ca.in_todo_n = nullptr;
     hipEvent_t ta = snpgpu_time_begin(ctx);
-    if (d_out_counts) {
-        k_call_sites<<<grid, CALL_WAVES * 64, 0, st>>>(ca);      // per-site counts: the wave-per-site kernel does it all
-    } else {
+    {
         // one lane per site: a 256-byte window for every site, a 512-byte window for what that left (deeper pileups),
-        // then one wave per site for the rest
+        // then one wave per site for the rest; with per-site records (consensus.vcf) the same chain writes them too
         ca.todo = d_todo;
         ca.todo_n = d_todo_n;
         const uint64_t lblocks = ((n_work + 63) / 64 + 1) / 2, lmax = (uint64_t)ctx->n_cu * 8;
-        k_call_lanes<256, 2, 2><<<(unsigned)(lblocks < lmax ? lblocks : lmax), 128, 0, st>>>(ca);
+        const unsigned g1 = (unsigned)(lblocks < lmax ? lblocks : lmax);
+        if (d_out_counts) k_call_lanes<256, 2, 2, true><<<g1, 128, 0, st>>>(ca); else k_call_lanes<256, 2, 2, false><<<g1, 128, 0, st>>>(ca);
         ca.in_todo = d_todo;
         ca.in_todo_n = d_todo_n;
         ca.todo = d_todo2;
         ca.todo_n = d_todo_n + 1;
         const uint64_t l2blocks = (n_work + 63) / 64, l2max = (uint64_t)ctx->n_cu * 4;
-        k_call_lanes<512, 4, 1><<<(unsigned)(l2blocks < l2max ? l2blocks : l2max), 64, 0, st>>>(ca);
+        const unsigned g2 = (unsigned)(l2blocks < l2max ? l2blocks : l2max);
+        if (d_out_counts) k_call_lanes<512, 4, 1, true><<<g2, 64, 0, st>>>(ca); else k_call_lanes<512, 4, 1, false><<<g2, 64, 0, st>>>(ca);
         k_call_sites<<<grid, CALL_WAVES * 64, 0, st>>>(ca);
     }
     snpgpu_time_end(ctx, SNPGPU_K_CALL, ta);
@@ -906,7 +942,7 @@ static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const Sample
     const size_t ws_bytes = (snpgpu_scan_workspace_bytes(ctx, n) + 255) / 256 * 256;
     const size_t rows_bytes = d_site_line ? 0 : 8ull * n_sites * n;
     const size_t list_bytes = (8ull * n_sites * n + 255) / 256 * 256;
-    const size_t todo_bytes = d_out_counts ? 0 : 2 * list_bytes + 256;          // leftovers of the two lane kernels + their counts
+    const size_t todo_bytes = 2 * list_bytes + 256;                             // leftovers of the two lane kernels + their counts
     void *ws = nullptr;
     {
         int rc = snpgpu_scratch(ctx, ws_bytes + rows_bytes + todo_bytes + 256, &ws);
@@ -924,7 +960,7 @@ static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const Sample
         samples[i].status = io[i].d_status;
     }
     // the scan's prepare kernel also zeroes the line-offset rows and the two leftover counters of the lane kernels
-    int rc = snpgpu_enqueue_scan(ctx, ss, samples, ws, d_site_line, want_depth, d_out_counts ? nullptr : d_todo_n, d_out_counts ? 0 : 2);
+    int rc = snpgpu_enqueue_scan(ctx, ss, samples, ws, d_site_line, want_depth, d_todo_n, 2);
     if (rc) return rc;
     return snpgpu_enqueue_call(ctx, ss, (const SampleDev *)ws, n, prm, d_site_line, d_out_base, d_out_filters, d_out_counts,
                                d_todo_n, d_todo, d_todo2);

@@ -46,7 +46,14 @@ def main():
     base = min(ptrs)
     offs = np.array([p - base for p in ptrs], dtype=np.uint64)
 
+    counts = torch.empty(S * 128, dtype=torch.uint8, device="cuda") if os.environ.get("SNPGPU_TUNE_COUNTS") == "1" else None
+
     def run():
+        if counts is not None:                                  # the consensus.vcf path: per-site records
+            for i in range(B):
+                d.call_consensus_dev(ss, bufs[i].data_ptr(), sizes[i], prm, bases[i].data_ptr(), filt[i].data_ptr(), status[i].data_ptr(),
+                                     d_counts=counts.data_ptr())
+            return
         if batch:
             d.call_consensus_batch_dev(ss, base, offs, prm, bases.data_ptr(), filt.data_ptr(), status.data_ptr(), sizes=sizes)
             return
