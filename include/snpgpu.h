@@ -206,6 +206,17 @@ int  snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const
                                 uint64_t *out_line_off, uint8_t *out_line_flags, snpgpu_site_counts *out_counts,
                                 uint64_t *out_status);
 
+/* consensus.vcf data lines from per-site records — host-side text formatting, no device work, no context
+ * (vcf_writer.py:295-435: _make_vcf_record_from_pileup + the text PyVCF3's Writer emits for it).  Row r is the record
+ * counts[order[r]] (order == NULL: r) of site site_keys[order[r]] = (contig index << 32) | position, contig names as
+ * in snpgpu_siteset_create; filter_names: the six names in SNPGPU_F_* bit order; failed_snp_gt: '.', '0' or '1'.
+ * Writes at most `capacity` bytes to `out` (may be NULL) and returns the number of bytes the rows take; a record with
+ * more than SNPGPU_MAX_SYMS symbols is skipped and its row index left in *out_bad_row (else -1). */
+size_t snpgpu_format_vcf_rows(const snpgpu_site_counts *counts, const uint32_t *order, uint32_t n_rows,
+                              const uint8_t *contig_names, const uint32_t *contig_name_off, const uint64_t *site_keys,
+                              const char *const *filter_names, int preserve_ref_case, char failed_snp_gt,
+                              char *out, size_t capacity, int32_t *out_bad_row);
+
 /* After a call_consensus on `ss`: for every site, 1 + the byte offset of the pileup line that was used (0 = no
  * line).  consensus.vcf rows are written in pileup order (call_consensus.py:161-180), which this recovers.
  * out_line_off[n_sites] is a HOST pointer; synchronous. */

@@ -86,19 +86,42 @@ def row_from_counts(chrom, pos, c, filter_names, preserve_ref_case, failed_snp_g
     return "\t".join([chrom, str(pos), ".", ref, ",".join(alt) if alt else ".", ".", ft, "NS=1", FORMAT_IDS, data])
 
 
+def format_rows(counts, order, contig_names, contig_name_off, site_keys, filter_names, preserve_ref_case, failed_snp_gt):
+    """The data lines of ``order`` as one bytes object, formatted by the library (snpgpu_format_vcf_rows: the same layout as
+    row_from_counts, which stays as the readable statement of it and is tested against it row by row)."""
+    import ctypes as C
+    lib = L.load()
+    counts = np.ascontiguousarray(counts)
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    keys = np.ascontiguousarray(site_keys, dtype=np.uint64)
+    names = np.ascontiguousarray(contig_names, dtype=np.uint8)
+    offs = np.ascontiguousarray(contig_name_off, dtype=np.uint32)
+    fn = (C.c_char_p * 6)(*[n.encode("ascii") for n in filter_names])
+    bad = C.c_int32(-1)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)      # noqa: E731
+    gt = failed_snp_gt.encode("ascii")
+    need = lib.snpgpu_format_vcf_rows(ptr(counts), ptr(order), len(order), ptr(names), ptr(offs), ptr(keys), fn,
+                                      1 if preserve_ref_case else 0, gt, None, 0, C.byref(bad))
+    if bad.value >= 0:
+        slot = int(order[bad.value])
+        raise ValueError("site #%d has %d distinct symbols; the device record keeps %d" % (slot, int(counts[slot]["n_symbols"]), L.MAX_SYMS))
+    buf = C.create_string_buffer(max(int(need), 1))
+    lib.snpgpu_format_vcf_rows(ptr(counts), ptr(order), len(order), ptr(names), ptr(offs), ptr(keys), fn,
+                               1 if preserve_ref_case else 0, gt, buf, int(need), C.byref(bad))
+    return buf.raw[:int(need)]
+
+
 def write_consensus_vcf(path, sample_id, args, siteset, result, line_offsets):
     """Rows for every parsed position (snplist and exclude positions that have a pileup line), in pileup order."""
     filters = filter_descriptions(args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
     names = [n for n, _ in filters]
-    keys = siteset.key_tuples()
     have = np.nonzero(result.counts["status"] == L.ST_OK)[0]
     order = have[np.argsort(line_offsets[have], kind="stable")]
-    with open(path, "w") as f:
-        f.write("\n".join(header_lines(sample_id, filters, args.vcfRefName)) + "\n")
-        for slot in order:
-            chrom, pos = keys[int(slot)]
-            f.write(row_from_counts(chrom.decode("ascii"), pos, result.counts[int(slot)], names,
-                                    args.vcfPreserveRefCase, args.vcfFailedSnpGt) + "\n")
+    rows = format_rows(result.counts, order, siteset._names, siteset._offs, siteset.keys, names, args.vcfPreserveRefCase,
+                       args.vcfFailedSnpGt)
+    with open(path, "wb") as f:
+        f.write(("\n".join(header_lines(sample_id, filters, args.vcfRefName)) + "\n").encode("ascii"))
+        f.write(rows)
 
 
 def write_all_positions_vcf(path, sample_id, args, pileup_path, line_offsets, counts):

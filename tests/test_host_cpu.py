@@ -210,14 +210,17 @@ def test_consensus_vcf_rows_and_fasta_of_the_lambda_fixtures(fixture_trees):
             fasta = "".join(open(os.path.join(sdir, "consensus%s.fasta" % suffix)).read().split("\n")[1:])
             assert len(fasta) == len(snplist)
             called = {}
+            recs, rec_keys, rec_rows = [], [], []
             for row in lines:
                 if not row or row.startswith("#"):
                     continue
                 chrom, pos, c, ranked, ft, gt = _counts_from_vcf_row(row)
+                recs.append(c), rec_keys.append(pos), rec_rows.append(row)
                 mask = 0
                 for name in ([] if ft == "PASS" else ft.split(";")):
                     mask |= 1 << names.index(name)
                 c["filters"] = mask
+                recs[-1] = c
                 assert vcf_writer.row_from_counts(chrom, pos, c, names, False, ".") == row
                 rec = po.Record(chrom.encode(), pos, bytes([int(c["ref_base"])]), int(c["raw_depth"]), int(c["good_depth"]),
                                 int(c["fwd_good_depth"]), int(c["rev_good_depth"]),
@@ -230,6 +233,12 @@ def test_consensus_vcf_rows_and_fasta_of_the_lambda_fixtures(fixture_trees):
                 assert gt == ("." if (mask or not ranked) else ("0" if ranked[0] == chr(int(c["ref_base"])) else "1"))
                 called[(chrom, pos)] = "-" if (mask or not ranked or ranked[0] == "*") else ranked[0]
                 n_rows += 1
+            # ... and from the library's formatter (what the CLI writes), all rows of the file at once
+            import numpy as np
+            cname = np.frombuffer(chrom.encode(), dtype=np.uint8)
+            text = vcf_writer.format_rows(np.array(recs), np.arange(len(recs)), cname, np.array([0, len(cname)], dtype=np.uint32),
+                                          np.array(rec_keys, dtype=np.uint64), names, False, ".")
+            assert text.decode() == "".join(r + "\n" for r in rec_rows)
             want = "".join(called.get(key, "-") for key in snplist)
             assert want == fasta, (s, suffix)
             # consensus.vcf holds the snplist positions that have a pileup line; the preserved run adds the excluded ones
@@ -346,3 +355,44 @@ def test_call_consensus_batch_parser_and_all_positions_writer(tmp_path):
     data = [x for x in (tmp_path / "v.vcf").read_text().split("\n") if x and not x.startswith("#")]
     assert data[0] == "c1\t5\t.\tG\tA\t.\tPASS\tNS=1\tGT:SDP:RD:AD:RDF:RDR:ADF:ADR:FT\t1:2:1:1:1:0:1:0:PASS"   # a tie ranks A before G: GT 1
     assert data[1].startswith("long_contig_name_" + "x" * 300 + "\t77\t.\tA\t.\t.\tRawDpth\t")
+
+
+def test_library_vcf_formatter_equals_python_rows():
+    """snpgpu_format_vcf_rows against row_from_counts on random records: every GT option, both reference cases, 0 to 8
+    ranked symbols, every filter mask, multi-contig keys, a permuted row order."""
+    import random
+    import numpy as np
+    from snp_pipeline_amd import vcf_writer
+    from snp_pipeline_amd.device import COUNTS_DTYPE
+    rng = random.Random(5)
+    names = ["RawDpth", "VarFreq60", "Depth3", "StrDpth0", "StrBias0", "Region"]
+    contigs = [b"c", b"gi|9626243|ref|NC_001416.1|", b"NODE_1_length_419034_cov_23.1"]
+    cname = np.frombuffer(b"".join(contigs), dtype=np.uint8)
+    coff = np.cumsum([0] + [len(c) for c in contigs]).astype(np.uint32)
+    n = 400
+    recs = np.zeros(n, dtype=COUNTS_DTYPE)
+    keys = np.zeros(n, dtype=np.uint64)
+    for i in range(n):
+        c = recs[i]
+        k = rng.choice([0, 0, 1, 1, 2, 3, 6, 8])
+        syms = rng.sample(list(b"*ACGTN#<"), k)
+        tot = sorted((rng.randint(1, 300) for _ in range(k)), reverse=True)
+        c["ref_base"] = rng.choice(list(b"ACGTNacgtn"))
+        c["raw_depth"] = rng.randint(0, 100000)
+        c["good_depth"] = sum(tot)
+        c["n_symbols"] = k
+        c["filters"] = rng.randint(0, 63) if rng.random() < 0.5 else 0
+        for r in range(k):
+            f = rng.randint(0, tot[r])
+            c["sym"][r], c["total"][r], c["fwd"][r], c["rev"][r] = syms[r], tot[r], f, tot[r] - f
+        keys[i] = (rng.randrange(3) << 32) | rng.randint(0, 4_000_000_000)
+    order = np.array(rng.sample(range(n), n), dtype=np.uint32)
+    for gt in (".", "0", "1"):
+        for keep_case in (False, True):
+            text = vcf_writer.format_rows(recs, order, cname, coff, keys, names, keep_case, gt).decode()
+            want = "".join(vcf_writer.row_from_counts(contigs[int(keys[j]) >> 32].decode(), int(keys[j]) & 0xFFFFFFFF, recs[j], names, keep_case, gt) + "\n"
+                           for j in order)
+            assert text == want
+    recs[7]["n_symbols"] = 9
+    with pytest.raises(ValueError):
+        vcf_writer.format_rows(recs, order, cname, coff, keys, names, False, ".")
