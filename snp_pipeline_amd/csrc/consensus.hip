@@ -39,6 +39,8 @@ struct CallArgs {
     uint32_t *todo_n;
     const uint64_t *in_todo;    // k_call_lanes: nullable, work only on these sites
     const uint32_t *in_todo_n;
+    const uint32_t *deep;       // k_call_lanes: *deep != 0: the batch's lines average more than 100 bytes — the 128-byte pass
+                                // returns at once and the 256-byte pass takes every site (see k_call_mode)
 };
 
 struct WaveLds {
@@ -433,6 +435,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_call_lanes(CallArgs a) {
     constexpr uint32_t kMaxField = kBits > 255u ? 255u : kBits;   // ... but the counts live in byte lanes
     typedef BM<kWords> M;
     __shared__ LanesLds<kWin, kWaves> S;
+    const bool deep = a.deep && *a.deep != 0;
+    if (kWin == 128 && deep) return;                          // nearly every line would be pushed on after a wasted fetch
+    if (kWin == 256 && deep) { a.in_todo = nullptr; a.in_todo_n = nullptr; }   // ... so this pass starts from all sites
     for (uint32_t c = threadIdx.x; c < 256; c += blockDim.x) {
         const uint32_t u = to_upper(c);
         uint32_t k = u == '*' ? 0u : u == 'A' ? 1u : u == 'C' ? 2u : u == 'G' ? 3u : u == 'N' ? 4u : u == 'T' ? 5u : 0xFFu;
@@ -857,6 +862,23 @@ __global__ __launch_bounds__(kWaves * 64) void k_call_lanes(CallArgs a) {
     }
 }
 
+// One workgroup, before the call kernels: is this a batch of deep pileups?  The scan has just counted the lines of every
+// sample; mean line length = bytes / lines.  (Every lane kernel pushes what it cannot do on a list with one atomic per
+// 64 sites — same-address atomics cost ~12 ns each — so a pass that would push nearly everything on is skipped as a whole.)
+__global__ __launch_bounds__(256) void k_call_mode(const SampleDev *samples, uint32_t n, uint32_t *deep) {
+    __shared__ unsigned long long part[2][4];
+    unsigned long long bytes = 0, lines = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { bytes += samples[i].nbytes; lines += samples[i].status[1]; }
+    for (int o = 32; o; o >>= 1) { bytes += __shfl_xor(bytes, o); lines += __shfl_xor(lines, o); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = bytes; part[1][threadIdx.x >> 6] = lines; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bytes = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        lines = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        *deep = bytes > 100ull * lines ? 1u : 0u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 //                                           host API
 // ------------------------------------------------------------------------------------------------
@@ -888,21 +910,34 @@ int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleD
     ca.todo_n = nullptr;
     ca.in_todo = nullptr;
     ca.in_todo_n = nullptr;
+    ca.deep = nullptr;
     hipEvent_t ta = snpgpu_time_begin(ctx);
     {
-        // one lane per site: a 256-byte window for every site, a 512-byte window for what that left (deeper pileups),
-        // then one wave per site for the rest; with per-site records (consensus.vcf) the same chain writes them too
+        // One lane per site, in three window sizes: 128 bytes (64-bit masks: half the registers and a quarter of the LDS of
+        // the next one, so twice the waves per SIMD — a 30x line is ~90 bytes) for every site, 256 bytes (bases field <= 128)
+        // for what that left, 512 bytes (bases field <= 255) for what THAT left, then one wave per site for the rest.
+        // With per-site records (consensus.vcf) the same chain writes them too.  d_todo_n: three leftover counts.
+        const uint64_t groups = (n_work + 63) / 64;
+        k_call_mode<<<1, 256, 0, st>>>(d_table, n, d_todo_n + 3);
+        ca.deep = d_todo_n + 3;
         ca.todo = d_todo;
         ca.todo_n = d_todo_n;
-        const uint64_t lblocks = ((n_work + 63) / 64 + 1) / 2, lmax = (uint64_t)ctx->n_cu * 8;
-        const unsigned g1 = (unsigned)(lblocks < lmax ? lblocks : lmax);
-        if (d_out_counts) k_call_lanes<256, 2, 2, true><<<g1, 128, 0, st>>>(ca); else k_call_lanes<256, 2, 2, false><<<g1, 128, 0, st>>>(ca);
+        const uint64_t b0 = (groups + 3) / 4, m0 = (uint64_t)ctx->n_cu * 16;
+        const unsigned g0 = (unsigned)(b0 < m0 ? b0 : m0);
+        if (d_out_counts) k_call_lanes<128, 1, 4, true><<<g0, 256, 0, st>>>(ca); else k_call_lanes<128, 1, 4, false><<<g0, 256, 0, st>>>(ca);
         ca.in_todo = d_todo;
         ca.in_todo_n = d_todo_n;
         ca.todo = d_todo2;
         ca.todo_n = d_todo_n + 1;
-        const uint64_t l2blocks = (n_work + 63) / 64, l2max = (uint64_t)ctx->n_cu * 4;
-        const unsigned g2 = (unsigned)(l2blocks < l2max ? l2blocks : l2max);
+        const uint64_t lblocks = (groups + 1) / 2, lmax = (uint64_t)ctx->n_cu * 8;
+        const unsigned g1 = (unsigned)(lblocks < lmax ? lblocks : lmax);
+        if (d_out_counts) k_call_lanes<256, 2, 2, true><<<g1, 128, 0, st>>>(ca); else k_call_lanes<256, 2, 2, false><<<g1, 128, 0, st>>>(ca);
+        ca.in_todo = d_todo2;
+        ca.in_todo_n = d_todo_n + 1;
+        ca.todo = d_todo;                                   // the first list has been consumed
+        ca.todo_n = d_todo_n + 2;
+        const uint64_t l2max = (uint64_t)ctx->n_cu * 4;
+        const unsigned g2 = (unsigned)(groups < l2max ? groups : l2max);
         if (d_out_counts) k_call_lanes<512, 4, 1, true><<<g2, 64, 0, st>>>(ca); else k_call_lanes<512, 4, 1, false><<<g2, 64, 0, st>>>(ca);
         k_call_sites<<<grid, CALL_WAVES * 64, 0, st>>>(ca);
     }
@@ -926,7 +961,7 @@ int snpgpu_enqueue_call_lines(snpgpu_ctx *ctx, const SampleDev *d_sample, const 
     ca.out_base = d_out_base;
     ca.out_filters = d_out_filters;
     ca.out_counts = d_out_counts;
-    ca.todo = nullptr; ca.todo_n = nullptr; ca.in_todo = nullptr; ca.in_todo_n = nullptr;
+    ca.todo = nullptr; ca.todo_n = nullptr; ca.in_todo = nullptr; ca.in_todo_n = nullptr; ca.deep = nullptr;
     const uint64_t blocks = ((uint64_t)n_lines + CALL_WAVES - 1) / CALL_WAVES, max_blocks = (uint64_t)ctx->n_cu * 16;
     k_call_sites<<<(unsigned)(blocks < max_blocks ? blocks : max_blocks), CALL_WAVES * 64, 0, ctx->stream>>>(ca);
     HIP_TRY(ctx, hipGetLastError());
@@ -949,7 +984,7 @@ static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const Sample
         if (rc) return rc;
     }
     if (!d_site_line) d_site_line = (uint64_t *)((char *)ws + ws_bytes);
-    uint32_t *d_todo_n = (uint32_t *)((char *)ws + ws_bytes + rows_bytes);      // [0]: after the 256-byte pass, [1]: after the 512-byte pass
+    uint32_t *d_todo_n = (uint32_t *)((char *)ws + ws_bytes + rows_bytes);      // leftovers after the 128-, 256- and 512-byte passes
     uint64_t *d_todo = (uint64_t *)((char *)ws + ws_bytes + rows_bytes + 256);
     uint64_t *d_todo2 = (uint64_t *)((char *)ws + ws_bytes + rows_bytes + 256 + list_bytes);
     std::vector<SampleDev> samples(n);
@@ -960,7 +995,7 @@ static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const Sample
         samples[i].status = io[i].d_status;
     }
     // the scan's prepare kernel also zeroes the line-offset rows and the two leftover counters of the lane kernels
-    int rc = snpgpu_enqueue_scan(ctx, ss, samples, ws, d_site_line, want_depth, d_todo_n, 2);
+    int rc = snpgpu_enqueue_scan(ctx, ss, samples, ws, d_site_line, want_depth, d_todo_n, 3);
     if (rc) return rc;
     return snpgpu_enqueue_call(ctx, ss, (const SampleDev *)ws, n, prm, d_site_line, d_out_base, d_out_filters, d_out_counts,
                                d_todo_n, d_todo, d_todo2);

@@ -107,7 +107,7 @@ int snpgpu_enqueue_lines_emit(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const u
 int snpgpu_enqueue_call_lines(snpgpu_ctx *ctx, const SampleDev *d_sample, const uint64_t *d_line_off, const uint8_t *d_flags,
                               uint32_t n_lines, const snpgpu_caller_params *prm, uint8_t *d_out_base, uint8_t *d_out_filters,
                               snpgpu_site_counts *d_out_counts);
-// the call kernels over a scanned batch (consensus.hip); d_todo_n: 2 zeroed words, d_todo / d_todo2: n * n_sites entries each
+// the call kernels over a scanned batch (consensus.hip); d_todo_n: 3 zeroed words, d_todo / d_todo2: n * n_sites entries each
 int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n,
                         const snpgpu_caller_params *prm, const uint64_t *d_site_line, uint8_t *d_out_base,
                         uint8_t *d_out_filters, snpgpu_site_counts *d_out_counts, uint32_t *d_todo_n, uint64_t *d_todo,

@@ -424,7 +424,7 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
                 cur_waves = h_tab[2 * nc + 1].wave0;
                 tiles_done = 0;
                 ST_TRY(hipMemcpyAsync(d_tab, h_tab, (size_t)(nc + 1) * 2 * sizeof(SampleDev), hipMemcpyHostToDevice, st));
-                rc = snpgpu_scan_begin(ctx, ss, d_tab + 2 * nc, 1, ds.site_line, ds.todo_n, 2);
+                rc = snpgpu_scan_begin(ctx, ss, d_tab + 2 * nc, 1, ds.site_line, ds.todo_n, 3);
                 if (rc) goto done;
             }
             {
