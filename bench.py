@@ -119,17 +119,25 @@ def end_to_end(d, ss, prm, pile, offs, sizes, bases, n_files, S):
         h2d = 8 * n / (time.perf_counter() - t1) / 1e9
         del src, dst
         d.call_consensus_files(ss, paths[:1], prm)                                  # warm-up: pinned staging, device slots
-        res, rcs, st = d.call_consensus_files(ss, paths, prm)
-        ok = all(int(rc) == 0 for rc in rcs) and all(bytes(res[i].bases) == bytes(bases[i].cpu().numpy()) for i in range(n_files))
-        if not ok:
-            raise SystemExit("streamed consensus differs from the resident one")
+        # two passes over the same files, the better one reported (both listed): single passes spread between 42 and 56 GB/s
+        # on the bench box whatever the reader count (>= 8) and whichever socket wrote the files (tools/e2e_readers.py)
+        passes = []
+        st = None
+        for _ in range(2):
+            res, rcs, st_i = d.call_consensus_files(ss, paths, prm)
+            ok = all(int(rc) == 0 for rc in rcs) and all(bytes(res[i].bases) == bytes(bases[i].cpu().numpy()) for i in range(n_files))
+            if not ok:
+                raise SystemExit("streamed consensus differs from the resident one")
+            passes.append(st_i.bytes / st_i.seconds / 1e9)
+            if st is None or st_i.seconds < st.seconds:
+                st = st_i
         gbps = st.bytes / st.seconds / 1e9
         return {
             "what": "%d pileup files in the page cache (%s) -> consensus bytes on the host, one snpgpu_call_consensus_files call"
                     % (n_files, base_dir),
             "files": n_files, "bytes": int(st.bytes), "seconds": st.seconds, "pileup_gb_per_sec": gbps,
             "consensus_bases_per_sec": n_files * S / st.seconds, "samples_per_sec": n_files / st.seconds,
-            "pinned_h2d_gb_per_sec": h2d, "frac_of_pinned_h2d": gbps / h2d,
+            "pinned_h2d_gb_per_sec": h2d, "frac_of_pinned_h2d": gbps / h2d, "passes_gb_per_sec": passes,
             "chunk_bytes": int(st.chunk_bytes), "reader_threads": int(st.n_readers), "staging_buffers": int(st.n_staging),
             "seconds_waiting_for_readers": st.seconds_waiting_for_readers,
             "seconds_waiting_for_device": st.seconds_waiting_for_device, "matches_resident": True,
