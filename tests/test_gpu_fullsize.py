@@ -114,6 +114,22 @@ def test_configs3_shard_125_and_grouped_batch_300(d):
     d.call_consensus_batch_dev(ss, pile.data_ptr(), offs[:125], prm, b125.data_ptr(), f125.data_ptr(), s125.data_ptr(), sizes=sizes_np[:125])
     torch.cuda.synchronize()
     assert torch.equal(b125, bases[:125]) and torch.equal(f125, filt[:125]) and s125.cpu().numpy().tolist() == st[:125].tolist()
+    # two of the samples as FILES through the streamed ingestion (432 MB each: 26 chunks of 16 MiB, two device slots)
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="snpfull_") as tmp:
+        paths = []
+        for i in (3, 299):
+            path = os.path.join(tmp, "s%d.pileup" % i)
+            with open(path, "wb") as fh:
+                fh.write(pile[int(offs[i]):int(offs[i]) + sizes[i]].cpu().numpy().tobytes())
+            paths.append(path)
+        results, rcs, stats = d.call_consensus_files(ss, paths, prm, want_line_offsets=True)
+        assert list(rcs) == [0, 0] and stats.bytes == sizes[3] + sizes[299] and stats.n_chunks >= 50
+        for r, i in zip(results, (3, 299)):
+            assert bytes(r.bases) == bytes(bases[i].cpu().numpy()) and bytes(r.filters) == bytes(filt[i].cpu().numpy())
+            assert r.status.astype(np.int64).tolist() == st[i].tolist()
+            assert int(np.count_nonzero(r.line_offsets)) == int(st[i, 2])
     # single-sample calls around the group boundary and at the ends; the oracle on the lines the device picked
     for i in (0, 124, 255, 256, 257, 299):
         b1 = torch.zeros(S, dtype=torch.uint8, device="cuda")
