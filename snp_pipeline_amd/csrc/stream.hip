@@ -350,14 +350,28 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
     }
     hipStream_t st = ctx->stream;
     // whatever the caller enqueued before on the compute stream is done before the slots are overwritten
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    {
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            for (auto &s2 : src) if (s2.fd >= 0) { close(s2.fd); s2.fd = -1; }
+            return snpgpu_set_error(ctx, SNPGPU_E_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+        }
+    }
 
     Shared sh;
     sh.R = R;
     sh.filled.assign(J, 0);
     sh.job_err.assign(J, 0);
     std::vector<std::thread> readers;
-    for (uint32_t i = 0; i < n_readers; ++i) readers.emplace_back(reader_main, ctx, &sh, &jobs, &src);
+    try {
+        for (uint32_t i = 0; i < n_readers; ++i) readers.emplace_back(reader_main, ctx, &sh, &jobs, &src);
+    } catch (const std::exception &e) {                      // no thread to be had: nothing has been enqueued yet
+        { std::lock_guard<std::mutex> lk(sh.mu); sh.abort = true; sh.next.store(J); }
+        sh.cv.notify_all();
+        for (auto &t : readers) t.join();
+        for (auto &s2 : src) if (s2.fd >= 0) { close(s2.fd); s2.fd = -1; }
+        return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "cannot start the reader threads: %s", e.what());
+    }
 
     int rc = SNPGPU_OK;
     double t_wait_read = 0, t_wait_gpu = 0, t_enqueue = 0;
