@@ -305,14 +305,18 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     // request tile tt into slot `buf`; returns the number of DMA wave-instructions now in flight for it (0: staged synchronously)
     auto request = [&](uint64_t tt, int buf) -> uint32_t {
         if (interior(tt)) {
-            const uint8_t *g = f.base + tt * SCAN_TILE - 16 + (size_t)lane * 16;
+            // scalar base + per-lane 32-bit offset (lane * 16, the same for every tile) + immediate: no vector address
+            // arithmetic per tile; the tile's base address lives in an SGPR pair
+            const uint8_t *gs = f.base + tt * SCAN_TILE - 16;
+            const uint32_t voff = lane * 16u;
             const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)&ws.slot[buf][0]);
 #pragma unroll
             for (int r = 0; r < SCAN_DMA_PER_TILE; ++r) {
-                const uint8_t *gp = g + (size_t)r * 1024;                 // chunk r*64 + lane of the slot
-                const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + r * 1024);
+                // (the immediate offset — 12 bits — moves the global AND the LDS address; M0 carries the rest)
+                const uint8_t *gr = gs + (r >= 4 ? 4096 : 0);
+                const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (r >= 4 ? 4096 : 0));
                 if (r * 64 + lane < SCAN_WTILE_CHUNKS)                     // the last instruction has a partial exec mask
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m0v) : "memory");
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(gr), "s"(m0v), "n"((r & 3) * 1024) : "memory");
             }
             return SCAN_DMA_PER_TILE;
         }
