@@ -313,7 +313,10 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
 #pragma unroll
             for (int r = 0; r < SCAN_DMA_PER_TILE; ++r) {
                 // (the immediate offset — 12 bits — moves the global AND the LDS address; M0 carries the rest)
-                const uint8_t *gr = gs + (r >= 4 ? 4096 : 0);
+                const uint64_t ga = (uint64_t)(uintptr_t)gs + (r >= 4 ? 4096u : 0u);
+                // (wave-uniform by construction; the readfirstlane pair makes that a fact for the "s" constraint)
+                const uint64_t gr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ga >> 32)) << 32) |
+                                    (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ga);      // (the builtin returns int)
                 const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (r >= 4 ? 4096 : 0));
                 if (r * 64 + lane < SCAN_WTILE_CHUNKS)                     // the last instruction has a partial exec mask
                     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(gr), "s"(m0v), "n"((r & 3) * 1024) : "memory");
