@@ -34,7 +34,7 @@ extern "C" {
 #define SNPGPU_E_NOMEM      -3
 #define SNPGPU_E_PILEUP     -4   /* malformed pileup text; see snpgpu_scan_status */
 #define SNPGPU_E_UNSUPPORTED -5  /* input the reference accepts but this build refuses (reported loudly) */
-#define SNPGPU_E_IO         -6   /* a pileup file could not be opened or read */
+#define SNPGPU_E_IO         -6   /* a file could not be opened, read or written */
 
 /* ---- failed-filter bits, in the order pileup.py:564-584 appends them and
  *      call_consensus.py:165-168 appends "Region" ------------------------- */
@@ -238,6 +238,16 @@ int  snpgpu_distance_packed_dev(snpgpu_ctx *ctx, const void *d_packed, uint32_t 
                                 uint32_t tile_rank, uint32_t tile_nranks, int32_t *d_out);
 /* Host form: symbols is n_rows x n_sites bytes (row-major, the sequences of snpma.fasta); out is n x n int32. */
 int  snpgpu_distance(snpgpu_ctx *ctx, const uint8_t *symbols, uint32_t n_rows, uint32_t n_sites, int32_t *out);
+
+/* The two text layouts of the distance step, written straight to `path` (host code, no device work): replaces the print
+ * loops of distance.py:100-105 (SNPGPU_TSV_PAIRWISE: "Seq1\tSeq2\tDistance" header, one line per ordered pair, the
+ * diagonal included) and distance.py:107-114 (SNPGPU_TSV_MATRIX: header "\t" + ids, one row per id).  ids: the names
+ * back to back, name i = ids[id_off[i], id_off[i+1]); matrix: HOST int32, row i at matrix + i * row_stride.
+ * SNPGPU_E_IO when the file cannot be created or written. */
+#define SNPGPU_TSV_PAIRWISE 0
+#define SNPGPU_TSV_MATRIX   1
+int  snpgpu_write_distance_tsv(const char *path, int layout, const char *ids, const uint64_t *id_off, uint32_t n,
+                               const int32_t *matrix, uint64_t row_stride);
 
 /* ---- filter_regions: find_dense_regions (filter_regions.py:17-71) + utils.merge_regions
  *      (utils.py:1267-1282) + utils.in_region (utils.py:1314-1318); merge_sites (merge_sites.py:91-117) ---------

@@ -82,6 +82,7 @@ SIGNATURES = {
     "snpgpu_pack_matrix_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_size_t, _P]),
     "snpgpu_distance_packed_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     "snpgpu_distance": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P]),
+    "snpgpu_write_distance_tsv": (C.c_int, [C.c_char_p, C.c_int, _P, _P, C.c_uint32, _P, C.c_uint64]),
     "snpgpu_dense_windows": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_uint32)]),
     "snpgpu_merge_regions": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_uint32)]),
     "snpgpu_in_regions": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, _P, C.c_uint32, _P]),

@@ -396,3 +396,54 @@ def test_library_vcf_formatter_equals_python_rows():
     recs[7]["n_symbols"] = 9
     with pytest.raises(ValueError):
         vcf_writer.format_rows(recs, order, cname, coff, keys, names, False, ".")
+
+
+def test_library_distance_tsv_writer_equals_reference_layout(tmp_path, fixture_trees):
+    """csrc/tsv_out.hip against the print loops of distance.py:100-114 written out in Python, and against the bundled
+    snp_distance_*.tsv of the lambda fixture (matrix values parsed back from the pairwise file)."""
+    import numpy as np
+    from snp_pipeline_amd import distance
+
+    def py_pairwise(path, ids, mat):
+        with open(path, "w") as out:
+            out.write("%s\n" % "\t".join(["Seq1", "Seq2", "Distance"]))
+            for i, id1 in enumerate(ids):
+                for j, id2 in enumerate(ids):
+                    out.write("%s\t%s\t%i\n" % (id1, id2, mat[i][j]))
+
+    def py_matrix(path, ids, mat):
+        with open(path, "w") as out:
+            out.write("\t%s\n" % "\t".join(ids))
+            for i, id1 in enumerate(ids):
+                out.write("%s\t%s\n" % (id1, "\t".join(map(str, [int(x) for x in mat[i]]))))
+
+    a, b = str(tmp_path / "a.tsv"), str(tmp_path / "b.tsv")
+    for n in (0, 1, 3, 150):
+        ids = ["S%d_é" % i if i % 7 == 3 else "sample%d" % i for i in range(n)]
+        mat = np.random.default_rng(n).integers(0, 2 ** 31 - 1, size=(n, n), dtype=np.int32) if n else np.zeros((0, 0), dtype=np.int32)
+        if n > 1:
+            mat[0, 1], mat[1, 0] = 0, -5
+        for ours, theirs in ((distance.write_pairwise, py_pairwise), (distance.write_matrix, py_matrix)):
+            ours(a, ids, mat)
+            theirs(b, ids, mat)
+            assert open(a, "rb").read() == open(b, "rb").read(), (n, ours.__name__)
+    # a name longer than the writer's buffer, and a strided view of a larger matrix
+    ids = ["x" * (5 << 20), "y"]
+    big = np.arange(16, dtype=np.int32).reshape(4, 4)
+    distance.write_matrix(a, ids, big[:2, :2])
+    py_matrix(b, ids, big[:2, :2])
+    assert open(a, "rb").read() == open(b, "rb").read()
+    with pytest.raises(IOError):
+        distance.write_pairwise(str(tmp_path / "no_such_dir" / "p.tsv"), ["a"], np.zeros((1, 1), dtype=np.int32))
+    # the bundled files: ids and values from the pairwise fixture reproduce both fixture files byte for byte
+    tree, _ = fixture_trees["lambdaVirus"]
+    want_p = open(os.path.join(tree, "snp_distance_pairwise.tsv"), "rb").read()
+    want_m = open(os.path.join(tree, "snp_distance_matrix.tsv"), "rb").read()
+    rows = [ln.split("\t") for ln in want_p.decode().splitlines()[1:]]
+    ids = sorted({r[0] for r in rows})
+    mat = np.zeros((len(ids), len(ids)), dtype=np.int32)
+    for s1, s2, v in rows:
+        mat[ids.index(s1), ids.index(s2)] = int(v)
+    distance.write_pairwise(a, ids, mat)
+    distance.write_matrix(b, ids, mat)
+    assert open(a, "rb").read() == want_p and open(b, "rb").read() == want_m
