@@ -206,6 +206,38 @@ int  snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const
                                 uint64_t *out_line_off, uint8_t *out_line_flags, snpgpu_site_counts *out_counts,
                                 uint64_t *out_status);
 
+/* ---- phase-1 site calling: the counting + selection half of `VarScan mpileup2snp` -------------------------------
+ * Replaces what call_sites.py:89-108 gets from the VarScan v2.3.9 jar (a third-party dependency that is not in the
+ * reference tree): VarScan.qualityDepth, VarScan.getReadCounts and the min-coverage / min-reads2 / min-avg-qual /
+ * min-var-freq tests of VarScan.callPosition, for every line of a one-sample pileup.  Each (line, allele) that passes
+ * leaves one record; Fisher's exact test, --p-value, the strand filter and the VCF text are host work on those
+ * records (snp_pipeline_amd/varscan.py). */
+typedef struct snpgpu_varscan_params {
+    uint32_t min_coverage;          /* --min-coverage, default 8: raw depth AND qualities >= min_avg_qual */
+    uint32_t min_reads2;            /* --min-reads2, default 2 (the pipeline passes 5) */
+    uint32_t min_avg_qual;          /* --min-avg-qual, default 15 */
+    uint32_t reserved;
+    double   min_var_freq;          /* --min-var-freq, default 0.20 (the pipeline passes 0.90) */
+} snpgpu_varscan_params;
+typedef struct snpgpu_varscan_site {
+    uint64_t line_off;              /* byte offset of the pileup line in the file (chrom / position text are read there) */
+    uint32_t sdp;                   /* depth column */
+    uint32_t dp;                    /* qualities >= min_avg_qual */
+    uint32_t total;                 /* reads over all alleles at that quality + indel-carrying reads: FREQ's denominator */
+    uint32_t rdf, rdr, ref_qual_sum;/* '.' / ',' at that quality, and the sum of their qualities */
+    uint32_t adf, adr, alt_qual_sum;/* the same for alt_base */
+    uint8_t  ref_base, alt_base;    /* upper case */
+    uint8_t  reserved[2];
+} snpgpu_varscan_site;
+/* path -> records in file order (ties: allele A < C < G < T).  Streams the file to the device, indexes its lines, runs
+ * the kernel, copies the records back; synchronous.  *out_n_sites is the number of records found; when it exceeds
+ * `capacity` only `capacity` arbitrary ones were written and the caller comes back with a larger array.
+ * out_status[2]: [0] byte offset of the first malformed line (fewer than six non-empty TAB-separated columns, a depth
+ * that is not a plain integer, a reference column longer than one byte) else UINT64_MAX — the call then returns
+ * SNPGPU_E_PILEUP; [1] lines in the file.  SNPGPU_E_IO when the file cannot be read. */
+int  snpgpu_varscan_file(snpgpu_ctx *ctx, const char *path, const snpgpu_varscan_params *params, uint32_t capacity,
+                         snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status);
+
 /* consensus.vcf data lines from per-site records — host-side text formatting, no device work, no context
  * (vcf_writer.py:295-435: _make_vcf_record_from_pileup + the text PyVCF3's Writer emits for it).  Row r is the record
  * counts[order[r]] (order == NULL: r) of site site_keys[order[r]] = (contig index << 32) | position, contig names as

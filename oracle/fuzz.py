@@ -155,3 +155,61 @@ def odd_depth_lines(seed, eol=b"\n", n=4000):
         else:
             lines.append(b"c9\t%d\tA\t%d" % (pos, depth))
     return eol.join(lines) + eol
+
+
+def varscan_pileup(seed, n_lines=3000, contigs=("ctgA", "ctg_B|2"), eol=b"\n"):
+    """A TAB-separated one-sample pileup for the phase-1 site caller: mostly reference-matching columns of depth 0..80,
+    every ~12th line a variant column (one dominant alternate allele at 60..100 %, sometimes a second one, strands from
+    balanced to one-sided), with indels, read starts / ends, N, '*', low qualities, depth-0 lines ("*\\t*"), qualities
+    shorter or longer than the bases, a seventh column now and then."""
+    rng = random.Random(seed)
+    out = []
+    pos = 0
+    for k in range(n_lines):
+        chrom = contigs[0] if k < n_lines // 2 else contigs[-1]
+        pos += rng.choice((1, 1, 1, 1, 2, 17))
+        ref = rng.choice("ACGTacgtN")
+        depth = rng.choice((0, 0, 3, 7, 8, 9, 12, 20, 30, 30, 45, 80))
+        if depth == 0:
+            out.append(("%s\t%d\t%s\t0\t*\t*" % (chrom, pos, ref)).encode())
+            continue
+        variant = rng.random() < 0.085
+        alt = rng.choice([b for b in "ACGT" if b != ref.upper()])
+        alt2 = rng.choice([b for b in "ACGT" if b not in (ref.upper(), alt)])
+        frac = rng.choice((0.55, 0.8, 0.88, 0.9, 0.93, 1.0, 1.0)) if variant else 0.02
+        fwd_p = rng.choice((0.0, 0.05, 0.5, 0.5, 0.5, 0.95, 1.0))
+        var_fwd_p = rng.choice((fwd_p, fwd_p, 0.0, 0.04, 0.97, 1.0))
+        toks, quals = [], []
+        for _ in range(depth):
+            r = rng.random()
+            fwd = rng.random() < (var_fwd_p if r < frac else fwd_p)
+            if r < frac:
+                b = alt if fwd else alt.lower()
+            elif r < frac + 0.03:
+                b = alt2 if fwd else alt2.lower()
+            elif r < frac + 0.05:
+                b = rng.choice("Nn*")
+            else:
+                b = "." if fwd else ","
+            t = b
+            r = rng.random()
+            if r < 0.04:
+                t = "^" + chr(rng.randint(33, 126)) + t
+            elif r < 0.08:
+                t = t + "$"
+            elif r < 0.12 and b != "*":
+                n = rng.choice((1, 1, 2, 3, 11))
+                t = t + rng.choice("+-") + str(n) + "".join(rng.choice("ACGTN" if fwd else "acgtn") for _ in range(n))
+            toks.append(t)
+            quals.append(chr(33 + (rng.randint(0, 14) if rng.random() < 0.12 else rng.randint(15, 41))))
+        q = "".join(quals)
+        r = rng.random()
+        if r < 0.01:
+            q = q[:-1]
+        elif r < 0.02:
+            q = q + "I"
+        line = "%s\t%d\t%s\t%d\t%s\t%s" % (chrom, pos, ref, depth, "".join(toks), q)
+        if rng.random() < 0.02:
+            line += "\t" + "]" * depth
+        out.append(line.encode())
+    return eol.join(out) + (eol if rng.random() < 0.5 else b"")

@@ -48,7 +48,19 @@ class StreamStats(C.Structure):
                 ("reader_seconds_waiting", C.c_double), ("seconds_enqueueing", C.c_double)]
 
 
-assert C.sizeof(SiteCounts) == 128 and C.sizeof(CallerParams) == 32
+class VarscanParams(C.Structure):
+    _fields_ = [("min_coverage", C.c_uint32), ("min_reads2", C.c_uint32), ("min_avg_qual", C.c_uint32),
+                ("reserved", C.c_uint32), ("min_var_freq", C.c_double)]
+
+
+class VarscanSite(C.Structure):
+    _fields_ = [("line_off", C.c_uint64), ("sdp", C.c_uint32), ("dp", C.c_uint32), ("total", C.c_uint32),
+                ("rdf", C.c_uint32), ("rdr", C.c_uint32), ("ref_qual_sum", C.c_uint32),
+                ("adf", C.c_uint32), ("adr", C.c_uint32), ("alt_qual_sum", C.c_uint32),
+                ("ref_base", C.c_uint8), ("alt_base", C.c_uint8), ("reserved", C.c_uint8 * 2)]
+
+
+assert C.sizeof(SiteCounts) == 128 and C.sizeof(CallerParams) == 32 and C.sizeof(VarscanSite) == 48 and C.sizeof(VarscanParams) == 24
 
 # name -> (restype, argtypes); every exported symbol of include/snpgpu.h
 _P = C.c_void_p
@@ -82,6 +94,7 @@ SIGNATURES = {
     "snpgpu_pack_matrix_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_size_t, _P]),
     "snpgpu_distance_packed_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     "snpgpu_distance": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P]),
+    "snpgpu_varscan_file": (C.c_int, [_P, C.c_char_p, _P, C.c_uint32, _P, C.POINTER(C.c_uint32), _P]),
     "snpgpu_write_distance_tsv": (C.c_int, [C.c_char_p, C.c_int, _P, _P, C.c_uint32, _P, C.c_uint64]),
     "snpgpu_dense_windows": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_uint32)]),
     "snpgpu_merge_regions": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_uint32)]),

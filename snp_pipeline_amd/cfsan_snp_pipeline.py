@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """``cfsan_snp_pipeline`` console entry for the post-alignment subcommands on MI355X.
 
-Mirrors the argparse surface of snppipeline/cfsan_snp_pipeline.py for filter_regions (:309-324, list validation
+Mirrors the argparse surface of snppipeline/cfsan_snp_pipeline.py for call_sites (:294-304), filter_regions (:309-324, list validation
 :530-543), merge_sites (:329-340), call_consensus (:345-410), snp_matrix (:429-443), distance (:448-457) and snp_reference (:460-471): same
 flags, defaults, type validators, per-subcommand exception hook, exit codes and "finished" banner, plus the
 python-level helpers the reference's unit tests use (parse_command_line, parse_argument_list,
@@ -13,10 +13,10 @@ from __future__ import absolute_import
 import argparse
 import sys
 
-from . import call_consensus, distance, filter_regions, merge_sites, snp_matrix, snp_reference, utils
+from . import call_consensus, call_sites, distance, filter_regions, merge_sites, snp_matrix, snp_reference, utils
 from .utils import __version__, verbose_print
 
-NOT_PROVIDED = ("run", "data", "index_ref", "map_reads", "call_sites", "merge_vcfs",
+NOT_PROVIDED = ("run", "data", "index_ref", "map_reads", "merge_vcfs",
                 "collect_metrics", "combine_metrics", "purge")
 
 
@@ -57,6 +57,14 @@ def parse_argument_list(argv):
     parser.add_argument("--version", action="version", version="%(prog)s version " + __version__)
     subparsers = parser.add_subparsers(dest="subparser_name", help=None, metavar="subcommand       ")
     subparsers.required = True
+
+    sub = subparsers.add_parser("call_sites", help="Find the sites with high-confidence SNPs in a sample", formatter_class=fmt,
+                                description="Find the sites with high-confidence SNPs in a sample.")
+    sub.add_argument(dest="referenceFile", type=str, help="Relative or absolute path to the reference fasta file")
+    sub.add_argument(dest="sampleDir", type=str, help="Relative or absolute directory of the sample")
+    sub.add_argument("-f", "--force", dest="forceFlag", action="store_true", help="Force processing even when result files already exist and are newer than inputs")
+    _common(sub)
+    sub.set_defaults(func=call_sites.call_sites, excepthook=utils.handle_sample_exception)
 
     sub = subparsers.add_parser("filter_regions", help="Remove abnormally dense SNPs from all samples", formatter_class=fmt,
                                 description="Remove abnormally dense SNPs from the input VCF file, save the reserved SNPs into a new VCF file, and save the removed SNPs into another VCF file.")

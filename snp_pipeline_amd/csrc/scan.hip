@@ -925,6 +925,14 @@ int snpgpu_enqueue_lines_emit(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const u
     return SNPGPU_OK;
 }
 
+// the offsets alone
+int snpgpu_enqueue_lines_offsets(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, uint32_t *ws, uint64_t *d_line_off, uint64_t n_lines) {
+    const uint64_t nb = (nbytes + LINES_BLOCK - 1) / LINES_BLOCK;
+    if (nb) k_lines_index<true><<<(unsigned)nb, LINES_THREADS, 0, ctx->stream>>>(d_buf, nbytes, ws, d_line_off, n_lines);
+    HIP_TRY(ctx, hipGetLastError());
+    return SNPGPU_OK;
+}
+
 size_t snpgpu_scan_totals_bytes(const snpgpu_ctx *ctx) { return 3 * 8 * (size_t)ctx->n_cu * 2 * 16 + 256; }
 size_t snpgpu_scan_workspace_bytes(const snpgpu_ctx *ctx, uint32_t n_samples) {
     return ((size_t)(n_samples + 1) * sizeof(SampleDev) + 255) / 256 * 256 + snpgpu_scan_totals_bytes(ctx);

@@ -31,6 +31,8 @@
 #include <thread>
 #include <vector>
 
+#include <algorithm>
+
 #include "internal.h"
 
 namespace {
@@ -667,6 +669,66 @@ int snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const 
     HIP_TRY(ctx, hipStreamSynchronize(st));
     out_status[1] = n_lines;
     if (out_status[0] != ~0ull) return scan_status_error(ctx, out_status, path);
+    return SNPGPU_OK;
+}
+
+// Phase-1 site calling over a pileup file: load, index the lines, count + select on the device (varscan.hip), records back in
+// file order.
+int snpgpu_varscan_file(snpgpu_ctx *ctx, const char *path, const snpgpu_varscan_params *params, uint32_t capacity,
+                        snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status) {
+    if (!ctx || !path || !params || !out_n_sites || !out_status) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (capacity && !out_sites) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint8_t *d_file = nullptr;
+    uint64_t nbytes = 0;
+    int rc = load_file(ctx, path, &d_file, &nbytes);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    const size_t ws_words = snpgpu_lines_workspace_words(nbytes);
+    void *scr = nullptr;
+    rc = snpgpu_scratch(ctx, up(4 * ws_words, 256) + 512, &scr);
+    if (rc) return rc;
+    uint32_t *d_total = nullptr;
+    rc = snpgpu_enqueue_lines_count(ctx, d_file, nbytes, (uint32_t *)scr, &d_total);
+    if (rc) return rc;
+    uint32_t n_lines = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n_lines, d_total, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    *out_n_sites = 0;
+    out_status[0] = ~0ull; out_status[1] = n_lines;
+    if (n_lines == 0) return SNPGPU_OK;
+    size_t o = up(4 * ws_words, 256);
+    const size_t o_off = o; o += up(8ull * n_lines, 256);
+    const size_t o_ctl = o; o += 256;                          // [0] u64 status, [8] u32 record count
+    const size_t o_rec = o; o += sizeof(snpgpu_varscan_site) * (size_t)capacity;
+    rc = snpgpu_scratch(ctx, o + 256, &scr);
+    if (rc) return rc;
+    char *b = (char *)scr;
+    rc = snpgpu_enqueue_lines_count(ctx, d_file, nbytes, (uint32_t *)b, &d_total);       // the scratch may have moved
+    if (rc) return rc;
+    rc = snpgpu_enqueue_lines_offsets(ctx, d_file, nbytes, (uint32_t *)b, (uint64_t *)(b + o_off), n_lines);
+    if (rc) return rc;
+    uint64_t h_ctl[2] = {~0ull, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(b + o_ctl, h_ctl, sizeof h_ctl, hipMemcpyHostToDevice, st));
+    rc = snpgpu_enqueue_varscan(ctx, d_file, nbytes, (const uint64_t *)(b + o_off), n_lines, params, (snpgpu_varscan_site *)(b + o_rec), capacity,
+                                (uint32_t *)(b + o_ctl + 8), (uint64_t *)(b + o_ctl));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(h_ctl, b + o_ctl, sizeof h_ctl, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    out_status[0] = h_ctl[0];
+    const uint32_t found = (uint32_t)h_ctl[1];
+    *out_n_sites = found;
+    if (h_ctl[0] != ~0ull)
+        return snpgpu_set_error(ctx, SNPGPU_E_PILEUP, "malformed pileup line at byte %llu of %s", (unsigned long long)h_ctl[0], path);
+    const uint32_t got = found < capacity ? found : capacity;
+    if (got) {
+        HIP_TRY(ctx, hipMemcpyAsync(out_sites, b + o_rec, sizeof(snpgpu_varscan_site) * (size_t)got, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (found <= capacity)
+            std::sort(out_sites, out_sites + got, [](const snpgpu_varscan_site &x, const snpgpu_varscan_site &y) {
+                return x.line_off != y.line_off ? x.line_off < y.line_off : x.alt_base < y.alt_base;
+            });
+    }
     return SNPGPU_OK;
 }
 

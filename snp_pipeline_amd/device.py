@@ -17,6 +17,10 @@ COUNTS_DTYPE = np.dtype([
     ("sym", "u1", (L.MAX_SYMS,)), ("total", "<u4", (L.MAX_SYMS,)), ("fwd", "<u4", (L.MAX_SYMS,)),
     ("rev", "<u4", (L.MAX_SYMS,))])
 assert COUNTS_DTYPE.itemsize == 128
+VARSCAN_DTYPE = np.dtype([("line_off", "<u8"), ("sdp", "<u4"), ("dp", "<u4"), ("total", "<u4"), ("rdf", "<u4"), ("rdr", "<u4"),
+                          ("ref_qual_sum", "<u4"), ("adf", "<u4"), ("adr", "<u4"), ("alt_qual_sum", "<u4"), ("ref_base", "u1"),
+                          ("alt_base", "u1"), ("reserved", "u1", (2,))])
+assert VARSCAN_DTYPE.itemsize == 48
 
 _SCAN_CODES = {1: "line has fewer than 2 fields", 2: "position field is not an unsigned decimal integer",
                3: "non-ASCII byte in pileup"}
@@ -273,6 +277,24 @@ class Device(object):
         if check:
             self.raise_site_status(ConsensusResult(None, None, counts[:n], status))
         return off[:n], flags[:n], counts[:n]
+
+    def varscan_file(self, path, params, capacity=4096):
+        """Phase-1 site calling over a pileup file: numpy records (VARSCAN_DTYPE) of every (line, allele) that passes the
+        count tests of `VarScan mpileup2snp`, in file order.  Raises PileupFormatError for a malformed line."""
+        n = C.c_uint32()
+        status = np.zeros(2, dtype=np.uint64)
+        while True:
+            cap = int(capacity)
+            sites = np.zeros(max(cap, 1), dtype=VARSCAN_DTYPE)
+            rc = self.lib.snpgpu_varscan_file(self.ctx, os.fsencode(path), C.byref(params), cap, _ptr(sites), C.byref(n), _ptr(status))
+            if rc == L.E_IO:
+                raise PileupIOError("cannot open or read the pileup file %s" % path)
+            if rc == L.E_PILEUP:
+                raise PileupFormatError("Invalid format for pileup at byte %d of %s" % (int(status[0]), path), ValueError)
+            self._check(rc)
+            if n.value <= cap:
+                return sites[:n.value], int(status[1])
+            capacity = max(n.value, 2 * cap)
 
     def raise_file_status(self, path, rc, res, check=True):
         """Raise for one file of call_consensus_files the way call_consensus does for its single pileup."""

@@ -1,0 +1,174 @@
+"""Phase-1 site calling: the device pass + host finish (snp_pipeline_amd/varscan.py) against the CPU restatement
+of `VarScan mpileup2snp` (oracle/varscan_oracle.py) on seeded pileups, through the C ABI and through the console script.
+
+What the reference's own data pins (the text and arithmetic of all 69 019 bundled var.flt.vcf lines) is checked on the CPU in
+tests/test_oracle.py and tests/test_host_cpu.py; no pileup accompanies those files, so here the oracle is the checker."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from oracle import fuzz
+from oracle import varscan_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def d():
+    from tests.gpu_util import get_device
+    return get_device()
+
+
+def _vcf(d, path, out, extra):
+    from snp_pipeline_amd import varscan
+    return varscan.mpileup2snp(d, path, out, varscan.Options(extra))
+
+
+CASES = [("--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5", dict(vo.PIPELINE_DEFAULTS)),
+         ("", {}),
+         ("--min-var-freq 0.5 --min-reads2 3 --p-value 1e-6 --strand-filter 0 --min-coverage 10 --output-vcf 1",
+          dict(min_var_freq=0.5, min_reads2=3, p_value=1e-6, strand_filter=0, min_coverage=10)),
+         ("--min-avg-qual 0 --min-var-freq 0.3 --min-freq-for-hom 0.95", dict(min_avg_qual=0, min_var_freq=0.3, min_freq_for_hom=0.95))]
+
+
+@pytest.mark.parametrize("seed,eol", [(1, b"\n"), (2, b"\r\n"), (3, b"\n")])
+def test_var_flt_vcf_equals_oracle(d, tmp_path, seed, eol):
+    data = fuzz.varscan_pileup(seed, 7000, eol=eol)
+    path = str(tmp_path / "reads.all.pileup")
+    with open(path, "wb") as f:
+        f.write(data)
+    for extra, kw in CASES:
+        out = str(tmp_path / "var.flt.vcf")
+        n_lines, n_rows = _vcf(d, path, out, extra)
+        want = vo.mpileup2snp(data, vo.Params(**kw))
+        got = open(out).read()
+        assert got == want, (seed, extra)
+        assert n_rows == sum(1 for ln in want.splitlines() if not ln.startswith("#")) and n_rows > 20
+        assert n_lines == len([ln for ln in data.split(eol) if ln])
+
+
+def test_records_capacity_retry_and_order(d, tmp_path):
+    from snp_pipeline_amd import varscan
+    data = fuzz.varscan_pileup(5, 5000)
+    path = str(tmp_path / "p.pileup")
+    with open(path, "wb") as f:
+        f.write(data)
+    prm = varscan.Options("--min-var-freq 0.01 --min-reads2 1").device_params()
+    a, n_lines = d.varscan_file(path, prm, capacity=1)                 # grows until everything fits
+    b, _ = d.varscan_file(path, prm, capacity=1 << 16)
+    assert len(a) == len(b) > 300 and a.tobytes() == b.tobytes()
+    key = a["line_off"].astype(np.int64) * 256 + a["alt_base"]
+    assert (np.diff(key) > 0).all()                                    # file order, alleles A < C < G < T within a line
+    assert (a["adf"] + a["adr"] > 0).all() and (a["total"] >= a["adf"] + a["adr"] + a["rdf"] + a["rdr"]).all()
+
+
+def test_malformed_lines_are_refused_like_the_oracle(d, tmp_path):
+    from snp_pipeline_amd import varscan
+    from snp_pipeline_amd.device import PileupFormatError, PileupIOError
+    good = b"c\t1\tA\t9\tGGGGGGGGG\tIIIIIIIII\n"
+    for bad in (b"c\t2\tA\t9\tGGGGGGGGG\n", b"c\t2\tA\tx9\tGGGGGGGGG\tIIIIIIIII\n", b"c 2 A 9 GGGGGGGGG IIIIIIIII\n", b"c\t2\tAC\t9\tGGGGGGGGG\tIIIIIIIII\n",
+                b"c\t2\tA\t9\tGGGGGGGGG\t\n", b"\t2\tA\t9\tGGGGGGGGG\tIIIIIIIII\n"):
+        path = str(tmp_path / "bad.pileup")
+        data = good * 3 + bad + good
+        with open(path, "wb") as f:
+            f.write(data)
+        with pytest.raises(PileupFormatError) as e:
+            _vcf(d, path, str(tmp_path / "o.vcf"), "")
+        assert "byte %d " % (3 * len(good)) in str(e.value)
+        with pytest.raises(ValueError):
+            vo.mpileup2snp(data, vo.Params())
+    with pytest.raises(PileupIOError):
+        _vcf(d, str(tmp_path / "missing.pileup"), str(tmp_path / "o.vcf"), "")
+    # an empty file and a file of empty lines give the bare header
+    for data in (b"", b"\n\n\n"):
+        path = str(tmp_path / "e.pileup")
+        with open(path, "wb") as f:
+            f.write(data)
+        assert _vcf(d, path, str(tmp_path / "o.vcf"), "")[1] == 0
+        assert open(str(tmp_path / "o.vcf")).read() == vo.VCF_HEADER % {"q": 15} == varscan.header_text(15)
+
+
+def test_call_sites_console_script(tmp_path, monkeypatch):
+    """cfsan_snp_pipeline call_sites with a fresh pileup (samtools is not run, call_sites.py:70-72): var.flt.vcf from the device,
+    VarscanMpileup2snp_ExtraParams honoured, the freshness check on the second run, sample errors for a missing BAM."""
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    ref = tmp_path / "ref.fasta"
+    ref.write_text(">ctgA\nACGT\n")
+    sdir = tmp_path / "samples" / "s1"
+    sdir.mkdir(parents=True)
+    bam = sdir / "reads.sorted.deduped.indelrealigned.bam"
+    bam.write_bytes(b"not really a bam")
+    old = time.time() - 100
+    os.utime(str(bam), (old, old))
+    os.utime(str(ref), (old, old))
+    data = fuzz.varscan_pileup(11, 4000)
+    (sdir / "reads.all.pileup").write_bytes(data)
+    monkeypatch.setenv("VarscanMpileup2snp_ExtraParams", "--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5")
+    monkeypatch.chdir(tmp_path)
+    cli.run_command_from_args(cli.parse_command_line("call_sites -v 0 %s %s" % (ref, sdir)))
+    want = vo.mpileup2snp(data, vo.Params(**vo.PIPELINE_DEFAULTS))
+    vcf = sdir / "var.flt.vcf"
+    assert vcf.read_text() == want
+    # fresh: not rebuilt
+    stamp = os.stat(str(vcf)).st_mtime_ns
+    monkeypatch.setenv("VarscanMpileup2snp_ExtraParams", "--min-var-freq 0.5")
+    cli.run_command_from_args(cli.parse_command_line("call_sites -v 0 %s %s" % (ref, sdir)))
+    assert os.stat(str(vcf)).st_mtime_ns == stamp
+    os.utime(str(vcf), (old + 50, old + 50))                             # now older than the pileup: rebuilt (-f would also re-run samtools)
+    cli.run_command_from_args(cli.parse_command_line("call_sites -v 0 %s %s" % (ref, sdir)))
+    assert vcf.read_text() == vo.mpileup2snp(data, vo.Params(min_var_freq=0.5))
+    # the result feeds the next stage's reader
+    from snp_pipeline_amd import utils
+    assert len(utils.convert_vcf_file_to_snp_set(str(vcf))) == sum(1 for ln in vcf.read_text().splitlines() if not ln.startswith("#"))
+
+
+def test_full_size_sample_runs_and_matches_oracle_on_its_variant_lines(d, tmp_path):
+    """One 5 Mbp x 30x sample (432 MB) written to disk: every record's line re-parsed by the oracle gives the same row, and
+    every planted homozygous site with enough depth is found."""
+    import torch
+    from snp_pipeline_amd import varscan
+    G, S = 5_000_000, 5_000
+    d.use_torch_stream()
+    ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda")
+    d.synth_reference_dev(1, G, ref.data_ptr())
+    rng = np.random.default_rng(4)
+    pos = np.sort(rng.choice(np.arange(501, G - 499), size=S, replace=False))
+    refh = ref.cpu().numpy()
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    alt_h = np.zeros(G + 1, dtype=np.uint8)
+    alt_h[pos] = acgt[(np.searchsorted(acgt, refh[pos]) + 1 + rng.integers(0, 3, size=S)) % 4]
+    alt = torch.from_numpy(alt_h).cuda()
+    n = d.synth_pileup_dev(3, 0, G, ref.data_ptr(), alt.data_ptr(), 0, 0, p_same=1.0, p_other=1.0)
+    buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    assert d.synth_pileup_dev(3, 0, G, ref.data_ptr(), alt.data_ptr(), buf.data_ptr(), n + 64, p_same=1.0, p_other=1.0) == n
+    data = buf[:n].cpu().numpy().tobytes()
+    path = str(tmp_path / "reads.all.pileup")
+    with open(path, "wb") as f:
+        f.write(data)
+    out = str(tmp_path / "var.flt.vcf")
+    t0 = time.time()
+    n_lines, n_rows = _vcf(d, path, out, "--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5")
+    wall = time.time() - t0
+    assert n_lines == data.count(b"\n")
+    rows = [ln for ln in open(out).read().splitlines(True) if not ln.startswith("#")]
+    assert len(rows) == n_rows and n_rows > 0.5 * S
+    prm = vo.Params(**vo.PIPELINE_DEFAULTS)
+    recs, _ = d.varscan_file(path, varscan.Options("--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5").device_params())
+    assert len(recs) == n_rows
+    for k in rng.choice(n_rows, size=400, replace=False):
+        off = int(recs["line_off"][k])
+        f = data[off:data.index(b"\n", off)].split(b"\t")
+        r = vo.call_line(f[2].decode(), int(f[3]), f[4], f[5], prm)
+        assert r is not None and vo.vcf_row(f[0].decode(), f[1].decode(), r) == rows[k]
+    # lines that are NOT in the output: the oracle calls nothing on a sample of them either
+    called = set(int(x) for x in recs["line_off"])
+    starts = [0] + [i + 1 for i in rng.choice(n - 400, size=300)]
+    for s in starts:
+        s = data.index(b"\n", s) + 1 if s else 0
+        if s in called:
+            continue
+        f = data[s:data.index(b"\n", s)].split(b"\t")
+        assert vo.call_line(f[2].decode(), int(f[3]), f[4], f[5], prm) is None
+    print("full-size sample: %d lines, %d sites, %.2f s wall (%.1f GB/s file -> var.flt.vcf)" % (n_lines, n_rows, wall, n / wall / 1e9))

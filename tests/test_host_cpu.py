@@ -447,3 +447,43 @@ def test_library_distance_tsv_writer_equals_reference_layout(tmp_path, fixture_t
     distance.write_pairwise(a, ids, mat)
     distance.write_matrix(b, ids, mat)
     assert open(a, "rb").read() == want_p and open(b, "rb").read() == want_m
+
+
+def test_varscan_host_finish_reproduces_every_bundled_var_flt_vcf_line():
+    """snp_pipeline_amd/varscan.py (the product's host half of phase-1 site calling): header text and every data line of the 58
+    bundled var.flt.vcf files from the line's own counts; the ExtraParams parser; the strand filter on hand-made cases."""
+    import tarfile
+    from snp_pipeline_amd import varscan
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fixtures")
+    n = 0
+    for ds in ("lambdaVirus", "agona", "listeria"):
+        with tarfile.open(os.path.join(here, ds, "expected.tar.xz")) as t:
+            for m in t.getmembers():
+                if not m.name.endswith("/var.flt.vcf"):
+                    continue
+                lines = t.extractfile(m).read().decode().splitlines(True)
+                assert "".join(ln for ln in lines if ln.startswith("#")) == varscan.header_text(15)
+                for ln in lines:
+                    if ln.startswith("#"):
+                        continue
+                    f = ln.rstrip("\n").split("\t")
+                    v = dict(zip(f[8].split(":"), f[9].split(":")))
+                    rd, ad = int(v["RD"]), int(v["AD"])
+                    total = rd + ad                                          # FREQ's denominator: indel reads count, DP does not matter
+                    while varscan._percent(ad, total) != v["FREQ"]:
+                        total += 1
+                        assert total < 4 * (rd + ad) + 64, ln
+                    got = varscan.data_line(f[0], f[1], f[3], f[4], int(v["SDP"]), int(v["DP"]), total, int(v["RDF"]), int(v["RDR"]), int(v["RBQ"]),
+                                            int(v["ADF"]), int(v["ADR"]), int(v["ABQ"]), varscan.variant_p_value(rd, ad), v["GT"] == "1/1", f[6])
+                    assert got == ln
+                    assert not varscan.strand_filter_fails(int(v["RDF"]), int(v["RDR"]), int(v["ADF"]), int(v["ADR"]))     # all bundled lines PASS
+                    n += 1
+    assert n == 69019
+    o = varscan.Options("--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5")
+    assert (o.min_coverage, o.min_reads2, o.min_avg_qual, o.min_var_freq, o.min_freq_for_hom, o.p_value, o.strand_filter) == (8, 5, 15, 0.9, 0.75, 0.99, 1)
+    o = varscan.Options("--output-vcf 1 --p-value 1e-3 --strand-filter 0 --min-coverage 3 --variants --min-freq-for-hom 0.8")
+    assert (o.min_coverage, o.p_value, o.strand_filter, o.min_freq_for_hom, o.min_reads2) == (3, 1e-3, 0, 0.8, 2)
+    p = o.device_params()
+    assert (p.min_coverage, p.min_reads2, p.min_avg_qual, p.min_var_freq) == (3, 2, 15, 0.2)
+    assert varscan.strand_filter_fails(10, 10, 0, 20) and not varscan.strand_filter_fails(1, 0, 0, 20) and not varscan.strand_filter_fails(20, 0, 0, 20)
+    assert not varscan.strand_filter_fails(10, 10, 10, 10) and varscan._sci(0.0) == "0E0" and varscan._sci(9.99996e-5) == "1E-4"

@@ -161,3 +161,64 @@ def test_depth_sum_against_the_reference_collect_metrics():
             data = fuzz.odd_depth_lines(kw["seed"], kw["eol"].encode())
         assert len(data) == v["bytes"]
         assert "%.2f" % float(po.depth_sum(data)) == v["avePileupDepth"]
+
+
+# ---- phase-1 site calling (VarScan mpileup2snp): the restatement against the reference's bundled var.flt.vcf files --------
+def _var_flt_vcfs():
+    import tarfile
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fixtures")
+    for ds in ("lambdaVirus", "agona", "listeria"):
+        with tarfile.open(os.path.join(here, ds, "expected.tar.xz")) as t:
+            for m in t.getmembers():
+                if m.name.endswith("/var.flt.vcf"):
+                    yield ds + "/" + m.name, t.extractfile(m).read().decode()
+
+
+def test_varscan_oracle_reproduces_every_bundled_var_flt_vcf_line():
+    """58 files, 69 019 data lines: header text, column layout, PVAL / GQ (Fisher against the 0.1 % error model), FREQ text,
+    GT / HOM / HET, ADP — each line rebuilt from its own counts.  And the selection rules hold on every line."""
+    from oracle import varscan_oracle as vo
+    prm = vo.Params(**vo.PIPELINE_DEFAULTS)
+    n_files = n_rows = one_sided = 0
+    for name, text in _var_flt_vcfs():
+        n_files += 1
+        lines = text.splitlines(True)
+        assert "".join(ln for ln in lines if ln.startswith("#")) == vo.VCF_HEADER % {"q": 15}, name
+        for ln in lines:
+            if ln.startswith("#"):
+                continue
+            chrom, pos, r = vo.row_from_fixture_line(ln)
+            assert vo.vcf_row(chrom, pos, r) == ln, (name, ln)
+            n_rows += 1
+            # the selection tests, from inside
+            assert r["SDP"] >= prm.min_coverage and r["DP"] >= prm.min_coverage and r["AD"] >= prm.min_reads2 and r["ABQ"] >= prm.min_avg_qual
+            assert float(r["AD"]) / float(r["total"]) >= prm.min_var_freq and r["p"] <= prm.p_value and r["hom"]
+            assert r["total"] >= r["RD"] + r["AD"] and r["RDF"] + r["RDR"] == r["RD"] and r["ADF"] + r["ADR"] == r["AD"]
+            # the strand filter as restated passes every bundled line (all are PASS)
+            var_plus = r["ADF"] / float(r["AD"])
+            if var_plus < 0.1 or var_plus > 0.9:
+                one_sided += 1
+                if r["RD"] > 1:
+                    ref_plus = r["RDF"] / float(r["RD"])
+                    assert not (vo.two_tailed_p(r["RDF"], r["RDR"], r["ADF"], r["ADR"]) < 0.01 and 0.1 <= ref_plus <= 0.9), ln
+    assert (n_files, n_rows) == (58, 69019) and one_sided > 1000
+
+
+def test_varscan_oracle_read_counting_rules():
+    """The read-base walk as restated (UNPINNED by reference data — see the module header): which bytes own a quality,
+    what counts where."""
+    from oracle import varscan_oracle as vo
+    c = vo.read_counts(b".,Aa^]G$*Nn+2AC.-1g,", b"IIIIIIIIIII", 15)
+    # . , A a (^] skipped) G ($ skipped) * N n (+2AC: one indel read) . (-1g: one indel read) ,
+    assert c.ref == [2, 2, 4 * 40] and c.alt == {"A": [1, 1, 80], "G": [1, 0, 40]} and c.indel == 2 and c.total() == 9
+    assert vo.quality_depth(b"IIIIIIIIIII", 15) == 11
+    # qualities below the threshold do not count, but still advance the cursor; a short quality string reads as quality 0
+    c = vo.read_counts(b"AAAA", b"I#I", 15)
+    assert c.alt == {"A": [2, 0, 80]}
+    # three-digit and four-digit indel lengths, an indel that runs off the end, a sign without digits
+    assert vo.read_counts(b".+12ACGTACGTACGT.", b"II", 15).ref == [2, 0, 80]
+    assert vo.read_counts(b".+3AC", b"I", 15).indel == 1 and vo.read_counts(b".+A", b"II", 15).alt == {"A": [1, 0, 40]}
+    # one line end to end: 9 of 10 reads G at quality 40 over an A reference
+    r = vo.call_line("a", 10, b"GGGGggggg.", b"I" * 10, vo.Params(**vo.PIPELINE_DEFAULTS))
+    assert vo.vcf_row("c", "7", r) == "c\t7\t.\tA\tG\t.\tPASS\tADP=10;WT=0;HET=0;HOM=1;NC=0\tGT:GQ:SDP:DP:RD:AD:FREQ:PVAL:RBQ:ABQ:RDF:RDR:ADF:ADR\t" \
+                                       "1/1:42:10:10:1:9:90%:5.9538E-5:40:40:1:0:4:5\n"       # (GQ / PVAL of RD 1, AD 9 as in agona ERR178926 pos 226973)
