@@ -847,19 +847,56 @@ __global__ __launch_bounds__(256) void k_scan_finish(const SampleDev *samples, c
 #define LINES_THREADS 256
 #define LINES_PER_THREAD (LINES_BLOCK / LINES_THREADS)
 
+// 0x80 in every byte of w that equals the byte replicated in c4 (exact for any byte values: no carries between bytes)
+__device__ __forceinline__ uint32_t eq_flags(uint32_t w, uint32_t c4) {
+    const uint32_t x = w ^ c4;
+    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
+
+// Each thread owns 64 consecutive bytes (four 16-byte loads from the 16-byte aligned address at or below the buffer);
+// blocks are laid out in those aligned coordinates.
 template <bool kEmit>
 __global__ __launch_bounds__(LINES_THREADS) void k_lines_index(const uint8_t *buf, uint64_t nbytes, uint32_t *block_counts, uint64_t *line_off, uint64_t capacity) {
     __shared__ uint32_t lds[17];
-    const uint64_t b0 = (uint64_t)blockIdx.x * LINES_BLOCK + (uint64_t)threadIdx.x * LINES_PER_THREAD;
-    // bit k of `starts`: a line starts at byte b0 + k
+    const uint32_t shift = (uint32_t)((uintptr_t)buf & 15u);
+    const uint4 *abase = (const uint4 *)(buf - shift);
+    const uint64_t a0 = (uint64_t)blockIdx.x * LINES_BLOCK + (uint64_t)threadIdx.x * LINES_PER_THREAD;    // aligned coordinate of my byte 0
+    const int64_t p0 = (int64_t)a0 - (int64_t)shift;                                                      // ... and its file offset
+    // bit k of N / C: byte p0 + k is '\n' / '\r'
+    uint64_t N = 0, C = 0;
+    if (p0 < (int64_t)nbytes && p0 + LINES_PER_THREAD > 0) {
+#pragma unroll
+        for (int q = 0; q < LINES_PER_THREAD / 16; ++q) {
+            const int64_t pq = p0 + 16 * q;
+            if (pq >= (int64_t)nbytes || pq + 16 <= 0) continue;
+            const uint4 v = abase[a0 / 16 + q];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t nb = 0, cb = 0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                nb |= (__builtin_amdgcn_udot4(eq_flags(w[d], 0x0A0A0A0Au), 0x08040201u, 0u, false) >> 7) << (4 * d);
+                cb |= (__builtin_amdgcn_udot4(eq_flags(w[d], 0x0D0D0D0Du), 0x08040201u, 0u, false) >> 7) << (4 * d);
+            }
+            N |= (uint64_t)nb << (16 * q);
+            C |= (uint64_t)cb << (16 * q);
+        }
+        // bytes before the file / past its end are neither
+        uint64_t valid = ~0ull;
+        if (p0 < 0) valid &= ~0ull << (uint32_t)(-p0);
+        if (p0 + LINES_PER_THREAD > (int64_t)nbytes) valid &= ~0ull >> (uint32_t)(p0 + LINES_PER_THREAD - (int64_t)nbytes);
+        N &= valid;
+        C &= valid;
+    }
+    // bit k of `starts`: a line starts at byte p0 + k — the byte before it is '\n', or a '\r' that it does not follow with '\n';
+    // byte 0 of the file starts a line; a start at the end of the file is no line
     uint64_t starts = 0;
-    uint32_t prev = b0 == 0 ? 10u : (b0 - 1 < nbytes ? buf[b0 - 1] : 0u);
-    for (int k = 0; k < LINES_PER_THREAD; ++k) {
-        const uint64_t p = b0 + k;
-        if (p >= nbytes) break;
-        const uint32_t c = buf[p];
-        if (prev == 10u || (prev == 13u && c != 10u)) starts |= 1ull << k;
-        prev = c;
+    if (p0 < (int64_t)nbytes && p0 + LINES_PER_THREAD > 0) {
+        uint64_t pn = 0, pc = 0;
+        if (p0 > 0) { const uint32_t b = buf[p0 - 1]; pn = b == 10u; pc = b == 13u; }
+        starts = ((N << 1) | pn) | (((C << 1) | pc) & ~N);
+        if (p0 <= 0) starts |= 1ull << (uint32_t)(-p0);
+        if (p0 < 0) starts &= ~0ull << (uint32_t)(-p0);
+        if (p0 + LINES_PER_THREAD > (int64_t)nbytes) starts &= ~0ull >> (uint32_t)(p0 + LINES_PER_THREAD - (int64_t)nbytes);
     }
     uint32_t total;
     const uint32_t mine = (uint32_t)__popcll(starts);
@@ -872,7 +909,7 @@ __global__ __launch_bounds__(LINES_THREADS) void k_lines_index(const uint8_t *bu
     while (starts) {
         const uint32_t k = (uint32_t)__ffsll((long long)starts) - 1;
         starts &= starts - 1;
-        if (idx < capacity) line_off[idx] = b0 + k + 1;
+        if (idx < capacity) line_off[idx] = (uint64_t)(p0 + (int64_t)k) + 1;
         ++idx;
     }
 }
@@ -899,11 +936,14 @@ __global__ __launch_bounds__(256) void k_lines_flags(const uint8_t *buf, uint64_
     }
 }
 
-size_t snpgpu_lines_workspace_words(uint64_t nbytes) { return prim_scan_workspace_words((nbytes + LINES_BLOCK - 1) / LINES_BLOCK + 1) + (nbytes + LINES_BLOCK - 1) / LINES_BLOCK + 1; }
+static inline uint64_t lines_blocks(const uint8_t *d_buf, uint64_t nbytes) {     // blocks in the aligned coordinates of k_lines_index
+    return nbytes ? (((uintptr_t)d_buf & 15u) + nbytes + LINES_BLOCK - 1) / LINES_BLOCK : 0;
+}
+size_t snpgpu_lines_workspace_words(uint64_t nbytes) { return prim_scan_workspace_words((nbytes + LINES_BLOCK - 1) / LINES_BLOCK + 2) + (nbytes + LINES_BLOCK - 1) / LINES_BLOCK + 2; }
 
 // ws: snpgpu_lines_workspace_words(nbytes) words.  Leaves the number of lines in *d_total (a pointer into ws).
 int snpgpu_enqueue_lines_count(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, uint32_t *ws, uint32_t **d_total) {
-    const uint64_t nb = (nbytes + LINES_BLOCK - 1) / LINES_BLOCK;
+    const uint64_t nb = lines_blocks(d_buf, nbytes);
     if (nb > 0x7FFFFFFFull) return snpgpu_set_error(ctx, SNPGPU_E_UNSUPPORTED, "pileup too large for the line index");
     uint32_t *counts = ws, *scan_ws = ws + nb + 1;
     if (nb) k_lines_index<false><<<(unsigned)nb, LINES_THREADS, 0, ctx->stream>>>(d_buf, nbytes, counts, nullptr, 0);
@@ -915,7 +955,7 @@ int snpgpu_enqueue_lines_count(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t n
 // after snpgpu_enqueue_lines_count with the same ws: line offsets (+1) in file order and the flags of every line
 int snpgpu_enqueue_lines_emit(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *d_buf, uint64_t nbytes, uint32_t *ws,
                               uint64_t *d_line_off, uint8_t *d_flags, uint64_t n_lines, uint64_t *d_status) {
-    const uint64_t nb = (nbytes + LINES_BLOCK - 1) / LINES_BLOCK;
+    const uint64_t nb = lines_blocks(d_buf, nbytes);
     if (nb) k_lines_index<true><<<(unsigned)nb, LINES_THREADS, 0, ctx->stream>>>(d_buf, nbytes, ws, d_line_off, n_lines);
     if (n_lines) {
         const uint64_t blocks = (n_lines + 255) / 256, cap = (uint64_t)ctx->n_cu * 8;
@@ -927,7 +967,7 @@ int snpgpu_enqueue_lines_emit(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const u
 
 // the offsets alone
 int snpgpu_enqueue_lines_offsets(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, uint32_t *ws, uint64_t *d_line_off, uint64_t n_lines) {
-    const uint64_t nb = (nbytes + LINES_BLOCK - 1) / LINES_BLOCK;
+    const uint64_t nb = lines_blocks(d_buf, nbytes);
     if (nb) k_lines_index<true><<<(unsigned)nb, LINES_THREADS, 0, ctx->stream>>>(d_buf, nbytes, ws, d_line_off, n_lines);
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;

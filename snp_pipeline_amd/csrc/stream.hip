@@ -517,40 +517,79 @@ done:
     return rc;
 }
 
-// Synchronous load of one file into device slot 0 (the --vcfAllPos path: a diagnostic option, no overlap needed).
+// One file into device slot 0 through the same reader threads / staging ring / two copy streams as run_stream (the
+// all-lines passes: --vcfAllPos and phase-1 site calling index the whole file before they look at a line, so there is
+// nothing to overlap the copy with but the reads).  Synchronous.
 int load_file(snpgpu_ctx *ctx, const char *path, uint8_t **d_file, uint64_t *size) {
-    int fd = open(path, O_RDONLY | O_CLOEXEC);
+    std::vector<Source> src(1);
+    Source &s = src[0];
+    s.path = path;
+    s.fd = open(path, O_RDONLY | O_CLOEXEC);
     struct stat stt;
-    if (fd < 0 || fstat(fd, &stt) != 0 || !S_ISREG(stt.st_mode)) {
-        if (fd >= 0) close(fd);
+    if (s.fd < 0 || fstat(s.fd, &stt) != 0 || !S_ISREG(stt.st_mode)) {
+        if (s.fd >= 0) close(s.fd);
         return snpgpu_set_error(ctx, SNPGPU_E_IO, "cannot open the pileup file %s", path);
     }
-    const uint64_t n = (uint64_t)stt.st_size;
-    const size_t chunk = (size_t)8 << 20;
-    int rc = pool_ensure(ctx, chunk, 2, 1, up(n + SNPGPU_SCAN_TILE + 256, 4096), 256, 256);
-    if (rc) { close(fd); return rc; }
+    const uint64_t n = s.size = (uint64_t)stt.st_size;
+    (void)posix_fadvise(s.fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    const size_t chunk = (size_t)16 << 20;
+    std::vector<Job> jobs;
+    for (uint64_t off = 0, c = 0; off < n; off += chunk, ++c)
+        jobs.push_back(Job{0, off, n - off < chunk ? n - off : chunk, c == 0, off + chunk >= n, (uint32_t)c});
+    const uint64_t J = jobs.size();
+    unsigned hc = std::thread::hardware_concurrency();
+    uint32_t n_readers = hc >= 32 ? 8 : (hc >= 8 ? hc / 2 : (hc > 1 ? hc - 1 : 1));
+    if (n_readers > J) n_readers = (uint32_t)J;
+    uint32_t n_staging = n_readers + 4;
+    if (n_staging > J) n_staging = (uint32_t)J;
+    if (n_staging < 1) n_staging = 1;
+    int rc = pool_ensure(ctx, chunk, n_staging, 1, up(n + SNPGPU_SCAN_TILE + 256, 4096), 256, 256);
+    if (rc) { close(s.fd); return rc; }
     snpgpu_stream_pool *p = ctx->pool;
-    hipStream_t st = ctx->stream;
+    const uint64_t R = p->staging.size() < n_staging ? p->staging.size() : n_staging;
     uint8_t *d = (uint8_t *)p->slot[0];
-    hipError_t he = hipStreamSynchronize(st);
-    uint64_t j = 0;
-    for (uint64_t off = 0; off < n && he == hipSuccess; off += chunk, ++j) {
-        const uint64_t len = n - off < chunk ? n - off : chunk;
-        if (j >= 2) he = hipEventSynchronize(p->ev_copy[j % 2]);
-        uint8_t *h = (uint8_t *)p->staging[j % 2];
-        uint64_t got = 0;
-        while (got < len) {
-            ssize_t r = pread(fd, h + got, len - got, (off_t)(off + got));
-            if (r < 0 && errno == EINTR) continue;
-            if (r <= 0) { close(fd); (void)hipStreamSynchronize(st); return snpgpu_set_error(ctx, SNPGPU_E_IO, "cannot read the pileup file %s", path); }
-            got += (uint64_t)r;
+    hipError_t he = hipStreamSynchronize(ctx->stream);          // earlier work on the slot is done
+    Shared sh;
+    sh.R = R ? R : 1;
+    sh.filled.assign(J, 0);
+    sh.job_err.assign(J, 0);
+    std::vector<std::thread> readers;
+    bool io_failed = false;
+    if (he == hipSuccess && J) {
+        try {
+            for (uint32_t i = 0; i < n_readers; ++i) readers.emplace_back(reader_main, ctx, &sh, &jobs, &src);
+        } catch (const std::exception &e) {
+            { std::lock_guard<std::mutex> lk(sh.mu); sh.abort = true; sh.next.store(J); }
+            sh.cv.notify_all();
+            for (auto &t : readers) t.join();
+            close(s.fd);
+            return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "cannot start the reader threads: %s", e.what());
         }
-        if (he == hipSuccess) he = hipMemcpyAsync(d + off, h, len, hipMemcpyHostToDevice, st);
-        if (he == hipSuccess) he = hipEventRecord(p->ev_copy[j % 2], st);
+        int64_t copies_done = 0;
+        for (uint64_t j = 0; j < J && he == hipSuccess; ++j) {
+            for (;;) {                                          // wait for chunk j; retire finished copies meanwhile
+                bool progress = false;
+                while (copies_done < (int64_t)j && hipEventQuery(p->ev_copy[copies_done % R]) == hipSuccess) { ++copies_done; progress = true; }
+                std::unique_lock<std::mutex> lk(sh.mu);
+                if (progress) { sh.freed = copies_done; lk.unlock(); sh.cv.notify_all(); lk.lock(); }
+                if (sh.filled[j]) break;
+                sh.cv.wait_for(lk, std::chrono::microseconds(copies_done < (int64_t)j ? 20 : 2000), [&] { return sh.filled[j] != 0; });
+                if (sh.filled[j]) break;
+            }
+            if (sh.job_err[j]) io_failed = true;
+            hipStream_t cs = (j & 1) ? p->copy_stream2 : p->copy_stream;
+            he = hipMemcpyAsync(d + jobs[j].off, p->staging[j % R], jobs[j].len, hipMemcpyHostToDevice, cs);
+            if (he == hipSuccess) he = hipEventRecord(p->ev_copy[j % R], cs);
+        }
+        { std::lock_guard<std::mutex> lk(sh.mu); if (he != hipSuccess) { sh.abort = true; sh.next.store(J); } }
+        sh.cv.notify_all();
+        for (auto &t : readers) t.join();
+        hipError_t e1 = hipStreamSynchronize(p->copy_stream), e2 = hipStreamSynchronize(p->copy_stream2);
+        if (he == hipSuccess) he = e1 != hipSuccess ? e1 : e2;
     }
-    close(fd);
-    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    close(s.fd);
     if (he != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_HIP, "loading %s failed: %s", path, hipGetErrorString(he));
+    if (io_failed) return snpgpu_set_error(ctx, SNPGPU_E_IO, "cannot read the pileup file %s", path);
     *d_file = d;
     *size = n;
     return SNPGPU_OK;

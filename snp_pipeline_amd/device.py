@@ -278,7 +278,7 @@ class Device(object):
             self.raise_site_status(ConsensusResult(None, None, counts[:n], status))
         return off[:n], flags[:n], counts[:n]
 
-    def varscan_file(self, path, params, capacity=4096):
+    def varscan_file(self, path, params, capacity=65536):
         """Phase-1 site calling over a pileup file: numpy records (VARSCAN_DTYPE) of every (line, allele) that passes the
         count tests of `VarScan mpileup2snp`, in file order.  Raises PileupFormatError for a malformed line."""
         n = C.c_uint32()

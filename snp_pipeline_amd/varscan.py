@@ -151,10 +151,17 @@ def _sci(p):
     return "%sE%d" % (text, exp10)
 
 
+_PERCENT_TEXT = {}
+
+
 def _percent(part, whole):
     """Java DecimalFormat("###.##") of part / whole * 100, with the % sign."""
-    value = Decimal((float(part) / float(whole)) * 100.0).quantize(Decimal("0.01"), rounding=ROUND_HALF_EVEN)
-    return format(value, "f").rstrip("0").rstrip(".") + "%"
+    key = (part, whole)
+    text = _PERCENT_TEXT.get(key)
+    if text is None:
+        value = Decimal((float(part) / float(whole)) * 100.0).quantize(Decimal("0.01"), rounding=ROUND_HALF_EVEN)
+        text = _PERCENT_TEXT[key] = format(value, "f").rstrip("0").rstrip(".") + "%"
+    return text
 
 
 def strand_filter_fails(rdf, rdr, adf, adr):
@@ -167,10 +174,15 @@ def strand_filter_fails(rdf, rdr, adf, adr):
     return 0.10 <= ref_plus <= 0.90 and _HG.two_tails(rdf, rdr, adf, adr) < 0.01
 
 
+_P_TEXT = {}
+
+
 def data_line(chrom, pos, ref, alt, sdp, dp, total, rdf, rdr, rbq, adf, adr, abq, p, homozygous, filter_text="PASS"):
-    gq = 255 if p <= 0.0 else min(255, int(-10.0 * math.log10(p)))
+    pt = _P_TEXT.get(p)
+    if pt is None:
+        pt = _P_TEXT[p] = (255 if p <= 0.0 else min(255, int(-10.0 * math.log10(p))), _sci(p))
     rd, ad = rdf + rdr, adf + adr
-    sample = "%s:%d:%d:%d:%d:%d:%s:%s:%d:%d:%d:%d:%d:%d" % ("1/1" if homozygous else "0/1", gq, sdp, dp, rd, ad, _percent(ad, total), _sci(p),
+    sample = "%s:%d:%d:%d:%d:%d:%s:%s:%d:%d:%d:%d:%d:%d" % ("1/1" if homozygous else "0/1", pt[0], sdp, dp, rd, ad, _percent(ad, total), pt[1],
                                                             rbq, abq, rdf, rdr, adf, adr)
     info = "ADP=%d;WT=0;HET=%d;HOM=%d;NC=0" % (dp, 0 if homozygous else 1, 1 if homozygous else 0)
     return "%s\t%s\t.\t%s\t%s\t.\t%s\t%s\t%s\t%s\n" % (chrom, pos, ref, alt, filter_text, info, FORMAT_KEYS, sample)
@@ -178,32 +190,32 @@ def data_line(chrom, pos, ref, alt, sdp, dp, total, rdf, rdr, rbq, adf, adr, abq
 
 def rows_from_records(records, pileup_bytes, opts):
     """records: Device.varscan_file's array (file order); pileup_bytes: the file (an mmap).  Yields the data lines."""
-    i, n = 0, len(records)
+    cols = [records[k].tolist() for k in ("line_off", "sdp", "dp", "total", "rdf", "rdr", "ref_qual_sum", "adf", "adr", "alt_qual_sum",
+                                          "ref_base", "alt_base")]
+    rows = list(zip(*cols))
+    i, n = 0, len(rows)
+    strand = bool(opts.strand_filter)
     while i < n:
-        j = i
+        off = rows[i][0]
         best = None
-        while j < n and records["line_off"][j] == records["line_off"][i]:       # the alleles of one line: most reads wins, first on ties
-            r = records[j]
-            ad = int(r["adf"]) + int(r["adr"])
-            p = variant_p_value(int(r["rdf"]) + int(r["rdr"]), ad)
-            if p <= opts.p_value and (best is None or ad > best[1]):
-                best = (r, ad, p)
-            j += 1
-        i = j
+        best_ad = -1
+        while i < n and rows[i][0] == off:                      # the alleles of one line: most reads wins, first on ties
+            r = rows[i]
+            ad = r[7] + r[8]
+            p = variant_p_value(r[4] + r[5], ad)
+            if p <= opts.p_value and ad > best_ad:
+                best, best_ad, best_p = r, ad, p
+            i += 1
         if best is None:
             continue
-        r, ad, p = best
-        off = int(r["line_off"])
+        _, sdp, dp, total, rdf, rdr, rq, adf, adr, aq, ref, alt = best
         t1 = pileup_bytes.find(b"\t", off)
         t2 = pileup_bytes.find(b"\t", t1 + 1)
-        chrom = pileup_bytes[off:t1].decode("latin-1")
-        pos = pileup_bytes[t1 + 1:t2].decode("latin-1")
-        rdf, rdr, adf, adr = int(r["rdf"]), int(r["rdr"]), int(r["adf"]), int(r["adr"])
         rd = rdf + rdr
-        fails = bool(opts.strand_filter) and strand_filter_fails(rdf, rdr, adf, adr)
-        yield data_line(chrom, pos, chr(int(r["ref_base"])), chr(int(r["alt_base"])), int(r["sdp"]), int(r["dp"]), int(r["total"]), rdf, rdr,
-                        int(r["ref_qual_sum"]) // rd if rd else 0, adf, adr, int(r["alt_qual_sum"]) // ad, p,
-                        float(ad) / float(int(r["total"])) >= opts.min_freq_for_hom, "str10" if fails else "PASS")
+        fails = strand and strand_filter_fails(rdf, rdr, adf, adr)
+        yield data_line(pileup_bytes[off:t1].decode("latin-1"), pileup_bytes[t1 + 1:t2].decode("latin-1"), chr(ref), chr(alt), sdp, dp, total, rdf, rdr,
+                        rq // rd if rd else 0, adf, adr, aq // best_ad, best_p, float(best_ad) / float(total) >= opts.min_freq_for_hom,
+                        "str10" if fails else "PASS")
 
 
 def mpileup2snp(device, pileup_path, vcf_path, opts):
