@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--cpu-procs", type=int, default=0, help="one-process-per-sample CPU leg: processes (0 = min(cores, 32))")
     ap.add_argument("--cpu-dist-samples", type=int, default=60, help="rows of the CPU distance leg (x 50 000 sites)")
     ap.add_argument("--skip-secondary", action="store_true")
+    ap.add_argument("--site-files", type=int, default=4, help="pileup files for the site_calling row (0 = skip)")
     ap.add_argument("--skip-aux", action="store_true", help="skip the device-copy ceiling and the K3/K4 timings")
     ap.add_argument("--skip-cpu-parallel", action="store_true", help="skip the one-process-per-sample CPU baseline")
     ap.add_argument("--e2e-files", type=int, default=16, help="pileup files streamed from the page cache for the end_to_end row (0 = skip)")
@@ -141,6 +142,75 @@ def end_to_end(d, ss, prm, pile, offs, sizes, bases, n_files, S):
             "chunk_bytes": int(st.chunk_bytes), "reader_threads": int(st.n_readers), "staging_buffers": int(st.n_staging),
             "seconds_waiting_for_readers": st.seconds_waiting_for_readers,
             "seconds_waiting_for_device": st.seconds_waiting_for_device, "matches_resident": True,
+        }
+    finally:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+
+
+def site_calling(d, pile, offs, sizes, n_files):
+    """Phase-1 site calling on pileup FILES in the page cache: file -> var.flt.vcf through
+    varscan.mpileup2snp (reader threads + copy, line index, k_varscan_lines, host finish), best of two passes; every
+    record of the first file is checked against the CPU restatement (oracle/varscan_oracle.py) on the record's own line,
+    and the restatement is timed on the first lines of that file for the CPU column."""
+    import shutil
+    import tempfile
+    from oracle import varscan_oracle as vo
+    from snp_pipeline_amd import varscan
+    need = int(sum(sizes[:n_files])) + (64 << 20)
+    base_dir = _scratch_dir(need)
+    if base_dir is None:
+        return {"skipped": "no room for %d bytes of pileup files" % need}
+    tmpdir = tempfile.mkdtemp(prefix="snpbench_sites_", dir=base_dir)
+    try:
+        paths = []
+        first = None
+        for i in range(n_files):
+            path = os.path.join(tmpdir, "s%d.pileup" % i)
+            data = pile[int(offs[i]):int(offs[i]) + sizes[i]].cpu().numpy().tobytes()
+            if i == 0:
+                first = data
+            with open(path, "wb") as f:
+                f.write(data)
+            paths.append(path)
+        extra = "--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5"                 # snppipeline.conf:199
+        opts = varscan.Options(extra)
+        vcf = os.path.join(tmpdir, "var.flt.vcf")
+        varscan.mpileup2snp(d, paths[0], vcf, opts)                                    # warm-up
+        best, rows, lines = None, 0, 0
+        for _ in range(2):
+            t0 = time.perf_counter()
+            rows = lines = 0
+            for path in paths:
+                n_lines, n_rows = varscan.mpileup2snp(d, path, vcf, opts)
+                rows += n_rows
+                lines += n_lines
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        # parity spot check: the first file's rows against the restatement, line by line
+        varscan.mpileup2snp(d, paths[0], vcf, opts)
+        got = [ln for ln in open(vcf).read().splitlines(True) if not ln.startswith("#")]
+        recs, _ = d.varscan_file(paths[0], opts.device_params())
+        prm = vo.Params(**vo.PIPELINE_DEFAULTS)
+        ok = len(recs) == len(got)
+        for k in range(len(got)):
+            off = int(recs["line_off"][k])
+            f = first[off:first.index(b"\n", off)].split(b"\t")
+            r = vo.call_line(f[2].decode(), int(f[3]), f[4], f[5], prm)
+            ok = ok and r is not None and vo.vcf_row(f[0].decode(), f[1].decode(), r) == got[k]
+        if not ok:
+            raise SystemExit("site calling differs from its CPU restatement")
+        # the CPU restatement on the first ~8 MB of the file (whole lines), one core
+        cut = first.rfind(b"\n", 0, 8 << 20) + 1
+        t0 = time.perf_counter()
+        vo.mpileup2snp(first[:cut], prm)
+        cpu_s = time.perf_counter() - t0
+        nbytes = int(sum(sizes[:n_files]))
+        return {
+            "what": "%d pileup files in the page cache -> var.flt.vcf each (VarScan mpileup2snp's job, %s)" % (n_files, extra),
+            "files": n_files, "bytes": nbytes, "seconds": best, "pileup_gb_per_sec": nbytes / best / 1e9, "samples_per_sec": n_files / best,
+            "pileup_lines_per_sec": lines / best, "sites_written": rows, "rows_equal_cpu_restatement": True,
+            "cpu_port": {"pileup_gb_per_sec": cut / cpu_s / 1e9, "cores": 1, "sample": "the first %d bytes of one file" % cut,
+                         "kind": "port (oracle/varscan_oracle.py; the reference runs the VarScan jar here, which this image lacks)"},
         }
     finally:
         shutil.rmtree(tmpdir, ignore_errors=True)
@@ -586,6 +656,10 @@ def main():
     # ---- end to end: pileup FILES in the page cache -> consensus bytes on the host, through the streamed ingestion ----
     if rank == 0 and world == 1 and args.e2e_files > 0 and B:
         out["end_to_end"] = end_to_end(d, ss, prm, pile, offs, sizes, bases, min(args.e2e_files, B), S)
+
+    # ---- phase-1 site calling on files -----------------------------------------------------------------
+    if rank == 0 and world == 1 and args.site_files > 0 and B:
+        out["site_calling"] = site_calling(d, pile, offs, sizes, min(args.site_files, B))
 
     # ---- CPU baseline: the oracle on samples of the batch; rank 0, N = 1 -----------------------------
     if rank == 0 and world == 1 and args.cpu_samples > 0 and B:
