@@ -157,7 +157,7 @@ def odd_depth_lines(seed, eol=b"\n", n=4000):
     return eol.join(lines) + eol
 
 
-def varscan_pileup(seed, n_lines=3000, contigs=("ctgA", "ctg_B|2"), eol=b"\n"):
+def varscan_pileup(seed, n_lines=3000, contigs=("ctgA", "ctg_B|2"), eol=b"\n", depths=(0, 0, 3, 7, 8, 9, 12, 20, 30, 30, 45, 80)):
     """A TAB-separated one-sample pileup for the phase-1 site caller: mostly reference-matching columns of depth 0..80,
     every ~12th line a variant column (one dominant alternate allele at 60..100 %, sometimes a second one, strands from
     balanced to one-sided), with indels, read starts / ends, N, '*', low qualities, depth-0 lines ("*\\t*"), qualities
@@ -169,7 +169,7 @@ def varscan_pileup(seed, n_lines=3000, contigs=("ctgA", "ctg_B|2"), eol=b"\n"):
         chrom = contigs[0] if k < n_lines // 2 else contigs[-1]
         pos += rng.choice((1, 1, 1, 1, 2, 17))
         ref = rng.choice("ACGTacgtN")
-        depth = rng.choice((0, 0, 3, 7, 8, 9, 12, 20, 30, 30, 45, 80))
+        depth = rng.choice(depths)
         if depth == 0:
             out.append(("%s\t%d\t%s\t0\t*\t*" % (chrom, pos, ref)).encode())
             continue

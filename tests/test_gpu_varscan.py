@@ -49,6 +49,21 @@ def test_var_flt_vcf_equals_oracle(d, tmp_path, seed, eol):
         assert n_lines == len([ln for ln in data.split(eol) if ln])
 
 
+def test_deep_and_mixed_lines_take_the_other_code_paths(d, tmp_path):
+    """Blocks whose lines do not fit the LDS span are walked in global memory (depth 1500-4000), blocks of 128 and 64 lines
+    (mean line length), and a file that mixes 4 KiB lines with short ones: all equal to the restatement."""
+    for seed, n, depths in ((21, 600, (1500, 2500, 4000, 30, 0)), (22, 3000, (150, 200, 120, 0)), (23, 3000, (300, 420, 8, 350)),
+                            (24, 2500, (30, 30, 30, 30, 30, 30, 30, 3000))):
+        data = fuzz.varscan_pileup(seed, n, depths=depths)
+        path = str(tmp_path / "deep.pileup")
+        with open(path, "wb") as f:
+            f.write(data)
+        for extra, kw in CASES[:2]:
+            out = str(tmp_path / "deep.vcf")
+            _vcf(d, path, out, extra)
+            assert open(out).read() == vo.mpileup2snp(data, vo.Params(**kw)), (seed, extra)
+
+
 def test_records_capacity_retry_and_order(d, tmp_path):
     from snp_pipeline_amd import varscan
     data = fuzz.varscan_pileup(5, 5000)
