@@ -213,3 +213,60 @@ def varscan_pileup(seed, n_lines=3000, contigs=("ctgA", "ctg_B|2"), eol=b"\n", d
             line += "\t" + "]" * depth
         out.append(line.encode())
     return eol.join(out) + (eol if rng.random() < 0.5 else b"")
+
+
+def cohort_pileups(seed, n_samples=6, genome_len=5000, contigs=("ctg1", "ctg2"), mean_depth=26):
+    """A small outbreak: one reference, shared SNP sites (scattered ones, a dense cluster, two near a contig end), samples in
+    two clades that carry a site with probability 0.85 / 0.1, reads with sequencing errors, read starts / ends, a few indels,
+    '*', low qualities.  Returns (reference {contig: str}, [pileup bytes per sample])."""
+    rng = random.Random(seed)
+    refs = {c: "".join(rng.choice("ACGT") for _ in range(genome_len)) for c in contigs}
+    plan = {}                                                  # (contig, pos) -> (alt, clade)
+    for c in contigs:
+        pos = set(rng.sample(range(150, genome_len - 150), 36))
+        start = rng.randrange(1000, genome_len - 1000)
+        pos.update(start + k for k in (0, 9, 23, 40, 41, 77))  # dense cluster
+        pos.update((40, genome_len - 30))                      # edge sites
+        for p in sorted(pos):
+            plan[(c, p)] = (rng.choice([b for b in "ACGT" if b != refs[c][p - 1]]), rng.randrange(2))
+    piles = []
+    for s in range(n_samples):
+        srng = random.Random(seed * 1000 + s)
+        carried = {k for k, (_, clade) in plan.items() if srng.random() < (0.85 if clade == s % 2 else 0.1)}
+        lines = []
+        for c in contigs:
+            ref = refs[c]
+            for pos in range(1, genome_len + 1):
+                if srng.random() < 0.004:
+                    continue
+                depth = max(0, int(srng.gauss(mean_depth, mean_depth ** 0.5)))
+                r = ref[pos - 1]
+                if depth == 0:
+                    lines.append("%s\t%d\t%s\t0\t*\t*\n" % (c, pos, r))
+                    continue
+                toks, quals = [], []
+                for _ in range(depth):
+                    fwd = srng.random() < 0.5
+                    if (c, pos) in carried and srng.random() < 0.97:
+                        b = plan[(c, pos)][0]
+                        t = b if fwd else b.lower()
+                    elif srng.random() < 0.004:
+                        b = srng.choice([x for x in "ACGT" if x != r])
+                        t = b if fwd else b.lower()
+                    elif srng.random() < 0.002:
+                        t = srng.choice("*Nn")
+                    else:
+                        t = "." if fwd else ","
+                    if srng.random() < 1 / 120:
+                        t = "^" + chr(33 + srng.randint(0, 42)) + t
+                    if t != "*" and srng.random() < 2e-3:
+                        k = srng.randint(1, 3)
+                        seq = "".join(srng.choice("ACGT") for _ in range(k))
+                        t += srng.choice("+-") + str(k) + (seq if fwd else seq.lower())
+                    if srng.random() < 1 / 120:
+                        t += "$"
+                    toks.append(t)
+                    quals.append(chr(33 + min(41, max(2, int(round(srng.gauss(33, 7)))))))
+                lines.append("%s\t%d\t%s\t%d\t%s\t%s\n" % (c, pos, r, depth, "".join(toks), "".join(quals)))
+        piles.append("".join(lines).encode())
+    return refs, piles

@@ -1,0 +1,109 @@
+"""The post-alignment pipeline end to end through the console script, the way run.py chains it (run.py:672-784, steps 4-11),
+on a small synthetic outbreak: call_sites -> filter_regions -> merge_sites -> call_consensus -> snp_matrix -> distance ->
+snp_reference, each stage reading the files the stage before wrote.  Every artifact is compared with the chain of CPU
+restatements fed with the same pileups (varscan_oracle -> steps_oracle -> pileup_oracle -> steps_oracle)."""
+import os
+import time
+
+import pytest
+
+from oracle import fuzz
+from oracle import pileup_oracle as po
+from oracle import steps_oracle as so
+from oracle import varscan_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(line):
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    args = cli.parse_command_line(line)
+    args.verbose = 0
+    assert cli.run_command_from_args(args) == 0
+
+
+def _fasta(name, seq):
+    return ">%s\n" % name + "".join(seq[i:i + 60] + "\n" for i in range(0, len(seq), 60))
+
+
+def test_pipeline_stages_chained_on_a_synthetic_outbreak(tmp_path, monkeypatch):
+    refs, piles = fuzz.cohort_pileups(7, n_samples=6, genome_len=4000)
+    names = ["iso%02d" % i for i in range(len(piles))]
+    work = tmp_path
+    ref_path = work / "reference" / "ref.fasta"
+    ref_path.parent.mkdir()
+    ref_path.write_text("".join(_fasta(c, refs[c]) for c in refs))
+    old = time.time() - 1000
+    os.utime(str(ref_path), (old, old))
+    dirs = []
+    for name, data in zip(names, piles):
+        sdir = work / "samples" / name
+        sdir.mkdir(parents=True)
+        bam = sdir / "reads.sorted.deduped.indelrealigned.bam"
+        bam.write_bytes(b"placeholder: the pileup below is newer, so samtools is not run (call_sites.py:70-72)")
+        os.utime(str(bam), (old, old))
+        (sdir / "reads.all.pileup").write_bytes(data)
+        dirs.append(str(sdir))
+    dirs_file = str(work / "sampleDirectories.txt")
+    with open(dirs_file, "w") as f:
+        f.write("\n".join(reversed(dirs)) + "\n")
+    monkeypatch.setenv("VarscanMpileup2snp_ExtraParams", "--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5")
+    monkeypatch.chdir(work)
+
+    # ---- step 4 (second half): call_sites -> var.flt.vcf ----
+    vprm = vo.Params(**vo.PIPELINE_DEFAULTS)
+    sites = {}
+    for name, data, sdir in zip(names, piles, dirs):
+        _run("call_sites %s %s" % (ref_path, sdir))
+        want = vo.mpileup2snp(data, vprm)
+        assert open(os.path.join(sdir, "var.flt.vcf")).read() == want, name
+        sites[name] = [(ln.split("\t")[0], int(ln.split("\t")[1])) for ln in want.splitlines() if not ln.startswith("#")]
+        assert len(sites[name]) > 10
+    # ---- step 5: filter_regions ----
+    lens = {c: len(refs[c]) for c in refs}
+    _run("filter_regions -n var.flt.vcf %s %s --edge_length 100 --window_size 1000 125 15 --max_snp 3 2 1 --mode all" % (dirs_file, ref_path))
+    bad = so.bad_regions([(n, sites[n]) for n in names], lens, 100, [3, 2, 1], [1000, 125, 15], mode="all")
+    kept, removed = {}, {}
+    for name, sdir in zip(names, dirs):
+        kept[name] = [k for k in sites[name] if not so.in_region(k[1], bad.get(k[0], []))]
+        removed[name] = [k for k in sites[name] if so.in_region(k[1], bad.get(k[0], []))]
+        src = [ln for ln in open(os.path.join(sdir, "var.flt.vcf")).read().splitlines(True) if not ln.startswith("#")]
+        for fname, keys in (("var.flt_preserved.vcf", kept[name]), ("var.flt_removed.vcf", removed[name])):
+            got = [ln for ln in open(os.path.join(sdir, fname)).read().splitlines(True) if not ln.startswith("#")]
+            keyset = set(keys)
+            assert got == [ln for ln in src if (ln.split("\t")[0], int(ln.split("\t")[1])) in keyset], (name, fname)
+    assert sum(len(v) for v in removed.values()) > 10 and sum(len(v) for v in kept.values()) > 50
+    # ---- step 6: merge_sites on the preserved files ----
+    snplist = str(work / "snplist_preserved.txt")
+    _run("merge_sites -n var.flt_preserved.vcf -o %s %s %s.filtered" % (snplist, dirs_file, dirs_file))
+    merged, excluded = so.merge_sites([(d, n, kept[n]) for d, n in sorted(zip(dirs, names))])
+    assert open(snplist).read() == so.snplist_text(merged) and not excluded
+    snp_keys = [(k[0].encode(), k[1]) for k, _ in merged]
+    # ---- step 7: call_consensus per sample, with the removed sites as the exclude file, and a consensus.vcf ----
+    cprm = po.CallerParams(15, 0.9, 5, 2, 0.1)
+    seqs = {}
+    for name, data, sdir in zip(names, piles, dirs):
+        _run("call_consensus -l %s -e %s/var.flt_removed.vcf -o %s/consensus_preserved.fasta -q 15 -c 0.9 -D 5 -d 2 -b 0.1 "
+             "--vcfRefName ref.fasta --vcfFileName consensus_preserved.vcf %s/reads.all.pileup" % (snplist, sdir, sdir, sdir))
+        want, _ = po.call_consensus_sites(data, snp_keys, set((c.encode(), p) for c, p in removed[name]), cprm)
+        seqs[name] = want.decode()
+        assert open(os.path.join(sdir, "consensus_preserved.fasta")).read() == _fasta(name, seqs[name]), name
+        rows = [ln for ln in open(os.path.join(sdir, "consensus_preserved.vcf")).read().splitlines() if not ln.startswith("#")]
+        assert len(snp_keys) - 4 <= len(rows) <= len(snp_keys)  # one row per snplist position that has a pileup line
+    # ---- steps 8 / 11: snp_matrix, distance ----
+    snpma = str(work / "snpma_preserved.fasta")
+    _run("snp_matrix -c consensus_preserved.fasta -o %s %s.filtered" % (snpma, dirs_file))
+    assert open(snpma).read() == "".join(_fasta(n, seqs[n]) for n in sorted(names))
+    _run("distance -p %s/pairs.tsv -m %s/matrix.tsv %s" % (work, work, snpma))
+    ids, table = so.distance_tables(seqs)
+    assert open(str(work / "pairs.tsv")).read() == so.pairwise_text(ids, table)
+    assert open(str(work / "matrix.tsv")).read() == so.matrix_text(ids, table)
+    assert max(table.values()) > 10                         # the two clades are apart
+    # ---- step 9: snp_reference ----
+    _run("snp_reference -l %s -o %s/referenceSNP_preserved.fasta %s" % (snplist, work, ref_path))
+    want_ref = ""
+    for c in sorted(refs):
+        bases = "".join(refs[c][p - 1].upper() for k, p in [kk for kk, _ in merged] if k == c)
+        if bases:
+            want_ref += _fasta(c, bases)
+    assert open(str(work / "referenceSNP_preserved.fasta")).read() == want_ref
