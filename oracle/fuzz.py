@@ -215,7 +215,7 @@ def varscan_pileup(seed, n_lines=3000, contigs=("ctgA", "ctg_B|2"), eol=b"\n", d
     return eol.join(out) + (eol if rng.random() < 0.5 else b"")
 
 
-def cohort_pileups(seed, n_samples=6, genome_len=5000, contigs=("ctg1", "ctg2"), mean_depth=26):
+def cohort_pileups(seed, n_samples=6, genome_len=5000, contigs=("ctg1", "ctg2"), mean_depth=26, n_scattered=36):
     """A small outbreak: one reference, shared SNP sites (scattered ones, a dense cluster, two near a contig end), samples in
     two clades that carry a site with probability 0.85 / 0.1, reads with sequencing errors, read starts / ends, a few indels,
     '*', low qualities.  Returns (reference {contig: str}, [pileup bytes per sample])."""
@@ -223,7 +223,7 @@ def cohort_pileups(seed, n_samples=6, genome_len=5000, contigs=("ctg1", "ctg2"),
     refs = {c: "".join(rng.choice("ACGT") for _ in range(genome_len)) for c in contigs}
     plan = {}                                                  # (contig, pos) -> (alt, clade)
     for c in contigs:
-        pos = set(rng.sample(range(150, genome_len - 150), 36))
+        pos = set(rng.sample(range(150, genome_len - 150), n_scattered))
         start = rng.randrange(1000, genome_len - 1000)
         pos.update(start + k for k in (0, 9, 23, 40, 41, 77))  # dense cluster
         pos.update((40, genome_len - 30))                      # edge sites
