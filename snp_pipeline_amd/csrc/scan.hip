@@ -997,14 +997,22 @@ ScanConfig &scan_config() {
         c.blocks_per_cu = b && atoi(b) > 0 && atoi(b) <= 2 ? atoi(b) : 1;
         c.mode = m ? atoi(m) : 0;
         if (w && atoi(w) >= 1 && atoi(w) <= 16) c.waves = atoi(w);
-        for (auto f : {(const void *)k_scan_wave<false, 1>, (const void *)k_scan_wave<false, 2>, (const void *)k_scan_wave<false, 3>})
-            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
-        for (auto f : {(const void *)k_scan_wave<false, 0>, (const void *)k_scan_wave<false, 4>, (const void *)k_scan_wave<true, 0>})
-            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         c.ready = true;
     }
     return c;
+}
+// The scan kernels ask for more than 64 KiB of dynamic LDS; the permission is a per-device function attribute, so every
+// context sets it for its own device (a process may drive several GPUs: call_consensus_batch).
+void scan_allow_lds(snpgpu_ctx *ctx) {
+    if (ctx->scan_lds_attr) return;
+#ifdef SNPGPU_TUNING
+    for (auto f : {(const void *)k_scan_wave<false, 1>, (const void *)k_scan_wave<false, 2>, (const void *)k_scan_wave<false, 3>})
+        (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+    for (auto f : {(const void *)k_scan_wave<false, 0>, (const void *)k_scan_wave<false, 4>, (const void *)k_scan_wave<true, 0>})
+        (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    ctx->scan_lds_attr = true;
 }
 // Exactly blocks_per_cu workgroups fit on a CU (the LDS request is padded to make sure) and a full grid is
 // n_cu * blocks_per_cu, so every CU runs the same number of waves and equal shares finish together.
@@ -1083,6 +1091,7 @@ int snpgpu_scan_begin(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev
 int snpgpu_scan_range(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n, uint32_t n_waves,
                       uint64_t *d_totals, uint64_t *d_site_line, int want_depth) {
     const ScanConfig &c = scan_config();
+    scan_allow_lds(ctx);
     hipStream_t st = ctx->stream;
     if (n > (uint64_t)ctx->n_cu * c.blocks_per_cu * c.waves) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "too many samples for one scan launch");
     ScanArgs sa = scan_args(ss, c, d_table, n, d_totals, d_site_line, want_depth);
@@ -1120,6 +1129,7 @@ int snpgpu_scan_range(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev
 int snpgpu_scan_end(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n, uint32_t n_waves,
                     uint64_t *d_totals, uint64_t *d_site_line, int want_depth) {
     const ScanConfig &c = scan_config();
+    scan_allow_lds(ctx);
     hipStream_t st = ctx->stream;
     ScanArgs sa = scan_args(ss, c, d_table, n, d_totals, d_site_line, want_depth);
     const unsigned grid = (unsigned)((n_waves + c.waves - 1) / c.waves), threads = (unsigned)c.waves * 64;

@@ -534,8 +534,14 @@ int load_file(snpgpu_ctx *ctx, const char *path, uint8_t **d_file, uint64_t *siz
     (void)posix_fadvise(s.fd, 0, 0, POSIX_FADV_SEQUENTIAL);
     const size_t chunk = (size_t)16 << 20;
     std::vector<Job> jobs;
-    for (uint64_t off = 0, c = 0; off < n; off += chunk, ++c)
-        jobs.push_back(Job{0, off, n - off < chunk ? n - off : chunk, c == 0, off + chunk >= n, (uint32_t)c});
+    // the first pieces are small, so that the first copy starts after ~1 MiB has been read instead of after 16 (all readers
+    // start at once and each takes a few milliseconds per 16 MiB)
+    for (uint64_t off = 0, c = 0; off < n; ++c) {
+        const uint64_t want = c < 2 ? (uint64_t)1 << 20 : (c < 5 ? (uint64_t)1 << (18 + c) : chunk);      // 1, 1, 2, 4, 8, 16, 16, ... MiB
+        const uint64_t len = n - off < want ? n - off : want;
+        jobs.push_back(Job{0, off, len, c == 0, off + len >= n, (uint32_t)c});
+        off += len;
+    }
     const uint64_t J = jobs.size();
     unsigned hc = std::thread::hardware_concurrency();
     uint32_t n_readers = hc >= 32 ? 8 : (hc >= 8 ? hc / 2 : (hc > 1 ? hc - 1 : 1));

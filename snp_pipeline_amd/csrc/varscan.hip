@@ -315,11 +315,10 @@ __global__ __launch_bounds__(kThreads) void k_varscan_lines(const uint8_t *__res
 int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, const uint64_t *d_line_off, uint64_t n_lines,
                            const snpgpu_varscan_params *prm, snpgpu_varscan_site *d_sites, uint32_t capacity, uint32_t *d_n, uint64_t *d_status) {
     if (n_lines == 0) return SNPGPU_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->varscan_lds_attr) {                                   // per device, so per context
         for (auto f : {(const void *)k_varscan_lines<256>, (const void *)k_varscan_lines<128>, (const void *)k_varscan_lines<64>})
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VS_LDS_BYTES);
-        attr_set = true;
+        ctx->varscan_lds_attr = true;
     }
     // lines per block by the mean line length, so that a block's span fits the 32 KiB it may stage (5 blocks per CU)
     const uint64_t mean = nbytes / n_lines + 1;
