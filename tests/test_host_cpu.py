@@ -487,3 +487,35 @@ def test_varscan_host_finish_reproduces_every_bundled_var_flt_vcf_line():
     assert (p.min_coverage, p.min_reads2, p.min_avg_qual, p.min_var_freq) == (3, 2, 15, 0.2)
     assert varscan.strand_filter_fails(10, 10, 0, 20) and not varscan.strand_filter_fails(1, 0, 0, 20) and not varscan.strand_filter_fails(20, 0, 0, 20)
     assert not varscan.strand_filter_fails(10, 10, 10, 10) and varscan._sci(0.0) == "0E0" and varscan._sci(9.99996e-5) == "1E-4"
+
+
+def test_call_sites_input_errors_follow_the_reference_protocol(tmp_path, monkeypatch, capsys):
+    """call_sites.py:53-60: a missing / empty reference is a global error (exit 100), a missing BAM a sample error (exit 100, or 98
+    with StopOnSampleError=false); the BAM name follows RemoveDuplicateReads / EnableLocalRealignment (call_sites.py:55-59).
+    Nothing here touches the device."""
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    log = tmp_path / "error.log"
+    monkeypatch.setenv("errorOutputFile", str(log))
+    sdir = tmp_path / "samples" / "s1"
+    sdir.mkdir(parents=True)
+    ref = tmp_path / "ref.fasta"
+
+    def run():
+        args = cli.parse_command_line("call_sites -v 0 %s %s" % (ref, sdir))
+        with pytest.raises(SystemExit) as ei:
+            cli.run_command_from_args(args)
+        return ei.value.code
+
+    monkeypatch.delenv("StopOnSampleError", raising=False)
+    assert run() == 100 and "Reference file" in log.read_text()
+    ref.write_text(">c\nACGT\n")
+    log.write_text("")
+    assert run() == 100 and "reads.sorted.deduped.indelrealigned.bam" in log.read_text()
+    monkeypatch.setenv("StopOnSampleError", "false")
+    monkeypatch.setenv("RemoveDuplicateReads", "false")
+    log.write_text("")
+    assert run() == 98 and "reads.sorted.indelrealigned.bam" in log.read_text()
+    monkeypatch.setenv("EnableLocalRealignment", "false")
+    log.write_text("")
+    assert run() == 98 and "Sample BAM file %s/reads.sorted.bam" % sdir in log.read_text()
+    capsys.readouterr()
