@@ -270,3 +270,34 @@ def cohort_pileups(seed, n_samples=6, genome_len=5000, contigs=("ctg1", "ctg2"),
                 lines.append("%s\t%d\t%s\t%d\t%s\t%s\n" % (c, pos, r, depth, "".join(toks), "".join(quals)))
         piles.append("".join(lines).encode())
     return refs, piles
+
+
+def varscan_adversarial(seed, n_lines=2000):
+    """Lines whose read-base column is arbitrary printable text (carets at the end, signs followed by huge or missing
+    numbers, indel tails that run off the column, digits everywhere, bytes >= 0x80) and whose quality column has any length
+    and any non-TAB byte: the walk must agree with its restatement on every one of them."""
+    rng = random.Random(seed)
+    alphabet = ".,.,.,ACGTacgtNn*^$+-0123456789<>#!~XYZxyz"
+    out = []
+    for k in range(n_lines):
+        depth = rng.choice((8, 9, 15, 30, 60, 200, 999999999))
+        n = rng.randint(8, 70)
+        bases = bytearray()
+        for _ in range(n):
+            r = rng.random()
+            if r < 0.8:
+                bases.append(ord(rng.choice(alphabet)))
+            elif r < 0.9:
+                bases += rng.choice((b"+", b"-")) + str(rng.choice((0, 1, 2, 5, 12, 300, 10 ** 15))).encode() + b"ACgtN"[:rng.randint(0, 5)]
+            elif r < 0.95:
+                bases.append(rng.randint(0x80, 0xFF))
+            else:
+                bases.append(rng.choice((0x20, 0x0B, 0x0C, 0x7F, 0x01)))
+        if rng.random() < 0.1:
+            bases += rng.choice((b"^", b"+", b"-", b"+1", b"^^", b"+3A"))
+        nq = rng.choice((n, n, n, n // 2, n + 9, 1))
+        quals = bytes(rng.choice((rng.randint(33, 126), rng.randint(33, 60), rng.randint(0x80, 0xFF), 0x20)) for _ in range(nq))
+        quals = quals.replace(b"\t", b"!").replace(b"\n", b"!").replace(b"\r", b"!")
+        ref = rng.choice("ACGTNacgtn*.")
+        out.append(b"c%d\t%d\t%s\t%d\t%s\t%s" % (k % 3, k + 1, ref.encode(), depth, bytes(bases), quals))
+    return b"\n".join(out) + b"\n"

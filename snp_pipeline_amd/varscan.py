@@ -222,7 +222,7 @@ def mpileup2snp(device, pileup_path, vcf_path, opts):
     """reads.all.pileup -> var.flt.vcf.  Returns (lines in the pileup, sites written)."""
     records, n_lines = device.varscan_file(pileup_path, opts.device_params())
     n_rows = 0
-    with open(vcf_path, "w") as out:
+    with open(vcf_path, "w", encoding="latin-1", newline="\n") as out:           # contig names pass through byte for byte
         out.write(header_text(opts.min_avg_qual))
         if len(records):
             with open(pileup_path, "rb") as f:

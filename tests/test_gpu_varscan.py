@@ -64,6 +64,25 @@ def test_deep_and_mixed_lines_take_the_other_code_paths(d, tmp_path):
             assert open(out).read() == vo.mpileup2snp(data, vo.Params(**kw)), (seed, extra)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_arbitrary_read_base_text_walks_like_the_restatement(d, tmp_path, seed):
+    """Adversarial columns (fuzz.varscan_adversarial): the LDS walk, the global-memory walk and the restatement agree."""
+    data = fuzz.varscan_adversarial(seed, 3000)
+    if seed == 4:                                               # the same lines between very long ones: blocks that walk global memory
+        long_line = b"cL\t1\tA\t9000\t" + b".,Aa" * 9000 + b"\t" + b"I5" * 18000 + b"\n"
+        lines = data.split(b"\n")
+        data = b"\n".join(lines[:500]) + b"\n" + long_line * 3 + b"\n".join(lines[500:])
+    path = str(tmp_path / "adv.pileup")
+    with open(path, "wb") as f:
+        f.write(data)
+    for extra, kw in CASES + [("--min-avg-qual 0 --min-var-freq 0.05 --min-reads2 1 --min-coverage 1 --strand-filter 0",
+                               dict(min_avg_qual=0, min_var_freq=0.05, min_reads2=1, min_coverage=1, strand_filter=0)),
+                              ("--min-avg-qual 100 --min-coverage 1 --min-reads2 1 --min-var-freq 0.01", dict(min_avg_qual=100, min_coverage=1, min_reads2=1, min_var_freq=0.01))]:
+        out = str(tmp_path / "adv.vcf")
+        _vcf(d, path, out, extra)
+        assert open(out, encoding="latin-1").read() == vo.mpileup2snp(data, vo.Params(**kw)), (seed, extra)
+
+
 def test_records_capacity_retry_and_order(d, tmp_path):
     from snp_pipeline_amd import varscan
     data = fuzz.varscan_pileup(5, 5000)
