@@ -46,10 +46,16 @@ def consensus_for_sample(dev, pileup_bytes, snp_list, excluded_positions, params
     return consensus_string(ss, n_keys, res), ss, res
 
 
-def _raise_as_reference(err):
+def _raise_as_reference(err, pileup_path=None):
     """Re-raise a device-detected malformed pileup as the exception class the reference raises for it, so that the
     error log names the same exception type (utils.handle_sample_exception prints ``exc_type.__name__``)."""
     exc = getattr(err, "reference_exception", None)
+    if getattr(err, "scan_code", 0) == 3 and pileup_path:
+        # A byte >= 0x80.  The reference reads the pileup as text (pileup.py:405, the locale's encoding: UTF-8 on the
+        # pipeline's platforms), so a file that is not valid UTF-8 ends its run with UnicodeDecodeError: the same here.
+        # (Valid multi-byte characters are the one input that is still refused: they would count as single symbols.)
+        with open(pileup_path, "rb") as f:
+            f.read().decode("utf-8")
     if exc is None:
         raise err
     raise exc(str(err))
@@ -79,7 +85,7 @@ def _write_outputs(plan, dev, ss, n_keys, res):
             try:
                 line_off, _, counts = dev.call_all_lines(ss, plan.pileup_path, params, capacity=res.n_lines)
             except devmod.PileupFormatError as err:
-                _raise_as_reference(err)
+                _raise_as_reference(err, plan.pileup_path)
             vcf_writer.write_all_positions_vcf(plan.vcf_path, plan.sample_name, args, plan.pileup_path, line_off, counts)
         elif res.n_matched > int(np.count_nonzero(res.line_offsets)):
             # a pileup that repeats a position: the reference writes a row for every matching LINE (call_consensus.py:178-180),
@@ -150,7 +156,7 @@ def call_consensus(args):
     try:
         dev.raise_file_status(all_pileup_file_path, int(rcs[0]), results[0])
     except devmod.PileupFormatError as err:
-        _raise_as_reference(err)
+        _raise_as_reference(err, all_pileup_file_path)
     _write_outputs(plan, dev, ss, n_keys, results[0])
 
 

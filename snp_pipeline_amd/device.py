@@ -183,8 +183,10 @@ class Device(object):
         w0 = int(status[0])
         if w0 != 0xFFFFFFFFFFFFFFFF:
             code, off = w0 & 0xFF, (w0 >> 8) - 1
-            raise PileupFormatError("pileup: %s at byte offset %d" % (_SCAN_CODES.get(code, "malformed line"), off),
+            err = PileupFormatError("pileup: %s at byte offset %d" % (_SCAN_CODES.get(code, "malformed line"), off),
                                     _SCAN_EXC.get(code, ValueError))
+            err.scan_code = code
+            raise err
 
     def call_consensus(self, siteset, pileup, params, want_counts=False, want_depth_sum=False, check=True):
         """pileup: bytes-like (host).  Returns ConsensusResult over siteset.keys order.  check=False: do not raise for

@@ -179,6 +179,15 @@ def test_call_consensus_cli_error_paths(tmp_path, monkeypatch):
     (tmp_path / "corrupt.txt").write_text("c\tnot_a_number\n")
     with pytest.raises(ValueError):
         _run("call_consensus -f -l %s/corrupt.txt -o %s/c.fasta %s" % (tmp_path, tmp_path, pile))
+    # a pileup that is not valid UTF-8 ends the reference's text-mode read with UnicodeDecodeError: same exception class here;
+    # valid multi-byte characters are refused as what they are
+    from snp_pipeline_amd.device import PileupFormatError
+    pile.write_bytes(b"c\t1\tA\t3\t.\xff.\tIII\n")
+    with pytest.raises(UnicodeDecodeError):
+        _run("call_consensus -f -l %s/snplist.txt -o %s/c.fasta %s" % (tmp_path, tmp_path, pile))
+    pile.write_bytes("c\t1\tA\t3\t.\u00e9.\tIII\n".encode("utf-8"))
+    with pytest.raises(PileupFormatError):
+        _run("call_consensus -f -l %s/snplist.txt -o %s/c.fasta %s" % (tmp_path, tmp_path, pile))
 
 
 def test_console_script_subprocess_without_torch(tmp_path):
