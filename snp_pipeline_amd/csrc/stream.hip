@@ -448,7 +448,7 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
                 const double t0 = now_s();
                 for (;;) {
                     bool progress = false;
-                    while (copies_done < (int64_t)j && hipEventQuery(p->ev_copy[copies_done % R]) == hipSuccess) { ++copies_done; progress = true; }
+                    while (copies_done < (int64_t)j && hipEventQuery(p->ev_copy[copies_done % R]) != hipErrorNotReady) { ++copies_done; progress = true; }   // (an error counts as done: the next HIP call reports it, nobody waits forever)
                     std::unique_lock<std::mutex> lk(sh.mu);
                     if (progress) { sh.freed = copies_done; lk.unlock(); sh.cv.notify_all(); lk.lock(); }
                     if (sh.filled[j]) break;
@@ -575,7 +575,7 @@ int load_file(snpgpu_ctx *ctx, const char *path, uint8_t **d_file, uint64_t *siz
         for (uint64_t j = 0; j < J && he == hipSuccess; ++j) {
             for (;;) {                                          // wait for chunk j; retire finished copies meanwhile
                 bool progress = false;
-                while (copies_done < (int64_t)j && hipEventQuery(p->ev_copy[copies_done % R]) == hipSuccess) { ++copies_done; progress = true; }
+                while (copies_done < (int64_t)j && hipEventQuery(p->ev_copy[copies_done % R]) != hipErrorNotReady) { ++copies_done; progress = true; }   // (an error counts as done: the next HIP call reports it, nobody waits forever)
                 std::unique_lock<std::mutex> lk(sh.mu);
                 if (progress) { sh.freed = copies_done; lk.unlock(); sh.cv.notify_all(); lk.lock(); }
                 if (sh.filled[j]) break;
