@@ -238,6 +238,22 @@ typedef struct snpgpu_varscan_site {
 int  snpgpu_varscan_file(snpgpu_ctx *ctx, const char *path, const snpgpu_varscan_params *params, uint32_t capacity,
                          snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status);
 
+/* The host half of the same step (no device work, no context): the records of snpgpu_varscan_file, in its order, ->
+ * var.flt.vcf data lines.  Per line: the allele with the most variant reads among those whose Fisher p (reads against a
+ * 0.1 % error model, VarScan.getSignificance) is <= p_value; strand filter (FILTER str10); GT 1/1 at or above
+ * min_freq_for_hom, else 0/1; chrom and position text are taken from `pileup` (the file's bytes, e.g. an mmap) at the
+ * record's line offset.  Writes at most `capacity` bytes to `out` (may be NULL), returns the bytes the lines take and
+ * leaves their number in *out_rows. */
+typedef struct snpgpu_varscan_finish {
+    double  p_value;                /* --p-value, default 0.99 */
+    double  min_freq_for_hom;       /* --min-freq-for-hom, default 0.75 */
+    int32_t strand_filter;          /* --strand-filter, default 1 */
+    int32_t reserved;
+} snpgpu_varscan_finish;
+size_t snpgpu_varscan_format_rows(const snpgpu_varscan_site *sites, uint32_t n_sites, const uint8_t *pileup,
+                                  uint64_t pileup_bytes, const snpgpu_varscan_finish *fin, char *out, size_t capacity,
+                                  uint32_t *out_rows);
+
 /* consensus.vcf data lines from per-site records — host-side text formatting, no device work, no context
  * (vcf_writer.py:295-435: _make_vcf_record_from_pileup + the text PyVCF3's Writer emits for it).  Row r is the record
  * counts[order[r]] (order == NULL: r) of site site_keys[order[r]] = (contig index << 32) | position, contig names as

@@ -53,6 +53,10 @@ class VarscanParams(C.Structure):
                 ("reserved", C.c_uint32), ("min_var_freq", C.c_double)]
 
 
+class VarscanFinish(C.Structure):
+    _fields_ = [("p_value", C.c_double), ("min_freq_for_hom", C.c_double), ("strand_filter", C.c_int32), ("reserved", C.c_int32)]
+
+
 class VarscanSite(C.Structure):
     _fields_ = [("line_off", C.c_uint64), ("sdp", C.c_uint32), ("dp", C.c_uint32), ("total", C.c_uint32),
                 ("rdf", C.c_uint32), ("rdr", C.c_uint32), ("ref_qual_sum", C.c_uint32),
@@ -95,6 +99,7 @@ SIGNATURES = {
     "snpgpu_distance_packed_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     "snpgpu_distance": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P]),
     "snpgpu_varscan_file": (C.c_int, [_P, C.c_char_p, _P, C.c_uint32, _P, C.POINTER(C.c_uint32), _P]),
+    "snpgpu_varscan_format_rows": (C.c_size_t, [_P, C.c_uint32, _P, C.c_uint64, _P, _P, C.c_size_t, C.POINTER(C.c_uint32)]),
     "snpgpu_write_distance_tsv": (C.c_int, [C.c_char_p, C.c_int, _P, _P, C.c_uint32, _P, C.c_uint64]),
     "snpgpu_dense_windows": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_uint32)]),
     "snpgpu_merge_regions": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_uint32)]),

@@ -3,17 +3,16 @@
 Replaces the VarScan v2.3.9 jar that snppipeline/call_sites.py:89-108 shells out to (third-party, not in the reference
 tree).  The device pass (csrc/varscan.hip through ``Device.varscan_file``) does the per-line counting and the
 min-coverage / min-reads2 / min-avg-qual / min-var-freq tests and returns one record per passing (line, allele); this
-module finishes the few records that come back: Fisher's exact test against a 0.1 % error model (``PVAL``, ``GQ``,
-``--p-value``), the strand filter, the homozygous threshold, and VarScan's VCF 4.1 text.  The text and the arithmetic are
-pinned by the 69 019 data lines of the reference's bundled var.flt.vcf fixtures (tests/test_host_cpu.py feeds every line's
-own counts back in); how unusual read-base strings are counted is not (see oracle/varscan_oracle.py and DESIGN.md).
+module parses the options, and hands the few records that come back to the library's host code (csrc/varscan_rows.hip):
+Fisher's exact test against a 0.1 % error model (``PVAL``, ``GQ``, ``--p-value``), the strand filter, the homozygous
+threshold, and VarScan's VCF 4.1 text.  The text and the arithmetic are pinned by the 69 019 data lines of the reference's
+bundled var.flt.vcf fixtures (tests/test_host_cpu.py feeds every line's own counts back in); how unusual read-base strings
+are counted is not (see oracle/varscan_oracle.py and DESIGN.md).
 """
 from __future__ import print_function
 
-import math
 import mmap
 import shlex
-from decimal import ROUND_HALF_EVEN, Decimal
 
 from . import _lib as L
 
@@ -85,152 +84,42 @@ def header_text(min_avg_qual=15):
     return "".join(line.replace("{q}", str(min_avg_qual)) + "\n" for line in _HEADER_LINES)
 
 
-# ---- Fisher's exact test on 2 x 2 tables, terms from log-factorials --------------------------------------------------
-class _Hypergeometric(object):
-    def __init__(self):
-        self.logfact = [0.0]
-
-    def _upto(self, n):
-        t = self.logfact
-        while len(t) <= n:
-            t.append(t[-1] + math.log(len(t)))
-
-    def term(self, a, b, c, d):
-        n = a + b + c + d
-        self._upto(n)
-        t = self.logfact
-        return math.exp(t[a + b] + t[c + d] + t[a + c] + t[b + d] - (t[a] + t[b] + t[c] + t[d] + t[n]))
-
-    def right_tail(self, a, b, c, d):
-        total = self.term(a, b, c, d)
-        steps = c if c < b else b
-        for k in range(1, steps + 1):
-            total += self.term(a + k, b - k, c - k, d + k)
-        return total
-
-    def two_tails(self, a, b, c, d):
-        here = self.term(a, b, c, d)
-        total = here
-        for k in range(1, min(a, d) + 1):
-            t = self.term(a - k, b + k, c + k, d - k)
-            if t <= here:
-                total += t
-        for k in range(1, min(b, c) + 1):
-            t = self.term(a + k, b - k, c - k, d + k)
-            if t <= here:
-                total += t
-        return total
-
-
-_HG = _Hypergeometric()
-_PVALUES = {}
-
-
-def variant_p_value(reads1, reads2):
-    """VarScan.getSignificance: (reads1, reads2) against the split a 0.001 error rate predicts at that coverage."""
-    key = (reads1, reads2)
-    p = _PVALUES.get(key)
-    if p is None:
-        cover = reads1 + reads2
-        expected2 = int(cover * 0.001)
-        p = _PVALUES[key] = _HG.right_tail(cover - expected2, expected2, reads1, reads2)
-    return p
-
-
-def _sci(p):
-    """Java DecimalFormat("0.####E0")."""
-    if p == 0.0:
-        return "0E0"
-    d = Decimal(p)
-    exp10 = d.adjusted()
-    mant = d.scaleb(-exp10).quantize(Decimal("0.0001"), rounding=ROUND_HALF_EVEN)
-    if mant >= 10:
-        exp10 += 1
-        mant = d.scaleb(-exp10).quantize(Decimal("0.0001"), rounding=ROUND_HALF_EVEN)
-    text = format(mant, "f").rstrip("0").rstrip(".")
-    return "%sE%d" % (text, exp10)
-
-
-_PERCENT_TEXT = {}
-
-
-def _percent(part, whole):
-    """Java DecimalFormat("###.##") of part / whole * 100, with the % sign."""
-    key = (part, whole)
-    text = _PERCENT_TEXT.get(key)
-    if text is None:
-        value = Decimal((float(part) / float(whole)) * 100.0).quantize(Decimal("0.01"), rounding=ROUND_HALF_EVEN)
-        text = _PERCENT_TEXT[key] = format(value, "f").rstrip("0").rstrip(".") + "%"
-    return text
-
-
-def strand_filter_fails(rdf, rdr, adf, adr):
-    """str10: >90 % of the variant reads on one strand, a reference count of 2+ that is not itself that lopsided, and a
-    two-tailed Fisher p < 0.01 between the two strand splits."""
-    var_plus = float(adf) / float(adf + adr)
-    if 0.10 <= var_plus <= 0.90 or rdf + rdr < 2:
-        return False
-    ref_plus = float(rdf) / float(rdf + rdr)
-    return 0.10 <= ref_plus <= 0.90 and _HG.two_tails(rdf, rdr, adf, adr) < 0.01
-
-
-_P_TEXT = {}
-
-
-def data_line(chrom, pos, ref, alt, sdp, dp, total, rdf, rdr, rbq, adf, adr, abq, p, homozygous, filter_text="PASS"):
-    pt = _P_TEXT.get(p)
-    if pt is None:
-        pt = _P_TEXT[p] = (255 if p <= 0.0 else min(255, int(-10.0 * math.log10(p))), _sci(p))
-    rd, ad = rdf + rdr, adf + adr
-    sample = "%s:%d:%d:%d:%d:%d:%s:%s:%d:%d:%d:%d:%d:%d" % ("1/1" if homozygous else "0/1", pt[0], sdp, dp, rd, ad, _percent(ad, total), pt[1],
-                                                            rbq, abq, rdf, rdr, adf, adr)
-    info = "ADP=%d;WT=0;HET=%d;HOM=%d;NC=0" % (dp, 0 if homozygous else 1, 1 if homozygous else 0)
-    return "%s\t%s\t.\t%s\t%s\t.\t%s\t%s\t%s\t%s\n" % (chrom, pos, ref, alt, filter_text, info, FORMAT_KEYS, sample)
-
-
-def rows_from_records(records, pileup_bytes, opts):
-    """records: Device.varscan_file's array (file order); pileup_bytes: the file (an mmap).  Yields the data lines."""
-    cols = [records[k].tolist() for k in ("line_off", "sdp", "dp", "total", "rdf", "rdr", "ref_qual_sum", "adf", "adr", "alt_qual_sum",
-                                          "ref_base", "alt_base")]
-    rows = list(zip(*cols))
-    i, n = 0, len(rows)
-    strand = bool(opts.strand_filter)
-    while i < n:
-        off = rows[i][0]
-        best = None
-        best_ad = -1
-        while i < n and rows[i][0] == off:                      # the alleles of one line: most reads wins, first on ties
-            r = rows[i]
-            ad = r[7] + r[8]
-            p = variant_p_value(r[4] + r[5], ad)
-            if p <= opts.p_value and ad > best_ad:
-                best, best_ad, best_p = r, ad, p
-            i += 1
-        if best is None:
-            continue
-        _, sdp, dp, total, rdf, rdr, rq, adf, adr, aq, ref, alt = best
-        t1 = pileup_bytes.find(b"\t", off)
-        t2 = pileup_bytes.find(b"\t", t1 + 1)
-        rd = rdf + rdr
-        fails = strand and strand_filter_fails(rdf, rdr, adf, adr)
-        yield data_line(pileup_bytes[off:t1].decode("latin-1"), pileup_bytes[t1 + 1:t2].decode("latin-1"), chr(ref), chr(alt), sdp, dp, total, rdf, rdr,
-                        rq // rd if rd else 0, adf, adr, aq // best_ad, best_p, float(best_ad) / float(total) >= opts.min_freq_for_hom,
-                        "str10" if fails else "PASS")
+def format_rows(records, pileup_bytes, opts):
+    """records: Device.varscan_file's array (file order); pileup_bytes: the file (bytes, or an mmap).  Returns (the data lines as
+    bytes, their number) — Fisher's exact test, --p-value, the strand filter, GT and the VCF text are the library's host code
+    (csrc/varscan_rows.hip)."""
+    import ctypes as C
+    import numpy as np
+    lib = L.load()
+    fin = L.VarscanFinish(opts.p_value, opts.min_freq_for_hom, 1 if opts.strand_filter else 0, 0)
+    recs = np.ascontiguousarray(records)
+    view = np.frombuffer(pileup_bytes, dtype=np.uint8)
+    n_rows = C.c_uint32()
+    cap = 256 * len(recs) + 4096
+    try:
+        while True:
+            out = C.create_string_buffer(cap)
+            need = lib.snpgpu_varscan_format_rows(recs.ctypes.data, len(recs), view.ctypes.data if len(view) else None, len(view), C.byref(fin),
+                                                  out, cap, C.byref(n_rows))
+            if need <= cap:
+                return out.raw[:need], n_rows.value
+            cap = need
+    finally:
+        del view                                               # an mmap cannot be closed while a view of it exists
 
 
 def mpileup2snp(device, pileup_path, vcf_path, opts):
     """reads.all.pileup -> var.flt.vcf.  Returns (lines in the pileup, sites written)."""
     records, n_lines = device.varscan_file(pileup_path, opts.device_params())
     n_rows = 0
-    with open(vcf_path, "w", encoding="latin-1", newline="\n") as out:           # contig names pass through byte for byte
-        out.write(header_text(opts.min_avg_qual))
+    with open(vcf_path, "wb") as out:                           # contig names pass through byte for byte
+        out.write(header_text(opts.min_avg_qual).encode("ascii"))
         if len(records):
             with open(pileup_path, "rb") as f:
                 view = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
                 try:
-                    for line in rows_from_records(records, view, opts):
-                        out.write(line)
-                        n_rows += 1
+                    text, n_rows = format_rows(records, view, opts)
+                    out.write(text)
                 finally:
                     view.close()
     return n_lines, n_rows

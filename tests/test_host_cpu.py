@@ -450,11 +450,16 @@ def test_library_distance_tsv_writer_equals_reference_layout(tmp_path, fixture_t
 
 
 def test_varscan_host_finish_reproduces_every_bundled_var_flt_vcf_line():
-    """snp_pipeline_amd/varscan.py (the product's host half of phase-1 site calling): header text and every data line of the 58
-    bundled var.flt.vcf files from the line's own counts; the ExtraParams parser; the strand filter on hand-made cases."""
+    """The product's host half of phase-1 site calling (csrc/varscan_rows.hip through varscan.format_rows): header text and every
+    data line of the 58 bundled var.flt.vcf files from the line's own counts; the ExtraParams parser; the strand filter,
+    allele choice and --p-value on hand-made records."""
     import tarfile
+    import numpy as np
+    from oracle import varscan_oracle as vo
     from snp_pipeline_amd import varscan
+    from snp_pipeline_amd.device import VARSCAN_DTYPE
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fixtures")
+    opts = varscan.Options("--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5")
     n = 0
     for ds in ("lambdaVirus", "agona", "listeria"):
         with tarfile.open(os.path.join(here, ds, "expected.tar.xz")) as t:
@@ -463,21 +468,27 @@ def test_varscan_host_finish_reproduces_every_bundled_var_flt_vcf_line():
                     continue
                 lines = t.extractfile(m).read().decode().splitlines(True)
                 assert "".join(ln for ln in lines if ln.startswith("#")) == varscan.header_text(15)
-                for ln in lines:
-                    if ln.startswith("#"):
-                        continue
+                data = [ln for ln in lines if not ln.startswith("#")]
+                # one record and one stand-in pileup line (chrom, position, then anything) per fixture line
+                recs = np.zeros(len(data), dtype=VARSCAN_DTYPE)
+                pile = bytearray()
+                for k, ln in enumerate(data):
                     f = ln.rstrip("\n").split("\t")
                     v = dict(zip(f[8].split(":"), f[9].split(":")))
                     rd, ad = int(v["RD"]), int(v["AD"])
                     total = rd + ad                                          # FREQ's denominator: indel reads count, DP does not matter
-                    while varscan._percent(ad, total) != v["FREQ"]:
+                    while vo.java_percent(ad, total) != v["FREQ"]:
                         total += 1
                         assert total < 4 * (rd + ad) + 64, ln
-                    got = varscan.data_line(f[0], f[1], f[3], f[4], int(v["SDP"]), int(v["DP"]), total, int(v["RDF"]), int(v["RDR"]), int(v["RBQ"]),
-                                            int(v["ADF"]), int(v["ADR"]), int(v["ABQ"]), varscan.variant_p_value(rd, ad), v["GT"] == "1/1", f[6])
-                    assert got == ln
-                    assert not varscan.strand_filter_fails(int(v["RDF"]), int(v["RDR"]), int(v["ADF"]), int(v["ADR"]))     # all bundled lines PASS
-                    n += 1
+                    r = recs[k]
+                    r["line_off"], r["sdp"], r["dp"], r["total"] = len(pile), int(v["SDP"]), int(v["DP"]), total
+                    r["rdf"], r["rdr"], r["adf"], r["adr"] = int(v["RDF"]), int(v["RDR"]), int(v["ADF"]), int(v["ADR"])
+                    r["ref_qual_sum"], r["alt_qual_sum"] = int(v["RBQ"]) * rd, int(v["ABQ"]) * ad
+                    r["ref_base"], r["alt_base"] = ord(f[3]), ord(f[4])
+                    pile += ("%s\t%s\tN\t0\t*\t*\n" % (f[0], f[1])).encode()
+                text, n_rows = varscan.format_rows(recs, bytes(pile), opts)
+                assert n_rows == len(data) and text.decode() == "".join(data), m.name
+                n += n_rows
     assert n == 69019
     o = varscan.Options("--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5")
     assert (o.min_coverage, o.min_reads2, o.min_avg_qual, o.min_var_freq, o.min_freq_for_hom, o.p_value, o.strand_filter) == (8, 5, 15, 0.9, 0.75, 0.99, 1)
@@ -485,8 +496,24 @@ def test_varscan_host_finish_reproduces_every_bundled_var_flt_vcf_line():
     assert (o.min_coverage, o.p_value, o.strand_filter, o.min_freq_for_hom, o.min_reads2) == (3, 1e-3, 0, 0.8, 2)
     p = o.device_params()
     assert (p.min_coverage, p.min_reads2, p.min_avg_qual, p.min_var_freq) == (3, 2, 15, 0.2)
-    assert varscan.strand_filter_fails(10, 10, 0, 20) and not varscan.strand_filter_fails(1, 0, 0, 20) and not varscan.strand_filter_fails(20, 0, 0, 20)
-    assert not varscan.strand_filter_fails(10, 10, 10, 10) and varscan._sci(0.0) == "0E0" and varscan._sci(9.99996e-5) == "1E-4"
+
+    # hand-made records: (rdf, rdr, adf, adr, total) -> FILTER / GT; two alleles on one line; --p-value
+    def one(rdf, rdr, adf, adr, total, alt="G", off=0):
+        r = np.zeros(1, dtype=VARSCAN_DTYPE)
+        r["line_off"], r["sdp"], r["dp"], r["total"], r["rdf"], r["rdr"], r["adf"], r["adr"] = off, total, total, total, rdf, rdr, adf, adr
+        r["ref_qual_sum"], r["alt_qual_sum"], r["ref_base"], r["alt_base"] = 30 * (rdf + rdr), 31 * (adf + adr), ord("A"), ord(alt)
+        return r
+    line = b"ctg\t77\tA\t40\t...\tIII\n"
+    dflt = varscan.Options("")
+    row = lambda recs, op=dflt: varscan.format_rows(recs, line, op)[0].decode().split("\t")
+    assert row(one(10, 10, 0, 20, 40))[6] == "str10" and row(one(1, 0, 0, 20, 21))[6] == "PASS" and row(one(20, 0, 0, 20, 40))[6] == "PASS"
+    assert row(one(10, 10, 10, 10, 40))[6] == "PASS" and row(one(10, 10, 0, 20, 40), varscan.Options("--strand-filter 0"))[6] == "PASS"
+    assert row(one(10, 10, 10, 10, 40))[9].startswith("0/1:") and row(one(2, 2, 20, 16, 40))[9].startswith("1/1:")
+    assert row(one(2, 2, 20, 16, 40))[:6] == ["ctg", "77", ".", "A", "G", "."]
+    both = np.concatenate([one(0, 0, 5, 5, 30, "C"), one(0, 0, 10, 10, 30, "T")])
+    assert row(both)[4] == "T" and row(np.concatenate([one(0, 0, 5, 5, 30, "C"), one(0, 0, 5, 5, 30, "T")]))[4] == "C"
+    assert varscan.format_rows(one(1000, 1000, 1, 1, 2002), line, varscan.Options("--p-value 0.05")) == (b"", 0)      # p = 0.75
+    assert varscan.format_rows(np.zeros(0, dtype=VARSCAN_DTYPE), b"", dflt) == (b"", 0)
 
 
 def test_call_sites_input_errors_follow_the_reference_protocol(tmp_path, monkeypatch, capsys):
