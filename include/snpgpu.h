@@ -238,6 +238,16 @@ typedef struct snpgpu_varscan_site {
 int  snpgpu_varscan_file(snpgpu_ctx *ctx, const char *path, const snpgpu_varscan_params *params, uint32_t capacity,
                          snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status);
 
+/* Many files in one call: the reader threads run ahead across file boundaries, the files alternate between two device
+ * slots, and a file's kernels run while the next file is read and copied (the shape of snpgpu_call_consensus_files).
+ * out_sites is [n_files][capacity], out_n_sites [n_files], out_status [n_files][2], out_rc [n_files] (SNPGPU_OK, SNPGPU_E_IO or
+ * SNPGPU_E_PILEUP per file; the call itself fails only for argument, memory or HIP errors).  A file with more records
+ * than `capacity` reports its count in out_n_sites and leaves out_sites undefined for it: repeat it with
+ * snpgpu_varscan_file. */
+int  snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, const snpgpu_varscan_params *params,
+                          uint32_t capacity, snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status,
+                          int32_t *out_rc);
+
 /* The host half of the same step (no device work, no context): the records of snpgpu_varscan_file, in its order, ->
  * var.flt.vcf data lines.  Per line: the allele with the most variant reads among those whose Fisher p (reads against a
  * 0.1 % error model, VarScan.getSignificance) is <= p_value; strand filter (FILTER str10); GT 1/1 at or above

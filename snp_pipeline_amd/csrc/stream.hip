@@ -777,4 +777,195 @@ int snpgpu_varscan_file(snpgpu_ctx *ctx, const char *path, const snpgpu_varscan_
     return SNPGPU_OK;
 }
 
+// Phase-1 site calling over many pileup files: the readers run ahead across file boundaries (one job list, one staging
+// ring, as in run_stream), the files alternate between two device slots, and a file's kernels and result copy run on the
+// compute stream while the next file is being read and copied.  out_sites: [n_files][capacity]; a file with more records
+// than `capacity` reports its count and the caller repeats it alone (snpgpu_varscan_file).
+int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, const snpgpu_varscan_params *params, uint32_t capacity,
+                         snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status, int32_t *out_rc) {
+    if (!ctx || !params || !out_n_sites || !out_status || !out_rc || (n_files && !paths) || (capacity && !out_sites))
+        return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (!n_files) return SNPGPU_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t chunk = (size_t)16 << 20;
+    std::vector<Source> src(n_files);
+    uint64_t max_size = 0;
+    for (uint32_t f = 0; f < n_files; ++f) {
+        Source &s = src[f];
+        s.path = paths[f];
+        s.fd = open(s.path, O_RDONLY | O_CLOEXEC);
+        struct stat stt;
+        if (s.fd < 0 || fstat(s.fd, &stt) != 0 || !S_ISREG(stt.st_mode)) {
+            if (s.fd >= 0) { close(s.fd); s.fd = -1; }
+            s.rc = SNPGPU_E_IO;
+            s.size = 0;
+        } else {
+            s.size = (uint64_t)stt.st_size;
+            (void)posix_fadvise(s.fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+        }
+        if (s.size > max_size) max_size = s.size;
+        out_n_sites[f] = 0;
+        out_status[2 * f] = ~0ull; out_status[2 * f + 1] = 0;
+    }
+    std::vector<Job> jobs;
+    for (uint32_t f = 0; f < n_files; ++f) {
+        const uint64_t n = src[f].size;
+        if (n == 0) { jobs.push_back(Job{f, 0, 0, true, true, 0}); continue; }
+        for (uint64_t off = 0, c = 0; off < n; ++c) {
+            // the very first pieces are small, so that the first copy starts after ~1 MiB has been read
+            const uint64_t want = f == 0 && c < 5 ? (c < 2 ? (uint64_t)1 << 20 : (uint64_t)1 << (18 + c)) : chunk;
+            const uint64_t len = n - off < want ? n - off : want;
+            jobs.push_back(Job{f, off, len, c == 0, off + len >= n, (uint32_t)c});
+            off += len;
+        }
+    }
+    const uint64_t J = jobs.size();
+    unsigned hc = std::thread::hardware_concurrency();
+    uint32_t n_readers = hc >= 32 ? 8 : (hc >= 8 ? hc / 2 : (hc > 1 ? hc - 1 : 1));
+    if (n_readers > J) n_readers = (uint32_t)J;
+    uint32_t n_staging = n_readers + 4;
+    if (n_staging > J) n_staging = (uint32_t)J;
+    const size_t r_rec = 256;                                  // result block: [0] u64 status, [8] u32 records found, [16] u32 lines; records at 256
+    const size_t result_bytes = r_rec + sizeof(snpgpu_varscan_site) * (size_t)capacity + 256;
+    auto close_all = [&]() { for (auto &s2 : src) if (s2.fd >= 0) { close(s2.fd); s2.fd = -1; } };
+    int rc = pool_ensure(ctx, chunk, n_staging, n_files > 1 ? 2 : 1, up(max_size + SNPGPU_SCAN_TILE + 256, 4096), result_bytes, 256);
+    if (rc) { close_all(); return rc; }
+    snpgpu_stream_pool *p = ctx->pool;
+    const uint64_t R = p->staging.size() < n_staging ? p->staging.size() : n_staging;
+    const uint32_t n_slots = n_files > 1 ? 2 : 1;
+    hipStream_t st = ctx->stream;
+    {
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { close_all(); return snpgpu_set_error(ctx, SNPGPU_E_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e)); }
+    }
+    Shared sh;
+    sh.R = R ? R : 1;
+    sh.filled.assign(J, 0);
+    sh.job_err.assign(J, 0);
+    std::vector<std::thread> readers;
+    try {
+        for (uint32_t i = 0; i < n_readers; ++i) readers.emplace_back(reader_main, ctx, &sh, &jobs, &src);
+    } catch (const std::exception &e) {
+        { std::lock_guard<std::mutex> lk(sh.mu); sh.abort = true; sh.next.store(J); }
+        sh.cv.notify_all();
+        for (auto &t : readers) t.join();
+        close_all();
+        return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "cannot start the reader threads: %s", e.what());
+    }
+    std::vector<uint8_t> has_result(n_files, 0);
+    auto harvest = [&](uint32_t f) -> int {                     // results of file f: pinned block -> the caller's arrays
+        if (!has_result[f]) return SNPGPU_OK;
+        const uint32_t slot = f % n_slots;
+        hipError_t e = hipEventSynchronize(p->ev_done[slot]);
+        if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_HIP, "waiting for the results of pileup %u failed: %s", f, hipGetErrorString(e));
+        const char *r = (const char *)p->result[slot];
+        uint64_t status;
+        uint32_t found;
+        memcpy(&status, r, 8);
+        memcpy(&found, r + 8, 4);
+        out_status[2 * f] = status;
+        out_n_sites[f] = found;
+        if (status != ~0ull) { if (src[f].rc == SNPGPU_OK) src[f].rc = SNPGPU_E_PILEUP; return SNPGPU_OK; }
+        const uint32_t got = found < capacity ? found : capacity;
+        snpgpu_varscan_site *dst = out_sites + (size_t)f * capacity;
+        if (got) memcpy(dst, r + r_rec, sizeof(snpgpu_varscan_site) * (size_t)got);
+        if (found <= capacity)
+            std::sort(dst, dst + got, [](const snpgpu_varscan_site &x, const snpgpu_varscan_site &y) {
+                return x.line_off != y.line_off ? x.line_off < y.line_off : x.alt_base < y.alt_base;
+            });
+        return SNPGPU_OK;
+    };
+#define VS_TRY(expr)                                                                                                \
+    do {                                                                                                            \
+        hipError_t e_ = (expr);                                                                                     \
+        if (e_ != hipSuccess) { rc = snpgpu_set_error(ctx, SNPGPU_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } \
+    } while (0)
+    {
+        uint32_t harvested = 0;
+        int64_t copies_done = 0;
+        for (uint64_t j = 0; j < J; ++j) {
+            const Job &jb = jobs[j];
+            const uint32_t f = jb.file, slot = f % n_slots;
+            Source &s = src[f];
+            uint8_t *d_file = (uint8_t *)p->slot[slot];
+            if (jb.first)                                       // the slot and its result block are free once their last user has been harvested
+                while (harvested + n_slots <= f) { rc = harvest(harvested); if (rc) goto done; ++harvested; }
+            for (;;) {                                          // wait for the piece to be read; retire finished copies meanwhile
+                bool progress = false;
+                while (copies_done < (int64_t)j && hipEventQuery(p->ev_copy[copies_done % R]) != hipErrorNotReady) { ++copies_done; progress = true; }
+                std::unique_lock<std::mutex> lk(sh.mu);
+                if (progress) { sh.freed = copies_done; lk.unlock(); sh.cv.notify_all(); lk.lock(); }
+                if (sh.filled[j]) break;
+                sh.cv.wait_for(lk, std::chrono::microseconds(copies_done < (int64_t)j ? 20 : 2000), [&] { return sh.filled[j] != 0; });
+                if (sh.filled[j]) break;
+            }
+            if (sh.job_err[j] && s.rc == SNPGPU_OK) s.rc = SNPGPU_E_IO;
+            hipStream_t cs = (j & 1) ? p->copy_stream2 : p->copy_stream;
+            if (jb.len) VS_TRY(hipMemcpyAsync(d_file + jb.off, p->staging[j % R], jb.len, hipMemcpyHostToDevice, cs));
+            VS_TRY(hipEventRecord(p->ev_copy[j % R], cs));
+            VS_TRY(hipStreamWaitEvent(st, p->ev_copy[j % R], 0));
+            if (!jb.last || s.rc != SNPGPU_OK || s.size == 0) continue;
+            // ---- the whole file is on its way: index its lines, walk them, results into the slot's pinned block ----
+            const uint64_t nbytes = s.size;
+            const size_t ws_words = snpgpu_lines_workspace_words(nbytes);
+            void *scr = nullptr;
+            rc = snpgpu_scratch(ctx, 2 * (up(4 * ws_words, 256) + 512), &scr);
+            if (rc) goto done;
+            size_t half = ctx->scratch_bytes / 2 / 256 * 256;
+            uint32_t *d_total = nullptr;
+            rc = snpgpu_enqueue_lines_count(ctx, d_file, nbytes, (uint32_t *)((char *)scr + half * slot), &d_total);
+            if (rc) goto done;
+            uint32_t n_lines = 0;
+            VS_TRY(hipMemcpyAsync(&n_lines, d_total, 4, hipMemcpyDeviceToHost, st));
+            VS_TRY(hipStreamSynchronize(st));                   // (also: the previous file's kernels and result copy are done)
+            out_status[2 * f + 1] = n_lines;
+            char *res = (char *)p->result[slot];
+            if (n_lines == 0) {
+                const uint64_t none = ~0ull;
+                memcpy(res, &none, 8);
+                memset(res + 8, 0, 8);
+                VS_TRY(hipEventRecord(p->ev_done[slot], st));
+                has_result[f] = 1;
+                continue;
+            }
+            size_t o = up(4 * ws_words, 256);
+            const size_t o_off = o; o += up(8ull * n_lines, 256);
+            const size_t o_ctl = o; o += 256;
+            const size_t o_rec = o; o += sizeof(snpgpu_varscan_site) * (size_t)capacity + 256;
+            rc = snpgpu_scratch(ctx, 2 * o + 512, &scr);        // may move the scratch: everything enqueued so far has finished (sync above)
+            if (rc) goto done;
+            half = ctx->scratch_bytes / 2 / 256 * 256;
+            char *b = (char *)scr + half * slot;
+            rc = snpgpu_enqueue_lines_count(ctx, d_file, nbytes, (uint32_t *)b, &d_total);
+            if (rc == SNPGPU_OK) rc = snpgpu_enqueue_lines_offsets(ctx, d_file, nbytes, (uint32_t *)b, (uint64_t *)(b + o_off), n_lines);
+            if (rc) goto done;
+            {
+                uint64_t h_ctl[2] = {~0ull, 0};
+                memcpy(res + 32, h_ctl, sizeof h_ctl);          // (a pinned source that stays valid until the copy has run)
+                VS_TRY(hipMemcpyAsync(b + o_ctl, res + 32, sizeof h_ctl, hipMemcpyHostToDevice, st));
+            }
+            rc = snpgpu_enqueue_varscan(ctx, d_file, nbytes, (const uint64_t *)(b + o_off), n_lines, params, (snpgpu_varscan_site *)(b + o_rec), capacity,
+                                        (uint32_t *)(b + o_ctl + 8), (uint64_t *)(b + o_ctl));
+            if (rc) goto done;
+            VS_TRY(hipMemcpyAsync(res, b + o_ctl, 16, hipMemcpyDeviceToHost, st));
+            if (capacity) VS_TRY(hipMemcpyAsync(res + r_rec, b + o_rec, sizeof(snpgpu_varscan_site) * (size_t)capacity, hipMemcpyDeviceToHost, st));
+            VS_TRY(hipEventRecord(p->ev_done[slot], st));
+            has_result[f] = 1;
+        }
+        while (harvested < n_files) { rc = harvest(harvested); if (rc) goto done; ++harvested; }
+    }
+done:
+#undef VS_TRY
+    {
+        std::lock_guard<std::mutex> lk(sh.mu);
+        if (rc) { sh.abort = true; sh.next.store(J); }
+    }
+    sh.cv.notify_all();
+    for (auto &t : readers) t.join();
+    if (rc) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamSynchronize(p->copy_stream2); (void)hipStreamSynchronize(st); }
+    close_all();
+    for (uint32_t f = 0; f < n_files; ++f) out_rc[f] = src[f].rc;
+    return rc;
+}
+
 }  // extern "C"

@@ -298,6 +298,31 @@ class Device(object):
                 return sites[:n.value], int(status[1])
             capacity = max(n.value, 2 * cap)
 
+    def varscan_files(self, paths, params, capacity=32768):
+        """varscan_file for many pileups in one streamed call (a file's kernels run while the next file is read and copied).
+        Returns [(records, lines)] in input order; a file that failed carries an exception object in place of its records
+        (PileupIOError / PileupFormatError), so that the caller can treat it as a sample error and go on."""
+        n = len(paths)
+        if n == 0:
+            return []
+        arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        sites = np.zeros((n, max(int(capacity), 1)), dtype=VARSCAN_DTYPE)
+        counts = np.zeros(n, dtype=np.uint32)
+        status = np.zeros((n, 2), dtype=np.uint64)
+        rcs = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.snpgpu_varscan_files(self.ctx, arr, n, C.byref(params), int(capacity), _ptr(sites), _ptr(counts), _ptr(status), _ptr(rcs)))
+        out = []
+        for i, path in enumerate(paths):
+            if rcs[i] == L.E_IO:
+                out.append((PileupIOError("cannot open or read the pileup file %s" % path), 0))
+            elif rcs[i] == L.E_PILEUP:
+                out.append((PileupFormatError("Invalid format for pileup at byte %d of %s" % (int(status[i, 0]), path), ValueError), int(status[i, 1])))
+            elif counts[i] > capacity:
+                out.append(self.varscan_file(path, params, capacity=int(counts[i])))           # more records than the shared array holds
+            else:
+                out.append((sites[i, :counts[i]].copy(), int(status[i, 1])))
+        return out
+
     def raise_file_status(self, path, rc, res, check=True):
         """Raise for one file of call_consensus_files the way call_consensus does for its single pileup."""
         if rc == L.E_IO:

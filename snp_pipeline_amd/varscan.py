@@ -108,9 +108,7 @@ def format_rows(records, pileup_bytes, opts):
         del view                                               # an mmap cannot be closed while a view of it exists
 
 
-def mpileup2snp(device, pileup_path, vcf_path, opts):
-    """reads.all.pileup -> var.flt.vcf.  Returns (lines in the pileup, sites written)."""
-    records, n_lines = device.varscan_file(pileup_path, opts.device_params())
+def _write_vcf(vcf_path, pileup_path, records, opts):
     n_rows = 0
     with open(vcf_path, "wb") as out:                           # contig names pass through byte for byte
         out.write(header_text(opts.min_avg_qual).encode("ascii"))
@@ -122,4 +120,21 @@ def mpileup2snp(device, pileup_path, vcf_path, opts):
                     out.write(text)
                 finally:
                     view.close()
-    return n_lines, n_rows
+    return n_rows
+
+
+def mpileup2snp_files(device, pileup_paths, vcf_paths, opts):
+    """Many samples in one streamed device call.  Returns [(lines, sites written) or the exception of that sample]."""
+    results = []
+    for (records, n_lines), pileup_path, vcf_path in zip(device.varscan_files(pileup_paths, opts.device_params()), pileup_paths, vcf_paths):
+        if isinstance(records, Exception):
+            results.append(records)
+        else:
+            results.append((n_lines, _write_vcf(vcf_path, pileup_path, records, opts)))
+    return results
+
+
+def mpileup2snp(device, pileup_path, vcf_path, opts):
+    """reads.all.pileup -> var.flt.vcf.  Returns (lines in the pileup, sites written)."""
+    records, n_lines = device.varscan_file(pileup_path, opts.device_params())
+    return n_lines, _write_vcf(vcf_path, pileup_path, records, opts)

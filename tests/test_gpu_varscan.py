@@ -83,6 +83,42 @@ def test_arbitrary_read_base_text_walks_like_the_restatement(d, tmp_path, seed):
         assert open(out, encoding="latin-1").read() == vo.mpileup2snp(data, vo.Params(**kw)), (seed, extra)
 
 
+def test_many_files_in_one_call_equal_single_calls(d, tmp_path):
+    """snpgpu_varscan_files: files of very different sizes, an empty one, a missing one, a malformed one, one with more
+    records than the shared array holds — each result equals the single-file call's."""
+    from snp_pipeline_amd import varscan
+    from snp_pipeline_amd.device import PileupFormatError, PileupIOError
+    opts = varscan.Options("--min-var-freq 0.2 --min-reads2 2")
+    blobs = [fuzz.varscan_pileup(31, 9000), fuzz.varscan_pileup(32, 300), b"", fuzz.varscan_pileup(33, 40000, depths=(20, 30, 30, 45)),
+             b"c\t1\tA\t9\tGGGGGGGGG\n", fuzz.varscan_pileup(34, 2500, eol=b"\r\n"), fuzz.varscan_pileup(35, 1)]
+    paths = []
+    for i, data in enumerate(blobs):
+        path = str(tmp_path / ("f%d.pileup" % i))
+        with open(path, "wb") as f:
+            f.write(data)
+        paths.append(path)
+    paths.insert(3, str(tmp_path / "missing.pileup"))
+    for capacity in (32768, 64):                                 # 64: most files overflow the shared array and are repeated alone
+        got = d.varscan_files(paths, opts.device_params(), capacity=capacity)
+        assert len(got) == len(paths)
+        for path, (recs, n_lines) in zip(paths, got):
+            if path.endswith("missing.pileup"):
+                assert isinstance(recs, PileupIOError)
+            elif path.endswith("f4.pileup"):
+                assert isinstance(recs, PileupFormatError) and "byte 0 " in str(recs)
+            else:
+                want, want_lines = d.varscan_file(path, opts.device_params())
+                assert n_lines == want_lines and recs.tobytes() == want.tobytes(), path
+    vcfs = [p + ".vcf" for p in paths]
+    res = varscan.mpileup2snp_files(d, paths, vcfs, opts)
+    for path, vcf, r, data in zip([p for p in paths if "missing" not in p], [v for v in vcfs if "missing" not in v],
+                                  [r for p, r in zip(paths, res) if "missing" not in p], blobs):
+        if isinstance(r, Exception):
+            assert path.endswith("f4.pileup")
+            continue
+        assert open(vcf, "rb").read().decode("latin-1") == vo.mpileup2snp(data, vo.Params(min_var_freq=0.2, min_reads2=2)), path
+
+
 def test_records_capacity_retry_and_order(d, tmp_path):
     from snp_pipeline_amd import varscan
     data = fuzz.varscan_pileup(5, 5000)
