@@ -66,6 +66,15 @@ def parse_argument_list(argv):
     _common(sub)
     sub.set_defaults(func=call_sites.call_sites, excepthook=utils.handle_sample_exception)
 
+    sub = subparsers.add_parser("call_sites_batch", help="call_sites for every sample directory, one process, all visible GPUs", formatter_class=fmt,
+                                description="Extension of the MI355X build: the call_sites step for every sample directory listed in sampleDirsFile "
+                                            "(samtools mpileup where the pileup is stale, then one streamed device call per GPU).")
+    sub.add_argument(dest="referenceFile", type=str, help="Relative or absolute path to the reference fasta file")
+    sub.add_argument(dest="sampleDirsFile", type=str, help="Relative or absolute path to file containing a list of directories -- one per sample")
+    sub.add_argument("-f", "--force", dest="forceFlag", action="store_true", help="Force processing even when result files already exist and are newer than inputs")
+    _common(sub)
+    sub.set_defaults(func=call_sites.call_sites_batch, excepthook=utils.handle_global_exception)
+
     sub = subparsers.add_parser("filter_regions", help="Remove abnormally dense SNPs from all samples", formatter_class=fmt,
                                 description="Remove abnormally dense SNPs from the input VCF file, save the reserved SNPs into a new VCF file, and save the removed SNPs into another VCF file.")
     sub.add_argument(dest="sampleDirsFile", type=str, help="Relative or absolute path to file containing a list of directories -- one per sample")

@@ -242,3 +242,43 @@ def test_full_size_sample_runs_and_matches_oracle_on_its_variant_lines(d, tmp_pa
         f = data[s:data.index(b"\n", s)].split(b"\t")
         assert vo.call_line(f[2].decode(), int(f[3]), f[4], f[5], prm) is None
     print("full-size sample: %d lines, %d sites, %.2f s wall (%.1f GB/s file -> var.flt.vcf)" % (n_lines, n_rows, wall, n / wall / 1e9))
+
+
+def test_call_sites_batch_equals_per_sample_cli(tmp_path, monkeypatch):
+    """call_sites_batch (extension): every sample of a sampleDirsFile in one process = the per-sample subcommand; a sample
+    without a BAM and one with a malformed pileup are sample errors, the others still get their var.flt.vcf."""
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    ref = tmp_path / "ref.fasta"
+    ref.write_text(">ctgA\nACGT\n")
+    old = time.time() - 100
+    os.utime(str(ref), (old, old))
+    dirs, blobs = [], []
+    for i in range(5):
+        sdir = tmp_path / "samples" / ("s%d" % i)
+        sdir.mkdir(parents=True)
+        if i != 3:
+            bam = sdir / "reads.sorted.deduped.indelrealigned.bam"
+            bam.write_bytes(b"placeholder")
+            os.utime(str(bam), (old, old))
+        data = fuzz.varscan_pileup(50 + i, 3000 + 500 * i) if i != 4 else b"c\t1\tA\t9\tGGGGGGGGG\n"
+        (sdir / "reads.all.pileup").write_bytes(data)
+        dirs.append(str(sdir))
+        blobs.append(data)
+    dirs_file = tmp_path / "sampleDirectories.txt"
+    dirs_file.write_text("\n".join(dirs) + "\n")
+    monkeypatch.setenv("VarscanMpileup2snp_ExtraParams", "--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5")
+    monkeypatch.setenv("StopOnSampleError", "false")
+    monkeypatch.setenv("errorOutputFile", str(tmp_path / "error.log"))
+    monkeypatch.chdir(tmp_path)
+    args = cli.parse_command_line("call_sites_batch -v 0 %s %s" % (ref, dirs_file))
+    assert cli.run_command_from_args(args) == 0
+    log = (tmp_path / "error.log").read_text()
+    assert "s3/reads.sorted.deduped.indelrealigned.bam" in log and "call_sites failed for sample s4: PileupFormatError" in log
+    for i in (0, 1, 2):
+        want = vo.mpileup2snp(blobs[i], vo.Params(**vo.PIPELINE_DEFAULTS))
+        assert open(os.path.join(dirs[i], "var.flt.vcf")).read() == want
+    assert not os.path.exists(os.path.join(dirs[3], "var.flt.vcf"))
+    # the per-sample subcommand finds the batch's files fresh and leaves them alone
+    stamp = os.stat(os.path.join(dirs[0], "var.flt.vcf")).st_mtime_ns
+    cli.run_command_from_args(cli.parse_command_line("call_sites -v 0 %s %s" % (ref, dirs[0])))
+    assert os.stat(os.path.join(dirs[0], "var.flt.vcf")).st_mtime_ns == stamp
