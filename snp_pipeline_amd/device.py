@@ -306,7 +306,7 @@ class Device(object):
         if n == 0:
             return []
         arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
-        sites = np.zeros((n, max(int(capacity), 1)), dtype=VARSCAN_DTYPE)
+        sites = np.empty((n, max(int(capacity), 1)), dtype=VARSCAN_DTYPE)       # only the rows the library reports are read
         counts = np.zeros(n, dtype=np.uint32)
         status = np.zeros((n, 2), dtype=np.uint64)
         rcs = np.zeros(n, dtype=np.int32)

@@ -123,14 +123,40 @@ def _write_vcf(vcf_path, pileup_path, records, opts):
     return n_rows
 
 
-def mpileup2snp_files(device, pileup_paths, vcf_paths, opts):
-    """Many samples in one streamed device call.  Returns [(lines, sites written) or the exception of that sample]."""
-    results = []
-    for (records, n_lines), pileup_path, vcf_path in zip(device.varscan_files(pileup_paths, opts.device_params()), pileup_paths, vcf_paths):
-        if isinstance(records, Exception):
-            results.append(records)
-        else:
-            results.append((n_lines, _write_vcf(vcf_path, pileup_path, records, opts)))
+def mpileup2snp_files(device, pileup_paths, vcf_paths, opts, group=6):
+    """Many samples: streamed device calls over groups of `group` files in a helper thread (the library releases the GIL), while
+    this thread turns the records of the group before into VCF files.  Returns [(lines, sites written) or the exception of
+    that sample] in input order."""
+    import queue
+    import threading
+    n = len(pileup_paths)
+    done = queue.Queue(maxsize=2)
+
+    def produce():
+        try:
+            for g0 in range(0, n, group):
+                done.put((g0, device.varscan_files(pileup_paths[g0:g0 + group], opts.device_params())))
+        except BaseException as err:                            # noqa: B902 — handed to the consumer
+            done.put((None, err))
+        done.put((None, None))
+
+    producer = threading.Thread(target=produce)
+    producer.start()
+    results = [None] * n
+    failure = None
+    while True:
+        g0, batch = done.get()
+        if g0 is None:
+            if batch is None:
+                break
+            failure = batch
+            continue
+        for k, (records, n_lines) in enumerate(batch):
+            i = g0 + k
+            results[i] = records if isinstance(records, Exception) else (n_lines, _write_vcf(vcf_paths[i], pileup_paths[i], records, opts))
+    producer.join()
+    if failure is not None:
+        raise failure
     return results
 
 

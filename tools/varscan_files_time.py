@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development helper: N synthetic full-size pileup files through snpgpu_varscan_files (the library call alone) and through
-varscan.mpileup2snp_files (with the VCF files written).  Usage: python tools/varscan_files_time.py [n_files] [passes]"""
+varscan.mpileup2snp_files (with the VCF files written).  Usage: python tools/varscan_files_time.py [n_files] [passes] [site spacing]"""
 import os
 import sys
 import tempfile
@@ -21,7 +21,8 @@ def main():
     ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda")
     d.synth_reference_dev(1, G, ref.data_ptr())
     alt = torch.zeros(G + 1, dtype=torch.uint8, device="cuda")
-    alt[1000::1000] = ord("A")
+    spacing = int(sys.argv[3]) if len(sys.argv) > 3 else 1000       # one planted site per `spacing` bases (carried by ~10 % of samples)
+    alt[spacing::spacing] = ord("A")
     tmp = tempfile.mkdtemp(prefix="vsf_", dir=os.environ.get("SNPGPU_BENCH_TMP", "/tmp"))
     paths, total = [], 0
     for i in range(n_files):
