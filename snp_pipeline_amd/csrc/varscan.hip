@@ -208,8 +208,24 @@ __device__ void varscan_line_lds(const uint32_t *lds32, uint32_t p0, uint32_t en
     uint64_t F = 0, R = 0, QS01 = 0, QS23 = 0;
     uint32_t bw = lds32[b0 >> 2], qw = 0, qwi = 0xFFFFFFFFu;
     uint32_t j = q0;
+    const uint32_t c4 = (qmin < 128u ? qmin : 128u) * 0x01010101u;
     for (uint32_t i = b0; i < b1; ++i) {
-        if ((i & 3u) == 0u) bw = lds32[i >> 2];
+        if ((i & 3u) == 0u) {
+            bw = lds32[i >> 2];
+            // four reference matches in a row ('.' 0x2E / ',' 0x2C), the common case: their four qualities in one go
+            if ((bw & 0xFDFDFDFDu) == 0x2C2C2C2Cu && i + 4u <= b1 && j + 4u <= q1 && qmin < 128u) {
+                const uint64_t two = (uint64_t)lds32[j >> 2] | ((uint64_t)lds32[(j >> 2) + 1u] << 32);
+                const uint32_t qq = (uint32_t)(two >> ((j & 3u) * 8u));
+                const uint32_t good = ge4(qq, c4) >> 7;                                // 0x01 per quality at or above the threshold
+                const uint32_t fwd = (bw >> 1) & good;                                 // ... that belongs to a '.'
+                rf_f += (uint32_t)__popc(fwd);
+                rf_r += (uint32_t)__popc(good ^ fwd);
+                rf_q += __builtin_amdgcn_udot4(qq & (good * 0xFFu), 0x01010101u, 0u, false) - 33u * (uint32_t)__popc(good);
+                j += 4u;
+                i += 3u;                                                               // (the loop adds the fourth)
+                continue;
+            }
+        }
         const uint32_t ch = (bw >> ((i & 3u) * 8u)) & 0xFFu;
         const uint64_t bit = 1ull << (ch & 63u);
         const bool lo = ch < 64u, hi = (ch ^ 64u) < 64u;
