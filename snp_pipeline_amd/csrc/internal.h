@@ -23,7 +23,7 @@ struct snpgpu_ctx {
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     int n_cu = 256;
-    bool scan_lds_attr = false, varscan_lds_attr = false;   // hipFuncSetAttribute is per device: done once per context
+    bool scan_lds_attr = false;         // hipFuncSetAttribute is per device: done once per context
     // optional per-kernel timing (bench): event pairs recorded around selected launches
     bool time_kernels = false;
     struct Timed { int kernel; hipEvent_t a, b; };

@@ -7,10 +7,9 @@
 // min-avg-qual / min-var-freq.  Lines that pass leave one 48-byte record per passing allele; Fisher's exact test, the
 // strand filter and the VCF text are host work on those few records (snp_pipeline_amd/varscan.py).
 //
-// One lane per line over the line index of scan.hip (k_lines_index); a block of 256 / 128 / 64 lanes (by mean line length)
-// first copies the contiguous span of its lines to LDS with 16-byte loads, so every byte of the file crosses HBM once and
-// the byte-wise walk of the read-base automaton runs out of LDS (a span over 32 KiB — a block of very deep lines — is
-// read from global memory instead).  The file arrives over PCIe at ~50 GB/s, so the pass as a whole is bounded by that
+// One lane per line over the line index of scan.hip (k_lines_index); a wave first copies the contiguous span of its 64
+// lines to LDS with 16-byte loads, so every byte of the file crosses HBM once and the byte-wise walk of the read-base
+// automaton runs out of LDS (a span over the wave's LDS — 64 very deep lines — is read from global memory instead).  The file arrives over PCIe at ~50 GB/s, so the pass as a whole is bounded by that
 // copy, not by this kernel.  The read-base automaton follows the restatement in oracle/varscan_oracle.py (which tests
 // compare it with); see its header for what the reference's fixtures pin.
 #include "internal.h"
@@ -295,23 +294,24 @@ __device__ void varscan_line_lds(const uint32_t *lds32, uint32_t p0, uint32_t en
     }
 }
 
-// A block takes kThreads consecutive lines: their bytes are one contiguous span of the file, copied to LDS with 16-byte
-// loads (coalesced; every byte of the file crosses HBM once) when it fits, and each lane then walks its own line there.
-template <int kThreads>
-__global__ __launch_bounds__(kThreads) void k_varscan_lines(const uint8_t *__restrict__ buf, uint64_t nbytes, const uint64_t *__restrict__ line_off,
-                                                            uint64_t n_lines, snpgpu_varscan_params prm, snpgpu_varscan_site *out, uint32_t capacity,
-                                                            uint32_t *out_n, unsigned long long *status) {
+// A workgroup is ONE wave and takes 64 consecutive lines: their bytes are one contiguous span of the file, copied to LDS
+// with 16-byte loads (coalesced; every byte of the file crosses HBM once) when it fits the launch's LDS size, and each lane
+// then walks its own line there.  One wave per workgroup: no wave ever waits at a barrier for a slower one, and the LDS
+// size (by the file's mean line length) sets how many waves a CU holds.
+__global__ __launch_bounds__(64) void k_varscan_lines(const uint8_t *__restrict__ buf, uint64_t nbytes, const uint64_t *__restrict__ line_off,
+                                                      uint64_t n_lines, snpgpu_varscan_params prm, snpgpu_varscan_site *out, uint32_t capacity,
+                                                      uint32_t *out_n, unsigned long long *status, uint32_t lds_bytes) {
     extern __shared__ uint4 vs_lds[];
-    const uint64_t n_groups = (n_lines + kThreads - 1) / kThreads;
+    const uint64_t n_groups = (n_lines + 63) / 64;
     for (uint64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        const uint64_t first = grp * kThreads, last = first + kThreads < n_lines ? first + kThreads : n_lines;
+        const uint64_t first = grp * 64, last = first + 64 < n_lines ? first + 64 : n_lines;
         const uint64_t s0 = line_off[first] - 1, s1 = last < n_lines ? line_off[last] - 1 : nbytes;
         // 16-byte chunks of the aligned span [a0, a1) that covers [s0, s1)
         const uint64_t a0 = ((uintptr_t)buf + s0) & ~(uint64_t)15, a1 = (((uintptr_t)buf + s1) + 15) & ~(uint64_t)15;
-        const bool staged = a1 - a0 <= VS_LDS_BYTES;
+        const bool staged = a1 - a0 <= lds_bytes;
         if (staged) {
             const uint4 *src = (const uint4 *)a0;
-            for (uint32_t c = threadIdx.x; c < (uint32_t)((a1 - a0) / 16); c += kThreads) vs_lds[c] = src[c];
+            for (uint32_t c = threadIdx.x; c < (uint32_t)((a1 - a0) / 16); c += 64) vs_lds[c] = src[c];
         }
         __syncthreads();
         const uint64_t line = first + threadIdx.x;
@@ -331,21 +331,16 @@ __global__ __launch_bounds__(kThreads) void k_varscan_lines(const uint8_t *__res
 int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, const uint64_t *d_line_off, uint64_t n_lines,
                            const snpgpu_varscan_params *prm, snpgpu_varscan_site *d_sites, uint32_t capacity, uint32_t *d_n, uint64_t *d_status) {
     if (n_lines == 0) return SNPGPU_OK;
-    if (!ctx->varscan_lds_attr) {                                   // per device, so per context
-        for (auto f : {(const void *)k_varscan_lines<256>, (const void *)k_varscan_lines<128>, (const void *)k_varscan_lines<64>})
-            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VS_LDS_BYTES);
-        ctx->varscan_lds_attr = true;
-    }
-    // lines per block by the mean line length, so that a block's span fits the 32 KiB it may stage (5 blocks per CU)
+    // LDS per wave: 64 lines of the file's mean length with 40 % to spare, 4 .. 32 KiB (a span that does not fit is walked in
+    // global memory); a CU's 160 KiB then hold 160 / that many waves
     const uint64_t mean = nbytes / n_lines + 1;
-    const int threads = mean * 256 <= VS_LDS_BYTES * 3 / 4 ? 256 : (mean * 128 <= VS_LDS_BYTES * 3 / 4 ? 128 : 64);
-    const uint64_t groups = (n_lines + threads - 1) / threads;
-    const uint64_t cap = (uint64_t)ctx->n_cu * 5 * 8;
+    uint32_t lds = 4096;
+    while (lds < VS_LDS_BYTES && (uint64_t)lds * 5 < mean * 64 * 7) lds *= 2;
+    const uint32_t waves_per_cu = 160 * 1024 / lds < 32 ? 160 * 1024 / lds : 32;
+    const uint64_t groups = (n_lines + 63) / 64;
+    const uint64_t cap = (uint64_t)ctx->n_cu * waves_per_cu * 4;
     const unsigned grid = (unsigned)(groups < cap ? groups : cap);
-    auto *st = (unsigned long long *)d_status;
-    if (threads == 256) k_varscan_lines<256><<<grid, 256, VS_LDS_BYTES, ctx->stream>>>(d_buf, nbytes, d_line_off, n_lines, *prm, d_sites, capacity, d_n, st);
-    else if (threads == 128) k_varscan_lines<128><<<grid, 128, VS_LDS_BYTES, ctx->stream>>>(d_buf, nbytes, d_line_off, n_lines, *prm, d_sites, capacity, d_n, st);
-    else k_varscan_lines<64><<<grid, 64, VS_LDS_BYTES, ctx->stream>>>(d_buf, nbytes, d_line_off, n_lines, *prm, d_sites, capacity, d_n, st);
+    k_varscan_lines<<<grid, 64, lds, ctx->stream>>>(d_buf, nbytes, d_line_off, n_lines, *prm, d_sites, capacity, d_n, (unsigned long long *)d_status, lds);
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;
 }
