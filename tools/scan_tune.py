@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development helper: time k_scan_wave / k_call_sites on a few device-generated samples.
-Usage: python tools/scan_tune.py [n_samples] [genome_len] [batch|single] [mean_depth]   (knobs via SNPGPU_SCAN_* env vars)
+Usage: python tools/scan_tune.py [n_samples] [genome_len] [batch|single] [mean_depth] [contig name]   (knobs via SNPGPU_SCAN_* env vars)
 "batch": all samples through one call of the batch entry point (one scan launch, one call launch)."""
 import os
 import sys
@@ -19,6 +19,7 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     G = int(sys.argv[2]) if len(sys.argv) > 2 else 5_000_000
     depth = float(sys.argv[4]) if len(sys.argv) > 4 else 30.0
+    contig = sys.argv[5].encode() if len(sys.argv) > 5 else b"synth_chr1"
     S = G // 100
     d = dev.Device(0)
     d.use_torch_stream()
@@ -30,12 +31,12 @@ def main():
     alt = torch.from_numpy(alt_h).cuda()
     bufs, sizes = [], []
     for i in range(B):
-        n = d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), 0, 0, mean_depth=depth)
+        n = d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), 0, 0, mean_depth=depth, contig=contig)
         t = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
-        d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), t.data_ptr(), n + 64, mean_depth=depth)
+        d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), t.data_ptr(), n + 64, mean_depth=depth, contig=contig)
         bufs.append(t)
         sizes.append(n)
-    ss = d.siteset([(b"synth_chr1", int(p)) for p in pos], [1] * S)
+    ss = d.siteset([(contig, int(p)) for p in pos], [1] * S)
     prm = dev.make_params(0, 0.6, 3, 0, 0.0)
     bases = torch.empty((B, S), dtype=torch.uint8, device="cuda")
     filt = torch.empty((B, S), dtype=torch.uint8, device="cuda")
