@@ -30,6 +30,17 @@ def _sample_error_on_missing_file(file_path, program, empty_ok=False):
         utils.sample_error("Error: %s is empty after running %s." % (file_path, program))
 
 
+def _bam_and_pileup(sample_dir):
+    """The BAM the pileup is made from (its name follows RemoveDuplicateReads / EnableLocalRealignment, call_sites.py:55-59)
+    and the pileup's path."""
+    remove_duplicate_reads = os.environ.get("RemoveDuplicateReads", "true").lower() == "true"
+    enable_local_realignment = os.environ.get("EnableLocalRealignment", "true").lower() == "true"
+    input_bam_file = os.path.join(sample_dir, "reads.sorted.bam")
+    input_bam_file = _add_file_suffix(input_bam_file, ".deduped", enable=remove_duplicate_reads)
+    input_bam_file = _add_file_suffix(input_bam_file, ".indelrealigned", enable=enable_local_realignment)
+    return input_bam_file, os.path.join(sample_dir, "reads.all.pileup")
+
+
 def call_sites(args):
     """Entry point of ``cfsan_snp_pipeline call_sites`` (cfsan_snp_pipeline.py:294-304)."""
     utils.print_log_header(classpath=True)
@@ -39,16 +50,11 @@ def call_sites(args):
     utils.verify_non_empty_input_files("Reference file", [reference_file_path], error_handler="global")
     sample_dir = args.sampleDir
 
-    remove_duplicate_reads = os.environ.get("RemoveDuplicateReads", "true").lower() == "true"
-    enable_local_realignment = os.environ.get("EnableLocalRealignment", "true").lower() == "true"
-    input_bam_file = os.path.join(sample_dir, "reads.sorted.bam")
-    input_bam_file = _add_file_suffix(input_bam_file, ".deduped", enable=remove_duplicate_reads)
-    input_bam_file = _add_file_suffix(input_bam_file, ".indelrealigned", enable=enable_local_realignment)
+    input_bam_file, pileup_file = _bam_and_pileup(sample_dir)
     utils.verify_non_empty_input_files("Sample BAM file", [input_bam_file], error_handler="sample")
     sample_id = os.path.basename(os.path.abspath(sample_dir))
 
     # ---- the pileup: samtools, exactly as the reference runs it (call_sites.py:68-83) ----
-    pileup_file = os.path.join(sample_dir, "reads.all.pileup")
     needs_rebuild = utils.target_needs_rebuild([input_bam_file, reference_file_path], pileup_file)
     if not args.forceFlag and not needs_rebuild:
         verbose_print("# Pileup file is already freshly created for %s.  Use the -f option to force a rebuild." % sample_id)
@@ -76,15 +82,6 @@ def call_sites(args):
         n_lines, n_rows = varscan.mpileup2snp(default_device(), pileup_file, vcf_file, opts)
         verbose_print("# %d pileup lines, %d variant sites" % (n_lines, n_rows))
         _sample_error_on_missing_file(vcf_file, "VarScan")
-
-
-def _bam_and_pileup(sample_dir):
-    remove_duplicate_reads = os.environ.get("RemoveDuplicateReads", "true").lower() == "true"
-    enable_local_realignment = os.environ.get("EnableLocalRealignment", "true").lower() == "true"
-    input_bam_file = os.path.join(sample_dir, "reads.sorted.bam")
-    input_bam_file = _add_file_suffix(input_bam_file, ".deduped", enable=remove_duplicate_reads)
-    input_bam_file = _add_file_suffix(input_bam_file, ".indelrealigned", enable=enable_local_realignment)
-    return input_bam_file, os.path.join(sample_dir, "reads.all.pileup")
 
 
 def call_sites_batch(args):
