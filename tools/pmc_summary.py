@@ -10,7 +10,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     with open(path) as f:
         for row in csv.DictReader(f):
-            name = row.get("Kernel_Name", "?").split("(")[0][:60]
+            name = row.get("Kernel_Name", "?").replace("(anonymous namespace)::", "").split("(")[0][:60]
             acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for name in sorted(acc):
     print(name)
