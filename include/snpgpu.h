@@ -297,6 +297,17 @@ int  snpgpu_distance_packed_dev(snpgpu_ctx *ctx, const void *d_packed, uint32_t 
 /* Host form: symbols is n_rows x n_sites bytes (row-major, the sequences of snpma.fasta); out is n x n int32. */
 int  snpgpu_distance(snpgpu_ctx *ctx, const uint8_t *symbols, uint32_t n_rows, uint32_t n_sites, int32_t *out);
 
+/* snpma.fasta into a byte matrix (host code, no device work): replaces the read loop of distance.py:76-84 — text-mode lines
+ * ("\n", "\r\n", lone "\r"), a line that starts with '>' opens a record named by the rest of the line without its leading
+ * '>'s, every other line is appended to the current record.  Two passes: snpgpu_fasta_scan counts the records, the longest
+ * sequence and the bytes of all names (SNPGPU_E_UNSUPPORTED: sequence text before the first header, which the reference
+ * cannot handle either); snpgpu_fasta_load fills out_matrix (record r at r * row_stride, padded with `pad` up to row_stride
+ * >= the longest sequence), out_len[n_records], and the names back to back with out_name_off[n_records + 1].  Records keep
+ * the file's order and its duplicates (the reference's dict keeps the last of equal names: the caller's business). */
+int  snpgpu_fasta_scan(const char *path, uint64_t *out_n_records, uint64_t *out_max_len, uint64_t *out_names_bytes);
+int  snpgpu_fasta_load(const char *path, uint64_t n_records, uint64_t row_stride, uint8_t pad, uint8_t *out_matrix,
+                       uint64_t *out_len, char *out_names, uint64_t *out_name_off);
+
 /* The two text layouts of the distance step, written straight to `path` (host code, no device work): replaces the print
  * loops of distance.py:100-105 (SNPGPU_TSV_PAIRWISE: "Seq1\tSeq2\tDistance" header, one line per ordered pair, the
  * diagonal included) and distance.py:107-114 (SNPGPU_TSV_MATRIX: header "\t" + ids, one row per id).  ids: the names

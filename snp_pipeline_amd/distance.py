@@ -36,6 +36,27 @@ def distance_matrix(dev, seqs):
     return ids, dev.distance(sym)
 
 
+def distance_of_matrix(dev, file_ids, sym, lens):
+    """distance_matrix for the arrays of snp_matrix.load_matrix (no Python strings in between): equal ids keep their last
+    record (the reference's dict, distance.py:80-84), rows go into sorted-id order, lengths follow the same rule."""
+    last = {}
+    for r, i in enumerate(file_ids):
+        last[i] = r
+    ids = sorted(last)
+    rows = np.asarray([last[i] for i in ids], dtype=np.int64)
+    n = len(ids)
+    if n == 0:
+        return ids, np.zeros((0, 0), dtype=np.int32)
+    ordered = lens[rows]
+    if (ordered[1:] < ordered[:-1]).any():
+        raise IndexError("string index out of range")                         # what seq2[pos] raises in utils.py:1158
+    if sym.shape[1] == 0:
+        return ids, np.zeros((n, n), dtype=np.int32)
+    if not np.array_equal(rows, np.arange(len(file_ids))):
+        sym = sym[rows]                                                         # (snp_matrix writes sorted sample order: usually a no-op)
+    return ids, dev.distance(np.ascontiguousarray(sym))
+
+
 def _write_tsv(path, layout, ids, mat):
     """distance.py:100-114 through the library's host formatter (csrc/tsv_out.hip): at 10 000 samples the pairwise file has
     10^8 lines, ~35 s of Python string formatting for 38 ms of kernel."""
@@ -79,10 +100,10 @@ def calculate_snp_distances(args):
         utils.verbose_print("Distance files have already been freshly built.  Use the -f option to force a rebuild.")
         return
 
-    seqs = snp_matrix.read_matrix(input_file)
+    file_ids, sym, lens = snp_matrix.load_matrix(input_file)
     utils.verbose_print("# %s %s" % (utils.timestamp(), "Calculating all pairwise distances"))
     from .device import default_device
-    ids, mat = distance_matrix(default_device(), seqs)
+    ids, mat = distance_of_matrix(default_device(), file_ids, sym, lens)
     if pairwise_file:
         write_pairwise(pairwise_file, ids, mat)
     if matrix_file:

@@ -63,3 +63,31 @@ def read_matrix(path):
             else:
                 seqs[curr].append(line)             # KeyError(None) if data precedes the first header, like the reference's NameError
     return {k: "".join(v) for k, v in seqs.items()}
+
+
+def load_matrix(path):
+    """The same parse straight into a byte matrix, by the library's host code (csrc/fasta_in.hip): returns (ids in file order,
+    (records x longest) uint8 matrix padded with '-', lengths).  Raises KeyError(None) for sequence text before the first
+    header, like read_matrix.  Duplicate ids are all returned (the reference's dict keeps the last one: see distance.py)."""
+    import ctypes as C
+    from . import _lib as L
+    lib = L.load()
+    n, longest, names_bytes = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    rc = lib.snpgpu_fasta_scan(os.fsencode(path), C.byref(n), C.byref(longest), C.byref(names_bytes))
+    if rc == L.E_IO:
+        raise IOError("cannot read %s" % path)
+    if rc == L.E_UNSUPPORTED:
+        raise KeyError(None)
+    if rc != 0:
+        raise RuntimeError("snpgpu_fasta_scan failed (%d)" % rc)
+    mat = np.empty((n.value, longest.value), dtype=np.uint8)
+    lens = np.zeros(n.value, dtype=np.uint64)
+    names = C.create_string_buffer(max(1, names_bytes.value))
+    off = np.zeros(n.value + 1, dtype=np.uint64)
+    rc = lib.snpgpu_fasta_load(os.fsencode(path), n.value, longest.value, 0x2D, mat.ctypes.data if mat.size else None, lens.ctypes.data,
+                               names, off.ctypes.data)
+    if rc != 0:
+        raise IOError("%s changed while it was read" % path)
+    raw = names.raw
+    ids = [raw[int(off[i]):int(off[i + 1])].decode("utf-8") for i in range(n.value)]
+    return ids, mat, lens

@@ -266,3 +266,36 @@ def test_distance_unequal_lengths_and_no_sites(d):
     d.distance_packed_dev(0, 300, 0, out.data_ptr())
     torch.cuda.synchronize()
     assert not bool(out.any().item())
+
+
+def test_distance_cli_on_an_untidy_snpma(d, tmp_path):
+    """The distance subcommand through the native FASTA loader: ids out of order, a duplicate id (the later record counts, as in the
+    reference's dict), CR LF line ends, wrapped and unwrapped records, unequal lengths in non-decreasing id order — TSVs equal to
+    the oracle's; a shorter later sequence raises IndexError as utils.py:1158 does; text before the first header KeyError."""
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    rng = np.random.default_rng(12)
+    letters = np.frombuffer(b"ACGTacgt-N", dtype=np.uint8)
+
+    def seq(n):
+        return bytes(rng.choice(letters, size=n)).decode()
+
+    recs = [("zeta", seq(500)), ("alpha", seq(300)), ("mid", seq(400)), ("alpha", seq(310)), ("beta", seq(310)), ("omega", seq(500))]
+    text = ""
+    for k, (name, s_) in enumerate(recs):
+        eol = "\r\n" if k % 2 else "\n"
+        width = 60 if k % 3 else 10 ** 6
+        text += ">" + name + eol + eol.join(s_[i:i + width] for i in range(0, len(s_), width)) + eol
+    snpma = tmp_path / "snpma.fasta"
+    snpma.write_bytes(text.encode())
+    args = cli.parse_command_line("distance -v 0 -p %s/p.tsv -m %s/m.tsv %s" % (tmp_path, tmp_path, snpma))
+    assert cli.run_command_from_args(args) == 0
+    seqs = so.parse_snpma(text.replace("\r\n", "\n"))
+    assert seqs["alpha"] == recs[3][1]
+    ids, table = so.distance_tables(seqs)
+    assert (tmp_path / "p.tsv").read_text() == so.pairwise_text(ids, table) and (tmp_path / "m.tsv").read_text() == so.matrix_text(ids, table)
+    snpma.write_bytes(b">a\nACGTA\n>b\nACG\n")
+    with pytest.raises(IndexError):
+        cli.run_command_from_args(cli.parse_command_line("distance -f -v 0 -p %s/p.tsv %s" % (tmp_path, snpma)))
+    snpma.write_bytes(b"ACGT\n>a\nACGTA\n")
+    with pytest.raises(KeyError):
+        cli.run_command_from_args(cli.parse_command_line("distance -f -v 0 -p %s/p.tsv %s" % (tmp_path, snpma)))
