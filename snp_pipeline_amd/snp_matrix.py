@@ -42,12 +42,19 @@ def create_snp_matrix(args):
         utils.verbose_print("SNP matrix %s has already been freshly built.  Use the -f option to force a rebuild." % snpma_file_path)
         return
 
-    with open(snpma_file_path, "w") as output_file:
+    # snp_matrix.py:112-117 copies the files line by line in text mode: the bytes, with "\r\n" and lone "\r" turned into
+    # "\n" (universal newlines) and an error for text that is not valid UTF-8.  Whole files at a time here (10 000 files
+    # of 200 kB = 3.3e7 lines at configs[4]).
+    with open(snpma_file_path, "wb") as output_file:
         for path in consensus_files:
             utils.verbose_print("Merging " + path)
-            with open(path, "r") as input_file:
-                for line in input_file:
-                    output_file.write(line)
+            with open(path, "rb") as input_file:
+                data = input_file.read()
+            if not data.isascii():
+                data.decode("utf-8")                            # raises UnicodeDecodeError where the reference's read does
+            if b"\r" in data:
+                data = data.replace(b"\r\n", b"\n").replace(b"\r", b"\n")
+            output_file.write(data)
 
 
 def read_matrix(path):

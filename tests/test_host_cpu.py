@@ -591,3 +591,30 @@ def test_library_fasta_matrix_loader_equals_the_line_loop(tmp_path):
         snp_matrix.load_matrix(path)
     with pytest.raises(IOError):
         snp_matrix.load_matrix(str(tmp_path / "absent.fasta"))
+
+
+def test_snp_matrix_whole_file_copy_equals_the_text_mode_line_loop(tmp_path):
+    """snp_matrix.py:112-117 copies the consensus files line by line in text mode; the whole-file copy gives the same bytes for
+    CR LF / lone CR line ends, a missing final newline and non-ASCII text, in sorted directory order, and a missing file is the
+    reference's sample error."""
+    import argparse
+    from snp_pipeline_amd import snp_matrix
+    blobs = [b">a\nACGT\n", b">b\r\nAC\rGT\r\n", b">c\nno final newline", "é>x\n".encode("utf-8"), b"\n\n"]
+    dirs = []
+    for i, b in enumerate(blobs):
+        sd = tmp_path / ("s%d" % (9 - i))
+        sd.mkdir()
+        (sd / "consensus.fasta").write_bytes(b)
+        dirs.append(str(sd))
+    (tmp_path / "dirs.txt").write_text("\n".join(dirs) + "\n")
+    args = argparse.Namespace(sampleDirsFile=str(tmp_path / "dirs.txt"), consFileName="consensus.fasta", snpmaFile=str(tmp_path / "snpma.fasta"),
+                              forceFlag=True, verbose=0)
+    snp_matrix.create_snp_matrix(args)
+    want = []
+    for sd in sorted(dirs):
+        with open(os.path.join(sd, "consensus.fasta"), "r", encoding="utf-8") as f:
+            want.extend(f)
+    assert (tmp_path / "snpma.fasta").read_bytes() == "".join(want).encode("utf-8")
+    (tmp_path / "s9" / "consensus.fasta").write_bytes(b">a\n\xff\n")
+    with pytest.raises(UnicodeDecodeError):
+        snp_matrix.create_snp_matrix(args)
