@@ -297,6 +297,22 @@ int  snpgpu_distance_packed_dev(snpgpu_ctx *ctx, const void *d_packed, uint32_t 
 /* Host form: symbols is n_rows x n_sites bytes (row-major, the sequences of snpma.fasta); out is n x n int32. */
 int  snpgpu_distance(snpgpu_ctx *ctx, const uint8_t *symbols, uint32_t n_rows, uint32_t n_sites, int32_t *out);
 
+/* The first two columns of every record of a VCF (host code): what utils.convert_vcf_file_to_snp_set (utils.py:1113-1132)
+ * and filter_regions.py:408-410 read through PyVCF3.  out_pos / out_contig [capacity] in file order (contig = index into
+ * the file's names in order of first appearance, returned back to back in out_names with out_name_off[n_names + 1]);
+ * *out_n_records may exceed `capacity` (then only the count is valid: come back with more room), SNPGPU_E_NOMEM: more
+ * room for the names.  Plain files only — TAB-separated, POS of plain digits below 2^32, header before data: anything else
+ * is SNPGPU_E_UNSUPPORTED and belongs to the caller's own reader. */
+int  snpgpu_vcf_sites(const char *path, uint64_t capacity, uint32_t *out_pos, uint32_t *out_contig, uint64_t *out_n_records,
+                      char *out_names, uint64_t names_capacity, uint64_t *out_name_off, uint32_t names_max,
+                      uint32_t *out_n_names);
+/* snplist.txt (utils.write_list_of_snps, utils.py:1056-1070): one "chrom\tpos\tcount\tname..." line per site; keys =
+ * (contig index << 32) | pos in output order, carriers of site i = carriers[carrier_off[i], carrier_off[i+1]) as sample
+ * indices; contig / sample names back to back with their offset arrays. */
+int  snpgpu_write_snplist(const char *path, const char *contig_names, const uint64_t *contig_off, const uint64_t *keys,
+                          uint64_t n_sites, const uint32_t *carrier_off, const uint32_t *carriers, const char *sample_names,
+                          const uint64_t *sample_off);
+
 /* snpma.fasta into a byte matrix (host code, no device work): replaces the read loop of distance.py:76-84 — text-mode lines
  * ("\n", "\r\n", lone "\r"), a line that starts with '>' opens a record named by the rest of the line without its leading
  * '>'s, every other line is appended to the current record.  Two passes: snpgpu_fasta_scan counts the records, the longest

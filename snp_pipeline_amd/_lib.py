@@ -103,6 +103,8 @@ SIGNATURES = {
     "snpgpu_varscan_format_rows": (C.c_size_t, [_P, C.c_uint32, _P, C.c_uint64, _P, _P, C.c_size_t, C.POINTER(C.c_uint32)]),
     "snpgpu_fasta_scan": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "snpgpu_fasta_load": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint8, _P, _P, _P, _P]),
+    "snpgpu_vcf_sites": (C.c_int, [C.c_char_p, C.c_uint64, _P, _P, C.POINTER(C.c_uint64), _P, C.c_uint64, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "snpgpu_write_snplist": (C.c_int, [C.c_char_p, _P, _P, _P, C.c_uint64, _P, _P, _P, _P]),
     "snpgpu_write_distance_tsv": (C.c_int, [C.c_char_p, C.c_int, _P, _P, C.c_uint32, _P, C.c_uint64]),
     "snpgpu_dense_windows": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_uint32)]),
     "snpgpu_merge_regions": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_uint32)]),

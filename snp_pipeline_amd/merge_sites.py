@@ -35,6 +35,51 @@ def merge_site_lists(dev, per_sample_sites):
     return out_keys, carriers
 
 
+def merge_site_arrays(dev, per_sample):
+    """The same union from arrays: per_sample = list (sorted-dir order) of (contig names, contig index per record, position
+    per record) as utils.read_vcf_site_arrays returns them.  Returns (sorted contig names, unique keys (contig << 32 | pos),
+    carrier offsets, carrier sample indices) — numpy all the way, for snpgpu_write_snplist."""
+    contigs = sorted({c for names, _, _ in per_sample for c in names})
+    cid = {c: i for i, c in enumerate(contigs)}
+    keys, samp = [], []
+    for si, (names, cidx, pos) in enumerate(per_sample):
+        if len(pos) == 0:
+            continue
+        if pos.min() < 0 or pos.max() >= (1 << 32):
+            raise ValueError("VCF position out of range")
+        lut = np.asarray([cid[c] for c in names], dtype=np.uint64)
+        keys.append((lut[cidx] << np.uint64(32)) | pos.astype(np.uint64))
+        samp.append(np.full(len(pos), si, dtype=np.uint32))
+    if not keys:
+        return contigs, np.zeros(0, np.uint64), np.zeros(1, np.uint32), np.zeros(0, np.uint32)
+    uniq, off, car = dev.merge_sites(np.concatenate(keys), np.concatenate(samp))
+    return contigs, uniq, off, car
+
+
+def write_snplist(path, contigs, uniq, off, car, sample_names):
+    """utils.write_list_of_snps through the library's host formatter (csrc/vcf_in.hip)."""
+    from . import _lib as L
+
+    def blob(strings):
+        raw = [x.encode("utf-8") for x in strings]
+        o = np.zeros(len(raw) + 1, dtype=np.uint64)
+        if raw:
+            np.cumsum([len(b) for b in raw], out=o[1:])
+        return b"".join(raw), o
+
+    cb, co = blob(contigs)
+    sb, so = blob(sample_names)
+    uniq = np.ascontiguousarray(uniq, dtype=np.uint64)
+    off = np.ascontiguousarray(off, dtype=np.uint32)
+    car = np.ascontiguousarray(car, dtype=np.uint32)
+    rc = L.load().snpgpu_write_snplist(os.fsencode(path), cb, co.ctypes.data, uniq.ctypes.data, len(uniq), off.ctypes.data, car.ctypes.data,
+                                       sb, so.ctypes.data)
+    if rc == L.E_IO:
+        raise IOError("cannot write %s" % path)
+    if rc != 0:
+        raise RuntimeError("snpgpu_write_snplist failed (%d)" % rc)
+
+
 def merge_sites(args):
     """Entry point of ``cfsan_snp_pipeline merge_sites`` (cfsan_snp_pipeline.py:329-340)."""
     utils.print_log_header()
@@ -61,24 +106,26 @@ def merge_sites(args):
         utils.verbose_print("SNP list %s has already been freshly built.  Use the -f option to force a rebuild." % snp_list_file_path)
         return
 
-    names, site_sets, excluded_dirs = [], [], set()
+    names, site_arrays, excluded_dirs = [], [], set()
     for sample_dir, vcf_file_path in zip(sorted_dirs, list_of_vcf_files):
         if not os.path.isfile(vcf_file_path) or os.path.getsize(vcf_file_path) == 0:
             continue
         utils.verbose_print("Processing VCF file %s" % vcf_file_path)
         sample_name = os.path.basename(os.path.dirname(vcf_file_path))
-        snp_set = utils.convert_vcf_file_to_snp_set(vcf_file_path)
-        if args.maxSnps >= 0 and len(snp_set) > args.maxSnps:
-            utils.verbose_print("Excluding sample %s having %d snps." % (sample_name, len(snp_set)))
-            excluded_dirs.add(sample_dir)
-            continue
+        contig_names, cidx, pos = utils.read_vcf_site_arrays(vcf_file_path)
+        if args.maxSnps >= 0:
+            n_snps = len(np.unique((cidx.astype(np.int64) << 40) ^ pos)) if len(pos) else 0      # size of the reference's snp_set
+            if n_snps > args.maxSnps:
+                utils.verbose_print("Excluding sample %s having %d snps." % (sample_name, n_snps))
+                excluded_dirs.add(sample_dir)
+                continue
         names.append(sample_name)
-        site_sets.append(snp_set)
+        site_arrays.append((contig_names, cidx, pos))
 
     from .device import default_device
-    keys, carriers = merge_site_lists(default_device(), site_sets)
-    utils.verbose_print('Found %d snp positions across %d sample vcf files.' % (len(keys), len(list_of_vcf_files)))
-    utils.write_list_of_snps(snp_list_file_path, keys, [[names[int(i)] for i in car] for car in carriers])
+    contigs, uniq, off, car = merge_site_arrays(default_device(), site_arrays)
+    utils.verbose_print('Found %d snp positions across %d sample vcf files.' % (len(uniq), len(list_of_vcf_files)))
+    write_snplist(snp_list_file_path, contigs, uniq, off, car, names)
 
     with open(args.filteredSampleDirsFile, "w") as f:
         for sample_dir in unsorted_dirs:                      # original order (merge_sites.py:127-131)

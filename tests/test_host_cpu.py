@@ -618,3 +618,56 @@ def test_snp_matrix_whole_file_copy_equals_the_text_mode_line_loop(tmp_path):
     (tmp_path / "s9" / "consensus.fasta").write_bytes(b">a\n\xff\n")
     with pytest.raises(UnicodeDecodeError):
         snp_matrix.create_snp_matrix(args)
+
+
+def test_library_vcf_site_reader_and_snplist_writer(tmp_path, fixture_trees):
+    """csrc/vcf_in.hip: the CHROM / POS arrays of every bundled VCF equal read_vcf_sites' tuples; files outside the plain case fall
+    back to the Python reader (same sites, same exceptions); the snplist text equals utils.write_list_of_snps'."""
+    import numpy as np
+    from snp_pipeline_amd import merge_sites, utils
+    n_files = 0
+    for ds in ("lambdaVirus", "agona", "listeria"):
+        root, _ = fixture_trees[ds]
+        for dirpath, _, files in os.walk(root):
+            for name in files:
+                if name.endswith(".vcf"):
+                    path = os.path.join(dirpath, name)
+                    want = utils.read_vcf_sites(path)[2]
+                    names, cidx, pos = utils.read_vcf_site_arrays(path)
+                    assert [(names[int(c)], int(p)) for c, p in zip(cidx, pos)] == want, path
+                    n_files += 1
+    assert n_files > 70
+    odd = {
+        "crlf.vcf": b"##fileformat=VCFv4.1\r\n#CHROM\tPOS\r\nc1\t5\tx\r\nc2\t7\r\n\r\nc1\t9",
+        "spaces.vcf": b"#CHROM POS\nc1 5 x\nc2\t7\n",                  # a line without TAB: the whitespace split of the Python reader
+        "plus.vcf": b"#h\nc1\t+5\tx\nc1\t1_0\n",                        # int() grammar
+        "empty_chrom.vcf": b"#h\n\t5\tx\n",
+        "header_only.vcf": b"##a\n#CHROM\n",
+        "late_header.vcf": b"#h\nc1\t5\n#again\nc9\t6\n",
+    }
+    for name, data in odd.items():
+        path = str(tmp_path / name)
+        with open(path, "wb") as f:
+            f.write(data)
+        want = utils.read_vcf_sites(path)[2]
+        names, cidx, pos = utils.read_vcf_site_arrays(path)
+        assert [(names[int(c)], int(p)) for c, p in zip(cidx, pos)] == want, name
+    for name, data, exc in (("nohdr.vcf", b"c1\t5\n", IOError), ("badpos.vcf", b"#h\nc1\tx\n", ValueError)):
+        path = str(tmp_path / name)
+        with open(path, "wb") as f:
+            f.write(data)
+        with pytest.raises(exc):
+            utils.read_vcf_site_arrays(path)
+    # the writer
+    contigs = ["ctg|1", "z", "é"]
+    uniq = np.array([(0 << 32) | 5, (0 << 32) | 4000000000, (2 << 32) | 1], dtype=np.uint64)
+    off = np.array([0, 2, 3, 6], dtype=np.uint32)
+    car = np.array([0, 2, 1, 2, 0, 1], dtype=np.uint32)
+    samples = ["s0", "sample one", "x"]
+    a, b = str(tmp_path / "a.txt"), str(tmp_path / "b.txt")
+    merge_sites.write_snplist(a, contigs, uniq, off, car, samples)
+    utils.write_list_of_snps(b, [(contigs[int(k) >> 32], int(k) & 0xFFFFFFFF) for k in uniq],
+                             [[samples[int(i)] for i in car[off[j]:off[j + 1]]] for j in range(len(uniq))])
+    assert open(a, "rb").read() == open(b, "rb").read()
+    merge_sites.write_snplist(a, [], np.zeros(0, np.uint64), np.zeros(1, np.uint32), np.zeros(0, np.uint32), [])
+    assert open(a, "rb").read() == b""
