@@ -36,7 +36,7 @@ def write_reference_snp_file(reference_file_path, snp_list_file_path, snp_refere
     the snplist positions of that contig, in snplist order (python indexing: position 0 reads the last base, a
     position past the end raises IndexError)."""
     with open(snp_list_file_path, "r") as snp_list_file:
-        position_list = [line.split()[0:2] for line in snp_list_file]
+        position_list = [line.split(None, 2)[0:2] for line in snp_list_file]
     match_dict = read_fasta_sequences(reference_file_path)
     by_contig = {}
     for item in position_list:

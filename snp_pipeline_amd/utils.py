@@ -222,7 +222,7 @@ def read_snp_position_list(snp_list_file_path):
     snp_list = list()
     with open(snp_list_file_path, "r") as snp_list_file_object:
         for line in snp_list_file_object:
-            chrom, pos = line.split()[0:2]
+            chrom, pos = line.split(None, 2)[0:2]            # (the first two fields only: a snplist line lists every carrier)
             snp_list.append((chrom, int(pos)))
     return snp_list
 
