@@ -8,6 +8,7 @@ behind ``Device.dense_windows / merge_regions / in_regions`` (csrc/regions.hip).
 """
 from __future__ import print_function
 
+import itertools
 import os
 import shutil
 import sys
@@ -25,12 +26,27 @@ def _edge_intervals(length, edge_length):
     return [(0, edge_length), (length - edge_length, length)]
 
 
+def sites_to_arrays(sites):
+    """[(contig, pos), ...] -> (contig names in order of first appearance, contig index per record, position per record): the
+    form utils.read_vcf_site_arrays returns."""
+    names, index = [], {}
+    for c, _ in sites:
+        if c not in index:
+            index[c] = len(names)
+            names.append(c)
+    return (names, np.fromiter((index[c] for c, _ in sites), dtype=np.uint32, count=len(sites)),
+            np.fromiter((p for _, p in sites), dtype=np.int64, count=len(sites)))
+
+
 def compute_bad_regions(dev, samples, contig_lengths, edge_length, max_snps_list, window_list, per_sample=False):
-    """samples: list (one per non-outgroup sample) of [(contig, pos), ...] in file order.
+    """samples: list (one per non-outgroup sample) of [(contig, pos), ...] in file order, or of the array triples of
+    sites_to_arrays / utils.read_vcf_site_arrays.
 
     Returns, for mode all, {contig: [(start, end), ...]} merged; for per_sample=True a list of such dicts.
     Every interval comes from the device: candidates from the dense-window kernel, the union from the merge
-    kernel.  The host only lays out segments and the contig-edge intervals (parameters, not data)."""
+    kernel.  The host only lays out segments (one per sample and contig, numpy) and the contig-edge intervals (parameters,
+    not data)."""
+    samples = [smp if isinstance(smp, tuple) and len(smp) == 3 and isinstance(smp[1], np.ndarray) else sites_to_arrays(smp) for smp in samples]
     # group ids: mode all -> contig; mode each -> (sample, contig)
     group_of = {}
     groups = []
@@ -43,13 +59,19 @@ def compute_bad_regions(dev, samples, contig_lengths, edge_length, max_snps_list
         return group_of[key]
 
     seg_positions, seg_group = [], []
-    for si, sites in enumerate(samples):
-        by_contig = {}
-        for contig, pos in sites:
-            by_contig.setdefault(contig, []).append(pos)
-        for contig, plist in by_contig.items():
-            seg_positions.append(plist)
-            seg_group.append(gid(si, contig))
+    for si, (names, cidx, pos) in enumerate(samples):
+        if len(pos) == 0:
+            continue
+        # one segment per contig, contigs in order of first appearance, positions in file order (a stable sort by contig index)
+        order = np.argsort(cidx, kind="stable")
+        sorted_c = cidx[order]
+        cuts = np.flatnonzero(np.diff(sorted_c)) + 1
+        starts = np.concatenate(([0], cuts))
+        ends = np.concatenate((cuts, [len(order)]))
+        ordered_pos = pos[order]
+        for a, b in zip(starts.tolist(), ends.tolist()):
+            seg_positions.append(ordered_pos[a:b])
+            seg_group.append(gid(si, names[int(sorted_c[a])]))
     g_list, s_list, e_list = [], [], []
     for (si, contig), g in sorted(group_of.items(), key=lambda kv: kv[1]):
         for a, b in _edge_intervals(contig_lengths.get(contig, UNKNOWN_CONTIG_LENGTH), edge_length):
@@ -57,7 +79,7 @@ def compute_bad_regions(dev, samples, contig_lengths, edge_length, max_snps_list
     if seg_positions:
         seg_off = np.zeros(len(seg_positions) + 1, dtype=np.uint32)
         seg_off[1:] = np.cumsum([len(p) for p in seg_positions])
-        flat = np.fromiter((p for plist in seg_positions for p in plist), dtype=np.int64, count=int(seg_off[-1]))
+        flat = np.concatenate(seg_positions).astype(np.int64, copy=False)
         cs, ce, cseg = dev.dense_windows(flat, seg_off, max_snps_list, window_list)
         seg_group_arr = np.asarray(seg_group, dtype=np.uint32)
         g_all = np.concatenate([np.asarray(g_list, dtype=np.uint32), seg_group_arr[cseg]])
@@ -69,19 +91,20 @@ def compute_bad_regions(dev, samples, contig_lengths, edge_length, max_snps_list
     mg, ms, me = dev.merge_regions(g_all, s_all, e_all)
     if per_sample:
         out = [dict() for _ in samples]
-        for g, a, b in zip(mg, ms, me):
-            si, contig = groups[int(g)]
-            out[si].setdefault(contig, []).append((int(a), int(b)))
+        for g, a, b in zip(mg.tolist(), ms.tolist(), me.tolist()):
+            si, contig = groups[g]
+            out[si].setdefault(contig, []).append((a, b))
         return out
     out = {}
-    for g, a, b in zip(mg, ms, me):
-        out.setdefault(groups[int(g)][1], []).append((int(a), int(b)))
+    for g, a, b in zip(mg.tolist(), ms.tolist(), me.tolist()):
+        out.setdefault(groups[g][1], []).append((a, b))
     return out
 
 
 def classify_records(dev, sites, regions):
-    """sites: [(contig, pos)]; regions: {contig: merged [(start, end)]}.  Returns a bool array, True = removed."""
-    if not sites:
+    """sites: [(contig, pos)] or an array triple; regions: {contig: merged [(start, end)]}.  Returns a bool array, True = removed."""
+    names, cidx, pos = sites if isinstance(sites, tuple) and len(sites) == 3 and isinstance(sites[1], np.ndarray) else sites_to_arrays(sites)
+    if len(pos) == 0:
         return np.zeros(0, dtype=bool)
     contigs = sorted(regions)
     cid = {c: i for i, c in enumerate(contigs)}
@@ -91,9 +114,8 @@ def classify_records(dev, sites, regions):
         rs.extend(a for a, _ in regions[c])
         re_.extend(b for _, b in regions[c])
         reg_off[i + 1] = len(rs)
-    pos_group = np.fromiter((cid[c] for c, _ in sites), dtype=np.uint32, count=len(sites))   # KeyError like bad_regions_dict[contig]
-    positions = np.fromiter((p for _, p in sites), dtype=np.int64, count=len(sites))
-    return dev.in_regions(pos_group, positions, reg_off, rs, re_)
+    lut = np.asarray([cid[c] for c in names], dtype=np.uint32)                  # KeyError like bad_regions_dict[contig]
+    return dev.in_regions(lut[cidx], pos.astype(np.int64, copy=False), reg_off, rs, re_)
 
 
 _STRUCTURED = ("##INFO=", "##FORMAT=", "##FILTER=", "##ALT=", "##contig=")
@@ -134,18 +156,32 @@ def write_preserved_and_removed_vcf_files(vcf_file_path, header, data_lines, rem
     removed = vcf_file_path[:-4] + "_removed.vcf"
     hdr = reorder_header(header)
     try:
-        _write_vcf(preserved, hdr, [ln for ln, r in zip(data_lines, removed_flags) if not r])
+        _write_vcf(preserved, hdr, itertools.compress(data_lines, (~np.asarray(removed_flags, dtype=bool)).tolist()))
     except (IOError, OSError):
         if os.path.exists(preserved):
             os.remove(preserved)
         utils.sample_error("Error: Cannot create the file for preserved SNPs: %s." % preserved, continue_possible=True)
         return
     try:
-        _write_vcf(removed, hdr, [ln for ln, r in zip(data_lines, removed_flags) if r])
+        _write_vcf(removed, hdr, itertools.compress(data_lines, np.asarray(removed_flags, dtype=bool).tolist()))
     except (IOError, OSError):
         if os.path.exists(removed):
             os.remove(removed)
         utils.sample_error("Error: Cannot create the file for removed SNPs: %s." % removed, continue_possible=True)
+
+
+def _read_vcf(vcf_path):
+    """(header lines, data lines, sites as arrays): the columns come from the library's reader (utils.read_vcf_site_arrays), the
+    lines from one readlines(); a file outside the reader's plain case is read by utils.read_vcf_sites, line by line."""
+    names, cidx, pos = utils.read_vcf_site_arrays(vcf_path)     # raises IOError for data before the header, like PyVCF3's Reader
+    with open(vcf_path, "r") as f:
+        lines = f.readlines()
+    header = [ln for ln in lines if ln.startswith("#")]
+    data_lines = [ln for ln in lines if not ln.startswith("#") and not ln.isspace()]
+    if len(data_lines) != len(pos):                             # (cannot happen for the files the plain reader accepts)
+        header, data_lines, sites = utils.read_vcf_sites(vcf_path)
+        return header, data_lines, sites_to_arrays(sites)
+    return header, data_lines, (names, cidx, pos)
 
 
 def filter_regions(args):
@@ -213,7 +249,7 @@ def filter_regions(args):
         if not filter_across_samples and not need_rebuild[vcf_path]:
             continue
         try:
-            header, data_lines, sites = utils.read_vcf_sites(vcf_path)
+            header, data_lines, sites = _read_vcf(vcf_path)
         except (IOError, OSError):
             utils.sample_error("Error: Cannot open the input vcf file: %s." % vcf_path, continue_possible=True)
             continue
