@@ -305,6 +305,11 @@ class Device(object):
         n = len(paths)
         if n == 0:
             return []
+        if n > 64:                                              # the shared record array is n x capacity: keep it small
+            out = []
+            for k in range(0, n, 64):
+                out.extend(self.varscan_files(paths[k:k + 64], params, capacity))
+            return out
         arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
         sites = np.empty((n, max(int(capacity), 1)), dtype=VARSCAN_DTYPE)       # only the rows the library reports are read
         counts = np.zeros(n, dtype=np.uint32)
