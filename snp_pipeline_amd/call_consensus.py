@@ -219,17 +219,22 @@ def call_consensus_batch(args):
                 groups.setdefault(frozenset(plan.excluded), []).append(plan)
             for excluded, group in groups.items():
                 ss, n_keys = build_siteset(dev, snp_list, excluded)
-                results, rcs, _ = dev.call_consensus_files(ss, [p.pileup_path for p in group], params, want_counts=True,
-                                                           want_line_offsets=True,
-                                                           want_depth_sum=bool(getattr(args, "amdMetricsRefFasta", None)))
-                for plan, rc, res in zip(group, rcs, results):
-                    try:
-                        dev.raise_file_status(plan.pileup_path, int(rc), res)
-                        with lock:                # the log lines of one sample stay together
-                            _write_outputs(plan, dev, ss, n_keys, res)
-                    except Exception as err:      # noqa: B902  (reported per sample below)
-                        with lock:
-                            errors.append((plan, err))
+                # a stream of at most `step` files per library call: the per-site records of a call are files x sites x 138 bytes
+                # on the host (0.4 GB for 16 files x 200 000 sites)
+                step = max(1, min(64, (1 << 29) // max(1, 138 * len(ss))))
+                for k in range(0, len(group), step):
+                    part = group[k:k + step]
+                    results, rcs, _ = dev.call_consensus_files(ss, [p.pileup_path for p in part], params, want_counts=True,
+                                                               want_line_offsets=True,
+                                                               want_depth_sum=bool(getattr(args, "amdMetricsRefFasta", None)))
+                    for plan, rc, res in zip(part, rcs, results):
+                        try:
+                            dev.raise_file_status(plan.pileup_path, int(rc), res)
+                            with lock:            # the log lines of one sample stay together
+                                _write_outputs(plan, dev, ss, n_keys, res)
+                        except Exception as err:  # noqa: B902  (reported per sample below)
+                            with lock:
+                                errors.append((plan, err))
                 ss.close()
         finally:
             dev.close()
