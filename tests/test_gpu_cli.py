@@ -3,6 +3,7 @@ ExpectedResults trees and, for call_consensus (no pileup ships with the referenc
 import filecmp
 import os
 import shutil
+import time
 
 import pytest
 
@@ -65,6 +66,22 @@ def test_filter_merge_matrix_distance_on_bundled_trees(tmp_path, fixture_trees, 
             want = os.path.join(root, "samples", s, name)
             if os.path.exists(want):
                 assert filecmp.cmp(os.path.join(work, "samples", s, name), want, shallow=False), (s, name)
+    if ds == "lambdaVirus":
+        # freshness (filter_regions.py:246-256): nothing is rewritten while every target is newer than every source; one newer
+        # source VCF makes all targets stale in mode all
+        probe = [os.path.join(work, "samples", s, name) for s in samples for name in ("var.flt_preserved.vcf", "var.flt_removed.vcf")]
+        before = [os.stat(p).st_mtime_ns for p in probe]
+        _run("filter_regions -n var.flt.vcf %s %s --edge_length 500 --window_size 1000 125 15 --max_snp 3 2 1 --mode all" % (dirs_file, ref))
+        assert [os.stat(p).st_mtime_ns for p in probe] == before
+        future = time.time() + 5
+        os.utime(os.path.join(work, "samples", samples[-1], "var.flt.vcf"), (future, future))
+        _run("filter_regions -n var.flt.vcf %s %s --edge_length 500 --window_size 1000 125 15 --max_snp 3 2 1 --mode all" % (dirs_file, ref))
+        assert all(a != b for a, b in zip([os.stat(p).st_mtime_ns for p in probe], before))
+        past = time.time() - 60
+        os.utime(os.path.join(work, "samples", samples[-1], "var.flt.vcf"), (past, past))
+        for s in samples:
+            for name in ("var.flt_preserved.vcf", "var.flt_removed.vcf"):
+                assert filecmp.cmp(os.path.join(work, "samples", s, name), os.path.join(root, "samples", s, name), shallow=False)
     # steps 6.1 / 6.2: merge_sites
     _run("merge_sites -n var.flt.vcf -o %s/snplist.txt %s %s.OrigVCF.filtered" % (work, dirs_file, dirs_file))
     _run("merge_sites -n var.flt_preserved.vcf -o %s/snplist_preserved.txt %s %s.PresVCF.filtered" % (work, dirs_file, dirs_file))
