@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development helper: scan rate on samples made of many contigs (device-generated pieces with different contig names
-laid back to back), some of them without any site.  Usage: python tools/scan_multi_contig.py [n_contigs] [contig_len]"""
+laid back to back), some of them without any site.  Usage: python tools/scan_multi_contig.py [n_contigs] [contig_len] [n_samples]"""
 import os
 import sys
 
@@ -17,7 +17,7 @@ def main():
     from snp_pipeline_amd import device as dev
     C = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     G = int(sys.argv[2]) if len(sys.argv) > 2 else 125_000
-    B = 8
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
     d = dev.Device(0)
     d.use_torch_stream()
     ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda")
