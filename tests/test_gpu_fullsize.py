@@ -152,3 +152,20 @@ def test_configs3_shard_125_and_grouped_batch_300(d):
             base, mask = po.call_record(po.parse_record(fields, p.min_base_quality), p)
             want = 0x2D if (mask or base == 0x2A) else base
             assert (int(bh[slot]), int(fh[slot])) == (want, mask)
+
+
+def test_merge_sites_at_configs4_scale(d):
+    """The C1 / merge_sites union at configs[4] size: 10 000 samples x 1 500 records over 200 000 sites on several contigs (15 M
+    keys, duplicates inside a sample included) against numpy: unique keys, carrier offsets, carriers in sample order."""
+    n, per, S = 10_000, 1_500, 200_000
+    rng = np.random.default_rng(8)
+    pool = np.unique(rng.integers(1, 5_000_000, size=S, dtype=np.uint64) | (rng.integers(0, 7, size=S, dtype=np.uint64) << np.uint64(32)))
+    keys = pool[rng.integers(0, len(pool), size=n * per)]
+    samp = np.repeat(np.arange(n, dtype=np.uint32), per)
+    perm = rng.permutation(n * per)                              # records arrive in any order
+    uniq, off, car = d.merge_sites(keys[perm], samp[perm])
+    pairs = np.unique(np.stack([keys, samp.astype(np.uint64)], axis=1), axis=0)       # (key, sample) once each, sorted by key then sample
+    want_u, first = np.unique(pairs[:, 0], return_index=True)
+    assert np.array_equal(uniq, want_u)
+    assert np.array_equal(off, np.append(first, len(pairs)).astype(np.uint32))
+    assert np.array_equal(car, pairs[:, 1].astype(np.uint32))
