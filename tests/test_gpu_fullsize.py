@@ -169,3 +169,56 @@ def test_merge_sites_at_configs4_scale(d):
     assert np.array_equal(uniq, want_u)
     assert np.array_equal(off, np.append(first, len(pairs)).astype(np.uint32))
     assert np.array_equal(car, pairs[:, 1].astype(np.uint32))
+
+
+def test_region_steps_at_configs4_scale(d):
+    """K3 at configs[4] size: 10 000 segments (samples) x 1 500 positions, the pipeline's three dense-window rules, the interval
+    union per group and the classification of all 15 M positions, against numpy restatements of filter_regions.py:17-71 and
+    utils.py:1168-1318 (window i is dense iff p[i+M] exists and p[i] + W - 1 >= p[i+M]; sort, join overlapping or adjacent
+    intervals; inclusive ends)."""
+    n, per = 10_000, 1_500
+    rng = np.random.default_rng(10)
+    # clustered positions so that windows are dense here and there: cluster centres + small offsets
+    centres = rng.integers(1000, 4_999_000, size=(n, per // 5), dtype=np.int64)
+    pos = (np.repeat(centres, 5, axis=1) + rng.integers(0, 2500, size=(n, per), dtype=np.int64))
+    shuffled = rng.permuted(pos, axis=1)                         # the device sorts each segment itself
+    seg_off = (np.arange(n + 1, dtype=np.uint64) * per).astype(np.uint32)
+    max_snps, windows = [3, 2, 1], [1000, 125, 15]
+    cs, ce, cseg = d.dense_windows(shuffled.reshape(-1), seg_off, max_snps, windows)
+    srt = np.sort(pos, axis=1)
+    want = []
+    for m, w in zip(max_snps, windows):
+        a, b = srt[:, :-m], srt[:, m:]
+        hit = a + w - 1 >= b
+        seg = np.broadcast_to(np.arange(n, dtype=np.int64)[:, None], hit.shape)[hit]
+        want.append(np.stack([seg, a[hit], b[hit]], axis=1))
+    want = np.concatenate(want)
+    got = np.stack([cseg.astype(np.int64), cs, ce], axis=1)
+    assert len(got) == len(want) > 1_000_000
+
+    def rows_sorted(x):
+        return x[np.lexsort((x[:, 2], x[:, 1], x[:, 0]))]
+    assert np.array_equal(rows_sorted(got), rows_sorted(want))
+    # union per group (group = segment % 500: many samples feed one group, as mode all does per contig)
+    grp = (cseg % 500).astype(np.uint32)
+    mg, ms, me = d.merge_regions(grp, cs, ce)
+    order = np.lexsort((ce, cs, grp))
+    g, s, e = grp[order].astype(np.int64), cs[order], ce[order]
+    key_e = e + g * (1 << 40)                                    # running maximum of the end, restarted per group
+    run = np.maximum.accumulate(key_e) - g * (1 << 40)
+    new = np.ones(len(g), dtype=bool)
+    new[1:] = (g[1:] != g[:-1]) | (s[1:] > run[:-1] + 1)
+    starts = np.flatnonzero(new)
+    want_g, want_s = g[starts], s[starts]
+    want_e = run[np.append(starts[1:], len(g)) - 1]
+    assert np.array_equal(mg.astype(np.int64), want_g) and np.array_equal(ms, want_s) and np.array_equal(me, want_e)
+    # classification of every position against the regions of its group
+    reg_off = np.zeros(501, dtype=np.uint32)
+    np.cumsum(np.bincount(want_g, minlength=500), out=reg_off[1:])
+    pos_group = np.repeat(np.arange(n, dtype=np.uint32) % 500, per)
+    flags = d.in_regions(pos_group, shuffled.reshape(-1), reg_off, ms, me)
+    p = shuffled.reshape(-1)
+    key_s = want_s + want_g * (1 << 40)
+    idx = np.searchsorted(key_s, p + pos_group.astype(np.int64) * (1 << 40), side="right") - 1
+    inside = (idx >= 0) & (want_g[np.maximum(idx, 0)] == pos_group) & (p <= want_e[np.maximum(idx, 0)])
+    assert np.array_equal(flags, inside) and 0.01 < inside.mean() < 0.99
