@@ -8,7 +8,7 @@ tmp=$(mktemp -d)
 mkdir -p "$root/tools/ab"
 base="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -Wno-unused-result -I$root/include"
 others=""
-for f in ctx consensus stream varscan vcf_rows tsv_out distance regions synth; do
+for f in ctx consensus stream varscan varscan_rows vcf_rows tsv_out fasta_in vcf_in distance regions synth; do
     /opt/rocm/bin/hipcc $base -c $csrc/$f.hip -o $tmp/$f.o &
     others="$others $tmp/$f.o"
 done
@@ -22,9 +22,5 @@ while IFS='|' read -r tag flags; do
 done <<LIST
 base|
 maxilp|-mllvm -amdgpu-sched-strategy=max-ilp
-maxmem|-mllvm -amdgpu-sched-strategy=max-memory-clause
-iterilp|-mllvm -amdgpu-sched-strategy=iterative-ilp
-minreg|-mllvm -amdgpu-sched-strategy=iterative-minreg
-nopostra|-mllvm -enable-post-misched=false
 LIST
 rm -rf "$tmp"
