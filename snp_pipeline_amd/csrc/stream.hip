@@ -875,6 +875,85 @@ int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_f
             });
         return SNPGPU_OK;
     };
+    // The work on a complete file, in two halves around the one number the host needs (its line count).
+    hipEvent_t ev_count = nullptr;
+    {
+        hipError_t e = hipEventCreateWithFlags(&ev_count, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            { std::lock_guard<std::mutex> lk(sh.mu); sh.abort = true; sh.next.store(J); }
+            sh.cv.notify_all();
+            for (auto &t : readers) t.join();
+            close_all();
+            return snpgpu_set_error(ctx, SNPGPU_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+        }
+    }
+#define VS_RET(expr)                                                                                                \
+    do {                                                                                                            \
+        hipError_t e_ = (expr);                                                                                     \
+        if (e_ != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+    auto post_begin = [&](uint32_t f) -> int {                  // count the lines; the count travels to the slot's pinned block
+        const uint32_t slot = f % n_slots;
+        const uint64_t nbytes = src[f].size;
+        void *scr = nullptr;
+        int r = snpgpu_scratch(ctx, 2 * (up(4 * snpgpu_lines_workspace_words(nbytes), 256) + 512), &scr);
+        if (r) return r;
+        const size_t half = ctx->scratch_bytes / 2 / 256 * 256;
+        uint32_t *d_total = nullptr;
+        r = snpgpu_enqueue_lines_count(ctx, (const uint8_t *)p->slot[slot], nbytes, (uint32_t *)((char *)scr + half * slot), &d_total);
+        if (r) return r;
+        VS_RET(hipMemcpyAsync((char *)p->result[slot] + 48, d_total, 4, hipMemcpyDeviceToHost, st));
+        VS_RET(hipEventRecord(ev_count, st));
+        return SNPGPU_OK;
+    };
+    auto post_finish = [&](uint32_t f) -> int {                 // index the lines, walk them, results into the slot's pinned block
+        const uint32_t slot = f % n_slots;
+        const uint64_t nbytes = src[f].size;
+        const uint8_t *d_file = (const uint8_t *)p->slot[slot];
+        char *res = (char *)p->result[slot];
+        VS_RET(hipEventSynchronize(ev_count));
+        uint32_t n_lines = 0;
+        memcpy(&n_lines, res + 48, 4);
+        out_status[2 * f + 1] = n_lines;
+        if (n_lines == 0) {
+            const uint64_t none = ~0ull;
+            memcpy(res, &none, 8);
+            memset(res + 8, 0, 8);
+            VS_RET(hipEventRecord(p->ev_done[slot], st));
+            has_result[f] = 1;
+            return SNPGPU_OK;
+        }
+        const size_t ws_words = snpgpu_lines_workspace_words(nbytes);
+        size_t o = up(4 * ws_words, 256);
+        const size_t o_off = o; o += up(8ull * n_lines, 256);
+        const size_t o_ctl = o; o += 256;
+        const size_t o_rec = o; o += sizeof(snpgpu_varscan_site) * (size_t)capacity + 256;
+        const size_t before = ctx->scratch_bytes;
+        void *scr = nullptr;
+        int r = snpgpu_scratch(ctx, 2 * o + 512, &scr);         // may move the scratch (it waits for the compute stream first)
+        if (r) return r;
+        const size_t half = ctx->scratch_bytes / 2 / 256 * 256;
+        char *b = (char *)scr + half * slot;
+        uint32_t *d_total = nullptr;
+        if (ctx->scratch_bytes != before) {                     // the block counts of post_begin went with the old scratch
+            r = snpgpu_enqueue_lines_count(ctx, d_file, nbytes, (uint32_t *)b, &d_total);
+            if (r) return r;
+        }
+        r = snpgpu_enqueue_lines_offsets(ctx, d_file, nbytes, (uint32_t *)b, (uint64_t *)(b + o_off), n_lines);
+        if (r) return r;
+        uint64_t h_ctl[2] = {~0ull, 0};
+        memcpy(res + 32, h_ctl, sizeof h_ctl);                  // (a pinned source that stays valid until the copy has run)
+        VS_RET(hipMemcpyAsync(b + o_ctl, res + 32, sizeof h_ctl, hipMemcpyHostToDevice, st));
+        r = snpgpu_enqueue_varscan(ctx, d_file, nbytes, (const uint64_t *)(b + o_off), n_lines, params, (snpgpu_varscan_site *)(b + o_rec), capacity,
+                                   (uint32_t *)(b + o_ctl + 8), (uint64_t *)(b + o_ctl));
+        if (r) return r;
+        VS_RET(hipMemcpyAsync(res, b + o_ctl, 16, hipMemcpyDeviceToHost, st));
+        if (capacity) VS_RET(hipMemcpyAsync(res + r_rec, b + o_rec, sizeof(snpgpu_varscan_site) * (size_t)capacity, hipMemcpyDeviceToHost, st));
+        VS_RET(hipEventRecord(p->ev_done[slot], st));
+        has_result[f] = 1;
+        return SNPGPU_OK;
+    };
+#undef VS_RET
 #define VS_TRY(expr)                                                                                                \
     do {                                                                                                            \
         hipError_t e_ = (expr);                                                                                     \
@@ -883,13 +962,17 @@ int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_f
     {
         uint32_t harvested = 0;
         int64_t copies_done = 0;
+        int64_t pending = -1;                                   // a file whose lines are being counted
         for (uint64_t j = 0; j < J; ++j) {
             const Job &jb = jobs[j];
             const uint32_t f = jb.file, slot = f % n_slots;
             Source &s = src[f];
             uint8_t *d_file = (uint8_t *)p->slot[slot];
-            if (jb.first)                                       // the slot and its result block are free once their last user has been harvested
+            if (pending >= 0 && hipEventQuery(ev_count) != hipErrorNotReady) { rc = post_finish((uint32_t)pending); pending = -1; if (rc) goto done; }
+            if (jb.first) {                                     // the slot and its result block are free once their last user has been harvested
+                if (pending >= 0 && (uint32_t)pending + n_slots <= f) { rc = post_finish((uint32_t)pending); pending = -1; if (rc) goto done; }
                 while (harvested + n_slots <= f) { rc = harvest(harvested); if (rc) goto done; ++harvested; }
+            }
             for (;;) {                                          // wait for the piece to be read; retire finished copies meanwhile
                 bool progress = false;
                 while (copies_done < (int64_t)j && hipEventQuery(p->ev_copy[copies_done % R]) != hipErrorNotReady) { ++copies_done; progress = true; }
@@ -905,53 +988,14 @@ int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_f
             VS_TRY(hipEventRecord(p->ev_copy[j % R], cs));
             VS_TRY(hipStreamWaitEvent(st, p->ev_copy[j % R], 0));
             if (!jb.last || s.rc != SNPGPU_OK || s.size == 0) continue;
-            // ---- the whole file is on its way: index its lines, walk them, results into the slot's pinned block ----
-            const uint64_t nbytes = s.size;
-            const size_t ws_words = snpgpu_lines_workspace_words(nbytes);
-            void *scr = nullptr;
-            rc = snpgpu_scratch(ctx, 2 * (up(4 * ws_words, 256) + 512), &scr);
+            // ---- the whole file is on its way: count its lines now, do the rest when the count has come back (the copies of
+            //      the next file are issued in the meantime: nobody waits for this file's tail) ----
+            if (pending >= 0) { rc = post_finish((uint32_t)pending); pending = -1; if (rc) goto done; }
+            rc = post_begin(f);
             if (rc) goto done;
-            size_t half = ctx->scratch_bytes / 2 / 256 * 256;
-            uint32_t *d_total = nullptr;
-            rc = snpgpu_enqueue_lines_count(ctx, d_file, nbytes, (uint32_t *)((char *)scr + half * slot), &d_total);
-            if (rc) goto done;
-            uint32_t n_lines = 0;
-            VS_TRY(hipMemcpyAsync(&n_lines, d_total, 4, hipMemcpyDeviceToHost, st));
-            VS_TRY(hipStreamSynchronize(st));                   // (also: the previous file's kernels and result copy are done)
-            out_status[2 * f + 1] = n_lines;
-            char *res = (char *)p->result[slot];
-            if (n_lines == 0) {
-                const uint64_t none = ~0ull;
-                memcpy(res, &none, 8);
-                memset(res + 8, 0, 8);
-                VS_TRY(hipEventRecord(p->ev_done[slot], st));
-                has_result[f] = 1;
-                continue;
-            }
-            size_t o = up(4 * ws_words, 256);
-            const size_t o_off = o; o += up(8ull * n_lines, 256);
-            const size_t o_ctl = o; o += 256;
-            const size_t o_rec = o; o += sizeof(snpgpu_varscan_site) * (size_t)capacity + 256;
-            rc = snpgpu_scratch(ctx, 2 * o + 512, &scr);        // may move the scratch: everything enqueued so far has finished (sync above)
-            if (rc) goto done;
-            half = ctx->scratch_bytes / 2 / 256 * 256;
-            char *b = (char *)scr + half * slot;
-            rc = snpgpu_enqueue_lines_count(ctx, d_file, nbytes, (uint32_t *)b, &d_total);
-            if (rc == SNPGPU_OK) rc = snpgpu_enqueue_lines_offsets(ctx, d_file, nbytes, (uint32_t *)b, (uint64_t *)(b + o_off), n_lines);
-            if (rc) goto done;
-            {
-                uint64_t h_ctl[2] = {~0ull, 0};
-                memcpy(res + 32, h_ctl, sizeof h_ctl);          // (a pinned source that stays valid until the copy has run)
-                VS_TRY(hipMemcpyAsync(b + o_ctl, res + 32, sizeof h_ctl, hipMemcpyHostToDevice, st));
-            }
-            rc = snpgpu_enqueue_varscan(ctx, d_file, nbytes, (const uint64_t *)(b + o_off), n_lines, params, (snpgpu_varscan_site *)(b + o_rec), capacity,
-                                        (uint32_t *)(b + o_ctl + 8), (uint64_t *)(b + o_ctl));
-            if (rc) goto done;
-            VS_TRY(hipMemcpyAsync(res, b + o_ctl, 16, hipMemcpyDeviceToHost, st));
-            if (capacity) VS_TRY(hipMemcpyAsync(res + r_rec, b + o_rec, sizeof(snpgpu_varscan_site) * (size_t)capacity, hipMemcpyDeviceToHost, st));
-            VS_TRY(hipEventRecord(p->ev_done[slot], st));
-            has_result[f] = 1;
+            pending = (int64_t)f;
         }
+        if (pending >= 0) { rc = post_finish((uint32_t)pending); pending = -1; if (rc) goto done; }
         while (harvested < n_files) { rc = harvest(harvested); if (rc) goto done; ++harvested; }
     }
 done:
@@ -964,6 +1008,7 @@ done:
     for (auto &t : readers) t.join();
     if (rc) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamSynchronize(p->copy_stream2); (void)hipStreamSynchronize(st); }
     close_all();
+    if (ev_count) (void)hipEventDestroy(ev_count);
     for (uint32_t f = 0; f < n_files; ++f) out_rc[f] = src[f].rc;
     return rc;
 }
