@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SNPGPU_ABI_VERSION 2
+#define SNPGPU_ABI_VERSION 3
 
 /* ---- error codes ------------------------------------------------------- */
 #define SNPGPU_OK            0
@@ -59,6 +59,7 @@ extern "C" {
 
 typedef struct snpgpu_ctx snpgpu_ctx;
 typedef struct snpgpu_siteset snpgpu_siteset;
+typedef struct snpgpu_pileups snpgpu_pileups;
 
 /* ConsensusCaller parameters, pileup.py:433-465 (+ Reader's min_base_quality, pileup.py:384). */
 typedef struct snpgpu_caller_params {
@@ -151,6 +152,14 @@ int  snpgpu_call_consensus_batch_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, 
                                      const uint64_t *h_offsets, const uint64_t *h_sizes, uint32_t n_samples,
                                      const snpgpu_caller_params *params, uint8_t *d_out_base,
                                      uint8_t *d_out_filters, uint64_t *d_status);
+/* Samples anywhere in device memory (d_pileups: HOST array of n device pointers, h_sizes their lengths), with everything the
+ * streamed form returns: d_out_counts (nullable) and d_out_line_off (nullable) are [n][n_sites] like the other outputs,
+ * d_site_flags (nullable) [n][n_sites] replaces the set's flags per sample (a sample's own exclude list).  Asynchronous. */
+int  snpgpu_call_consensus_many_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const void *const *d_pileups,
+                                    const uint64_t *h_sizes, uint32_t n_samples, const snpgpu_caller_params *params,
+                                    const uint8_t *d_site_flags, uint8_t *d_out_base, uint8_t *d_out_filters,
+                                    snpgpu_site_counts *d_out_counts, uint64_t *d_out_line_off, uint64_t *d_status,
+                                    int want_depth_sum);
 /* Host-buffer form for one pileup (an mmap, bytes read elsewhere): streamed through the same pipeline as
  * snpgpu_call_consensus_files below, synchronous.
  * Returns SNPGPU_E_PILEUP when the scan found a malformed line (status words still filled). */
@@ -170,7 +179,12 @@ int  snpgpu_call_consensus(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint
  * out_counts (nullable) the per-site records, out_line_off (nullable) 1 + byte offset of the line used for
  * each site (0 = none), out_status [n_files][4] the scan status words, out_rc (nullable) per file: 0,
  * SNPGPU_E_IO (could not open / read: its outputs are void), SNPGPU_E_PILEUP or SNPGPU_E_UNSUPPORTED (malformed
- * pileup: see its status words).  The return value is 0 unless the pipeline itself failed. */
+ * pileup: see its status words).  The return value is 0 unless the pipeline itself failed.
+ *
+ * excl_off / excl_slots (both nullable): per-file exclude lists (call_consensus.py:117-123: every sample of step 7.2 has its
+ * own var.flt_removed.vcf) as CSR over site-set slots — file f is called with the set's flags plus SNPGPU_SITE_EXCLUDED on
+ * slots excl_slots[excl_off[f] .. excl_off[f+1]), so one site set (the union of the snplist and every file's list) and one
+ * stream of files serve all samples. */
 typedef struct snpgpu_stream_opts {      /* 0 = default everywhere */
     uint32_t chunk_bytes;                /* bytes per host->device copy (default 8 MiB; rounded up to 4 KiB) */
     uint32_t n_staging;                  /* pinned staging buffers (default: readers + 4) */
@@ -191,7 +205,8 @@ typedef struct snpgpu_stream_stats {
     double   seconds_enqueueing;         /* issuing thread: inside HIP enqueue calls (copies, events, kernels) */
 } snpgpu_stream_stats;
 int  snpgpu_call_consensus_files(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const char *const *paths, uint32_t n_files,
-                                 const snpgpu_caller_params *params, uint8_t *out_base, uint8_t *out_filters,
+                                 const snpgpu_caller_params *params, const uint32_t *excl_off, const uint32_t *excl_slots,
+                                 uint8_t *out_base, uint8_t *out_filters,
                                  snpgpu_site_counts *out_counts, uint64_t *out_line_off, uint64_t *out_status,
                                  int32_t *out_rc, const snpgpu_stream_opts *opts, snpgpu_stream_stats *stats);
 
@@ -248,6 +263,38 @@ int  snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_
                           uint32_t capacity, snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status,
                           int32_t *out_rc);
 
+/* The same over a pileup that already is in device memory. */
+int  snpgpu_varscan_dev(snpgpu_ctx *ctx, const void *d_pileup, uint64_t nbytes, const snpgpu_varscan_params *params,
+                        uint32_t capacity, snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status);
+
+/* ---- resident pileups: the input side of the one-job pipeline (`cfsan_snp_pipeline hot_path_batch`) ----------------------
+ * The reference runs steps 4-11 as separate process arrays over a shared file system (run.py:662-784): call_sites
+ * (call_sites.py:89-108) and call_consensus twice (run.py:704-710, :712-718) each read a sample's reads.all.pileup again.
+ * A snpgpu_pileups store keeps the files in device memory instead: snpgpu_pileups_ingest streams them in exactly as
+ * snpgpu_varscan_files does (same reader threads, staging ring, copy streams; site calling on a file while the next one
+ * arrives) but leaves every file where it landed, while `budget_bytes` of device memory last (0: what is free at creation
+ * less 24 GiB); files past the budget are site-called through the two streaming slots and stay non-resident.  The consensus
+ * step then reads the resident files with snpgpu_call_consensus_many_dev: each pileup crosses the host link once.
+ * params == NULL: no site calling (the files are only made resident).  out_done (nullable) [n_files]: set to 1 (release
+ * store) when the outputs of file f are final, so that another host thread can turn them into var.flt.vcf while the call is
+ * still running.  Other arguments as snpgpu_varscan_files. */
+typedef struct snpgpu_pileups_stats {
+    uint64_t h2d_bytes;             /* bytes copied host -> device on behalf of the store */
+    uint64_t file_bytes;            /* sizes of the ingested files */
+    uint64_t resident_bytes;        /* device bytes taken (files + padding) */
+    uint64_t budget_bytes;
+    uint32_t n_files, n_resident;
+} snpgpu_pileups_stats;
+int  snpgpu_pileups_create(snpgpu_ctx *ctx, uint64_t budget_bytes, snpgpu_pileups **out);
+void snpgpu_pileups_destroy(snpgpu_pileups *store);
+int  snpgpu_pileups_ingest(snpgpu_ctx *ctx, snpgpu_pileups *store, const char *const *paths, uint32_t n_files,
+                           const snpgpu_varscan_params *params, uint32_t capacity, snpgpu_varscan_site *out_sites,
+                           uint32_t *out_n_sites, uint64_t *out_status, int32_t *out_rc, int32_t *out_done);
+uint32_t snpgpu_pileups_count(const snpgpu_pileups *store);
+/* file `index` in ingestion order: its device pointer (NULL when it is not resident) and size */
+int  snpgpu_pileups_get(const snpgpu_pileups *store, uint32_t index, void **d_ptr, uint64_t *nbytes);
+int  snpgpu_pileups_get_stats(const snpgpu_pileups *store, snpgpu_pileups_stats *out);
+
 /* The host half of the same step (no device work, no context): the records of snpgpu_varscan_file, in its order, ->
  * var.flt.vcf data lines.  Per line: the allele with the most variant reads among those whose Fisher p (reads against a
  * 0.1 % error model, VarScan.getSignificance) is <= p_value; strand filter (FILTER str10); GT 1/1 at or above
@@ -274,6 +321,45 @@ size_t snpgpu_format_vcf_rows(const snpgpu_site_counts *counts, const uint32_t *
                               const uint8_t *contig_names, const uint32_t *contig_name_off, const uint64_t *site_keys,
                               const char *const *filter_names, int preserve_ref_case, char failed_snp_gt,
                               char *out, size_t capacity, int32_t *out_bad_row);
+
+/* The output files of call_consensus (call_consensus.py:178-192: consensus.fasta through Bio.SeqIO, consensus.vcf through
+ * vcf_writer.SingleSampleWriter) for many (sample, flow) pairs at once, on host threads — host code, no device work, no
+ * context.  Per job: fasta_path (nullable) gets ">fasta_id" and `sequence` in lines of 60; vcf_path (nullable) gets vcf_header
+ * followed by one row per site whose record has status SNPGPU_ST_OK, in the order of line_off (pileup order) — with
+ * site_in_flow (nullable, [n_sites]) only the sites it marks and those whose row mask carries SNPGPU_F_REGION (the parse set
+ * of call_consensus.py:147-151 is the snplist plus the sample's exclude list); row_filters (nullable, [n_sites]) replaces the
+ * records' own failed-filter masks.  Out: rc (0, SNPGPU_E_IO, or SNPGPU_E_UNSUPPORTED for a record with more than
+ * SNPGPU_MAX_SYMS symbols) and n_rows.  Contig names / site_keys / filter_names as snpgpu_format_vcf_rows; n_threads 0 = as
+ * many as there are jobs, up to 64. */
+typedef struct snpgpu_consensus_job {
+    const char *fasta_path;
+    const char *fasta_id;
+    const uint8_t *sequence;
+    uint64_t n_bases;
+    const char *vcf_path;
+    const char *vcf_header;
+    const snpgpu_site_counts *counts;
+    const uint64_t *line_off;
+    const uint8_t *row_filters;
+    const uint8_t *site_in_flow;
+    int32_t rc;
+    uint32_t n_rows;
+} snpgpu_consensus_job;
+int  snpgpu_write_consensus_files(snpgpu_consensus_job *jobs, uint32_t n_jobs, uint32_t n_sites, const uint8_t *contig_names,
+                                  const uint32_t *contig_name_off, const uint64_t *site_keys, const char *const *filter_names,
+                                  int preserve_ref_case, char failed_snp_gt, uint32_t n_threads);
+
+/* Both consensus flows from one call (run.py:704-718 calls every sample twice: at the positions of snplist.txt, and at those
+ * of snplist_preserved.txt with the sample's var.flt_removed.vcf as exclude file).  From the result of the call over the FULL
+ * list — d_base / d_filters / d_line_off, [n_samples][n_sites] — derives the preserved flow: d_out_base [n_samples][n_cols] =
+ * the columns d_cols[n_cols] (slots of the preserved list, in its order), d_out_filters [n_samples][n_sites] = the filters,
+ * and for every slot of a sample's exclude list (CSR d_excl_off[n_samples + 1] / d_excl_slots) whose position has a pileup
+ * line: SNPGPU_F_REGION in the filters and '-' as its base when it is a column (d_col_of[n_sites]: column of a slot or -1) —
+ * call_consensus.py:165-176.  d_err: one zeroed word, bit 0 = an exclude slot >= n_sites.  Asynchronous. */
+int  snpgpu_region_flow_dev(snpgpu_ctx *ctx, const uint8_t *d_base, const uint8_t *d_filters, const uint64_t *d_line_off,
+                            uint32_t n_samples, uint32_t n_sites, const uint32_t *d_cols, const int32_t *d_col_of, uint32_t n_cols,
+                            const uint32_t *d_excl_off, const uint32_t *d_excl_slots, uint8_t *d_out_base, uint8_t *d_out_filters,
+                            uint32_t *d_err);
 
 /* After a call_consensus on `ss`: for every site, 1 + the byte offset of the pileup line that was used (0 = no
  * line).  consensus.vcf rows are written in pileup order (call_consensus.py:161-180), which this recovers.
@@ -306,6 +392,12 @@ int  snpgpu_distance(snpgpu_ctx *ctx, const uint8_t *symbols, uint32_t n_rows, u
 int  snpgpu_vcf_sites(const char *path, uint64_t capacity, uint32_t *out_pos, uint32_t *out_contig, uint64_t *out_n_records,
                       char *out_names, uint64_t names_capacity, uint64_t *out_name_off, uint32_t names_max,
                       uint32_t *out_n_names);
+/* The first two columns of snplist.txt, what utils.read_snp_position_list (utils.py:1073-1088) returns: as snpgpu_vcf_sites,
+ * but every line is a record (no header, no blank lines); a line outside the plain case — columns separated by anything but
+ * TAB, a position that is not 1-10 plain digits — is SNPGPU_E_UNSUPPORTED and belongs to the caller's own reader. */
+int  snpgpu_snplist_sites(const char *path, uint64_t capacity, uint32_t *out_pos, uint32_t *out_contig, uint64_t *out_n_records,
+                          char *out_names, uint64_t names_capacity, uint64_t *out_name_off, uint32_t names_max,
+                          uint32_t *out_n_names);
 /* snplist.txt (utils.write_list_of_snps, utils.py:1056-1070): one "chrom\tpos\tcount\tname..." line per site; keys =
  * (contig index << 32) | pos in output order, carriers of site i = carriers[carrier_off[i], carrier_off[i+1]) as sample
  * indices; contig / sample names back to back with their offset arrays. */

@@ -64,6 +64,17 @@ class VarscanSite(C.Structure):
                 ("ref_base", C.c_uint8), ("alt_base", C.c_uint8), ("reserved", C.c_uint8 * 2)]
 
 
+class PileupsStats(C.Structure):
+    _fields_ = [("h2d_bytes", C.c_uint64), ("file_bytes", C.c_uint64), ("resident_bytes", C.c_uint64), ("budget_bytes", C.c_uint64),
+                ("n_files", C.c_uint32), ("n_resident", C.c_uint32)]
+
+
+class ConsensusJob(C.Structure):
+    _fields_ = [("fasta_path", C.c_char_p), ("fasta_id", C.c_char_p), ("sequence", C.c_void_p), ("n_bases", C.c_uint64),
+                ("vcf_path", C.c_char_p), ("vcf_header", C.c_char_p), ("counts", C.c_void_p), ("line_off", C.c_void_p),
+                ("row_filters", C.c_void_p), ("site_in_flow", C.c_void_p), ("rc", C.c_int32), ("n_rows", C.c_uint32)]
+
+
 assert C.sizeof(SiteCounts) == 128 and C.sizeof(CallerParams) == 32 and C.sizeof(VarscanSite) == 48 and C.sizeof(VarscanParams) == 24
 
 # name -> (restype, argtypes); every exported symbol of include/snpgpu.h
@@ -87,8 +98,18 @@ SIGNATURES = {
     "snpgpu_call_consensus_dev": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(CallerParams), _P, _P, _P, _P, C.c_int]),
     "snpgpu_call_consensus_batch_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint32, C.POINTER(CallerParams), _P, _P, _P]),
     "snpgpu_call_consensus": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(CallerParams), _P, _P, _P, _P, C.c_int]),
-    "snpgpu_call_consensus_files": (C.c_int, [_P, _P, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(CallerParams), _P, _P,
+    "snpgpu_call_consensus_files": (C.c_int, [_P, _P, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(CallerParams), _P, _P, _P, _P,
                                               _P, _P, _P, _P, C.POINTER(StreamOpts), C.POINTER(StreamStats)]),
+    "snpgpu_call_consensus_many_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(CallerParams), _P, _P, _P, _P, _P, _P, C.c_int]),
+    "snpgpu_region_flow_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, C.c_uint32, _P, _P, _P, _P, _P]),
+    "snpgpu_write_consensus_files": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.POINTER(C.c_char_p), C.c_int, C.c_char, C.c_uint32]),
+    "snpgpu_varscan_dev": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P, C.POINTER(C.c_uint32), _P]),
+    "snpgpu_pileups_create": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
+    "snpgpu_pileups_destroy": (None, [_P]),
+    "snpgpu_pileups_ingest": (C.c_int, [_P, _P, C.POINTER(C.c_char_p), C.c_uint32, _P, C.c_uint32, _P, _P, _P, _P, _P]),
+    "snpgpu_pileups_count": (C.c_uint32, [_P]),
+    "snpgpu_pileups_get": (C.c_int, [_P, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "snpgpu_pileups_get_stats": (C.c_int, [_P, C.POINTER(PileupsStats)]),
     "snpgpu_call_all_lines_file": (C.c_int, [_P, _P, C.c_char_p, C.POINTER(CallerParams), C.c_uint64, C.POINTER(C.c_uint64),
                                              _P, _P, _P, _P]),
     "snpgpu_format_vcf_rows": (C.c_size_t, [_P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_char_p), C.c_int, C.c_char, _P, C.c_size_t,
@@ -104,6 +125,7 @@ SIGNATURES = {
     "snpgpu_fasta_scan": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "snpgpu_fasta_load": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint8, _P, _P, _P, _P]),
     "snpgpu_vcf_sites": (C.c_int, [C.c_char_p, C.c_uint64, _P, _P, C.POINTER(C.c_uint64), _P, C.c_uint64, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "snpgpu_snplist_sites": (C.c_int, [C.c_char_p, C.c_uint64, _P, _P, C.POINTER(C.c_uint64), _P, C.c_uint64, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     "snpgpu_write_snplist": (C.c_int, [C.c_char_p, _P, _P, _P, C.c_uint64, _P, _P, _P, _P]),
     "snpgpu_write_distance_tsv": (C.c_int, [C.c_char_p, C.c_int, _P, _P, C.c_uint32, _P, C.c_uint64]),
     "snpgpu_dense_windows": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_uint32)]),

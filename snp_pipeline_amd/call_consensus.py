@@ -17,33 +17,44 @@ import numpy as np
 
 from . import _lib as L
 from . import device as devmod
+from . import timing
 from . import utils
 from . import vcf_writer
 
 
-def build_siteset(dev, snp_list, excluded_positions):
-    """snp_list: [(chrom str, pos int)] in snplist order; excluded_positions: set of the same.  Returns (SiteSet, the
-    number of snplist keys): slots [0, n) of ``index_of`` are the snplist positions in order."""
-    keys = [(c.encode(), p) for c, p in snp_list]
-    snps = set(keys)
-    excl = {(c.encode(), p) for c, p in excluded_positions}
-    extra = [k for k in sorted(excl) if k not in snps]
-    all_keys = keys + extra
-    flags = [(L.SITE_IN_SNPLIST if k in snps else 0) | (L.SITE_EXCLUDED if k in excl else 0) for k in all_keys]
-    return dev.siteset(all_keys, flags), len(keys)
+def _unique_sites(arrays):
+    """The distinct (contig, position) pairs of an array triple (the size of the reference's set of them)."""
+    _, cidx, pos = arrays
+    return np.unique((cidx.astype(np.int64) << 40) ^ pos) if len(pos) else np.zeros(0, np.int64)
 
 
-def consensus_string(ss, n_keys, res):
-    idx = ss.index_of[:n_keys]
-    picked = np.where(idx >= 0, res.bases[np.maximum(idx, 0)], 0x2D).astype(np.uint8)
-    return picked.tobytes().decode("ascii")
+def build_siteset(dev, snp_arrays, excluded_arrays=None):
+    """snp_arrays / excluded_arrays: (contig names, contig index per record, position per record) as
+    utils.read_snp_position_arrays / read_vcf_site_arrays return them (snplist order / the exclude VCF's records).  Returns
+    (SiteSet over their union — call_consensus.py:147-151 —, the slot of every snplist line, the slots of the exclude list).
+    numpy all the way: no Python loop per key."""
+    lists = [snp_arrays + (L.SITE_IN_SNPLIST,)]
+    if excluded_arrays is not None:
+        lists.append(excluded_arrays + (L.SITE_EXCLUDED,))
+    ss, slots = dev.siteset_from_lists(lists)
+    return ss, slots[0], (slots[1] if excluded_arrays is not None else None)
+
+
+def tuples_to_arrays(sites):
+    """[(chrom str or bytes, pos)] -> the array triple of utils.read_vcf_site_arrays (tests and host-buffer callers)."""
+    return utils._site_arrays_from_tuples(sites)
+
+
+def consensus_string(snp_slots, res):
+    """The consensus bytes in snplist order: '-' for a position that cannot occur in a pileup (no slot)."""
+    return np.where(snp_slots >= 0, res.bases[np.maximum(snp_slots, 0)], 0x2D).astype(np.uint8)
 
 
 def consensus_for_sample(dev, pileup_bytes, snp_list, excluded_positions, params, want_counts=False):
     """Host-buffer form (tests, bench): returns (consensus str in snplist order, SiteSet, ConsensusResult)."""
-    ss, n_keys = build_siteset(dev, snp_list, excluded_positions)
+    ss, snp_slots, _ = build_siteset(dev, tuples_to_arrays(snp_list), tuples_to_arrays(sorted(excluded_positions)))
     res = dev.call_consensus(ss, pileup_bytes, params, want_counts=want_counts)
-    return consensus_string(ss, n_keys, res), ss, res
+    return consensus_string(snp_slots, res).tobytes().decode("ascii"), ss, res
 
 
 def _raise_as_reference(err, pileup_path=None):
@@ -72,31 +83,40 @@ class _Plan(object):
         self.sample_name = os.path.basename(os.path.dirname(os.path.abspath(all_pileup_file_path)))
         consensus_file_dir = os.path.dirname(os.path.abspath(consensus_file_path))
         self.vcf_path = os.path.join(consensus_file_dir, args.vcfFileName) if args.vcfFileName else None
-        self.excluded = set()
+        self.excluded = None                 # the exclude VCF's (contig names, contig index, position) arrays
 
 
-def _write_outputs(plan, dev, ss, n_keys, res):
+def _write_outputs(plan, dev, ss, snp_slots, res, file_flags=None):
+    """file_flags: the site flags this file was called with (the set's, plus its own exclude list in a batch); rows of the
+    VCF are the parsed positions of THIS sample (a batch's set also holds the other samples' exclude positions)."""
     args = plan.args
-    in_snplist = (ss.flags & L.SITE_IN_SNPLIST) != 0
+    if file_flags is None:
+        file_flags = ss.flags
+    in_snplist = (file_flags & L.SITE_IN_SNPLIST) != 0
     utils.verbose_print("called consensus positions = %i" % int(((res.counts["status"] != L.ST_NO_LINE) & in_snplist).sum()))
     if plan.vcf_path:
-        if args.vcfAllPos:
+        dup = res.n_matched > int(np.count_nonzero(res.line_offsets))
+        if args.vcfAllPos or dup:
+            # every LINE gets a record (--vcfAllPos, pileup.py:418-421), or the pileup repeats a position — the reference writes
+            # a row for every matching line (call_consensus.py:178-180) where the per-site result only knows the last one: the
+            # rows come from the all-lines pass, run with this sample's own flags (in a batch the shared set knows nothing of
+            # its exclude list)
             params = devmod.make_params(args.minBaseQual, args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
+            own = ss if file_flags is ss.flags else devmod.SiteSet.from_arrays(dev, ss.contigs, ss.keys[file_flags != 0], file_flags[file_flags != 0])
             try:
-                line_off, _, counts = dev.call_all_lines(ss, plan.pileup_path, params, capacity=res.n_lines)
+                line_off, line_flags, counts = dev.call_all_lines(own, plan.pileup_path, params, capacity=res.n_lines, check=bool(args.vcfAllPos))
             except devmod.PileupFormatError as err:
                 _raise_as_reference(err, plan.pileup_path)
+            finally:
+                if own is not ss:
+                    own.close()
+            if not args.vcfAllPos:
+                keep = np.nonzero(line_flags)[0]                # listed positions only
+                line_off, counts = line_off[keep], counts[keep]
             vcf_writer.write_all_positions_vcf(plan.vcf_path, plan.sample_name, args, plan.pileup_path, line_off, counts)
-        elif res.n_matched > int(np.count_nonzero(res.line_offsets)):
-            # a pileup that repeats a position: the reference writes a row for every matching LINE (call_consensus.py:178-180),
-            # the per-site result only knows the last one — take the rows from the all-lines pass, listed positions only
-            params = devmod.make_params(args.minBaseQual, args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
-            line_off, line_flags, counts = dev.call_all_lines(ss, plan.pileup_path, params, capacity=res.n_lines, check=False)
-            keep = np.nonzero(line_flags)[0]
-            vcf_writer.write_all_positions_vcf(plan.vcf_path, plan.sample_name, args, plan.pileup_path, line_off[keep], counts[keep])
         else:
-            vcf_writer.write_consensus_vcf(plan.vcf_path, plan.sample_name, args, ss, res, res.line_offsets)
-    consensus = consensus_string(ss, n_keys, res)
+            vcf_writer.write_consensus_vcf(plan.vcf_path, plan.sample_name, args, ss, res, res.line_offsets, parsed=file_flags != 0)
+    consensus = consensus_string(snp_slots, res).tobytes().decode("ascii")
     with open(plan.consensus_path, "w") as fasta_file_object:
         utils.write_fasta_record(fasta_file_object, plan.sample_name, consensus)
     if getattr(args, "amdMetricsRefFasta", None):
@@ -136,28 +156,34 @@ def call_consensus(args):
     if plan.exclude_path:
         if utils.verify_existing_input_files("Exclude file", [plan.exclude_path]) > 0:
             utils.sample_error("Error: cannot call consensus without the file of excluded positions.", continue_possible=False)
-        plan.excluded = utils.convert_vcf_file_to_snp_set(plan.exclude_path)
+        plan.excluded = utils.read_vcf_site_arrays(plan.exclude_path)
         source_files.append(plan.exclude_path)
 
     if not args.forceFlag and not utils.target_needs_rebuild(source_files, plan.consensus_path):
         utils.verbose_print("Consensus call file %s has already been freshly built.  Use the -f option to force a rebuild." % plan.consensus_path)
         return
 
-    snp_list = utils.read_snp_position_list(snp_list_file_path)
-    utils.verbose_print("snp position list length = %d" % len(snp_list))
-    utils.verbose_print("excluded snps list length = %d" % len(plan.excluded))
-    utils.verbose_print("total snp position list length = %d" % (len(snp_list) + len(plan.excluded)))
+    snp_arrays = utils.read_snp_position_arrays(snp_list_file_path)
+    n_excluded = len(_unique_sites(plan.excluded)) if plan.excluded is not None else 0
+    utils.verbose_print("snp position list length = %d" % len(snp_arrays[2]))
+    utils.verbose_print("excluded snps list length = %d" % n_excluded)
+    utils.verbose_print("total snp position list length = %d" % (len(snp_arrays[2]) + n_excluded))
+    timing.mark("inputs read")
 
     params = devmod.make_params(args.minBaseQual, args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
     dev = devmod.default_device()
-    ss, n_keys = build_siteset(dev, snp_list, plan.excluded)
+    timing.mark("device context")
+    ss, snp_slots, _ = build_siteset(dev, snp_arrays, plan.excluded)
+    timing.mark("site set")
     results, rcs, _ = dev.call_consensus_files(ss, [all_pileup_file_path], params, want_counts=True, want_line_offsets=True,
                                                want_depth_sum=bool(getattr(args, "amdMetricsRefFasta", None)))
+    timing.mark("streamed call")
     try:
         dev.raise_file_status(all_pileup_file_path, int(rcs[0]), results[0])
     except devmod.PileupFormatError as err:
         _raise_as_reference(err, all_pileup_file_path)
-    _write_outputs(plan, dev, ss, n_keys, results[0])
+    _write_outputs(plan, dev, ss, snp_slots, results[0])
+    timing.mark("outputs written")
 
 
 def call_consensus_batch(args):
@@ -192,7 +218,7 @@ def call_consensus_batch(args):
                 utils.sample_error("Error: cannot call consensus without the file of excluded positions.", continue_possible=True)
                 failed += 1
                 continue
-            plan.excluded = utils.convert_vcf_file_to_snp_set(plan.exclude_path)
+            plan.excluded = utils.read_vcf_site_arrays(plan.exclude_path)
             source_files.append(plan.exclude_path)
         if not args.forceFlag and not utils.target_needs_rebuild(source_files, plan.consensus_path):
             utils.verbose_print("Consensus call file %s has already been freshly built.  Use the -f option to force a rebuild." % plan.consensus_path)
@@ -201,8 +227,8 @@ def call_consensus_batch(args):
     if not plans:
         return
 
-    snp_list = utils.read_snp_position_list(snp_list_file_path)
-    utils.verbose_print("snp position list length = %d" % len(snp_list))
+    snp_arrays = utils.read_snp_position_arrays(snp_list_file_path)
+    utils.verbose_print("snp position list length = %d" % len(snp_arrays[2]))
     params = devmod.make_params(args.minBaseQual, args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
     pinned = os.environ.get("SNPGPU_DEVICE", os.environ.get("LOCAL_RANK"))
     devices = [int(pinned)] if pinned is not None else list(range(max(1, devmod.device_count())))
@@ -211,33 +237,53 @@ def call_consensus_batch(args):
     lock = threading.Lock()
 
     def worker(dev_index, my_plans):
-        dev = devmod.Device(dev_index)
+        todo = list(my_plans)                     # whatever is still here when the worker dies is reported as failed
+        dev = None
         try:
-            # samples that share the site set (no per-sample exclude file) go through the device as one stream of files
-            groups = {}
-            for plan in my_plans:
-                groups.setdefault(frozenset(plan.excluded), []).append(plan)
-            for excluded, group in groups.items():
-                ss, n_keys = build_siteset(dev, snp_list, excluded)
-                # a stream of at most `step` files per library call: the per-site records of a call are files x sites x 138 bytes
-                # on the host (0.4 GB for 16 files x 200 000 sites)
-                step = max(1, min(64, (1 << 29) // max(1, 138 * len(ss))))
-                for k in range(0, len(group), step):
-                    part = group[k:k + step]
-                    results, rcs, _ = dev.call_consensus_files(ss, [p.pileup_path for p in part], params, want_counts=True,
-                                                               want_line_offsets=True,
-                                                               want_depth_sum=bool(getattr(args, "amdMetricsRefFasta", None)))
-                    for plan, rc, res in zip(part, rcs, results):
-                        try:
-                            dev.raise_file_status(plan.pileup_path, int(rc), res)
-                            with lock:            # the log lines of one sample stay together
-                                _write_outputs(plan, dev, ss, n_keys, res)
-                        except Exception as err:  # noqa: B902  (reported per sample below)
-                            with lock:
-                                errors.append((plan, err))
-                ss.close()
+            dev = devmod.Device(dev_index)
+            # ONE site set for all samples of this GPU: the snplist plus every sample's exclude positions, with the flags of the
+            # snplist only; a file's own exclude list travels with the file (per-file slots), so the samples of step 7.2 — each
+            # with its own var.flt_removed.vcf — go through the device as one stream of files like those of step 7.1
+            lists = [snp_arrays + (L.SITE_IN_SNPLIST,)] + [p.excluded + (0,) for p in my_plans if p.excluded is not None]
+            ss, slots = dev.siteset_from_lists(lists)
+            snp_slots = slots[0]
+            excl_slots, k = {}, 1
+            for p in my_plans:
+                if p.excluded is not None:
+                    excl_slots[id(p)] = slots[k]
+                    k += 1
+            with_excl = bool(excl_slots)
+            # a stream of at most `step` files per library call: the per-site records of a call are files x sites x 138 bytes
+            # on the host (0.4 GB for 16 files x 200 000 sites)
+            step = max(1, min(64, (1 << 29) // max(1, 138 * len(ss))))
+            for k0 in range(0, len(my_plans), step):
+                part = my_plans[k0:k0 + step]
+                exclude = [excl_slots.get(id(p), np.zeros(0, np.int64)) for p in part] if with_excl else None
+                results, rcs, _ = dev.call_consensus_files(ss, [p.pileup_path for p in part], params, want_counts=True,
+                                                           want_line_offsets=True, exclude=exclude,
+                                                           want_depth_sum=bool(getattr(args, "amdMetricsRefFasta", None)))
+                for plan, rc, res in zip(part, rcs, results):
+                    try:
+                        dev.raise_file_status(plan.pileup_path, int(rc), res)
+                        flags = ss.flags
+                        if with_excl:
+                            flags = ss.flags.copy()
+                            mine = excl_slots.get(id(plan))
+                            if mine is not None:
+                                flags[mine[mine >= 0]] |= L.SITE_EXCLUDED
+                        with lock:            # the log lines of one sample stay together
+                            _write_outputs(plan, dev, ss, snp_slots, res, flags)
+                    except Exception as err:  # noqa: B902  (reported per sample below)
+                        with lock:
+                            errors.append((plan, err))
+                    todo.remove(plan)
+            ss.close()
+        except Exception as err:              # noqa: B902 — the device, the site set or a whole call failed: every sample left is reported
+            with lock:
+                errors.extend((plan, err) for plan in todo)
         finally:
-            dev.close()
+            if dev is not None:
+                dev.close()
 
     threads = [threading.Thread(target=worker, args=(dv, plans[i::len(devices)])) for i, dv in enumerate(devices)]
     for t in threads:

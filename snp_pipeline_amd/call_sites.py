@@ -139,8 +139,9 @@ def call_sites_batch(args):
         errors, lock = [], threading.Lock()
 
         def worker(dev_index, mine):
-            dev = devmod.Device(dev_index)
+            dev = None
             try:
+                dev = devmod.Device(dev_index)
                 res = varscan.mpileup2snp_files(dev, [t[1] for t in mine], [t[2] for t in mine], opts)
                 with lock:
                     for t, r in zip(mine, res):
@@ -152,7 +153,8 @@ def call_sites_batch(args):
                 with lock:
                     errors.extend((t, err) for t in mine)
             finally:
-                dev.close()
+                if dev is not None:
+                    dev.close()
 
         threads = [threading.Thread(target=worker, args=(dv, todo[i::len(devices)])) for i, dv in enumerate(devices)]
         for t in threads:

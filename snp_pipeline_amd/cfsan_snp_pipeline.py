@@ -13,7 +13,7 @@ from __future__ import absolute_import
 import argparse
 import sys
 
-from . import call_consensus, call_sites, distance, filter_regions, merge_sites, snp_matrix, snp_reference, utils
+from . import call_consensus, call_sites, distance, filter_regions, hot_path, merge_sites, snp_matrix, snp_reference, utils
 from .utils import __version__, verbose_print
 
 NOT_PROVIDED = ("run", "data", "index_ref", "map_reads", "merge_vcfs",
@@ -146,6 +146,13 @@ def parse_argument_list(argv):
     _common(sub)
     sub.set_defaults(func=call_consensus.call_consensus_batch, excepthook=utils.handle_global_exception)
 
+    # Extension of this build (no reference counterpart): steps 4-11 as one job, every pileup over the host link once
+    sub = subparsers.add_parser("hot_path_batch", help="site calling to distance matrices for all samples as one job, one rank per GPU", formatter_class=fmt,
+                                description="Run the post-alignment steps of the pipeline (site calling, filter_regions, merge_sites, call_consensus, snp_matrix, snp_reference, distance — for the original and the preserved SNP lists) for every sample directory of sampleDirsFile as one job: each pileup is copied to the GPU once and stays there between the steps.  Start one process per GPU with torchrun for more than one GPU.  Writes the same files as the separate steps.")
+    hot_path.add_arguments(sub)
+    _common(sub)
+    sub.set_defaults(func=hot_path.hot_path_batch, excepthook=utils.handle_global_exception)
+
     sub = subparsers.add_parser("snp_matrix", help="Create a matrix of SNPs", formatter_class=fmt,
                                 description="Create the SNP matrix containing the consensus base for each of the samples at the positions where high-confidence SNPs were found in any of the samples.")
     sub.add_argument(dest="sampleDirsFile", type=str, help="Relative or absolute path to file containing a list of directories -- one per sample")
@@ -205,6 +212,9 @@ def run_command_from_args(args):
         sys.excepthook = args.excepthook
     utils.set_logging_verbosity(args)
     args.func(args)
+    from . import timing
+    timing.mark("done")
+    timing.report(args.subparser_name)
     verbose_print("")
     verbose_print("# %s %s %s finished" % (utils.timestamp(), utils.program_name(), args.subparser_name))
     return 0

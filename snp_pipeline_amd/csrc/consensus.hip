@@ -29,7 +29,8 @@ struct CallArgs {
     const SampleDev *samples;   // the batch; outputs and site_line are [n_samples][n_sites] row-major
     uint32_t n_samples;
     const uint64_t *site_line;
-    const uint8_t *site_flags;
+    const uint8_t *site_flags;  // [n_sites], or one row per sample when flags_stride != 0 (per-sample exclude lists)
+    uint32_t flags_stride;
     uint32_t n_sites;
     snpgpu_caller_params prm;
     uint8_t *out_base;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
             const uint32_t sample = (uint32_t)(s / a.n_sites);
             r.site = s;
             r.lv = a.site_line[s];
-            r.sflags = a.site_flags[s - (uint64_t)sample * a.n_sites];
+            r.sflags = a.site_flags[s - (uint64_t)sample * a.n_sites + (uint64_t)sample * a.flags_stride];
             r.buf = a.samples[sample].buf;
             r.nbytes = a.samples[sample].nbytes;
         }
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_call_lanes(CallArgs a) {
             const uint32_t sample = (uint32_t)(s / a.n_sites);
             r.site = s;
             r.lv = a.site_line[s];
-            r.sflags = a.site_flags[s - (uint64_t)sample * a.n_sites];
+            r.sflags = a.site_flags[s - (uint64_t)sample * a.n_sites + (uint64_t)sample * a.flags_stride];
             r.buf = (uintptr_t)a.samples[sample].buf;
             r.end = r.buf + a.samples[sample].nbytes;
         }
@@ -888,7 +889,7 @@ struct SampleIO { const uint8_t *d_pileup; size_t nbytes; uint64_t *d_status; };
 int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n,
                         const snpgpu_caller_params *prm, const uint64_t *d_site_line, uint8_t *d_out_base,
                         uint8_t *d_out_filters, snpgpu_site_counts *d_out_counts, uint32_t *d_todo_n, uint64_t *d_todo,
-                        uint64_t *d_todo2) {
+                        uint64_t *d_todo2, const uint8_t *d_site_flags, uint32_t flags_stride) {
     hipStream_t st = ctx->stream;
     const uint32_t n_sites = ss->n_sites;
     if (!n_sites || !n) return SNPGPU_OK;
@@ -896,7 +897,8 @@ int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleD
     ca.samples = d_table;
     ca.n_samples = n;
     ca.site_line = d_site_line;
-    ca.site_flags = ss->dev.flags;
+    ca.site_flags = d_site_flags ? d_site_flags : ss->dev.flags;
+    ca.flags_stride = d_site_flags ? flags_stride : 0;
     ca.n_sites = n_sites;
     ca.prm = *prm;
     ca.out_base = d_out_base;
@@ -956,6 +958,7 @@ int snpgpu_enqueue_call_lines(snpgpu_ctx *ctx, const SampleDev *d_sample, const 
     ca.n_samples = 1;
     ca.site_line = d_line_off;
     ca.site_flags = d_flags;
+    ca.flags_stride = 0;
     ca.n_sites = n_lines;
     ca.prm = *prm;
     ca.out_base = d_out_base;
@@ -972,7 +975,8 @@ int snpgpu_enqueue_call_lines(snpgpu_ctx *ctx, const SampleDev *d_sample, const 
 // d_site_line == nullptr: the rows live in the context's scratch; outputs are [n][n_sites] row-major.
 static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleIO *io, uint32_t n,
                          const snpgpu_caller_params *prm, uint8_t *d_out_base, uint8_t *d_out_filters,
-                         snpgpu_site_counts *d_out_counts, uint64_t *d_site_line, int want_depth) {
+                         snpgpu_site_counts *d_out_counts, uint64_t *d_site_line, int want_depth,
+                         const uint8_t *d_site_flags = nullptr, uint32_t flags_stride = 0) {
     const uint32_t n_sites = ss->n_sites;
     const size_t ws_bytes = (snpgpu_scan_workspace_bytes(ctx, n) + 255) / 256 * 256;
     const size_t rows_bytes = d_site_line ? 0 : 8ull * n_sites * n;
@@ -998,7 +1002,7 @@ static int enqueue_group(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const Sample
     int rc = snpgpu_enqueue_scan(ctx, ss, samples, ws, d_site_line, want_depth, d_todo_n, 3);
     if (rc) return rc;
     return snpgpu_enqueue_call(ctx, ss, (const SampleDev *)ws, n, prm, d_site_line, d_out_base, d_out_filters, d_out_counts,
-                               d_todo_n, d_todo, d_todo2);
+                               d_todo_n, d_todo, d_todo2, d_site_flags, flags_stride);
 }
 
 static int enqueue_sample(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *d_pileup, size_t nbytes,
@@ -1055,6 +1059,37 @@ int snpgpu_call_consensus_batch_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, c
                              d_status + (size_t)(i0 + k) * SNPGPU_SCAN_STATUS_WORDS};
         const size_t off = (size_t)i0 * ss->n_sites;
         int rc = enqueue_group(ctx, ss, io.data(), n, params, d_out_base + off, d_out_filters + off, nullptr, nullptr, 0);
+        if (rc) return rc;
+    }
+    return SNPGPU_OK;
+}
+
+// The same for samples that live anywhere in device memory (the resident pileups of the one-job pipeline), with everything
+// the per-sample CLI gets from the streamed form: per-site records, the line offsets, and optionally one row of site flags
+// per sample (a sample's own exclude list, call_consensus.py:117-123, 165-168).
+int snpgpu_call_consensus_many_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const void *const *d_pileups, const uint64_t *h_sizes,
+                                   uint32_t n_samples, const snpgpu_caller_params *params, const uint8_t *d_site_flags,
+                                   uint8_t *d_out_base, uint8_t *d_out_filters, snpgpu_site_counts *d_out_counts,
+                                   uint64_t *d_out_line_off, uint64_t *d_status, int want_depth_sum) {
+    if (!ctx || !ss || !params || !d_status || (n_samples && (!d_pileups || !h_sizes))) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (ss->n_sites && n_samples && (!d_out_base || !d_out_filters)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t group = SNPGPU_SCAN_MAX_BATCH;
+    if (ss->n_sites) {                                          // per group in scratch: two leftover lists (+ the rows when not given)
+        const uint64_t by_mem = (1ull << 30) / (8ull * ss->n_sites);
+        if (by_mem < group) group = by_mem ? (uint32_t)by_mem : 1;
+    }
+    std::vector<SampleIO> io;
+    for (uint32_t i0 = 0; i0 < n_samples; i0 += group) {
+        const uint32_t n = n_samples - i0 < group ? n_samples - i0 : group;
+        io.resize(n);
+        for (uint32_t k = 0; k < n; ++k) {
+            if (h_sizes[i0 + k] && !d_pileups[i0 + k]) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null pileup %u", i0 + k);
+            io[k] = SampleIO{(const uint8_t *)d_pileups[i0 + k], (size_t)h_sizes[i0 + k], d_status + (size_t)(i0 + k) * SNPGPU_SCAN_STATUS_WORDS};
+        }
+        const size_t off = (size_t)i0 * ss->n_sites;
+        int rc = enqueue_group(ctx, ss, io.data(), n, params, d_out_base + off, d_out_filters + off, d_out_counts ? d_out_counts + off : nullptr,
+                               d_out_line_off ? d_out_line_off + off : nullptr, want_depth_sum, d_site_flags ? d_site_flags + off : nullptr, ss->n_sites);
         if (rc) return rc;
     }
     return SNPGPU_OK;

@@ -233,6 +233,7 @@ int snpgpu_siteset_create(snpgpu_ctx *ctx, const uint8_t *contig_names, const ui
     ss->ctx = ctx;
     ss->n_sites = n_sites;
     ss->total_bits = total_bits;
+    if (n_sites) ss->h_flags.assign(site_flags, site_flags + n_sites);
     hipError_t e = hipMalloc(&ss->blob, total);
     if (e != hipSuccess) {
         delete ss;

@@ -39,6 +39,19 @@ struct snpgpu_ctx {
 hipEvent_t snpgpu_time_begin(snpgpu_ctx *ctx);
 void snpgpu_time_end(snpgpu_ctx *ctx, int kernel, hipEvent_t a);
 
+// Pileup files kept in device memory between the steps of the one-job pipeline (stream.hip): bump-allocated out of a few
+// large blocks, so that a file is copied over the host link once and then read by site calling and by the consensus scan.
+struct snpgpu_pileups {
+    snpgpu_ctx *ctx = nullptr;
+    uint64_t budget = 0;                // device bytes the resident files may take
+    uint64_t used = 0;
+    std::vector<void *> blocks;         // hipMalloc'd
+    struct Entry { uint8_t *d = nullptr; uint64_t nbytes = 0; bool resident = false; };
+    std::vector<Entry> files;           // in the order they were ingested
+    uint64_t h2d_bytes = 0;             // every byte copied host -> device through this store
+    uint64_t file_bytes = 0;            // sizes of the files that were ingested
+};
+
 // Device-side view of a site set.
 struct SiteSetDev {
     const uint8_t *names;       // concatenated contig names (sorted bytewise)
@@ -58,6 +71,7 @@ struct snpgpu_siteset {
     SiteSetDev dev{};
     void *blob = nullptr;       // one allocation backing every device array
     uint64_t total_bits = 0;
+    std::vector<uint8_t> h_flags;    // host copy of the flags (per-file exclude lists are OR-ed into copies of it)
     uint64_t *site_line = nullptr;   // n_sites scratch: (offset+1) of the last matching line
     uint64_t *slow_queue = nullptr;  // SNPGPU_SLOW_QUEUE_CAP file offsets of lines the fast scan path left over
     uint32_t *slow_ctl = nullptr;    // [0] queue length, [1] overflow flag
@@ -112,11 +126,12 @@ int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbyte
 int snpgpu_enqueue_call_lines(snpgpu_ctx *ctx, const SampleDev *d_sample, const uint64_t *d_line_off, const uint8_t *d_flags,
                               uint32_t n_lines, const snpgpu_caller_params *prm, uint8_t *d_out_base, uint8_t *d_out_filters,
                               snpgpu_site_counts *d_out_counts);
-// the call kernels over a scanned batch (consensus.hip); d_todo_n: 3 zeroed words, d_todo / d_todo2: n * n_sites entries each
+// the call kernels over a scanned batch (consensus.hip); d_todo_n: 4 words (3 zeroed), d_todo / d_todo2: n * n_sites entries each;
+// d_site_flags: nullptr = the site set's flags for every sample, else flags of sample i at d_site_flags + i * flags_stride
 int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n,
                         const snpgpu_caller_params *prm, const uint64_t *d_site_line, uint8_t *d_out_base,
                         uint8_t *d_out_filters, snpgpu_site_counts *d_out_counts, uint32_t *d_todo_n, uint64_t *d_todo,
-                        uint64_t *d_todo2);
+                        uint64_t *d_todo2, const uint8_t *d_site_flags = nullptr, uint32_t flags_stride = 0);
 #define SCAN_ERR_FEW_FIELDS 1
 #define SCAN_ERR_BAD_POS 2
 #define SCAN_ERR_NON_ASCII 3

@@ -97,8 +97,11 @@ void snpgpu_stream_pool_destroy(snpgpu_ctx *ctx) {
 
 namespace {
 
+// n_slots device file buffers of slot_bytes; n_blocks (>= n_slots) pinned result blocks, table mirrors and done-events — files
+// that go to resident memory (snpgpu_pileups) need the blocks but no slot
 int pool_ensure(snpgpu_ctx *ctx, size_t chunk_bytes, uint32_t n_staging, uint32_t n_slots, size_t slot_bytes, size_t result_bytes,
-                size_t table_bytes) {
+                size_t table_bytes, uint32_t n_blocks = 0) {
+    if (n_blocks < n_slots) n_blocks = n_slots;
     if (!ctx->pool) ctx->pool = new snpgpu_stream_pool();
     snpgpu_stream_pool *p = ctx->pool;
     if (!p->copy_stream) {
@@ -154,14 +157,16 @@ int pool_ensure(snpgpu_ctx *ctx, size_t chunk_bytes, uint32_t n_staging, uint32_
         }
         p->slot_bytes = want;
     }
-    while (p->ev_done.size() < p->slot.size()) {
+    if (n_blocks < p->slot.size()) n_blocks = (uint32_t)p->slot.size();
+    while (p->ev_done.size() < n_blocks) {
         hipEvent_t ev = nullptr;
         HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         p->ev_done.push_back(ev);
     }
-    if (p->result_bytes < result_bytes || p->result.size() < p->slot.size()) {
+    if (p->result_bytes < result_bytes || p->result.size() < n_blocks) {
         pool_free_host(p->result);
-        for (size_t i = 0; i < p->slot.size(); ++i) {
+        if (result_bytes < p->result_bytes) result_bytes = p->result_bytes;
+        for (size_t i = 0; i < n_blocks; ++i) {
             void *h = nullptr;
             hipError_t e = hipHostMalloc(&h, result_bytes, hipHostMallocDefault);
             if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipHostMalloc(%zu) failed: %s", result_bytes, hipGetErrorString(e));
@@ -169,9 +174,10 @@ int pool_ensure(snpgpu_ctx *ctx, size_t chunk_bytes, uint32_t n_staging, uint32_
         }
         p->result_bytes = result_bytes;
     }
-    if (p->table_bytes < table_bytes || p->table_host.size() < p->slot.size()) {
+    if (p->table_bytes < table_bytes || p->table_host.size() < n_blocks) {
         pool_free_host(p->table_host);
-        for (size_t i = 0; i < p->slot.size(); ++i) {
+        if (table_bytes < p->table_bytes) table_bytes = p->table_bytes;
+        for (size_t i = 0; i < n_blocks; ++i) {
             void *h = nullptr;
             hipError_t e = hipHostMalloc(&h, table_bytes, hipHostMallocDefault);
             if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipHostMalloc(%zu) failed: %s", table_bytes, hipGetErrorString(e));
@@ -253,17 +259,30 @@ struct DevScratch {                 // one carve-up of the context's scratch, sh
     uint32_t *todo_n;
     uint8_t *base, *filters;
     snpgpu_site_counts *counts;
+    uint8_t *flag_rows;             // per slot: the site flags of its file (only with per-file exclude lists)
+    size_t flag_row_stride;
 };
 
 // d_site_line: nullptr = in scratch; the single-pileup form passes the site set's own row, where
 // snpgpu_siteset_line_offsets finds it afterwards.
+// excl_off / excl_slots: nullptr, or per file the site-set slots of ITS exclude list (CSR, n_files + 1 offsets): the file is
+// called with the set's flags | SNPGPU_SITE_EXCLUDED on those slots.
 int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &src, const snpgpu_caller_params *prm,
-               const Outputs &out, const snpgpu_stream_opts *opts, snpgpu_stream_stats *stats, uint64_t *d_site_line) {
+               const Outputs &out, const snpgpu_stream_opts *opts, snpgpu_stream_stats *stats, uint64_t *d_site_line,
+               const uint32_t *excl_off = nullptr, const uint32_t *excl_slots = nullptr) {
     const double t_start = now_s();
     const uint32_t n_files = (uint32_t)src.size();
     const uint32_t n_sites = ss->n_sites;
     if (stats) memset(stats, 0, sizeof *stats);
     if (!n_files) return SNPGPU_OK;
+    if (excl_off) {
+        if (excl_off[n_files] && !excl_slots) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "exclude slots missing");
+        for (uint32_t f = 0; f < n_files; ++f) {
+            if (excl_off[f + 1] < excl_off[f]) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "exclude offsets must be non-decreasing");
+            for (uint32_t k = excl_off[f]; k < excl_off[f + 1]; ++k)
+                if (excl_slots[k] >= n_sites) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "exclude slot %u of file %u is not in the site set", excl_slots[k], f);
+        }
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     size_t chunk = opts && opts->chunk_bytes ? opts->chunk_bytes : (size_t)16 << 20;
     chunk = up(chunk < 65536 ? 65536 : chunk, SNPGPU_SCAN_TILE);
@@ -317,7 +336,8 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
     const size_t slot_bytes = up(max_size + SNPGPU_SCAN_TILE + 256, 4096);
     const size_t r_base = 0, r_filt = up(r_base + n_sites, 256), r_stat = up(r_filt + n_sites, 256), r_line = r_stat + 256;
     const size_t r_cnt = up(r_line + (out.line_off ? 8ull * n_sites : 0), 256);
-    const size_t result_bytes = r_cnt + (out.counts ? sizeof(snpgpu_site_counts) * (size_t)n_sites : 0) + 256;
+    const size_t r_flags = up(r_cnt + (out.counts ? sizeof(snpgpu_site_counts) * (size_t)n_sites : 0), 256);
+    const size_t result_bytes = r_flags + (excl_off ? up(n_sites, 256) : 0) + 256;
     const size_t table_bytes = up((size_t)(max_chunks + 1) * 2 * sizeof(SampleDev), 256);
     {
         int rc = pool_ensure(ctx, chunk, n_staging, n_slots, slot_bytes, result_bytes, table_bytes);
@@ -339,6 +359,7 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
         const size_t o_filt = o; o += up(n_sites, 256);
         const size_t o_stat = o; o += 256;
         const size_t o_cnt = o; o += out.counts ? up(sizeof(snpgpu_site_counts) * (size_t)n_sites, 256) : 0;
+        const size_t o_frow = o; o += excl_off ? up(n_sites, 256) * p->slot.size() : 0;
         void *ws = nullptr;
         int rc = snpgpu_scratch(ctx, o + 256, &ws);
         if (rc) { for (auto &s : src) if (s.fd >= 0) close(s.fd); return rc; }
@@ -348,6 +369,8 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
         ds.todo = (uint64_t *)(b + o_todo); ds.todo2 = (uint64_t *)(b + o_todo2); ds.base = (uint8_t *)(b + o_base);
         ds.filters = (uint8_t *)(b + o_filt); ds.status = (uint64_t *)(b + o_stat);
         ds.counts = out.counts ? (snpgpu_site_counts *)(b + o_cnt) : nullptr;
+        ds.flag_rows = excl_off ? (uint8_t *)(b + o_frow) : nullptr;
+        ds.flag_row_stride = up(n_sites, 256);
         if (d_site_line) ds.site_line = d_site_line;
     }
     hipStream_t st = ctx->stream;
@@ -472,10 +495,22 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
             if (jb.last) {
                 const SampleDev *d_whole = d_tab + 2 * nc;
                 rc = snpgpu_scan_end(ctx, ss, d_whole, 1, cur_waves, ds.totals, ds.site_line, want_depth);
-                if (rc == SNPGPU_OK)
-                    rc = snpgpu_enqueue_call(ctx, ss, d_whole, 1, prm, ds.site_line, ds.base, ds.filters, ds.counts, ds.todo_n, ds.todo, ds.todo2);
-                if (rc) goto done;
                 char *r = (char *)p->result[slot];
+                const uint8_t *d_flags = nullptr;
+                if (rc == SNPGPU_OK && excl_off && n_sites) {
+                    // this file's site flags: the set's, with its own exclude list on top (the pinned row is free: the file that
+                    // used this block before has been harvested)
+                    uint8_t *hf = (uint8_t *)(r + r_flags);
+                    memcpy(hf, ss->h_flags.data(), n_sites);
+                    for (uint32_t k = excl_off[f]; k < excl_off[f + 1]; ++k) hf[excl_slots[k]] |= SNPGPU_SITE_EXCLUDED;
+                    uint8_t *d_row = ds.flag_rows + ds.flag_row_stride * slot;
+                    ST_TRY(hipMemcpyAsync(d_row, hf, n_sites, hipMemcpyHostToDevice, st));
+                    d_flags = d_row;
+                }
+                if (rc == SNPGPU_OK)
+                    rc = snpgpu_enqueue_call(ctx, ss, d_whole, 1, prm, ds.site_line, ds.base, ds.filters, ds.counts, ds.todo_n, ds.todo, ds.todo2,
+                                             d_flags, 0);
+                if (rc) goto done;
                 if (n_sites) {
                     ST_TRY(hipMemcpyAsync(r + r_base, ds.base, n_sites, hipMemcpyDeviceToHost, st));
                     ST_TRY(hipMemcpyAsync(r + r_filt, ds.filters, n_sites, hipMemcpyDeviceToHost, st));
@@ -616,7 +651,8 @@ int scan_status_error(snpgpu_ctx *ctx, const uint64_t *status, const char *what_
 extern "C" {
 
 int snpgpu_call_consensus_files(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const char *const *paths, uint32_t n_files,
-                                const snpgpu_caller_params *params, uint8_t *out_base, uint8_t *out_filters,
+                                const snpgpu_caller_params *params, const uint32_t *excl_off, const uint32_t *excl_slots,
+                                uint8_t *out_base, uint8_t *out_filters,
                                 snpgpu_site_counts *out_counts, uint64_t *out_line_off, uint64_t *out_status,
                                 int32_t *out_rc, const snpgpu_stream_opts *opts, snpgpu_stream_stats *stats) {
     if (!ctx || !ss || !params || !out_status || (n_files && !paths)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
@@ -627,7 +663,7 @@ int snpgpu_call_consensus_files(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const
         src[f].path = paths[f];
     }
     Outputs out{out_base, out_filters, out_counts, out_line_off, out_status, out_rc};
-    return run_stream(ctx, ss, src, params, out, opts, stats, nullptr);
+    return run_stream(ctx, ss, src, params, out, opts, stats, nullptr, excl_off, excl_slots);
 }
 
 // Host-buffer form for ONE pileup (an mmap, bytes read elsewhere): same pipeline, the readers memcpy instead of pread.
@@ -717,21 +753,18 @@ int snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const 
     return SNPGPU_OK;
 }
 
-// Phase-1 site calling over a pileup file: load, index the lines, count + select on the device (varscan.hip), records back in
-// file order.
-int snpgpu_varscan_file(snpgpu_ctx *ctx, const char *path, const snpgpu_varscan_params *params, uint32_t capacity,
-                        snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status) {
-    if (!ctx || !path || !params || !out_n_sites || !out_status) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
-    if (capacity && !out_sites) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    uint8_t *d_file = nullptr;
-    uint64_t nbytes = 0;
-    int rc = load_file(ctx, path, &d_file, &nbytes);
-    if (rc) return rc;
+}  // extern "C"
+
+namespace {
+
+// Phase-1 site calling over a pileup that is in device memory: index the lines, count + select on the device (varscan.hip),
+// records back in file order.  Synchronous.
+int varscan_resident(snpgpu_ctx *ctx, const uint8_t *d_file, uint64_t nbytes, const char *what, const snpgpu_varscan_params *params,
+                     uint32_t capacity, snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status) {
     hipStream_t st = ctx->stream;
     const size_t ws_words = snpgpu_lines_workspace_words(nbytes);
     void *scr = nullptr;
-    rc = snpgpu_scratch(ctx, up(4 * ws_words, 256) + 512, &scr);
+    int rc = snpgpu_scratch(ctx, up(4 * ws_words, 256) + 512, &scr);
     if (rc) return rc;
     uint32_t *d_total = nullptr;
     rc = snpgpu_enqueue_lines_count(ctx, d_file, nbytes, (uint32_t *)scr, &d_total);
@@ -764,7 +797,7 @@ int snpgpu_varscan_file(snpgpu_ctx *ctx, const char *path, const snpgpu_varscan_
     const uint32_t found = (uint32_t)h_ctl[1];
     *out_n_sites = found;
     if (h_ctl[0] != ~0ull)
-        return snpgpu_set_error(ctx, SNPGPU_E_PILEUP, "malformed pileup line at byte %llu of %s", (unsigned long long)h_ctl[0], path);
+        return snpgpu_set_error(ctx, SNPGPU_E_PILEUP, "malformed pileup line at byte %llu of %s", (unsigned long long)h_ctl[0], what);
     const uint32_t got = found < capacity ? found : capacity;
     if (got) {
         HIP_TRY(ctx, hipMemcpyAsync(out_sites, b + o_rec, sizeof(snpgpu_varscan_site) * (size_t)got, hipMemcpyDeviceToHost, st));
@@ -777,19 +810,30 @@ int snpgpu_varscan_file(snpgpu_ctx *ctx, const char *path, const snpgpu_varscan_
     return SNPGPU_OK;
 }
 
+// Device memory for the files of one ingest call that are to stay resident: whole files, 256-byte aligned, bump-allocated out
+// of blocks of at most `block_cap` bytes (a block is allocated right before the first copy into it: one huge allocation up
+// front would delay the first byte by its page-table set-up).  Files past the budget stay non-resident (d == nullptr).
+struct Placement { uint32_t block; uint64_t off; };
+const uint64_t PILEUP_BLOCK_CAP = 8ull << 30;
+const uint64_t PILEUP_TAIL_PAD = SNPGPU_SCAN_TILE + 512;       // the scan reads whole tiles (+ halo) past a file's last byte
+
 // Phase-1 site calling over many pileup files: the readers run ahead across file boundaries (one job list, one staging
-// ring, as in run_stream), the files alternate between two device slots, and a file's kernels and result copy run on the
-// compute stream while the next file is being read and copied.  out_sites: [n_files][capacity]; a file with more records
-// than `capacity` reports its count and the caller repeats it alone (snpgpu_varscan_file).
-int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, const snpgpu_varscan_params *params, uint32_t capacity,
-                         snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status, int32_t *out_rc) {
-    if (!ctx || !params || !out_n_sites || !out_status || !out_rc || (n_files && !paths) || (capacity && !out_sites))
-        return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
-    if (!n_files) return SNPGPU_OK;
+// ring, as in run_stream), and a file's kernels and result copy run on the compute stream while the next file is being read
+// and copied.  Without a store the files alternate between two device slots; with one, a file goes to resident memory while
+// the store's budget lasts (entry store->files[first + f]) and only the overflow uses the slots.  params == nullptr: no site
+// calling, the files are only made resident.  out_done (nullable): out_done[f] becomes 1 when the outputs of file f are final,
+// so that another thread can start on them while the call is still running.
+int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, const snpgpu_varscan_params *params, uint32_t capacity,
+                   snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status, int32_t *out_rc, snpgpu_pileups *store,
+                   int32_t *out_done) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t chunk = (size_t)16 << 20;
     std::vector<Source> src(n_files);
-    uint64_t max_size = 0;
+    uint64_t max_slot_size = 0;
+    const size_t first = store ? store->files.size() : 0;
+    if (store) store->files.resize(first + n_files);
+    std::vector<Placement> place(n_files, Placement{~0u, 0});
+    std::vector<uint64_t> block_bytes;                          // blocks of this call
     for (uint32_t f = 0; f < n_files; ++f) {
         Source &s = src[f];
         s.path = paths[f];
@@ -803,10 +847,29 @@ int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_f
             s.size = (uint64_t)stt.st_size;
             (void)posix_fadvise(s.fd, 0, 0, POSIX_FADV_SEQUENTIAL);
         }
-        if (s.size > max_size) max_size = s.size;
+        bool resident = false;
+        if (store && s.rc == SNPGPU_OK) {
+            const uint64_t need = up(s.size + 1, 256);
+            if (store->used + need + PILEUP_TAIL_PAD <= store->budget) {
+                if (block_bytes.empty() || block_bytes.back() + need + PILEUP_TAIL_PAD > PILEUP_BLOCK_CAP) block_bytes.push_back(0);
+                place[f] = Placement{(uint32_t)(block_bytes.size() - 1), block_bytes.back()};
+                block_bytes.back() += need;
+                store->used += need;
+                resident = true;
+            }
+        }
+        if (store) {
+            store->files[first + f].nbytes = s.size;
+            store->files[first + f].resident = resident;
+            store->file_bytes += s.size;
+        }
+        if (!resident && s.size > max_slot_size) max_slot_size = s.size;
         out_n_sites[f] = 0;
         out_status[2 * f] = ~0ull; out_status[2 * f + 1] = 0;
+        if (out_done) out_done[f] = 0;
     }
+    if (store) for (auto &b : block_bytes) { b += PILEUP_TAIL_PAD; store->used += PILEUP_TAIL_PAD; }
+    std::vector<uint8_t *> block_ptr(block_bytes.size(), nullptr);
     std::vector<Job> jobs;
     for (uint32_t f = 0; f < n_files; ++f) {
         const uint64_t n = src[f].size;
@@ -825,19 +888,27 @@ int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_f
     if (n_readers > J) n_readers = (uint32_t)J;
     uint32_t n_staging = n_readers + 4;
     if (n_staging > J) n_staging = (uint32_t)J;
-    const size_t r_rec = 256;                                  // result block: [0] u64 status, [8] u32 records found, [16] u32 lines; records at 256
+    const size_t r_rec = 256;                                  // result block: [0] u64 status, [8] u32 records found, [48] u32 lines; records at 256
     const size_t result_bytes = r_rec + sizeof(snpgpu_varscan_site) * (size_t)capacity + 256;
     auto close_all = [&]() { for (auto &s2 : src) if (s2.fd >= 0) { close(s2.fd); s2.fd = -1; } };
-    int rc = pool_ensure(ctx, chunk, n_staging, n_files > 1 ? 2 : 1, up(max_size + SNPGPU_SCAN_TILE + 256, 4096), result_bytes, 256);
+    const uint32_t n_slots = n_files > 1 ? 2 : 1;              // result blocks / scratch halves alternate between files
+    bool any_slot = false;
+    for (uint32_t f = 0; f < n_files; ++f) if (place[f].block == ~0u) any_slot = true;
+    int rc = pool_ensure(ctx, chunk, n_staging, any_slot ? n_slots : 0, any_slot ? up(max_slot_size + SNPGPU_SCAN_TILE + 256, 4096) : 0,
+                         result_bytes, 256, n_slots);
     if (rc) { close_all(); return rc; }
     snpgpu_stream_pool *p = ctx->pool;
     const uint64_t R = p->staging.size() < n_staging ? p->staging.size() : n_staging;
-    const uint32_t n_slots = n_files > 1 ? 2 : 1;
     hipStream_t st = ctx->stream;
     {
         hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess) { close_all(); return snpgpu_set_error(ctx, SNPGPU_E_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e)); }
     }
+    // where file f lives on the device (a resident file's block is allocated when its first piece is about to be copied)
+    auto dest = [&](uint32_t f) -> uint8_t * {
+        if (place[f].block == ~0u) return (uint8_t *)p->slot[f % n_slots];
+        return block_ptr[place[f].block] + place[f].off;
+    };
     Shared sh;
     sh.R = R ? R : 1;
     sh.filled.assign(J, 0);
@@ -853,8 +924,9 @@ int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_f
         return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "cannot start the reader threads: %s", e.what());
     }
     std::vector<uint8_t> has_result(n_files, 0);
+    auto publish = [&](uint32_t f) { if (out_done) __atomic_store_n(&out_done[f], 1, __ATOMIC_RELEASE); };
     auto harvest = [&](uint32_t f) -> int {                     // results of file f: pinned block -> the caller's arrays
-        if (!has_result[f]) return SNPGPU_OK;
+        if (!has_result[f]) { out_rc[f] = src[f].rc; publish(f); return SNPGPU_OK; }
         const uint32_t slot = f % n_slots;
         hipError_t e = hipEventSynchronize(p->ev_done[slot]);
         if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_HIP, "waiting for the results of pileup %u failed: %s", f, hipGetErrorString(e));
@@ -865,7 +937,7 @@ int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_f
         memcpy(&found, r + 8, 4);
         out_status[2 * f] = status;
         out_n_sites[f] = found;
-        if (status != ~0ull) { if (src[f].rc == SNPGPU_OK) src[f].rc = SNPGPU_E_PILEUP; return SNPGPU_OK; }
+        if (status != ~0ull) { if (src[f].rc == SNPGPU_OK) src[f].rc = SNPGPU_E_PILEUP; out_rc[f] = src[f].rc; publish(f); return SNPGPU_OK; }
         const uint32_t got = found < capacity ? found : capacity;
         snpgpu_varscan_site *dst = out_sites + (size_t)f * capacity;
         if (got) memcpy(dst, r + r_rec, sizeof(snpgpu_varscan_site) * (size_t)got);
@@ -873,6 +945,8 @@ int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_f
             std::sort(dst, dst + got, [](const snpgpu_varscan_site &x, const snpgpu_varscan_site &y) {
                 return x.line_off != y.line_off ? x.line_off < y.line_off : x.alt_base < y.alt_base;
             });
+        out_rc[f] = src[f].rc;
+        publish(f);
         return SNPGPU_OK;
     };
     // The work on a complete file, in two halves around the one number the host needs (its line count).
@@ -900,7 +974,7 @@ int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_f
         if (r) return r;
         const size_t half = ctx->scratch_bytes / 2 / 256 * 256;
         uint32_t *d_total = nullptr;
-        r = snpgpu_enqueue_lines_count(ctx, (const uint8_t *)p->slot[slot], nbytes, (uint32_t *)((char *)scr + half * slot), &d_total);
+        r = snpgpu_enqueue_lines_count(ctx, dest(f), nbytes, (uint32_t *)((char *)scr + half * slot), &d_total);
         if (r) return r;
         VS_RET(hipMemcpyAsync((char *)p->result[slot] + 48, d_total, 4, hipMemcpyDeviceToHost, st));
         VS_RET(hipEventRecord(ev_count, st));
@@ -909,7 +983,7 @@ int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_f
     auto post_finish = [&](uint32_t f) -> int {                 // index the lines, walk them, results into the slot's pinned block
         const uint32_t slot = f % n_slots;
         const uint64_t nbytes = src[f].size;
-        const uint8_t *d_file = (const uint8_t *)p->slot[slot];
+        const uint8_t *d_file = dest(f);
         char *res = (char *)p->result[slot];
         VS_RET(hipEventSynchronize(ev_count));
         uint32_t n_lines = 0;
@@ -965,14 +1039,25 @@ int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_f
         int64_t pending = -1;                                   // a file whose lines are being counted
         for (uint64_t j = 0; j < J; ++j) {
             const Job &jb = jobs[j];
-            const uint32_t f = jb.file, slot = f % n_slots;
+            const uint32_t f = jb.file;
             Source &s = src[f];
-            uint8_t *d_file = (uint8_t *)p->slot[slot];
             if (pending >= 0 && hipEventQuery(ev_count) != hipErrorNotReady) { rc = post_finish((uint32_t)pending); pending = -1; if (rc) goto done; }
-            if (jb.first) {                                     // the slot and its result block are free once their last user has been harvested
+            if (jb.first) {                                     // the result block (and a slot) are free once their last user has been harvested
                 if (pending >= 0 && (uint32_t)pending + n_slots <= f) { rc = post_finish((uint32_t)pending); pending = -1; if (rc) goto done; }
                 while (harvested + n_slots <= f) { rc = harvest(harvested); if (rc) goto done; ++harvested; }
+                if (place[f].block != ~0u && !block_ptr[place[f].block]) {
+                    void *d = nullptr;
+                    hipError_t e = hipMalloc(&d, block_bytes[place[f].block]);
+                    if (e != hipSuccess) {
+                        rc = snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipMalloc(%llu) for resident pileups failed: %s", (unsigned long long)block_bytes[place[f].block], hipGetErrorString(e));
+                        goto done;
+                    }
+                    block_ptr[place[f].block] = (uint8_t *)d;
+                    store->blocks.push_back(d);
+                }
+                if (store && place[f].block != ~0u) store->files[first + f].d = dest(f);
             }
+            uint8_t *d_file = dest(f);
             for (;;) {                                          // wait for the piece to be read; retire finished copies meanwhile
                 bool progress = false;
                 while (copies_done < (int64_t)j && hipEventQuery(p->ev_copy[copies_done % R]) != hipErrorNotReady) { ++copies_done; progress = true; }
@@ -985,9 +1070,10 @@ int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_f
             if (sh.job_err[j] && s.rc == SNPGPU_OK) s.rc = SNPGPU_E_IO;
             hipStream_t cs = (j & 1) ? p->copy_stream2 : p->copy_stream;
             if (jb.len) VS_TRY(hipMemcpyAsync(d_file + jb.off, p->staging[j % R], jb.len, hipMemcpyHostToDevice, cs));
+            if (store) store->h2d_bytes += jb.len;
             VS_TRY(hipEventRecord(p->ev_copy[j % R], cs));
             VS_TRY(hipStreamWaitEvent(st, p->ev_copy[j % R], 0));
-            if (!jb.last || s.rc != SNPGPU_OK || s.size == 0) continue;
+            if (!jb.last || s.rc != SNPGPU_OK || s.size == 0 || !params) continue;
             // ---- the whole file is on its way: count its lines now, do the rest when the count has come back (the copies of
             //      the next file are issued in the meantime: nobody waits for this file's tail) ----
             if (pending >= 0) { rc = post_finish((uint32_t)pending); pending = -1; if (rc) goto done; }
@@ -1006,11 +1092,112 @@ done:
     }
     sh.cv.notify_all();
     for (auto &t : readers) t.join();
-    if (rc) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamSynchronize(p->copy_stream2); (void)hipStreamSynchronize(st); }
+    {   // every copy has landed before the caller looks at resident memory (or reuses a slot)
+        hipError_t e1 = hipStreamSynchronize(p->copy_stream), e2 = hipStreamSynchronize(p->copy_stream2), e3 = rc ? hipStreamSynchronize(st) : hipSuccess;
+        if (!rc && (e1 != hipSuccess || e2 != hipSuccess)) rc = snpgpu_set_error(ctx, SNPGPU_E_HIP, "pileup copies failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        (void)e3;
+    }
     close_all();
     if (ev_count) (void)hipEventDestroy(ev_count);
-    for (uint32_t f = 0; f < n_files; ++f) out_rc[f] = src[f].rc;
+    for (uint32_t f = 0; f < n_files; ++f) {
+        out_rc[f] = src[f].rc;
+        if (store && (src[f].rc == SNPGPU_E_IO || (place[f].block != ~0u && !block_ptr[place[f].block])))
+            store->files[first + f].resident = false;                                       // its bytes are void / never arrived
+        if (rc && out_done) __atomic_store_n(&out_done[f], 1, __ATOMIC_RELEASE);            // nobody waits for a call that failed
+    }
     return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int snpgpu_varscan_file(snpgpu_ctx *ctx, const char *path, const snpgpu_varscan_params *params, uint32_t capacity,
+                        snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status) {
+    if (!ctx || !path || !params || !out_n_sites || !out_status) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (capacity && !out_sites) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint8_t *d_file = nullptr;
+    uint64_t nbytes = 0;
+    int rc = load_file(ctx, path, &d_file, &nbytes);
+    if (rc) return rc;
+    return varscan_resident(ctx, d_file, nbytes, path, params, capacity, out_sites, out_n_sites, out_status);
+}
+
+// The same over a pileup that is already in device memory (a resident file of snpgpu_pileups, a synthetic one).
+int snpgpu_varscan_dev(snpgpu_ctx *ctx, const void *d_pileup, uint64_t nbytes, const snpgpu_varscan_params *params, uint32_t capacity,
+                       snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status) {
+    if (!ctx || !params || !out_n_sites || !out_status || (nbytes && !d_pileup)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (capacity && !out_sites) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return varscan_resident(ctx, (const uint8_t *)d_pileup, nbytes, "the resident pileup", params, capacity, out_sites, out_n_sites, out_status);
+}
+
+int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, const snpgpu_varscan_params *params, uint32_t capacity,
+                         snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status, int32_t *out_rc) {
+    if (!ctx || !params || !out_n_sites || !out_status || !out_rc || (n_files && !paths) || (capacity && !out_sites))
+        return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (!n_files) return SNPGPU_OK;
+    return varscan_stream(ctx, paths, n_files, params, capacity, out_sites, out_n_sites, out_status, out_rc, nullptr, nullptr);
+}
+
+// ---- resident pileups: the input side of the one-job pipeline -----------------------------------------------------------
+int snpgpu_pileups_create(snpgpu_ctx *ctx, uint64_t budget_bytes, snpgpu_pileups **out) {
+    if (!ctx || !out) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!budget_bytes) {                                        // what is free now, less room for the outputs of the later steps
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+        const uint64_t keep = (uint64_t)24 << 30;
+        budget_bytes = free_b > keep ? (uint64_t)free_b - keep : 0;
+    }
+    snpgpu_pileups *s = new snpgpu_pileups();
+    s->ctx = ctx;
+    s->budget = budget_bytes;
+    *out = s;
+    return SNPGPU_OK;
+}
+
+void snpgpu_pileups_destroy(snpgpu_pileups *s) {
+    if (!s) return;
+    if (s->ctx) {
+        (void)hipSetDevice(s->ctx->device);
+        (void)hipStreamSynchronize(s->ctx->stream);
+    }
+    for (void *d : s->blocks) if (d) (void)hipFree(d);
+    delete s;
+}
+
+int snpgpu_pileups_ingest(snpgpu_ctx *ctx, snpgpu_pileups *store, const char *const *paths, uint32_t n_files,
+                          const snpgpu_varscan_params *params, uint32_t capacity, snpgpu_varscan_site *out_sites, uint32_t *out_n_sites,
+                          uint64_t *out_status, int32_t *out_rc, int32_t *out_done) {
+    if (!ctx || !store || store->ctx != ctx || !out_n_sites || !out_status || !out_rc || (n_files && !paths) || (params && capacity && !out_sites))
+        return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (!n_files) return SNPGPU_OK;
+    return varscan_stream(ctx, paths, n_files, params, params ? capacity : 0, out_sites, out_n_sites, out_status, out_rc, store, out_done);
+}
+
+uint32_t snpgpu_pileups_count(const snpgpu_pileups *store) { return store ? (uint32_t)store->files.size() : 0; }
+
+int snpgpu_pileups_get(const snpgpu_pileups *store, uint32_t index, void **d_ptr, uint64_t *nbytes) {
+    if (!store || index >= store->files.size()) return SNPGPU_E_ARG;
+    const snpgpu_pileups::Entry &e = store->files[index];
+    if (d_ptr) *d_ptr = e.resident ? (void *)e.d : nullptr;
+    if (nbytes) *nbytes = e.nbytes;
+    return SNPGPU_OK;
+}
+
+int snpgpu_pileups_get_stats(const snpgpu_pileups *store, snpgpu_pileups_stats *out) {
+    if (!store || !out) return SNPGPU_E_ARG;
+    memset(out, 0, sizeof *out);
+    out->h2d_bytes = store->h2d_bytes;
+    out->file_bytes = store->file_bytes;
+    out->resident_bytes = store->used;
+    out->budget_bytes = store->budget;
+    out->n_files = (uint32_t)store->files.size();
+    for (const auto &e : store->files) if (e.resident) ++out->n_resident;
+    return SNPGPU_OK;
 }
 
 }  // extern "C"

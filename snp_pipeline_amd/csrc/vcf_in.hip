@@ -19,8 +19,9 @@
 
 #include "internal.h"
 
-extern "C" int snpgpu_vcf_sites(const char *path, uint64_t capacity, uint32_t *out_pos, uint32_t *out_contig, uint64_t *out_n_records,
-                                char *out_names, uint64_t names_capacity, uint64_t *out_name_off, uint32_t names_max, uint32_t *out_n_names) {
+// is_vcf: '#' lines are the header (and must come first), blank lines are skipped; a snplist has neither — every line is data
+static int read_sites(bool is_vcf, const char *path, uint64_t capacity, uint32_t *out_pos, uint32_t *out_contig, uint64_t *out_n_records,
+                      char *out_names, uint64_t names_capacity, uint64_t *out_name_off, uint32_t names_max, uint32_t *out_n_names) {
     if (!path || !out_n_records || !out_n_names || (capacity && (!out_pos || !out_contig)) || (names_max && (!out_names || !out_name_off)))
         return SNPGPU_E_ARG;
     *out_n_records = 0;
@@ -54,13 +55,16 @@ extern "C" int snpgpu_vcf_sites(const char *path, uint64_t capacity, uint32_t *o
         const char *cr = (const char *)memchr(p + pos, '\r', e - pos);
         if (cr) { e = (size_t)(cr - p); pos = e + 1; if (pos < n && p[pos] == '\n') ++pos; }
         else pos = nl ? e + 1 : n;
-        if (e > b && p[b] == '#') { header_seen = true; continue; }
+        if (is_vcf && e > b && p[b] == '#') { header_seen = true; continue; }
         bool blank = true;
         for (size_t k = b; k < e && blank; ++k) blank = p[k] == ' ' || (p[k] >= 9 && p[k] <= 13) || (p[k] >= 28 && p[k] <= 31);
-        if (blank) continue;
-        if (!header_seen) return SNPGPU_E_UNSUPPORTED;          // PyVCF3 refuses the file: the Python reader raises for it
+        if (blank) { if (is_vcf) continue; return SNPGPU_E_UNSUPPORTED; }   // (utils.read_snp_position_list raises for a blank line)
+        if (is_vcf && !header_seen) return SNPGPU_E_UNSUPPORTED; // PyVCF3 refuses the file: the Python reader raises for it
         const char *t1 = (const char *)memchr(p + b, '\t', e - b);
         if (!t1 || t1 == p + b) return SNPGPU_E_UNSUPPORTED;
+        if (!is_vcf)                                            // str.split() cuts at ANY white space: a name with a blank in it is not plain
+            for (const char *q = p + b; q < t1; ++q)
+                if (*q == ' ' || (*q >= 9 && *q <= 13) || (*q >= 28 && *q <= 31)) return SNPGPU_E_UNSUPPORTED;
         const char *d0 = t1 + 1;
         const char *t2 = (const char *)memchr(d0, '\t', (size_t)(p + e - d0));
         const char *d1 = t2 ? t2 : p + e;
@@ -102,6 +106,17 @@ extern "C" int snpgpu_vcf_sites(const char *path, uint64_t capacity, uint32_t *o
         }
     }
     return names.empty() ? SNPGPU_OK : SNPGPU_E_NOMEM;           // the caller comes back with more room for the names
+}
+
+extern "C" int snpgpu_vcf_sites(const char *path, uint64_t capacity, uint32_t *out_pos, uint32_t *out_contig, uint64_t *out_n_records,
+                                char *out_names, uint64_t names_capacity, uint64_t *out_name_off, uint32_t names_max, uint32_t *out_n_names) {
+    return read_sites(true, path, capacity, out_pos, out_contig, out_n_records, out_names, names_capacity, out_name_off, names_max, out_n_names);
+}
+
+// The first two columns of snplist.txt (utils.read_snp_position_list, utils.py:1073-1088): the same plain case, every line a record.
+extern "C" int snpgpu_snplist_sites(const char *path, uint64_t capacity, uint32_t *out_pos, uint32_t *out_contig, uint64_t *out_n_records,
+                                    char *out_names, uint64_t names_capacity, uint64_t *out_name_off, uint32_t names_max, uint32_t *out_n_names) {
+    return read_sites(false, path, capacity, out_pos, out_contig, out_n_records, out_names, names_capacity, out_name_off, names_max, out_n_names);
 }
 
 extern "C" int snpgpu_write_snplist(const char *path, const char *contig_names, const uint64_t *contig_off, const uint64_t *keys, uint64_t n_sites,

@@ -4,7 +4,14 @@
 // (snppipeline/vcf_writer.py:295-435) + the text PyVCF3's Writer emits for it.  Formatting 50 k rows takes Python 0.33 s per
 // sample process — more than everything else the call_consensus subcommand does; here it is a few milliseconds.  The layout
 // is pinned by the eight lambda consensus*.vcf fixtures (every row, byte for byte) and by the reference's doctest answers.
+#include <errno.h>
+#include <fcntl.h>
 #include <string.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
 
 #include "internal.h"
 
@@ -24,6 +31,130 @@ struct Out {
     }
 };
 
+
+// One data line.  `mask`: the failed-filter bits of the row (the record's own, or — for the preserved flow of the pipeline —
+// the record's plus Region).  Returns false for a record with more symbols than it keeps.
+bool put_row(Out &o, const snpgpu_site_counts &c, uint32_t mask, uint64_t key, const uint8_t *contig_names, const uint32_t *contig_name_off,
+             const char *const *filter_names, int preserve_ref_case, char failed_snp_gt) {
+    if (c.n_symbols > SNPGPU_MAX_SYMS) return false;
+    char ref = (char)c.ref_base, upper_ref = ref;
+    if (upper_ref >= 'a' && upper_ref <= 'z') upper_ref = (char)(upper_ref - 32);
+    if (!preserve_ref_case) ref = upper_ref;
+    // failed filters in bit order
+    char ft[256];
+    size_t ftn = 0;
+    for (int b = 0; b < 6; ++b)
+        if (mask >> b & 1) {
+            const size_t len = strlen(filter_names[b]);
+            if (ftn + len + 2 < sizeof ft) {
+                if (ftn) ft[ftn++] = ';';
+                memcpy(ft + ftn, filter_names[b], len);
+                ftn += len;
+            }
+        }
+    const bool failed = ftn != 0;
+    if (!failed) { memcpy(ft, "PASS", 4); ftn = 4; }
+    // ALT = ranked symbols other than the (upper-case) reference
+    int alt[SNPGPU_MAX_SYMS], n_alt = 0, ref_at = -1;
+    for (uint32_t k = 0; k < c.n_symbols; ++k) {
+        if ((char)c.sym[k] == upper_ref) ref_at = (int)k; else alt[n_alt++] = (int)k;
+    }
+    char gt;
+    const bool none = c.good_depth == 0;                    // most_common_good_bases is None
+    if (none) { gt = '.'; n_alt = 0; }
+    else {
+        gt = n_alt == 0 ? '0' : ((char)c.sym[0] == upper_ref ? '0' : '1');
+        if (failed) gt = failed_snp_gt == '.' ? '.' : (failed_snp_gt == '0' ? '0' : '1');
+    }
+    const uint32_t cid = (uint32_t)(key >> 32);
+    o.putn((const char *)contig_names + contig_name_off[cid], contig_name_off[cid + 1] - contig_name_off[cid]);
+    o.put('\t'); o.putu(key & 0xFFFFFFFFull);
+    o.puts_("\t.\t"); o.put(ref); o.put('\t');
+    if (n_alt == 0) o.put('.');
+    else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.put((char)c.sym[alt[k]]); }
+    o.puts_("\t.\t"); o.putn(ft, ftn);
+    o.puts_("\tNS=1\tGT:SDP:RD:AD:RDF:RDR:ADF:ADR:FT\t");
+    o.put(gt); o.put(':'); o.putu(c.raw_depth); o.put(':');
+    o.putu(ref_at >= 0 && !none ? c.total[ref_at] : 0); o.put(':');
+    if (n_alt == 0) o.put('0'); else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.putu(c.total[alt[k]]); }
+    o.put(':'); o.putu(ref_at >= 0 && !none ? c.fwd[ref_at] : 0);
+    o.put(':'); o.putu(ref_at >= 0 && !none ? c.rev[ref_at] : 0); o.put(':');
+    if (n_alt == 0) o.put('0'); else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.putu(c.fwd[alt[k]]); }
+    o.put(':');
+    if (n_alt == 0) o.put('0'); else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.putu(c.rev[alt[k]]); }
+    o.put(':'); o.putn(ft, ftn); o.put('\n');
+    return true;
+}
+
+bool write_all(const char *path, const char *a, size_t na, const char *b, size_t nb) {
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+    if (fd < 0) return false;
+    bool ok = true;
+    for (int part = 0; part < 2 && ok; ++part) {
+        const char *p = part ? b : a;
+        size_t left = part ? nb : na;
+        while (left) {
+            const ssize_t w = write(fd, p, left);
+            if (w < 0) { if (errno == EINTR) continue; ok = false; break; }
+            p += w;
+            left -= (size_t)w;
+        }
+    }
+    if (close(fd) != 0) ok = false;
+    return ok;
+}
+
+// consensus.fasta + consensus.vcf of one sample and flow
+void write_consensus_job(snpgpu_consensus_job &job, uint32_t n_sites, const uint8_t *contig_names, const uint32_t *contig_name_off, const uint64_t *site_keys,
+                         const char *const *filter_names, int preserve_ref_case, char failed_snp_gt, std::vector<char> &text, std::vector<uint32_t> &order) {
+    job.rc = SNPGPU_OK;
+    job.n_rows = 0;
+    if (job.fasta_path) {
+        // Bio.SeqIO's FASTA layout (call_consensus.py:189-192): ">id", then the sequence in lines of 60
+        const size_t idn = strlen(job.fasta_id);
+        text.resize(idn + 2 + job.n_bases + job.n_bases / 60 + 2);
+        char *p = text.data();
+        *p++ = '>';
+        memcpy(p, job.fasta_id, idn); p += idn;
+        *p++ = '\n';
+        for (uint64_t i = 0; i < job.n_bases; i += 60) {
+            const uint64_t n = job.n_bases - i < 60 ? job.n_bases - i : 60;
+            memcpy(p, job.sequence + i, n); p += n;
+            *p++ = '\n';
+        }
+        if (!write_all(job.fasta_path, text.data(), (size_t)(p - text.data()), nullptr, 0)) job.rc = SNPGPU_E_IO;
+    }
+    if (job.vcf_path) {
+        // a row for every parsed position that has a pileup line, in pileup order (call_consensus.py:161-180)
+        order.clear();
+        bool sorted = true;
+        uint64_t prev = 0;
+        for (uint32_t i = 0; i < n_sites; ++i) {
+            if (job.counts[i].status != SNPGPU_ST_OK) continue;
+            const uint32_t mask = job.row_filters ? job.row_filters[i] : job.counts[i].filters;
+            if (job.site_in_flow && !job.site_in_flow[i] && !(mask & SNPGPU_F_REGION)) continue;
+            order.push_back(i);
+            if (job.line_off[i] < prev) sorted = false;
+            prev = job.line_off[i];
+        }
+        if (!sorted) std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return job.line_off[x] < job.line_off[y]; });
+        text.resize(order.size() * 96 + 4096);
+        for (;;) {
+            Out o{text.data(), text.size(), 0};
+            bool bad = false;
+            for (uint32_t i : order) {
+                const uint32_t mask = job.row_filters ? job.row_filters[i] : job.counts[i].filters;
+                if (!put_row(o, job.counts[i], mask & 0x3Fu, site_keys[i], contig_names, contig_name_off, filter_names, preserve_ref_case, failed_snp_gt)) { bad = true; break; }
+            }
+            if (bad) { job.rc = SNPGPU_E_UNSUPPORTED; break; }
+            if (o.n > text.size()) { text.resize(o.n + 4096); continue; }
+            if (!write_all(job.vcf_path, job.vcf_header, strlen(job.vcf_header), text.data(), o.n)) job.rc = SNPGPU_E_IO;
+            job.n_rows = (uint32_t)order.size();
+            break;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" size_t snpgpu_format_vcf_rows(const snpgpu_site_counts *counts, const uint32_t *order, uint32_t n_rows,
@@ -35,56 +166,41 @@ extern "C" size_t snpgpu_format_vcf_rows(const snpgpu_site_counts *counts, const
     for (uint32_t r = 0; r < n_rows; ++r) {
         const uint32_t idx = order ? order[r] : r;
         const snpgpu_site_counts &c = counts[idx];
-        if (c.n_symbols > SNPGPU_MAX_SYMS) {                    // the record keeps 8 symbols: the caller raises
-            if (out_bad_row && *out_bad_row < 0) *out_bad_row = (int32_t)r;
-            continue;
+        if (!put_row(o, c, c.filters & 0x3Fu, site_keys[idx], contig_names, contig_name_off, filter_names, preserve_ref_case, failed_snp_gt)) {
+            if (out_bad_row && *out_bad_row < 0) *out_bad_row = (int32_t)r;   // the record keeps 8 symbols: the caller raises
         }
-        char ref = (char)c.ref_base, upper_ref = ref;
-        if (upper_ref >= 'a' && upper_ref <= 'z') upper_ref = (char)(upper_ref - 32);
-        if (!preserve_ref_case) ref = upper_ref;
-        // failed filters in bit order
-        char ft[256];
-        size_t ftn = 0;
-        for (int b = 0; b < 6; ++b)
-            if (c.filters >> b & 1) {
-                const size_t len = strlen(filter_names[b]);
-                if (ftn + len + 2 < sizeof ft) {
-                    if (ftn) ft[ftn++] = ';';
-                    memcpy(ft + ftn, filter_names[b], len);
-                    ftn += len;
-                }
-            }
-        const bool failed = ftn != 0;
-        if (!failed) { memcpy(ft, "PASS", 4); ftn = 4; }
-        // ALT = ranked symbols other than the (upper-case) reference
-        int alt[SNPGPU_MAX_SYMS], n_alt = 0, ref_at = -1;
-        for (uint32_t k = 0; k < c.n_symbols; ++k) {
-            if ((char)c.sym[k] == upper_ref) ref_at = (int)k; else alt[n_alt++] = (int)k;
-        }
-        char gt;
-        const bool none = c.good_depth == 0;                    // most_common_good_bases is None
-        if (none) { gt = '.'; n_alt = 0; }
-        else {
-            gt = n_alt == 0 ? '0' : ((char)c.sym[0] == upper_ref ? '0' : '1');
-            if (failed) gt = failed_snp_gt == '.' ? '.' : (failed_snp_gt == '0' ? '0' : '1');
-        }
-        const uint32_t cid = (uint32_t)(site_keys[idx] >> 32);
-        o.putn((const char *)contig_names + contig_name_off[cid], contig_name_off[cid + 1] - contig_name_off[cid]);
-        o.put('\t'); o.putu(site_keys[idx] & 0xFFFFFFFFull);
-        o.puts_("\t.\t"); o.put(ref); o.put('\t');
-        if (n_alt == 0) o.put('.');
-        else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.put((char)c.sym[alt[k]]); }
-        o.puts_("\t.\t"); o.putn(ft, ftn);
-        o.puts_("\tNS=1\tGT:SDP:RD:AD:RDF:RDR:ADF:ADR:FT\t");
-        o.put(gt); o.put(':'); o.putu(c.raw_depth); o.put(':');
-        o.putu(ref_at >= 0 && !none ? c.total[ref_at] : 0); o.put(':');
-        if (n_alt == 0) o.put('0'); else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.putu(c.total[alt[k]]); }
-        o.put(':'); o.putu(ref_at >= 0 && !none ? c.fwd[ref_at] : 0);
-        o.put(':'); o.putu(ref_at >= 0 && !none ? c.rev[ref_at] : 0); o.put(':');
-        if (n_alt == 0) o.put('0'); else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.putu(c.fwd[alt[k]]); }
-        o.put(':');
-        if (n_alt == 0) o.put('0'); else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.putu(c.rev[alt[k]]); }
-        o.put(':'); o.putn(ft, ftn); o.put('\n');
     }
     return o.n;
+}
+
+// The output files of call_consensus for many (sample, flow) pairs at once, on `n_threads` host threads (0: one per job up to
+// the hardware's): the text of 125 samples x 2 flows x 50 000 rows is a gigabyte — formatted and written by one thread it would
+// take longer than the pileups take to cross the host link.
+extern "C" int snpgpu_write_consensus_files(snpgpu_consensus_job *jobs, uint32_t n_jobs, uint32_t n_sites, const uint8_t *contig_names,
+                                            const uint32_t *contig_name_off, const uint64_t *site_keys, const char *const *filter_names,
+                                            int preserve_ref_case, char failed_snp_gt, uint32_t n_threads) {
+    if (n_jobs && !jobs) return SNPGPU_E_ARG;
+    if (!n_threads) {
+        n_threads = std::thread::hardware_concurrency();
+        if (n_threads > 64) n_threads = 64;
+    }
+    if (n_threads > n_jobs) n_threads = n_jobs;
+    if (n_threads < 1) n_threads = 1;
+    std::atomic<uint32_t> next{0};
+    auto work = [&]() {
+        std::vector<char> text;
+        std::vector<uint32_t> order;
+        for (;;) {
+            const uint32_t j = next.fetch_add(1);
+            if (j >= n_jobs) return;
+            write_consensus_job(jobs[j], n_sites, contig_names, contig_name_off, site_keys, filter_names, preserve_ref_case, failed_snp_gt, text, order);
+        }
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    } catch (...) {}                                            // fewer threads than asked for: the others do the work
+    work();
+    for (auto &t : pool) t.join();
+    return SNPGPU_OK;
 }

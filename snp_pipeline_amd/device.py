@@ -84,6 +84,54 @@ class SiteSet(object):
         self.contigs = contigs
         self.keys = np.ascontiguousarray(uniq, dtype=np.uint64)
         self.flags = np.ascontiguousarray(ufl)
+        self._create()
+
+    @classmethod
+    def from_arrays(cls, device, contigs, keys, flags):
+        """contigs: bytewise sorted, unique list of contig names (bytes); keys: uint64 (contig index << 32 | pos), strictly
+        increasing; flags: SITE_* per key.  No Python loop per key (``index_of`` is the identity and is not materialised)."""
+        self = cls.__new__(cls)
+        self.device = device
+        self.contigs = list(contigs)
+        self.keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        self.flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        self.index_of = None
+        self._create()
+        return self
+
+    @classmethod
+    def from_lists(cls, device, lists):
+        """lists: [(contig names (str or bytes), contig index per record, position per record, SITE_* flag)] — the array
+        triples of utils.read_vcf_site_arrays / read_snp_position_arrays.  Returns (SiteSet over the union, one array of
+        slots per list: -1 for a position that cannot occur in a pileup (negative or >= 2**32))."""
+        as_bytes = [[n if isinstance(n, bytes) else n.encode("utf-8") for n in names] for names, _, _, _ in lists]
+        contigs = sorted({n for names in as_bytes for n in names})
+        cid = {c: i for i, c in enumerate(contigs)}
+        parts, oks, fl = [], [], []
+        for names, (_, cidx, pos, flag) in zip(as_bytes, lists):
+            pos = np.asarray(pos, dtype=np.int64)
+            ok = (pos >= 0) & (pos < (1 << 32))
+            lut = np.asarray([cid[c] for c in names] + [0], dtype=np.uint64)
+            key = (lut[np.asarray(cidx, dtype=np.int64)] << np.uint64(32)) | (pos & 0xFFFFFFFF).astype(np.uint64) if len(pos) else np.zeros(0, np.uint64)
+            parts.append(key[ok])
+            oks.append(ok)
+            fl.append(np.full(int(ok.sum()), flag, dtype=np.uint8))
+        every = np.concatenate(parts) if parts else np.zeros(0, np.uint64)
+        uniq, inv = np.unique(every, return_inverse=True)
+        flags = np.zeros(len(uniq), dtype=np.uint8)
+        if len(every):
+            np.bitwise_or.at(flags, inv, np.concatenate(fl))
+        slots, at = [], 0
+        for ok in oks:
+            k = int(ok.sum())
+            sl = np.full(len(ok), -1, dtype=np.int64)
+            sl[ok] = inv[at:at + k]
+            at += k
+            slots.append(sl)
+        return cls.from_arrays(device, contigs, uniq, flags), slots
+
+    def _create(self):
+        device, contigs = self.device, self.contigs
         names = b"".join(contigs)
         offs = np.zeros(len(contigs) + 1, dtype=np.uint32)
         if contigs:
@@ -178,6 +226,9 @@ class Device(object):
     def siteset(self, keys, flags):
         return SiteSet(self, keys, flags)
 
+    def siteset_from_lists(self, lists):
+        return SiteSet.from_lists(self, lists)
+
     @staticmethod
     def raise_scan_status(status):
         w0 = int(status[0])
@@ -227,13 +278,24 @@ class Device(object):
             raise PileupFormatError("pileup line for site #%d: %s" % (int(bad[0]), what), exc)
 
     def call_consensus_files(self, siteset, paths, params, want_counts=False, want_line_offsets=False,
-                             want_depth_sum=False, chunk_bytes=0, n_readers=0, n_staging=0, n_slots=0):
+                             want_depth_sum=False, chunk_bytes=0, n_readers=0, n_staging=0, n_slots=0, exclude=None):
         """Streamed ingestion of pileup FILES (snpgpu_call_consensus_files): reader threads -> pinned staging -> copy
         stream -> scan of the tiles that have landed; no file is resident in host memory.
         Returns (results, rcs, stats): one ConsensusResult per path (``.line_offsets`` set when asked for), the per-file
         return codes (0, E_IO, E_PILEUP, E_UNSUPPORTED) and the StreamStats of the call.  Nothing is raised per file:
-        use ``raise_file_status``."""
+        use ``raise_file_status``.  exclude: per path, the site-set slots of that file's own exclude list (arrays; slots < 0
+        are ignored) — the file is called with SITE_EXCLUDED on them on top of the set's flags."""
         n_files, n = len(paths), len(siteset)
+        excl_off = excl_slots = None
+        if exclude is not None:
+            lists = [np.asarray(e, dtype=np.int64) for e in exclude]
+            lists = [e[e >= 0].astype(np.uint32) for e in lists]
+            excl_off = np.zeros(n_files + 1, dtype=np.uint32)
+            if lists:
+                np.cumsum([len(e) for e in lists], out=excl_off[1:])
+            excl_slots = np.ascontiguousarray(np.concatenate(lists) if lists else np.zeros(0, np.uint32), dtype=np.uint32)
+            if len(excl_slots) == 0:
+                excl_slots = np.zeros(1, dtype=np.uint32)
         enc = [os.fsencode(p) for p in paths]
         arr = (C.c_char_p * max(n_files, 1))(*enc)
         bases = np.empty((n_files, n), dtype=np.uint8)
@@ -245,8 +307,8 @@ class Device(object):
         opts = L.StreamOpts(int(chunk_bytes), int(n_staging), int(n_readers), int(n_slots), 1 if want_depth_sum else 0)
         stats = L.StreamStats()
         self._check(self.lib.snpgpu_call_consensus_files(
-            self.ctx, siteset.handle, arr, n_files, C.byref(params), _ptr(bases), _ptr(filters), _ptr(counts),
-            _ptr(line_off), _ptr(status), _ptr(rcs), C.byref(opts), C.byref(stats)))
+            self.ctx, siteset.handle, arr, n_files, C.byref(params), _ptr(excl_off), _ptr(excl_slots), _ptr(bases), _ptr(filters),
+            _ptr(counts), _ptr(line_off), _ptr(status), _ptr(rcs), C.byref(opts), C.byref(stats)))
         results = []
         for f in range(n_files):
             r = ConsensusResult(bases[f], filters[f], counts[f] if want_counts else None, status[f])
@@ -368,6 +430,44 @@ class Device(object):
             self.ctx, siteset.handle, C.c_void_p(d_pileups_ptr), _ptr(offs), _ptr(sz) if sz is not None else None, n,
             C.byref(params), C.c_void_p(d_bases), C.c_void_p(d_filters), C.c_void_p(d_status)))
 
+    def call_consensus_many_dev(self, siteset, d_ptrs, sizes, params, d_bases, d_filters, d_status, d_counts=0, d_line_off=0,
+                                d_site_flags=0, want_depth_sum=False):
+        """Samples anywhere in device memory (the resident pileups of the pipeline): d_ptrs / sizes per sample; the d_*
+        arguments are device pointers (ints) of [n][n_sites] outputs; asynchronous."""
+        n = len(sizes)
+        ptrs = (C.c_void_p * max(n, 1))(*[C.c_void_p(int(p)) for p in d_ptrs])
+        sz = np.ascontiguousarray(sizes, dtype=np.uint64)
+        opt = lambda v: C.c_void_p(v) if v else None     # noqa: E731
+        self._check(self.lib.snpgpu_call_consensus_many_dev(
+            self.ctx, siteset.handle, ptrs, _ptr(sz), n, C.byref(params), opt(d_site_flags), C.c_void_p(d_bases), C.c_void_p(d_filters),
+            opt(d_counts), opt(d_line_off), C.c_void_p(d_status), 1 if want_depth_sum else 0))
+
+    def region_flow_dev(self, d_base, d_filters, d_line_off, n_samples, n_sites, d_cols, d_col_of, n_cols, d_excl_off, d_excl_slots,
+                        d_out_base, d_out_filters, d_err):
+        """The preserved flow from the result of the full-list call (snpgpu_region_flow_dev); device pointers; asynchronous."""
+        opt = lambda v: C.c_void_p(v) if v else None     # noqa: E731
+        self._check(self.lib.snpgpu_region_flow_dev(self.ctx, opt(d_base), opt(d_filters), opt(d_line_off), n_samples, n_sites, opt(d_cols),
+                                                    opt(d_col_of), n_cols, opt(d_excl_off), opt(d_excl_slots), opt(d_out_base),
+                                                    opt(d_out_filters), C.c_void_p(d_err)))
+
+    def varscan_dev(self, d_ptr, nbytes, params, capacity=65536):
+        """varscan_file for a pileup that is in device memory."""
+        n = C.c_uint32()
+        status = np.zeros(2, dtype=np.uint64)
+        while True:
+            cap = int(capacity)
+            sites = np.zeros(max(cap, 1), dtype=VARSCAN_DTYPE)
+            rc = self.lib.snpgpu_varscan_dev(self.ctx, C.c_void_p(int(d_ptr)), int(nbytes), C.byref(params), cap, _ptr(sites), C.byref(n), _ptr(status))
+            if rc == L.E_PILEUP:
+                raise PileupFormatError("Invalid format for pileup at byte %d" % int(status[0]), ValueError)
+            self._check(rc)
+            if n.value <= cap:
+                return sites[:n.value], int(status[1])
+            capacity = max(n.value, 2 * cap)
+
+    def pileups(self, budget_bytes=0):
+        return Pileups(self, budget_bytes)
+
     # ---- distance ------------------------------------------------------------------------------
     def packed_row_bytes(self, n_sites):
         return int(self.lib.snpgpu_packed_row_bytes(n_sites))
@@ -470,6 +570,114 @@ class Device(object):
                                                      C.c_void_p(d_site_alt) if d_site_alt else None,
                                                      C.c_void_p(d_out) if d_out else None, capacity, C.byref(nbytes)))
         return nbytes.value
+
+
+class Pileups(object):
+    """Pileup files kept in device memory between site calling and the consensus scan (snpgpu_pileups): the input side of
+    ``hot_path_batch``.  ``ingest`` streams files in (site calling on each while the next arrives) and keeps them while the
+    budget lasts; ``get`` returns where file i lives."""
+
+    def __init__(self, device, budget_bytes=0):
+        self.device = device
+        h = C.c_void_p()
+        device._check(device.lib.snpgpu_pileups_create(device.ctx, int(budget_bytes), C.byref(h)))
+        self.handle = h
+
+    def ingest(self, paths, params=None, capacity=16384, done=None):
+        """One streamed call over `paths`.  Returns (records array [n][capacity], counts, status [n][2], rcs); with `done`
+        (an int32 array of len(paths)) the caller may watch done[f] become 1 from another thread and use row f then."""
+        n = len(paths)
+        arr = (C.c_char_p * max(n, 1))(*[os.fsencode(p) for p in paths])
+        cap = int(capacity) if params is not None else 0
+        sites = np.empty((n, max(cap, 1)), dtype=VARSCAN_DTYPE)
+        counts = np.zeros(max(n, 1), dtype=np.uint32)
+        status = np.zeros((max(n, 1), 2), dtype=np.uint64)
+        rcs = np.zeros(max(n, 1), dtype=np.int32)
+        self.device._check(self.device.lib.snpgpu_pileups_ingest(
+            self.device.ctx, self.handle, arr, n, C.byref(params) if params is not None else None, cap, _ptr(sites), _ptr(counts),
+            _ptr(status), _ptr(rcs), _ptr(done) if done is not None else None))
+        return sites, counts[:n], status[:n], rcs[:n]
+
+    def ingest_buffers(self, n, capacity):
+        """The output arrays of one ingest call, allocated by the caller so that a consumer thread can read row f as soon as
+        done[f] is set: (sites, counts, status, rcs, done)."""
+        return (np.empty((n, max(int(capacity), 1)), dtype=VARSCAN_DTYPE), np.zeros(max(n, 1), dtype=np.uint32),
+                np.zeros((max(n, 1), 2), dtype=np.uint64), np.zeros(max(n, 1), dtype=np.int32), np.zeros(max(n, 1), dtype=np.int32))
+
+    def ingest_into(self, paths, params, capacity, bufs):
+        n = len(paths)
+        sites, counts, status, rcs, done = bufs
+        arr = (C.c_char_p * max(n, 1))(*[os.fsencode(p) for p in paths])
+        self.device._check(self.device.lib.snpgpu_pileups_ingest(
+            self.device.ctx, self.handle, arr, n, C.byref(params) if params is not None else None, int(capacity) if params is not None else 0,
+            _ptr(sites), _ptr(counts), _ptr(status), _ptr(rcs), _ptr(done)))
+
+    def __len__(self):
+        return int(self.device.lib.snpgpu_pileups_count(self.handle))
+
+    def get(self, index):
+        """(device pointer or 0 when the file is not resident, size in bytes)"""
+        p, n = C.c_void_p(), C.c_uint64()
+        if self.device.lib.snpgpu_pileups_get(self.handle, int(index), C.byref(p), C.byref(n)) != 0:
+            raise IndexError(index)
+        return int(p.value or 0), int(n.value)
+
+    def stats(self):
+        st = L.PileupsStats()
+        self.device.lib.snpgpu_pileups_get_stats(self.handle, C.byref(st))
+        return st
+
+    def close(self):
+        if self.handle:
+            self.device.lib.snpgpu_pileups_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_consensus_files(jobs, siteset, filter_names, preserve_ref_case, failed_snp_gt, n_threads=0):
+    """jobs: list of dicts with the fields of snpgpu_consensus_job (numpy arrays for the pointers; absent = NULL).  Writes
+    the consensus FASTA / VCF files of all jobs on host threads (csrc/vcf_rows.hip).  Returns [(rc, rows)] per job."""
+    lib = L.load()
+    n = len(jobs)
+    arr = (L.ConsensusJob * max(n, 1))()
+    keep = []
+
+    def ptr(a):
+        if a is None:
+            return None
+        keep.append(a)
+        return a.ctypes.data
+
+    def text(t):
+        if t is None:
+            return None
+        b = t if isinstance(t, bytes) else os.fsencode(t)
+        keep.append(b)
+        return b
+
+    for j, job in enumerate(jobs):
+        seq = job.get("sequence")
+        arr[j].fasta_path = text(job.get("fasta_path"))
+        arr[j].fasta_id = text(job.get("fasta_id"))
+        arr[j].sequence = ptr(seq)
+        arr[j].n_bases = len(seq) if seq is not None else 0
+        arr[j].vcf_path = text(job.get("vcf_path"))
+        arr[j].vcf_header = text(job.get("vcf_header"))
+        arr[j].counts = ptr(job.get("counts"))
+        arr[j].line_off = ptr(job.get("line_off"))
+        arr[j].row_filters = ptr(job.get("row_filters"))
+        arr[j].site_in_flow = ptr(job.get("site_in_flow"))
+    fn = (C.c_char_p * 6)(*[x.encode("ascii") for x in filter_names])
+    rc = lib.snpgpu_write_consensus_files(arr, n, len(siteset), _ptr(siteset._names), _ptr(siteset._offs), _ptr(siteset.keys), fn,
+                                          1 if preserve_ref_case else 0, failed_snp_gt.encode("ascii"), int(n_threads))
+    if rc != 0:
+        raise SnpGpuError(rc, "snpgpu_write_consensus_files")
+    return [(int(arr[j].rc), int(arr[j].n_rows)) for j in range(n)]
 
 
 _default = None

@@ -250,15 +250,27 @@ def read_vcf_sites(vcf_file_path):
     return header, data, sites
 
 
-def read_vcf_site_arrays(vcf_file_path):
-    """The same CHROM / POS columns as numpy arrays, by the library's host code (csrc/vcf_in.hip): returns (contig names in
-    order of first appearance, contig index per record, position per record).  Files outside the plain case (see
-    snpgpu_vcf_sites) go through read_vcf_sites, which also raises what the reference raises for them."""
+def _site_arrays_from_tuples(sites):
+    import numpy as np
+    order, index = [], {}
+    for c, _ in sites:
+        if c not in index:
+            index[c] = len(order)
+            order.append(c)
+    return (order, np.fromiter((index[c] for c, _ in sites), dtype=np.uint32, count=len(sites)),
+            np.fromiter((p for _, p in sites), dtype=np.int64, count=len(sites)))
+
+
+def _read_site_arrays(symbol, file_path, python_reader):
+    """(contig names in order of first appearance, contig index per record, position per record) of a VCF or a snplist by
+    the library's host code (csrc/vcf_in.hip); files outside its plain case go through `python_reader` (-> [(chrom, pos)]),
+    which also raises what the reference raises for them."""
     import ctypes as C
     import numpy as np
     from . import _lib as L
     lib = L.load()
-    cap = max(1024, os.path.getsize(vcf_file_path) // 24)
+    fn = getattr(lib, symbol)
+    cap = max(1024, os.path.getsize(file_path) // 24)
     names_cap, names_max = 1 << 16, 4096
     while True:
         pos = np.empty(cap, dtype=np.uint32)
@@ -266,30 +278,35 @@ def read_vcf_site_arrays(vcf_file_path):
         names = C.create_string_buffer(names_cap)
         off = np.zeros(names_max + 1, dtype=np.uint64)
         n, nn = C.c_uint64(), C.c_uint32()
-        rc = lib.snpgpu_vcf_sites(os.fsencode(vcf_file_path), cap, pos.ctypes.data, cidx.ctypes.data, C.byref(n), names, names_cap,
-                                  off.ctypes.data, names_max, C.byref(nn))
+        rc = fn(os.fsencode(file_path), cap, pos.ctypes.data, cidx.ctypes.data, C.byref(n), names, names_cap,
+                off.ctypes.data, names_max, C.byref(nn))
         if rc == L.E_IO:
-            raise IOError("cannot read %s" % vcf_file_path)
+            raise IOError("cannot read %s" % file_path)
         if rc == L.E_UNSUPPORTED:
-            sites = read_vcf_sites(vcf_file_path)[2]
-            order = []
-            index = {}
-            for c, _ in sites:
-                if c not in index:
-                    index[c] = len(order)
-                    order.append(c)
-            return (order, np.fromiter((index[c] for c, _ in sites), dtype=np.uint32, count=len(sites)),
-                    np.fromiter((p for _, p in sites), dtype=np.int64, count=len(sites)))
+            return _site_arrays_from_tuples(python_reader(file_path))
         if rc == L.E_NOMEM:
             names_cap, names_max = names_cap * 8, names_max * 8
             continue
         if rc != 0:
-            raise RuntimeError("snpgpu_vcf_sites failed (%d)" % rc)
+            raise RuntimeError("%s failed (%d)" % (symbol, rc))
         if n.value > cap:
             cap = n.value
             continue
         raw = names.raw
         return ([raw[int(off[i]):int(off[i + 1])].decode("utf-8") for i in range(nn.value)], cidx[:n.value], pos[:n.value].astype(np.int64))
+
+
+def read_vcf_site_arrays(vcf_file_path):
+    """The CHROM / POS columns of read_vcf_sites as numpy arrays (see _read_site_arrays, snpgpu_vcf_sites)."""
+    return _read_site_arrays("snpgpu_vcf_sites", vcf_file_path, lambda path: read_vcf_sites(path)[2])
+
+
+def read_snp_position_arrays(snp_list_file_path):
+    """read_snp_position_list as numpy arrays: 200 000 lines cost the per-sample process ~0.15 s of Python otherwise."""
+    if os.path.getsize(snp_list_file_path) == 0:
+        import numpy as np
+        return [], np.zeros(0, np.uint32), np.zeros(0, np.int64)
+    return _read_site_arrays("snpgpu_snplist_sites", snp_list_file_path, read_snp_position_list)
 
 
 def convert_vcf_file_to_snp_set(vcf_file_path):

@@ -126,35 +126,61 @@ def _write_vcf(vcf_path, pileup_path, records, opts):
 def mpileup2snp_files(device, pileup_paths, vcf_paths, opts, group=6):
     """Many samples: streamed device calls over groups of `group` files in a helper thread (the library releases the GIL), while
     this thread turns the records of the group before into VCF files.  Returns [(lines, sites written) or the exception of
-    that sample] in input order."""
+    that sample] in input order.  A sample whose VCF cannot be written (unwritable directory, full disk) carries that exception
+    and the others go on; whatever happens, the helper thread has been stopped and joined when this function returns."""
     import queue
     import threading
     n = len(pileup_paths)
     done = queue.Queue(maxsize=2)
+    stop = threading.Event()
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                done.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
 
     def produce():
         try:
             for g0 in range(0, n, group):
-                done.put((g0, device.varscan_files(pileup_paths[g0:g0 + group], opts.device_params())))
+                if stop.is_set() or not put((g0, device.varscan_files(pileup_paths[g0:g0 + group], opts.device_params()))):
+                    return
         except BaseException as err:                            # noqa: B902 — handed to the consumer
-            done.put((None, err))
-        done.put((None, None))
+            put((None, err))
+        put((None, None))
 
     producer = threading.Thread(target=produce)
     producer.start()
     results = [None] * n
     failure = None
-    while True:
-        g0, batch = done.get()
-        if g0 is None:
-            if batch is None:
-                break
-            failure = batch
-            continue
-        for k, (records, n_lines) in enumerate(batch):
-            i = g0 + k
-            results[i] = records if isinstance(records, Exception) else (n_lines, _write_vcf(vcf_paths[i], pileup_paths[i], records, opts))
-    producer.join()
+    try:
+        while True:
+            g0, batch = done.get()
+            if g0 is None:
+                if batch is None:
+                    break
+                failure = batch
+                continue
+            for k, (records, n_lines) in enumerate(batch):
+                i = g0 + k
+                if isinstance(records, Exception):
+                    results[i] = records
+                    continue
+                try:
+                    results[i] = (n_lines, _write_vcf(vcf_paths[i], pileup_paths[i], records, opts))
+                except Exception as err:                        # noqa: B902 — this sample's error; the stream goes on
+                    results[i] = err
+    finally:
+        stop.set()                                              # on any exit: no producer left blocked on the queue or inside the device
+        while producer.is_alive():
+            try:
+                done.get(timeout=0.05)
+            except queue.Empty:
+                pass
+        producer.join()
     if failure is not None:
         raise failure
     return results

@@ -111,11 +111,13 @@ def format_rows(counts, order, contig_names, contig_name_off, site_keys, filter_
     return buf.raw[:int(need)]
 
 
-def write_consensus_vcf(path, sample_id, args, siteset, result, line_offsets):
-    """Rows for every parsed position (snplist and exclude positions that have a pileup line), in pileup order."""
+def write_consensus_vcf(path, sample_id, args, siteset, result, line_offsets, parsed=None):
+    """Rows for every parsed position (snplist and exclude positions that have a pileup line), in pileup order.  parsed:
+    bool per site — the positions THIS sample parses, when the site set also serves other samples' exclude lists."""
     filters = filter_descriptions(args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
     names = [n for n, _ in filters]
-    have = np.nonzero(result.counts["status"] == L.ST_OK)[0]
+    ok = result.counts["status"] == L.ST_OK
+    have = np.nonzero(ok if parsed is None else (ok & parsed))[0]
     order = have[np.argsort(line_offsets[have], kind="stable")]
     rows = format_rows(result.counts, order, siteset._names, siteset._offs, siteset.keys, names, args.vcfPreserveRefCase,
                        args.vcfFailedSnpGt)

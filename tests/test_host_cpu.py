@@ -671,3 +671,154 @@ def test_library_vcf_site_reader_and_snplist_writer(tmp_path, fixture_trees):
     assert open(a, "rb").read() == open(b, "rb").read()
     merge_sites.write_snplist(a, [], np.zeros(0, np.uint64), np.zeros(1, np.uint32), np.zeros(0, np.uint32), [])
     assert open(a, "rb").read() == b""
+
+
+def test_library_snplist_reader_equals_read_snp_position_list(tmp_path, fixture_trees):
+    """csrc/vcf_in.hip snpgpu_snplist_sites (utils.read_snp_position_arrays) against utils.read_snp_position_list on the six
+    bundled snplists and on lines outside the plain case, which go through the Python reader (same answers, same exceptions)."""
+    from snp_pipeline_amd import utils
+    n = 0
+    for ds in ("lambdaVirus", "agona", "listeria"):
+        root, _ = fixture_trees[ds]
+        for name in ("snplist.txt", "snplist_preserved.txt"):
+            path = os.path.join(root, name)
+            want = utils.read_snp_position_list(path)
+            names, cidx, pos = utils.read_snp_position_arrays(path)
+            assert [(names[int(c)], int(p)) for c, p in zip(cidx, pos)] == want, path
+            n += len(want)
+    assert n > 14000
+    odd = {"spaces.txt": b"c1 5 1 a\nc2\t7\t1\tb\n", "plus.txt": b"c1\t+5\t1\ta\n", "crlf.txt": b"c1\t5\t1\ta\r\nc1\t9\t1\tb\r\n",
+           "hash.txt": b"#c\t5\t1\ta\n", "blank_in_name.txt": b"c 1\t5\t1\ta\n", "two_fields.txt": b"c1\t5\nc1\t6"}
+    for name, data in odd.items():
+        path = str(tmp_path / name)
+        with open(path, "wb") as f:
+            f.write(data)
+        want = utils.read_snp_position_list(path)
+        names, cidx, pos = utils.read_snp_position_arrays(path)
+        assert [(names[int(c)], int(p)) for c, p in zip(cidx, pos)] == want, name
+    empty = str(tmp_path / "empty.txt")
+    open(empty, "wb").close()
+    assert utils.read_snp_position_arrays(empty)[0] == [] and utils.read_snp_position_list(empty) == []
+    for name, data in (("blank.txt", b"c1\t5\t1\ta\n\nc1\t6\t1\ta\n"), ("badpos.txt", b"c1\tx\t1\ta\n"), ("one_field.txt", b"c1\n")):
+        path = str(tmp_path / name)
+        with open(path, "wb") as f:
+            f.write(data)
+        with pytest.raises(ValueError):
+            utils.read_snp_position_list(path)
+        with pytest.raises(ValueError):
+            utils.read_snp_position_arrays(path)
+
+
+def test_library_consensus_file_writer_reproduces_the_lambda_fixtures(tmp_path, fixture_trees):
+    """snpgpu_write_consensus_files (csrc/vcf_rows.hip; what hot_path_batch writes its consensus files with): the sixteen
+    bundled lambda consensus*.fasta / consensus*.vcf files come back byte for byte from the per-site records their rows
+    encode — all samples and both flows in ONE call on host threads; rows in pileup order although the records are handed over
+    in site order with shuffled line offsets; the preserved flow's Region rows of positions outside its snplist included."""
+    import numpy as np
+    from snp_pipeline_amd import _lib as L
+    from snp_pipeline_amd import device, utils
+    from snp_pipeline_amd.device import COUNTS_DTYPE
+    root, _ = fixture_trees["lambdaVirus"]
+    samples = sorted(os.listdir(os.path.join(root, "samples")))
+    snplists = {sfx: utils.read_snp_position_list(os.path.join(root, "snplist%s.txt" % sfx)) for sfx in ("", "_preserved")}
+    # one site set for everything: every position any file mentions
+    every = set(p for sl in snplists.values() for _, p in sl)
+    parsed = {}
+    for sfx in ("", "_preserved"):
+        for s in samples:
+            rows = [ln for ln in open(os.path.join(root, "samples", s, "consensus%s.vcf" % sfx)).read().split("\n") if ln and not ln.startswith("#")]
+            parsed[(s, sfx)] = [_counts_from_vcf_row(r) + (r,) for r in rows]
+            every.update(p for _, p, _, _, _, _, _ in parsed[(s, sfx)])
+    chrom = snplists[""][0][0]
+    keys = np.array(sorted(every), dtype=np.uint64)
+    slot = {int(p): i for i, p in enumerate(keys)}
+
+    class Set(object):                      # what write_consensus_files reads of a SiteSet
+        _names = np.frombuffer(chrom.encode(), dtype=np.uint8)
+        _offs = np.array([0, len(chrom)], dtype=np.uint32)
+
+        def __len__(self):
+            return len(keys)
+    Set.keys = keys
+    names = ["RawDpth", "VarFreq60", "Depth3", "StrDpth0", "StrBias0", "Region"]
+    rng = np.random.default_rng(3)
+    jobs, want = [], []
+    for sfx in ("", "_preserved"):
+        in_flow = np.zeros(len(keys), dtype=np.uint8)
+        for _, p in snplists[sfx]:
+            in_flow[slot[p]] = 1
+        for s in samples:
+            sdir = os.path.join(root, "samples", s)
+            text = open(os.path.join(sdir, "consensus%s.vcf" % sfx)).read()
+            header = "".join(ln + "\n" for ln in text.split("\n") if ln.startswith("#"))
+            counts = np.zeros(len(keys), dtype=COUNTS_DTYPE)
+            line_off = np.zeros(len(keys), dtype=np.uint64)
+            row_filters = np.zeros(len(keys), dtype=np.uint8)
+            called = {}
+            # line offsets: increasing with the row's place in the file, whatever the site order
+            offs = np.sort(rng.choice(10 ** 7, size=len(parsed[(s, sfx)]), replace=False)) + 1
+            for k, (c_, pos, c, ranked, ft, gt, row) in enumerate(parsed[(s, sfx)]):
+                mask = 0
+                for name in ([] if ft == "PASS" else ft.split(";")):
+                    mask |= 1 << names.index(name)
+                i = slot[pos]
+                counts[i] = c
+                counts[i]["filters"] = mask & ~L.F_REGION           # the record carries the caller's own filters; Region comes with the flow
+                row_filters[i] = mask
+                line_off[i] = offs[k]
+                called[pos] = "-" if (mask or not ranked or ranked[0] == "*") else ranked[0]
+            seq = np.frombuffer("".join(called.get(p, "-") for _, p in snplists[sfx]).encode(), dtype=np.uint8)
+            out_f, out_v = str(tmp_path / ("%s%s.fasta" % (s, sfx))), str(tmp_path / ("%s%s.vcf" % (s, sfx)))
+            jobs.append({"fasta_path": out_f, "fasta_id": s.encode(), "sequence": seq, "vcf_path": out_v, "vcf_header": header.encode(),
+                         "counts": counts, "line_off": line_off, "row_filters": row_filters, "site_in_flow": in_flow})
+            want.append((out_f, open(os.path.join(sdir, "consensus%s.fasta" % sfx), "rb").read(), out_v, text.encode(), len(parsed[(s, sfx)])))
+    res = device.write_consensus_files(jobs, Set(), names, False, ".", n_threads=4)
+    assert len(res) == 8
+    for (rc, n_rows), (out_f, fasta, out_v, vcf, n) in zip(res, want):
+        assert rc == 0 and n_rows == n
+        assert open(out_f, "rb").read() == fasta and open(out_v, "rb").read() == vcf
+    # an unwritable path is that job's error only; a record with too many symbols is refused, not truncated
+    jobs[0]["fasta_path"] = str(tmp_path / "no_such_dir" / "x.fasta")
+    jobs[1]["counts"] = jobs[1]["counts"].copy()
+    jobs[1]["counts"]["n_symbols"][np.flatnonzero(jobs[1]["counts"]["status"] == L.ST_OK)[0]] = 9
+    res = device.write_consensus_files(jobs[:3], Set(), names, False, ".")
+    assert [rc for rc, _ in res] == [L.E_IO, L.E_UNSUPPORTED, 0]
+    # an empty snplist: ">name" alone, and a VCF of its header (regression_tests.sh:3156-3207 only asks for non-empty files)
+    e = {"fasta_path": str(tmp_path / "e.fasta"), "fasta_id": b"s", "sequence": np.zeros(0, np.uint8), "vcf_path": str(tmp_path / "e.vcf"),
+         "vcf_header": b"#h\n", "counts": np.zeros(1, dtype=COUNTS_DTYPE), "line_off": np.zeros(1, np.uint64)}
+
+    class Empty(Set):
+        def __len__(self):
+            return 0
+    assert device.write_consensus_files([e], Empty(), names, False, ".") == [(0, 0)]
+    assert open(e["fasta_path"], "rb").read() == b">s\n" and open(e["vcf_path"], "rb").read() == b"#h\n"
+
+
+def test_mpileup2snp_files_reports_an_unwritable_vcf_per_sample_and_never_hangs(monkeypatch):
+    """an exception from the VCF writer must not leave the producer thread blocked on its queue (more than ~18 files
+    per GPU used to hang the process): the sample carries the error, the others are written, the helper thread is gone."""
+    import threading
+    from snp_pipeline_amd import varscan
+
+    class FakeDevice(object):
+        def varscan_files(self, paths, prm):
+            return [([], 10) for _ in paths]
+    calls = []
+
+    def writer(vcf_path, pileup_path, records, opts):
+        calls.append(vcf_path)
+        if vcf_path in ("v3", "v40"):
+            raise OSError("No space left on device")
+        return 0
+    monkeypatch.setattr(varscan, "_write_vcf", writer)
+    before = threading.active_count()
+    res = varscan.mpileup2snp_files(FakeDevice(), ["p%d" % i for i in range(64)], ["v%d" % i for i in range(64)], varscan.Options(""))
+    assert len(calls) == 64 and [i for i, r in enumerate(res) if isinstance(r, Exception)] == [3, 40]
+    assert all(r == (10, 0) for i, r in enumerate(res) if i not in (3, 40)) and threading.active_count() == before
+
+    def interrupt(vcf_path, pileup_path, records, opts):
+        raise KeyboardInterrupt()
+    monkeypatch.setattr(varscan, "_write_vcf", interrupt)
+    with pytest.raises(KeyboardInterrupt):
+        varscan.mpileup2snp_files(FakeDevice(), ["p%d" % i for i in range(64)], ["v%d" % i for i in range(64)], varscan.Options(""))
+    assert threading.active_count() == before
