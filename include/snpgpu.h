@@ -284,6 +284,12 @@ typedef struct snpgpu_pileups_stats {
     uint64_t resident_bytes;        /* device bytes taken (files + padding) */
     uint64_t budget_bytes;
     uint32_t n_files, n_resident;
+    double   seconds;                       /* wall time of the ingest calls, of which the issuing thread spent ... */
+    double   seconds_allocating;            /* ... allocating device memory, */
+    double   seconds_waiting_for_readers;   /* waiting for a piece of a file to be read, */
+    double   seconds_waiting_for_device;    /* and waiting for the device (line counts, results) */
+    double   reader_seconds_reading;        /* summed over the reader threads: inside pread */
+    double   reader_seconds_waiting;        /* ... waiting for a staging buffer to be copied out */
 } snpgpu_pileups_stats;
 int  snpgpu_pileups_create(snpgpu_ctx *ctx, uint64_t budget_bytes, snpgpu_pileups **out);
 void snpgpu_pileups_destroy(snpgpu_pileups *store);

@@ -1020,14 +1020,14 @@ int snpgpu_call_consensus_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const v
                               snpgpu_site_counts *d_out_counts, uint64_t *d_status, int want_depth_sum) {
     if (!ctx || !ss || !params || !d_status || (nbytes && !d_pileup)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
     if (ss->n_sites && (!d_out_base || !d_out_filters)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     return enqueue_sample(ctx, ss, (const uint8_t *)d_pileup, nbytes, params, d_out_base, d_out_filters, d_out_counts, d_status, want_depth_sum);
 }
 
 int snpgpu_siteset_line_offsets(snpgpu_ctx *ctx, const snpgpu_siteset *ss, uint64_t *out_line_off) {
     if (!ctx || !ss || (ss->n_sites && !out_line_off)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
     if (!ss->n_sites) return SNPGPU_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     HIP_TRY(ctx, hipMemcpyAsync(out_line_off, ss->site_line, 8ull * ss->n_sites, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SNPGPU_OK;
@@ -1038,7 +1038,7 @@ int snpgpu_call_consensus_batch_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, c
                                     const snpgpu_caller_params *params, uint8_t *d_out_base,
                                     uint8_t *d_out_filters, uint64_t *d_status) {
     if (!ctx || !ss || !params || !d_status || !h_offsets) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     const uint8_t *p = (const uint8_t *)d_pileups;
     if (!h_sizes)
         for (uint32_t i = 0; i < n_samples; ++i)
@@ -1073,7 +1073,7 @@ int snpgpu_call_consensus_many_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, co
                                    uint64_t *d_out_line_off, uint64_t *d_status, int want_depth_sum) {
     if (!ctx || !ss || !params || !d_status || (n_samples && (!d_pileups || !h_sizes))) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
     if (ss->n_sites && n_samples && (!d_out_base || !d_out_filters)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     uint32_t group = SNPGPU_SCAN_MAX_BATCH;
     if (ss->n_sites) {                                          // per group in scratch: two leftover lists (+ the rows when not given)
         const uint64_t by_mem = (1ull << 30) / (8ull * ss->n_sites);

@@ -188,7 +188,7 @@ int snpgpu_siteset_create(snpgpu_ctx *ctx, const uint8_t *contig_names, const ui
     *out = nullptr;
     if (n_contigs && (!contig_names || !contig_name_off)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "contig table missing");
     if (n_sites && (!site_keys || !site_flags)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "site arrays missing");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     // validate ordering: names sorted + unique, keys strictly increasing, contig ids in range
     for (uint32_t c = 1; c < n_contigs; ++c) {
         uint32_t a0 = contig_name_off[c - 1], a1 = contig_name_off[c], b1 = contig_name_off[c + 1];

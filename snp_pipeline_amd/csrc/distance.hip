@@ -182,7 +182,7 @@ int snpgpu_pack_matrix_dev(snpgpu_ctx *ctx, const uint8_t *d_symbols, uint32_t n
     if (!ctx) return SNPGPU_E_ARG;
     if (n_rows == 0 || n_sites == 0) return SNPGPU_OK;
     if (!d_symbols || !d_packed || row_stride < n_sites) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "bad pack arguments");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     uint32_t words = padded_words(n_sites);                 // the padding words come out all zero (no valid site)
     uint64_t groups = (uint64_t)n_rows * ((words + 1) / 2);
     uint64_t blocks = (groups + 3) / 4, cap = (uint64_t)ctx->n_cu * 32;
@@ -197,7 +197,7 @@ int snpgpu_distance_packed_dev(snpgpu_ctx *ctx, const void *d_packed, uint32_t n
     if (tile_nranks == 0 || tile_rank >= tile_nranks) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "bad tile rank %u of %u", tile_rank, tile_nranks);
     if (n_rows == 0) return SNPGPU_OK;
     if (!d_out || (n_sites && !d_packed)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null distance argument");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     DistArgs a;
     a.packed = (const uint4 *)d_packed;
     a.n = n_rows;
@@ -238,7 +238,7 @@ int snpgpu_distance(snpgpu_ctx *ctx, const uint8_t *symbols, uint32_t n_rows, ui
     if (!ctx) return SNPGPU_E_ARG;
     if (n_rows == 0) return SNPGPU_OK;
     if (!out || (n_sites && !symbols)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null distance argument");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     size_t sym_bytes = (size_t)n_rows * n_sites;
     size_t o_pack = (sym_bytes + 255) / 256 * 256;
     size_t pack_bytes = snpgpu_packed_row_bytes(n_sites) * n_rows;

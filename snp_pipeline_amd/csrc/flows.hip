@@ -53,7 +53,7 @@ extern "C" int snpgpu_region_flow_dev(snpgpu_ctx *ctx, const uint8_t *d_base, co
     if (n_sites && (!d_base || !d_filters || !d_line_off || !d_out_filters || !d_col_of)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
     if (n_cols && (!d_cols || !d_out_base)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
     if (!d_excl_off || !d_err) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     hipStream_t st = ctx->stream;
     if (n_sites) HIP_TRY(ctx, hipMemcpyAsync(d_out_filters, d_filters, (size_t)n_samples * n_sites, hipMemcpyDeviceToDevice, st));
     if (n_cols) {

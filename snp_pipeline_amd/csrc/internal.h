@@ -50,6 +50,8 @@ struct snpgpu_pileups {
     std::vector<Entry> files;           // in the order they were ingested
     uint64_t h2d_bytes = 0;             // every byte copied host -> device through this store
     uint64_t file_bytes = 0;            // sizes of the files that were ingested
+    double seconds = 0, seconds_allocating = 0, seconds_waiting_for_readers = 0, seconds_waiting_for_device = 0;   // summed over the ingest calls
+    double reader_seconds_reading = 0, reader_seconds_waiting = 0;
 };
 
 // Device-side view of a site set.
@@ -138,6 +140,14 @@ int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleD
 #define SNPGPU_SCAN_MAX_BATCH 256   // samples per scan launch (each gets at least ~16 of the 4096 waves)
 
 int snpgpu_set_error(snpgpu_ctx *ctx, int code, const char *fmt, ...);
+// Start of an entry point: make the context's device current and drop whatever error an EARLIER runtime call of this thread left
+// behind — other users of the HIP runtime in the process (torch probes devices and pointers) leave sticky errors that the launch
+// checks (hipGetLastError after a kernel launch) would otherwise report as ours.
+static inline hipError_t snpgpu_enter(snpgpu_ctx *ctx) {
+    const hipError_t e = hipSetDevice(ctx->device);
+    (void)hipGetLastError();
+    return e;
+}
 int snpgpu_scratch(snpgpu_ctx *ctx, size_t bytes, void **out);
 
 #define HIP_TRY(ctx, expr)                                                                              \

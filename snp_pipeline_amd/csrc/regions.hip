@@ -314,7 +314,7 @@ int snpgpu_dense_windows_dev(snpgpu_ctx *ctx, const int64_t *d_positions, const 
     if ((uint64_t)n_pos * n_rules > 0x7FFFFFFFull) return snpgpu_set_error(ctx, SNPGPU_E_UNSUPPORTED, "too many (position, rule) pairs");
     if (n_segs >= (1u << 24)) return snpgpu_set_error(ctx, SNPGPU_E_UNSUPPORTED, "too many segments");
     if (n_pos && (!d_positions || !d_seg_off || !d_out_start || !d_out_end || !d_out_seg)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null dense-window argument");
-    R_TRY(ctx, hipSetDevice(ctx->device));
+    R_TRY(ctx, snpgpu_enter(ctx));
     void *ws = nullptr;
     rc = snpgpu_scratch(ctx, dense_ws_bytes(n_pos, n_rules), &ws);
     if (rc) return rc;
@@ -325,7 +325,7 @@ int snpgpu_merge_regions_dev(snpgpu_ctx *ctx, const uint32_t *d_group, const int
                              uint32_t *d_out_group, int64_t *d_out_start, int64_t *d_out_end, uint32_t *d_out_n) {
     if (!ctx || !d_out_n) return SNPGPU_E_ARG;
     if (n && (!d_group || !d_start || !d_end || !d_out_group || !d_out_start || !d_out_end)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null merge argument");
-    R_TRY(ctx, hipSetDevice(ctx->device));
+    R_TRY(ctx, snpgpu_enter(ctx));
     void *ws = nullptr;
     int rc = snpgpu_scratch(ctx, merge_regions_ws_bytes(n), &ws);
     if (rc) return rc;
@@ -338,7 +338,7 @@ int snpgpu_in_regions_dev(snpgpu_ctx *ctx, const uint32_t *d_pos_group, const in
     if (!ctx) return SNPGPU_E_ARG;
     if (n_pos == 0) return SNPGPU_OK;
     if (!d_pos_group || !d_positions || !d_out_flag || (n_groups && !d_reg_off)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null in_regions argument");
-    R_TRY(ctx, hipSetDevice(ctx->device));
+    R_TRY(ctx, snpgpu_enter(ctx));
     k_in_regions<<<nblk(n_pos), 256, 0, ctx->stream>>>(d_pos_group, d_positions, n_pos, d_reg_off, d_reg_start, d_reg_end, n_groups, d_out_flag);
     R_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;
@@ -349,7 +349,7 @@ int snpgpu_merge_sites_dev(snpgpu_ctx *ctx, const uint64_t *d_keys, const uint32
     if (!ctx || !d_out_n || !d_out_off) return SNPGPU_E_ARG;
     if (n > 0x7FFFFFFFu) return snpgpu_set_error(ctx, SNPGPU_E_UNSUPPORTED, "too many site records");
     if (n && (!d_keys || !d_sample_of_key || !d_out_unique || !d_out_carrier)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null merge_sites argument");
-    R_TRY(ctx, hipSetDevice(ctx->device));
+    R_TRY(ctx, snpgpu_enter(ctx));
     void *ws = nullptr;
     int rc = snpgpu_scratch(ctx, merge_sites_ws_bytes(n), &ws);
     if (rc) return rc;
@@ -373,7 +373,7 @@ int snpgpu_dense_windows(snpgpu_ctx *ctx, const int64_t *positions, const uint32
     const uint64_t total = (uint64_t)n_pos * n_rules;
     if (total > 0x7FFFFFFFull) return snpgpu_set_error(ctx, SNPGPU_E_UNSUPPORTED, "too many (position, rule) pairs");
     if (n_segs >= (1u << 24)) return snpgpu_set_error(ctx, SNPGPU_E_UNSUPPORTED, "too many segments");
-    R_TRY(ctx, hipSetDevice(ctx->device));
+    R_TRY(ctx, snpgpu_enter(ctx));
     hipStream_t st = ctx->stream;
     size_t o = 0;
     const size_t o_pos = o; o += up256(8ull * n_pos);
@@ -412,7 +412,7 @@ int snpgpu_merge_regions(snpgpu_ctx *ctx, const uint32_t *group, const int64_t *
     *out_n = 0;
     if (n == 0) return SNPGPU_OK;
     if (!group || !start || !end || !out_group || !out_start || !out_end) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null merge argument");
-    R_TRY(ctx, hipSetDevice(ctx->device));
+    R_TRY(ctx, snpgpu_enter(ctx));
     hipStream_t st = ctx->stream;
     size_t o = 0;
     const size_t o_g = o; o += up256(4ull * n);
@@ -451,7 +451,7 @@ int snpgpu_in_regions(snpgpu_ctx *ctx, const uint32_t *pos_group, const int64_t 
     if (!ctx) return SNPGPU_E_ARG;
     if (n_pos == 0) return SNPGPU_OK;
     if (!pos_group || !positions || !out_flag || (n_groups && !reg_off)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null in_regions argument");
-    R_TRY(ctx, hipSetDevice(ctx->device));
+    R_TRY(ctx, snpgpu_enter(ctx));
     hipStream_t st = ctx->stream;
     const uint32_t n_reg = n_groups ? reg_off[n_groups] : 0;
     size_t o = 0;
@@ -488,7 +488,7 @@ int snpgpu_merge_sites(snpgpu_ctx *ctx, const uint64_t *keys, const uint32_t *sa
     if (n == 0) return SNPGPU_OK;
     if (n > 0x7FFFFFFFull) return snpgpu_set_error(ctx, SNPGPU_E_UNSUPPORTED, "too many site records");
     if (!keys || !sample_of_key || !out_unique || !out_off || !out_carrier) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null merge_sites argument");
-    R_TRY(ctx, hipSetDevice(ctx->device));
+    R_TRY(ctx, snpgpu_enter(ctx));
     hipStream_t st = ctx->stream;
     const uint32_t m = (uint32_t)n;
     size_t o = 0;

@@ -20,6 +20,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <sched.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -27,6 +28,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -207,6 +209,7 @@ struct Shared {
     std::atomic<uint64_t> ns_reading{0}, ns_waiting{0};   // summed over the readers
     bool abort = false;
     std::atomic<uint64_t> next{0};
+    uint64_t base = 0;              // the ring serves jobs [base, ...): job j uses staging[(j - base) % R]
 };
 
 void reader_main(snpgpu_ctx *ctx, Shared *sh, const std::vector<Job> *jobs, std::vector<Source> *src) {
@@ -218,13 +221,14 @@ void reader_main(snpgpu_ctx *ctx, Shared *sh, const std::vector<Job> *jobs, std:
         if (j >= jobs->size()) return;
         const Job &jb = (*jobs)[j];
         const double t_w = now_s();
-        if (j >= R) {                                       // staging[j % R] is free once job j - R has been copied out of it
+        const uint64_t k = j - sh->base;                    // place in the ring
+        if (k >= R) {                                       // staging[k % R] is free once the job R places before has been copied out of it
             std::unique_lock<std::mutex> lk(sh->mu);         // (the issuing thread watches the copy events: readers never call HIP)
-            sh->cv.wait(lk, [&] { return sh->abort || sh->freed > (int64_t)(j - R); });
+            sh->cv.wait(lk, [&] { return sh->abort || sh->freed > (int64_t)(k - R); });
             if (sh->abort) return;
         }
         const double t_r = now_s();
-        uint8_t *dst = (uint8_t *)p->staging[j % R];
+        uint8_t *dst = (uint8_t *)p->staging[k % R];
         Source &s = (*src)[jb.file];
         int err = 0;
         if (s.mem) {
@@ -283,7 +287,7 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
                 if (excl_slots[k] >= n_sites) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "exclude slot %u of file %u is not in the site set", excl_slots[k], f);
         }
     }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     size_t chunk = opts && opts->chunk_bytes ? opts->chunk_bytes : (size_t)16 << 20;
     chunk = up(chunk < 65536 ? 65536 : chunk, SNPGPU_SCAN_TILE);
     const int want_depth = opts && opts->want_depth_sum ? 1 : 0;
@@ -696,7 +700,7 @@ int snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const 
                                snpgpu_site_counts *out_counts, uint64_t *out_status) {
     if (!ctx || !ss || !path || !params || !out_n_lines || !out_status) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
     if (capacity && (!out_line_off || !out_line_flags || !out_counts)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     uint8_t *d_file = nullptr;
     uint64_t nbytes = 0;
     int rc = load_file(ctx, path, &d_file, &nbytes);
@@ -811,22 +815,81 @@ int varscan_resident(snpgpu_ctx *ctx, const uint8_t *d_file, uint64_t nbytes, co
 }
 
 // Device memory for the files of one ingest call that are to stay resident: whole files, 256-byte aligned, bump-allocated out
-// of blocks of at most `block_cap` bytes (a block is allocated right before the first copy into it: one huge allocation up
-// front would delay the first byte by its page-table set-up).  Files past the budget stay non-resident (d == nullptr).
+// of blocks of at most `block_cap` bytes (a block is allocated right before the first copy into it).  Files are placed in
+// order while the budget lasts; from the first one that does not fit on, they stay non-resident.
 struct Placement { uint32_t block; uint64_t off; };
 const uint64_t PILEUP_BLOCK_CAP = 8ull << 30;
 const uint64_t PILEUP_TAIL_PAD = SNPGPU_SCAN_TILE + 512;       // the scan reads whole tiles (+ halo) past a file's last byte
 
-// Phase-1 site calling over many pileup files: the readers run ahead across file boundaries (one job list, one staging
-// ring, as in run_stream), and a file's kernels and result copy run on the compute stream while the next file is being read
-// and copied.  Without a store the files alternate between two device slots; with one, a file goes to resident memory while
-// the store's budget lasts (entry store->files[first + f]) and only the overflow uses the slots.  params == nullptr: no site
-// calling, the files are only made resident.  out_done (nullable): out_done[f] becomes 1 when the outputs of file f are final,
-// so that another thread can start on them while the call is still running.
+// What the readers and the issuing thread share when pieces may be copied in ANY order (resident files: every piece has its
+// own place in device memory, so nobody has to wait for the slowest read — with the in-order ring one slow pread stalls the
+// copy engine and, a few pieces later, every other reader).
+struct AnyOrder {
+    std::mutex mu;
+    std::condition_variable cv_free, cv_ready;
+    std::vector<uint32_t> free_bufs;
+    struct Ready { uint64_t job; int32_t buf; int err; };
+    std::deque<Ready> ready;
+    bool abort = false;
+    std::atomic<uint64_t> next{0};
+    uint64_t n_jobs = 0;
+    std::atomic<uint64_t> ns_reading{0}, ns_waiting{0};
+};
+
+void reader_any_order(snpgpu_ctx *ctx, AnyOrder *sh, const std::vector<Job> *jobs, std::vector<Source> *src) {
+    snpgpu_stream_pool *p = ctx->pool;
+    if (p->have_near_cpus) (void)sched_setaffinity(0, sizeof p->near_cpus, &p->near_cpus);
+    for (;;) {
+        const uint64_t j = sh->next.fetch_add(1);
+        if (j >= sh->n_jobs) return;
+        const Job &jb = (*jobs)[j];
+        Source &s = (*src)[jb.file];
+        int32_t buf = -1;
+        int err = 0;
+        if (jb.len) {
+            const double t_w = now_s();
+            {
+                std::unique_lock<std::mutex> lk(sh->mu);
+                sh->cv_free.wait(lk, [&] { return sh->abort || !sh->free_bufs.empty(); });
+                if (sh->abort) return;
+                buf = (int32_t)sh->free_bufs.back();
+                sh->free_bufs.pop_back();
+            }
+            const double t_r = now_s();
+            uint8_t *dst = (uint8_t *)p->staging[buf];
+            if (s.fd >= 0) {
+                uint64_t got = 0;
+                while (got < jb.len) {
+                    ssize_t r = pread(s.fd, dst + got, jb.len - got, (off_t)(jb.off + got));
+                    if (r < 0) { if (errno == EINTR) continue; err = errno ? errno : EIO; break; }
+                    if (r == 0) { err = EIO; break; }
+                    got += (uint64_t)r;
+                }
+                if (err) memset(dst + got, '\n', jb.len - got);
+            } else {
+                memset(dst, '\n', jb.len);
+            }
+            sh->ns_waiting.fetch_add((uint64_t)((t_r - t_w) * 1e9));
+            sh->ns_reading.fetch_add((uint64_t)((now_s() - t_r) * 1e9));
+        }
+        {
+            std::lock_guard<std::mutex> lk(sh->mu);
+            sh->ready.push_back(AnyOrder::Ready{j, buf, err});
+        }
+        sh->cv_ready.notify_one();
+    }
+}
+
+// Phase-1 site calling over many pileup files: the readers run ahead across file boundaries, and a file's kernels and result
+// copy run on the compute stream while the next files are being read and copied.  Without a store the files alternate between
+// two device slots and their pieces are copied in file order; with one, files go to resident memory while the store's budget
+// lasts (entry store->files[first + f]), their pieces copied in whatever order the reads finish, and only the files past the
+// budget use the slots.  params == nullptr: no site calling, the files are only made resident.  out_done (nullable): out_done[f]
+// becomes 1 when the outputs of file f are final, so that another thread can start on them while the call is still running.
 int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, const snpgpu_varscan_params *params, uint32_t capacity,
                    snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status, int32_t *out_rc, snpgpu_pileups *store,
                    int32_t *out_done) {
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     const size_t chunk = (size_t)16 << 20;
     std::vector<Source> src(n_files);
     uint64_t max_slot_size = 0;
@@ -834,6 +897,8 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
     if (store) store->files.resize(first + n_files);
     std::vector<Placement> place(n_files, Placement{~0u, 0});
     std::vector<uint64_t> block_bytes;                          // blocks of this call
+    uint32_t n_prefix = 0;                                      // files [0, n_prefix) are resident (or have nothing to copy)
+    bool budget_left = store != nullptr;
     for (uint32_t f = 0; f < n_files; ++f) {
         Source &s = src[f];
         s.path = paths[f];
@@ -848,16 +913,19 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
             (void)posix_fadvise(s.fd, 0, 0, POSIX_FADV_SEQUENTIAL);
         }
         bool resident = false;
-        if (store && s.rc == SNPGPU_OK) {
+        if (budget_left && s.rc == SNPGPU_OK) {
             const uint64_t need = up(s.size + 1, 256);
             if (store->used + need + PILEUP_TAIL_PAD <= store->budget) {
-                if (block_bytes.empty() || block_bytes.back() + need + PILEUP_TAIL_PAD > PILEUP_BLOCK_CAP) block_bytes.push_back(0);
+                if (block_bytes.empty() || block_bytes.back() + need + PILEUP_TAIL_PAD > PILEUP_BLOCK_CAP) { block_bytes.push_back(0); store->used += PILEUP_TAIL_PAD; }
                 place[f] = Placement{(uint32_t)(block_bytes.size() - 1), block_bytes.back()};
                 block_bytes.back() += need;
                 store->used += need;
                 resident = true;
+            } else {
+                budget_left = false;
             }
         }
+        if (store && n_prefix == f && (resident || s.rc != SNPGPU_OK || s.size == 0)) n_prefix = f + 1;
         if (store) {
             store->files[first + f].nbytes = s.size;
             store->files[first + f].resident = resident;
@@ -868,32 +936,42 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
         out_status[2 * f] = ~0ull; out_status[2 * f + 1] = 0;
         if (out_done) out_done[f] = 0;
     }
-    if (store) for (auto &b : block_bytes) { b += PILEUP_TAIL_PAD; store->used += PILEUP_TAIL_PAD; }
+    for (auto &b : block_bytes) b += PILEUP_TAIL_PAD;
     std::vector<uint8_t *> block_ptr(block_bytes.size(), nullptr);
     std::vector<Job> jobs;
+    std::vector<uint32_t> chunks_left(n_files, 0);
+    uint64_t JA = 0;                                            // jobs [0, JA): files of the prefix; [JA, J): the rest, in file order
     for (uint32_t f = 0; f < n_files; ++f) {
         const uint64_t n = src[f].size;
-        if (n == 0) { jobs.push_back(Job{f, 0, 0, true, true, 0}); continue; }
+        if (f == n_prefix) JA = jobs.size();
+        if (n == 0) { jobs.push_back(Job{f, 0, 0, true, true, 0}); chunks_left[f] = 1; continue; }
         for (uint64_t off = 0, c = 0; off < n; ++c) {
             // the very first pieces are small, so that the first copy starts after ~1 MiB has been read
             const uint64_t want = f == 0 && c < 5 ? (c < 2 ? (uint64_t)1 << 20 : (uint64_t)1 << (18 + c)) : chunk;
             const uint64_t len = n - off < want ? n - off : want;
             jobs.push_back(Job{f, off, len, c == 0, off + len >= n, (uint32_t)c});
+            ++chunks_left[f];
             off += len;
         }
     }
     const uint64_t J = jobs.size();
+    if (n_prefix == n_files) JA = J;
     unsigned hc = std::thread::hardware_concurrency();
     uint32_t n_readers = hc >= 32 ? 8 : (hc >= 8 ? hc / 2 : (hc > 1 ? hc - 1 : 1));
+    uint32_t extra_staging = 4;
+#ifdef SNPGPU_TUNING                                            // development builds only (tools/)
+    if (const char *e = getenv("SNPGPU_INGEST_READERS")) if (atoi(e) > 0) n_readers = (uint32_t)atoi(e);
+    if (const char *e = getenv("SNPGPU_INGEST_EXTRA_STAGING")) if (atoi(e) >= 0) extra_staging = (uint32_t)atoi(e);
+#endif
     if (n_readers > J) n_readers = (uint32_t)J;
-    uint32_t n_staging = n_readers + 4;
+    uint32_t n_staging = n_readers + extra_staging;
     if (n_staging > J) n_staging = (uint32_t)J;
+    if (n_staging < 1) n_staging = 1;
     const size_t r_rec = 256;                                  // result block: [0] u64 status, [8] u32 records found, [48] u32 lines; records at 256
     const size_t result_bytes = r_rec + sizeof(snpgpu_varscan_site) * (size_t)capacity + 256;
     auto close_all = [&]() { for (auto &s2 : src) if (s2.fd >= 0) { close(s2.fd); s2.fd = -1; } };
-    const uint32_t n_slots = n_files > 1 ? 2 : 1;              // result blocks / scratch halves alternate between files
-    bool any_slot = false;
-    for (uint32_t f = 0; f < n_files; ++f) if (place[f].block == ~0u) any_slot = true;
+    const uint32_t n_slots = n_files > 1 ? 2 : 1;              // result blocks / scratch halves (/ device slots) alternate between files
+    const bool any_slot = n_prefix < n_files;
     int rc = pool_ensure(ctx, chunk, n_staging, any_slot ? n_slots : 0, any_slot ? up(max_slot_size + SNPGPU_SCAN_TILE + 256, 4096) : 0,
                          result_bytes, 256, n_slots);
     if (rc) { close_all(); return rc; }
@@ -904,31 +982,27 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
         hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess) { close_all(); return snpgpu_set_error(ctx, SNPGPU_E_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e)); }
     }
-    // where file f lives on the device (a resident file's block is allocated when its first piece is about to be copied)
+    // Files are post-processed in the order in which they become complete ("sequence numbers"); result blocks, scratch halves
+    // and device slots alternate by sequence number.
+    std::vector<int64_t> seq_of(n_files, -1);
+    std::vector<uint32_t> file_of;
+    file_of.reserve(n_files);
     auto dest = [&](uint32_t f) -> uint8_t * {
-        if (place[f].block == ~0u) return (uint8_t *)p->slot[f % n_slots];
+        if (place[f].block == ~0u) return (uint8_t *)p->slot[(uint32_t)seq_of[f] % n_slots];
         return block_ptr[place[f].block] + place[f].off;
     };
-    Shared sh;
-    sh.R = R ? R : 1;
-    sh.filled.assign(J, 0);
-    sh.job_err.assign(J, 0);
-    std::vector<std::thread> readers;
-    try {
-        for (uint32_t i = 0; i < n_readers; ++i) readers.emplace_back(reader_main, ctx, &sh, &jobs, &src);
-    } catch (const std::exception &e) {
-        { std::lock_guard<std::mutex> lk(sh.mu); sh.abort = true; sh.next.store(J); }
-        sh.cv.notify_all();
-        for (auto &t : readers) t.join();
-        close_all();
-        return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "cannot start the reader threads: %s", e.what());
-    }
-    std::vector<uint8_t> has_result(n_files, 0);
+    std::vector<uint8_t> has_result(n_files, 0), completed(n_files, 0);   // by sequence number
+    const double t_begin = now_s();
+    double t_alloc = 0, t_read_wait = 0, t_dev_wait = 0;
+    uint64_t ns_reading = 0, ns_waiting = 0;
     auto publish = [&](uint32_t f) { if (out_done) __atomic_store_n(&out_done[f], 1, __ATOMIC_RELEASE); };
-    auto harvest = [&](uint32_t f) -> int {                     // results of file f: pinned block -> the caller's arrays
-        if (!has_result[f]) { out_rc[f] = src[f].rc; publish(f); return SNPGPU_OK; }
-        const uint32_t slot = f % n_slots;
+    auto harvest = [&](uint32_t c) -> int {                     // results of the c-th completed file: pinned block -> the caller's arrays
+        const uint32_t f = file_of[c];
+        if (!has_result[c]) { out_rc[f] = src[f].rc; publish(f); return SNPGPU_OK; }
+        const uint32_t slot = c % n_slots;
+        const double tw = now_s();
         hipError_t e = hipEventSynchronize(p->ev_done[slot]);
+        t_dev_wait += now_s() - tw;
         if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_HIP, "waiting for the results of pileup %u failed: %s", f, hipGetErrorString(e));
         const char *r = (const char *)p->result[slot];
         uint64_t status;
@@ -953,21 +1027,15 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
     hipEvent_t ev_count = nullptr;
     {
         hipError_t e = hipEventCreateWithFlags(&ev_count, hipEventDisableTiming);
-        if (e != hipSuccess) {
-            { std::lock_guard<std::mutex> lk(sh.mu); sh.abort = true; sh.next.store(J); }
-            sh.cv.notify_all();
-            for (auto &t : readers) t.join();
-            close_all();
-            return snpgpu_set_error(ctx, SNPGPU_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
-        }
+        if (e != hipSuccess) { close_all(); return snpgpu_set_error(ctx, SNPGPU_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }
     }
 #define VS_RET(expr)                                                                                                \
     do {                                                                                                            \
         hipError_t e_ = (expr);                                                                                     \
         if (e_ != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
-    auto post_begin = [&](uint32_t f) -> int {                  // count the lines; the count travels to the slot's pinned block
-        const uint32_t slot = f % n_slots;
+    auto post_begin = [&](uint32_t c) -> int {                  // count the lines; the count travels to the slot's pinned block
+        const uint32_t f = file_of[c], slot = c % n_slots;
         const uint64_t nbytes = src[f].size;
         void *scr = nullptr;
         int r = snpgpu_scratch(ctx, 2 * (up(4 * snpgpu_lines_workspace_words(nbytes), 256) + 512), &scr);
@@ -980,12 +1048,16 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
         VS_RET(hipEventRecord(ev_count, st));
         return SNPGPU_OK;
     };
-    auto post_finish = [&](uint32_t f) -> int {                 // index the lines, walk them, results into the slot's pinned block
-        const uint32_t slot = f % n_slots;
+    auto post_finish = [&](uint32_t c) -> int {                 // index the lines, walk them, results into the slot's pinned block
+        const uint32_t f = file_of[c], slot = c % n_slots;
         const uint64_t nbytes = src[f].size;
         const uint8_t *d_file = dest(f);
         char *res = (char *)p->result[slot];
-        VS_RET(hipEventSynchronize(ev_count));
+        {
+            const double tw = now_s();
+            VS_RET(hipEventSynchronize(ev_count));
+            t_dev_wait += now_s() - tw;
+        }
         uint32_t n_lines = 0;
         memcpy(&n_lines, res + 48, 4);
         out_status[2 * f + 1] = n_lines;
@@ -994,7 +1066,7 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
             memcpy(res, &none, 8);
             memset(res + 8, 0, 8);
             VS_RET(hipEventRecord(p->ev_done[slot], st));
-            has_result[f] = 1;
+            has_result[c] = 1;
             return SNPGPU_OK;
         }
         const size_t ws_words = snpgpu_lines_workspace_words(nbytes);
@@ -1024,81 +1096,212 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
         VS_RET(hipMemcpyAsync(res, b + o_ctl, 16, hipMemcpyDeviceToHost, st));
         if (capacity) VS_RET(hipMemcpyAsync(res + r_rec, b + o_rec, sizeof(snpgpu_varscan_site) * (size_t)capacity, hipMemcpyDeviceToHost, st));
         VS_RET(hipEventRecord(p->ev_done[slot], st));
-        has_result[f] = 1;
+        has_result[c] = 1;
         return SNPGPU_OK;
     };
 #undef VS_RET
+    uint32_t harvested = 0;                                     // sequence numbers [0, harvested) have been copied out
+    int64_t pending = -1;                                       // a sequence number whose lines are being counted
+    // file f is complete (every piece issued): give it its sequence number (unless it has one) and start its post-processing
+    auto file_complete = [&](uint32_t f) -> int {
+        if (seq_of[f] < 0) { seq_of[f] = (int64_t)file_of.size(); file_of.push_back(f); }
+        const uint32_t c = (uint32_t)seq_of[f];
+        completed[c] = 1;
+        if (!params || src[f].rc != SNPGPU_OK || src[f].size == 0) return SNPGPU_OK;
+        int r = SNPGPU_OK;
+        while (!r && harvested + n_slots <= c) r = harvest(harvested++);
+        if (!r && pending >= 0) { r = post_finish((uint32_t)pending); pending = -1; }
+        if (!r) r = post_begin(c);
+        if (!r) pending = (int64_t)c;
+        return r;
+    };
+    // what can be done without waiting: finish the file whose line count has arrived, hand out results that are ready
+    auto opportunistic = [&]() -> int {
+        int r = SNPGPU_OK;
+        if (pending >= 0 && hipEventQuery(ev_count) != hipErrorNotReady) { r = post_finish((uint32_t)pending); pending = -1; }
+        while (!r && harvested < file_of.size() && completed[harvested] && (int64_t)harvested != pending &&
+               (!has_result[harvested] || hipEventQuery(p->ev_done[harvested % n_slots]) != hipErrorNotReady))
+            r = harvest(harvested++);
+        return r;
+    };
 #define VS_TRY(expr)                                                                                                \
     do {                                                                                                            \
         hipError_t e_ = (expr);                                                                                     \
         if (e_ != hipSuccess) { rc = snpgpu_set_error(ctx, SNPGPU_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } \
     } while (0)
     {
-        uint32_t harvested = 0;
-        int64_t copies_done = 0;
-        int64_t pending = -1;                                   // a file whose lines are being counted
-        for (uint64_t j = 0; j < J; ++j) {
-            const Job &jb = jobs[j];
-            const uint32_t f = jb.file;
-            Source &s = src[f];
-            if (pending >= 0 && hipEventQuery(ev_count) != hipErrorNotReady) { rc = post_finish((uint32_t)pending); pending = -1; if (rc) goto done; }
-            if (jb.first) {                                     // the result block (and a slot) are free once their last user has been harvested
-                if (pending >= 0 && (uint32_t)pending + n_slots <= f) { rc = post_finish((uint32_t)pending); pending = -1; if (rc) goto done; }
-                while (harvested + n_slots <= f) { rc = harvest(harvested); if (rc) goto done; ++harvested; }
+        // ---- pass A: the resident prefix, pieces copied in the order in which their reads finish -----------------------------
+        if (JA) {
+            AnyOrder sh;
+            sh.n_jobs = JA;
+            for (uint32_t i = 0; i < R; ++i) sh.free_bufs.push_back(i);
+            std::vector<std::thread> readers;
+            const uint32_t nr = n_readers < JA ? n_readers : (uint32_t)JA;
+            try {
+                for (uint32_t i = 0; i < nr; ++i) readers.emplace_back(reader_any_order, ctx, &sh, &jobs, &src);
+            } catch (const std::exception &e) {
+                { std::lock_guard<std::mutex> lk(sh.mu); sh.abort = true; sh.next.store(JA); }
+                sh.cv_free.notify_all();
+                for (auto &t : readers) t.join();
+                rc = snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "cannot start the reader threads: %s", e.what());
+                goto done;
+            }
+            std::deque<uint32_t> inflight;                      // staging buffers whose copies are on their way, in issue order per stream pair
+            uint64_t issued = 0;
+            int rcA = SNPGPU_OK;
+            while (issued < JA && !rcA) {
+                // staging buffers whose copy has finished go back to the readers
+                bool freed = false;
+                while (!inflight.empty() && hipEventQuery(p->ev_copy[inflight.front()]) != hipErrorNotReady) {
+                    std::lock_guard<std::mutex> lk(sh.mu);
+                    sh.free_bufs.push_back(inflight.front());
+                    inflight.pop_front();
+                    freed = true;
+                }
+                if (freed) sh.cv_free.notify_all();
+                rcA = opportunistic();
+                if (rcA) break;
+                AnyOrder::Ready rd{0, -1, 0};
+                bool have = false;
+                {
+                    const double tr = now_s();
+                    std::unique_lock<std::mutex> lk(sh.mu);
+                    if (sh.ready.empty())
+                        sh.cv_ready.wait_for(lk, std::chrono::microseconds(inflight.empty() && pending < 0 ? 2000 : 20), [&] { return !sh.ready.empty(); });
+                    if (!sh.ready.empty()) { rd = sh.ready.front(); sh.ready.pop_front(); have = true; }
+                    lk.unlock();
+                    t_read_wait += now_s() - tr;
+                }
+                if (!have) continue;
+                const Job &jb = jobs[rd.job];
+                const uint32_t f = jb.file;
+                Source &s = src[f];
+                if (rd.err && s.rc == SNPGPU_OK) s.rc = SNPGPU_E_IO;
                 if (place[f].block != ~0u && !block_ptr[place[f].block]) {
                     void *d = nullptr;
+                    const double ta = now_s();
                     hipError_t e = hipMalloc(&d, block_bytes[place[f].block]);
+                    t_alloc += now_s() - ta;
                     if (e != hipSuccess) {
-                        rc = snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipMalloc(%llu) for resident pileups failed: %s", (unsigned long long)block_bytes[place[f].block], hipGetErrorString(e));
-                        goto done;
+                        rcA = snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipMalloc(%llu) for resident pileups failed: %s", (unsigned long long)block_bytes[place[f].block], hipGetErrorString(e));
+                        break;
                     }
                     block_ptr[place[f].block] = (uint8_t *)d;
                     store->blocks.push_back(d);
                 }
-                if (store && place[f].block != ~0u) store->files[first + f].d = dest(f);
+                if (place[f].block != ~0u) store->files[first + f].d = dest(f);
+                if (jb.len) {
+                    hipStream_t cs = (issued & 1) ? p->copy_stream2 : p->copy_stream;
+                    hipError_t e = hipMemcpyAsync(dest(f) + jb.off, p->staging[rd.buf], jb.len, hipMemcpyHostToDevice, cs);
+                    if (e == hipSuccess) e = hipEventRecord(p->ev_copy[rd.buf], cs);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(st, p->ev_copy[rd.buf], 0);
+                    if (e != hipSuccess) { rcA = snpgpu_set_error(ctx, SNPGPU_E_HIP, "copying a piece of %s failed: %s", s.path, hipGetErrorString(e)); break; }
+                    store->h2d_bytes += jb.len;
+                    // (the two copy streams finish their copies in their own order: a buffer is retired when the one at the head of
+                    // the queue is — at most one copy later than it could be)
+                    inflight.push_back((uint32_t)rd.buf);
+                }
+                ++issued;
+                if (--chunks_left[f] == 0) rcA = file_complete(f);
             }
-            uint8_t *d_file = dest(f);
-            for (;;) {                                          // wait for the piece to be read; retire finished copies meanwhile
-                bool progress = false;
-                while (copies_done < (int64_t)j && hipEventQuery(p->ev_copy[copies_done % R]) != hipErrorNotReady) { ++copies_done; progress = true; }
-                std::unique_lock<std::mutex> lk(sh.mu);
-                if (progress) { sh.freed = copies_done; lk.unlock(); sh.cv.notify_all(); lk.lock(); }
-                if (sh.filled[j]) break;
-                sh.cv.wait_for(lk, std::chrono::microseconds(copies_done < (int64_t)j ? 20 : 2000), [&] { return sh.filled[j] != 0; });
-                if (sh.filled[j]) break;
+            {
+                std::lock_guard<std::mutex> lk(sh.mu);
+                if (rcA) { sh.abort = true; sh.next.store(JA); }
             }
-            if (sh.job_err[j] && s.rc == SNPGPU_OK) s.rc = SNPGPU_E_IO;
-            hipStream_t cs = (j & 1) ? p->copy_stream2 : p->copy_stream;
-            if (jb.len) VS_TRY(hipMemcpyAsync(d_file + jb.off, p->staging[j % R], jb.len, hipMemcpyHostToDevice, cs));
-            if (store) store->h2d_bytes += jb.len;
-            VS_TRY(hipEventRecord(p->ev_copy[j % R], cs));
-            VS_TRY(hipStreamWaitEvent(st, p->ev_copy[j % R], 0));
-            if (!jb.last || s.rc != SNPGPU_OK || s.size == 0 || !params) continue;
-            // ---- the whole file is on its way: count its lines now, do the rest when the count has come back (the copies of
-            //      the next file are issued in the meantime: nobody waits for this file's tail) ----
-            if (pending >= 0) { rc = post_finish((uint32_t)pending); pending = -1; if (rc) goto done; }
-            rc = post_begin(f);
-            if (rc) goto done;
-            pending = (int64_t)f;
+            sh.cv_free.notify_all();
+            for (auto &t : readers) t.join();
+            ns_reading += sh.ns_reading.load();
+            ns_waiting += sh.ns_waiting.load();
+            if (rcA) { rc = rcA; goto done; }
+            // every staging buffer is free again before the in-order ring of pass B uses them
+            if (JA < J) { VS_TRY(hipStreamSynchronize(p->copy_stream)); VS_TRY(hipStreamSynchronize(p->copy_stream2)); }
+        }
+        // ---- pass B: files that go through the device slots, pieces in file order -------------------------------------------
+        if (JA < J) {
+            Shared sh;
+            sh.R = R ? R : 1;
+            sh.filled.assign(J, 0);
+            sh.job_err.assign(J, 0);
+            sh.next.store(JA);
+            sh.base = JA;
+            std::vector<std::thread> readers;
+            try {
+                for (uint32_t i = 0; i < n_readers; ++i) readers.emplace_back(reader_main, ctx, &sh, &jobs, &src);
+            } catch (const std::exception &e) {
+                { std::lock_guard<std::mutex> lk(sh.mu); sh.abort = true; sh.next.store(J); }
+                sh.cv.notify_all();
+                for (auto &t : readers) t.join();
+                rc = snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "cannot start the reader threads: %s", e.what());
+                goto done;
+            }
+            int rcB = SNPGPU_OK;
+            int64_t copies_done = (int64_t)JA;
+            for (uint64_t j = JA; j < J && !rcB; ++j) {
+                const Job &jb = jobs[j];
+                const uint32_t f = jb.file;
+                Source &s = src[f];
+                rcB = opportunistic();
+                if (rcB) break;
+                if (jb.first) {                                 // a sequence number now: its slot is where the pieces go
+                    seq_of[f] = (int64_t)file_of.size();
+                    file_of.push_back(f);
+                    const uint32_t c = (uint32_t)seq_of[f];
+                    if (pending >= 0 && (uint32_t)pending + n_slots <= c) { rcB = post_finish((uint32_t)pending); pending = -1; }
+                    while (!rcB && harvested + n_slots <= c) rcB = harvest(harvested++);
+                    if (rcB) break;
+                }
+                uint8_t *d_file = dest(f);
+                const double tr = now_s();
+                for (;;) {                                      // wait for the piece to be read; retire finished copies meanwhile
+                    bool progress = false;
+                    while (copies_done < (int64_t)j && hipEventQuery(p->ev_copy[(copies_done - JA) % R]) != hipErrorNotReady) { ++copies_done; progress = true; }
+                    std::unique_lock<std::mutex> lk(sh.mu);
+                    if (progress) { sh.freed = copies_done - (int64_t)JA; lk.unlock(); sh.cv.notify_all(); lk.lock(); }
+                    if (sh.filled[j]) break;
+                    sh.cv.wait_for(lk, std::chrono::microseconds(copies_done < (int64_t)j ? 20 : 2000), [&] { return sh.filled[j] != 0; });
+                    if (sh.filled[j]) break;
+                }
+                t_read_wait += now_s() - tr;
+                if (sh.job_err[j] && s.rc == SNPGPU_OK) s.rc = SNPGPU_E_IO;
+                hipStream_t cs = (j & 1) ? p->copy_stream2 : p->copy_stream;
+                hipError_t e = hipSuccess;
+                if (jb.len) e = hipMemcpyAsync(d_file + jb.off, p->staging[(j - JA) % R], jb.len, hipMemcpyHostToDevice, cs);
+                if (store) store->h2d_bytes += jb.len;
+                if (e == hipSuccess) e = hipEventRecord(p->ev_copy[(j - JA) % R], cs);
+                if (e == hipSuccess) e = hipStreamWaitEvent(st, p->ev_copy[(j - JA) % R], 0);
+                if (e != hipSuccess) { rcB = snpgpu_set_error(ctx, SNPGPU_E_HIP, "copying a piece of %s failed: %s", s.path, hipGetErrorString(e)); break; }
+                if (jb.last) rcB = file_complete(f);
+            }
+            {
+                std::lock_guard<std::mutex> lk(sh.mu);
+                if (rcB) { sh.abort = true; sh.next.store(J); }
+            }
+            sh.cv.notify_all();
+            for (auto &t : readers) t.join();
+            ns_reading += sh.ns_reading.load();
+            ns_waiting += sh.ns_waiting.load();
+            if (rcB) { rc = rcB; goto done; }
         }
         if (pending >= 0) { rc = post_finish((uint32_t)pending); pending = -1; if (rc) goto done; }
-        while (harvested < n_files) { rc = harvest(harvested); if (rc) goto done; ++harvested; }
+        while (harvested < file_of.size()) { rc = harvest(harvested++); if (rc) goto done; }
     }
 done:
 #undef VS_TRY
-    {
-        std::lock_guard<std::mutex> lk(sh.mu);
-        if (rc) { sh.abort = true; sh.next.store(J); }
-    }
-    sh.cv.notify_all();
-    for (auto &t : readers) t.join();
     {   // every copy has landed before the caller looks at resident memory (or reuses a slot)
-        hipError_t e1 = hipStreamSynchronize(p->copy_stream), e2 = hipStreamSynchronize(p->copy_stream2), e3 = rc ? hipStreamSynchronize(st) : hipSuccess;
+        hipError_t e1 = hipStreamSynchronize(p->copy_stream), e2 = hipStreamSynchronize(p->copy_stream2);
+        if (rc) (void)hipStreamSynchronize(st);
         if (!rc && (e1 != hipSuccess || e2 != hipSuccess)) rc = snpgpu_set_error(ctx, SNPGPU_E_HIP, "pileup copies failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-        (void)e3;
     }
     close_all();
     if (ev_count) (void)hipEventDestroy(ev_count);
+    if (store) {
+        store->seconds += now_s() - t_begin;
+        store->seconds_allocating += t_alloc;
+        store->seconds_waiting_for_readers += t_read_wait;
+        store->seconds_waiting_for_device += t_dev_wait;
+        store->reader_seconds_reading += ns_reading * 1e-9;
+        store->reader_seconds_waiting += ns_waiting * 1e-9;
+    }
     for (uint32_t f = 0; f < n_files; ++f) {
         out_rc[f] = src[f].rc;
         if (store && (src[f].rc == SNPGPU_E_IO || (place[f].block != ~0u && !block_ptr[place[f].block])))
@@ -1116,7 +1319,7 @@ int snpgpu_varscan_file(snpgpu_ctx *ctx, const char *path, const snpgpu_varscan_
                         snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status) {
     if (!ctx || !path || !params || !out_n_sites || !out_status) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
     if (capacity && !out_sites) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     uint8_t *d_file = nullptr;
     uint64_t nbytes = 0;
     int rc = load_file(ctx, path, &d_file, &nbytes);
@@ -1129,7 +1332,7 @@ int snpgpu_varscan_dev(snpgpu_ctx *ctx, const void *d_pileup, uint64_t nbytes, c
                        snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status) {
     if (!ctx || !params || !out_n_sites || !out_status || (nbytes && !d_pileup)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
     if (capacity && !out_sites) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     return varscan_resident(ctx, (const uint8_t *)d_pileup, nbytes, "the resident pileup", params, capacity, out_sites, out_n_sites, out_status);
 }
 
@@ -1145,7 +1348,7 @@ int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_f
 int snpgpu_pileups_create(snpgpu_ctx *ctx, uint64_t budget_bytes, snpgpu_pileups **out) {
     if (!ctx || !out) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
     *out = nullptr;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     if (!budget_bytes) {                                        // what is free now, less room for the outputs of the later steps
         size_t free_b = 0, total_b = 0;
         HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -1197,6 +1400,12 @@ int snpgpu_pileups_get_stats(const snpgpu_pileups *store, snpgpu_pileups_stats *
     out->budget_bytes = store->budget;
     out->n_files = (uint32_t)store->files.size();
     for (const auto &e : store->files) if (e.resident) ++out->n_resident;
+    out->seconds = store->seconds;
+    out->seconds_allocating = store->seconds_allocating;
+    out->seconds_waiting_for_readers = store->seconds_waiting_for_readers;
+    out->seconds_waiting_for_device = store->seconds_waiting_for_device;
+    out->reader_seconds_reading = store->reader_seconds_reading;
+    out->reader_seconds_waiting = store->reader_seconds_waiting;
     return SNPGPU_OK;
 }
 

@@ -141,7 +141,7 @@ extern "C" {
 
 int snpgpu_synth_reference_dev(snpgpu_ctx *ctx, uint64_t seed, uint32_t genome_len, uint8_t *d_ref) {
     if (!ctx || !d_ref) return SNPGPU_E_ARG;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     k_synth_ref<<<(genome_len + 1 + 255) / 256, 256, 0, ctx->stream>>>(seed, genome_len, d_ref);
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;
@@ -152,7 +152,7 @@ int snpgpu_synth_pileup_dev(snpgpu_ctx *ctx, const snpgpu_synth_params *p, const
     if (!ctx || !p || !d_ref || !out_nbytes) return SNPGPU_E_ARG;
     *out_nbytes = 0;
     if (p->genome_len == 0) return SNPGPU_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, snpgpu_enter(ctx));
     SynthDev P;
     P.seed = p->seed; P.sample = p->sample; P.genome_len = p->genome_len;
     P.n_clades = p->n_clades ? p->n_clades : 1;

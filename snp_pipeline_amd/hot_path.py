@@ -172,14 +172,17 @@ def hot_path_batch(args):
     torch.cuda.set_device(comm.local_rank)
     store = dev.pileups(int(args.residentBytes or 0))
     try:
-        # pinned host memory for the per-site results of step 3, allocated while the pileups stream in (pinning a gigabyte takes
-        # a good part of a second)
+        # host memory for the per-site results of step 3, allocated AND touched while the pileups stream in.  Plain pageable
+        # memory: on this platform a device-to-host copy into touched pageable memory runs at the pinned rate (55 GB/s), while
+        # pinning a gigabyte takes 0.23 s during which every other thread's copies stand still (tools/probe/pin_probe.cpp)
         group_bytes = int(args.groupBytes) if args.groupBytes else (1 << 30)
         arenas = [None, None]
 
         def alloc_arenas():
             for k in range(2 if hi - lo > 1 else 1):
-                arenas[k] = torch.empty(group_bytes, dtype=torch.uint8, pin_memory=True)
+                a = np.empty(group_bytes, dtype=np.uint8)
+                a.fill(0)
+                arenas[k] = torch.from_numpy(a)
 
         arena_thread = threading.Thread(target=alloc_arenas)
         arena_thread.start()
@@ -215,6 +218,7 @@ def hot_path_batch(args):
                     failure.append(err)
                     bufs[4][:] = 1
 
+            t_call = time.perf_counter()
             th = threading.Thread(target=run_ingest)
             th.start()
             pending = list(range(len(batch)))
@@ -244,10 +248,13 @@ def hot_path_batch(args):
                 if pending:
                     time.sleep(0.0005)
             th.join()
+            lap("1a   of which: streamed ingest calls", t_call)
             if failure:
                 raise failure[0]
+            t_tail = time.perf_counter()
             for fu in futures:
                 fu.result()
+            lap("1b   of which: waiting for the last var.flt.vcf files", t_tail)
         for s in redo:
             ptr, nbytes = store.get(s.store_index)
             try:
@@ -386,6 +393,7 @@ def hot_path_batch(args):
         col_of2 = np.full(S, -1, dtype=np.int32)
         col_of2[cols2] = np.arange(len(cols2), dtype=np.int32)
         ss = devmod.SiteSet.from_arrays(dev, [c.encode("utf-8") for c in contigs], set_keys.astype(np.uint64), in1 * np.uint8(L.SITE_IN_SNPLIST))
+        lap("3-   of which: site set", t0)
         identity1 = len(extra) == 0
         S1, S2 = len(list1), len(list2)
         filters_desc = vcf_writer.filter_descriptions(cc_args.minConsFreq, cc_args.minConsDpth, cc_args.minConsStrdDpth, cc_args.minConsStrdBias)
@@ -407,10 +415,10 @@ def hot_path_batch(args):
         h2d_extra = [0]
 
         def host_set(k):
-            """Pinned result arrays of one group, carved out of arena k (allocated while the pileups were streaming in)."""
+            """Result arrays of one group, carved out of arena k (allocated while the pileups were streaming in)."""
             need = g_alloc * per_sample_bytes + 4096
             if arenas[k] is None or arenas[k].numel() < need:
-                arenas[k] = torch.empty(need, dtype=torch.uint8, pin_memory=True)
+                arenas[k] = torch.from_numpy(np.zeros(need, dtype=np.uint8))
             at = [0]
 
             def carve(shape, dtype):
@@ -470,6 +478,7 @@ def hot_path_batch(args):
         vcf_date = datetime.datetime.now()
         write_failures = []
         for g0 in range(0, n_local, group):
+            t_g = time.perf_counter()
             part = callable_[g0:g0 + group]
             g = len(part)
             which = (g0 // group) & 1
@@ -523,6 +532,10 @@ def hot_path_batch(args):
                 dev.region_flow_dev(d_base.data_ptr(), d_filt.data_ptr(), d_line.data_ptr(), g, S, d_cols1.data_ptr(), d_col_of1.data_ptr(), S1,
                                     d_e0.data_ptr(), 0, rows1[g0:g0 + g].data_ptr() if S1 else 0, d_nofilt.data_ptr(), d_err.data_ptr())
             # results to the host
+            if args.verbose >= 2:
+                torch.cuda.current_stream().synchronize()
+                lap("3a   of which: scan + call + flows on the device", t_g)
+                t_g = time.perf_counter()
             hs["status"][:g].copy_(d_status[:g], non_blocking=True)
             if S1:
                 hs["base1"][:g, :S1].copy_(rows1[g0:g0 + g, :S1], non_blocking=True)
@@ -535,6 +548,8 @@ def hot_path_batch(args):
                 if want_vcf:
                     hs["counts"][:g, :S].copy_(d_counts[:g, :S], non_blocking=True)
             torch.cuda.current_stream().synchronize()
+            lap("3b   of which: results to the host" if args.verbose >= 2 else "3ab  of which: device work + results to the host", t_g)
+            t_g = time.perf_counter()
             # what the per-sample CLI raises for: malformed chrom / position columns anywhere, a malformed line at a listed position
             st_np = hs["status"].numpy()[:g]
             for k, s in enumerate(part):
@@ -557,12 +572,17 @@ def hot_path_batch(args):
                                             "for this sample" % s.name)
                     continue
                 row_ok[g0 + k] = True
+            lap("3c   of which: status checks", t_g)
+            t_g = time.perf_counter()
             if pending_write is not None:
                 write_failures.extend(pending_write.result())
             pending_write = writer.submit(write_group, part, hs, g0)
+            lap("3d   of which: waiting for the previous group's files", t_g)
+        t_g = time.perf_counter()
         if pending_write is not None:
             write_failures.extend(pending_write.result())
         writer.shutdown()
+        lap("3e   of which: waiting for the last group's files", t_g)
         for s, msg in write_failures:
             s.ok, s.error = False, msg
             row_ok[callable_.index(s)] = False
@@ -573,6 +593,7 @@ def hot_path_batch(args):
         # ================================ 4: matrices, distances, top-level files ==========================================
         t0 = time.perf_counter()
         # which samples of the whole job have a consensus row (gathered: small)
+        ref_seqs = [None]
         ok_local = np.zeros(hi - lo, dtype=bool)
         for k, s in enumerate(callable_):
             ok_local[s.index - lo] = bool(row_ok[k])
@@ -633,13 +654,18 @@ def hot_path_batch(args):
                 from . import distance as dmod
                 dmod.write_pairwise(outputs[pairs], ids, full)
                 dmod.write_matrix(outputs[matrix], ids, full)
+                if ref_seqs[0] is None:
+                    ref_seqs[0] = snp_reference.read_fasta_sequences(ref_path)
                 snp_reference.write_reference_snp_file(ref_path, outputs["snplist" if flow == 1 else "snplist_p"],
-                                                       outputs["refsnp" if flow == 1 else "refsnp_p"])
+                                                       outputs["refsnp" if flow == 1 else "refsnp_p"], match_dict=ref_seqs[0])
         comm.barrier()
         lap("4 matrices + distances", t0)
         st = store.stats()
         stats = {"h2d_bytes": int(st.h2d_bytes) + h2d_extra[0], "file_bytes": int(st.file_bytes), "resident_files": int(st.n_resident),
-                 "files": int(st.n_files), "seconds": time.perf_counter() - t_start, "phases": timings, "sites": S1, "sites_preserved": S2,
+                 "files": int(st.n_files), "seconds": time.perf_counter() - t_start,
+                 "ingest": {"seconds": st.seconds, "allocating": st.seconds_allocating, "waiting_for_readers": st.seconds_waiting_for_readers,
+                            "waiting_for_device": st.seconds_waiting_for_device, "reader_seconds_reading": st.reader_seconds_reading,
+                            "reader_seconds_waiting": st.reader_seconds_waiting}, "phases": timings, "sites": S1, "sites_preserved": S2,
                  "samples": hi - lo}
         hot_path_batch.last_stats = stats
         verbose_print("# hot_path_batch rank %d: %d samples, %d pileup bytes, %d bytes copied to the device (%d files resident), %.3f s"

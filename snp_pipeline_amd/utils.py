@@ -313,8 +313,35 @@ def convert_vcf_file_to_snp_set(vcf_file_path):
     return set(read_vcf_sites(vcf_file_path)[2])
 
 
+_WS = bytes(range(9, 14)) + bytes(range(28, 33))          # what str.split() removes from ASCII text
+
+
+def fasta_records_ascii(path):
+    """[(record id, sequence bytes)] of a FASTA file the way the line loops below see it, whole records at a time (a 5 Mbp
+    reference is 83 000 lines): the id is the first word of the header, the sequence the data lines without any white space;
+    text before the first header is ignored.  Returns None for a file that is not plain ASCII or uses lone CRs as line ends
+    (the line loops then do the work, with text-mode decoding and universal newlines)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if not data.isascii() or (b"\r" in data and b"\r" in data.replace(b"\r\n", b"")):
+        return None
+    out = []
+    # a header is a line that STARTS with '>': a '>' elsewhere is sequence text
+    start = 0 if data.startswith(b">") else data.find(b"\n>") + 1
+    if start == 0 and not data.startswith(b">"):
+        return out
+    for chunk in data[start + 1:].split(b"\n>"):
+        head, _, body = chunk.partition(b"\n")
+        words = head.split()
+        out.append((words[0].decode("ascii") if words else "", body.translate(None, _WS)))
+    return out
+
+
 def read_fasta_lengths(path):
     """{record id: sequence length} as Bio.SeqIO.parse yields them (id = first word of the header)."""
+    fast = fasta_records_ascii(path)
+    if fast is not None:
+        return {name: len(seq) for name, seq in fast}
     lengths = {}
     name, n = None, 0
     with open(path, "r") as f:

@@ -154,7 +154,7 @@ def _outbreak_tree(work, seed=7, n_samples=6, genome_len=12000):
 def _separate_steps(work, ref_path, dirs, dirs_file, filter_extra, merge_extra):
     """What run.py:662-784 runs, one subcommand after the other."""
     for sdir in dirs:
-        _run("call_sites -f %s %s" % (ref_path, sdir))
+        _run("call_sites %s %s" % (ref_path, sdir))
     _run("filter_regions -f -n var.flt.vcf %s %s %s" % (dirs_file, ref_path, filter_extra))
     _run("merge_sites -f -n var.flt.vcf -o %s/snplist.txt %s %s %s.OrigVCF.filtered" % (work, merge_extra, dirs_file, dirs_file))
     _run("merge_sites -f -n var.flt_preserved.vcf -o %s/snplist_preserved.txt %s %s %s.PresVCF.filtered" % (work, merge_extra, dirs_file, dirs_file))
@@ -206,7 +206,7 @@ def test_hot_path_batch_equals_the_separate_steps(tmp_path, monkeypatch, filter_
     if maxsnps:                                                # a threshold that takes some samples out of the lists, not all
         counts = []
         for sdir in dirs:
-            _run("call_sites -f %s %s" % (ref_path, sdir))
+            _run("call_sites %s %s" % (ref_path, sdir))
             counts.append(sum(1 for ln in open(os.path.join(sdir, "var.flt.vcf")) if not ln.startswith("#")))
         merge_extra = "--maxsnps %d" % sorted(counts)[len(counts) // 2]
     _separate_steps(work, ref_path, dirs, dirs_file, filter_extra, merge_extra)
@@ -226,3 +226,32 @@ def test_hot_path_batch_equals_the_separate_steps(tmp_path, monkeypatch, filter_
         assert st["h2d_bytes"] == total and st["resident_files"] == len(piles)     # every pileup crossed the host link exactly once
     else:
         assert 0 < st["resident_files"] < len(piles) and st["h2d_bytes"] > total
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_hot_path_batch_sharded_over_ranks_writes_the_same_files(tmp_path, monkeypatch, world):
+    """torchrun, one rank per GPU in production (RCCL); here all ranks on the one GPU of the test box with gloo moving the
+    bytes: contiguous blocks of the sorted samples per rank, C1 / C2 / row bands between them — every file as the one-rank job
+    writes it (which the test above compares with the separate subcommands)."""
+    import socket
+    import subprocess
+    import sys
+    work = tmp_path
+    ref_path, dirs, dirs_file, piles = _outbreak_tree(work, n_samples=7)
+    filter_extra = "--edge_length 100 --window_size 1000 125 15 --max_snp 3 2 1 --mode all"
+    line = ("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s --varscanExtraParams=%s"
+            % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), CONSENSUS_EXTRA.replace(" ", "\x00"), VARSCAN_EXTRA.replace(" ", "\x00")))
+    monkeypatch.chdir(work)
+    _run(line)
+    want = _snapshot(work, dirs)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SNPGPU_PIPELINE_ONE_GPU="1", MASTER_ADDR="127.0.0.1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bin", "cfsan_snp_pipeline")] + [w.replace("\x00", " ") for w in line.split()] + ["-v", "0"]
+    r = subprocess.run(cmd, cwd=str(work), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    _compare(_snapshot(work, dirs, remove=False), want)
