@@ -17,6 +17,9 @@ The same JSON line carries
                 duration measured with HIP events recorded on the launch stream inside the timed region;
   end_to_end    pileup FILES in the page cache -> consensus bytes on the host through the streamed ingestion, next to the
                 pinned host-to-device copy rate measured in the same process;
+  pipeline_from_files   the whole rank's shard as ONE job from files to files (`cfsan_snp_pipeline hot_path_batch`: site calling,
+                region filter, both site unions, both consensus flows, matrices, distances; every pileup over the host link
+                once), its wall time against bytes / pinned copy rate, and the separate subcommands on the same tree beside it;
   cpu_baseline  the CPU oracle (a statement-for-statement Python port of the reference's loop structure) on samples of
                 the same batch: 1 core, one process per sample on min(cores, 32) cores, and the distance loop; rank 0, N=1;
   secondary     pairwise SNP distances/s of the distance step alone at BASELINE configs[4] shape (10 000 x 200 000).
@@ -58,6 +61,8 @@ def parse_args():
     ap.add_argument("--skip-aux", action="store_true", help="skip the device-copy ceiling and the K3/K4 timings")
     ap.add_argument("--skip-cpu-parallel", action="store_true", help="skip the one-process-per-sample CPU baseline")
     ap.add_argument("--e2e-files", type=int, default=16, help="pileup files streamed from the page cache for the end_to_end row (0 = skip)")
+    ap.add_argument("--pipeline-files", type=int, default=125, help="samples of the pipeline_from_files row (0 = skip)")
+    ap.add_argument("--skip-separate-steps", action="store_true", help="pipeline_from_files: do not time the separate subcommands beside it")
     ap.add_argument("--dump", type=str, default=None, help="write this rank's results (site union, packed matrix, distance band) to DUMP.rankN.npz")
     return ap.parse_args()
 
@@ -212,6 +217,184 @@ def site_calling(d, pile, offs, sizes, n_files):
             "cpu_port": {"pileup_gb_per_sec": cut / cpu_s / 1e9, "cores": 1, "sample": "the first %d bytes of one file" % cut,
                          "kind": "port (oracle/varscan_oracle.py; the reference runs the VarScan jar here, which this image lacks)"},
         }
+    finally:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+
+
+# ---- pipeline_from_files: the shard as one job from files to files ------------------------------------------------------------
+FILTER_EXTRA = "--edge_length 500 --window_size 1000 125 15 --max_snp 3 2 1 --mode all"       # snppipeline.conf:211
+CONSENSUS_EXTRA = "--minConsFreq 0.6 --minConsDpth 3"                                          # snppipeline.conf:249
+VARSCAN_EXTRA = "--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5"                        # snppipeline.conf:199
+TOP_LEVEL_FILES = ("snplist.txt", "snplist_preserved.txt", "snpma.fasta", "snpma_preserved.fasta", "snp_distance_pairwise.tsv",
+                   "snp_distance_matrix.tsv", "snp_distance_pairwise_preserved.tsv", "snp_distance_matrix_preserved.tsv",
+                   "referenceSNP.fasta", "referenceSNP_preserved.fasta")
+PER_SAMPLE_FILES = ("var.flt.vcf", "var.flt_preserved.vcf", "var.flt_removed.vcf", "consensus.fasta", "consensus.vcf",
+                    "consensus_preserved.fasta", "consensus_preserved.vcf")
+
+
+def run_cli(line, verbose=0):
+    """One subcommand in this process (\\x00 stands for a blank inside an argument).  Returns its wall time."""
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    a = cli.parse_argument_list([w.replace("\x00", " ") for w in line.split()])
+    a.verbose = verbose
+    t = time.perf_counter()
+    cli.run_command_from_args(a)
+    return time.perf_counter() - t
+
+
+def hot_path_line(dirs_file, ref_path, extra=""):
+    q = lambda x: x.replace(" ", "\x00")     # noqa: E731
+    return ("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s --varscanExtraParams=%s%s"
+            % (dirs_file, ref_path, q(FILTER_EXTRA), q(CONSENSUS_EXTRA), q(VARSCAN_EXTRA), extra))
+
+
+def separate_steps(work, ref_path, dirs_file):
+    """The same files through the separate subcommands (their batch forms: the per-sample CLI of run.py:704-718 adds a process
+    start per sample on top): call_sites_batch, filter_regions, merge_sites x 2, call_consensus_batch x 2, snp_matrix x 2,
+    snp_reference x 2, distance x 2.  Returns {step: seconds}."""
+    os.environ["VarscanMpileup2snp_ExtraParams"] = VARSCAN_EXTRA
+    t = {}
+    t["call_sites_batch"] = run_cli("call_sites_batch %s %s" % (ref_path, dirs_file))       # (no -f: that would also re-run samtools)
+    t["filter_regions"] = run_cli("filter_regions -f -n var.flt.vcf %s %s %s" % (dirs_file, ref_path, FILTER_EXTRA))
+    t["merge_sites"] = run_cli("merge_sites -f -n var.flt.vcf -o %s/snplist.txt %s %s.OrigVCF.filtered" % (work, dirs_file, dirs_file))
+    t["merge_sites_preserved"] = run_cli("merge_sites -f -n var.flt_preserved.vcf -o %s/snplist_preserved.txt %s %s.PresVCF.filtered" % (work, dirs_file, dirs_file))
+    t["call_consensus_batch"] = run_cli("call_consensus_batch -f -l %s/snplist.txt -o consensus.fasta --vcfRefName ref.fasta %s --vcfFileName consensus.vcf %s"
+                                        % (work, CONSENSUS_EXTRA, dirs_file))
+    t["call_consensus_batch_preserved"] = run_cli("call_consensus_batch -f -l %s/snplist_preserved.txt -o consensus_preserved.fasta -e var.flt_removed.vcf "
+                                                  "--vcfRefName ref.fasta %s --vcfFileName consensus_preserved.vcf %s" % (work, CONSENSUS_EXTRA, dirs_file))
+    for sfx, flt in (("", "OrigVCF"), ("_preserved", "PresVCF")):
+        t["snp_matrix" + sfx] = run_cli("snp_matrix -f -c consensus%s.fasta -o %s/snpma%s.fasta %s.%s.filtered" % (sfx, work, sfx, dirs_file, flt))
+        t["snp_reference" + sfx] = run_cli("snp_reference -f -l %s/snplist%s.txt -o %s/referenceSNP%s.fasta %s" % (work, sfx, work, sfx, ref_path))
+        t["distance" + sfx] = run_cli("distance -f -p %s/snp_distance_pairwise%s.tsv -m %s/snp_distance_matrix%s.tsv %s/snpma%s.fasta" % (work, sfx, work, sfx, work, sfx))
+    return t
+
+
+def output_digests(work, dirs):
+    import hashlib
+    h = {}
+    for name in TOP_LEVEL_FILES:
+        with open(os.path.join(work, name), "rb") as f:
+            h[name] = hashlib.sha256(f.read()).hexdigest()
+    for name in PER_SAMPLE_FILES:
+        m = hashlib.sha256()
+        for sdir in dirs:
+            with open(os.path.join(sdir, name), "rb") as f:
+                m.update(f.read())
+        h["samples/*/" + name] = m.hexdigest()
+    return h
+
+
+def write_sample_tree(base_dir, refh, G, sample_bytes, n, contig="synth_chr1"):
+    """reference/ref.fasta + samples/sNNNN/reads.all.pileup for n samples; sample_bytes(i) -> the pileup of sample i as a host
+    array.  Returns (tmpdir, ref path, dirs file, sample dirs, total pileup bytes)."""
+    import concurrent.futures
+    import tempfile
+    tmpdir = tempfile.mkdtemp(prefix="snpbench_pipeline_", dir=base_dir)
+    os.makedirs(os.path.join(tmpdir, "reference"))
+    ref_path = os.path.join(tmpdir, "reference", "ref.fasta")
+    seq = refh[1:G + 1].tobytes().decode()
+    with open(ref_path, "w") as f:
+        f.write(">%s\n" % contig)
+        f.write("\n".join(seq[i:i + 60] for i in range(0, G, 60)) + "\n")
+    old = time.time() - 1000
+    os.utime(ref_path, (old, old))
+
+    def write(path, arr):
+        with open(path, "wb") as f:
+            f.write(memoryview(arr))
+
+    dirs, total, futures = [], 0, []
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as pool:
+        for i in range(n):
+            host = sample_bytes(i)
+            sdir = os.path.join(tmpdir, "samples", "s%04d" % i)
+            os.makedirs(sdir)
+            bam = os.path.join(sdir, "reads.sorted.deduped.indelrealigned.bam")
+            with open(bam, "wb") as f:
+                f.write(b"placeholder: the pileup is newer, samtools is not run (call_sites.py:70-72)")
+            os.utime(bam, (old, old))
+            futures.append(pool.submit(write, os.path.join(sdir, "reads.all.pileup"), host))
+            dirs.append(sdir)
+            total += len(host)
+            if len(futures) > 16:
+                futures.pop(0).result()
+        for fu in futures:
+            fu.result()
+    dirs_file = os.path.join(tmpdir, "sampleDirectories.txt")
+    with open(dirs_file, "w") as f:
+        f.write("\n".join(dirs) + "\n")
+    return tmpdir, ref_path, dirs_file, dirs, total
+
+
+def pinned_h2d_gbps(torch, n=256 << 20, reps=8):
+    src = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    dst = torch.empty(n, dtype=torch.uint8, device="cuda")
+    dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    return reps * n / (time.perf_counter() - t) / 1e9
+
+
+def pipeline_from_files(pile, offs, sizes, refh, G, n_files, with_separate=True):
+    """The rank's shard as one job from files to files.  The sample tree is written first (page cache); a two-sample job
+    warms the process up (code objects, Python imports); then ONE run of hot_path_batch over all samples is timed — its first
+    and only one, as in a real job (a second run in the same process would start by waiting for the driver to take back the
+    54 GB the first one freed).  Beside it: bytes / pinned copy rate, and the separate subcommands on the same tree."""
+    import shutil
+    import torch
+    from snp_pipeline_amd import hot_path
+    need = int(sum(sizes[:n_files])) + (1 << 30)
+    base_dir = None
+    for cand in (__import__("tempfile").gettempdir(), "/dev/shm"):
+        try:
+            if shutil.disk_usage(cand).free > need + (8 << 30):
+                base_dir = cand
+                break
+        except OSError:
+            pass
+    if base_dir is None:
+        return {"skipped": "no room for %d bytes of pileup files" % need}
+    t0 = time.perf_counter()
+    tmpdir, ref_path, dirs_file, dirs, total = write_sample_tree(
+        base_dir, refh, G, lambda i: pile[int(offs[i]):int(offs[i]) + sizes[i]].cpu().numpy(), n_files)
+    t_tree = time.perf_counter() - t0
+    try:
+        warm = os.path.join(tmpdir, "warmup")
+        os.makedirs(warm)
+        with open(os.path.join(warm, "sampleDirectories.txt"), "w") as f:
+            f.write("\n".join(dirs[:2]) + "\n")
+        run_cli(hot_path_line(os.path.join(warm, "sampleDirectories.txt"), ref_path, " --workDir %s" % warm))
+        h2d = pinned_h2d_gbps(torch)
+        wall = run_cli(hot_path_line(dirs_file, ref_path))
+        st = dict(hot_path.hot_path_batch.last_stats)
+        ideal = total / (h2d * 1e9)
+        out = {
+            "what": "%d samples (%s): reads.all.pileup files in the page cache -> var.flt.vcf, var.flt_preserved/_removed.vcf, both snplists, "
+                    "consensus(.fasta|.vcf) x 2 flows, snpma x 2, referenceSNP x 2, distance TSVs x 4 — one hot_path_batch job" % (n_files, base_dir),
+            "samples": n_files, "pileup_bytes": total, "seconds": st["seconds"], "cli_seconds": wall,
+            "h2d_bytes": st["h2d_bytes"], "each_pileup_crossed_the_link_once": st["h2d_bytes"] == total,
+            "pinned_h2d_gb_per_sec": h2d, "bytes_over_pinned_h2d_seconds": ideal, "wall_over_copy_time": st["seconds"] / ideal,
+            "samples_per_sec": n_files / st["seconds"], "pileup_gb_per_sec": total / st["seconds"] / 1e9,
+            "phases_seconds": st["phases"], "ingest": st["ingest"], "snp_sites": st["sites"], "snp_sites_preserved": st["sites_preserved"],
+            "tree_written_in_seconds": t_tree,
+        }
+        if with_separate:
+            mine = output_digests(tmpdir, dirs)
+            for sdir in dirs:                                   # nothing of the one-job run is left to be "fresh"
+                for name in PER_SAMPLE_FILES:
+                    os.remove(os.path.join(sdir, name))
+            sep = separate_steps(tmpdir, ref_path, dirs_file)
+            theirs = output_digests(tmpdir, dirs)
+            out["separate_steps_seconds"] = sep
+            out["separate_steps_total_seconds"] = sum(sep.values())
+            out["speedup_over_separate_steps"] = sum(sep.values()) / st["seconds"]
+            out["outputs_identical_to_separate_steps"] = mine == theirs
+            if mine != theirs:
+                raise SystemExit("hot_path_batch and the separate subcommands disagree on %r" % [k for k in mine if mine[k] != theirs[k]])
+        return out
     finally:
         shutil.rmtree(tmpdir, ignore_errors=True)
 
@@ -656,6 +839,10 @@ def main():
     # ---- end to end: pileup FILES in the page cache -> consensus bytes on the host, through the streamed ingestion ----
     if rank == 0 and world == 1 and args.e2e_files > 0 and B:
         out["end_to_end"] = end_to_end(d, ss, prm, pile, offs, sizes, bases, min(args.e2e_files, B), S)
+
+    # ---- the shard as ONE job from files to files (hot_path_batch) ------------------------------------------------------
+    if rank == 0 and world == 1 and args.pipeline_files > 0 and B:
+        out["pipeline_from_files"] = pipeline_from_files(pile, offs, sizes, refh, G, min(args.pipeline_files, B), not args.skip_separate_steps)
 
     # ---- phase-1 site calling on files -----------------------------------------------------------------
     if rank == 0 and world == 1 and args.site_files > 0 and B:

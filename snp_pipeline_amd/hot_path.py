@@ -25,8 +25,8 @@ environment variable of the same name), parsed by the step's own argument parser
 """
 from __future__ import print_function
 
-import argparse
 import concurrent.futures
+import ctypes
 import os
 import shlex
 import threading
@@ -181,7 +181,7 @@ def hot_path_batch(args):
         def alloc_arenas():
             for k in range(2 if hi - lo > 1 else 1):
                 a = np.empty(group_bytes, dtype=np.uint8)
-                a.fill(0)
+                ctypes.memset(a.ctypes.data, 0, a.nbytes)      # touches the pages with the GIL released (ndarray.fill would hold it)
                 arenas[k] = torch.from_numpy(a)
 
         arena_thread = threading.Thread(target=alloc_arenas)
@@ -339,7 +339,11 @@ def hot_path_batch(args):
 
         dir_index = {d: i for i, d in enumerate(sorted_dirs)}
         every = np.ones(len(all_keys), dtype=bool)
+        lap("2a   of which: gathering the records", t0)
+        t2 = time.perf_counter()
         list1, excluded1 = site_union(every, "snplist")
+        lap("2b   of which: site union + snplist.txt", t2)
+        t2 = time.perf_counter()
 
         # filter_regions (filter_regions.py:205-383): dense windows + contig edges -> merged bad regions -> classification of
         # every record; mode all unions the regions over the samples, mode each keeps them per sample; outgroup samples bypass
@@ -359,9 +363,15 @@ def hot_path_batch(args):
         triples = [(contigs, rec_cid[rec_off[i]:rec_off[i + 1]], rec_pos[rec_off[i]:rec_off[i + 1]]) for i in np.flatnonzero(filt)]
         regions = fr.compute_bad_regions(dev, triples, contig_lengths, fr_args.edgeLength, fr_args.maxSnpsList, fr_args.windowSizeList,
                                          per_sample=per_sample)
+        lap("2c   of which: dense windows + region merge", t2)
+        t2 = time.perf_counter()
         removed = _classify_all(dev, regions, per_sample, np.flatnonzero(filt), contigs, rec_off, rec_cid, rec_pos, len(all_keys))
         preserved = every & ~removed
+        lap("2d   of which: classification of the records", t2)
+        t2 = time.perf_counter()
         list2, excluded2 = site_union(preserved, "snplist_p")
+        lap("2e   of which: preserved site union + snplist_preserved.txt", t2)
+        t2 = time.perf_counter()
         # the split VCF files of this rank's samples
         for s in mine:
             if not s.ok:
@@ -372,6 +382,7 @@ def hot_path_batch(args):
             else:
                 s.removed = removed[rec_off[s.index]:rec_off[s.index + 1]]
                 fr.write_preserved_and_removed_vcf_files(vcf_path, s.header, s.vcf_lines, s.removed)
+        lap("2f   of which: var.flt_preserved / _removed.vcf files", t2)
         lap("2 site union + region filter", t0)
 
         # ================================ 3: both consensus flows from one scan + call =====================================

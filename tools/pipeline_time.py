@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Wall time of `hot_path_batch` on N synthetic samples (5 Mbp x 30x by default) written to a sample tree first, with its
-phases, next to the pinned host-to-device copy rate and (optionally) the separate subcommands on the same tree.
+phases, next to the pinned host-to-device copy rate and (optionally) the separate subcommands on the same tree.  The helpers
+are bench.py's (its pipeline_from_files row is this measurement at the bench's own workload).
 
-    python tools/pipeline_time.py [--samples 125] [--genome 5000000] [--sites 50000] [--separate] [--runs 2] [--no-vcf]
+    python tools/pipeline_time.py [--samples 125] [--genome 5000000] [--sites 50000] [--separate] [--runs 1] [--no-vcf]
 """
 import argparse
-import concurrent.futures
 import json
 import os
 import shutil
@@ -17,142 +17,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-
-FILTER_EXTRA = "--edge_length 500 --window_size 1000 125 15 --max_snp 3 2 1 --mode all"       # snppipeline.conf:211
-CONSENSUS_EXTRA = "--minConsFreq 0.6 --minConsDpth 3"                                          # snppipeline.conf:249
-VARSCAN_EXTRA = "--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5"                        # snppipeline.conf:199
-
-
-def synth_tree(d, torch, n, G, S, depth, base_dir, contig=b"synth_chr1"):
-    """n synthetic samples as a sample tree (reference/ref.fasta, samples/sNNNN/reads.all.pileup).  Returns (tmpdir, ref path,
-    dirs file, sample dirs, total pileup bytes)."""
-    ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda")
-    d.synth_reference_dev(1, G, ref.data_ptr())
-    torch.cuda.synchronize()
-    refh = ref.cpu().numpy()
-    rng = np.random.default_rng(2)
-    pos = np.unique(rng.choice(np.arange(501, G - 499, dtype=np.int64), size=S, replace=False))
-    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-    code = np.searchsorted(acgt, refh[pos])
-    alt_host = np.zeros(G + 1, dtype=np.uint8)
-    alt_host[pos] = acgt[(code + 1 + rng.integers(0, 3, size=len(pos))) % 4]
-    alt = torch.from_numpy(alt_host).cuda()
-    tmpdir = tempfile.mkdtemp(prefix="snp_pipeline_", dir=base_dir)
-    os.makedirs(os.path.join(tmpdir, "reference"))
-    ref_path = os.path.join(tmpdir, "reference", "ref.fasta")
-    seq = refh[1:].tobytes().decode()
-    with open(ref_path, "w") as f:
-        f.write(">%s\n" % contig.decode())
-        f.write("\n".join(seq[i:i + 60] for i in range(0, G, 60)) + "\n")
-    dirs = []
-    total = 0
-    pool = concurrent.futures.ThreadPoolExecutor(max_workers=8)
-    futures = []
-
-    def write(path, arr):
-        with open(path, "wb") as f:
-            f.write(memoryview(arr))
-
-    cap = 0
-    buf = None
-    for i in range(n):
-        size = d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), 0, 0, mean_depth=depth, contig=contig)
-        if size + 256 > cap:
-            cap = size + (size >> 3) + 256
-            buf = torch.empty(cap, dtype=torch.uint8, device="cuda")
-        got = d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), buf.data_ptr(), size, mean_depth=depth, contig=contig)
-        assert got == size
-        torch.cuda.synchronize()
-        host = buf[:size].cpu().numpy()
-        sdir = os.path.join(tmpdir, "samples", "s%04d" % i)
-        os.makedirs(sdir)
-        with open(os.path.join(sdir, "reads.sorted.deduped.indelrealigned.bam"), "wb") as f:
-            f.write(b"placeholder")
-        old = time.time() - 1000
-        os.utime(os.path.join(sdir, "reads.sorted.deduped.indelrealigned.bam"), (old, old))
-        futures.append(pool.submit(write, os.path.join(sdir, "reads.all.pileup"), host))
-        dirs.append(sdir)
-        total += size
-        if len(futures) > 16:
-            futures.pop(0).result()
-    for fu in futures:
-        fu.result()
-    pool.shutdown()
-    old = time.time() - 1000
-    os.utime(ref_path, (old, old))
-    dirs_file = os.path.join(tmpdir, "sampleDirectories.txt")
-    with open(dirs_file, "w") as f:
-        f.write("\n".join(dirs) + "\n")
-    return tmpdir, ref_path, dirs_file, dirs, total
-
-
-def pinned_h2d_gbps(torch, n=256 << 20, reps=8):
-    src = torch.empty(n, dtype=torch.uint8, pin_memory=True)
-    dst = torch.empty(n, dtype=torch.uint8, device="cuda")
-    dst.copy_(src, non_blocking=True)
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(reps):
-        dst.copy_(src, non_blocking=True)
-    torch.cuda.synchronize()
-    return reps * n / (time.perf_counter() - t) / 1e9
-
-
-def run_cli(line, verbose=0):
-    from snp_pipeline_amd import cfsan_snp_pipeline as cli
-    args = cli.parse_argument_list([w.replace("\x00", " ") for w in line.split()])
-    args.verbose = verbose
-    t = time.perf_counter()
-    cli.run_command_from_args(args)
-    return time.perf_counter() - t
-
-
-def hot_path_line(dirs_file, ref_path, no_vcf=False, extra=""):
-    q = lambda s: s.replace(" ", "\x00")     # noqa: E731
-    return ("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s --varscanExtraParams=%s%s%s"
-            % (dirs_file, ref_path, q(FILTER_EXTRA), q(CONSENSUS_EXTRA), q(VARSCAN_EXTRA), " --noConsensusVcf" if no_vcf else "", extra))
-
-
-def separate_steps(work, ref_path, dirs_file):
-    """The same files through the batch forms of the separate subcommands (the per-sample CLI would add a process start per
-    sample): call_sites_batch, filter_regions, merge_sites x 2, call_consensus_batch x 2, snp_matrix x 2, snp_reference x 2,
-    distance x 2.  Returns {step: seconds}."""
-    os.environ["VarscanMpileup2snp_ExtraParams"] = VARSCAN_EXTRA
-    t = {}
-    t["call_sites_batch"] = run_cli("call_sites_batch %s %s" % (ref_path, dirs_file))       # (no -f: that would also re-run samtools)
-    t["filter_regions"] = run_cli("filter_regions -f -n var.flt.vcf %s %s %s" % (dirs_file, ref_path, FILTER_EXTRA))
-    t["merge_sites"] = run_cli("merge_sites -f -n var.flt.vcf -o %s/snplist.txt %s %s.OrigVCF.filtered" % (work, dirs_file, dirs_file))
-    t["merge_sites_preserved"] = run_cli("merge_sites -f -n var.flt_preserved.vcf -o %s/snplist_preserved.txt %s %s.PresVCF.filtered" % (work, dirs_file, dirs_file))
-    t["call_consensus_batch"] = run_cli("call_consensus_batch -f -l %s/snplist.txt -o consensus.fasta --vcfRefName ref.fasta %s --vcfFileName consensus.vcf %s"
-                                        % (work, CONSENSUS_EXTRA, dirs_file))
-    t["call_consensus_batch_preserved"] = run_cli("call_consensus_batch -f -l %s/snplist_preserved.txt -o consensus_preserved.fasta -e var.flt_removed.vcf "
-                                                  "--vcfRefName ref.fasta %s --vcfFileName consensus_preserved.vcf %s" % (work, CONSENSUS_EXTRA, dirs_file))
-    for sfx, flt in (("", "OrigVCF"), ("_preserved", "PresVCF")):
-        t["snp_matrix" + sfx] = run_cli("snp_matrix -f -c consensus%s.fasta -o %s/snpma%s.fasta %s.%s.filtered" % (sfx, work, sfx, dirs_file, flt))
-        t["snp_reference" + sfx] = run_cli("snp_reference -f -l %s/snplist%s.txt -o %s/referenceSNP%s.fasta %s" % (work, sfx, work, sfx, ref_path))
-        t["distance" + sfx] = run_cli("distance -f -p %s/snp_distance_pairwise%s.tsv -m %s/snp_distance_matrix%s.tsv %s/snpma%s.fasta" % (work, sfx, work, sfx, work, sfx))
-    return t
-
-
-TOP_LEVEL = ("snplist.txt", "snplist_preserved.txt", "snpma.fasta", "snpma_preserved.fasta", "snp_distance_pairwise.tsv", "snp_distance_matrix.tsv",
-             "snp_distance_pairwise_preserved.tsv", "snp_distance_matrix_preserved.tsv", "referenceSNP.fasta", "referenceSNP_preserved.fasta")
-PER_SAMPLE = ("var.flt.vcf", "var.flt_preserved.vcf", "var.flt_removed.vcf", "consensus.fasta", "consensus.vcf", "consensus_preserved.fasta",
-              "consensus_preserved.vcf")
-
-
-def digest(work, dirs, per_sample=PER_SAMPLE):
-    import hashlib
-    h = {}
-    for name in TOP_LEVEL:
-        with open(os.path.join(work, name), "rb") as f:
-            h[name] = hashlib.sha256(f.read()).hexdigest()
-    for name in per_sample:
-        m = hashlib.sha256()
-        for sdir in dirs:
-            with open(os.path.join(sdir, name), "rb") as f:
-                m.update(f.read())
-        h["samples/*/" + name] = m.hexdigest()
-    return h
+import bench  # noqa: E402
 
 
 def main():
@@ -161,9 +26,10 @@ def main():
     ap.add_argument("--genome", type=int, default=5_000_000)
     ap.add_argument("--sites", type=int, default=50_000)
     ap.add_argument("--depth", type=float, default=30.0)
-    ap.add_argument("--runs", type=int, default=2)
+    ap.add_argument("--runs", type=int, default=1)
     ap.add_argument("--separate", action="store_true")
     ap.add_argument("--no-vcf", action="store_true")
+    ap.add_argument("--verbose", type=int, default=0)
     ap.add_argument("--dir", type=str, default=None)
     a = ap.parse_args()
     import torch
@@ -171,37 +37,53 @@ def main():
     from snp_pipeline_amd import hot_path
     d = dev.Device(0)
     d.use_torch_stream()
-    base = a.dir or tempfile.gettempdir()
+    G, S = a.genome, a.sites
+    ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda")
+    d.synth_reference_dev(1, G, ref.data_ptr())
+    torch.cuda.synchronize()
+    refh = ref.cpu().numpy()
+    rng = np.random.default_rng(2)
+    pos = np.unique(rng.choice(np.arange(501, G - 499, dtype=np.int64), size=S, replace=False))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    alt_host = np.zeros(G + 1, dtype=np.uint8)
+    alt_host[pos] = acgt[(np.searchsorted(acgt, refh[pos]) + 1 + rng.integers(0, 3, size=len(pos))) % 4]
+    alt = torch.from_numpy(alt_host).cuda()
+    state = {"buf": None, "cap": 0}
+
+    def sample_bytes(i):
+        size = d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), 0, 0, mean_depth=a.depth)
+        if size + 256 > state["cap"]:
+            state["cap"] = size + (size >> 3) + 256
+            state["buf"] = torch.empty(state["cap"], dtype=torch.uint8, device="cuda")
+        assert d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), state["buf"].data_ptr(), size, mean_depth=a.depth) == size
+        torch.cuda.synchronize()
+        return state["buf"][:size].cpu().numpy()
+
     t0 = time.perf_counter()
-    tmpdir, ref_path, dirs_file, dirs, total = synth_tree(d, torch, a.samples, a.genome, a.sites, a.depth, base)
-    out = {"samples": a.samples, "pileup_bytes": total, "tree_seconds": time.perf_counter() - t0, "dir": base}
+    tmpdir, ref_path, dirs_file, dirs, total = bench.write_sample_tree(a.dir or tempfile.gettempdir(), refh, G, sample_bytes, a.samples)
+    out = {"samples": a.samples, "pileup_bytes": total, "tree_seconds": time.perf_counter() - t0}
     try:
-        out["pinned_h2d_gb_per_sec"] = pinned_h2d_gbps(torch)
+        out["pinned_h2d_gb_per_sec"] = bench.pinned_h2d_gbps(torch)
         runs = []
         for _ in range(a.runs):
-            wall = run_cli(hot_path_line(dirs_file, ref_path, a.no_vcf))
+            wall = bench.run_cli(bench.hot_path_line(dirs_file, ref_path, " --noConsensusVcf" if a.no_vcf else ""), verbose=a.verbose)
             st = dict(hot_path.hot_path_batch.last_stats)
             st["cli_seconds"] = wall
             runs.append(st)
         out["runs"] = runs
         best = min(runs, key=lambda r: r["seconds"])
         ideal = total / (out["pinned_h2d_gb_per_sec"] * 1e9)
-        out["best_seconds"] = best["seconds"]
-        out["ideal_copy_seconds"] = ideal
-        out["wall_over_copy"] = best["seconds"] / ideal
-        out["h2d_equals_file_bytes"] = best["h2d_bytes"] == total
-        if a.separate:
-            mine = digest(tmpdir, dirs, PER_SAMPLE if not a.no_vcf else tuple(n for n in PER_SAMPLE if not n.startswith("consensus") or n.endswith(".fasta")))
-            for sdir in dirs:                                   # nothing of the one-job run is left to be "fresh"
-                for name in PER_SAMPLE:
-                    if os.path.exists(os.path.join(sdir, name)):
-                        os.remove(os.path.join(sdir, name))
-            sep = separate_steps(tmpdir, ref_path, dirs_file)
-            out["separate_steps_seconds"] = sep
-            out["separate_total_seconds"] = sum(sep.values())
-            theirs = digest(tmpdir, dirs, PER_SAMPLE if not a.no_vcf else tuple(n for n in PER_SAMPLE if not n.startswith("consensus") or n.endswith(".fasta")))
-            out["identical_outputs"] = mine == theirs
-            out["different"] = [k for k in mine if mine[k] != theirs[k]]
+        out.update({"best_seconds": best["seconds"], "ideal_copy_seconds": ideal, "wall_over_copy": best["seconds"] / ideal,
+                    "h2d_equals_file_bytes": best["h2d_bytes"] == total})
+        if a.separate and not a.no_vcf:
+            mine = bench.output_digests(tmpdir, dirs)
+            for sdir in dirs:
+                for name in bench.PER_SAMPLE_FILES:
+                    os.remove(os.path.join(sdir, name))
+            sep = bench.separate_steps(tmpdir, ref_path, dirs_file)
+            theirs = bench.output_digests(tmpdir, dirs)
+            out.update({"separate_steps_seconds": sep, "separate_total_seconds": sum(sep.values()), "identical_outputs": mine == theirs,
+                        "different": [k for k in mine if mine[k] != theirs[k]]})
         print(json.dumps(out))
     finally:
         shutil.rmtree(tmpdir, ignore_errors=True)
