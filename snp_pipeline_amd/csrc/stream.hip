@@ -782,7 +782,8 @@ int varscan_resident(snpgpu_ctx *ctx, const uint8_t *d_file, uint64_t nbytes, co
     size_t o = up(4 * ws_words, 256);
     const size_t o_off = o; o += up(8ull * n_lines, 256);
     const size_t o_ctl = o; o += 256;                          // [0] u64 status, [8] u32 record count
-    const size_t o_rec = o; o += sizeof(snpgpu_varscan_site) * (size_t)capacity;
+    const size_t o_rec = o; o += up(sizeof(snpgpu_varscan_site) * (size_t)capacity, 256);
+    const size_t o_cand = o; o += 12ull * n_lines;
     rc = snpgpu_scratch(ctx, o + 256, &scr);
     if (rc) return rc;
     char *b = (char *)scr;
@@ -790,13 +791,18 @@ int varscan_resident(snpgpu_ctx *ctx, const uint8_t *d_file, uint64_t nbytes, co
     if (rc) return rc;
     rc = snpgpu_enqueue_lines_offsets(ctx, d_file, nbytes, (uint32_t *)b, (uint64_t *)(b + o_off), n_lines);
     if (rc) return rc;
-    uint64_t h_ctl[2] = {~0ull, 0};
+    uint64_t h_ctl[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0};           // status; records found + candidates; long candidates + spare; (tuning: cycle sums)
     HIP_TRY(ctx, hipMemcpyAsync(b + o_ctl, h_ctl, sizeof h_ctl, hipMemcpyHostToDevice, st));
     rc = snpgpu_enqueue_varscan(ctx, d_file, nbytes, (const uint64_t *)(b + o_off), n_lines, params, (snpgpu_varscan_site *)(b + o_rec), capacity,
-                                (uint32_t *)(b + o_ctl + 8), (uint64_t *)(b + o_ctl));
+                                (uint32_t *)(b + o_ctl + 8), (uint64_t *)(b + o_ctl), (uint32_t *)(b + o_cand));
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(h_ctl, b + o_ctl, sizeof h_ctl, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+#ifdef SNPGPU_TUNING
+    if (getenv("SNPGPU_VARSCAN_DEBUG"))
+        fprintf(stderr, "varscan walk: candidates %u, long %u; cycles summed over waves: lines in LDS after %llu, rounds %llu, kernel %llu\n", (uint32_t)(h_ctl[1] >> 32),
+                (uint32_t)h_ctl[2], (unsigned long long)h_ctl[3], (unsigned long long)h_ctl[4], (unsigned long long)h_ctl[5]);
+#endif
     out_status[0] = h_ctl[0];
     const uint32_t found = (uint32_t)h_ctl[1];
     *out_n_sites = found;
@@ -1073,7 +1079,8 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
         size_t o = up(4 * ws_words, 256);
         const size_t o_off = o; o += up(8ull * n_lines, 256);
         const size_t o_ctl = o; o += 256;
-        const size_t o_rec = o; o += sizeof(snpgpu_varscan_site) * (size_t)capacity + 256;
+        const size_t o_rec = o; o += up(sizeof(snpgpu_varscan_site) * (size_t)capacity, 256) + 256;
+        const size_t o_cand = o; o += up(12ull * n_lines, 256);
         const size_t before = ctx->scratch_bytes;
         void *scr = nullptr;
         int r = snpgpu_scratch(ctx, 2 * o + 512, &scr);         // may move the scratch (it waits for the compute stream first)
@@ -1087,11 +1094,11 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
         }
         r = snpgpu_enqueue_lines_offsets(ctx, d_file, nbytes, (uint32_t *)b, (uint64_t *)(b + o_off), n_lines);
         if (r) return r;
-        uint64_t h_ctl[2] = {~0ull, 0};
-        memcpy(res + 32, h_ctl, sizeof h_ctl);                  // (a pinned source that stays valid until the copy has run)
-        VS_RET(hipMemcpyAsync(b + o_ctl, res + 32, sizeof h_ctl, hipMemcpyHostToDevice, st));
+        uint64_t h_ctl[3] = {~0ull, 0, 0};                      // status; records found + candidates; long candidates + spare
+        memcpy(res + 64, h_ctl, sizeof h_ctl);                  // (a pinned source that stays valid until the copy has run)
+        VS_RET(hipMemcpyAsync(b + o_ctl, res + 64, sizeof h_ctl, hipMemcpyHostToDevice, st));
         r = snpgpu_enqueue_varscan(ctx, d_file, nbytes, (const uint64_t *)(b + o_off), n_lines, params, (snpgpu_varscan_site *)(b + o_rec), capacity,
-                                   (uint32_t *)(b + o_ctl + 8), (uint64_t *)(b + o_ctl));
+                                   (uint32_t *)(b + o_ctl + 8), (uint64_t *)(b + o_ctl), (uint32_t *)(b + o_cand));
         if (r) return r;
         VS_RET(hipMemcpyAsync(res, b + o_ctl, 16, hipMemcpyDeviceToHost, st));
         if (capacity) VS_RET(hipMemcpyAsync(res + r_rec, b + o_rec, sizeof(snpgpu_varscan_site) * (size_t)capacity, hipMemcpyDeviceToHost, st));
