@@ -13,7 +13,7 @@ from __future__ import absolute_import
 import argparse
 import sys
 
-from . import call_consensus, call_sites, distance, filter_regions, hot_path, merge_sites, snp_matrix, snp_reference, utils
+from . import call_consensus, call_sites, distance, filter_regions, hot_path, merge_sites, service, snp_matrix, snp_reference, utils
 from .utils import __version__, verbose_print
 
 NOT_PROVIDED = ("run", "data", "index_ref", "map_reads", "merge_vcfs",
@@ -152,6 +152,13 @@ def parse_argument_list(argv):
     hot_path.add_arguments(sub)
     _common(sub)
     sub.set_defaults(func=hot_path.hot_path_batch, excepthook=utils.handle_global_exception)
+
+    # Extension of this build (no reference counterpart): the per-node service behind the per-sample CLI (SNPGPU_SERVICE)
+    sub = subparsers.add_parser("serve", help="keep the GPU context for the per-sample subcommands of this node", formatter_class=fmt,
+                                description="Start the per-node service: one worker process per GPU that keeps the device context and the pinned staging buffers, and runs the subcommands that cfsan_snp_pipeline processes started with SNPGPU_SERVICE set pass on to it.")
+    service.add_arguments(sub)
+    _common(sub)
+    sub.set_defaults(func=service.serve, excepthook=utils.handle_global_exception)
 
     sub = subparsers.add_parser("snp_matrix", help="Create a matrix of SNPs", formatter_class=fmt,
                                 description="Create the SNP matrix containing the consensus base for each of the samples at the positions where high-confidence SNPs were found in any of the samples.")

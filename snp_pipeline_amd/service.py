@@ -1,0 +1,324 @@
+"""A per-node service behind the unchanged per-sample CLI.
+
+run.py starts one ``cfsan_snp_pipeline call_consensus`` process per sample and flow (run.py:704-718) and one ``call_sites``
+per sample (run.py:662-664).  In-process, such a call costs ~0.5 s of wall time around 70 ms of device work: interpreter and
+numpy (0.13 s), HIP runtime + context (0.12 s), pinned staging buffers (0.05 s), and ~0.1 s of runtime tear-down at exit
+(tools/cli_time.py).  With ``SNPGPU_SERVICE`` set, the console script becomes a thin client instead — standard library only,
+no numpy, no HIP: it hands its argument list, working directory and environment to a long-lived server process over a unix
+socket, prints what the server captured and exits with the server's exit code.  The server keeps the device context and the
+pinned staging ring between requests and runs every request exactly as the CLI would (same parser, same exception hooks and
+exit codes, same log text), one at a time per GPU.
+
+    SNPGPU_SERVICE=auto     use the per-user default socket directory; start the server(s) when there are none
+    SNPGPU_SERVICE=<dir>    an explicit directory (started on demand only with SNPGPU_SERVICE_SPAWN=1)
+    unset / 0 / off         no service: everything in-process, as before
+
+``cfsan_snp_pipeline serve`` starts the service by hand (one worker process per GPU; ``--device N`` one worker).  A client that
+cannot reach a server does the work in-process.
+"""
+from __future__ import print_function
+
+import json
+import os
+import socket
+import struct
+import sys
+import time
+
+SERVED = ("call_sites", "filter_regions", "merge_sites", "call_consensus", "snp_matrix", "distance", "snp_reference")
+_MAX_MESSAGE = 1 << 30
+
+
+def default_dir():
+    import tempfile
+    return os.path.join(tempfile.gettempdir(), "snpgpu-%d" % os.getuid(), "service")
+
+
+def service_dir():
+    """The socket directory the environment asks for, or None when the service is off."""
+    v = os.environ.get("SNPGPU_SERVICE", "")
+    if v in ("", "0", "off", "no", "false"):
+        return None
+    return default_dir() if v in ("auto", "1", "on", "yes", "true") else v
+
+
+def _send(conn, obj):
+    data = json.dumps(obj).encode("utf-8")
+    conn.sendall(struct.pack("<Q", len(data)) + data)
+
+
+def _recv_exact(conn, n):
+    parts = []
+    while n:
+        b = conn.recv(min(n, 1 << 20))
+        if not b:
+            raise EOFError("connection closed")
+        parts.append(b)
+        n -= len(b)
+    return b"".join(parts)
+
+
+def _recv(conn):
+    (n,) = struct.unpack("<Q", _recv_exact(conn, 8))
+    if n > _MAX_MESSAGE:
+        raise ValueError("message too long")
+    return json.loads(_recv_exact(conn, n).decode("utf-8"))
+
+
+def _sockets(directory):
+    try:
+        return sorted(os.path.join(directory, n) for n in os.listdir(directory) if n.startswith("dev") and n.endswith(".sock"))
+    except OSError:
+        return []
+
+
+def _connect(path, timeout=None):
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    try:
+        if timeout is not None:
+            s.settimeout(timeout)
+        s.connect(path)
+        s.settimeout(None)
+        return s
+    except (OSError, socket.error):
+        s.close()
+        return None
+
+
+# ---- client ----------------------------------------------------------------------------------------------------------------
+def _spawn(directory):
+    """Start the service (detached) unless somebody else is doing so, and wait until a socket answers."""
+    import fcntl
+    import subprocess
+    os.makedirs(directory, mode=0o700, exist_ok=True)
+    with open(os.path.join(directory, "spawn.lock"), "a+") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)                     # one starter; the others wait here and then find the sockets
+        try:
+            if any(_probe(p) for p in _sockets(directory)):
+                return
+            script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "cfsan_snp_pipeline")
+            env = dict(os.environ)
+            env.pop("SNPGPU_SERVICE", None)                  # the server itself works in-process
+            with open(os.devnull, "r+b") as null, open(os.path.join(directory, "server.log"), "ab") as log:
+                subprocess.Popen([sys.executable, script, "serve", "--socketDir", directory, "--idleTimeout", os.environ.get("SNPGPU_SERVICE_IDLE", "300")],
+                                 stdin=null, stdout=log, stderr=log, start_new_session=True, env=env, cwd="/")
+            deadline = time.time() + float(os.environ.get("SNPGPU_SERVICE_START_TIMEOUT", "60"))
+            while time.time() < deadline:
+                if os.path.exists(os.path.join(directory, "ready")) and any(_probe(p) for p in _sockets(directory)):
+                    return
+                time.sleep(0.02)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _probe(path):
+    s = _connect(path, timeout=1.0)
+    if s is None:
+        return False
+    try:
+        _send(s, {"ping": True})
+        return bool(_recv(s).get("pong"))
+    except (OSError, EOFError, ValueError):
+        return False
+    finally:
+        s.close()
+
+
+def try_client(argv):
+    """Run ``argv`` (the arguments after the program name) through the service.  Returns the exit code, or None when the
+    request was not served (service off, subcommand not served, no server reachable): the caller then works in-process."""
+    directory = service_dir()
+    if directory is None or not argv or argv[0] not in SERVED:
+        return None
+    socks = _sockets(directory)
+    if not socks and (os.environ.get("SNPGPU_SERVICE", "") in ("auto", "1", "on", "yes", "true") or os.environ.get("SNPGPU_SERVICE_SPAWN") == "1"):
+        _spawn(directory)
+        socks = _sockets(directory)
+    if not socks:
+        return None
+    # samples spread over the workers (one per GPU) by what they work on; a dead worker's neighbours take over
+    start = sum(bytearray((os.getcwd() + "\0" + "\0".join(argv)).encode("utf-8", "surrogateescape"))) % len(socks)
+    conn = None
+    for k in range(len(socks)):
+        conn = _connect(socks[(start + k) % len(socks)])
+        if conn is not None:
+            break
+    if conn is None:
+        return None
+    try:
+        _send(conn, {"argv": list(argv), "argv0": sys.argv[0], "cwd": os.getcwd(), "env": dict(os.environ)})
+        reply = _recv(conn)
+    except (OSError, EOFError, ValueError):
+        return None                                          # (nothing has been printed yet: the in-process path starts clean)
+    finally:
+        conn.close()
+    sys.stdout.write(reply.get("stdout", ""))
+    sys.stdout.flush()
+    sys.stderr.write(reply.get("stderr", ""))
+    sys.stderr.flush()
+    return int(reply.get("rc", 1))
+
+
+# ---- server ----------------------------------------------------------------------------------------------------------------
+def _run_request(req):
+    """One CLI invocation inside the server process, with the client's argv / cwd / environment, output captured."""
+    import io
+    import traceback
+    from . import cfsan_snp_pipeline as cli
+    saved = (os.getcwd(), dict(os.environ), list(sys.argv), sys.stdout, sys.stderr, sys.excepthook)
+    keep = {k: os.environ[k] for k in ("SNPGPU_DEVICE", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "HSA_ENABLE_IPC_MODE_LEGACY") if k in os.environ}
+    out, err = io.StringIO(), io.StringIO()
+    rc = 0
+    try:
+        os.chdir(req["cwd"])
+        os.environ.clear()
+        os.environ.update(req.get("env", {}))
+        os.environ.update(keep)
+        os.environ.pop("SNPGPU_SERVICE", None)
+        sys.argv = [req.get("argv0", "cfsan_snp_pipeline")] + list(req["argv"])
+        sys.stdout, sys.stderr = out, err
+        args = None
+        try:
+            args = cli.parse_argument_list(list(req["argv"]))
+            rc = cli.run_command_from_args(args)
+        except SystemExit as e:
+            rc = _exit_code(e, err)
+        except BaseException:                                # noqa: B902 — what the process's excepthook would have got
+            hook = getattr(args, "excepthook", None) or sys.__excepthook__
+            try:
+                hook(*sys.exc_info())
+                rc = 1
+            except SystemExit as e:
+                rc = _exit_code(e, err)
+            except BaseException:                            # noqa: B902
+                traceback.print_exc(file=err)
+                rc = 1
+    finally:
+        sys.stdout, sys.stderr, sys.excepthook = saved[3], saved[4], saved[5]
+        sys.argv = saved[2]
+        os.environ.clear()
+        os.environ.update(saved[1])
+        try:
+            os.chdir(saved[0])
+        except OSError:
+            pass
+    return {"rc": rc, "stdout": out.getvalue(), "stderr": err.getvalue()}
+
+
+def _exit_code(e, err):
+    if e.code is None:
+        return 0
+    if isinstance(e.code, int):
+        return e.code
+    err.write("%s\n" % (e.code,))
+    return 1
+
+
+def _worker(directory, device, idle_timeout):
+    """Serve requests for one GPU until told to stop or idle for too long."""
+    os.environ["SNPGPU_DEVICE"] = str(device)
+    from . import _lib
+    _lib.TORCH_FREE_OK = True
+    from . import device as devmod
+    dev = None
+    try:
+        dev = devmod.default_device()                        # the context, the staging ring and the code objects stay for all requests
+    except Exception as e:                                   # noqa: B902 — the steps that need the device will say so themselves
+        print("snpgpu service: no device %d (%s): only the host-side steps can be served" % (device, e))
+    path = os.path.join(directory, "dev%d.sock" % device)
+    if os.path.exists(path):
+        if _probe(path):
+            print("snpgpu service: device %d is already served at %s" % (device, path))
+            return 0
+        os.unlink(path)
+    srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    old = os.umask(0o177)
+    try:
+        srv.bind(path)
+    finally:
+        os.umask(old)
+    srv.listen(256)
+    srv.settimeout(idle_timeout if idle_timeout > 0 else None)
+    print("snpgpu service: device %d ready at %s" % (device, path))
+    sys.stdout.flush()
+    served = 0
+    try:
+        while True:
+            try:
+                conn, _ = srv.accept()
+            except socket.timeout:
+                print("snpgpu service: device %d idle for %g s, %d requests served: leaving" % (device, idle_timeout, served))
+                break
+            try:
+                conn.settimeout(None)
+                req = _recv(conn)
+                if req.get("ping"):
+                    _send(conn, {"pong": True, "device": device, "served": served})
+                elif req.get("stop"):
+                    _send(conn, {"stopped": True})
+                    break
+                else:
+                    _send(conn, _run_request(req))
+                    served += 1
+            except (OSError, EOFError, ValueError) as e:
+                print("snpgpu service: request dropped: %s" % e)
+            finally:
+                conn.close()
+            sys.stdout.flush()
+    finally:
+        srv.close()
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+        if dev is not None:
+            dev.close()
+    return 0
+
+
+def serve(args):
+    """Entry point of ``cfsan_snp_pipeline serve``."""
+    import subprocess
+    directory = args.socketDir or service_dir() or default_dir()
+    os.makedirs(directory, mode=0o700, exist_ok=True)
+    if args.stop:
+        for p in _sockets(directory):
+            s = _connect(p, timeout=1.0)
+            if s is not None:
+                try:
+                    _send(s, {"stop": True})
+                    _recv(s)
+                except (OSError, EOFError, ValueError):
+                    pass
+                finally:
+                    s.close()
+        return
+    if args.device is not None:
+        _worker(directory, int(args.device), float(args.idleTimeout))
+        return
+    from . import _lib
+    _lib.TORCH_FREE_OK = True
+    from . import device as devmod
+    n = max(1, devmod.device_count())
+    ready = os.path.join(directory, "ready")
+    if os.path.exists(ready):
+        os.unlink(ready)
+    if n == 1:                                               # one GPU: this process is the worker
+        with open(ready, "w") as f:
+            f.write("1\n")
+        _worker(directory, 0, float(args.idleTimeout))
+        return
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "cfsan_snp_pipeline")
+    kids = [subprocess.Popen([sys.executable, script, "serve", "--socketDir", directory, "--idleTimeout", str(args.idleTimeout), "--device", str(i)])
+            for i in range(n)]
+    with open(ready, "w") as f:
+        f.write("%d\n" % n)
+    for k in kids:
+        k.wait()
+
+
+def add_arguments(sub):
+    sub.add_argument("--socketDir", dest="socketDir", type=str, default=None, metavar="DIR", help="Directory of the service's unix sockets (default: $SNPGPU_SERVICE, or a per-user directory under the temporary directory)")
+    sub.add_argument("--device", dest="device", type=int, default=None, metavar="INT", help="Serve this GPU only (default: one worker process per visible GPU)")
+    sub.add_argument("--idleTimeout", dest="idleTimeout", type=float, default=0, metavar="SECONDS", help="Leave after this long without a request (0 = never)")
+    sub.add_argument("--stop", dest="stop", action="store_true", help="Tell the running service to stop")

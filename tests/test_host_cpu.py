@@ -822,3 +822,69 @@ def test_mpileup2snp_files_reports_an_unwritable_vcf_per_sample_and_never_hangs(
     with pytest.raises(KeyboardInterrupt):
         varscan.mpileup2snp_files(FakeDevice(), ["p%d" % i for i in range(64)], ["v%d" % i for i in range(64)], varscan.Options(""))
     assert threading.active_count() == before
+
+
+def test_service_runs_the_cli_for_thin_clients(tmp_path, fixture_trees):
+    """SNPGPU_SERVICE: the console script hands argv / cwd / environment to the per-node server and prints / exits as the server
+    says.  Host-side steps only here (no GPU): outputs, exit codes (0, 2 for argparse, 100 for a global error with its
+    error-log entry written where the CLIENT's environment says) equal the in-process run; eight clients at once; a client
+    without a reachable server works in-process."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "bin", "cfsan_snp_pipeline")
+    sdir = str(tmp_path / "svc")
+    env0 = {k: v for k, v in os.environ.items() if k != "SNPGPU_SERVICE"}
+    server = subprocess.Popen([sys.executable, exe, "serve", "--socketDir", sdir, "--device", "0", "--idleTimeout", "60"], env=env0,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        deadline = time.time() + 60
+        while not os.path.exists(os.path.join(sdir, "dev0.sock")):
+            assert server.poll() is None and time.time() < deadline, "the server did not come up"
+            time.sleep(0.05)
+        lroot, _ = fixture_trees["lambdaVirus"]
+        ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fixtures", "lambdaVirus", "lambda_virus.fasta")
+        if not os.path.exists(ref):
+            ref = [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.dirname(lroot)) for f in fs if f.endswith(".fasta") and "lambda" in f.lower() and "snp" not in f.lower()][0]
+
+        def run(argv, service, cwd=str(tmp_path), extra_env=None):
+            env = dict(env0)
+            if service:
+                env["SNPGPU_SERVICE"] = sdir
+            env.update(extra_env or {})
+            return subprocess.run([sys.executable, exe] + argv, cwd=cwd, env=env, capture_output=True, text=True, timeout=120)
+
+        outs = {}
+        for mode in (False, True):
+            out = str(tmp_path / ("ref_%d.fasta" % mode))
+            r = run(["snp_reference", "-f", "-l", os.path.join(lroot, "snplist.txt"), "-o", out, ref], mode)
+            assert r.returncode == 0 and "snp_reference finished" in r.stdout, (r.stdout, r.stderr)
+            assert "# Working Directory : %s" % tmp_path in r.stdout                 # the client's cwd, also when the server ran it
+            outs[mode] = open(out, "rb").read()
+        assert outs[False] == outs[True] == open(os.path.join(lroot, "referenceSNP.fasta"), "rb").read()
+        # argparse error: exit 2 and the message on stderr, from the server as in-process
+        a, b = run(["snp_reference"], False), run(["snp_reference"], True)
+        assert a.returncode == b.returncode == 2 and a.stderr == b.stderr and "Error:" in b.stderr
+        # a global error: exit 100, the error log written at the CLIENT's errorOutputFile
+        for mode in (False, True):
+            log = str(tmp_path / ("error_%d.log" % mode))
+            r = run(["snp_reference", "-l", str(tmp_path / "no_such_snplist.txt"), "-o", str(tmp_path / "x.fasta"), ref], mode, extra_env={"errorOutputFile": log})
+            assert r.returncode == 100 and "does not exist" in open(log).read(), (r.returncode, r.stderr)
+        # eight clients at once
+        procs = []
+        for k in range(8):
+            env = dict(env0, SNPGPU_SERVICE=sdir)
+            procs.append(subprocess.Popen([sys.executable, exe, "snp_reference", "-f", "-v", "0", "-l", os.path.join(lroot, "snplist_preserved.txt"),
+                                           "-o", str(tmp_path / ("c%d.fasta" % k)), ref], cwd=str(tmp_path), env=env))
+        assert [p.wait(timeout=120) for p in procs] == [0] * 8
+        want = open(os.path.join(lroot, "referenceSNP_preserved.fasta"), "rb").read()
+        assert all(open(str(tmp_path / ("c%d.fasta" % k)), "rb").read() == want for k in range(8))
+        # no server behind the directory: in-process
+        r = run(["snp_reference", "-f", "-l", os.path.join(lroot, "snplist.txt"), "-o", str(tmp_path / "d.fasta"), ref], False, extra_env={"SNPGPU_SERVICE": str(tmp_path / "nobody")})
+        assert r.returncode == 0 and open(str(tmp_path / "d.fasta"), "rb").read() == outs[False]
+        r = subprocess.run([sys.executable, exe, "serve", "--socketDir", sdir, "--stop"], env=env0, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and server.wait(timeout=60) == 0
+    finally:
+        if server.poll() is None:
+            server.kill()

@@ -53,9 +53,26 @@ def main():
                 r = subprocess.run(cmd, capture_output=True, text=True)
                 dt = time.perf_counter() - t0
                 assert r.returncode == 0, r.stderr[-2000:]
-            print("%-26s %.2f s  (%.1f MB pileup, %d sites)" % (label, dt, n / 1e6, S))
+            print("%-26s %.3f s  (%.1f MB pileup, %d sites)" % (label, dt, n / 1e6, S))
+            if label == "fasta + consensus.vcf":                 # where the time goes (SNPGPU_TIMING=1)
+                r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, SNPGPU_TIMING="1"))
+                print("\n".join(ln for ln in r.stderr.split("\n") if ln.startswith("#")))
             if "profiled" in label:
                 print("\n".join(r.stdout.split("\n")[:45]))
+        # the same call as a thin client of the per-node service (SNPGPU_SERVICE): the first one starts the server
+        svc = os.path.join(tmp, "svc")
+        env = dict(os.environ, SNPGPU_SERVICE=svc, SNPGPU_SERVICE_SPAWN="1")
+        cmd = base + ["--vcfFileName", "consensus.vcf", os.path.join(sdir, "reads.all.pileup")]
+        times = []
+        for rep in range(6):
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+            times.append(time.perf_counter() - t0)
+            assert r.returncode == 0, r.stderr[-2000:]
+        print("through the service        first (starts the server) %.3f s, then %s s" % (times[0], " ".join("%.3f" % x for x in times[1:])))
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(env, SNPGPU_TIMING="1"))
+        print("\n".join(ln for ln in r.stderr.split("\n") if ln.startswith("#")))
+        subprocess.run([sys.executable, exe, "serve", "--socketDir", svc, "--stop"], capture_output=True, text=True)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
