@@ -84,6 +84,7 @@ class _Plan(object):
         consensus_file_dir = os.path.dirname(os.path.abspath(consensus_file_path))
         self.vcf_path = os.path.join(consensus_file_dir, args.vcfFileName) if args.vcfFileName else None
         self.excluded = None                 # the exclude VCF's (contig names, contig index, position) arrays
+        self.batch = False
 
 
 def _write_outputs(plan, dev, ss, snp_slots, res, file_flags=None):
@@ -128,14 +129,22 @@ def _record_metrics(plan, res, consensus):
     (collect_metrics.py:325-340) and re-reads the consensus FASTA to count its gaps (:109-128) — both fall out of this step.
     They are recorded in the sample's metrics file under the names collect_metrics uses; when that file is newer than the
     pileup / the FASTA, the reference's collect_metrics takes them from there (:318-321, :441-447) and skips the re-reads.
-    The preserved flow (an exclude file was given) records missingPosPreserved."""
+    The preserved flow (an exclude file was given) records missingPosPreserved.  An EXISTING metrics file keeps its
+    modification time (collect_metrics judges every metric by the file's age: a touched file would make its other, possibly
+    stale values look fresh), so the by-products only save the re-reads where this step creates the file or the file was
+    fresh already; the update itself is serialised by a lock file (the two flows of a sample may run at the same time)."""
     args = plan.args
-    path = args.amdMetricsFile or os.path.join(os.path.dirname(os.path.abspath(plan.pileup_path)), "metrics")
+    sample_dir = os.path.dirname(os.path.abspath(plan.pileup_path))
+    path = args.amdMetricsFile or os.path.join(sample_dir, "metrics")
+    if plan.batch and args.amdMetricsFile:                  # in a batch the option is a NAME inside each sample directory, like -o / -e
+        path = os.path.join(sample_dir, os.path.basename(args.amdMetricsFile))
     updates = {("missingPosPreserved" if plan.exclude_path else "missingPos"): str(consensus.count("-"))}
     reference_length = sum(utils.read_fasta_lengths(args.amdMetricsRefFasta).values())
     if res.depth_sum > 0 and reference_length > 0:
         updates["avePileupDepth"] = "%.2f" % (float(res.depth_sum) / float(reference_length))
-    utils.update_properties(path, updates)
+    # the file keeps its modification time: collect_metrics (collect_metrics.py:318-321, :441-447) would otherwise take every
+    # OTHER value already in it for fresh, also after the BAM or the VCF was rebuilt
+    utils.update_properties(path, updates, keep_mtime=True)
 
 
 def call_consensus(args):
@@ -208,6 +217,7 @@ def call_consensus_batch(args):
     for d in sample_dirs:
         plan = _Plan(args, os.path.join(d, args.pileupName), os.path.join(d, args.consensusFile),
                      os.path.join(d, args.excludeFile) if args.excludeFile else None)
+        plan.batch = True
         if utils.verify_non_empty_input_files("Pileup file", [plan.pileup_path]) > 0:
             utils.sample_error("Error: cannot call consensus without the pileup file.", continue_possible=True)
             failed += 1

@@ -79,6 +79,7 @@ def call_sites(args):
         verbose_print("# Create vcf file")
         verbose_print("# %s mpileup2snp (device) %s --output-vcf 1 %s" % (utils.timestamp(), pileup_file, extra))
         from .device import default_device
+        open(vcf_file, "w").close()                          # as command.run does for its target: a failed pass leaves no stale var.flt.vcf behind
         n_lines, n_rows = varscan.mpileup2snp(default_device(), pileup_file, vcf_file, opts)
         verbose_print("# %d pileup lines, %d variant sites" % (n_lines, n_rows))
         _sample_error_on_missing_file(vcf_file, "VarScan")

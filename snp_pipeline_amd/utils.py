@@ -145,17 +145,26 @@ def sample_error(message, continue_possible=False):
 
 
 def _log_exception(exc_type, exc_value, exc_traceback):
+    """The part the two exception hooks of the reference share (utils.py:629-700): an entry in the error log, the trace on
+    stderr — or, for a failed external program (subprocess.CalledProcessError: samtools in call_sites), its command line."""
+    import subprocess
+    external_program_command = exc_value.cmd if exc_type == subprocess.CalledProcessError else None
     path = os.environ.get("errorOutputFile")
     if path:
         entries = traceback.extract_tb(exc_traceback)
         file_name, line_number, function_name, code_text = entries[-1] if entries else ("?", 0, "?", "")
-        _append_error_log([
-            "Error detected while running %s." % program_name_with_command(), "",
-            "The command line was:", "    %s" % command_line_short(), "",
-            "%s exception in function %s at line %d in file %s" % (exc_type.__name__, function_name, line_number, file_name),
-            "    %s" % code_text, "=" * 80])
+        head = ["Error detected while running %s." % program_name_with_command(), "", "The command line was:", "    %s" % command_line_short(), ""]
+        if external_program_command:
+            body = ["The error occured while running:", "    %s" % external_program_command]
+        else:
+            body = ["%s exception in function %s at line %d in file %s" % (exc_type.__name__, function_name, line_number, file_name), "    %s" % code_text]
+        _append_error_log(head + body + ["=" * 80])
     sys.stdout.flush()
-    traceback.print_exception(exc_type, exc_value, exc_traceback)
+    if external_program_command:
+        print("Error occured while running:", file=sys.stderr)
+        print("    %s" % external_program_command, file=sys.stderr)
+    else:
+        traceback.print_exception(exc_type, exc_value, exc_traceback)
 
 
 def handle_global_exception(exc_type, exc_value, exc_traceback):
@@ -366,8 +375,24 @@ def write_fasta_record(handle, record_id, sequence, width=60):
 
 
 # ---- the per-sample metrics file (name=value properties, utils.py:323-380 of the reference reads it back) ---------------
-def update_properties(prop_file_path, updates):
-    """Set ``name=value`` lines in a properties file, keeping every other line; the file is created when missing."""
+def update_properties(prop_file_path, updates, keep_mtime=False):
+    """Set ``name=value`` lines in a properties file, keeping every other line; the file is created when missing.  The
+    read-modify-write runs under an exclusive lock on ``<file>.lock`` (the regular and the preserved call_consensus job of one
+    sample may get here at the same time); keep_mtime: an existing file keeps its modification time, so that make-style
+    consumers (collect_metrics decides per metric with target_needs_rebuild) do not take its OTHER values for fresh."""
+    import fcntl
+    with open(prop_file_path + ".lock", "a") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            before = os.stat(prop_file_path) if (keep_mtime and os.path.isfile(prop_file_path)) else None
+            _update_properties_unlocked(prop_file_path, updates)
+            if before is not None:
+                os.utime(prop_file_path, ns=(before.st_atime_ns, before.st_mtime_ns))
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _update_properties_unlocked(prop_file_path, updates):
     lines = []
     if os.path.isfile(prop_file_path):
         with open(prop_file_path, "r") as f:

@@ -888,3 +888,56 @@ def test_service_runs_the_cli_for_thin_clients(tmp_path, fixture_trees):
     finally:
         if server.poll() is None:
             server.kill()
+
+
+def test_exception_hooks_and_metrics_update_follow_the_reference(tmp_path, monkeypatch, capsys):
+    """(1) a failed external program (subprocess.CalledProcessError — samtools in call_sites) is logged with its command
+    line, not with a Python trace (utils.py:629-700 of the reference); (2) updating an EXISTING metrics file keeps its
+    modification time, a new one is created, and concurrent updates do not lose each other."""
+    import subprocess
+    import threading
+    import time
+    from snp_pipeline_amd import utils
+    log = tmp_path / "error.log"
+    monkeypatch.setenv("errorOutputFile", str(log))
+    monkeypatch.setenv("StopOnSampleError", "false")
+    monkeypatch.setattr("sys.argv", ["cfsan_snp_pipeline", "call_sites", "ref.fasta", "sample1"])
+    try:
+        raise subprocess.CalledProcessError(1, "samtools mpileup -f ref.fasta reads.bam")
+    except subprocess.CalledProcessError:
+        import sys
+        with pytest.raises(SystemExit) as ei:
+            utils.handle_sample_exception(*sys.exc_info())
+    assert ei.value.code == 98
+    text = log.read_text()
+    assert "Error detected while running cfsan_snp_pipeline call_sites." in text
+    assert "The error occured while running:\n    samtools mpileup -f ref.fasta reads.bam\n" in text and "exception in function" not in text
+    err = capsys.readouterr().err
+    assert "Error occured while running:\n    samtools mpileup -f ref.fasta reads.bam" in err and "Traceback" not in err
+    try:
+        raise KeyError("x")
+    except KeyError:
+        import sys
+        with pytest.raises(SystemExit) as ei:
+            utils.handle_global_exception(*sys.exc_info())
+    assert ei.value.code == 100 and "KeyError exception in function test_exception_hooks" in log.read_text()
+    capsys.readouterr()
+    # metrics
+    m = tmp_path / "metrics"
+    m.write_text("sample=s1\naveInsertSize=250\n")
+    old = time.time() - 5000
+    os.utime(str(m), (old, old))
+    utils.update_properties(str(m), {"missingPos": "7"}, keep_mtime=True)
+    assert m.read_text() == "sample=s1\naveInsertSize=250\nmissingPos=7\n" and abs(os.stat(str(m)).st_mtime - old) < 1e-3
+    utils.update_properties(str(m), {"missingPos": "8"})
+    assert os.stat(str(m)).st_mtime > old + 1000
+    fresh = tmp_path / "metrics_new"
+    utils.update_properties(str(fresh), {"avePileupDepth": "31.20"}, keep_mtime=True)
+    assert fresh.read_text() == "avePileupDepth=31.20\n"
+    threads = [threading.Thread(target=utils.update_properties, args=(str(fresh), {"k%d" % i: str(i)}), kwargs={"keep_mtime": True}) for i in range(16)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    got = dict(ln.split("=") for ln in fresh.read_text().splitlines())
+    assert got == dict([("avePileupDepth", "31.20")] + [("k%d" % i, str(i)) for i in range(16)])
