@@ -118,6 +118,56 @@ def classify_records(dev, sites, regions):
     return dev.in_regions(lut[cidx], pos.astype(np.int64, copy=False), reg_off, rs, re_)
 
 
+def removed_flags(dev, contigs, contig_lengths, rec_sample, rec_cid, rec_pos, n_samples, edge_length, max_snps_list, window_list, per_sample=False):
+    """The whole region step for ALL samples at once, on arrays (10 000 samples x 1 500 records at BASELINE configs[4]: no Python
+    loop per sample, three device calls in total).  Records of the samples that take part (outgroup samples left out), grouped
+    by sample: rec_sample (index 0 .. n_samples-1, non-decreasing), rec_cid (index into `contigs`), rec_pos.  Returns the
+    removed flag of every record: it lies in a bad region of its contig — contig edges (filter_regions.py:416-422), dense windows
+    (find_dense_regions :17-71) — of any sample (mode all) or of its own sample (mode each)."""
+    n = len(rec_pos)
+    if n == 0:
+        return np.zeros(0, dtype=bool)
+    n_c = max(1, len(contigs))
+    rec_sample = np.asarray(rec_sample, dtype=np.int64)
+    rec_cid64 = np.asarray(rec_cid, dtype=np.int64)
+    rec_pos = np.asarray(rec_pos, dtype=np.int64)
+    # one segment per (sample, contig): records in file order inside (the device sorts the positions of a segment itself)
+    key = rec_sample * n_c + rec_cid64
+    order = None
+    if (key[1:] < key[:-1]).any():                            # a VCF whose contigs are interleaved: group them, file order kept
+        order = np.argsort(key, kind="stable")
+        key = key[order]
+    cuts = np.flatnonzero(key[1:] != key[:-1]) + 1
+    seg_start = np.concatenate(([0], cuts))
+    seg_off = np.concatenate((seg_start, [n])).astype(np.uint32)
+    seg_key = key[seg_start]
+    seg_cid = seg_key % n_c
+    seg_group = (seg_key if per_sample else seg_cid).astype(np.int64)        # mode each: (sample, contig); mode all: contig
+    flat = rec_pos if order is None else rec_pos[order]
+    cs, ce, cseg = dev.dense_windows(flat, seg_off, max_snps_list, window_list)
+    # contig-edge intervals, once per group that has records
+    groups, first = np.unique(seg_group, return_index=True)
+    lengths = np.asarray([contig_lengths.get(c, UNKNOWN_CONTIG_LENGTH) for c in contigs] + [UNKNOWN_CONTIG_LENGTH], dtype=np.int64)
+    g_len = lengths[seg_cid[first]]
+    whole = g_len <= 2 * edge_length
+    eg = np.concatenate((groups, groups[~whole]))
+    es = np.concatenate((np.zeros(len(groups), np.int64), (g_len - edge_length)[~whole]))
+    ee = np.concatenate((np.where(whole, g_len, edge_length), g_len[~whole]))
+    # dense group ids for the device (uint32): rank among the groups present
+    rank_of_seg = np.searchsorted(groups, seg_group)
+    g_all = np.concatenate((np.searchsorted(groups, eg), rank_of_seg[cseg])).astype(np.uint32)
+    mg, ms, me = dev.merge_regions(g_all, np.concatenate((es, cs)), np.concatenate((ee, ce)))
+    reg_off = np.zeros(len(groups) + 1, dtype=np.uint32)
+    np.cumsum(np.bincount(mg, minlength=len(groups)), out=reg_off[1:])
+    rec_group = np.repeat(rank_of_seg, np.diff(seg_off.astype(np.int64))).astype(np.uint32)
+    flags = dev.in_regions(rec_group, flat, reg_off, ms, me)
+    if order is not None:
+        out = np.empty(n, dtype=bool)
+        out[order] = flags
+        return out
+    return flags
+
+
 _STRUCTURED = ("##INFO=", "##FORMAT=", "##FILTER=", "##ALT=", "##contig=")
 
 
@@ -132,10 +182,30 @@ def reorder_header(header_lines):
     return out
 
 
-def _write_vcf(path, header, data_lines):
+class DataLines(object):
+    """The data lines of a plain VCF as ONE byte array plus the line lengths (1 500 lines per file, 10 000 files: no Python
+    object per line).  ``select(keep)`` is the text of the lines `keep` marks, in file order."""
+
+    def __init__(self, data, lengths):
+        self.data, self.lengths = data, lengths
+
+    def __len__(self):
+        return len(self.lengths)
+
+    def select(self, keep):
+        return self.data[np.repeat(np.asarray(keep, dtype=bool), self.lengths)].tobytes()
+
+
+def _write_vcf(path, header, data_lines, keep=None):
+    """header lines + the data lines `keep` marks (all of them when None)."""
+    if isinstance(data_lines, DataLines):
+        with open(path, "wb") as f:
+            f.write("".join(header).encode("ascii"))
+            f.write(data_lines.data.tobytes() if keep is None else data_lines.select(keep))
+        return
     with open(path, "w") as f:
         f.writelines(header)
-        f.writelines(data_lines)
+        f.writelines(data_lines if keep is None else itertools.compress(data_lines, np.asarray(keep, dtype=bool).tolist()))
 
 
 def write_outgroup_preserved_and_removed_vcf_files(vcf_file_path, header):
@@ -156,14 +226,14 @@ def write_preserved_and_removed_vcf_files(vcf_file_path, header, data_lines, rem
     removed = vcf_file_path[:-4] + "_removed.vcf"
     hdr = reorder_header(header)
     try:
-        _write_vcf(preserved, hdr, itertools.compress(data_lines, (~np.asarray(removed_flags, dtype=bool)).tolist()))
+        _write_vcf(preserved, hdr, data_lines, ~np.asarray(removed_flags, dtype=bool))
     except (IOError, OSError):
         if os.path.exists(preserved):
             os.remove(preserved)
         utils.sample_error("Error: Cannot create the file for preserved SNPs: %s." % preserved, continue_possible=True)
         return
     try:
-        _write_vcf(removed, hdr, itertools.compress(data_lines, np.asarray(removed_flags, dtype=bool).tolist()))
+        _write_vcf(removed, hdr, data_lines, np.asarray(removed_flags, dtype=bool))
     except (IOError, OSError):
         if os.path.exists(removed):
             os.remove(removed)
@@ -174,6 +244,20 @@ def _read_vcf(vcf_path):
     """(header lines, data lines, sites as arrays): the columns come from the library's reader (utils.read_vcf_site_arrays), the
     lines from one readlines(); a file outside the reader's plain case is read by utils.read_vcf_sites, line by line."""
     names, cidx, pos = utils.read_vcf_site_arrays(vcf_path)     # raises IOError for data before the header, like PyVCF3's Reader
+    # the plain case on bytes: ASCII, "\n" line ends, the header first, one record per remaining line
+    with open(vcf_path, "rb") as f:
+        raw = f.read()
+    if raw.isascii() and b"\r" not in raw and len(raw):
+        arr = np.frombuffer(raw, dtype=np.uint8)
+        starts = np.concatenate(([0], np.flatnonzero(arr == 10) + 1))
+        if starts[-1] == len(arr):
+            starts = starts[:-1]
+        is_header = arr[starts] == 35                          # '#'
+        n_header = int(np.count_nonzero(is_header))
+        if is_header[:n_header].all() and len(starts) - n_header == len(pos):
+            first = int(starts[n_header]) if n_header < len(starts) else len(arr)
+            lengths = np.diff(np.concatenate((starts[n_header:], [len(arr)])))
+            return raw[:first].decode("ascii").splitlines(True), DataLines(arr[first:], lengths), (names, cidx, pos)
     with open(vcf_path, "r") as f:
         lines = f.readlines()
     header = [ln for ln in lines if ln.startswith("#")]
@@ -268,14 +352,22 @@ def filter_regions(args):
             continue
         parsed.append((vcf_path, header, data_lines, sites))
 
-    site_lists = [p[3] for p in parsed]
-    if filter_across_samples:
-        regions = compute_bad_regions(dev, site_lists, contig_length_dict, edge_length, max_num_snps_list, window_size_list)
-        for vcf_path, header, data_lines, sites in parsed:
-            if need_rebuild[vcf_path]:
-                write_preserved_and_removed_vcf_files(vcf_path, header, data_lines, classify_records(dev, sites, regions))
-    else:
-        per_sample = compute_bad_regions(dev, site_lists, contig_length_dict, edge_length, max_num_snps_list,
-                                         window_size_list, per_sample=True)
-        for (vcf_path, header, data_lines, sites), regions in zip(parsed, per_sample):
-            write_preserved_and_removed_vcf_files(vcf_path, header, data_lines, classify_records(dev, sites, regions))
+    # every record of every sample that takes part, as arrays over one table of contig names
+    contigs = sorted({c for _, _, _, (names, _, _) in parsed for c in names})
+    cid = {c: i for i, c in enumerate(contigs)}
+    cidx_all, pos_all, counts = [], [], []
+    for _, _, _, (names, cidx, pos) in parsed:
+        lut = np.asarray([cid[c] for c in names] + [0], dtype=np.int64)
+        cidx_all.append(lut[cidx.astype(np.int64)])
+        pos_all.append(np.asarray(pos, dtype=np.int64))
+        counts.append(len(pos))
+    n_rec = int(sum(counts))
+    rec_sample = np.repeat(np.arange(len(parsed), dtype=np.int64), counts)
+    removed = removed_flags(dev, contigs, contig_length_dict, rec_sample, np.concatenate(cidx_all) if n_rec else np.zeros(0, np.int64),
+                            np.concatenate(pos_all) if n_rec else np.zeros(0, np.int64), len(parsed), edge_length, max_num_snps_list,
+                            window_size_list, per_sample=not filter_across_samples)
+    at = 0
+    for (vcf_path, header, data_lines, _), k in zip(parsed, counts):
+        if need_rebuild[vcf_path]:
+            write_preserved_and_removed_vcf_files(vcf_path, header, data_lines, removed[at:at + k])
+        at += k

@@ -79,6 +79,7 @@ class _Comm(object):
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.one_gpu = os.environ.get("SNPGPU_PIPELINE_ONE_GPU") == "1"      # functional tests: all ranks on device 0 over gloo
         self.dist = None
+        self.owns_group = False
         if self.one_gpu:
             self.local_rank = 0
         if self.world > 1:
@@ -90,7 +91,14 @@ class _Comm(object):
                     dist.init_process_group("gloo")
                 else:
                     dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+                self.owns_group = True
             self.dist = dist
+
+    def close(self):
+        """Leave the process group this job created (its helper threads must not outlive the interpreter's teardown)."""
+        if self.dist and self.owns_group and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+            self.owns_group = False
 
     def barrier(self):
         if self.dist:
@@ -359,15 +367,17 @@ def hot_path_batch(args):
             utils.global_error("Error: cannot open the reference fastq file, or fail to read the contigs in the reference fastq file.")
         is_out = np.asarray([s.name in outgroup for s in samples], dtype=bool)
         filt = has_vcf & ~is_out                                 # the samples that take part in the region step
-        per_sample = fr_args.mode == "each"
-        triples = [(contigs, rec_cid[rec_off[i]:rec_off[i + 1]], rec_pos[rec_off[i]:rec_off[i + 1]]) for i in np.flatnonzero(filt)]
-        regions = fr.compute_bad_regions(dev, triples, contig_lengths, fr_args.edgeLength, fr_args.maxSnpsList, fr_args.windowSizeList,
-                                         per_sample=per_sample)
-        lap("2c   of which: dense windows + region merge", t2)
+        filt_ids = np.flatnonzero(filt)
+        part_rank = np.full(n_total, -1, dtype=np.int64)
+        part_rank[filt_ids] = np.arange(len(filt_ids))
+        takes_part = filt[rec_sample]
+        lap("2c   of which: (records laid out)", t2)
         t2 = time.perf_counter()
-        removed = _classify_all(dev, regions, per_sample, np.flatnonzero(filt), contigs, rec_off, rec_cid, rec_pos, len(all_keys))
+        removed = np.zeros(len(all_keys), dtype=bool)
+        removed[takes_part] = fr.removed_flags(dev, contigs, contig_lengths, part_rank[rec_sample[takes_part]], rec_cid[takes_part], rec_pos[takes_part],
+                                               len(filt_ids), fr_args.edgeLength, fr_args.maxSnpsList, fr_args.windowSizeList, per_sample=fr_args.mode == "each")
         preserved = every & ~removed
-        lap("2d   of which: classification of the records", t2)
+        lap("2d   of which: dense windows, region merge, classification", t2)
         t2 = time.perf_counter()
         list2, excluded2 = site_union(preserved, "snplist_p")
         lap("2e   of which: preserved site union + snplist_preserved.txt", t2)
@@ -690,6 +700,7 @@ def hot_path_batch(args):
     errs = [s.error for s in mine if not s.ok]
     all_errs = comm.gather_objects(errs)
     failed = sum(len(e) for e in all_errs)
+    comm.close()                                             # (before anything that may end the process: sample_error exits when StopOnSampleError says so)
     for msg in errs:
         utils.sample_error(msg, continue_possible=True)
     if failed:
@@ -713,36 +724,6 @@ def _fasta_bytes(name, seq):
     if tail:
         out += seq[full * 60:].tobytes() + b"\n"
     return head + out
-
-
-def _classify_all(dev, regions, per_sample, filt_ids, contigs, rec_off, rec_cid, rec_pos, n_records):
-    """utils.in_region for every record of every filtered sample in ONE device call: group = contig (mode all) or
-    (sample, contig) (mode each).  Returns the removed flag per record of the job (False for outgroup / missing samples)."""
-    removed = np.zeros(n_records, dtype=bool)
-    if len(filt_ids) == 0:
-        return removed
-    n_c = len(contigs)
-    region_dicts = regions if per_sample else [regions]
-    reg_off = np.zeros(len(region_dicts) * n_c + 1, dtype=np.uint32)
-    rs, re_ = [], []
-    g = 0
-    for rd in region_dicts:
-        for c in contigs:
-            for a, b in rd.get(c, ()):
-                rs.append(a)
-                re_.append(b)
-            g += 1
-            reg_off[g] = len(rs)
-    idx = np.concatenate([np.arange(rec_off[i], rec_off[i + 1]) for i in filt_ids]) if len(filt_ids) else np.zeros(0, np.int64)
-    if len(idx) == 0:
-        return removed
-    group = rec_cid[idx].astype(np.uint32)
-    if per_sample:
-        which = np.concatenate([np.full(rec_off[i + 1] - rec_off[i], k, dtype=np.uint32) for k, i in enumerate(filt_ids)])
-        group = which * np.uint32(n_c) + group
-    flags = dev.in_regions(group, rec_pos[idx].astype(np.int64), reg_off, np.asarray(rs, dtype=np.int64), np.asarray(re_, dtype=np.int64))
-    removed[idx] = flags
-    return removed
 
 
 def _call_scattered(dev, ss, prm, res_idx, ptrs, sizes, d_base, d_filt, d_status, d_counts, d_line, S, want_vcf, torch):

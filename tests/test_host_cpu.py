@@ -941,3 +941,68 @@ def test_exception_hooks_and_metrics_update_follow_the_reference(tmp_path, monke
         t.join()
     got = dict(ln.split("=") for ln in fresh.read_text().splitlines())
     assert got == dict([("avePileupDepth", "31.20")] + [("k%d" % i, str(i)) for i in range(16)])
+
+
+def test_library_fasta_loader_in_parallel_ranges_equals_the_line_loop(tmp_path):
+    """csrc/fasta_in.hip splits a large snpma.fasta into byte ranges, one per thread (2 GB at BASELINE configs[4]): records that
+    straddle range bounds, CR LF pairs cut by one, '>' inside sequence text, records without sequence, and a header as the
+    very last line must come out as from the line loop of distance.py:76-84 (snp_matrix.read_matrix)."""
+    import numpy as np
+    from snp_pipeline_amd import snp_matrix
+    rng = np.random.default_rng(11)
+    letters = np.frombuffer(b"ACGTacgt-N>", dtype=np.uint8)
+    for variant, eol in ((0, b"\n"), (1, b"\r\n"), (2, b"\r")):
+        parts = []
+        n_rec = 330
+        for i in range(n_rec):
+            L = int(rng.integers(0, 400_000)) if i % 7 else 0
+            parts.append(b">" * (1 + i % 3) + b"sample %05d" % i + eol)
+            if L:
+                row = rng.choice(letters, size=L, p=[.2, .2, .2, .2, .03, .03, .03, .03, .04, .03, .01])
+                width = (60, 61, 59)[variant]
+                starts = row[::width]
+                starts[starts == ord(">")] = ord("A")                 # a '>' at a line start would be a header
+                wrapped = b"".join(row[k:k + width].tobytes() + eol for k in range(0, L, width))
+                parts.append(wrapped)
+        parts.append(b">last_without_sequence")
+        data = b"".join(parts)
+        assert len(data) > 48 << 20                                   # several ranges
+        path = str(tmp_path / ("big%d.fasta" % variant))
+        with open(path, "wb") as f:
+            f.write(data)
+        want = snp_matrix.read_matrix(path)
+        ids, mat, lens = snp_matrix.load_matrix(path)
+        assert len(ids) == n_rec + 1 and len(set(ids)) == len(ids) and ids[-1] == "last_without_sequence"
+        assert mat.shape[1] == max(len(v) for v in want.values())
+        for r in (0, 1, 7, 8, 100, 163, 164, 165, 166, 200, 250, 328, 329, 330):
+            assert lens[r] == len(want[ids[r]]), (variant, r)
+            assert mat[r, :lens[r]].tobytes() == want[ids[r]].encode("latin-1"), (variant, r)
+            assert (mat[r, lens[r]:] == 0x2D).all()
+        assert [int(x) for x in lens] == [len(want[i]) for i in ids]
+        os.remove(path)
+
+
+def test_library_distance_tsv_writer_in_parallel_row_blocks(tmp_path):
+    """csrc/tsv_out.hip formats large matrices in row blocks on several threads (sizes first, then pwrite at the block's place in
+    the file): both layouts byte for byte as the print loops of distance.py:100-114 would write them, for ids of unequal
+    lengths (one of them empty, one non-ASCII) and values of 1 to 10 digits."""
+    import numpy as np
+    from snp_pipeline_amd import distance
+    rng = np.random.default_rng(4)
+    n = 2100                                                   # n * n above the single-thread threshold
+    ids = sorted(set(["s%d" % (i * 7919 % 100003) for i in range(n - 3)] + ["", "é_sample", "x" * 300]))
+    n = len(ids)
+    mat = rng.integers(0, 10 ** rng.integers(1, 10, size=(n, n)), dtype=np.int64).astype(np.int32)
+    mat[5, 7] = 2147483647
+    np.fill_diagonal(mat, 0)
+    a, b = str(tmp_path / "p.tsv"), str(tmp_path / "m.tsv")
+    distance.write_pairwise(a, ids, mat)
+    distance.write_matrix(b, ids, mat)
+    rows = mat.tolist()
+    want_p = "Seq1\tSeq2\tDistance\n" + "".join("%s\t%s\t%i\n" % (ids[i], ids[j], rows[i][j]) for i in range(n) for j in range(n))
+    want_m = "\t" + "\t".join(ids) + "\n" + "".join("%s\t%s\n" % (ids[i], "\t".join(str(v) for v in rows[i])) for i in range(n))
+    assert open(a, "rb").read() == want_p.encode("utf-8")
+    assert open(b, "rb").read() == want_m.encode("utf-8")
+    # a file that cannot be created is an IOError, also on the threaded path
+    with pytest.raises(IOError):
+        distance.write_pairwise(str(tmp_path / "no_such_dir" / "p.tsv"), ids, mat)
