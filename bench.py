@@ -59,6 +59,7 @@ def parse_args():
     ap.add_argument("--skip-secondary", action="store_true")
     ap.add_argument("--site-files", type=int, default=16, help="pileup files for the site_calling row (0 = skip)")
     ap.add_argument("--skip-aux", action="store_true", help="skip the device-copy ceiling and the K3/K4 timings")
+    ap.add_argument("--shape-samples", type=int, default=64, help="samples per launch of the scan_shapes rows (0 = skip)")
     ap.add_argument("--skip-cpu-parallel", action="store_true", help="skip the one-process-per-sample CPU baseline")
     ap.add_argument("--e2e-files", type=int, default=16, help="pileup files streamed from the page cache for the end_to_end row (0 = skip)")
     ap.add_argument("--pipeline-files", type=int, default=125, help="samples of the pipeline_from_files row (0 = skip)")
@@ -75,6 +76,29 @@ def _oracle_worker(job):
         data = f.read()
     cons, _ = po.call_consensus_sites(data, [(b"synth_chr1", p) for p in positions], set(), po.CallerParams(0, 0.6, 3, 0, 0.0))
     return cons
+
+
+def effective_cores():
+    """CPUs this process may really use: the scheduler's affinity mask, capped by the cgroup's CPU quota (a container that sees
+    256 CPUs may be allowed the time of 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                words = f.read().split()
+            if path.endswith("cpu.max"):
+                if words and words[0] != "max":
+                    n = min(n, max(1, int(int(words[0]) / int(words[1]))))
+            else:
+                quota = int(words[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                    period = int(f2.read().split()[0])
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def _scratch_dir(need_bytes):
@@ -339,7 +363,7 @@ def pinned_h2d_gbps(torch, n=256 << 20, reps=8):
 
 
 def pipeline_from_files(pile, offs, sizes, refh, G, n_files, with_separate=True):
-    """The rank's shard as one job from files to files.  The sample tree is written first (page cache); a two-sample job
+    """The rank's shard as one job from files to files.  The sample tree is written first (page cache, then os.sync()); a two-sample job
     warms the process up (code objects, Python imports); then ONE run of hot_path_batch over all samples is timed — its first
     and only one, as in a real job (a second run in the same process would start by waiting for the driver to take back the
     54 GB the first one freed).  Beside it: bytes / pinned copy rate, and the separate subcommands on the same tree."""
@@ -357,10 +381,25 @@ def pipeline_from_files(pile, offs, sizes, refh, G, n_files, with_separate=True)
             pass
     if base_dir is None:
         return {"skipped": "no room for %d bytes of pileup files" % need}
+    # Device memory in its steady state: on a box fresh from boot the FIRST allocation of a stretch of device memory costs ~30 ms
+    # per GiB (64 GiB: 1.9 s) and the copies that run beside it drop to half their rate; memory that has been allocated and freed
+    # once comes back in microseconds (tools/pipeline_time.py --recycle).  A node that has run one job before is in that state.
+    t0 = time.perf_counter()
+    recycled = torch.empty(need + (4 << 30), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    t_recycle = time.perf_counter() - t0
+    n_recycled = recycled.numel()
+    del recycled
+    torch.cuda.empty_cache()
     t0 = time.perf_counter()
     tmpdir, ref_path, dirs_file, dirs, total = write_sample_tree(
         base_dir, refh, G, lambda i: pile[int(offs[i]):int(offs[i]) + sizes[i]].cpu().numpy(), n_files)
     t_tree = time.perf_counter() - t0
+    # the job reads files that sit in the page cache and have been written back, as pileups made some time before would be: without
+    # this the kernel's write-back of the 54 GB this process has just written runs beside the timed job (+0.1-0.2 s of reading)
+    t0 = time.perf_counter()
+    os.sync()
+    t_sync = time.perf_counter() - t0
     try:
         warm = os.path.join(tmpdir, "warmup")
         os.makedirs(warm)
@@ -379,7 +418,10 @@ def pipeline_from_files(pile, offs, sizes, refh, G, n_files, with_separate=True)
             "pinned_h2d_gb_per_sec": h2d, "bytes_over_pinned_h2d_seconds": ideal, "wall_over_copy_time": st["seconds"] / ideal,
             "samples_per_sec": n_files / st["seconds"], "pileup_gb_per_sec": total / st["seconds"] / 1e9,
             "phases_seconds": st["phases"], "ingest": st["ingest"], "snp_sites": st["sites"], "snp_sites_preserved": st["sites_preserved"],
-            "tree_written_in_seconds": t_tree,
+            "tree_written_in_seconds": t_tree, "tree_synced_in_seconds": t_sync,
+            "device_memory_recycled_first": {"bytes": n_recycled, "first_allocation_seconds": t_recycle,
+                                             "note": "allocated and freed once before the tree was written: the job's own allocations "
+                                                     "then take microseconds, as on a node that has run a job before"},
         }
         if with_separate:
             mine = output_digests(tmpdir, dirs)
@@ -397,6 +439,106 @@ def pipeline_from_files(pile, offs, sizes, refh, G, n_files, with_separate=True)
         return out
     finally:
         shutil.rmtree(tmpdir, ignore_errors=True)
+
+
+def scan_shapes(d, L, dev, ref, alt, G, pos, n_samples):
+    """The pileup-scan kernel on the shapes where it is weakest, measured the same way as the headline
+    (HIP events around the launches of one batched call, 3 launches after a warm-up): shallow pileups (more, shorter lines per
+    tile), a deep one, CR LF line ends, and samples of many short contigs with long names.  Each entry: bytes per launch,
+    GB/s, fraction of the HBM peak."""
+    import torch
+    out = {}
+    prm = dev.make_params(0, 0.6, 3, 0, 0.0)
+    S = len(pos)
+
+    def measure(ss, buf, offs, sizes, n_sites):
+        B = len(sizes)
+        bases = torch.empty((B, max(n_sites, 1)), dtype=torch.uint8, device="cuda")
+        filt = torch.empty((B, max(n_sites, 1)), dtype=torch.uint8, device="cuda")
+        status = torch.empty((B, 4), dtype=torch.int64, device="cuda")
+        run = lambda: d.call_consensus_batch_dev(ss, buf.data_ptr(), np.asarray(offs, dtype=np.uint64), prm, bases.data_ptr(), filt.data_ptr(),   # noqa: E731
+                                                 status.data_ptr(), sizes=np.asarray(sizes, dtype=np.uint64))
+        run()
+        torch.cuda.synchronize()
+        d.kernel_timing(True)
+        d.kernel_time_ms(0)
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        ms, n = d.kernel_time_ms(0)
+        d.kernel_timing(False)
+        st = status.cpu().numpy()
+        if (st[:, 0] != -1).any():
+            raise SystemExit("scan_shapes: the scan reported a malformed pileup")
+        nbytes = int(sum(sizes))
+        gbps = nbytes / (ms / n * 1e-3) / 1e9
+        return {"samples": B, "bytes_per_launch": nbytes, "avg_launch_ms": ms / n, "gb_per_sec": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS,
+                "lines_per_sample": int(st[0, 1]), "bases": bases}
+
+    ss1 = d.siteset([(b"synth_chr1", int(p)) for p in pos], [L.SITE_IN_SNPLIST] * S)
+    for label, depth, B in (("depth_8x", 8.0, n_samples), ("depth_15x", 15.0, n_samples), ("depth_100x", 100.0, max(1, n_samples // 4))):
+        sizes = [d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), 0, 0, mean_depth=depth) for i in range(B)]
+        offs = np.concatenate(([0], np.cumsum([(n + 255) // 256 * 256 for n in sizes])))
+        buf = torch.empty(int(offs[-1]) + 8192, dtype=torch.uint8, device="cuda")
+        for i in range(B):
+            d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), buf.data_ptr() + int(offs[i]), sizes[i], mean_depth=depth)
+        torch.cuda.synchronize()
+        r = measure(ss1, buf, offs[:-1], sizes, S)
+        r.pop("bases")
+        out[label] = r
+        del buf
+    # CR LF: one 30x sample with "\r" put in front of every "\n" (torch index arithmetic on the device), replicated
+    n = d.synth_pileup_dev(3, 0, G, ref.data_ptr(), alt.data_ptr(), 0, 0, mean_depth=30.0)
+    lf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    d.synth_pileup_dev(3, 0, G, ref.data_ptr(), alt.data_ptr(), lf.data_ptr(), n, mean_depth=30.0)
+    torch.cuda.synchronize()
+    lf = lf[:n]
+    is_nl = lf == 10
+    before = torch.cumsum(is_nl.to(torch.int32), 0, dtype=torch.int64)            # '\n' at or before i
+    crlf = torch.full((n + int(before[-1]),), 13, dtype=torch.uint8, device="cuda")
+    crlf[torch.arange(n, device="cuda") + before] = lf                           # byte i moves behind the '\r's of the '\n's up to and including it
+    del before, is_nl
+    B = max(1, n_samples // 2)
+    res = {}
+    for label, one in (("lf_same_sample", lf), ("cr_lf", crlf)):
+        step = (one.numel() + 255) // 256 * 256
+        buf = torch.empty(B * step + 8192, dtype=torch.uint8, device="cuda")
+        for i in range(B):
+            buf[i * step:i * step + one.numel()] = one
+        r = measure(ss1, buf, np.arange(B) * step, [one.numel()] * B, S)
+        res[label] = bytes(r.pop("bases")[0].cpu().numpy())
+        if label == "cr_lf":
+            out[label] = r
+        del buf
+    if res["cr_lf"] != res["lf_same_sample"]:
+        raise SystemExit("scan_shapes: CR LF consensus differs from the LF one")
+    out["cr_lf"]["same_consensus_as_lf"] = True
+    del lf, crlf
+    # many contigs: 40 x 125 kbp per sample, names of 6 to 20 bytes, every fifth contig without a site
+    C, Gc = 40, 125_000
+    refc = torch.empty(Gc + 1, dtype=torch.uint8, device="cuda")
+    d.synth_reference_dev(1, Gc, refc.data_ptr())
+    posc = np.sort(np.random.default_rng(2).choice(np.arange(51, Gc - 49), size=Gc // 100, replace=False))
+    alt_h = np.zeros(Gc + 1, dtype=np.uint8)
+    alt_h[posc] = ord("A")
+    altc = torch.from_numpy(alt_h).cuda()
+    names = [("NODE_%d_len_%d" % (c + 1, Gc)).encode() if c % 2 else ("ctg%03d" % c).encode() for c in range(C)]
+    keys = [(names[c], int(p)) for c in range(C) if c % 5 != 3 for p in posc]
+    B = max(1, n_samples // 2)
+    piece = [[d.synth_pileup_dev(3, s * C + c, Gc, refc.data_ptr(), altc.data_ptr(), 0, 0, contig=names[c]) for c in range(C)] for s in range(B)]
+    total = sum(sum(x) for x in piece)
+    buf = torch.empty(total + 8192, dtype=torch.uint8, device="cuda")
+    offs, lens, o = [], [], 0
+    for s_ in range(B):
+        offs.append(o)
+        for c in range(C):
+            o += d.synth_pileup_dev(3, s_ * C + c, Gc, refc.data_ptr(), altc.data_ptr(), buf.data_ptr() + o, piece[s_][c], contig=names[c])
+        lens.append(o - offs[-1])
+    ssc = d.siteset(keys, [L.SITE_IN_SNPLIST] * len(keys))
+    r = measure(ssc, buf, offs, lens, len(keys))
+    r.pop("bases")
+    out["contigs_40_x_125kbp"] = r
+    return out
 
 
 def _event_ms(torch, fn, reps=3):
@@ -508,40 +650,55 @@ def cpu_baseline(args, d, pile, offs, sizes, bases, pos, G, S, gpu_value, second
         "reference_probe": "BASELINE.md 2: the real reference measured 1.2e4 consensus bases/s and 1.19e6 genome-bp/s on 1 core "
                            "(survey container, 200 kbp synthetic pileup)",
     }
-    # the reference runs one call_consensus process per sample (xargs -P / run.py:710): one oracle process per sample on
-    # min(cores, 32) cores, files in the page cache
+    # the reference runs one call_consensus process per sample (xargs -P / run.py:710): one oracle process per sample, files in
+    # the page cache, at TWO process counts — half of and all of the CPUs this process may use (affinity mask and cgroup quota:
+    # the bench box shows 256 CPUs and grants the time of 16), at most 128 — so that how the rate grows with the processes is
+    # measured rather than asserted
     if not args.skip_cpu_parallel:
         import multiprocessing as mp
         import shutil
         import tempfile
         cores = os.cpu_count() or 1
-        nproc = args.cpu_procs or min(cores, 32)
-        nproc = max(1, min(nproc, B))
-        base_dir = _scratch_dir(int(sum(sizes[:nproc])))
+        usable = effective_cores()
+        n_files = max(1, min(32, B))
+        base_dir = _scratch_dir(int(sum(sizes[:n_files])))
         if base_dir is not None:
             tmpdir = tempfile.mkdtemp(prefix="snpbench_cpu_", dir=base_dir)
             try:
                 paths = []
-                for i in range(nproc):
+                for i in range(n_files):
                     path = os.path.join(tmpdir, "s%d.pileup" % i)
                     with open(path, "wb") as f:
                         f.write(pile[int(offs[i]):int(offs[i]) + sizes[i]].cpu().numpy().tobytes())
                     paths.append(path)
-                rows = bases[:nproc].cpu().numpy()
+                rows = bases[:n_files].cpu().numpy()
                 ctx_mp = mp.get_context("spawn")                     # no fork of a process that holds a HIP context
-                t1 = time.perf_counter()
-                with ctx_mp.Pool(nproc) as pool:
-                    got = pool.map(_oracle_worker, [(pth, [int(x) for x in pos]) for pth in paths])
-                t_par = time.perf_counter() - t1
+                legs = []
+                top_n = max(1, min(args.cpu_procs or usable, 128))
+                counts = sorted({max(1, top_n // 2), top_n})
+                for nproc in counts:
+                    jobs = [(paths[k % n_files], [int(x) for x in pos]) for k in range(nproc)]      # one sample per process
+                    t1 = time.perf_counter()
+                    with ctx_mp.Pool(nproc) as pool:
+                        got = pool.map(_oracle_worker, jobs, chunksize=1)
+                    t_par = time.perf_counter() - t1
+                    same = bool(all(r == bytes(rows[k % n_files]) for k, r in enumerate(got)))
+                    legs.append({"processes": nproc, "seconds": t_par, "value": nproc * S / t_par, "matches_gpu": same})
             finally:
                 shutil.rmtree(tmpdir, ignore_errors=True)
+            top = legs[-1]
             res["parallel"] = {
-                "value": nproc * S / t_par, "unit": "bases/s", "processes": nproc, "host_cores": cores,
-                "seconds": t_par, "matches_gpu": bool(all(r == bytes(rows[i]) for i, r in enumerate(got))),
-                "gpu_over_cpu": gpu_value / (nproc * S / t_par),
+                "value": top["value"], "unit": "bases/s", "processes": top["processes"], "host_cores": cores, "usable_cores": usable,
+                "seconds": top["seconds"],
+                "matches_gpu": bool(all(leg["matches_gpu"] for leg in legs)), "legs": legs,
+                "gpu_over_cpu": gpu_value / top["value"],
                 "note": "one oracle process per sample incl. process start and file read, as the reference's xargs -P does; "
-                        "both steps are linear in samples, so the whole host's rate is this x cores / processes",
+                        "legs = the same at every process count tried (the rate per process is value / processes)",
             }
+            if len(legs) > 1:
+                res["parallel"]["measured_scaling"] = {"processes": [leg["processes"] for leg in legs],
+                                                       "rate_ratio": legs[-1]["value"] / legs[0]["value"],
+                                                       "ideal_ratio": legs[-1]["processes"] / legs[0]["processes"]}
     # distance: the reference's per-pair Python loop (utils.py:1135-1165, distance.py:93-98), single process
     if args.cpu_dist_samples > 1:
         rng = np.random.default_rng(3)
@@ -666,21 +823,35 @@ def main():
     sizes_np = np.asarray(sizes, dtype=np.uint64)
     band_holder = [None]
 
-    def step():
+    PHASES = ("c1_gather_and_site_union", "scan_and_call", "pack_and_c2_row_gather", "distance_tiles", "row_band_exchange")
+    phase_events = []                                         # per timed step: len(PHASES) + 1 events on the stream the kernels run on
+
+    def step(timed=False):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(PHASES) + 1)] if timed else None
+        mark = (lambda k: ev[k].record()) if timed else (lambda k: None)
+        mark(0)
         # C1: every rank's SNP records -> the same site union on every rank (the snplist)
         keys_all, _ = sharding.all_gather_varlen(local_keys)
         samp_all, _ = sharding.all_gather_varlen(local_samp)
         d.merge_sites_dev(keys_all.data_ptr(), samp_all.data_ptr(), keys_all.numel(), u_keys.data_ptr(), u_off.data_ptr(),
                           u_car.data_ptr(), u_n.data_ptr())
+        mark(1)
         # one scan launch and one call launch for the rank's whole batch; sample i is bytes [offs[i], offs[i] + sizes[i])
         if B:
             d.call_consensus_batch_dev(ss, pile.data_ptr(), offs[:B], prm, bases.data_ptr(), filt.data_ptr(), status.data_ptr(),
                                        sizes=sizes_np)
+        mark(2)
+        if B:
             d.pack_matrix_dev(bases.data_ptr(), B, S, S, packed.data_ptr())
         # C2: RCCL all-gather of the packed rows over xGMI when world > 1 (straight into the padded matrix)
         sharding.all_gather_rows_into(packed, n_total, packed_pad)
+        mark(3)
         d.distance_packed_dev(packed_pad.data_ptr(), bands.n_padded, S, dmat.data_ptr(), rank, world)
+        mark(4)
         band_holder[0] = bands.exchange(dmat, rank)           # every rank: the complete rows of its band
+        mark(5)
+        if timed:
+            phase_events.append(ev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -695,9 +866,17 @@ def main():
     d.kernel_time_ms(0), d.kernel_time_ms(1), d.kernel_time_ms(2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(timed=True)
     barrier()
     elapsed = time.perf_counter() - t0
+    # where the step's time goes on this rank (events on the kernels' stream; with gloo the collectives are host work between
+    # them), and the slowest rank per phase
+    phase_ms = [sum(ev[k].elapsed_time(ev[k + 1]) for ev in phase_events) / max(len(phase_events), 1) for k in range(len(PHASES))]
+    phase_max = list(phase_ms)
+    if world > 1:
+        pt = torch.tensor(phase_ms, dtype=torch.float64, device="cpu" if one_gpu else "cuda")
+        dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+        phase_max = [float(x) for x in pt.tolist()]
     scan_ms, scan_n = d.kernel_time_ms(0)
     call_ms, call_n = d.kernel_time_ms(1)
     dist_ms, dist_n = d.kernel_time_ms(2)
@@ -766,7 +945,14 @@ def main():
         "kernels_ms_per_step": {"k_scan_wave": scan_ms / args.steps, "k_call_sites": call_ms / args.steps,
                                 "k_distance": dist_ms / args.steps},
         "site_union": {"records": n_records, "unique_sites": int(u_n[0]), "carriers": int(u_n[1])},
+        "phases_ms_per_step": {"rank0": dict(zip(PHASES, phase_ms)), "max_over_ranks": dict(zip(PHASES, phase_max)),
+                               "note": "device time between events on the kernels' stream, averaged over the timed steps"},
     }
+
+    # ---- the shard as ONE job from files to files (hot_path_batch); first of the side rows: the device memory it takes has not
+    #      been through the other rows' allocations and frees, as in a job of its own -------------------------------------
+    if rank == 0 and world == 1 and args.pipeline_files > 0 and B:
+        out["pipeline_from_files"] = pipeline_from_files(pile, offs, sizes, refh, G, min(args.pipeline_files, B), not args.skip_separate_steps)
 
     # ---- secondary metric: the distance step alone at configs[4] shape (kernel + row-band exchange) ------------------
     if not args.skip_secondary:
@@ -836,13 +1022,13 @@ def main():
         out["roofline"]["measured_copy_gbps_read_plus_write"] = 2 * (1 << 30) / copy_s / 1e9
         out["aux_steps_ms"] = aux_steps(d, pos, G)
 
+    # ---- the scan kernel on its weak shapes (shallow / deep pileups, CR LF, many contigs) -------------------------------
+    if rank == 0 and world == 1 and args.shape_samples > 0 and B:
+        out["scan_shapes"] = scan_shapes(d, L, dev, ref, alt, G, pos, args.shape_samples)
+
     # ---- end to end: pileup FILES in the page cache -> consensus bytes on the host, through the streamed ingestion ----
     if rank == 0 and world == 1 and args.e2e_files > 0 and B:
         out["end_to_end"] = end_to_end(d, ss, prm, pile, offs, sizes, bases, min(args.e2e_files, B), S)
-
-    # ---- the shard as ONE job from files to files (hot_path_batch) ------------------------------------------------------
-    if rank == 0 and world == 1 and args.pipeline_files > 0 and B:
-        out["pipeline_from_files"] = pipeline_from_files(pile, offs, sizes, refh, G, min(args.pipeline_files, B), not args.skip_separate_steps)
 
     # ---- phase-1 site calling on files -----------------------------------------------------------------
     if rank == 0 and world == 1 and args.site_files > 0 and B:
@@ -850,7 +1036,22 @@ def main():
 
     # ---- CPU baseline: the oracle on samples of the batch; rank 0, N = 1 -----------------------------
     if rank == 0 and world == 1 and args.cpu_samples > 0 and B:
-        out["cpu_baseline"] = cpu_baseline(args, d, pile, offs, sizes, bases, pos, G, S, value, out.get("secondary"))
+        cb = cpu_baseline(args, d, pile, offs, sizes, bases, pos, G, S, value, out.get("secondary"))
+        out["cpu_baseline"] = cb
+        # the same ratios for the rates that include the host link (files -> results), next to the HBM-resident ones
+        e2e = out.get("end_to_end", {}).get("consensus_bases_per_sec")
+        pipe = out.get("pipeline_from_files", {}).get("samples_per_sec")
+        ratios = {"note": "GPU rates that start from FILES over the CPU oracle's call_consensus rate (the pipeline row also does site calling, "
+                          "the region filter, both flows, matrices and distances in that time)"}
+        if e2e:
+            ratios["end_to_end_over_cpu_1core"] = e2e / cb["value"]
+            if "parallel" in cb:
+                ratios["end_to_end_over_cpu_parallel"] = e2e / cb["parallel"]["value"]
+        if pipe:
+            ratios["pipeline_from_files_over_cpu_1core"] = pipe * S / cb["value"]
+            if "parallel" in cb:
+                ratios["pipeline_from_files_over_cpu_parallel"] = pipe * S / cb["parallel"]["value"]
+        cb["from_files"] = ratios
 
     if rank == 0:
         print(json.dumps(out))

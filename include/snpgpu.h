@@ -290,6 +290,7 @@ typedef struct snpgpu_pileups_stats {
     double   seconds_waiting_for_device;    /* and waiting for the device (line counts, results) */
     double   reader_seconds_reading;        /* summed over the reader threads: inside pread */
     double   reader_seconds_waiting;        /* ... waiting for a staging buffer to be copied out */
+    double   seconds_preparing;             /* part of `seconds` before the first read starts: files opened and placed, staging memory */
 } snpgpu_pileups_stats;
 int  snpgpu_pileups_create(snpgpu_ctx *ctx, uint64_t budget_bytes, snpgpu_pileups **out);
 void snpgpu_pileups_destroy(snpgpu_pileups *store);

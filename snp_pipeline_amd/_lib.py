@@ -68,7 +68,7 @@ class PileupsStats(C.Structure):
     _fields_ = [("h2d_bytes", C.c_uint64), ("file_bytes", C.c_uint64), ("resident_bytes", C.c_uint64), ("budget_bytes", C.c_uint64),
                 ("n_files", C.c_uint32), ("n_resident", C.c_uint32), ("seconds", C.c_double), ("seconds_allocating", C.c_double),
                 ("seconds_waiting_for_readers", C.c_double), ("seconds_waiting_for_device", C.c_double),
-                ("reader_seconds_reading", C.c_double), ("reader_seconds_waiting", C.c_double)]
+                ("reader_seconds_reading", C.c_double), ("reader_seconds_waiting", C.c_double), ("seconds_preparing", C.c_double)]
 
 
 class ConsensusJob(C.Structure):

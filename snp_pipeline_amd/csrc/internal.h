@@ -51,7 +51,7 @@ struct snpgpu_pileups {
     uint64_t h2d_bytes = 0;             // every byte copied host -> device through this store
     uint64_t file_bytes = 0;            // sizes of the files that were ingested
     double seconds = 0, seconds_allocating = 0, seconds_waiting_for_readers = 0, seconds_waiting_for_device = 0;   // summed over the ingest calls
-    double reader_seconds_reading = 0, reader_seconds_waiting = 0;
+    double reader_seconds_reading = 0, reader_seconds_waiting = 0, seconds_preparing = 0;
 };
 
 // Device-side view of a site set.

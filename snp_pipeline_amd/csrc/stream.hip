@@ -29,6 +29,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -55,6 +56,70 @@ struct Job {
     uint64_t off, len;
     bool first, last;
     uint32_t chunk;                 // index of the chunk inside its file
+};
+
+// The files of a batch are opened by a thread of their own, a few files ahead of the readers, and each is closed by the reader
+// that reads its last piece: at most OPEN_WINDOW of them are open at a time.  Opening all of them up front is what costs: a
+// process whose descriptor table has to grow beyond its current size waits for an RCU grace period per doubling while the
+// table is shared between threads (expand_fdtable), and so does every other thread that needs a descriptor meanwhile — 0.3 s
+// for the 125 files of a job on the 256-CPU box, and the pinning of the staging memory stood still with it
+// (tools/pipeline_time.py --probe-open, tools/probe/open_stall_probe.py).  Sizes come from stat(); a file that cannot be opened, or
+// has become smaller than stat() said, is an I/O error of that file (its pieces are read as blank lines).
+struct Opener {
+    static constexpr uint32_t OPEN_WINDOW = 16;
+    std::vector<Source> *src = nullptr;
+    std::unique_ptr<std::atomic<uint8_t>[]> opened;
+    std::unique_ptr<std::atomic<uint32_t>[]> reads_left;        // pieces of the file not read yet
+    std::atomic<uint32_t> n_closed{0};
+    std::atomic<bool> stop{false};
+    std::thread th;
+
+    void open_one(Source &s) const {
+        if (s.rc != SNPGPU_OK || s.size == 0 || !s.path) return;
+        s.fd = open(s.path, O_RDONLY | O_CLOEXEC);
+        struct stat stt;
+        if (s.fd < 0 || fstat(s.fd, &stt) != 0 || !S_ISREG(stt.st_mode) || (uint64_t)stt.st_size < s.size) {
+            if (s.fd >= 0) { close(s.fd); s.fd = -1; }
+            s.rc = SNPGPU_E_IO;
+            return;
+        }
+        (void)posix_fadvise(s.fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    }
+    void run() {
+        for (size_t f = 0; f < src->size(); ++f) {
+            while (!stop.load(std::memory_order_relaxed) && f >= (size_t)n_closed.load(std::memory_order_acquire) + OPEN_WINDOW)
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            if (!stop.load(std::memory_order_relaxed)) open_one((*src)[f]);
+            opened[f].store(1, std::memory_order_release);       // (after a cancel: nobody reads any more, nobody may wait either)
+        }
+    }
+    // pieces[f]: the number of jobs of file f (each of them ends in one done_reading(f))
+    void start(std::vector<Source> *sources, const std::vector<uint32_t> &pieces) {
+        src = sources;
+        const size_t n = sources->size() ? sources->size() : 1;
+        opened.reset(new std::atomic<uint8_t>[n]);
+        reads_left.reset(new std::atomic<uint32_t>[n]);
+        for (size_t f = 0; f < sources->size(); ++f) {
+            opened[f].store(0, std::memory_order_relaxed);
+            reads_left[f].store(pieces[f], std::memory_order_relaxed);
+        }
+        try { th = std::thread(&Opener::run, this); } catch (const std::exception &) { stop.store(true); run(); stop.store(false); open_all_now(); }
+    }
+    void open_all_now() { for (auto &s : *src) open_one(s); }   // no thread to be had: everything up front after all
+    void wait(uint32_t f) const {
+        while (!opened[f].load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    void done_reading(uint32_t f) {                             // by the reader that has just read (or skipped) a piece of file f
+        if (reads_left[f].fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+        Source &s = (*src)[f];
+        if (s.fd >= 0 && s.path) { close(s.fd); s.fd = -1; }
+        n_closed.fetch_add(1, std::memory_order_release);
+    }
+    void cancel() { stop.store(true); }                         // before the readers are told to give up: none of them may wait for a file
+    void finish() {
+        stop.store(true);
+        if (th.joinable()) th.join();
+    }
 };
 
 }  // namespace
@@ -210,6 +275,7 @@ struct Shared {
     bool abort = false;
     std::atomic<uint64_t> next{0};
     uint64_t base = 0;              // the ring serves jobs [base, ...): job j uses staging[(j - base) % R]
+    Opener *opener = nullptr;       // (optional) the files are opened by another thread and closed by the last reader
 };
 
 void reader_main(snpgpu_ctx *ctx, Shared *sh, const std::vector<Job> *jobs, std::vector<Source> *src) {
@@ -230,6 +296,7 @@ void reader_main(snpgpu_ctx *ctx, Shared *sh, const std::vector<Job> *jobs, std:
         const double t_r = now_s();
         uint8_t *dst = (uint8_t *)p->staging[k % R];
         Source &s = (*src)[jb.file];
+        if (sh->opener) sh->opener->wait(jb.file);
         int err = 0;
         if (s.mem) {
             memcpy(dst, s.mem + jb.off, jb.len);
@@ -245,6 +312,7 @@ void reader_main(snpgpu_ctx *ctx, Shared *sh, const std::vector<Job> *jobs, std:
         } else {
             memset(dst, '\n', jb.len);                       // could not be opened: its result is void (rc says so)
         }
+        if (sh->opener) sh->opener->done_reading(jb.file);
         sh->ns_waiting.fetch_add((uint64_t)((t_r - t_w) * 1e9));
         sh->ns_reading.fetch_add((uint64_t)((now_s() - t_r) * 1e9));
         {
@@ -295,21 +363,20 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
     // ---- sources and jobs -------------------------------------------------------------------------------------
     uint64_t max_size = 0, total_bytes = 0;
     for (auto &s : src) {
-        if (s.path) {
-            s.fd = open(s.path, O_RDONLY | O_CLOEXEC);
+        if (s.path) {                                           // (sized here, opened by the opener thread as the readers get to it)
             struct stat stt;
-            if (s.fd < 0 || fstat(s.fd, &stt) != 0 || !S_ISREG(stt.st_mode)) {
-                if (s.fd >= 0) { close(s.fd); s.fd = -1; }
+            if (stat(s.path, &stt) != 0 || !S_ISREG(stt.st_mode)) {
                 s.rc = SNPGPU_E_IO;
                 s.size = 0;
             } else {
                 s.size = (uint64_t)stt.st_size;
-                (void)posix_fadvise(s.fd, 0, 0, POSIX_FADV_SEQUENTIAL);
             }
         }
         if (s.size > max_size) max_size = s.size;
         total_bytes += s.size;
     }
+    Opener opener;
+    auto close_all = [&]() { opener.finish(); for (auto &s2 : src) if (s2.fd >= 0) { close(s2.fd); s2.fd = -1; } };
     std::vector<Job> jobs;
     std::vector<uint32_t> chunks_of(n_files);
     uint32_t max_chunks = 1;
@@ -324,6 +391,7 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
         }
     }
     const uint64_t J = jobs.size();
+    opener.start(&src, chunks_of);                          // (the first files open while the staging memory is being pinned)
 
     // ---- resources ----------------------------------------------------------------------------------------------
     uint32_t n_readers = opts && opts->n_readers ? opts->n_readers : 0;
@@ -345,7 +413,7 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
     const size_t table_bytes = up((size_t)(max_chunks + 1) * 2 * sizeof(SampleDev), 256);
     {
         int rc = pool_ensure(ctx, chunk, n_staging, n_slots, slot_bytes, result_bytes, table_bytes);
-        if (rc) { for (auto &s : src) if (s.fd >= 0) close(s.fd); return rc; }
+        if (rc) { close_all(); return rc; }
     }
     snpgpu_stream_pool *p = ctx->pool;
     const uint64_t R = p->staging.size() < n_staging ? p->staging.size() : n_staging;   // ring actually used
@@ -366,7 +434,7 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
         const size_t o_frow = o; o += excl_off ? up(n_sites, 256) * p->slot.size() : 0;
         void *ws = nullptr;
         int rc = snpgpu_scratch(ctx, o + 256, &ws);
-        if (rc) { for (auto &s : src) if (s.fd >= 0) close(s.fd); return rc; }
+        if (rc) { close_all(); return rc; }
         char *b = (char *)ws;
         ds.tables = (SampleDev *)(b + o_tab); ds.table_stride = table_bytes;
         ds.totals = (uint64_t *)(b + o_tot); ds.site_line = (uint64_t *)(b + o_line); ds.todo_n = (uint32_t *)(b + o_todon);
@@ -382,7 +450,7 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
     {
         hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess) {
-            for (auto &s2 : src) if (s2.fd >= 0) { close(s2.fd); s2.fd = -1; }
+            close_all();
             return snpgpu_set_error(ctx, SNPGPU_E_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
         }
     }
@@ -391,14 +459,16 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
     sh.R = R;
     sh.filled.assign(J, 0);
     sh.job_err.assign(J, 0);
+    sh.opener = &opener;
     std::vector<std::thread> readers;
     try {
         for (uint32_t i = 0; i < n_readers; ++i) readers.emplace_back(reader_main, ctx, &sh, &jobs, &src);
     } catch (const std::exception &e) {                      // no thread to be had: nothing has been enqueued yet
+        opener.cancel();
         { std::lock_guard<std::mutex> lk(sh.mu); sh.abort = true; sh.next.store(J); }
         sh.cv.notify_all();
         for (auto &t : readers) t.join();
-        for (auto &s2 : src) if (s2.fd >= 0) { close(s2.fd); s2.fd = -1; }
+        close_all();
         return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "cannot start the reader threads: %s", e.what());
     }
 
@@ -531,6 +601,7 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
     }
 done:
 #undef ST_TRY
+    if (rc) opener.cancel();
     {
         std::lock_guard<std::mutex> lk(sh.mu);
         if (rc) { sh.abort = true; sh.next.store(J); }
@@ -538,7 +609,7 @@ done:
     sh.cv.notify_all();
     for (auto &t : readers) t.join();
     if (rc) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamSynchronize(p->copy_stream2); (void)hipStreamSynchronize(st); }
-    for (auto &s : src) if (s.fd >= 0) { close(s.fd); s.fd = -1; }
+    close_all();
     if (out.rc) for (uint32_t f = 0; f < n_files; ++f) out.rc[f] = src[f].rc;
     if (stats) {
         stats->bytes = total_bytes;
@@ -840,6 +911,7 @@ struct AnyOrder {
     std::atomic<uint64_t> next{0};
     uint64_t n_jobs = 0;
     std::atomic<uint64_t> ns_reading{0}, ns_waiting{0};
+    Opener *opener = nullptr;
 };
 
 void reader_any_order(snpgpu_ctx *ctx, AnyOrder *sh, const std::vector<Job> *jobs, std::vector<Source> *src) {
@@ -854,6 +926,7 @@ void reader_any_order(snpgpu_ctx *ctx, AnyOrder *sh, const std::vector<Job> *job
         int err = 0;
         if (jb.len) {
             const double t_w = now_s();
+            if (sh->opener) sh->opener->wait(jb.file);
             {
                 std::unique_lock<std::mutex> lk(sh->mu);
                 sh->cv_free.wait(lk, [&] { return sh->abort || !sh->free_bufs.empty(); });
@@ -878,6 +951,7 @@ void reader_any_order(snpgpu_ctx *ctx, AnyOrder *sh, const std::vector<Job> *job
             sh->ns_waiting.fetch_add((uint64_t)((t_r - t_w) * 1e9));
             sh->ns_reading.fetch_add((uint64_t)((now_s() - t_r) * 1e9));
         }
+        if (sh->opener) sh->opener->done_reading(jb.file);
         {
             std::lock_guard<std::mutex> lk(sh->mu);
             sh->ready.push_back(AnyOrder::Ready{j, buf, err});
@@ -896,6 +970,7 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
                    snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status, int32_t *out_rc, snpgpu_pileups *store,
                    int32_t *out_done) {
     HIP_TRY(ctx, snpgpu_enter(ctx));
+    const double t_enter = now_s();
     const size_t chunk = (size_t)16 << 20;
     std::vector<Source> src(n_files);
     uint64_t max_slot_size = 0;
@@ -908,21 +983,20 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
     for (uint32_t f = 0; f < n_files; ++f) {
         Source &s = src[f];
         s.path = paths[f];
-        s.fd = open(s.path, O_RDONLY | O_CLOEXEC);
-        struct stat stt;
-        if (s.fd < 0 || fstat(s.fd, &stt) != 0 || !S_ISREG(stt.st_mode)) {
-            if (s.fd >= 0) { close(s.fd); s.fd = -1; }
+        struct stat stt;                                        // (the file itself is opened later, by the opener thread)
+        if (stat(s.path, &stt) != 0 || !S_ISREG(stt.st_mode)) {
             s.rc = SNPGPU_E_IO;
             s.size = 0;
         } else {
             s.size = (uint64_t)stt.st_size;
-            (void)posix_fadvise(s.fd, 0, 0, POSIX_FADV_SEQUENTIAL);
         }
         bool resident = false;
         if (budget_left && s.rc == SNPGPU_OK) {
             const uint64_t need = up(s.size + 1, 256);
             if (store->used + need + PILEUP_TAIL_PAD <= store->budget) {
-                if (block_bytes.empty() || block_bytes.back() + need + PILEUP_TAIL_PAD > PILEUP_BLOCK_CAP) { block_bytes.push_back(0); store->used += PILEUP_TAIL_PAD; }
+                // (the first blocks are small — 1, 2, 4 GiB, then 8 — so that the first copy does not wait for a large allocation)
+                const uint64_t cap_now = block_bytes.size() <= 3 ? (PILEUP_BLOCK_CAP >> (4 - (block_bytes.size() ? block_bytes.size() : 1))) : PILEUP_BLOCK_CAP;
+                if (block_bytes.empty() || block_bytes.back() + need + PILEUP_TAIL_PAD > cap_now) { block_bytes.push_back(0); store->used += PILEUP_TAIL_PAD; }
                 place[f] = Placement{(uint32_t)(block_bytes.size() - 1), block_bytes.back()};
                 block_bytes.back() += need;
                 store->used += need;
@@ -943,7 +1017,9 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
         if (out_done) out_done[f] = 0;
     }
     for (auto &b : block_bytes) b += PILEUP_TAIL_PAD;
+    [[maybe_unused]] const double t_opened = now_s();
     std::vector<uint8_t *> block_ptr(block_bytes.size(), nullptr);
+    std::vector<uint8_t> block_seen(block_bytes.size(), 0);     // the issuing thread has waited for the block's allocation
     std::vector<Job> jobs;
     std::vector<uint32_t> chunks_left(n_files, 0);
     uint64_t JA = 0;                                            // jobs [0, JA): files of the prefix; [JA, J): the rest, in file order
@@ -975,7 +1051,9 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
     if (n_staging < 1) n_staging = 1;
     const size_t r_rec = 256;                                  // result block: [0] u64 status, [8] u32 records found, [48] u32 lines; records at 256
     const size_t result_bytes = r_rec + sizeof(snpgpu_varscan_site) * (size_t)capacity + 256;
-    auto close_all = [&]() { for (auto &s2 : src) if (s2.fd >= 0) { close(s2.fd); s2.fd = -1; } };
+    Opener opener;
+    auto close_all = [&]() { opener.finish(); for (auto &s2 : src) if (s2.fd >= 0) { close(s2.fd); s2.fd = -1; } };
+    opener.start(&src, chunks_left);                            // (the first files open while the staging memory is being pinned)
     const uint32_t n_slots = n_files > 1 ? 2 : 1;              // result blocks / scratch halves (/ device slots) alternate between files
     const bool any_slot = n_prefix < n_files;
     int rc = pool_ensure(ctx, chunk, n_staging, any_slot ? n_slots : 0, any_slot ? up(max_slot_size + SNPGPU_SCAN_TILE + 256, 4096) : 0,
@@ -984,10 +1062,16 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
     snpgpu_stream_pool *p = ctx->pool;
     const uint64_t R = p->staging.size() < n_staging ? p->staging.size() : n_staging;
     hipStream_t st = ctx->stream;
+    [[maybe_unused]] const double t_pool = now_s();
     {
         hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess) { close_all(); return snpgpu_set_error(ctx, SNPGPU_E_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e)); }
     }
+#ifdef SNPGPU_TUNING
+    if (getenv("SNPGPU_VARSCAN_DEBUG"))
+        fprintf(stderr, "ingest prepare: files sized and placed %.4f s, staging pool %.4f s, stream idle %.4f s\n", t_opened - t_enter,
+                t_pool - t_opened, now_s() - t_pool);
+#endif
     // Files are post-processed in the order in which they become complete ("sequence numbers"); result blocks, scratch halves
     // and device slots alternate by sequence number.
     std::vector<int64_t> seq_of(n_files, -1);
@@ -1141,18 +1225,49 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
         if (JA) {
             AnyOrder sh;
             sh.n_jobs = JA;
+            sh.opener = &opener;
             for (uint32_t i = 0; i < R; ++i) sh.free_bufs.push_back(i);
             std::vector<std::thread> readers;
             const uint32_t nr = n_readers < JA ? n_readers : (uint32_t)JA;
             try {
                 for (uint32_t i = 0; i < nr; ++i) readers.emplace_back(reader_any_order, ctx, &sh, &jobs, &src);
             } catch (const std::exception &e) {
+                opener.cancel();
                 { std::lock_guard<std::mutex> lk(sh.mu); sh.abort = true; sh.next.store(JA); }
                 sh.cv_free.notify_all();
                 for (auto &t : readers) t.join();
                 rc = snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "cannot start the reader threads: %s", e.what());
                 goto done;
             }
+            // The blocks are allocated by a helper thread, in the order in which they will be needed, while this thread copies
+            // into the ones that exist: an allocation from the driver costs ~15 ms per GiB (and many times that for memory that
+            // was freed a moment ago), about as long as the copy into it, but it does not hold up copies issued by another thread
+            // (tools/probe/alloc_dirty_probe.cpp).
+            std::mutex alloc_mu;
+            std::condition_variable alloc_cv;
+            std::vector<hipError_t> alloc_err(block_bytes.size(), hipSuccess);
+            std::vector<uint8_t> alloc_done(block_bytes.size(), 0);
+            std::atomic<bool> alloc_stop{false};
+            double alloc_thread_seconds = 0;
+            auto allocate_all = [&] {
+                (void)hipSetDevice(ctx->device);
+                for (size_t b = 0; b < block_bytes.size() && !alloc_stop.load(); ++b) {
+                    void *d = nullptr;
+                    const double ta = now_s();
+                    const hipError_t e = hipMalloc(&d, block_bytes[b]);
+                    alloc_thread_seconds += now_s() - ta;
+                    {
+                        std::lock_guard<std::mutex> lk(alloc_mu);
+                        block_ptr[b] = e == hipSuccess ? (uint8_t *)d : nullptr;
+                        alloc_err[b] = e;
+                        alloc_done[b] = 1;
+                    }
+                    alloc_cv.notify_all();
+                    if (e != hipSuccess) break;
+                }
+            };
+            std::thread allocator;
+            try { allocator = std::thread(allocate_all); } catch (const std::exception &) { allocate_all(); }      // no thread to be had: up front, here
             std::deque<uint32_t> inflight;                      // staging buffers whose copies are on their way, in issue order per stream pair
             uint64_t issued = 0;
             int rcA = SNPGPU_OK;
@@ -1184,17 +1299,21 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
                 const uint32_t f = jb.file;
                 Source &s = src[f];
                 if (rd.err && s.rc == SNPGPU_OK) s.rc = SNPGPU_E_IO;
-                if (place[f].block != ~0u && !block_ptr[place[f].block]) {
-                    void *d = nullptr;
+                if (place[f].block != ~0u && !block_seen[place[f].block]) {
+                    const uint32_t b = place[f].block;
                     const double ta = now_s();
-                    hipError_t e = hipMalloc(&d, block_bytes[place[f].block]);
+                    hipError_t e;
+                    {
+                        std::unique_lock<std::mutex> lk(alloc_mu);
+                        alloc_cv.wait(lk, [&] { return alloc_done[b] != 0 || (b > 0 && alloc_done[b - 1] && alloc_err[b - 1] != hipSuccess); });
+                        e = alloc_done[b] ? alloc_err[b] : hipErrorOutOfMemory;
+                    }
                     t_alloc += now_s() - ta;
                     if (e != hipSuccess) {
-                        rcA = snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipMalloc(%llu) for resident pileups failed: %s", (unsigned long long)block_bytes[place[f].block], hipGetErrorString(e));
+                        rcA = snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipMalloc(%llu) for resident pileups failed: %s", (unsigned long long)block_bytes[b], hipGetErrorString(e));
                         break;
                     }
-                    block_ptr[place[f].block] = (uint8_t *)d;
-                    store->blocks.push_back(d);
+                    block_seen[b] = 1;
                 }
                 if (place[f].block != ~0u) store->files[first + f].d = dest(f);
                 if (jb.len) {
@@ -1211,12 +1330,19 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
                 ++issued;
                 if (--chunks_left[f] == 0) rcA = file_complete(f);
             }
+            if (rcA) opener.cancel();
             {
                 std::lock_guard<std::mutex> lk(sh.mu);
                 if (rcA) { sh.abort = true; sh.next.store(JA); }
             }
             sh.cv_free.notify_all();
             for (auto &t : readers) t.join();
+            if (rcA) alloc_stop.store(true);
+            if (allocator.joinable()) allocator.join();
+#ifdef SNPGPU_TUNING
+            if (getenv("SNPGPU_VARSCAN_DEBUG")) fprintf(stderr, "ingest: the allocator thread spent %.3f s in hipMalloc (%zu blocks)\n", alloc_thread_seconds, block_bytes.size());
+#endif
+            for (size_t b = 0; b < block_ptr.size(); ++b) if (block_ptr[b]) store->blocks.push_back(block_ptr[b]);      // the store owns them, used or not
             ns_reading += sh.ns_reading.load();
             ns_waiting += sh.ns_waiting.load();
             if (rcA) { rc = rcA; goto done; }
@@ -1231,10 +1357,12 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
             sh.job_err.assign(J, 0);
             sh.next.store(JA);
             sh.base = JA;
+            sh.opener = &opener;
             std::vector<std::thread> readers;
             try {
                 for (uint32_t i = 0; i < n_readers; ++i) readers.emplace_back(reader_main, ctx, &sh, &jobs, &src);
             } catch (const std::exception &e) {
+                opener.cancel();
                 { std::lock_guard<std::mutex> lk(sh.mu); sh.abort = true; sh.next.store(J); }
                 sh.cv.notify_all();
                 for (auto &t : readers) t.join();
@@ -1279,6 +1407,7 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
                 if (e != hipSuccess) { rcB = snpgpu_set_error(ctx, SNPGPU_E_HIP, "copying a piece of %s failed: %s", s.path, hipGetErrorString(e)); break; }
                 if (jb.last) rcB = file_complete(f);
             }
+            if (rcB) opener.cancel();
             {
                 std::lock_guard<std::mutex> lk(sh.mu);
                 if (rcB) { sh.abort = true; sh.next.store(J); }
@@ -1302,7 +1431,8 @@ done:
     close_all();
     if (ev_count) (void)hipEventDestroy(ev_count);
     if (store) {
-        store->seconds += now_s() - t_begin;
+        store->seconds += now_s() - t_enter;
+        store->seconds_preparing += t_begin - t_enter;
         store->seconds_allocating += t_alloc;
         store->seconds_waiting_for_readers += t_read_wait;
         store->seconds_waiting_for_device += t_dev_wait;
@@ -1413,6 +1543,7 @@ int snpgpu_pileups_get_stats(const snpgpu_pileups *store, snpgpu_pileups_stats *
     out->seconds_waiting_for_device = store->seconds_waiting_for_device;
     out->reader_seconds_reading = store->reader_seconds_reading;
     out->reader_seconds_waiting = store->reader_seconds_waiting;
+    out->seconds_preparing = store->seconds_preparing;
     return SNPGPU_OK;
 }
 

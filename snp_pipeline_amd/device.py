@@ -143,6 +143,7 @@ class SiteSet(object):
             device.ctx, _ptr(self._names), _ptr(self._offs), len(contigs), _ptr(self.keys), _ptr(self.flags),
             len(self.keys), C.byref(h)))
         self.handle = h
+        device._children.add(self)                         # the library object points at the context: it must go first
 
     def __len__(self):
         return len(self.keys)
@@ -152,7 +153,8 @@ class SiteSet(object):
 
     def close(self):
         if self.handle:
-            self.device.lib.snpgpu_siteset_destroy(self.handle)
+            if self.device.ctx:                            # (a context that is gone has taken its site sets with it)
+                self.device.lib.snpgpu_siteset_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -182,6 +184,8 @@ class Device(object):
         if rc != 0:
             raise SnpGpuError(rc, "no usable gfx950 device %d (the HIP path has no CPU fallback)" % index)
         self.ctx = h
+        import weakref
+        self._children = weakref.WeakSet()                  # site sets and pileup stores of this context
 
     # ---- plumbing ------------------------------------------------------------------------------
     def _check(self, rc):
@@ -191,6 +195,8 @@ class Device(object):
 
     def close(self):
         if self.ctx:
+            for child in list(self._children):              # they hold pointers into the context: closed before it, whoever forgot
+                child.close()
             self.lib.snpgpu_ctx_destroy(self.ctx)
             self.ctx = None
 
@@ -582,6 +588,7 @@ class Pileups(object):
         h = C.c_void_p()
         device._check(device.lib.snpgpu_pileups_create(device.ctx, int(budget_bytes), C.byref(h)))
         self.handle = h
+        device._children.add(self)
 
     def ingest(self, paths, params=None, capacity=16384, done=None):
         """One streamed call over `paths`.  Returns (records array [n][capacity], counts, status [n][2], rcs); with `done`
@@ -629,7 +636,8 @@ class Pileups(object):
 
     def close(self):
         if self.handle:
-            self.device.lib.snpgpu_pileups_destroy(self.handle)
+            if self.device.ctx:
+                self.device.lib.snpgpu_pileups_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

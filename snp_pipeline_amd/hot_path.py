@@ -382,17 +382,19 @@ def hot_path_batch(args):
         list2, excluded2 = site_union(preserved, "snplist_p")
         lap("2e   of which: preserved site union + snplist_preserved.txt", t2)
         t2 = time.perf_counter()
-        # the split VCF files of this rank's samples
+        # the split VCF files of this rank's samples: written by host threads while step 3 keeps the device busy
+        split_pool = concurrent.futures.ThreadPoolExecutor(max_workers=4)
+        split_files = []
         for s in mine:
             if not s.ok:
                 continue
             vcf_path = os.path.join(s.dir, "var.flt.vcf")
             if is_out[s.index]:
-                fr.write_outgroup_preserved_and_removed_vcf_files(vcf_path, s.header)
+                split_files.append(split_pool.submit(fr.write_outgroup_preserved_and_removed_vcf_files, vcf_path, s.header))
             else:
                 s.removed = removed[rec_off[s.index]:rec_off[s.index + 1]]
-                fr.write_preserved_and_removed_vcf_files(vcf_path, s.header, s.vcf_lines, s.removed)
-        lap("2f   of which: var.flt_preserved / _removed.vcf files", t2)
+                split_files.append(split_pool.submit(fr.write_preserved_and_removed_vcf_files, vcf_path, s.header, s.vcf_lines, s.removed))
+        lap("2f   of which: var.flt_preserved / _removed.vcf files handed to writer threads", t2)
         lap("2 site union + region filter", t0)
 
         # ================================ 3: both consensus flows from one scan + call =====================================
@@ -431,6 +433,8 @@ def hot_path_batch(args):
         writer = concurrent.futures.ThreadPoolExecutor(max_workers=1)
         per_sample_bytes = max(S1, 1) + max(S2, 1) + 2 * max(S, 1) + 8 * max(S, 1) + 32 + (128 * max(S, 1) if want_vcf else 0) + 64
         group = max(1, min(256, group_bytes // per_sample_bytes))
+        if n_local >= 32:
+            group = min(group, (n_local + 1) // 2)             # at least two groups: the files of one are written while the next is on the device
         g_alloc = min(group, max(n_local, 1))
         arena_thread.join()
         h2d_extra = [0]
@@ -557,6 +561,10 @@ def hot_path_batch(args):
                 torch.cuda.current_stream().synchronize()
                 lap("3a   of which: scan + call + flows on the device", t_g)
                 t_g = time.perf_counter()
+            # per sample, for the checks below: a malformed line at a listed position?  how many listed positions have a line?
+            if S:
+                d_bad = (d_counts[:g, :S, 23] > L.ST_OK).any(dim=1) if want_vcf else ((d_filt[:g, :S] & 0x80) != 0).any(dim=1)
+                d_chk = torch.stack([d_bad.to(torch.int64), (d_line[:g, :S] != 0).sum(dim=1)], dim=1)
             hs["status"][:g].copy_(d_status[:g], non_blocking=True)
             if S1:
                 hs["base1"][:g, :S1].copy_(rows1[g0:g0 + g, :S1], non_blocking=True)
@@ -568,6 +576,7 @@ def hot_path_batch(args):
                 hs["line"][:g, :S].copy_(d_line[:g, :S], non_blocking=True)
                 if want_vcf:
                     hs["counts"][:g, :S].copy_(d_counts[:g, :S], non_blocking=True)
+            chk = d_chk.cpu().numpy() if S else np.zeros((g, 2), dtype=np.int64)      # (the stream is idle after this)
             torch.cuda.current_stream().synchronize()
             lap("3b   of which: results to the host" if args.verbose >= 2 else "3ab  of which: device work + results to the host", t_g)
             t_g = time.perf_counter()
@@ -580,15 +589,10 @@ def hot_path_batch(args):
                 if w0 != 0xFFFFFFFFFFFFFFFF:
                     s.ok, s.error = False, "Error: call_consensus failed for sample %s: malformed pileup %s at byte offset %d" % (s.name, s.pileup, (w0 >> 8) - 1)
                     continue
-                if S and want_vcf:
-                    stat = hs["counts"].numpy()[k, :S, 23]
-                    if (stat > L.ST_OK).any():
-                        s.ok, s.error = False, "Error: call_consensus failed for sample %s: malformed pileup line at a listed position" % s.name
-                        continue
-                elif S and (hs["filt1"].numpy()[k, :S] & 0x80).any():
+                if S and chk[k, 0]:
                     s.ok, s.error = False, "Error: call_consensus failed for sample %s: malformed pileup line at a listed position" % s.name
                     continue
-                if S and int(st_np[k, 2]) > int(np.count_nonzero(hs["line"].numpy()[k, :S])) and want_vcf:
+                if S and int(st_np[k, 2]) > int(chk[k, 1]) and want_vcf:
                     s.ok, s.error = False, ("Error: call_consensus failed for sample %s: its pileup repeats a position; run call_consensus "
                                             "for this sample" % s.name)
                     continue
@@ -609,6 +613,11 @@ def hot_path_batch(args):
             row_ok[callable_.index(s)] = False
         if int(d_err[0]) != 0:
             raise RuntimeError("an exclude slot fell outside the site set")
+        t_g = time.perf_counter()
+        for fu in split_files:
+            fu.result()
+        split_pool.shutdown()
+        lap("3f   of which: waiting for the split VCF files of step 2", t_g)
         lap("3 consensus, both flows", t0)
 
         # ================================ 4: matrices, distances, top-level files ==========================================
@@ -686,7 +695,7 @@ def hot_path_batch(args):
                  "files": int(st.n_files), "seconds": time.perf_counter() - t_start,
                  "ingest": {"seconds": st.seconds, "allocating": st.seconds_allocating, "waiting_for_readers": st.seconds_waiting_for_readers,
                             "waiting_for_device": st.seconds_waiting_for_device, "reader_seconds_reading": st.reader_seconds_reading,
-                            "reader_seconds_waiting": st.reader_seconds_waiting}, "phases": timings, "sites": S1, "sites_preserved": S2,
+                            "reader_seconds_waiting": st.reader_seconds_waiting, "preparing": st.seconds_preparing}, "phases": timings, "sites": S1, "sites_preserved": S2,
                  "samples": hi - lo}
         hot_path_batch.last_stats = stats
         verbose_print("# hot_path_batch rank %d: %d samples, %d pileup bytes, %d bytes copied to the device (%d files resident), %.3f s"

@@ -516,3 +516,22 @@ def test_python_int_fields(d):
     # a negative depth is an integer for the reference; the 32-bit record cannot hold it: refused loudly
     with pytest.raises(PileupFormatError):
         gpu_consensus(d, b"c1\t5\tA\t-3\t...\tIII\n", keys, [], po.CallerParams())
+
+
+def test_site_sets_and_stores_outliving_their_device_are_closed_with_it():
+    """A site set or a pileup store points into its context; closing the device first must not leave either to be
+    destroyed against freed memory later (the garbage collector runs their __del__ whenever it likes)."""
+    from snp_pipeline_amd import device as devmod
+    dev = devmod.Device(0)
+    ss = devmod.SiteSet.from_arrays(dev, [b"c1"], np.array([5, 9], dtype=np.uint64), np.array([1, 1], dtype=np.uint8))
+    store = dev.pileups(1 << 20)
+    dev.close()
+    assert ss.handle is None and store.handle is None
+    ss.close(), store.close()                               # and again: nothing left to do
+    del ss, store
+    again = devmod.Device(0)                                # the process' HIP state is intact
+    try:
+        ss2 = devmod.SiteSet.from_arrays(again, [b"c1"], np.array([5], dtype=np.uint64), np.array([1], dtype=np.uint8))
+        assert len(ss2) == 1
+    finally:
+        again.close()

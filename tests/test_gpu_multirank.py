@@ -27,7 +27,7 @@ def _free_port():
 
 def _run_bench(world, dump, extra):
     args = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--scaling", "strong", "--skip-aux", "--e2e-files", "0", "--site-files", "0",
-            "--cpu-samples", "0", "--pipeline-files", "0", "--dump", dump] + extra
+            "--cpu-samples", "0", "--pipeline-files", "0", "--shape-samples", "0", "--dump", dump] + extra
     env = dict(os.environ, SNPGPU_BENCH_TEST_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
     if world == 1:
         cmd = [sys.executable] + args

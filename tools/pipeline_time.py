@@ -31,6 +31,10 @@ def main():
     ap.add_argument("--no-vcf", action="store_true")
     ap.add_argument("--verbose", type=int, default=0)
     ap.add_argument("--dir", type=str, default=None)
+    ap.add_argument("--recycle", type=int, default=0, help="GiB of device memory allocated, touched and freed before the tree is written")
+    ap.add_argument("--sync", action="store_true", help="os.sync() after writing the tree: the run does not compete with the write-back of 54 GB")
+    ap.add_argument("--probe-open", choices=("none", "stat", "serial", "parallel"), default="none",
+                    help="before the first run: time stat / open of every pileup (what does the first open after the write cost?)")
     a = ap.parse_args()
     import torch
     from snp_pipeline_amd import device as dev
@@ -38,6 +42,14 @@ def main():
     d = dev.Device(0)
     d.use_torch_stream()
     G, S = a.genome, a.sites
+    if a.recycle:
+        t0 = time.perf_counter()
+        x = torch.empty(a.recycle << 30, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        del x
+        torch.cuda.empty_cache()
+        print("recycle: allocated %d GiB in %.3f s, freed in %.3f s" % (a.recycle, t1 - t0, time.perf_counter() - t1), file=sys.stderr)
     ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda")
     d.synth_reference_dev(1, G, ref.data_ptr())
     torch.cuda.synchronize()
@@ -64,6 +76,49 @@ def main():
     out = {"samples": a.samples, "pileup_bytes": total, "tree_seconds": time.perf_counter() - t0}
     try:
         out["pinned_h2d_gb_per_sec"] = bench.pinned_h2d_gbps(torch)
+        if a.sync:
+            t0 = time.perf_counter()
+            os.sync()
+            out["sync_seconds"] = time.perf_counter() - t0
+        if a.probe_open != "none":
+            import concurrent.futures
+            piles = [os.path.join(sd, "reads.all.pileup") for sd in dirs]
+            t0 = time.perf_counter()
+            for p in piles:
+                os.stat(p)
+            out["probe_stat_seconds"] = time.perf_counter() - t0
+            if a.probe_open == "serial":                         # whose cost is it: the file's first open anywhere, or this process'?
+                import subprocess
+                third = len(piles) // 3
+                code = "import os,sys,time\nt=time.perf_counter()\nfor p in sys.argv[1:]: os.open(p, os.O_RDONLY)\nprint((time.perf_counter()-t)/max(len(sys.argv)-1,1)*1e3)"
+                r = subprocess.run([sys.executable, "-c", code] + piles[:third], capture_output=True, text=True)
+                out["probe_open_ms_each_in_a_fresh_process"] = float(r.stdout.strip() or "nan")
+                t0 = time.perf_counter()
+                for p in piles[:third]:
+                    os.close(os.open(p, os.O_RDONLY))
+                out["probe_open_ms_each_here_after_that_process"] = (time.perf_counter() - t0) / max(third, 1) * 1e3
+                per = []
+                for p in piles[third:2 * third]:
+                    t0 = time.perf_counter()
+                    os.close(os.open(p, os.O_RDONLY))
+                    per.append((time.perf_counter() - t0) * 1e3)
+                out["probe_open_ms_each_here_first"] = [round(x, 2) for x in per[:12]]
+                t0 = time.perf_counter()
+                for p in piles[third:2 * third]:
+                    with open(p, "rb") as f:
+                        f.read(1 << 20)
+                out["probe_open_and_read_1MiB_again_ms_each"] = (time.perf_counter() - t0) / max(third, 1) * 1e3
+                piles = piles[2 * third:]
+            if a.probe_open != "stat":
+                t0 = time.perf_counter()
+                if a.probe_open == "serial":
+                    fds = [os.open(p, os.O_RDONLY) for p in piles]
+                else:
+                    with concurrent.futures.ThreadPoolExecutor(max_workers=16) as ex:
+                        fds = list(ex.map(lambda p: os.open(p, os.O_RDONLY), piles))
+                out["probe_open_seconds"] = time.perf_counter() - t0
+                for fd in fds:
+                    os.close(fd)
         runs = []
         for _ in range(a.runs):
             wall = bench.run_cli(bench.hot_path_line(dirs_file, ref_path, " --noConsensusVcf" if a.no_vcf else ""), verbose=a.verbose)

@@ -7,8 +7,8 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$round
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-short="--cpu-samples 0 --skip-aux --e2e-files 0 --pipeline-files 0"      # the default 20 steps + 3 warm-up launches, so the trace average is not dominated by the first (cold) launches
-pmc="--steps 3 --warmup 1 --cpu-samples 0 --skip-secondary --skip-aux --e2e-files 0 --site-files 0 --pipeline-files 0"
+short="--cpu-samples 0 --skip-aux --e2e-files 0 --pipeline-files 0 --shape-samples 0"      # the default 20 steps + 3 warm-up launches, so the trace average is not dominated by the first (cold) launches
+pmc="--steps 3 --warmup 1 --cpu-samples 0 --skip-secondary --skip-aux --e2e-files 0 --site-files 0 --pipeline-files 0 --shape-samples 0"
 python $root/bench.py > "$out/bench_n1.json" 2> "$out/bench_n1.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python $root/bench.py $short > "$out/trace_bench.json" 2> "$out/trace.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python $root/bench.py $pmc > /dev/null 2> "$out/pmc_fetch.err"
