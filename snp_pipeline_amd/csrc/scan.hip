@@ -13,12 +13,14 @@
 // vmcnt(0), which would serialise fetch and parse; the steady-state parse issues no other vector-memory load (the
 // site bitmap is probed through a register window), so the explicit counted wait is the only one on the path.
 // Per tile:
-//   B  each lane scans four 16-byte chunks for line terminators (SWAR, v_dot4_u32_u8 gathers byte flags into bits);
-//      a DPP prefix sum over the wave turns the per-lane counts into a list of line starts in LDS; every start is then
-//      checked to follow a '\n' (else the tile is indexed again byte by byte with the universal-newline rules)
+//   B  each lane scans four 16-byte chunks for bytes in 0x0A..0x0D (SWAR, v_dot4_u32_u8 gathers byte flags into bits); two
+//      flagged neighbours (CR LF) are told apart by reading them, so that the '\r' flags nothing; a DPP prefix sum over
+//      the wave turns the per-lane counts into a list of line starts in LDS
 //   C  one lane per line.  One-window form: with the name length L and the digit count g of the positions known, the
-//      24 bytes that end with the separator after the position hold "name SEP digits SEP" at fixed places — masked
-//      compares, SWAR digit test, dot4 decimal conversion.  General form (calibrates g, handles long names): name
+//      24 bytes that end with the separator after the position hold "\n name SEP digits SEP" at fixed places — masked
+//      compares (the '\n' in front is what makes the flagged start a line start), SWAR digit test, dot4 decimal
+//      conversion; a round in which every line fits does no other bookkeeping.  A start that does not follow '\n' is
+//      looked at bytewise: after "\r\n" split over two chunks, '\v' or '\f' there is no line; after a lone '\r' there is.  General form (calibrates g, handles long names): name
 //      window, digit window, SWAR "<= 0x20" mask + ffs for the digit count.  Then the site probe by ds_bpermute into a
 //      64-dword register window of the bitmap / rank directory.
 // A line that fits neither (other contig, another digit count, odd whitespace, > 10 digits, names > 44 bytes) is
@@ -203,8 +205,9 @@ __device__ __forceinline__ void lds_window24(const uint8_t *tile, int off, uint3
 }
 
 // What the one-window parse expects to see in the 24 bytes that END with the separator after the position, for a contig
-// name of L bytes and positions of g digits:  [.. junk ..][name, L][TAB][digits, g][TAB].  lay[0..5] name bytes and the two
-// TABs in place, lay[6..11] their byte masks, lay[12..14] byte masks of the digits in dwords 3..5.  One lane per dword.
+// name of L bytes and positions of g digits:  [.. junk ..]['\n'][name, L][TAB][digits, g][TAB].  lay[0..5] name bytes, the two
+// TABs and (when it fits: L + g <= 21) the '\n' before the line in place, lay[6..11] their byte masks, lay[12..14] byte masks of
+// the digits in dwords 3..5.  One lane per dword.
 // (Only TAB-separated lines take the one-window parse — what samtools writes; a line with other whitespace there goes
 // through the general parse or the exact parser.)
 __device__ __noinline__ void scan_layout(uint32_t *lay, const uint32_t *hint_w, uint32_t L, uint32_t g, uint32_t lane) {
@@ -220,6 +223,10 @@ __device__ __noinline__ void scan_layout(uint32_t *lay, const uint32_t *hint_w, 
         const uint32_t seps[2] = {22u - g, 23u};                  // the separators after the name and after the digits
         for (int q = 0; q < 2; ++q)
             if ((seps[q] >> 2) == lane) { w |= 9u << (8 * (seps[q] & 3)); m |= 0xFFu << (8 * (seps[q] & 3)); }
+        if (L + g <= 21u) {                                       // the byte before the line: '\n' (the start is a proper one)
+            const uint32_t pb = 21u - g - L;
+            if ((pb >> 2) == lane) { w |= 10u << (8 * (pb & 3)); m |= 0xFFu << (8 * (pb & 3)); }
+        }
         lay[lane] = w;
         lay[6 + lane] = m;
     }
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     const uint32_t *bitmap = ss.bitmap, *rank = ss.rank;
     uint32_t hits = 0, lines_seen = 0, any_hi = 0;
     unsigned long long depth_acc = 0;
-    unsigned long long t_a = 0, t_b = 0, t_c = 0, t_mark = kTime == 2 ? __builtin_readcyclecounter() : 0;
+    unsigned long long t_a = 0, t_b = 0, t_c = 0, t_s = 0, t_i = 0, t_mark = kTime == 2 ? __builtin_readcyclecounter() : 0;
     constexpr bool kStamp = kTime == 1 || kTime == 2;
     const unsigned long long rt_start = kStamp ? __builtin_amdgcn_s_memrealtime() : 0;    // 100 MHz wall clock
     unsigned long long rt_prologue = 0, rt_first = 0;
@@ -374,12 +381,13 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     // second separator.  A line whose position has another digit count fails the separator / digit tests (exactly: the
     // tests pass iff the count is g), goes to the queue, and resets g; the general path then recalibrates it.
     uint32_t g = 0, nw[6] = {0, 0, 0, 0, 0, 0}, nm[6] = {0, 0, 0, 0, 0, 0}, dmk[3] = {0, 0, 0};
-    bool fastc = false, name_split = false;
+    bool fastc = false, name_split = false, prev_in_window = false;
     auto relayout = [&]() {
         // names that do not fit in front of the digits (L > 22 - g) are checked in two pieces: their tail in the window,
         // their first 16 bytes against the hint registers of the general parse (together: names up to 38 - g bytes)
         fastc = hint_bad == 0 && g >= 1 && g <= 10 && L + g <= 38;
         name_split = L + g > 22;
+        prev_in_window = L + g <= 21;                                   // (scan_layout puts the '\n' before the line into the masks)
         if (!fastc) return;
         scan_layout(ws.lay, ws.hint_w, L, g, lane);
 #pragma unroll
@@ -452,9 +460,24 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                     }
                     S = (uint64_t)(bits[0] | (bits[1] << 16)) | ((uint64_t)(bits[2] | (bits[3] << 16)) << 32);
                 }
+                WTICK(t_s);
                 // The last byte of the sub-tile (lane 63, chunk 3, byte 15) starts a line in the NEXT sub-tile, which
                 // sees it as its byte -1; byte 0 starts a line iff the byte before it ends a terminator.
                 if (lane == 63) S &= ~(1ull << 63);
+                if (!kExact) {
+                    // CR LF files: the '\r' of a pair flags the '\n' after it as a start.  Two flagged neighbours in one 16-byte
+                    // chunk are looked at here (two byte reads per pair) and the '\r' loses its flag, so such files index and
+                    // parse like LF files; a pair across chunks keeps both flags and phase C sorts it out.
+                    uint64_t pairs = S & (S >> 1) & 0x7FFF7FFF7FFF7FFFull;
+                    if (__ballot(pairs != 0)) {
+                        while (pairs) {
+                            const uint32_t bpos = (uint32_t)__ffsll((long long)pairs) - 1;
+                            pairs &= pairs - 1;
+                            const uint32_t q = (((bpos >> 4) * 64 + lane) << 4) + (bpos & 15);
+                            if (tile[q] == 13u && tile[q + 1] == 10u) S &= ~(1ull << bpos);
+                        }
+                    }
+                }
                 const uint32_t pv0 = tile[-1], cv0 = tile[0];
                 bool s0 = (lane == 0) && (pv0 == 10u || (pv0 == 13u && cv0 != 10u));
                 uint32_t cnt, n_lines, base;
@@ -500,8 +523,12 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                     __builtin_amdgcn_wave_barrier();
                 };
                 finish_index();
-                bool redo = n_lines > SCAN_LIST_CAP || __ballot((lane == 0) && (pv0 - 11u <= 2u)) != 0;
-                if (!redo) {
+                // The fast index flags every byte in 0x0A..0x0D.  The fast parse checks each start itself (phase C: the byte
+                // before it is '\n', else the lane decides from two bytes what it is looking at); the exact instantiation
+                // checks the list here and, when a tile holds anything but "\n" and "\r\n", indexes it again byte by byte.
+                bool redo = kExact && (n_lines > SCAN_LIST_CAP || __ballot((lane == 0) && (pv0 - 11u <= 2u)) != 0);
+                if (!kExact) build_list(0);
+                else if (!redo) {
                     build_list(0);
                     // A start is proper when it follows a '\n'.  In a CR LF file every '\r' flags a second start, the '\n'
                     // that follows it: such a phantom (it follows '\r' and IS '\n') is marked in the list (bit 15) and
@@ -539,6 +566,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                     finish_index();
                 }
                 lines_seen += (lane == 0) ? n_lines : 0;
+                WTICK(t_i);
 
                 for (uint32_t pass0 = 0; pass0 < n_lines; pass0 += SCAN_LIST_CAP) {
                     if (!listed || pass0 != 0) build_list(pass0);
@@ -552,7 +580,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                         for (uint32_t j0 = 0; j0 < n_here; j0 += 64) {
                             const uint32_t j = j0 + lane;
                             const uint32_t s_raw = j < n_here ? lstart[j] : 0x8000u;        // bit 15: the '\n' of a CR LF pair, no line
-                            const bool active = (s_raw >> 15) == 0;
+                            bool active = (s_raw >> 15) == 0;
                             const uint32_t s = s_raw & 0x7FFFu;
                             uint32_t bad, pos;
                             bool big;
@@ -562,18 +590,18 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             if (fast_round) {
                                 uint32_t w[6];
                                 lds_window24(tile, (int)s + (int)(L + g) - 22, w);       // ends with the second separator
-                                // the name and both TABs in one masked compare per dword
-                                bad = ((w[0] ^ nw[0]) & nm[0]) | ((w[1] ^ nw[1]) & nm[1]) | ((w[2] ^ nw[2]) & nm[2]) |
-                                      ((w[3] ^ nw[3]) & nm[3]) | ((w[4] ^ nw[4]) & nm[4]) | ((w[5] ^ nw[5]) & nm[5]);
+                                // the '\n' before the line, the name and both TABs in one masked compare per dword
+                                uint32_t bad_name = ((w[0] ^ nw[0]) & nm[0]) | ((w[1] ^ nw[1]) & nm[1]) | ((w[2] ^ nw[2]) & nm[2]) |
+                                                    ((w[3] ^ nw[3]) & nm[3]) | ((w[4] ^ nw[4]) & nm[4]) | ((w[5] ^ nw[5]) & nm[5]);
                                 if (__builtin_amdgcn_readfirstlane((uint32_t)name_split)) {  // uniform: a long name's first 16 bytes
                                     uint32_t v0, v1, v2, v3;
                                     lds_window16(tile, (int)s, v0, v1, v2, v3);
-                                    bad |= ((v0 ^ hw[0]) & hm[0]) | ((v1 ^ hw[1]) & hm[1]) | ((v2 ^ hw[2]) & hm[2]) | ((v3 ^ hw[3]) & hm[3]);
+                                    bad_name |= ((v0 ^ hw[0]) & hm[0]) | ((v1 ^ hw[1]) & hm[1]) | ((v2 ^ hw[2]) & hm[2]) | ((v3 ^ hw[3]) & hm[3]);
                                 }
-                                if (active && bad != 0) mismatch_at = s;                 // another contig, or another digit count
-                                else if (active) nd_seen = g;
+                                if (!__builtin_amdgcn_readfirstlane((uint32_t)prev_in_window)) // uniform: the window starts with the name
+                                    bad_name |= (uint32_t)tile[(int)s - 1] ^ 10u;
                                 const uint32_t x3 = (w[3] ^ 0x30303030u) & dmk[0], x4 = (w[4] ^ 0x30303030u) & dmk[1], x5 = (w[5] ^ 0x30303030u) & dmk[2];
-                                bad |= (((x3 + 0x76767676u) | x3) | ((x4 + 0x76767676u) | x4) | ((x5 + 0x76767676u) | x5)) & 0x80808080u;
+                                bad = bad_name | ((((x3 + 0x76767676u) | x3) | ((x4 + 0x76767676u) | x4) | ((x5 + 0x76767676u) | x5)) & 0x80808080u);
                                 // decimal value: v_dot4_u32_u8 with weights 100, 10, 1 over three digits, the fourth added on top
                                 // (24-bit multiplies: v_mad_u32_u24 is full rate, the 32-bit multiplies are quarter rate)
                                 const uint32_t f3 = __umul24(__builtin_amdgcn_udot4(x3, 0x00010A64u, 0u, false), 10u) + (x3 >> 24);
@@ -582,9 +610,36 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                 // positions past 2^32 - 1 cannot be in the site set: 4294966 * 1000 + 999 still fits 32 bits
                                 big = hi7 > 4294966u;
                                 pos = __umul24(hi7, 1000u) + __builtin_amdgcn_udot4(x5, 0x00010A64u, 0u, false);
-                                if (__ballot(active && bad != 0 && nd_seen != 0)) { g = 0; fastc = false; }   // a digit count changed
+                                nd_seen = g;
+                                // Everything else only when some line of the round does not fit (one ballot in the steady state).
+                                if (__ballot(active && bad != 0)) {
+                                    // A start that does not follow '\n' (never in an LF file, every other one in a CR LF file): the
+                                    // '\n' of a "\r\n" pair and a byte after '\v' / '\f' start no line; after a lone '\r' one does
+                                    // start (universal newlines), and the exact parser takes it.
+                                    if (__ballot(active && bad_name != 0)) {
+                                        const uint32_t pv = tile[(int)s - 1], cv = tile[s];
+                                        const bool no_line = active && (pv == 13u ? cv == 10u : pv != 10u);
+                                        const uint64_t nl = __ballot(no_line);
+                                        if (nl) {
+                                            active = active && !no_line;
+                                            lines_seen -= (lane == 0) ? (uint32_t)__popcll(nl) : 0u;
+                                        }
+                                    }
+                                    if (active && bad_name != 0) { mismatch_at = s; nd_seen = 0; }   // another contig, or another digit count
+                                    if (__ballot(active && bad != 0 && bad_name == 0)) { g = 0; fastc = false; }   // a digit count changed
+                                }
                             } else {
                             bad = hint_bad;                                              // uniform: no usable hint
+                            {                                                            // is this a line start at all? (as above)
+                                const uint32_t pv = tile[(int)s - 1];
+                                if (__ballot(active && pv != 10u)) {
+                                    const uint32_t cv = tile[s];
+                                    const bool no_line = active && (pv == 13u ? cv == 10u : pv != 10u);
+                                    const uint64_t nl = __ballot(no_line);
+                                    active = active && !no_line;
+                                    lines_seen -= (lane == 0) ? (uint32_t)__popcll(nl) : 0u;
+                                }
+                            }
                             // name: masked dword compare (masks are zero past the name)
                             uint32_t w0, w1, w2, w3;
                             lds_window16(tile, (int)s, w0, w1, w2, w3);
@@ -760,7 +815,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
         unsigned long long *rec = a.dbg + 8 * gwave;
         rec[0] = rt_start; rec[1] = __builtin_amdgcn_s_memrealtime();
         rec[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);   // XCC_ID, HW_ID
-        rec[3] = t_a; rec[4] = t_b; rec[5] = t_c; rec[6] = rt_prologue; rec[7] = rt_first;
+        rec[3] = t_a; rec[4] = t_b; rec[5] = t_c; rec[6] = kTime == 2 ? t_s : rt_prologue; rec[7] = kTime == 2 ? t_i : rt_first;
     }
 #undef WTICK
     // a byte >= 0x80 anywhere in this wave's share of the file (checked once: the answers are void anyway)

@@ -18,6 +18,11 @@ sh = (hw >> 12) & 1
 se = (hw >> 13) & 7
 wait, parse, req = (r[:, k].astype(np.float64) for k in (3, 4, 5))
 print("waves %d  life us: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f" % (len(life), life.min(), *np.percentile(life, [10, 50, 90]), life.max()))
+if len(sys.argv) > 2 and sys.argv[2] == "phases":                # mode 8: rec[6], rec[7] are cycle sums of the terminator scan and the line index
+    swar, index = r[:, 6].astype(np.float64), r[:, 7].astype(np.float64)
+    tot = wait.sum() + parse.sum() + req.sum() + swar.sum() + index.sum()
+    print("cycle shares: dma-wait %.1f%%  terminator scan %.1f%%  line index %.1f%%  line parse + probe %.1f%%  next request %.1f%%"
+          % tuple(100 * x / tot for x in (wait.sum(), swar.sum(), index.sum(), parse.sum(), req.sum())))
 print("start us: max %.1f | kernel span %.1f us | phase cycles: dma-wait %.3g parse %.3g request %.3g" % (start.max(), (r[:, 1].max() - t0) * 0.01, wait.sum(), parse.sum(), req.sum()))
 for name, key in (("xcc", xcc), ("se", se), ("sh", sh), ("cu", cu), ("simd", simd)):
     print(name, " ".join("%d:%.0f(n=%d)" % (k, life[key == k].mean(), (key == k).sum()) for k in np.unique(key)))
