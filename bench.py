@@ -984,7 +984,7 @@ def main():
         d.kernel_time_ms(2)
         t1 = time.perf_counter()
         for _ in range(args.dist_reps):
-            dstep()
+            band2 = dstep()
         barrier()
         el2 = (time.perf_counter() - t1) / args.dist_reps
         k_ms, k_n = d.kernel_time_ms(2)
@@ -993,6 +993,21 @@ def main():
             tt = torch.tensor([el2], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el2 = float(tt.item())
+        # what the rows this rank owns add up to, by row and by column (summed over ranks: the same numbers whatever the world
+        # size — the strong-scaling test compares them with the one-rank run)
+        lo2, hi2 = b2.band_rows(rank)
+        mine2 = band2[lo2:hi2, :n2] if world == 1 else band2[:hi2 - lo2, :n2]
+        w_row = torch.arange(lo2, hi2, dtype=torch.int64, device="cuda") * 1000003 + 17
+        w_col = torch.arange(n2, dtype=torch.int64, device="cuda") * 10007 + 3
+        m64 = mine2.to(torch.int64)
+        chk = torch.stack([m64.sum(), (m64.sum(dim=1) * w_row).sum(), (m64.sum(dim=0) * w_col).sum()])
+        del m64
+        if world > 1:
+            chk_t = chk.cpu() if one_gpu else chk
+            dist.all_reduce(chk_t, op=dist.ReduceOp.SUM)
+            chk = chk_t
+        band_checksum = [int(x) for x in chk.cpu().tolist()]
+        del band2
         pairs = n2 * (n2 - 1) / 2
         # 4 VALU lane-ops per 32 site-compares (v_xor, 2 x v_bitop3, v_bcnt); integer VALU peak = 256 CU x 4 SIMD x 16 lanes
         # x 2.4 GHz
@@ -1002,7 +1017,7 @@ def main():
             "site_compares_per_sec": pairs * s2 / el2, "seconds": el2,
             "config": {"workload": "BASELINE configs[4] shape: %d samples x %d sites, random ACGT- matrix; tiles dealt to %d rank(s)%s"
                                    % (n2, s2, world, ", row-band exchange included" if world > 1 else "")},
-            "kernel_ms": k_ms / max(k_n, 1),
+            "kernel_ms": k_ms / max(k_n, 1), "band_checksum": band_checksum,
             "valu_frac_of_peak": (pairs * s2 / 32 * 4 / el2) / valu_peak,
         }
         del pk, dm

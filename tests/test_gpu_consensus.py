@@ -535,3 +535,26 @@ def test_site_sets_and_stores_outliving_their_device_are_closed_with_it():
         assert len(ss2) == 1
     finally:
         again.close()
+
+
+@pytest.mark.parametrize("variant", ["crlf", "mixed", "vt_ff"])
+def test_terminators_across_many_tiles(d, variant):
+    """Files of many scan tiles whose lines end in "\\r\\n" (pairs inside and across the 16-byte chunks of the index), in a mix
+    of "\\n", "\\r\\n" and lone "\\r", or carry '\\v' / '\\f' (flagged by the index, no line terminators): the fast parse sorts the
+    flagged starts out itself, line counts and calls as the oracle's (Python's universal newlines)."""
+    import io
+    from tests.gpu_util import check_against_oracle
+    data, _, sites = fuzz.synth_pileup(31, genome_len=30000, n_sites=500, mean_depth=20)
+    rng = random.Random(7)
+    lines = data.split(b"\n")[:-1]
+    if variant == "crlf":
+        data2 = b"\r\n".join(lines) + b"\r\n"
+    elif variant == "mixed":
+        data2 = b"".join(ln + rng.choice((b"\n", b"\n", b"\r\n", b"\r")) for ln in lines)
+    else:
+        data2 = b"".join(ln + rng.choice((b"", b"", b"\x0b", b"\x0c", b" \x0b")) + b"\n" for ln in lines)
+    assert len(data2) > 40 * 4096
+    snps = sorted(set(sites + [(sites[0][0], 99_999_999)]))
+    res = check_against_oracle(d, data2, snps, rng.sample(sites, 50), po.CallerParams(0, 0.6, 3, 0, 0.0))
+    n_py = sum(1 for _ in io.TextIOWrapper(io.BytesIO(data2), encoding="latin-1", newline=None))
+    assert res.n_lines == n_py == len(lines)

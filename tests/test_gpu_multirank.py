@@ -69,3 +69,20 @@ def test_sharded_step_equals_single_rank(tmp_path, world):
         assert np.array_equal(got["band"], full[lo:hi]), r
         covered += hi - lo
     assert covered == n_total
+
+
+def test_strong_scaling_of_the_distance_step_at_configs4_shape(tmp_path):
+    """BASELINE configs[4] (10 000 samples x 200 000 sites) with the tiles dealt to two ranks and the row bands exchanged: the
+    rows the ranks end up owning add up — by row and by column — to what the one-rank matrix does."""
+    extra = ["--samples", "8", "--genome", "20000", "--sites", "200", "--vcf-records", "20", "--dist-samples", "10000",
+             "--dist-sites", "200000", "--dist-reps", "1"]
+    one = _run_bench(1, str(tmp_path / "one"), extra)
+    two = _run_bench(2, str(tmp_path / "two"), extra)
+    assert two["scaling"] == "strong" and "10000 samples x 200000 sites" in two["secondary"]["config"]["workload"]
+    assert "row-band exchange included" in two["secondary"]["config"]["workload"]
+    assert one["secondary"]["band_checksum"][0] > 0
+    assert two["secondary"]["band_checksum"] == one["secondary"]["band_checksum"]
+    # per-phase device times of the step are reported for every world size (max over ranks next to rank 0's)
+    for run in (one, two):
+        ph = run["phases_ms_per_step"]
+        assert set(ph["rank0"]) == set(ph["max_over_ranks"]) and all(v >= 0 for v in ph["max_over_ranks"].values())
