@@ -80,7 +80,8 @@ typedef struct snpgpu_site_counts {
     uint32_t good_depth;            /* Record.good_depth */
     uint32_t fwd_good_depth;        /* Record.forward_good_depth */
     uint32_t rev_good_depth;        /* Record.reverse_good_depth */
-    uint32_t n_symbols;             /* distinct upper-cased symbols with good depth (may exceed 8) */
+    uint32_t n_symbols;             /* bits 0-7: distinct upper-cased symbols with good depth; when that is more than 8: bits 8-31
+                                     * = 1 + index of the position's snpgpu_symbol_spill record (0xFFFFFF: there was no room) */
     uint8_t  ref_base;              /* Record.reference_base, case preserved */
     uint8_t  cons_base;             /* ConsensusCaller.call_consensus()[0] */
     uint8_t  filters;               /* SNPGPU_F_* mask, incl. REGION */
@@ -90,6 +91,21 @@ typedef struct snpgpu_site_counts {
     uint32_t fwd[SNPGPU_MAX_SYMS];  /* forward_base_good_depth[sym] */
     uint32_t rev[SNPGPU_MAX_SYMS];  /* reverse_base_good_depth[sym] */
 } snpgpu_site_counts;
+
+/* Ranks 8, 9, ... of a position with more than SNPGPU_MAX_SYMS distinct symbols (pileup.py:259-266 ranks any number of them and
+ * vcf_writer.py:317-331 lists every one as an ALT allele): the record itself keeps the first eight, the rest goes to one of
+ * SNPGPU_SPILL_CAP records the context holds.  A call that produces per-site records starts with an empty spill;
+ * snpgpu_symbol_spill_read copies out what the context's calls have put there since (synchronises the context's stream). */
+#define SNPGPU_SPILL_SYMS 120
+#define SNPGPU_SPILL_CAP  1024
+typedef struct snpgpu_symbol_spill {
+    uint32_t n;                         /* entries used */
+    uint32_t reserved[3];
+    uint8_t  sym[SNPGPU_SPILL_SYMS];    /* most_common_good_bases[8 + k] */
+    uint32_t total[SNPGPU_SPILL_SYMS];
+    uint32_t fwd[SNPGPU_SPILL_SYMS];
+    uint32_t rev[SNPGPU_SPILL_SYMS];
+} snpgpu_symbol_spill;
 
 /* Result words of one pileup scan (device-written, 4 x u64). */
 #define SNPGPU_SCAN_STATUS_WORDS 4
@@ -322,12 +338,16 @@ size_t snpgpu_varscan_format_rows(const snpgpu_varscan_site *sites, uint32_t n_s
  * (vcf_writer.py:295-435: _make_vcf_record_from_pileup + the text PyVCF3's Writer emits for it).  Row r is the record
  * counts[order[r]] (order == NULL: r) of site site_keys[order[r]] = (contig index << 32) | position, contig names as
  * in snpgpu_siteset_create; filter_names: the six names in SNPGPU_F_* bit order; failed_snp_gt: '.', '0' or '1'.
+ * spill / n_spill (nullable / 0): the context's spill records for positions with more than SNPGPU_MAX_SYMS symbols.
  * Writes at most `capacity` bytes to `out` (may be NULL) and returns the number of bytes the rows take; a record with
- * more than SNPGPU_MAX_SYMS symbols is skipped and its row index left in *out_bad_row (else -1). */
+ * more than SNPGPU_MAX_SYMS symbols whose spill record is not in `spill` is skipped and its row index left in *out_bad_row
+ * (else -1). */
 size_t snpgpu_format_vcf_rows(const snpgpu_site_counts *counts, const uint32_t *order, uint32_t n_rows,
                               const uint8_t *contig_names, const uint32_t *contig_name_off, const uint64_t *site_keys,
                               const char *const *filter_names, int preserve_ref_case, char failed_snp_gt,
+                              const snpgpu_symbol_spill *spill, uint32_t n_spill,
                               char *out, size_t capacity, int32_t *out_bad_row);
+int  snpgpu_symbol_spill_read(snpgpu_ctx *ctx, snpgpu_symbol_spill *out, uint32_t capacity, uint32_t *out_n);
 
 /* The output files of call_consensus (call_consensus.py:178-192: consensus.fasta through Bio.SeqIO, consensus.vcf through
  * vcf_writer.SingleSampleWriter) for many (sample, flow) pairs at once, on host threads — host code, no device work, no
@@ -336,7 +356,7 @@ size_t snpgpu_format_vcf_rows(const snpgpu_site_counts *counts, const uint32_t *
  * site_in_flow (nullable, [n_sites]) only the sites it marks and those whose row mask carries SNPGPU_F_REGION (the parse set
  * of call_consensus.py:147-151 is the snplist plus the sample's exclude list); row_filters (nullable, [n_sites]) replaces the
  * records' own failed-filter masks.  Out: rc (0, SNPGPU_E_IO, or SNPGPU_E_UNSUPPORTED for a record with more than
- * SNPGPU_MAX_SYMS symbols) and n_rows.  Contig names / site_keys / filter_names as snpgpu_format_vcf_rows; n_threads 0 = as
+ * SNPGPU_MAX_SYMS symbols that has no record in spill[n_spill]) and n_rows.  Contig names / site_keys / filter_names as snpgpu_format_vcf_rows; n_threads 0 = as
  * many as there are jobs, up to 64. */
 typedef struct snpgpu_consensus_job {
     const char *fasta_path;
@@ -354,7 +374,8 @@ typedef struct snpgpu_consensus_job {
 } snpgpu_consensus_job;
 int  snpgpu_write_consensus_files(snpgpu_consensus_job *jobs, uint32_t n_jobs, uint32_t n_sites, const uint8_t *contig_names,
                                   const uint32_t *contig_name_off, const uint64_t *site_keys, const char *const *filter_names,
-                                  int preserve_ref_case, char failed_snp_gt, uint32_t n_threads);
+                                  int preserve_ref_case, char failed_snp_gt, const snpgpu_symbol_spill *spill, uint32_t n_spill,
+                                  uint32_t n_threads);
 
 /* Both consensus flows from one call (run.py:704-718 calls every sample twice: at the positions of snplist.txt, and at those
  * of snplist_preserved.txt with the sample's var.flt_removed.vcf as exclude file).  From the result of the call over the FULL

@@ -29,6 +29,14 @@ class SiteCounts(C.Structure):
                 ("fwd", C.c_uint32 * MAX_SYMS), ("rev", C.c_uint32 * MAX_SYMS)]
 
 
+SPILL_SYMS, SPILL_CAP = 120, 1024
+
+
+class SymbolSpill(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("reserved", C.c_uint32 * 3), ("sym", C.c_uint8 * SPILL_SYMS), ("total", C.c_uint32 * SPILL_SYMS),
+                ("fwd", C.c_uint32 * SPILL_SYMS), ("rev", C.c_uint32 * SPILL_SYMS)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("sample", C.c_uint32), ("genome_len", C.c_uint32),
                 ("mean_depth", C.c_float), ("carrier_p_same_clade", C.c_float),
@@ -104,7 +112,8 @@ SIGNATURES = {
                                               _P, _P, _P, _P, C.POINTER(StreamOpts), C.POINTER(StreamStats)]),
     "snpgpu_call_consensus_many_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(CallerParams), _P, _P, _P, _P, _P, _P, C.c_int]),
     "snpgpu_region_flow_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, C.c_uint32, _P, _P, _P, _P, _P]),
-    "snpgpu_write_consensus_files": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.POINTER(C.c_char_p), C.c_int, C.c_char, C.c_uint32]),
+    "snpgpu_write_consensus_files": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.POINTER(C.c_char_p), C.c_int, C.c_char, _P, C.c_uint32,
+                                               C.c_uint32]),
     "snpgpu_varscan_dev": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P, C.POINTER(C.c_uint32), _P]),
     "snpgpu_pileups_create": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
     "snpgpu_pileups_destroy": (None, [_P]),
@@ -114,8 +123,9 @@ SIGNATURES = {
     "snpgpu_pileups_get_stats": (C.c_int, [_P, C.POINTER(PileupsStats)]),
     "snpgpu_call_all_lines_file": (C.c_int, [_P, _P, C.c_char_p, C.POINTER(CallerParams), C.c_uint64, C.POINTER(C.c_uint64),
                                              _P, _P, _P, _P]),
-    "snpgpu_format_vcf_rows": (C.c_size_t, [_P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_char_p), C.c_int, C.c_char, _P, C.c_size_t,
-                                            C.POINTER(C.c_int32)]),
+    "snpgpu_format_vcf_rows": (C.c_size_t, [_P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_char_p), C.c_int, C.c_char, _P, C.c_uint32, _P,
+                                            C.c_size_t, C.POINTER(C.c_int32)]),
+    "snpgpu_symbol_spill_read": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     "snpgpu_siteset_line_offsets": (C.c_int, [_P, _P, _P]),
     "snpgpu_packed_row_bytes": (C.c_size_t, [C.c_uint32]),
     "snpgpu_pack_matrix_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_size_t, _P]),

@@ -114,7 +114,7 @@ def _write_outputs(plan, dev, ss, snp_slots, res, file_flags=None):
             if not args.vcfAllPos:
                 keep = np.nonzero(line_flags)[0]                # listed positions only
                 line_off, counts = line_off[keep], counts[keep]
-            vcf_writer.write_all_positions_vcf(plan.vcf_path, plan.sample_name, args, plan.pileup_path, line_off, counts)
+            vcf_writer.write_all_positions_vcf(plan.vcf_path, plan.sample_name, args, plan.pileup_path, line_off, counts, spill=dev.last_spill)
         else:
             vcf_writer.write_consensus_vcf(plan.vcf_path, plan.sample_name, args, ss, res, res.line_offsets, parsed=file_flags != 0)
     consensus = consensus_string(snp_slots, res).tobytes().decode("ascii")

@@ -42,6 +42,8 @@ struct CallArgs {
     const uint32_t *in_todo_n;
     const uint32_t *deep;       // k_call_lanes: *deep != 0: the batch's lines average more than 100 bytes — the 128-byte pass
                                 // returns at once and the 256-byte pass takes every site (see k_call_mode)
+    snpgpu_symbol_spill *spill; // k_call_sites, with out_counts: where ranks 8.. of a position with more symbols go (nullable)
+    uint32_t *spill_n;          // records taken so far
 };
 
 struct WaveLds {
@@ -335,6 +337,34 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
                     top_f[r] = __builtin_amdgcn_readlane(tf, owner);
                     top_r[r] = __builtin_amdgcn_readlane(tr, owner);
                     if (lane == owner) { if (sym < 64) t0 = 0; else t1 = 0; }
+                }
+                // more than the record keeps (consensus.vcf lists every one as an ALT allele): ranks 8, 9, ... in the same order go to
+                // a spill record of the context; its index + 1 travels in the upper bits of n_symbols
+                if (a.out_counts && nsym > SNPGPU_MAX_SYMS) {
+                    uint32_t slot = 0xFFFFFFu;
+                    if (a.spill) {
+                        if (lane == 0) slot = atomicAdd(a.spill_n, 1u);
+                        slot = __builtin_amdgcn_readfirstlane(slot);
+                    }
+                    if (slot < SNPGPU_SPILL_CAP) {
+                        snpgpu_symbol_spill *sp = a.spill + slot;
+                        uint32_t r = 0;
+                        for (; r < SNPGPU_SPILL_SYMS; ++r) {
+                            uint64_t k0 = t0 ? ((uint64_t)t0 << 8) | (255u - lane) : 0ull;
+                            uint64_t k1 = t1 ? ((uint64_t)t1 << 8) | (255u - (lane + 64)) : 0ull;
+                            uint64_t best = k0 > k1 ? k0 : k1;
+                            for (int o = 32; o; o >>= 1) { uint64_t other = __shfl_xor((unsigned long long)best, o); best = other > best ? other : best; }
+                            if (best == 0) break;
+                            const uint32_t sym = 255u - (uint32_t)(best & 255u), owner = sym & 63u;
+                            const uint32_t ef = __builtin_amdgcn_readlane(sym < 64 ? f0 : f1, owner), er = __builtin_amdgcn_readlane(sym < 64 ? r0 : r1, owner);
+                            if (lane == 0) { sp->sym[r] = (uint8_t)sym; sp->total[r] = (uint32_t)(best >> 8); sp->fwd[r] = ef; sp->rev[r] = er; }
+                            if (lane == owner) { if (sym < 64) t0 = 0; else t1 = 0; }
+                        }
+                        if (lane == 0) sp->n = r;
+                        nsym |= (slot + 1u) << 8;
+                    } else {
+                        nsym |= 0xFFFFFFu << 8;                   // no room (or no spill): the writer refuses this record
+                    }
                 }
                 cons = top_sym[0];
                 const uint32_t n = top_t[0], nf = top_f[0], nr = top_r[0];
@@ -904,6 +934,8 @@ int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleD
     ca.out_base = d_out_base;
     ca.out_filters = d_out_filters;
     ca.out_counts = d_out_counts;
+    ca.spill = d_out_counts ? ctx->d_spill : nullptr;
+    ca.spill_n = ctx->d_spill_n;
     const uint64_t n_work = (uint64_t)n_sites * n;
     const uint64_t blocks = (n_work + CALL_WAVES - 1) / CALL_WAVES;
     const uint64_t max_blocks = (uint64_t)ctx->n_cu * 16;
@@ -964,6 +996,8 @@ int snpgpu_enqueue_call_lines(snpgpu_ctx *ctx, const SampleDev *d_sample, const 
     ca.out_base = d_out_base;
     ca.out_filters = d_out_filters;
     ca.out_counts = d_out_counts;
+    ca.spill = d_out_counts ? ctx->d_spill : nullptr;
+    ca.spill_n = ctx->d_spill_n;
     ca.todo = nullptr; ca.todo_n = nullptr; ca.in_todo = nullptr; ca.in_todo_n = nullptr; ca.deep = nullptr;
     const uint64_t blocks = ((uint64_t)n_lines + CALL_WAVES - 1) / CALL_WAVES, max_blocks = (uint64_t)ctx->n_cu * 16;
     k_call_sites<<<(unsigned)(blocks < max_blocks ? blocks : max_blocks), CALL_WAVES * 64, 0, ctx->stream>>>(ca);
@@ -1021,6 +1055,7 @@ int snpgpu_call_consensus_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const v
     if (!ctx || !ss || !params || !d_status || (nbytes && !d_pileup)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
     if (ss->n_sites && (!d_out_base || !d_out_filters)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
     HIP_TRY(ctx, snpgpu_enter(ctx));
+    if (d_out_counts) { int rc = snpgpu_spill_begin(ctx); if (rc) return rc; }
     return enqueue_sample(ctx, ss, (const uint8_t *)d_pileup, nbytes, params, d_out_base, d_out_filters, d_out_counts, d_status, want_depth_sum);
 }
 
@@ -1074,6 +1109,7 @@ int snpgpu_call_consensus_many_dev(snpgpu_ctx *ctx, const snpgpu_siteset *ss, co
     if (!ctx || !ss || !params || !d_status || (n_samples && (!d_pileups || !h_sizes))) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
     if (ss->n_sites && n_samples && (!d_out_base || !d_out_filters)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
     HIP_TRY(ctx, snpgpu_enter(ctx));
+    if (d_out_counts) { int rc = snpgpu_spill_begin(ctx); if (rc) return rc; }
     uint32_t group = SNPGPU_SCAN_MAX_BATCH;
     if (ss->n_sites) {                                          // per group in scratch: two leftover lists (+ the rows when not given)
         const uint64_t by_mem = (1ull << 30) / (8ull * ss->n_sites);

@@ -116,12 +116,47 @@ void snpgpu_ctx_destroy(snpgpu_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     snpgpu_stream_pool_destroy(ctx);
     if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->d_spill) hipFree(ctx->d_spill);
     for (auto &t : ctx->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
     if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
+}
+
+// ---- positions with more than SNPGPU_MAX_SYMS symbols ----------------------------------------------------------------
+}  // extern "C"  (closed for the internal helper; reopened below)
+int snpgpu_spill_begin(snpgpu_ctx *ctx) {
+    if (!ctx->d_spill) {
+        void *d = nullptr;
+        const size_t bytes = sizeof(snpgpu_symbol_spill) * (size_t)SNPGPU_SPILL_CAP + 256;
+        hipError_t e = hipMalloc(&d, bytes);
+        if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipMalloc(%zu) for the symbol spill failed: %s", bytes, hipGetErrorString(e));
+        ctx->d_spill = (snpgpu_symbol_spill *)d;
+        ctx->d_spill_n = (uint32_t *)((char *)d + sizeof(snpgpu_symbol_spill) * (size_t)SNPGPU_SPILL_CAP);
+    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_spill_n, 0, 4, ctx->stream));
+    return SNPGPU_OK;
+}
+extern "C" {
+
+int snpgpu_symbol_spill_read(snpgpu_ctx *ctx, snpgpu_symbol_spill *out, uint32_t capacity, uint32_t *out_n) {
+    if (!ctx || !out_n || (capacity && !out)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    *out_n = 0;
+    if (!ctx->d_spill) return SNPGPU_OK;                       // no call has asked for per-site records yet
+    HIP_TRY(ctx, snpgpu_enter(ctx));
+    uint32_t n = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n, ctx->d_spill_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n > SNPGPU_SPILL_CAP) n = SNPGPU_SPILL_CAP;            // (positions past the last record carry "no room" in their own record)
+    *out_n = n;
+    if (n > capacity) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "%u spill records, room for %u", n, capacity);
+    if (n) {
+        HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_spill, sizeof(snpgpu_symbol_spill) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SNPGPU_OK;
 }
 
 const char *snpgpu_last_error(const snpgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }

@@ -24,6 +24,9 @@ struct snpgpu_ctx {
     size_t scratch_bytes = 0;
     int n_cu = 256;
     bool scan_lds_attr = false;         // hipFuncSetAttribute is per device: done once per context
+    // positions with more than SNPGPU_MAX_SYMS symbols: [SNPGPU_SPILL_CAP] records + one counter word (allocated on first use)
+    snpgpu_symbol_spill *d_spill = nullptr;
+    uint32_t *d_spill_n = nullptr;
     // optional per-kernel timing (bench): event pairs recorded around selected launches
     bool time_kernels = false;
     struct Timed { int kernel; hipEvent_t a, b; };
@@ -36,6 +39,8 @@ struct snpgpu_ctx {
 #define SNPGPU_K_CALL 1
 #define SNPGPU_K_DISTANCE 2
 // RAII-less helpers: call begin before the launch and end right after it (no-ops unless timing is enabled)
+// Start of a public call that produces per-site records: the spill is there and empty (enqueued on the context's stream).
+int snpgpu_spill_begin(snpgpu_ctx *ctx);
 hipEvent_t snpgpu_time_begin(snpgpu_ctx *ctx);
 void snpgpu_time_end(snpgpu_ctx *ctx, int kernel, hipEvent_t a);
 

@@ -356,6 +356,7 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
         }
     }
     HIP_TRY(ctx, snpgpu_enter(ctx));
+    if (out.counts) { int rc0 = snpgpu_spill_begin(ctx); if (rc0) return rc0; }
     size_t chunk = opts && opts->chunk_bytes ? opts->chunk_bytes : (size_t)16 << 20;
     chunk = up(chunk < 65536 ? 65536 : chunk, SNPGPU_SCAN_TILE);
     const int want_depth = opts && opts->want_depth_sum ? 1 : 0;
@@ -774,7 +775,9 @@ int snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const 
     HIP_TRY(ctx, snpgpu_enter(ctx));
     uint8_t *d_file = nullptr;
     uint64_t nbytes = 0;
-    int rc = load_file(ctx, path, &d_file, &nbytes);
+    int rc = snpgpu_spill_begin(ctx);
+    if (rc) return rc;
+    rc = load_file(ctx, path, &d_file, &nbytes);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
     const size_t ws_words = snpgpu_lines_workspace_words(nbytes);

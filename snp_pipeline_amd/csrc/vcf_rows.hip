@@ -35,8 +35,19 @@ struct Out {
 // One data line.  `mask`: the failed-filter bits of the row (the record's own, or — for the preserved flow of the pipeline —
 // the record's plus Region).  Returns false for a record with more symbols than it keeps.
 bool put_row(Out &o, const snpgpu_site_counts &c, uint32_t mask, uint64_t key, const uint8_t *contig_names, const uint32_t *contig_name_off,
-             const char *const *filter_names, int preserve_ref_case, char failed_snp_gt) {
-    if (c.n_symbols > SNPGPU_MAX_SYMS) return false;
+             const char *const *filter_names, int preserve_ref_case, char failed_snp_gt, const snpgpu_symbol_spill *spill, uint32_t n_spill) {
+    // the ranked symbols: eight in the record, the rest (rare) in the position's spill record
+    const uint32_t n_symbols = c.n_symbols & 0xFFu, spill_code = c.n_symbols >> 8;
+    const snpgpu_symbol_spill *more = nullptr;
+    if (n_symbols > SNPGPU_MAX_SYMS) {
+        if (!spill || spill_code == 0 || spill_code - 1 >= n_spill) return false;
+        more = &spill[spill_code - 1];
+        if (more->n != n_symbols - SNPGPU_MAX_SYMS || more->n > SNPGPU_SPILL_SYMS) return false;
+    }
+    auto sym_of = [&](int k) -> char { return (char)(k < SNPGPU_MAX_SYMS ? c.sym[k] : more->sym[k - SNPGPU_MAX_SYMS]); };
+    auto total_of = [&](int k) -> uint32_t { return k < SNPGPU_MAX_SYMS ? c.total[k] : more->total[k - SNPGPU_MAX_SYMS]; };
+    auto fwd_of = [&](int k) -> uint32_t { return k < SNPGPU_MAX_SYMS ? c.fwd[k] : more->fwd[k - SNPGPU_MAX_SYMS]; };
+    auto rev_of = [&](int k) -> uint32_t { return k < SNPGPU_MAX_SYMS ? c.rev[k] : more->rev[k - SNPGPU_MAX_SYMS]; };
     char ref = (char)c.ref_base, upper_ref = ref;
     if (upper_ref >= 'a' && upper_ref <= 'z') upper_ref = (char)(upper_ref - 32);
     if (!preserve_ref_case) ref = upper_ref;
@@ -55,15 +66,15 @@ bool put_row(Out &o, const snpgpu_site_counts &c, uint32_t mask, uint64_t key, c
     const bool failed = ftn != 0;
     if (!failed) { memcpy(ft, "PASS", 4); ftn = 4; }
     // ALT = ranked symbols other than the (upper-case) reference
-    int alt[SNPGPU_MAX_SYMS], n_alt = 0, ref_at = -1;
-    for (uint32_t k = 0; k < c.n_symbols; ++k) {
-        if ((char)c.sym[k] == upper_ref) ref_at = (int)k; else alt[n_alt++] = (int)k;
+    int alt[SNPGPU_MAX_SYMS + SNPGPU_SPILL_SYMS], n_alt = 0, ref_at = -1;
+    for (uint32_t k = 0; k < n_symbols; ++k) {
+        if (sym_of((int)k) == upper_ref) ref_at = (int)k; else alt[n_alt++] = (int)k;
     }
     char gt;
     const bool none = c.good_depth == 0;                    // most_common_good_bases is None
     if (none) { gt = '.'; n_alt = 0; }
     else {
-        gt = n_alt == 0 ? '0' : ((char)c.sym[0] == upper_ref ? '0' : '1');
+        gt = n_alt == 0 ? '0' : (sym_of(0) == upper_ref ? '0' : '1');
         if (failed) gt = failed_snp_gt == '.' ? '.' : (failed_snp_gt == '0' ? '0' : '1');
     }
     const uint32_t cid = (uint32_t)(key >> 32);
@@ -71,17 +82,17 @@ bool put_row(Out &o, const snpgpu_site_counts &c, uint32_t mask, uint64_t key, c
     o.put('\t'); o.putu(key & 0xFFFFFFFFull);
     o.puts_("\t.\t"); o.put(ref); o.put('\t');
     if (n_alt == 0) o.put('.');
-    else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.put((char)c.sym[alt[k]]); }
+    else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.put(sym_of(alt[k])); }
     o.puts_("\t.\t"); o.putn(ft, ftn);
     o.puts_("\tNS=1\tGT:SDP:RD:AD:RDF:RDR:ADF:ADR:FT\t");
     o.put(gt); o.put(':'); o.putu(c.raw_depth); o.put(':');
-    o.putu(ref_at >= 0 && !none ? c.total[ref_at] : 0); o.put(':');
-    if (n_alt == 0) o.put('0'); else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.putu(c.total[alt[k]]); }
-    o.put(':'); o.putu(ref_at >= 0 && !none ? c.fwd[ref_at] : 0);
-    o.put(':'); o.putu(ref_at >= 0 && !none ? c.rev[ref_at] : 0); o.put(':');
-    if (n_alt == 0) o.put('0'); else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.putu(c.fwd[alt[k]]); }
+    o.putu(ref_at >= 0 && !none ? total_of(ref_at) : 0); o.put(':');
+    if (n_alt == 0) o.put('0'); else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.putu(total_of(alt[k])); }
+    o.put(':'); o.putu(ref_at >= 0 && !none ? fwd_of(ref_at) : 0);
+    o.put(':'); o.putu(ref_at >= 0 && !none ? rev_of(ref_at) : 0); o.put(':');
+    if (n_alt == 0) o.put('0'); else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.putu(fwd_of(alt[k])); }
     o.put(':');
-    if (n_alt == 0) o.put('0'); else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.putu(c.rev[alt[k]]); }
+    if (n_alt == 0) o.put('0'); else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.putu(rev_of(alt[k])); }
     o.put(':'); o.putn(ft, ftn); o.put('\n');
     return true;
 }
@@ -106,7 +117,8 @@ bool write_all(const char *path, const char *a, size_t na, const char *b, size_t
 
 // consensus.fasta + consensus.vcf of one sample and flow
 void write_consensus_job(snpgpu_consensus_job &job, uint32_t n_sites, const uint8_t *contig_names, const uint32_t *contig_name_off, const uint64_t *site_keys,
-                         const char *const *filter_names, int preserve_ref_case, char failed_snp_gt, std::vector<char> &text, std::vector<uint32_t> &order) {
+                         const char *const *filter_names, int preserve_ref_case, char failed_snp_gt, const snpgpu_symbol_spill *spill, uint32_t n_spill,
+                         std::vector<char> &text, std::vector<uint32_t> &order) {
     job.rc = SNPGPU_OK;
     job.n_rows = 0;
     if (job.fasta_path) {
@@ -144,7 +156,7 @@ void write_consensus_job(snpgpu_consensus_job &job, uint32_t n_sites, const uint
             bool bad = false;
             for (uint32_t i : order) {
                 const uint32_t mask = job.row_filters ? job.row_filters[i] : job.counts[i].filters;
-                if (!put_row(o, job.counts[i], mask & 0x3Fu, site_keys[i], contig_names, contig_name_off, filter_names, preserve_ref_case, failed_snp_gt)) { bad = true; break; }
+                if (!put_row(o, job.counts[i], mask & 0x3Fu, site_keys[i], contig_names, contig_name_off, filter_names, preserve_ref_case, failed_snp_gt, spill, n_spill)) { bad = true; break; }
             }
             if (bad) { job.rc = SNPGPU_E_UNSUPPORTED; break; }
             if (o.n > text.size()) { text.resize(o.n + 4096); continue; }
@@ -160,14 +172,15 @@ void write_consensus_job(snpgpu_consensus_job &job, uint32_t n_sites, const uint
 extern "C" size_t snpgpu_format_vcf_rows(const snpgpu_site_counts *counts, const uint32_t *order, uint32_t n_rows,
                                          const uint8_t *contig_names, const uint32_t *contig_name_off, const uint64_t *site_keys,
                                          const char *const *filter_names, int preserve_ref_case, char failed_snp_gt,
+                                         const snpgpu_symbol_spill *spill, uint32_t n_spill,
                                          char *out, size_t capacity, int32_t *out_bad_row) {
     Out o{out, out ? capacity : 0, 0};
     if (out_bad_row) *out_bad_row = -1;
     for (uint32_t r = 0; r < n_rows; ++r) {
         const uint32_t idx = order ? order[r] : r;
         const snpgpu_site_counts &c = counts[idx];
-        if (!put_row(o, c, c.filters & 0x3Fu, site_keys[idx], contig_names, contig_name_off, filter_names, preserve_ref_case, failed_snp_gt)) {
-            if (out_bad_row && *out_bad_row < 0) *out_bad_row = (int32_t)r;   // the record keeps 8 symbols: the caller raises
+        if (!put_row(o, c, c.filters & 0x3Fu, site_keys[idx], contig_names, contig_name_off, filter_names, preserve_ref_case, failed_snp_gt, spill, n_spill)) {
+            if (out_bad_row && *out_bad_row < 0) *out_bad_row = (int32_t)r;   // more than 8 symbols and no spill record: the caller raises
         }
     }
     return o.n;
@@ -178,7 +191,8 @@ extern "C" size_t snpgpu_format_vcf_rows(const snpgpu_site_counts *counts, const
 // take longer than the pileups take to cross the host link.
 extern "C" int snpgpu_write_consensus_files(snpgpu_consensus_job *jobs, uint32_t n_jobs, uint32_t n_sites, const uint8_t *contig_names,
                                             const uint32_t *contig_name_off, const uint64_t *site_keys, const char *const *filter_names,
-                                            int preserve_ref_case, char failed_snp_gt, uint32_t n_threads) {
+                                            int preserve_ref_case, char failed_snp_gt, const snpgpu_symbol_spill *spill, uint32_t n_spill,
+                                            uint32_t n_threads) {
     if (n_jobs && !jobs) return SNPGPU_E_ARG;
     if (!n_threads) {
         n_threads = std::thread::hardware_concurrency();
@@ -193,7 +207,7 @@ extern "C" int snpgpu_write_consensus_files(snpgpu_consensus_job *jobs, uint32_t
         for (;;) {
             const uint32_t j = next.fetch_add(1);
             if (j >= n_jobs) return;
-            write_consensus_job(jobs[j], n_sites, contig_names, contig_name_off, site_keys, filter_names, preserve_ref_case, failed_snp_gt, text, order);
+            write_consensus_job(jobs[j], n_sites, contig_names, contig_name_off, site_keys, filter_names, preserve_ref_case, failed_snp_gt, spill, n_spill, text, order);
         }
     };
     std::vector<std::thread> pool;

@@ -164,13 +164,24 @@ class SiteSet(object):
             pass
 
 
-class ConsensusResult(object):
-    __slots__ = ("bases", "filters", "counts", "status", "n_lines", "n_matched", "depth_sum", "line_offsets")
+SPILL_DTYPE = np.dtype([("n", "<u4"), ("reserved", "<u4", (3,)), ("sym", "u1", (L.SPILL_SYMS,)), ("total", "<u4", (L.SPILL_SYMS,)),
+                        ("fwd", "<u4", (L.SPILL_SYMS,)), ("rev", "<u4", (L.SPILL_SYMS,))])
+assert SPILL_DTYPE.itemsize == C.sizeof(L.SymbolSpill)
 
-    def __init__(self, bases, filters, counts, status):
+
+def symbol_count(counts):
+    """Distinct symbols of the records (the low byte of n_symbols; the rest points at a spill record)."""
+    return counts["n_symbols"] & 0xFF
+
+
+class ConsensusResult(object):
+    __slots__ = ("bases", "filters", "counts", "status", "n_lines", "n_matched", "depth_sum", "line_offsets", "spill")
+
+    def __init__(self, bases, filters, counts, status, spill=None):
         self.bases, self.filters, self.counts, self.status = bases, filters, counts, status
         self.n_lines, self.n_matched, self.depth_sum = int(status[1]), int(status[2]), int(status[3])
         self.line_offsets = None
+        self.spill = spill                                   # SPILL_DTYPE records of the call, or None (no position has > 8 symbols)
 
 
 class Device(object):
@@ -186,6 +197,16 @@ class Device(object):
         self.ctx = h
         import weakref
         self._children = weakref.WeakSet()                  # site sets and pileup stores of this context
+
+    def read_symbol_spill(self, counts=None):
+        """The spill records of the context's last call that produced per-site records (positions with more than 8 distinct
+        symbols); with `counts`: None unless one of those records points at one."""
+        if counts is not None and not (symbol_count(counts) > L.MAX_SYMS).any():
+            return None
+        out = np.zeros(L.SPILL_CAP, dtype=SPILL_DTYPE)
+        n = C.c_uint32()
+        self._check(self.lib.snpgpu_symbol_spill_read(self.ctx, _ptr(out), L.SPILL_CAP, C.byref(n)))
+        return out[:n.value]
 
     # ---- plumbing ------------------------------------------------------------------------------
     def _check(self, rc):
@@ -261,7 +282,7 @@ class Device(object):
         if rc in (L.E_PILEUP, L.E_UNSUPPORTED) and int(status[0]) != 0xFFFFFFFFFFFFFFFF:
             self.raise_scan_status(status)
         self._check(rc)
-        res = ConsensusResult(bases, filters, counts, status)
+        res = ConsensusResult(bases, filters, counts, status, self.read_symbol_spill(counts) if want_counts else None)
         if check:
             self.raise_site_status(res)
         return res
@@ -316,8 +337,9 @@ class Device(object):
             self.ctx, siteset.handle, arr, n_files, C.byref(params), _ptr(excl_off), _ptr(excl_slots), _ptr(bases), _ptr(filters),
             _ptr(counts), _ptr(line_off), _ptr(status), _ptr(rcs), C.byref(opts), C.byref(stats)))
         results = []
+        spill = self.read_symbol_spill(counts) if want_counts else None      # one spill per call: shared by its files
         for f in range(n_files):
-            r = ConsensusResult(bases[f], filters[f], counts[f] if want_counts else None, status[f])
+            r = ConsensusResult(bases[f], filters[f], counts[f] if want_counts else None, status[f], spill)
             r.line_offsets = line_off[f] if want_line_offsets else None
             results.append(r)
         return results, rcs[:n_files], stats
@@ -346,6 +368,7 @@ class Device(object):
         n = n_lines.value
         if check:
             self.raise_site_status(ConsensusResult(None, None, counts[:n], status))
+        self.last_spill = self.read_symbol_spill(counts[:n])     # (for the rows of these records: vcf_writer.write_all_positions_vcf)
         return off[:n], flags[:n], counts[:n]
 
     def varscan_file(self, path, params, capacity=65536):
@@ -647,9 +670,10 @@ class Pileups(object):
             pass
 
 
-def write_consensus_files(jobs, siteset, filter_names, preserve_ref_case, failed_snp_gt, n_threads=0):
+def write_consensus_files(jobs, siteset, filter_names, preserve_ref_case, failed_snp_gt, n_threads=0, spill=None):
     """jobs: list of dicts with the fields of snpgpu_consensus_job (numpy arrays for the pointers; absent = NULL).  Writes
-    the consensus FASTA / VCF files of all jobs on host threads (csrc/vcf_rows.hip).  Returns [(rc, rows)] per job."""
+    the consensus FASTA / VCF files of all jobs on host threads (csrc/vcf_rows.hip).  spill: Device.read_symbol_spill() of the
+    call the records came from.  Returns [(rc, rows)] per job."""
     lib = L.load()
     n = len(jobs)
     arr = (L.ConsensusJob * max(n, 1))()
@@ -682,7 +706,8 @@ def write_consensus_files(jobs, siteset, filter_names, preserve_ref_case, failed
         arr[j].site_in_flow = ptr(job.get("site_in_flow"))
     fn = (C.c_char_p * 6)(*[x.encode("ascii") for x in filter_names])
     rc = lib.snpgpu_write_consensus_files(arr, n, len(siteset), _ptr(siteset._names), _ptr(siteset._offs), _ptr(siteset.keys), fn,
-                                          1 if preserve_ref_case else 0, failed_snp_gt.encode("ascii"), int(n_threads))
+                                          1 if preserve_ref_case else 0, failed_snp_gt.encode("ascii"),
+                                          _ptr(spill) if spill is not None and len(spill) else None, len(spill) if spill is not None else 0, int(n_threads))
     if rc != 0:
         raise SnpGpuError(rc, "snpgpu_write_consensus_files")
     return [(int(arr[j].rc), int(arr[j].n_rows)) for j in range(n)]

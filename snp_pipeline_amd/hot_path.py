@@ -471,7 +471,7 @@ def hot_path_batch(args):
         vcf_date = None
         pending_write = None
 
-        def write_group(part, hs, g0):
+        def write_group(part, hs, g0, spill=None):
             """FASTA + VCF files of one group, both flows (host threads inside the library); returns the samples that failed."""
             jobs, owners = [], []
             counts_np = hs["counts"].numpy().view(devmod.COUNTS_DTYPE).reshape(hs["g"], max(S, 1)) if want_vcf else None
@@ -490,7 +490,8 @@ def hot_path_batch(args):
                                     "site_in_flow": in1 if flow == 1 else in2})
                     jobs.append(job)
                     owners.append(s)
-            res = devmod.write_consensus_files(jobs, ss, filter_names, cc_args.vcfPreserveRefCase, cc_args.vcfFailedSnpGt, n_threads=args.writerThreads)
+            res = devmod.write_consensus_files(jobs, ss, filter_names, cc_args.vcfPreserveRefCase, cc_args.vcfFailedSnpGt, n_threads=args.writerThreads,
+                                               spill=spill)
             bad = []
             for s, job, (rc, _) in zip(owners, jobs, res):
                 if rc == L.E_UNSUPPORTED:
@@ -564,7 +565,9 @@ def hot_path_batch(args):
             # per sample, for the checks below: a malformed line at a listed position?  how many listed positions have a line?
             if S:
                 d_bad = (d_counts[:g, :S, 23] > L.ST_OK).any(dim=1) if want_vcf else ((d_filt[:g, :S] & 0x80) != 0).any(dim=1)
-                d_chk = torch.stack([d_bad.to(torch.int64), (d_line[:g, :S] != 0).sum(dim=1)], dim=1)
+                # (byte 16 of a record: its number of distinct symbols; more than 8 = the rest is in the context's spill)
+                d_ovf = (d_counts[:g, :S, 16] > L.MAX_SYMS).sum(dim=1) if want_vcf else torch.zeros(g, dtype=torch.int64, device="cuda")
+                d_chk = torch.stack([d_bad.to(torch.int64), (d_line[:g, :S] != 0).sum(dim=1), d_ovf], dim=1)
             hs["status"][:g].copy_(d_status[:g], non_blocking=True)
             if S1:
                 hs["base1"][:g, :S1].copy_(rows1[g0:g0 + g, :S1], non_blocking=True)
@@ -576,7 +579,18 @@ def hot_path_batch(args):
                 hs["line"][:g, :S].copy_(d_line[:g, :S], non_blocking=True)
                 if want_vcf:
                     hs["counts"][:g, :S].copy_(d_counts[:g, :S], non_blocking=True)
-            chk = d_chk.cpu().numpy() if S else np.zeros((g, 2), dtype=np.int64)      # (the stream is idle after this)
+            chk = d_chk.cpu().numpy() if S else np.zeros((g, 3), dtype=np.int64)      # (the stream is idle after this)
+            group_spill = None
+            if S and chk[:, 2].any():
+                # positions with more than 8 distinct symbols: their spill records belong to ONE library call — there is one
+                # when the whole group was resident; a sample of a mixed group goes back to the per-sample command
+                if not rest:
+                    group_spill = dev.read_symbol_spill()
+                else:
+                    for k, s in enumerate(part):
+                        if s.ok and chk[k, 2]:
+                            s.ok, s.error = False, ("Error: call_consensus failed for sample %s: a position has more than %d distinct symbols and the "
+                                                    "sample's group was only partly resident; run call_consensus for this sample" % (s.name, L.MAX_SYMS))
             torch.cuda.current_stream().synchronize()
             lap("3b   of which: results to the host" if args.verbose >= 2 else "3ab  of which: device work + results to the host", t_g)
             t_g = time.perf_counter()
@@ -601,7 +615,7 @@ def hot_path_batch(args):
             t_g = time.perf_counter()
             if pending_write is not None:
                 write_failures.extend(pending_write.result())
-            pending_write = writer.submit(write_group, part, hs, g0)
+            pending_write = writer.submit(write_group, part, hs, g0, group_spill)
             lap("3d   of which: waiting for the previous group's files", t_g)
         t_g = time.perf_counter()
         if pending_write is not None:

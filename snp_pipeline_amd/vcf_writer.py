@@ -52,21 +52,26 @@ def header_lines(sample_id, filters, reference, now=None):
     return out
 
 
-def row_from_counts(chrom, pos, c, filter_names, preserve_ref_case, failed_snp_gt):
-    """One VCF data line from a snpgpu_site_counts record (vcf_writer.py:295-379)."""
+def row_from_counts(chrom, pos, c, filter_names, preserve_ref_case, failed_snp_gt, spill=None):
+    """One VCF data line from a snpgpu_site_counts record (vcf_writer.py:295-379); spill: the call's spill records, for a
+    position with more than 8 distinct symbols."""
     ref = chr(int(c["ref_base"]))
     upper_ref = ref.upper()
     if not preserve_ref_case:
         ref = upper_ref
     mask = int(c["filters"])
     failed = [filter_names[i] for i in range(6) if mask >> i & 1]
-    n_sym = int(c["n_symbols"])
+    n_sym, code = int(c["n_symbols"]) & 0xFF, int(c["n_symbols"]) >> 8
+    ranked = [(chr(int(c["sym"][r])), int(c["total"][r]), int(c["fwd"][r]), int(c["rev"][r])) for r in range(min(n_sym, L.MAX_SYMS))]
     if n_sym > L.MAX_SYMS:
-        raise ValueError("%s:%d has %d distinct symbols; the device record keeps %d" % (chrom, pos, n_sym, L.MAX_SYMS))
-    syms = [chr(int(c["sym"][r])) for r in range(n_sym)]
-    total = {s: int(c["total"][r]) for r, s in enumerate(syms)}
-    fwd = {s: int(c["fwd"][r]) for r, s in enumerate(syms)}
-    rev = {s: int(c["rev"][r]) for r, s in enumerate(syms)}
+        if spill is None or code == 0 or code - 1 >= len(spill) or int(spill[code - 1]["n"]) != n_sym - L.MAX_SYMS:
+            raise ValueError("%s:%d has %d distinct symbols and no spill record; the device record keeps %d" % (chrom, pos, n_sym, L.MAX_SYMS))
+        more = spill[code - 1]
+        ranked += [(chr(int(more["sym"][r])), int(more["total"][r]), int(more["fwd"][r]), int(more["rev"][r])) for r in range(n_sym - L.MAX_SYMS)]
+    syms = [t[0] for t in ranked]
+    total = {t[0]: t[1] for t in ranked}
+    fwd = {t[0]: t[2] for t in ranked}
+    rev = {t[0]: t[3] for t in ranked}
     if int(c["good_depth"]) == 0:                       # most_common_good_bases is None
         alt, gt, ad, adf, adr = [], ".", "0", "0", "0"
     else:
@@ -86,7 +91,7 @@ def row_from_counts(chrom, pos, c, filter_names, preserve_ref_case, failed_snp_g
     return "\t".join([chrom, str(pos), ".", ref, ",".join(alt) if alt else ".", ".", ft, "NS=1", FORMAT_IDS, data])
 
 
-def format_rows(counts, order, contig_names, contig_name_off, site_keys, filter_names, preserve_ref_case, failed_snp_gt):
+def format_rows(counts, order, contig_names, contig_name_off, site_keys, filter_names, preserve_ref_case, failed_snp_gt, spill=None):
     """The data lines of ``order`` as one bytes object, formatted by the library (snpgpu_format_vcf_rows: the same layout as
     row_from_counts, which stays as the readable statement of it and is tested against it row by row)."""
     import ctypes as C
@@ -100,14 +105,20 @@ def format_rows(counts, order, contig_names, contig_name_off, site_keys, filter_
     bad = C.c_int32(-1)
     ptr = lambda a: a.ctypes.data_as(C.c_void_p)      # noqa: E731
     gt = failed_snp_gt.encode("ascii")
+    if spill is not None and len(spill):
+        spill = np.ascontiguousarray(spill)
+        sp, n_sp = ptr(spill), len(spill)
+    else:
+        sp, n_sp = None, 0
     need = lib.snpgpu_format_vcf_rows(ptr(counts), ptr(order), len(order), ptr(names), ptr(offs), ptr(keys), fn,
-                                      1 if preserve_ref_case else 0, gt, None, 0, C.byref(bad))
+                                      1 if preserve_ref_case else 0, gt, sp, n_sp, None, 0, C.byref(bad))
     if bad.value >= 0:
         slot = int(order[bad.value])
-        raise ValueError("site #%d has %d distinct symbols; the device record keeps %d" % (slot, int(counts[slot]["n_symbols"]), L.MAX_SYMS))
+        raise ValueError("site #%d has %d distinct symbols and no spill record; the device record keeps %d"
+                         % (slot, int(counts[slot]["n_symbols"]) & 0xFF, L.MAX_SYMS))
     buf = C.create_string_buffer(max(int(need), 1))
     lib.snpgpu_format_vcf_rows(ptr(counts), ptr(order), len(order), ptr(names), ptr(offs), ptr(keys), fn,
-                               1 if preserve_ref_case else 0, gt, buf, int(need), C.byref(bad))
+                               1 if preserve_ref_case else 0, gt, sp, n_sp, buf, int(need), C.byref(bad))
     return buf.raw[:int(need)]
 
 
@@ -120,13 +131,13 @@ def write_consensus_vcf(path, sample_id, args, siteset, result, line_offsets, pa
     have = np.nonzero(ok if parsed is None else (ok & parsed))[0]
     order = have[np.argsort(line_offsets[have], kind="stable")]
     rows = format_rows(result.counts, order, siteset._names, siteset._offs, siteset.keys, names, args.vcfPreserveRefCase,
-                       args.vcfFailedSnpGt)
+                       args.vcfFailedSnpGt, spill=getattr(result, "spill", None))
     with open(path, "wb") as f:
         f.write(("\n".join(header_lines(sample_id, filters, args.vcfRefName)) + "\n").encode("ascii"))
         f.write(rows)
 
 
-def write_all_positions_vcf(path, sample_id, args, pileup_path, line_offsets, counts):
+def write_all_positions_vcf(path, sample_id, args, pileup_path, line_offsets, counts, spill=None):
     """--vcfAllPos (call_consensus.py:148-151): one row per pileup LINE, in file order.  The numbers come from the
     per-line records of ``Device.call_all_lines``; CHROM and POS are the first two fields of the line itself."""
     import mmap
@@ -146,6 +157,6 @@ def write_all_positions_vcf(path, sample_id, args, pileup_path, line_offsets, co
                         end = mm.find(b"\n", start)
                         fields = mm[start:end if end >= 0 else len(mm)].split(None, 2)
                     f.write(row_from_counts(fields[0].decode("ascii"), int(fields[1]), counts[i], names,
-                                            args.vcfPreserveRefCase, args.vcfFailedSnpGt) + "\n")
+                                            args.vcfPreserveRefCase, args.vcfFailedSnpGt, spill=spill) + "\n")
             finally:
                 mm.close()

@@ -40,12 +40,20 @@ def check_against_oracle(d, data, snp_list, excluded, p):
             (rec.raw_depth, rec.good_depth, rec.forward_good_depth, rec.reverse_good_depth), key
         assert c["cons_base"] == base and c["filters"] == mask, key
         ranked = rec.most_common_good_bases or []
-        assert c["n_symbols"] == len(ranked)
+        assert c["n_symbols"] & 0xFF == len(ranked)
         for r, sym in enumerate(ranked[:L.MAX_SYMS]):
             assert c["sym"][r] == sym
             assert c["total"][r] == rec.base_good_depth[sym]
             assert c["fwd"][r] == rec.forward_base_good_depth.get(sym, 0)
             assert c["rev"][r] == rec.reverse_base_good_depth.get(sym, 0)
+        if len(ranked) > L.MAX_SYMS:                                # ranks 8, 9, ...: the position's spill record
+            more = res.spill[(int(c["n_symbols"]) >> 8) - 1]
+            assert more["n"] == len(ranked) - L.MAX_SYMS
+            for r, sym in enumerate(ranked[L.MAX_SYMS:]):
+                assert (more["sym"][r], more["total"][r], more["fwd"][r], more["rev"][r]) == \
+                    (sym, rec.base_good_depth[sym], rec.forward_base_good_depth.get(sym, 0), rec.reverse_base_good_depth.get(sym, 0)), (key, sym)
+        else:
+            assert c["n_symbols"] >> 8 == 0
     # the throughput path (no per-site counts: one lane per site, leftovers by the wave-per-site kernel) must agree
     got2, res2, _ = gpu_consensus(d, data, snp_list, excluded, p, want_counts=False)
     assert got2 == want

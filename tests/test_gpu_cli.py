@@ -287,3 +287,61 @@ def test_consensus_vcf_rows_for_repeated_positions(tmp_path):
         want.append(vo.vcf_row(rec, [names[i] for i in range(6) if mask >> i & 1] or None, "."))
     got = [x for x in (sdir / "consensus.vcf").read_text().split("\n") if x and not x.startswith("#")]
     assert got == want
+
+
+def test_positions_with_more_than_eight_symbols_get_all_their_alt_alleles(tmp_path):
+    """pileup.Record ranks any number of distinct symbols (pileup.py:259-266) and consensus.vcf lists every one that is not the
+    reference as an ALT allele with its depths (vcf_writer.py:317-331).  The per-site record keeps eight; the rest comes back
+    through the context's spill.  Read bases with IUPAC codes give 10 to 16 symbols here: rows of the per-sample command, of
+    --vcfAllPos and of the batch command against the oracle's writer."""
+    import random
+    rng = random.Random(5)
+    alphabet = "ACGTNRYKMSWBDHV*"
+    lines, keys = [], []
+    for i in range(40):
+        pos = 100 + 7 * i
+        k = rng.choice((3, 6, 9, 10, 12, 16))
+        syms = rng.sample(alphabet, k)
+        reads = [rng.choice(syms) for _ in range(rng.randint(k, 60))] + syms
+        rng.shuffle(reads)
+        bases = "".join(c.lower() if (c != "*" and rng.random() < 0.5) else c for c in reads)
+        quals = "".join(chr(33 + rng.randint(0, 40)) for _ in reads)
+        lines.append("ctg1\t%d\t%s\t%d\t%s\t%s" % (pos, rng.choice("ACGTacgt"), len(reads), bases, quals))
+        keys.append((b"ctg1", pos))
+    data = ("\n".join(lines) + "\n").encode()
+    params = po.CallerParams(10, 0.6, 3, 0, 0.0)
+    want, detail = po.call_consensus_sites(data, keys, set(), params)
+    assert sum(1 for rec, _, _ in detail.values() if len(rec.most_common_good_bases or []) > 8) >= 10
+    names = po.filter_names(params)
+    rows = []
+    for key in keys:
+        rec, base, mask = detail[key]
+        rows.append(vo.vcf_row(rec, [names[i] for i in range(6) if mask >> i & 1] or None, "."))
+    assert any(row.split("\t")[4].count(",") >= 9 for row in rows)             # ten or more ALT alleles in a row
+    with open(str(tmp_path / "snplist.txt"), "w") as f:
+        for c, p in keys:
+            f.write("%s\t%d\t1\ts\n" % (c.decode(), p))
+    flags = "--minBaseQual 10 --minConsFreq 0.6 --minConsDpth 3 --vcfRefName ref.fasta --vcfFileName consensus.vcf"
+    dirs = []
+    for name in ("sA", "sB"):
+        sdir = tmp_path / name
+        sdir.mkdir()
+        (sdir / "reads.all.pileup").write_bytes(data)
+        dirs.append(str(sdir))
+    fa = ">sA\n" + "".join(want.decode()[i:i + 60] + "\n" for i in range(0, len(want), 60))
+
+    def data_rows(path):
+        return [ln for ln in open(path).read().split("\n") if ln and not ln.startswith("#")]
+
+    _run("call_consensus -l %s/snplist.txt -o %s/consensus.fasta %s %s/reads.all.pileup" % (tmp_path, dirs[0], flags, dirs[0]))
+    assert open(dirs[0] + "/consensus.fasta").read() == fa and data_rows(dirs[0] + "/consensus.vcf") == rows
+    _run("call_consensus -f --vcfAllPos -l %s/snplist.txt -o %s/consensus.fasta %s %s/reads.all.pileup" % (tmp_path, dirs[0], flags, dirs[0]))
+    assert data_rows(dirs[0] + "/consensus.vcf") == rows
+    (tmp_path / "dirs.txt").write_text("\n".join(dirs) + "\n")
+    for d in dirs:
+        for n in ("consensus.fasta", "consensus.vcf"):
+            if os.path.exists(os.path.join(d, n)):
+                os.remove(os.path.join(d, n))
+    _run("call_consensus_batch -l %s/snplist.txt %s %s/dirs.txt" % (tmp_path, flags, tmp_path))
+    for d in dirs:
+        assert data_rows(d + "/consensus.vcf") == rows

@@ -27,7 +27,7 @@ def test_golden_record_vectors(d, pileup_vectors):
     from tests.gpu_util import gpu_consensus
     recs = pileup_vectors["records"]
     param_sets = sorted({tuple(c["params"]) for v in recs for q in v["by_q"].values() if "calls" in q for c in q["calls"]})
-    checked = 0
+    checked = spilled = 0
     for params in param_sets:
         p = po.CallerParams(*params)
         q = str(params[0])
@@ -48,16 +48,22 @@ def test_golden_record_vectors(d, pileup_vectors):
             assert chr(c["cons_base"]) == call["base"], (key, call)
             assert _names(int(c["filters"]), p) == call["failed"], (key, call)
             ranked = w["ranked"] or []
-            assert c["n_symbols"] == len(ranked)
+            assert c["n_symbols"] & 0xFF == len(ranked)
             tot, fw, rv = dict(map(tuple, w["total_hist"])), dict(map(tuple, w["fwd_hist"])), dict(map(tuple, w["rev_hist"]))
             for r, sym in enumerate(ranked[:L.MAX_SYMS]):
                 assert chr(c["sym"][r]) == sym
                 assert (c["total"][r], c["fwd"][r], c["rev"][r]) == (tot[sym], fw.get(sym, 0), rv.get(sym, 0)), (key, sym)
+            if len(ranked) > L.MAX_SYMS:                            # the reference ranks any number of symbols: the rest is in the spill
+                more = res.spill[(int(c["n_symbols"]) >> 8) - 1]
+                assert more["n"] == len(ranked) - L.MAX_SYMS
+                for r, sym in enumerate(ranked[L.MAX_SYMS:]):
+                    assert (chr(more["sym"][r]), more["total"][r], more["fwd"][r], more["rev"][r]) == (sym, tot[sym], fw.get(sym, 0), rv.get(sym, 0)), (key, sym)
+                spilled += 1
             checked += 1
         # the lane-per-site kernel on the same lines (no per-site counts requested)
         cons2, res2, _ = gpu_consensus(d, data, keys, [], p, want_counts=False)
         assert bytes(res2.bases) == bytes(res.bases) and bytes(res2.filters) == bytes(res.filters)
-    assert checked > 15000
+    assert checked > 15000 and spilled > 100
 
 
 def test_golden_error_lines_raise(d, pileup_vectors):

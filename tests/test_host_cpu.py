@@ -396,6 +396,31 @@ def test_library_vcf_formatter_equals_python_rows():
     recs[7]["n_symbols"] = 9
     with pytest.raises(ValueError):
         vcf_writer.format_rows(recs, order, cname, coff, keys, names, False, ".")
+    # more than eight symbols: ranks 8.. come from the spill record the position's n_symbols points at
+    from snp_pipeline_amd.device import SPILL_DTYPE
+    spill = np.zeros(3, dtype=SPILL_DTYPE)
+    for i, extra in ((7, 1), (20, 8), (33, 120)):
+        c = recs[i]
+        alphabet = [x for x in range(33, 127) if not (97 <= x <= 122)] + list(range(161, 256))
+        syms = rng.sample(alphabet, 8 + extra)
+        tot = sorted((rng.randint(1, 300) for _ in syms), reverse=True)
+        slot = {7: 0, 20: 1, 33: 2}[i]
+        c["n_symbols"] = (8 + extra) | ((slot + 1) << 8)
+        c["good_depth"] = sum(tot)
+        c["ref_base"] = syms[rng.randrange(len(syms))] if rng.random() < 0.7 else ord("A")
+        spill[slot]["n"] = extra
+        for r, (sym, t) in enumerate(zip(syms, tot)):
+            f = rng.randint(0, t)
+            tgt, k = (c, r) if r < 8 else (spill[slot], r - 8)
+            tgt["sym"][k], tgt["total"][k], tgt["fwd"][k], tgt["rev"][k] = sym, t, f, t - f
+    recs[33]["ref_base"] = ord("A")                             # (a latin-1 symbol as REF would not be ASCII text)
+    text = vcf_writer.format_rows(recs, order, cname, coff, keys, names, True, ".", spill=spill)
+    want = "".join(vcf_writer.row_from_counts(contigs[int(keys[j]) >> 32].decode(), int(keys[j]) & 0xFFFFFFFF, recs[j], names, True, ".", spill=spill) + "\n"
+                   for j in order)
+    assert text == want.encode("latin-1")
+    assert max(ln.split(b"\t")[4].count(b",") for ln in text.split(b"\n") if ln) >= 126
+    with pytest.raises(ValueError):                             # a record that points past the spill it is given
+        vcf_writer.format_rows(recs, order, cname, coff, keys, names, True, ".", spill=spill[:2])
 
 
 def test_library_distance_tsv_writer_equals_reference_layout(tmp_path, fixture_trees):
@@ -1006,3 +1031,67 @@ def test_library_distance_tsv_writer_in_parallel_row_blocks(tmp_path):
     # a file that cannot be created is an IOError, also on the threaded path
     with pytest.raises(IOError):
         distance.write_pairwise(str(tmp_path / "no_such_dir" / "p.tsv"), ids, mat)
+
+
+def test_vcf_split_copies_record_lines_which_is_the_pyvcf_round_trip_for_varscan_output(tmp_path):
+    """filter_regions writes var.flt_preserved / _removed.vcf by copying the input's record lines.  The reference sends every
+    record through PyVCF3's reader and writer (filter_regions.py:250-275), which re-formats what it parsed as numbers: a
+    Float-typed INFO / FORMAT value ("60.00" -> "60.0") and a numeric QUAL.  VarScan's output — the only caller the pipeline
+    runs in front of filter_regions — has neither: pinned here on every bundled var.flt.vcf (no Type=Float in any header, QUAL
+    '.' in every record, and every bundled var.flt_preserved + _removed pair is a verbatim partition of its var.flt.vcf).
+    The second half documents the known difference for other callers' files: the lines are still copied, not re-formatted."""
+    import tarfile
+    import numpy as np
+    from snp_pipeline_amd import filter_regions as fr
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fixtures")
+    n_files = n_records = n_pairs = 0
+    for ds in ("lambdaVirus", "agona", "listeria"):
+        with tarfile.open(os.path.join(here, ds, "expected.tar.xz")) as t:
+            members = {m.name: m for m in t.getmembers()}
+            for name, m in members.items():
+                if not name.endswith("/var.flt.vcf"):
+                    continue
+                lines = t.extractfile(m).read().decode().splitlines(True)
+                header = [ln for ln in lines if ln.startswith("#")]
+                records = [ln for ln in lines if not ln.startswith("#")]
+                assert not any("Type=Float" in ln for ln in header)
+                assert all(ln.split("\t")[5] == "." for ln in records)
+                n_files += 1
+                n_records += len(records)
+                pres, rem = name[:-4] + "_preserved.vcf", name[:-4] + "_removed.vcf"
+                if pres in members and rem in members:
+                    kept = [ln for ln in t.extractfile(members[pres]).read().decode().splitlines(True) if not ln.startswith("#")]
+                    gone = [ln for ln in t.extractfile(members[rem]).read().decode().splitlines(True) if not ln.startswith("#")]
+                    assert sorted(kept + gone, key=records.index) == records and not set(kept) & set(gone)
+                    n_pairs += 1
+    assert n_files >= 50 and n_records > 1000 and n_pairs >= 4
+    # another caller's file: MQ is Float-typed; PyVCF3 would write MQ=60.0, the copy keeps the text
+    other = tmp_path / "other.vcf"
+    other.write_text('##fileformat=VCFv4.1\n##INFO=<ID=MQ,Number=1,Type=Float,Description="mapping quality">\n'
+                     "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n"
+                     "c1\t5\t.\tA\tG\t30.50\tPASS\tMQ=60.00\tGT\t1\nc1\t9\t.\tC\tT\t.\tPASS\tMQ=7\tGT\t1\n")
+    header, data_lines, (names, cidx, pos) = fr._read_vcf(str(other))
+    assert list(pos) == [5, 9] and names == ["c1"]
+    out = tmp_path / "split.vcf"
+    fr._write_vcf(str(out), header, data_lines, np.array([True, False]))
+    assert out.read_text().splitlines()[-1] == "c1\t5\t.\tA\tG\t30.50\tPASS\tMQ=60.00\tGT\t1"
+
+
+def test_a_pileup_that_is_no_regular_file_is_an_input_error_as_a_fifo_is_for_the_reference(tmp_path):
+    """pileup.Reader opens the file, closes it, and opens it again to read (pileup.py:401-403, 414): a FIFO does not survive
+    that — the writer sees the first reader go away — so the reference cannot consume one either.  Here a pileup path that
+    is not a regular file is refused before anything is read (SNPGPU_E_IO per file in the library: csrc/stream.hip), with the
+    reference's input-file error protocol at the CLI: nothing blocks on a pipe nobody writes to."""
+    import stat
+    import subprocess
+    import sys
+    fifo = tmp_path / "reads.all.pileup"
+    os.mkfifo(str(fifo))
+    assert stat.S_ISFIFO(os.stat(str(fifo)).st_mode)
+    snplist = tmp_path / "snplist.txt"
+    snplist.write_text("c1\t5\t1\ts1\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bin", "cfsan_snp_pipeline"), "call_consensus", "-l", str(snplist),
+                        "-o", str(tmp_path / "consensus.fasta"), str(fifo)], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, SNPGPU_SERVICE=""))
+    assert r.returncode != 0 and not (tmp_path / "consensus.fasta").exists()
