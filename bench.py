@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-PROFILE_ROUND = "r2"
+PROFILE_ROUND = "r3"
 
 
 def parse_args():
@@ -913,7 +913,7 @@ def main():
     # quoted when it was measured on this very workload
     traffic = None
     traffic_note = None
-    for rnd in (PROFILE_ROUND, "r1"):
+    for rnd in (PROFILE_ROUND, "r2", "r1"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
                 pt = json.load(f)
