@@ -55,7 +55,7 @@ extern "C" {
 #define SNPGPU_ST_SHORT_LINE   2   /* < 4 fields: IndexError in pileup.py:224-225 */
 #define SNPGPU_ST_BAD_DEPTH    3   /* depth field is not [0-9]+: ValueError in pileup.py:225 */
 #define SNPGPU_ST_NO_QUALS     4   /* depth > 0 and exactly 5 fields: IndexError in pileup.py:237 */
-#define SNPGPU_ST_MULTI_REF    5   /* reference-base field longer than one byte (unsupported) */
+#define SNPGPU_ST_MULTI_REF    5   /* reference-base field longer than SNPGPU_SPILL_REF bytes (unsupported) */
 
 typedef struct snpgpu_ctx snpgpu_ctx;
 typedef struct snpgpu_siteset snpgpu_siteset;
@@ -80,9 +80,10 @@ typedef struct snpgpu_site_counts {
     uint32_t good_depth;            /* Record.good_depth */
     uint32_t fwd_good_depth;        /* Record.forward_good_depth */
     uint32_t rev_good_depth;        /* Record.reverse_good_depth */
-    uint32_t n_symbols;             /* bits 0-7: distinct upper-cased symbols with good depth; when that is more than 8: bits 8-31
-                                     * = 1 + index of the position's snpgpu_symbol_spill record (0xFFFFFF: there was no room) */
-    uint8_t  ref_base;              /* Record.reference_base, case preserved */
+    uint32_t n_symbols;             /* bits 0-7: distinct upper-cased symbols with good depth; when that is more than 8, or the
+                                     * reference-base field has more than one byte: bits 8-31 = 1 + index of the position's
+                                     * snpgpu_symbol_spill record (0xFFFFFF: there was no room) */
+    uint8_t  ref_base;              /* Record.reference_base (its first byte), case preserved */
     uint8_t  cons_base;             /* ConsensusCaller.call_consensus()[0] */
     uint8_t  filters;               /* SNPGPU_F_* mask, incl. REGION */
     uint8_t  status;                /* SNPGPU_ST_* */
@@ -94,17 +95,22 @@ typedef struct snpgpu_site_counts {
 
 /* Ranks 8, 9, ... of a position with more than SNPGPU_MAX_SYMS distinct symbols (pileup.py:259-266 ranks any number of them and
  * vcf_writer.py:317-331 lists every one as an ALT allele): the record itself keeps the first eight, the rest goes to one of
- * SNPGPU_SPILL_CAP records the context holds.  A call that produces per-site records starts with an empty spill;
+ * SNPGPU_SPILL_CAP records the context holds.  The same record carries a reference-base field of more than one byte
+ * (pileup.py:223 takes any string; every '.' / ',' then stands for all of its characters, pileup.py:255-258, and the VCF
+ * REF column shows the string): ref_len > 1 and ref[] hold it, n may be 0.  A call that produces per-site records starts with an empty spill;
  * snpgpu_symbol_spill_read copies out what the context's calls have put there since (synchronises the context's stream). */
 #define SNPGPU_SPILL_SYMS 120
+#define SNPGPU_SPILL_REF  64
 #define SNPGPU_SPILL_CAP  1024
 typedef struct snpgpu_symbol_spill {
     uint32_t n;                         /* entries used */
-    uint32_t reserved[3];
+    uint32_t ref_len;                   /* 0 or 1: the record's ref_base is the whole field; else bytes used of ref[] */
+    uint32_t reserved[2];
     uint8_t  sym[SNPGPU_SPILL_SYMS];    /* most_common_good_bases[8 + k] */
     uint32_t total[SNPGPU_SPILL_SYMS];
     uint32_t fwd[SNPGPU_SPILL_SYMS];
     uint32_t rev[SNPGPU_SPILL_SYMS];
+    uint8_t  ref[SNPGPU_SPILL_REF];     /* Record.reference_base when it is longer than one byte, case preserved */
 } snpgpu_symbol_spill;
 
 /* Result words of one pileup scan (device-written, 4 x u64). */

@@ -273,6 +273,27 @@ def gen_pileup_vectors(captured):
 
 
 
+LONG_REFS = ["AC", "ac", "Ac", "N,", ".,", ",.", "A.", "gT,", "12", "*A", "a[", "`T", "ACGTNacgtn", ",,", "..", "T,c.G", "zZ", "-+",
+             "AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAa"]
+
+
+def gen_longref_vectors():
+    """pileup.Record on lines whose reference-base field has several bytes (pileup.py:223 takes any string; '.' and ','
+    are then replaced by the whole upper- / lower-cased field, pileup.py:255-258)."""
+    from snppipeline import pileup
+    from oracle import fuzz
+    rng = random.Random(4242)
+    lines = []
+    for k in range(600):
+        f = fuzz.fuzz_line(rng).split("\t")
+        if len(f) < 6:
+            continue
+        f[2] = LONG_REFS[k % len(LONG_REFS)]
+        lines.append("\t".join(f))
+    lines += ["ID\t42\tGC\t14\taaaAAA....,,,,\t00011122223333", "ID\t43\tg,\t6\t..,,AC\tIIIIII", "ID\t44\tAC\t0", "ID\t45\tAC\t3\t.,.\t!!!"]
+    return {"records": [record_vector(pileup, ln) for ln in lines]}
+
+
 def gen_steps_vectors():
     from snppipeline import filter_regions as fr
     from snppipeline import utils as ru
@@ -526,6 +547,9 @@ def main():
     if sys.argv[1:] == ["--only", "metrics"]:
         dump("metrics_vectors.json.gz", gen_metrics_vectors())
         return
+    if sys.argv[1:] == ["--only", "longref"]:
+        dump("longref_vectors.json.gz", gen_longref_vectors())
+        return
     if sys.argv[1:] == ["--only", "runs2"]:
         # later additions: shapes the device kernels treat specially (512-byte lane window, long contig names,
         # positions around the powers of ten), again through the reference's own driver
@@ -542,6 +566,7 @@ def main():
     dump("steps_vectors.json.gz", gen_steps_vectors())
     dump("cli_vectors.json.gz", gen_cli_vectors())
     dump("metrics_vectors.json.gz", gen_metrics_vectors())
+    dump("longref_vectors.json.gz", gen_longref_vectors())
     copy_fixtures()
 
 

@@ -157,28 +157,25 @@ def parse_record(fields, min_base_quality):
         return rec
     bases = strip_bases(fields[4])
     quals = fields[5]                      # IndexError when absent, as pileup.py:237
-    if len(rec.reference_base) != 1:
-        raise NotImplementedError("multi-byte reference base field")
-    ref = rec.reference_base[0]
-    ref_up, ref_lo = _upper(ref), _lower(ref)
+    # bases_str.replace('.', ref.upper()).replace(',', ref.lower()), pileup.py:255-258, for a field of any length: a ','
+    # that the first replace brought in (the field itself holds one) is hit by the second replace too
+    ref_lo = bytes(_lower(c) for c in rec.reference_base)
+    for_dot = b"".join(ref_lo if c == 0x2C else bytes([_upper(c)]) for c in rec.reference_base)
     total, fwd, rev = {}, {}, {}
     good = nf = nr = 0
-    for b, q in zip(bases, quals):         # zip truncates at the shorter one
+    for b0, q in zip(bases, quals):        # zip truncates at the shorter one
         if q - 33 < min_base_quality:
             continue
-        good += 1
-        if b == 0x2E:
-            b = ref_up
-        elif b == 0x2C:
-            b = ref_lo
-        u = _upper(b)
-        total[u] = total.get(u, 0) + 1
-        if b <= 0x5A:
-            nf += 1
-            fwd[b] = fwd.get(b, 0) + 1
-        elif b >= 0x61:
-            nr += 1
-            rev[u] = rev.get(u, 0) + 1
+        good += 1                          # good_depth counts reads (pileup.py:250), whatever they are spelled out to
+        for b in (for_dot if b0 == 0x2E else ref_lo if b0 == 0x2C else (b0,)):
+            u = _upper(b)
+            total[u] = total.get(u, 0) + 1
+            if b <= 0x5A:
+                nf += 1
+                fwd[b] = fwd.get(b, 0) + 1
+            elif b >= 0x61:
+                nr += 1
+                rev[u] = rev.get(u, 0) + 1
     rec.good_depth, rec.forward_good_depth, rec.reverse_good_depth = good, nf, nr
     rec.base_good_depth, rec.forward_base_good_depth, rec.reverse_base_good_depth = total, fwd, rev
     if good >= 1:
@@ -213,9 +210,10 @@ def call_record(rec, p):
     bias = n * p.min_cons_strand_bias
     if nf < bias or nr < bias:
         mask |= F_STRBIAS
-    ref = rec.reference_base[0]
-    if cons == _upper(ref):
-        cons = ref
+    if len(rec.reference_base) == 1:       # (a one-character base never equals a longer field, pileup.py:586-587)
+        ref = rec.reference_base[0]
+        if cons == _upper(ref):
+            cons = ref
     return cons, mask
 
 

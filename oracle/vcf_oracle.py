@@ -14,7 +14,7 @@ def vcf_row(rec, failed, failed_snp_gt=".", preserve_ref_case=False):
     upper_ref = ref.upper()
     if not preserve_ref_case:
         ref = upper_ref
-    ur = ord(upper_ref)
+    ur = ord(upper_ref) if len(upper_ref) == 1 else None      # a field of several characters equals no symbol
     if rec.most_common_good_bases is None:
         alt, gt, ad, adf, adr = [], ".", "0", "0", "0"
     else:

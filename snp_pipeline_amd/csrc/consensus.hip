@@ -151,7 +151,7 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
         const uint64_t lv = cur.lv;
         const uint32_t sflags = cur.sflags;
         uint32_t status = SNPGPU_ST_NO_LINE, filters = 0, cons = '-', out_b = '-';
-        uint32_t raw_depth = 0, good = 0, nfwd = 0, nrev = 0, nsym = 0, ref = 0;
+        uint32_t raw_depth = 0, good = 0, nfwd = 0, nrev = 0, nsym = 0, ref = 0, ref_len = 1, ref_at = 0;
         bool have_hist = false;
         if (lv != 0) {
             const uint64_t ls = lv - 1;
@@ -183,9 +183,11 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
             const uint8_t *gl = buf + ls;                 // line bytes in global memory
             auto lb = [&](uint32_t off) -> uint32_t { return off < CALL_LBUF ? L.line[off] : (uint32_t)gl[off]; };
             if (nfields < 4) status = SNPGPU_ST_SHORT_LINE;
-            else if (L.fe[2] - L.fs[2] != 1) status = SNPGPU_ST_MULTI_REF;
+            else if (L.fe[2] - L.fs[2] > SNPGPU_SPILL_REF) status = SNPGPU_ST_MULTI_REF;
             else {
-                ref = lb(L.fs[2]);
+                ref_at = L.fs[2];
+                ref_len = L.fe[2] - L.fs[2];                   // (a field has at least one byte)
+                ref = lb(ref_at);
                 uint32_t ds = L.fs[3], de = L.fe[3];
                 PyInt di;                                    // int(depth), pileup.py:225 ("+30" and "3_0" are integers too)
                 for (uint32_t q = ds; q < de; ++q) di.feed(lb(q));   // uniform loop, a handful of bytes
@@ -200,7 +202,9 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
                 have_hist = true;
                 const uint32_t bs = L.fs[4], be = L.fe[4], qs = L.fs[5], qe = L.fe[5];
                 const uint32_t L0 = be - bs, qlen = qe - qs;
-                const uint32_t ref_up = to_upper(ref), ref_lo = to_lower(ref);
+                // A reference field of several bytes (pileup.py:223 takes any string): '.' and ',' are counted as themselves
+                // here and spelled out afterwards
+                const uint32_t ref_up = ref_len == 1 ? to_upper(ref) : (uint32_t)'.', ref_lo = ref_len == 1 ? to_lower(ref) : (uint32_t)',';
                 const int minq = a.prm.min_base_quality;
                 if (line_len <= CALL_LBUF && L0 <= CALL_LMAX) {
                     // ---- pass A: '^' + next byte (pileup.py:312).  Openers are the carets at even distance from
@@ -297,6 +301,22 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
                     good = __builtin_amdgcn_readfirstlane(good);
                 }
                 __builtin_amdgcn_wave_barrier();
+                if (ref_len > 1) {
+                    // bases_str.replace('.', ref.upper()).replace(',', ref.lower()) (pileup.py:255-258): every good '.' stands
+                    // for all characters of the upper-cased field — and a ',' among THOSE is hit by the second replace too —,
+                    // every good ',' for all characters of the lower-cased field.  good_depth stays the number of reads.
+                    if (lane == 0) {
+                        const uint32_t nd = L.hist[(uint32_t)'.'], nc = L.hist[(uint32_t)','];      // both bytes are <= 'Z': strand class 0
+                        L.hist[(uint32_t)'.'] = 0; L.hist[(uint32_t)','] = 0;
+                        for (uint32_t i = 0; i < ref_len; ++i) {
+                            const uint32_t u = to_upper(lb(ref_at + i));
+                            if (u == ',') { for (uint32_t j = 0; j < ref_len; ++j) L.hist[hist_bin(to_lower(lb(ref_at + j)))] += nd; }
+                            else L.hist[hist_bin(u)] += nd;
+                            L.hist[hist_bin(to_lower(lb(ref_at + i)))] += nc;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
 
@@ -338,34 +358,6 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
                     top_r[r] = __builtin_amdgcn_readlane(tr, owner);
                     if (lane == owner) { if (sym < 64) t0 = 0; else t1 = 0; }
                 }
-                // more than the record keeps (consensus.vcf lists every one as an ALT allele): ranks 8, 9, ... in the same order go to
-                // a spill record of the context; its index + 1 travels in the upper bits of n_symbols
-                if (a.out_counts && nsym > SNPGPU_MAX_SYMS) {
-                    uint32_t slot = 0xFFFFFFu;
-                    if (a.spill) {
-                        if (lane == 0) slot = atomicAdd(a.spill_n, 1u);
-                        slot = __builtin_amdgcn_readfirstlane(slot);
-                    }
-                    if (slot < SNPGPU_SPILL_CAP) {
-                        snpgpu_symbol_spill *sp = a.spill + slot;
-                        uint32_t r = 0;
-                        for (; r < SNPGPU_SPILL_SYMS; ++r) {
-                            uint64_t k0 = t0 ? ((uint64_t)t0 << 8) | (255u - lane) : 0ull;
-                            uint64_t k1 = t1 ? ((uint64_t)t1 << 8) | (255u - (lane + 64)) : 0ull;
-                            uint64_t best = k0 > k1 ? k0 : k1;
-                            for (int o = 32; o; o >>= 1) { uint64_t other = __shfl_xor((unsigned long long)best, o); best = other > best ? other : best; }
-                            if (best == 0) break;
-                            const uint32_t sym = 255u - (uint32_t)(best & 255u), owner = sym & 63u;
-                            const uint32_t ef = __builtin_amdgcn_readlane(sym < 64 ? f0 : f1, owner), er = __builtin_amdgcn_readlane(sym < 64 ? r0 : r1, owner);
-                            if (lane == 0) { sp->sym[r] = (uint8_t)sym; sp->total[r] = (uint32_t)(best >> 8); sp->fwd[r] = ef; sp->rev[r] = er; }
-                            if (lane == owner) { if (sym < 64) t0 = 0; else t1 = 0; }
-                        }
-                        if (lane == 0) sp->n = r;
-                        nsym |= (slot + 1u) << 8;
-                    } else {
-                        nsym |= 0xFFFFFFu << 8;                   // no room (or no spill): the writer refuses this record
-                    }
-                }
                 cons = top_sym[0];
                 const uint32_t n = top_t[0], nf = top_f[0], nr = top_r[0];
                 // CPython compares int < float exactly; one IEEE double multiply, no contraction (pileup.py:564, 580-582)
@@ -374,7 +366,40 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
                 if ((int64_t)nf < (int64_t)a.prm.min_cons_strand_depth || (int64_t)nr < (int64_t)a.prm.min_cons_strand_depth) filters |= SNPGPU_F_STRDPTH;
                 const double bias = (double)n * a.prm.min_cons_strand_bias;
                 if ((double)nf < bias || (double)nr < bias) filters |= SNPGPU_F_STRBIAS;
-                if (cons == to_upper(ref)) cons = ref;
+                if (ref_len == 1 && cons == to_upper(ref)) cons = ref;                     // (a one-character base never equals a longer field)
+            }
+            // more symbols than the record keeps (consensus.vcf lists every one as an ALT allele), or a reference field of several
+            // bytes (with or without good reads): ranks 8, 9, ... in the same order and the field go to a spill record of the
+            // context; its index + 1 travels in the upper bits of n_symbols
+            if (a.out_counts && (nsym > SNPGPU_MAX_SYMS || ref_len > 1)) {
+                uint32_t slot = 0xFFFFFFu;
+                if (a.spill) {
+                    if (lane == 0) slot = atomicAdd(a.spill_n, 1u);
+                    slot = __builtin_amdgcn_readfirstlane(slot);
+                }
+                if (slot < SNPGPU_SPILL_CAP) {
+                    snpgpu_symbol_spill *sp = a.spill + slot;
+                    uint32_t r = 0;
+                    for (; r < SNPGPU_SPILL_SYMS; ++r) {
+                        uint64_t k0 = t0 ? ((uint64_t)t0 << 8) | (255u - lane) : 0ull;
+                        uint64_t k1 = t1 ? ((uint64_t)t1 << 8) | (255u - (lane + 64)) : 0ull;
+                        uint64_t best = k0 > k1 ? k0 : k1;
+                        for (int o = 32; o; o >>= 1) { uint64_t other = __shfl_xor((unsigned long long)best, o); best = other > best ? other : best; }
+                        if (best == 0) break;
+                        const uint32_t sym = 255u - (uint32_t)(best & 255u), owner = sym & 63u;
+                        const uint32_t ef = __builtin_amdgcn_readlane(sym < 64 ? f0 : f1, owner), er = __builtin_amdgcn_readlane(sym < 64 ? r0 : r1, owner);
+                        if (lane == 0) { sp->sym[r] = (uint8_t)sym; sp->total[r] = (uint32_t)(best >> 8); sp->fwd[r] = ef; sp->rev[r] = er; }
+                        if (lane == owner) { if (sym < 64) t0 = 0; else t1 = 0; }
+                    }
+                    if (lane == 0) {
+                        sp->n = r;
+                        sp->ref_len = ref_len > 1 ? ref_len : 0u;
+                        if (ref_len > 1) for (uint32_t i = 0; i < ref_len; ++i) sp->ref[i] = (uint8_t)((ref_at + i) < CALL_LBUF ? (uint32_t)L.line[ref_at + i] : (uint32_t)buf[lv - 1 + ref_at + i]);
+                    }
+                    nsym |= (slot + 1u) << 8;
+                } else {
+                    nsym |= 0xFFFFFFu << 8;                   // no room (or no spill): the writer refuses this record
+                }
             }
             if (sflags & SNPGPU_SITE_EXCLUDED) filters |= SNPGPU_F_REGION;
             out_b = (filters || cons == '*') ? '-' : cons;                                // call_consensus.py:169-176

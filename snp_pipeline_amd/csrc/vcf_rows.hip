@@ -39,11 +39,13 @@ bool put_row(Out &o, const snpgpu_site_counts &c, uint32_t mask, uint64_t key, c
     // the ranked symbols: eight in the record, the rest (rare) in the position's spill record
     const uint32_t n_symbols = c.n_symbols & 0xFFu, spill_code = c.n_symbols >> 8;
     const snpgpu_symbol_spill *more = nullptr;
-    if (n_symbols > SNPGPU_MAX_SYMS) {
+    if (n_symbols > SNPGPU_MAX_SYMS || spill_code != 0) {
         if (!spill || spill_code == 0 || spill_code - 1 >= n_spill) return false;
         more = &spill[spill_code - 1];
-        if (more->n != n_symbols - SNPGPU_MAX_SYMS || more->n > SNPGPU_SPILL_SYMS) return false;
+        if (more->n != (n_symbols > SNPGPU_MAX_SYMS ? n_symbols - SNPGPU_MAX_SYMS : 0u) || more->n > SNPGPU_SPILL_SYMS || more->ref_len > SNPGPU_SPILL_REF) return false;
     }
+    // a reference field of several bytes: REF shows the string, and no single symbol equals it (vcf_writer.py:295-331)
+    const bool long_ref = more && more->ref_len > 1;
     auto sym_of = [&](int k) -> char { return (char)(k < SNPGPU_MAX_SYMS ? c.sym[k] : more->sym[k - SNPGPU_MAX_SYMS]); };
     auto total_of = [&](int k) -> uint32_t { return k < SNPGPU_MAX_SYMS ? c.total[k] : more->total[k - SNPGPU_MAX_SYMS]; };
     auto fwd_of = [&](int k) -> uint32_t { return k < SNPGPU_MAX_SYMS ? c.fwd[k] : more->fwd[k - SNPGPU_MAX_SYMS]; };
@@ -68,19 +70,27 @@ bool put_row(Out &o, const snpgpu_site_counts &c, uint32_t mask, uint64_t key, c
     // ALT = ranked symbols other than the (upper-case) reference
     int alt[SNPGPU_MAX_SYMS + SNPGPU_SPILL_SYMS], n_alt = 0, ref_at = -1;
     for (uint32_t k = 0; k < n_symbols; ++k) {
-        if (sym_of((int)k) == upper_ref) ref_at = (int)k; else alt[n_alt++] = (int)k;
+        if (!long_ref && sym_of((int)k) == upper_ref) ref_at = (int)k; else alt[n_alt++] = (int)k;
     }
     char gt;
     const bool none = c.good_depth == 0;                    // most_common_good_bases is None
     if (none) { gt = '.'; n_alt = 0; }
     else {
-        gt = n_alt == 0 ? '0' : (sym_of(0) == upper_ref ? '0' : '1');
+        gt = n_alt == 0 ? '0' : (!long_ref && sym_of(0) == upper_ref ? '0' : '1');
         if (failed) gt = failed_snp_gt == '.' ? '.' : (failed_snp_gt == '0' ? '0' : '1');
     }
     const uint32_t cid = (uint32_t)(key >> 32);
     o.putn((const char *)contig_names + contig_name_off[cid], contig_name_off[cid + 1] - contig_name_off[cid]);
     o.put('\t'); o.putu(key & 0xFFFFFFFFull);
-    o.puts_("\t.\t"); o.put(ref); o.put('\t');
+    o.puts_("\t.\t");
+    if (long_ref) {
+        for (uint32_t i = 0; i < more->ref_len; ++i) {
+            char ch = (char)more->ref[i];
+            if (!preserve_ref_case && ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+            o.put(ch);
+        }
+    } else o.put(ref);
+    o.put('\t');
     if (n_alt == 0) o.put('.');
     else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.put(sym_of(alt[k])); }
     o.puts_("\t.\t"); o.putn(ft, ftn);

@@ -164,8 +164,9 @@ class SiteSet(object):
             pass
 
 
-SPILL_DTYPE = np.dtype([("n", "<u4"), ("reserved", "<u4", (3,)), ("sym", "u1", (L.SPILL_SYMS,)), ("total", "<u4", (L.SPILL_SYMS,)),
-                        ("fwd", "<u4", (L.SPILL_SYMS,)), ("rev", "<u4", (L.SPILL_SYMS,))])
+SPILL_DTYPE = np.dtype([("n", "<u4"), ("ref_len", "<u4"), ("reserved", "<u4", (2,)), ("sym", "u1", (L.SPILL_SYMS,)),
+                        ("total", "<u4", (L.SPILL_SYMS,)), ("fwd", "<u4", (L.SPILL_SYMS,)), ("rev", "<u4", (L.SPILL_SYMS,)),
+                        ("ref", "u1", (L.SPILL_REF,))])
 assert SPILL_DTYPE.itemsize == C.sizeof(L.SymbolSpill)
 
 
@@ -200,8 +201,8 @@ class Device(object):
 
     def read_symbol_spill(self, counts=None):
         """The spill records of the context's last call that produced per-site records (positions with more than 8 distinct
-        symbols); with `counts`: None unless one of those records points at one."""
-        if counts is not None and not (symbol_count(counts) > L.MAX_SYMS).any():
+        symbols or a reference-base field of several bytes); with `counts`: None unless one of those records points at one."""
+        if counts is not None and not (counts["n_symbols"] >> 8).any():
             return None
         out = np.zeros(L.SPILL_CAP, dtype=SPILL_DTYPE)
         n = C.c_uint32()
@@ -300,7 +301,7 @@ class Device(object):
             what, exc = {L.ST_SHORT_LINE: ("line has fewer than 4 fields", IndexError),
                          L.ST_BAD_DEPTH: ("depth field is not an unsigned decimal integer", ValueError),
                          L.ST_NO_QUALS: ("depth > 0 but no quality field", IndexError),
-                         L.ST_MULTI_REF: ("unsupported: reference-base field longer than one byte", None)
+                         L.ST_MULTI_REF: ("unsupported: reference-base field longer than %d bytes" % L.SPILL_REF, None)
                          }.get(code, ("malformed line", ValueError))
             raise PileupFormatError("pileup line for site #%d: %s" % (int(bad[0]), what), exc)
 

@@ -565,8 +565,9 @@ def hot_path_batch(args):
             # per sample, for the checks below: a malformed line at a listed position?  how many listed positions have a line?
             if S:
                 d_bad = (d_counts[:g, :S, 23] > L.ST_OK).any(dim=1) if want_vcf else ((d_filt[:g, :S] & 0x80) != 0).any(dim=1)
-                # (byte 16 of a record: its number of distinct symbols; more than 8 = the rest is in the context's spill)
-                d_ovf = (d_counts[:g, :S, 16] > L.MAX_SYMS).sum(dim=1) if want_vcf else torch.zeros(g, dtype=torch.int64, device="cuda")
+                # (bytes 17-19 of a record: nonzero = the position has a record in the context's spill — more than 8 symbols, or a
+                # reference field of several bytes)
+                d_ovf = (d_counts[:g, :S, 17:20] != 0).any(dim=2).sum(dim=1) if want_vcf else torch.zeros(g, dtype=torch.int64, device="cuda")
                 d_chk = torch.stack([d_bad.to(torch.int64), (d_line[:g, :S] != 0).sum(dim=1), d_ovf], dim=1)
             hs["status"][:g].copy_(d_status[:g], non_blocking=True)
             if S1:

@@ -63,11 +63,18 @@ def row_from_counts(chrom, pos, c, filter_names, preserve_ref_case, failed_snp_g
     failed = [filter_names[i] for i in range(6) if mask >> i & 1]
     n_sym, code = int(c["n_symbols"]) & 0xFF, int(c["n_symbols"]) >> 8
     ranked = [(chr(int(c["sym"][r])), int(c["total"][r]), int(c["fwd"][r]), int(c["rev"][r])) for r in range(min(n_sym, L.MAX_SYMS))]
-    if n_sym > L.MAX_SYMS:
-        if spill is None or code == 0 or code - 1 >= len(spill) or int(spill[code - 1]["n"]) != n_sym - L.MAX_SYMS:
-            raise ValueError("%s:%d has %d distinct symbols and no spill record; the device record keeps %d" % (chrom, pos, n_sym, L.MAX_SYMS))
+    if n_sym > L.MAX_SYMS or code:
+        extra = max(n_sym - L.MAX_SYMS, 0)
+        if spill is None or code == 0 or code - 1 >= len(spill) or int(spill[code - 1]["n"]) != extra:
+            raise ValueError("%s:%d has %d distinct symbols (or a long reference field) and no spill record; the device record keeps %d"
+                             % (chrom, pos, n_sym, L.MAX_SYMS))
         more = spill[code - 1]
-        ranked += [(chr(int(more["sym"][r])), int(more["total"][r]), int(more["fwd"][r]), int(more["rev"][r])) for r in range(n_sym - L.MAX_SYMS)]
+        ranked += [(chr(int(more["sym"][r])), int(more["total"][r]), int(more["fwd"][r]), int(more["rev"][r])) for r in range(extra)]
+        if int(more["ref_len"]) > 1:                    # a reference field of several bytes: the string itself, equal to no symbol
+            ref = bytes(more["ref"][:int(more["ref_len"])]).decode("latin-1")
+            upper_ref = ref.upper()
+            if not preserve_ref_case:
+                ref = upper_ref
     syms = [t[0] for t in ranked]
     total = {t[0]: t[1] for t in ranked}
     fwd = {t[0]: t[2] for t in ranked}

@@ -41,6 +41,11 @@ def steps_vectors():
     return load_golden("steps_vectors.json.gz")
 
 
+@pytest.fixture(scope="session")
+def longref_vectors():
+    return load_golden("longref_vectors.json.gz")
+
+
 def extract_fixture(dataset, dest):
     """Unpack tests/golden/fixtures/<dataset>/expected.tar.xz into dest; returns meta."""
     d = os.path.join(GOLD, "fixtures", dataset)

@@ -292,7 +292,8 @@ def test_consensus_vcf_rows_for_repeated_positions(tmp_path):
 def test_positions_with_more_than_eight_symbols_get_all_their_alt_alleles(tmp_path):
     """pileup.Record ranks any number of distinct symbols (pileup.py:259-266) and consensus.vcf lists every one that is not the
     reference as an ALT allele with its depths (vcf_writer.py:317-331).  The per-site record keeps eight; the rest comes back
-    through the context's spill.  Read bases with IUPAC codes give 10 to 16 symbols here: rows of the per-sample command, of
+    through the context's spill.  Read bases with IUPAC codes give 10 to 16 symbols here, and every fifth line has a reference
+    field of two or three bytes (REF shows the string, pileup.py:223, vcf_writer.py:295): rows of the per-sample command, of
     --vcfAllPos and of the batch command against the oracle's writer."""
     import random
     rng = random.Random(5)
@@ -306,7 +307,10 @@ def test_positions_with_more_than_eight_symbols_get_all_their_alt_alleles(tmp_pa
         rng.shuffle(reads)
         bases = "".join(c.lower() if (c != "*" and rng.random() < 0.5) else c for c in reads)
         quals = "".join(chr(33 + rng.randint(0, 40)) for _ in reads)
-        lines.append("ctg1\t%d\t%s\t%d\t%s\t%s" % (pos, rng.choice("ACGTacgt"), len(reads), bases, quals))
+        if i % 5 == 4:                                              # every '.' / ',' spelled out by a reference field of several bytes
+            bases = bases.replace("*", ".").replace("n", ",")
+        ref = rng.choice(("AC", "g,", "Tn", "ac.")) if i % 5 == 4 else rng.choice("ACGTacgt")
+        lines.append("ctg1\t%d\t%s\t%d\t%s\t%s" % (pos, ref, len(reads), bases, quals))
         keys.append((b"ctg1", pos))
     data = ("\n".join(lines) + "\n").encode()
     params = po.CallerParams(10, 0.6, 3, 0, 0.0)
@@ -318,6 +322,7 @@ def test_positions_with_more_than_eight_symbols_get_all_their_alt_alleles(tmp_pa
         rec, base, mask = detail[key]
         rows.append(vo.vcf_row(rec, [names[i] for i in range(6) if mask >> i & 1] or None, "."))
     assert any(row.split("\t")[4].count(",") >= 9 for row in rows)             # ten or more ALT alleles in a row
+    assert sum(1 for row in rows if len(row.split("\t")[3]) > 1) == 8          # REF strings
     with open(str(tmp_path / "snplist.txt"), "w") as f:
         for c, p in keys:
             f.write("%s\t%d\t1\ts\n" % (c.decode(), p))

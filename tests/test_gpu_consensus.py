@@ -23,11 +23,22 @@ def _names(mask, p):
 
 def test_golden_record_vectors(d, pileup_vectors):
     """Every fuzzed line the real reference parsed: counts, ranking, consensus and filter list."""
+    checked, spilled, long_refs = _golden_records(d, pileup_vectors["records"])
+    assert checked > 15000 and spilled > 100 and long_refs == 0
+
+
+def test_golden_reference_fields_of_several_bytes(d, longref_vectors):
+    """The same for lines whose reference-base field has several bytes (the real reference's Records): every '.' / ','
+    counts once per character of the field, the field itself travels in the position's spill record."""
+    checked, spilled, long_refs = _golden_records(d, longref_vectors["records"])
+    assert checked > 1500 and long_refs == checked
+
+
+def _golden_records(d, recs):
     from snp_pipeline_amd import _lib as L
     from tests.gpu_util import gpu_consensus
-    recs = pileup_vectors["records"]
     param_sets = sorted({tuple(c["params"]) for v in recs for q in v["by_q"].values() if "calls" in q for c in q["calls"]})
-    checked = spilled = 0
+    checked = spilled = long_refs = 0
     for params in param_sets:
         p = po.CallerParams(*params)
         q = str(params[0])
@@ -53,6 +64,13 @@ def test_golden_record_vectors(d, pileup_vectors):
             for r, sym in enumerate(ranked[:L.MAX_SYMS]):
                 assert chr(c["sym"][r]) == sym
                 assert (c["total"][r], c["fwd"][r], c["rev"][r]) == (tot[sym], fw.get(sym, 0), rv.get(sym, 0)), (key, sym)
+            if len(w["ref"]) > 1:                                   # the field itself is in the spill record, its first byte in the record
+                more = res.spill[(int(c["n_symbols"]) >> 8) - 1]
+                assert bytes(more["ref"][:int(more["ref_len"])]).decode() == w["ref"] and chr(c["ref_base"]) == w["ref"][0]
+                assert more["n"] == max(len(ranked) - L.MAX_SYMS, 0)
+                long_refs += 1
+            else:
+                assert chr(c["ref_base"]) == w["ref"]
             if len(ranked) > L.MAX_SYMS:                            # the reference ranks any number of symbols: the rest is in the spill
                 more = res.spill[(int(c["n_symbols"]) >> 8) - 1]
                 assert more["n"] == len(ranked) - L.MAX_SYMS
@@ -63,7 +81,7 @@ def test_golden_record_vectors(d, pileup_vectors):
         # the lane-per-site kernel on the same lines (no per-site counts requested)
         cons2, res2, _ = gpu_consensus(d, data, keys, [], p, want_counts=False)
         assert bytes(res2.bases) == bytes(res.bases) and bytes(res2.filters) == bytes(res.filters)
-    assert checked > 15000 and spilled > 100
+    return checked, spilled, long_refs
 
 
 def test_golden_error_lines_raise(d, pileup_vectors):

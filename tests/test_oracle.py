@@ -23,8 +23,20 @@ def _hist(d):
 
 
 def test_record_and_caller_vectors(pileup_vectors):
+    assert _check_records(pileup_vectors["records"]) > 15000
+
+
+def test_reference_fields_of_several_bytes(longref_vectors):
+    """pileup.py:223 takes any string as the reference base; '.' / ',' then stand for the whole upper- / lower-cased field
+    (pileup.py:255-258): counts, ranking and calls of the real reference on ~600 such lines."""
+    recs = longref_vectors["records"]
+    assert all(len(v["line"].split("\t")[2]) > 1 for v in recs)
+    assert _check_records(recs) > 1500
+
+
+def _check_records(records):
     n_calls = 0
-    for v in pileup_vectors["records"]:
+    for v in records:
         line = v["line"].encode()
         for q, want in v["by_q"].items():
             q = int(q)
@@ -49,7 +61,7 @@ def test_record_and_caller_vectors(pileup_vectors):
                 failed = [names[i] for i in range(6) if mask >> i & 1] or None
                 assert (chr(base), failed) == (c["base"], c["failed"]), (v["line"], c["params"])
                 n_calls += 1
-    assert n_calls > 15000
+    return n_calls
 
 
 def test_float_threshold_table(pileup_vectors):
