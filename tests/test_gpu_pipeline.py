@@ -255,3 +255,64 @@ def test_hot_path_batch_sharded_over_ranks_writes_the_same_files(tmp_path, monke
     r = subprocess.run(cmd, cwd=str(work), env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     _compare(_snapshot(work, dirs, remove=False), want)
+
+
+def _plain_tree(work, n_samples, genome_len=3000, variants=()):
+    """Samples whose reads all show the reference, except at `variants` [(sample, pos, alt)]."""
+    import random
+    rng = random.Random(3)
+    ref = "".join(rng.choice("ACGT") for _ in range(genome_len))
+    ref_path = work / "reference" / "ref.fasta"
+    ref_path.parent.mkdir()
+    ref_path.write_text(_fasta("ctg1", ref))
+    old = time.time() - 1000
+    os.utime(str(ref_path), (old, old))
+    dirs, piles = [], []
+    for s in range(n_samples):
+        alts = {p: a for (k, p, a) in variants if k == s}
+        lines = []
+        for pos in range(1, genome_len + 1):
+            if pos in alts:
+                bases = (alts[pos] + alts[pos].lower()) * 6
+            else:
+                bases = ".," * 6
+            lines.append("ctg1\t%d\t%s\t12\t%s\t%s\n" % (pos, ref[pos - 1], bases, "I" * 12))
+        data = "".join(lines).encode()
+        sdir = work / "samples" / ("s%02d" % s)
+        sdir.mkdir(parents=True)
+        bam = sdir / "reads.sorted.deduped.indelrealigned.bam"
+        bam.write_bytes(b"placeholder")
+        os.utime(str(bam), (old, old))
+        (sdir / "reads.all.pileup").write_bytes(data)
+        dirs.append(str(sdir))
+        piles.append(data)
+    dirs_file = str(work / "sampleDirectories.txt")
+    with open(dirs_file, "w") as f:
+        f.write("\n".join(dirs) + "\n")
+    return str(ref_path), dirs, dirs_file, piles
+
+
+@pytest.mark.parametrize("case", ["no_variant_anywhere", "one_sample", "one_sample_without_variants"])
+def test_hot_path_batch_on_the_smallest_jobs(tmp_path, monkeypatch, case):
+    """Empty site lists (no sample differs from the reference) and a job of one sample: every file as the separate steps
+    write it (empty snplists, header-only consensus files, TSVs of one row)."""
+    work = tmp_path
+    n = 3 if case == "no_variant_anywhere" else 1
+    variants = [(0, 500, "A"), (0, 1500, "C"), (0, 2500, "G")] if case == "one_sample" else []
+    ref_path, dirs, dirs_file, piles = _plain_tree(work, n, variants=variants)
+    # (a variant allele that equals the reference base would be no variant: make them differ)
+    ref_seq = "".join(open(ref_path).read().split("\n")[1:])
+    variants = [(s, p, a if ref_seq[p - 1] != a else "T" if a != "T" else "A") for s, p, a in variants]
+    if variants:
+        import shutil
+        shutil.rmtree(str(work / "samples")), shutil.rmtree(str(work / "reference"))
+        ref_path, dirs, dirs_file, piles = _plain_tree(work, n, variants=variants)
+    monkeypatch.setenv("VarscanMpileup2snp_ExtraParams", VARSCAN_EXTRA)
+    monkeypatch.chdir(work)
+    filter_extra = "--edge_length 100 --window_size 1000 --max_snp 3 --mode all"
+    _separate_steps(work, ref_path, dirs, dirs_file, filter_extra, "")
+    want = _snapshot(work, dirs)
+    assert len(want["snplist.txt"].splitlines()) == (3 if case == "one_sample" else 0)
+    _run("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s"
+         % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), CONSENSUS_EXTRA.replace(" ", "\x00")))
+    _compare(_snapshot(work, dirs, remove=False), want)
