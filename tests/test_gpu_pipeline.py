@@ -316,3 +316,73 @@ def test_hot_path_batch_on_the_smallest_jobs(tmp_path, monkeypatch, case):
     _run("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s"
          % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), CONSENSUS_EXTRA.replace(" ", "\x00")))
     _compare(_snapshot(work, dirs, remove=False), want)
+
+
+def test_hot_path_batch_goes_on_without_the_samples_that_fail(tmp_path, monkeypatch):
+    """StopOnSampleError=false (run.py's default for the job arrays): a sample without a pileup and one whose pileup has a
+    malformed position (site calling takes that column as text, call_consensus raises ValueError for it) are reported in the
+    error log, and every file of the other samples and every top-level file comes out as the separate steps write them in the
+    same situation."""
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    work = tmp_path
+    ref_path, dirs, dirs_file, piles = _outbreak_tree(work, n_samples=6)
+    os.remove(os.path.join(dirs[1], "reads.all.pileup"))
+    bad = os.path.join(dirs[4], "reads.all.pileup")
+    lines = open(bad, "rb").read().split(b"\n")
+    f = lines[4000].split(b"\t")
+    f[1] = b"12x"                                               # int(position) raises ValueError in the reference
+    lines[4000] = b"\t".join(f)
+    open(bad, "wb").write(b"\n".join(lines))
+    log = work / "error.log"
+    monkeypatch.setenv("StopOnSampleError", "false")
+    monkeypatch.setenv("errorOutputFile", str(log))
+    monkeypatch.setenv("VarscanMpileup2snp_ExtraParams", VARSCAN_EXTRA)
+    monkeypatch.chdir(work)
+
+    def run(line):                                              # 98 = "a sample failed, the others went on"
+        args = cli.parse_argument_list([w.replace("\x00", " ") for w in line.split()])
+        args.verbose = 0
+        try:
+            return cli.run_command_from_args(args)
+        except SystemExit as e:
+            assert e.code == 98, (line, e.code)
+            return 98
+        except (ValueError, IndexError):                         # what the sample exception hook turns into exit code 98
+            return 98
+
+    good = [d for i, d in enumerate(dirs) if i not in (1, 4)]
+    filter_extra = "--edge_length 100 --window_size 1000 125 15 --max_snp 3 2 1 --mode all"
+    for sdir in dirs:
+        if sdir != dirs[1]:                                      # (without a pileup call_sites would start samtools, as the reference does)
+            run("call_sites %s %s" % (ref_path, sdir))
+    # (VarScan takes the position column as text: the malformed sample gets its var.flt.vcf and fails at call_consensus)
+    assert os.path.getsize(os.path.join(dirs[4], "var.flt.vcf")) > 0
+    run("filter_regions -f -n var.flt.vcf %s %s %s" % (dirs_file, ref_path, filter_extra))
+    run("merge_sites -f -n var.flt.vcf -o %s/snplist.txt %s %s.OrigVCF.filtered" % (work, dirs_file, dirs_file))
+    run("merge_sites -f -n var.flt_preserved.vcf -o %s/snplist_preserved.txt %s %s.PresVCF.filtered" % (work, dirs_file, dirs_file))
+    for sdir in good:
+        run("call_consensus -f -l %s/snplist.txt -o %s/consensus.fasta --vcfRefName ref.fasta %s --vcfFileName consensus.vcf %s/reads.all.pileup"
+            % (work, sdir, CONSENSUS_EXTRA, sdir))
+        run("call_consensus -f -l %s/snplist_preserved.txt -o %s/consensus_preserved.fasta -e %s/var.flt_removed.vcf --vcfRefName ref.fasta %s "
+            "--vcfFileName consensus_preserved.vcf %s/reads.all.pileup" % (work, sdir, sdir, CONSENSUS_EXTRA, sdir))
+    for suffix, flt in (("", "OrigVCF"), ("_preserved", "PresVCF")):
+        run("snp_matrix -f -c consensus%s.fasta -o %s/snpma%s.fasta %s.%s.filtered" % (suffix, work, suffix, dirs_file, flt))
+        run("snp_reference -f -l %s/snplist%s.txt -o %s/referenceSNP%s.fasta %s" % (work, suffix, work, suffix, ref_path))
+        run("distance -f -p %s/snp_distance_pairwise%s.tsv -m %s/snp_distance_matrix%s.tsv %s/snpma%s.fasta" % (work, suffix, work, suffix, work, suffix))
+    var_files = ("var.flt.vcf", "var.flt_preserved.vcf", "var.flt_removed.vcf")
+    want_bad = {n: open(os.path.join(dirs[4], n), "rb").read() for n in var_files}
+    want = _snapshot(work, good)
+    assert want["snpma.fasta"].count(b">") == len(good)
+    for sdir in (dirs[1], dirs[4]):                              # whatever the separate steps left for the failed samples goes away
+        for name in PER_SAMPLE:
+            if os.path.exists(os.path.join(sdir, name)):
+                os.remove(os.path.join(sdir, name))
+    log.write_text("")
+    rc = run("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s"
+             % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), CONSENSUS_EXTRA.replace(" ", "\x00")))
+    assert rc in (0, 98)
+    _compare(_snapshot(work, good, remove=False), want)
+    assert {n: open(os.path.join(dirs[4], n), "rb").read() for n in var_files} == want_bad
+    text = log.read_text()
+    assert os.path.basename(dirs[1]) in text and os.path.basename(dirs[4]) in text
+    assert not os.path.exists(os.path.join(dirs[4], "consensus.fasta"))
