@@ -974,7 +974,12 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
                    int32_t *out_done) {
     HIP_TRY(ctx, snpgpu_enter(ctx));
     const double t_enter = now_s();
-    const size_t chunk = (size_t)16 << 20;
+    // pieces of 32 MiB: 53-54 GB/s of files into resident memory where 16 MiB pieces give 50-52 (fewer, larger preads and copies;
+    // 64 MiB: 46 — the pipeline of 12 staging buffers gets too coarse); tools/pipeline_time.py with SNPGPU_INGEST_CHUNK_MIB
+    size_t chunk = (size_t)32 << 20;
+#ifdef SNPGPU_TUNING                                            // development builds only (tools/)
+    if (const char *e = getenv("SNPGPU_INGEST_CHUNK_MIB")) if (atoi(e) > 0) chunk = (size_t)atoi(e) << 20;
+#endif
     std::vector<Source> src(n_files);
     uint64_t max_slot_size = 0;
     const size_t first = store ? store->files.size() : 0;
