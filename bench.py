@@ -162,9 +162,34 @@ def end_to_end(d, ss, prm, pile, offs, sizes, bases, n_files, S):
             if st is None or st_i.seconds < st.seconds:
                 st = st_i
         gbps = st.bytes / st.seconds / 1e9
+        # the preserved flow's shape (run.py:712-718: call_consensus -e var.flt_removed.vcf): every file with its OWN exclude list
+        # — 1 500 slots each, as a sample's removed positions — in the same single call; the excluded positions that have a pileup
+        # line must come back as '-' with the Region bit, everything else as in the plain pass
+        rng = np.random.default_rng(11)
+        excl = [np.sort(rng.choice(S, size=min(1500, S), replace=False)) for _ in range(n_files)]
+        res_e, rcs_e, st_e = d.call_consensus_files(ss, paths, prm, exclude=excl)
+        passes_e = [st_e.bytes / st_e.seconds / 1e9]
+        res_e2, rcs_e2, st_e2 = d.call_consensus_files(ss, paths, prm, exclude=excl)          # two passes, as for the plain call
+        passes_e.append(st_e2.bytes / st_e2.seconds / 1e9)
+        if st_e2.seconds < st_e.seconds:
+            res_e, rcs_e, st_e = res_e2, rcs_e2, st_e2
+        region_bit = 0x20
+        for i in range(n_files):
+            plain, got = res[i], res_e[i]
+            mask = np.zeros(S, dtype=bool)
+            mask[excl[i]] = True
+            has_line = np.asarray(plain.bases) != 0x2D                           # (a '-' of the plain pass stays '-')
+            want = np.where(mask, 0x2D, np.asarray(plain.bases)).astype(np.uint8)
+            if int(rcs_e[i]) != 0 or not np.array_equal(np.asarray(got.bases), want) or \
+                    not ((np.asarray(got.filters)[mask & has_line] & region_bit) != 0).all() or \
+                    not np.array_equal(np.asarray(got.filters)[~mask], np.asarray(plain.filters)[~mask]):
+                raise SystemExit("the pass with per-file exclude lists differs from the plain pass outside the excluded positions")
+        gbps_e = st_e.bytes / st_e.seconds / 1e9
         return {
             "what": "%d pileup files in the page cache (%s) -> consensus bytes on the host, one snpgpu_call_consensus_files call"
                     % (n_files, base_dir),
+            "with_per_file_exclude_lists": {"pileup_gb_per_sec": gbps_e, "seconds": st_e.seconds, "over_plain_pass": gbps_e / gbps,
+                                            "excluded_positions_per_file": int(len(excl[0])), "passes_gb_per_sec": passes_e, "checked": True},
             "files": n_files, "bytes": int(st.bytes), "seconds": st.seconds, "pileup_gb_per_sec": gbps,
             "consensus_bases_per_sec": n_files * S / st.seconds, "samples_per_sec": n_files / st.seconds,
             "pinned_h2d_gb_per_sec": h2d, "frac_of_pinned_h2d": gbps / h2d, "passes_gb_per_sec": passes,
