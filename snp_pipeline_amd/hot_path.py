@@ -419,6 +419,10 @@ def hot_path_batch(args):
         lap("3-   of which: site set", t0)
         identity1 = len(extra) == 0
         S1, S2 = len(list1), len(list2)
+        # collect_metrics by-products (call_consensus --amdMetricsRefFasta, given through CallConsensus_ExtraParams): the depth
+        # column is summed by the same scan, the gaps are counted in the rows that are written anyway
+        metrics_ref = getattr(cc_args, "amdMetricsRefFasta", None)
+        metrics_ref_len = sum(utils.read_fasta_lengths(metrics_ref).values()) if metrics_ref else 0
         filters_desc = vcf_writer.filter_descriptions(cc_args.minConsFreq, cc_args.minConsDpth, cc_args.minConsStrdDpth, cc_args.minConsStrdBias)
         filter_names = [n for n, _ in filters_desc]
         d_cols1, d_cols2 = torch.from_numpy(cols1.astype(np.int32)).cuda(), torch.from_numpy(cols2.astype(np.int32)).cuda()
@@ -492,6 +496,18 @@ def hot_path_batch(args):
                     owners.append(s)
             res = devmod.write_consensus_files(jobs, ss, filter_names, cc_args.vcfPreserveRefCase, cc_args.vcfFailedSnpGt, n_threads=args.writerThreads,
                                                spill=spill)
+            if metrics_ref:                                      # as call_consensus._record_metrics does for the two flows, in their order
+                st_h = hs["status"].numpy()
+                for k, s in enumerate(part):
+                    if not s.ok:
+                        continue
+                    name = os.path.basename(cc_args.amdMetricsFile) if cc_args.amdMetricsFile else "metrics"
+                    depth_sum = int(st_h[k, 3]) & 0xFFFFFFFFFFFFFFFF
+                    ave = {"avePileupDepth": "%.2f" % (float(depth_sum) / float(metrics_ref_len))} if depth_sum > 0 and metrics_ref_len > 0 else {}
+                    for key, row, n in (("missingPos", hs["base1"], S1), ("missingPosPreserved", hs["base2"], S2)):
+                        updates = {key: str(int(np.count_nonzero(row.numpy()[k, :n] == 0x2D)))}
+                        updates.update(ave)
+                        utils.update_properties(os.path.join(s.dir, name), updates, keep_mtime=True)
             bad = []
             for s, job, (rc, _) in zip(owners, jobs, res):
                 if rc == L.E_UNSUPPORTED:
@@ -520,15 +536,18 @@ def hot_path_batch(args):
                 sizes = [n for _, _, ptr, n in resident if ptr]
                 if len(res_idx) == g:
                     dev.call_consensus_many_dev(ss, ptrs, sizes, prm, d_base.data_ptr(), d_filt.data_ptr(), d_status.data_ptr(),
-                                                d_counts=d_counts.data_ptr() if want_vcf else 0, d_line_off=d_line.data_ptr())
+                                                d_counts=d_counts.data_ptr() if want_vcf else 0, d_line_off=d_line.data_ptr(),
+                                                want_depth_sum=bool(metrics_ref))
                 else:
-                    _call_scattered(dev, ss, prm, res_idx, ptrs, sizes, d_base, d_filt, d_status, d_counts, d_line, S, want_vcf, torch)
+                    _call_scattered(dev, ss, prm, res_idx, ptrs, sizes, d_base, d_filt, d_status, d_counts, d_line, S, want_vcf, torch,
+                                    want_depth_sum=bool(metrics_ref))
             elif res_idx:
                 d_status[:g] = torch.tensor([-1, 0, 0, 0], dtype=torch.int64, device="cuda")
             rest = [(k, s) for k, s, ptr, _ in resident if not ptr]
             if rest:
                 # files that did not fit the memory budget: streamed again (the only pileups that cross the link twice)
-                results, rcs, st = dev.call_consensus_files(ss, [s.pileup for _, s in rest], prm, want_counts=want_vcf, want_line_offsets=True)
+                results, rcs, st = dev.call_consensus_files(ss, [s.pileup for _, s in rest], prm, want_counts=want_vcf, want_line_offsets=True,
+                                                            want_depth_sum=bool(metrics_ref))
                 h2d_extra[0] += int(st.bytes)
                 for (k, s), rc, r in zip(rest, rcs, results):
                     if int(rc) == L.E_IO:
@@ -750,7 +769,7 @@ def _fasta_bytes(name, seq):
     return head + out
 
 
-def _call_scattered(dev, ss, prm, res_idx, ptrs, sizes, d_base, d_filt, d_status, d_counts, d_line, S, want_vcf, torch):
+def _call_scattered(dev, ss, prm, res_idx, ptrs, sizes, d_base, d_filt, d_status, d_counts, d_line, S, want_vcf, torch, want_depth_sum=False):
     """A group in which only some samples are resident: they are called into temporary arrays and scattered to their rows."""
     m = len(res_idx)
     tb = torch.empty((m, S), dtype=torch.uint8, device="cuda")
@@ -759,7 +778,7 @@ def _call_scattered(dev, ss, prm, res_idx, ptrs, sizes, d_base, d_filt, d_status
     ts = torch.empty((m, 4), dtype=torch.int64, device="cuda")
     tc = torch.empty((m, S, 128), dtype=torch.uint8, device="cuda") if want_vcf else None
     dev.call_consensus_many_dev(ss, ptrs, sizes, prm, tb.data_ptr(), tf.data_ptr(), ts.data_ptr(), d_counts=tc.data_ptr() if want_vcf else 0,
-                                d_line_off=tl.data_ptr())
+                                d_line_off=tl.data_ptr(), want_depth_sum=want_depth_sum)
     idx = torch.tensor(res_idx, dtype=torch.int64, device="cuda")
     d_base[idx, :S] = tb
     d_filt[idx, :S] = tf

@@ -151,8 +151,9 @@ def _outbreak_tree(work, seed=7, n_samples=6, genome_len=12000):
     return str(ref_path), dirs, dirs_file, piles
 
 
-def _separate_steps(work, ref_path, dirs, dirs_file, filter_extra, merge_extra):
+def _separate_steps(work, ref_path, dirs, dirs_file, filter_extra, merge_extra, consensus_extra=None):
     """What run.py:662-784 runs, one subcommand after the other."""
+    consensus_extra = consensus_extra or CONSENSUS_EXTRA
     for sdir in dirs:
         _run("call_sites %s %s" % (ref_path, sdir))
     _run("filter_regions -f -n var.flt.vcf %s %s %s" % (dirs_file, ref_path, filter_extra))
@@ -160,9 +161,9 @@ def _separate_steps(work, ref_path, dirs, dirs_file, filter_extra, merge_extra):
     _run("merge_sites -f -n var.flt_preserved.vcf -o %s/snplist_preserved.txt %s %s %s.PresVCF.filtered" % (work, merge_extra, dirs_file, dirs_file))
     for sdir in dirs:
         _run("call_consensus -f -l %s/snplist.txt -o %s/consensus.fasta --vcfRefName ref.fasta %s --vcfFileName consensus.vcf %s/reads.all.pileup"
-             % (work, sdir, CONSENSUS_EXTRA, sdir))
+             % (work, sdir, consensus_extra, sdir))
         _run("call_consensus -f -l %s/snplist_preserved.txt -o %s/consensus_preserved.fasta -e %s/var.flt_removed.vcf --vcfRefName ref.fasta %s "
-             "--vcfFileName consensus_preserved.vcf %s/reads.all.pileup" % (work, sdir, sdir, CONSENSUS_EXTRA, sdir))
+             "--vcfFileName consensus_preserved.vcf %s/reads.all.pileup" % (work, sdir, sdir, consensus_extra, sdir))
     for suffix, flt in (("", "OrigVCF"), ("_preserved", "PresVCF")):
         _run("snp_matrix -f -c consensus%s.fasta -o %s/snpma%s.fasta %s.%s.filtered" % (suffix, work, suffix, dirs_file, flt))
         _run("snp_reference -f -l %s/snplist%s.txt -o %s/referenceSNP%s.fasta %s" % (work, suffix, work, suffix, ref_path))
@@ -386,3 +387,28 @@ def test_hot_path_batch_goes_on_without_the_samples_that_fail(tmp_path, monkeypa
     text = log.read_text()
     assert os.path.basename(dirs[1]) in text and os.path.basename(dirs[4]) in text
     assert not os.path.exists(os.path.join(dirs[4], "consensus.fasta"))
+
+
+def test_hot_path_batch_records_the_collect_metrics_by_products(tmp_path, monkeypatch):
+    """call_consensus --amdMetricsRefFasta (through CallConsensus_ExtraParams) records avePileupDepth, missingPos and
+    missingPosPreserved in each sample's metrics file (collect_metrics.py:109-128, 325-340 reuse them); the one job writes the
+    same files as the two call_consensus arrays."""
+    work = tmp_path
+    ref_path, dirs, dirs_file, piles = _outbreak_tree(work, n_samples=5)
+    monkeypatch.setenv("VarscanMpileup2snp_ExtraParams", VARSCAN_EXTRA)
+    monkeypatch.chdir(work)
+    filter_extra = "--edge_length 100 --window_size 1000 125 15 --max_snp 3 2 1 --mode all"
+    extra = CONSENSUS_EXTRA + " --amdMetricsRefFasta " + ref_path
+    _separate_steps(work, ref_path, dirs, dirs_file, filter_extra, "", consensus_extra=extra)
+    want = _snapshot(work, dirs)
+    want_metrics = {}
+    for sdir in dirs:
+        path = os.path.join(sdir, "metrics")
+        want_metrics[sdir] = open(path).read()
+        assert "avePileupDepth=" in want_metrics[sdir] and "missingPos=" in want_metrics[sdir] and "missingPosPreserved=" in want_metrics[sdir]
+        os.remove(path)
+    _run("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s"
+         % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), extra.replace(" ", "\x00")))
+    _compare(_snapshot(work, dirs, remove=False), want)
+    for sdir in dirs:
+        assert open(os.path.join(sdir, "metrics")).read() == want_metrics[sdir], sdir
