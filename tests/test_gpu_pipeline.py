@@ -398,7 +398,7 @@ def test_hot_path_batch_records_the_collect_metrics_by_products(tmp_path, monkey
     monkeypatch.setenv("VarscanMpileup2snp_ExtraParams", VARSCAN_EXTRA)
     monkeypatch.chdir(work)
     filter_extra = "--edge_length 100 --window_size 1000 125 15 --max_snp 3 2 1 --mode all"
-    extra = CONSENSUS_EXTRA + " --amdMetricsRefFasta " + ref_path
+    extra = CONSENSUS_EXTRA + " --vcfFailedSnpGt 1 --vcfPreserveRefCase --amdMetricsRefFasta " + ref_path    # (and the two VCF layout options)
     _separate_steps(work, ref_path, dirs, dirs_file, filter_extra, "", consensus_extra=extra)
     want = _snapshot(work, dirs)
     want_metrics = {}
