@@ -20,7 +20,6 @@ struct Acc { uint32_t f, r, q; };
 
 __device__ __forceinline__ bool is_digit(uint32_t c) { return c - 0x30u < 10u; }
 
-constexpr uint32_t VS_LDS_BYTES = 32 * 1024;
 constexpr uint32_t VS_CAND_LOCAL = 256;
 // A list entry: the line's index (bits 0-31), and for a line whose shape k_varscan_select has checked (VS_ENTRY_PLAIN) its depth
 // (bits 32-51) and where, counted from the line's first byte, its second and fourth TAB are (bits 52-56, 57-61)
