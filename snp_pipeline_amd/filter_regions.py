@@ -336,23 +336,14 @@ def filter_regions(args):
     from .device import default_device
     dev = default_device()
     parsed = []          # (vcf_path, header, data_lines, sites)
-    # (the files are read, and further down written, by a few host threads: 10 000 samples are 10 000 + 20 000 small files; file
-    # I/O and the library's column reader release the interpreter lock.  Errors are reported here, in sample order.)
-    import concurrent.futures
-    io_pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 4) // 2)))
-
-    def read_one(vcf_path):
+    for vcf_path in list_of_vcf_files:
+        if not filter_across_samples and not need_rebuild[vcf_path]:
+            continue
         try:
-            return _read_vcf(vcf_path)
-        except (IOError, OSError) as err:
-            return err
-
-    wanted = [p_ for p_ in list_of_vcf_files if filter_across_samples or need_rebuild[p_]]
-    for vcf_path, got in zip(wanted, io_pool.map(read_one, wanted)):
-        if isinstance(got, Exception):
+            header, data_lines, sites = _read_vcf(vcf_path)
+        except (IOError, OSError):
             utils.sample_error("Error: Cannot open the input vcf file: %s." % vcf_path, continue_possible=True)
             continue
-        header, data_lines, sites = got
         sample_id = utils.sample_id_from_file(vcf_path)
         utils.verbose_print("Processing sample %s" % sample_id)
         if sample_id in outgroup:
@@ -376,11 +367,7 @@ def filter_regions(args):
                             np.concatenate(pos_all) if n_rec else np.zeros(0, np.int64), len(parsed), edge_length, max_num_snps_list,
                             window_size_list, per_sample=not filter_across_samples)
     at = 0
-    writes = []
     for (vcf_path, header, data_lines, _), k in zip(parsed, counts):
         if need_rebuild[vcf_path]:
-            writes.append(io_pool.submit(write_preserved_and_removed_vcf_files, vcf_path, header, data_lines, removed[at:at + k]))
+            write_preserved_and_removed_vcf_files(vcf_path, header, data_lines, removed[at:at + k])
         at += k
-    for fu in writes:
-        fu.result()                                             # (a writer's sample error — or the exit it asks for — surfaces here)
-    io_pool.shutdown()
