@@ -49,3 +49,7 @@ print("slow waves: %d; per block counts of slow waves: %s" % (slow.sum(), dict(z
 wpb = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 print("life by wave-in-block (%d waves/block):" % wpb, " ".join("%.0f" % life[w::wpb].mean() for w in range(wpb)))
 print("simd of wave-in-block:", " ".join("%.1f" % simd[w::wpb].mean() for w in range(wpb)))
+# life by age rank on the SIMD (wave-in-block / 4: the host's shares are per rank) — equal lives = balanced shares
+rank = (np.arange(len(r)) % 16) // 4 if len(r) % 16 == 0 else None
+if rank is not None:
+    print("life by age rank:", " ".join("%d:%.1f" % (k, life[rank == k].mean()) for k in range(4)), "| max by rank:", " ".join("%d:%.1f" % (k, life[rank == k].max()) for k in range(4)))
