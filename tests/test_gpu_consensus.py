@@ -586,3 +586,25 @@ def test_terminators_across_many_tiles(d, variant, names):
     res = check_against_oracle(d, data2, snps, rng.sample(sites, 50), po.CallerParams(0, 0.6, 3, 0, 0.0))
     n_py = sum(1 for _ in io.TextIOWrapper(io.BytesIO(data2), encoding="latin-1", newline=None))
     assert res.n_lines == n_py == len(lines)
+
+
+def test_more_spilled_positions_than_the_context_holds_are_refused_not_lost(d):
+    """1 100 positions with nine symbols in one call: the context keeps 1 024 spill records; the positions past that carry the
+    "no room" mark in their own record and the row writer refuses them by name instead of printing a short ALT list."""
+    from snp_pipeline_amd import _lib as L
+    from snp_pipeline_amd import vcf_writer
+    from tests.gpu_util import gpu_consensus
+    bases = "ACGTN*RYK" * 2
+    lines = ["c\t%d\tA\t18\t%s\t%s" % (p, bases, "I" * 18) for p in range(1, 1101)]
+    keys = [(b"c", p) for p in range(1, 1101)]
+    _, res, ss = gpu_consensus(d, ("\n".join(lines) + "\n").encode(), keys, [], po.CallerParams())
+    codes = res.counts["n_symbols"] >> 8
+    assert (res.counts["n_symbols"] & 0xFF == 9).all() and len(res.spill) == L.SPILL_CAP
+    assert int((codes == 0xFFFFFF).sum()) == 1100 - L.SPILL_CAP and sorted(codes[codes != 0xFFFFFF]) == list(range(1, L.SPILL_CAP + 1))
+    names = po.filter_names(po.CallerParams())
+    order = np.arange(1100, dtype=np.uint32)
+    ok = order[codes != 0xFFFFFF]
+    text = vcf_writer.format_rows(res.counts, ok, ss._names, ss._offs, ss.keys, names, False, ".", spill=res.spill)
+    assert text.count(b"\n") == L.SPILL_CAP and all(ln.split(b"\t")[4].count(b",") == 7 for ln in text.split(b"\n") if ln)   # A is REF: 8 ALTs
+    with pytest.raises(ValueError):
+        vcf_writer.format_rows(res.counts, order, ss._names, ss._offs, ss.keys, names, False, ".", spill=res.spill)
