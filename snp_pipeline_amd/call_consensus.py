@@ -249,6 +249,7 @@ def call_consensus_batch(args):
     def worker(dev_index, my_plans):
         todo = list(my_plans)                     # whatever is still here when the worker dies is reported as failed
         dev = None
+        writer = None
         try:
             dev = devmod.Device(dev_index)
             # ONE site set for all samples of this GPU: the snplist plus every sample's exclude positions, with the flags of the
@@ -265,13 +266,29 @@ def call_consensus_batch(args):
             with_excl = bool(excl_slots)
             # a stream of at most `step` files per library call: the per-site records of a call are files x sites x 138 bytes
             # on the host (0.4 GB for 16 files x 200 000 sites)
-            step = max(1, min(64, (1 << 29) // max(1, 138 * len(ss))))
+            # (16 files per call at most: the output files of one call are written by a thread of their own while the next
+            # call streams — text formatting and file writes of 16 samples take about as long as their pileups take to arrive)
+            step = max(1, min(16, (1 << 29) // max(1, 138 * len(ss))))
+
+            def write_part(items):
+                for plan, res, flags in items:
+                    try:
+                        with lock:            # the log lines of one sample stay together
+                            _write_outputs(plan, dev, ss, snp_slots, res, flags)
+                    except Exception as err:  # noqa: B902  (reported per sample below)
+                        with lock:
+                            errors.append((plan, err))
+
             for k0 in range(0, len(my_plans), step):
                 part = my_plans[k0:k0 + step]
                 exclude = [excl_slots.get(id(p), np.zeros(0, np.int64)) for p in part] if with_excl else None
                 results, rcs, _ = dev.call_consensus_files(ss, [p.pileup_path for p in part], params, want_counts=True,
                                                            want_line_offsets=True, exclude=exclude,
                                                            want_depth_sum=bool(getattr(args, "amdMetricsRefFasta", None)))
+                if writer is not None:
+                    writer.join()             # one writer at a time: the device context below is this thread's again
+                    writer = None
+                in_background = []
                 for plan, rc, res in zip(part, rcs, results):
                     try:
                         dev.raise_file_status(plan.pileup_path, int(rc), res)
@@ -281,17 +298,28 @@ def call_consensus_batch(args):
                             mine = excl_slots.get(id(plan))
                             if mine is not None:
                                 flags[mine[mine >= 0]] |= L.SITE_EXCLUDED
-                        with lock:            # the log lines of one sample stay together
-                            _write_outputs(plan, dev, ss, snp_slots, res, flags)
+                        needs_device = bool(plan.vcf_path) and (args.vcfAllPos or res.n_matched > int(np.count_nonzero(res.line_offsets)))
+                        if needs_device:      # (the all-lines pass: a device call, so here and now)
+                            with lock:
+                                _write_outputs(plan, dev, ss, snp_slots, res, flags)
+                        else:
+                            in_background.append((plan, res, flags))
                     except Exception as err:  # noqa: B902  (reported per sample below)
                         with lock:
                             errors.append((plan, err))
                     todo.remove(plan)
+                if in_background:
+                    writer = threading.Thread(target=write_part, args=(in_background,))
+                    writer.start()
+            if writer is not None:
+                writer.join()
             ss.close()
         except Exception as err:              # noqa: B902 — the device, the site set or a whole call failed: every sample left is reported
             with lock:
                 errors.extend((plan, err) for plan in todo)
         finally:
+            if writer is not None:
+                writer.join()                 # (its samples' files are complete before the device goes)
             if dev is not None:
                 dev.close()
 
