@@ -301,3 +301,17 @@ def varscan_adversarial(seed, n_lines=2000):
         ref = rng.choice("ACGTNacgtn*.")
         out.append(b"c%d\t%d\t%s\t%d\t%s\t%s" % (k % 3, k + 1, ref.encode(), depth, bytes(bases), quals))
     return b"\n".join(out) + b"\n"
+
+
+def with_line_ends(data, variant, seed=0):
+    """The same pileup with other line ends: "crlf" (every line), "mixed" (LF / CR LF / lone CR at random), "vt_ff" (a '\\v' or
+    '\\f' — whitespace to str.split(), no line end to the text-mode reader — before some line ends).  Deterministic in seed."""
+    rng = random.Random(1000 + seed)
+    lines = data.split(b"\n")[:-1]
+    if variant == "crlf":
+        return b"\r\n".join(lines) + b"\r\n"
+    if variant == "mixed":
+        return b"".join(ln + rng.choice((b"\n", b"\n", b"\r\n", b"\r")) for ln in lines)
+    if variant == "vt_ff":
+        return b"".join(ln + rng.choice((b"", b"", b"\x0b", b"\x0c", b" \x0b")) + b"\n" for ln in lines)
+    raise ValueError(variant)

@@ -153,8 +153,9 @@ def record_vector(pileup, line, with_calls=True):
     return out
 
 
-def gen_file_runs(captured, specs, extra_sites=()):
-    """Whole files through the reference's own call_consensus driver.  specs: (seed, synth_pileup kwargs, params)."""
+def gen_file_runs(captured, specs, extra_sites=(), line_ends=None):
+    """Whole files through the reference's own call_consensus driver.  specs: (seed, synth_pileup kwargs, params).
+    line_ends: fuzz.with_line_ends variant applied to the synthetic file (recorded in the run)."""
     # --- whole-file runs through the reference's own call_consensus driver
     from oracle import fuzz
     from snppipeline import call_consensus as cc
@@ -164,6 +165,8 @@ def gen_file_runs(captured, specs, extra_sites=()):
     try:
         for seed, kw, pset in specs:
             data, refs, sites = fuzz.synth_pileup(seed, **kw)
+            if line_ends:
+                data = fuzz.with_line_ends(data, line_ends, seed)
             rng = random.Random(seed)
             # snplist: sites (+ some positions that have no pileup line, + one duplicate)
             snps = list(sites)
@@ -206,7 +209,7 @@ def gen_file_runs(captured, specs, extra_sites=()):
                     "seed": seed, "kw": {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()},
                     "params": pset, "snplist": [[c.decode(), p] for c, p in snps],
                     "excluded": [[c.decode(), p] for c, p in excluded + extra_excl] if use_excl else [],
-                    "sample": sid, "consensus": seq,
+                    "sample": sid, "consensus": seq, "line_ends": line_ends,
                 })
     finally:
         shutil.rmtree(tmp)
@@ -546,6 +549,16 @@ def main():
         return
     if sys.argv[1:] == ["--only", "metrics"]:
         dump("metrics_vectors.json.gz", gen_metrics_vectors())
+        return
+    if sys.argv[1:] == ["--only", "runs3"]:
+        # line ends: the reference reads the pileup in text mode (universal newlines: "\n", "\r\n" and a lone "\r" end a line;
+        # '\v' / '\f' do not, they are whitespace to str.split()) — files of a few dozen scan tiles through its own driver
+        runs = []
+        for variant in ("crlf", "mixed", "vt_ff"):
+            runs += gen_file_runs(captured, [(21, dict(genome_len=2600, n_sites=90, mean_depth=18), PARAM_SETS[1]),
+                                             (22, dict(genome_len=1800, n_sites=60, contigs=("NODE_1_length_419034_cov_23.1", "c")), PARAM_SETS[2])],
+                                  line_ends=variant)
+        dump("pileup_runs3.json.gz", {"runs": runs})
         return
     if sys.argv[1:] == ["--only", "longref"]:
         dump("longref_vectors.json.gz", gen_longref_vectors())

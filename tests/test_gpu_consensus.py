@@ -99,11 +99,14 @@ def test_golden_whole_file_runs(d, pileup_vectors):
     """Whole files that went through the reference's own call_consensus driver: the FASTA string, from both device paths."""
     from tests.conftest import load_golden
     from tests.gpu_util import gpu_consensus
-    for run in pileup_vectors["runs"] + load_golden("pileup_runs2.json.gz")["runs"]:
+    # (pileup_runs3: the same through the reference's text-mode reader with CR LF, mixed and '\v' / '\f' line ends)
+    for run in pileup_vectors["runs"] + load_golden("pileup_runs2.json.gz")["runs"] + load_golden("pileup_runs3.json.gz")["runs"]:
         kw = dict(run["kw"])
         if "contigs" in kw:
             kw["contigs"] = tuple(kw["contigs"])
         data, _, _ = fuzz.synth_pileup(run["seed"], **kw)
+        if run.get("line_ends"):
+            data = fuzz.with_line_ends(data, run["line_ends"], run["seed"])
         snps = [(c.encode(), p) for c, p in run["snplist"]]
         excl = [(c.encode(), p) for c, p in run["excluded"]]
         for want_counts in (True, False):

@@ -75,11 +75,14 @@ def test_whole_file_runs(pileup_vectors):
     from oracle import fuzz
     from tests.conftest import load_golden
     # the second file holds later additions (deep pileups, long contig names, positions around the powers of ten)
-    for run in pileup_vectors["runs"] + load_golden("pileup_runs2.json.gz")["runs"]:
+    # ... the third one files with other line ends (CR LF, a mix with lone CRs, '\v' / '\f' before the line end)
+    for run in pileup_vectors["runs"] + load_golden("pileup_runs2.json.gz")["runs"] + load_golden("pileup_runs3.json.gz")["runs"]:
         kw = dict(run["kw"])
         if "contigs" in kw:
             kw["contigs"] = tuple(kw["contigs"])
         data, _, _ = fuzz.synth_pileup(run["seed"], **kw)
+        if run.get("line_ends"):
+            data = fuzz.with_line_ends(data, run["line_ends"], run["seed"])
         snps = [(c.encode(), p) for c, p in run["snplist"]]
         excl = {(c.encode(), p) for c, p in run["excluded"]}
         cons, _ = po.call_consensus_sites(data, snps, excl, po.CallerParams(*run["params"]))
