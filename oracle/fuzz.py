@@ -305,7 +305,8 @@ def varscan_adversarial(seed, n_lines=2000):
 
 def with_line_ends(data, variant, seed=0):
     """The same pileup with other line ends: "crlf" (every line), "mixed" (LF / CR LF / lone CR at random), "vt_ff" (a '\\v' or
-    '\\f' — whitespace to str.split(), no line end to the text-mode reader — before some line ends).  Deterministic in seed."""
+    '\\f' — whitespace to str.split(), no line end to the text-mode reader — before some line ends), or with "repeats" (positions that
+    come a second time, later in the file).  Deterministic in seed."""
     rng = random.Random(1000 + seed)
     lines = data.split(b"\n")[:-1]
     if variant == "crlf":
@@ -314,4 +315,15 @@ def with_line_ends(data, variant, seed=0):
         return b"".join(ln + rng.choice((b"\n", b"\n", b"\r\n", b"\r")) for ln in lines)
     if variant == "vt_ff":
         return b"".join(ln + rng.choice((b"", b"", b"\x0b", b"\x0c", b" \x0b")) + b"\n" for ln in lines)
+    if variant == "repeats":
+        # one line in twelve comes again further down (out of position order) with other read bases: the last line of a
+        # position is the one that counts (call_consensus.py:171-176)
+        out = list(lines)
+        for ln in lines:
+            f = ln.split(b"\t")
+            if len(f) >= 6 and rng.random() < 1 / 12.0:
+                swap = bytes.maketrans(b"ACGTacgt.,", b"CATGcatgAa")
+                f[4] = f[4].translate(swap)
+                out.insert(rng.randrange(len(out) // 2, len(out) + 1), b"\t".join(f))
+        return b"\n".join(out) + b"\n"
     raise ValueError(variant)

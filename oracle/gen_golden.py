@@ -554,7 +554,7 @@ def main():
         # line ends: the reference reads the pileup in text mode (universal newlines: "\n", "\r\n" and a lone "\r" end a line;
         # '\v' / '\f' do not, they are whitespace to str.split()) — files of a few dozen scan tiles through its own driver
         runs = []
-        for variant in ("crlf", "mixed", "vt_ff"):
+        for variant in ("crlf", "mixed", "vt_ff", "repeats"):
             runs += gen_file_runs(captured, [(21, dict(genome_len=2600, n_sites=90, mean_depth=18), PARAM_SETS[1]),
                                              (22, dict(genome_len=1800, n_sites=60, contigs=("NODE_1_length_419034_cov_23.1", "c")), PARAM_SETS[2])],
                                   line_ends=variant)
