@@ -327,3 +327,46 @@ def with_line_ends(data, variant, seed=0):
                 out.insert(rng.randrange(len(out) // 2, len(out) + 1), b"\t".join(f))
         return b"\n".join(out) + b"\n"
     raise ValueError(variant)
+
+
+BAD_LINE_SCENARIOS = ("one_field", "blank", "bad_position", "listed_five_fields", "listed_three_fields", "listed_bad_depth",
+                      "unlisted_five_fields", "unlisted_bad_depth", "listed_negative_position_text")
+
+
+def with_bad_line(data, scenario, listed):
+    """The pileup with ONE line changed or inserted, about the middle of the file.  listed: set of (chrom bytes, pos) that the
+    caller will parse.  What the reference does with it (pileup.py:423-429, 209-237): a line with fewer than two fields or a
+    position that int() refuses raises ValueError wherever it is; the rest of a line is only looked at for listed positions."""
+    lines = data.split(b"\n")[:-1]
+    mid = len(lines) // 2
+    def find(want_listed):
+        for k in list(range(mid, len(lines))) + list(range(mid)):
+            f = lines[k].split(b"\t")
+            if len(f) >= 6 and f[3] != b"0" and ((f[0], int(f[1])) in listed) == want_listed:
+                return k, f
+        raise ValueError("no such line")
+    if scenario == "one_field":
+        lines.insert(mid, b"justonefield")
+    elif scenario == "blank":
+        lines.insert(mid, b"")
+    elif scenario == "bad_position":
+        k, f = find(False)
+        f[1] = f[1] + b"x"
+        lines[k] = b"\t".join(f)
+    elif scenario == "listed_negative_position_text":
+        k, f = find(False)
+        f[1] = b"-" + f[1]                                      # an integer for int(): in no site set, no error
+        lines[k] = b"\t".join(f)
+    elif scenario in ("listed_five_fields", "unlisted_five_fields"):
+        k, f = find(scenario.startswith("listed"))
+        lines[k] = b"\t".join(f[:5])
+    elif scenario == "listed_three_fields":
+        k, f = find(True)
+        lines[k] = b"\t".join(f[:3])
+    elif scenario in ("listed_bad_depth", "unlisted_bad_depth"):
+        k, f = find(scenario.startswith("listed"))
+        f[3] = b"x7"
+        lines[k] = b"\t".join(f)
+    else:
+        raise ValueError(scenario)
+    return b"\n".join(lines) + b"\n"

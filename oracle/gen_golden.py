@@ -276,6 +276,51 @@ def gen_pileup_vectors(captured):
 
 
 
+def gen_bad_line_runs(captured):
+    """Files with ONE odd line through the reference's own call_consensus driver: the exception class it ends with, or the
+    consensus when the line is none of its business."""
+    from oracle import fuzz
+    from snppipeline import call_consensus as cc
+    from snppipeline import utils as ref_utils
+    runs = []
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    try:
+        for seed, kw in ((31, dict(genome_len=1500, n_sites=50, mean_depth=14)), (32, dict(genome_len=1200, n_sites=40, contigs=("cB", "cA")))):
+            base, refs, sites = fuzz.synth_pileup(seed, **kw)
+            snps = sorted(sites)
+            lpath = os.path.join(tmp, "snplist%d.txt" % seed)
+            with open(lpath, "w") as f:
+                for c, p in snps:
+                    f.write("%s\t%d\t1\tx\n" % (c.decode(), p))
+            for scenario in fuzz.BAD_LINE_SCENARIOS:
+                data = fuzz.with_bad_line(base, scenario, set(snps))
+                sdir = os.path.join(tmp, "s%d_%s" % (seed, scenario))
+                os.makedirs(sdir)
+                ppath = os.path.join(sdir, "reads.all.pileup")
+                with open(ppath, "wb") as f:
+                    f.write(data)
+                args = argparse.Namespace(
+                    snpListFile=lpath, allPileupFile=ppath, consensusFile=os.path.join(sdir, "consensus.fasta"), excludeFile=None,
+                    forceFlag=True, vcfFileName=None, vcfRefName="x", vcfAllPos=False, vcfPreserveRefCase=False, vcfFailedSnpGt=".",
+                    minBaseQual=0, minConsFreq=0.6, minConsDpth=1, minConsStrdDpth=0, minConsStrdBias=0.0)
+                ref_utils.log_verbosity = 0
+                sink, old = io.StringIO(), sys.stdout
+                sys.stdout = sink
+                run = {"seed": seed, "kw": {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()}, "scenario": scenario,
+                       "snplist": [[c.decode(), p] for c, p in snps], "params": [0, 0.6, 1, 0, 0.0]}
+                try:
+                    cc.call_consensus(args)
+                    run["consensus"] = captured["last"][1]
+                except Exception as err:                        # noqa: B902 — the class is the datum
+                    run["exception"] = type(err).__name__
+                finally:
+                    sys.stdout = old
+                runs.append(run)
+    finally:
+        shutil.rmtree(tmp)
+    return runs
+
+
 LONG_REFS = ["AC", "ac", "Ac", "N,", ".,", ",.", "A.", "gT,", "12", "*A", "a[", "`T", "ACGTNacgtn", ",,", "..", "T,c.G", "zZ", "-+",
              "AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAa"]
 
@@ -559,6 +604,9 @@ def main():
                                              (22, dict(genome_len=1800, n_sites=60, contigs=("NODE_1_length_419034_cov_23.1", "c")), PARAM_SETS[2])],
                                   line_ends=variant)
         dump("pileup_runs3.json.gz", {"runs": runs})
+        return
+    if sys.argv[1:] == ["--only", "badlines"]:
+        dump("badline_runs.json.gz", {"runs": gen_bad_line_runs(captured)})
         return
     if sys.argv[1:] == ["--only", "longref"]:
         dump("longref_vectors.json.gz", gen_longref_vectors())

@@ -611,3 +611,26 @@ def test_more_spilled_positions_than_the_context_holds_are_refused_not_lost(d):
     assert text.count(b"\n") == L.SPILL_CAP and all(ln.split(b"\t")[4].count(b",") == 7 for ln in text.split(b"\n") if ln)   # A is REF: 8 ALTs
     with pytest.raises(ValueError):
         vcf_writer.format_rows(res.counts, order, ss._names, ss._offs, ss.keys, names, False, ".", spill=res.spill)
+
+
+def test_files_with_one_odd_line_end_as_the_reference_does(d):
+    """The reference's driver on files with one odd line (badline_runs.json.gz): the same exception class — carried by
+    PileupFormatError.reference_exception, which the CLI re-raises as — or the same consensus, with and without per-site records."""
+    from snp_pipeline_amd.device import PileupFormatError
+    from tests.conftest import load_golden
+    from tests.gpu_util import gpu_consensus
+    for run in load_golden("badline_runs.json.gz")["runs"]:
+        kw = dict(run["kw"])
+        if "contigs" in kw:
+            kw["contigs"] = tuple(kw["contigs"])
+        base, _, _ = fuzz.synth_pileup(run["seed"], **kw)
+        snps = [(c.encode(), p) for c, p in run["snplist"]]
+        data = fuzz.with_bad_line(base, run["scenario"], set(snps))
+        for want_counts in (True, False):
+            if "exception" in run:
+                with pytest.raises(PileupFormatError) as ei:
+                    gpu_consensus(d, data, snps, [], po.CallerParams(*run["params"]), want_counts=want_counts)
+                assert ei.value.reference_exception.__name__ == run["exception"], (run["scenario"], want_counts)
+            else:
+                cons, _, _ = gpu_consensus(d, data, snps, [], po.CallerParams(*run["params"]), want_counts=want_counts)
+                assert cons.decode() == run["consensus"], (run["scenario"], want_counts)

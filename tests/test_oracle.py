@@ -237,3 +237,26 @@ def test_varscan_oracle_read_counting_rules():
     r = vo.call_line("a", 10, b"GGGGggggg.", b"I" * 10, vo.Params(**vo.PIPELINE_DEFAULTS))
     assert vo.vcf_row("c", "7", r) == "c\t7\t.\tA\tG\t.\tPASS\tADP=10;WT=0;HET=0;HOM=1;NC=0\tGT:GQ:SDP:DP:RD:AD:FREQ:PVAL:RBQ:ABQ:RDF:RDR:ADF:ADR\t" \
                                        "1/1:42:10:10:1:9:90%:5.9538E-5:40:40:1:0:4:5\n"       # (GQ / PVAL of RD 1, AD 9 as in agona ERR178926 pos 226973)
+
+
+def test_files_with_one_odd_line_end_as_the_reference_does():
+    """badline_runs.json.gz: the reference's own driver on files with one odd line — the exception class it raises, or the
+    consensus when the line is none of its business (pileup.py:423-429 only looks at chrom and position of unlisted lines)."""
+    from oracle import fuzz
+    from tests.conftest import load_golden
+    runs = load_golden("badline_runs.json.gz")["runs"]
+    assert {r["scenario"] for r in runs} == set(fuzz.BAD_LINE_SCENARIOS)
+    for run in runs:
+        kw = dict(run["kw"])
+        if "contigs" in kw:
+            kw["contigs"] = tuple(kw["contigs"])
+        base, _, _ = fuzz.synth_pileup(run["seed"], **kw)
+        snps = [(c.encode(), p) for c, p in run["snplist"]]
+        data = fuzz.with_bad_line(base, run["scenario"], set(snps))
+        if "exception" in run:
+            with pytest.raises((ValueError, IndexError)) as ei:
+                po.call_consensus_sites(data, snps, set(), po.CallerParams(*run["params"]))
+            assert type(ei.value).__name__ == run["exception"], run["scenario"]
+        else:
+            cons, _ = po.call_consensus_sites(data, snps, set(), po.CallerParams(*run["params"]))
+            assert cons.decode() == run["consensus"], run["scenario"]
