@@ -370,3 +370,31 @@ def with_bad_line(data, scenario, listed):
     else:
         raise ValueError(scenario)
     return b"\n".join(lines) + b"\n"
+
+
+def vcf_cohort(seed, n_samples=6):
+    """SNP records of a small cohort for the region filter: ({contig: length}, {sample name: [(contig, pos), ...] in file order}).
+    Shared scattered sites, one dense cluster that only some samples carry, sites near both contig ends, a contig the reference
+    FASTA does not list last in name order, and one sample with a single record."""
+    rng = random.Random(seed)
+    lengths = {"ctgB": 6000, "ctgA": 3500, "c": 900}
+    shared = [("ctgB", p) for p in sorted(rng.sample(range(700, 5300), 14))] + [("ctgA", p) for p in sorted(rng.sample(range(700, 2800), 8))]
+    cluster = [("ctgB", 2000 + k) for k in (0, 7, 19, 40, 41, 90, 118)]
+    ends = [("ctgB", 30), ("ctgB", 5990), ("ctgA", 480), ("ctgA", 3021), ("c", 450)]
+    cohort = {}
+    for s in range(n_samples):
+        recs = [r for r in shared if rng.random() < 0.7]
+        if s % 2 == 0:
+            recs += [r for r in cluster if rng.random() < 0.9]
+        recs += [r for r in ends if rng.random() < 0.5]
+        recs += [("ctgB", rng.randrange(600, 5400)) for _ in range(rng.randint(0, 3))]
+        recs = sorted(set(recs), key=lambda r: (r[0], r[1]))
+        if s == n_samples - 1:
+            recs = recs[:1]
+        cohort["smp%02d" % s] = recs
+    return lengths, cohort
+
+
+def vcf_text(records):
+    head = "##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSample1\n"
+    return head + "".join("%s\t%d\t.\tA\tG\t.\tPASS\tADP=20\tGT\t1/1\n" % (c, p) for c, p in records)

@@ -105,7 +105,22 @@ def install_stubs():
                 f = line.split("\t")
                 yield _Rec(f[0], int(f[1]))
 
+    class Writer(object):
+        """Stand-in for vcf.Writer: the decisions (which record goes to which file) as "CHROM<TAB>POS" lines."""
+        def __init__(self, stream, template=None, **kw):
+            self._s = stream
+
+        def write_record(self, rec):
+            self._s.write("%s\t%d\n" % (rec.CHROM, rec.POS))
+
+        def flush(self):
+            self._s.flush()
+
+        def close(self):
+            self._s.close()
+
     vcf.Reader = Reader
+    vcf.Writer = Writer
     for name, mod in [("Bio", bio), ("Bio.SeqIO", seqio), ("Bio.Seq", seqm), ("Bio.SeqRecord", recm), ("vcf", vcf)]:
         sys.modules[name] = mod
     return captured
@@ -318,6 +333,67 @@ def gen_bad_line_runs(captured):
                 runs.append(run)
     finally:
         shutil.rmtree(tmp)
+    return runs
+
+
+def gen_filter_runs():
+    """The reference's own filter_regions driver (filter_regions.py:17-71, 205-428) on a small cohort: which records of which
+    sample it preserves and removes — mode all / each, with and without outgroup samples, two rule sets."""
+    from oracle import fuzz
+    from snppipeline import filter_regions as fr
+    from snppipeline import utils as ref_utils
+    runs = []
+    for seed in (41, 42):
+        lengths, cohort = fuzz.vcf_cohort(seed)
+        for mode in ("all", "each"):
+            for outgroup in ([], ["smp02", "smp03"]):
+                for edge, windows, max_snps in ((500, [1000, 125, 15], [3, 2, 1]), (100, [300], [2])):
+                    tmp = tempfile.mkdtemp(prefix="golden_fr_")
+                    try:
+                        ref = os.path.join(tmp, "ref.fasta")
+                        with open(ref, "w") as f:
+                            for c, n in lengths.items():
+                                f.write(">%s\n%s\n" % (c, "A" * n))
+                        dirs = []
+                        for name, recs in cohort.items():
+                            sd = os.path.join(tmp, name)
+                            os.makedirs(sd)
+                            with open(os.path.join(sd, "var.flt.vcf"), "w") as f:
+                                f.write(fuzz.vcf_text(recs) if recs else "")
+                            dirs.append(sd)
+                        dirs_file = os.path.join(tmp, "dirs.txt")
+                        with open(dirs_file, "w") as f:
+                            f.write("\n".join(dirs) + "\n")
+                        og = None
+                        if outgroup:
+                            og = os.path.join(tmp, "outgroup.txt")
+                            with open(og, "w") as f:
+                                f.write("\n".join(outgroup) + "\n")
+                        args = argparse.Namespace(sampleDirsFile=dirs_file, refFastaFile=ref, forceFlag=True, vcfFileName="var.flt.vcf",
+                                                  edgeLength=edge, windowSizeList=windows, maxSnpsList=max_snps, outGroupFile=og, mode=mode)
+                        ref_utils.log_verbosity = 0
+                        os.environ["StopOnSampleError"] = "false"
+                        sink, old_out, old_err = io.StringIO(), sys.stdout, sys.stderr
+                        sys.stdout = sys.stderr = sink
+                        try:
+                            fr.filter_regions(args)
+                        finally:
+                            sys.stdout, sys.stderr = old_out, old_err
+                        result = {}
+                        for name, recs in cohort.items():
+                            out = {}
+                            for kind in ("preserved", "removed"):
+                                path = os.path.join(tmp, name, "var.flt_%s.vcf" % kind)
+                                if not os.path.exists(path):
+                                    out[kind] = None
+                                    continue
+                                rows = [ln.split("\t")[:2] for ln in open(path).read().split("\n") if ln and not ln.startswith("#")]
+                                out[kind] = [[c, int(p)] for c, p in rows]
+                            result[name] = out
+                        runs.append({"seed": seed, "mode": mode, "outgroup": outgroup, "edge": edge, "windows": windows, "max_snps": max_snps,
+                                     "result": result})
+                    finally:
+                        shutil.rmtree(tmp)
     return runs
 
 
@@ -604,6 +680,9 @@ def main():
                                              (22, dict(genome_len=1800, n_sites=60, contigs=("NODE_1_length_419034_cov_23.1", "c")), PARAM_SETS[2])],
                                   line_ends=variant)
         dump("pileup_runs3.json.gz", {"runs": runs})
+        return
+    if sys.argv[1:] == ["--only", "filter"]:
+        dump("filter_runs.json.gz", {"runs": gen_filter_runs()})
         return
     if sys.argv[1:] == ["--only", "badlines"]:
         dump("badline_runs.json.gz", {"runs": gen_bad_line_runs(captured)})

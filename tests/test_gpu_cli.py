@@ -350,3 +350,32 @@ def test_positions_with_more_than_eight_symbols_get_all_their_alt_alleles(tmp_pa
     _run("call_consensus_batch -l %s/snplist.txt %s %s/dirs.txt" % (tmp_path, flags, tmp_path))
     for d in dirs:
         assert data_rows(d + "/consensus.vcf") == rows
+
+
+def test_filter_regions_runs_of_the_reference_driver(tmp_path):
+    """filter_runs.json.gz through the console script: the records each sample keeps and loses, as the reference's own driver
+    decided them (mode all / each, outgroup samples, two rule sets)."""
+    from tests.conftest import load_golden
+    for k, run in enumerate(load_golden("filter_runs.json.gz")["runs"]):
+        lengths, cohort = fuzz.vcf_cohort(run["seed"])
+        work = tmp_path / ("run%d" % k)
+        work.mkdir()
+        ref = work / "ref.fasta"
+        ref.write_text("".join(">%s\n%s\n" % (c, "A" * n) for c, n in lengths.items()))
+        dirs = []
+        for name, recs in cohort.items():
+            sd = work / name
+            sd.mkdir()
+            (sd / "var.flt.vcf").write_text(fuzz.vcf_text(recs))
+            dirs.append(str(sd))
+        (work / "dirs.txt").write_text("\n".join(dirs) + "\n")
+        extra = ""
+        if run["outgroup"]:
+            (work / "outgroup.txt").write_text("\n".join(run["outgroup"]) + "\n")
+            extra = " -g %s/outgroup.txt" % work
+        _run("filter_regions -f -n var.flt.vcf --edge_length %d --window_size %s --max_snp %s --mode %s%s %s/dirs.txt %s"
+             % (run["edge"], " ".join(map(str, run["windows"])), " ".join(map(str, run["max_snps"])), run["mode"], extra, work, ref))
+        for name in cohort:
+            for kind in ("preserved", "removed"):
+                rows = [ln.split("\t")[:2] for ln in (work / name / ("var.flt_%s.vcf" % kind)).read_text().split("\n") if ln and not ln.startswith("#")]
+                assert [[c, int(p)] for c, p in rows] == run["result"][name][kind], (k, run["mode"], run["outgroup"], name, kind)

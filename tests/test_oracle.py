@@ -260,3 +260,25 @@ def test_files_with_one_odd_line_end_as_the_reference_does():
         else:
             cons, _ = po.call_consensus_sites(data, snps, set(), po.CallerParams(*run["params"]))
             assert cons.decode() == run["consensus"], run["scenario"]
+
+
+def test_filter_regions_runs_of_the_reference_driver():
+    """filter_runs.json.gz: which records the reference's own filter_regions driver preserves and removes per sample (mode
+    all / each, outgroup samples, two rule sets; the VCF writer replaced by a stand-in that records CHROM and POS)."""
+    from oracle import fuzz
+    from tests.conftest import load_golden
+    runs = load_golden("filter_runs.json.gz")["runs"]
+    assert {(r["mode"], bool(r["outgroup"])) for r in runs} == {("all", False), ("all", True), ("each", False), ("each", True)}
+    for run in runs:
+        lengths, cohort = fuzz.vcf_cohort(run["seed"])
+        samples = sorted(cohort.items())
+        bad = so.bad_regions(samples, lengths, run["edge"], run["max_snps"], run["windows"], mode=run["mode"], outgroup=set(run["outgroup"]))
+        for name, recs in samples:
+            want = run["result"][name]
+            if name in run["outgroup"]:
+                got_p, got_r = [list(r) for r in recs], []
+            else:
+                regions = bad if run["mode"] == "all" else bad[name]
+                got_r = [list(r) for r in recs if so.in_region(r[1], regions.get(r[0], []))]
+                got_p = [list(r) for r in recs if not so.in_region(r[1], regions.get(r[0], []))]
+            assert (got_p, got_r) == (want["preserved"], want["removed"]), (run["mode"], run["outgroup"], run["edge"], name)
