@@ -397,6 +397,46 @@ def gen_filter_runs():
     return runs
 
 
+def gen_merge_runs():
+    """The reference's own merge_sites driver (merge_sites.py:12-133) on the cohort of the filter runs: snplist text and the
+    filtered list of sample directories, without a limit and with --maxsnps limits that take some samples out (the directory
+    of the run is written as $W; the directories are listed in reverse order, as a user's file may be)."""
+    from oracle import fuzz
+    from snppipeline import merge_sites as ms
+    from snppipeline import utils as ref_utils
+    runs = []
+    for seed in (41, 42):
+        lengths, cohort = fuzz.vcf_cohort(seed)
+        sizes = sorted(len(set(r)) for r in cohort.values())
+        for max_snps in (-1, sizes[len(sizes) // 2], sizes[0], 0):
+            tmp = tempfile.mkdtemp(prefix="golden_ms_")
+            try:
+                dirs = []
+                for name, recs in cohort.items():
+                    sd = os.path.join(tmp, name)
+                    os.makedirs(sd)
+                    with open(os.path.join(sd, "var.flt.vcf"), "w") as f:
+                        f.write(fuzz.vcf_text(recs + recs[:2]))            # (two records twice: a VCF may repeat a position)
+                    dirs.append(sd)
+                dirs_file = os.path.join(tmp, "dirs.txt")
+                with open(dirs_file, "w") as f:
+                    f.write("\n".join(reversed(dirs)) + "\n")
+                args = argparse.Namespace(sampleDirsFile=dirs_file, vcfFileName="var.flt.vcf", snpListFile=os.path.join(tmp, "snplist.txt"),
+                                          forceFlag=True, maxSnps=max_snps, filteredSampleDirsFile=dirs_file + ".filtered")
+                ref_utils.log_verbosity = 0
+                sink, old = io.StringIO(), sys.stdout
+                sys.stdout = sink
+                try:
+                    ms.merge_sites(args)
+                finally:
+                    sys.stdout = old
+                runs.append({"seed": seed, "max_snps": max_snps, "snplist": open(args.snpListFile).read(),
+                             "filtered": open(args.filteredSampleDirsFile).read().replace(tmp, "$W")})
+            finally:
+                shutil.rmtree(tmp)
+    return runs
+
+
 LONG_REFS = ["AC", "ac", "Ac", "N,", ".,", ",.", "A.", "gT,", "12", "*A", "a[", "`T", "ACGTNacgtn", ",,", "..", "T,c.G", "zZ", "-+",
              "AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAa"]
 
@@ -680,6 +720,9 @@ def main():
                                              (22, dict(genome_len=1800, n_sites=60, contigs=("NODE_1_length_419034_cov_23.1", "c")), PARAM_SETS[2])],
                                   line_ends=variant)
         dump("pileup_runs3.json.gz", {"runs": runs})
+        return
+    if sys.argv[1:] == ["--only", "merge"]:
+        dump("merge_runs.json.gz", {"runs": gen_merge_runs()})
         return
     if sys.argv[1:] == ["--only", "filter"]:
         dump("filter_runs.json.gz", {"runs": gen_filter_runs()})

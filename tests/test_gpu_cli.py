@@ -379,3 +379,23 @@ def test_filter_regions_runs_of_the_reference_driver(tmp_path):
             for kind in ("preserved", "removed"):
                 rows = [ln.split("\t")[:2] for ln in (work / name / ("var.flt_%s.vcf" % kind)).read_text().split("\n") if ln and not ln.startswith("#")]
                 assert [[c, int(p)] for c, p in rows] == run["result"][name][kind], (k, run["mode"], run["outgroup"], name, kind)
+
+
+def test_merge_sites_runs_of_the_reference_driver(tmp_path):
+    """merge_runs.json.gz through the console script: snplist.txt and the filtered list of sample directories byte for byte
+    as the reference's own driver wrote them (no limit, --maxsnps limits that take some / all but one / all samples out)."""
+    from tests.conftest import load_golden
+    for k, run in enumerate(load_golden("merge_runs.json.gz")["runs"]):
+        _, cohort = fuzz.vcf_cohort(run["seed"])
+        work = tmp_path / ("run%d" % k)
+        work.mkdir()
+        dirs = []
+        for name, recs in cohort.items():
+            sd = work / name
+            sd.mkdir()
+            (sd / "var.flt.vcf").write_text(fuzz.vcf_text(recs + recs[:2]))
+            dirs.append(str(sd))
+        (work / "dirs.txt").write_text("\n".join(reversed(dirs)) + "\n")
+        _run("merge_sites -f -n var.flt.vcf --maxsnps %d -o %s/snplist.txt %s/dirs.txt %s/dirs.txt.filtered" % (run["max_snps"], work, work, work))
+        assert (work / "snplist.txt").read_text() == run["snplist"], (run["seed"], run["max_snps"])
+        assert (work / "dirs.txt.filtered").read_text().replace(str(work), "$W") == run["filtered"], (run["seed"], run["max_snps"])

@@ -282,3 +282,17 @@ def test_filter_regions_runs_of_the_reference_driver():
                 got_r = [list(r) for r in recs if so.in_region(r[1], regions.get(r[0], []))]
                 got_p = [list(r) for r in recs if not so.in_region(r[1], regions.get(r[0], []))]
             assert (got_p, got_r) == (want["preserved"], want["removed"]), (run["mode"], run["outgroup"], run["edge"], name)
+
+
+def test_merge_sites_runs_of_the_reference_driver():
+    """merge_runs.json.gz: snplist text and filtered sample list of the reference's own merge_sites driver, with --maxsnps
+    limits that take samples out; VCFs that repeat a position."""
+    from oracle import fuzz
+    from tests.conftest import load_golden
+    for run in load_golden("merge_runs.json.gz")["runs"]:
+        _, cohort = fuzz.vcf_cohort(run["seed"])
+        samples = [("$W/" + name, name, recs + recs[:2]) for name, recs in sorted(cohort.items())]
+        merged, excluded = so.merge_sites(samples, run["max_snps"])
+        assert so.snplist_text(merged) == run["snplist"], (run["seed"], run["max_snps"])
+        listed = "".join(d + "\n" for d, _, _ in reversed(samples) if d not in excluded)
+        assert listed == run["filtered"], (run["seed"], run["max_snps"])
