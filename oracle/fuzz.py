@@ -398,3 +398,27 @@ def vcf_cohort(seed, n_samples=6):
 def vcf_text(records):
     head = "##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSample1\n"
     return head + "".join("%s\t%d\t.\tA\tG\t.\tPASS\tADP=20\tGT\t1/1\n" % (c, p) for c, p in records)
+
+
+def untidy_snpmas():
+    """SNP matrix files the distance step must read as the reference's line loop does (distance.py:76-84): [(name, text)]."""
+    rng = random.Random(77)
+    letters = "ACGTacgt-NnRY*"
+
+    def seq(n):
+        return "".join(rng.choice(letters) for _ in range(n))
+
+    def fasta(recs, width=60, eol="\n"):
+        return "".join(">" + name + eol + "".join(s[i:i + width] + eol for i in range(0, len(s), width)) for name, s in recs)
+
+    out = []
+    out.append(("plain", fasta([("s%02d" % (7 - k), seq(300)) for k in range(7)])))
+    out.append(("repeated_id", fasta([("b", seq(120)), ("a", seq(120)), ("b", seq(120)), ("c", seq(120))])))
+    out.append(("growing_lengths", fasta([("zeta", seq(500)), ("alpha", seq(300)), ("mid", seq(400)), ("beta", seq(310)), ("omega", seq(500))])))
+    out.append(("shorter_later", fasta([("a", seq(50)), ("b", seq(30))])))
+    out.append(("crlf_and_unwrapped", fasta([("x", seq(200)), ("y", seq(200))], width=10 ** 6, eol="\r\n")))
+    out.append(("header_with_blanks", fasta([("sample one extra words", seq(70)), (">double", seq(70)), ("plain", seq(70))])))
+    out.append(("an_empty_record", fasta([("a", ""), ("b", seq(40)), ("c", seq(40))])))
+    out.append(("text_before_the_first_header", "ACGT\n" + fasta([("a", seq(20)), ("b", seq(20))])))
+    out.append(("one_sample", fasta([("only", seq(33))])))
+    return out

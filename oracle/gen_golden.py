@@ -437,6 +437,37 @@ def gen_merge_runs():
     return runs
 
 
+def gen_distance_runs():
+    """The reference's own distance driver (distance.py:14-118) on untidy SNP matrix files: both TSV texts, or the exception."""
+    from oracle import fuzz
+    from snppipeline import distance as dm
+    from snppipeline import utils as ref_utils
+    runs = []
+    for name, text in fuzz.untidy_snpmas():
+        tmp = tempfile.mkdtemp(prefix="golden_dist_")
+        try:
+            path = os.path.join(tmp, "snpma.fasta")
+            with open(path, "w", newline="") as f:
+                f.write(text)
+            args = argparse.Namespace(inputFile=path, pairwiseFile=os.path.join(tmp, "p.tsv"), matrixFile=os.path.join(tmp, "m.tsv"), forceFlag=True)
+            ref_utils.log_verbosity = 0
+            sink, old = io.StringIO(), sys.stdout
+            sys.stdout = sink
+            run = {"name": name}
+            try:
+                dm.calculate_snp_distances(args)
+                run["pairwise"] = open(args.pairwiseFile).read()
+                run["matrix"] = open(args.matrixFile).read()
+            except Exception as err:                            # noqa: B902 — the class is the datum
+                run["exception"] = type(err).__name__
+            finally:
+                sys.stdout = old
+            runs.append(run)
+        finally:
+            shutil.rmtree(tmp)
+    return runs
+
+
 LONG_REFS = ["AC", "ac", "Ac", "N,", ".,", ",.", "A.", "gT,", "12", "*A", "a[", "`T", "ACGTNacgtn", ",,", "..", "T,c.G", "zZ", "-+",
              "AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAa"]
 
@@ -720,6 +751,9 @@ def main():
                                              (22, dict(genome_len=1800, n_sites=60, contigs=("NODE_1_length_419034_cov_23.1", "c")), PARAM_SETS[2])],
                                   line_ends=variant)
         dump("pileup_runs3.json.gz", {"runs": runs})
+        return
+    if sys.argv[1:] == ["--only", "distance"]:
+        dump("distance_runs.json.gz", {"runs": gen_distance_runs()})
         return
     if sys.argv[1:] == ["--only", "merge"]:
         dump("merge_runs.json.gz", {"runs": gen_merge_runs()})

@@ -140,6 +140,8 @@ def parse_snpma(text):
             cur = line.lstrip(">")
             seqs[cur] = ""
         elif cur is not None or line:
+            if cur is None:                     # distance.py:84: curr_sample is read before any header has bound it
+                raise UnboundLocalError("local variable 'curr_sample' referenced before assignment")
             seqs[cur] += line
     return seqs
 

@@ -68,14 +68,16 @@ def read_matrix(path):
                 curr = line.lstrip(">")
                 seqs[curr] = []
             else:
-                seqs[curr].append(line)             # KeyError(None) if data precedes the first header, like the reference's NameError
+                if curr is None:                    # distance.py:84 reads curr_sample before any header has set it
+                    raise UnboundLocalError("local variable 'curr_sample' referenced before assignment")
+                seqs[curr].append(line)
     return {k: "".join(v) for k, v in seqs.items()}
 
 
 def load_matrix(path):
     """The same parse straight into a byte matrix, by the library's host code (csrc/fasta_in.hip): returns (ids in file order,
-    (records x longest) uint8 matrix padded with '-', lengths).  Raises KeyError(None) for sequence text before the first
-    header, like read_matrix.  Duplicate ids are all returned (the reference's dict keeps the last one: see distance.py)."""
+    (records x longest) uint8 matrix padded with '-', lengths).  Raises UnboundLocalError for sequence text before the first
+    header, like read_matrix and the reference (golden: distance_runs).  Duplicate ids are all returned (the reference's dict keeps the last one: see distance.py)."""
     import ctypes as C
     from . import _lib as L
     lib = L.load()
@@ -84,7 +86,7 @@ def load_matrix(path):
     if rc == L.E_IO:
         raise IOError("cannot read %s" % path)
     if rc == L.E_UNSUPPORTED:
-        raise KeyError(None)
+        raise UnboundLocalError("local variable 'curr_sample' referenced before assignment")
     if rc != 0:
         raise RuntimeError("snpgpu_fasta_scan failed (%d)" % rc)
     mat = np.empty((n.value, longest.value), dtype=np.uint8)

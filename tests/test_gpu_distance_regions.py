@@ -271,7 +271,8 @@ def test_distance_unequal_lengths_and_no_sites(d):
 def test_distance_cli_on_an_untidy_snpma(d, tmp_path):
     """The distance subcommand through the native FASTA loader: ids out of order, a duplicate id (the later record counts, as in the
     reference's dict), CR LF line ends, wrapped and unwrapped records, unequal lengths in non-decreasing id order — TSVs equal to
-    the oracle's; a shorter later sequence raises IndexError as utils.py:1158 does; text before the first header KeyError."""
+    the oracle's; a shorter later sequence raises IndexError as utils.py:1158 does; text before the first header
+    UnboundLocalError (distance.py:84)."""
     from snp_pipeline_amd import cfsan_snp_pipeline as cli
     rng = np.random.default_rng(12)
     letters = np.frombuffer(b"ACGTacgt-N", dtype=np.uint8)
@@ -297,5 +298,31 @@ def test_distance_cli_on_an_untidy_snpma(d, tmp_path):
     with pytest.raises(IndexError):
         cli.run_command_from_args(cli.parse_command_line("distance -f -v 0 -p %s/p.tsv %s" % (tmp_path, snpma)))
     snpma.write_bytes(b"ACGT\n>a\nACGTA\n")
-    with pytest.raises(KeyError):
+    with pytest.raises(UnboundLocalError):
         cli.run_command_from_args(cli.parse_command_line("distance -f -v 0 -p %s/p.tsv %s" % (tmp_path, snpma)))
+
+
+def test_distance_cli_reproduces_the_reference_drivers_runs(d, tmp_path):
+    """tests/golden/distance_runs.json.gz holds what the reference's own distance driver wrote (or raised) for the untidy SNP
+    matrix files of oracle/fuzz.untidy_snpmas (gen_golden.py --only distance): the subcommand writes the same bytes / raises the
+    same class."""
+    import gzip
+    import json
+    from oracle import fuzz
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    runs = json.loads(gzip.open(os.path.join(os.path.dirname(__file__), "golden", "distance_runs.json.gz")).read())["runs"]
+    texts = dict(fuzz.untidy_snpmas())
+    assert len(runs) == len(texts) >= 9
+    for run in runs:
+        snpma = tmp_path / (run["name"] + ".fasta")
+        snpma.write_bytes(texts[run["name"]].encode())
+        p, m = tmp_path / (run["name"] + ".p.tsv"), tmp_path / (run["name"] + ".m.tsv")
+        args = cli.parse_command_line("distance -f -v 0 -p %s -m %s %s" % (p, m, snpma))
+        if "exception" in run:
+            with pytest.raises(Exception) as ei:
+                cli.run_command_from_args(args)
+            assert type(ei.value).__name__ == run["exception"], run["name"]
+        else:
+            assert cli.run_command_from_args(args) == 0
+            assert p.read_text() == run["pairwise"], run["name"]
+            assert m.read_text() == run["matrix"], run["name"]

@@ -296,3 +296,22 @@ def test_merge_sites_runs_of_the_reference_driver():
         assert so.snplist_text(merged) == run["snplist"], (run["seed"], run["max_snps"])
         listed = "".join(d + "\n" for d, _, _ in reversed(samples) if d not in excluded)
         assert listed == run["filtered"], (run["seed"], run["max_snps"])
+
+
+def test_distance_runs_of_the_reference_driver():
+    """distance_runs.json.gz: both TSV texts (or the exception class) of the reference's own distance driver on the untidy SNP
+    matrix files of fuzz.untidy_snpmas: ids out of order, a repeated id, growing lengths, a shorter later sequence, CR LF, an
+    empty record, text before the first header."""
+    from oracle import fuzz
+    from tests.conftest import load_golden
+    texts = dict(fuzz.untidy_snpmas())
+    for run in load_golden("distance_runs.json.gz")["runs"]:
+        text = texts[run["name"]].replace("\r\n", "\n")
+        if "exception" in run:
+            with pytest.raises(Exception) as ei:
+                so.distance_tables(so.parse_snpma(text))
+            assert type(ei.value).__name__ == run["exception"], run["name"]
+            continue
+        ids, table = so.distance_tables(so.parse_snpma(text))
+        assert so.pairwise_text(ids, table) == run["pairwise"], run["name"]
+        assert so.matrix_text(ids, table) == run["matrix"], run["name"]
