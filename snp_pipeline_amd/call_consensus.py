@@ -247,7 +247,7 @@ def call_consensus_batch(args):
     lock = threading.Lock()
 
     def worker(dev_index, my_plans):
-        todo = list(my_plans)                     # whatever is still here when the worker dies is reported as failed
+        n_done = 0                                # the plans from here on are reported as failed when the worker dies
         dev = None
         writer = None
         try:
@@ -307,7 +307,7 @@ def call_consensus_batch(args):
                     except Exception as err:  # noqa: B902  (reported per sample below)
                         with lock:
                             errors.append((plan, err))
-                    todo.remove(plan)
+                    n_done += 1
                 if in_background:
                     writer = threading.Thread(target=write_part, args=(in_background,))
                     writer.start()
@@ -316,7 +316,7 @@ def call_consensus_batch(args):
             ss.close()
         except Exception as err:              # noqa: B902 — the device, the site set or a whole call failed: every sample left is reported
             with lock:
-                errors.extend((plan, err) for plan in todo)
+                errors.extend((plan, err) for plan in my_plans[n_done:])
         finally:
             if writer is not None:
                 writer.join()                 # (its samples' files are complete before the device goes)

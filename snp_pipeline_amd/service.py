@@ -130,19 +130,24 @@ def try_client(argv):
     directory = service_dir()
     if directory is None or not argv or argv[0] not in SERVED:
         return None
-    socks = _sockets(directory)
-    if not socks and (os.environ.get("SNPGPU_SERVICE", "") in ("auto", "1", "on", "yes", "true") or os.environ.get("SNPGPU_SERVICE_SPAWN") == "1"):
-        _spawn(directory)
+    may_spawn = os.environ.get("SNPGPU_SERVICE", "") in ("auto", "1", "on", "yes", "true") or os.environ.get("SNPGPU_SERVICE_SPAWN") == "1"
+
+    def connect_any():
+        # samples spread over the workers (one per GPU) by what they work on; a dead worker's neighbours take over
         socks = _sockets(directory)
-    if not socks:
+        if not socks:
+            return None
+        start = sum(bytearray((os.getcwd() + "\0" + "\0".join(argv)).encode("utf-8", "surrogateescape"))) % len(socks)
+        for k in range(len(socks)):
+            c = _connect(socks[(start + k) % len(socks)])
+            if c is not None:
+                return c
         return None
-    # samples spread over the workers (one per GPU) by what they work on; a dead worker's neighbours take over
-    start = sum(bytearray((os.getcwd() + "\0" + "\0".join(argv)).encode("utf-8", "surrogateescape"))) % len(socks)
-    conn = None
-    for k in range(len(socks)):
-        conn = _connect(socks[(start + k) % len(socks)])
-        if conn is not None:
-            break
+
+    conn = connect_any()
+    if conn is None and may_spawn:                           # no socket, or only the files a killed server left behind
+        _spawn(directory)
+        conn = connect_any()
     if conn is None:
         return None
     try:
@@ -250,8 +255,9 @@ def _worker(directory, device, idle_timeout):
                 print("snpgpu service: device %d idle for %g s, %d requests served: leaving" % (device, idle_timeout, served))
                 break
             try:
-                conn.settimeout(None)
+                conn.settimeout(60.0)                        # a client that connects and says nothing does not hold the GPU's queue
                 req = _recv(conn)
+                conn.settimeout(None)
                 if req.get("ping"):
                     _send(conn, {"pong": True, "device": device, "served": served})
                 elif req.get("stop"):
@@ -260,7 +266,7 @@ def _worker(directory, device, idle_timeout):
                 else:
                     _send(conn, _run_request(req))
                     served += 1
-            except (OSError, EOFError, ValueError) as e:
+            except (OSError, EOFError, ValueError) as e:         # (socket.timeout is an OSError)
                 print("snpgpu service: request dropped: %s" % e)
             finally:
                 conn.close()

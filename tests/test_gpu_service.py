@@ -4,6 +4,7 @@ and exit with the same codes as the in-process console script."""
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -78,5 +79,21 @@ def test_call_consensus_through_the_service_equals_in_process(tmp_path):
         r = subprocess.run([sys.executable, "-X", "importtime", EXE] + cmd(samples[1][0], "served")[2:], env=env1, capture_output=True, text=True, timeout=300,
                            cwd=str(tmp_path))
         assert r.returncode == 0 and "numpy" not in r.stderr and "ctypes" not in r.stderr
+        # a killed server leaves its socket file behind: the next client finds nobody there, starts a new server and is served by it
+        import socket
+        from snp_pipeline_amd import service
+        subprocess.run([sys.executable, EXE, "serve", "--socketDir", svc, "--stop"], env=env0, capture_output=True, text=True, timeout=120)
+        stale = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        for _ in range(200):                                        # (the stopped server unlinks its socket on the way out)
+            if not os.path.exists(os.path.join(svc, "dev0.sock")):
+                break
+            time.sleep(0.05)
+        stale.bind(os.path.join(svc, "dev0.sock"))
+        stale.close()
+        assert os.path.exists(os.path.join(svc, "dev0.sock")) and not service._probe(os.path.join(svc, "dev0.sock"))
+        os.remove(os.path.join(samples[2][0], "served.fasta"))
+        r = subprocess.run(cmd(samples[2][0], "served"), env=env1, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+        assert r.returncode == 0 and os.path.exists(os.path.join(samples[2][0], "served.fasta"))
+        assert service._probe(os.path.join(svc, "dev0.sock"))       # a live server again
     finally:
         subprocess.run([sys.executable, EXE, "serve", "--socketDir", svc, "--stop"], env=env0, capture_output=True, text=True, timeout=120)
