@@ -11,6 +11,7 @@ provided by this build: asking for one exits with an explanatory message.
 from __future__ import absolute_import
 
 import argparse
+import os
 import sys
 
 from . import call_consensus, call_sites, distance, filter_regions, hot_path, merge_sites, service, snp_matrix, snp_reference, utils
@@ -28,7 +29,22 @@ class HelpParser(argparse.ArgumentParser):
 
 def _not_provided(args):
     utils.global_error("Error: the %s command is not part of the MI355X hot-path build; use the reference "
-                       "cfsan_snp_pipeline for it." % args.subparser_name)
+                       "cfsan_snp_pipeline for it (SNPGPU_REFERENCE_CLI=<its path>, or leave it further down PATH)." % args.subparser_name)
+
+
+def reference_cli():
+    """The reference's own console script for the subcommands outside the hot path (run, map_reads, merge_vcfs, collect_metrics
+    ...): $SNPGPU_REFERENCE_CLI, or the next ``cfsan_snp_pipeline`` on PATH that is not this build's.  None when there is none."""
+    given = os.environ.get("SNPGPU_REFERENCE_CLI")
+    if given:
+        return given if os.access(given, os.X_OK) else None
+    here = os.path.realpath(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "cfsan_snp_pipeline"))
+    me = os.path.realpath(sys.argv[0]) if sys.argv and sys.argv[0] else None
+    for d in os.environ.get("PATH", "").split(os.pathsep):
+        cand = os.path.join(d or ".", "cfsan_snp_pipeline")
+        if os.path.isfile(cand) and os.access(cand, os.X_OK) and os.path.realpath(cand) not in (here, me):
+            return cand
+    return None
 
 
 def _min_cons_freq(value):
@@ -238,6 +254,11 @@ def run_command_from_line(line):
 def main():
     """Console entry point.  A CLI process never exchanges device pointers with torch, so the HIP library is loaded
     without importing it (seconds per sample process); see _lib.load()."""
+    if len(sys.argv) > 1 and sys.argv[1] in NOT_PROVIDED:    # with bin/ in front of PATH, `cfsan_snp_pipeline run ...` still works
+        other = reference_cli()
+        if other:
+            sys.stdout.flush()
+            os.execv(other, [other] + sys.argv[1:])
     from . import _lib
     _lib.TORCH_FREE_OK = True
     return run_command_from_arg_list(sys.argv[1:])

@@ -1095,3 +1095,31 @@ def test_a_pileup_that_is_no_regular_file_is_an_input_error_as_a_fifo_is_for_the
                         "-o", str(tmp_path / "consensus.fasta"), str(fifo)], capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, SNPGPU_SERVICE=""))
     assert r.returncode != 0 and not (tmp_path / "consensus.fasta").exists()
+
+
+def test_subcommands_outside_the_hot_path_go_to_the_reference_cli(tmp_path):
+    """With this build's bin/ in front of PATH, `cfsan_snp_pipeline run|map_reads|collect_metrics ...` is handed, argument for
+    argument, to the reference's console script: $SNPGPU_REFERENCE_CLI or the next cfsan_snp_pipeline on PATH; without either the
+    command ends as a global error (exit 100) that says so."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "bin", "cfsan_snp_pipeline")
+    other = tmp_path / "refbin"
+    other.mkdir()
+    fake = other / "cfsan_snp_pipeline"
+    fake.write_text("#!/bin/sh\necho \"reference got: $*\"\nexit 7\n")
+    fake.chmod(0o755)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SNPGPU_")}
+    env["errorOutputFile"] = str(tmp_path / "error.log")
+    on_path = dict(env, PATH=os.pathsep.join([os.path.join(root, "bin"), str(other), env.get("PATH", "")]))
+    r = subprocess.run([exe, "map_reads", "-f", "-v", "3", "ref.fasta", "a b.fastq"], env=on_path, capture_output=True, text=True, timeout=120)
+    assert (r.returncode, r.stdout) == (7, "reference got: map_reads -f -v 3 ref.fasta a b.fastq\n")
+    named = dict(env, SNPGPU_REFERENCE_CLI=str(fake), PATH=os.path.join(root, "bin") + os.pathsep + "/usr/bin" + os.pathsep + "/bin")
+    r = subprocess.run([exe, "run", "-s", "samples", "ref.fasta"], env=named, capture_output=True, text=True, timeout=120)
+    assert (r.returncode, r.stdout) == (7, "reference got: run -s samples ref.fasta\n")
+    alone = dict(env, PATH=os.path.join(root, "bin") + os.pathsep + "/usr/bin" + os.pathsep + "/bin")
+    r = subprocess.run([exe, "collect_metrics", "-v", "0", "x"], env=alone, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 100 and "not part of the MI355X hot-path build" in r.stderr + r.stdout + open(env["errorOutputFile"]).read()
+    # the hot-path subcommands never go there
+    r = subprocess.run([exe, "distance", "--version"], env=on_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "reference got" not in r.stdout
