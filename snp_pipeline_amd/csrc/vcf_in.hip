@@ -3,7 +3,7 @@
 // snpgpu_vcf_sites replaces what utils.convert_vcf_file_to_snp_set (utils.py:1113-1132) and filter_regions.py:408-410 get
 // from PyVCF3's Reader — the first two columns of every data line — for 10 000 files of ~1 500 records at configs[4]
 // (12 s of Python line handling per pass).  It takes the plain case only: TAB-separated columns, POS of 1..10 plain
-// digits below 2^32, text-mode line ends; anything else (and data before the header, which PyVCF3 refuses) is reported
+// digits below 2^32, text-mode line ends; anything else (and data before the header: PyVCF takes such a line AS the header) is reported
 // as SNPGPU_E_UNSUPPORTED and the caller reads that file with its Python reader, which knows the corner cases.
 // snpgpu_write_snplist replaces utils.write_list_of_snps (utils.py:1056-1070): "%s\t%d\t%d\t%s\n" per site.
 #include <errno.h>
@@ -55,11 +55,11 @@ static int read_sites(bool is_vcf, const char *path, uint64_t capacity, uint32_t
         const char *cr = (const char *)memchr(p + pos, '\r', e - pos);
         if (cr) { e = (size_t)(cr - p); pos = e + 1; if (pos < n && p[pos] == '\n') ++pos; }
         else pos = nl ? e + 1 : n;
-        if (is_vcf && e > b && p[b] == '#') { header_seen = true; continue; }
+        if (is_vcf && e > b && p[b] == '#') { header_seen = header_seen || !(e - b >= 2 && p[b + 1] == '#'); continue; }   // "##" lines are meta
         bool blank = true;
         for (size_t k = b; k < e && blank; ++k) blank = p[k] == ' ' || (p[k] >= 9 && p[k] <= 13) || (p[k] >= 28 && p[k] <= 31);
         if (blank) { if (is_vcf) continue; return SNPGPU_E_UNSUPPORTED; }   // (utils.read_snp_position_list raises for a blank line)
-        if (is_vcf && !header_seen) return SNPGPU_E_UNSUPPORTED; // PyVCF3 refuses the file: the Python reader raises for it
+        if (is_vcf && !header_seen) return SNPGPU_E_UNSUPPORTED; // PyVCF takes this line as the column header: left to the Python reader
         const char *t1 = (const char *)memchr(p + b, '\t', e - b);
         if (!t1 || t1 == p + b) return SNPGPU_E_UNSUPPORTED;
         if (!is_vcf)                                            // str.split() cuts at ANY white space: a name with a blank in it is not plain

@@ -243,7 +243,7 @@ def write_preserved_and_removed_vcf_files(vcf_file_path, header, data_lines, rem
 def _read_vcf(vcf_path):
     """(header lines, data lines, sites as arrays): the columns come from the library's reader (utils.read_vcf_site_arrays), the
     lines from one readlines(); a file outside the reader's plain case is read by utils.read_vcf_sites, line by line."""
-    names, cidx, pos = utils.read_vcf_site_arrays(vcf_path)     # raises IOError for data before the header, like PyVCF3's Reader
+    names, cidx, pos = utils.read_vcf_site_arrays(vcf_path)     # (a file without a "#CHROM" line: utils.read_vcf_sites says what becomes of it)
     # the plain case on bytes: ASCII, "\n" line ends, the header first, one record per remaining line
     with open(vcf_path, "rb") as f:
         raw = f.read()
