@@ -35,11 +35,11 @@ def _not_provided(args):
 def reference_cli():
     """The reference's own console script for the subcommands outside the hot path (run, map_reads, merge_vcfs, collect_metrics
     ...): $SNPGPU_REFERENCE_CLI, or the next ``cfsan_snp_pipeline`` on PATH that is not this build's.  None when there is none."""
-    given = os.environ.get("SNPGPU_REFERENCE_CLI")
-    if given:
-        return given if os.access(given, os.X_OK) else None
     here = os.path.realpath(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "cfsan_snp_pipeline"))
     me = os.path.realpath(sys.argv[0]) if sys.argv and sys.argv[0] else None
+    given = os.environ.get("SNPGPU_REFERENCE_CLI")
+    if given:                                                # (pointing it at this build would be a loop of execs)
+        return given if os.access(given, os.X_OK) and os.path.realpath(given) not in (here, me) else None
     for d in os.environ.get("PATH", "").split(os.pathsep):
         cand = os.path.join(d or ".", "cfsan_snp_pipeline")
         if os.path.isfile(cand) and os.access(cand, os.X_OK) and os.path.realpath(cand) not in (here, me):
