@@ -189,6 +189,7 @@ def call_consensus(args):
     timing.mark("streamed call")
     try:
         dev.raise_file_status(all_pileup_file_path, int(rcs[0]), results[0])
+        dev.check_repeated_positions(ss, all_pileup_file_path, params, results[0])
     except devmod.PileupFormatError as err:
         _raise_as_reference(err, all_pileup_file_path)
     _write_outputs(plan, dev, ss, snp_slots, results[0])
@@ -291,13 +292,15 @@ def call_consensus_batch(args):
                 in_background = []
                 for plan, rc, res in zip(part, rcs, results):
                     try:
-                        dev.raise_file_status(plan.pileup_path, int(rc), res)
                         flags = ss.flags
                         if with_excl:
                             flags = ss.flags.copy()
                             mine = excl_slots.get(id(plan))
                             if mine is not None:
                                 flags[mine[mine >= 0]] |= L.SITE_EXCLUDED
+                        # (positions that are only on OTHER samples' exclude lists are nothing this sample is asked about)
+                        dev.raise_file_status(plan.pileup_path, int(rc), res, wanted=(flags != 0) if with_excl else None)
+                        dev.check_repeated_positions(ss, plan.pileup_path, params, res)
                         needs_device = bool(plan.vcf_path) and (args.vcfAllPos or res.n_matched > int(np.count_nonzero(res.line_offsets)))
                         if needs_device:      # (the all-lines pass: a device call, so here and now)
                             with lock:
@@ -329,7 +332,8 @@ def call_consensus_batch(args):
     for t in threads:
         t.join()
     for plan, err in errors:
-        utils.sample_error("Error: call_consensus failed for sample %s: %s: %s" % (plan.sample_name, type(err).__name__, err),
+        kind = getattr(err, "reference_exception", None) or type(err)      # (a malformed pileup: the class the reference ends with)
+        utils.sample_error("Error: call_consensus failed for sample %s: %s: %s" % (plan.sample_name, kind.__name__, err),
                            continue_possible=True)
     if failed or errors:
         utils.verbose_print("%d of %d samples failed." % (failed + len(errors), len(sample_dirs)))

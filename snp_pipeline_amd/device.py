@@ -258,14 +258,35 @@ class Device(object):
         return SiteSet.from_lists(self, lists)
 
     @staticmethod
-    def raise_scan_status(status):
+    def scan_error(status):
+        """(exception, byte offset of its line) for the first line whose chrom / position columns the reader cannot take, or
+        (None, None)."""
         w0 = int(status[0])
-        if w0 != 0xFFFFFFFFFFFFFFFF:
-            code, off = w0 & 0xFF, (w0 >> 8) - 1
-            err = PileupFormatError("pileup: %s at byte offset %d" % (_SCAN_CODES.get(code, "malformed line"), off),
-                                    _SCAN_EXC.get(code, ValueError))
-            err.scan_code = code
+        if w0 == 0xFFFFFFFFFFFFFFFF:
+            return None, None
+        code, off = w0 & 0xFF, (w0 >> 8) - 1
+        err = PileupFormatError("pileup: %s at byte offset %d" % (_SCAN_CODES.get(code, "malformed line"), off),
+                                _SCAN_EXC.get(code, ValueError))
+        err.scan_code = code
+        return err, off
+
+    @staticmethod
+    def raise_scan_status(status):
+        err, _ = Device.scan_error(status)
+        if err is not None:
             raise err
+
+    def raise_first_error(self, status, res=None, check=True, wanted=None):
+        """The reference reads a pileup top to bottom and ends at the FIRST line it cannot take: a line whose first two columns
+        the reader cannot split or convert (pileup.py:425-426, any line), or a line at a listed position that Record cannot be
+        built from (pileup.py:224-237).  Both kinds are found here by different kernels, so the earlier one in the file is
+        picked by byte offset (per-site offsets: ``res.line_offsets``; without them a reader-level error goes first)."""
+        scan, s_off = self.scan_error(status)
+        site, t_off = self.site_error(res, wanted) if (check and res is not None) else (None, None)
+        if scan is not None and (site is None or t_off is None or s_off <= t_off or scan.scan_code == 3):
+            raise scan
+        if site is not None:
+            raise site
 
     def call_consensus(self, siteset, pileup, params, want_counts=False, want_depth_sum=False, check=True):
         """pileup: bytes-like (host).  Returns ConsensusResult over siteset.keys order.  check=False: do not raise for
@@ -280,30 +301,50 @@ class Device(object):
         rc = self.lib.snpgpu_call_consensus(self.ctx, siteset.handle, _ptr(buf) if len(buf) else None, len(buf),
                                             C.byref(params), _ptr(bases), _ptr(filters), _ptr(counts), _ptr(status),
                                             1 if want_depth_sum else 0)
-        if rc in (L.E_PILEUP, L.E_UNSUPPORTED) and int(status[0]) != 0xFFFFFFFFFFFFFFFF:
-            self.raise_scan_status(status)
-        self._check(rc)
-        res = ConsensusResult(bases, filters, counts, status, self.read_symbol_spill(counts) if want_counts else None)
-        if check:
-            self.raise_site_status(res)
+        scan_failed = rc in (L.E_PILEUP, L.E_UNSUPPORTED) and int(status[0]) != 0xFFFFFFFFFFFFFFFF
+        if not scan_failed:
+            self._check(rc)
+        res = ConsensusResult(bases, filters, counts, status, self.read_symbol_spill(counts) if want_counts and not scan_failed else None)
+        if scan_failed or (check and self.site_error(res)[0] is not None):
+            res.line_offsets = self.line_offsets(siteset)       # which malformed line comes first in the file
+            self.raise_first_error(status, res, check)
         return res
+
+    @staticmethod
+    def site_error(res, wanted=None):
+        """(exception, byte offset of its line or None) for the first line at a listed position that makes the reference raise
+        while building a Record — first in file order when the result carries line offsets — or (None, None).  wanted: a mask
+        over the site set's slots, the positions THIS file is asked about (a batch shares one set between files with different
+        exclude lists; the reference builds no Record at a position that is on neither of a sample's lists)."""
+        if res.counts is not None:
+            codes = res.counts["status"]
+            is_bad = codes > L.ST_OK
+        else:
+            codes = res.filters & 0x7F
+            is_bad = (res.filters & 0x80) != 0
+        if wanted is not None:
+            is_bad = is_bad & np.asarray(wanted, dtype=bool)
+        bad = np.nonzero(is_bad)[0]
+        if not len(bad):
+            return None, None
+        k, off = int(bad[0]), None
+        if res.line_offsets is not None and len(res.line_offsets) >= len(codes):
+            lo = np.asarray(res.line_offsets)[bad]
+            j = int(np.argmin(lo))
+            k, off = int(bad[j]), int(lo[j]) - 1
+        what, exc = {L.ST_SHORT_LINE: ("line has fewer than 4 fields", IndexError),
+                     L.ST_BAD_DEPTH: ("depth field is not an unsigned decimal integer", ValueError),
+                     L.ST_NO_QUALS: ("depth > 0 but no quality field", IndexError),
+                     L.ST_MULTI_REF: ("unsupported: reference-base field longer than %d bytes" % L.SPILL_REF, None)
+                     }.get(int(codes[k]), ("malformed line", ValueError))
+        return PileupFormatError("pileup line for site #%d: %s" % (k, what), exc), off
 
     @staticmethod
     def raise_site_status(res):
         """Per-line failures that make the reference raise while building a Record."""
-        if res.counts is not None:
-            bad = np.nonzero(res.counts["status"] > L.ST_OK)[0]
-            code = int(res.counts["status"][bad[0]]) if len(bad) else 0
-        else:
-            bad = np.nonzero(res.filters & 0x80)[0]
-            code = int(res.filters[bad[0]] & 0x7F) if len(bad) else 0
-        if len(bad):
-            what, exc = {L.ST_SHORT_LINE: ("line has fewer than 4 fields", IndexError),
-                         L.ST_BAD_DEPTH: ("depth field is not an unsigned decimal integer", ValueError),
-                         L.ST_NO_QUALS: ("depth > 0 but no quality field", IndexError),
-                         L.ST_MULTI_REF: ("unsupported: reference-base field longer than %d bytes" % L.SPILL_REF, None)
-                         }.get(code, ("malformed line", ValueError))
-            raise PileupFormatError("pileup line for site #%d: %s" % (int(bad[0]), what), exc)
+        err, _ = Device.site_error(res)
+        if err is not None:
+            raise err
 
     def call_consensus_files(self, siteset, paths, params, want_counts=False, want_line_offsets=False,
                              want_depth_sum=False, chunk_bytes=0, n_readers=0, n_staging=0, n_slots=0, exclude=None):
@@ -420,16 +461,31 @@ class Device(object):
                 out.append((sites[i, :counts[i]].copy(), int(status[i, 1])))
         return out
 
-    def raise_file_status(self, path, rc, res, check=True):
-        """Raise for one file of call_consensus_files the way call_consensus does for its single pileup."""
+    def raise_file_status(self, path, rc, res, check=True, wanted=None):
+        """Raise for one file of call_consensus_files the way call_consensus does for its single pileup (wanted: see site_error)."""
         if rc == L.E_IO:
             raise PileupIOError("cannot open or read the pileup file %s" % path)
         if rc in (L.E_PILEUP, L.E_UNSUPPORTED):
-            self.raise_scan_status(res.status)
+            self.raise_first_error(res.status, res, check, wanted)
         if rc != 0:
             raise SnpGpuError(int(rc), "pileup %s" % path)
         if check:
-            self.raise_site_status(res)
+            err, _ = self.site_error(res, wanted)
+            if err is not None:
+                raise err
+
+    def check_repeated_positions(self, siteset, path, params, res):
+        """A pileup that repeats a listed position: the per-site result knows the LAST line of a position, the reference builds a
+        Record from every one of them in file order (call_consensus.py:161-176) and ends at the first it cannot build.  When the
+        file has more matching lines than positions with a line, the all-lines pass looks at each (a second read of the file;
+        a sorted pileup never takes it).  Lines count as listed by the flags of `siteset`."""
+        if res.line_offsets is None or res.n_matched <= int(np.count_nonzero(res.line_offsets)):
+            return
+        _, flags, counts = self.call_all_lines(siteset, path, params, capacity=res.n_lines, check=False)
+        bad = np.nonzero((flags != 0) & (counts["status"] > L.ST_OK))[0]
+        if len(bad):
+            err, _ = self.site_error(ConsensusResult(None, None, counts[bad[:1]], res.status))
+            raise err
 
     def line_offsets(self, siteset):
         """1 + byte offset of the pileup line used for each site by the last call_consensus on this set (0 = none)."""

@@ -545,6 +545,46 @@ def test_python_int_fields(d):
         gpu_consensus(d, b"c1\t5\tA\t-3\t...\tIII\n", keys, [], po.CallerParams())
 
 
+def test_the_first_malformed_line_in_file_order_decides_the_exception(d, tmp_path):
+    """The reference stops at the first line it cannot take, whichever kind: one whose position the reader cannot convert (any
+    line, ValueError) or one at a listed position that Record cannot be built from (IndexError / ValueError).  Found by
+    tools/fuzz_campaign.py: a lone CR inside the read bases of a listed line makes two lines, "c1 145 A 3 c" (IndexError if listed)
+    and "cc JEJ" (ValueError) — the device used to report the reader-level one whatever its place."""
+    from snp_pipeline_amd.device import PileupFormatError
+    from tests.gpu_util import gpu_consensus
+    good = b"".join(b"c1\t%d\tA\t3\t...\tIII\n" % k for k in range(1, 60))
+    split = b"c1\t60\tA\t3\tc\rcc\tJEJ\n"
+    tail = [b"c1\t%d\tA\t3\t...\tIII\n" % k for k in range(61, 90)]
+    tail = [b"".join(tail[k:]) for k in range(len(tail))]           # tail[10:] starts at position 71
+    bad_pos = b"c1\tx7\tA\t3\t...\tIII\n"
+    five = b"c1\t70\tA\t3\t...\n"
+    p = po.CallerParams()
+    cases = [(good + split + tail[0], [(b"c1", 60)], IndexError),         # listed: Record fails first
+             (good + split + tail[0], [(b"c1", 59)], ValueError),         # not listed: the reader fails on "cc JEJ"
+             (good + bad_pos + five + tail[10], [(b"c1", 70)], ValueError),   # reader-level line first
+             (good + five + bad_pos + tail[10], [(b"c1", 70)], IndexError),   # record-level line first
+             (good + five + bad_pos + tail[10], [(b"c1", 5)], ValueError)]
+    for data, keys, exc in cases:
+        with pytest.raises(exc):
+            po.call_consensus_sites(data, keys, set(), p)
+        with pytest.raises(PileupFormatError) as ei:
+            gpu_consensus(d, data, keys, [], p)
+        assert ei.value.reference_exception is exc, (keys, exc)
+        path = str(tmp_path / "f.pileup")
+        with open(path, "wb") as f:
+            f.write(data)
+        ss = d.siteset(keys, [1] * len(keys))
+        results, rcs, _ = d.call_consensus_files(ss, [path], devmod_params(p), want_counts=True, want_line_offsets=True)
+        with pytest.raises(PileupFormatError) as ei:
+            d.raise_file_status(path, int(rcs[0]), results[0])
+        assert ei.value.reference_exception is exc, ("files", keys, exc)
+
+
+def devmod_params(p):
+    from snp_pipeline_amd import device as devmod
+    return devmod.make_params(p.min_base_quality, p.min_cons_freq, p.min_cons_depth, p.min_cons_strand_depth, p.min_cons_strand_bias)
+
+
 def test_site_sets_and_stores_outliving_their_device_are_closed_with_it():
     """A site set or a pileup store points into its context; closing the device first must not leave either to be
     destroyed against freed memory later (the garbage collector runs their __del__ whenever it likes)."""

@@ -233,3 +233,48 @@ def test_vcf_all_pos_rows_for_every_line(tmp_path, monkeypatch):
         assert cli.run_command_from_line(line.replace(" --vcfAllPos", "")) == 0
         with pytest.raises(exc):
             cli.run_command_from_line(line)
+
+
+def test_batch_ignores_lines_at_positions_only_other_samples_exclude_and_sees_superseded_lines(tmp_path, monkeypatch):
+    """One site set serves the whole batch, other samples' exclude positions included.  A malformed line at a position that is on
+    neither of a sample's own lists is no business of that sample (the reference builds no Record there): the batch and the
+    per-sample command both finish.  And a listed position that comes twice with a malformed FIRST line ends the sample with the
+    reference's exception class although the per-site result only knows the last line (found while reading
+    tools/fuzz_campaign.py's first finding)."""
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    monkeypatch.setenv("errorOutputFile", str(tmp_path / "error.log"))
+    monkeypatch.setenv("StopOnSampleError", "false")
+    lines = [b"c1\t%d\tA\t4\t....\tIIII\n" % k for k in range(1, 200)]
+    a = list(lines)
+    a[49] = b"c1\t50\tA\t4\t....\n"                                 # position 50: only on sample B's exclude list
+    b = list(lines)
+    c = list(lines)
+    c.insert(20, b"c1\t120\tA\t4\t....\n")                           # position 120 (listed) comes early without qualities, and again
+    for name, body in (("A", a), ("B", b), ("C", c)):
+        sdir = _write_sample(tmp_path, name, b"".join(body))
+        with open(str(sdir / "excl.vcf"), "w") as f:
+            f.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n")
+            if name == "B":
+                f.write("c1\t50\t.\tA\tC\t.\tPASS\t.\tGT\t1/1\n")
+    with open(str(tmp_path / "snplist.txt"), "w") as f:
+        for p in (10, 120, 150):
+            f.write("c1\t%d\t1\ts\n" % p)
+    with open(str(tmp_path / "dirs.txt"), "w") as f:
+        f.write("".join("%s\n" % (tmp_path / n) for n in "ABC"))
+    common = "-v 0 -f -l %s/snplist.txt -e excl.vcf" % tmp_path
+    # (sample C fails; with StopOnSampleError=false that is a logged sample error and the batch goes on)
+    assert cli.run_command_from_line("call_consensus_batch %s -o batch.fasta %s/dirs.txt" % (common, tmp_path)) == 0
+    assert not (tmp_path / "C" / "batch.fasta").exists()
+    log = (tmp_path / "error.log").read_text()
+    assert "sample C" in log and "IndexError" in log and "sample A" not in log and "sample B" not in log
+    for name in "AB":
+        sdir = tmp_path / name
+        assert cli.run_command_from_line("call_consensus -v 0 -f -l %s/snplist.txt -e %s/excl.vcf -o %s/one.fasta %s/reads.all.pileup"
+                                         % (tmp_path, sdir, sdir, sdir)) == 0
+        assert (sdir / "batch.fasta").read_text() == (sdir / "one.fasta").read_text() == ">%s\nAAA\n" % name
+    sdir = tmp_path / "C"
+    with pytest.raises(IndexError):
+        cli.run_command_from_line("call_consensus -v 0 -f -l %s/snplist.txt -e %s/excl.vcf -o %s/one.fasta %s/reads.all.pileup" % (tmp_path, sdir, sdir, sdir))
+    assert po.call_consensus_sites(b"".join(a), [(b"c1", 10), (b"c1", 120), (b"c1", 150)], set(), po.CallerParams())[0] == b"AAA"
+    with pytest.raises(IndexError):
+        po.call_consensus_sites(b"".join(c), [(b"c1", 10), (b"c1", 120), (b"c1", 150)], set(), po.CallerParams())

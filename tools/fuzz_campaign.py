@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Development helper: a timed differential campaign of the device paths against the oracle on FRESH seeds (the -m gpu tests use
+fixed ones).  Usage: python tools/fuzz_campaign.py [seconds] [first seed]   -> one line per kind with the number of cases that
+agreed; the first disagreement is written to gpurun_out/fuzz/ (input bytes + what differed) and ends the run with exit code 1.
+
+Kinds: fuzz.fuzz_line files (adversarial read-base columns, odd separators) with three caller parameter sets; synthetic pileups of
+random shape (depth 2-300, 1-3 contigs with names of 1-50 bytes, CR LF / mixed / VT FF line ends, repeated positions) through the
+file-level scan + call; site calling (fuzz.varscan_pileup / varscan_adversarial) with two option sets against the VarScan
+restatement."""
+import os
+import random
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time()) % 1000000
+    import tempfile
+    from oracle import fuzz
+    from oracle import pileup_oracle as po
+    from oracle import varscan_oracle as vo
+    from snp_pipeline_amd import varscan
+    from tests.gpu_util import check_against_oracle, get_device, gpu_consensus
+    d = get_device()
+    out_dir = os.path.join(ROOT, "gpurun_out", "fuzz")
+    tmp = tempfile.mkdtemp(prefix="fuzz_")
+    counts = {"lines": 0, "shapes": 0, "sites": 0, "mutants": 0, "mutants_raising": 0, "mutants_refused": 0}
+    from snp_pipeline_amd.device import PileupFormatError
+    param_sets = (po.CallerParams(), po.CallerParams(15, 0.9, 5, 2, 0.1), po.CallerParams(30, 0.75, 2, 1, 0.25), po.CallerParams(0, 0.6, 3, 0, 0.0))
+    vs_cases = (("--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5", dict(vo.PIPELINE_DEFAULTS)),
+                ("--min-avg-qual 0 --min-var-freq 0.05 --min-reads2 1 --min-coverage 1 --strand-filter 0",
+                 dict(min_avg_qual=0, min_var_freq=0.05, min_reads2=1, min_coverage=1, strand_filter=0)))
+
+    def fail(kind, seed, data, err):
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "%s_%d.pileup" % (kind, seed)), "wb") as f:
+            f.write(data)
+        with open(os.path.join(out_dir, "%s_%d.txt" % (kind, seed)), "w") as f:
+            f.write(err)
+        print("DISAGREEMENT kind=%s seed=%d (%d bytes): %s" % (kind, seed, len(data), err.splitlines()[-1] if err else ""))
+        print("agreed before that:", counts)
+        sys.exit(1)
+
+    t_end = time.time() + seconds
+    seed = seed0
+    while time.time() < t_end:
+        seed += 1
+        rng = random.Random(seed)
+        kind = ("lines", "shapes", "sites", "mutants")[seed % 4]
+        data = b""
+        try:
+            if kind == "lines":
+                lines, keys, pos = [], [], 0
+                chrom = rng.choice(["chrF", "c", "a_rather_long_contig_name|with|bars.1", "x" * rng.randint(1, 44)])
+                n = rng.choice([40, 400, 1500])
+                while len(lines) < n:
+                    ln = fuzz.fuzz_line(rng, chrom=chrom)
+                    f = po.split_fields(ln.encode())
+                    try:
+                        po.parse_record(f, 0)
+                    except (IndexError, ValueError):
+                        continue
+                    pos += rng.choice([1, 1, 1, 2, 7, 1000])
+                    f[1] = str(pos).encode()
+                    lines.append(b"\t".join(f))
+                    keys.append((f[0], pos))
+                data = b"\n".join(lines) + (b"\n" if rng.random() < 0.8 else b"")
+                step = rng.choice([1, 2, 9])
+                check_against_oracle(d, data, keys[::step] if step > 1 else keys, keys[::13], rng.choice(param_sets))
+            elif kind == "shapes":
+                contigs = tuple(rng.choice(["c", "ctg%d" % rng.randint(1, 99), "NODE_%d_length_%d_cov_1.5" % (rng.randint(1, 999), rng.randint(100, 99999)),
+                                            "n" * rng.randint(17, 50)]) + ("_%d" % k) for k in range(rng.randint(1, 3)))
+                depth = rng.choice([2, 8, 15, 30, 30, 100, 300])
+                glen = rng.choice([g for g in (300, 2000, 9000, 30000) if g * depth * len(contigs) <= 600000])
+                data, _, sites = fuzz.synth_pileup(seed, genome_len=glen, contigs=contigs, mean_depth=depth, n_sites=rng.choice([5, 60, 250]))
+                variant = rng.choice([None, None, "crlf", "mixed", "vt_ff", "repeats"])
+                if variant:
+                    data = fuzz.with_line_ends(data, variant, seed)
+                keys = sorted(sites)
+                p = rng.choice(param_sets)
+                want, _ = po.call_consensus_sites(data, keys, set(keys[::11]), p)
+                for want_counts in (True, False):
+                    got, _, _ = gpu_consensus(d, data, keys, keys[::11], p, want_counts=want_counts)
+                    assert got == want, "consensus differs (want_counts=%s, line ends %s)" % (want_counts, variant)
+            elif kind == "mutants":
+                # a well-formed pileup with a few ASCII bytes changed, inserted or removed: the same consensus, or the same exception
+                # class as the reference's text-mode reader / Record raises first (pileup.py:224-237, 425-426)
+                base, _, sites = fuzz.synth_pileup(seed, genome_len=rng.choice([200, 1500]), mean_depth=rng.choice([6, 30]), n_sites=rng.choice([20, 150]),
+                                                   contigs=(rng.choice(["c1", "contig_with_a_longer_name_%d" % seed]),))
+                buf = bytearray(base)
+                for _ in range(rng.choice([1, 1, 2, 4])):
+                    at = rng.randrange(len(buf))
+                    op = rng.random()
+                    ch = rng.choice(b"\t\t\n\r \x0b\x0c0123456789-+_*ACGTacgt.,^$<>!I~xX")
+                    if op < 0.4:
+                        buf[at] = ch
+                    elif op < 0.7:
+                        buf.insert(at, ch)
+                    elif op < 0.9:
+                        del buf[at]
+                    else:                                            # a field boundary: remove what is left of the line
+                        end = buf.find(b"\n", at)
+                        del buf[at:end if end >= 0 else len(buf)]
+                data = bytes(buf)
+                keys = sorted(sites)
+                p = rng.choice(param_sets)
+                try:
+                    want = po.call_consensus_sites(data, keys, set(keys[::11]), p)[0]
+                except (ValueError, IndexError) as e:
+                    want = type(e)
+                try:
+                    got = gpu_consensus(d, data, keys, keys[::11], p)[0]
+                except PileupFormatError as e:
+                    got = e.reference_exception
+                    if got is None:                                  # an input this build refuses by name: counted, not compared
+                        counts["mutants_refused"] += 1
+                        continue
+                assert got == want, "device %r, oracle %r" % (got, want)
+                counts["mutants_raising"] += isinstance(want, type)
+            else:
+                data = fuzz.varscan_adversarial(seed, rng.choice([300, 2000])) if seed % 2 else \
+                    fuzz.varscan_pileup(seed, rng.choice([200, 3000, 12000]), eol=rng.choice([b"\n", b"\n", b"\r\n"]),
+                                        depths=rng.choice([(0, 0, 3, 7, 8, 9, 12, 20, 30, 30, 45, 80), (150, 200, 120, 0), (8, 8, 9, 30), (1500, 30, 0)]))
+                path, out = os.path.join(tmp, "p.pileup"), os.path.join(tmp, "p.vcf")
+                with open(path, "wb") as f:
+                    f.write(data)
+                for extra, kw in vs_cases:
+                    varscan.mpileup2snp(d, path, out, varscan.Options(extra))
+                    assert open(out, encoding="latin-1").read() == vo.mpileup2snp(data, vo.Params(**kw)), "var.flt.vcf differs for %r" % extra
+            counts[kind] += 1
+        except SystemExit:
+            raise
+        except Exception:                                        # noqa: B902 — any disagreement or refusal is the finding
+            fail(kind, seed, data, traceback.format_exc())
+    print("fuzz campaign: %.0f s, seeds %d..%d, all agreed: %r" % (seconds, seed0 + 1, seed, counts))
+
+
+if __name__ == "__main__":
+    main()
