@@ -27,6 +27,7 @@ PARITY — what is pinned and what is not:
 """
 
 import math
+import re
 from decimal import ROUND_HALF_EVEN, Decimal
 
 VCF_HEADER = (
@@ -252,9 +253,7 @@ def mpileup2snp(data, prm):
     """Whole pileup (bytes) -> the text VarScan prints.  Lines are split on TAB (String.split("\\t")); a line needs six
     non-empty leading columns."""
     out = [VCF_HEADER % {"q": prm.min_avg_qual}]
-    for line in data.split(b"\n"):
-        if line.endswith(b"\r"):
-            line = line[:-1]
+    for line in re.split(b"\r\n|\r|\n", data):                 # BufferedReader.readLine(): a line ends at LF, CR or CR LF
         if not line:
             continue
         f = line.split(b"\t")

@@ -49,8 +49,13 @@ __device__ void varscan_line(const Rd B, Off p0, Off end, uint64_t zero, const s
     for (Off p = p0; p < end && nt < 6; ++p)
         if (B(p) == 9u) tab[nt++] = p;
     if (nt == 5) tab[nt++] = end;
-    bool ok = nt == 6 && tab[0] > p0 && tab[1] > tab[0] + 1 && tab[2] == tab[1] + 2 && tab[3] > tab[2] + 1 && tab[4] > tab[3] + 1 &&
-              tab[5] > tab[4] + 1;                                                     // six non-empty columns, a one-byte reference
+    // String.split drops TRAILING empty strings only: more than five columns are left when some byte after the fifth TAB is not a
+    // TAB; chrom, position, reference (one byte here) and depth must not be empty, the read bases and the qualities may be
+    bool ok = nt == 6 && tab[0] > p0 && tab[1] > tab[0] + 1 && tab[2] == tab[1] + 2 && tab[3] > tab[2] + 1;
+    if (ok && tab[5] == tab[4] + 1) {                                                  // an empty quality column: is there anything behind it?
+        ok = false;
+        for (Off p = tab[5] + 1; p < end && !ok; ++p) ok = B(p) != 9u;
+    }
     uint32_t depth = 0;
     if (ok) {
         if (tab[3] - tab[2] - 1 > 9) ok = false;
@@ -290,7 +295,11 @@ __device__ __forceinline__ bool varscan_parse_lds(const uint32_t *lds32, uint32_
     if (nt == 5) { P1 |= (uint64_t)end << 16; ++nt; }
     const uint32_t t0 = (uint32_t)P0 & 0xFFFFu, t1 = (uint32_t)(P0 >> 16) & 0xFFFFu, t2 = (uint32_t)(P0 >> 32) & 0xFFFFu, t3 = (uint32_t)(P0 >> 48),
                    t4 = (uint32_t)P1 & 0xFFFFu, t5 = (uint32_t)(P1 >> 16) & 0xFFFFu;
-    bool ok = nt == 6 && t0 > p0 && t1 > t0 + 1 && t2 == t1 + 2 && t3 > t2 + 1 && t4 > t3 + 1 && t5 > t4 + 1;
+    bool ok = nt == 6 && t0 > p0 && t1 > t0 + 1 && t2 == t1 + 2 && t3 > t2 + 1;     // (read bases and qualities may be empty: varscan_line)
+    if (ok && t5 == t4 + 1) {
+        ok = false;
+        for (uint32_t p = t5 + 1; p < end && !ok; ++p) ok = byte_at(p) != 9u;
+    }
     uint32_t depth = 0;
     if (ok) {
         if (t3 - t2 - 1 > 9) ok = false;

@@ -282,3 +282,58 @@ def test_call_sites_batch_equals_per_sample_cli(tmp_path, monkeypatch):
     stamp = os.stat(os.path.join(dirs[0], "var.flt.vcf")).st_mtime_ns
     cli.run_command_from_args(cli.parse_command_line("call_sites -v 0 %s %s" % (ref, dirs[0])))
     assert os.stat(os.path.join(dirs[0], "var.flt.vcf")).st_mtime_ns == stamp
+
+
+def test_a_lone_carriage_return_ends_a_line_as_for_javas_readline(d, tmp_path):
+    """BufferedReader.readLine() ends a line at LF, CR or CR LF.  A CR in the middle of the read bases therefore makes two lines,
+    both with too few columns: VarScan stops with "Invalid format for pileup", the device pass and the restatement refuse the file
+    alike; a CR between two complete lines is a line end like any other (found by tools/fuzz_campaign.py: the restatement split
+    at LF only)."""
+    from snp_pipeline_amd import varscan
+    from snp_pipeline_amd.device import PileupFormatError
+    data = fuzz.varscan_pileup(77, 400)
+    lines = data.split(b"\n")
+    k = next(i for i, ln in enumerate(lines) if ln.count(b"\t") == 5 and len(ln.split(b"\t")[4]) > 12)
+    f = lines[k].split(b"\t")
+    f[4] = f[4][:6] + b"\r" + f[4][6:]
+    broken = b"\n".join(lines[:k] + [b"\t".join(f)] + lines[k + 1:])
+    path = str(tmp_path / "p.pileup")
+    with open(path, "wb") as fh:
+        fh.write(broken)
+    with pytest.raises(ValueError):
+        vo.mpileup2snp(broken, vo.Params(**vo.PIPELINE_DEFAULTS))
+    with pytest.raises(PileupFormatError):
+        varscan.mpileup2snp(d, path, str(tmp_path / "p.vcf"), varscan.Options(CASES[0][0]))
+    mixed = b"".join(ln + (b"\r" if i % 3 == 0 else b"\r\n" if i % 3 == 1 else b"\n") for i, ln in enumerate(lines) if ln)
+    with open(path, "wb") as fh:
+        fh.write(mixed)
+    varscan.mpileup2snp(d, path, str(tmp_path / "p.vcf"), varscan.Options(CASES[0][0]))
+    assert open(str(tmp_path / "p.vcf")).read() == vo.mpileup2snp(mixed, vo.Params(**CASES[0][1])) == vo.mpileup2snp(data, vo.Params(**CASES[0][1]))
+
+
+def test_empty_read_base_and_quality_columns_are_columns(d, tmp_path):
+    """String.split("\\t") drops TRAILING empty strings only: a line with an empty read-base column, or an empty quality column
+    followed by a seventh column, still has more than five columns and is processed (it can call nothing); an empty quality
+    column at the end of the line leaves five and is "Invalid format" (found by tools/fuzz_campaign.py: the kernels asked for six
+    non-empty columns)."""
+    from snp_pipeline_amd import varscan
+    from snp_pipeline_amd.device import PileupFormatError
+    data = fuzz.varscan_pileup(78, 300)
+    lines = [ln for ln in data.split(b"\n") if ln]
+    extra = [b"ctgA\t9001\tA\t3\t\tGGG,,,\tIIIIII", b"ctgA\t9002\tA\t12\tGGGGGGGGGGGG\t\tIIIIIIIIIIII", b"ctgA\t9003\tA\t12\t\t\tx"]
+    ok = b"\n".join(lines[:100] + extra + lines[100:]) + b"\n"
+    path = str(tmp_path / "p.pileup")
+    opts = "--min-avg-qual 0 --min-var-freq 0.05 --min-reads2 1 --min-coverage 1 --strand-filter 0"
+    kw = dict(min_avg_qual=0, min_var_freq=0.05, min_reads2=1, min_coverage=1, strand_filter=0)
+    with open(path, "wb") as fh:
+        fh.write(ok)
+    varscan.mpileup2snp(d, path, str(tmp_path / "p.vcf"), varscan.Options(opts))
+    assert open(str(tmp_path / "p.vcf")).read() == vo.mpileup2snp(ok, vo.Params(**kw))
+    for bad_line in (b"ctgA\t9004\tA\t12\tGGGGGGGGGGGG\t", b"ctgA\t9004\tA\t12\tGGGGGGGGGGGG\t\t\t", b"ctgA\t9004\tA\t12\t\t"):
+        bad = b"\n".join(lines[:100] + [bad_line] + lines[100:]) + b"\n"
+        with open(path, "wb") as fh:
+            fh.write(bad)
+        with pytest.raises(ValueError):
+            vo.mpileup2snp(bad, vo.Params(**kw))
+        with pytest.raises(PileupFormatError):
+            varscan.mpileup2snp(d, path, str(tmp_path / "p.vcf"), varscan.Options(opts))

@@ -29,7 +29,56 @@ def main():
     d = get_device()
     out_dir = os.path.join(ROOT, "gpurun_out", "fuzz")
     tmp = tempfile.mkdtemp(prefix="fuzz_")
-    counts = {"lines": 0, "shapes": 0, "sites": 0, "mutants": 0, "mutants_raising": 0, "mutants_refused": 0}
+    counts = {"lines": 0, "shapes": 0, "sites": 0, "mutants": 0, "mutants_raising": 0, "mutants_refused": 0, "site_mutants": 0, "site_mutants_raising": 0}
+    from snp_pipeline_amd import _lib as L
+    from snp_pipeline_amd import device as devmod
+
+    def mutate(rng, base, alphabet, n_ops):
+        buf = bytearray(base)
+        for _ in range(n_ops):
+            at = rng.randrange(len(buf))
+            op = rng.random()
+            ch = rng.choice(alphabet)
+            if op < 0.35:
+                buf[at] = ch
+            elif op < 0.6:
+                buf.insert(at, ch)
+            elif op < 0.75:
+                del buf[at]
+            elif op < 0.83:                                      # a field boundary: remove what is left of the line
+                end = buf.find(b"\n", at)
+                del buf[at:end if end >= 0 else len(buf)]
+            else:                                                # whole lines: one copied to another place, or two swapped, or one dropped
+                lines = bytes(buf).split(b"\n")
+                i, j = rng.randrange(len(lines)), rng.randrange(len(lines))
+                if op < 0.91:
+                    lines.insert(j, lines[i])
+                elif op < 0.96:
+                    lines[i], lines[j] = lines[j], lines[i]
+                else:
+                    del lines[i]
+                buf = bytearray(b"\n".join(lines))
+            if not buf:
+                buf = bytearray(b"\n")
+        return bytes(buf)
+
+    def consensus_through_files(data, keys, excluded, p):
+        """The per-sample command's path: streamed file, status checks in the reference's order, consensus in snplist order."""
+        path = os.path.join(tmp, "m.pileup")
+        with open(path, "wb") as f:
+            f.write(data)
+        allk = list(keys) + [k for k in excluded if k not in set(keys)]
+        flags = [(L.SITE_IN_SNPLIST if k in set(keys) else 0) | (L.SITE_EXCLUDED if k in set(excluded) else 0) for k in allk]
+        ss = d.siteset(allk, flags)
+        try:
+            prm = devmod.make_params(p.min_base_quality, p.min_cons_freq, p.min_cons_depth, p.min_cons_strand_depth, p.min_cons_strand_bias)
+            results, rcs, _ = d.call_consensus_files(ss, [path], prm, want_counts=True, want_line_offsets=True)
+            d.raise_file_status(path, int(rcs[0]), results[0])
+            d.check_repeated_positions(ss, path, prm, results[0])
+            idx = ss.index_of[:len(keys)]
+            return bytes(int(results[0].bases[i]) if i >= 0 else 0x2D for i in idx)
+        finally:
+            ss.close()
     from snp_pipeline_amd.device import PileupFormatError
     param_sets = (po.CallerParams(), po.CallerParams(15, 0.9, 5, 2, 0.1), po.CallerParams(30, 0.75, 2, 1, 0.25), po.CallerParams(0, 0.6, 3, 0, 0.0))
     vs_cases = (("--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5", dict(vo.PIPELINE_DEFAULTS)),
@@ -51,7 +100,7 @@ def main():
     while time.time() < t_end:
         seed += 1
         rng = random.Random(seed)
-        kind = ("lines", "shapes", "sites", "mutants")[seed % 4]
+        kind = ("lines", "shapes", "sites", "mutants", "site_mutants", "mutants")[seed % 6]
         data = b""
         try:
             if kind == "lines":
@@ -92,21 +141,7 @@ def main():
                 # class as the reference's text-mode reader / Record raises first (pileup.py:224-237, 425-426)
                 base, _, sites = fuzz.synth_pileup(seed, genome_len=rng.choice([200, 1500]), mean_depth=rng.choice([6, 30]), n_sites=rng.choice([20, 150]),
                                                    contigs=(rng.choice(["c1", "contig_with_a_longer_name_%d" % seed]),))
-                buf = bytearray(base)
-                for _ in range(rng.choice([1, 1, 2, 4])):
-                    at = rng.randrange(len(buf))
-                    op = rng.random()
-                    ch = rng.choice(b"\t\t\n\r \x0b\x0c0123456789-+_*ACGTacgt.,^$<>!I~xX")
-                    if op < 0.4:
-                        buf[at] = ch
-                    elif op < 0.7:
-                        buf.insert(at, ch)
-                    elif op < 0.9:
-                        del buf[at]
-                    else:                                            # a field boundary: remove what is left of the line
-                        end = buf.find(b"\n", at)
-                        del buf[at:end if end >= 0 else len(buf)]
-                data = bytes(buf)
+                data = mutate(rng, base, b"\t\t\n\r \x0b\x0c0123456789-+_*ACGTacgt.,^$<>!I~xX", rng.choice([1, 1, 2, 4]))
                 keys = sorted(sites)
                 p = rng.choice(param_sets)
                 try:
@@ -114,7 +149,7 @@ def main():
                 except (ValueError, IndexError) as e:
                     want = type(e)
                 try:
-                    got = gpu_consensus(d, data, keys, keys[::11], p)[0]
+                    got = consensus_through_files(data, keys, keys[::11], p)
                 except PileupFormatError as e:
                     got = e.reference_exception
                     if got is None:                                  # an input this build refuses by name: counted, not compared
@@ -122,6 +157,24 @@ def main():
                         continue
                 assert got == want, "device %r, oracle %r" % (got, want)
                 counts["mutants_raising"] += isinstance(want, type)
+            elif kind == "site_mutants":
+                base = fuzz.varscan_pileup(seed, rng.choice([60, 600]), eol=rng.choice([b"\n", b"\n", b"\r\n"]))
+                data = mutate(rng, base, b"\t\t\n\r 0123456789-+*ACGTNacgtn.,^$!I5~", rng.choice([1, 1, 2, 3]))
+                path, out = os.path.join(tmp, "p.pileup"), os.path.join(tmp, "p.vcf")
+                with open(path, "wb") as f:
+                    f.write(data)
+                extra, kw = vs_cases[seed % 2]
+                try:
+                    want = vo.mpileup2snp(data, vo.Params(**kw))
+                except ValueError:
+                    want = ValueError
+                try:
+                    varscan.mpileup2snp(d, path, out, varscan.Options(extra))
+                    got = open(out, encoding="latin-1").read()
+                except PileupFormatError:
+                    got = ValueError
+                assert got == want, "site calling: device %r, restatement %r" % (str(got)[-200:], str(want)[-200:])
+                counts["site_mutants_raising"] += want is ValueError
             else:
                 data = fuzz.varscan_adversarial(seed, rng.choice([300, 2000])) if seed % 2 else \
                     fuzz.varscan_pileup(seed, rng.choice([200, 3000, 12000]), eol=rng.choice([b"\n", b"\n", b"\r\n"]),
