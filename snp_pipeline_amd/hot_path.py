@@ -25,6 +25,7 @@ environment variable of the same name), parsed by the step's own argument parser
 """
 from __future__ import print_function
 
+import argparse
 import concurrent.futures
 import ctypes
 import os
@@ -145,8 +146,8 @@ def hot_path_batch(args):
 
     fr_args = _step_args("filter_regions", ["-n", "var.flt.vcf", dirs_file, ref_path], env("FilterRegions_ExtraParams", args.filterRegionsExtraParams))
     ms_args = _step_args("merge_sites", [dirs_file, dirs_file + ".OrigVCF.filtered"], env("MergeSites_ExtraParams", args.mergeSitesExtraParams))
-    cc_args = _step_args("call_consensus", ["--vcfRefName", os.path.basename(ref_path), "--vcfFileName", "consensus.vcf", "x.pileup"],
-                         env("CallConsensus_ExtraParams", args.callConsensusExtraParams))
+    cc_extra = env("CallConsensus_ExtraParams", args.callConsensusExtraParams)
+    cc_args = _step_args("call_consensus", ["--vcfRefName", os.path.basename(ref_path), "--vcfFileName", "consensus.vcf", "x.pileup"], cc_extra)
     vs_opts = varscan.Options(env("VarscanMpileup2snp_ExtraParams", args.varscanExtraParams))
     want_vcf = not args.noConsensusVcf
     if cc_args.vcfAllPos and want_vcf:
@@ -401,11 +402,16 @@ def hot_path_batch(args):
         t0 = time.perf_counter()
         prm = devmod.make_params(cc_args.minBaseQual, cc_args.minConsFreq, cc_args.minConsDpth, cc_args.minConsStrdDpth, cc_args.minConsStrdBias)
         # the site set: snplist.txt, plus removed positions of this rank's samples that are not in it (a sample merge_sites
-        # excluded for --maxsnps is still called, run.py:704-718, and its exclude list is parsed: call_consensus.py:147-151)
+        # excluded for --maxsnps is still called, run.py:704-718, and its exclude list is parsed: call_consensus.py:147-151),
+        # plus what snplist_preserved.txt has and snplist.txt has not: with --maxsnps a sample can be out of the first list for its
+        # var.flt.vcf and in the second for its shorter var.flt_preserved.vcf (found by tools/fuzz_jobs.py)
         own_removed = {s.index: (all_keys[rec_off[s.index]:rec_off[s.index + 1]][s.removed] if (s.ok and s.removed is not None) else np.zeros(0, np.int64))
                        for s in mine}
         extra = np.setdiff1d(np.concatenate(list(own_removed.values())) if own_removed else np.zeros(0, np.int64), list1)
-        set_keys = np.union1d(list1, extra) if len(extra) else list1
+        set_keys = list1
+        for more in (extra, np.setdiff1d(list2, list1)):
+            if len(more):
+                set_keys = np.union1d(set_keys, more)
         S = len(set_keys)
         cols1 = np.searchsorted(set_keys, list1).astype(np.uint32)
         cols2 = np.searchsorted(set_keys, list2).astype(np.uint32)
@@ -417,7 +423,7 @@ def hot_path_batch(args):
         col_of2[cols2] = np.arange(len(cols2), dtype=np.int32)
         ss = devmod.SiteSet.from_arrays(dev, [c.encode("utf-8") for c in contigs], set_keys.astype(np.uint64), in1 * np.uint8(L.SITE_IN_SNPLIST))
         lap("3-   of which: site set", t0)
-        identity1 = len(extra) == 0
+        identity1 = len(set_keys) == len(list1)
         S1, S2 = len(list1), len(list2)
         # collect_metrics by-products (call_consensus --amdMetricsRefFasta, given through CallConsensus_ExtraParams): the depth
         # column is summed by the same scan, the gaps are counted in the rows that are written anyway
@@ -474,6 +480,7 @@ def hot_path_batch(args):
         d_counts = torch.empty((g_alloc, max(S, 1), 128), dtype=torch.uint8, device="cuda") if want_vcf else None
         vcf_date = None
         pending_write = None
+        vcf_again = []                                           # samples whose pileup repeats a listed position (see the status checks)
 
         def write_group(part, hs, g0, spill=None):
             """FASTA + VCF files of one group, both flows (host threads inside the library); returns the samples that failed."""
@@ -626,10 +633,22 @@ def hot_path_batch(args):
                 if S and chk[k, 0]:
                     s.ok, s.error = False, "Error: call_consensus failed for sample %s: malformed pileup line at a listed position" % s.name
                     continue
-                if S and int(st_np[k, 2]) > int(chk[k, 1]) and want_vcf:
-                    s.ok, s.error = False, ("Error: call_consensus failed for sample %s: its pileup repeats a position; run call_consensus "
-                                            "for this sample" % s.name)
-                    continue
+                if S and int(st_np[k, 2]) > int(chk[k, 1]):
+                    # The pileup repeats a listed position.  The last line of a position is the one that counts for the consensus
+                    # (call_consensus.py:171-176) and that is what the device returned; but the reference builds a Record from
+                    # every such line — it ends at the first it cannot build — and writes a consensus.vcf row for each.  The
+                    # all-lines pass looks at them now; the VCF files of such a sample are written by the per-sample command
+                    # once the job's own files are done (a sorted pileup never comes here).
+                    try:
+                        _, line_flags, line_counts = dev.call_all_lines(ss, s.pileup, prm, check=False)
+                        err, _ = devmod.Device.site_error(devmod.ConsensusResult(None, None, line_counts[line_flags != 0], st_np[k]))
+                    except (devmod.PileupFormatError, devmod.PileupIOError) as e:
+                        err = e
+                    if err is not None:
+                        s.ok, s.error = False, "Error: call_consensus failed for sample %s: %s" % (s.name, err)
+                        continue
+                    if want_vcf:
+                        vcf_again.append(s)
                 row_ok[g0 + k] = True
             lap("3c   of which: status checks", t_g)
             t_g = time.perf_counter()
@@ -724,6 +743,26 @@ def hot_path_batch(args):
                                                        outputs["refsnp" if flow == 1 else "refsnp_p"], match_dict=ref_seqs[0])
         comm.barrier()
         lap("4 matrices + distances", t0)
+        # ---- samples whose pileup repeats a listed position: consensus.vcf rows for EVERY matching line, by the per-sample command
+        #      (call_consensus.py:178-180); its consensus.fasta is the same bytes the job wrote ----------------------------------------
+        if vcf_again:
+            from . import call_consensus as cc_step
+            quiet = argparse.Namespace(verbose=0)
+            utils.set_logging_verbosity(quiet)
+            try:
+                for s in vcf_again:
+                    if not s.ok:
+                        continue
+                    try:
+                        for snplist, suffix, more in ((outputs["snplist"], "", []),
+                                                      (outputs["snplist_p"], "_preserved", ["-e", os.path.join(s.dir, "var.flt_removed.vcf")])):
+                            cc_step.call_consensus(_step_args("call_consensus", ["-f", "-l", snplist, "-o", os.path.join(s.dir, "consensus%s.fasta" % suffix),
+                                                                                 "--vcfRefName", os.path.basename(ref_path), "--vcfFileName", "consensus%s.vcf" % suffix]
+                                                              + more + [s.pileup], cc_extra))
+                    except (Exception, SystemExit) as e:         # noqa: B902 — reported as this sample's error below
+                        s.ok, s.error = False, "Error: call_consensus failed for sample %s: %s: %s" % (s.name, type(e).__name__, e)
+            finally:
+                utils.set_logging_verbosity(args)
         st = store.stats()
         stats = {"h2d_bytes": int(st.h2d_bytes) + h2d_extra[0], "file_bytes": int(st.file_bytes), "resident_files": int(st.n_resident),
                  "files": int(st.n_files), "seconds": time.perf_counter() - t_start,

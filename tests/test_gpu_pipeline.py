@@ -412,3 +412,34 @@ def test_hot_path_batch_records_the_collect_metrics_by_products(tmp_path, monkey
     _compare(_snapshot(work, dirs, remove=False), want)
     for sdir in dirs:
         assert open(os.path.join(sdir, "metrics")).read() == want_metrics[sdir], sdir
+
+
+@pytest.mark.parametrize("tree, line_ends, filter_extra, merge_extra, consensus_extra, varscan_extra", [
+    # --maxsnps takes samples out of snplist.txt for their var.flt.vcf and leaves them in snplist_preserved.txt for their shorter
+    # var.flt_preserved.vcf: the second list is no subset of the first
+    (dict(seed=681771, n_samples=3, genome_len=12000), {"iso01": "crlf"}, "--edge_length 500 --window_size 500 --max_snp 2 --mode all", "--maxsnps 10",
+     "-q 10 -c 0.51 -D 1 -d 0 -b 0.0", VARSCAN_EXTRA),
+    # a pileup that repeats positions: a consensus.vcf row for every matching line (the job hands that sample's VCF files to the
+    # per-sample command)
+    (dict(seed=681455, n_samples=2, genome_len=6000), {"iso01": "repeats"}, "--edge_length 1 --window_size 1000 125 15 --max_snp 3 2 1 --mode each", "",
+     CONSENSUS_EXTRA, "--min-var-freq 0.5 --min-reads2 3 --p-value 1e-6 --strand-filter 0"),
+])
+def test_hot_path_batch_on_jobs_the_fuzz_campaign_found(tmp_path, monkeypatch, tree, line_ends, filter_extra, merge_extra, consensus_extra, varscan_extra):
+    """Two jobs tools/fuzz_jobs.py stopped at: every output file of the one job equals the separate subcommands'."""
+    work = tmp_path
+    ref_path, dirs, dirs_file, piles = _outbreak_tree(work, **tree)
+    for i, sdir in enumerate(dirs):
+        variant = line_ends.get(os.path.basename(sdir))
+        if variant:
+            with open(os.path.join(sdir, "reads.all.pileup"), "wb") as f:
+                f.write(fuzz.with_line_ends(piles[i], variant, tree["seed"] + i))
+    monkeypatch.setenv("VarscanMpileup2snp_ExtraParams", varscan_extra)
+    monkeypatch.chdir(work)
+    _separate_steps(work, ref_path, dirs, dirs_file, filter_extra, merge_extra, consensus_extra)
+    want = _snapshot(work, dirs)
+    if merge_extra:
+        first, second = set(want["snplist.txt"].splitlines()), set(ln.split(b"\t")[0] + b"\t" + ln.split(b"\t")[1] for ln in want["snplist_preserved.txt"].splitlines())
+        assert second - set(ln.split(b"\t")[0] + b"\t" + ln.split(b"\t")[1] for ln in first)       # positions only the preserved list has
+    _run("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --mergeSitesExtraParams=%s --callConsensusExtraParams=%s"
+         % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), merge_extra.replace(" ", "\x00"), consensus_extra.replace(" ", "\x00")))
+    _compare(_snapshot(work, dirs, remove=False), want)

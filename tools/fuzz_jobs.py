@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Development helper: a timed campaign of whole jobs on FRESH seeds — a small synthetic outbreak with random shape and random
+step options through the separate subcommands (what run.py starts) and through ONE hot_path_batch job; every output file must
+be the same bytes.  Usage: python tools/fuzz_jobs.py [seconds] [first seed]; the first disagreement is kept under
+gpurun_out/fuzz_jobs/ (the options and the names of the files that differ) and ends the run with exit code 1."""
+import os
+import pathlib
+import random
+import shutil
+import sys
+import tempfile
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time()) % 1000000
+    sys.argv = ["cfsan_snp_pipeline", "fuzz_jobs"]
+    from oracle import fuzz
+    from tests import test_gpu_pipeline as tp
+    out_dir = os.path.join(ROOT, "gpurun_out", "fuzz_jobs")
+    home = os.getcwd()
+    done, stopped, seed = 0, 0, seed0
+    t_end = time.time() + seconds
+    while time.time() < t_end:
+        seed += 1
+        rng = random.Random(seed)
+        work = pathlib.Path(tempfile.mkdtemp(prefix="job_%d_" % seed))
+        what = {}
+        try:
+            n = rng.choice([1, 2, 3, 5, 7])
+            what["tree"] = dict(seed=seed, n_samples=n, genome_len=rng.choice([2500, 6000, 12000]))
+            ref_path, dirs, dirs_file, piles = tp._outbreak_tree(work, **what["tree"])
+            # some samples with other line ends, one now and then with positions that come twice
+            for i, sdir in enumerate(dirs):
+                variant = rng.choice([None, None, None, "crlf", "mixed", "repeats"])
+                if variant:
+                    with open(os.path.join(sdir, "reads.all.pileup"), "wb") as f:
+                        f.write(fuzz.with_line_ends(piles[i], variant, seed + i))
+                    what.setdefault("line_ends", {})[os.path.basename(sdir)] = variant
+            mode = rng.choice(["all", "each"])
+            rules = rng.choice([("1000 125 15", "3 2 1"), ("500", "2"), ("60 2000", "1 6")])
+            filter_extra = "--edge_length %d --window_size %s --max_snp %s --mode %s" % (rng.choice([1, 100, 500, 5000]), rules[0], rules[1], mode)
+            if n > 1 and rng.random() < 0.3:
+                og = work / "outgroup.txt"
+                og.write_text("".join(os.path.basename(d) + "\n" for d in rng.sample(dirs, rng.choice([1, 1, 2][:n - 1] or [1]))))
+                filter_extra += " --out_group %s" % og
+            merge_extra = rng.choice(["", "", "--maxsnps %d" % rng.choice([0, 10, 25, 40, 1000])])
+            consensus_extra = rng.choice([tp.CONSENSUS_EXTRA, "-q 0 -c 0.6 -D 3 -d 0 -b 0", "-q 30 -c 0.75 -D 2 -d 1 -b 0.25 --vcfFailedSnpGt 1",
+                                          "-q 15 -c 0.9 -D 5 -d 2 -b 0.1 --vcfPreserveRefCase", "-q 10 -c 0.51 -D 1 -d 0 -b 0.0"])         # (--vcfAllPos is the per-sample command's: the one job says so and stops)
+            varscan_extra = rng.choice([tp.VARSCAN_EXTRA, "--min-avg-qual 0 --min-var-freq 0.3 --min-reads2 2", "--min-var-freq 0.5 --min-reads2 3 --p-value 1e-6 --strand-filter 0"])
+            what.update(filter=filter_extra, merge=merge_extra, consensus=consensus_extra, varscan=varscan_extra)
+            os.environ["VarscanMpileup2snp_ExtraParams"] = varscan_extra
+            os.environ.pop("errorOutputFile", None)
+            os.chdir(str(work))
+            job = ("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --mergeSitesExtraParams=%s --callConsensusExtraParams=%s"
+                   % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), merge_extra.replace(" ", "\x00"), consensus_extra.replace(" ", "\x00")))
+            try:
+                tp._separate_steps(work, ref_path, dirs, dirs_file, filter_extra, merge_extra, consensus_extra)
+            except SystemExit as stop:                           # e.g. --maxsnps took every sample out: snp_matrix ends the run (exit 100)
+                try:
+                    tp._run(job)
+                except SystemExit as stop2:
+                    assert stop2.code == stop.code, "the steps stopped with %r, the one job with %r" % (stop.code, stop2.code)
+                    stopped += 1
+                    continue
+                raise AssertionError("the separate steps stopped with exit code %r, the one job went through" % (stop.code,))
+            want = tp._snapshot(work, dirs)
+            tp._run(job)
+            got = tp._snapshot(work, dirs, remove=False)
+            differ = [k for k in sorted(want) if got.get(k) != want[k]] + [k for k in got if k not in want]
+            if differ:                                           # keep both versions of the first few, and the small top-level inputs
+                keep = os.path.join(out_dir, "job_%d" % seed)
+                os.makedirs(keep, exist_ok=True)
+                for k in differ[:4] + [x for x in ("snplist.txt", "snplist_preserved.txt", "sampleDirectories.txt.OrigVCF.filtered", "sampleDirectories.txt.PresVCF.filtered") if x in want]:
+                    for tag, src in (("steps", want), ("job", got)):
+                        with open(os.path.join(keep, k.replace("/", "_") + "." + tag), "wb") as f:
+                            f.write(src.get(k, b""))
+                for sdir in dirs:
+                    shutil.copy(os.path.join(sdir, "var.flt_removed.vcf"), os.path.join(keep, os.path.basename(sdir) + "_var.flt_removed.vcf"))
+            assert not differ, "files that differ: %r" % differ
+            done += 1
+        except BaseException:                                    # noqa: B902 — SystemExit of a step included: that is a finding too
+            os.makedirs(out_dir, exist_ok=True)
+            with open(os.path.join(out_dir, "job_%d.txt" % seed), "w") as f:
+                f.write(repr(what) + "\n" + traceback.format_exc())
+            print("DISAGREEMENT seed=%d %r\n%s" % (seed, what, traceback.format_exc().splitlines()[-1]))
+            print("jobs that agreed before that: %d" % done)
+            sys.exit(1)
+        finally:
+            os.chdir(home)
+            shutil.rmtree(str(work), ignore_errors=True)
+    print("fuzz jobs: %.0f s, seeds %d..%d, %d jobs with every output file of the one job equal to the separate steps', %d that both ways stopped alike"
+          % (seconds, seed0 + 1, seed, done, stopped))
+
+
+if __name__ == "__main__":
+    main()
