@@ -53,12 +53,18 @@ def main():
             consensus_extra = rng.choice([tp.CONSENSUS_EXTRA, "-q 0 -c 0.6 -D 3 -d 0 -b 0", "-q 30 -c 0.75 -D 2 -d 1 -b 0.25 --vcfFailedSnpGt 1",
                                           "-q 15 -c 0.9 -D 5 -d 2 -b 0.1 --vcfPreserveRefCase", "-q 10 -c 0.51 -D 1 -d 0 -b 0.0"])         # (--vcfAllPos is the per-sample command's: the one job says so and stops)
             varscan_extra = rng.choice([tp.VARSCAN_EXTRA, "--min-avg-qual 0 --min-var-freq 0.3 --min-reads2 2", "--min-var-freq 0.5 --min-reads2 3 --p-value 1e-6 --strand-filter 0"])
-            what.update(filter=filter_extra, merge=merge_extra, consensus=consensus_extra, varscan=varscan_extra)
+            if rng.random() < 0.25:                              # collect_metrics by-products: the samples' metrics files are compared too
+                consensus_extra += " --amdMetricsRefFasta %s" % ref_path
+            resident = int(rng.choice([1.2, 2.5]) * max(len(p) for p in piles)) if (n > 2 and rng.random() < 0.25) else 0   # part of the pileups streamed twice
+            what.update(filter=filter_extra, merge=merge_extra, consensus=consensus_extra, varscan=varscan_extra, resident=resident)
+
+            def metrics():
+                return {os.path.basename(d) + "/metrics": open(os.path.join(d, "metrics"), "rb").read() for d in dirs if os.path.exists(os.path.join(d, "metrics"))}
             os.environ["VarscanMpileup2snp_ExtraParams"] = varscan_extra
             os.environ.pop("errorOutputFile", None)
             os.chdir(str(work))
             job = ("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --mergeSitesExtraParams=%s --callConsensusExtraParams=%s"
-                   % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), merge_extra.replace(" ", "\x00"), consensus_extra.replace(" ", "\x00")))
+                   % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), merge_extra.replace(" ", "\x00"), consensus_extra.replace(" ", "\x00"))) + (" --residentBytes %d" % resident if resident else "")
             try:
                 tp._separate_steps(work, ref_path, dirs, dirs_file, filter_extra, merge_extra, consensus_extra)
             except SystemExit as stop:                           # e.g. --maxsnps took every sample out: snp_matrix ends the run (exit 100)
@@ -70,8 +76,13 @@ def main():
                     continue
                 raise AssertionError("the separate steps stopped with exit code %r, the one job went through" % (stop.code,))
             want = tp._snapshot(work, dirs)
+            want.update(metrics())
+            for d in dirs:
+                if os.path.exists(os.path.join(d, "metrics")):
+                    os.remove(os.path.join(d, "metrics"))
             tp._run(job)
             got = tp._snapshot(work, dirs, remove=False)
+            got.update(metrics())
             differ = [k for k in sorted(want) if got.get(k) != want[k]] + [k for k in got if k not in want]
             if differ:                                           # keep both versions of the first few, and the small top-level inputs
                 keep = os.path.join(out_dir, "job_%d" % seed)
