@@ -127,8 +127,20 @@ def main():
                 depth = rng.choice([2, 8, 15, 30, 30, 100, 300])
                 glen = rng.choice([g for g in (300, 2000, 9000, 30000) if g * depth * len(contigs) <= 600000])
                 data, _, sites = fuzz.synth_pileup(seed, genome_len=glen, contigs=contigs, mean_depth=depth, n_sites=rng.choice([5, 60, 250]))
-                variant = rng.choice([None, None, "crlf", "mixed", "vt_ff", "repeats"])
-                if variant:
+                variant = rng.choice([None, None, "crlf", "mixed", "vt_ff", "repeats", "shuffle", "interleave", "blanks"])
+                if variant in ("shuffle", "interleave", "blanks"):
+                    body = data.split(b"\n")[:-1]
+                    if variant == "shuffle":                         # no order at all: the bitmap window and the contig hint never settle
+                        rng.shuffle(body)
+                    elif variant == "interleave":                    # the contigs' lines dealt round robin: the hint changes on every line
+                        per = {}
+                        for ln in body:
+                            per.setdefault(ln.split(b"\t")[0], []).append(ln)
+                        body = [ln for group in zip(*[v[:min(map(len, per.values()))] for v in per.values()]) for ln in group]
+                    else:                                            # every separator a run of blanks: every line takes the exact parser
+                        body = [b"  ".join(ln.split(b"\t")) for ln in body]
+                    data = b"\n".join(body) + b"\n"
+                elif variant:
                     data = fuzz.with_line_ends(data, variant, seed)
                 keys = sorted(sites)
                 p = rng.choice(param_sets)
