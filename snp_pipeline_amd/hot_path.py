@@ -749,6 +749,7 @@ def hot_path_batch(args):
             from . import call_consensus as cc_step
             quiet = argparse.Namespace(verbose=0)
             utils.set_logging_verbosity(quiet)
+            process_device, devmod._default = devmod._default, dev       # (the command's "process-wide device" is this job's context)
             try:
                 for s in vcf_again:
                     if not s.ok:
@@ -762,6 +763,7 @@ def hot_path_batch(args):
                     except (Exception, SystemExit) as e:         # noqa: B902 — reported as this sample's error below
                         s.ok, s.error = False, "Error: call_consensus failed for sample %s: %s: %s" % (s.name, type(e).__name__, e)
             finally:
+                devmod._default = process_device
                 utils.set_logging_verbosity(args)
         st = store.stats()
         stats = {"h2d_bytes": int(st.h2d_bytes) + h2d_extra[0], "file_bytes": int(st.file_bytes), "resident_files": int(st.n_resident),

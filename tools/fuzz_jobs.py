@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development helper: a timed campaign of whole jobs on FRESH seeds — a small synthetic outbreak with random shape and random
 step options through the separate subcommands (what run.py starts) and through ONE hot_path_batch job; every output file must
-be the same bytes.  Usage: python tools/fuzz_jobs.py [seconds] [first seed]; the first disagreement is kept under
+be the same bytes.  Usage: python tools/fuzz_jobs.py [seconds] [first seed, 0 = from the clock] [n: every n-th job also sharded over 2 / 3 ranks]; the first disagreement is kept under
 gpurun_out/fuzz_jobs/ (the options and the names of the files that differ) and ends the run with exit code 1."""
 import os
 import pathlib
@@ -18,13 +18,15 @@ sys.path.insert(0, ROOT)
 
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time()) % 1000000
-    sys.argv = ["cfsan_snp_pipeline", "fuzz_jobs"]
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) else int(time.time()) % 1000000
+    argv = list(sys.argv)
     from oracle import fuzz
     from tests import test_gpu_pipeline as tp
     out_dir = os.path.join(ROOT, "gpurun_out", "fuzz_jobs")
     home = os.getcwd()
-    done, stopped, seed = 0, 0, seed0
+    done, stopped, sharded, seed = 0, 0, 0, seed0
+    ranks_every = int(argv[3]) if len(argv) > 3 else 0             # every n-th job also sharded over 2 or 3 ranks
+    sys.argv = ["cfsan_snp_pipeline", "fuzz_jobs"]
     t_end = time.time() + seconds
     while time.time() < t_end:
         seed += 1
@@ -84,10 +86,36 @@ def main():
             got = tp._snapshot(work, dirs, remove=False)
             got.update(metrics())
             differ = [k for k in sorted(want) if got.get(k) != want[k]] + [k for k in got if k not in want]
+            if not differ and ranks_every and done % ranks_every == 0:
+                # the same job sharded over 2 or 3 ranks (torchrun; all ranks on this one GPU, gloo between them): the same files again
+                import socket
+                import subprocess
+                world = rng.choice([2, 3])
+                what["world"] = world
+                for d in dirs:
+                    for name in list(tp.PER_SAMPLE) + ["metrics"]:
+                        if os.path.exists(os.path.join(d, name)):
+                            os.remove(os.path.join(d, name))
+                for name in tp.TOP_LEVEL:
+                    os.remove(os.path.join(str(work), name))
+                s = socket.socket()
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+                s.close()
+                env = dict(os.environ, SNPGPU_PIPELINE_ONE_GPU="1", MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+                cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                       "--master-port", str(port), os.path.join(ROOT, "bin", "cfsan_snp_pipeline")] + [w.replace("\x00", " ") for w in job.split()] + ["-v", "0"]
+                r = subprocess.run(cmd, cwd=str(work), env=env, capture_output=True, text=True, timeout=900)
+                assert r.returncode == 0, "sharded job failed: %s" % (r.stdout[-1500:] + r.stderr[-3000:])
+                again = tp._snapshot(work, dirs, remove=False)
+                again.update(metrics())
+                differ = ["ranks%d:" % world + k for k in sorted(got) if again.get(k) != got[k]]
+                want, got = got, again
+                sharded += 1
             if differ:                                           # keep both versions of the first few, and the small top-level inputs
                 keep = os.path.join(out_dir, "job_%d" % seed)
                 os.makedirs(keep, exist_ok=True)
-                for k in differ[:4] + [x for x in ("snplist.txt", "snplist_preserved.txt", "sampleDirectories.txt.OrigVCF.filtered", "sampleDirectories.txt.PresVCF.filtered") if x in want]:
+                for k in [x.split(":", 1)[-1] for x in differ[:4]] + [x for x in ("snplist.txt", "snplist_preserved.txt", "sampleDirectories.txt.OrigVCF.filtered", "sampleDirectories.txt.PresVCF.filtered") if x in want]:
                     for tag, src in (("steps", want), ("job", got)):
                         with open(os.path.join(keep, k.replace("/", "_") + "." + tag), "wb") as f:
                             f.write(src.get(k, b""))
@@ -106,7 +134,7 @@ def main():
             os.chdir(home)
             shutil.rmtree(str(work), ignore_errors=True)
     print("fuzz jobs: %.0f s, seeds %d..%d, %d jobs with every output file of the one job equal to the separate steps', %d that both ways stopped alike"
-          % (seconds, seed0 + 1, seed, done, stopped))
+          % (seconds, seed0 + 1, seed, done, stopped) + (", %d of them again sharded over 2 / 3 ranks" % sharded if ranks_every else ""))
 
 
 if __name__ == "__main__":
