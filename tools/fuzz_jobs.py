@@ -82,6 +82,32 @@ def main():
             for d in dirs:
                 if os.path.exists(os.path.join(d, "metrics")):
                     os.remove(os.path.join(d, "metrics"))
+            # the batch subcommands (every sample of the list in one process) write what the per-sample commands wrote
+            tp._run("call_sites_batch %s %s" % (ref_path, dirs_file))
+            for name in ("snplist.txt", "snplist_preserved.txt"):
+                with open(os.path.join(str(work), name), "wb") as f:
+                    f.write(want[name])
+            for d in dirs:
+                with open(os.path.join(d, "var.flt_removed.vcf"), "wb") as f:
+                    f.write(want[os.path.join(os.path.basename(d), "var.flt_removed.vcf")])
+            tp._run("call_consensus_batch -f -l %s/snplist.txt -o consensus.fasta --vcfRefName ref.fasta %s --vcfFileName consensus.vcf %s" % (work, consensus_extra, dirs_file))
+            tp._run("call_consensus_batch -f -l %s/snplist_preserved.txt -e var.flt_removed.vcf -o consensus_preserved.fasta --vcfRefName ref.fasta %s "
+                    "--vcfFileName consensus_preserved.vcf %s" % (work, consensus_extra, dirs_file))
+            batch_differ = []
+            for d in dirs:
+                for name in ("var.flt.vcf", "consensus.fasta", "consensus.vcf", "consensus_preserved.fasta", "consensus_preserved.vcf"):
+                    key = os.path.join(os.path.basename(d), name)
+                    if open(os.path.join(d, name), "rb").read() != want[key]:
+                        batch_differ.append("batch:" + key)
+                    os.remove(os.path.join(d, name))
+                os.remove(os.path.join(d, "var.flt_removed.vcf"))
+                if os.path.exists(os.path.join(d, "metrics")):
+                    if open(os.path.join(d, "metrics"), "rb").read() != want.get(os.path.join(os.path.basename(d), "metrics")):
+                        batch_differ.append("batch:" + os.path.basename(d) + "/metrics")
+                    os.remove(os.path.join(d, "metrics"))
+            for name in ("snplist.txt", "snplist_preserved.txt"):
+                os.remove(os.path.join(str(work), name))
+            assert not batch_differ, "the batch subcommands' files differ: %r" % batch_differ
             tp._run(job)
             got = tp._snapshot(work, dirs, remove=False)
             got.update(metrics())
