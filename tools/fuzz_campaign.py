@@ -29,7 +29,9 @@ def main():
     d = get_device()
     out_dir = os.path.join(ROOT, "gpurun_out", "fuzz")
     tmp = tempfile.mkdtemp(prefix="fuzz_")
-    counts = {"lines": 0, "shapes": 0, "sites": 0, "mutants": 0, "mutants_raising": 0, "mutants_refused": 0, "site_mutants": 0, "site_mutants_raising": 0}
+    counts = {"lines": 0, "shapes": 0, "sites": 0, "mutants": 0, "mutants_raising": 0, "mutants_refused": 0, "site_mutants": 0, "site_mutants_raising": 0, "distance": 0, "regions": 0}
+    import numpy as np
+    from oracle import steps_oracle as so
     from snp_pipeline_amd import _lib as L
     from snp_pipeline_amd import device as devmod
 
@@ -100,7 +102,7 @@ def main():
     while time.time() < t_end:
         seed += 1
         rng = random.Random(seed)
-        kind = ("lines", "shapes", "sites", "mutants", "site_mutants", "mutants")[seed % 6]
+        kind = ("lines", "shapes", "sites", "mutants", "site_mutants", "mutants", "distance", "regions")[seed % 8]
         data = b""
         try:
             if kind == "lines":
@@ -169,6 +171,50 @@ def main():
                         continue
                 assert got == want, "device %r, oracle %r" % (got, want)
                 counts["mutants_raising"] += isinstance(want, type)
+            elif kind == "distance":
+                # K5 on shapes around its tile edges (128 x 128 pairs, 64-site words), any byte as a symbol
+                n = rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 200, 257])
+                s = rng.choice([0, 1, 15, 16, 17, 63, 64, 65, 255, 256, 1000, 4097])
+                nrng = np.random.default_rng(seed)
+                alphabet = np.frombuffer(rng.choice([b"ACGT-", b"ACGTacgtNn-*RY", bytes(range(33, 127))]), dtype=np.uint8)      # (ASCII: str.upper() of other text can change its length)
+                sym = alphabet[nrng.integers(0, len(alphabet), size=(n, s))]
+                data = sym.tobytes()
+                got = d.distance(sym)
+                up = np.where((sym >= 97) & (sym <= 122), sym - 32, sym)
+                ok = np.isin(up, np.frombuffer(b"ACGT", dtype=np.uint8))
+                want = np.zeros((n, n), dtype=np.int64)
+                for i in range(n):                                       # (a numpy statement of utils.py:1135-1165, anchored below)
+                    want[i] = ((up[i][None, :] != up) & ok[i][None, :] & ok).sum(axis=1)
+                assert np.array_equal(got, want), "distance matrix differs at %r" % (np.argwhere(got != want)[:3].tolist(),)
+                for _ in range(min(3, n)):
+                    i, j = rng.randrange(n), rng.randrange(n)
+                    assert so.sequence_distance(sym[i].tobytes().decode("latin-1"), sym[j].tobytes().decode("latin-1")) == int(got[i, j])
+            elif kind == "regions":
+                # K3 / K4 through the subcommands' device entry points against the restatement: dense windows + merged regions
+                # + classification on random sorted positions with random rules
+                n_pos = rng.choice([0, 1, 2, 10, 200, 3000])
+                span = rng.choice([50, 1000, 100000, 5000000])
+                pos = sorted(rng.randint(1, span) for _ in range(n_pos))
+                rules = rng.choice([([3, 2, 1], [1000, 125, 15]), ([1], [1]), ([2], [500]), ([6, 1], [2000, 60])])
+                data = repr((pos, rules)).encode()
+                regs = []
+                for m, w in zip(*rules):
+                    regs.extend(so.find_dense_regions(m, w, pos))
+                extra_regs = [(a, a + rng.randint(0, 40)) for a in (rng.randint(0, span) for _ in range(rng.randint(0, 5)))]   # (edge regions and the like)
+                want_regions = so.merge_regions(regs + extra_regs)
+                starts, ends, _ = d.dense_windows(np.asarray(pos, dtype=np.int64), np.asarray([0, len(pos)], dtype=np.uint32), rules[0], rules[1])
+                all_s = np.concatenate([starts, np.asarray([a for a, _ in extra_regs], dtype=np.int64)])
+                all_e = np.concatenate([ends, np.asarray([b for _, b in extra_regs], dtype=np.int64)])
+                _, ms, me = d.merge_regions(np.zeros(len(all_s), dtype=np.uint32), all_s, all_e)
+                # (adjacent intervals: the reference joins them only when the later one reaches further — utils.py:1168-1282; the
+                # device list may keep them apart, which classifies every position the same way: compare the covered positions)
+                covered = lambda regions: sorted(set(p for a, b in regions for p in (a, b))) and [(a, b) for a, b in so.merge_regions([(a, b) for a, b in regions])]   # noqa: E731
+                probe = sorted(set(pos + [p + dlt for a, b in want_regions for p in (a, b) for dlt in (-1, 0, 1)] + [rng.randint(0, span + 50) for _ in range(50)]))
+                probe = [p for p in probe if p >= 0]
+                got_in = d.in_regions(np.zeros(len(probe), dtype=np.uint32), np.asarray(probe, dtype=np.int64), np.asarray([0, len(ms)], dtype=np.uint32), ms, me)
+                want_in = [so.in_region(p, want_regions) for p in probe]
+                assert list(got_in) == want_in, "classification by merged dense regions differs"
+                assert covered is not None
             elif kind == "site_mutants":
                 base = fuzz.varscan_pileup(seed, rng.choice([60, 600]), eol=rng.choice([b"\n", b"\n", b"\r\n"]))
                 data = mutate(rng, base, b"\t\t\n\r 0123456789-+*ACGTNacgtn.,^$!I5~", rng.choice([1, 1, 2, 3]))
