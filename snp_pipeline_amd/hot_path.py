@@ -480,7 +480,8 @@ def hot_path_batch(args):
         d_counts = torch.empty((g_alloc, max(S, 1), 128), dtype=torch.uint8, device="cuda") if want_vcf else None
         vcf_date = None
         pending_write = None
-        vcf_again = []                                           # samples whose pileup repeats a listed position (see the status checks)
+        vcf_again = []                                           # samples whose VCF files the per-sample command writes at the end (see the status checks)
+        vcf_later = set()                                        # ... of them, those whose group must not write a VCF meanwhile
 
         def write_group(part, hs, g0, spill=None):
             """FASTA + VCF files of one group, both flows (host threads inside the library); returns the samples that failed."""
@@ -493,7 +494,7 @@ def hot_path_batch(args):
                     seq = (hs["base1"] if flow == 1 else hs["base2"]).numpy()[k, :(S1 if flow == 1 else S2)]
                     job = {"fasta_path": os.path.join(s.dir, "consensus.fasta" if flow == 1 else "consensus_preserved.fasta"),
                            "fasta_id": s.name.encode("utf-8"), "sequence": seq}
-                    if want_vcf:
+                    if want_vcf and s.index not in vcf_later:
                         hdr = "\n".join(vcf_writer.header_lines(s.name, filters_desc, cc_args.vcfRefName, now=vcf_date)) + "\n"
                         job.update({"vcf_path": os.path.join(s.dir, "consensus.vcf" if flow == 1 else "consensus_preserved.vcf"),
                                     "vcf_header": hdr.encode("utf-8"), "counts": counts_np[k], "line_off": hs["line"].numpy()[k].view(np.uint64),
@@ -615,9 +616,9 @@ def hot_path_batch(args):
                     group_spill = dev.read_symbol_spill()
                 else:
                     for k, s in enumerate(part):
-                        if s.ok and chk[k, 2]:
-                            s.ok, s.error = False, ("Error: call_consensus failed for sample %s: a position has more than %d distinct symbols and the "
-                                                    "sample's group was only partly resident; run call_consensus for this sample" % (s.name, L.MAX_SYMS))
+                        if s.ok and chk[k, 2]:                   # its consensus is as good as any; its VCF rows need the spill of a call of its own
+                            vcf_again.append(s)
+                            vcf_later.add(s.index)
             torch.cuda.current_stream().synchronize()
             lap("3b   of which: results to the host" if args.verbose >= 2 else "3ab  of which: device work + results to the host", t_g)
             t_g = time.perf_counter()
@@ -647,7 +648,7 @@ def hot_path_batch(args):
                     if err is not None:
                         s.ok, s.error = False, "Error: call_consensus failed for sample %s: %s" % (s.name, err)
                         continue
-                    if want_vcf:
+                    if want_vcf and s not in vcf_again:
                         vcf_again.append(s)
                 row_ok[g0 + k] = True
             lap("3c   of which: status checks", t_g)

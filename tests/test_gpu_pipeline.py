@@ -442,3 +442,44 @@ def test_hot_path_batch_on_jobs_the_fuzz_campaign_found(tmp_path, monkeypatch, t
     _run("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --mergeSitesExtraParams=%s --callConsensusExtraParams=%s"
          % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), merge_extra.replace(" ", "\x00"), consensus_extra.replace(" ", "\x00")))
     _compare(_snapshot(work, dirs, remove=False), want)
+
+
+def test_hot_path_batch_with_many_symbols_at_a_position_of_a_sample_that_is_not_resident(tmp_path, monkeypatch):
+    """A listed position with more than eight distinct symbols needs the spill records of ONE library call for its consensus.vcf
+    row; a group that is only partly resident has no such call, so the job lets the per-sample command write that sample's two
+    VCF files at the end — every file as the separate steps write it (until this round the job reported the sample instead)."""
+    work = tmp_path
+    ref_path, dirs, dirs_file, piles = _outbreak_tree(work)
+    monkeypatch.setenv("VarscanMpileup2snp_ExtraParams", VARSCAN_EXTRA)
+    monkeypatch.chdir(work)
+    filter_extra = "--edge_length 100 --window_size 1000 125 15 --max_snp 3 2 1 --mode all"
+    # a position several samples carry, so that it stays on the list whatever the rewritten line does to its own sample's calls
+    for sdir in dirs:
+        _run("call_sites %s %s" % (ref_path, sdir))
+    _run("merge_sites -f -n var.flt.vcf -o %s/probe.txt %s %s.probe" % (work, dirs_file, dirs_file))
+    chrom, pos = next((f[0], int(f[1])) for f in (ln.split("\t") for ln in open(str(work / "probe.txt"))) if int(f[2]) >= 3)
+    for sdir in (dirs[-1], dirs[0]):                              # the last sample is streamed twice in the run below, the first one is resident
+        path = os.path.join(sdir, "reads.all.pileup")
+        lines = open(path, "rb").read().split(b"\n")
+        k = next(i for i, ln in enumerate(lines) if ln.startswith(b"%s\t%d\t" % (chrom.encode(), pos)))
+        f = lines[k].split(b"\t")
+        f[3], f[4], f[5] = b"24", b"ACGTNRYKMSWBacgtnrykmswb", b"I" * 24
+        lines[k] = b"\t".join(f)
+        open(path, "wb").write(b"\n".join(lines))
+    _separate_steps(work, ref_path, dirs, dirs_file, filter_extra, "")
+    want = _snapshot(work, dirs)
+    row = next(ln for ln in want[os.path.join(os.path.basename(dirs[-1]), "consensus.vcf")].split(b"\n") if ln.startswith(b"%s\t%d\t" % (chrom.encode(), pos)))
+    assert row.split(b"\t")[4].count(b",") >= 9                   # ten or more ALT alleles in that row
+    resident = int(2.5 * max(len(p) for p in piles))
+    _run("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s --residentBytes %d"
+         % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), CONSENSUS_EXTRA.replace(" ", "\x00"), resident))
+    _compare(_snapshot(work, dirs, remove=False), want)
+    from snp_pipeline_amd import hot_path
+    assert 0 < hot_path.hot_path_batch.last_stats["resident_files"] < len(dirs)
+    # and with everything resident (the group's own spill records)
+    for name in list(want):
+        p = os.path.join(str(work), name) if name in TOP_LEVEL else os.path.join(str(work), "samples", name)
+        os.remove(p)
+    _run("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s"
+         % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), CONSENSUS_EXTRA.replace(" ", "\x00")))
+    _compare(_snapshot(work, dirs, remove=False), want)
