@@ -150,8 +150,11 @@ def hot_path_batch(args):
     cc_args = _step_args("call_consensus", ["--vcfRefName", os.path.basename(ref_path), "--vcfFileName", "consensus.vcf", "x.pileup"], cc_extra)
     vs_opts = varscan.Options(env("VarscanMpileup2snp_ExtraParams", args.varscanExtraParams))
     want_vcf = not args.noConsensusVcf
-    if cc_args.vcfAllPos and want_vcf:
-        utils.global_error("Error: hot_path_batch does not write --vcfAllPos consensus VCF files; run call_consensus for those.")
+    # --vcfAllPos (a row for every line of the pileup, call_consensus.py:148-151) is the per-sample command's all-lines pass: the job
+    # writes the FASTA files and everything downstream, and lets that command write every sample's two VCF files at the end
+    vcf_all_pos = bool(cc_args.vcfAllPos and want_vcf)
+    if vcf_all_pos:
+        want_vcf = False
     outputs = {k: os.path.join(work_dir, v) for k, v in (
         ("snplist", "snplist.txt"), ("snplist_p", "snplist_preserved.txt"), ("snpma", "snpma.fasta"), ("snpma_p", "snpma_preserved.fasta"),
         ("pairs", "snp_distance_pairwise.tsv"), ("matrix", "snp_distance_matrix.tsv"), ("pairs_p", "snp_distance_pairwise_preserved.tsv"),
@@ -746,6 +749,8 @@ def hot_path_batch(args):
         lap("4 matrices + distances", t0)
         # ---- samples whose pileup repeats a listed position: consensus.vcf rows for EVERY matching line, by the per-sample command
         #      (call_consensus.py:178-180); its consensus.fasta is the same bytes the job wrote ----------------------------------------
+        if vcf_all_pos:
+            vcf_again = [s for k, s in enumerate(callable_) if row_ok[k]]
         if vcf_again:
             from . import call_consensus as cc_step
             quiet = argparse.Namespace(verbose=0)

@@ -53,7 +53,8 @@ def main():
                 filter_extra += " --out_group %s" % og
             merge_extra = rng.choice(["", "", "--maxsnps %d" % rng.choice([0, 10, 25, 40, 1000])])
             consensus_extra = rng.choice([tp.CONSENSUS_EXTRA, "-q 0 -c 0.6 -D 3 -d 0 -b 0", "-q 30 -c 0.75 -D 2 -d 1 -b 0.25 --vcfFailedSnpGt 1",
-                                          "-q 15 -c 0.9 -D 5 -d 2 -b 0.1 --vcfPreserveRefCase", "-q 10 -c 0.51 -D 1 -d 0 -b 0.0"])         # (--vcfAllPos is the per-sample command's: the one job says so and stops)
+                                          "-q 15 -c 0.9 -D 5 -d 2 -b 0.1 --vcfPreserveRefCase", "-q 10 -c 0.51 -D 1 -d 0 -b 0.0",
+                                          "-q 10 -c 0.51 -D 1 -d 0 -b 0.0 --vcfAllPos"])
             varscan_extra = rng.choice([tp.VARSCAN_EXTRA, "--min-avg-qual 0 --min-var-freq 0.3 --min-reads2 2", "--min-var-freq 0.5 --min-reads2 3 --p-value 1e-6 --strand-filter 0"])
             if rng.random() < 0.25:                              # collect_metrics by-products: the samples' metrics files are compared too
                 consensus_extra += " --amdMetricsRefFasta %s" % ref_path
