@@ -422,9 +422,13 @@ def test_hot_path_batch_records_the_collect_metrics_by_products(tmp_path, monkey
     # per-sample command)
     (dict(seed=681455, n_samples=2, genome_len=6000), {"iso01": "repeats"}, "--edge_length 1 --window_size 1000 125 15 --max_snp 3 2 1 --mode each", "",
      CONSENSUS_EXTRA, "--min-var-freq 0.5 --min-reads2 3 --p-value 1e-6 --strand-filter 0"),
+    # --vcfAllPos among the call_consensus options: a VCF row for every pileup line, written by the per-sample command at the end
+    (dict(seed=11, n_samples=3, genome_len=2500), {"iso02": "crlf"}, "--edge_length 100 --window_size 1000 125 15 --max_snp 3 2 1 --mode all", "",
+     "-q 10 -c 0.51 -D 1 -d 0 -b 0.0 --vcfAllPos", VARSCAN_EXTRA),
 ])
 def test_hot_path_batch_on_jobs_the_fuzz_campaign_found(tmp_path, monkeypatch, tree, line_ends, filter_extra, merge_extra, consensus_extra, varscan_extra):
-    """Two jobs tools/fuzz_jobs.py stopped at: every output file of the one job equals the separate subcommands'."""
+    """Jobs tools/fuzz_jobs.py stopped at (and one with --vcfAllPos, which the job used to refuse): every output file of the one job
+    equals the separate subcommands'."""
     work = tmp_path
     ref_path, dirs, dirs_file, piles = _outbreak_tree(work, **tree)
     for i, sdir in enumerate(dirs):
