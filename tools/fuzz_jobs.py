@@ -24,7 +24,7 @@ def main():
     from tests import test_gpu_pipeline as tp
     out_dir = os.path.join(ROOT, "gpurun_out", "fuzz_jobs")
     home = os.getcwd()
-    done, stopped, sharded, seed = 0, 0, 0, seed0
+    done, stopped, sharded, failing, seed = 0, 0, 0, 0, seed0
     ranks_every = int(argv[3]) if len(argv) > 3 else 0             # every n-th job also sharded over 2 or 3 ranks
     sys.argv = ["cfsan_snp_pipeline", "fuzz_jobs"]
     t_end = time.time() + seconds
@@ -66,6 +66,77 @@ def main():
             os.environ["VarscanMpileup2snp_ExtraParams"] = varscan_extra
             os.environ.pop("errorOutputFile", None)
             os.chdir(str(work))
+            if n >= 2 and rng.random() < 0.2:
+                # one sample whose pileup has a position the reference cannot convert (site calling takes the column as text, call_consensus
+                # ends with ValueError): StopOnSampleError=false, the others go on — in the separate steps and in the job alike
+                from snp_pipeline_amd import cfsan_snp_pipeline as cli
+                bad_dir = rng.choice(dirs)
+                bad_path = os.path.join(bad_dir, "reads.all.pileup")
+                lines = open(bad_path, "rb").read().split(b"\n")
+                k = rng.randrange(len(lines) - 1)
+                f = lines[k].split(b"\t")
+                f[1] = f[1] + b"x"
+                lines[k] = b"\t".join(f)
+                open(bad_path, "wb").write(b"\n".join(lines))
+                what["failing"] = os.path.basename(bad_dir)
+                os.environ["StopOnSampleError"] = "false"
+                os.environ["errorOutputFile"] = str(work / "error.log")
+                good = [d for d in dirs if d != bad_dir]
+
+                def run(line):
+                    a = cli.parse_argument_list([w.replace("\x00", " ") for w in line.split()])
+                    a.verbose = 0
+                    try:
+                        return cli.run_command_from_args(a)
+                    except SystemExit as e:
+                        if e.code != 98:                         # a global error (every sample excluded ...): the caller counts it as stopped
+                            raise
+                        return 98
+                    except (ValueError, IndexError):
+                        return 98
+                try:
+                    for sdir in dirs:
+                        run("call_sites %s %s" % (ref_path, sdir))
+                    run("filter_regions -f -n var.flt.vcf %s %s %s" % (dirs_file, ref_path, filter_extra))
+                    run("merge_sites -f -n var.flt.vcf -o %s/snplist.txt %s %s %s.OrigVCF.filtered" % (work, merge_extra, dirs_file, dirs_file))
+                    run("merge_sites -f -n var.flt_preserved.vcf -o %s/snplist_preserved.txt %s %s %s.PresVCF.filtered" % (work, merge_extra, dirs_file, dirs_file))
+                    for sdir in dirs:
+                        run("call_consensus -f -l %s/snplist.txt -o %s/consensus.fasta --vcfRefName ref.fasta %s --vcfFileName consensus.vcf %s/reads.all.pileup"
+                            % (work, sdir, consensus_extra, sdir))
+                        run("call_consensus -f -l %s/snplist_preserved.txt -o %s/consensus_preserved.fasta -e %s/var.flt_removed.vcf --vcfRefName ref.fasta %s "
+                            "--vcfFileName consensus_preserved.vcf %s/reads.all.pileup" % (work, sdir, sdir, consensus_extra, sdir))
+                    for suffix, flt in (("", "OrigVCF"), ("_preserved", "PresVCF")):
+                        run("snp_matrix -f -c consensus%s.fasta -o %s/snpma%s.fasta %s.%s.filtered" % (suffix, work, suffix, dirs_file, flt))
+                        run("snp_reference -f -l %s/snplist%s.txt -o %s/referenceSNP%s.fasta %s" % (work, suffix, work, suffix, ref_path))
+                        run("distance -f -p %s/snp_distance_pairwise%s.tsv -m %s/snp_distance_matrix%s.tsv %s/snpma%s.fasta" % (work, suffix, work, suffix, work, suffix))
+                    var_files = ("var.flt.vcf", "var.flt_preserved.vcf", "var.flt_removed.vcf")
+                    want = tp._snapshot(work, good)
+                    want.update({"bad/" + nm: open(os.path.join(bad_dir, nm), "rb").read() for nm in var_files})
+                    left = sorted(nm for nm in tp.PER_SAMPLE if os.path.exists(os.path.join(bad_dir, nm)))
+                    for nm in left:
+                        os.remove(os.path.join(bad_dir, nm))
+                    if os.path.exists(os.path.join(bad_dir, "metrics")):
+                        os.remove(os.path.join(bad_dir, "metrics"))
+                    for d in good:
+                        if os.path.exists(os.path.join(d, "metrics")):
+                            os.remove(os.path.join(d, "metrics"))
+                    rc = run("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --mergeSitesExtraParams=%s --callConsensusExtraParams=%s"
+                             % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), merge_extra.replace(" ", "\x00"), consensus_extra.replace(" ", "\x00")))
+                    assert rc in (0, 98)
+                    got = tp._snapshot(work, good, remove=False)
+                    got.update({"bad/" + nm: open(os.path.join(bad_dir, nm), "rb").read() for nm in var_files})
+                    differ = [kk for kk in sorted(want) if got.get(kk) != want[kk]]
+                    assert not differ, "with a failing sample, files that differ: %r" % differ
+                    assert sorted(nm for nm in tp.PER_SAMPLE if os.path.exists(os.path.join(bad_dir, nm))) == left, "the failing sample's files"
+                    failing += 1
+                except SystemExit as stop:                       # a global error of a later step (e.g. every sample excluded): not this branch's subject
+                    if stop.code not in (100,):
+                        raise
+                    stopped += 1
+                finally:
+                    os.environ.pop("StopOnSampleError", None)
+                    os.environ.pop("errorOutputFile", None)
+                continue
             job = ("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --mergeSitesExtraParams=%s --callConsensusExtraParams=%s"
                    % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), merge_extra.replace(" ", "\x00"), consensus_extra.replace(" ", "\x00"))) + (" --residentBytes %d" % resident if resident else "")
             try:
@@ -161,7 +232,8 @@ def main():
             os.chdir(home)
             shutil.rmtree(str(work), ignore_errors=True)
     print("fuzz jobs: %.0f s, seeds %d..%d, %d jobs with every output file of the one job equal to the separate steps', %d that both ways stopped alike"
-          % (seconds, seed0 + 1, seed, done, stopped) + (", %d of them again sharded over 2 / 3 ranks" % sharded if ranks_every else ""))
+          % (seconds, seed0 + 1, seed, done, stopped) + (", %d of them again sharded over 2 / 3 ranks" % sharded if ranks_every else "")
+          + ", %d jobs with a failing sample alike" % failing)
 
 
 if __name__ == "__main__":
