@@ -39,6 +39,8 @@ def main():
         buf = bytearray(base)
         for _ in range(n_ops):
             at = rng.randrange(len(buf))
+            if len(buf) > 9000 and rng.random() < 0.35:           # near an edge of the scan's 4 KiB tiles (lines, CRs, TABs that straddle one)
+                at = min(len(buf) - 1, max(0, rng.randrange(1, len(buf) // 4096 + 1) * 4096 + rng.randint(-24, 24)))
             op = rng.random()
             ch = rng.choice(alphabet)
             if op < 0.35:
@@ -153,7 +155,7 @@ def main():
             elif kind == "mutants":
                 # a well-formed pileup with a few ASCII bytes changed, inserted or removed: the same consensus, or the same exception
                 # class as the reference's text-mode reader / Record raises first (pileup.py:224-237, 425-426)
-                base, _, sites = fuzz.synth_pileup(seed, genome_len=rng.choice([200, 1500]), mean_depth=rng.choice([6, 30]), n_sites=rng.choice([20, 150]),
+                base, _, sites = fuzz.synth_pileup(seed, genome_len=rng.choice([200, 1500, 1500]), mean_depth=rng.choice([6, 30, 30]), n_sites=rng.choice([20, 150, 600]),
                                                    contigs=(rng.choice(["c1", "contig_with_a_longer_name_%d" % seed]),))
                 data = mutate(rng, base, b"\t\t\n\r \x0b\x0c0123456789-+_*ACGTacgt.,^$<>!I~xX", rng.choice([1, 1, 2, 4]))
                 keys = sorted(sites)
