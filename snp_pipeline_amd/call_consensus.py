@@ -57,10 +57,15 @@ def consensus_for_sample(dev, pileup_bytes, snp_list, excluded_positions, params
     return consensus_string(snp_slots, res).tobytes().decode("ascii"), ss, res
 
 
-def _raise_as_reference(err, pileup_path=None):
+def _raise_as_reference(err, pileup_path=None, every_line_is_a_record=False):
     """Re-raise a device-detected malformed pileup as the exception class the reference raises for it, so that the
-    error log names the same exception type (utils.handle_sample_exception prints ``exc_type.__name__``)."""
+    error log names the same exception type (utils.handle_sample_exception prints ``exc_type.__name__``).
+    every_line_is_a_record: the --vcfAllPos reader (pileup.py:418-421) builds a Record from every line, and a line with fewer
+    than two fields then ends with IndexError (pileup.py:223-224) where the reader with a position set fails to unpack two
+    values (ValueError, pileup.py:425)."""
     exc = getattr(err, "reference_exception", None)
+    if every_line_is_a_record and getattr(err, "scan_code", 0) == 1:
+        exc = IndexError
     if getattr(err, "scan_code", 0) == 3 and pileup_path:
         # A byte >= 0x80.  The reference reads the pileup as text (pileup.py:405, the locale's encoding: UTF-8 on the
         # pipeline's platforms), so a file that is not valid UTF-8 ends its run with UnicodeDecodeError: the same here.
@@ -107,7 +112,7 @@ def _write_outputs(plan, dev, ss, snp_slots, res, file_flags=None):
             try:
                 line_off, line_flags, counts = dev.call_all_lines(own, plan.pileup_path, params, capacity=res.n_lines, check=bool(args.vcfAllPos))
             except devmod.PileupFormatError as err:
-                _raise_as_reference(err, plan.pileup_path)
+                _raise_as_reference(err, plan.pileup_path, bool(args.vcfAllPos))
             finally:
                 if own is not ss:
                     own.close()
@@ -187,11 +192,17 @@ def call_consensus(args):
     results, rcs, _ = dev.call_consensus_files(ss, [all_pileup_file_path], params, want_counts=True, want_line_offsets=True,
                                                want_depth_sum=bool(getattr(args, "amdMetricsRefFasta", None)))
     timing.mark("streamed call")
+    all_pos = bool(args.vcfAllPos and plan.vcf_path)
     try:
-        dev.raise_file_status(all_pileup_file_path, int(rcs[0]), results[0])
-        dev.check_repeated_positions(ss, all_pileup_file_path, params, results[0])
+        # (--vcfAllPos: the Records of ALL lines are checked, in file order, by the all-lines pass — of _write_outputs, or here and now
+        # when the scan has already met a line it cannot take: which line ends the run is decided among all of them)
+        if all_pos and int(rcs[0]) in (L.E_PILEUP, L.E_UNSUPPORTED):
+            dev.call_all_lines(ss, all_pileup_file_path, params, capacity=results[0].n_lines, check=True)
+        dev.raise_file_status(all_pileup_file_path, int(rcs[0]), results[0], check=not all_pos)
+        if not all_pos:
+            dev.check_repeated_positions(ss, all_pileup_file_path, params, results[0])
     except devmod.PileupFormatError as err:
-        _raise_as_reference(err, all_pileup_file_path)
+        _raise_as_reference(err, all_pileup_file_path, bool(args.vcfAllPos))
     _write_outputs(plan, dev, ss, snp_slots, results[0])
     timing.mark("outputs written")
 

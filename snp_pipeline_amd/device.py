@@ -402,6 +402,10 @@ class Device(object):
             if rc == L.E_IO:
                 raise PileupIOError("cannot open or read the pileup file %s" % path)
             if rc in (L.E_PILEUP, L.E_UNSUPPORTED) and int(status[0]) != 0xFFFFFFFFFFFFFFFF:
+                if check and 0 < n_lines.value <= cap:          # the records are there: a Record-level failure earlier in the file goes first
+                    res = ConsensusResult(None, None, counts[:n_lines.value], status)
+                    res.line_offsets = off[:n_lines.value]
+                    self.raise_first_error(status, res, True)
                 self.raise_scan_status(status)
             self._check(rc)
             if n_lines.value <= cap:

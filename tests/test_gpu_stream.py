@@ -278,3 +278,26 @@ def test_batch_ignores_lines_at_positions_only_other_samples_exclude_and_sees_su
     assert po.call_consensus_sites(b"".join(a), [(b"c1", 10), (b"c1", 120), (b"c1", 150)], set(), po.CallerParams())[0] == b"AAA"
     with pytest.raises(IndexError):
         po.call_consensus_sites(b"".join(c), [(b"c1", 10), (b"c1", 120), (b"c1", 150)], set(), po.CallerParams())
+
+
+def test_vcf_all_pos_ends_at_the_first_malformed_line_of_any_kind(tmp_path, monkeypatch):
+    """With --vcfAllPos the reference builds a Record from EVERY line (pileup.py:418-421): a blank or one-field line ends with
+    IndexError there (with a position set the reader fails to unpack two fields: ValueError), and of several malformed lines the
+    first in the file decides — a line without qualities before a line whose position is no number is IndexError, not ValueError
+    (both found by tools/fuzz_campaign.py's "allpos" kind)."""
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    monkeypatch.delenv("errorOutputFile", raising=False)
+    good = b"".join(b"c1\t%d\tA\t3\t...\tIII\n" % k for k in range(1, 40))
+    tail = b"".join(b"c1\t%d\tA\t3\t...\tIII\n" % k for k in range(50, 70))
+    sdir = _write_sample(tmp_path, "s", good)
+    (tmp_path / "snplist.txt").write_text("c1\t5\t1\ts\nc1\t60\t1\ts\n")
+    line = "call_consensus -v 0 -f -l %s/snplist.txt -o %s/consensus.fasta --vcfFileName all.vcf%%s %s/reads.all.pileup" % (tmp_path, sdir, sdir)
+    for body, all_pos_exc, listed_exc in ((good + b"\n" + tail, IndexError, ValueError),                      # a blank line
+                                          (good + b"onefield\n" + tail, IndexError, ValueError),
+                                          (good + b"c1\t45\tA\t3\t..\n" + b"c1\tx\tA\t3\t...\tIII\n" + tail, IndexError, ValueError),   # (45 is not listed)
+                                          (good + b"c1\tx\tA\t3\t...\tIII\n" + b"c1\t45\tA\t3\t..\n" + tail, ValueError, ValueError)):
+        (sdir / "reads.all.pileup").write_bytes(body)
+        with pytest.raises(all_pos_exc):
+            cli.run_command_from_line(line % " --vcfAllPos")
+        with pytest.raises(listed_exc):
+            cli.run_command_from_line(line % "")

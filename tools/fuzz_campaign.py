@@ -29,7 +29,9 @@ def main():
     d = get_device()
     out_dir = os.path.join(ROOT, "gpurun_out", "fuzz")
     tmp = tempfile.mkdtemp(prefix="fuzz_")
-    counts = {"lines": 0, "shapes": 0, "sites": 0, "mutants": 0, "mutants_raising": 0, "mutants_refused": 0, "site_mutants": 0, "site_mutants_raising": 0, "distance": 0, "regions": 0}
+    counts = {"lines": 0, "shapes": 0, "sites": 0, "mutants": 0, "mutants_raising": 0, "mutants_refused": 0, "site_mutants": 0, "site_mutants_raising": 0, "distance": 0, "regions": 0, "allpos": 0, "allpos_raising": 0}
+    from oracle import vcf_oracle as vco
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
     import numpy as np
     from oracle import steps_oracle as so
     from snp_pipeline_amd import _lib as L
@@ -104,7 +106,7 @@ def main():
     while time.time() < t_end:
         seed += 1
         rng = random.Random(seed)
-        kind = ("lines", "shapes", "sites", "mutants", "site_mutants", "mutants", "distance", "regions")[seed % 8]
+        kind = ("lines", "shapes", "sites", "mutants", "site_mutants", "mutants", "distance", "regions", "allpos")[seed % 9]
         data = b""
         try:
             if kind == "lines":
@@ -173,6 +175,80 @@ def main():
                         continue
                 assert got == want, "device %r, oracle %r" % (got, want)
                 counts["mutants_raising"] += isinstance(want, type)
+            elif kind == "allpos":
+                # the per-sample command with a consensus.vcf (rows for the listed positions, or --vcfAllPos: for EVERY line), on
+                # fuzzed lines with a few mutations: the same rows as the restatement of the writer, or the same exception class
+                lines, keys, pos = [], [], 0
+                chrom = rng.choice(["chrF", "c", "a_rather_long_contig_name|with|bars.1"])
+                while len(lines) < rng.choice([30, 300]):
+                    ln = fuzz.fuzz_line(rng, chrom=chrom)
+                    f = po.split_fields(ln.encode())
+                    try:
+                        rec = po.parse_record(f, 0)
+                    except (IndexError, ValueError):
+                        continue
+                    if len(rec.reference_base) != 1 or rec.reference_base[0] >= 0x80:
+                        continue
+                    pos += rng.choice([1, 1, 2, 50])
+                    f[1] = str(pos).encode()
+                    lines.append(b"\t".join(f))
+                    keys.append((f[0], pos))
+                data = b"\n".join(lines) + b"\n"
+                if rng.random() < 0.4:
+                    data = mutate(rng, data, b"\t\t\n\r 0123456789-+*ACGTacgt.,^$<>!I~", rng.choice([1, 2]))
+                snps = keys[::rng.choice([1, 2, 7])]
+                excl = keys[::9]
+                all_pos = rng.random() < 0.6
+                q, c_, D, d_, b_ = rng.choice([(0, 0.6, 1, 0, 0.0), (15, 0.9, 5, 2, 0.1), (30, 0.75, 2, 1, 0.25)])
+                p = po.CallerParams(q, c_, D, d_, b_)
+                gt, keep_case = rng.choice([".", "0", "1"]), rng.random() < 0.5
+                sdir = os.path.join(tmp, "sampleA")
+                os.makedirs(sdir, exist_ok=True)
+                with open(os.path.join(sdir, "reads.all.pileup"), "wb") as f:
+                    f.write(data)
+                with open(os.path.join(tmp, "snplist.txt"), "w") as f:
+                    f.write("".join("%s\t%d\t1\ts\n" % (c.decode(), pp) for c, pp in snps))
+                with open(os.path.join(sdir, "excl.vcf"), "w") as f:
+                    f.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n")
+                    f.write("".join("%s\t%d\t.\tA\tC\t.\tPASS\t.\tGT\t1/1\n" % (c.decode(), pp) for c, pp in excl))
+                line = ("call_consensus -v 0 -f -l %s/snplist.txt -o %s/consensus.fasta -e %s/excl.vcf -q %d -c %s -D %d -d %d -b %s --vcfFileName all.vcf "
+                        "--vcfFailedSnpGt %s%s%s %s/reads.all.pileup" % (tmp, sdir, sdir, q, c_, D, d_, b_, gt, " --vcfPreserveRefCase" if keep_case else "",
+                                                                        " --vcfAllPos" if all_pos else "", sdir))
+                wanted = set(snps) | set(excl)
+                names = po.filter_names(p)
+                try:
+                    rows = []
+                    for _, ln in po.iter_lines(data):
+                        f = po.split_fields(ln)
+                        if all_pos:                                  # pileup.py:418-421: a Record from every line (IndexError for a short one)
+                            rec = po.parse_record(f, q)
+                            key = (rec.chrom, rec.position)
+                        else:                                        # pileup.py:423-429: two fields unpacked (ValueError), Records at listed positions
+                            chrom_, pos_ = f[:2]
+                            key = (chrom_, int(pos_.decode()))
+                            if key not in wanted:
+                                continue
+                            rec = po.parse_record(f, q)
+                        base, mask = po.call_record(rec, p)
+                        if key in set(excl):
+                            mask |= 32
+                        rows.append(vco.vcf_row(rec, [names[i] for i in range(6) if mask >> i & 1] or None, gt, preserve_ref_case=keep_case))
+                    want = rows
+                except (ValueError, IndexError) as e:
+                    want = type(e)
+                os.environ.pop("errorOutputFile", None)
+                try:
+                    cli.run_command_from_line(line)
+                    got = [x for x in open(os.path.join(sdir, "all.vcf"), encoding="latin-1").read().split("\n") if x and not x.startswith("#")]
+                except (ValueError, IndexError) as e:
+                    got = type(e) if not isinstance(e, PileupFormatError) else "refused"
+                if got == "refused":
+                    counts["mutants_refused"] += 1
+                    continue
+                if isinstance(want, list) and len(set(k for k in keys)) == len(keys) and not all_pos:
+                    pass
+                assert got == want, "consensus.vcf: command %r, restatement %r" % (got if isinstance(got, type) else len(got), want if isinstance(want, type) else len(want))
+                counts["allpos_raising"] += isinstance(want, type)
             elif kind == "distance":
                 # K5 on shapes around its tile edges (128 x 128 pairs, 64-site words), any byte as a symbol
                 n = rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 200, 257])
