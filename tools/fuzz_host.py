@@ -58,7 +58,10 @@ def main():
     from snp_pipeline_amd import snp_matrix, utils
     tmp = tempfile.mkdtemp(prefix="fuzz_host_")
     path = os.path.join(tmp, "f")
-    counts = {"vcf": 0, "snplist": 0, "fasta": 0, "vcf_rows": 0, "raised": 0}
+    counts = {"vcf": 0, "snplist": 0, "fasta": 0, "vcf_rows": 0, "tsv": 0, "raised": 0}
+    from oracle import steps_oracle as so
+    from snp_pipeline_amd import distance as dmod
+    from snp_pipeline_amd import merge_sites as msites
     from oracle import fuzz
     from oracle import pileup_oracle as po
     from oracle import vcf_oracle as vo
@@ -70,7 +73,7 @@ def main():
     while time.time() < t_end:
         seed += 1
         rng = random.Random(seed)
-        kind = ("vcf", "snplist", "fasta", "vcf_rows")[seed % 4]
+        kind = ("vcf", "snplist", "fasta", "vcf_rows", "tsv")[seed % 5]
         data = b""
         contigs = [rng.choice(["c", "ctg|%d" % rng.randint(1, 9), "NODE_%d_cov_1.5" % rng.randint(1, 99), "x" * rng.randint(1, 30)]) for _ in range(rng.randint(1, 3))]
         eol = rng.choice([b"\n", b"\n", b"\r\n"])
@@ -98,6 +101,28 @@ def main():
                 want = outcome(lambda: utils.read_snp_position_list(path))
                 got = outcome(lambda: (lambda r: [(r[0][int(c)], int(p)) for c, p in zip(r[1], r[2])])(utils.read_snp_position_arrays(path)))
                 assert got == want, ("snplist arrays", got if got[0] == "raised" else len(got[1]), want if want[0] == "raised" else len(want[1]))
+            elif kind == "tsv":
+                # the two distance TSV files (csrc/tsv_out.hip vs distance.py:100-114) and the snplist text (vs utils.py:1056-1070)
+                m = rng.choice([0, 1, 2, 7, 40])
+                ids = sorted(set("".join(rng.choice("abcXYZ019_-|. ") for _ in range(rng.randint(1, 12))) for _ in range(m)))
+                mat = np.asarray([[rng.choice([0, 1, 9, 10, 99, 12345, 2 ** 31 - 1]) for _ in ids] for _ in ids], dtype=np.int32).reshape(len(ids), len(ids))
+                table = {(a, b): int(mat[i, j]) for i, a in enumerate(ids) for j, b in enumerate(ids)}
+                if ids:
+                    dmod.write_pairwise(path, ids, mat)
+                    assert open(path).read() == so.pairwise_text(ids, table), "pairwise TSV"
+                    dmod.write_matrix(path, ids, mat)
+                    assert open(path).read() == so.matrix_text(ids, table), "matrix TSV"
+                samples = ["s%d" % k for k in range(rng.randint(1, 5))]
+                sites = sorted(set((rng.randrange(len(contigs)), rng.randint(0, 4000000000)) for _ in range(n)))
+                uniq = np.asarray([(c << 32) | p_ for c, p_ in sites], dtype=np.uint64)
+                carriers = [sorted(rng.sample(range(len(samples)), rng.randint(1, len(samples)))) for _ in sites]
+                off = np.cumsum([0] + [len(c) for c in carriers]).astype(np.uint32)
+                car = np.asarray([x for c in carriers for x in c], dtype=np.uint32)
+                msites.write_snplist(path, contigs, uniq, off, car, samples)
+                got_text = open(path).read()
+                utils.write_list_of_snps(path, [(contigs[c], p_) for c, p_ in sites], [[samples[x] for x in c] for c in carriers])
+                assert got_text == open(path).read(), "snplist text"
+                want = ("ok", None)
             elif kind == "vcf_rows":
                 # consensus.vcf rows: records as the device fills them, built here from the oracle's Records of fuzzed lines ->
                 # the library's formatter and the Python row function against the restatement of vcf_writer.py:295-379
