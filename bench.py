@@ -758,8 +758,28 @@ def cpu_baseline(args, d, pile, offs, sizes, bases, pos, G, S, gpu_value, second
     return res
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks of this very command line on this node (one per GPU,
+    rendezvous on 127.0.0.1 — the fan-out the reference does with its per-sample job arrays, run.py:613-627) and pass on what
+    rank 0 prints.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                                  # a free port: two benches on one node do not collide
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: what RCCL needs on this platform
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env["SNPGPU_BENCH_LAUNCHER"] = "self"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     import torch
     import torch.distributed as dist
     from snp_pipeline_amd import _lib as L
@@ -770,7 +790,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, args.gpus))
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch %d ranks with torch.distributed.run, or run plain "
+                         "`python bench.py --gpus %d` and let it start them" % (world, args.gpus, args.gpus, args.gpus))
     # functional test hook (not a measurement mode): all ranks on one GPU over gloo, to exercise the N > 1 code path on
     # a single-GPU box
     one_gpu = os.environ.get("SNPGPU_BENCH_TEST_ONE_GPU") == "1"
@@ -973,6 +994,10 @@ def main():
                    "pileup_bytes_this_rank": pile_bytes, "caller": "q0 c0.6 D3 d0 b0",
                    "parallelism": "samples sharded over %d rank(s)%s"
                                   % (world, (", backend %s, world size %d" % (backend, dist.get_world_size())) if world > 1 else "")},
+        "comm": {"backend": (dist.get_backend() if world > 1 else None), "world_size": (dist.get_world_size() if world > 1 else 1),
+                 "launcher": "bench.py started its own ranks (torch.distributed.run, 127.0.0.1)" if os.environ.get("SNPGPU_BENCH_LAUNCHER") == "self"
+                 else ("torch.distributed.run around bench.py" if world > 1 else "none (one process)"),
+                 "collectives_per_step": "C1 variable-length all-gather of site records, C2 all-gather of packed rows, one all-to-all of distance tiles" if world > 1 else "none"},
         "genome_bp_per_sec": n_total * G / (elapsed / args.steps),
         "pileup_gb_per_sec": (pile_bytes * n_total / max(B, 1)) / (elapsed / args.steps) / 1e9,
         "roofline": {"kernel": "k_scan_wave", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -422,3 +422,33 @@ def untidy_snpmas():
     out.append(("text_before_the_first_header", "ACGT\n" + fasta([("a", seq(20)), ("b", seq(20))])))
     out.append(("one_sample", fasta([("only", seq(33))])))
     return out
+
+
+def pileup_at_positions(seed, contig_positions, refs=None, neighbours=2, mean_depth=24):
+    """A well-formed pileup with lines only at the given positions (and a few neighbours): what a sample looks like whose
+    var.flt.vcf exists already and whose reads are not at hand.  contig_positions: [(contig str, sorted positions)] in file
+    order; refs: {contig: sequence} for the reference column (N when absent).  At about a third of the listed positions every
+    read shows one variant letter; elsewhere the reads match."""
+    rng = random.Random(seed)
+    out = []
+    for contig, positions in contig_positions:
+        seq = (refs or {}).get(contig)
+        want = set()
+        for p in positions:
+            for q in range(p - neighbours, p + neighbours + 1):
+                if q >= 1 and (seq is None or q <= len(seq)):
+                    want.add(q)
+        listed = set(positions)
+        name = contig.encode()
+        for p in sorted(want):
+            r = seq[p - 1].upper() if seq is not None else "N"
+            depth = max(1, int(rng.gauss(mean_depth, mean_depth ** 0.5)))
+            alt = rng.choice([b for b in "ACGT" if b != r]) if (p in listed and rng.random() < 0.35) else None
+            toks = []
+            for _ in range(depth):
+                fwd = rng.random() < 0.5
+                t = (alt if fwd else alt.lower()) if alt else ("." if fwd else ",")
+                toks.append(t)
+            quals = "".join(chr(33 + rng.randint(20, 40)) for _ in range(depth))
+            out.append(b"%s\t%d\t%s\t%d\t%s\t%s\n" % (name, p, r.encode(), depth, "".join(toks).encode(), quals.encode()))
+    return b"".join(out)

@@ -88,6 +88,9 @@ def parse_argument_list(argv):
     sub.add_argument(dest="referenceFile", type=str, help="Relative or absolute path to the reference fasta file")
     sub.add_argument(dest="sampleDirsFile", type=str, help="Relative or absolute path to file containing a list of directories -- one per sample")
     sub.add_argument("-f", "--force", dest="forceFlag", action="store_true", help="Force processing even when result files already exist and are newer than inputs")
+    sub.add_argument("--siteCalling", dest="siteCalling", type=str, default=None, choices=call_sites.SITE_CALLING_MODES, metavar="MODE",
+                     help="Who writes var.flt.vcf: varscan (the VarScan jar on CLASSPATH, as the reference), device (this build's restatement; parity unpinned), "
+                          "existing (nobody: the files are inputs), auto (varscan when a jar is on CLASSPATH, else device).  Default: $SNPGPU_SITE_CALLING, else auto")
     _common(sub)
     sub.set_defaults(func=call_sites.call_sites_batch, excepthook=utils.handle_global_exception)
 

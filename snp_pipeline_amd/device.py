@@ -791,13 +791,16 @@ def acquire_device_slot(n_devices, max_per_device=None, lock_dir=None, poll_seco
     ``max_per_device`` contexts exist per GPU at a time; the lock dies with the process.  Returns (device index, open
     lock file)."""
     import fcntl
-    import tempfile
     import time
+    from . import _paths
     if max_per_device is None:
         max_per_device = int(os.environ.get("SNPGPU_MAX_PROCS_PER_DEVICE", "4"))
     max_per_device = max(1, max_per_device)
-    lock_dir = lock_dir or os.environ.get("SNPGPU_LOCK_DIR") or os.path.join(tempfile.gettempdir(), "snpgpu-%d" % os.getuid())
-    os.makedirs(lock_dir, exist_ok=True)
+    lock_dir = lock_dir or os.environ.get("SNPGPU_LOCK_DIR")
+    if lock_dir:
+        os.makedirs(lock_dir, exist_ok=True)       # a directory the caller named (several users of one node may share its slots)
+    else:
+        lock_dir = _paths.private_dir()            # (refused when /tmp/snpgpu-<uid> is somebody else's)
     start = os.getpid() % n_devices
     order = [((start + i) % n_devices, j) for j in range(max_per_device) for i in range(n_devices)]
     while True:

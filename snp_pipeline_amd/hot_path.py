@@ -4,21 +4,33 @@ The reference runs these steps as separate process arrays over a shared file sys
 (call_sites.py:89-108), filter_regions, merge_sites twice, call_consensus twice per sample (run.py:704-710 and :712-718),
 snp_matrix twice, snp_reference twice, distance twice — and every one of call_sites and the two call_consensus passes reads the
 sample's reads.all.pileup (0.4 GB per 5 Mbp x 30x sample) again.  This module is the same chain of steps, writing the same
-files with the same bytes, arranged around the device instead of around the file system:
+files with the same bytes, arranged around the device instead of around the file system.  The job is a sequence of STAGES over
+one explicit state object (``_Job``); a stage is a plain function of the job and can be driven alone:
 
-  1  every rank (= one GPU; torchrun-able) streams the pileups of ITS samples (a contiguous block of the sorted sample
-     directories) into HBM and KEEPS them (``Device.pileups``; files past the memory budget are re-streamed in step 3);
-     site calling (csrc/varscan.hip) runs on each file while the next one arrives; host threads finish each sample as its
-     records come back: var.flt.vcf
-  2  C1: all-gather of every sample's (CHROM, POS) records; dense-region filter (K3), both site unions (K4) on every rank —
-     identical results everywhere; rank 0 writes snplist.txt / snplist_preserved.txt and the two filtered directory lists,
-     every rank the var.flt_preserved.vcf / var.flt_removed.vcf of its samples
-  3  ONE scan + call over the resident pileups at the positions of snplist.txt, with per-site records; the preserved flow
-     (snplist_preserved.txt columns, ``Region`` for the sample's removed positions) is derived from it on the device
-     (csrc/flows.hip); consensus.fasta / consensus.vcf / consensus_preserved.fasta / consensus_preserved.vcf of a group of
-     samples are written by host threads while the next group is on the device
-  4  4-bit pack of both matrices, C2 all-gather of the rows, all-pairs distance tiles dealt to the ranks, row-band exchange;
-     snpma*.fasta (every rank writes its block of the file), the four TSVs and referenceSNP*.fasta (rank 0)
+  stage_ingest_and_sites      every rank (= one GPU; torchrun-able) streams the pileups of ITS samples (a contiguous block of
+                              the sorted sample directories) into HBM and KEEPS them (``Device.pileups``; files past the memory
+                              budget are re-streamed by the consensus stage).  Where var.flt.vcf comes from is the site calling
+                              mode (``--siteCalling``, call_sites.py): ``device`` — site calling (csrc/varscan.hip) runs on each
+                              file while the next one arrives and host threads finish each sample as its records come back;
+                              ``varscan`` — the VarScan jar, as the reference runs it, on host threads beside the ingest;
+                              ``existing`` — the files are inputs and are never written
+  stage_site_union_and_regions  C1: all-gather of every sample's (CHROM, POS) records; dense-region filter (K3), both site unions
+                              (K4) on every rank — identical results everywhere; rank 0 writes snplist.txt / snplist_preserved.txt
+                              and the two filtered directory lists, every rank the var.flt_preserved.vcf / var.flt_removed.vcf of
+                              its samples
+  stage_consensus             ONE scan + call over the resident pileups at the positions of snplist.txt, with per-site records;
+                              the preserved flow (snplist_preserved.txt columns, ``Region`` for the sample's removed positions) is
+                              derived from it on the device (csrc/flows.hip); consensus.fasta / consensus.vcf /
+                              consensus_preserved.fasta / consensus_preserved.vcf of a group of samples are written by host threads
+                              while the next group is on the device
+  stage_matrices_and_distances  4-bit pack of both matrices, C2 all-gather of the rows, all-pairs distance tiles dealt to the
+                              ranks, row-band exchange; snpma*.fasta (every rank writes its block of the file), the four TSVs and
+                              referenceSNP*.fasta (rank 0)
+  stage_leftover_vcfs         the VCF files the per-sample command has to write (repeated positions, --vcfAllPos)
+
+Between stages the ranks AGREE on failure (``_Job.agree``): a rank whose stage raised does not leave its peers waiting in the
+next collective — every rank learns of it, the failing rank reports its own error, all leave with the same exit code.  Inside a
+stage, collectives come first and rank-local work that can fail (file output) after them, or under ``_Job.guard``.
 
 Options of the individual steps are given as the reference gives them: the ``*_ExtraParams`` strings (argument or the
 environment variable of the same name), parsed by the step's own argument parser.
@@ -27,15 +39,19 @@ from __future__ import print_function
 
 import argparse
 import concurrent.futures
+import contextlib
 import ctypes
+import datetime
 import os
 import shlex
+import sys
 import threading
 import time
 
 import numpy as np
 
 from . import _lib as L
+from . import call_sites as cs
 from . import device as devmod
 from . import filter_regions as fr
 from . import merge_sites as ms
@@ -63,6 +79,9 @@ class _Sample(object):
         self.store_index = -1
         self.vcf_lines = self.header = self.sites = self.removed = None
         self.n_lines = self.n_rows = 0
+
+    def fail(self, message):
+        self.ok, self.error = False, message
 
 
 def _step_args(step, fixed, extra):
@@ -116,685 +135,977 @@ class _Comm(object):
         return out
 
 
-def hot_path_batch(args):
-    """Entry point of ``cfsan_snp_pipeline hot_path_batch`` (an extension of this build; see the module docstring)."""
-    utils.print_log_header(classpath=True)
-    utils.print_arguments(args)
-    t_start = time.perf_counter()
-    import torch                                   # device tensors, pinned host buffers and the collectives: plumbing
-    from . import sharding
-    comm = _Comm()
-    rank, world = comm.rank, comm.world
-    timings = {}
+class _Job(object):
+    """Everything the stages of one hot_path_batch job share.  Set up by ``_Job.__init__`` (arguments, samples, the rank's
+    shard, device + resident store); each stage documents the fields it adds."""
 
-    def lap(name, t0):
-        timings[name] = timings.get(name, 0.0) + time.perf_counter() - t0
+    def __init__(self, args, comm):
+        import torch                                   # device tensors, pinned host buffers and the collectives: plumbing
+        from . import sharding
+        self.torch, self.sharding = torch, sharding
+        self.args, self.comm = args, comm
+        self.rank, self.world = comm.rank, comm.world
+        self.t_start = time.perf_counter()
+        self.timings = {}
+        self.deferred = None                           # first exception of a guarded block (see guard)
+        self.dev = self.store = None
 
-    # ---- arguments: what run.py:662-784 puts on the command lines of the steps -------------------------------------------
-    dirs_file = args.sampleDirsFile
-    ref_path = args.referenceFile
-    if utils.verify_non_empty_input_files("File of sample directories", [dirs_file]) > 0:
-        utils.global_error(None)
-    utils.verify_non_empty_input_files("Reference file", [ref_path], error_handler="global")
-    with open(dirs_file, "r") as f:
-        unsorted_dirs = [d for d in (line.rstrip() for line in f) if d]
-    sorted_dirs = sorted(unsorted_dirs)
-    work_dir = args.workDir or os.path.dirname(os.path.abspath(dirs_file))
+        # ---- arguments: what run.py:662-784 puts on the command lines of the steps ---------------------------------------
+        self.dirs_file = dirs_file = args.sampleDirsFile
+        self.ref_path = ref_path = args.referenceFile
+        if utils.verify_non_empty_input_files("File of sample directories", [dirs_file]) > 0:
+            utils.global_error(None)
+        utils.verify_non_empty_input_files("Reference file", [ref_path], error_handler="global")
+        with open(dirs_file, "r") as f:
+            self.unsorted_dirs = [d for d in (line.rstrip() for line in f) if d]
+        self.sorted_dirs = sorted(self.unsorted_dirs)
+        self.dir_index = {d: i for i, d in enumerate(self.sorted_dirs)}
+        self.work_dir = work_dir = args.workDir or os.path.dirname(os.path.abspath(dirs_file))
 
-    def env(name, given):
-        return given if given is not None else (os.environ.get(name) or "")
+        def env(name, given):
+            return given if given is not None else (os.environ.get(name) or "")
 
-    fr_args = _step_args("filter_regions", ["-n", "var.flt.vcf", dirs_file, ref_path], env("FilterRegions_ExtraParams", args.filterRegionsExtraParams))
-    ms_args = _step_args("merge_sites", [dirs_file, dirs_file + ".OrigVCF.filtered"], env("MergeSites_ExtraParams", args.mergeSitesExtraParams))
-    cc_extra = env("CallConsensus_ExtraParams", args.callConsensusExtraParams)
-    cc_args = _step_args("call_consensus", ["--vcfRefName", os.path.basename(ref_path), "--vcfFileName", "consensus.vcf", "x.pileup"], cc_extra)
-    vs_opts = varscan.Options(env("VarscanMpileup2snp_ExtraParams", args.varscanExtraParams))
-    want_vcf = not args.noConsensusVcf
-    # --vcfAllPos (a row for every line of the pileup, call_consensus.py:148-151) is the per-sample command's all-lines pass: the job
-    # writes the FASTA files and everything downstream, and lets that command write every sample's two VCF files at the end
-    vcf_all_pos = bool(cc_args.vcfAllPos and want_vcf)
-    if vcf_all_pos:
-        want_vcf = False
-    outputs = {k: os.path.join(work_dir, v) for k, v in (
-        ("snplist", "snplist.txt"), ("snplist_p", "snplist_preserved.txt"), ("snpma", "snpma.fasta"), ("snpma_p", "snpma_preserved.fasta"),
-        ("pairs", "snp_distance_pairwise.tsv"), ("matrix", "snp_distance_matrix.tsv"), ("pairs_p", "snp_distance_pairwise_preserved.tsv"),
-        ("matrix_p", "snp_distance_matrix_preserved.tsv"), ("refsnp", "referenceSNP.fasta"), ("refsnp_p", "referenceSNP_preserved.fasta"))}
-    filtered1, filtered2 = dirs_file + ".OrigVCF.filtered", dirs_file + ".PresVCF.filtered"
+        self.fr_args = _step_args("filter_regions", ["-n", "var.flt.vcf", dirs_file, ref_path], env("FilterRegions_ExtraParams", args.filterRegionsExtraParams))
+        self.ms_args = _step_args("merge_sites", [dirs_file, dirs_file + ".OrigVCF.filtered"], env("MergeSites_ExtraParams", args.mergeSitesExtraParams))
+        self.cc_extra = env("CallConsensus_ExtraParams", args.callConsensusExtraParams)
+        self.cc_args = _step_args("call_consensus", ["--vcfRefName", os.path.basename(ref_path), "--vcfFileName", "consensus.vcf", "x.pileup"], self.cc_extra)
+        self.vs_opts = varscan.Options(env("VarscanMpileup2snp_ExtraParams", args.varscanExtraParams))
+        self.site_calling = cs.site_calling_mode(getattr(args, "siteCalling", None))
+        self.want_vcf = not args.noConsensusVcf
+        # --vcfAllPos (a row for every line of the pileup, call_consensus.py:148-151) is the per-sample command's all-lines pass: the
+        # job writes the FASTA files and everything downstream, and lets that command write every sample's two VCF files at the end
+        self.vcf_all_pos = bool(self.cc_args.vcfAllPos and self.want_vcf)
+        if self.vcf_all_pos:
+            self.want_vcf = False
+        self.outputs = {k: os.path.join(work_dir, v) for k, v in (
+            ("snplist", "snplist.txt"), ("snplist_p", "snplist_preserved.txt"), ("snpma", "snpma.fasta"), ("snpma_p", "snpma_preserved.fasta"),
+            ("pairs", "snp_distance_pairwise.tsv"), ("matrix", "snp_distance_matrix.tsv"), ("pairs_p", "snp_distance_pairwise_preserved.tsv"),
+            ("matrix_p", "snp_distance_matrix_preserved.tsv"), ("refsnp", "referenceSNP.fasta"), ("refsnp_p", "referenceSNP_preserved.fasta"))}
+        self.filtered1, self.filtered2 = dirs_file + ".OrigVCF.filtered", dirs_file + ".PresVCF.filtered"
 
-    samples = [_Sample(i, d, args.pileupName) for i, d in enumerate(sorted_dirs)]
-    n_total = len(samples)
-    lo, hi = sharding.shard_bounds(n_total, rank, world)
-    mine = samples[lo:hi]
+        self.samples = [_Sample(i, d, args.pileupName) for i, d in enumerate(self.sorted_dirs)]
+        self.n_total = len(self.samples)
+        self.lo, self.hi = sharding.shard_bounds(self.n_total, self.rank, self.world)
+        self.mine = self.samples[self.lo:self.hi]
+        self.group_bytes = int(args.groupBytes) if args.groupBytes else (1 << 30)
+        self.arenas = [None, None]
+        self.arena_thread = None
+        self.h2d_extra = 0
 
-    # make-style freshness for the job as a whole: every top-level output newer than every input
-    if not args.forceFlag:
-        inputs = [dirs_file, ref_path] + [s.pileup for s in samples]
-        per_sample = [os.path.join(s.dir, n) for s in samples for n in ("var.flt.vcf", "consensus.fasta", "consensus_preserved.fasta")]
-        if all(not utils.target_needs_rebuild(inputs, t) for t in list(outputs.values()) + per_sample):
-            verbose_print("All outputs of the hot path have already been freshly built.  Use the -f option to force a rebuild.")
+    # ---- small services of the state object ----------------------------------------------------------------------------------
+    def lap(self, name, t0):
+        self.timings[name] = self.timings.get(name, 0.0) + time.perf_counter() - t0
+
+    def is_fresh(self):
+        """make-style freshness for the job as a whole: every output newer than every input (in mode ``existing`` the
+        var.flt.vcf files are inputs too)."""
+        inputs = [self.dirs_file, self.ref_path] + [s.pileup for s in self.samples]
+        names = ["consensus.fasta", "consensus_preserved.fasta"]
+        if self.site_calling == "existing":
+            inputs += [os.path.join(s.dir, "var.flt.vcf") for s in self.samples]
+        else:
+            names.append("var.flt.vcf")
+        per_sample = [os.path.join(s.dir, n) for s in self.samples for n in names]
+        return all(not utils.target_needs_rebuild(inputs, t) for t in list(self.outputs.values()) + per_sample)
+
+    def open_device(self):
+        torch = self.torch
+        self.dev = devmod.Device(self.comm.local_rank)
+        self.dev.use_torch_stream()
+        torch.cuda.set_device(self.comm.local_rank)
+        self.store = self.dev.pileups(int(self.args.residentBytes or 0))
+
+    def close_device(self):
+        if self.store is not None:
+            self.store.close()
+        if self.dev is not None:
+            self.dev.close()
+        self.store = self.dev = None
+
+    @contextlib.contextmanager
+    def guard(self):
+        """Rank-local work between two collectives that may fail (file output): the first exception is kept and raised at the end
+        of the stage, later guarded blocks are skipped, and the collectives in between still run — the peers are not left alone."""
+        if self.deferred is not None:
+            yield False
             return
+        try:
+            yield True
+        except BaseException as err:                         # noqa: B902 — raised again by run_stage
+            self.deferred = err
 
-    failed = 0
-    for s in mine:
-        if utils.verify_non_empty_input_files("Pileup file", [s.pileup]) > 0:
-            s.ok, s.error = False, "Error: cannot process sample %s without its pileup file." % s.name
+    def agree(self, err, where):
+        """Collective: does any rank have a failure?  The failing rank(s) raise their own exception (its text reaches the log
+        through the usual hooks); the others leave quietly with the same exit code."""
+        if not self.comm.dist:
+            if err is not None:
+                raise err
+            return
+        mine = None
+        if err is not None:
+            code = err.code if isinstance(err, SystemExit) and isinstance(err.code, int) else (0 if isinstance(err, SystemExit) and err.code is None else 100)
+            mine = (code, "%s: %s" % (type(err).__name__, err))
+        every = self.comm.gather_objects(mine)
+        if not any(e is not None for e in every):
+            return
+        self.close_device()
+        self.comm.close()
+        if err is not None:
+            raise err
+        first = next(k for k, e in enumerate(every) if e is not None)
+        verbose_print("# hot_path_batch rank %d stops after %s: rank %d failed (%s)" % (self.rank, where, first, every[first][1]))
+        sys.exit(every[first][0] or 100)
 
-    dev = devmod.Device(comm.local_rank)
-    dev.use_torch_stream()
-    torch.cuda.set_device(comm.local_rank)
-    store = dev.pileups(int(args.residentBytes or 0))
+    def run_stage(self, stage):
+        err = None
+        try:
+            stage(self)
+            if self.deferred is not None:
+                err, self.deferred = self.deferred, None
+        except BaseException as e:                            # noqa: B902 — every rank must reach the agreement below
+            err = e
+        self.agree(err, stage.__name__)
+
+
+# ==================================== stage 1: pileups -> HBM, var.flt.vcf ====================================================
+def _alloc_arenas(job):
+    """Host memory for the per-site results of the consensus stage, allocated AND touched while the pileups stream in.  Plain
+    pageable memory: on this platform a device-to-host copy into touched pageable memory runs at the pinned rate (55 GB/s), while
+    pinning a gigabyte takes 0.23 s during which every other thread's copies stand still (tools/probe/pin_probe.cpp)."""
+    for k in range(2 if job.hi - job.lo > 1 else 1):
+        a = np.empty(job.group_bytes, dtype=np.uint8)
+        ctypes.memset(a.ctypes.data, 0, a.nbytes)      # touches the pages with the GIL released (ndarray.fill would hold it)
+        job.arenas[k] = job.torch.from_numpy(a)
+
+
+def _read_sample_vcf(s):
+    """The records filter_regions / merge_sites read from the sample's var.flt.vcf (whoever wrote it)."""
     try:
-        # host memory for the per-site results of step 3, allocated AND touched while the pileups stream in.  Plain pageable
-        # memory: on this platform a device-to-host copy into touched pageable memory runs at the pinned rate (55 GB/s), while
-        # pinning a gigabyte takes 0.23 s during which every other thread's copies stand still (tools/probe/pin_probe.cpp)
-        group_bytes = int(args.groupBytes) if args.groupBytes else (1 << 30)
-        arenas = [None, None]
+        s.header, s.vcf_lines, s.sites = fr._read_vcf(os.path.join(s.dir, "var.flt.vcf"))
+    except Exception as err:                                 # noqa: B902 — reported as this sample's error
+        s.fail("Error: cannot read the VCF file of sample %s: %s: %s" % (s.name, type(err).__name__, err))
 
-        def alloc_arenas():
-            for k in range(2 if hi - lo > 1 else 1):
-                a = np.empty(group_bytes, dtype=np.uint8)
-                ctypes.memset(a.ctypes.data, 0, a.nbytes)      # touches the pages with the GIL released (ndarray.fill would hold it)
-                arenas[k] = torch.from_numpy(a)
 
-        arena_thread = threading.Thread(target=alloc_arenas)
-        arena_thread.start()
-        # ================================ 1: pileups -> HBM, site calling -> var.flt.vcf ===================================
-        t0 = time.perf_counter()
-        todo = [s for s in mine if s.ok]
-        vparams = vs_opts.device_params()
-        pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // 4)))
-        redo = []
+def _finish_device_sample(job, s, records, n_lines):
+    """Host half of the device's call_sites for one sample (Fisher's exact test, VCF text: csrc/varscan_rows.hip), then the
+    records filter_regions / merge_sites read from the file it has just written."""
+    try:
+        vcf_path = os.path.join(s.dir, "var.flt.vcf")
+        s.n_lines = n_lines
+        s.n_rows = varscan._write_vcf(vcf_path, s.pileup, records, job.vs_opts)
+        s.header, s.vcf_lines, s.sites = fr._read_vcf(vcf_path)
+    except Exception as err:                                 # noqa: B902 — reported as this sample's error
+        s.fail("Error: call_sites failed for sample %s: %s: %s" % (s.name, type(err).__name__, err))
 
-        def finish_sample(s, records, n_lines):
-            """Host half of call_sites for one sample (Fisher's exact test, VCF text: csrc/varscan_rows.hip), then the records
-            filter_regions / merge_sites read from the file it has just written."""
+
+def _ingest_failed(s, rc, status_word):
+    """The sample error for a non-zero per-file return code of the ingest, or None."""
+    if rc == L.E_IO:
+        return "Error: cannot open or read the pileup file %s" % s.pileup
+    if rc == L.E_PILEUP:
+        return "Error: call_sites failed for sample %s: ValueError: Invalid format for pileup at byte %d of %s" % (s.name, int(status_word), s.pileup)
+    if rc != 0:
+        return "Error: call_sites failed for sample %s (device error %d)" % (s.name, int(rc))
+    return None
+
+
+def _ingest_with_device_site_calling(job, todo):
+    """Mode ``device``: site calling on each file while the next arrives; var.flt.vcf written by host threads as records return."""
+    dev, store = job.dev, job.store
+    vparams = job.vs_opts.device_params()
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // 4)))
+    redo = []
+    for b0 in range(0, len(todo), INGEST_BATCH):
+        batch = todo[b0:b0 + INGEST_BATCH]
+        bufs = store.ingest_buffers(len(batch), VARSCAN_CAPACITY)
+        sites, counts, status, rcs, done = bufs
+        first = len(store)
+        failure = []
+
+        def run_ingest(batch=batch, bufs=bufs):
             try:
-                vcf_path = os.path.join(s.dir, "var.flt.vcf")
-                s.n_lines = n_lines
-                s.n_rows = varscan._write_vcf(vcf_path, s.pileup, records, vs_opts)
-                s.header, s.vcf_lines, s.sites = fr._read_vcf(vcf_path)
-            except Exception as err:                             # noqa: B902 — reported as this sample's error
-                s.ok, s.error = False, "Error: call_sites failed for sample %s: %s: %s" % (s.name, type(err).__name__, err)
+                store.ingest_into([s.pileup for s in batch], vparams, VARSCAN_CAPACITY, bufs)
+            except BaseException as err:                     # noqa: B902 — handed to the main thread
+                failure.append(err)
+                bufs[4][:] = 1
 
-        for b0 in range(0, len(todo), INGEST_BATCH):
-            batch = todo[b0:b0 + INGEST_BATCH]
-            bufs = store.ingest_buffers(len(batch), VARSCAN_CAPACITY)
-            sites, counts, status, rcs, done = bufs
-            first = len(store)
-            failure = []
+        t_call = time.perf_counter()
+        th = threading.Thread(target=run_ingest)
+        th.start()
+        pending = list(range(len(batch)))
+        futures = []
+        while pending:
+            still = []
+            for k in pending:
+                if not done[k]:
+                    still.append(k)
+                    continue
+                s = batch[k]
+                s.store_index = first + k
+                if failure:
+                    continue
+                message = _ingest_failed(s, rcs[k], status[k, 0])
+                if message:
+                    s.fail(message)
+                elif counts[k] > VARSCAN_CAPACITY:
+                    redo.append(s)                           # more records than the shared array holds: alone, afterwards
+                else:
+                    futures.append(pool.submit(_finish_device_sample, job, s, sites[k, :counts[k]], int(status[k, 1])))
+            pending = still
+            if pending:
+                time.sleep(0.0005)
+        th.join()
+        job.lap("1a   of which: streamed ingest calls", t_call)
+        if failure:
+            raise failure[0]
+        t_tail = time.perf_counter()
+        for fu in futures:
+            fu.result()
+        job.lap("1b   of which: waiting for the last var.flt.vcf files", t_tail)
+    for s in redo:
+        ptr, nbytes = store.get(s.store_index)
+        try:
+            records, n_lines = dev.varscan_dev(ptr, nbytes, vparams, capacity=4 * VARSCAN_CAPACITY) if ptr else dev.varscan_file(s.pileup, vparams)
+            _finish_device_sample(job, s, records, n_lines)
+        except Exception as err:                             # noqa: B902
+            s.fail("Error: call_sites failed for sample %s: %s: %s" % (s.name, type(err).__name__, err))
+    pool.shutdown()
 
-            def run_ingest(batch=batch, bufs=bufs):
-                try:
-                    store.ingest_into([s.pileup for s in batch], vparams, VARSCAN_CAPACITY, bufs)
-                except BaseException as err:                     # noqa: B902 — handed to the main thread
-                    failure.append(err)
-                    bufs[4][:] = 1
 
-            t_call = time.perf_counter()
-            th = threading.Thread(target=run_ingest)
-            th.start()
-            pending = list(range(len(batch)))
-            futures = []
-            while pending:
-                still = []
-                for k in pending:
-                    if not done[k]:
-                        still.append(k)
-                        continue
-                    s = batch[k]
+def _ingest_only(job, todo):
+    """Modes ``varscan`` and ``existing``: the files are only made resident (snpgpu_pileups_ingest without parameters), in a
+    helper thread; meanwhile this thread's pool runs the VarScan jar where a var.flt.vcf is stale (``varscan``) or checks that
+    the files can serve as inputs (``existing`` — nothing under samples/*/var.flt.vcf is written), and reads the records."""
+    store = job.store
+    failure = []
+
+    def run_ingest():
+        try:
+            for b0 in range(0, len(todo), INGEST_BATCH):
+                batch = todo[b0:b0 + INGEST_BATCH]
+                bufs = store.ingest_buffers(len(batch), 0)
+                first = len(store)
+                store.ingest_into([s.pileup for s in batch], None, 0, bufs)
+                for k, s in enumerate(batch):
                     s.store_index = first + k
-                    if failure:
-                        continue
-                    if rcs[k] == L.E_IO:
-                        s.ok, s.error = False, "Error: cannot open or read the pileup file %s" % s.pileup
-                    elif rcs[k] == L.E_PILEUP:
-                        s.ok, s.error = False, "Error: call_sites failed for sample %s: ValueError: Invalid format for pileup at byte %d of %s" % (
-                            s.name, int(status[k, 0]), s.pileup)
-                    elif rcs[k] != 0:
-                        s.ok, s.error = False, "Error: call_sites failed for sample %s (device error %d)" % (s.name, int(rcs[k]))
-                    elif counts[k] > VARSCAN_CAPACITY:
-                        redo.append(s)                           # more records than the shared array holds: alone, afterwards
-                    else:
-                        futures.append(pool.submit(finish_sample, s, sites[k, :counts[k]], int(status[k, 1])))
-                pending = still
-                if pending:
-                    time.sleep(0.0005)
-            th.join()
-            lap("1a   of which: streamed ingest calls", t_call)
-            if failure:
-                raise failure[0]
-            t_tail = time.perf_counter()
-            for fu in futures:
-                fu.result()
-            lap("1b   of which: waiting for the last var.flt.vcf files", t_tail)
-        for s in redo:
-            ptr, nbytes = store.get(s.store_index)
-            try:
-                records, n_lines = dev.varscan_dev(ptr, nbytes, vparams, capacity=4 * VARSCAN_CAPACITY) if ptr else dev.varscan_file(s.pileup, vparams)
-                finish_sample(s, records, n_lines)
-            except Exception as err:                             # noqa: B902
-                s.ok, s.error = False, "Error: call_sites failed for sample %s: %s: %s" % (s.name, type(err).__name__, err)
-        pool.shutdown()
-        lap("1 ingest + site calling", t0)
+                    message = _ingest_failed(s, bufs[3][k], bufs[2][k, 0])
+                    if message and s.ok:
+                        s.fail(message)
+        except BaseException as err:                         # noqa: B902 — handed to the main thread
+            failure.append(err)
 
-        # ================================ 2: C1 + filter_regions + merge_sites x 2 =========================================
-        t0 = time.perf_counter()
-        # every rank learns every sample's records: contig names as objects (a few strings), the records as one all-gather
-        local_names = sorted({c for s in mine if s.ok for c in s.sites[0]})
-        contigs = sorted({c for names in comm.gather_objects(local_names) for c in names})
-        cid = {c: i for i, c in enumerate(contigs)}
-        rec_count = np.zeros(hi - lo, dtype=np.int64)
-        keys_local = []
-        for k, s in enumerate(mine):
-            if not s.ok:
-                rec_count[k] = -1                                # no var.flt.vcf: the steps below report it missing
-                continue
+    t_call = time.perf_counter()
+    th = threading.Thread(target=run_ingest)
+    th.start()
+    t_sites = time.perf_counter()
+    try:
+        if job.site_calling == "existing":
+            for s in todo:
+                message = cs.check_existing_vcf(s.pileup, os.path.join(s.dir, "var.flt.vcf"))
+                if message:
+                    s.fail(message)
+        else:
+            stale = [s for s in todo if job.args.forceFlag or utils.target_needs_rebuild([s.pileup], os.path.join(s.dir, "var.flt.vcf"))]
+            if stale:
+                jar = cs.find_path_in_path_list("VarScan", "CLASSPATH")
+                verbose_print("# %s %s  (and so on: %d samples)" % (utils.timestamp(), cs.varscan_command_line(jar or "VarScan.jar", stale[0].pileup), len(stale)))
+            for s, message in zip(stale, cs.run_varscan_jar_many([(s.pileup, os.path.join(s.dir, "var.flt.vcf")) for s in stale])):
+                if message:
+                    s.fail(message)
+        with concurrent.futures.ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // 4))) as pool:
+            list(pool.map(_read_sample_vcf, [s for s in todo if s.ok]))
+        job.lap("1c   of which: var.flt.vcf files (%s) beside the ingest" % job.site_calling, t_sites)
+    finally:
+        th.join()
+    job.lap("1a   of which: streamed ingest calls", t_call)
+    if failure:
+        raise failure[0]
+
+
+def _local_site_keys(job):
+    """The rank's records as (contig id << 32 | position) keys over a rank-local contig table; ids are made global in the next
+    stage.  Fails here — before any collective — for a position no pileup can have."""
+    keys, rec_count = [], np.zeros(job.hi - job.lo, dtype=np.int64)
+    job.local_names = sorted({c for s in job.mine if s.ok for c in s.sites[0]})
+    for k, s in enumerate(job.mine):
+        if not s.ok:
+            rec_count[k] = -1                                # no var.flt.vcf: the steps below report it missing
+            continue
+        _, _, pos = s.sites
+        if len(pos) and (pos.min() < 0 or pos.max() >= (1 << 32)):
+            raise ValueError("VCF position out of range")    # as merge_sites (utils.py:1127 has no such record either)
+        rec_count[k] = len(pos)
+    job.rec_count_local = rec_count
+
+
+def stage_ingest_and_sites(job):
+    """Adds: per sample ``store_index`` and, for the samples that are still ok, ``header / vcf_lines / sites`` of its var.flt.vcf;
+    ``local_names`` and ``rec_count_local`` for the gather of the next stage."""
+    t0 = time.perf_counter()
+    for s in job.mine:
+        if utils.verify_non_empty_input_files("Pileup file", [s.pileup]) > 0:
+            s.fail("Error: cannot process sample %s without its pileup file." % s.name)
+    job.arena_thread = threading.Thread(target=_alloc_arenas, args=(job,))
+    job.arena_thread.start()
+    todo = [s for s in job.mine if s.ok]
+    verbose_print("# site calling mode: %s" % job.site_calling)
+    if job.site_calling == "device":
+        _ingest_with_device_site_calling(job, todo)
+    else:
+        _ingest_only(job, todo)
+    _local_site_keys(job)
+    job.lap("1 ingest + site calling", t0)
+
+
+# ==================================== stage 2: C1 + filter_regions + merge_sites x 2 ==========================================
+def _unique_per_sample(job, keep):
+    """Distinct (contig, position) pairs per sample among the records `keep` selects (the size of merge_sites' snp_set)."""
+    pairs = np.unique(np.stack([job.rec_sample[keep], job.all_keys[keep]]), axis=1)
+    return np.bincount(pairs[0], minlength=job.n_total)
+
+
+def _site_union(job, keep, which):
+    """merge_sites.py:91-117 over the records `keep`: --maxsnps sample exclusion, then the union with its carriers."""
+    n_total, samples, rank = job.n_total, job.samples, job.rank
+    excluded = np.zeros(n_total, bool)
+    if job.ms_args.maxSnps >= 0:
+        per = _unique_per_sample(job, keep)
+        excluded = job.has_vcf & (per > job.ms_args.maxSnps)
+        if rank == 0:
+            for i in np.flatnonzero(excluded):
+                verbose_print("Excluding sample %s having %d snps." % (samples[i].name, per[i]))
+    inc = job.has_vcf & ~excluded
+    carrier_ids = np.flatnonzero(inc)                        # carriers are indices into the INCLUDED samples, sorted-dir order
+    remap = np.full(n_total, -1, dtype=np.int64)
+    remap[carrier_ids] = np.arange(len(carrier_ids))
+    use = keep & inc[job.rec_sample]
+    if use.any():
+        uniq, off, car = job.dev.merge_sites(job.all_keys[use].astype(np.uint64), remap[job.rec_sample[use]].astype(np.uint32))
+    else:
+        uniq, off, car = np.zeros(0, np.uint64), np.zeros(1, np.uint32), np.zeros(0, np.uint32)
+    if rank == 0:
+        verbose_print("Found %d snp positions across %d sample vcf files." % (len(uniq), n_total))
+        ms.write_snplist(job.outputs[which], job.contigs, uniq, off, car, [samples[i].name for i in carrier_ids])
+        with open(job.filtered1 if which == "snplist" else job.filtered2, "w") as f:
+            for d in job.unsorted_dirs:                      # original order (merge_sites.py:127-131)
+                if not excluded[job.dir_index[d]]:
+                    f.write("%s\n" % d)
+    return uniq.astype(np.int64), excluded
+
+
+def stage_site_union_and_regions(job):
+    """Collectives first (contig names, record keys, record counts), then identical work on every rank.  Adds: ``contigs``,
+    ``all_keys`` / ``rec_off`` / ``rec_sample`` (every sample's records), ``has_vcf``, ``list1`` / ``list2`` (the two site unions),
+    ``excluded1`` / ``excluded2``, per sample ``removed``, and the futures of the split VCF writers (``split_files``)."""
+    torch, comm, sharding = job.torch, job.comm, job.sharding
+    n_total, samples, mine, dev = job.n_total, job.samples, job.mine, job.dev
+    t0 = time.perf_counter()
+    # every rank learns every sample's records: contig names as objects (a few strings), the records as one all-gather
+    job.contigs = contigs = sorted({c for names in comm.gather_objects(job.local_names) for c in names})
+    cid = {c: i for i, c in enumerate(contigs)}
+    keys_local = []
+    for s in mine:
+        if s.ok:
             names, cidx, pos = s.sites
-            if len(pos) and (pos.min() < 0 or pos.max() >= (1 << 32)):
-                raise ValueError("VCF position out of range")    # as merge_sites (utils.py:1127 has no such record either)
             lut = np.asarray([cid[c] for c in names] + [0], dtype=np.int64)
             keys_local.append((lut[cidx.astype(np.int64)] << 32) | pos)
-            rec_count[k] = len(pos)
-        keys_local = np.concatenate(keys_local) if keys_local else np.zeros(0, np.int64)
-        if world > 1:
-            dv = "cpu" if comm.one_gpu else "cuda"
-            all_keys, _ = sharding.all_gather_varlen(torch.from_numpy(keys_local).to(dv))
-            all_cnt, _ = sharding.all_gather_varlen(torch.from_numpy(rec_count).to(dv))
-            all_keys, all_cnt = all_keys.cpu().numpy(), all_cnt.cpu().numpy()
-        else:
-            all_keys, all_cnt = keys_local, rec_count
-        has_vcf = all_cnt >= 0
-        cnt0 = np.maximum(all_cnt, 0)
-        rec_off = np.zeros(n_total + 1, dtype=np.int64)
-        np.cumsum(cnt0, out=rec_off[1:])
-        rec_sample = np.repeat(np.arange(n_total, dtype=np.int64), cnt0)
-        rec_cid = (all_keys >> 32).astype(np.uint32)
-        rec_pos = all_keys & 0xFFFFFFFF
-        n_bad = int((~has_vcf).sum())
-        if rank == 0:
-            if n_bad == n_total:
-                utils.global_error("Error: all %d VCF files were missing or empty." % n_bad)
-            elif n_bad > 0:
+    keys_local = np.concatenate(keys_local) if keys_local else np.zeros(0, np.int64)
+    if job.world > 1:
+        dv = "cpu" if comm.one_gpu else "cuda"
+        all_keys, _ = sharding.all_gather_varlen(torch.from_numpy(keys_local).to(dv))
+        all_cnt, _ = sharding.all_gather_varlen(torch.from_numpy(job.rec_count_local).to(dv))
+        all_keys, all_cnt = all_keys.cpu().numpy(), all_cnt.cpu().numpy()
+    else:
+        all_keys, all_cnt = keys_local, job.rec_count_local
+    job.all_keys = all_keys
+    job.has_vcf = has_vcf = all_cnt >= 0
+    cnt0 = np.maximum(all_cnt, 0)
+    job.rec_off = rec_off = np.zeros(n_total + 1, dtype=np.int64)
+    np.cumsum(cnt0, out=rec_off[1:])
+    job.rec_sample = rec_sample = np.repeat(np.arange(n_total, dtype=np.int64), cnt0)
+    rec_cid = (all_keys >> 32).astype(np.uint32)
+    rec_pos = all_keys & 0xFFFFFFFF
+    n_bad = int((~has_vcf).sum())
+    if n_bad == n_total:                                     # every rank sees the same counts: all leave, rank 0 says why
+        if job.rank == 0:
+            utils.global_error("Error: all %d VCF files were missing or empty." % n_bad)
+        sys.exit(100)
+    elif n_bad > 0:
+        # a sample without var.flt.vcf.  Under StopOnSampleError the pipeline ends here, as it does when the call_sites array or
+        # merge_sites reports it (run.py stops at the first failed step) — on EVERY rank: each says what failed for its own samples
+        if utils._stop_on_sample_error():
+            for s in mine:
+                if not s.ok:
+                    utils.sample_error(s.error, continue_possible=True)          # (exits 100)
+            if job.rank == 0:
                 utils.sample_error("Error: %d VCF files were missing or empty." % n_bad, continue_possible=True)
+            sys.exit(100)
+        if job.rank == 0:
+            utils.sample_error("Error: %d VCF files were missing or empty." % n_bad, continue_possible=True)
 
-        def unique_per_sample(keep):
-            """Distinct (contig, position) pairs per sample among the records `keep` selects (the size of merge_sites' snp_set)."""
-            pairs = np.unique(np.stack([rec_sample[keep], all_keys[keep]]), axis=1)
-            return np.bincount(pairs[0], minlength=n_total)
+    every = np.ones(len(all_keys), dtype=bool)
+    job.lap("2a   of which: gathering the records", t0)
+    t2 = time.perf_counter()
+    job.list1, job.excluded1 = _site_union(job, every, "snplist")
+    job.lap("2b   of which: site union + snplist.txt", t2)
+    t2 = time.perf_counter()
 
-        def site_union(keep, which):
-            """merge_sites.py:91-117 over the records `keep`: --maxsnps sample exclusion, then the union with its carriers."""
-            excluded = np.zeros(n_total, bool)
-            if ms_args.maxSnps >= 0:
-                per = unique_per_sample(keep)
-                excluded = has_vcf & (per > ms_args.maxSnps)
-                if rank == 0:
-                    for i in np.flatnonzero(excluded):
-                        verbose_print("Excluding sample %s having %d snps." % (samples[i].name, per[i]))
-            inc = has_vcf & ~excluded
-            carrier_ids = np.flatnonzero(inc)                    # carriers are indices into the INCLUDED samples, sorted-dir order
-            remap = np.full(n_total, -1, dtype=np.int64)
-            remap[carrier_ids] = np.arange(len(carrier_ids))
-            use = keep & inc[rec_sample]
-            if use.any():
-                uniq, off, car = dev.merge_sites(all_keys[use].astype(np.uint64), remap[rec_sample[use]].astype(np.uint32))
-            else:
-                uniq, off, car = np.zeros(0, np.uint64), np.zeros(1, np.uint32), np.zeros(0, np.uint32)
-            if rank == 0:
-                verbose_print("Found %d snp positions across %d sample vcf files." % (len(uniq), n_total))
-                ms.write_snplist(outputs[which], contigs, uniq, off, car, [samples[i].name for i in carrier_ids])
-                with open(filtered1 if which == "snplist" else filtered2, "w") as f:
-                    for d in unsorted_dirs:                      # original order (merge_sites.py:127-131)
-                        if not excluded[dir_index[d]]:
-                            f.write("%s\n" % d)
-            return uniq.astype(np.int64), excluded
+    # filter_regions (filter_regions.py:205-383): dense windows + contig edges -> merged bad regions -> classification of
+    # every record; mode all unions the regions over the samples, mode each keeps them per sample; outgroup samples bypass
+    fr_args = job.fr_args
+    outgroup = set()
+    if fr_args.outGroupFile is not None:
+        if utils.verify_non_empty_input_files("File of outgroup samples", [fr_args.outGroupFile]) > 0:
+            utils.global_error(None)
+        with open(fr_args.outGroupFile, "r") as f:
+            outgroup = {line.rstrip() for line in f}
+    try:
+        contig_lengths = utils.read_fasta_lengths(job.ref_path)
+    except (IOError, OSError, UnicodeDecodeError):
+        utils.global_error("Error: cannot open the reference fastq file, or fail to read the contigs in the reference fastq file.")
+    job.is_out = is_out = np.asarray([s.name in outgroup for s in samples], dtype=bool)
+    filt = has_vcf & ~is_out                                 # the samples that take part in the region step
+    filt_ids = np.flatnonzero(filt)
+    part_rank = np.full(n_total, -1, dtype=np.int64)
+    part_rank[filt_ids] = np.arange(len(filt_ids))
+    takes_part = filt[rec_sample]
+    job.lap("2c   of which: (records laid out)", t2)
+    t2 = time.perf_counter()
+    removed = np.zeros(len(all_keys), dtype=bool)
+    removed[takes_part] = fr.removed_flags(dev, contigs, contig_lengths, part_rank[rec_sample[takes_part]], rec_cid[takes_part], rec_pos[takes_part],
+                                           len(filt_ids), fr_args.edgeLength, fr_args.maxSnpsList, fr_args.windowSizeList, per_sample=fr_args.mode == "each")
+    preserved = every & ~removed
+    job.lap("2d   of which: dense windows, region merge, classification", t2)
+    t2 = time.perf_counter()
+    job.list2, job.excluded2 = _site_union(job, preserved, "snplist_p")
+    job.lap("2e   of which: preserved site union + snplist_preserved.txt", t2)
+    t2 = time.perf_counter()
+    # the split VCF files of this rank's samples: written by host threads while the consensus stage keeps the device busy
+    job.split_pool = concurrent.futures.ThreadPoolExecutor(max_workers=4)
+    job.split_files = []
+    for s in mine:
+        if not s.ok:
+            continue
+        vcf_path = os.path.join(s.dir, "var.flt.vcf")
+        if is_out[s.index]:
+            job.split_files.append(job.split_pool.submit(fr.write_outgroup_preserved_and_removed_vcf_files, vcf_path, s.header))
+        else:
+            s.removed = removed[rec_off[s.index]:rec_off[s.index + 1]]
+            job.split_files.append(job.split_pool.submit(fr.write_preserved_and_removed_vcf_files, vcf_path, s.header, s.vcf_lines, s.removed))
+    job.lap("2f   of which: var.flt_preserved / _removed.vcf files handed to writer threads", t2)
+    job.lap("2 site union + region filter", t0)
 
-        dir_index = {d: i for i, d in enumerate(sorted_dirs)}
-        every = np.ones(len(all_keys), dtype=bool)
-        lap("2a   of which: gathering the records", t0)
-        t2 = time.perf_counter()
-        list1, excluded1 = site_union(every, "snplist")
-        lap("2b   of which: site union + snplist.txt", t2)
-        t2 = time.perf_counter()
 
-        # filter_regions (filter_regions.py:205-383): dense windows + contig edges -> merged bad regions -> classification of
-        # every record; mode all unions the regions over the samples, mode each keeps them per sample; outgroup samples bypass
-        outgroup = set()
-        if fr_args.outGroupFile is not None:
-            if utils.verify_non_empty_input_files("File of outgroup samples", [fr_args.outGroupFile]) > 0:
-                utils.global_error(None)
-            with open(fr_args.outGroupFile, "r") as f:
-                outgroup = {line.rstrip() for line in f}
-        try:
-            contig_lengths = utils.read_fasta_lengths(ref_path)
-        except (IOError, OSError, UnicodeDecodeError):
-            utils.global_error("Error: cannot open the reference fastq file, or fail to read the contigs in the reference fastq file.")
-        is_out = np.asarray([s.name in outgroup for s in samples], dtype=bool)
-        filt = has_vcf & ~is_out                                 # the samples that take part in the region step
-        filt_ids = np.flatnonzero(filt)
-        part_rank = np.full(n_total, -1, dtype=np.int64)
-        part_rank[filt_ids] = np.arange(len(filt_ids))
-        takes_part = filt[rec_sample]
-        lap("2c   of which: (records laid out)", t2)
-        t2 = time.perf_counter()
-        removed = np.zeros(len(all_keys), dtype=bool)
-        removed[takes_part] = fr.removed_flags(dev, contigs, contig_lengths, part_rank[rec_sample[takes_part]], rec_cid[takes_part], rec_pos[takes_part],
-                                               len(filt_ids), fr_args.edgeLength, fr_args.maxSnpsList, fr_args.windowSizeList, per_sample=fr_args.mode == "each")
-        preserved = every & ~removed
-        lap("2d   of which: dense windows, region merge, classification", t2)
-        t2 = time.perf_counter()
-        list2, excluded2 = site_union(preserved, "snplist_p")
-        lap("2e   of which: preserved site union + snplist_preserved.txt", t2)
-        t2 = time.perf_counter()
-        # the split VCF files of this rank's samples: written by host threads while step 3 keeps the device busy
-        split_pool = concurrent.futures.ThreadPoolExecutor(max_workers=4)
-        split_files = []
-        for s in mine:
+# ==================================== stage 3: both consensus flows from one scan + call ======================================
+class _Flows(object):
+    """What the consensus stage works with: the site set (snplist.txt, the rank's own removed positions, what only
+    snplist_preserved.txt has), the column maps of the two flows, device and host result arrays."""
+
+
+def _prepare_flows(job):
+    torch, dev, mine = job.torch, job.dev, job.mine
+    cc_args = job.cc_args
+    fl = _Flows()
+    list1, list2, all_keys, rec_off = job.list1, job.list2, job.all_keys, job.rec_off
+    # the site set: snplist.txt, plus removed positions of this rank's samples that are not in it (a sample merge_sites
+    # excluded for --maxsnps is still called, run.py:704-718, and its exclude list is parsed: call_consensus.py:147-151),
+    # plus what snplist_preserved.txt has and snplist.txt has not: with --maxsnps a sample can be out of the first list for its
+    # var.flt.vcf and in the second for its shorter var.flt_preserved.vcf (found by tools/fuzz_jobs.py)
+    fl.own_removed = {s.index: (all_keys[rec_off[s.index]:rec_off[s.index + 1]][s.removed] if (s.ok and s.removed is not None) else np.zeros(0, np.int64))
+                      for s in mine}
+    extra = np.setdiff1d(np.concatenate(list(fl.own_removed.values())) if fl.own_removed else np.zeros(0, np.int64), list1)
+    set_keys = list1
+    for more in (extra, np.setdiff1d(list2, list1)):
+        if len(more):
+            set_keys = np.union1d(set_keys, more)
+    fl.set_keys = set_keys
+    fl.S = S = len(set_keys)
+    fl.S1, fl.S2 = S1, S2 = len(list1), len(list2)
+    cols1 = np.searchsorted(set_keys, list1).astype(np.uint32)
+    cols2 = np.searchsorted(set_keys, list2).astype(np.uint32)
+    fl.in1 = in1 = np.zeros(S, dtype=np.uint8)
+    in1[cols1] = 1
+    fl.in2 = in2 = np.zeros(S, dtype=np.uint8)
+    in2[cols2] = 1
+    col_of2 = np.full(S, -1, dtype=np.int32)
+    col_of2[cols2] = np.arange(len(cols2), dtype=np.int32)
+    fl.contig_bytes = [c.encode("utf-8") for c in job.contigs]
+    fl.ss = devmod.SiteSet.from_arrays(dev, fl.contig_bytes, set_keys.astype(np.uint64), in1 * np.uint8(L.SITE_IN_SNPLIST))
+    fl.identity1 = len(set_keys) == len(list1)
+    fl.prm = devmod.make_params(cc_args.minBaseQual, cc_args.minConsFreq, cc_args.minConsDpth, cc_args.minConsStrdDpth, cc_args.minConsStrdBias)
+    # collect_metrics by-products (call_consensus --amdMetricsRefFasta, given through CallConsensus_ExtraParams): the depth
+    # column is summed by the same scan, the gaps are counted in the rows that are written anyway
+    fl.metrics_ref = getattr(cc_args, "amdMetricsRefFasta", None)
+    fl.metrics_ref_len = sum(utils.read_fasta_lengths(fl.metrics_ref).values()) if fl.metrics_ref else 0
+    fl.filters_desc = vcf_writer.filter_descriptions(cc_args.minConsFreq, cc_args.minConsDpth, cc_args.minConsStrdDpth, cc_args.minConsStrdBias)
+    fl.filter_names = [n for n, _ in fl.filters_desc]
+    fl.d_cols1, fl.d_cols2 = torch.from_numpy(cols1.astype(np.int32)).cuda(), torch.from_numpy(cols2.astype(np.int32)).cuda()
+    fl.d_col_of2 = torch.from_numpy(col_of2).cuda()
+    fl.d_col_of1 = torch.from_numpy(np.where(in1 != 0, np.cumsum(in1, dtype=np.int64) - 1, -1).astype(np.int32)).cuda()
+    fl.d_in12 = torch.from_numpy((in1 | in2).astype(bool)).cuda()     # the positions every sample of the job is asked about
+    fl.d_err = torch.zeros(4, dtype=torch.int32, device="cuda")
+    job.callable_ = callable_ = [s for s in mine if s.ok]
+    fl.n_local = n_local = len(callable_)
+    job.rows1 = torch.full((max(n_local, 1), max(S1, 1)), 0x2D, dtype=torch.uint8, device="cuda")     # the consensus rows, for stage 4
+    job.rows2 = torch.full((max(n_local, 1), max(S2, 1)), 0x2D, dtype=torch.uint8, device="cuda")
+    job.row_ok = np.zeros(n_local, dtype=bool)
+    want_vcf = job.want_vcf
+    fl.per_sample_bytes = max(S1, 1) + max(S2, 1) + 2 * max(S, 1) + 8 * max(S, 1) + 32 + (128 * max(S, 1) if want_vcf else 0) + 64
+    fl.group = max(1, min(256, job.group_bytes // fl.per_sample_bytes))
+    if n_local >= 32:
+        fl.group = min(fl.group, (n_local + 1) // 2)       # at least two groups: the files of one are written while the next is on the device
+    fl.g_alloc = g_alloc = min(fl.group, max(n_local, 1))
+    fl.d_base = torch.empty((g_alloc, max(S, 1)), dtype=torch.uint8, device="cuda")
+    fl.d_filt = torch.empty((g_alloc, max(S, 1)), dtype=torch.uint8, device="cuda")
+    fl.d_filt2 = torch.empty((g_alloc, max(S, 1)), dtype=torch.uint8, device="cuda")
+    fl.d_line = torch.zeros((g_alloc, max(S, 1)), dtype=torch.int64, device="cuda")
+    fl.d_status = torch.empty((g_alloc, 4), dtype=torch.int64, device="cuda")
+    fl.d_counts = torch.empty((g_alloc, max(S, 1), 128), dtype=torch.uint8, device="cuda") if want_vcf else None
+    fl.host_sets = [None, None]
+    fl.vcf_date = datetime.datetime.now()
+    return fl
+
+
+def _host_set(job, fl, k):
+    """Result arrays of one group, carved out of arena k (allocated while the pileups were streaming in)."""
+    torch = job.torch
+    S, S1, S2, g_alloc = fl.S, fl.S1, fl.S2, fl.g_alloc
+    need = g_alloc * fl.per_sample_bytes + 4096
+    if job.arenas[k] is None or job.arenas[k].numel() < need:
+        job.arenas[k] = torch.from_numpy(np.zeros(need, dtype=np.uint8))
+    at = [0]
+
+    def carve(shape, dtype):
+        nbytes = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
+        start = (at[0] + 63) // 64 * 64
+        at[0] = start + nbytes
+        return job.arenas[k][start:start + nbytes].view(dtype).view(*shape)
+
+    return {"g": g_alloc,
+            "status": carve((g_alloc, 4), torch.int64),
+            "line": carve((g_alloc, max(S, 1)), torch.int64),
+            "counts": carve((g_alloc, max(S, 1), 128), torch.uint8) if job.want_vcf else None,
+            "base1": carve((g_alloc, max(S1, 1)), torch.uint8),
+            "base2": carve((g_alloc, max(S2, 1)), torch.uint8),
+            "filt1": carve((g_alloc, max(S, 1)), torch.uint8),
+            "filt2": carve((g_alloc, max(S, 1)), torch.uint8)}
+
+
+def _write_group(job, fl, part, hs, vcf_later, spill=None):
+    """FASTA + VCF files of one group, both flows (host threads inside the library); returns the samples that failed."""
+    cc_args, want_vcf = job.cc_args, job.want_vcf
+    S, S1, S2 = fl.S, fl.S1, fl.S2
+    jobs, owners = [], []
+    counts_np = hs["counts"].numpy().view(devmod.COUNTS_DTYPE).reshape(hs["g"], max(S, 1)) if want_vcf else None
+    for k, s in enumerate(part):
+        if not s.ok:
+            continue
+        for flow in (1, 2):
+            seq = (hs["base1"] if flow == 1 else hs["base2"]).numpy()[k, :(S1 if flow == 1 else S2)]
+            item = {"fasta_path": os.path.join(s.dir, "consensus.fasta" if flow == 1 else "consensus_preserved.fasta"),
+                    "fasta_id": s.name.encode("utf-8"), "sequence": seq}
+            if want_vcf and s.index not in vcf_later:
+                hdr = "\n".join(vcf_writer.header_lines(s.name, fl.filters_desc, cc_args.vcfRefName, now=fl.vcf_date)) + "\n"
+                item.update({"vcf_path": os.path.join(s.dir, "consensus.vcf" if flow == 1 else "consensus_preserved.vcf"),
+                             "vcf_header": hdr.encode("utf-8"), "counts": counts_np[k], "line_off": hs["line"].numpy()[k].view(np.uint64),
+                             "row_filters": (hs["filt1"] if flow == 1 else hs["filt2"]).numpy()[k],
+                             "site_in_flow": fl.in1 if flow == 1 else fl.in2})
+            jobs.append(item)
+            owners.append(s)
+    res = devmod.write_consensus_files(jobs, fl.ss, fl.filter_names, cc_args.vcfPreserveRefCase, cc_args.vcfFailedSnpGt, n_threads=job.args.writerThreads,
+                                       spill=spill)
+    if fl.metrics_ref:                                       # as call_consensus._record_metrics does for the two flows, in their order
+        st_h = hs["status"].numpy()
+        for k, s in enumerate(part):
             if not s.ok:
                 continue
-            vcf_path = os.path.join(s.dir, "var.flt.vcf")
-            if is_out[s.index]:
-                split_files.append(split_pool.submit(fr.write_outgroup_preserved_and_removed_vcf_files, vcf_path, s.header))
-            else:
-                s.removed = removed[rec_off[s.index]:rec_off[s.index + 1]]
-                split_files.append(split_pool.submit(fr.write_preserved_and_removed_vcf_files, vcf_path, s.header, s.vcf_lines, s.removed))
-        lap("2f   of which: var.flt_preserved / _removed.vcf files handed to writer threads", t2)
-        lap("2 site union + region filter", t0)
+            name = os.path.basename(cc_args.amdMetricsFile) if cc_args.amdMetricsFile else "metrics"
+            depth_sum = int(st_h[k, 3]) & 0xFFFFFFFFFFFFFFFF
+            ave = {"avePileupDepth": "%.2f" % (float(depth_sum) / float(fl.metrics_ref_len))} if depth_sum > 0 and fl.metrics_ref_len > 0 else {}
+            for key, row, n in (("missingPos", hs["base1"], S1), ("missingPosPreserved", hs["base2"], S2)):
+                updates = {key: str(int(np.count_nonzero(row.numpy()[k, :n] == 0x2D)))}
+                updates.update(ave)
+                utils.update_properties(os.path.join(s.dir, name), updates, keep_mtime=True)
+    bad = []
+    for s, item, (rc, _) in zip(owners, jobs, res):
+        if rc == L.E_UNSUPPORTED:
+            bad.append((s, "Error: call_consensus failed for sample %s: ValueError: a position has more than %d distinct symbols" % (s.name, L.MAX_SYMS)))
+        elif rc != 0:
+            bad.append((s, "Error: cannot write %s" % item["fasta_path"]))
+    return bad
 
-        # ================================ 3: both consensus flows from one scan + call =====================================
-        t0 = time.perf_counter()
-        prm = devmod.make_params(cc_args.minBaseQual, cc_args.minConsFreq, cc_args.minConsDpth, cc_args.minConsStrdDpth, cc_args.minConsStrdBias)
-        # the site set: snplist.txt, plus removed positions of this rank's samples that are not in it (a sample merge_sites
-        # excluded for --maxsnps is still called, run.py:704-718, and its exclude list is parsed: call_consensus.py:147-151),
-        # plus what snplist_preserved.txt has and snplist.txt has not: with --maxsnps a sample can be out of the first list for its
-        # var.flt.vcf and in the second for its shorter var.flt_preserved.vcf (found by tools/fuzz_jobs.py)
-        own_removed = {s.index: (all_keys[rec_off[s.index]:rec_off[s.index + 1]][s.removed] if (s.ok and s.removed is not None) else np.zeros(0, np.int64))
-                       for s in mine}
-        extra = np.setdiff1d(np.concatenate(list(own_removed.values())) if own_removed else np.zeros(0, np.int64), list1)
-        set_keys = list1
-        for more in (extra, np.setdiff1d(list2, list1)):
-            if len(more):
-                set_keys = np.union1d(set_keys, more)
-        S = len(set_keys)
-        cols1 = np.searchsorted(set_keys, list1).astype(np.uint32)
-        cols2 = np.searchsorted(set_keys, list2).astype(np.uint32)
-        in1 = np.zeros(S, dtype=np.uint8)
-        in1[cols1] = 1
-        in2 = np.zeros(S, dtype=np.uint8)
-        in2[cols2] = 1
-        col_of2 = np.full(S, -1, dtype=np.int32)
-        col_of2[cols2] = np.arange(len(cols2), dtype=np.int32)
-        ss = devmod.SiteSet.from_arrays(dev, [c.encode("utf-8") for c in contigs], set_keys.astype(np.uint64), in1 * np.uint8(L.SITE_IN_SNPLIST))
-        lap("3-   of which: site set", t0)
-        identity1 = len(set_keys) == len(list1)
-        S1, S2 = len(list1), len(list2)
-        # collect_metrics by-products (call_consensus --amdMetricsRefFasta, given through CallConsensus_ExtraParams): the depth
-        # column is summed by the same scan, the gaps are counted in the rows that are written anyway
-        metrics_ref = getattr(cc_args, "amdMetricsRefFasta", None)
-        metrics_ref_len = sum(utils.read_fasta_lengths(metrics_ref).values()) if metrics_ref else 0
-        filters_desc = vcf_writer.filter_descriptions(cc_args.minConsFreq, cc_args.minConsDpth, cc_args.minConsStrdDpth, cc_args.minConsStrdBias)
-        filter_names = [n for n, _ in filters_desc]
-        d_cols1, d_cols2 = torch.from_numpy(cols1.astype(np.int32)).cuda(), torch.from_numpy(cols2.astype(np.int32)).cuda()
-        d_col_of2 = torch.from_numpy(col_of2).cuda()
-        d_col_of1 = torch.from_numpy(np.where(in1 != 0, np.cumsum(in1, dtype=np.int64) - 1, -1).astype(np.int32)).cuda()
-        d_err = torch.zeros(4, dtype=torch.int32, device="cuda")
-        callable_ = [s for s in mine if s.ok]
-        n_local = len(callable_)
-        rows1 = torch.full((max(n_local, 1), max(S1, 1)), 0x2D, dtype=torch.uint8, device="cuda")     # the consensus rows, for step 4
-        rows2 = torch.full((max(n_local, 1), max(S2, 1)), 0x2D, dtype=torch.uint8, device="cuda")
-        row_ok = np.zeros(n_local, dtype=bool)
-        writer = concurrent.futures.ThreadPoolExecutor(max_workers=1)
-        per_sample_bytes = max(S1, 1) + max(S2, 1) + 2 * max(S, 1) + 8 * max(S, 1) + 32 + (128 * max(S, 1) if want_vcf else 0) + 64
-        group = max(1, min(256, group_bytes // per_sample_bytes))
-        if n_local >= 32:
-            group = min(group, (n_local + 1) // 2)             # at least two groups: the files of one are written while the next is on the device
-        g_alloc = min(group, max(n_local, 1))
-        arena_thread.join()
-        h2d_extra = [0]
 
-        def host_set(k):
-            """Result arrays of one group, carved out of arena k (allocated while the pileups were streaming in)."""
-            need = g_alloc * per_sample_bytes + 4096
-            if arenas[k] is None or arenas[k].numel() < need:
-                arenas[k] = torch.from_numpy(np.zeros(need, dtype=np.uint8))
-            at = [0]
+def _wanted_mask(fl, s):
+    """The slots of the site set THIS sample's two call_consensus runs are asked about (call_consensus.py:147-151): snplist.txt,
+    snplist_preserved.txt and its own removed positions.  The set also holds other samples' removed positions; the reference
+    builds no Record at those for this sample."""
+    wanted = (fl.in1 | fl.in2).astype(bool)
+    own = fl.own_removed[s.index]
+    if len(own):
+        wanted[np.searchsorted(fl.set_keys, own)] = True
+    return wanted
 
-            def carve(shape, dtype):
-                nbytes = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
-                start = (at[0] + 63) // 64 * 64
-                at[0] = start + nbytes
-                return arenas[k][start:start + nbytes].view(dtype).view(*shape)
 
-            return {"g": g_alloc,
-                    "status": carve((g_alloc, 4), torch.int64),
-                    "line": carve((g_alloc, max(S, 1)), torch.int64),
-                    "counts": carve((g_alloc, max(S, 1), 128), torch.uint8) if want_vcf else None,
-                    "base1": carve((g_alloc, max(S1, 1)), torch.uint8),
-                    "base2": carve((g_alloc, max(S2, 1)), torch.uint8),
-                    "filt1": carve((g_alloc, max(S, 1)), torch.uint8),
-                    "filt2": carve((g_alloc, max(S, 1)), torch.uint8)}
+def _check_repeated_lines(job, fl, s, status_row):
+    """The pileup repeats a listed position.  The last line of a position is the one that counts for the consensus
+    (call_consensus.py:171-176) and that is what the device returned; but the reference builds a Record from every such line —
+    it ends at the first it cannot build — and writes a consensus.vcf row for each.  The all-lines pass looks at them now,
+    with the sample's OWN positions flagged as listed.  Returns the exception the reference would end with, or None."""
+    wanted = _wanted_mask(fl, s)
+    own_set = devmod.SiteSet.from_arrays(job.dev, fl.contig_bytes, fl.set_keys.astype(np.uint64), wanted.astype(np.uint8) * np.uint8(L.SITE_IN_SNPLIST))
+    try:
+        _, line_flags, line_counts = job.dev.call_all_lines(own_set, s.pileup, fl.prm, check=False)
+        err, _ = devmod.Device.site_error(devmod.ConsensusResult(None, None, line_counts[line_flags != 0], status_row))
+    except (devmod.PileupFormatError, devmod.PileupIOError) as e:
+        err = e
+    finally:
+        own_set.close()
+    return err
 
-        host_sets = [None, None]
-        d_base = torch.empty((g_alloc, max(S, 1)), dtype=torch.uint8, device="cuda")
-        d_filt = torch.empty((g_alloc, max(S, 1)), dtype=torch.uint8, device="cuda")
-        d_filt2 = torch.empty((g_alloc, max(S, 1)), dtype=torch.uint8, device="cuda")
-        d_line = torch.zeros((g_alloc, max(S, 1)), dtype=torch.int64, device="cuda")
-        d_status = torch.empty((g_alloc, 4), dtype=torch.int64, device="cuda")
-        d_counts = torch.empty((g_alloc, max(S, 1), 128), dtype=torch.uint8, device="cuda") if want_vcf else None
-        vcf_date = None
-        pending_write = None
-        vcf_again = []                                           # samples whose VCF files the per-sample command writes at the end (see the status checks)
-        vcf_later = set()                                        # ... of them, those whose group must not write a VCF meanwhile
 
-        def write_group(part, hs, g0, spill=None):
-            """FASTA + VCF files of one group, both flows (host threads inside the library); returns the samples that failed."""
-            jobs, owners = [], []
-            counts_np = hs["counts"].numpy().view(devmod.COUNTS_DTYPE).reshape(hs["g"], max(S, 1)) if want_vcf else None
-            for k, s in enumerate(part):
-                if not s.ok:
-                    continue
-                for flow in (1, 2):
-                    seq = (hs["base1"] if flow == 1 else hs["base2"]).numpy()[k, :(S1 if flow == 1 else S2)]
-                    job = {"fasta_path": os.path.join(s.dir, "consensus.fasta" if flow == 1 else "consensus_preserved.fasta"),
-                           "fasta_id": s.name.encode("utf-8"), "sequence": seq}
-                    if want_vcf and s.index not in vcf_later:
-                        hdr = "\n".join(vcf_writer.header_lines(s.name, filters_desc, cc_args.vcfRefName, now=vcf_date)) + "\n"
-                        job.update({"vcf_path": os.path.join(s.dir, "consensus.vcf" if flow == 1 else "consensus_preserved.vcf"),
-                                    "vcf_header": hdr.encode("utf-8"), "counts": counts_np[k], "line_off": hs["line"].numpy()[k].view(np.uint64),
-                                    "row_filters": (hs["filt1"] if flow == 1 else hs["filt2"]).numpy()[k],
-                                    "site_in_flow": in1 if flow == 1 else in2})
-                    jobs.append(job)
-                    owners.append(s)
-            res = devmod.write_consensus_files(jobs, ss, filter_names, cc_args.vcfPreserveRefCase, cc_args.vcfFailedSnpGt, n_threads=args.writerThreads,
-                                               spill=spill)
-            if metrics_ref:                                      # as call_consensus._record_metrics does for the two flows, in their order
-                st_h = hs["status"].numpy()
-                for k, s in enumerate(part):
-                    if not s.ok:
-                        continue
-                    name = os.path.basename(cc_args.amdMetricsFile) if cc_args.amdMetricsFile else "metrics"
-                    depth_sum = int(st_h[k, 3]) & 0xFFFFFFFFFFFFFFFF
-                    ave = {"avePileupDepth": "%.2f" % (float(depth_sum) / float(metrics_ref_len))} if depth_sum > 0 and metrics_ref_len > 0 else {}
-                    for key, row, n in (("missingPos", hs["base1"], S1), ("missingPosPreserved", hs["base2"], S2)):
-                        updates = {key: str(int(np.count_nonzero(row.numpy()[k, :n] == 0x2D)))}
-                        updates.update(ave)
-                        utils.update_properties(os.path.join(s.dir, name), updates, keep_mtime=True)
-            bad = []
-            for s, job, (rc, _) in zip(owners, jobs, res):
-                if rc == L.E_UNSUPPORTED:
-                    bad.append((s, "Error: call_consensus failed for sample %s: ValueError: a position has more than %d distinct symbols" % (s.name, L.MAX_SYMS)))
-                elif rc != 0:
-                    bad.append((s, "Error: cannot write %s" % job["fasta_path"]))
-            return bad
-
-        import datetime
-        vcf_date = datetime.datetime.now()
-        write_failures = []
-        for g0 in range(0, n_local, group):
-            t_g = time.perf_counter()
-            part = callable_[g0:g0 + group]
-            g = len(part)
-            which = (g0 // group) & 1
-            if host_sets[which] is None:
-                host_sets[which] = host_set(which)
-            hs = host_sets[which]
-            resident = [(k, s) + store.get(s.store_index) for k, s in enumerate(part)]
-            res_idx = [k for k, s, ptr, _ in resident if ptr]
-            if res_idx and S:
-                # resident samples first in the group's arrays would need a permutation: call them in place, sample by sample
-                # position, with one launch over all resident ones
-                ptrs = [ptr for _, _, ptr, _ in resident if ptr]
-                sizes = [n for _, _, ptr, n in resident if ptr]
-                if len(res_idx) == g:
-                    dev.call_consensus_many_dev(ss, ptrs, sizes, prm, d_base.data_ptr(), d_filt.data_ptr(), d_status.data_ptr(),
-                                                d_counts=d_counts.data_ptr() if want_vcf else 0, d_line_off=d_line.data_ptr(),
-                                                want_depth_sum=bool(metrics_ref))
-                else:
-                    _call_scattered(dev, ss, prm, res_idx, ptrs, sizes, d_base, d_filt, d_status, d_counts, d_line, S, want_vcf, torch,
-                                    want_depth_sum=bool(metrics_ref))
-            elif res_idx:
-                d_status[:g] = torch.tensor([-1, 0, 0, 0], dtype=torch.int64, device="cuda")
-            rest = [(k, s) for k, s, ptr, _ in resident if not ptr]
-            if rest:
-                # files that did not fit the memory budget: streamed again (the only pileups that cross the link twice)
-                results, rcs, st = dev.call_consensus_files(ss, [s.pileup for _, s in rest], prm, want_counts=want_vcf, want_line_offsets=True,
-                                                            want_depth_sum=bool(metrics_ref))
-                h2d_extra[0] += int(st.bytes)
-                for (k, s), rc, r in zip(rest, rcs, results):
-                    if int(rc) == L.E_IO:
-                        s.ok, s.error = False, "Error: cannot open or read the pileup file %s" % s.pileup
-                    d_status[k] = torch.from_numpy(r.status.astype(np.int64)).cuda()
-                    if S:
-                        d_base[k, :S] = torch.from_numpy(r.bases).cuda()
-                        d_filt[k, :S] = torch.from_numpy(r.filters).cuda()
-                        d_line[k, :S] = torch.from_numpy(r.line_offsets.astype(np.int64)).cuda()
-                        if want_vcf:
-                            d_counts[k, :S] = torch.from_numpy(r.counts.view(np.uint8).reshape(S, 128)).cuda()
-            # the preserved flow (and, when the set is wider than snplist.txt, the columns of the full flow) on the device
-            excl = [np.searchsorted(set_keys, own_removed[s.index]).astype(np.uint32) for s in part]
-            eoff = np.zeros(g + 1, dtype=np.int32)
-            np.cumsum([len(e) for e in excl], out=eoff[1:])
-            d_eoff = torch.from_numpy(eoff).cuda()
-            d_eslots = torch.from_numpy(np.concatenate(excl).astype(np.int32) if eoff[-1] else np.zeros(1, np.int32)).cuda()
-            d_b2 = rows2[g0:g0 + g]
-            dev.region_flow_dev(d_base.data_ptr(), d_filt.data_ptr(), d_line.data_ptr(), g, S, d_cols2.data_ptr(), d_col_of2.data_ptr(), S2,
-                                d_eoff.data_ptr(), d_eslots.data_ptr() if eoff[-1] else 0, d_b2.data_ptr() if S2 else 0, d_filt2.data_ptr(), d_err.data_ptr())
-            if identity1:
-                if S1:
-                    rows1[g0:g0 + g, :S1] = d_base[:g, :S1]
-            else:
-                d_nofilt = torch.empty_like(d_filt2)
-                d_e0 = torch.zeros(g + 1, dtype=torch.int32, device="cuda")
-                dev.region_flow_dev(d_base.data_ptr(), d_filt.data_ptr(), d_line.data_ptr(), g, S, d_cols1.data_ptr(), d_col_of1.data_ptr(), S1,
-                                    d_e0.data_ptr(), 0, rows1[g0:g0 + g].data_ptr() if S1 else 0, d_nofilt.data_ptr(), d_err.data_ptr())
-            # results to the host
-            if args.verbose >= 2:
-                torch.cuda.current_stream().synchronize()
-                lap("3a   of which: scan + call + flows on the device", t_g)
-                t_g = time.perf_counter()
-            # per sample, for the checks below: a malformed line at a listed position?  how many listed positions have a line?
+def _consensus_group(job, fl, g0, part, hs, vcf_again, vcf_later):
+    """Device work of one group of samples and its results on the way to the host.  Returns (chk, rest, t_mark): per sample
+    [malformed line at one of ITS positions, listed positions with a line, positions with a spill record]."""
+    torch, dev, store, args = job.torch, job.dev, job.store, job.args
+    S, S1, S2, want_vcf = fl.S, fl.S1, fl.S2, job.want_vcf
+    ss, prm = fl.ss, fl.prm
+    d_base, d_filt, d_filt2, d_line, d_status, d_counts = fl.d_base, fl.d_filt, fl.d_filt2, fl.d_line, fl.d_status, fl.d_counts
+    t_g = time.perf_counter()
+    g = len(part)
+    resident = [(k, s) + store.get(s.store_index) for k, s in enumerate(part)]
+    res_idx = [k for k, s, ptr, _ in resident if ptr]
+    if res_idx and S:
+        # resident samples first in the group's arrays would need a permutation: call them in place, sample by sample
+        # position, with one launch over all resident ones
+        ptrs = [ptr for _, _, ptr, _ in resident if ptr]
+        sizes = [n for _, _, ptr, n in resident if ptr]
+        if len(res_idx) == g:
+            dev.call_consensus_many_dev(ss, ptrs, sizes, prm, d_base.data_ptr(), d_filt.data_ptr(), d_status.data_ptr(),
+                                        d_counts=d_counts.data_ptr() if want_vcf else 0, d_line_off=d_line.data_ptr(),
+                                        want_depth_sum=bool(fl.metrics_ref))
+        else:
+            _call_scattered(dev, ss, prm, res_idx, ptrs, sizes, d_base, d_filt, d_status, d_counts, d_line, S, want_vcf, torch,
+                            want_depth_sum=bool(fl.metrics_ref))
+    elif res_idx:
+        d_status[:g] = torch.tensor([-1, 0, 0, 0], dtype=torch.int64, device="cuda")
+    rest = [(k, s) for k, s, ptr, _ in resident if not ptr]
+    if rest:
+        # files that did not fit the memory budget: streamed again (the only pileups that cross the link twice)
+        results, rcs, st = dev.call_consensus_files(ss, [s.pileup for _, s in rest], prm, want_counts=want_vcf, want_line_offsets=True,
+                                                    want_depth_sum=bool(fl.metrics_ref))
+        job.h2d_extra += int(st.bytes)
+        for (k, s), rc, r in zip(rest, rcs, results):
+            if int(rc) == L.E_IO:
+                s.fail("Error: cannot open or read the pileup file %s" % s.pileup)
+            d_status[k] = torch.from_numpy(r.status.astype(np.int64)).cuda()
             if S:
-                d_bad = (d_counts[:g, :S, 23] > L.ST_OK).any(dim=1) if want_vcf else ((d_filt[:g, :S] & 0x80) != 0).any(dim=1)
-                # (bytes 17-19 of a record: nonzero = the position has a record in the context's spill — more than 8 symbols, or a
-                # reference field of several bytes)
-                d_ovf = (d_counts[:g, :S, 17:20] != 0).any(dim=2).sum(dim=1) if want_vcf else torch.zeros(g, dtype=torch.int64, device="cuda")
-                d_chk = torch.stack([d_bad.to(torch.int64), (d_line[:g, :S] != 0).sum(dim=1), d_ovf], dim=1)
-            hs["status"][:g].copy_(d_status[:g], non_blocking=True)
-            if S1:
-                hs["base1"][:g, :S1].copy_(rows1[g0:g0 + g, :S1], non_blocking=True)
-            if S2:
-                hs["base2"][:g, :S2].copy_(rows2[g0:g0 + g, :S2], non_blocking=True)
-            if S:
-                hs["filt1"][:g, :S].copy_(d_filt[:g, :S], non_blocking=True)
-                hs["filt2"][:g, :S].copy_(d_filt2[:g, :S], non_blocking=True)
-                hs["line"][:g, :S].copy_(d_line[:g, :S], non_blocking=True)
+                d_base[k, :S] = torch.from_numpy(r.bases).cuda()
+                d_filt[k, :S] = torch.from_numpy(r.filters).cuda()
+                d_line[k, :S] = torch.from_numpy(r.line_offsets.astype(np.int64)).cuda()
                 if want_vcf:
-                    hs["counts"][:g, :S].copy_(d_counts[:g, :S], non_blocking=True)
-            chk = d_chk.cpu().numpy() if S else np.zeros((g, 3), dtype=np.int64)      # (the stream is idle after this)
-            group_spill = None
-            if S and chk[:, 2].any():
-                # positions with more than 8 distinct symbols: their spill records belong to ONE library call — there is one
-                # when the whole group was resident; a sample of a mixed group goes back to the per-sample command
-                if not rest:
-                    group_spill = dev.read_symbol_spill()
-                else:
-                    for k, s in enumerate(part):
-                        if s.ok and chk[k, 2]:                   # its consensus is as good as any; its VCF rows need the spill of a call of its own
-                            vcf_again.append(s)
-                            vcf_later.add(s.index)
-            torch.cuda.current_stream().synchronize()
-            lap("3b   of which: results to the host" if args.verbose >= 2 else "3ab  of which: device work + results to the host", t_g)
-            t_g = time.perf_counter()
-            # what the per-sample CLI raises for: malformed chrom / position columns anywhere, a malformed line at a listed position
-            st_np = hs["status"].numpy()[:g]
+                    d_counts[k, :S] = torch.from_numpy(r.counts.view(np.uint8).reshape(S, 128)).cuda()
+    # the preserved flow (and, when the set is wider than snplist.txt, the columns of the full flow) on the device
+    excl = [np.searchsorted(fl.set_keys, fl.own_removed[s.index]).astype(np.uint32) for s in part]
+    eoff = np.zeros(g + 1, dtype=np.int32)
+    np.cumsum([len(e) for e in excl], out=eoff[1:])
+    d_eoff = torch.from_numpy(eoff).cuda()
+    d_eslots = torch.from_numpy(np.concatenate(excl).astype(np.int32) if eoff[-1] else np.zeros(1, np.int32)).cuda()
+    d_b2 = job.rows2[g0:g0 + g]
+    dev.region_flow_dev(d_base.data_ptr(), d_filt.data_ptr(), d_line.data_ptr(), g, S, fl.d_cols2.data_ptr(), fl.d_col_of2.data_ptr(), S2,
+                        d_eoff.data_ptr(), d_eslots.data_ptr() if eoff[-1] else 0, d_b2.data_ptr() if S2 else 0, d_filt2.data_ptr(), fl.d_err.data_ptr())
+    if fl.identity1:
+        if S1:
+            job.rows1[g0:g0 + g, :S1] = d_base[:g, :S1]
+    else:
+        d_nofilt = torch.empty_like(d_filt2)
+        d_e0 = torch.zeros(g + 1, dtype=torch.int32, device="cuda")
+        dev.region_flow_dev(d_base.data_ptr(), d_filt.data_ptr(), d_line.data_ptr(), g, S, fl.d_cols1.data_ptr(), fl.d_col_of1.data_ptr(), S1,
+                            d_e0.data_ptr(), 0, job.rows1[g0:g0 + g].data_ptr() if S1 else 0, d_nofilt.data_ptr(), fl.d_err.data_ptr())
+    # results to the host
+    if args.verbose >= 2:
+        torch.cuda.current_stream().synchronize()
+        job.lap("3a   of which: scan + call + flows on the device", t_g)
+        t_g = time.perf_counter()
+    # per sample, for the checks below — over the positions THAT SAMPLE is asked about (snplist.txt, snplist_preserved.txt, its own
+    # removed positions; the set also holds other samples' removed positions, where the reference builds no Record for this one):
+    # a malformed line at one of them?  how many of the set's positions have a line?  how many have a spill record?
+    d_chk = None
+    if S:
+        d_wanted = fl.d_in12.unsqueeze(0).expand(g, S)
+        if eoff[-1] and not fl.identity1:                    # (with the set == snplist.txt every own position is in it already)
+            d_wanted = d_wanted.clone()
+            rows = torch.repeat_interleave(torch.arange(g, device="cuda"), torch.from_numpy(np.diff(eoff).astype(np.int64)).cuda())
+            d_wanted[rows, d_eslots[:int(eoff[-1])].to(torch.int64)] = True
+        d_badmask = (d_counts[:g, :S, 23] > L.ST_OK) if want_vcf else ((d_filt[:g, :S] & 0x80) != 0)
+        d_bad = (d_badmask & d_wanted).any(dim=1)
+        # (bytes 17-19 of a record: nonzero = the position has a record in the context's spill — more than 8 symbols, or a
+        # reference field of several bytes)
+        d_ovf = (d_counts[:g, :S, 17:20] != 0).any(dim=2).sum(dim=1) if want_vcf else torch.zeros(g, dtype=torch.int64, device="cuda")
+        d_chk = torch.stack([d_bad.to(torch.int64), (d_line[:g, :S] != 0).sum(dim=1), d_ovf], dim=1)
+    hs["status"][:g].copy_(d_status[:g], non_blocking=True)
+    if S1:
+        hs["base1"][:g, :S1].copy_(job.rows1[g0:g0 + g, :S1], non_blocking=True)
+    if S2:
+        hs["base2"][:g, :S2].copy_(job.rows2[g0:g0 + g, :S2], non_blocking=True)
+    if S:
+        hs["filt1"][:g, :S].copy_(d_filt[:g, :S], non_blocking=True)
+        hs["filt2"][:g, :S].copy_(d_filt2[:g, :S], non_blocking=True)
+        hs["line"][:g, :S].copy_(d_line[:g, :S], non_blocking=True)
+        if want_vcf:
+            hs["counts"][:g, :S].copy_(d_counts[:g, :S], non_blocking=True)
+    chk = d_chk.cpu().numpy() if S else np.zeros((g, 3), dtype=np.int64)      # (the stream is idle after this)
+    group_spill = None
+    if S and chk[:, 2].any():
+        # positions with more than 8 distinct symbols: their spill records belong to ONE library call — there is one
+        # when the whole group was resident; a sample of a mixed group goes back to the per-sample command
+        if not rest:
+            group_spill = dev.read_symbol_spill()
+        else:
             for k, s in enumerate(part):
-                if not s.ok:
-                    continue
-                w0 = int(st_np[k, 0]) & 0xFFFFFFFFFFFFFFFF
-                if w0 != 0xFFFFFFFFFFFFFFFF:
-                    s.ok, s.error = False, "Error: call_consensus failed for sample %s: malformed pileup %s at byte offset %d" % (s.name, s.pileup, (w0 >> 8) - 1)
-                    continue
-                if S and chk[k, 0]:
-                    s.ok, s.error = False, "Error: call_consensus failed for sample %s: malformed pileup line at a listed position" % s.name
-                    continue
-                if S and int(st_np[k, 2]) > int(chk[k, 1]):
-                    # The pileup repeats a listed position.  The last line of a position is the one that counts for the consensus
-                    # (call_consensus.py:171-176) and that is what the device returned; but the reference builds a Record from
-                    # every such line — it ends at the first it cannot build — and writes a consensus.vcf row for each.  The
-                    # all-lines pass looks at them now; the VCF files of such a sample are written by the per-sample command
-                    # once the job's own files are done (a sorted pileup never comes here).
-                    try:
-                        _, line_flags, line_counts = dev.call_all_lines(ss, s.pileup, prm, check=False)
-                        err, _ = devmod.Device.site_error(devmod.ConsensusResult(None, None, line_counts[line_flags != 0], st_np[k]))
-                    except (devmod.PileupFormatError, devmod.PileupIOError) as e:
-                        err = e
-                    if err is not None:
-                        s.ok, s.error = False, "Error: call_consensus failed for sample %s: %s" % (s.name, err)
-                        continue
-                    if want_vcf and s not in vcf_again:
-                        vcf_again.append(s)
-                row_ok[g0 + k] = True
-            lap("3c   of which: status checks", t_g)
-            t_g = time.perf_counter()
-            if pending_write is not None:
-                write_failures.extend(pending_write.result())
-            pending_write = writer.submit(write_group, part, hs, g0, group_spill)
-            lap("3d   of which: waiting for the previous group's files", t_g)
+                if s.ok and chk[k, 2]:                       # its consensus is as good as any; its VCF rows need the spill of a call of its own
+                    vcf_again.append(s)
+                    vcf_later.add(s.index)
+    torch.cuda.current_stream().synchronize()
+    job.lap("3b   of which: results to the host" if args.verbose >= 2 else "3ab  of which: device work + results to the host", t_g)
+    return chk, group_spill
+
+
+def _check_group(job, fl, g0, part, hs, chk, vcf_again):
+    """What the per-sample CLI raises for: malformed chrom / position columns anywhere, a malformed line at a listed position, a
+    line of a repeated position that no Record can be built from.  Marks the rows that stand (``row_ok``)."""
+    S = fl.S
+    st_np = hs["status"].numpy()[:len(part)]
+    for k, s in enumerate(part):
+        if not s.ok:
+            continue
+        w0 = int(st_np[k, 0]) & 0xFFFFFFFFFFFFFFFF
+        if w0 != 0xFFFFFFFFFFFFFFFF:
+            s.fail("Error: call_consensus failed for sample %s: malformed pileup %s at byte offset %d" % (s.name, s.pileup, (w0 >> 8) - 1))
+            continue
+        if S and chk[k, 0]:
+            s.fail("Error: call_consensus failed for sample %s: malformed pileup line at a listed position" % s.name)
+            continue
+        if S and int(st_np[k, 2]) > int(chk[k, 1]):
+            # more matching lines than positions with a line: a position comes twice (a sorted pileup never gets here).  The VCF
+            # files of such a sample are written by the per-sample command once the job's own files are done
+            err = _check_repeated_lines(job, fl, s, st_np[k])
+            if err is not None:
+                s.fail("Error: call_consensus failed for sample %s: %s" % (s.name, err))
+                continue
+            if job.want_vcf and s not in vcf_again:
+                vcf_again.append(s)
+        job.row_ok[g0 + k] = True
+
+
+def stage_consensus(job):
+    """No collective in this stage.  Adds: ``flows`` (site set, column maps), ``callable_`` (the rank's samples that got this far),
+    ``rows1`` / ``rows2`` (device: consensus rows of both flows), ``row_ok``, ``vcf_again``."""
+    t0 = time.perf_counter()
+    job.flows = fl = _prepare_flows(job)
+    job.lap("3-   of which: site set", t0)
+    callable_, n_local, group = job.callable_, fl.n_local, fl.group
+    job.arena_thread.join()
+    writer = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+    pending_write = None
+    job.vcf_again = vcf_again = []                           # samples whose VCF files the per-sample command writes at the end
+    vcf_later = set()                                        # ... of them, those whose group must not write a VCF meanwhile
+    write_failures = []
+    for g0 in range(0, n_local, group):
+        part = callable_[g0:g0 + group]
+        which = (g0 // group) & 1
+        if fl.host_sets[which] is None:
+            fl.host_sets[which] = _host_set(job, fl, which)
+        hs = fl.host_sets[which]
+        chk, group_spill = _consensus_group(job, fl, g0, part, hs, vcf_again, vcf_later)
+        t_g = time.perf_counter()
+        _check_group(job, fl, g0, part, hs, chk, vcf_again)
+        job.lap("3c   of which: status checks", t_g)
         t_g = time.perf_counter()
         if pending_write is not None:
             write_failures.extend(pending_write.result())
-        writer.shutdown()
-        lap("3e   of which: waiting for the last group's files", t_g)
-        for s, msg in write_failures:
-            s.ok, s.error = False, msg
-            row_ok[callable_.index(s)] = False
-        if int(d_err[0]) != 0:
-            raise RuntimeError("an exclude slot fell outside the site set")
-        t_g = time.perf_counter()
-        for fu in split_files:
-            fu.result()
-        split_pool.shutdown()
-        lap("3f   of which: waiting for the split VCF files of step 2", t_g)
-        lap("3 consensus, both flows", t0)
+        pending_write = writer.submit(_write_group, job, fl, part, hs, vcf_later, group_spill)
+        job.lap("3d   of which: waiting for the previous group's files", t_g)
+    t_g = time.perf_counter()
+    if pending_write is not None:
+        write_failures.extend(pending_write.result())
+    writer.shutdown()
+    job.lap("3e   of which: waiting for the last group's files", t_g)
+    for s, msg in write_failures:
+        s.fail(msg)
+        job.row_ok[callable_.index(s)] = False
+    if int(fl.d_err[0]) != 0:
+        raise RuntimeError("an exclude slot fell outside the site set")
+    t_g = time.perf_counter()
+    for fu in job.split_files:
+        fu.result()
+    job.split_pool.shutdown()
+    job.lap("3f   of which: waiting for the split VCF files of step 2", t_g)
+    job.lap("3 consensus, both flows", t0)
 
-        # ================================ 4: matrices, distances, top-level files ==========================================
-        t0 = time.perf_counter()
-        # which samples of the whole job have a consensus row (gathered: small)
-        ref_seqs = [None]
-        ok_local = np.zeros(hi - lo, dtype=bool)
-        for k, s in enumerate(callable_):
-            ok_local[s.index - lo] = bool(row_ok[k])
-        ok_all = np.concatenate(comm.gather_objects(ok_local)) if n_total else np.zeros(0, bool)
-        local_row_of = {s.index: k for k, s in enumerate(callable_)}
-        for flow, rows, Sx, excluded, snpma, pairs, matrix in ((1, rows1, S1, excluded1, "snpma", "pairs", "matrix"),
-                                                              (2, rows2, S2, excluded2, "snpma_p", "pairs_p", "matrix_p")):
-            # snp_matrix (snp_matrix.py:79-119): the samples of the step's filtered list, sorted-dir order, that have a consensus file
-            member = ok_all & ~excluded
-            if rank == 0 and not member.any():
-                utils.global_error("Error: all %d consensus fasta files were missing or empty." % int((~excluded).sum()))
-            chunks = []
-            for s in mine:
-                if member[s.index]:
-                    k = local_row_of[s.index]
-                    chunks.append(_fasta_bytes(s.name, rows[k, :Sx].cpu().numpy() if Sx else np.zeros(0, np.uint8)))
-            blob = b"".join(chunks)
-            sizes = comm.gather_objects(len(blob))
+
+# ==================================== stage 4: matrices, distances, top-level files ===========================================
+def stage_matrices_and_distances(job):
+    """Collectives interleaved with file output; the output runs under ``job.guard`` so that a rank whose disk is full still takes
+    part in every collective and the failure surfaces at the agreement after the stage."""
+    torch, comm, sharding, dev = job.torch, job.comm, job.sharding, job.dev
+    rank, world, n_total, samples, mine, lo, hi = job.rank, job.world, job.n_total, job.samples, job.mine, job.lo, job.hi
+    callable_, outputs, fl = job.callable_, job.outputs, job.flows
+    n_local = fl.n_local
+    t0 = time.perf_counter()
+    # which samples of the whole job have a consensus row (gathered: small)
+    ref_seqs = [None]
+    ok_local = np.zeros(hi - lo, dtype=bool)
+    for k, s in enumerate(callable_):
+        ok_local[s.index - lo] = bool(job.row_ok[k])
+    ok_all = np.concatenate(comm.gather_objects(ok_local)) if n_total else np.zeros(0, bool)
+    local_row_of = {s.index: k for k, s in enumerate(callable_)}
+    for flow, rows, Sx, excluded, snpma, pairs, matrix in ((1, job.rows1, fl.S1, job.excluded1, "snpma", "pairs", "matrix"),
+                                                          (2, job.rows2, fl.S2, job.excluded2, "snpma_p", "pairs_p", "matrix_p")):
+        # snp_matrix (snp_matrix.py:79-119): the samples of the step's filtered list, sorted-dir order, that have a consensus file
+        member = ok_all & ~excluded
+        if not member.any():                                 # every rank sees the same flags: all leave, rank 0 says why
             if rank == 0:
+                utils.global_error("Error: all %d consensus fasta files were missing or empty." % int((~excluded).sum()))
+            sys.exit(100)
+        chunks = []
+        for s in mine:
+            if member[s.index]:
+                k = local_row_of[s.index]
+                chunks.append(_fasta_bytes(s.name, rows[k, :Sx].cpu().numpy() if Sx else np.zeros(0, np.uint8)))
+        blob = b"".join(chunks)
+        sizes = comm.gather_objects(len(blob))
+        with job.guard() as go:
+            if go and rank == 0:
                 with open(outputs[snpma], "wb") as f:
                     f.truncate(sum(sizes))
-            comm.barrier()
-            with open(outputs[snpma], "r+b") as f:
-                f.seek(sum(sizes[:rank]))
-                f.write(blob)
-            # distance (distance.py:76-114): ids = sorted names, equal names keep the last record of the file
-            last = {}
-            for i in np.flatnonzero(member):
-                last[samples[i].name] = i
-            ids = sorted(last)
-            order = np.asarray([last[i] for i in ids], dtype=np.int64)
-            n = len(ids)
-            row_bytes = dev.packed_row_bytes(Sx)
-            per = (n_total + world - 1) // world if n_total else 0
-            packed_local = torch.zeros((max(hi - lo, 1), row_bytes), dtype=torch.uint8, device="cuda")
-            if n_local and Sx:
-                tmp = torch.zeros((n_local, row_bytes), dtype=torch.uint8, device="cuda")
-                dev.pack_matrix_dev(rows.data_ptr(), n_local, Sx, rows.shape[1], tmp.data_ptr())
-                idx = torch.tensor([s.index - lo for s in callable_], dtype=torch.int64, device="cuda")
-                packed_local[idx] = tmp
-            packed_all = torch.zeros((max(world * per, 1), row_bytes), dtype=torch.uint8, device="cuda")
-            sharding.all_gather_rows_into(packed_local[:hi - lo], n_total, packed_all)
-            bands = sharding.RowBands(n, world)
-            packed_sorted = torch.zeros((max(bands.n_padded, 1), row_bytes), dtype=torch.uint8, device="cuda")
-            if n:
-                packed_sorted[:n] = packed_all[torch.from_numpy(order).cuda()]
-            dmat = torch.zeros((max(bands.n_padded, 1), max(bands.n_padded, 1)), dtype=torch.int32, device="cuda")
-            if n and Sx:
-                dev.distance_packed_dev(packed_sorted.data_ptr(), bands.n_padded, Sx, dmat.data_ptr(), rank, world)
-            if world > 1 and n:
-                band = bands.exchange(dmat, rank)                # the complete rows of this rank's band
-                blo, bhi = bands.band_rows(rank)
-                pieces = comm.gather_objects(band[:bhi - blo, :n].cpu().numpy())
-                full = np.concatenate(pieces, axis=0) if rank == 0 else None
-            else:
-                full = dmat[:n, :n].cpu().numpy()
-            if rank == 0:
+        comm.barrier()
+        with job.guard() as go:
+            if go:
+                with open(outputs[snpma], "r+b") as f:
+                    f.seek(sum(sizes[:rank]))
+                    f.write(blob)
+        # distance (distance.py:76-114): ids = sorted names, equal names keep the last record of the file
+        last = {}
+        for i in np.flatnonzero(member):
+            last[samples[i].name] = i
+        ids = sorted(last)
+        order = np.asarray([last[i] for i in ids], dtype=np.int64)
+        n = len(ids)
+        row_bytes = dev.packed_row_bytes(Sx)
+        per = (n_total + world - 1) // world if n_total else 0
+        packed_local = torch.zeros((max(hi - lo, 1), row_bytes), dtype=torch.uint8, device="cuda")
+        if n_local and Sx:
+            tmp = torch.zeros((n_local, row_bytes), dtype=torch.uint8, device="cuda")
+            dev.pack_matrix_dev(rows.data_ptr(), n_local, Sx, rows.shape[1], tmp.data_ptr())
+            idx = torch.tensor([s.index - lo for s in callable_], dtype=torch.int64, device="cuda")
+            packed_local[idx] = tmp
+        packed_all = torch.zeros((max(world * per, 1), row_bytes), dtype=torch.uint8, device="cuda")
+        sharding.all_gather_rows_into(packed_local[:hi - lo], n_total, packed_all)
+        bands = sharding.RowBands(n, world)
+        packed_sorted = torch.zeros((max(bands.n_padded, 1), row_bytes), dtype=torch.uint8, device="cuda")
+        if n:
+            packed_sorted[:n] = packed_all[torch.from_numpy(order).cuda()]
+        dmat = torch.zeros((max(bands.n_padded, 1), max(bands.n_padded, 1)), dtype=torch.int32, device="cuda")
+        if n and Sx:
+            dev.distance_packed_dev(packed_sorted.data_ptr(), bands.n_padded, Sx, dmat.data_ptr(), rank, world)
+        if world > 1 and n:
+            band = bands.exchange(dmat, rank)                # the complete rows of this rank's band
+            blo, bhi = bands.band_rows(rank)
+            pieces = comm.gather_objects(band[:bhi - blo, :n].cpu().numpy())
+            full = np.concatenate(pieces, axis=0) if rank == 0 else None
+        else:
+            full = dmat[:n, :n].cpu().numpy()
+        with job.guard() as go:
+            if go and rank == 0:
                 from . import distance as dmod
                 dmod.write_pairwise(outputs[pairs], ids, full)
                 dmod.write_matrix(outputs[matrix], ids, full)
                 if ref_seqs[0] is None:
-                    ref_seqs[0] = snp_reference.read_fasta_sequences(ref_path)
-                snp_reference.write_reference_snp_file(ref_path, outputs["snplist" if flow == 1 else "snplist_p"],
+                    ref_seqs[0] = snp_reference.read_fasta_sequences(job.ref_path)
+                snp_reference.write_reference_snp_file(job.ref_path, outputs["snplist" if flow == 1 else "snplist_p"],
                                                        outputs["refsnp" if flow == 1 else "refsnp_p"], match_dict=ref_seqs[0])
-        comm.barrier()
-        lap("4 matrices + distances", t0)
-        # ---- samples whose pileup repeats a listed position: consensus.vcf rows for EVERY matching line, by the per-sample command
-        #      (call_consensus.py:178-180); its consensus.fasta is the same bytes the job wrote ----------------------------------------
-        if vcf_all_pos:
-            vcf_again = [s for k, s in enumerate(callable_) if row_ok[k]]
-        if vcf_again:
-            from . import call_consensus as cc_step
-            quiet = argparse.Namespace(verbose=0)
-            utils.set_logging_verbosity(quiet)
-            process_device, devmod._default = devmod._default, dev       # (the command's "process-wide device" is this job's context)
+    comm.barrier()
+    job.lap("4 matrices + distances", t0)
+
+
+# ==================================== stage 5: the VCF files the per-sample command writes ====================================
+def stage_leftover_vcfs(job):
+    """Samples whose pileup repeats a listed position get consensus.vcf rows for EVERY matching line from the per-sample command
+    (call_consensus.py:178-180); its consensus.fasta is the same bytes the job wrote.  With --vcfAllPos: every sample."""
+    vcf_again = job.vcf_again
+    if job.vcf_all_pos:
+        vcf_again = [s for k, s in enumerate(job.callable_) if job.row_ok[k]]
+    if not vcf_again:
+        return
+    from . import call_consensus as cc_step
+    outputs, ref_path = job.outputs, job.ref_path
+    quiet = argparse.Namespace(verbose=0)
+    utils.set_logging_verbosity(quiet)
+    process_device, devmod._default = devmod._default, job.dev   # (the command's "process-wide device" is this job's context)
+    try:
+        for s in vcf_again:
+            if not s.ok:
+                continue
             try:
-                for s in vcf_again:
-                    if not s.ok:
-                        continue
-                    try:
-                        for snplist, suffix, more in ((outputs["snplist"], "", []),
-                                                      (outputs["snplist_p"], "_preserved", ["-e", os.path.join(s.dir, "var.flt_removed.vcf")])):
-                            cc_step.call_consensus(_step_args("call_consensus", ["-f", "-l", snplist, "-o", os.path.join(s.dir, "consensus%s.fasta" % suffix),
-                                                                                 "--vcfRefName", os.path.basename(ref_path), "--vcfFileName", "consensus%s.vcf" % suffix]
-                                                              + more + [s.pileup], cc_extra))
-                    except (Exception, SystemExit) as e:         # noqa: B902 — reported as this sample's error below
-                        s.ok, s.error = False, "Error: call_consensus failed for sample %s: %s: %s" % (s.name, type(e).__name__, e)
-            finally:
-                devmod._default = process_device
-                utils.set_logging_verbosity(args)
-        st = store.stats()
-        stats = {"h2d_bytes": int(st.h2d_bytes) + h2d_extra[0], "file_bytes": int(st.file_bytes), "resident_files": int(st.n_resident),
-                 "files": int(st.n_files), "seconds": time.perf_counter() - t_start,
-                 "ingest": {"seconds": st.seconds, "allocating": st.seconds_allocating, "waiting_for_readers": st.seconds_waiting_for_readers,
-                            "waiting_for_device": st.seconds_waiting_for_device, "reader_seconds_reading": st.reader_seconds_reading,
-                            "reader_seconds_waiting": st.reader_seconds_waiting, "preparing": st.seconds_preparing}, "phases": timings, "sites": S1, "sites_preserved": S2,
-                 "samples": hi - lo}
+                for snplist, suffix, more in ((outputs["snplist"], "", []),
+                                              (outputs["snplist_p"], "_preserved", ["-e", os.path.join(s.dir, "var.flt_removed.vcf")])):
+                    cc_step.call_consensus(_step_args("call_consensus", ["-f", "-l", snplist, "-o", os.path.join(s.dir, "consensus%s.fasta" % suffix),
+                                                                         "--vcfRefName", os.path.basename(ref_path), "--vcfFileName", "consensus%s.vcf" % suffix]
+                                                      + more + [s.pileup], job.cc_extra))
+            except (Exception, SystemExit) as e:             # noqa: B902 — reported as this sample's error below
+                s.fail("Error: call_consensus failed for sample %s: %s: %s" % (s.name, type(e).__name__, e))
+    finally:
+        devmod._default = process_device
+        utils.set_logging_verbosity(job.args)
+
+
+STAGES = (stage_ingest_and_sites, stage_site_union_and_regions, stage_consensus, stage_matrices_and_distances, stage_leftover_vcfs)
+
+
+def _job_stats(job):
+    st = job.store.stats()
+    fl = job.flows
+    return {"h2d_bytes": int(st.h2d_bytes) + job.h2d_extra, "file_bytes": int(st.file_bytes), "resident_files": int(st.n_resident),
+            "files": int(st.n_files), "seconds": time.perf_counter() - job.t_start, "site_calling": job.site_calling,
+            "ingest": {"seconds": st.seconds, "allocating": st.seconds_allocating, "waiting_for_readers": st.seconds_waiting_for_readers,
+                       "waiting_for_device": st.seconds_waiting_for_device, "reader_seconds_reading": st.reader_seconds_reading,
+                       "reader_seconds_waiting": st.reader_seconds_waiting, "preparing": st.seconds_preparing},
+            "phases": job.timings, "sites": fl.S1, "sites_preserved": fl.S2, "samples": job.hi - job.lo}
+
+
+def hot_path_batch(args):
+    """Entry point of ``cfsan_snp_pipeline hot_path_batch`` (an extension of this build; see the module docstring)."""
+    utils.print_log_header(classpath=True)
+    utils.print_arguments(args)
+    comm = _Comm()
+    job = _Job(args, comm)
+    if not args.forceFlag and job.is_fresh():
+        verbose_print("All outputs of the hot path have already been freshly built.  Use the -f option to force a rebuild.")
+        comm.close()
+        return
+    try:
+        job.open_device()
+        for stage in STAGES:
+            job.run_stage(stage)
+        stats = _job_stats(job)
         hot_path_batch.last_stats = stats
         verbose_print("# hot_path_batch rank %d: %d samples, %d pileup bytes, %d bytes copied to the device (%d files resident), %.3f s"
-                      % (rank, hi - lo, stats["file_bytes"], stats["h2d_bytes"], stats["resident_files"], stats["seconds"]))
-        for k in sorted(timings):
-            verbose_print("#   %-34s %.3f s" % (k, timings[k]))
+                      % (job.rank, job.hi - job.lo, stats["file_bytes"], stats["h2d_bytes"], stats["resident_files"], stats["seconds"]))
+        for k in sorted(job.timings):
+            verbose_print("#   %-34s %.3f s" % (k, job.timings[k]))
     finally:
-        store.close()
-        dev.close()
+        job.close_device()
     # ---- per-sample errors: reported the way the batch subcommands do ----------------------------------------------------
-    errs = [s.error for s in mine if not s.ok]
+    errs = [s.error for s in job.mine if not s.ok]
     all_errs = comm.gather_objects(errs)
     failed = sum(len(e) for e in all_errs)
     comm.close()                                             # (before anything that may end the process: sample_error exits when StopOnSampleError says so)
     for msg in errs:
         utils.sample_error(msg, continue_possible=True)
     if failed:
-        verbose_print("%d of %d samples failed." % (failed, n_total))
+        verbose_print("%d of %d samples failed." % (failed, job.n_total))
+        if not errs and utils._stop_on_sample_error():       # a peer's sample failed: leave with the code it leaves with
+            sys.exit(100)
 
 
 hot_path_batch.last_stats = None
@@ -841,11 +1152,14 @@ def add_arguments(sub):
     sub.add_argument("-f", "--force", dest="forceFlag", action="store_true", help="Force processing even when result files already exist and are newer than inputs")
     sub.add_argument("--workDir", dest="workDir", type=str, default=None, metavar="DIR", help="Directory of the top-level output files (default: the directory of sampleDirsFile)")
     sub.add_argument("--pileupName", dest="pileupName", type=str, default="reads.all.pileup", metavar="NAME", help="File name of the genome-wide pileup file in each sample directory.")
+    sub.add_argument("--siteCalling", dest="siteCalling", type=str, default=None, choices=cs.SITE_CALLING_MODES, metavar="MODE",
+                     help="Who writes var.flt.vcf: varscan (the VarScan jar on CLASSPATH, as the reference), device (this build's restatement; parity unpinned), "
+                          "existing (nobody: the files are inputs and stay byte for byte), auto (varscan when a jar is on CLASSPATH, else device).  Default: $SNPGPU_SITE_CALLING, else auto")
     for name, env in (("filterRegionsExtraParams", "FilterRegions_ExtraParams"), ("mergeSitesExtraParams", "MergeSites_ExtraParams"),
                       ("callConsensusExtraParams", "CallConsensus_ExtraParams"), ("varscanExtraParams", "VarscanMpileup2snp_ExtraParams")):
         sub.add_argument("--" + name, dest=name, type=str, default=None, metavar="STRING",
                          help="Options of that step, as the configuration file gives them (default: the environment variable %s)" % env)
     sub.add_argument("--noConsensusVcf", dest="noConsensusVcf", action="store_true", help="Do not write consensus.vcf / consensus_preserved.vcf")
     sub.add_argument("--residentBytes", dest="residentBytes", type=int, default=0, metavar="INT", help="Device memory for resident pileups (0 = what is free, less 24 GiB); files past it are streamed twice")
-    sub.add_argument("--groupBytes", dest="groupBytes", type=int, default=0, metavar="INT", help="Host bytes of per-site results per group of samples (default 1.5 GiB)")
+    sub.add_argument("--groupBytes", dest="groupBytes", type=int, default=0, metavar="INT", help="Host bytes of per-site results per group of samples (default 1 GiB)")
     sub.add_argument("--writerThreads", dest="writerThreads", type=int, default=0, metavar="INT", help="Host threads that write the consensus files (0 = up to 64)")

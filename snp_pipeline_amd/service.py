@@ -15,6 +15,11 @@ exit codes, same log text), one at a time per GPU.
 
 ``cfsan_snp_pipeline serve`` starts the service by hand (one worker process per GPU; ``--device N`` one worker).  A client that
 cannot reach a server does the work in-process.
+
+Whom the client trusts: the socket directory must be a real directory of this user that nobody else can write to (the default
+one lives under ``$XDG_RUNTIME_DIR``, or ``<tmp>/snpgpu-<uid>`` created 0700 and refused when another user made it first:
+_paths.py), the process at the other end of the socket must run under this user's uid (SO_PEERCRED), and what it is sent of
+the environment is the list of variables the steps read (``_forwarded``) — not the whole of ``os.environ``.
 """
 from __future__ import print_function
 
@@ -29,9 +34,38 @@ SERVED = ("call_sites", "filter_regions", "merge_sites", "call_consensus", "snp_
 _MAX_MESSAGE = 1 << 30
 
 
+# What a step reads from its environment (the reference's configuration travels in environment variables: run.py exports the
+# *_ExtraParams of snppipeline.conf and the error-handling switches), plus what the programs a step starts need.
+_FORWARDED = frozenset((
+    "errorOutputFile", "StopOnSampleError", "RemoveDuplicateReads", "EnableLocalRealignment", "CLASSPATH", "PATH", "JAVA_HOME",
+    "PBS_JOBID", "JOB_ID", "SGE_TASK_ID", "SLURM_ARRAY_JOB_ID", "SLURM_JOBID", "SLURM_ARRAY_TASK_ID",
+    "LANG", "LC_ALL", "LC_CTYPE", "TZ", "TMPDIR"))
+
+
+def _forwarded(name):
+    return name in _FORWARDED or name.endswith("_ExtraParams") or (name.startswith("SNPGPU_") and name != "SNPGPU_SERVICE")
+
+
 def default_dir():
-    import tempfile
-    return os.path.join(tempfile.gettempdir(), "snpgpu-%d" % os.getuid(), "service")
+    """The per-user socket directory (created, and checked to be ours: _paths.private_dir raises UnsafeDirectory when it is not)."""
+    from . import _paths
+    return _paths.private_dir("service")
+
+
+def _checked_dir(directory):
+    """An explicitly named socket directory: it may be readable by others, but only this user may write to it."""
+    from . import _paths
+    return _paths.ensure_private_dir(directory, allow_group_read=True)
+
+
+def _peer_is_me(conn):
+    """True when the process that accepted this connection runs under our uid (SO_PEERCRED: pid, uid, gid of the peer)."""
+    try:
+        creds = conn.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i"))
+        _, uid, _ = struct.unpack("3i", creds)
+        return uid == os.getuid()
+    except (OSError, AttributeError, struct.error):
+        return False
 
 
 def service_dir():
@@ -39,7 +73,7 @@ def service_dir():
     v = os.environ.get("SNPGPU_SERVICE", "")
     if v in ("", "0", "off", "no", "false"):
         return None
-    return default_dir() if v in ("auto", "1", "on", "yes", "true") else v
+    return default_dir() if v in ("auto", "1", "on", "yes", "true") else _checked_dir(v)
 
 
 def _send(conn, obj):
@@ -90,7 +124,7 @@ def _spawn(directory):
     """Start the service (detached) unless somebody else is doing so, and wait until a socket answers."""
     import fcntl
     import subprocess
-    os.makedirs(directory, mode=0o700, exist_ok=True)
+    _checked_dir(directory)
     with open(os.path.join(directory, "spawn.lock"), "a+") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)                     # one starter; the others wait here and then find the sockets
         try:
@@ -127,8 +161,14 @@ def _probe(path):
 def try_client(argv):
     """Run ``argv`` (the arguments after the program name) through the service.  Returns the exit code, or None when the
     request was not served (service off, subcommand not served, no server reachable): the caller then works in-process."""
-    directory = service_dir()
-    if directory is None or not argv or argv[0] not in SERVED:
+    if not argv or argv[0] not in SERVED:
+        return None
+    try:
+        directory = service_dir()
+    except OSError as e:                                      # the directory is not provably ours: nothing in it is trusted
+        sys.stderr.write("snpgpu service not used: %s\n" % e)
+        return None
+    if directory is None:
         return None
     may_spawn = os.environ.get("SNPGPU_SERVICE", "") in ("auto", "1", "on", "yes", "true") or os.environ.get("SNPGPU_SERVICE_SPAWN") == "1"
 
@@ -151,7 +191,11 @@ def try_client(argv):
     if conn is None:
         return None
     try:
-        _send(conn, {"argv": list(argv), "argv0": sys.argv[0], "cwd": os.getcwd(), "env": dict(os.environ)})
+        if not _peer_is_me(conn):
+            sys.stderr.write("snpgpu service not used: the server at %s runs under another user\n" % directory)
+            return None
+        _send(conn, {"argv": list(argv), "argv0": sys.argv[0], "cwd": os.getcwd(),
+                     "env": {k: v for k, v in os.environ.items() if _forwarded(k)}})
         reply = _recv(conn)
     except (OSError, EOFError, ValueError):
         return None                                          # (nothing has been printed yet: the in-process path starts clean)
@@ -176,8 +220,10 @@ def _run_request(req):
     rc = 0
     try:
         os.chdir(req["cwd"])
-        os.environ.clear()
-        os.environ.update(req.get("env", {}))
+        # the server's own environment, with the variables a step reads taken from the client — set, changed or absent as there
+        for k in [k for k in os.environ if _forwarded(k)]:
+            del os.environ[k]
+        os.environ.update({k: v for k, v in req.get("env", {}).items() if _forwarded(k)})
         os.environ.update(keep)
         os.environ.pop("SNPGPU_SERVICE", None)
         sys.argv = [req.get("argv0", "cfsan_snp_pipeline")] + list(req["argv"])
@@ -256,6 +302,8 @@ def _worker(directory, device, idle_timeout):
                 break
             try:
                 conn.settimeout(60.0)                        # a client that connects and says nothing does not hold the GPU's queue
+                if not _peer_is_me(conn):                    # (the socket is 0600 in a 0700 directory; this is the second lock)
+                    raise ValueError("connection from another user refused")
                 req = _recv(conn)
                 conn.settimeout(None)
                 if req.get("ping"):
@@ -285,8 +333,7 @@ def _worker(directory, device, idle_timeout):
 def serve(args):
     """Entry point of ``cfsan_snp_pipeline serve``."""
     import subprocess
-    directory = args.socketDir or service_dir() or default_dir()
-    os.makedirs(directory, mode=0o700, exist_ok=True)
+    directory = _checked_dir(args.socketDir) if args.socketDir else (service_dir() or default_dir())
     if args.stop:
         for p in _sockets(directory):
             s = _connect(p, timeout=1.0)

@@ -328,6 +328,7 @@ def convert_vcf_file_to_snp_set(vcf_file_path):
 
 
 _WS = bytes(range(9, 14)) + bytes(range(28, 33))          # what str.split() removes from ASCII text
+_WS_TO_SPACE = bytes.maketrans(_WS, b" " * len(_WS))       # (bytes.split() does not know 0x1c-0x1f; the text-mode loops below do)
 
 
 def fasta_records_ascii(path):
@@ -346,7 +347,7 @@ def fasta_records_ascii(path):
         return out
     for chunk in data[start + 1:].split(b"\n>"):
         head, _, body = chunk.partition(b"\n")
-        words = head.split()
+        words = head.translate(_WS_TO_SPACE).split()
         out.append((words[0].decode("ascii") if words else "", body.translate(None, _WS)))
     return out
 
@@ -379,22 +380,44 @@ def write_fasta_record(handle, record_id, sequence, width=60):
         handle.write(sequence[i:i + width] + "\n")
 
 
+def private_temp_dir():
+    """This user's private scratch directory (lock files): see _paths.private_dir."""
+    from . import _paths
+    return _paths.private_dir()
+
+
 # ---- the per-sample metrics file (name=value properties, utils.py:323-380 of the reference reads it back) ---------------
 def update_properties(prop_file_path, updates, keep_mtime=False):
     """Set ``name=value`` lines in a properties file, keeping every other line; the file is created when missing.  The
-    read-modify-write runs under an exclusive lock on ``<file>.lock`` (the regular and the preserved call_consensus job of one
-    sample may get here at the same time); keep_mtime: an existing file keeps its modification time, so that make-style
+    read-modify-write runs under an exclusive lock (the regular and the preserved call_consensus job of one sample may get here
+    at the same time).  The lock file lives in the per-user temporary directory, named after the metrics file's real path: the
+    sample directory gets no file the reference's tools do not write, and a shared file system without a lock daemon is not
+    asked to lock anything; when even that lock cannot be had the update goes ahead unlocked — these are optional by-products,
+    never a reason for the step to fail.  keep_mtime: an existing file keeps its modification time, so that make-style
     consumers (collect_metrics decides per metric with target_needs_rebuild) do not take its OTHER values for fresh."""
     import fcntl
-    with open(prop_file_path + ".lock", "a") as lock:
+    import hashlib
+    lock = None
+    try:
+        lock_dir = private_temp_dir()
+        digest = hashlib.sha1(os.path.realpath(prop_file_path).encode("utf-8", "surrogateescape")).hexdigest()
+        lock = open(os.path.join(lock_dir, "metrics-%s.lock" % digest), "a")
         fcntl.flock(lock, fcntl.LOCK_EX)
-        try:
-            before = os.stat(prop_file_path) if (keep_mtime and os.path.isfile(prop_file_path)) else None
-            _update_properties_unlocked(prop_file_path, updates)
-            if before is not None:
-                os.utime(prop_file_path, ns=(before.st_atime_ns, before.st_mtime_ns))
-        finally:
-            fcntl.flock(lock, fcntl.LOCK_UN)
+    except (OSError, IOError):
+        if lock is not None:
+            lock.close()
+        lock = None
+    try:
+        before = os.stat(prop_file_path) if (keep_mtime and os.path.isfile(prop_file_path)) else None
+        _update_properties_unlocked(prop_file_path, updates)
+        if before is not None:
+            os.utime(prop_file_path, ns=(before.st_atime_ns, before.st_mtime_ns))
+    finally:
+        if lock is not None:
+            try:
+                fcntl.flock(lock, fcntl.LOCK_UN)
+            finally:
+                lock.close()
 
 
 def _update_properties_unlocked(prop_file_path, updates):

@@ -25,12 +25,13 @@ def _free_port():
     return p
 
 
-def _run_bench(world, dump, extra):
+def _run_bench(world, dump, extra, launcher=False):
     args = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--scaling", "strong", "--skip-aux", "--e2e-files", "0", "--site-files", "0",
             "--cpu-samples", "0", "--pipeline-files", "0", "--shape-samples", "0", "--dump", dump] + extra
-    env = dict(os.environ, SNPGPU_BENCH_TEST_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
-    if world == 1:
-        cmd = [sys.executable] + args
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(SNPGPU_BENCH_TEST_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    if world == 1 or not launcher:
+        cmd = [sys.executable] + args                                   # plain `python bench.py --gpus N`: bench.py starts its own ranks
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port())] + args
@@ -46,8 +47,11 @@ def test_sharded_step_equals_single_rank(tmp_path, world):
     extra = ["--samples", str(n_total), "--genome", "40000", "--sites", "400", "--vcf-records", "60", "--dist-samples", "700",
              "--dist-sites", "3000", "--dist-reps", "1"]
     one = _run_bench(1, str(tmp_path / "one"), extra)
-    many = _run_bench(world, str(tmp_path / "many"), extra)
+    many = _run_bench(world, str(tmp_path / "many"), extra, launcher=(world == 3))      # 2 ranks: self-launched; 3: the driver's way
     assert many["n_gpus"] == world and many["scaling"] == "strong" and "world size %d" % world in many["config"]["parallelism"]
+    assert many["comm"]["world_size"] == world and many["comm"]["backend"] == "gloo"
+    assert ("started its own ranks" in many["comm"]["launcher"]) == (world == 2)
+    assert one["comm"] == {"backend": None, "world_size": 1, "launcher": "none (one process)", "collectives_per_step": "none"}
     assert many["site_union"] == one["site_union"]
     assert many["secondary"]["value"] > 0
     ref = np.load(str(tmp_path / "one.rank0.npz"))

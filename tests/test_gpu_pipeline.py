@@ -487,3 +487,119 @@ def test_hot_path_batch_with_many_symbols_at_a_position_of_a_sample_that_is_not_
     _run("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s"
          % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), CONSENSUS_EXTRA.replace(" ", "\x00")))
     _compare(_snapshot(work, dirs, remove=False), want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Site calling mode ``existing``: a tree whose var.flt.vcf files were written by somebody else — here the reference's own
+# bundled files, i.e. real VarScan output — goes through the job with those files as INPUTS.  They must stay byte for byte (and
+# keep their modification times), and everything downstream of them that the reference ships must come out as bundled: the split
+# VCF files, both snplists, both referenceSNP files.  The consensus side is checked against the restatement on the pileups the
+# test makes (the reference ships no pileup).
+# ---------------------------------------------------------------------------------------------------------------------------
+def _foreign_tree(tmp_path, fixture_trees, ds):
+    import lzma
+    import shutil
+    from tests.conftest import GOLD
+    from snp_pipeline_amd import utils
+    root, meta = fixture_trees[ds]
+    work = tmp_path / "work"
+    (work / "samples").mkdir(parents=True)
+    ref_path = str(work / "reference.fasta")
+    if ds == "lambdaVirus":
+        shutil.copy(os.path.join(GOLD, "fixtures", "lambdaVirus", "lambda_virus.fasta"), ref_path)
+    else:
+        with lzma.open(os.path.join(GOLD, "fixtures", "listeria", "CFSAN023463.HGAP.draft.fasta.xz")) as f, open(ref_path, "wb") as out:
+            out.write(f.read())
+    refs = dict(utils.fasta_records_ascii(ref_path))
+    refs = {k: v.decode("ascii") for k, v in refs.items()}
+    contig_order = list(refs)
+    names = sorted(os.listdir(os.path.join(root, "samples")))
+    per_sample = {}
+    for name in names:
+        _, _, sites = utils.read_vcf_sites(os.path.join(root, "samples", name, "var.flt.vcf"))
+        per_sample[name] = sites
+    union = {}
+    for sites in per_sample.values():
+        for c, p in sites:
+            union.setdefault(c, set()).add(p)
+    layout = [(c, sorted(union[c])) for c in contig_order if c in union]
+    dirs, piles = [], {}
+    old = time.time() - 1000
+    for k, name in enumerate(names):
+        sdir = work / "samples" / name
+        sdir.mkdir()
+        piles[name] = fuzz.pileup_at_positions(100 + k, layout, refs)
+        bam = sdir / "reads.sorted.deduped.indelrealigned.bam"
+        bam.write_bytes(b"placeholder: the pileup is newer, so samtools is not run (call_sites.py:70-72)")
+        os.utime(str(bam), (old - 10, old - 10))
+        (sdir / "reads.all.pileup").write_bytes(piles[name])
+        os.utime(str(sdir / "reads.all.pileup"), (old, old))
+        shutil.copy(os.path.join(root, "samples", name, "var.flt.vcf"), str(sdir / "var.flt.vcf"))
+        dirs.append(str(sdir))
+    dirs_file = str(work / "sampleDirectories.txt")
+    with open(dirs_file, "w") as f:
+        f.write("\n".join(reversed(dirs)) + "\n")
+    return root, str(work), ref_path, names, dirs, dirs_file, piles
+
+
+@pytest.mark.parametrize("ds", ["lambdaVirus", "listeria"])
+def test_hot_path_batch_with_foreign_var_flt_vcf_files(tmp_path, fixture_trees, monkeypatch, ds):
+    import filecmp
+    from snp_pipeline_amd import hot_path
+    from snp_pipeline_amd import utils
+    root, work, ref_path, names, dirs, dirs_file, piles = _foreign_tree(tmp_path, fixture_trees, ds)
+    monkeypatch.chdir(work)
+    monkeypatch.delenv("SNPGPU_SITE_CALLING", raising=False)
+    before = {d: (open(os.path.join(d, "var.flt.vcf"), "rb").read(), os.stat(os.path.join(d, "var.flt.vcf")).st_mtime_ns) for d in dirs}
+    _run("hot_path_batch -f --siteCalling existing %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s"
+         % (dirs_file, ref_path, "--edge_length\x00500\x00--window_size\x001000\x00125\x0015\x00--max_snp\x003\x002\x001\x00--mode\x00all",
+            CONSENSUS_EXTRA.replace(" ", "\x00")))
+    assert hot_path.hot_path_batch.last_stats["site_calling"] == "existing"
+    # 1. nobody touched the foreign files
+    for d in dirs:
+        path = os.path.join(d, "var.flt.vcf")
+        assert (open(path, "rb").read(), os.stat(path).st_mtime_ns) == before[d], d
+    # 2. what the reference ships downstream of them
+    for name, d in zip(names, dirs):
+        for fname in ("var.flt_preserved.vcf", "var.flt_removed.vcf"):
+            assert filecmp.cmp(os.path.join(d, fname), os.path.join(root, "samples", name, fname), shallow=False), (name, fname)
+    for fname in ("snplist.txt", "snplist_preserved.txt", "referenceSNP.fasta", "referenceSNP_preserved.fasta"):
+        assert filecmp.cmp(os.path.join(work, fname), os.path.join(root, fname), shallow=False), fname
+    # 3. the consensus side against the restatement on these pileups, both flows
+    cprm = po.CallerParams(15, 0.9, 5, 2, 0.1)
+    for suffix in ("", "_preserved"):
+        snp_keys = [(c.encode(), p) for c, p in utils.read_snp_position_list(os.path.join(work, "snplist%s.txt" % suffix))]
+        seqs = {}
+        for name, d in zip(names, dirs):
+            excluded = set()
+            if suffix:
+                _, _, rm = utils.read_vcf_sites(os.path.join(d, "var.flt_removed.vcf"))
+                excluded = set((c.encode(), p) for c, p in rm)
+            want, _ = po.call_consensus_sites(piles[name], snp_keys, excluded, cprm)
+            seqs[name] = want.decode()
+            assert open(os.path.join(d, "consensus%s.fasta" % suffix)).read() == _fasta(name, seqs[name]), (name, suffix)
+        assert open(os.path.join(work, "snpma%s.fasta" % suffix)).read() == "".join(_fasta(n, seqs[n]) for n in names)
+        ids, table = so.distance_tables(seqs)
+        assert open(os.path.join(work, "snp_distance_pairwise%s.tsv" % suffix)).read() == so.pairwise_text(ids, table)
+        assert open(os.path.join(work, "snp_distance_matrix%s.tsv" % suffix)).read() == so.matrix_text(ids, table)
+    # 4. the batch call_sites in the same mode checks and writes nothing; a sample without the file is that sample's error
+    _run("call_sites_batch --siteCalling existing %s %s" % (ref_path, dirs_file))
+
+
+def test_site_calling_mode_existing_reports_a_sample_without_its_vcf(tmp_path, fixture_trees, monkeypatch, capfd):
+    root, work, ref_path, names, dirs, dirs_file, piles = _foreign_tree(tmp_path, fixture_trees, "lambdaVirus")
+    monkeypatch.chdir(work)
+    monkeypatch.setenv("StopOnSampleError", "false")
+    monkeypatch.setenv("SNPGPU_SITE_CALLING", "existing")        # the environment's spelling of --siteCalling
+    os.remove(os.path.join(dirs[1], "var.flt.vcf"))
+    late = time.time() + 100
+    os.utime(os.path.join(dirs[2], "reads.all.pileup"), (late, late))    # its var.flt.vcf is now older than its pileup
+    _run("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s"
+         % (dirs_file, ref_path, "--edge_length\x00500", CONSENSUS_EXTRA.replace(" ", "\x00")))
+    err = capfd.readouterr().err
+    assert "var.flt.vcf does not exist" in err and "is older than" in err
+    assert not os.path.exists(os.path.join(dirs[1], "var.flt.vcf"))
+    for k in (0, 3):
+        assert os.path.getsize(os.path.join(dirs[k], "consensus.fasta")) > 0
+    got = open(os.path.join(work, "snpma.fasta")).read()
+    assert got.count(">") == 2 and ">%s\n" % names[0] in got and ">%s\n" % names[3] in got

@@ -1131,3 +1131,183 @@ def test_subcommands_outside_the_hot_path_go_to_the_reference_cli(tmp_path):
     # the hot-path subcommands never go there
     r = subprocess.run([exe, "distance", "--version"], env=on_path, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "reference got" not in r.stdout
+
+
+def _call_sites_tree(tmp_path):
+    """A sample directory whose pileup is fresh (samtools is not run, call_sites.py:70-72) and a reference file."""
+    sdir = tmp_path / "samples" / "s1"
+    sdir.mkdir(parents=True)
+    ref = tmp_path / "ref.fasta"
+    ref.write_text(">c\nACGT\n")
+    old = time.time() - 1000
+    os.utime(str(ref), (old, old))
+    bam = sdir / "reads.sorted.deduped.indelrealigned.bam"
+    bam.write_bytes(b"placeholder")
+    os.utime(str(bam), (old, old))
+    (sdir / "reads.all.pileup").write_bytes(b"c\t1\tA\t9\t.........\tIIIIIIIII\n")
+    return ref, sdir
+
+
+def _fake_java(tmp_path, body):
+    """A `java` on PATH that records its arguments and prints `body` — the image has no JVM and no VarScan jar; what is checked
+    is the command the reference would run (call_sites.py:96-99) and what becomes of its output."""
+    bindir = tmp_path / "fakebin"
+    bindir.mkdir(exist_ok=True)
+    java = bindir / "java"
+    java.write_text("#!/bin/sh\necho \"$@\" >> %s/java_calls.txt\ncase \"$*\" in *mpileup2snp*) printf '%%s' '%s';; *) echo 'VarScan v2.3.9' 1>&2;; esac\n" % (tmp_path, body))
+    java.chmod(0o755)
+    return str(bindir)
+
+
+def test_call_sites_runs_the_varscan_jar_exactly_as_the_reference_does(tmp_path, monkeypatch, capsys):
+    """SNPGPU_SITE_CALLING=varscan, and auto with a jar on CLASSPATH (call_sites.py:89-108): `java <VarscanJvm_ExtraParams> -jar
+    <jar> mpileup2snp <pileup> --output-vcf 1 <VarscanMpileup2snp_ExtraParams>` with stdout as var.flt.vcf; no device involved
+    (this test runs without one).  Without a jar: the reference's global error in mode varscan."""
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    ref, sdir = _call_sites_tree(tmp_path)
+    vcf_text = "##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSample1\nc\t1\t.\tA\tG\t.\tPASS\tADP=9\tGT\t1/1\n"
+    monkeypatch.setenv("PATH", _fake_java(tmp_path, vcf_text) + os.pathsep + os.environ["PATH"])
+    monkeypatch.setenv("CLASSPATH", "/opt/x/picard.jar:/opt/y/VarScan.v2.3.9.jar")
+    monkeypatch.setenv("VarscanJvm_ExtraParams", "-Xmx300m")
+    monkeypatch.setenv("VarscanMpileup2snp_ExtraParams", "--min-var-freq 0.90")
+    log = tmp_path / "error.log"
+    monkeypatch.setenv("errorOutputFile", str(log))
+    for mode in ("varscan", None):                           # None: auto -> varscan, because the jar is on CLASSPATH
+        if mode:
+            monkeypatch.setenv("SNPGPU_SITE_CALLING", mode)
+        else:
+            monkeypatch.delenv("SNPGPU_SITE_CALLING")
+        (tmp_path / "java_calls.txt").write_text("")
+        if (sdir / "var.flt.vcf").exists():
+            (sdir / "var.flt.vcf").unlink()                  # (stale by absence: -f would also re-run samtools)
+        cli.run_command_from_args(cli.parse_command_line("call_sites %s %s" % (ref, sdir)))
+        out = capsys.readouterr().out
+        calls = (tmp_path / "java_calls.txt").read_text().splitlines()
+        assert calls[-1] == "-Xmx300m -jar /opt/y/VarScan.v2.3.9.jar mpileup2snp %s/reads.all.pileup --output-vcf 1 --min-var-freq 0.90" % sdir
+        assert (sdir / "var.flt.vcf").read_text() == vcf_text
+        assert "# Create vcf file" in out and "java -Xmx300m -jar /opt/y/VarScan.v2.3.9.jar mpileup2snp" in out and "# VarScan version v2.3.9" in out
+    # fresh: nothing runs
+    (tmp_path / "java_calls.txt").write_text("")
+    cli.run_command_from_args(cli.parse_command_line("call_sites %s %s" % (ref, sdir)))
+    assert (tmp_path / "java_calls.txt").read_text() == "" and "already freshly created" in capsys.readouterr().out
+    # the reference's checks of the result (utils.sample_error_on_file_contains)
+    monkeypatch.setenv("PATH", _fake_java(tmp_path, "Insufficient memory") + os.pathsep + os.environ["PATH"])
+    monkeypatch.setenv("StopOnSampleError", "false")
+    monkeypatch.setenv("SNPGPU_SITE_CALLING", "varscan")
+    (sdir / "var.flt.vcf").unlink()
+    with pytest.raises(SystemExit) as ei:
+        cli.run_command_from_args(cli.parse_command_line("call_sites %s %s" % (ref, sdir)))
+    assert ei.value.code == 98 and "contains unexpected text: 'Insufficient' after running VarScan." in log.read_text()
+    # no jar: global error, the reference's words
+    monkeypatch.setenv("CLASSPATH", "/opt/x/picard.jar")
+    (sdir / "var.flt.vcf").unlink()
+    with pytest.raises(SystemExit) as ei:
+        cli.run_command_from_args(cli.parse_command_line("call_sites %s %s" % (ref, sdir)))
+    assert ei.value.code == 100 and "Error: cannot execute VarScan. Define the path to VarScan.jar in the CLASSPATH environment variable." in log.read_text()
+    capsys.readouterr()
+
+
+def test_site_calling_mode_existing_never_writes_and_batch_modes(tmp_path, monkeypatch, capsys):
+    """Mode existing: var.flt.vcf is an input — present and not older than the pileup, else a sample error; call_sites_batch
+    --siteCalling varscan runs the jar per stale sample (no device involved)."""
+    from snp_pipeline_amd import call_sites as cs
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    ref, sdir = _call_sites_tree(tmp_path)
+    log = tmp_path / "error.log"
+    monkeypatch.setenv("errorOutputFile", str(log))
+    monkeypatch.setenv("StopOnSampleError", "false")
+    monkeypatch.setenv("SNPGPU_SITE_CALLING", "existing")
+    with pytest.raises(SystemExit) as ei:
+        cli.run_command_from_args(cli.parse_command_line("call_sites %s %s" % (ref, sdir)))
+    assert ei.value.code == 98 and "needs the var.flt.vcf" in log.read_text()
+    (sdir / "var.flt.vcf").write_text("foreign\n")
+    stamp = os.stat(str(sdir / "var.flt.vcf")).st_mtime_ns
+    cli.run_command_from_args(cli.parse_command_line("call_sites %s %s" % (ref, sdir)))
+    assert (sdir / "var.flt.vcf").read_text() == "foreign\n" and os.stat(str(sdir / "var.flt.vcf")).st_mtime_ns == stamp
+    late = time.time() + 100
+    os.utime(str(sdir / "reads.all.pileup"), (late, late))
+    with pytest.raises(SystemExit) as ei:
+        cli.run_command_from_args(cli.parse_command_line("call_sites %s %s" % (ref, sdir)))
+    assert ei.value.code == 98 and "is older than" in log.read_text()
+    # the batch subcommand with the jar
+    dirs_file = tmp_path / "dirs.txt"
+    dirs_file.write_text("%s\n" % sdir)
+    monkeypatch.setenv("PATH", _fake_java(tmp_path, "##fileformat=VCFv4.1\n") + os.pathsep + os.environ["PATH"])
+    monkeypatch.setenv("CLASSPATH", "/somewhere/varscan.jar")
+    monkeypatch.delenv("SNPGPU_SITE_CALLING")
+    cli.run_command_from_args(cli.parse_command_line("call_sites_batch --siteCalling varscan %s %s" % (ref, dirs_file)))
+    assert (sdir / "var.flt.vcf").read_text() == "##fileformat=VCFv4.1\n"
+    assert cs.site_calling_mode() == "varscan" and cs.site_calling_mode("device") == "device"
+    monkeypatch.setenv("CLASSPATH", "")
+    assert cs.site_calling_mode() == "device"
+    monkeypatch.setenv("SNPGPU_SITE_CALLING", "nonsense")
+    with pytest.raises(SystemExit) as ei:
+        cs.site_calling_mode()
+    assert ei.value.code == 100
+    capsys.readouterr()
+
+
+def test_private_directories_and_what_the_service_client_sends(tmp_path, monkeypatch):
+    """the per-user directory under a world-writable place is used only when it is provably ours (a real directory,
+    owned by this uid, closed to others); the service client sends the variables the steps read, not the whole environment, and
+    only to a server of the same uid; the metrics lock file does not land in the sample directory."""
+    import socket
+    from snp_pipeline_amd import _paths, service, utils
+    monkeypatch.delenv("XDG_RUNTIME_DIR", raising=False)
+    monkeypatch.setattr("tempfile.tempdir", str(tmp_path))
+    d = _paths.private_dir("service")
+    assert d == os.path.join(str(tmp_path), "snpgpu-%d" % os.getuid(), "service") and (os.stat(d).st_mode & 0o777) == 0o700
+    os.chmod(os.path.dirname(d), 0o777)                       # somebody opened it up: refused
+    with pytest.raises(_paths.UnsafeDirectory):
+        _paths.private_dir("service")
+    os.chmod(os.path.dirname(d), 0o700)
+    os.rmdir(d)
+    os.symlink(str(tmp_path), d)                              # a link where the directory should be: refused
+    with pytest.raises(_paths.UnsafeDirectory):
+        _paths.private_dir("service")
+    monkeypatch.setenv("SNPGPU_SERVICE", "auto")
+    assert service.try_client(["snp_reference", "-h"]) is None          # not used, the caller works in-process
+    os.unlink(d)
+    xdg = tmp_path / "xdg"
+    xdg.mkdir(mode=0o700)
+    monkeypatch.setenv("XDG_RUNTIME_DIR", str(xdg))
+    assert _paths.private_dir() == str(xdg / "snpgpu")
+    # what travels
+    monkeypatch.setenv("AWS_SECRET_ACCESS_KEY", "hunter2")
+    monkeypatch.setenv("CallConsensus_ExtraParams", "-q 15")
+    monkeypatch.setenv("errorOutputFile", "/x/error.log")
+    sent = {k: v for k, v in os.environ.items() if service._forwarded(k)}
+    assert "AWS_SECRET_ACCESS_KEY" not in sent and "HOME" not in sent and "SNPGPU_SERVICE" not in sent
+    assert sent["CallConsensus_ExtraParams"] == "-q 15" and sent["errorOutputFile"] == "/x/error.log" and "PATH" in sent
+    a, b = socket.socketpair(socket.AF_UNIX, socket.SOCK_STREAM)
+    try:
+        assert service._peer_is_me(a) and service._peer_is_me(b)
+    finally:
+        a.close()
+        b.close()
+    # the metrics by-product: no lock file beside it
+    sample = tmp_path / "sampleX"
+    sample.mkdir()
+    utils.update_properties(str(sample / "metrics"), {"missingPos": "3"})
+    utils.update_properties(str(sample / "metrics"), {"avePileupDepth": "22.10"}, keep_mtime=True)
+    assert sorted(os.listdir(str(sample))) == ["metrics"] and (sample / "metrics").read_text() == "missingPos=3\navePileupDepth=22.10\n"
+
+
+def test_fasta_header_words_split_as_text_mode_does(tmp_path):
+    """str.split() also splits at 0x1c-0x1f; the bytes path has to agree with the text-mode line loop."""
+    from snp_pipeline_amd import utils
+    p = tmp_path / "odd.fasta"
+    p.write_bytes(b">id1\x1c>id2 rest\nAC\x1dGT\n>\x1e\nAA\n")
+    fast = utils.fasta_records_ascii(str(p))
+    assert fast == [("id1", b"ACGT"), ("", b"AA")]
+    slow = {}
+    name = None
+    with open(str(p), "r") as f:
+        for line in f:
+            if line.startswith(">"):
+                words = line[1:].split()
+                name = words[0] if words else ""
+                slow[name] = 0
+            else:
+                slow[name] += len("".join(line.split()))
+    assert {k: len(v) for k, v in fast} == slow

@@ -116,3 +116,34 @@ def test_shard_bounds_and_tiles():
     # one rank: the exchange is the identity on the padded matrix
     m = torch.arange(256 * 256, dtype=torch.int32).view(256, 256)
     assert torch.equal(sharding.RowBands(200, 1).exchange(m, 0), m)
+
+
+def test_plans_at_world_8_with_sizes_that_do_not_divide():
+    """The exchange plan is a pure function of (n, world): checked here for the 8 ranks of a node without starting any — sample
+    blocks cover [0, n) in order; every tile of the upper triangle is computed by exactly one rank; every tile of the FULL matrix
+    (a tile and its mirror image) is sent exactly once, to the owner of its tile row; what rank q expects from rank p is what p
+    sends to q; the bands cover all rows once."""
+    for world in (8, 5, 2):
+        for n in (0, 1, 7, 127, 128, 129, 1000, 1023, 1025, 10_000):
+            bounds = [sharding.shard_bounds(n, r, world) for r in range(world)]
+            assert bounds[0][0] == 0 and bounds[-1][1] == n and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+            assert max(hi - lo for lo, hi in bounds) == (n + world - 1) // world
+            dealt = [sharding.tiles_of_rank(n, r, world) for r in range(world)]
+            every = sharding.upper_tiles(n)
+            assert sorted(t for part in dealt for t in part) == sorted(every) and len(set(every)) == len(every)
+            assert max(len(p) for p in dealt) - min(len(p) for p in dealt) <= 1
+            bands = sharding.RowBands(n, world)
+            nt = bands.nt
+            assert bands.n_padded == nt * sharding.DIST_TILE >= n and bands.n_padded - n < sharding.DIST_TILE
+            rows = [bands.band_rows(q) for q in range(world)]
+            assert rows[0][0] == 0 and rows[-1][1] == n and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+            seen = {}
+            for src in range(world):
+                for dst in range(world):
+                    lo, hi = bands.bands[dst]
+                    for (r, c) in bands.blocks[src][dst]:
+                        assert lo <= r < hi                                  # goes to the owner of its tile row
+                        assert ((min(r, c), max(r, c)) in set(dealt[src]))   # and comes from the rank that computed it
+                        assert (r, c) not in seen
+                        seen[(r, c)] = (src, dst)
+            assert len(seen) == nt * nt                                     # the whole matrix, every tile once
