@@ -174,14 +174,15 @@ def load():
     global _lib, loaded_without_torch
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError("%s is missing: run `python -m snp_pipeline_amd.build` (there is no CPU fallback)" % LIB_PATH)
+    path = os.environ.get("SNPGPU_LIB") or LIB_PATH          # (SNPGPU_LIB: the sanitizer builds of build.py, loaded by its sanitized_env)
+    if not os.path.exists(path):
+        raise ImportError("%s is missing: run `python -m snp_pipeline_amd.build` (there is no CPU fallback)" % path)
     import sys
     if "torch" in sys.modules or not TORCH_FREE_OK or os.environ.get("SNPGPU_TORCH") == "1":
         import torch  # noqa: F401  (side effect: loads libamdhip64)
     else:
         loaded_without_torch = True
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

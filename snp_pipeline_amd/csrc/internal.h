@@ -125,11 +125,13 @@ size_t snpgpu_lines_workspace_words(uint64_t nbytes);
 int snpgpu_enqueue_lines_count(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, uint32_t *ws, uint32_t **d_total);
 int snpgpu_enqueue_lines_emit(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8_t *d_buf, uint64_t nbytes, uint32_t *ws,
                               uint64_t *d_line_off, uint8_t *d_flags, uint64_t n_lines, uint64_t *d_status);
-// the line offsets alone (after snpgpu_enqueue_lines_count with the same ws), and the phase-1 site caller over them (varscan.hip)
+// the line offsets alone (after snpgpu_enqueue_lines_count with the same ws)
 int snpgpu_enqueue_lines_offsets(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, uint32_t *ws, uint64_t *d_line_off, uint64_t n_lines);
-int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, const uint64_t *d_line_off, uint64_t n_lines,
-                           const snpgpu_varscan_params *prm, snpgpu_varscan_site *d_sites, uint32_t capacity, uint32_t *d_n, uint64_t *d_status,
-                           uint32_t *d_cand /* 3 * n_lines words of scratch, 8-byte aligned; d_n: FOUR zeroed words */);
+// phase-1 site calling straight over the text, no line index (varscan.hip): see snpgpu_enqueue_varscan there for the arguments
+size_t snpgpu_varscan_scratch_bytes(uint64_t nbytes);
+int snpgpu_varscan_halo_class(const uint8_t *head, uint64_t n);
+int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, const snpgpu_varscan_params *prm, snpgpu_varscan_site *d_sites,
+                           uint32_t capacity, uint32_t *d_ctl, uint64_t *d_status, void *d_scratch, int halo_class);
 // ... and the wave-per-site call kernel over such a list (consensus.hip): "site" i is line i
 int snpgpu_enqueue_call_lines(snpgpu_ctx *ctx, const SampleDev *d_sample, const uint64_t *d_line_off, const uint8_t *d_flags,
                               uint32_t n_lines, const snpgpu_caller_params *prm, uint8_t *d_out_base, uint8_t *d_out_filters,

@@ -835,49 +835,41 @@ int snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const 
 
 namespace {
 
-// Phase-1 site calling over a pileup that is in device memory: index the lines, count + select on the device (varscan.hip),
-// records back in file order.  Synchronous.
+// Phase-1 site calling over a pileup that is in device memory: one pass over the text (line starts + select) and a walk over the
+// few candidate lines on the device (varscan.hip), records back in file order.  Synchronous.
 int varscan_resident(snpgpu_ctx *ctx, const uint8_t *d_file, uint64_t nbytes, const char *what, const snpgpu_varscan_params *params,
                      uint32_t capacity, snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status) {
     hipStream_t st = ctx->stream;
-    const size_t ws_words = snpgpu_lines_workspace_words(nbytes);
-    void *scr = nullptr;
-    int rc = snpgpu_scratch(ctx, up(4 * ws_words, 256) + 512, &scr);
-    if (rc) return rc;
-    uint32_t *d_total = nullptr;
-    rc = snpgpu_enqueue_lines_count(ctx, d_file, nbytes, (uint32_t *)scr, &d_total);
-    if (rc) return rc;
-    uint32_t n_lines = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&n_lines, d_total, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
     *out_n_sites = 0;
-    out_status[0] = ~0ull; out_status[1] = n_lines;
-    if (n_lines == 0) return SNPGPU_OK;
-    size_t o = up(4 * ws_words, 256);
-    const size_t o_off = o; o += up(8ull * n_lines, 256);
-    const size_t o_ctl = o; o += 256;                          // [0] u64 status, [8] u32 record count
+    out_status[0] = ~0ull; out_status[1] = 0;
+    if (nbytes == 0) return SNPGPU_OK;
+    // how long the lines are, from the file's first bytes: decides how much of the next tile a tile's LDS window takes along
+    uint8_t head[16384];
+    const uint64_t n_head = nbytes < sizeof head ? nbytes : sizeof head;
+    HIP_TRY(ctx, hipMemcpyAsync(head, d_file, n_head, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const int halo_class = snpgpu_varscan_halo_class(head, n_head);
+    size_t o = 0;
+    const size_t o_ctl = o; o += 256;                          // [0] u64 status, then the kernels' eight control words
     const size_t o_rec = o; o += up(sizeof(snpgpu_varscan_site) * (size_t)capacity, 256);
-    const size_t o_cand = o; o += 12ull * n_lines;
-    rc = snpgpu_scratch(ctx, o + 256, &scr);
+    const size_t o_var = o; o += up(snpgpu_varscan_scratch_bytes(nbytes), 256);
+    void *scr = nullptr;
+    int rc = snpgpu_scratch(ctx, o + 256, &scr);
     if (rc) return rc;
     char *b = (char *)scr;
-    rc = snpgpu_enqueue_lines_count(ctx, d_file, nbytes, (uint32_t *)b, &d_total);       // the scratch may have moved
-    if (rc) return rc;
-    rc = snpgpu_enqueue_lines_offsets(ctx, d_file, nbytes, (uint32_t *)b, (uint64_t *)(b + o_off), n_lines);
-    if (rc) return rc;
-    uint64_t h_ctl[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0};           // status; records found + candidates; long candidates + spare; (tuning: cycle sums)
+    uint64_t h_ctl[5] = {~0ull, 0, 0, 0, 0};                    // status; records found + candidates; long candidates + spare; lines; spare
     HIP_TRY(ctx, hipMemcpyAsync(b + o_ctl, h_ctl, sizeof h_ctl, hipMemcpyHostToDevice, st));
-    rc = snpgpu_enqueue_varscan(ctx, d_file, nbytes, (const uint64_t *)(b + o_off), n_lines, params, (snpgpu_varscan_site *)(b + o_rec), capacity,
-                                (uint32_t *)(b + o_ctl + 8), (uint64_t *)(b + o_ctl), (uint32_t *)(b + o_cand));
+    rc = snpgpu_enqueue_varscan(ctx, d_file, nbytes, params, (snpgpu_varscan_site *)(b + o_rec), capacity, (uint32_t *)(b + o_ctl + 8), (uint64_t *)(b + o_ctl),
+                                b + o_var, halo_class);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(h_ctl, b + o_ctl, sizeof h_ctl, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
 #ifdef SNPGPU_TUNING
     if (getenv("SNPGPU_VARSCAN_DEBUG"))
-        fprintf(stderr, "varscan walk: candidates %u, long %u; cycles summed over waves: lines in LDS after %llu, rounds %llu, kernel %llu\n", (uint32_t)(h_ctl[1] >> 32),
-                (uint32_t)h_ctl[2], (unsigned long long)h_ctl[3], (unsigned long long)h_ctl[4], (unsigned long long)h_ctl[5]);
+        fprintf(stderr, "varscan: halo class %d, %llu lines, candidates %u, long %u\n", halo_class, (unsigned long long)h_ctl[3], (uint32_t)(h_ctl[1] >> 32), (uint32_t)h_ctl[2]);
 #endif
     out_status[0] = h_ctl[0];
+    out_status[1] = h_ctl[3];
     const uint32_t found = (uint32_t)h_ctl[1];
     *out_n_sites = found;
     if (h_ctl[0] != ~0ull)
@@ -1107,6 +1099,7 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
         uint32_t found;
         memcpy(&status, r, 8);
         memcpy(&found, r + 8, 4);
+        memcpy(&out_status[2 * f + 1], r + 24, 8);              // the file's line count
         out_status[2 * f] = status;
         out_n_sites[f] = found;
         if (status != ~0ull) { if (src[f].rc == SNPGPU_OK) src[f].rc = SNPGPU_E_PILEUP; out_rc[f] = src[f].rc; publish(f); return SNPGPU_OK; }
@@ -1121,78 +1114,35 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
         publish(f);
         return SNPGPU_OK;
     };
-    // The work on a complete file, in two halves around the one number the host needs (its line count).
-    hipEvent_t ev_count = nullptr;
-    {
-        hipError_t e = hipEventCreateWithFlags(&ev_count, hipEventDisableTiming);
-        if (e != hipSuccess) { close_all(); return snpgpu_set_error(ctx, SNPGPU_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }
-    }
+    // The work on a complete file: one pass over its text, the walk over the candidates, results into the slot's pinned block.
+    // Nothing here waits for the device (round 3 needed the file's line count on the host between two halves of this).
+    std::vector<int8_t> halo_cls(n_files, 1);                   // set from the file's first piece as it passes through the staging ring
 #define VS_RET(expr)                                                                                                \
     do {                                                                                                            \
         hipError_t e_ = (expr);                                                                                     \
         if (e_ != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
-    auto post_begin = [&](uint32_t c) -> int {                  // count the lines; the count travels to the slot's pinned block
-        const uint32_t f = file_of[c], slot = c % n_slots;
-        const uint64_t nbytes = src[f].size;
-        void *scr = nullptr;
-        int r = snpgpu_scratch(ctx, 2 * (up(4 * snpgpu_lines_workspace_words(nbytes), 256) + 512), &scr);
-        if (r) return r;
-        const size_t half = ctx->scratch_bytes / 2 / 256 * 256;
-        uint32_t *d_total = nullptr;
-        r = snpgpu_enqueue_lines_count(ctx, dest(f), nbytes, (uint32_t *)((char *)scr + half * slot), &d_total);
-        if (r) return r;
-        VS_RET(hipMemcpyAsync((char *)p->result[slot] + 48, d_total, 4, hipMemcpyDeviceToHost, st));
-        VS_RET(hipEventRecord(ev_count, st));
-        return SNPGPU_OK;
-    };
-    auto post_finish = [&](uint32_t c) -> int {                 // index the lines, walk them, results into the slot's pinned block
+    auto post = [&](uint32_t c) -> int {
         const uint32_t f = file_of[c], slot = c % n_slots;
         const uint64_t nbytes = src[f].size;
         const uint8_t *d_file = dest(f);
         char *res = (char *)p->result[slot];
-        {
-            const double tw = now_s();
-            VS_RET(hipEventSynchronize(ev_count));
-            t_dev_wait += now_s() - tw;
-        }
-        uint32_t n_lines = 0;
-        memcpy(&n_lines, res + 48, 4);
-        out_status[2 * f + 1] = n_lines;
-        if (n_lines == 0) {
-            const uint64_t none = ~0ull;
-            memcpy(res, &none, 8);
-            memset(res + 8, 0, 8);
-            VS_RET(hipEventRecord(p->ev_done[slot], st));
-            has_result[c] = 1;
-            return SNPGPU_OK;
-        }
-        const size_t ws_words = snpgpu_lines_workspace_words(nbytes);
-        size_t o = up(4 * ws_words, 256);
-        const size_t o_off = o; o += up(8ull * n_lines, 256);
+        size_t o = 0;
         const size_t o_ctl = o; o += 256;
         const size_t o_rec = o; o += up(sizeof(snpgpu_varscan_site) * (size_t)capacity, 256) + 256;
-        const size_t o_cand = o; o += up(12ull * n_lines, 256);
-        const size_t before = ctx->scratch_bytes;
+        const size_t o_var = o; o += up(snpgpu_varscan_scratch_bytes(nbytes), 256);
         void *scr = nullptr;
         int r = snpgpu_scratch(ctx, 2 * o + 512, &scr);         // may move the scratch (it waits for the compute stream first)
         if (r) return r;
         const size_t half = ctx->scratch_bytes / 2 / 256 * 256;
         char *b = (char *)scr + half * slot;
-        uint32_t *d_total = nullptr;
-        if (ctx->scratch_bytes != before) {                     // the block counts of post_begin went with the old scratch
-            r = snpgpu_enqueue_lines_count(ctx, d_file, nbytes, (uint32_t *)b, &d_total);
-            if (r) return r;
-        }
-        r = snpgpu_enqueue_lines_offsets(ctx, d_file, nbytes, (uint32_t *)b, (uint64_t *)(b + o_off), n_lines);
-        if (r) return r;
-        uint64_t h_ctl[3] = {~0ull, 0, 0};                      // status; records found + candidates; long candidates + spare
+        uint64_t h_ctl[5] = {~0ull, 0, 0, 0, 0};                // status; records found + candidates; long candidates + spare; lines; spare
         memcpy(res + 64, h_ctl, sizeof h_ctl);                  // (a pinned source that stays valid until the copy has run)
         VS_RET(hipMemcpyAsync(b + o_ctl, res + 64, sizeof h_ctl, hipMemcpyHostToDevice, st));
-        r = snpgpu_enqueue_varscan(ctx, d_file, nbytes, (const uint64_t *)(b + o_off), n_lines, params, (snpgpu_varscan_site *)(b + o_rec), capacity,
-                                   (uint32_t *)(b + o_ctl + 8), (uint64_t *)(b + o_ctl), (uint32_t *)(b + o_cand));
+        r = snpgpu_enqueue_varscan(ctx, d_file, nbytes, params, (snpgpu_varscan_site *)(b + o_rec), capacity, (uint32_t *)(b + o_ctl + 8), (uint64_t *)(b + o_ctl),
+                                   b + o_var, halo_cls[f]);
         if (r) return r;
-        VS_RET(hipMemcpyAsync(res, b + o_ctl, 16, hipMemcpyDeviceToHost, st));
+        VS_RET(hipMemcpyAsync(res, b + o_ctl, 32, hipMemcpyDeviceToHost, st));
         if (capacity) VS_RET(hipMemcpyAsync(res + r_rec, b + o_rec, sizeof(snpgpu_varscan_site) * (size_t)capacity, hipMemcpyDeviceToHost, st));
         VS_RET(hipEventRecord(p->ev_done[slot], st));
         has_result[c] = 1;
@@ -1200,7 +1150,6 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
     };
 #undef VS_RET
     uint32_t harvested = 0;                                     // sequence numbers [0, harvested) have been copied out
-    int64_t pending = -1;                                       // a sequence number whose lines are being counted
     // file f is complete (every piece issued): give it its sequence number (unless it has one) and start its post-processing
     auto file_complete = [&](uint32_t f) -> int {
         if (seq_of[f] < 0) { seq_of[f] = (int64_t)file_of.size(); file_of.push_back(f); }
@@ -1208,17 +1157,14 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
         completed[c] = 1;
         if (!params || src[f].rc != SNPGPU_OK || src[f].size == 0) return SNPGPU_OK;
         int r = SNPGPU_OK;
-        while (!r && harvested + n_slots <= c) r = harvest(harvested++);
-        if (!r && pending >= 0) { r = post_finish((uint32_t)pending); pending = -1; }
-        if (!r) r = post_begin(c);
-        if (!r) pending = (int64_t)c;
+        while (!r && harvested + n_slots <= c) r = harvest(harvested++);           // its result block and scratch half are free then
+        if (!r) r = post(c);
         return r;
     };
-    // what can be done without waiting: finish the file whose line count has arrived, hand out results that are ready
+    // what can be done without waiting: hand out results that are ready
     auto opportunistic = [&]() -> int {
         int r = SNPGPU_OK;
-        if (pending >= 0 && hipEventQuery(ev_count) != hipErrorNotReady) { r = post_finish((uint32_t)pending); pending = -1; }
-        while (!r && harvested < file_of.size() && completed[harvested] && (int64_t)harvested != pending &&
+        while (!r && harvested < file_of.size() && completed[harvested] &&
                (!has_result[harvested] || hipEventQuery(p->ev_done[harvested % n_slots]) != hipErrorNotReady))
             r = harvest(harvested++);
         return r;
@@ -1297,7 +1243,7 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
                     const double tr = now_s();
                     std::unique_lock<std::mutex> lk(sh.mu);
                     if (sh.ready.empty())
-                        sh.cv_ready.wait_for(lk, std::chrono::microseconds(inflight.empty() && pending < 0 ? 2000 : 20), [&] { return !sh.ready.empty(); });
+                        sh.cv_ready.wait_for(lk, std::chrono::microseconds(inflight.empty() ? 2000 : 20), [&] { return !sh.ready.empty(); });
                     if (!sh.ready.empty()) { rd = sh.ready.front(); sh.ready.pop_front(); have = true; }
                     lk.unlock();
                     t_read_wait += now_s() - tr;
@@ -1325,6 +1271,7 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
                 }
                 if (place[f].block != ~0u) store->files[first + f].d = dest(f);
                 if (jb.len) {
+                    if (jb.off == 0 && params) halo_cls[f] = (int8_t)snpgpu_varscan_halo_class((const uint8_t *)p->staging[rd.buf], jb.len < 16384 ? jb.len : 16384);
                     hipStream_t cs = (issued & 1) ? p->copy_stream2 : p->copy_stream;
                     hipError_t e = hipMemcpyAsync(dest(f) + jb.off, p->staging[rd.buf], jb.len, hipMemcpyHostToDevice, cs);
                     if (e == hipSuccess) e = hipEventRecord(p->ev_copy[rd.buf], cs);
@@ -1389,7 +1336,6 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
                     seq_of[f] = (int64_t)file_of.size();
                     file_of.push_back(f);
                     const uint32_t c = (uint32_t)seq_of[f];
-                    if (pending >= 0 && (uint32_t)pending + n_slots <= c) { rcB = post_finish((uint32_t)pending); pending = -1; }
                     while (!rcB && harvested + n_slots <= c) rcB = harvest(harvested++);
                     if (rcB) break;
                 }
@@ -1408,6 +1354,7 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
                 if (sh.job_err[j] && s.rc == SNPGPU_OK) s.rc = SNPGPU_E_IO;
                 hipStream_t cs = (j & 1) ? p->copy_stream2 : p->copy_stream;
                 hipError_t e = hipSuccess;
+                if (jb.len && jb.off == 0 && params) halo_cls[f] = (int8_t)snpgpu_varscan_halo_class((const uint8_t *)p->staging[(j - JA) % R], jb.len < 16384 ? jb.len : 16384);
                 if (jb.len) e = hipMemcpyAsync(d_file + jb.off, p->staging[(j - JA) % R], jb.len, hipMemcpyHostToDevice, cs);
                 if (store) store->h2d_bytes += jb.len;
                 if (e == hipSuccess) e = hipEventRecord(p->ev_copy[(j - JA) % R], cs);
@@ -1426,7 +1373,6 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
             ns_waiting += sh.ns_waiting.load();
             if (rcB) { rc = rcB; goto done; }
         }
-        if (pending >= 0) { rc = post_finish((uint32_t)pending); pending = -1; if (rc) goto done; }
         while (harvested < file_of.size()) { rc = harvest(harvested++); if (rc) goto done; }
     }
 done:
@@ -1437,7 +1383,6 @@ done:
         if (!rc && (e1 != hipSuccess || e2 != hipSuccess)) rc = snpgpu_set_error(ctx, SNPGPU_E_HIP, "pileup copies failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     }
     close_all();
-    if (ev_count) (void)hipEventDestroy(ev_count);
     if (store) {
         store->seconds += now_s() - t_enter;
         store->seconds_preparing += t_begin - t_enter;

@@ -13,6 +13,7 @@
 // copy, not by this kernel.  The read-base automaton follows the restatement in oracle/varscan_oracle.py (which tests
 // compare it with); see its header for what the reference's fixtures pin.
 #include "internal.h"
+#include "prims.h"
 
 namespace {
 
@@ -317,262 +318,355 @@ __device__ __forceinline__ bool varscan_parse_lds(const uint32_t *lds32, uint32_
     return true;
 }
 
-// ---- two passes: select, then walk ------------------------------------------------------------------------------------------
-// Four lines in five of a real pileup show nothing but reference matches: no allele can reach min-reads2 there, and the
-// byte-wise walk over their read bases — 90 % of this step's instructions — computes nothing that is used.  So the step runs
-// as two kernels.  k_varscan_select looks at every line the cheap way: the first four TABs and the depth, then — the quality
-// column of a well-formed line being exactly `depth` bytes long — the fifth TAB where it must be, and ONE pass of word-wide
-// "is any byte ..." tests over the two long columns: no further TAB (so the line has exactly six columns, as the walk would
-// find), and any of ACGTacgt among the read bases.  A line without such a letter is done (it passed the format checks and can
-// call nothing); a line with one goes on the candidate list; a line whose shape the shortcut cannot vouch for (fewer TABs, a
-// quality column of another length, more columns) takes the complete walk right there, as before.  k_varscan_walk then gives
-// every lane one candidate: the lane copies its line into its own strip of LDS and runs the same walk as before over it.
-// Letters that are not read bases (inside an indel, after '^') only cost a walk, never a record.
+// ---- two passes over what matters: scan + select every line, then walk the few that can call something ------------------------
+// Nearly every line of a real pileup cannot reach min-reads2 for any allele, and the byte-wise walk over its read bases — 90 % of
+// this step's instructions in round 2 — computes nothing that is used.  So the step runs as two kernels, and since round 4 the
+// first of them needs NO line index: k_varscan_scan reads the text once, in tiles, finds the line starts of a tile itself (as the
+// consensus scan does) and looks at every line the cheap way: the first four TABs and the depth, then — the quality column of a
+// well-formed line being exactly `depth` bytes long — the fifth TAB where it must be, and ONE pass of word-wide tests over the two
+// long columns: no further TAB (so the line has exactly six columns, as the walk would find), and HOW MANY bytes of the read-base
+// column have bit 6 set and bit 3 clear.  Every read-base letter (ACGTacgt: 0x41 43 47 54 and 0x20 more) is such a byte; N, n and
+// '^' are not (bit 3), '$', digits, '.', ',' are not (bit 6); a mapping-quality character after '^' or a letter inside an indel
+// may be, which only makes the count an upper bound: a line with fewer such bytes than min-reads2 cannot call anything and is
+// done (it passed the format checks); a line with at least that many goes on the candidate list; a line whose shape the shortcut cannot vouch for
+// (fewer TABs, a quality column of another length, more columns) goes on the list as it is and the walk parses it in full.
+// k_varscan_walk then gives every lane one candidate: the lane copies its line into its own strip of LDS and runs the exact
+// automaton over it.  Round 3 put every line with ANY letter on the list — 14 % of the lines at 30x, 39 % at 100x, which made
+// the walk grow 6.4 x for 2.6 x the bytes; with the count it is the variant sites and little else, at any depth.
 
 // nonzero iff some byte of w is zero (exact as a yes/no test)
 __device__ __forceinline__ uint32_t any_zero_byte(uint32_t w) { return (w - 0x01010101u) & ~w & 0x80808080u; }
 __device__ __forceinline__ uint32_t any_byte_eq(uint32_t w, uint32_t c4) { return any_zero_byte(w ^ c4); }
 
-// One line for k_varscan_select: [p0, end) in the LDS copy.  Returns whether the line goes on the list, and its entry's extras.
-__device__ __forceinline__ bool select_line(const uint32_t *lds32, const uint32_t p0, uint32_t end, const snpgpu_varscan_params &prm, uint64_t &entry) {
+// A list entry (16 bytes): x, y = file offset of the line's first byte; z = its length in bytes (terminator included; 0 for a
+// line that did not end inside the tile's LDS window: VS_W_LONG, the walk finds its end itself); w = what the walk need not find
+// out again for a line whose shape the select has checked (VS_W_PLAIN): depth (bits 0-19), and where, counted from the line's
+// first byte, its second and fourth TAB are (bits 20-24, 25-29)
+constexpr uint32_t VS_W_PLAIN = 1u << 31, VS_W_LONG = 1u << 30;
+
+// One line for k_varscan_scan: [p0, end) in the LDS copy.  Returns whether the line goes on the list, and its entry's last word.
+__device__ __forceinline__ bool select_line(const uint32_t *lds32, const uint32_t p0, uint32_t end, const snpgpu_varscan_params &prm, uint32_t &extras) {
     bool is_cand = false;
-                auto byte_at = [&](uint32_t p) -> uint32_t { return (lds32[p >> 2] >> ((p & 3u) * 8u)) & 0xFFu; };
-        while (end > p0) { const uint32_t c = byte_at(end - 1); if (c != 10u && c != 13u) break; --end; }
-        bool plain = false;                                                     // the shortcut vouches for the line's shape
-        if (end > p0) {
-            // the first four TABs out of a bit mask over the 32 bytes from the line's first word on (chrom, position, reference
-            // and depth columns of a usual line end well inside; a longer prefix leaves the line to the walk)
-            const uint32_t w0 = p0 >> 2, sh0 = p0 & 3u;
-            uint32_t M = 0;
+    auto byte_at = [&](uint32_t p) -> uint32_t { return (lds32[p >> 2] >> ((p & 3u) * 8u)) & 0xFFu; };
+    while (end > p0) { const uint32_t c = byte_at(end - 1); if (c != 10u && c != 13u) break; --end; }
+    bool plain = false;                                                     // the shortcut vouches for the line's shape
+    if (end > p0) {
+        // the first four TABs out of a bit mask over the 32 bytes from the line's first word on (chrom, position, reference
+        // and depth columns of a usual line end well inside; a longer prefix leaves the line to the walk)
+        const uint32_t w0 = p0 >> 2, sh0 = p0 & 3u;
+        uint32_t M = 0;
 #pragma unroll
-            for (uint32_t q = 0; q < 8; ++q)
-                M |= (__builtin_amdgcn_udot4(eq4(lds32[w0 + q], 0x09090909u), 0x08040201u, 0u, false) >> 7) << (4u * q);
-            M &= 0xFFFFFFFFu << sh0;
-            if (end - w0 * 4u < 32u) M &= (1u << (end - w0 * 4u)) - 1u;
-            if (__popc(M) >= 4) {
-                const uint32_t t0 = w0 * 4u + (uint32_t)__ffs((int)M) - 1u; M &= M - 1u;
-                const uint32_t t1 = w0 * 4u + (uint32_t)__ffs((int)M) - 1u; M &= M - 1u;
-                const uint32_t t2 = w0 * 4u + (uint32_t)__ffs((int)M) - 1u; M &= M - 1u;
-                const uint32_t t3 = w0 * 4u + (uint32_t)__ffs((int)M) - 1u;
-                bool ok = t0 > p0 && t1 > t0 + 1 && t2 == t1 + 2 && t3 > t2 + 1 && t3 - t2 - 1 <= 9;
-                uint32_t depth = 0;
-                if (ok)
-                    for (uint32_t p = t2 + 1; p < t3; ++p) {
-                        const uint32_t c = byte_at(p);
-                        if (!is_digit(c)) ok = false;
-                        depth = depth * 10u + (c - 0x30u);
+        for (uint32_t q = 0; q < 8; ++q)
+            M |= (__builtin_amdgcn_udot4(eq4(lds32[w0 + q], 0x09090909u), 0x08040201u, 0u, false) >> 7) << (4u * q);
+        M &= 0xFFFFFFFFu << sh0;
+        if (end - w0 * 4u < 32u) M &= (1u << (end - w0 * 4u)) - 1u;
+        if (__popc(M) >= 4) {
+            const uint32_t t0 = w0 * 4u + (uint32_t)__ffs((int)M) - 1u; M &= M - 1u;
+            const uint32_t t1 = w0 * 4u + (uint32_t)__ffs((int)M) - 1u; M &= M - 1u;
+            const uint32_t t2 = w0 * 4u + (uint32_t)__ffs((int)M) - 1u; M &= M - 1u;
+            const uint32_t t3 = w0 * 4u + (uint32_t)__ffs((int)M) - 1u;
+            bool ok = t0 > p0 && t1 > t0 + 1 && t2 == t1 + 2 && t3 > t2 + 1 && t3 - t2 - 1 <= 9;
+            uint32_t depth = 0;
+            if (ok)
+                for (uint32_t p = t2 + 1; p < t3; ++p) {
+                    const uint32_t c = byte_at(p);
+                    if (!is_digit(c)) ok = false;
+                    depth = depth * 10u + (c - 0x30u);
+                }
+            const uint32_t b0 = t3 + 1;
+            // six columns with a quality column of `depth` bytes: the fifth TAB sits depth + 1 bytes before the end
+            if (ok && depth >= 1 && (uint64_t)b0 + 1 + depth < end) {
+                const uint32_t t4 = end - depth - 1;
+                if (byte_at(t4) == 9u) {
+                    // a further TAB in [b0, t4) or (t4, end)?  how many bytes with bit 6 in [b0, t4)?  Whole words in the
+                    // loops, the first and last word of each column with the bytes outside it replaced by '.'
+                    uint32_t tabs = 0, letters = 0;
+                    auto keep = [](uint32_t v, uint32_t lo, uint32_t hi) -> uint32_t {       // bytes [lo, hi) of the word, hi <= 4
+                        const uint32_t m = (0xFFFFFFFFu << (lo * 8u)) & (hi >= 4u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (hi * 8u)));
+                        return (v & m) | (0x2E2E2E2Eu & ~m);
+                    };
+                    auto bases_word = [&](uint32_t v) {
+                        tabs |= any_byte_eq(v, 0x09090909u);
+                        letters += (uint32_t)__popc(v & ~(v << 3) & 0x40404040u);
+                    };
+                    {
+                        const uint32_t wf = b0 >> 2, wl = (t4 - 1u) >> 2;
+                        if (wf == wl) bases_word(keep(lds32[wf], b0 & 3u, ((t4 - 1u) & 3u) + 1u));
+                        else {
+                            bases_word(keep(lds32[wf], b0 & 3u, 4u));
+                            for (uint32_t w = wf + 1u; w < wl; ++w) bases_word(lds32[w]);
+                            bases_word(keep(lds32[wl], 0u, ((t4 - 1u) & 3u) + 1u));
+                        }
                     }
-                const uint32_t b0 = t3 + 1;
-                // six columns with a quality column of `depth` bytes: the fifth TAB sits depth + 1 bytes before the end
-                if (ok && depth >= 1 && (uint64_t)b0 + 1 + depth < end) {
-                    const uint32_t t4 = end - depth - 1;
-                    if (byte_at(t4) == 9u) {
-                        // a further TAB in [b0, t4) or (t4, end)?  a read-base letter in [b0, t4)?  Whole words in the
-                        // loops, the first and last word of each column with the bytes outside it replaced by '.'
-                        uint32_t tabs = 0, letters = 0;
-                        auto keep = [](uint32_t v, uint32_t lo, uint32_t hi) -> uint32_t {       // bytes [lo, hi) of the word, hi <= 4
-                            const uint32_t m = (0xFFFFFFFFu << (lo * 8u)) & (hi >= 4u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (hi * 8u)));
-                            return (v & m) | (0x2E2E2E2Eu & ~m);
-                        };
-                        auto bases_word = [&](uint32_t v) {
-                            tabs |= any_byte_eq(v, 0x09090909u);
-                            const uint32_t x = v & 0xDFDFDFDFu;
-                            letters |= any_byte_eq(x, 0x41414141u) | any_byte_eq(x, 0x43434343u) | any_byte_eq(x, 0x47474747u) | any_byte_eq(x, 0x54545454u);
-                        };
-                        {
-                            const uint32_t wf = b0 >> 2, wl = (t4 - 1u) >> 2;
-                            if (wf == wl) bases_word(keep(lds32[wf], b0 & 3u, ((t4 - 1u) & 3u) + 1u));
-                            else {
-                                bases_word(keep(lds32[wf], b0 & 3u, 4u));
-                                for (uint32_t w = wf + 1u; w < wl; ++w) bases_word(lds32[w]);
-                                bases_word(keep(lds32[wl], 0u, ((t4 - 1u) & 3u) + 1u));
-                            }
+                    {
+                        const uint32_t q0 = t4 + 1u, wf = q0 >> 2, wl = (end - 1u) >> 2;
+                        if (wf == wl) tabs |= any_byte_eq(keep(lds32[wf], q0 & 3u, ((end - 1u) & 3u) + 1u), 0x09090909u);
+                        else {
+                            tabs |= any_byte_eq(keep(lds32[wf], q0 & 3u, 4u), 0x09090909u);
+                            for (uint32_t w = wf + 1u; w < wl; ++w) tabs |= any_byte_eq(lds32[w], 0x09090909u);
+                            tabs |= any_byte_eq(keep(lds32[wl], 0u, ((end - 1u) & 3u) + 1u), 0x09090909u);
                         }
-                        {
-                            const uint32_t q0 = t4 + 1u, wf = q0 >> 2, wl = (end - 1u) >> 2;
-                            if (wf == wl) tabs |= any_byte_eq(keep(lds32[wf], q0 & 3u, ((end - 1u) & 3u) + 1u), 0x09090909u);
-                            else {
-                                tabs |= any_byte_eq(keep(lds32[wf], q0 & 3u, 4u), 0x09090909u);
-                                for (uint32_t w = wf + 1u; w < wl; ++w) tabs |= any_byte_eq(lds32[w], 0x09090909u);
-                                tabs |= any_byte_eq(keep(lds32[wl], 0u, ((end - 1u) & 3u) + 1u), 0x09090909u);
-                            }
-                        }
-                        if (!tabs) {
-                            plain = true;
-                            is_cand = depth >= prm.min_coverage && letters != 0;
-                            if (depth < (1u << 20))
-                                entry |= VS_ENTRY_PLAIN | ((uint64_t)depth << 32) | ((uint64_t)(t1 - p0) << 52) | ((uint64_t)(t3 - p0) << 57);
-                        }
+                    }
+                    if (!tabs) {
+                        plain = true;
+                        // (min_reads2 0: an allele without reads is skipped by the walk, so one letter is still needed)
+                        is_cand = depth >= prm.min_coverage && letters >= (prm.min_reads2 > 1u ? prm.min_reads2 : 1u);
+                        if (depth < (1u << 20)) extras = VS_W_PLAIN | depth | ((t1 - p0) << 20) | ((t3 - p0) << 25);
                     }
                 }
             }
         }
-        if (!plain && end > p0) is_cand = true;                                 // the walk looks at it in full (format errors included)
+    }
+    if (!plain && end > p0) is_cand = true;                                 // the walk looks at it in full (format errors included)
     return is_cand;
 }
 
-// One wave per workgroup; a wave takes groups of 64 consecutive lines.  A group's bytes are one contiguous span of the file:
-// it is fetched with 16-byte loads (coalesced; every byte of the file crosses HBM once) into REGISTERS one round ahead — the
-// line offsets that say where it is, two rounds ahead — and written to LDS when the round before is done, so that the loads
-// of the next group are in flight while this one's lines are looked at (without that the kernel sits out two dependent trips
-// to memory per group and runs at a third of its arithmetic).  kChunks: 16-byte pieces per lane a span may have (LDS bytes /
-// 1024); a longer span (a group of very long lines) goes to the walk as it is.
-template <int kChunks>
-__global__ __launch_bounds__(64) void k_varscan_select(const uint8_t *__restrict__ buf, uint64_t nbytes, const uint64_t *__restrict__ line_off,
-                                                       uint64_t n_lines, snpgpu_varscan_params prm, uint64_t *cand, uint32_t *cand_n) {
-    // (a workgroup is ONE wave: its LDS operations execute in order, so no s_barrier is needed between writing the span and
-    // reading it — and __syncthreads() would also wait for the loads that are meant to stay in flight)
+// A candidate straight from global memory, byte by byte (the generic form of the walk; also what a full list falls back on).
+__device__ void walk_entry_global(const uint8_t *buf, uint64_t nbytes, uint4 e, const snpgpu_varscan_params &prm, snpgpu_varscan_site *out,
+                                  uint32_t capacity, uint32_t *out_n, unsigned long long *status) {
+    const uint64_t p0 = (uint64_t)e.x | ((uint64_t)e.y << 32);
+    uint64_t end = p0 + e.z;
+    if (e.w & VS_W_LONG) {                                                              // ends at the first line terminator
+        end = p0;
+        while (end < nbytes && buf[end] != 10u && buf[end] != 13u) ++end;
+    }
+    varscan_line<uint64_t>(GlobalBytes{buf}, p0, end < nbytes ? end : nbytes, 0, prm, out, capacity, out_n, status);
+}
+
+#define VS_TILE 4096u
+#define VS_LIST_CAP 256u          // line starts held in LDS per pass (a tile with more makes extra passes)
+#define VS_CAND_LOCAL 128u        // candidate entries a wave collects in LDS before it takes a place on the list
+
+// 0x80 in every byte of w that is '\n' / '\r' -> 16 bits per 16-byte chunk
+__device__ __forceinline__ uint32_t bits16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
+    return (__builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false) >> 7) | ((__builtin_amdgcn_udot4(f1, 0x08040201u, 0u, false) >> 7) << 4) |
+           ((__builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false) >> 7) << 8) | ((__builtin_amdgcn_udot4(f3, 0x08040201u, 0u, false) >> 7) << 12);
+}
+// bit k: a line starts at byte k of the chunk — the byte before it is '\n', or a '\r' that it does not follow with '\n'
+// (Java's readLine(): LF, CR, CR LF).  prev: the dword that ends right before the chunk.
+__device__ __forceinline__ uint32_t chunk_starts(uint4 v, uint32_t prev) {
+    const uint32_t N = bits16(eq4(v.x, 0x0A0A0A0Au), eq4(v.y, 0x0A0A0A0Au), eq4(v.z, 0x0A0A0A0Au), eq4(v.w, 0x0A0A0A0Au));
+    const uint32_t C = bits16(eq4(v.x, 0x0D0D0D0Du), eq4(v.y, 0x0D0D0D0Du), eq4(v.z, 0x0D0D0D0Du), eq4(v.w, 0x0D0D0D0Du));
+    const uint32_t pb = prev >> 24, pn = pb == 10u ? 1u : 0u, pc = pb == 13u ? 1u : 0u;
+    return (((N << 1) | pn) | (((C << 1) | pc) & ~N)) & 0xFFFFu;
+}
+
+// One wave per workgroup, every wave one contiguous run of 4 KiB tiles of the file.  A tile's slot in LDS holds the bytes
+// [t0 - 16, t0 + 4096 + halo): tile k+1 streams into the other slot with LDS-DMA (global_load_lds_dwordx4, no register round
+// trip) while tile k is looked at, the wave waits for its own requests with a counted s_waitcnt, nothing else waits for anything.
+// Per tile: lane l looks at chunks l, 64 + l, 128 + l, 192 + l (conflict-free ds_read_b128) for line terminators; a wave prefix
+// sum puts the starts into an LDS list in file order; then one lane per line (select_line).  A line that starts in the tile lies
+// completely in the slot when it is shorter than the halo; one that does not is left to the walk (VS_W_LONG).  The halo is
+// fetched again with the next tile (mostly from L2): 6 % / 25 % more requests for kHaloChunks 15 / 63.
+// Coordinates are "aligned": byte a of abase = file byte a - lo, with abase 16-byte aligned and the file at [lo, hi).
+template <int kHaloChunks>
+__global__ __launch_bounds__(64) void k_varscan_scan(const uint8_t *__restrict__ abase, uint64_t lo, uint64_t hi, uint64_t n_tiles, snpgpu_varscan_params prm,
+                                                     uint4 *cand, uint32_t cand_cap, uint32_t *ctl, unsigned long long *status, snpgpu_varscan_site *out,
+                                                     uint32_t capacity, uint32_t *wave_lines) {
+    constexpr uint32_t kChunks = 1u + VS_TILE / 16u + (uint32_t)kHaloChunks;            // 16-byte chunks of a slot
+    constexpr uint32_t kSlotBytes = kChunks * 16u;
+    constexpr uint32_t kDma = (kChunks + 63u) / 64u;                                    // wave instructions per tile request
     extern __shared__ uint4 vs_lds[];
-    const uint32_t *lds32 = (const uint32_t *)vs_lds;
-    constexpr uint32_t lds_bytes = kChunks * 1024;
-    // candidates collect in LDS (behind the span) and leave with ONE atomic per VS_CAND_LOCAL of them: an atomic per wave of
-    // 64 lines on one address (~12 ns each, 78 000 waves per 5 Mbp sample) would cost more than everything else in this kernel
-    uint64_t *cand_local = (uint64_t *)((char *)vs_lds + lds_bytes);
-    uint32_t n_local = 0;
+    uint4 *slot0 = vs_lds, *slot1 = vs_lds + kChunks;
+    uint4 *cand_local = vs_lds + 2 * kChunks;
+    uint16_t *lstart = (uint16_t *)(cand_local + VS_CAND_LOCAL);                        // VS_LIST_CAP + 2 entries
+    const uint32_t lane = threadIdx.x;
+    const uint8_t *fbuf = abase + lo;                                                   // file byte 0
+    const uint64_t nbytes = hi - lo;
+    uint32_t n_local = 0, lines_seen = 0;
     auto flush = [&]() {
         if (n_local == 0) return;
         uint32_t base = 0;
-        if (threadIdx.x == 0) base = atomicAdd(cand_n, n_local);
+        if (lane == 0) base = atomicAdd(ctl + 1, n_local);
         base = __builtin_amdgcn_readfirstlane(base);
-        for (uint32_t k = threadIdx.x; k < n_local; k += 64) cand[base + k] = cand_local[k];
+        for (uint32_t k = lane; k < n_local; k += 64) {
+            const uint4 e = cand_local[k];
+            if (base + k < cand_cap) cand[base + k] = e;
+            else walk_entry_global(fbuf, nbytes, e, prm, out, capacity, ctl, status);  // the list is full: looked at on the spot
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                // (the requests in flight are counted from zero again)
         n_local = 0;
     };
-    const uint64_t n_groups = (n_lines + 63) / 64;
-    const uint32_t lane = threadIdx.x;
-    // where the lines of a group start: lane l holds the offset (+1) of line first + l, every lane that of the line after the group
-    struct Meta { uint64_t lo, next; };
-    auto load_meta = [&](uint64_t grp) -> Meta {
-        Meta m{0, 0};
-        if (grp < n_groups) {
-            const uint64_t first = grp * 64;
-            m.lo = first + lane < n_lines ? line_off[first + lane] : nbytes + 1;
-            m.next = first + 64 < n_lines ? line_off[first + 64] : nbytes + 1;
+    // my run of tiles
+    const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const uint64_t t_first = (uint64_t)blockIdx.x * per, t_end = t_first + per < n_tiles ? t_first + per : n_tiles;
+    auto interior = [&](uint64_t tt) { const uint64_t x0 = tt * VS_TILE; return x0 >= lo + 16 && x0 + VS_TILE + 16u * kHaloChunks <= hi; };
+    // request tile tt into `slot`; returns whether it travels by DMA (else it has been staged synchronously)
+    auto request = [&](uint64_t tt, uint4 *slot) -> bool {
+        if (interior(tt)) {
+            const uint8_t *gs = abase + tt * VS_TILE - 16;
+            const uint32_t voff = lane * 16u;
+            const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)slot);
+#pragma unroll
+            for (uint32_t r = 0; r < kDma; ++r) {
+                const uint64_t ga = (uint64_t)(uintptr_t)gs + (r >> 2) * 4096u;
+                const uint64_t gr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ga >> 32)) << 32) |
+                                    (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ga);
+                const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (r >> 2) * 4096u);
+                if (r * 64u + lane < kChunks)
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(gr), "s"(m0v), "n"((r & 3u) * 1024u) : "memory");
+            }
+            return true;
         }
-        return m;
-    };
-    struct Span { uint64_t a0; uint32_t n16; bool staged; };
-    auto span_of = [&](uint64_t grp, const Meta &m) -> Span {
-        Span sp{0, 0, false};
-        if (grp < n_groups) {
-            const uint64_t s0 = __shfl(m.lo, 0) - 1, s1 = m.next - 1;
-            const uint64_t a0 = ((uintptr_t)buf + s0) & ~(uint64_t)15, a1 = (((uintptr_t)buf + s1) + 15) & ~(uint64_t)15;
-            sp.a0 = a0;
-            sp.staged = a1 - a0 <= lds_bytes;
-            sp.n16 = sp.staged ? (uint32_t)((a1 - a0) / 16) : 0;
+        // first / last tiles of the file: byte loads; the byte before the file reads as '\n' (byte 0 starts a line), the other
+        // bytes outside it as NUL (no line starts past the end)
+        const int64_t x0 = (int64_t)(tt * VS_TILE) - 16;
+#pragma nounroll
+        for (uint32_t e = lane; e < kChunks; e += 64) {
+            uint32_t d[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t idx = x0 + (int64_t)e * 16 + 4 * k + j;
+                    const uint32_t bb = (idx >= (int64_t)lo && idx < (int64_t)hi) ? (uint32_t)abase[idx] : (idx + 1 == (int64_t)lo ? 10u : 0u);
+                    d[k] |= bb << (8 * j);
+                }
+            slot[e] = make_uint4(d[0], d[1], d[2], d[3]);
         }
-        return sp;
+        return false;
     };
-    // the span in flight: one named register quadruple per chunk (an array indexed in a loop ends up in scratch memory); every
-    // lane loads every round, from a clamped index (a0 of a group past the end is the file's first chunk)
-#define VS_EACH(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23)
-#define VS_DECL(k) uint4 R##k = make_uint4(0, 0, 0, 0);
-    VS_EACH(VS_DECL)
-#undef VS_DECL
-#define VS_LOAD(k) if constexpr (kChunks > k) { const uint32_t c_ = k * 64u + lane; R##k = src_[c_ < top_ ? c_ : top_]; }
-#define VS_FETCH(sp)                                                                          \
-    {                                                                                         \
-        const uint4 *src_ = (const uint4 *)((sp).n16 ? (sp).a0 : ((uintptr_t)buf & ~(uint64_t)15)); \
-        const uint32_t top_ = (sp).n16 ? (sp).n16 - 1u : 0u;                                  \
-        VS_EACH(VS_LOAD)                                                                      \
-    }
-#define VS_STORE(k) if constexpr (kChunks > k) { const uint32_t c_ = k * 64u + lane; if (c_ < sp0.n16) vs_lds[c_] = R##k; }
-    uint64_t grp = blockIdx.x;
-    Meta m0 = load_meta(grp), m1 = load_meta(grp + gridDim.x);
-    Span sp0 = span_of(grp, m0);
-    VS_FETCH(sp0)
-    for (; grp < n_groups; grp += gridDim.x) {
-        // this group's bytes: registers -> LDS
-        VS_EACH(VS_STORE)
+    bool dma_cur = false, dma_next = false;
+    if (t_first < t_end) dma_cur = request(t_first, slot0);
+    if (t_first + 1 < t_end) dma_next = request(t_first + 1, slot1);
+    uint4 *cur = slot0, *other = slot1;
+    for (uint64_t tt = t_first; tt < t_end; ++tt) {
+        // the current tile's request has landed when only the next tile's is outstanding
+        if (dma_next && tt + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kDma) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        // the next group's bytes and the offsets of the one after it are on their way while this group is looked at
-        const Span sp1 = span_of(grp + gridDim.x, m1);
-        VS_FETCH(sp1)
-        const Meta m2 = load_meta(grp + 2 * (uint64_t)gridDim.x);
-        const uint64_t first = grp * 64, last = first + 64 < n_lines ? first + 64 : n_lines;
-        const uint64_t line = first + lane;
-        bool is_cand = false;
-        uint64_t entry = line;                                                          // + what the walk need not find out again (VS_ENTRY_*)
-        {
-            uint64_t up1 = __shfl_down(m0.lo, 1);                                       // the next line's start
-            if (lane == 63 || line + 1 >= last) up1 = m0.next;
-            if (line < last) {
-                if (!sp0.staged) is_cand = true;                                        // a span of very long lines: all of it to the walk
-                else {
-                    const uint64_t zero = sp0.a0 - (uintptr_t)buf;                      // file offset of LDS byte 0 (mod 2^64)
-                    is_cand = select_line(lds32, (uint32_t)(m0.lo - 1 - zero), (uint32_t)(up1 - 1 - zero), prm, entry);
+        (void)dma_cur;
+        const uint32_t *lds32 = (const uint32_t *)cur;
+        const uint64_t t0 = tt * VS_TILE;                                               // aligned coordinate of slot byte 16
+        // slot offset of the file's end (what a line without a terminator runs to), when that is inside the slot
+        const uint64_t hi_rel = hi - (t0 - 16);
+        const uint32_t hi_slot = hi_rel < kSlotBytes ? (uint32_t)hi_rel : 0xFFFFFFFFu;
+        // ---- the line starts of the tile: chunk i * 64 + lane, i = 0..3 -------------------------------------------------
+        uint32_t m[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t c = 1u + (uint32_t)i * 64u + lane;                           // chunk of the slot
+            m[i] = chunk_starts(cur[c], lds32[c * 4u - 1u]);
+            if (hi_slot != 0xFFFFFFFFu) {                                               // a start at or past the end of the file is no line
+                const uint32_t b = c * 16u;
+                m[i] &= hi_slot <= b ? 0u : (hi_slot - b >= 16u ? 0xFFFFu : (1u << (hi_slot - b)) - 1u);
+            }
+        }
+        const uint32_t cA = (uint32_t)__popc(m[0]) | ((uint32_t)__popc(m[1]) << 16), cB = (uint32_t)__popc(m[2]) | ((uint32_t)__popc(m[3]) << 16);
+        const uint32_t iA = wave_inclusive_sum(cA), iB = wave_inclusive_sum(cB);
+        const uint32_t tA = (uint32_t)__builtin_amdgcn_readlane((int)iA, 63), tB = (uint32_t)__builtin_amdgcn_readlane((int)iB, 63);
+        const uint32_t tot0 = tA & 0xFFFFu, tot1 = tA >> 16, tot2 = tB & 0xFFFFu, tot3 = tB >> 16;
+        const uint32_t T = tot0 + tot1 + tot2 + tot3;
+        const uint32_t first_idx[4] = {(iA - cA) & 0xFFFFu, tot0 + ((iA - cA) >> 16), tot0 + tot1 + ((iB - cB) & 0xFFFFu), tot0 + tot1 + tot2 + ((iB - cB) >> 16)};
+        lines_seen += T;
+        // ---- where the line after the tile's last one starts: the first start in the halo, else the end of the file, else unknown ----
+        uint32_t next = hi_slot;                                                        // 0xFFFFFFFF: not in the slot
+        if (T) {
+#pragma unroll 1
+            for (uint32_t r = 0; r * 64u < (uint32_t)kHaloChunks; ++r) {
+                const uint32_t c = 1u + VS_TILE / 16u + r * 64u + lane;
+                uint32_t st = 0;
+                if (c < kChunks) {
+                    st = chunk_starts(cur[c], lds32[c * 4u - 1u]);
+                    if (hi_slot != 0xFFFFFFFFu) { const uint32_t b = c * 16u; st &= hi_slot <= b ? 0u : (hi_slot - b >= 16u ? 0xFFFFu : (1u << (hi_slot - b)) - 1u); }
+                }
+                const unsigned long long any = __ballot(st != 0);
+                if (any) {
+                    const uint32_t src = (uint32_t)__ffsll((long long)any) - 1u;
+                    const uint32_t pos = c * 16u + (uint32_t)__ffs((int)st) - 1u;
+                    next = (uint32_t)__builtin_amdgcn_readlane((int)pos, src);
+                    break;
                 }
             }
         }
-        const unsigned long long m = __ballot(is_cand);
-        if (m) {
-            if (is_cand) cand_local[n_local + __popcll(m & ((1ull << lane) - 1ull))] = entry;
-            n_local += (uint32_t)__popcll(m);
+        // ---- passes of up to VS_LIST_CAP lines: the list, then one lane per line ---------------------------------------
+#pragma unroll 1
+        for (uint32_t base = 0; base < T; base += VS_LIST_CAP) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t mm = m[i], idx = first_idx[i];
+                const uint32_t b = (1u + (uint32_t)i * 64u + lane) * 16u;
+                while (mm) {
+                    const uint32_t k = (uint32_t)__ffs((int)mm) - 1u;
+                    mm &= mm - 1u;
+                    if (idx - base <= VS_LIST_CAP) lstart[idx - base] = (uint16_t)(b + k);      // (unsigned: also false for idx < base)
+                    ++idx;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n_here = T - base < VS_LIST_CAP ? T - base : VS_LIST_CAP;
+#pragma unroll 1
+            for (uint32_t r = 0; r < n_here; r += 64) {
+                const uint32_t i = r + lane;
+                bool is_cand = false;
+                uint4 e = make_uint4(0, 0, 0, 0);
+                if (i < n_here) {
+                    const uint32_t p0 = lstart[i];
+                    const uint32_t end = base + i + 1u < T ? (uint32_t)lstart[i + 1u] : next;
+                    const uint64_t off = t0 - 16 + p0 - lo;                             // file offset of the line
+                    e.x = (uint32_t)off; e.y = (uint32_t)(off >> 32);
+                    if (end == 0xFFFFFFFFu) { is_cand = true; e.w = VS_W_LONG; }        // runs past the slot: the walk finds its end
+                    else { e.z = end - p0; is_cand = select_line(lds32, p0, end, prm, e.w); }
+                }
+                const unsigned long long mk = __ballot(is_cand);
+                if (mk) {
+                    if (is_cand) cand_local[n_local + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = e;
+                    n_local += (uint32_t)__popcll(mk);
+                    __builtin_amdgcn_wave_barrier();
+                    if (n_local + 64u > VS_CAND_LOCAL) { flush(); __builtin_amdgcn_wave_barrier(); }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
+        // this slot is free: every LDS read of it has returned
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if (n_local + 64 > VS_CAND_LOCAL) { flush(); __builtin_amdgcn_wave_barrier(); }
-        m0 = m1; m1 = m2; sp0 = sp1;
+        dma_cur = dma_next;
+        dma_next = tt + 2 < t_end ? request(tt + 2, cur) : false;
+        uint4 *t_ = cur; cur = other; other = t_;
     }
     __builtin_amdgcn_wave_barrier();
     flush();
-#undef VS_FETCH
-#undef VS_LOAD
-#undef VS_STORE
-#undef VS_EACH
+    if (lane == 0) wave_lines[blockIdx.x] = lines_seen;
 }
 
 // One lane per candidate line: the 64 lines of a wave are copied into LDS back to back (16-byte chunks; a wave prefix sum of
 // the chunk counts gives every lane its place) and every lane walks its own there.  What does not fit the wave's LDS (a few
-// lines several times the mean length) goes on a second list.  The kernel is a chain of dependent loads per line — list entry,
-// line offsets, bytes — so the entries are fetched two rounds ahead and the offsets one round ahead of their use.
-__global__ __launch_bounds__(64) void k_varscan_walk(const uint8_t *__restrict__ buf, uint64_t nbytes, const uint64_t *__restrict__ line_off,
-                                                     uint64_t n_lines, snpgpu_varscan_params prm, snpgpu_varscan_site *out, uint32_t capacity,
-                                                     uint32_t *out_n, unsigned long long *status, uint32_t lds_bytes, const uint64_t *__restrict__ cand,
-                                                     const uint32_t *__restrict__ cand_n, uint32_t *long_lines, uint32_t *long_n) {
+// lines several times the mean length) and what the scan could not measure (VS_W_LONG) goes on a second list.  The entries are
+// fetched two rounds ahead of their use.
+__global__ __launch_bounds__(64) void k_varscan_walk(const uint8_t *__restrict__ buf, uint64_t nbytes, snpgpu_varscan_params prm, snpgpu_varscan_site *out,
+                                                     uint32_t capacity, uint32_t *out_n, unsigned long long *status, uint32_t lds_bytes,
+                                                     const uint4 *__restrict__ cand, const uint32_t *__restrict__ cand_n, uint32_t cand_cap,
+                                                     uint32_t *long_idx, uint32_t *long_n) {
     extern __shared__ uint4 vs_lds[];
-    const uint32_t n = *cand_n;
+    const uint32_t n = *cand_n < cand_cap ? *cand_n : cand_cap;
     const uint64_t stride = (uint64_t)gridDim.x * 64;
     uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-    const uint64_t NONE = ~0ull;
-    auto entry = [&](uint64_t k) -> uint64_t { return k < n ? cand[k] : NONE; };
-    auto bounds = [&](uint64_t e, uint64_t &p0, uint64_t &end) {
-        p0 = end = 0;
-        const uint32_t ln = (uint32_t)e;
-        if (e != NONE) { p0 = line_off[ln] - 1; end = (uint64_t)ln + 1 < n_lines ? line_off[ln + 1] - 1 : nbytes; }
-    };
-    uint64_t line = entry(i), line1 = entry(i + stride);
-    uint64_t p0, end;
-    bounds(line, p0, end);
-#ifdef SNPGPU_TUNING
-    unsigned long long t_copy = 0, t_walk = 0, t_all = __builtin_readcyclecounter();
-#endif
+    const uint4 NONE = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
+    auto entry = [&](uint64_t k) -> uint4 { return k < n ? cand[k] : NONE; };
+    uint4 e = entry(i), e1 = entry(i + stride);
     for (uint64_t i0 = (uint64_t)blockIdx.x * 64; i0 < n; i0 += stride, i += stride) {
-#ifdef SNPGPU_TUNING
-        const unsigned long long c0 = __builtin_readcyclecounter();
-#endif
-        const uint64_t line2 = entry(i + 2 * stride);               // two rounds ahead
-        uint64_t p0n, endn;
-        bounds(line1, p0n, endn);                                    // one round ahead
-        const bool have = line != NONE;
-        const uint64_t a0 = ((uintptr_t)buf + p0) & ~(uint64_t)15, a1 = have ? (((uintptr_t)buf + end) + 15) & ~(uint64_t)15 : a0;
-        const uint32_t chunks = (uint32_t)((a1 - a0) / 16);
-        // exclusive prefix sum of the chunk counts over the wave
-        uint32_t incl = chunks;
+        const uint4 e2 = entry(i + 2 * stride);                      // two rounds ahead
+        const bool have = !(e.x == 0xFFFFFFFFu && e.y == 0xFFFFFFFFu);
+        const bool is_long = have && (e.w & VS_W_LONG);
+        const uint64_t p0 = (uint64_t)e.x | ((uint64_t)e.y << 32), end = p0 + e.z;
+        const uint64_t a0 = ((uintptr_t)buf + p0) & ~(uint64_t)15, a1 = (have && !is_long) ? (((uintptr_t)buf + end) + 15) & ~(uint64_t)15 : a0;
+        const uint32_t chunks = a1 - a0 > 0xFFFFFFull ? 0xFFFFFFu / 16u : (uint32_t)((a1 - a0) / 16);
+        // exclusive prefix sum of the chunk counts over the wave (a line that does not fit takes no room)
+        const bool alone_fits = (uint64_t)chunks * 16 <= lds_bytes;
+        const uint32_t mine_chunks = alone_fits ? chunks : 0u;
+        uint32_t incl = mine_chunks;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t up_ = __shfl_up(incl, o);
             if ((int)threadIdx.x >= o) incl += up_;
         }
-        const uint32_t first_chunk = incl - chunks;
-        const bool fits = (uint64_t)incl * 16 <= lds_bytes;
-        if (have && fits) {
+        const uint32_t first_chunk = incl - mine_chunks;
+        const bool fits = alone_fits && (uint64_t)incl * 16 <= lds_bytes;
+        if (have && !is_long && fits) {
             uint4 *mine = vs_lds + first_chunk;
             const uint4 *src = (const uint4 *)a0;
             for (uint32_t c = 0; c < chunks; ++c) mine[c] = src[c];
-#ifdef SNPGPU_TUNING
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
-            if (threadIdx.x == 0) t_copy += __builtin_readcyclecounter() - c0;
-#endif
             const uint32_t lane0 = first_chunk * 16u;                                   // LDS offset of this lane's bytes
             const uint64_t a0_off = a0 - (uintptr_t)buf;                                // their file offset
             const uint32_t *lds32 = (const uint32_t *)vs_lds;
@@ -580,10 +674,10 @@ __global__ __launch_bounds__(64) void k_varscan_walk(const uint8_t *__restrict__
             uint32_t l1 = lane0 + (uint32_t)(end - a0_off);
             LineCols cols;
             bool ok;
-            if (line & VS_ENTRY_PLAIN) {
-                // the columns are where k_varscan_select found them
+            if (e.w & VS_W_PLAIN) {
+                // the columns are where k_varscan_scan found them
                 while (l1 > l0) { const uint32_t c = (lds32[(l1 - 1u) >> 2] >> (((l1 - 1u) & 3u) * 8u)) & 0xFFu; if (c != 10u && c != 13u) break; --l1; }
-                const uint32_t depth = (uint32_t)(line >> 32) & 0xFFFFFu, t1 = l0 + ((uint32_t)(line >> 52) & 31u), t3 = l0 + ((uint32_t)(line >> 57) & 31u);
+                const uint32_t depth = e.w & 0xFFFFFu, t1 = l0 + ((e.w >> 20) & 31u), t3 = l0 + ((e.w >> 25) & 31u);
                 const uint32_t t4 = l1 - depth - 1u;
                 cols = LineCols{t1 + 1u, depth, t3 + 1u, t4, t4 + 1u, l1};
                 ok = true;
@@ -592,71 +686,88 @@ __global__ __launch_bounds__(64) void k_varscan_walk(const uint8_t *__restrict__
             }
             if (ok) varscan_core_lds(lds32, l0, cols.ref_at, cols.depth, cols.b0, cols.b1, cols.q0, cols.q1, a0_off - lane0, prm, out, capacity, out_n);
         } else if (have) {
-            long_lines[atomicAdd(long_n, 1u)] = (uint32_t)line;                         // (rare)
+            long_idx[atomicAdd(long_n, 1u)] = (uint32_t)i;                              // (rare)
         }
-        line = line1; line1 = line2;
-        p0 = p0n; end = endn;
-#ifdef SNPGPU_TUNING
-        __builtin_amdgcn_wave_barrier();
-        if (threadIdx.x == 0) t_walk += __builtin_readcyclecounter() - c0;
-#endif
+        e = e1; e1 = e2;
     }
-#ifdef SNPGPU_TUNING
-    if (threadIdx.x == 0) {                                                             // [0] cycles until the lines were in LDS, [1] whole rounds, [2] whole kernel (summed over the waves)
-        unsigned long long *dbg = (unsigned long long *)(long_n + 2);
-        atomicAdd(dbg, t_copy); atomicAdd(dbg + 1, t_walk); atomicAdd(dbg + 2, __builtin_readcyclecounter() - t_all);
-    }
-#endif
 }
 
-// The candidates that did not fit a strip: one lane per line, bytes straight from global memory.
-__global__ __launch_bounds__(64) void k_varscan_walk_long(const uint8_t *__restrict__ buf, uint64_t nbytes, const uint64_t *__restrict__ line_off,
-                                                          uint64_t n_lines, snpgpu_varscan_params prm, snpgpu_varscan_site *out, uint32_t capacity,
-                                                          uint32_t *out_n, unsigned long long *status, const uint32_t *__restrict__ long_lines,
-                                                          const uint32_t *__restrict__ long_n) {
-    const uint32_t n = *long_n;
-    for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 64) {
-        const uint64_t line = long_lines[i];
-        const uint64_t p0 = line_off[line] - 1, end = line + 1 < n_lines ? line_off[line + 1] - 1 : nbytes;
-        varscan_line<uint64_t>(GlobalBytes{buf}, p0, end, 0, prm, out, capacity, out_n, status);
+// The candidates that did not fit a strip or have no known end: one lane per line, bytes straight from global memory.  Block 0
+// also adds up the line counts of the scan's waves (the one number besides the records that the host is told).
+__global__ __launch_bounds__(64) void k_varscan_walk_long(const uint8_t *__restrict__ buf, uint64_t nbytes, snpgpu_varscan_params prm, snpgpu_varscan_site *out,
+                                                          uint32_t capacity, uint32_t *ctl, unsigned long long *status, const uint4 *__restrict__ cand,
+                                                          const uint32_t *__restrict__ long_idx, const uint32_t *__restrict__ wave_lines, uint32_t n_waves) {
+    const uint32_t n = ctl[2];
+    for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 64)
+        walk_entry_global(buf, nbytes, cand[long_idx[i]], prm, out, capacity, ctl, status);
+    if (blockIdx.x == 0) {
+        unsigned long long s = 0;
+        for (uint32_t k = threadIdx.x; k < n_waves; k += 64) s += wave_lines[k];
+        for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+        if (threadIdx.x == 0) { ctl[4] = (uint32_t)s; ctl[5] = (uint32_t)(s >> 32); }
     }
 }
 
 }  // namespace
 
-// d_n: FOUR zeroed words — [0] records found, [1] candidate lines, [2] candidates too long for a strip (scratch of the passes);
-// d_status: one u64 preset to UINT64_MAX (becomes the offset of the first malformed line); d_cand: 2 * n_lines words of scratch
-int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, const uint64_t *d_line_off, uint64_t n_lines,
-                           const snpgpu_varscan_params *prm, snpgpu_varscan_site *d_sites, uint32_t capacity, uint32_t *d_n, uint64_t *d_status,
-                           uint32_t *d_cand) {
-    if (n_lines == 0) return SNPGPU_OK;
-    // select: LDS per wave = the span of 64 lines of the file's mean length with a quarter to spare, in KiB steps up to 32 KiB (a
-    // span that does not fit goes to the walk as it is) + the local candidate list; a CU's 160 KiB then hold 160 / that many waves
-    const uint64_t mean = nbytes / n_lines + 1;
-    uint64_t want_lds = mean * 64 * 5 / 4 + 64;
-    const uint32_t lds = want_lds <= 4096 ? 4096 : want_lds <= 6144 ? 6144 : want_lds <= 8192 ? 8192 : want_lds <= 12288 ? 12288 : want_lds <= 16384 ? 16384 : 24576;
-    const uint32_t sel_lds = lds + 8 * VS_CAND_LOCAL;
-    const uint32_t waves_per_cu = 160 * 1024 / sel_lds < 32 ? 160 * 1024 / sel_lds : 32;
-    const uint64_t groups = (n_lines + 63) / 64;
-    const uint64_t cap = (uint64_t)ctx->n_cu * waves_per_cu * 2;
-    const unsigned grid = (unsigned)(groups < cap ? groups : cap);
-    uint64_t *d_list = (uint64_t *)d_cand;
-#define VS_SELECT(K) k_varscan_select<K><<<grid, 64, sel_lds, ctx->stream>>>(d_buf, nbytes, d_line_off, n_lines, *prm, d_list, d_n + 1)
-    if (lds == 4096) VS_SELECT(4); else if (lds == 6144) VS_SELECT(6); else if (lds == 8192) VS_SELECT(8); else if (lds == 12288) VS_SELECT(12);
-    else if (lds == 16384) VS_SELECT(16); else VS_SELECT(24);
-#undef VS_SELECT
-    // walk: LDS for 64 lines of 1.3 x the mean length + the alignment slack of each (candidates are the deeper lines), 2 .. 60 KiB
-    uint64_t want = (uint64_t)64 * (mean * 13 / 10 + 40);
-    want = (want + 1023) / 1024 * 1024;
-    const uint32_t walk_bytes = (uint32_t)(want < 2048 ? 2048 : (want > 60 * 1024 ? 60 * 1024 : want));
+// Device scratch the site calling of one file needs besides its records: the candidate list (16 bytes per entry, one entry per 64
+// bytes of text: twelve times what a 30x pileup puts on it; a list that is full anyway costs speed, not answers), the indices of
+// the long candidates, one line count per scan wave.
+static inline uint32_t varscan_cand_cap(uint64_t nbytes) {
+    const uint64_t c = nbytes / 64 + 4096;
+    return (uint32_t)(c < 0x7FFFFFFFull ? c : 0x7FFFFFFFull);
+}
+static const uint32_t VARSCAN_MAX_WAVES = 256 * 16;
+size_t snpgpu_varscan_scratch_bytes(uint64_t nbytes) {
+    return (size_t)varscan_cand_cap(nbytes) * 20u + 4u * VARSCAN_MAX_WAVES + 1024;
+}
+
+// d_ctl: 8 zeroed words — [0] records found, [1] candidate lines, [2] long candidates, [4..5] lines of the file (written by the
+// last kernel); d_status: one u64 preset to UINT64_MAX (becomes the offset of the first malformed line); d_scratch:
+// snpgpu_varscan_scratch_bytes(nbytes) bytes, 16-byte aligned.
+int snpgpu_varscan_halo_class(const uint8_t *head, uint64_t n) {
+    // from the first bytes of the file (on the host): 0 for lines of up to ~110 bytes on average, 1 up to ~480, else 2
+    uint64_t lines = 0;
+    for (uint64_t i = 0; i < n; ++i) lines += head[i] == '\n' || head[i] == '\r';
+    const uint64_t mean = n / (lines ? lines : 1);
+    return mean <= 110 ? 0 : mean <= 480 ? 1 : 2;
+}
+
+int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, const snpgpu_varscan_params *prm, snpgpu_varscan_site *d_sites,
+                           uint32_t capacity, uint32_t *d_ctl, uint64_t *d_status, void *d_scratch, int halo_class) {
+    if (nbytes == 0) return SNPGPU_OK;
+    const uint32_t cand_cap = varscan_cand_cap(nbytes);
+    uint4 *d_cand = (uint4 *)d_scratch;
+    uint32_t *d_long = (uint32_t *)((char *)d_scratch + (size_t)cand_cap * 16u);
+    uint32_t *d_wave_lines = d_long + cand_cap;
+    const uint64_t shift = (uintptr_t)d_buf & 15u;
+    const uint8_t *abase = d_buf - shift;
+    const uint64_t lo = shift, hi = shift + nbytes;
+    const uint64_t n_tiles = (hi + VS_TILE - 1) / VS_TILE;
+    // the halo decides how long a line may be and still be looked at in LDS: a quarter KiB does for 30x pileups (lines of ~90
+    // bytes), 1 KiB up to ~150x, 4 KiB beyond; longer lines are left to the walk
+    // (halo_class — 0: 240 bytes, 1: 1008, 2: 4080 — comes from snpgpu_varscan_halo_class over the file's first bytes)
+    const uint32_t halo_chunks = halo_class == 0 ? 15u : halo_class == 1 ? 63u : 255u;
+    const uint32_t slot_bytes = (1u + VS_TILE / 16u + halo_chunks) * 16u;
+    const uint32_t lds = 2u * slot_bytes + VS_CAND_LOCAL * 16u + (VS_LIST_CAP + 2u) * 2u + 12u;
+    uint32_t waves_per_cu = 160u * 1024u / lds;
+    if (waves_per_cu > 16u) waves_per_cu = 16u;                                        // (its registers allow 4 per SIMD)
+    uint64_t grid = (uint64_t)ctx->n_cu * waves_per_cu;
+    if (grid > VARSCAN_MAX_WAVES) grid = VARSCAN_MAX_WAVES;
+    if (grid > n_tiles) grid = n_tiles;
+#define VS_SCAN(H) k_varscan_scan<H><<<(unsigned)grid, 64, lds, ctx->stream>>>(abase, lo, hi, n_tiles, *prm, d_cand, cand_cap, d_ctl, (unsigned long long *)d_status, \
+                                                                            d_sites, capacity, d_wave_lines)
+    if (halo_class == 0) VS_SCAN(15); else if (halo_class == 1) VS_SCAN(63); else VS_SCAN(255);
+#undef VS_SCAN
+    // walk: LDS for 64 candidate lines — the deeper lines of the file — 2 .. 60 KiB
+    const uint32_t walk_bytes = halo_class == 0 ? 16u * 1024u : halo_class == 1 ? 32u * 1024u : 60u * 1024u;
     const uint32_t walk_lds = walk_bytes + 16;                   // (+ one chunk: the walk may read the word after a line)
-    const uint32_t walk_waves_per_cu = 160 * 1024 / walk_lds < 16 ? 160 * 1024 / walk_lds : 16;       // (its registers allow 4 per SIMD)
+    const uint32_t walk_waves_per_cu = 160 * 1024 / walk_lds < 16 ? 160 * 1024 / walk_lds : 16;
     const unsigned walk_grid = (unsigned)((uint64_t)ctx->n_cu * (walk_waves_per_cu ? walk_waves_per_cu : 1));
-    uint32_t *d_long = d_cand + 2 * n_lines;
-    k_varscan_walk<<<walk_grid, 64, walk_lds, ctx->stream>>>(d_buf, nbytes, d_line_off, n_lines, *prm, d_sites, capacity, d_n, (unsigned long long *)d_status,
-                                                              walk_bytes, d_list, d_n + 1, d_long, d_n + 2);
-    k_varscan_walk_long<<<ctx->n_cu, 64, 0, ctx->stream>>>(d_buf, nbytes, d_line_off, n_lines, *prm, d_sites, capacity, d_n, (unsigned long long *)d_status, d_long,
-                                                           d_n + 2);
+    k_varscan_walk<<<walk_grid, 64, walk_lds, ctx->stream>>>(d_buf, nbytes, *prm, d_sites, capacity, d_ctl, (unsigned long long *)d_status, walk_bytes, d_cand,
+                                                              d_ctl + 1, cand_cap, d_long, d_ctl + 2);
+    k_varscan_walk_long<<<ctx->n_cu, 64, 0, ctx->stream>>>(d_buf, nbytes, *prm, d_sites, capacity, d_ctl, (unsigned long long *)d_status, d_cand, d_long,
+                                                           d_wave_lines, (uint32_t)grid);
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;
 }

@@ -16,6 +16,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "fuzz: a bounded, seeded slice of one of the differential campaigns of tools/fuzz_*.py")
 
 
 @pytest.fixture(scope="session", autouse=True)

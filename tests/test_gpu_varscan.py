@@ -337,3 +337,76 @@ def test_empty_read_base_and_quality_columns_are_columns(d, tmp_path):
             vo.mpileup2snp(bad, vo.Params(**kw))
         with pytest.raises(PileupFormatError):
             varscan.mpileup2snp(d, path, str(tmp_path / "p.vcf"), varscan.Options(opts))
+
+
+def test_full_candidate_list_unaligned_text_and_lines_across_tiles(d, tmp_path):
+    """Round 4's index-free pass (k_varscan_scan): (1) more candidate lines than the list holds — depth-0 lines, which the
+    shortcut cannot vouch for, by the ten thousand — are looked at on the spot and the answer is the same; (2) text at every
+    alignment mod 16 in device memory (snpgpu_varscan_dev); (3) line terminators, TABs and whole lines placed on the edges of the
+    4 KiB tiles and of the halo behind them, with LF / CR LF / lone CR ends."""
+    import torch
+    from snp_pipeline_amd import varscan
+    opts = varscan.Options("--min-var-freq 0.2 --min-reads2 2")
+    prm = opts.device_params()
+    kw = dict(min_var_freq=0.2, min_reads2=2)
+    # (1)
+    rng = np.random.default_rng(5)
+    real = fuzz.varscan_pileup(41, 3000).split(b"\n")
+    lines = []
+    for i in range(70000):
+        lines.append(b"c0\t%d\tA\t0\t*\t*" % (i + 1))
+        if i % 23 == 0:
+            lines.append(real[(i // 23) % len(real)])
+    data = b"\n".join(ln for ln in lines if ln) + b"\n"
+    path = str(tmp_path / "many.pileup")
+    with open(path, "wb") as f:
+        f.write(data)
+    out = str(tmp_path / "many.vcf")
+    n_lines, _ = varscan.mpileup2snp(d, path, out, opts)
+    assert open(out).read() == vo.mpileup2snp(data, vo.Params(**kw)) and n_lines == data.count(b"\n")
+    # (2)
+    data = fuzz.varscan_pileup(42, 4000)
+    want, want_lines = None, None
+    buf = torch.zeros(len(data) + 64, dtype=torch.uint8, device="cuda")
+    for shift in range(16):
+        buf.zero_()
+        buf[shift:shift + len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        recs, nl = d.varscan_dev(buf.data_ptr() + shift, len(data), prm)
+        if want is None:
+            want, want_lines = recs.tobytes(), nl
+            assert nl == len([ln for ln in data.split(b"\n") if ln]) and len(recs) > 50
+        assert recs.tobytes() == want and nl == want_lines, shift
+    # (3) a variant line pushed byte by byte across a tile edge, three line ends, with padding lines of chosen length in front
+    variant = b"c1\t7\tA\t12\tGGGGGGgggggg\tIIIIIIIIIIII"
+    plainl = b"c1\t6\tA\t12\t......,,,,,,\tIIIIIIIIIIII"
+    for eol in (b"\n", b"\r\n", b"\r"):
+        for edge in (4096, 8192, 4096 + 240, 4096 + 1008):
+            for delta in range(-len(variant) - 3, 4):
+                pad_total = edge + delta
+                head = []
+                used = 0
+                while pad_total - used > 2 * (len(plainl) + len(eol)):
+                    head.append(plainl)
+                    used += len(plainl) + len(eol)
+                rest = pad_total - used - len(eol)
+                if rest >= 22:                                   # a last padding line of exactly the missing length
+                    head.append(b"c1\t5\tA\t%d\t%s\t%s" % ((rest - 10) // 2, b"." * ((rest - 10) // 2), b"I" * ((rest - 10) - (rest - 10) // 2)))
+                text = eol.join(head + [variant, plainl, variant]) + eol
+                p2 = str(tmp_path / "edge.pileup")
+                with open(p2, "wb") as f:
+                    f.write(text)
+                o2 = str(tmp_path / "edge.vcf")
+                try:
+                    varscan.mpileup2snp(d, p2, o2, opts)
+                    got = open(o2).read()
+                except Exception as e:                           # noqa: B902 — compared by class below
+                    got = type(e).__name__
+                try:
+                    want2 = vo.mpileup2snp(text, vo.Params(**kw))
+                except Exception as e:                           # noqa: B902
+                    want2 = type(e).__name__
+                if want2 in ("ValueError", "IndexError"):
+                    assert got == "PileupFormatError", (eol, edge, delta)
+                else:
+                    assert got == want2, (eol, edge, delta)
