@@ -138,7 +138,8 @@ int  snpgpu_timer_start(snpgpu_ctx *ctx);
 int  snpgpu_timer_stop_ms(snpgpu_ctx *ctx, float *out_ms);   /* synchronises on the stop event */
 
 /* Per-kernel timing for bench.py: when enabled, HIP events are recorded on the stream around every launch of
- * the scan (0), per-site caller (1) and distance (2) kernels; snpgpu_ctx_kernel_time_ms synchronises, returns the
+ * the scan (0), per-site caller (1) and distance (2) kernels and around everything phase-1 site calling launches for a
+ * file (3); snpgpu_ctx_kernel_time_ms synchronises, returns the
  * summed elapsed time and the number of launches of that kernel since the last query, and clears them. */
 int  snpgpu_ctx_kernel_timing(snpgpu_ctx *ctx, int enable);
 int  snpgpu_ctx_kernel_time_ms(snpgpu_ctx *ctx, int kernel, float *total_ms, uint32_t *launches);

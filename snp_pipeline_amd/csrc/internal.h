@@ -38,6 +38,7 @@ struct snpgpu_ctx {
 #define SNPGPU_K_SCAN 0
 #define SNPGPU_K_CALL 1
 #define SNPGPU_K_DISTANCE 2
+#define SNPGPU_K_VARSCAN 3          // everything phase-1 site calling launches for one file (scan, walk, long walk)
 // RAII-less helpers: call begin before the launch and end right after it (no-ops unless timing is enabled)
 // Start of a public call that produces per-site records: the spill is there and empty (enqueued on the context's stream).
 int snpgpu_spill_begin(snpgpu_ctx *ctx);

@@ -321,109 +321,34 @@ __device__ __forceinline__ bool varscan_parse_lds(const uint32_t *lds32, uint32_
 // ---- two passes over what matters: scan + select every line, then walk the few that can call something ------------------------
 // Nearly every line of a real pileup cannot reach min-reads2 for any allele, and the byte-wise walk over its read bases — 90 % of
 // this step's instructions in round 2 — computes nothing that is used.  So the step runs as two kernels, and since round 4 the
-// first of them needs NO line index: k_varscan_scan reads the text once, in tiles, finds the line starts of a tile itself (as the
-// consensus scan does) and looks at every line the cheap way: the first four TABs and the depth, then — the quality column of a
-// well-formed line being exactly `depth` bytes long — the fifth TAB where it must be, and ONE pass of word-wide tests over the two
-// long columns: no further TAB (so the line has exactly six columns, as the walk would find), and HOW MANY bytes of the read-base
-// column have bit 6 set and bit 3 clear.  Every read-base letter (ACGTacgt: 0x41 43 47 54 and 0x20 more) is such a byte; N, n and
-// '^' are not (bit 3), '$', digits, '.', ',' are not (bit 6); a mapping-quality character after '^' or a letter inside an indel
-// may be, which only makes the count an upper bound: a line with fewer such bytes than min-reads2 cannot call anything and is
-// done (it passed the format checks); a line with at least that many goes on the candidate list; a line whose shape the shortcut cannot vouch for
-// (fewer TABs, a quality column of another length, more columns) goes on the list as it is and the walk parses it in full.
-// k_varscan_walk then gives every lane one candidate: the lane copies its line into its own strip of LDS and runs the exact
-// automaton over it.  Round 3 put every line with ANY letter on the list — 14 % of the lines at 30x, 39 % at 100x, which made
-// the walk grow 6.4 x for 2.6 x the bytes; with the count it is the variant sites and little else, at any depth.
-
-// nonzero iff some byte of w is zero (exact as a yes/no test)
-__device__ __forceinline__ uint32_t any_zero_byte(uint32_t w) { return (w - 0x01010101u) & ~w & 0x80808080u; }
-__device__ __forceinline__ uint32_t any_byte_eq(uint32_t w, uint32_t c4) { return any_zero_byte(w ^ c4); }
+// first of them needs NO line index and has no loop over the bytes of a line: k_varscan_scan reads the text once, in tiles, and
+// per tile
+//   A1  classifies every byte, 16 at a time, into three bit strings over the tile: line terminators, TABs, and "letters" — bytes
+//       with bit 6 set and bit 3 clear.  Every read-base letter (ACGTacgt: 0x41 43 47 54 and 0x20 more) is such a byte; N, n and
+//       '^' are not (bit 3), '$', digits, '.', ',' are not (bit 6); a mapping-quality character after '^' or a letter inside an
+//       indel may be, which only makes a count of them an upper bound of any allele's reads;
+//   A2  turns the terminator string into the list of line starts (a wave prefix sum) and the other two into running counts per
+//       32 bytes;
+//   B   gives every line one lane, which answers in constant time, from the bit strings alone: where are the first four TABs
+//       (find-first-set on 64 bits of the TAB string), the depth (one unaligned load, SWAR digits), is the fifth TAB where a
+//       quality column of exactly `depth` bytes puts it, are there five TABs in all (difference of two running counts), how many
+//       letters has the read-base column (another difference).
+// A line whose shape checks out ("plain") with fewer letters than min-reads2 cannot call anything and is done; with at least that
+// many it goes on the candidate list; a line the shortcut cannot vouch for goes on the list as it is and the walk parses it in
+// full (format errors included).  k_varscan_walk then gives every lane one candidate: the lane copies its line into its own strip
+// of LDS and runs the exact automaton over it.  Round 3 looked at every byte of every line in a lane-per-line loop (a third of the
+// lanes idle at 100x) and put every line with ANY letter on the list — 14 % of the lines at 30x, 39 % at 100x, which made the
+// walk grow 6.4 x for 2.6 x the bytes; now it is the variant sites and little else, at any depth.
 
 // A list entry (16 bytes): x, y = file offset of the line's first byte; z = its length in bytes (terminator included; 0 for a
 // line that did not end inside the tile's LDS window: VS_W_LONG, the walk finds its end itself); w = what the walk need not find
-// out again for a line whose shape the select has checked (VS_W_PLAIN): depth (bits 0-19), and where, counted from the line's
-// first byte, its second and fourth TAB are (bits 20-24, 25-29)
+// out again for a line whose shape the scan has checked (VS_W_PLAIN): depth (bits 0-13), and where, counted from the line's
+// first byte, its second and fourth TAB are (bits 14-19, 20-25)
 constexpr uint32_t VS_W_PLAIN = 1u << 31, VS_W_LONG = 1u << 30;
 
-// One line for k_varscan_scan: [p0, end) in the LDS copy.  Returns whether the line goes on the list, and its entry's last word.
-__device__ __forceinline__ bool select_line(const uint32_t *lds32, const uint32_t p0, uint32_t end, const snpgpu_varscan_params &prm, uint32_t &extras) {
-    bool is_cand = false;
-    auto byte_at = [&](uint32_t p) -> uint32_t { return (lds32[p >> 2] >> ((p & 3u) * 8u)) & 0xFFu; };
-    while (end > p0) { const uint32_t c = byte_at(end - 1); if (c != 10u && c != 13u) break; --end; }
-    bool plain = false;                                                     // the shortcut vouches for the line's shape
-    if (end > p0) {
-        // the first four TABs out of a bit mask over the 32 bytes from the line's first word on (chrom, position, reference
-        // and depth columns of a usual line end well inside; a longer prefix leaves the line to the walk)
-        const uint32_t w0 = p0 >> 2, sh0 = p0 & 3u;
-        uint32_t M = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 8; ++q)
-            M |= (__builtin_amdgcn_udot4(eq4(lds32[w0 + q], 0x09090909u), 0x08040201u, 0u, false) >> 7) << (4u * q);
-        M &= 0xFFFFFFFFu << sh0;
-        if (end - w0 * 4u < 32u) M &= (1u << (end - w0 * 4u)) - 1u;
-        if (__popc(M) >= 4) {
-            const uint32_t t0 = w0 * 4u + (uint32_t)__ffs((int)M) - 1u; M &= M - 1u;
-            const uint32_t t1 = w0 * 4u + (uint32_t)__ffs((int)M) - 1u; M &= M - 1u;
-            const uint32_t t2 = w0 * 4u + (uint32_t)__ffs((int)M) - 1u; M &= M - 1u;
-            const uint32_t t3 = w0 * 4u + (uint32_t)__ffs((int)M) - 1u;
-            bool ok = t0 > p0 && t1 > t0 + 1 && t2 == t1 + 2 && t3 > t2 + 1 && t3 - t2 - 1 <= 9;
-            uint32_t depth = 0;
-            if (ok)
-                for (uint32_t p = t2 + 1; p < t3; ++p) {
-                    const uint32_t c = byte_at(p);
-                    if (!is_digit(c)) ok = false;
-                    depth = depth * 10u + (c - 0x30u);
-                }
-            const uint32_t b0 = t3 + 1;
-            // six columns with a quality column of `depth` bytes: the fifth TAB sits depth + 1 bytes before the end
-            if (ok && depth >= 1 && (uint64_t)b0 + 1 + depth < end) {
-                const uint32_t t4 = end - depth - 1;
-                if (byte_at(t4) == 9u) {
-                    // a further TAB in [b0, t4) or (t4, end)?  how many bytes with bit 6 in [b0, t4)?  Whole words in the
-                    // loops, the first and last word of each column with the bytes outside it replaced by '.'
-                    uint32_t tabs = 0, letters = 0;
-                    auto keep = [](uint32_t v, uint32_t lo, uint32_t hi) -> uint32_t {       // bytes [lo, hi) of the word, hi <= 4
-                        const uint32_t m = (0xFFFFFFFFu << (lo * 8u)) & (hi >= 4u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (hi * 8u)));
-                        return (v & m) | (0x2E2E2E2Eu & ~m);
-                    };
-                    auto bases_word = [&](uint32_t v) {
-                        tabs |= any_byte_eq(v, 0x09090909u);
-                        letters += (uint32_t)__popc(v & ~(v << 3) & 0x40404040u);
-                    };
-                    {
-                        const uint32_t wf = b0 >> 2, wl = (t4 - 1u) >> 2;
-                        if (wf == wl) bases_word(keep(lds32[wf], b0 & 3u, ((t4 - 1u) & 3u) + 1u));
-                        else {
-                            bases_word(keep(lds32[wf], b0 & 3u, 4u));
-                            for (uint32_t w = wf + 1u; w < wl; ++w) bases_word(lds32[w]);
-                            bases_word(keep(lds32[wl], 0u, ((t4 - 1u) & 3u) + 1u));
-                        }
-                    }
-                    {
-                        const uint32_t q0 = t4 + 1u, wf = q0 >> 2, wl = (end - 1u) >> 2;
-                        if (wf == wl) tabs |= any_byte_eq(keep(lds32[wf], q0 & 3u, ((end - 1u) & 3u) + 1u), 0x09090909u);
-                        else {
-                            tabs |= any_byte_eq(keep(lds32[wf], q0 & 3u, 4u), 0x09090909u);
-                            for (uint32_t w = wf + 1u; w < wl; ++w) tabs |= any_byte_eq(lds32[w], 0x09090909u);
-                            tabs |= any_byte_eq(keep(lds32[wl], 0u, ((end - 1u) & 3u) + 1u), 0x09090909u);
-                        }
-                    }
-                    if (!tabs) {
-                        plain = true;
-                        // (min_reads2 0: an allele without reads is skipped by the walk, so one letter is still needed)
-                        is_cand = depth >= prm.min_coverage && letters >= (prm.min_reads2 > 1u ? prm.min_reads2 : 1u);
-                        if (depth < (1u << 20)) extras = VS_W_PLAIN | depth | ((t1 - p0) << 20) | ((t3 - p0) << 25);
-                    }
-                }
-            }
-        }
-    }
-    if (!plain && end > p0) is_cand = true;                                 // the walk looks at it in full (format errors included)
-    return is_cand;
-}
-
 // A candidate straight from global memory, byte by byte (the generic form of the walk; also what a full list falls back on).
-__device__ void walk_entry_global(const uint8_t *buf, uint64_t nbytes, uint4 e, const snpgpu_varscan_params &prm, snpgpu_varscan_site *out,
-                                  uint32_t capacity, uint32_t *out_n, unsigned long long *status) {
+__device__ __noinline__ void walk_entry_global(const uint8_t *buf, uint64_t nbytes, uint4 e, const snpgpu_varscan_params &prm, snpgpu_varscan_site *out,
+                                               uint32_t capacity, uint32_t *out_n, unsigned long long *status) {
     const uint64_t p0 = (uint64_t)e.x | ((uint64_t)e.y << 32);
     uint64_t end = p0 + e.z;
     if (e.w & VS_W_LONG) {                                                              // ends at the first line terminator
@@ -433,47 +358,76 @@ __device__ void walk_entry_global(const uint8_t *buf, uint64_t nbytes, uint4 e, 
     varscan_line<uint64_t>(GlobalBytes{buf}, p0, end < nbytes ? end : nbytes, 0, prm, out, capacity, out_n, status);
 }
 
-#define VS_TILE 4096u
 #define VS_LIST_CAP 256u          // line starts held in LDS per pass (a tile with more makes extra passes)
-#define VS_CAND_LOCAL 128u        // candidate entries a wave collects in LDS before it takes a place on the list
+#define VS_CAND_LOCAL 96u         // candidate entries a wave collects in LDS before it takes a place on the list
 
-// 0x80 in every byte of w that is '\n' / '\r' -> 16 bits per 16-byte chunk
+// 0x80 in every byte of w in 0x0A..0x0D (what a line terminator can be, and VT / FF: sorted out by whoever uses the flag)
+__device__ __forceinline__ uint32_t term4(uint32_t w) { return (w + 0x76767676u) & ~(w + 0x72727272u) & 0x80808080u; }
+// the four flag words of a 16-byte chunk (0x80 per flagged byte) -> 16 bits, byte k of the chunk = bit k
 __device__ __forceinline__ uint32_t bits16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
-    return (__builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false) >> 7) | ((__builtin_amdgcn_udot4(f1, 0x08040201u, 0u, false) >> 7) << 4) |
-           ((__builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false) >> 7) << 8) | ((__builtin_amdgcn_udot4(f3, 0x08040201u, 0u, false) >> 7) << 12);
-}
-// bit k: a line starts at byte k of the chunk — the byte before it is '\n', or a '\r' that it does not follow with '\n'
-// (Java's readLine(): LF, CR, CR LF).  prev: the dword that ends right before the chunk.
-__device__ __forceinline__ uint32_t chunk_starts(uint4 v, uint32_t prev) {
-    const uint32_t N = bits16(eq4(v.x, 0x0A0A0A0Au), eq4(v.y, 0x0A0A0A0Au), eq4(v.z, 0x0A0A0A0Au), eq4(v.w, 0x0A0A0A0Au));
-    const uint32_t C = bits16(eq4(v.x, 0x0D0D0D0Du), eq4(v.y, 0x0D0D0D0Du), eq4(v.z, 0x0D0D0D0Du), eq4(v.w, 0x0D0D0D0Du));
-    const uint32_t pb = prev >> 24, pn = pb == 10u ? 1u : 0u, pc = pb == 13u ? 1u : 0u;
-    return (((N << 1) | pn) | (((C << 1) | pc) & ~N)) & 0xFFFFu;
+    uint32_t r = __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false);
+    r |= __builtin_amdgcn_udot4(f1, 0x08040201u, 0u, false) << 4;
+    r |= __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false) << 8;
+    r |= __builtin_amdgcn_udot4(f3, 0x08040201u, 0u, false) << 12;
+    return r >> 7;
 }
 
-// One wave per workgroup, every wave one contiguous run of 4 KiB tiles of the file.  A tile's slot in LDS holds the bytes
-// [t0 - 16, t0 + 4096 + halo): tile k+1 streams into the other slot with LDS-DMA (global_load_lds_dwordx4, no register round
-// trip) while tile k is looked at, the wave waits for its own requests with a counted s_waitcnt, nothing else waits for anything.
-// Per tile: lane l looks at chunks l, 64 + l, 128 + l, 192 + l (conflict-free ds_read_b128) for line terminators; a wave prefix
-// sum puts the starts into an LDS list in file order; then one lane per line (select_line).  A line that starts in the tile lies
-// completely in the slot when it is shorter than the halo; one that does not is left to the walk (VS_W_LONG).  The halo is
-// fetched again with the next tile (mostly from L2): 6 % / 25 % more requests for kHaloChunks 15 / 63.
-// Coordinates are "aligned": byte a of abase = file byte a - lo, with abase 16-byte aligned and the file at [lo, hi).
-template <int kHaloChunks>
-__global__ __launch_bounds__(64) void k_varscan_scan(const uint8_t *__restrict__ abase, uint64_t lo, uint64_t hi, uint64_t n_tiles, snpgpu_varscan_params prm,
-                                                     uint4 *cand, uint32_t cand_cap, uint32_t *ctl, unsigned long long *status, snpgpu_varscan_site *out,
-                                                     uint32_t capacity, uint32_t *wave_lines) {
-    constexpr uint32_t kChunks = 1u + VS_TILE / 16u + (uint32_t)kHaloChunks;            // 16-byte chunks of a slot
+// A1 for one chunk: the 16 bytes of v -> 16 bits of each string (lt: bit 6 set and bit 3 clear, flagged at bit 6 -> shift 6)
+__device__ __forceinline__ uint32_t bits16s(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3, uint32_t shift) {
+    uint32_t r = __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false);
+    r |= __builtin_amdgcn_udot4(f1, 0x08040201u, 0u, false) << 4;
+    r |= __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false) << 8;
+    r |= __builtin_amdgcn_udot4(f3, 0x08040201u, 0u, false) << 12;
+    return r >> shift;
+}
+template <bool kExact>
+__device__ __forceinline__ void classify_chunk(const uint4 v, uint32_t c, uint16_t *nl, uint16_t *cr, uint16_t *tab, uint16_t *let) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t ft[4], fl[4], fn[4], fc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ft[k] = eq4(w[k], 0x09090909u);
+        fl[k] = w[k] & ~(w[k] << 3) & 0x40404040u;
+        if (!kExact) { fn[k] = term4(w[k]); fc[k] = 0; }
+        else { fn[k] = eq4(w[k], 0x0A0A0A0Au); fc[k] = eq4(w[k], 0x0D0D0D0Du); }
+    }
+    nl[c] = (uint16_t)bits16s(fn[0], fn[1], fn[2], fn[3], 7);
+    tab[c] = (uint16_t)bits16s(ft[0], ft[1], ft[2], ft[3], 7);
+    let[c] = (uint16_t)bits16s(fl[0], fl[1], fl[2], fl[3], 6);
+    if (kExact) cr[c] = (uint16_t)bits16s(fc[0], fc[1], fc[2], fc[3], 7);
+}
+
+// One wave per workgroup, every wave one contiguous run of tiles of the file.  A tile's slot in LDS holds the bytes
+// [t0 - 16, t0 + tile + halo) = 64 * kCPL chunks of 16 bytes: tile k+1 streams into the other slot with LDS-DMA
+// (global_load_lds_dwordx4, kCPL wave instructions, no register round trip) while tile k is looked at; the wave waits for its own
+// requests with a counted s_waitcnt, nothing else waits for anything.  A line that starts in the tile lies completely in the slot
+// when it is shorter than the halo; one that does not is left to the walk (VS_W_LONG).  The halo is fetched again with the next
+// tile (mostly from L2).  Geometries (chunks per lane, tile, halo): 4, 3840, 240 for lines of ~100 bytes (30x); 6, 5120, 1008 up
+// to ~480 bytes; 8, 4096, 4080 beyond.  Coordinates are "aligned": byte a of abase = file byte a - lo, abase 16-byte aligned, the
+// file at [lo, hi).
+// Line terminators are Java's readLine(): LF, CR, CR LF.  The fast form of A1 flags bytes 0x0A..0x0D with two adds and takes every
+// one for LF; phase B looks at the byte that ends each line, and the first that is not LF switches the wave to the exact form
+// (separate LF and CR strings, starts after LF, or after a CR that no LF follows) for this and all its later tiles.
+template <int kCPL>
+__global__ __launch_bounds__(64) void k_varscan_scan(const uint8_t *__restrict__ abase, uint64_t lo, uint64_t hi, uint32_t tile_bytes, uint64_t n_tiles,
+                                                     snpgpu_varscan_params prm, uint4 *cand, uint32_t cand_cap, uint32_t *ctl, unsigned long long *status,
+                                                     snpgpu_varscan_site *out, uint32_t capacity, uint32_t *wave_lines) {
+    constexpr uint32_t kChunks = 64u * kCPL;                                            // 16-byte chunks of a slot
     constexpr uint32_t kSlotBytes = kChunks * 16u;
-    constexpr uint32_t kDma = (kChunks + 63u) / 64u;                                    // wave instructions per tile request
+    constexpr uint32_t kW = kSlotBytes / 32u;                                           // words of a bit string over the slot
+    constexpr uint32_t kMW = kW / 64u;                                                  // ... per lane in A2
     extern __shared__ uint4 vs_lds[];
     uint4 *slot0 = vs_lds, *slot1 = vs_lds + kChunks;
-    uint4 *cand_local = vs_lds + 2 * kChunks;
+    uint32_t *nlbits = (uint32_t *)(vs_lds + 2 * kChunks);                              // terminators (exact form: LF)
+    uint32_t *crbits = nlbits + kW + 4, *tabbits = crbits + kW + 4, *letbits = tabbits + kW + 4, *pre = letbits + kW + 4;   // (+4: the window reads run two words over)
+    uint4 *cand_local = (uint4 *)(pre + kW + 4);
     uint16_t *lstart = (uint16_t *)(cand_local + VS_CAND_LOCAL);                        // VS_LIST_CAP + 2 entries
     const uint32_t lane = threadIdx.x;
     const uint8_t *fbuf = abase + lo;                                                   // file byte 0
     const uint64_t nbytes = hi - lo;
     uint32_t n_local = 0, lines_seen = 0;
+    bool exact = false;                                                                 // wave-uniform: the exact form of A1 / A2
+    if (lane < 8) { nlbits[kW + (lane & 3)] = 0; crbits[kW + (lane & 3)] = 0; tabbits[kW + (lane & 3)] = 0; letbits[kW + (lane & 3)] = 0; pre[kW + (lane & 3)] = 0; }
     auto flush = [&]() {
         if (n_local == 0) return;
         uint32_t base = 0;
@@ -490,27 +444,26 @@ __global__ __launch_bounds__(64) void k_varscan_scan(const uint8_t *__restrict__
     // my run of tiles
     const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
     const uint64_t t_first = (uint64_t)blockIdx.x * per, t_end = t_first + per < n_tiles ? t_first + per : n_tiles;
-    auto interior = [&](uint64_t tt) { const uint64_t x0 = tt * VS_TILE; return x0 >= lo + 16 && x0 + VS_TILE + 16u * kHaloChunks <= hi; };
+    auto interior = [&](uint64_t tt) { const uint64_t x0 = tt * tile_bytes; return x0 >= lo + 16 && x0 - 16 + kSlotBytes <= hi; };
     // request tile tt into `slot`; returns whether it travels by DMA (else it has been staged synchronously)
     auto request = [&](uint64_t tt, uint4 *slot) -> bool {
         if (interior(tt)) {
-            const uint8_t *gs = abase + tt * VS_TILE - 16;
+            const uint8_t *gs = abase + tt * tile_bytes - 16;
             const uint32_t voff = lane * 16u;
             const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)slot);
 #pragma unroll
-            for (uint32_t r = 0; r < kDma; ++r) {
+            for (uint32_t r = 0; r < (uint32_t)kCPL; ++r) {
                 const uint64_t ga = (uint64_t)(uintptr_t)gs + (r >> 2) * 4096u;
                 const uint64_t gr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ga >> 32)) << 32) |
                                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ga);
                 const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (r >> 2) * 4096u);
-                if (r * 64u + lane < kChunks)
-                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(gr), "s"(m0v), "n"((r & 3u) * 1024u) : "memory");
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(gr), "s"(m0v), "n"((r & 3u) * 1024u) : "memory");
             }
             return true;
         }
         // first / last tiles of the file: byte loads; the byte before the file reads as '\n' (byte 0 starts a line), the other
         // bytes outside it as NUL (no line starts past the end)
-        const int64_t x0 = (int64_t)(tt * VS_TILE) - 16;
+        const int64_t x0 = (int64_t)(tt * tile_bytes) - 16;
 #pragma nounroll
         for (uint32_t e = lane; e < kChunks; e += 64) {
             uint32_t d[4] = {0, 0, 0, 0};
@@ -526,102 +479,220 @@ __global__ __launch_bounds__(64) void k_varscan_scan(const uint8_t *__restrict__
         }
         return false;
     };
-    bool dma_cur = false, dma_next = false;
-    if (t_first < t_end) dma_cur = request(t_first, slot0);
+    // the bits of a 32-bit word of a string (over the slot bytes from `b` on) that lie below slot offset x
+    auto below = [](uint32_t x, uint32_t b) -> uint32_t { return x <= b ? 0u : (x - b >= 32u ? 0xFFFFFFFFu : (1u << (x - b)) - 1u); };
+    // ... for this lane's words in A2: starts in [16, 16 + tile) are the tile's lines, in [16 + tile, slot end) end its last one
+    uint32_t own_mask[kMW], halo_mask[kMW];
+#pragma unroll
+    for (uint32_t k = 0; k < kMW; ++k) {
+        const uint32_t b = (lane * kMW + k) * 32u;
+        own_mask[k] = below(16u + tile_bytes, b) & ~below(16u, b);
+        halo_mask[k] = below(kSlotBytes, b) & ~below(16u + tile_bytes, b);
+    }
+    bool dma_next = false;
+    if (t_first < t_end) (void)request(t_first, slot0);
     if (t_first + 1 < t_end) dma_next = request(t_first + 1, slot1);
     uint4 *cur = slot0, *other = slot1;
     for (uint64_t tt = t_first; tt < t_end; ++tt) {
         // the current tile's request has landed when only the next tile's is outstanding
-        if (dma_next && tt + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kDma) : "memory");
+        if (dma_next && tt + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kCPL) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        (void)dma_cur;
         const uint32_t *lds32 = (const uint32_t *)cur;
-        const uint64_t t0 = tt * VS_TILE;                                               // aligned coordinate of slot byte 16
+        const uint64_t t0 = tt * tile_bytes;                                            // aligned coordinate of slot byte 16
         // slot offset of the file's end (what a line without a terminator runs to), when that is inside the slot
         const uint64_t hi_rel = hi - (t0 - 16);
         const uint32_t hi_slot = hi_rel < kSlotBytes ? (uint32_t)hi_rel : 0xFFFFFFFFu;
-        // ---- the line starts of the tile: chunk i * 64 + lane, i = 0..3 -------------------------------------------------
-        uint32_t m[4];
+        const uint32_t own_end = 16u + tile_bytes < hi_slot ? 16u + tile_bytes : hi_slot;   // starts in [16, own_end) are this tile's lines
+        const uint32_t halo_end = hi_slot < kSlotBytes ? hi_slot : kSlotBytes;              // ... in [own_end, halo_end) end its last one
+        bool redo;
+        do {
+            redo = false;
+            __builtin_amdgcn_wave_barrier();
+            // ---- A1: chunk i * 64 + lane (conflict-free ds_read_b128) -> 16 bits of each string ------------------------------
+            if (!exact) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t c = 1u + (uint32_t)i * 64u + lane;                           // chunk of the slot
-            m[i] = chunk_starts(cur[c], lds32[c * 4u - 1u]);
-            if (hi_slot != 0xFFFFFFFFu) {                                               // a start at or past the end of the file is no line
-                const uint32_t b = c * 16u;
-                m[i] &= hi_slot <= b ? 0u : (hi_slot - b >= 16u ? 0xFFFFu : (1u << (hi_slot - b)) - 1u);
-            }
-        }
-        const uint32_t cA = (uint32_t)__popc(m[0]) | ((uint32_t)__popc(m[1]) << 16), cB = (uint32_t)__popc(m[2]) | ((uint32_t)__popc(m[3]) << 16);
-        const uint32_t iA = wave_inclusive_sum(cA), iB = wave_inclusive_sum(cB);
-        const uint32_t tA = (uint32_t)__builtin_amdgcn_readlane((int)iA, 63), tB = (uint32_t)__builtin_amdgcn_readlane((int)iB, 63);
-        const uint32_t tot0 = tA & 0xFFFFu, tot1 = tA >> 16, tot2 = tB & 0xFFFFu, tot3 = tB >> 16;
-        const uint32_t T = tot0 + tot1 + tot2 + tot3;
-        const uint32_t first_idx[4] = {(iA - cA) & 0xFFFFu, tot0 + ((iA - cA) >> 16), tot0 + tot1 + ((iB - cB) & 0xFFFFu), tot0 + tot1 + tot2 + ((iB - cB) >> 16)};
-        lines_seen += T;
-        // ---- where the line after the tile's last one starts: the first start in the halo, else the end of the file, else unknown ----
-        uint32_t next = hi_slot;                                                        // 0xFFFFFFFF: not in the slot
-        if (T) {
-#pragma unroll 1
-            for (uint32_t r = 0; r * 64u < (uint32_t)kHaloChunks; ++r) {
-                const uint32_t c = 1u + VS_TILE / 16u + r * 64u + lane;
-                uint32_t st = 0;
-                if (c < kChunks) {
-                    st = chunk_starts(cur[c], lds32[c * 4u - 1u]);
-                    if (hi_slot != 0xFFFFFFFFu) { const uint32_t b = c * 16u; st &= hi_slot <= b ? 0u : (hi_slot - b >= 16u ? 0xFFFFu : (1u << (hi_slot - b)) - 1u); }
-                }
-                const unsigned long long any = __ballot(st != 0);
-                if (any) {
-                    const uint32_t src = (uint32_t)__ffsll((long long)any) - 1u;
-                    const uint32_t pos = c * 16u + (uint32_t)__ffs((int)st) - 1u;
-                    next = (uint32_t)__builtin_amdgcn_readlane((int)pos, src);
-                    break;
-                }
-            }
-        }
-        // ---- passes of up to VS_LIST_CAP lines: the list, then one lane per line ---------------------------------------
-#pragma unroll 1
-        for (uint32_t base = 0; base < T; base += VS_LIST_CAP) {
+                for (uint32_t i = 0; i < (uint32_t)kCPL; ++i)
+                    classify_chunk<false>(cur[i * 64u + lane], i * 64u + lane, (uint16_t *)nlbits, (uint16_t *)crbits, (uint16_t *)tabbits, (uint16_t *)letbits);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t mm = m[i], idx = first_idx[i];
-                const uint32_t b = (1u + (uint32_t)i * 64u + lane) * 16u;
-                while (mm) {
-                    const uint32_t k = (uint32_t)__ffs((int)mm) - 1u;
-                    mm &= mm - 1u;
-                    if (idx - base <= VS_LIST_CAP) lstart[idx - base] = (uint16_t)(b + k);      // (unsigned: also false for idx < base)
-                    ++idx;
-                }
+                for (uint32_t i = 0; i < (uint32_t)kCPL; ++i)
+                    classify_chunk<true>(cur[i * 64u + lane], i * 64u + lane, (uint16_t *)nlbits, (uint16_t *)crbits, (uint16_t *)tabbits, (uint16_t *)letbits);
             }
             __builtin_amdgcn_wave_barrier();
-            const uint32_t n_here = T - base < VS_LIST_CAP ? T - base : VS_LIST_CAP;
-#pragma unroll 1
-            for (uint32_t r = 0; r < n_here; r += 64) {
-                const uint32_t i = r + lane;
-                bool is_cand = false;
-                uint4 e = make_uint4(0, 0, 0, 0);
-                if (i < n_here) {
-                    const uint32_t p0 = lstart[i];
-                    const uint32_t end = base + i + 1u < T ? (uint32_t)lstart[i + 1u] : next;
-                    const uint64_t off = t0 - 16 + p0 - lo;                             // file offset of the line
-                    e.x = (uint32_t)off; e.y = (uint32_t)(off >> 32);
-                    if (end == 0xFFFFFFFFu) { is_cand = true; e.w = VS_W_LONG; }        // runs past the slot: the walk finds its end
-                    else { e.z = end - p0; is_cand = select_line(lds32, p0, end, prm, e.w); }
-                }
-                const unsigned long long mk = __ballot(is_cand);
-                if (mk) {
-                    if (is_cand) cand_local[n_local + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = e;
-                    n_local += (uint32_t)__popcll(mk);
-                    __builtin_amdgcn_wave_barrier();
-                    if (n_local + 64u > VS_CAND_LOCAL) { flush(); __builtin_amdgcn_wave_barrier(); }
+            // ---- A2: words lane * kMW .. of the strings: line starts, running counts ----------------------------------------
+            uint32_t S[kMW], tw[kMW], lw[kMW];
+            uint32_t c_nl = 0, c_tab = 0, c_let = 0, halo_first = 0xFFFFFFFFu;
+            {
+                const uint32_t w0 = lane * kMW;
+                uint32_t carry_n = w0 ? nlbits[w0 - 1] >> 31 : 0u, carry_c = (exact && w0) ? crbits[w0 - 1] >> 31 : 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < kMW; ++k) {
+                    const uint32_t n = nlbits[w0 + k];
+                    tw[k] = tabbits[w0 + k];
+                    lw[k] = letbits[w0 + k];
+                    uint32_t st = (n << 1) | carry_n;
+                    carry_n = n >> 31;
+                    if (exact) { const uint32_t cr = crbits[w0 + k]; st |= ((cr << 1) | carry_c) & ~n; carry_c = cr >> 31; }
+                    // bits of this word inside [16, own_end) / [own_end, halo_end)
+                    const uint32_t b = (w0 + k) * 32u;
+                    uint32_t m_own = own_mask[k], m_halo = halo_mask[k];
+                    if (hi_slot != 0xFFFFFFFFu) {                                       // (a tile the file ends in: its own limits)
+                        m_own = below(own_end, b) & ~below(16u, b);
+                        m_halo = below(halo_end, b) & ~below(own_end, b);
+                    }
+                    const uint32_t halo = st & m_halo;
+                    if (halo && halo_first == 0xFFFFFFFFu) halo_first = b + (uint32_t)__ffs((int)halo) - 1u;
+                    S[k] = st & m_own;
+                    c_nl += (uint32_t)__popc(S[k]);
+                    c_tab += (uint32_t)__popc(tw[k]);
+                    c_let += (uint32_t)__popc(lw[k]);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-        }
+            const uint32_t packed = c_nl | (c_tab << 13);
+            const uint32_t i1 = wave_inclusive_sum(packed), i2 = wave_inclusive_sum(c_let);
+            const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63) & 0x1FFFu;
+            uint32_t idx0 = (i1 - packed) & 0x1FFFu;
+            {
+                uint32_t ptab = (i1 - packed) >> 13, plet = i2 - c_let;
+#pragma unroll
+                for (uint32_t k = 0; k < kMW; ++k) {
+                    pre[lane * kMW + k] = (ptab & 0xFFFFu) | (plet << 16);
+                    ptab += (uint32_t)__popc(tw[k]);
+                    plet += (uint32_t)__popc(lw[k]);
+                }
+            }
+            // where the line after the tile's last one starts: the first start in the halo, else the end of the file, else unknown
+            uint32_t next = hi_slot;                                                    // 0xFFFFFFFF: not in the slot
+            {
+                const unsigned long long any = __ballot(halo_first != 0xFFFFFFFFu);
+                if (any) next = (uint32_t)__builtin_amdgcn_readlane((int)halo_first, (int)(__ffsll((long long)any) - 1));
+            }
+            // ---- passes of up to VS_LIST_CAP lines: the list, then one lane per line ---------------------------------------
+#pragma unroll 1
+            for (uint32_t base = 0; base < T; base += VS_LIST_CAP) {
+                {
+                    // The fast form took every byte in 0x0A..0x0D for LF: on the way through the starts (first pass), is the byte in
+                    // front of each one?  The first that is not — CR, VT, FF — switches the wave to the exact form, before anything
+                    // of this tile has been used.
+                    const bool check = !exact && base == 0;
+                    bool odd = check && halo_first != 0xFFFFFFFFu && halo_first == next && ((lds32[(next - 1u) >> 2] >> (((next - 1u) & 3u) * 8u)) & 0xFFu) != 10u;
+                    uint32_t idx = idx0;
+#pragma unroll
+                    for (uint32_t k = 0; k < kMW; ++k) {
+                        uint32_t mm = S[k];
+                        const uint32_t b = (lane * kMW + k) * 32u;
+                        while (mm) {
+                            const uint32_t q = b + (uint32_t)__ffs((int)mm) - 1u;
+                            mm &= mm - 1u;
+                            if (idx - base <= VS_LIST_CAP) lstart[idx - base] = (uint16_t)q;            // (unsigned: also false for idx < base)
+                            if (check) odd |= ((lds32[(q - 1u) >> 2] >> (((q - 1u) & 3u) * 8u)) & 0xFFu) != 10u;
+                            ++idx;
+                        }
+                    }
+                    if (check && __ballot(odd)) { exact = true; redo = true; break; }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t n_here = T - base < VS_LIST_CAP ? T - base : VS_LIST_CAP;
+#pragma unroll 1
+                for (uint32_t r = 0; r < n_here; r += 64) {
+                    const uint32_t i = r + lane;
+                    bool is_cand = false;
+                    uint4 e = make_uint4(0, 0, 0, 0);
+                    if (i < n_here) {
+                        const uint32_t p0 = lstart[i];
+                        const uint32_t end = base + i + 1u < T ? (uint32_t)lstart[i + 1u] : next;
+                        const uint64_t off = t0 - 16 + p0 - lo;                         // file offset of the line
+                        e.x = (uint32_t)off; e.y = (uint32_t)(off >> 32);
+                        if (end == 0xFFFFFFFFu) { is_cand = true; e.w = VS_W_LONG; }    // runs past the slot: the walk finds its end
+                        else {
+                            e.z = end - p0;
+                            auto byte_at = [&](uint32_t p) -> uint32_t { return (lds32[p >> 2] >> ((p & 3u) * 8u)) & 0xFFu; };
+                            // the line without its terminator
+                            uint32_t le = end;
+                            if (!exact) {
+                                if (byte_at(end - 1u) == 10u) le = end - 1u;           // (else: the file's last line, without a terminator)
+                            } else {
+                                while (le > p0) { const uint32_t cb = byte_at(le - 1u); if (cb != 10u && cb != 13u) break; --le; }
+                            }
+                            if (le > p0) {
+                                bool plain = false;
+                                // the first four TABs out of the 64 bits of the TAB string from the line's first byte on
+                                const uint32_t wq = p0 >> 5, sh = p0 & 31u;
+                                const uint32_t a0 = tabbits[wq], a1 = tabbits[wq + 1u];
+                                const uint32_t span = le - p0;
+                                uint32_t m32 = __builtin_amdgcn_alignbit(a1, a0, sh);
+                                if (span < 32u) m32 &= (1u << span) - 1u;
+                                uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+                                bool four = false;
+                                if (__popc(m32) >= 4) {                                 // the usual case: all four within 32 bytes
+                                    four = true;
+                                    r0 = (uint32_t)__ffs((int)m32) - 1u; m32 &= m32 - 1u;
+                                    r1 = (uint32_t)__ffs((int)m32) - 1u; m32 &= m32 - 1u;
+                                    r2 = (uint32_t)__ffs((int)m32) - 1u; m32 &= m32 - 1u;
+                                    r3 = (uint32_t)__ffs((int)m32) - 1u;
+                                } else if (span > 32u) {                                // long contig names: 64 bytes
+                                    const uint32_t a2 = tabbits[wq + 2u];
+                                    uint64_t M = (uint64_t)m32 | ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, sh) << 32);
+                                    if (span < 64u) M &= (1ull << span) - 1ull;
+                                    if (__popcll(M) >= 4) {
+                                        four = true;
+                                        r0 = (uint32_t)__ffsll((long long)M) - 1u; M &= M - 1ull;
+                                        r1 = (uint32_t)__ffsll((long long)M) - 1u; M &= M - 1ull;
+                                        r2 = (uint32_t)__ffsll((long long)M) - 1u; M &= M - 1ull;
+                                        r3 = (uint32_t)__ffsll((long long)M) - 1u;
+                                    }
+                                }
+                                if (four) {
+                                    const uint32_t nd = r3 - r2 - 1u;                   // digits of the depth
+                                    if (r0 > 0u && r1 > r0 + 1u && r2 == r1 + 2u && nd >= 1u && nd <= 4u) {
+                                        // the depth: four bytes from its first digit on, most significant first
+                                        const uint32_t da = p0 + r2 + 1u;
+                                        const uint32_t x = __builtin_amdgcn_alignbyte(lds32[(da >> 2) + 1u], lds32[da >> 2], da & 3u);
+                                        const uint32_t keep = nd >= 4u ? 0xFFFFFFFFu : (1u << (8u * nd)) - 1u;
+                                        const uint32_t z = (x & keep) | (0x30303030u & ~keep);      // the bytes behind the digits read as '0'
+                                        // every byte in '0'..'9': bit 7 clear, z + 0x46 below 0x80, z + 0x50 at or above it
+                                        const bool digits = ((z | (z + 0x46464646u) | ~(z + 0x50505050u)) & 0x80808080u) == 0u;
+                                        const uint32_t ys = (z - 0x30303030u) << (8u * (4u - nd));  // digit k in byte 4 - nd + k: weights 1000, 100, 10, 1 by byte
+                                        const uint32_t depth = __builtin_amdgcn_udot4(ys, 0x010A6400u, 0u, false) + (ys & 0xFFu) * 1000u;
+                                        const uint32_t b0 = p0 + r3 + 1u;
+                                        if (digits && depth >= 1u && b0 + 1u + depth < le) {
+                                            const uint32_t t4 = le - depth - 1u;
+                                            const uint32_t t4w = tabbits[t4 >> 5];
+                                            // TABs in [p0, le), letters in [b0, t4): differences of running counts
+                                            auto upto = [&](uint32_t at, uint32_t word, uint32_t shift) -> uint32_t {
+                                                return ((pre[at >> 5] >> shift) & 0xFFFFu) + (uint32_t)__popc(word & ((1u << (at & 31u)) - 1u));
+                                            };
+                                            const uint32_t tabs = (upto(le, tabbits[le >> 5], 0) - upto(p0, a0, 0)) & 0xFFFFu;
+                                            const uint32_t letters = (upto(t4, letbits[t4 >> 5], 16) - upto(b0, letbits[b0 >> 5], 16)) & 0xFFFFu;
+                                            if (((t4w >> (t4 & 31u)) & 1u) && tabs == 5u) {
+                                                plain = true;
+                                                // (min_reads2 0: an allele without reads is skipped by the walk, so one letter is still needed)
+                                                is_cand = depth >= prm.min_coverage && letters >= (prm.min_reads2 > 1u ? prm.min_reads2 : 1u);
+                                                e.w = VS_W_PLAIN | depth | (r1 << 14) | (r3 << 20);
+                                            }
+                                        }
+                                    }
+                                }
+                                if (!plain) is_cand = true;                              // the walk looks at it in full (format errors included)
+                            }
+                        }
+                    }
+                    const unsigned long long mk = __ballot(is_cand);
+                    if (mk) {
+                        if (is_cand) cand_local[n_local + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = e;
+                        n_local += (uint32_t)__popcll(mk);
+                        __builtin_amdgcn_wave_barrier();
+                        if (n_local + 64u > VS_CAND_LOCAL) { flush(); __builtin_amdgcn_wave_barrier(); }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (!redo) lines_seen += T;
+        } while (redo);
         // this slot is free: every LDS read of it has returned
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        dma_cur = dma_next;
         dma_next = tt + 2 < t_end ? request(tt + 2, cur) : false;
         uint4 *t_ = cur; cur = other; other = t_;
     }
@@ -677,7 +748,7 @@ __global__ __launch_bounds__(64) void k_varscan_walk(const uint8_t *__restrict__
             if (e.w & VS_W_PLAIN) {
                 // the columns are where k_varscan_scan found them
                 while (l1 > l0) { const uint32_t c = (lds32[(l1 - 1u) >> 2] >> (((l1 - 1u) & 3u) * 8u)) & 0xFFu; if (c != 10u && c != 13u) break; --l1; }
-                const uint32_t depth = e.w & 0xFFFFFu, t1 = l0 + ((e.w >> 20) & 31u), t3 = l0 + ((e.w >> 25) & 31u);
+                const uint32_t depth = e.w & 0x3FFFu, t1 = l0 + ((e.w >> 14) & 63u), t3 = l0 + ((e.w >> 20) & 63u);
                 const uint32_t t4 = l1 - depth - 1u;
                 cols = LineCols{t1 + 1u, depth, t3 + 1u, t4, t4 + 1u, l1};
                 ok = true;
@@ -717,7 +788,7 @@ static inline uint32_t varscan_cand_cap(uint64_t nbytes) {
     const uint64_t c = nbytes / 64 + 4096;
     return (uint32_t)(c < 0x7FFFFFFFull ? c : 0x7FFFFFFFull);
 }
-static const uint32_t VARSCAN_MAX_WAVES = 256 * 16;
+static const uint32_t VARSCAN_MAX_WAVES = 256 * 64;
 size_t snpgpu_varscan_scratch_bytes(uint64_t nbytes) {
     return (size_t)varscan_cand_cap(nbytes) * 20u + 4u * VARSCAN_MAX_WAVES + 1024;
 }
@@ -743,21 +814,29 @@ int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbyte
     const uint64_t shift = (uintptr_t)d_buf & 15u;
     const uint8_t *abase = d_buf - shift;
     const uint64_t lo = shift, hi = shift + nbytes;
-    const uint64_t n_tiles = (hi + VS_TILE - 1) / VS_TILE;
-    // the halo decides how long a line may be and still be looked at in LDS: a quarter KiB does for 30x pileups (lines of ~90
-    // bytes), 1 KiB up to ~150x, 4 KiB beyond; longer lines are left to the walk
-    // (halo_class — 0: 240 bytes, 1: 1008, 2: 4080 — comes from snpgpu_varscan_halo_class over the file's first bytes)
-    const uint32_t halo_chunks = halo_class == 0 ? 15u : halo_class == 1 ? 63u : 255u;
-    const uint32_t slot_bytes = (1u + VS_TILE / 16u + halo_chunks) * 16u;
-    const uint32_t lds = 2u * slot_bytes + VS_CAND_LOCAL * 16u + (VS_LIST_CAP + 2u) * 2u + 12u;
+    // (halo_class comes from snpgpu_varscan_halo_class over the file's first bytes: how long the lines are decides the geometry)
+    const uint32_t cpl = halo_class == 0 ? 4u : halo_class == 1 ? 6u : 8u;             // 16-byte chunks per lane: the slot is 64 of that
+    const uint32_t tile_bytes = halo_class == 0 ? 3840u : halo_class == 1 ? 5120u : 4096u;
+    const uint64_t n_tiles = (hi + tile_bytes - 1) / tile_bytes;
+    const uint32_t slot_bytes = cpl * 1024u, kw = slot_bytes / 32u;
+    const uint32_t lds = 2u * slot_bytes + 5u * (kw + 4u) * 4u + VS_CAND_LOCAL * 16u + (VS_LIST_CAP + 2u) * 2u + 12u;
     uint32_t waves_per_cu = 160u * 1024u / lds;
     if (waves_per_cu > 16u) waves_per_cu = 16u;                                        // (its registers allow 4 per SIMD)
-    uint64_t grid = (uint64_t)ctx->n_cu * waves_per_cu;
+    // Eight workgroups for every place a CU has: the dispatcher hands out the next one when a wave ends, which evens out what a
+    // grid of exactly the resident size leaves to chance — how many waves share a SIMD, the oldest of them taking most issue slots
+    // (tools/vs_sweep.sh: 250 us for 432 MB with 12 waves per CU and one workgroup each, 174 us with eight each; 30x).
+    uint64_t grid = (uint64_t)ctx->n_cu * waves_per_cu * 8u;
+    if (grid > n_tiles / 4u) grid = n_tiles / 4u ? n_tiles / 4u : 1u;                   // (at least four tiles per wave)
+#ifdef SNPGPU_TUNING                                            // development builds only (tools/)
+    if (const char *e = getenv("SNPGPU_VS_WAVES")) if (atoi(e) > 0) grid = (uint64_t)ctx->n_cu * (uint32_t)atoi(e);
+    if (const char *e = getenv("SNPGPU_VS_GRID_MUL")) if (atoi(e) > 0) grid *= (uint32_t)atoi(e);
+#endif
     if (grid > VARSCAN_MAX_WAVES) grid = VARSCAN_MAX_WAVES;
     if (grid > n_tiles) grid = n_tiles;
-#define VS_SCAN(H) k_varscan_scan<H><<<(unsigned)grid, 64, lds, ctx->stream>>>(abase, lo, hi, n_tiles, *prm, d_cand, cand_cap, d_ctl, (unsigned long long *)d_status, \
-                                                                            d_sites, capacity, d_wave_lines)
-    if (halo_class == 0) VS_SCAN(15); else if (halo_class == 1) VS_SCAN(63); else VS_SCAN(255);
+    hipEvent_t ta = snpgpu_time_begin(ctx);
+#define VS_SCAN(C) k_varscan_scan<C><<<(unsigned)grid, 64, lds, ctx->stream>>>(abase, lo, hi, tile_bytes, n_tiles, *prm, d_cand, cand_cap, d_ctl,        \
+                                                                            (unsigned long long *)d_status, d_sites, capacity, d_wave_lines)
+    if (halo_class == 0) VS_SCAN(4); else if (halo_class == 1) VS_SCAN(6); else VS_SCAN(8);
 #undef VS_SCAN
     // walk: LDS for 64 candidate lines — the deeper lines of the file — 2 .. 60 KiB
     const uint32_t walk_bytes = halo_class == 0 ? 16u * 1024u : halo_class == 1 ? 32u * 1024u : 60u * 1024u;
@@ -768,6 +847,7 @@ int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbyte
                                                               d_ctl + 1, cand_cap, d_long, d_ctl + 2);
     k_varscan_walk_long<<<ctx->n_cu, 64, 0, ctx->stream>>>(d_buf, nbytes, *prm, d_sites, capacity, d_ctl, (unsigned long long *)d_status, d_cand, d_long,
                                                            d_wave_lines, (uint32_t)grid);
+    snpgpu_time_end(ctx, SNPGPU_K_VARSCAN, ta);
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;
 }

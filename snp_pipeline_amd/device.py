@@ -237,7 +237,7 @@ class Device(object):
         self._check(self.lib.snpgpu_ctx_kernel_timing(self.ctx, 1 if enable else 0))
 
     def kernel_time_ms(self, kernel):
-        """(total ms, launches) of kernel 0=scan 1=call 2=distance since the last query."""
+        """(total ms, launches) of kernel 0=scan 1=call 2=distance 3=site calling (all of a file's launches) since the last query."""
         ms, n = C.c_float(), C.c_uint32()
         self._check(self.lib.snpgpu_ctx_kernel_time_ms(self.ctx, kernel, C.byref(ms), C.byref(n)))
         return ms.value, n.value

@@ -561,9 +561,13 @@ def test_hot_path_batch_with_foreign_var_flt_vcf_files(tmp_path, fixture_trees, 
         path = os.path.join(d, "var.flt.vcf")
         assert (open(path, "rb").read(), os.stat(path).st_mtime_ns) == before[d], d
     # 2. what the reference ships downstream of them
+    n_split = 0
     for name, d in zip(names, dirs):
         for fname in ("var.flt_preserved.vcf", "var.flt_removed.vcf"):
-            assert filecmp.cmp(os.path.join(d, fname), os.path.join(root, "samples", name, fname), shallow=False), (name, fname)
+            if os.path.exists(os.path.join(root, "samples", name, fname)):       # (the listeria fixture ships the split files of some samples only)
+                assert filecmp.cmp(os.path.join(d, fname), os.path.join(root, "samples", name, fname), shallow=False), (name, fname)
+                n_split += 1
+    assert n_split >= 8
     for fname in ("snplist.txt", "snplist_preserved.txt", "referenceSNP.fasta", "referenceSNP_preserved.fasta"):
         assert filecmp.cmp(os.path.join(work, fname), os.path.join(root, fname), shallow=False), fname
     # 3. the consensus side against the restatement on these pileups, both flows

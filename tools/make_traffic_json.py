@@ -38,3 +38,26 @@ out = {
 }
 json.dump(out, open(base + "pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
+
+
+# phase-1 site calling: FETCH_SIZE / WRITE_SIZE of its three kernels on one resident sample (varscan_kernels.txt of the same round)
+try:
+    txt = open(base + "varscan_kernels.txt").read()
+    m = re.search(r"^(\d+) bytes, (\d+) lines", txt, re.M)
+    nbytes = int(m.group(1))
+    fetch = write = 0.0
+    for kern in ("k_varscan_scan", "k_varscan_walk\n", "k_varscan_walk_long"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            mm = re.search(r"%s[^\n]*\n\s+%s\s+n=\d+\s+mean=(\S+)" % (kern.replace("\n", "(?=\n)"), counter), txt)
+            if mm:
+                if counter == "FETCH_SIZE":
+                    fetch += float(mm.group(1))
+                else:
+                    write += float(mm.group(1))
+    vs = {"kernels": "k_varscan_scan + k_varscan_walk + k_varscan_walk_long, one resident 5 Mbp x 30x sample", "bytes": nbytes,
+          "FETCH_SIZE_kb_per_file": fetch, "WRITE_SIZE_kb_per_file": write, "corrections": out["corrections"],
+          "traffic_bytes_per_file": fetch * 1024 * 2 + write * 1024, "traffic_over_algorithmic": (fetch * 1024 * 2 + write * 1024) / nbytes}
+    json.dump(vs, open(base + "varscan_traffic.json", "w"), indent=1)
+    print(json.dumps(vs, indent=1))
+except (OSError, AttributeError) as e:
+    print("no varscan traffic summary: %s" % e)

@@ -18,9 +18,9 @@ for r in csv.reader(open('$root/gpurun_out/vs_stats_$dp.csv')):
 PY
 done
 if [ -n "$VS_PMC" ]; then
-    for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+    for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
         rocprofv3 --pmc $set --output-format csv -d $root/gpurun_out/vs_pmc -- python $root/tools/varscan_kernel_time.py 5000000 ${VS_PMC} 3 > /dev/null 2>&1
-        python $root/tools/pmc_summary.py $root/gpurun_out/vs_pmc | grep -A12 -E "k_varscan|k_lines_index"
+        python $root/tools/pmc_summary.py $root/gpurun_out/vs_pmc | grep -A12 -E "k_varscan"
         rm -rf $root/gpurun_out/vs_pmc
     done
 fi
