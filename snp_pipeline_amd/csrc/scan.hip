@@ -1028,14 +1028,16 @@ int snpgpu_enqueue_lines_offsets(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t
     return SNPGPU_OK;
 }
 
-size_t snpgpu_scan_totals_bytes(const snpgpu_ctx *ctx) { return 3 * 8 * (size_t)ctx->n_cu * 2 * 16 + 256; }
+size_t snpgpu_scan_totals_bytes(const snpgpu_ctx *ctx) { return 3 * 8 * (size_t)ctx->n_cu * 16 * 16 + 256; }   // (room for 16 launches' worth of waves: the grid may be a multiple of what is resident)
 size_t snpgpu_scan_workspace_bytes(const snpgpu_ctx *ctx, uint32_t n_samples) {
     return ((size_t)(n_samples + 1) * sizeof(SampleDev) + 255) / 256 * 256 + snpgpu_scan_totals_bytes(ctx);
 }
 
 namespace {
 struct ScanConfig {
-    int blocks_per_cu = 1, mode = 0, waves = SCAN_NBUF == 2 ? 16 : 12;
+    // oversub: the grid holds twice the workgroups that are resident at a time, so a CU that finishes its first one early takes
+    // another (tools/scan_oversub.sh: 66.3 -> 67.9 % of HBM peak in a 96-sample launch at 30x; 4 and 8 give the same)
+    int blocks_per_cu = 1, mode = 0, waves = SCAN_NBUF == 2 ? 16 : 12, oversub = 2;
     int share[4] = {329, 282, 223, 169};                    // measured: 1 / (finish time with equal shares), oldest first
     bool ready = false;
 };
@@ -1049,7 +1051,8 @@ ScanConfig &scan_config() {
             if (sscanf(sh, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0)
                 for (int g = 0; g < 4; ++g) c.share[g] = v[g];
         }
-        c.blocks_per_cu = b && atoi(b) > 0 && atoi(b) <= 2 ? atoi(b) : 1;
+        c.blocks_per_cu = b && atoi(b) > 0 && atoi(b) <= 16 ? atoi(b) : 1;
+        if (const char *o = getenv("SNPGPU_SCAN_OVERSUB")) if (atoi(o) >= 1 && atoi(o) <= 16) c.oversub = atoi(o);
         c.mode = m ? atoi(m) : 0;
         if (w && atoi(w) >= 1 && atoi(w) <= 16) c.waves = atoi(w);
 #endif
@@ -1098,7 +1101,6 @@ ScanArgs scan_args(const snpgpu_siteset *ss, const ScanConfig &c, const SampleDe
 // least one wave each, at least min_tiles_per_wave tiles per wave where the range allows it).  Returns the wave count.
 uint32_t snpgpu_scan_deal(const snpgpu_ctx *ctx, SampleDev *h, uint32_t n, uint32_t min_tiles_per_wave) {
     const ScanConfig &c = scan_config();
-    const uint64_t max_waves = (uint64_t)ctx->n_cu * c.blocks_per_cu * c.waves;
     if (!min_tiles_per_wave) min_tiles_per_wave = 1;
     std::vector<uint64_t> tiles(n);
     uint64_t total_tiles = 0;
@@ -1106,6 +1108,10 @@ uint32_t snpgpu_scan_deal(const snpgpu_ctx *ctx, SampleDev *h, uint32_t n, uint3
         tiles[i] = h[i].tile_hi - h[i].tile_lo;
         total_tiles += tiles[i];
     }
+    // the grid is a multiple of what is resident only for launches long enough that a wave's start-up does not show (a second
+    // workgroup per CU costs ~1.5 % at 800 tiles per wave, gains 2 % at 2 500: tools/scan_oversub.sh)
+    const uint64_t resident = (uint64_t)ctx->n_cu * c.blocks_per_cu * c.waves;
+    const uint64_t max_waves = resident * (total_tiles / resident >= 1500 ? c.oversub : 1);
     uint64_t budget = total_tiles / min_tiles_per_wave, used = 0;
     if (budget > max_waves) budget = max_waves;
     if (budget < n) budget = n;
@@ -1148,7 +1154,7 @@ int snpgpu_scan_range(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev
     const ScanConfig &c = scan_config();
     scan_allow_lds(ctx);
     hipStream_t st = ctx->stream;
-    if (n > (uint64_t)ctx->n_cu * c.blocks_per_cu * c.waves) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "too many samples for one scan launch");
+    if (n > (uint64_t)ctx->n_cu * c.blocks_per_cu * c.waves * c.oversub) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "too many samples for one scan launch");
     ScanArgs sa = scan_args(ss, c, d_table, n, d_totals, d_site_line, want_depth);
     const size_t lds = scan_lds_bytes(c);
     const unsigned grid = (unsigned)((n_waves + c.waves - 1) / c.waves), threads = (unsigned)c.waves * 64;

@@ -33,6 +33,10 @@ def main():
     ap.add_argument("--dir", type=str, default=None)
     ap.add_argument("--recycle", type=int, default=0, help="GiB of device memory allocated, touched and freed before the tree is written")
     ap.add_argument("--sync", action="store_true", help="os.sync() after writing the tree: the run does not compete with the write-back of 54 GB")
+    ap.add_argument("--extra", type=str, default="", help="more options for hot_path_batch, e.g. '--siteCalling existing'")
+    ap.add_argument("--resident-frac", type=float, default=0.0,
+                    help="after the timed runs: one more run with --residentBytes = this fraction of the pileup bytes (the rest is streamed twice); "
+                         "its time and whether every output file equals the fully resident run's")
     ap.add_argument("--probe-open", choices=("none", "stat", "serial", "parallel"), default="none",
                     help="before the first run: time stat / open of every pileup (what does the first open after the write cost?)")
     a = ap.parse_args()
@@ -121,7 +125,7 @@ def main():
                     os.close(fd)
         runs = []
         for _ in range(a.runs):
-            wall = bench.run_cli(bench.hot_path_line(dirs_file, ref_path, " --noConsensusVcf" if a.no_vcf else ""), verbose=a.verbose)
+            wall = bench.run_cli(bench.hot_path_line(dirs_file, ref_path, (" --noConsensusVcf" if a.no_vcf else "") + (" " + a.extra if a.extra else "")), verbose=a.verbose)
             st = dict(hot_path.hot_path_batch.last_stats)
             st["cli_seconds"] = wall
             runs.append(st)
@@ -129,7 +133,20 @@ def main():
         best = min(runs, key=lambda r: r["seconds"])
         ideal = total / (out["pinned_h2d_gb_per_sec"] * 1e9)
         out.update({"best_seconds": best["seconds"], "ideal_copy_seconds": ideal, "wall_over_copy": best["seconds"] / ideal,
-                    "h2d_equals_file_bytes": best["h2d_bytes"] == total})
+                    "h2d_equals_file_bytes": best["h2d_bytes"] == total,
+                    # what the job costs per sample beyond moving its bytes: Python per sample, the files it writes, launches
+                    "host_ms_per_sample_outside_the_copy": (best["seconds"] - ideal) / a.samples * 1e3,
+                    "ms_per_sample": best["seconds"] / a.samples * 1e3})
+        if a.resident_frac > 0 and not a.no_vcf:
+            full = bench.output_digests(tmpdir, dirs)
+            budget = int(total * a.resident_frac)
+            wall = bench.run_cli(bench.hot_path_line(dirs_file, ref_path, " --residentBytes %d" % budget + (" " + a.extra if a.extra else "")), verbose=a.verbose)
+            st = dict(hot_path.hot_path_batch.last_stats)
+            part = bench.output_digests(tmpdir, dirs)
+            out["partly_resident"] = {"resident_bytes_budget": budget, "resident_files": st["resident_files"], "files": st["files"], "seconds": st["seconds"],
+                                      "h2d_bytes": st["h2d_bytes"], "h2d_over_file_bytes": st["h2d_bytes"] / total,
+                                      "over_fully_resident": st["seconds"] / best["seconds"], "outputs_identical_to_fully_resident": part == full,
+                                      "phases": st["phases"]}
         if a.separate and not a.no_vcf:
             mine = bench.output_digests(tmpdir, dirs)
             for sdir in dirs:
