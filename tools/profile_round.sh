@@ -1,8 +1,8 @@
 #!/bin/sh
 # Round profile on the GPU box: the bench line, the rocprofv3 kernel trace of the same command, and the PMC passes
 # (FETCH_SIZE / WRITE_SIZE / SQ counters, separate runs) -> gpurun_out/<round>/ ; copy what is to be judged into profiles/<round>/.
-# Usage: sh tools/profile_round.sh r3
-round=${1:-r3}
+# Usage: sh tools/profile_round.sh r4
+round=${1:-r4}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$round
 mkdir -p "$out"
