@@ -97,7 +97,7 @@ typedef struct snpgpu_site_counts {
  * vcf_writer.py:317-331 lists every one as an ALT allele): the record itself keeps the first eight, the rest goes to one of
  * SNPGPU_SPILL_CAP records the context holds.  The same record carries a reference-base field of more than one byte
  * (pileup.py:223 takes any string; every '.' / ',' then stands for all of its characters, pileup.py:255-258, and the VCF
- * REF column shows the string): ref_len > 1 and ref[] hold it, n may be 0.  A call that produces per-site records starts with an empty spill;
+ * REF column shows the string): ref_len > 1 and ref[] hold it, n may be 0.  And a depth column outside 0 .. 2^32 - 1 (depth64).  A call that produces per-site records starts with an empty spill;
  * snpgpu_symbol_spill_read copies out what the context's calls have put there since (synchronises the context's stream). */
 #define SNPGPU_SPILL_SYMS 120
 #define SNPGPU_SPILL_REF  64
@@ -105,7 +105,8 @@ typedef struct snpgpu_site_counts {
 typedef struct snpgpu_symbol_spill {
     uint32_t n;                         /* entries used */
     uint32_t ref_len;                   /* 0 or 1: the record's ref_base is the whole field; else bytes used of ref[] */
-    uint32_t reserved[2];
+    int64_t  depth64;                   /* Record.raw_depth when the record's 32 unsigned bits cannot hold it — int() takes "-3"
+                                         * and "5000000000" (pileup.py:225) and consensus.vcf prints what it got; else 0 */
     uint8_t  sym[SNPGPU_SPILL_SYMS];    /* most_common_good_bases[8 + k] */
     uint32_t total[SNPGPU_SPILL_SYMS];
     uint32_t fwd[SNPGPU_SPILL_SYMS];

@@ -486,7 +486,15 @@ def gen_longref_vectors():
         f[2] = LONG_REFS[k % len(LONG_REFS)]
         lines.append("\t".join(f))
     lines += ["ID\t42\tGC\t14\taaaAAA....,,,,\t00011122223333", "ID\t43\tg,\t6\t..,,AC\tIIIIII", "ID\t44\tAC\t0", "ID\t45\tAC\t3\t.,.\t!!!"]
-    return {"records": [record_vector(pileup, ln) for ln in lines]}
+    # depth columns that int() takes and the 32 unsigned bits of the device record do not hold (pileup.py:225): the reference
+    # compares the value with 0 and prints it
+    wide = []
+    for k, depth in enumerate(["-3", "-0", "+7", "4294967295", "4294967296", "5000000000", "-5000000000", "1_000", "-1_0", "00012",
+                               "4611686018427387903", "-4611686018427387903"]):
+        wide.append("DP\t%d\t%s\t%s\t..,,AaCc*\tIIII5IIII" % (100 + k, "ACGTN"[k % 5], depth))
+        wide.append("DP\t%d\tAC\t%s\t..,,Gg\tIIIIII" % (200 + k, depth))
+        wide.append("DP\t%d\tT\t%s" % (300 + k, depth))
+    return {"records": [record_vector(pileup, ln) for ln in lines], "wide_depth_records": [record_vector(pileup, ln) for ln in wide]}
 
 
 def gen_steps_vectors():

@@ -33,7 +33,7 @@ SPILL_SYMS, SPILL_REF, SPILL_CAP = 120, 64, 1024
 
 
 class SymbolSpill(C.Structure):
-    _fields_ = [("n", C.c_uint32), ("ref_len", C.c_uint32), ("reserved", C.c_uint32 * 2), ("sym", C.c_uint8 * SPILL_SYMS),
+    _fields_ = [("n", C.c_uint32), ("ref_len", C.c_uint32), ("depth64", C.c_int64), ("sym", C.c_uint8 * SPILL_SYMS),
                 ("total", C.c_uint32 * SPILL_SYMS), ("fwd", C.c_uint32 * SPILL_SYMS), ("rev", C.c_uint32 * SPILL_SYMS),
                 ("ref", C.c_uint8 * SPILL_REF)]
 

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
         const uint32_t sflags = cur.sflags;
         uint32_t status = SNPGPU_ST_NO_LINE, filters = 0, cons = '-', out_b = '-';
         uint32_t raw_depth = 0, good = 0, nfwd = 0, nrev = 0, nsym = 0, ref = 0, ref_len = 1, ref_at = 0;
+        long long depth64 = 0;
         bool have_hist = false;
         if (lv != 0) {
             const uint64_t ls = lv - 1;
@@ -191,10 +192,12 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
                 uint32_t ds = L.fs[3], de = L.fe[3];
                 PyInt di;                                    // int(depth), pileup.py:225 ("+30" and "3_0" are integers too)
                 for (uint32_t q = ds; q < de; ++q) di.feed(lb(q));   // uniform loop, a handful of bytes
-                // (a negative depth is an integer for the reference as well; the 32-bit record cannot hold it: refused)
-                if (!di.ok() || (di.neg && di.v != 0)) status = SNPGPU_ST_BAD_DEPTH;
+                // (a negative depth, or one past 2^32, is an integer for the reference as well — it only ever prints it and compares it
+                // with 0: such a value travels in the position's spill record; past 2^62 it is refused)
+                if (!di.ok() || di.v >= (1ull << 62)) status = SNPGPU_ST_BAD_DEPTH;
                 else {
                     raw_depth = di.v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)di.v;
+                    if (di.v > 0xFFFFFFFFull || (di.neg && di.v != 0)) depth64 = di.neg ? -(long long)di.v : (long long)di.v;
                     if (raw_depth != 0 && nfields == 5) status = SNPGPU_ST_NO_QUALS;
                 }
             }
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
             // more symbols than the record keeps (consensus.vcf lists every one as an ALT allele), or a reference field of several
             // bytes (with or without good reads): ranks 8, 9, ... in the same order and the field go to a spill record of the
             // context; its index + 1 travels in the upper bits of n_symbols
-            if (a.out_counts && (nsym > SNPGPU_MAX_SYMS || ref_len > 1)) {
+            if (a.out_counts && (nsym > SNPGPU_MAX_SYMS || ref_len > 1 || depth64 != 0)) {
                 uint32_t slot = 0xFFFFFFu;
                 if (a.spill) {
                     if (lane == 0) slot = atomicAdd(a.spill_n, 1u);
@@ -394,6 +397,7 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
                     if (lane == 0) {
                         sp->n = r;
                         sp->ref_len = ref_len > 1 ? ref_len : 0u;
+                        sp->depth64 = depth64;
                         if (ref_len > 1) for (uint32_t i = 0; i < ref_len; ++i) sp->ref[i] = (uint8_t)((ref_at + i) < CALL_LBUF ? (uint32_t)L.line[ref_at + i] : (uint32_t)buf[lv - 1 + ref_at + i]);
                     }
                     nsym |= (slot + 1u) << 8;

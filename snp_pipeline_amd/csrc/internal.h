@@ -175,12 +175,12 @@ __device__ __forceinline__ bool is_term(uint32_t c) { return c == 10u || c == 13
 __device__ __forceinline__ bool is_digit(uint32_t c) { return c - 48u <= 9u; }
 // Python's int() on an ASCII field, one byte at a time: [+-]? digit ( _? digit )*.  Feed the bytes in order; `ok()` at the end.
 struct PyInt {
-    uint64_t v = 0;             // magnitude, saturating at 2^40
+    uint64_t v = 0;             // magnitude, saturating at 2^62
     uint32_t n = 0;             // bytes seen
     bool neg = false, bad = false, last_digit = false;
     __device__ __forceinline__ void feed(uint32_t c) {
         if (n == 0 && (c == '+' || c == '-')) neg = c == '-';
-        else if (is_digit(c)) { v = v * 10 + (c - 48u); if (v > (1ull << 40)) v = 1ull << 40; last_digit = true; }
+        else if (is_digit(c)) { v = v * 10 + (c - 48u); if (v > (1ull << 62)) v = 1ull << 62; last_digit = true; }
         else if (c == '_' && last_digit) last_digit = false;     // an underscore sits between two digits
         else bad = true;
         ++n;

@@ -763,19 +763,19 @@ __global__ __launch_bounds__(64) void k_varscan_walk(const uint8_t *__restrict__
     }
 }
 
-// The candidates that did not fit a strip or have no known end: one lane per line, bytes straight from global memory.  Block 0
-// also adds up the line counts of the scan's waves (the one number besides the records that the host is told).
+// The candidates that did not fit a strip or have no known end: one lane per line, bytes straight from global memory.  The blocks
+// also add up the line counts of the scan's waves (the one number besides the records that the host is told; ctl[4..5] start at 0).
 __global__ __launch_bounds__(64) void k_varscan_walk_long(const uint8_t *__restrict__ buf, uint64_t nbytes, snpgpu_varscan_params prm, snpgpu_varscan_site *out,
                                                           uint32_t capacity, uint32_t *ctl, unsigned long long *status, const uint4 *__restrict__ cand,
                                                           const uint32_t *__restrict__ long_idx, const uint32_t *__restrict__ wave_lines, uint32_t n_waves) {
     const uint32_t n = ctl[2];
     for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 64)
         walk_entry_global(buf, nbytes, cand[long_idx[i]], prm, out, capacity, ctl, status);
-    if (blockIdx.x == 0) {
+    {   // every block a slice of the waves' line counts (up to 16 384 of them: one block alone would take longer than the scan's tail)
         unsigned long long s = 0;
-        for (uint32_t k = threadIdx.x; k < n_waves; k += 64) s += wave_lines[k];
+        for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < n_waves; k += gridDim.x * 64u) s += wave_lines[k];
         for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
-        if (threadIdx.x == 0) { ctl[4] = (uint32_t)s; ctl[5] = (uint32_t)(s >> 32); }
+        if (threadIdx.x == 0 && s) atomicAdd((unsigned long long *)(ctl + 4), s);
     }
 }
 

@@ -95,7 +95,10 @@ bool put_row(Out &o, const snpgpu_site_counts &c, uint32_t mask, uint64_t key, c
     else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.put(sym_of(alt[k])); }
     o.puts_("\t.\t"); o.putn(ft, ftn);
     o.puts_("\tNS=1\tGT:SDP:RD:AD:RDF:RDR:ADF:ADR:FT\t");
-    o.put(gt); o.put(':'); o.putu(c.raw_depth); o.put(':');
+    o.put(gt); o.put(':');
+    if (more && more->depth64 != 0) { if (more->depth64 < 0) o.put('-'); o.putu(more->depth64 < 0 ? 0ull - (uint64_t)more->depth64 : (uint64_t)more->depth64); }
+    else o.putu(c.raw_depth);
+    o.put(':');
     o.putu(ref_at >= 0 && !none ? total_of(ref_at) : 0); o.put(':');
     if (n_alt == 0) o.put('0'); else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.putu(total_of(alt[k])); }
     o.put(':'); o.putu(ref_at >= 0 && !none ? fwd_of(ref_at) : 0);

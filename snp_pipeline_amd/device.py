@@ -164,7 +164,7 @@ class SiteSet(object):
             pass
 
 
-SPILL_DTYPE = np.dtype([("n", "<u4"), ("ref_len", "<u4"), ("reserved", "<u4", (2,)), ("sym", "u1", (L.SPILL_SYMS,)),
+SPILL_DTYPE = np.dtype([("n", "<u4"), ("ref_len", "<u4"), ("depth64", "<i8"), ("sym", "u1", (L.SPILL_SYMS,)),
                         ("total", "<u4", (L.SPILL_SYMS,)), ("fwd", "<u4", (L.SPILL_SYMS,)), ("rev", "<u4", (L.SPILL_SYMS,)),
                         ("ref", "u1", (L.SPILL_REF,))])
 assert SPILL_DTYPE.itemsize == C.sizeof(L.SymbolSpill)

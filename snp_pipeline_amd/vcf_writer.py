@@ -63,12 +63,15 @@ def row_from_counts(chrom, pos, c, filter_names, preserve_ref_case, failed_snp_g
     failed = [filter_names[i] for i in range(6) if mask >> i & 1]
     n_sym, code = int(c["n_symbols"]) & 0xFF, int(c["n_symbols"]) >> 8
     ranked = [(chr(int(c["sym"][r])), int(c["total"][r]), int(c["fwd"][r]), int(c["rev"][r])) for r in range(min(n_sym, L.MAX_SYMS))]
+    raw_depth = int(c["raw_depth"])
     if n_sym > L.MAX_SYMS or code:
         extra = max(n_sym - L.MAX_SYMS, 0)
         if spill is None or code == 0 or code - 1 >= len(spill) or int(spill[code - 1]["n"]) != extra:
             raise ValueError("%s:%d has %d distinct symbols (or a long reference field) and no spill record; the device record keeps %d"
                              % (chrom, pos, n_sym, L.MAX_SYMS))
         more = spill[code - 1]
+        if int(more["depth64"]) != 0:                   # a depth column outside 0 .. 2^32 - 1 ("-3", "5000000000": int() takes them)
+            raw_depth = int(more["depth64"])
         ranked += [(chr(int(more["sym"][r])), int(more["total"][r]), int(more["fwd"][r]), int(more["rev"][r])) for r in range(extra)]
         if int(more["ref_len"]) > 1:                    # a reference field of several bytes: the string itself, equal to no symbol
             ref = bytes(more["ref"][:int(more["ref_len"])]).decode("latin-1")
@@ -93,7 +96,7 @@ def row_from_counts(chrom, pos, c, filter_names, preserve_ref_case, failed_snp_g
         if failed:
             gt = "." if failed_snp_gt == "." else ("0" if failed_snp_gt == "0" else "1")
     ft = ";".join(failed) if failed else "PASS"
-    data = ":".join([gt, str(int(c["raw_depth"])), str(total.get(upper_ref, 0)), ad, str(fwd.get(upper_ref, 0)),
+    data = ":".join([gt, str(raw_depth), str(total.get(upper_ref, 0)), ad, str(fwd.get(upper_ref, 0)),
                      str(rev.get(upper_ref, 0)), adf, adr, ft])
     return "\t".join([chrom, str(pos), ".", ref, ",".join(alt) if alt else ".", ".", ft, "NS=1", FORMAT_IDS, data])
 

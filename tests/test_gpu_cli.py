@@ -310,7 +310,9 @@ def test_positions_with_more_than_eight_symbols_get_all_their_alt_alleles(tmp_pa
         if i % 5 == 4:                                              # every '.' / ',' spelled out by a reference field of several bytes
             bases = bases.replace("*", ".").replace("n", ",")
         ref = rng.choice(("AC", "g,", "Tn", "ac.")) if i % 5 == 4 else rng.choice("ACGTacgt")
-        lines.append("ctg1\t%d\t%s\t%d\t%s\t%s" % (pos, ref, len(reads), bases, quals))
+        # (round 4) a depth column int() takes and 32 unsigned bits do not hold: the reference only prints it (pileup.py:225)
+        depth = "-%d" % len(reads) if i % 7 == 3 else ("%d" % (5_000_000_000 + i) if i % 7 == 5 else "%d" % len(reads))
+        lines.append("ctg1\t%d\t%s\t%s\t%s\t%s" % (pos, ref, depth, bases, quals))
         keys.append((b"ctg1", pos))
     data = ("\n".join(lines) + "\n").encode()
     params = po.CallerParams(10, 0.6, 3, 0, 0.0)
@@ -323,6 +325,7 @@ def test_positions_with_more_than_eight_symbols_get_all_their_alt_alleles(tmp_pa
         rows.append(vo.vcf_row(rec, [names[i] for i in range(6) if mask >> i & 1] or None, "."))
     assert any(row.split("\t")[4].count(",") >= 9 for row in rows)             # ten or more ALT alleles in a row
     assert sum(1 for row in rows if len(row.split("\t")[3]) > 1) == 8          # REF strings
+    assert sum(1 for row in rows if row.split("\t")[9].split(":")[1].startswith("-")) == 6 and sum(1 for row in rows if row.split("\t")[9].split(":")[1].startswith("50000000")) == 5
     with open(str(tmp_path / "snplist.txt"), "w") as f:
         for c, p in keys:
             f.write("%s\t%d\t1\ts\n" % (c.decode(), p))

@@ -32,13 +32,16 @@ def test_golden_reference_fields_of_several_bytes(d, longref_vectors):
     counts once per character of the field, the field itself travels in the position's spill record."""
     checked, spilled, long_refs = _golden_records(d, longref_vectors["records"])
     assert checked > 1500 and long_refs == checked
+    # depth columns outside 0 .. 2^32 - 1 (closed in round 4: the value rides in the spill record's depth64)
+    checked, _, _ = _golden_records(d, longref_vectors["wide_depth_records"])
+    assert checked > 60 and _golden_records.wide_depths >= 15
 
 
 def _golden_records(d, recs):
     from snp_pipeline_amd import _lib as L
     from tests.gpu_util import gpu_consensus
     param_sets = sorted({tuple(c["params"]) for v in recs for q in v["by_q"].values() if "calls" in q for c in q["calls"]})
-    checked = spilled = long_refs = 0
+    checked = spilled = long_refs = wide = 0
     for params in param_sets:
         p = po.CallerParams(*params)
         q = str(params[0])
@@ -55,7 +58,11 @@ def _golden_records(d, recs):
             c = res.counts[slot]
             call = [x for x in w["calls"] if tuple(x["params"]) == params][0]
             assert c["status"] == L.ST_OK, w
-            assert (c["raw_depth"], c["good_depth"], c["fwd_good_depth"], c["rev_good_depth"]) == (w["raw"], w["good"], w["fwd"], w["rev"]), w
+            raw = int(c["raw_depth"])
+            if not 0 <= w["raw"] < (1 << 32):                       # "-3", "5000000000": the value is in the position's spill record
+                raw = int(res.spill[(int(c["n_symbols"]) >> 8) - 1]["depth64"])
+                wide += 1
+            assert (raw, c["good_depth"], c["fwd_good_depth"], c["rev_good_depth"]) == (w["raw"], w["good"], w["fwd"], w["rev"]), w
             assert chr(c["cons_base"]) == call["base"], (key, call)
             assert _names(int(c["filters"]), p) == call["failed"], (key, call)
             ranked = w["ranked"] or []
@@ -81,6 +88,7 @@ def _golden_records(d, recs):
         # the lane-per-site kernel on the same lines (no per-site counts requested)
         cons2, res2, _ = gpu_consensus(d, data, keys, [], p, want_counts=False)
         assert bytes(res2.bases) == bytes(res.bases) and bytes(res2.filters) == bytes(res.filters)
+    _golden_records.wide_depths = wide
     return checked, spilled, long_refs
 
 
@@ -540,9 +548,15 @@ def test_python_int_fields(d):
         with pytest.raises(PileupFormatError) as ei:
             gpu_consensus(d, bad, keys, [], po.CallerParams())
         assert ei.value.reference_exception is ValueError
-    # a negative depth is an integer for the reference; the 32-bit record cannot hold it: refused loudly
+    # a negative depth is an integer for the reference, which compares it with 0 and prints it: since round 4 the device does
+    # the same (the value rides in the position's spill record); only a depth of 2^62 and beyond is still refused
+    res = check_against_oracle(d, b"c1\t5\tA\t-3\t...\tIII\nc1\t7\tC\t5000000000\tGGg\tIII\n", keys, [], po.CallerParams(0, 0.6, 1, 0, 0.0))
+    slots = {k: i for i, k in enumerate(sorted(keys))}
+    for key, want in (((b"c1", 5), -3), ((b"c1", 7), 5000000000)):
+        c = res.counts[slots[key]]
+        assert int(res.spill[(int(c["n_symbols"]) >> 8) - 1]["depth64"]) == want and int(c["good_depth"]) == 3
     with pytest.raises(PileupFormatError):
-        gpu_consensus(d, b"c1\t5\tA\t-3\t...\tIII\n", keys, [], po.CallerParams())
+        gpu_consensus(d, b"c1\t5\tA\t4611686018427387904\t...\tIII\n", keys, [], po.CallerParams())
 
 
 def test_the_first_malformed_line_in_file_order_decides_the_exception(d, tmp_path):

@@ -32,6 +32,9 @@ def test_reference_fields_of_several_bytes(longref_vectors):
     recs = longref_vectors["records"]
     assert all(len(v["line"].split("\t")[2]) > 1 for v in recs)
     assert _check_records(recs) > 1500
+    # ... and on lines whose depth column is an integer outside 0 .. 2^32 - 1 ("-3", "5000000000", "1_000": pileup.py:225)
+    wide = longref_vectors["wide_depth_records"]
+    assert _check_records(wide) > 60 and sum(1 for v in wide if not 0 <= v["by_q"]["0"]["raw"] < (1 << 32)) >= 15
 
 
 def _check_records(records):
