@@ -361,8 +361,13 @@ __device__ __noinline__ void walk_entry_global(const uint8_t *buf, uint64_t nbyt
 #define VS_LIST_CAP 256u          // line starts held in LDS per pass (a tile with more makes extra passes)
 #define VS_CAND_LOCAL 96u         // candidate entries a wave collects in LDS before it takes a place on the list
 
-// 0x80 in every byte of w in 0x0A..0x0D (what a line terminator can be, and VT / FF: sorted out by whoever uses the flag)
-__device__ __forceinline__ uint32_t term4(uint32_t w) { return (w + 0x76767676u) & ~(w + 0x72727272u) & 0x80808080u; }
+// 0x80 in every byte of w in 0x0A..0x0D (what a line terminator can be, and VT / FF: sorted out by whoever uses the flag).  Exact
+// for any byte values: the adds run on the low seven bits, so nothing carries from a byte >= 0x8A into its neighbour (a pileup's
+// name or quality column may hold such bytes; the consensus scan refuses them, this pass must not be fooled by them).
+__device__ __forceinline__ uint32_t term4(uint32_t w) {
+    const uint32_t m = w & 0x7F7F7F7Fu;
+    return (m + 0x76767676u) & ~(m + 0x72727272u) & ~w & 0x80808080u;
+}
 // the four flag words of a 16-byte chunk (0x80 per flagged byte) -> 16 bits, byte k of the chunk = bit k
 __device__ __forceinline__ uint32_t bits16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
     uint32_t r = __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false);

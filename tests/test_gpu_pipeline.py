@@ -608,3 +608,34 @@ def test_site_calling_mode_existing_reports_a_sample_without_its_vcf(tmp_path, f
         assert os.path.getsize(os.path.join(dirs[k], "consensus.fasta")) > 0
     got = open(os.path.join(work, "snpma.fasta")).read()
     assert got.count(">") == 2 and ">%s\n" % names[0] in got and ">%s\n" % names[3] in got
+
+
+def test_a_rank_that_fails_takes_the_others_with_it_instead_of_leaving_them_in_a_collective(tmp_path):
+    """one rank's stage raises (here: a split VCF of ONE of rank 1's samples cannot be written — a directory sits where
+    the file should go) while its peer is healthy.  Between stages the ranks agree on failure: both leave, soon, with a non-zero
+    exit code; the failing rank's own error reaches the log; nobody waits in the next all-gather until a timeout ends it."""
+    import socket
+    import subprocess
+    import sys
+    work = tmp_path
+    ref_path, dirs, dirs_file, piles = _outbreak_tree(work, n_samples=6)
+    os.makedirs(os.path.join(sorted(dirs)[-1], "var.flt_removed.vcf"))          # the last sample belongs to rank 1
+    filter_extra = "--edge_length 100 --window_size 1000 125 15 --max_snp 3 2 1 --mode all"
+    line = ("hot_path_batch -f --siteCalling device %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s --varscanExtraParams=%s"
+            % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), CONSENSUS_EXTRA.replace(" ", "\x00"), VARSCAN_EXTRA.replace(" ", "\x00")))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    log = str(work / "error.log")
+    env = dict(os.environ, SNPGPU_PIPELINE_ONE_GPU="1", MASTER_ADDR="127.0.0.1", errorOutputFile=log,
+               PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bin", "cfsan_snp_pipeline")] + [w.replace("\x00", " ") for w in line.split()] + ["-v", "1"]
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=str(work), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and time.time() - t0 < 120, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    text = open(log).read()
+    assert "IsADirectoryError" in text and "hot_path_batch" in text
+    assert "rank 0 stops after stage_consensus: rank 1 failed" in r.stdout, r.stdout[-2500:]

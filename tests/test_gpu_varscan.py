@@ -410,3 +410,26 @@ def test_full_candidate_list_unaligned_text_and_lines_across_tiles(d, tmp_path):
                     assert got == "PileupFormatError", (eol, edge, delta)
                 else:
                     assert got == want2, (eol, edge, delta)
+
+
+@pytest.mark.parametrize("eol", [b"\r", b"\n", b"\r\n"])
+def test_bytes_above_0x89_next_to_terminators_and_tabs(d, tmp_path, eol):
+    """The SWAR terminator test of k_varscan_scan must not carry from one byte into the next: a quality column that ends with a
+    byte >= 0x8A right in front of the line terminator (lone CR: the fast form would have missed the line end), and a contig name
+    that ends with one right in front of the first TAB (the TAB would have looked like a terminator)."""
+    from snp_pipeline_amd import varscan
+    opts = varscan.Options("--min-var-freq 0.2 --min-reads2 2 --min-avg-qual 0")
+    lines = []
+    for i in range(4000):
+        depth = 10 + i % 7
+        bases = ("G" * depth if i % 9 == 0 else "." * depth).encode()
+        quals = bytes([0x49] * (depth - 1) + [0xFE if i % 2 else 0x8A])
+        lines.append(b"ctg\xe9\t%d\tA\t%d\t%s\t%s" % (i + 1, depth, bases, quals))
+    data = eol.join(lines) + eol
+    path = str(tmp_path / "hi.pileup")
+    with open(path, "wb") as f:
+        f.write(data)
+    out = str(tmp_path / "hi.vcf")
+    n_lines, n_rows = varscan.mpileup2snp(d, path, out, opts)
+    want = vo.mpileup2snp(data, vo.Params(min_var_freq=0.2, min_reads2=2, min_avg_qual=0))
+    assert open(out, "rb").read().decode("latin-1") == want and n_lines == len(lines) and n_rows > 400
