@@ -95,7 +95,7 @@ typedef struct snpgpu_site_counts {
 
 /* Ranks 8, 9, ... of a position with more than SNPGPU_MAX_SYMS distinct symbols (pileup.py:259-266 ranks any number of them and
  * vcf_writer.py:317-331 lists every one as an ALT allele): the record itself keeps the first eight, the rest goes to one of
- * SNPGPU_SPILL_CAP records the context holds.  The same record carries a reference-base field of more than one byte
+ * the records the context holds (SNPGPU_SPILL_CAP to begin with; more after a call that ran out: snpgpu_symbol_spill_read).  The same record carries a reference-base field of more than one byte
  * (pileup.py:223 takes any string; every '.' / ',' then stands for all of its characters, pileup.py:255-258, and the VCF
  * REF column shows the string): ref_len > 1 and ref[] hold it, n may be 0.  And a depth column outside 0 .. 2^32 - 1 (depth64).  A call that produces per-site records starts with an empty spill;
  * snpgpu_symbol_spill_read copies out what the context's calls have put there since (synchronises the context's stream). */
@@ -355,7 +355,11 @@ size_t snpgpu_format_vcf_rows(const snpgpu_site_counts *counts, const uint32_t *
                               const char *const *filter_names, int preserve_ref_case, char failed_snp_gt,
                               const snpgpu_symbol_spill *spill, uint32_t n_spill,
                               char *out, size_t capacity, int32_t *out_bad_row);
+/* *out_n = the records the context's calls have asked for since the last call that started an empty spill; up to `capacity` of
+ * them are copied to `out`.  *out_n > snpgpu_symbol_spill_capacity(ctx): the arena ran out (the records past it say "no room",
+ * nothing is copied) — repeat the call: the context allocates an arena of the size this one asked for at its next call. */
 int  snpgpu_symbol_spill_read(snpgpu_ctx *ctx, snpgpu_symbol_spill *out, uint32_t capacity, uint32_t *out_n);
+uint32_t snpgpu_symbol_spill_capacity(const snpgpu_ctx *ctx);
 
 /* The output files of call_consensus (call_consensus.py:178-192: consensus.fasta through Bio.SeqIO, consensus.vcf through
  * vcf_writer.SingleSampleWriter) for many (sample, flow) pairs at once, on host threads — host code, no device work, no

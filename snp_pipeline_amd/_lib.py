@@ -127,6 +127,7 @@ SIGNATURES = {
     "snpgpu_format_vcf_rows": (C.c_size_t, [_P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_char_p), C.c_int, C.c_char, _P, C.c_uint32, _P,
                                             C.c_size_t, C.POINTER(C.c_int32)]),
     "snpgpu_symbol_spill_read": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "snpgpu_symbol_spill_capacity": (C.c_uint32, [_P]),
     "snpgpu_siteset_line_offsets": (C.c_int, [_P, _P, _P]),
     "snpgpu_packed_row_bytes": (C.c_size_t, [C.c_uint32]),
     "snpgpu_pack_matrix_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_size_t, _P]),

@@ -44,6 +44,7 @@ struct CallArgs {
                                 // returns at once and the 256-byte pass takes every site (see k_call_mode)
     snpgpu_symbol_spill *spill; // k_call_sites, with out_counts: where ranks 8.. of a position with more symbols go (nullable)
     uint32_t *spill_n;          // records taken so far
+    uint32_t spill_cap;         // records the arena holds
 };
 
 struct WaveLds {
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
                     if (lane == 0) slot = atomicAdd(a.spill_n, 1u);
                     slot = __builtin_amdgcn_readfirstlane(slot);
                 }
-                if (slot < SNPGPU_SPILL_CAP) {
+                if (slot < a.spill_cap) {
                     snpgpu_symbol_spill *sp = a.spill + slot;
                     uint32_t r = 0;
                     for (; r < SNPGPU_SPILL_SYMS; ++r) {
@@ -965,6 +966,7 @@ int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleD
     ca.out_counts = d_out_counts;
     ca.spill = d_out_counts ? ctx->d_spill : nullptr;
     ca.spill_n = ctx->d_spill_n;
+    ca.spill_cap = ctx->spill_cap;
     const uint64_t n_work = (uint64_t)n_sites * n;
     const uint64_t blocks = (n_work + CALL_WAVES - 1) / CALL_WAVES;
     const uint64_t max_blocks = (uint64_t)ctx->n_cu * 16;
@@ -1027,6 +1029,7 @@ int snpgpu_enqueue_call_lines(snpgpu_ctx *ctx, const SampleDev *d_sample, const 
     ca.out_counts = d_out_counts;
     ca.spill = d_out_counts ? ctx->d_spill : nullptr;
     ca.spill_n = ctx->d_spill_n;
+    ca.spill_cap = ctx->spill_cap;
     ca.todo = nullptr; ca.todo_n = nullptr; ca.in_todo = nullptr; ca.in_todo_n = nullptr; ca.deep = nullptr;
     const uint64_t blocks = ((uint64_t)n_lines + CALL_WAVES - 1) / CALL_WAVES, max_blocks = (uint64_t)ctx->n_cu * 16;
     k_call_sites<<<(unsigned)(blocks < max_blocks ? blocks : max_blocks), CALL_WAVES * 64, 0, ctx->stream>>>(ca);

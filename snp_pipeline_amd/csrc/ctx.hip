@@ -128,13 +128,21 @@ void snpgpu_ctx_destroy(snpgpu_ctx *ctx) {
 // ---- positions with more than SNPGPU_MAX_SYMS symbols ----------------------------------------------------------------
 }  // extern "C"  (closed for the internal helper; reopened below)
 int snpgpu_spill_begin(snpgpu_ctx *ctx) {
-    if (!ctx->d_spill) {
+    if (!ctx->d_spill || ctx->spill_want > ctx->spill_cap) {
+        if (ctx->d_spill) {                                     // a call ran out of records: a larger arena for the repeat
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->d_spill);
+            ctx->d_spill = nullptr;
+            ctx->spill_cap = 0;
+        }
         void *d = nullptr;
-        const size_t bytes = sizeof(snpgpu_symbol_spill) * (size_t)SNPGPU_SPILL_CAP + 256;
+        const uint32_t cap = ctx->spill_want > SNPGPU_SPILL_CAP ? ctx->spill_want : SNPGPU_SPILL_CAP;
+        const size_t bytes = sizeof(snpgpu_symbol_spill) * (size_t)cap + 256;
         hipError_t e = hipMalloc(&d, bytes);
         if (e != hipSuccess) return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "hipMalloc(%zu) for the symbol spill failed: %s", bytes, hipGetErrorString(e));
         ctx->d_spill = (snpgpu_symbol_spill *)d;
-        ctx->d_spill_n = (uint32_t *)((char *)d + sizeof(snpgpu_symbol_spill) * (size_t)SNPGPU_SPILL_CAP);
+        ctx->d_spill_n = (uint32_t *)((char *)d + sizeof(snpgpu_symbol_spill) * (size_t)cap);
+        ctx->spill_cap = cap;
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_spill_n, 0, 4, ctx->stream));
     return SNPGPU_OK;
@@ -149,15 +157,24 @@ int snpgpu_symbol_spill_read(snpgpu_ctx *ctx, snpgpu_symbol_spill *out, uint32_t
     uint32_t n = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&n, ctx->d_spill_n, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (n > SNPGPU_SPILL_CAP) n = SNPGPU_SPILL_CAP;            // (positions past the last record carry "no room" in their own record)
-    *out_n = n;
-    if (n > capacity) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "%u spill records, room for %u", n, capacity);
-    if (n) {
-        HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_spill, sizeof(snpgpu_symbol_spill) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    *out_n = n;                                                // what the calls asked for, which may be more than the arena held
+    if (n > ctx->spill_cap) {
+        // positions past the last record carry "no room" in their own record: the caller repeats the call, and the arena will
+        // hold what this one asked for (and a quarter more: other files of a batch may differ)
+        const uint64_t want = (uint64_t)n + n / 4 + 64;
+        ctx->spill_want = want > 0xFFFFFEull ? 0xFFFFFEu : (uint32_t)want;
+        if (n > 0xFFFFFEu) return snpgpu_set_error(ctx, SNPGPU_E_UNSUPPORTED, "%u positions of one call need a spill record: more than a record's 24 index bits address", n);
+        return SNPGPU_OK;
+    }
+    const uint32_t k = n < capacity ? n : capacity;
+    if (k) {
+        HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_spill, sizeof(snpgpu_symbol_spill) * (size_t)k, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     return SNPGPU_OK;
 }
+
+uint32_t snpgpu_symbol_spill_capacity(const snpgpu_ctx *ctx) { return ctx ? (ctx->spill_cap ? ctx->spill_cap : SNPGPU_SPILL_CAP) : 0; }
 
 const char *snpgpu_last_error(const snpgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 

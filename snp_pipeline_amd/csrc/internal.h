@@ -27,6 +27,7 @@ struct snpgpu_ctx {
     // positions with more than SNPGPU_MAX_SYMS symbols: [SNPGPU_SPILL_CAP] records + one counter word (allocated on first use)
     snpgpu_symbol_spill *d_spill = nullptr;
     uint32_t *d_spill_n = nullptr;
+    uint32_t spill_cap = 0, spill_want = SNPGPU_SPILL_CAP;     // records the arena holds / should hold at the next call (it grows when a call ran out)
     // optional per-kernel timing (bench): event pairs recorded around selected launches
     bool time_kernels = false;
     struct Timed { int kernel; hipEvent_t a, b; };

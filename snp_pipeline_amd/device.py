@@ -175,6 +175,25 @@ def symbol_count(counts):
     return counts["n_symbols"] & 0xFF
 
 
+class SpillOverflow(RuntimeError):
+    """A call asked for more spill records than the context's arena held; repeating the call finds a larger one."""
+
+
+def _again_on_spill_overflow(method):
+    """Repeat a device call whose positions needed more spill records than the arena had (it grows between the attempts)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapped(self, *args, **kwargs):
+        for _ in range(4):
+            try:
+                return method(self, *args, **kwargs)
+            except SpillOverflow:
+                continue
+        return method(self, *args, **kwargs)
+    return wrapped
+
+
 class ConsensusResult(object):
     __slots__ = ("bases", "filters", "counts", "status", "n_lines", "n_matched", "depth_sum", "line_offsets", "spill")
 
@@ -201,12 +220,17 @@ class Device(object):
 
     def read_symbol_spill(self, counts=None):
         """The spill records of the context's last call that produced per-site records (positions with more than 8 distinct
-        symbols or a reference-base field of several bytes); with `counts`: None unless one of those records points at one."""
+        symbols, a reference-base field of several bytes, a depth outside 32 bits); with `counts`: None unless one of those
+        records points at one.  Raises SpillOverflow when the call asked for more records than the context's arena held: the
+        caller repeats the call (the arena grows at the next one)."""
         if counts is not None and not (counts["n_symbols"] >> 8).any():
             return None
-        out = np.zeros(L.SPILL_CAP, dtype=SPILL_DTYPE)
         n = C.c_uint32()
-        self._check(self.lib.snpgpu_symbol_spill_read(self.ctx, _ptr(out), L.SPILL_CAP, C.byref(n)))
+        self._check(self.lib.snpgpu_symbol_spill_read(self.ctx, None, 0, C.byref(n)))
+        if n.value > int(self.lib.snpgpu_symbol_spill_capacity(self.ctx)):
+            raise SpillOverflow(n.value)
+        out = np.zeros(max(n.value, 1), dtype=SPILL_DTYPE)
+        self._check(self.lib.snpgpu_symbol_spill_read(self.ctx, _ptr(out), n.value, C.byref(n)))
         return out[:n.value]
 
     # ---- plumbing ------------------------------------------------------------------------------
@@ -288,6 +312,7 @@ class Device(object):
         if site is not None:
             raise site
 
+    @_again_on_spill_overflow
     def call_consensus(self, siteset, pileup, params, want_counts=False, want_depth_sum=False, check=True):
         """pileup: bytes-like (host).  Returns ConsensusResult over siteset.keys order.  check=False: do not raise for
         the per-site failures the reference raises on (malformed line at a listed position); the scan-level errors
@@ -346,6 +371,7 @@ class Device(object):
         if err is not None:
             raise err
 
+    @_again_on_spill_overflow
     def call_consensus_files(self, siteset, paths, params, want_counts=False, want_line_offsets=False,
                              want_depth_sum=False, chunk_bytes=0, n_readers=0, n_staging=0, n_slots=0, exclude=None):
         """Streamed ingestion of pileup FILES (snpgpu_call_consensus_files): reader threads -> pinned staging -> copy
@@ -386,6 +412,7 @@ class Device(object):
             results.append(r)
         return results, rcs[:n_files], stats
 
+    @_again_on_spill_overflow
     def call_all_lines(self, siteset, path, params, capacity=0, check=True):
         """call_consensus --vcfAllPos: a record for EVERY line of the pileup file, in file order.
         Returns (line_offsets + 1, line site flags, counts records).  Raises like the reference for malformed lines

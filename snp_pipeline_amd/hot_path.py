@@ -916,7 +916,13 @@ def stage_consensus(job):
         if fl.host_sets[which] is None:
             fl.host_sets[which] = _host_set(job, fl, which)
         hs = fl.host_sets[which]
-        chk, group_spill = _consensus_group(job, fl, g0, part, hs, vcf_again, vcf_later)
+        for attempt in range(5):
+            try:
+                chk, group_spill = _consensus_group(job, fl, g0, part, hs, vcf_again, vcf_later)
+                break
+            except devmod.SpillOverflow:                     # more positions with a spill record than the arena held: it has grown, again
+                if attempt == 4:
+                    raise
         t_g = time.perf_counter()
         _check_group(job, fl, g0, part, hs, chk, vcf_again)
         job.lap("3c   of which: status checks", t_g)

@@ -402,3 +402,51 @@ def test_merge_sites_runs_of_the_reference_driver(tmp_path):
         _run("merge_sites -f -n var.flt.vcf --maxsnps %d -o %s/snplist.txt %s/dirs.txt %s/dirs.txt.filtered" % (run["max_snps"], work, work, work))
         assert (work / "snplist.txt").read_text() == run["snplist"], (run["seed"], run["max_snps"])
         assert (work / "dirs.txt.filtered").read_text().replace(str(work), "$W") == run["filtered"], (run["seed"], run["max_snps"])
+
+
+def test_more_spill_positions_than_the_first_arena_holds(tmp_path):
+    """Round 3 refused a call in which more than 1 024 positions needed a spill record (here: every listed position has a
+    reference-base field of two bytes, 3 000 of them, some with a depth outside 32 bits).  The context's arena now grows and the
+    call is repeated: rows of the per-sample command, of --vcfAllPos and of the batch command against the oracle's writer."""
+    import random
+    rng = random.Random(11)
+    lines, keys = [], []
+    for i in range(3000):
+        pos = 10 + 3 * i
+        n = rng.randint(3, 30)
+        bases = "".join(rng.choice(".,.,AaCcGgTt*") for _ in range(n))
+        quals = "".join(chr(33 + rng.randint(5, 40)) for _ in range(n))
+        depth = "-%d" % n if i % 97 == 0 else "%d" % n
+        lines.append("ctgX\t%d\t%s\t%s\t%s\t%s" % (pos, rng.choice(("AC", "gT", "N,", "ac.")), depth, bases, quals))
+        keys.append((b"ctgX", pos))
+    data = ("\n".join(lines) + "\n").encode()
+    params = po.CallerParams(10, 0.6, 3, 0, 0.0)
+    want, detail = po.call_consensus_sites(data, keys, set(), params)
+    names = po.filter_names(params)
+    rows = []
+    for key in keys:
+        rec, base, mask = detail[key]
+        rows.append(vo.vcf_row(rec, [names[i] for i in range(6) if mask >> i & 1] or None, "."))
+    with open(str(tmp_path / "snplist.txt"), "w") as f:
+        for c, p in keys:
+            f.write("%s\t%d\t1\ts\n" % (c.decode(), p))
+    flags = "--minBaseQual 10 --minConsFreq 0.6 --minConsDpth 3 --vcfRefName ref.fasta --vcfFileName consensus.vcf"
+    dirs = []
+    for name in ("sA", "sB"):
+        sdir = tmp_path / name
+        sdir.mkdir()
+        (sdir / "reads.all.pileup").write_bytes(data)
+        dirs.append(str(sdir))
+
+    def data_rows(path):
+        return [ln for ln in open(path).read().split("\n") if ln and not ln.startswith("#")]
+
+    _run("call_consensus -l %s/snplist.txt -o %s/consensus.fasta %s %s/reads.all.pileup" % (tmp_path, dirs[0], flags, dirs[0]))
+    assert data_rows(dirs[0] + "/consensus.vcf") == rows
+    assert open(dirs[0] + "/consensus.fasta").read() == ">sA\n" + "".join(want.decode()[i:i + 60] + "\n" for i in range(0, len(want), 60))
+    _run("call_consensus -f --vcfAllPos -l %s/snplist.txt -o %s/consensus.fasta %s %s/reads.all.pileup" % (tmp_path, dirs[0], flags, dirs[0]))
+    assert data_rows(dirs[0] + "/consensus.vcf") == rows
+    (tmp_path / "dirs.txt").write_text("\n".join(dirs) + "\n")
+    _run("call_consensus_batch -f -l %s/snplist.txt %s %s/dirs.txt" % (tmp_path, flags, tmp_path))
+    for d in dirs:
+        assert data_rows(d + "/consensus.vcf") == rows

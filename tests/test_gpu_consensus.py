@@ -645,26 +645,40 @@ def test_terminators_across_many_tiles(d, variant, names):
     assert res.n_lines == n_py == len(lines)
 
 
-def test_more_spilled_positions_than_the_context_holds_are_refused_not_lost(d):
-    """1 100 positions with nine symbols in one call: the context keeps 1 024 spill records; the positions past that carry the
-    "no room" mark in their own record and the row writer refuses them by name instead of printing a short ALT list."""
+def test_more_spilled_positions_than_the_first_arena_holds_grow_the_arena(d):
+    """1 100 positions with nine symbols in one call: a fresh context keeps 1 024 spill records.  Round 3 refused the positions past
+    that (they carry the "no room" mark in their own record); now the read of the spill says how many were asked for, the context
+    allocates that many for its next call, and the call is repeated (device.SpillOverflow inside, invisible outside): every
+    position has its record and its full ALT list."""
     from snp_pipeline_amd import _lib as L
+    from snp_pipeline_amd import device as dev
     from snp_pipeline_amd import vcf_writer
     from tests.gpu_util import gpu_consensus
     bases = "ACGTN*RYK" * 2
     lines = ["c\t%d\tA\t18\t%s\t%s" % (p, bases, "I" * 18) for p in range(1, 1101)]
     keys = [(b"c", p) for p in range(1, 1101)]
-    _, res, ss = gpu_consensus(d, ("\n".join(lines) + "\n").encode(), keys, [], po.CallerParams())
+    data = ("\n".join(lines) + "\n").encode()
+    # the bare call on a context of its own: the first attempt runs out and says so, the second finds room
+    d2 = dev.Device(0)
+    try:
+        ss2 = d2.siteset(keys, [L.SITE_IN_SNPLIST] * len(keys))
+        assert d2.lib.snpgpu_symbol_spill_capacity(d2.ctx) == L.SPILL_CAP
+        with pytest.raises(dev.SpillOverflow):
+            dev.Device.call_consensus.__wrapped__(d2, ss2, data, dev.make_params(), want_counts=True)
+        again = dev.Device.call_consensus.__wrapped__(d2, ss2, data, dev.make_params(), want_counts=True)
+        assert len(again.spill) == 1100 and d2.lib.snpgpu_symbol_spill_capacity(d2.ctx) >= 1100
+    finally:
+        d2.close()
+    _, res, ss = gpu_consensus(d, data, keys, [], po.CallerParams())
     codes = res.counts["n_symbols"] >> 8
-    assert (res.counts["n_symbols"] & 0xFF == 9).all() and len(res.spill) == L.SPILL_CAP
-    assert int((codes == 0xFFFFFF).sum()) == 1100 - L.SPILL_CAP and sorted(codes[codes != 0xFFFFFF]) == list(range(1, L.SPILL_CAP + 1))
+    assert (res.counts["n_symbols"] & 0xFF == 9).all() and len(res.spill) == 1100
+    assert sorted(codes) == list(range(1, 1101))
     names = po.filter_names(po.CallerParams())
     order = np.arange(1100, dtype=np.uint32)
-    ok = order[codes != 0xFFFFFF]
-    text = vcf_writer.format_rows(res.counts, ok, ss._names, ss._offs, ss.keys, names, False, ".", spill=res.spill)
-    assert text.count(b"\n") == L.SPILL_CAP and all(ln.split(b"\t")[4].count(b",") == 7 for ln in text.split(b"\n") if ln)   # A is REF: 8 ALTs
-    with pytest.raises(ValueError):
-        vcf_writer.format_rows(res.counts, order, ss._names, ss._offs, ss.keys, names, False, ".", spill=res.spill)
+    text = vcf_writer.format_rows(res.counts, order, ss._names, ss._offs, ss.keys, names, False, ".", spill=res.spill)
+    assert text.count(b"\n") == 1100 and all(ln.split(b"\t")[4].count(b",") == 7 for ln in text.split(b"\n") if ln)   # A is REF: 8 ALTs
+    with pytest.raises(ValueError):                              # (a record that points at a spill record the writer was not given)
+        vcf_writer.format_rows(res.counts, order, ss._names, ss._offs, ss.keys, names, False, ".", spill=res.spill[:500])
 
 
 def test_files_with_one_odd_line_end_as_the_reference_does(d):
