@@ -653,7 +653,9 @@ def _prepare_flows(job):
     fl.per_sample_bytes = max(S1, 1) + max(S2, 1) + 2 * max(S, 1) + 8 * max(S, 1) + 32 + (128 * max(S, 1) if want_vcf else 0) + 64
     fl.group = max(1, min(256, job.group_bytes // fl.per_sample_bytes))
     if n_local >= 32:
-        fl.group = min(fl.group, (n_local + 1) // 2)       # at least two groups: the files of one are written while the next is on the device
+        # at least two groups — four from 64 samples on: the files of one are written while the next is on the device, and what is
+        # left to wait for at the end is the last group's files (1.25 GB of VCF text for 125 samples: a quarter of it instead of half)
+        fl.group = min(fl.group, (n_local + 3) // 4 if n_local >= 64 else (n_local + 1) // 2)
     fl.g_alloc = g_alloc = min(fl.group, max(n_local, 1))
     fl.d_base = torch.empty((g_alloc, max(S, 1)), dtype=torch.uint8, device="cuda")
     fl.d_filt = torch.empty((g_alloc, max(S, 1)), dtype=torch.uint8, device="cuda")
