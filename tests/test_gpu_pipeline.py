@@ -639,3 +639,43 @@ def test_a_rank_that_fails_takes_the_others_with_it_instead_of_leaving_them_in_a
     text = open(log).read()
     assert "IsADirectoryError" in text and "hot_path_batch" in text
     assert "rank 0 stops after stage_consensus: rank 1 failed" in r.stdout, r.stdout[-2500:]
+
+
+def test_the_stages_of_the_job_can_be_driven_one_at_a_time(tmp_path, monkeypatch):
+    """hot_path_batch is five stage functions over one job-state object (round 3: one 680-line function): here the first two are
+    run alone — ingest + site calling, then site union + region filter — and what they leave in the job and on disk is what
+    call_sites / filter_regions / merge_sites x 2 write; then the rest, and the job's files are the separate steps' files."""
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    from snp_pipeline_amd import hot_path
+    work = tmp_path
+    ref_path, dirs, dirs_file, piles = _outbreak_tree(work, n_samples=5)
+    monkeypatch.chdir(work)
+    monkeypatch.setenv("VarscanMpileup2snp_ExtraParams", VARSCAN_EXTRA)
+    filter_extra = "--edge_length 100 --window_size 1000 125 15 --max_snp 3 2 1 --mode all"
+    _separate_steps(work, ref_path, dirs, dirs_file, filter_extra, "")
+    want = _snapshot(work, dirs)
+    args = cli.parse_argument_list(["hot_path_batch", "-f", "--siteCalling", "device", dirs_file, ref_path, "--filterRegionsExtraParams=" + filter_extra,
+                                    "--callConsensusExtraParams=" + CONSENSUS_EXTRA, "--varscanExtraParams=" + VARSCAN_EXTRA])
+    args.verbose = 0
+    job = hot_path._Job(args, hot_path._Comm())
+    job.open_device()
+    try:
+        job.run_stage(hot_path.stage_ingest_and_sites)
+        assert all(s.ok and s.store_index >= 0 and len(s.sites[2]) > 5 for s in job.mine) and len(job.store) == len(dirs)
+        for s in job.mine:
+            assert open(os.path.join(s.dir, "var.flt.vcf"), "rb").read() == want[os.path.join(s.name, "var.flt.vcf")]
+        job.run_stage(hot_path.stage_site_union_and_regions)
+        for fu in job.split_files:
+            fu.result()
+        for name in ("snplist.txt", "snplist_preserved.txt", "sampleDirectories.txt.OrigVCF.filtered", "sampleDirectories.txt.PresVCF.filtered"):
+            assert open(os.path.join(str(work), name), "rb").read() == want[name], name
+        for s in job.mine:
+            for name in ("var.flt_preserved.vcf", "var.flt_removed.vcf"):
+                assert open(os.path.join(s.dir, name), "rb").read() == want[os.path.join(s.name, name)], (s.name, name)
+        assert len(job.list1) >= len(job.list2) > 10 and not job.excluded1.any()
+        for stage in hot_path.STAGES[2:]:
+            job.run_stage(stage)
+        assert job.row_ok.all() and job.flows.S1 == len(job.list1)
+    finally:
+        job.close_device()
+    _compare(_snapshot(work, dirs, remove=False), want)
