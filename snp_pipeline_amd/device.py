@@ -827,7 +827,14 @@ def acquire_device_slot(n_devices, max_per_device=None, lock_dir=None, poll_seco
     if lock_dir:
         os.makedirs(lock_dir, exist_ok=True)       # a directory the caller named (several users of one node may share its slots)
     else:
-        lock_dir = _paths.private_dir()            # (refused when /tmp/snpgpu-<uid> is somebody else's)
+        try:
+            lock_dir = _paths.private_dir()        # (refused when /tmp/snpgpu-<uid> is somebody else's)
+        except _paths.UnsafeDirectory as err:
+            # nowhere to keep slot files that is provably ours: the processes of this user cannot see each other, so each takes a
+            # device by its process id (spread, not capped) and says why
+            import sys
+            sys.stderr.write("snpgpu: no device slots (%s); set SNPGPU_LOCK_DIR to a directory of your own\n" % err)
+            return os.getpid() % n_devices, None
     start = os.getpid() % n_devices
     order = [((start + i) % n_devices, j) for j in range(max_per_device) for i in range(n_devices)]
     while True:
