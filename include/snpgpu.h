@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SNPGPU_ABI_VERSION 3
+#define SNPGPU_ABI_VERSION 4
 
 /* ---- error codes ------------------------------------------------------- */
 #define SNPGPU_OK            0

@@ -760,6 +760,12 @@ def main():
                                   line_ends=variant)
         dump("pileup_runs3.json.gz", {"runs": runs})
         return
+    if sys.argv[1:] == ["--only", "utf8names"]:
+        # contig names that are not plain ASCII (the reference reads the pileup as text: they are just names to it), one with a '~'
+        runs = gen_file_runs(captured, [(31, dict(genome_len=1500, n_sites=50, contigs=("chr\u00e4", "\u67d3\u8272\u4f531", "a~b")), PARAM_SETS[1]),
+                                        (32, dict(genome_len=2200, n_sites=70, mean_depth=14, contigs=("\u00e9coli_K12", "z")), PARAM_SETS[2])])
+        dump("pileup_runs_utf8.json.gz", {"runs": runs})
+        return
     if sys.argv[1:] == ["--only", "distance"]:
         dump("distance_runs.json.gz", {"runs": gen_distance_runs()})
         return

@@ -57,6 +57,13 @@ def consensus_for_sample(dev, pileup_bytes, snp_list, excluded_positions, params
     return consensus_string(snp_slots, res).tobytes().decode("ascii"), ss, res
 
 
+class _ValidUtf8(devmod.PileupFormatError):
+    """The pileup holds bytes >= 0x80 and is valid UTF-8."""
+
+    def __init__(self, message):
+        devmod.PileupFormatError.__init__(self, message, None)
+
+
 def _raise_as_reference(err, pileup_path=None, every_line_is_a_record=False):
     """Re-raise a device-detected malformed pileup as the exception class the reference raises for it, so that the
     error log names the same exception type (utils.handle_sample_exception prints ``exc_type.__name__``).
@@ -72,6 +79,7 @@ def _raise_as_reference(err, pileup_path=None, every_line_is_a_record=False):
         # (Valid multi-byte characters are the one input that is still refused: they would count as single symbols.)
         with open(pileup_path, "rb") as f:
             f.read().decode("utf-8")
+        raise _ValidUtf8(str(err))                   # (call_consensus tries the escaped-names bridge, utf8_names.py, before giving up)
     if exc is None:
         raise err
     raise exc(str(err))
@@ -83,6 +91,7 @@ class _Plan(object):
     def __init__(self, args, all_pileup_file_path, consensus_file_path, exclude_file_path):
         self.args = args
         self.pileup_path = all_pileup_file_path
+        self.read_path = all_pileup_file_path         # what the device reads: the pileup, or its copy with escaped contig names (utf8_names.py)
         self.consensus_path = consensus_file_path
         self.exclude_path = exclude_file_path
         self.sample_name = os.path.basename(os.path.dirname(os.path.abspath(all_pileup_file_path)))
@@ -110,16 +119,16 @@ def _write_outputs(plan, dev, ss, snp_slots, res, file_flags=None):
             params = devmod.make_params(args.minBaseQual, args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
             own = ss if file_flags is ss.flags else devmod.SiteSet.from_arrays(dev, ss.contigs, ss.keys[file_flags != 0], file_flags[file_flags != 0])
             try:
-                line_off, line_flags, counts = dev.call_all_lines(own, plan.pileup_path, params, capacity=res.n_lines, check=bool(args.vcfAllPos))
+                line_off, line_flags, counts = dev.call_all_lines(own, plan.read_path, params, capacity=res.n_lines, check=bool(args.vcfAllPos))
             except devmod.PileupFormatError as err:
-                _raise_as_reference(err, plan.pileup_path, bool(args.vcfAllPos))
+                _raise_as_reference(err, plan.read_path, bool(args.vcfAllPos))
             finally:
                 if own is not ss:
                     own.close()
             if not args.vcfAllPos:
                 keep = np.nonzero(line_flags)[0]                # listed positions only
                 line_off, counts = line_off[keep], counts[keep]
-            vcf_writer.write_all_positions_vcf(plan.vcf_path, plan.sample_name, args, plan.pileup_path, line_off, counts, spill=dev.last_spill)
+            vcf_writer.write_all_positions_vcf(plan.vcf_path, plan.sample_name, args, plan.read_path, line_off, counts, spill=dev.last_spill)
         else:
             vcf_writer.write_consensus_vcf(plan.vcf_path, plan.sample_name, args, ss, res, res.line_offsets, parsed=file_flags != 0)
     consensus = consensus_string(snp_slots, res).tobytes().decode("ascii")
@@ -187,9 +196,35 @@ def call_consensus(args):
     params = devmod.make_params(args.minBaseQual, args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
     dev = devmod.default_device()
     timing.mark("device context")
+    try:
+        _call_one(plan, dev, params, snp_arrays)
+    except _ValidUtf8 as err:
+        # Non-ASCII characters in a valid UTF-8 pileup.  In contig names they are just names to the reference: the device gets a
+        # copy of the file in which every name is escaped to ASCII (order and equality kept), the site lists likewise, and the CHROM
+        # column of consensus.vcf is spelled back.  Anywhere else they stay refused.
+        from . import utf8_names
+        try:
+            plan.read_path = utf8_names.escaped_copy(plan.pileup_path)
+        except utf8_names.Refused as why:
+            raise devmod.PileupFormatError("%s (%s)" % (err, why), None)
+        try:
+            if plan.excluded is not None:
+                plan.excluded = (utf8_names.escape_names(plan.excluded[0]),) + tuple(plan.excluded[1:])
+            _call_one(plan, dev, params, (utf8_names.escape_names(snp_arrays[0]),) + tuple(snp_arrays[1:]))
+            if plan.vcf_path:
+                utf8_names.unescape_vcf_chrom(plan.vcf_path)
+        finally:
+            os.unlink(plan.read_path)
+            plan.read_path = plan.pileup_path
+    timing.mark("outputs written")
+
+
+def _call_one(plan, dev, params, snp_arrays):
+    """The device part of call_consensus for one sample: site set, streamed call, the checks the reference's loop makes, outputs."""
+    args = plan.args
     ss, snp_slots, _ = build_siteset(dev, snp_arrays, plan.excluded)
     timing.mark("site set")
-    results, rcs, _ = dev.call_consensus_files(ss, [all_pileup_file_path], params, want_counts=True, want_line_offsets=True,
+    results, rcs, _ = dev.call_consensus_files(ss, [plan.read_path], params, want_counts=True, want_line_offsets=True,
                                                want_depth_sum=bool(getattr(args, "amdMetricsRefFasta", None)))
     timing.mark("streamed call")
     all_pos = bool(args.vcfAllPos and plan.vcf_path)
@@ -197,14 +232,13 @@ def call_consensus(args):
         # (--vcfAllPos: the Records of ALL lines are checked, in file order, by the all-lines pass — of _write_outputs, or here and now
         # when the scan has already met a line it cannot take: which line ends the run is decided among all of them)
         if all_pos and int(rcs[0]) in (L.E_PILEUP, L.E_UNSUPPORTED):
-            dev.call_all_lines(ss, all_pileup_file_path, params, capacity=results[0].n_lines, check=True)
-        dev.raise_file_status(all_pileup_file_path, int(rcs[0]), results[0], check=not all_pos)
+            dev.call_all_lines(ss, plan.read_path, params, capacity=results[0].n_lines, check=True)
+        dev.raise_file_status(plan.read_path, int(rcs[0]), results[0], check=not all_pos)
         if not all_pos:
-            dev.check_repeated_positions(ss, all_pileup_file_path, params, results[0])
+            dev.check_repeated_positions(ss, plan.read_path, params, results[0])
     except devmod.PileupFormatError as err:
-        _raise_as_reference(err, all_pileup_file_path, bool(args.vcfAllPos))
+        _raise_as_reference(err, plan.read_path, bool(args.vcfAllPos))
     _write_outputs(plan, dev, ss, snp_slots, results[0])
-    timing.mark("outputs written")
 
 
 def call_consensus_batch(args):

@@ -450,3 +450,61 @@ def test_more_spill_positions_than_the_first_arena_holds(tmp_path):
     _run("call_consensus_batch -f -l %s/snplist.txt %s %s/dirs.txt" % (tmp_path, flags, tmp_path))
     for d in dirs:
         assert data_rows(d + "/consensus.vcf") == rows
+
+
+def test_contig_names_that_are_not_ascii(tmp_path, capfd):
+    """A pileup whose contig names are UTF-8 text ("chrä", "染色体1") is just a pileup to the reference, which reads it as text
+    (golden runs through its own driver: pileup_runs_utf8.json.gz).  Round 3 refused it; now the per-sample command hands the
+    device a copy with the names escaped to ASCII (utf8_names.py) and spells the CHROM column of consensus.vcf back.  Still
+    refused, loudly: non-ASCII characters in any other column."""
+    from snp_pipeline_amd.device import PileupFormatError
+    from tests.conftest import load_golden
+    for n, run in enumerate(load_golden("pileup_runs_utf8.json.gz")["runs"]):
+        kw = dict(run["kw"])
+        kw["contigs"] = tuple(kw["contigs"])
+        data, _, _ = fuzz.synth_pileup(run["seed"], **kw)
+        sdir = tmp_path / ("s%d" % n)
+        sdir.mkdir()
+        (sdir / "reads.all.pileup").write_bytes(data)
+        snps = [(c.encode(), p) for c, p in run["snplist"]]
+        excl = [(c.encode(), p) for c, p in run["excluded"]]
+        with open(str(sdir / "snplist.txt"), "w", encoding="utf-8") as f:
+            for c, p in run["snplist"]:
+                f.write("%s\t%d\t1\tx\n" % (c, p))
+        with open(str(sdir / "excl.vcf"), "w", encoding="utf-8") as f:
+            f.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n")
+            for c, p in run["excluded"]:
+                f.write("%s\t%d\t.\tA\tC\t.\tPASS\t.\tGT\t1/1\n" % (c, p))
+        q, c_, D, d_, b = run["params"]
+        flags = "-q %d -c %g -D %d -d %d -b %g --vcfRefName ref.fasta --vcfFileName consensus.vcf" % (q, c_, D, d_, b)
+        more = " -e %s/excl.vcf" % sdir if excl else ""
+        params = po.CallerParams(*run["params"])
+        want, detail = po.call_consensus_sites(data, snps, set(excl), params)
+        assert want.decode() == run["consensus"]
+        names = po.filter_names(params)
+        rows = []
+        for _, line in po.iter_lines(data):
+            f = line.split()
+            key = (f[0], int(f[1]))
+            if key in detail:
+                rec, base, mask = detail[key]
+                rows.append(vo.vcf_row(rec, [names[i] for i in range(6) if mask >> i & 1] or None, "."))
+        for all_pos in ("", " --vcfAllPos"):
+            _run("call_consensus -f -l %s/snplist.txt -o %s/consensus.fasta%s %s%s %s/reads.all.pileup" % (sdir, sdir, more, flags, all_pos, sdir))
+            fa = (sdir / "consensus.fasta").read_text()
+            assert fa == ">s%d\n" % n + "".join(run["consensus"][i:i + 60] + "\n" for i in range(0, len(run["consensus"]), 60)), (n, all_pos)
+            got = [ln for ln in (sdir / "consensus.vcf").read_text(encoding="utf-8").split("\n") if ln and not ln.startswith("#")]
+            if not all_pos:
+                assert got == rows and any(r.startswith("chrä\t") or r.startswith("écoli_K12\t") for r in got), (n, all_pos)
+            else:                                                   # a row for every line of the pileup, names spelled back
+                assert len(got) == len(list(po.iter_lines(data))) and set(r.split("\t")[0] for r in got) == set(kw["contigs"])
+        assert [p for p in os.listdir(str(sdir)) if "snpgpu_names" in p] == []
+    # a non-ASCII character where text and bytes part ways: refused, not guessed
+    sdir = tmp_path / "bad"
+    sdir.mkdir()
+    (sdir / "reads.all.pileup").write_bytes("c\t5\tA\t3\t.ä.\tIII\n".encode("utf-8"))
+    (sdir / "snplist.txt").write_text("c\t5\t1\tx\n")
+    with pytest.raises(PileupFormatError) as ei:
+        _run("call_consensus -l %s/snplist.txt -o %s/consensus.fasta %s/reads.all.pileup" % (sdir, sdir, sdir))
+    assert "outside the contig-name column" in str(ei.value)
+    capfd.readouterr()

@@ -1311,3 +1311,42 @@ def test_fasta_header_words_split_as_text_mode_does(tmp_path):
             else:
                 slow[name] += len("".join(line.split()))
     assert {k: len(v) for k, v in fast} == slow
+
+
+def test_contig_names_escape_to_ascii_in_order_and_back(tmp_path, monkeypatch):
+    """utf8_names.py: the escape the device sees instead of non-ASCII contig names is injective, keeps the bytewise order, leaves
+    every other column alone, works across its read blocks, and refuses what text and bytes would read differently."""
+    import random
+    from snp_pipeline_amd import utf8_names as u
+    rng = random.Random(3)
+    names = list({bytes(rng.choice([0x41, 0x7d, 0x7e, 0x7f, 0x80, 0xc3, 0xa4, 0xff, 0x30, 0x3f]) for _ in range(rng.randint(0, 6))) for _ in range(4000)})
+    esc = [u.escape_name(n) for n in names]
+    assert all(e.isascii() for e in esc) and len(set(esc)) == len(names)
+    assert [u.unescape_name(e) for e in sorted(esc)] == sorted(names)
+    assert u.escape_names(["chrä", "x"]) == ["chr~45~26", "x"]
+    lines = []
+    for i in range(3000):
+        name = ("chrä", "染色体1", "a~b", "plain")[i % 4]
+        lines.append(("%s%s\t%d\tA\t3\t.~.\t~I~" % ("  " if i % 50 == 0 else "", name, i + 1)).encode("utf-8") + (b"\r\n" if i % 7 == 0 else (b"\r" if i % 11 == 0 else b"\n")))
+    data = b"".join(lines)
+    path = tmp_path / "n.pileup"
+    path.write_bytes(data)
+    monkeypatch.setattr(u, "CHUNK", 997)                         # many read blocks, ends in the middle of lines and of CR LF pairs
+    tmp = u.escaped_copy(str(path), directory=str(tmp_path))
+    got = open(tmp, "rb").read()
+    os.unlink(tmp)
+    assert got.isascii() and got.count(b"\n") == data.count(b"\n") and got.count(b"\r") == data.count(b"\r")
+    import re
+    want = re.sub(rb"(?m)^( *)([^\t]+)", lambda m: m.group(1) + u.escape_name(m.group(2)), data.replace(b"\r\n", b"\n").replace(b"\r", b"\n"))
+    assert got.replace(b"\r\n", b"\n").replace(b"\r", b"\n") == want
+    assert b".~.\t~I~" in got                                    # a '~' outside the name column stays as it is
+    for bad, exc in ((("c\t1\tä\t1\t.\tI\n").encode(), u.Refused), (("c x\t1\tA\t1\t.\tI\n").encode(), u.Refused),
+                     (("c\t1\tA\t1\t.\tä\n").encode(), u.Refused), (b"c\xff\t1\tA\t1\t.\tI\n", UnicodeDecodeError)):
+        path.write_bytes(bad)
+        with pytest.raises(exc):
+            u.escaped_copy(str(path), directory=str(tmp_path))
+        assert [n for n in os.listdir(str(tmp_path)) if n.startswith("snpgpu_names_")] == []
+    vcf = tmp_path / "c.vcf"
+    vcf.write_bytes(b"##x\n#CHROM\tPOS\nchr~45~26\t5\t.\tA~\n~00\t6\t.\tC\n")
+    u.unescape_vcf_chrom(str(vcf))
+    assert vcf.read_bytes() == "##x\n#CHROM\tPOS\nchrä\t5\t.\tA~\n~\t6\t.\tC\n".encode("utf-8")

@@ -79,7 +79,9 @@ def test_whole_file_runs(pileup_vectors):
     from tests.conftest import load_golden
     # the second file holds later additions (deep pileups, long contig names, positions around the powers of ten)
     # ... the third one files with other line ends (CR LF, a mix with lone CRs, '\v' / '\f' before the line end)
-    for run in pileup_vectors["runs"] + load_golden("pileup_runs2.json.gz")["runs"] + load_golden("pileup_runs3.json.gz")["runs"]:
+    # ... the fourth one files whose contig names are not plain ASCII (text to the reference, UTF-8 bytes to the restatement)
+    for run in (pileup_vectors["runs"] + load_golden("pileup_runs2.json.gz")["runs"] + load_golden("pileup_runs3.json.gz")["runs"]
+                + load_golden("pileup_runs_utf8.json.gz")["runs"]):
         kw = dict(run["kw"])
         if "contigs" in kw:
             kw["contigs"] = tuple(kw["contigs"])
