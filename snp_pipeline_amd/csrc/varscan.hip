@@ -361,45 +361,43 @@ __device__ __noinline__ void walk_entry_global(const uint8_t *buf, uint64_t nbyt
 #define VS_LIST_CAP 256u          // line starts held in LDS per pass (a tile with more makes extra passes)
 #define VS_CAND_LOCAL 96u         // candidate entries a wave collects in LDS before it takes a place on the list
 
-// 0x80 in every byte of w in 0x0A..0x0D (what a line terminator can be, and VT / FF: sorted out by whoever uses the flag).  Exact
-// for any byte values: the adds run on the low seven bits, so nothing carries from a byte >= 0x8A into its neighbour (a pileup's
-// name or quality column may hold such bytes; the consensus scan refuses them, this pass must not be fooled by them).
-__device__ __forceinline__ uint32_t term4(uint32_t w) {
-    const uint32_t m = w & 0x7F7F7F7Fu;
-    return (m + 0x76767676u) & ~(m + 0x72727272u) & ~w & 0x80808080u;
-}
-// the four flag words of a 16-byte chunk (0x80 per flagged byte) -> 16 bits, byte k of the chunk = bit k
-__device__ __forceinline__ uint32_t bits16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
-    uint32_t r = __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false);
-    r |= __builtin_amdgcn_udot4(f1, 0x08040201u, 0u, false) << 4;
-    r |= __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false) << 8;
-    r |= __builtin_amdgcn_udot4(f3, 0x08040201u, 0u, false) << 12;
-    return r >> 7;
-}
-
-// A1 for one chunk: the 16 bytes of v -> 16 bits of each string (lt: bit 6 set and bit 3 clear, flagged at bit 6 -> shift 6)
-__device__ __forceinline__ uint32_t bits16s(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3, uint32_t shift) {
-    uint32_t r = __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false);
-    r |= __builtin_amdgcn_udot4(f1, 0x08040201u, 0u, false) << 4;
-    r |= __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false) << 8;
-    r |= __builtin_amdgcn_udot4(f3, 0x08040201u, 0u, false) << 12;
-    return r >> shift;
+// A1 for one chunk: the 16 bytes of v -> 16 bits of each string.  The SWAR tests run on 8 bytes at a time (one v_lshl_add_u64 per
+// add), and two dwords' flags are gathered into one register by a second v_dot4 that accumulates with weights 16 times the first's.
+__device__ __forceinline__ uint32_t gather16(uint64_t f_lo, uint64_t f_hi, uint32_t shift) {
+    // f: flag bit `shift` of every byte (7, or 6 for the letters); byte k of the chunk -> bit k
+    uint32_t a = __builtin_amdgcn_udot4((uint32_t)f_lo, 0x08040201u, 0u, false);
+    a = __builtin_amdgcn_udot4((uint32_t)(f_lo >> 32), 0x80402010u, a, false);
+    uint32_t b = __builtin_amdgcn_udot4((uint32_t)f_hi, 0x08040201u, 0u, false);
+    b = __builtin_amdgcn_udot4((uint32_t)(f_hi >> 32), 0x80402010u, b, false);
+    return ((a >> shift) & 0xFFu) | (((b >> shift) & 0xFFu) << 8);
 }
 template <bool kExact>
 __device__ __forceinline__ void classify_chunk(const uint4 v, uint32_t c, uint16_t *nl, uint16_t *cr, uint16_t *tab, uint16_t *let) {
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    uint32_t ft[4], fl[4], fn[4], fc[4];
+    constexpr uint64_t k7F = 0x7F7F7F7F7F7F7F7Full, k80 = 0x8080808080808080ull;
+    const uint64_t q[2] = {(uint64_t)v.x | ((uint64_t)v.y << 32), (uint64_t)v.z | ((uint64_t)v.w << 32)};
+    uint64_t ft[2], fl[2], fn[2], fc[2];
+    auto eq8 = [&](uint64_t w, uint64_t c8) -> uint64_t {      // 0x80 in every byte of w equal to the byte replicated in c8 (exact)
+        const uint64_t x = w ^ c8;
+        return ~(((x & k7F) + k7F) | x) & k80;
+    };
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        ft[k] = eq4(w[k], 0x09090909u);
-        fl[k] = w[k] & ~(w[k] << 3) & 0x40404040u;
-        if (!kExact) { fn[k] = term4(w[k]); fc[k] = 0; }
-        else { fn[k] = eq4(w[k], 0x0A0A0A0Au); fc[k] = eq4(w[k], 0x0D0D0D0Du); }
+    for (int h = 0; h < 2; ++h) {
+        const uint64_t w = q[h];
+        ft[h] = eq8(w, 0x0909090909090909ull);
+        fl[h] = w & ~(w << 3) & 0x4040404040404040ull;           // bit 6 set, bit 3 clear (what crosses a byte in the shift is masked)
+        if (!kExact) {
+            const uint64_t m = w & k7F;                            // the adds run on seven bits: nothing carries between bytes
+            fn[h] = (m + 0x7676767676767676ull) & ~(m + 0x7272727272727272ull) & ~w & k80;
+            fc[h] = 0;
+        } else {
+            fn[h] = eq8(w, 0x0A0A0A0A0A0A0A0Aull);
+            fc[h] = eq8(w, 0x0D0D0D0D0D0D0D0Dull);
+        }
     }
-    nl[c] = (uint16_t)bits16s(fn[0], fn[1], fn[2], fn[3], 7);
-    tab[c] = (uint16_t)bits16s(ft[0], ft[1], ft[2], ft[3], 7);
-    let[c] = (uint16_t)bits16s(fl[0], fl[1], fl[2], fl[3], 6);
-    if (kExact) cr[c] = (uint16_t)bits16s(fc[0], fc[1], fc[2], fc[3], 7);
+    nl[c] = (uint16_t)gather16(fn[0], fn[1], 7);
+    tab[c] = (uint16_t)gather16(ft[0], ft[1], 7);
+    let[c] = (uint16_t)gather16(fl[0], fl[1], 6);
+    if (kExact) cr[c] = (uint16_t)gather16(fc[0], fc[1], 7);
 }
 
 // One wave per workgroup, every wave one contiguous run of tiles of the file.  A tile's slot in LDS holds the bytes
