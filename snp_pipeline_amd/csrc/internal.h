@@ -24,6 +24,7 @@ struct snpgpu_ctx {
     size_t scratch_bytes = 0;
     int n_cu = 256;
     bool scan_lds_attr = false;         // hipFuncSetAttribute is per device: done once per context
+    bool varscan_lds_attr = false;
     // positions with more than SNPGPU_MAX_SYMS symbols: [SNPGPU_SPILL_CAP] records + one counter word (allocated on first use)
     snpgpu_symbol_spill *d_spill = nullptr;
     uint32_t *d_spill_n = nullptr;

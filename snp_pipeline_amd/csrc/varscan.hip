@@ -412,20 +412,24 @@ __device__ __forceinline__ void classify_chunk(const uint4 v, uint32_t c, uint16
 // one for LF; phase B looks at the byte that ends each line, and the first that is not LF switches the wave to the exact form
 // (separate LF and CR strings, starts after LF, or after a CR that no LF follows) for this and all its later tiles.
 template <int kCPL>
-__global__ __launch_bounds__(64) void k_varscan_scan(const uint8_t *__restrict__ abase, uint64_t lo, uint64_t hi, uint32_t tile_bytes, uint64_t n_tiles,
-                                                     snpgpu_varscan_params prm, uint4 *cand, uint32_t cand_cap, uint32_t *ctl, unsigned long long *status,
-                                                     snpgpu_varscan_site *out, uint32_t capacity, uint32_t *wave_lines) {
+__global__ __launch_bounds__(1024) void k_varscan_scan(const uint8_t *__restrict__ abase, uint64_t lo, uint64_t hi, uint32_t tile_bytes, uint64_t n_tiles,
+                                                       snpgpu_varscan_params prm, uint4 *cand, uint32_t cand_cap, uint32_t *ctl, unsigned long long *status,
+                                                       snpgpu_varscan_site *out, uint32_t capacity, uint32_t *wave_lines, uint32_t lds_chunks_per_wave, uint4 share) {
     constexpr uint32_t kChunks = 64u * kCPL;                                            // 16-byte chunks of a slot
     constexpr uint32_t kSlotBytes = kChunks * 16u;
     constexpr uint32_t kW = kSlotBytes / 32u;                                           // words of a bit string over the slot
     constexpr uint32_t kMW = kW / 64u;                                                  // ... per lane in A2
-    extern __shared__ uint4 vs_lds[];
+    extern __shared__ uint4 vs_lds_all[];
+    // the waves of a workgroup are independent (no barrier anywhere): each has its own stretch of the workgroup's LDS
+    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint4 *vs_lds = vs_lds_all + (size_t)wave_in_wg * lds_chunks_per_wave;
+    const uint32_t gwave = blockIdx.x * (blockDim.x >> 6) + wave_in_wg, n_gwaves = gridDim.x * (blockDim.x >> 6);
     uint4 *slot0 = vs_lds, *slot1 = vs_lds + kChunks;
     uint32_t *nlbits = (uint32_t *)(vs_lds + 2 * kChunks);                              // terminators (exact form: LF)
     uint32_t *crbits = nlbits + kW + 4, *tabbits = crbits + kW + 4, *letbits = tabbits + kW + 4, *pre = letbits + kW + 4;   // (+4: the window reads run two words over)
     uint4 *cand_local = (uint4 *)(pre + kW + 4);
     uint16_t *lstart = (uint16_t *)(cand_local + VS_CAND_LOCAL);                        // VS_LIST_CAP + 2 entries
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint8_t *fbuf = abase + lo;                                                   // file byte 0
     const uint64_t nbytes = hi - lo;
     uint32_t n_local = 0, lines_seen = 0;
@@ -445,8 +449,17 @@ __global__ __launch_bounds__(64) void k_varscan_scan(const uint8_t *__restrict__
         n_local = 0;
     };
     // my run of tiles
-    const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
-    const uint64_t t_first = (uint64_t)blockIdx.x * per, t_end = t_first + per < n_tiles ? t_first + per : n_tiles;
+    // ... in proportion to its share: wave w of a workgroup sits on SIMD w % 4 and is the (w / 4)-th oldest there; the SIMD issues
+    // oldest first, so with equal shares the oldest wave finishes early and the youngest runs on alone (share.x: oldest)
+    uint64_t t_first, t_end;
+    {
+        const uint32_t wpb = blockDim.x >> 6, sh[4] = {share.x, share.y, share.z, share.w};
+        uint64_t blk = 0, before = 0;
+        for (uint32_t w = 0; w < wpb; ++w) { const uint32_t x = sh[(w >> 2) & 3u]; blk += x; before += w < wave_in_wg ? x : 0u; }
+        const uint64_t total = blk * gridDim.x, c0 = (uint64_t)blockIdx.x * blk + before, c1 = c0 + sh[(wave_in_wg >> 2) & 3u];
+        t_first = (uint64_t)((unsigned __int128)n_tiles * c0 / total);
+        t_end = (uint64_t)((unsigned __int128)n_tiles * c1 / total);
+    }
     auto interior = [&](uint64_t tt) { const uint64_t x0 = tt * tile_bytes; return x0 >= lo + 16 && x0 - 16 + kSlotBytes <= hi; };
     // request tile tt into `slot`; returns whether it travels by DMA (else it has been staged synchronously)
     auto request = [&](uint64_t tt, uint4 *slot) -> bool {
@@ -701,7 +714,7 @@ __global__ __launch_bounds__(64) void k_varscan_scan(const uint8_t *__restrict__
     }
     __builtin_amdgcn_wave_barrier();
     flush();
-    if (lane == 0) wave_lines[blockIdx.x] = lines_seen;
+    if (lane == 0) wave_lines[gwave] = lines_seen;
 }
 
 // One lane per candidate line: the 64 lines of a wave are copied into LDS back to back (16-byte chunks; a wave prefix sum of
@@ -823,22 +836,36 @@ int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbyte
     const uint64_t n_tiles = (hi + tile_bytes - 1) / tile_bytes;
     const uint32_t slot_bytes = cpl * 1024u, kw = slot_bytes / 32u;
     const uint32_t lds = 2u * slot_bytes + 5u * (kw + 4u) * 4u + VS_CAND_LOCAL * 16u + (VS_LIST_CAP + 2u) * 2u + 12u;
-    uint32_t waves_per_cu = 160u * 1024u / lds;
+    const uint32_t lds_wave = (lds + 15u) / 16u * 16u;                                 // a wave's stretch of the workgroup's LDS
+    uint32_t waves_per_cu = 160u * 1024u / lds_wave;
     if (waves_per_cu > 16u) waves_per_cu = 16u;                                        // (its registers allow 4 per SIMD)
-    // Eight workgroups for every place a CU has: the dispatcher hands out the next one when a wave ends, which evens out what a
-    // grid of exactly the resident size leaves to chance — how many waves share a SIMD, the oldest of them taking most issue slots
-    // (tools/vs_sweep.sh: 250 us for 432 MB with 12 waves per CU and one workgroup each, 174 us with eight each; 30x).
-    uint64_t grid = (uint64_t)ctx->n_cu * waves_per_cu * 8u;
+    // Eight workgroups (of one wave) for every place a CU has: the dispatcher hands out the next one when a wave ends, which evens
+    // out what a grid of exactly the resident size leaves to chance — how many waves share a SIMD, the oldest of them taking most
+    // issue slots (tools/vs_sweep.sh: 250 us for 432 MB with 12 waves per CU and one workgroup each, 174 us with eight each; 30x).
+    // One workgroup per CU, a multiple of four waves (the same number on every SIMD; 13 waves: 240 us where 12 take 170), every
+    // wave one contiguous run of tiles weighted by its age on its SIMD.  (Round 4's first form — one-wave workgroups, eight per
+    // resident place, balanced by the dispatcher — took 182 us in the same session, each short-lived wave paying its prologue.)
+    uint32_t wg_waves = waves_per_cu >= 4u ? waves_per_cu / 4u * 4u : 1u;
+    uint64_t grid = (uint64_t)ctx->n_cu * (wg_waves == 1u ? waves_per_cu : wg_waves);
     if (grid > n_tiles / 4u) grid = n_tiles / 4u ? n_tiles / 4u : 1u;                   // (at least four tiles per wave)
+    uint32_t share[4] = {120, 100, 82, 70};                                             // tools/vs_share_sweep.sh: 181 -> 165 us at 30x, 513 -> 480 at 100x, 110 -> 100 at 8x
 #ifdef SNPGPU_TUNING                                            // development builds only (tools/)
     if (const char *e = getenv("SNPGPU_VS_WAVES")) if (atoi(e) > 0) grid = (uint64_t)ctx->n_cu * (uint32_t)atoi(e);
     if (const char *e = getenv("SNPGPU_VS_GRID_MUL")) if (atoi(e) > 0) grid *= (uint32_t)atoi(e);
+    if (const char *e = getenv("SNPGPU_VS_WG_WAVES")) if (atoi(e) > 0 && atoi(e) <= 16 && (uint32_t)atoi(e) * lds_wave <= 160u * 1024u) wg_waves = (uint32_t)atoi(e);
+    if (const char *e = getenv("SNPGPU_VS_SHARE")) { int v[4]; if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4) for (int k = 0; k < 4; ++k) share[k] = v[k] > 0 ? (uint32_t)v[k] : 1u; }
 #endif
-    if (grid > VARSCAN_MAX_WAVES) grid = VARSCAN_MAX_WAVES;
-    if (grid > n_tiles) grid = n_tiles;
+    grid = (grid + wg_waves - 1) / wg_waves;                                            // (counted in waves so far; the launch counts workgroups)
+    if (grid * wg_waves > VARSCAN_MAX_WAVES) grid = VARSCAN_MAX_WAVES / wg_waves;
+    if (grid * wg_waves > n_tiles) grid = (n_tiles + wg_waves - 1) / wg_waves;
+    if (!ctx->varscan_lds_attr) {                                                       // (more than 64 KiB of dynamic LDS needs the permission, per device)
+        for (auto f : {(const void *)k_varscan_scan<4>, (const void *)k_varscan_scan<6>, (const void *)k_varscan_scan<8>})
+            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        ctx->varscan_lds_attr = true;
+    }
     hipEvent_t ta = snpgpu_time_begin(ctx);
-#define VS_SCAN(C) k_varscan_scan<C><<<(unsigned)grid, 64, lds, ctx->stream>>>(abase, lo, hi, tile_bytes, n_tiles, *prm, d_cand, cand_cap, d_ctl,        \
-                                                                            (unsigned long long *)d_status, d_sites, capacity, d_wave_lines)
+#define VS_SCAN(C) k_varscan_scan<C><<<(unsigned)grid, 64u * wg_waves, lds_wave * wg_waves, ctx->stream>>>(abase, lo, hi, tile_bytes, n_tiles, *prm, d_cand, cand_cap, \
+                                                                            d_ctl, (unsigned long long *)d_status, d_sites, capacity, d_wave_lines, lds_wave / 16u, make_uint4(share[0], share[1], share[2], share[3]))
     if (halo_class == 0) VS_SCAN(4); else if (halo_class == 1) VS_SCAN(6); else VS_SCAN(8);
 #undef VS_SCAN
     // walk: LDS for 64 candidate lines — the deeper lines of the file — 2 .. 60 KiB
@@ -849,7 +876,7 @@ int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbyte
     k_varscan_walk<<<walk_grid, 64, walk_lds, ctx->stream>>>(d_buf, nbytes, *prm, d_sites, capacity, d_ctl, (unsigned long long *)d_status, walk_bytes, d_cand,
                                                               d_ctl + 1, cand_cap, d_long, d_ctl + 2);
     k_varscan_walk_long<<<ctx->n_cu, 64, 0, ctx->stream>>>(d_buf, nbytes, *prm, d_sites, capacity, d_ctl, (unsigned long long *)d_status, d_cand, d_long,
-                                                           d_wave_lines, (uint32_t)grid);
+                                                           d_wave_lines, (uint32_t)(grid * wg_waves));
     snpgpu_time_end(ctx, SNPGPU_K_VARSCAN, ta);
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;
