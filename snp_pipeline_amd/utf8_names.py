@@ -21,7 +21,7 @@ import numpy as np
 
 _WS = np.array([9, 10, 11, 12, 13, 32, 28, 29, 30, 31], dtype=np.uint8)       # what str.split() removes from ASCII text
 _UNICODE_SPACE = re.compile("[\x85\xa0  -     　]")
-CHUNK = 64 << 20
+CHUNK = 16 << 20           # bytes per read block (its index arrays take ~16 x that for a moment)
 
 
 class Refused(ValueError):
