@@ -843,7 +843,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     backend = None
-    if world > 1:
+    # (a second functional hook: SNPGPU_DIST_AT_WORLD_1=1 makes a group of one rank and still runs every collective of the
+    # N > 1 step — the RCCL calls on device tensors — on a box with one GPU)
+    multi = world > 1 or sharding.group_of_one_exchanges()
+    if multi:
         backend = "gloo" if one_gpu else "nccl"
         if one_gpu:
             dist.init_process_group("gloo")
@@ -956,7 +959,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -974,7 +977,7 @@ def main():
     # them), and the slowest rank per phase
     phase_ms = [sum(ev[k].elapsed_time(ev[k + 1]) for ev in phase_events) / max(len(phase_events), 1) for k in range(len(PHASES))]
     phase_max = list(phase_ms)
-    if world > 1:
+    if multi:
         pt = torch.tensor(phase_ms, dtype=torch.float64, device="cpu" if one_gpu else "cuda")
         dist.all_reduce(pt, op=dist.ReduceOp.MAX)
         phase_max = [float(x) for x in pt.tolist()]
@@ -982,7 +985,7 @@ def main():
     call_ms, call_n = d.kernel_time_ms(1)
     dist_ms, dist_n = d.kernel_time_ms(2)
     d.kernel_timing(False)
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -1037,11 +1040,11 @@ def main():
                    "samples_total": n_total, "samples_this_rank": B, "genome_bp": G, "mean_depth": args.depth, "snp_sites": S,
                    "pileup_bytes_this_rank": pile_bytes, "caller": "q0 c0.6 D3 d0 b0",
                    "parallelism": "samples sharded over %d rank(s)%s"
-                                  % (world, (", backend %s, world size %d" % (backend, dist.get_world_size())) if world > 1 else "")},
-        "comm": {"backend": (dist.get_backend() if world > 1 else None), "world_size": (dist.get_world_size() if world > 1 else 1),
+                                  % (world, (", backend %s, world size %d" % (backend, dist.get_world_size())) if multi else "")},
+        "comm": {"backend": (dist.get_backend() if multi else None), "world_size": (dist.get_world_size() if multi else 1),
                  "launcher": "bench.py started its own ranks (torch.distributed.run, 127.0.0.1)" if os.environ.get("SNPGPU_BENCH_LAUNCHER") == "self"
-                 else ("torch.distributed.run around bench.py" if world > 1 else "none (one process)"),
-                 "collectives_per_step": "C1 variable-length all-gather of site records, C2 all-gather of packed rows, one all-to-all of distance tiles" if world > 1 else "none"},
+                 else ("torch.distributed.run around bench.py" if multi else "none (one process)"),
+                 "collectives_per_step": "C1 variable-length all-gather of site records, C2 all-gather of packed rows, one all-to-all of distance tiles" if multi else "none"},
         "genome_bp_per_sec": n_total * G / (elapsed / args.steps),
         "pileup_gb_per_sec": (pile_bytes * n_total / max(B, 1)) / (elapsed / args.steps) / 1e9,
         "roofline": {"kernel": "k_scan_wave", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1081,7 +1084,7 @@ def main():
 
         def dstep():
             d.distance_packed_dev(pk.data_ptr(), b2.n_padded, s2, dm.data_ptr(), rank, world)
-            return b2.exchange(dm, rank) if world > 1 else dm
+            return b2.exchange(dm, rank) if multi else dm
 
         dstep()                                                  # warm-up
         barrier()
@@ -1094,20 +1097,20 @@ def main():
         el2 = (time.perf_counter() - t1) / args.dist_reps
         k_ms, k_n = d.kernel_time_ms(2)
         d.kernel_timing(False)
-        if world > 1:
+        if multi:
             tt = torch.tensor([el2], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el2 = float(tt.item())
         # what the rows this rank owns add up to, by row and by column (summed over ranks: the same numbers whatever the world
         # size — the strong-scaling test compares them with the one-rank run)
         lo2, hi2 = b2.band_rows(rank)
-        mine2 = band2[lo2:hi2, :n2] if world == 1 else band2[:hi2 - lo2, :n2]
+        mine2 = band2[:hi2 - lo2, :n2] if multi else band2[lo2:hi2, :n2]
         w_row = torch.arange(lo2, hi2, dtype=torch.int64, device="cuda") * 1000003 + 17
         w_col = torch.arange(n2, dtype=torch.int64, device="cuda") * 10007 + 3
         m64 = mine2.to(torch.int64)
         chk = torch.stack([m64.sum(), (m64.sum(dim=1) * w_row).sum(), (m64.sum(dim=0) * w_col).sum()])
         del m64
-        if world > 1:
+        if multi:
             chk_t = chk.cpu() if one_gpu else chk
             dist.all_reduce(chk_t, op=dist.ReduceOp.SUM)
             chk = chk_t
@@ -1121,7 +1124,7 @@ def main():
             "metric": "pairwise_snp_distances_per_sec", "value": pairs / el2, "unit": "pairs/s",
             "site_compares_per_sec": pairs * s2 / el2, "seconds": el2,
             "config": {"workload": "BASELINE configs[4] shape: %d samples x %d sites, random ACGT- matrix; tiles dealt to %d rank(s)%s"
-                                   % (n2, s2, world, ", row-band exchange included" if world > 1 else "")},
+                                   % (n2, s2, world, ", row-band exchange included" if multi else "")},
             "kernel_ms": k_ms / max(k_n, 1), "band_checksum": band_checksum,
             "valu_frac_of_peak": (pairs * s2 / 32 * 4 / el2) / valu_peak,
         }
@@ -1212,7 +1215,7 @@ def main():
         out["north_star"] = ns
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -199,24 +199,30 @@ def call_consensus(args):
     try:
         _call_one(plan, dev, params, snp_arrays)
     except _ValidUtf8 as err:
-        # Non-ASCII characters in a valid UTF-8 pileup.  In contig names they are just names to the reference: the device gets a
-        # copy of the file in which every name is escaped to ASCII (order and equality kept), the site lists likewise, and the CHROM
-        # column of consensus.vcf is spelled back.  Anywhere else they stay refused.
-        from . import utf8_names
-        try:
-            plan.read_path = utf8_names.escaped_copy(plan.pileup_path)
-        except utf8_names.Refused as why:
-            raise devmod.PileupFormatError("%s (%s)" % (err, why), None)
-        try:
-            if plan.excluded is not None:
-                plan.excluded = (utf8_names.escape_names(plan.excluded[0]),) + tuple(plan.excluded[1:])
-            _call_one(plan, dev, params, (utf8_names.escape_names(snp_arrays[0]),) + tuple(snp_arrays[1:]))
-            if plan.vcf_path:
-                utf8_names.unescape_vcf_chrom(plan.vcf_path)
-        finally:
-            os.unlink(plan.read_path)
-            plan.read_path = plan.pileup_path
+        _call_one_with_escaped_names(plan, dev, params, snp_arrays, err)
     timing.mark("outputs written")
+
+
+def _call_one_with_escaped_names(plan, dev, params, snp_arrays, err):
+    """Non-ASCII characters in a valid UTF-8 pileup.  In contig names they are just names to the reference: the device gets a copy
+    of the file in which every name is escaped to ASCII (order and equality kept), the site lists likewise, and the CHROM column of
+    consensus.vcf is spelled back.  Anywhere else they stay refused (utf8_names.py); a file that is not valid UTF-8 ends with
+    UnicodeDecodeError, as the reference's text-mode read does."""
+    from . import utf8_names
+    try:
+        plan.read_path = utf8_names.escaped_copy(plan.pileup_path)
+    except utf8_names.Refused as why:
+        raise devmod.PileupFormatError("%s (%s)" % (err, why), None)
+    kept = plan.excluded
+    try:
+        if plan.excluded is not None:
+            plan.excluded = (utf8_names.escape_names(plan.excluded[0]),) + tuple(plan.excluded[1:])
+        _call_one(plan, dev, params, (utf8_names.escape_names(snp_arrays[0]),) + tuple(snp_arrays[1:]))
+        if plan.vcf_path:
+            utf8_names.unescape_vcf_chrom(plan.vcf_path)
+    finally:
+        os.unlink(plan.read_path)
+        plan.read_path, plan.excluded = plan.pileup_path, kept
 
 
 def _call_one(plan, dev, params, snp_arrays):
@@ -353,8 +359,17 @@ def call_consensus_batch(args):
                         else:
                             in_background.append((plan, res, flags))
                     except Exception as err:  # noqa: B902  (reported per sample below)
-                        with lock:
-                            errors.append((plan, err))
+                        if getattr(err, "scan_code", 0) == 3:
+                            # bytes >= 0x80: contig names that are not plain ASCII go through the escaped copy, alone (utf8_names.py)
+                            try:
+                                with lock:
+                                    _call_one_with_escaped_names(plan, dev, params, snp_arrays, err)
+                                err = None
+                            except Exception as err2:                # noqa: B902
+                                err = err2
+                        if err is not None:
+                            with lock:
+                                errors.append((plan, err))
                     n_done += 1
                 if in_background:
                     writer = threading.Thread(target=write_part, args=(in_background,))

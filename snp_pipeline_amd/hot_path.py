@@ -102,7 +102,7 @@ class _Comm(object):
         self.owns_group = False
         if self.one_gpu:
             self.local_rank = 0
-        if self.world > 1:
+        if self.world > 1 or os.environ.get("SNPGPU_DIST_AT_WORLD_1") == "1":      # (the second: sharding.group_of_one_exchanges, tests)
             import torch
             import torch.distributed as dist
             torch.cuda.set_device(self.local_rank)
@@ -510,7 +510,7 @@ def stage_site_union_and_regions(job):
             lut = np.asarray([cid[c] for c in names] + [0], dtype=np.int64)
             keys_local.append((lut[cidx.astype(np.int64)] << 32) | pos)
     keys_local = np.concatenate(keys_local) if keys_local else np.zeros(0, np.int64)
-    if job.world > 1:
+    if comm.dist:
         dv = "cpu" if comm.one_gpu else "cuda"
         all_keys, _ = sharding.all_gather_varlen(torch.from_numpy(keys_local).to(dv))
         all_cnt, _ = sharding.all_gather_varlen(torch.from_numpy(job.rec_count_local).to(dv))
@@ -1016,7 +1016,7 @@ def stage_matrices_and_distances(job):
         dmat = torch.zeros((max(bands.n_padded, 1), max(bands.n_padded, 1)), dtype=torch.int32, device="cuda")
         if n and Sx:
             dev.distance_packed_dev(packed_sorted.data_ptr(), bands.n_padded, Sx, dmat.data_ptr(), rank, world)
-        if world > 1 and n:
+        if comm.dist and n:
             band = bands.exchange(dmat, rank)                # the complete rows of this rank's band
             blo, bhi = bands.band_rows(rank)
             pieces = comm.gather_objects(band[:bhi - blo, :n].cpu().numpy())

@@ -11,10 +11,26 @@ complete rows of its contiguous band of tile rows, and every computed tile trave
 (and its transpose once to the owner of its column) in one all-to-all — N*N*4/world bytes per rank over seven parallel xGMI
 links, where summing the partial matrices with an all-reduce would move the whole N x N through every rank.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 DIST_TILE = 128          # csrc/distance.hip
+
+
+def group_of_one_exchanges():
+    """SNPGPU_DIST_AT_WORLD_1=1 (functional tests on a one-GPU box): a process group of ONE rank still makes every collective
+    call of the N > 1 path, so that the RCCL entry points themselves execute — on device tensors, no host staging — where only
+    one GPU is there to run them.  Not a measurement mode."""
+    return os.environ.get("SNPGPU_DIST_AT_WORLD_1") == "1"
+
+
+def _alone():
+    """Nothing to exchange: no process group, or a group of one (unless the test hook above asks for the calls anyway)."""
+    if not dist.is_initialized():
+        return True
+    return dist.get_world_size() == 1 and not group_of_one_exchanges()
 
 
 def shard_bounds(n_items, rank, world):
@@ -31,7 +47,7 @@ def _via_host(t):
 
 def all_gather_varlen(t):
     """All-gather of 1-D tensors whose lengths differ per rank.  Returns (concatenation in rank order, lengths)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _alone():
         return t, [int(t.numel())]
     if _via_host(t):
         out, counts = all_gather_varlen(t.cpu())
@@ -54,7 +70,7 @@ def all_gather_varlen(t):
 def all_gather_rows(rows, n_total):
     """rows: this rank's (n_local, row_bytes) uint8 block of the packed matrix, blocks as in shard_bounds.
     Returns the (n_total, row_bytes) matrix on every rank."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _alone():
         return rows
     if _via_host(rows):
         return all_gather_rows(rows.cpu(), n_total).to(rows.device)
@@ -71,7 +87,7 @@ def all_gather_rows(rows, n_total):
 def all_gather_rows_into(rows, n_total, out):
     """As all_gather_rows, but straight into the first rows of `out` (at least max(n_total, world * ceil(n_total / world))
     rows; the distance kernel wants the matrix padded to whole 128-row tiles, the padding rows stay zero)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _alone():
         out[:rows.shape[0]].copy_(rows)
         return out
     world = dist.get_world_size()
@@ -102,7 +118,7 @@ def tiles_of_rank(n, rank, world):
 
 def sum_partial_distances(partial):
     """Every rank filled only its own tiles (and their mirror images) of an n x n int32 matrix of zeros."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if not _alone():
         dist.all_reduce(partial, op=dist.ReduceOp.SUM)
     return partial
 
@@ -160,7 +176,7 @@ class RowBands(object):
             send = p4[rows, :, cols, :].contiguous()                      # (k, 128, 128)
         else:
             send = torch.zeros((0, T, T), dtype=partial.dtype, device=dev)
-        if world == 1 or not dist.is_initialized():
+        if _alone():
             recv = send
         else:
             recv = torch.empty((sum(out_splits), T, T), dtype=partial.dtype, device=dev)

@@ -499,6 +499,25 @@ def test_contig_names_that_are_not_ascii(tmp_path, capfd):
             else:                                                   # a row for every line of the pileup, names spelled back
                 assert len(got) == len(list(po.iter_lines(data))) and set(r.split("\t")[0] for r in got) == set(kw["contigs"])
         assert [p for p in os.listdir(str(sdir)) if "snpgpu_names" in p] == []
+        # the batch form: this sample beside a plain-ASCII one, same snplist; the one with the names takes the bridge alone
+        one = {}
+        for all_pos in ("", " --vcfAllPos"):
+            _run("call_consensus -f -l %s/snplist.txt -o %s/consensus.fasta%s %s%s %s/reads.all.pileup" % (sdir, sdir, more, flags, all_pos, sdir))
+            one[all_pos] = ((sdir / "consensus.fasta").read_bytes(), (sdir / "consensus.vcf").read_bytes())
+        plain = tmp_path / ("p%d" % n)
+        plain.mkdir()
+        pdata, _, _ = fuzz.synth_pileup(run["seed"] + 1, **dict(kw, contigs=("plainA", "plainB")))
+        (plain / "reads.all.pileup").write_bytes(pdata)
+        (plain / "excl.vcf").write_bytes((sdir / "excl.vcf").read_bytes())
+        pwant, _ = po.call_consensus_sites(pdata, snps, set(excl), params)
+        (tmp_path / "dirs.txt").write_text("%s\n%s\n" % (plain, sdir))
+        for all_pos in ("", " --vcfAllPos"):
+            os.unlink(str(sdir / "consensus.fasta"))
+            _run("call_consensus_batch -f -l %s/snplist.txt%s %s%s %s/dirs.txt" % (sdir, " -e excl.vcf" if excl else "", flags, all_pos, tmp_path))
+            assert ((sdir / "consensus.fasta").read_bytes(), (sdir / "consensus.vcf").read_bytes()) == one[all_pos], (n, all_pos)
+            assert (plain / "consensus.fasta").read_text() == ">p%d\n" % n + "".join(
+                pwant.decode()[i:i + 60] + "\n" for i in range(0, len(pwant), 60))
+        assert [p for p in os.listdir(str(sdir)) if "snpgpu_names" in p] == []
     # a non-ASCII character where text and bytes part ways: refused, not guessed
     sdir = tmp_path / "bad"
     sdir.mkdir()

@@ -25,11 +25,14 @@ def _free_port():
     return p
 
 
-def _run_bench(world, dump, extra, launcher=False):
+def _run_bench(world, dump, extra, launcher=False, rccl_group_of_one=False):
     args = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--scaling", "strong", "--skip-aux", "--e2e-files", "0", "--site-files", "0",
             "--cpu-samples", "0", "--pipeline-files", "0", "--shape-samples", "0", "--dump", dump] + extra
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(SNPGPU_BENCH_TEST_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    if rccl_group_of_one:                                               # one rank, one GPU, backend nccl, every collective of the step made
+        del env["SNPGPU_BENCH_TEST_ONE_GPU"]
+        env.update(SNPGPU_DIST_AT_WORLD_1="1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     if world == 1 or not launcher:
         cmd = [sys.executable] + args                                   # plain `python bench.py --gpus N`: bench.py starts its own ranks
     else:
@@ -90,3 +93,24 @@ def test_strong_scaling_of_the_distance_step_at_configs4_shape(tmp_path):
     for run in (one, two):
         ph = run["phases_ms_per_step"]
         assert set(ph["rank0"]) == set(ph["max_over_ranks"]) and all(v >= 0 for v in ph["max_over_ranks"].values())
+
+
+def test_the_step_in_an_rccl_group_of_one(tmp_path):
+    """RCCL needs a GPU per rank and the test box has one: so the N > 1 step runs over gloo above, and RCCL runs here in a group of
+    ONE rank that still makes every collective call of the step on device tensors (SNPGPU_DIST_AT_WORLD_1: all_gather_into_tensor
+    of counts, padded keys and packed rows — the last straight into a slice of the padded matrix —, all_to_all_single with split
+    lists, all_reduce, barrier).  Same answers as the plain one-process run, array for array."""
+    n_total = 300
+    extra = ["--samples", str(n_total), "--genome", "40000", "--sites", "400", "--vcf-records", "60", "--dist-samples", "700",
+             "--dist-sites", "3000", "--dist-reps", "1"]
+    one = _run_bench(1, str(tmp_path / "one"), extra)
+    grp = _run_bench(1, str(tmp_path / "grp"), extra, rccl_group_of_one=True)
+    assert grp["comm"]["backend"] == "nccl" and grp["comm"]["world_size"] == 1 and grp["n_gpus"] == 1
+    assert "all-to-all" in grp["comm"]["collectives_per_step"]
+    assert grp["site_union"] == one["site_union"]
+    assert grp["secondary"]["band_checksum"] == one["secondary"]["band_checksum"] and "row-band exchange included" in grp["secondary"]["config"]["workload"]
+    ref = np.load(str(tmp_path / "one.rank0.npz"))
+    got = np.load(str(tmp_path / "grp.rank0.npz"))
+    assert sorted(ref.files) == sorted(got.files)
+    for k in ref.files:
+        assert np.array_equal(got[k], ref[k]), k

@@ -257,6 +257,47 @@ def test_hot_path_batch_sharded_over_ranks_writes_the_same_files(tmp_path, monke
     _compare(_snapshot(work, dirs, remove=False), want)
 
 
+def test_hot_path_batch_in_an_rccl_group_of_one_writes_the_same_files(tmp_path, monkeypatch):
+    """The box of the GPU tests has one GPU, and RCCL wants one GPU per rank — so the N > 1 job runs here over gloo (above).  What
+    CAN run here is RCCL itself: a process group of one rank with SNPGPU_DIST_AT_WORLD_1=1 makes every collective call of the job
+    (all_gather_object of names and errors, the variable-length all-gather of site keys, the all-gather of packed rows into the
+    padded matrix, the all-to-all of distance tiles with its split lists, barriers) on device tensors through backend nccl."""
+    import socket
+    import subprocess
+    import sys
+    work = tmp_path
+    ref_path, dirs, dirs_file, piles = _outbreak_tree(work, n_samples=7)
+    filter_extra = "--edge_length 100 --window_size 1000 125 15 --max_snp 3 2 1 --mode all"
+    line = ("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s --varscanExtraParams=%s"
+            % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), CONSENSUS_EXTRA.replace(" ", "\x00"), VARSCAN_EXTRA.replace(" ", "\x00")))
+    monkeypatch.chdir(work)
+    _run(line)
+    want = _snapshot(work, dirs)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "SNPGPU_PIPELINE_ONE_GPU"}
+    env.update(SNPGPU_DIST_AT_WORLD_1="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               TORCH_DISTRIBUTED_DEBUG="DETAIL", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    probe = ("import torch.distributed as dist, sys\n"
+             "from snp_pipeline_amd import cfsan_snp_pipeline as cli, hot_path\n"
+             "seen = []\n"
+             "init = dist.init_process_group\n"
+             "def spy(backend=None, *a, **k):\n"
+             "    seen.append(backend)\n"
+             "    return init(backend, *a, **k)\n"
+             "dist.init_process_group = spy\n"
+             "cli.run_command_from_args(cli.parse_argument_list(sys.argv[1:]))\n"
+             "assert seen == ['nccl'], seen\n"
+             "print('backend', seen[0])\n")
+    cmd = [sys.executable, "-c", probe] + [w.replace("\x00", " ") for w in line.split()] + ["-v", "0"]
+    r = subprocess.run(cmd, cwd=str(work), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "backend nccl" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    _compare(_snapshot(work, dirs, remove=False), want)
+
+
 def _plain_tree(work, n_samples, genome_len=3000, variants=()):
     """Samples whose reads all show the reference, except at `variants` [(sample, pos, alt)]."""
     import random

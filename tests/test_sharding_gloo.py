@@ -147,3 +147,39 @@ def test_plans_at_world_8_with_sizes_that_do_not_divide():
                         assert (r, c) not in seen
                         seen[(r, c)] = (src, dst)
             assert len(seen) == nt * nt                                     # the whole matrix, every tile once
+
+
+def _group_of_one(rank, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", SNPGPU_DIST_AT_WORLD_1="1")
+    calls = []
+    for name in ("all_gather_into_tensor", "all_to_all_single", "all_reduce"):
+        def spy(*a, _f=getattr(dist, name), _n=name, **k):
+            calls.append(_n)
+            return _f(*a, **k)
+        setattr(dist, name, spy)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert sharding.group_of_one_exchanges()
+        t = torch.arange(1000, dtype=torch.int64)
+        out, counts = sharding.all_gather_varlen(t)
+        assert torch.equal(out, t) and counts == [1000]
+        out, counts = sharding.all_gather_varlen(t[:0])
+        assert out.numel() == 0 and counts == [0]
+        rows = torch.randint(0, 255, (300, 77), dtype=torch.uint8)
+        assert torch.equal(sharding.all_gather_rows(rows, 300), rows)
+        padded = torch.zeros((384, 77), dtype=torch.uint8)
+        sharding.all_gather_rows_into(rows, 300, padded)
+        assert torch.equal(padded[:300], rows) and not padded[300:].any()
+        partial = torch.randint(0, 1000, (384, 384), dtype=torch.int32)
+        assert torch.equal(sharding.RowBands(300, 1).exchange(partial, 0), partial)
+        assert torch.equal(sharding.sum_partial_distances(partial.clone()), partial)
+        assert calls.count("all_gather_into_tensor") == 5 and calls.count("all_to_all_single") == 1 and calls.count("all_reduce") == 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_group_of_one_makes_the_calls_when_asked():
+    """SNPGPU_DIST_AT_WORLD_1=1: the hook the GPU tests use to run the RCCL entry points on a box with one GPU.  Here over gloo:
+    a group of one rank makes every collective call (a group of one without the variable makes none) and gets its own data back."""
+    mp.spawn(_group_of_one, args=(_free_port(),), nprocs=1, join=True)
+    assert not sharding.group_of_one_exchanges()
