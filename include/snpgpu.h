@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SNPGPU_ABI_VERSION 4
+#define SNPGPU_ABI_VERSION 5
 
 /* ---- error codes ------------------------------------------------------- */
 #define SNPGPU_OK            0
@@ -55,7 +55,7 @@ extern "C" {
 #define SNPGPU_ST_SHORT_LINE   2   /* < 4 fields: IndexError in pileup.py:224-225 */
 #define SNPGPU_ST_BAD_DEPTH    3   /* depth field is not [0-9]+: ValueError in pileup.py:225 */
 #define SNPGPU_ST_NO_QUALS     4   /* depth > 0 and exactly 5 fields: IndexError in pileup.py:237 */
-#define SNPGPU_ST_MULTI_REF    5   /* reference-base field longer than SNPGPU_SPILL_REF bytes (unsupported) */
+#define SNPGPU_ST_MULTI_REF    5   /* (ABI <= 4: reference-base field longer than SNPGPU_SPILL_REF bytes; no longer produced) */
 
 typedef struct snpgpu_ctx snpgpu_ctx;
 typedef struct snpgpu_siteset snpgpu_siteset;
@@ -104,7 +104,10 @@ typedef struct snpgpu_site_counts {
 #define SNPGPU_SPILL_CAP  1024
 typedef struct snpgpu_symbol_spill {
     uint32_t n;                         /* entries used */
-    uint32_t ref_len;                   /* 0 or 1: the record's ref_base is the whole field; else bytes used of ref[] */
+    uint32_t ref_len;                   /* 0 or 1: the record's ref_base is the whole field; else the field's length: its first
+                                         * SNPGPU_SPILL_REF bytes in ref[], the rest — raw, no header — in the
+                                         * ceil((ref_len - SNPGPU_SPILL_REF) / sizeof(record)) records that follow this one (ref[] is
+                                         * the last member, so the field is one run of bytes starting at ref) */
     int64_t  depth64;                   /* Record.raw_depth when the record's 32 unsigned bits cannot hold it — int() takes "-3"
                                          * and "5000000000" (pileup.py:225) and consensus.vcf prints what it got; else 0 */
     uint8_t  sym[SNPGPU_SPILL_SYMS];    /* most_common_good_bases[8 + k] */

@@ -494,7 +494,21 @@ def gen_longref_vectors():
         wide.append("DP\t%d\t%s\t%s\t..,,AaCc*\tIIII5IIII" % (100 + k, "ACGTN"[k % 5], depth))
         wide.append("DP\t%d\tAC\t%s\t..,,Gg\tIIIIII" % (200 + k, depth))
         wide.append("DP\t%d\tT\t%s" % (300 + k, depth))
-    return {"records": [record_vector(pileup, ln) for ln in lines], "wide_depth_records": [record_vector(pileup, ln) for ln in wide]}
+    # fields longer than the 64 bytes a spill record of the device holds (they go on in the records behind it: 1 640 bytes each):
+    # 65, 66, the last byte of one more record, the first of two more, thousands; with '.', ',' and both cases inside
+    very = []
+    for k, n in enumerate([65, 66, 100, 129, 500, 64 + 1640, 64 + 1640 + 1, 64 + 2 * 1640, 5000, 20000]):
+        # (',' inside the field makes the reference's replace — and the oracle's — quadratic: only in the shorter ones)
+        body = "".join(rng.choice("ACGTNacgtn" + (".," if k % 2 and n < 2000 else "")) for _ in range(n))
+        very.append("LR\t%d\t%s\t12\t..,,AaCc.,*G\tIIII5III!III" % (400 + k, body))
+        very.append("LR\t%d\t%s\t0" % (500 + k, body))
+        f = fuzz.fuzz_line(rng).split("\t")
+        while len(f) < 6:
+            f = fuzz.fuzz_line(rng).split("\t")
+        f[0], f[1], f[2] = "LR", str(600 + k), body
+        very.append("\t".join(f))
+    return {"records": [record_vector(pileup, ln) for ln in lines], "wide_depth_records": [record_vector(pileup, ln) for ln in wide],
+            "very_long_ref_records": [record_vector(pileup, ln) for ln in very]}
 
 
 def gen_steps_vectors():

@@ -185,7 +185,6 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
             const uint8_t *gl = buf + ls;                 // line bytes in global memory
             auto lb = [&](uint32_t off) -> uint32_t { return off < CALL_LBUF ? L.line[off] : (uint32_t)gl[off]; };
             if (nfields < 4) status = SNPGPU_ST_SHORT_LINE;
-            else if (L.fe[2] - L.fs[2] > SNPGPU_SPILL_REF) status = SNPGPU_ST_MULTI_REF;
             else {
                 ref_at = L.fs[2];
                 ref_len = L.fe[2] - L.fs[2];                   // (a field has at least one byte)
@@ -312,11 +311,14 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
                     if (lane == 0) {
                         const uint32_t nd = L.hist[(uint32_t)'.'], nc = L.hist[(uint32_t)','];      // both bytes are <= 'Z': strand class 0
                         L.hist[(uint32_t)'.'] = 0; L.hist[(uint32_t)','] = 0;
+                        // (one pass whatever the field's length: every ',' IN the field sends the nd '.' reads once more through the
+                        // whole lower-cased field)
+                        uint32_t commas = 0;
+                        for (uint32_t i = 0; i < ref_len; ++i) commas += lb(ref_at + i) == (uint32_t)',' ? 1u : 0u;
                         for (uint32_t i = 0; i < ref_len; ++i) {
-                            const uint32_t u = to_upper(lb(ref_at + i));
-                            if (u == ',') { for (uint32_t j = 0; j < ref_len; ++j) L.hist[hist_bin(to_lower(lb(ref_at + j)))] += nd; }
-                            else L.hist[hist_bin(u)] += nd;
-                            L.hist[hist_bin(to_lower(lb(ref_at + i)))] += nc;
+                            const uint32_t ch = lb(ref_at + i), u = to_upper(ch);
+                            if (u != ',') L.hist[hist_bin(u)] += nd;
+                            L.hist[hist_bin(to_lower(ch))] += nc + nd * commas;
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -376,12 +378,14 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
             // bytes (with or without good reads): ranks 8, 9, ... in the same order and the field go to a spill record of the
             // context; its index + 1 travels in the upper bits of n_symbols
             if (a.out_counts && (nsym > SNPGPU_MAX_SYMS || ref_len > 1 || depth64 != 0)) {
+                // (a field of more than SNPGPU_SPILL_REF bytes goes on, raw, in the records that follow its own: claimed in one step)
+                const uint32_t more_recs = ref_len > SNPGPU_SPILL_REF ? (ref_len - SNPGPU_SPILL_REF + (uint32_t)sizeof(snpgpu_symbol_spill) - 1) / (uint32_t)sizeof(snpgpu_symbol_spill) : 0u;
                 uint32_t slot = 0xFFFFFFu;
                 if (a.spill) {
-                    if (lane == 0) slot = atomicAdd(a.spill_n, 1u);
+                    if (lane == 0) slot = atomicAdd(a.spill_n, 1u + more_recs);
                     slot = __builtin_amdgcn_readfirstlane(slot);
                 }
-                if (slot < a.spill_cap) {
+                if (slot < a.spill_cap && more_recs < a.spill_cap - slot && slot + more_recs < 0xFFFFFEu) {
                     snpgpu_symbol_spill *sp = a.spill + slot;
                     uint32_t r = 0;
                     for (; r < SNPGPU_SPILL_SYMS; ++r) {
@@ -399,7 +403,12 @@ __global__ __launch_bounds__(CALL_WAVES * 64) void k_call_sites(CallArgs a) {
                         sp->n = r;
                         sp->ref_len = ref_len > 1 ? ref_len : 0u;
                         sp->depth64 = depth64;
-                        if (ref_len > 1) for (uint32_t i = 0; i < ref_len; ++i) sp->ref[i] = (uint8_t)((ref_at + i) < CALL_LBUF ? (uint32_t)L.line[ref_at + i] : (uint32_t)buf[lv - 1 + ref_at + i]);
+                    }
+                    if (ref_len > 1) {
+                        // ref[] is the record's last member: the bytes from SNPGPU_SPILL_REF on land in the records claimed with it
+                        uint8_t *dst = (uint8_t *)(sp + 1) - SNPGPU_SPILL_REF;
+                        for (uint32_t i = lane; i < ref_len; i += 64)
+                            dst[i] = (uint8_t)((ref_at + i) < CALL_LBUF ? (uint32_t)L.line[ref_at + i] : (uint32_t)buf[lv - 1 + ref_at + i]);
                     }
                     nsym |= (slot + 1u) << 8;
                 } else {

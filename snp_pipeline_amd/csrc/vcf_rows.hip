@@ -42,7 +42,10 @@ bool put_row(Out &o, const snpgpu_site_counts &c, uint32_t mask, uint64_t key, c
     if (n_symbols > SNPGPU_MAX_SYMS || spill_code != 0) {
         if (!spill || spill_code == 0 || spill_code - 1 >= n_spill) return false;
         more = &spill[spill_code - 1];
-        if (more->n != (n_symbols > SNPGPU_MAX_SYMS ? n_symbols - SNPGPU_MAX_SYMS : 0u) || more->n > SNPGPU_SPILL_SYMS || more->ref_len > SNPGPU_SPILL_REF) return false;
+        if (more->n != (n_symbols > SNPGPU_MAX_SYMS ? n_symbols - SNPGPU_MAX_SYMS : 0u) || more->n > SNPGPU_SPILL_SYMS) return false;
+        // (a field of more than SNPGPU_SPILL_REF bytes goes on in the records behind its own: they have to be there)
+        if (more->ref_len > SNPGPU_SPILL_REF &&
+            (more->ref_len - SNPGPU_SPILL_REF + sizeof(snpgpu_symbol_spill) - 1) / sizeof(snpgpu_symbol_spill) > (size_t)(n_spill - spill_code)) return false;
     }
     // a reference field of several bytes: REF shows the string, and no single symbol equals it (vcf_writer.py:295-331)
     const bool long_ref = more && more->ref_len > 1;
@@ -84,8 +87,9 @@ bool put_row(Out &o, const snpgpu_site_counts &c, uint32_t mask, uint64_t key, c
     o.put('\t'); o.putu(key & 0xFFFFFFFFull);
     o.puts_("\t.\t");
     if (long_ref) {
+        const uint8_t *field = (const uint8_t *)(more + 1) - SNPGPU_SPILL_REF;        // = more->ref, and on into the next records
         for (uint32_t i = 0; i < more->ref_len; ++i) {
-            char ch = (char)more->ref[i];
+            char ch = (char)field[i];
             if (!preserve_ref_case && ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
             o.put(ch);
         }

@@ -164,6 +164,20 @@ class SiteSet(object):
             pass
 
 
+def spill_reference_field(spill, index):
+    """The reference-base field (bytes) of spill record `index` whose ref_len is > 1: its first SPILL_REF bytes are in the
+    record's ref[], the rest — for a field longer than that — fills the records that follow it (include/snpgpu.h)."""
+    n = int(spill[index]["ref_len"])
+    if n <= L.SPILL_REF:
+        return bytes(spill[index]["ref"][:n])
+    size = SPILL_DTYPE.itemsize
+    more = (n - L.SPILL_REF + size - 1) // size
+    if index + more >= len(spill):
+        raise ValueError("spill record %d: a reference field of %d bytes needs %d more records, %d are there" % (index, n, more, len(spill) - index - 1))
+    raw = np.ascontiguousarray(spill[index:index + 1 + more]).view(np.uint8).reshape(-1)
+    return bytes(raw[size - L.SPILL_REF:size - L.SPILL_REF + n])
+
+
 SPILL_DTYPE = np.dtype([("n", "<u4"), ("ref_len", "<u4"), ("depth64", "<i8"), ("sym", "u1", (L.SPILL_SYMS,)),
                         ("total", "<u4", (L.SPILL_SYMS,)), ("fwd", "<u4", (L.SPILL_SYMS,)), ("rev", "<u4", (L.SPILL_SYMS,)),
                         ("ref", "u1", (L.SPILL_REF,))])
@@ -360,7 +374,6 @@ class Device(object):
         what, exc = {L.ST_SHORT_LINE: ("line has fewer than 4 fields", IndexError),
                      L.ST_BAD_DEPTH: ("depth field is not an unsigned decimal integer", ValueError),
                      L.ST_NO_QUALS: ("depth > 0 but no quality field", IndexError),
-                     L.ST_MULTI_REF: ("unsupported: reference-base field longer than %d bytes" % L.SPILL_REF, None)
                      }.get(int(codes[k]), ("malformed line", ValueError))
         return PileupFormatError("pileup line for site #%d: %s" % (k, what), exc), off
 

@@ -74,7 +74,8 @@ def row_from_counts(chrom, pos, c, filter_names, preserve_ref_case, failed_snp_g
             raw_depth = int(more["depth64"])
         ranked += [(chr(int(more["sym"][r])), int(more["total"][r]), int(more["fwd"][r]), int(more["rev"][r])) for r in range(extra)]
         if int(more["ref_len"]) > 1:                    # a reference field of several bytes: the string itself, equal to no symbol
-            ref = bytes(more["ref"][:int(more["ref_len"])]).decode("latin-1")
+            from .device import spill_reference_field
+            ref = spill_reference_field(spill, code - 1).decode("latin-1")
             upper_ref = ref.upper()
             if not preserve_ref_case:
                 ref = upper_ref

@@ -35,6 +35,10 @@ def test_golden_reference_fields_of_several_bytes(d, longref_vectors):
     # depth columns outside 0 .. 2^32 - 1 (closed in round 4: the value rides in the spill record's depth64)
     checked, _, _ = _golden_records(d, longref_vectors["wide_depth_records"])
     assert checked > 60 and _golden_records.wide_depths >= 15
+    # fields of 65 to 20 000 bytes (refused up to round 4): they go on in the spill records behind the position's own
+    very = longref_vectors["very_long_ref_records"]
+    checked, _, long_refs = _golden_records(d, very)
+    assert checked > 100 and long_refs == checked
 
 
 def _golden_records(d, recs):
@@ -73,7 +77,8 @@ def _golden_records(d, recs):
                 assert (c["total"][r], c["fwd"][r], c["rev"][r]) == (tot[sym], fw.get(sym, 0), rv.get(sym, 0)), (key, sym)
             if len(w["ref"]) > 1:                                   # the field itself is in the spill record, its first byte in the record
                 more = res.spill[(int(c["n_symbols"]) >> 8) - 1]
-                assert bytes(more["ref"][:int(more["ref_len"])]).decode() == w["ref"] and chr(c["ref_base"]) == w["ref"][0]
+                from snp_pipeline_amd.device import spill_reference_field
+                assert spill_reference_field(res.spill, (int(c["n_symbols"]) >> 8) - 1).decode() == w["ref"] and chr(c["ref_base"]) == w["ref"][0]
                 assert more["n"] == max(len(ranked) - L.MAX_SYMS, 0)
                 long_refs += 1
             else:

@@ -426,6 +426,36 @@ def test_library_vcf_formatter_equals_python_rows():
     assert max(ln.split(b"\t")[4].count(b",") for ln in text.split(b"\n") if ln) >= 126
     with pytest.raises(ValueError):                             # a record that points past the spill it is given
         vcf_writer.format_rows(recs, order, cname, coff, keys, names, True, ".", spill=spill[:2])
+    # reference fields of several bytes: up to 64 in the record's ref[], longer ones go on — raw — in the records behind it
+    from snp_pipeline_amd.device import spill_reference_field
+    size = SPILL_DTYPE.itemsize
+    fields = [(50, b"Ac"), (60, bytes(rng.choice(b"ACGTacgtn.,") for _ in range(64))), (70, bytes(rng.choice(b"ACGTacgtn.,") for _ in range(65))),
+              (80, bytes(rng.choice(b"ACGTacgt") for _ in range(64 + size))), (90, bytes(rng.choice(b"ACGTacgt") for _ in range(64 + size + 1)))]
+    spill2 = np.zeros(3 + sum(1 + (max(len(f) - 64, 0) + size - 1) // size for _, f in fields), dtype=SPILL_DTYPE)
+    spill2[:3] = spill
+    raw = spill2.view(np.uint8).reshape(-1)
+    slot = 3
+    for i, field in fields:
+        recs[i]["n_symbols"] = (int(recs[i]["n_symbols"]) & 0xFF) | ((slot + 1) << 8)
+        recs[i]["ref_base"] = field[0]
+        spill2[slot]["ref_len"] = len(field)
+        at = slot * size + size - 64
+        raw[at:at + len(field)] = np.frombuffer(field, dtype=np.uint8)
+        assert spill_reference_field(spill2, slot) == field
+        slot += 1 + (max(len(field) - 64, 0) + size - 1) // size
+    assert slot == len(spill2) and int(spill2[-1]["n"]) != 0    # (the last record is the tail of the 1 705-byte field: raw bytes, no header)
+    for keep_case in (False, True):
+        text = vcf_writer.format_rows(recs, order, cname, coff, keys, names, keep_case, "1", spill=spill2)
+        want = "".join(vcf_writer.row_from_counts(contigs[int(keys[j]) >> 32].decode(), int(keys[j]) & 0xFFFFFFFF, recs[j], names, keep_case, "1", spill=spill2) + "\n"
+                       for j in order)
+        assert text == want.encode("latin-1")
+        for i, field in fields:
+            row = [ln for ln in text.split(b"\n") if ln][list(order).index(i)].split(b"\t")
+            assert row[3] == (field if keep_case else field.upper())
+    with pytest.raises(ValueError):                             # the tail of a long field has to be there
+        vcf_writer.format_rows(recs, order, cname, coff, keys, names, True, ".", spill=spill2[:-1])
+    with pytest.raises(ValueError):
+        spill_reference_field(spill2[:-1], len(spill2) - 3)
 
 
 def test_library_distance_tsv_writer_equals_reference_layout(tmp_path, fixture_trees):

@@ -35,6 +35,9 @@ def test_reference_fields_of_several_bytes(longref_vectors):
     # ... and on lines whose depth column is an integer outside 0 .. 2^32 - 1 ("-3", "5000000000", "1_000": pileup.py:225)
     wide = longref_vectors["wide_depth_records"]
     assert _check_records(wide) > 60 and sum(1 for v in wide if not 0 <= v["by_q"]["0"]["raw"] < (1 << 32)) >= 15
+    # ... and whose reference field is longer than one spill record of the device holds (65 bytes to 20 000)
+    very = longref_vectors["very_long_ref_records"]
+    assert _check_records(very) > 100 and max(len(v["line"].split("\t")[2]) for v in very) == 20000
 
 
 def _check_records(records):

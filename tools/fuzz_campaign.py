@@ -191,6 +191,8 @@ def main():
                         continue
                     pos += rng.choice([1, 1, 2, 50])
                     f[1] = str(pos).encode()
+                    if rng.random() < 0.03:                          # a reference field of several bytes, up to a few spill records long
+                        f[2] = "".join(rng.choice("ACGTNacgtn.,*") for _ in range(rng.choice([2, 3, 64, 65, 300, 1704, 1705, 3500]))).encode()
                     lines.append(b"\t".join(f))
                     keys.append((f[0], pos))
                 data = b"\n".join(lines) + b"\n"
