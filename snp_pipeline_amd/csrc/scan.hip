@@ -275,6 +275,11 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveSlots &ws = sh.w[wave];
+    // Phase B: a lane owns 64 CONTIGUOUS bytes of the tile (chunks 4 * lane .. + 3) and reads them in the order i ^ (quad & 3), so
+    // that the sixteen lanes of every ds_read_b128 lane group hit sixteen different 16-byte slots; bit 16 * i + b of its
+    // terminator word is byte b of the i-th chunk it READ, which is byte byte_of(16 * i + b) of the tile.
+    const uint32_t k16 = ((lane >> 2) & 3u) << 4;
+    auto byte_of = [&](uint32_t bit) -> uint32_t { return (lane << 6) | (bit ^ k16); };
     const uint32_t *bitmap = ss.bitmap, *rank = ss.rank;
     uint32_t hits = 0, lines_seen = 0, any_hi = 0;
     unsigned long long depth_acc = 0;
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                     uint32_t bits[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const uint4 v = tile16[i * 64 + lane];
+                        const uint4 v = tile16[4 * lane + ((uint32_t)i ^ (k16 >> 4))];
                         any_hi |= v.x | v.y | v.z | v.w;
                         // the two SWAR adds on 8 bytes at a time (v_lshl_add_u64), the 3-input select per dword
                         const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                 WTICK(t_s);
                 // The last byte of the sub-tile (lane 63, chunk 3, byte 15) starts a line in the NEXT sub-tile, which
                 // sees it as its byte -1; byte 0 starts a line iff the byte before it ends a terminator.
-                if (lane == 63) S &= ~(1ull << 63);
+                if (lane == 63) S &= ~(1ull << 15);                 // (lane 63 reads its last chunk first: k16 = 48)
                 if (!kExact) {
                     // CR LF files: the '\r' of a pair flags the '\n' after it as a start.  Two flagged neighbours in one 16-byte
                     // chunk are looked at here (two byte reads per pair) and the '\r' loses its flag, so such files index and
@@ -473,25 +478,24 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                         while (pairs) {
                             const uint32_t bpos = (uint32_t)__ffsll((long long)pairs) - 1;
                             pairs &= pairs - 1;
-                            const uint32_t q = (((bpos >> 4) * 64 + lane) << 4) + (bpos & 15);
+                            const uint32_t q = byte_of(bpos);
                             if (tile[q] == 13u && tile[q + 1] == 10u) S &= ~(1ull << bpos);
                         }
                     }
                 }
                 const uint32_t pv0 = tile[-1], cv0 = tile[0];
                 bool s0 = (lane == 0) && (pv0 == 10u || (pv0 == 13u && cv0 != 10u));
-                uint32_t cnt, n_lines, base;
-                auto finish_index = [&]() {                         // edge tiles, per-lane counts, wave prefix sum
-                    if (edge) {                                     // starts must lie inside the file
+                uint32_t cnt = 0, n_lines = 0, base = 0;
+                auto mask_edge = [&]() {                            // first / last tiles of a file: starts must lie inside it
 #pragma nounroll
-                        for (int i = 0; i < 4; ++i)
-#pragma nounroll
-                            for (int b = 0; b < 16; ++b) {
-                                const uint64_t st = t0 + (uint64_t)((i * 64 + (int)lane) * 16 + b + 1);
-                                if (st < f.lo || st >= f.hi) S &= ~(1ull << (16 * i + b));
-                            }
-                        s0 = s0 && t0 >= f.lo && t0 < f.hi;
+                    for (uint32_t b = 0; b < 64; ++b) {
+                        const uint64_t st = t0 + (uint64_t)(byte_of(b) + 1u);
+                        if (st < f.lo || st >= f.hi) S &= ~(1ull << b);
                     }
+                    s0 = s0 && t0 >= f.lo && t0 < f.hi;
+                };
+                auto finish_index = [&]() {                         // (exact instantiation) per-lane counts, wave prefix sum
+                    if (edge) mask_edge();
                     cnt = (uint32_t)__popcll(S) + (s0 ? 1u : 0u);
                     const uint32_t incl = wave_inclusive_sum(cnt);
                     n_lines = __builtin_amdgcn_readlane(incl, 63);
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                     for (int r = 0; r < 2; ++r) {
                         const uint32_t bpos = (uint32_t)__ffsll((long long)s_bits) - 1;         // 0xFFFFFFFF when empty
                         const bool have = s_bits != 0;
-                        if (have && idx < SCAN_LIST_CAP) lstart[idx] = (uint16_t)((((bpos >> 4) * 64 + lane) << 4) + (bpos & 15) + 1);
+                        if (have && idx < SCAN_LIST_CAP) lstart[idx] = (uint16_t)(byte_of(bpos & 63u) + 1u);
                         idx += have ? 1u : 0u;
                         s_bits &= s_bits - 1;
                     }
@@ -516,19 +520,18 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                         while (s_bits) {
                             const uint32_t bpos = (uint32_t)__ffsll((long long)s_bits) - 1;
                             s_bits &= s_bits - 1;
-                            if (idx < SCAN_LIST_CAP) lstart[idx] = (uint16_t)((((bpos >> 4) * 64 + lane) << 4) + (bpos & 15) + 1);
+                            if (idx < SCAN_LIST_CAP) lstart[idx] = (uint16_t)(byte_of(bpos) + 1u);
                             ++idx;
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
                 };
-                finish_index();
+                if (kExact) finish_index();
                 // The fast index flags every byte in 0x0A..0x0D.  The fast parse checks each start itself (phase C: the byte
                 // before it is '\n', else the lane decides from two bytes what it is looking at); the exact instantiation
                 // checks the list here and, when a tile holds anything but "\n" and "\r\n", indexes it again byte by byte.
                 bool redo = kExact && (n_lines > SCAN_LIST_CAP || __ballot((lane == 0) && (pv0 - 11u <= 2u)) != 0);
-                if (!kExact) build_list(0);
-                else if (!redo) {
+                if (kExact && !redo) {
                     build_list(0);
                     // A start is proper when it follows a '\n'.  In a CR LF file every '\r' flags a second start, the '\n'
                     // that follows it: such a phantom (it follows '\r' and IS '\n') is marked in the list (bit 15) and
@@ -557,19 +560,24 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                     for (int i = 0; i < 4; ++i)
 #pragma nounroll
                         for (int b = 0; b < 16; ++b) {
-                            const int q = (i * 64 + (int)lane) * 16 + b;
+                            const int q = (int)byte_of((uint32_t)(16 * i + b));
                             const uint32_t cv = tile[q], nx = tile[q + 1];
                             if (cv == 10u || (cv == 13u && nx != 10u)) S |= 1ull << (16 * i + b);
                         }
-                    if (lane == 63) S &= ~(1ull << 63);
+                    if (lane == 63) S &= ~(1ull << 15);
                     s0 = (lane == 0) && (pv0 == 10u || (pv0 == 13u && cv0 != 10u));
                     finish_index();
                 }
-                lines_seen += (lane == 0) ? n_lines : 0;
+                if (kExact) lines_seen += (lane == 0) ? n_lines : 0;
+                else {
+                    if (edge) mask_edge();
+                    lines_seen += (uint32_t)__popcll(S) + (s0 ? 1u : 0u);     // (every lane keeps its own count; added up at the end)
+                    n_lines = 1;                                    // one trip through the pass loop below
+                }
                 WTICK(t_i);
 
                 for (uint32_t pass0 = 0; pass0 < n_lines; pass0 += SCAN_LIST_CAP) {
-                    if (!listed || pass0 != 0) build_list(pass0);
+                    if (kExact && (!listed || pass0 != 0)) build_list(pass0);
                     const uint32_t n_here = n_lines - pass0 < SCAN_LIST_CAP ? n_lines - pass0 : SCAN_LIST_CAP;
                     if (!kExact) {
                     // ---- C: one lane per line ------------------------------------------------------------------
@@ -577,11 +585,18 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                         // Straight-line code for "name SEP digits SEP" with as little scalar/exec traffic as possible:
                         // every test lands in one per-lane `bad` word; a line that does not fit (other contig, odd
                         // whitespace, > 10 digits, long name ...) is queued for the exact parser.
-                        for (uint32_t j0 = 0; j0 < n_here; j0 += 64) {
-                            const uint32_t j = j0 + lane;
-                            const uint32_t s_raw = j < n_here ? lstart[j] : 0x8000u;        // bit 15: the '\n' of a CR LF pair, no line
-                            bool active = (s_raw >> 15) == 0;
-                            const uint32_t s = s_raw & 0x7FFFu;
+                        // No list of line starts: a lane takes the lines that start behind the terminators of ITS 64 bytes,
+                        // one per round (30x: one round, now and then a second; 8x / 15x: two); the rounds end when no lane
+                        // has a terminator left.  Lane 0 first takes the line that starts with the tile (s0).
+                        uint64_t pend = S;
+                        bool extra = s0;
+                        for (;;) {
+                            bool active = extra || pend != 0;
+                            if (!__ballot(active)) break;
+                            const uint32_t bpos = extra ? 0xFFFFFFFFu : (uint32_t)__ffsll((long long)pend) - 1u;
+                            const uint32_t s = extra ? 0u : byte_of(bpos & 63u) + 1u;
+                            if (!extra) pend &= pend - 1;
+                            extra = false;
                             uint32_t bad, pos;
                             bool big;
                             uint32_t nd_seen = 0;                                        // digits of this line's position (0: unknown)
@@ -690,7 +705,8 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                 const uint32_t xm = (x ^ 0x30303030u) & (k >= 4 ? 0xFFFFFFFFu : ((1u << (8 * k)) - 1u));
                                 const bool digits_ok = ((((xm + 0x76767676u) | xm) & 0x80808080u) == 0) && k >= 1 && (k < 4 || after4 <= 0x20u);
                                 const bool shape_ok = refb > 0x20u && (sepb == 9u || sepb == 32u) && digits_ok;
-                                if (active && nd_here != 0 && c2d != 10u) {              // the line goes on after the position
+                                if (active && bad == 0 && nd_here != 0 && c2d != 10u) {  // the line goes on after the position (a line that is
+                                                                                         // queued already has its depth added by the exact parser)
                                     if (shape_ok) depth_acc += four_digits(k >= 4 ? xm : xm << (8 * (4 - k)));
                                     else bad |= 1u;                                      // exact parser: any ref field, any depth
                                 }
