@@ -52,7 +52,8 @@ struct ScanArgs {
     uint32_t *ctl;           // [0] queue length, [1] queue overflowed
     uint32_t q_cap;
     int want_depth;
-    uint32_t share[4];       // relative tile share of a wave by its age rank on its SIMD (wave-in-block / 4)
+    uint32_t share[4];       // relative tile share of a wave by its age rank on its SIMD (wave-in-block / 4): files of long lines
+    uint32_t share_dense[4]; // ... files of short lines (a wave measures the line density of its sample itself, below)
     uint64_t *totals;        // per-wave {lines, matched, depth sum}: same-address atomics from thousands of waves
                              // serialise at ~12 ns each and stall the loads of the waves still running
     unsigned long long *dbg; // optional: per-wave timing records (tuning only)
@@ -280,6 +281,14 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     // terminator word is byte b of the i-th chunk it READ, which is byte byte_of(16 * i + b) of the tile.
     const uint32_t k16 = ((lane >> 2) & 3u) << 4;
     auto byte_of = [&](uint32_t bit) -> uint32_t { return (lane << 6) | (bit ^ k16); };
+    // the 16-bit groups of a terminator word into address order and back (the same exchange both ways): neighbours swap where
+    // k16 & 16 (rotate both dwords by 16), the dwords swap where k16 & 32
+    auto regroup = [&](uint64_t x) -> uint64_t {
+        const uint32_t rot = k16 & 16u, lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+        const uint32_t a_lo = __builtin_amdgcn_alignbit(lo, lo, rot), a_hi = __builtin_amdgcn_alignbit(hi, hi, rot);
+        return (k16 & 32u) ? ((uint64_t)a_hi | ((uint64_t)a_lo << 32)) : ((uint64_t)a_lo | ((uint64_t)a_hi << 32));
+    };
+    bool crlf_mode = false;                                   // (wave-uniform, sticky) the file has "\r\n" line ends
     const uint32_t *bitmap = ss.bitmap, *rank = ss.rank;
     uint32_t hits = 0, lines_seen = 0, any_hi = 0;
     unsigned long long depth_acc = 0;
@@ -409,10 +418,32 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     // ... weighted by age: the SIMD issues oldest-first, so of the four waves it holds the oldest gets the most issue
     // slots; with equal shares it finishes ~35 % before the youngest, which then runs alone at half the SIMD's rate.
     // cum(x) = total weight of the launch's waves [0, x); a workgroup is 16 waves, wave w has age rank w / 4.
+    // How much faster the older waves are depends on what a tile costs: where lines are long (30x and deeper: <= 47 lines per tile) the
+    // measured best shares are a.share, where they are short (8x: 100 lines per tile and more) the flatter a.share_dense, in between
+    // (15x: 73 lines) what lies between the two (tools/scan_sweep.py).  Every wave of a sample counts the terminators of the same
+    // tile — the middle one of the sample's range in this launch — so all of them arrive at the same shares.
+    uint32_t shr[4] = {a.share[0], a.share[1], a.share[2], a.share[3]};
+    if (!kExact && n_tiles >= 3 && interior(r_lo + n_tiles / 2)) {
+        const uint4 *gp = (const uint4 *)(f.base + (r_lo + n_tiles / 2) * SCAN_TILE) + 4 * lane;
+        uint32_t n = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 v = gp[i];
+            n += __popc(term_flags(v.x)) + __popc(term_flags(v.y)) + __popc(term_flags(v.z)) + __popc(term_flags(v.w));
+        }
+        for (int o = 32; o; o >>= 1) n += __shfl_xor(n, o);
+        const uint32_t lines = __builtin_amdgcn_readfirstlane(n);
+        const uint32_t t256 = lines <= 47u ? 0u : lines >= 100u ? 256u : (lines - 47u) * 256u / 53u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) shr[k] = (a.share[k] * (256u - t256) + a.share_dense[k] * t256) >> 8;
+    }
     auto cum = [&](uint64_t x) -> uint64_t {
         const uint32_t wpb = blockDim.x >> 6, r = (uint32_t)(x % wpb);
         uint64_t c = 0, blk = 0;
-        for (uint32_t w = 0; w < wpb; ++w) { const uint32_t sw = a.share[(w >> 2) & 3u]; blk += sw; c += w < r ? sw : 0; }
+        for (uint32_t w = 0; w < wpb; ++w) {
+            const uint32_t q = (w >> 2) & 3u, sw = q == 0 ? shr[0] : q == 1 ? shr[1] : q == 2 ? shr[2] : shr[3];
+            blk += sw; c += w < r ? sw : 0;
+        }
         return (x / wpb) * blk + c;
     };
     const uint64_t c_lo = cum(s_wave0), c_span = cum((uint64_t)s_wave0 + s_waves) - c_lo;
@@ -433,7 +464,8 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
         const uint32_t later = (uint32_t)__builtin_popcount(dma_mask & ~(1u << cur));
         if (later == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else if (later == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SCAN_DMA_PER_TILE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * SCAN_DMA_PER_TILE) : "memory");
+        else if (later == 2 || SCAN_NBUF < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * SCAN_DMA_PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * SCAN_DMA_PER_TILE) : "memory");
         __builtin_amdgcn_wave_barrier();
         WTICK(t_a);
         {
@@ -472,15 +504,29 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                 if (!kExact) {
                     // CR LF files: the '\r' of a pair flags the '\n' after it as a start.  Two flagged neighbours in one 16-byte
                     // chunk are looked at here (two byte reads per pair) and the '\r' loses its flag, so such files index and
-                    // parse like LF files; a pair across chunks keeps both flags and phase C sorts it out.
-                    uint64_t pairs = S & (S >> 1) & 0x7FFF7FFF7FFF7FFFull;
-                    if (__ballot(pairs != 0)) {
+                    // parse like LF files; a pair across two chunks keeps both flags, phase C sorts it out — and switches the
+                    // wave to crlf_mode, in which every pair is looked at, the one that ends in the next lane too (a phantom
+                    // start costs a whole round where a lane takes one line per round).
+                    if (!crlf_mode) {
+                        uint64_t pairs = S & (S >> 1) & 0x7FFF7FFF7FFF7FFFull;
+                        if (__ballot(pairs != 0)) {
+                            while (pairs) {
+                                const uint32_t bpos = (uint32_t)__ffsll((long long)pairs) - 1;
+                                pairs &= pairs - 1;
+                                const uint32_t q = byte_of(bpos);
+                                if (tile[q] == 13u && tile[q + 1] == 10u) S &= ~(1ull << bpos);
+                            }
+                        }
+                    } else {                                        // every pair: the bits in address order, the next lane's first one
+                        uint64_t U = regroup(S);
+                        uint64_t pairs = U & ((U >> 1) | ((uint64_t)(__shfl_down((uint32_t)U, 1) & 1u) << 63));
                         while (pairs) {
                             const uint32_t bpos = (uint32_t)__ffsll((long long)pairs) - 1;
                             pairs &= pairs - 1;
-                            const uint32_t q = byte_of(bpos);
-                            if (tile[q] == 13u && tile[q + 1] == 10u) S &= ~(1ull << bpos);
+                            const uint32_t q = (lane << 6) | bpos;
+                            if (tile[q] == 13u && tile[q + 1] == 10u) U &= ~(1ull << bpos);
                         }
+                        S = regroup(U);
                     }
                 }
                 const uint32_t pv0 = tile[-1], cv0 = tile[0];
@@ -638,6 +684,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                         if (nl) {
                                             active = active && !no_line;
                                             lines_seen -= (lane == 0) ? (uint32_t)__popcll(nl) : 0u;
+                                            if (__ballot(no_line && pv == 13u)) crlf_mode = true;
                                         }
                                     }
                                     if (active && bad_name != 0) { mismatch_at = s; nd_seen = 0; }   // another contig, or another digit count
@@ -653,6 +700,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                     const uint64_t nl = __ballot(no_line);
                                     active = active && !no_line;
                                     lines_seen -= (lane == 0) ? (uint32_t)__popcll(nl) : 0u;
+                                    if (__ballot(no_line && pv == 13u)) crlf_mode = true;
                                 }
                             }
                             // name: masked dword compare (masks are zero past the name)
@@ -1053,22 +1101,31 @@ namespace {
 struct ScanConfig {
     // oversub: the grid holds twice the workgroups that are resident at a time, so a CU that finishes its first one early takes
     // another (tools/scan_oversub.sh: 66.3 -> 67.9 % of HBM peak in a 96-sample launch at 30x; 4 and 8 give the same)
-    int blocks_per_cu = 1, mode = 0, waves = SCAN_NBUF == 2 ? 16 : 12, oversub = 2;
-    int share[4] = {329, 282, 223, 169};                    // measured: 1 / (finish time with equal shares), oldest first
+    int blocks_per_cu = 1, mode = 0, waves = SCAN_NBUF == 2 ? 16 : 12, oversub = 0;   // oversub 0: chosen by the launch's length
+    int share[4] = {329, 282, 223, 169};                    // measured: 1 / (finish time with equal shares), oldest first (30x)
+    int share_dense[4] = {290, 266, 238, 206};              // ... at 8x (tools/scan_sweep.py)
     bool ready = false;
 };
 ScanConfig &scan_config() {
     static ScanConfig c;
+#ifdef SNPGPU_TUNING
+    if (getenv("SNPGPU_SCAN_RELOAD")) c = ScanConfig();     // tools/scan_sweep.py: many settings in one process
+#endif
     if (!c.ready) {
 #ifdef SNPGPU_TUNING                                        // development builds only (tools/): never in the product library
         const char *b = getenv("SNPGPU_SCAN_BLOCKS_PER_CU"), *m = getenv("SNPGPU_SCAN_MODE"), *w = getenv("SNPGPU_SCAN_WAVES");
         if (const char *sh = getenv("SNPGPU_SCAN_SHARE")) {
             int v[4];
             if (sscanf(sh, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0)
-                for (int g = 0; g < 4; ++g) c.share[g] = v[g];
+                for (int g = 0; g < 4; ++g) c.share[g] = c.share_dense[g] = v[g];
+        }
+        if (const char *sh = getenv("SNPGPU_SCAN_SHARE_DENSE")) {
+            int v[4];
+            if (sscanf(sh, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0)
+                for (int g = 0; g < 4; ++g) c.share_dense[g] = v[g];
         }
         c.blocks_per_cu = b && atoi(b) > 0 && atoi(b) <= 16 ? atoi(b) : 1;
-        if (const char *o = getenv("SNPGPU_SCAN_OVERSUB")) if (atoi(o) >= 1 && atoi(o) <= 16) c.oversub = atoi(o);
+        if (const char *o = getenv("SNPGPU_SCAN_OVERSUB")) if (atoi(o) >= 0 && atoi(o) <= 16) c.oversub = atoi(o);
         c.mode = m ? atoi(m) : 0;
         if (w && atoi(w) >= 1 && atoi(w) <= 16) c.waves = atoi(w);
 #endif
@@ -1103,7 +1160,11 @@ ScanArgs scan_args(const snpgpu_siteset *ss, const ScanConfig &c, const SampleDe
     sa.n_sites = ss->n_sites;
     sa.site_line = d_site_line;
     sa.want_depth = want_depth;
-    for (int g = 0; g < 4; ++g) sa.share[g] = ((c.waves == 16 || c.waves == 12) && c.blocks_per_cu == 1) ? (uint32_t)c.share[g] : 1u;
+    for (int g = 0; g < 4; ++g) {
+        const bool weighted = (c.waves == 16 || c.waves == 12) && c.blocks_per_cu == 1;
+        sa.share[g] = weighted ? (uint32_t)c.share[g] : 1u;
+        sa.share_dense[g] = weighted ? (uint32_t)c.share_dense[g] : 1u;
+    }
     sa.queue = ss->slow_queue;
     sa.q_cap = SNPGPU_SLOW_QUEUE_CAP - 65536;               // the tail holds the tuning modes' per-wave records
     sa.ctl = ss->slow_ctl;
@@ -1126,8 +1187,10 @@ uint32_t snpgpu_scan_deal(const snpgpu_ctx *ctx, SampleDev *h, uint32_t n, uint3
     }
     // the grid is a multiple of what is resident only for launches long enough that a wave's start-up does not show (a second
     // workgroup per CU costs ~1.5 % at 800 tiles per wave, gains 2 % at 2 500: tools/scan_oversub.sh)
-    const uint64_t resident = (uint64_t)ctx->n_cu * c.blocks_per_cu * c.waves;
-    const uint64_t max_waves = resident * (total_tiles / resident >= 1500 ? c.oversub : 1);
+    // (round 4, without the line list: eight times the resident waves 72.5 % of HBM peak at the headline, four 72.2, two 71.2, one 69.5;
+    // 125 samples at 8x — 1 536 tiles per resident wave — four 65.3, two 64.7, one 63.6: tools/scan_sweep.py)
+    const uint64_t resident = (uint64_t)ctx->n_cu * c.blocks_per_cu * c.waves, per_wave = total_tiles / resident;
+    const uint64_t max_waves = resident * (c.oversub ? (per_wave >= 1500 ? (uint64_t)c.oversub : 1) : per_wave >= 2500 ? 8 : per_wave >= 1500 ? 4 : 1);
     uint64_t budget = total_tiles / min_tiles_per_wave, used = 0;
     if (budget > max_waves) budget = max_waves;
     if (budget < n) budget = n;
@@ -1170,7 +1233,7 @@ int snpgpu_scan_range(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev
     const ScanConfig &c = scan_config();
     scan_allow_lds(ctx);
     hipStream_t st = ctx->stream;
-    if (n > (uint64_t)ctx->n_cu * c.blocks_per_cu * c.waves * c.oversub) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "too many samples for one scan launch");
+    if (n > (uint64_t)ctx->n_cu * c.blocks_per_cu * c.waves) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "too many samples for one scan launch");
     ScanArgs sa = scan_args(ss, c, d_table, n, d_totals, d_site_line, want_depth);
     const size_t lds = scan_lds_bytes(c);
     const unsigned grid = (unsigned)((n_waves + c.waves - 1) / c.waves), threads = (unsigned)c.waves * 64;
