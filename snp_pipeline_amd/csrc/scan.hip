@@ -6,17 +6,19 @@
 // line wins" (call_consensus.py:171-176).
 //
 // One launch serves a batch of pileups; every wavefront is an independent stream over a contiguous run of 4 KiB tiles
-// of ONE sample (shares dealt by the host, weighted by the wave's age rank on its SIMD).  A wave owns two LDS slots,
+// of ONE sample (waves dealt by the host, shares weighted in the kernel by the wave's age rank on its SIMD and the sample's line density).  A wave owns two LDS slots,
 // requests tile k+2 with LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B straight into LDS, no VGPR round trip) as
 // soon as tile k is parsed, and waits for its own DMA with a counted s_waitcnt — no workgroup barrier, no flags, no
 // polling.  The DMA goes through inline asm on purpose: hipcc orders every LDS read behind a *tracked* LDS-DMA with
 // vmcnt(0), which would serialise fetch and parse; the steady-state parse issues no other vector-memory load (the
 // site bitmap is probed through a register window), so the explicit counted wait is the only one on the path.
 // Per tile:
-//   B  each lane scans four 16-byte chunks for bytes in 0x0A..0x0D (SWAR, v_dot4_u32_u8 gathers byte flags into bits); two
-//      flagged neighbours (CR LF) are told apart by reading them, so that the '\r' flags nothing; a DPP prefix sum over
-//      the wave turns the per-lane counts into a list of line starts in LDS
-//   C  one lane per line.  One-window form: with the name length L and the digit count g of the positions known, the
+//   B  each lane scans the four 16-byte chunks of ITS 64 contiguous bytes for bytes in 0x0A..0x0D (SWAR, v_dot4_u32_u8 gathers byte
+//      flags into bits; the chunks are read in an order that keeps ds_read_b128 free of bank conflicts); two flagged neighbours
+//      (CR LF) are told apart by reading them, so that the '\r' flags nothing.  There is no list of line starts and no prefix sum
+//      (rounds 1-3 built one in LDS): the terminators a lane found are the lines it parses
+//   C  one lane per line, one line per lane and round: the line behind the lowest terminator bit the lane has left (30x: one round
+//      per tile, now and then a second; 8x / 15x: two).  One-window form: with the name length L and the digit count g of the positions known, the
 //      24 bytes that end with the separator after the position hold "\n name SEP digits SEP" at fixed places — masked
 //      compares (the '\n' in front is what makes the flagged start a line start), SWAR digit test, dot4 decimal
 //      conversion; a round in which every line fits does no other bookkeeping.  A start that does not follow '\n' is
@@ -395,13 +397,13 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     // second separator.  A line whose position has another digit count fails the separator / digit tests (exactly: the
     // tests pass iff the count is g), goes to the queue, and resets g; the general path then recalibrates it.
     uint32_t g = 0, nw[6] = {0, 0, 0, 0, 0, 0}, nm[6] = {0, 0, 0, 0, 0, 0}, dmk[3] = {0, 0, 0};
-    bool fastc = false, name_split = false, prev_in_window = false;
+    uint32_t mode = 0;                                        // (wave-uniform) bit 0: one-window rounds, bit 1: the name is checked in two pieces, bit 2: the
+                                                              // byte before the line lies in the window (one register, read once per round)
     auto relayout = [&]() {
         // names that do not fit in front of the digits (L > 22 - g) are checked in two pieces: their tail in the window,
         // their first 16 bytes against the hint registers of the general parse (together: names up to 38 - g bytes)
-        fastc = hint_bad == 0 && g >= 1 && g <= 10 && L + g <= 38;
-        name_split = L + g > 22;
-        prev_in_window = L + g <= 21;                                   // (scan_layout puts the '\n' before the line into the masks)
+        const bool fastc = hint_bad == 0 && g >= 1 && g <= 10 && L + g <= 38;
+        mode = (fastc ? 1u : 0u) | (L + g > 22 ? 2u : 0u) | (L + g <= 21 ? 4u : 0u);   // (scan_layout puts the '\n' before the line into the masks)
         if (!fastc) return;
         scan_layout(ws.lay, ws.hint_w, L, g, lane);
 #pragma unroll
@@ -636,9 +638,12 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                         // has a terminator left.  Lane 0 first takes the line that starts with the tile (s0).
                         uint64_t pend = S;
                         bool extra = s0;
-                        for (;;) {
+                        uint64_t extra_mask = __ballot(extra);          // (a ballot of a plain compare is one v_cmp; of anything else the
+                        for (;;) {                                      //  compiler first makes a 0 / 1 register: lane masks are kept in scalars)
                             bool active = extra || pend != 0;
-                            if (!__ballot(active)) break;
+                            uint64_t act_mask = __builtin_amdgcn_ballot_w64(pend != 0) | extra_mask;
+                            extra_mask = 0;
+                            if (!act_mask) break;
                             const uint32_t bpos = extra ? 0xFFFFFFFFu : (uint32_t)__ffsll((long long)pend) - 1u;
                             const uint32_t s = extra ? 0u : byte_of(bpos & 63u) + 1u;
                             if (!extra) pend &= pend - 1;
@@ -647,19 +652,20 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             bool big;
                             uint32_t nd_seen = 0;                                        // digits of this line's position (0: unknown)
                             bool tabs = true;
-                            const bool fast_round = __builtin_amdgcn_readfirstlane((uint32_t)fastc) != 0;    // wave-uniform: a scalar branch
+                            const uint32_t mode_now = __builtin_amdgcn_readfirstlane(mode);
+                            const bool fast_round = (mode_now & 1u) != 0;                // wave-uniform: a scalar branch
                             if (fast_round) {
                                 uint32_t w[6];
                                 lds_window24(tile, (int)s + (int)(L + g) - 22, w);       // ends with the second separator
                                 // the '\n' before the line, the name and both TABs in one masked compare per dword
                                 uint32_t bad_name = ((w[0] ^ nw[0]) & nm[0]) | ((w[1] ^ nw[1]) & nm[1]) | ((w[2] ^ nw[2]) & nm[2]) |
                                                     ((w[3] ^ nw[3]) & nm[3]) | ((w[4] ^ nw[4]) & nm[4]) | ((w[5] ^ nw[5]) & nm[5]);
-                                if (__builtin_amdgcn_readfirstlane((uint32_t)name_split)) {  // uniform: a long name's first 16 bytes
+                                if (mode_now & 2u) {                                     // uniform: a long name's first 16 bytes
                                     uint32_t v0, v1, v2, v3;
                                     lds_window16(tile, (int)s, v0, v1, v2, v3);
                                     bad_name |= ((v0 ^ hw[0]) & hm[0]) | ((v1 ^ hw[1]) & hm[1]) | ((v2 ^ hw[2]) & hm[2]) | ((v3 ^ hw[3]) & hm[3]);
                                 }
-                                if (!__builtin_amdgcn_readfirstlane((uint32_t)prev_in_window)) // uniform: the window starts with the name
+                                if (!(mode_now & 4u))                                    // uniform: the window starts with the name
                                     bad_name |= (uint32_t)tile[(int)s - 1] ^ 10u;
                                 const uint32_t x3 = (w[3] ^ 0x30303030u) & dmk[0], x4 = (w[4] ^ 0x30303030u) & dmk[1], x5 = (w[5] ^ 0x30303030u) & dmk[2];
                                 bad = bad_name | ((((x3 + 0x76767676u) | x3) | ((x4 + 0x76767676u) | x4) | ((x5 + 0x76767676u) | x5)) & 0x80808080u);
@@ -673,7 +679,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                 pos = __umul24(hi7, 1000u) + __builtin_amdgcn_udot4(x5, 0x00010A64u, 0u, false);
                                 nd_seen = g;
                                 // Everything else only when some line of the round does not fit (one ballot in the steady state).
-                                if (__ballot(active && bad != 0)) {
+                                if (__builtin_amdgcn_ballot_w64(bad != 0) & act_mask) {
                                     // A start that does not follow '\n' (never in an LF file, every other one in a CR LF file): the
                                     // '\n' of a "\r\n" pair and a byte after '\v' / '\f' start no line; after a lone '\r' one does
                                     // start (universal newlines), and the exact parser takes it.
@@ -688,7 +694,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                         }
                                     }
                                     if (active && bad_name != 0) { mismatch_at = s; nd_seen = 0; }   // another contig, or another digit count
-                                    if (__ballot(active && bad != 0 && bad_name == 0)) { g = 0; fastc = false; }   // a digit count changed
+                                    if (__ballot(active && bad != 0 && bad_name == 0)) { g = 0; mode = 0; }   // a digit count changed
                                 }
                             } else {
                             bad = hint_bad;                                              // uniform: no usable hint
@@ -845,11 +851,11 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                         for (uint32_t i = lane; i < len; i += 64) diff = diff || tile[s1 + i] != ((ws.hint_w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
                         same = __ballot(diff) == 0;
                     }
-                    if (same) { g = 0; fastc = false; }
+                    if (same) { g = 0; mode = 0; }
                     else if (len >= 1 && len <= 4 * SCAN_HINT_WORDS - 4) {
                         TileView tv{tile, f.base, t0, f.hi, (int64_t)(SCAN_TILE + SCAN_HALO)};
                         const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, (int64_t)s1, len) : 0xFFFFFFFFu;
-                        g = 0; fastc = false;                        // the next round calibrates against the new name
+                        g = 0; mode = 0;                             // the next round calibrates against the new name
                         if (cid != 0xFFFFFFFFu) adopt(load_hint(ss, cid, ws.hint_w, lane));
                         else {                                       // not a contig of the site set: remember the name itself
                             if (lane < SCAN_HINT_WORDS) {

@@ -707,3 +707,32 @@ def test_files_with_one_odd_line_end_as_the_reference_does(d):
             else:
                 cons, _, _ = gpu_consensus(d, data, snps, [], po.CallerParams(*run["params"]), want_counts=want_counts)
                 assert cons.decode() == run["consensus"], (run["scenario"], want_counts)
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_many_short_lines_per_lane_of_the_scan(d, seed):
+    """The scan keeps no list of line starts: a lane parses the lines that start behind the terminators of its own 64 bytes, one per
+    round.  Lines of 11 to 20 bytes put three to six of them into a lane's bytes (as many rounds per tile), stretches of deep lines
+    in between change the sample's line density from tile to tile, and the first / last tiles are short ones; counts and calls as
+    the oracle's (pileup.py:422-429)."""
+    from tests.gpu_util import check_against_oracle
+    rng = random.Random(seed)
+    out, sites, pos = [], [], 0
+    while sum(len(x) for x in out) < 30 * 4096:
+        if rng.random() < 0.15:                                  # a stretch of deep lines
+            for _ in range(rng.randrange(1, 40)):
+                pos += rng.randrange(1, 3)
+                dp = rng.randrange(20, 120)
+                out.append(b"c\t%d\tA\t%d\t%s\t%s\n" % (pos, dp, bytes(rng.choice(b".,ACgt") for _ in range(dp)), b"I" * dp))
+                if rng.random() < 0.3:
+                    sites.append((b"c", pos))
+        else:                                                    # a stretch of very short ones
+            for _ in range(rng.randrange(5, 400)):
+                pos += rng.randrange(1, 3)
+                dp = rng.randrange(0, 3)
+                out.append(b"c\t%d\tG\t%d\t%s\t%s\n" % (pos, dp, (b"." * dp) or b"*", (b"I" * dp) or b"*"))
+                if rng.random() < 0.1:
+                    sites.append((b"c", pos))
+    data = b"".join(out)
+    res = check_against_oracle(d, data, sorted(set(sites)), rng.sample(sites, 20), po.CallerParams(0, 0.6, 1, 0, 0.0))
+    assert res.n_lines == len(out) and res.n_matched == len(set(sites))

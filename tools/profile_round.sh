@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_rows" -- pyt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python $root/bench.py $pmc > /dev/null 2> "$out/pmc_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python $root/bench.py $pmc > /dev/null 2> "$out/pmc_write.err"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d "$out/pmc_sq" -- python $root/bench.py $pmc > /dev/null 2> "$out/pmc_sq.err"
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d "$out/pmc_sq2" -- python $root/bench.py $pmc > /dev/null 2> "$out/pmc_sq2.err"
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d "$out/pmc_sq2" -- python $root/bench.py $pmc > /dev/null 2> "$out/pmc_sq2.err"
 cd "$root"
 # phase-1 site calling on a resident sample (the kernels of the pipeline row's ingest): trace averages at three depths + SQ counters at 30x
 VS_PMC=30 bash tools/varscan_profile.sh 30 100 8 > "$out/varscan_kernels.txt" 2>&1
