@@ -1108,6 +1108,7 @@ struct ScanConfig {
     // oversub: the grid holds twice the workgroups that are resident at a time, so a CU that finishes its first one early takes
     // another (tools/scan_oversub.sh: 66.3 -> 67.9 % of HBM peak in a 96-sample launch at 30x; 4 and 8 give the same)
     int blocks_per_cu = 1, mode = 0, waves = SCAN_NBUF == 2 ? 16 : 12, oversub = 0;   // oversub 0: chosen by the launch's length
+    int oversub_min = 1500;                                 // (tuning) tiles per resident wave from which a forced oversub applies
     int share[4] = {329, 282, 223, 169};                    // measured: 1 / (finish time with equal shares), oldest first (30x)
     int share_dense[4] = {290, 266, 238, 206};              // ... at 8x (tools/scan_sweep.py)
     bool ready = false;
@@ -1132,6 +1133,7 @@ ScanConfig &scan_config() {
         }
         c.blocks_per_cu = b && atoi(b) > 0 && atoi(b) <= 16 ? atoi(b) : 1;
         if (const char *o = getenv("SNPGPU_SCAN_OVERSUB")) if (atoi(o) >= 0 && atoi(o) <= 16) c.oversub = atoi(o);
+        if (const char *o = getenv("SNPGPU_SCAN_OVERSUB_MIN")) if (atoi(o) >= 0) c.oversub_min = atoi(o);
         c.mode = m ? atoi(m) : 0;
         if (w && atoi(w) >= 1 && atoi(w) <= 16) c.waves = atoi(w);
 #endif
@@ -1194,9 +1196,10 @@ uint32_t snpgpu_scan_deal(const snpgpu_ctx *ctx, SampleDev *h, uint32_t n, uint3
     // the grid is a multiple of what is resident only for launches long enough that a wave's start-up does not show (a second
     // workgroup per CU costs ~1.5 % at 800 tiles per wave, gains 2 % at 2 500: tools/scan_oversub.sh)
     // (round 4, without the line list: eight times the resident waves 72.5 % of HBM peak at the headline, four 72.2, two 71.2, one 69.5;
-    // 125 samples at 8x — 1 536 tiles per resident wave — four 65.3, two 64.7, one 63.6: tools/scan_sweep.py)
+    // 125 samples at 8x — 1 536 tiles per resident wave — four 65.3, two 64.7, one 63.6; 48 samples at 30x — 1 237 — four 69.4, one 68.0;
+    // 16 at 100x — 1 117 — four 74.0, one 72.9; from 800 down one workgroup per CU is as good or better: tools/scan_sweep.py)
     const uint64_t resident = (uint64_t)ctx->n_cu * c.blocks_per_cu * c.waves, per_wave = total_tiles / resident;
-    const uint64_t max_waves = resident * (c.oversub ? (per_wave >= 1500 ? (uint64_t)c.oversub : 1) : per_wave >= 2500 ? 8 : per_wave >= 1500 ? 4 : 1);
+    const uint64_t max_waves = resident * (c.oversub ? (per_wave >= (uint64_t)c.oversub_min ? (uint64_t)c.oversub : 1) : per_wave >= 2500 ? 8 : per_wave >= 1000 ? 4 : 1);
     uint64_t budget = total_tiles / min_tiles_per_wave, used = 0;
     if (budget > max_waves) budget = max_waves;
     if (budget < n) budget = n;
