@@ -203,7 +203,7 @@ def end_to_end(d, ss, prm, pile, offs, sizes, bases, n_files, S):
 
 def site_calling(d, pile, offs, sizes, n_files):
     """Phase-1 site calling on pileup FILES in the page cache: file -> var.flt.vcf through
-    varscan.mpileup2snp (reader threads + copy, line index, k_varscan_lines, host finish), best of two passes; every
+    varscan.mpileup2snp (reader threads + copy, k_varscan_scan + k_varscan_walk, host finish), best of two passes; every
     record of the first file is checked against the CPU restatement (oracle/varscan_oracle.py) on the record's own line,
     and the restatement is timed on the first lines of that file for the CPU column."""
     import shutil
