@@ -208,12 +208,13 @@ __device__ __forceinline__ void lds_window24(const uint8_t *tile, int off, uint3
 }
 
 // What the one-window parse expects to see in the 24 bytes that END with the separator after the position, for a contig
-// name of L bytes and positions of g digits:  [.. junk ..]['\n'][name, L][TAB][digits, g][TAB].  lay[0..5] name bytes, the two
-// TABs and (when it fits: L + g <= 21) the '\n' before the line in place, lay[6..11] their byte masks, lay[12..14] byte masks of
-// the digits in dwords 3..5.  One lane per dword.
+// name of L bytes and positions of g digits whose first g - 4 digits are those of `top` (zero padded; none for g <= 4):
+// [.. junk ..]['\n'][name, L][TAB][top digits, g - 4][last four digits][TAB].  lay[0..5] name bytes, the two TABs, the top digits and
+// (when it fits: L + g <= 21) the '\n' before the line in place, lay[6..11] their byte masks, lay[12] the byte mask of the last
+// min(g, 4) digits in the dword made of window bytes 19..22.  One lane per dword.
 // (Only TAB-separated lines take the one-window parse — what samtools writes; a line with other whitespace there goes
 // through the general parse or the exact parser.)
-__device__ __noinline__ void scan_layout(uint32_t *lay, const uint32_t *hint_w, uint32_t L, uint32_t g, uint32_t lane) {
+__device__ __noinline__ void scan_layout(uint32_t *lay, const uint32_t *hint_w, uint32_t L, uint32_t g, uint32_t top, uint32_t lane) {
     if (lane < 6) {
         uint32_t w = 0, m = 0;
         for (uint32_t k = 0; k < L; ++k) {
@@ -230,15 +231,15 @@ __device__ __noinline__ void scan_layout(uint32_t *lay, const uint32_t *hint_w, 
             const uint32_t pb = 21u - g - L;
             if ((pb >> 2) == lane) { w |= 10u << (8 * (pb & 3)); m |= 0xFFu << (8 * (pb & 3)); }
         }
+        uint32_t t = top;                                         // the top digits, last one first: window bytes 18, 17, ... 23 - g
+        for (uint32_t b = 18u; g > 4u && b >= 23u - g; --b) {
+            if ((b >> 2) == lane) { w |= (0x30u + t % 10u) << (8 * (b & 3)); m |= 0xFFu << (8 * (b & 3)); }
+            t /= 10u;
+        }
         lay[lane] = w;
         lay[6 + lane] = m;
     }
-    if (lane < 3) {
-        uint32_t m = 0;
-        for (uint32_t b = 23u - g; b <= 22u; ++b)
-            if ((b >> 2) == lane + 3) m |= 0xFFu << (8 * (b & 3));
-        lay[12 + lane] = m;
-    }
+    if (lane == 6) lay[12] = g >= 4u ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8u * (4u - g));
 }
 
 struct Hint {                // the wave's current contig (all members wave-uniform); the name itself is in LDS
@@ -392,24 +393,30 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
             hm[k] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
         }
     };
-    // One-window parse: positions of a sorted pileup have the same number of digits g for long stretches, so with the
-    // name length L known the whole "name SEP digits SEP" prefix sits at a fixed place in the 24 bytes that end with the
-    // second separator.  A line whose position has another digit count fails the separator / digit tests (exactly: the
-    // tests pass iff the count is g), goes to the queue, and resets g; the general path then recalibrates it.
-    uint32_t g = 0, nw[6] = {0, 0, 0, 0, 0, 0}, nm[6] = {0, 0, 0, 0, 0, 0}, dmk[3] = {0, 0, 0};
+    // One-window parse: positions of a sorted pileup have the same number of digits g, and the same digits in front of the last four,
+    // for long stretches, so with the name length L known the whole "name SEP digits SEP" prefix sits at a fixed place in the 24 bytes
+    // that end with the second separator, and all of it but the last four digits is known in advance.  A line that differs — other top
+    // digits (every 10 000 positions), another digit count, another contig — fails the masked compare (exactly: it passes iff the
+    // bytes are the expected ones and the last four are digits); its round is done again in the general form, which sets g and the
+    // top digits for the rounds to come.
+    uint32_t g = 0, nw[6] = {0, 0, 0, 0, 0, 0}, nm[6] = {0, 0, 0, 0, 0, 0}, dmk4 = 0;
+    uint32_t top = 0, pos_base = 0;                           // (wave-uniform) the positions' digits before the last four, and top * 10 000
+    uint32_t streak = 0, cool = 0;                            // (wave-uniform) one-window rounds that failed in a row; general rounds still to run
     uint32_t mode = 0;                                        // (wave-uniform) bit 0: one-window rounds, bit 1: the name is checked in two pieces, bit 2: the
                                                               // byte before the line lies in the window (one register, read once per round)
     auto relayout = [&]() {
         // names that do not fit in front of the digits (L > 22 - g) are checked in two pieces: their tail in the window,
         // their first 16 bytes against the hint registers of the general parse (together: names up to 38 - g bytes)
-        const bool fastc = hint_bad == 0 && g >= 1 && g <= 10 && L + g <= 38;
+        // (g = 10 and top digits from 429 496 on: top * 10 000 + 9 999 would not fit 32 bits — such positions are in no site set, and
+        // the general parse knows)
+        const bool fastc = hint_bad == 0 && g >= 1 && g <= 10 && L + g <= 38 && top <= 429495u;
+        pos_base = top * 10000u;
         mode = (fastc ? 1u : 0u) | (L + g > 22 ? 2u : 0u) | (L + g <= 21 ? 4u : 0u);   // (scan_layout puts the '\n' before the line into the masks)
         if (!fastc) return;
-        scan_layout(ws.lay, ws.hint_w, L, g, lane);
+        scan_layout(ws.lay, ws.hint_w, L, g, top, lane);
 #pragma unroll
         for (int k = 0; k < 6; ++k) { nw[k] = ws.lay[k]; nm[k] = ws.lay[6 + k]; }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) dmk[k] = ws.lay[12 + k];
+        dmk4 = ws.lay[12];
     };
     if (!kExact) adopt(load_hint(ss, 0, ws.hint_w, lane));
 
@@ -653,11 +660,13 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             uint32_t nd_seen = 0;                                        // digits of this line's position (0: unknown)
                             bool tabs = true;
                             const uint32_t mode_now = __builtin_amdgcn_readfirstlane(mode);
-                            const bool fast_round = (mode_now & 1u) != 0;                // wave-uniform: a scalar branch
+                            bool fast_round = (mode_now & 1u) != 0 && cool == 0;         // wave-uniform: a scalar branch
+                            if (!fast_round && cool) --cool;
                             if (fast_round) {
                                 uint32_t w[6];
                                 lds_window24(tile, (int)s + (int)(L + g) - 22, w);       // ends with the second separator
-                                // the '\n' before the line, the name and both TABs in one masked compare per dword
+                                // the '\n' before the line, the name, both TABs and all but the last four digits of the position in one
+                                // masked compare per dword
                                 uint32_t bad_name = ((w[0] ^ nw[0]) & nm[0]) | ((w[1] ^ nw[1]) & nm[1]) | ((w[2] ^ nw[2]) & nm[2]) |
                                                     ((w[3] ^ nw[3]) & nm[3]) | ((w[4] ^ nw[4]) & nm[4]) | ((w[5] ^ nw[5]) & nm[5]);
                                 if (mode_now & 2u) {                                     // uniform: a long name's first 16 bytes
@@ -667,36 +676,23 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                 }
                                 if (!(mode_now & 4u))                                    // uniform: the window starts with the name
                                     bad_name |= (uint32_t)tile[(int)s - 1] ^ 10u;
-                                const uint32_t x3 = (w[3] ^ 0x30303030u) & dmk[0], x4 = (w[4] ^ 0x30303030u) & dmk[1], x5 = (w[5] ^ 0x30303030u) & dmk[2];
-                                bad = bad_name | ((((x3 + 0x76767676u) | x3) | ((x4 + 0x76767676u) | x4) | ((x5 + 0x76767676u) | x5)) & 0x80808080u);
-                                // decimal value: v_dot4_u32_u8 with weights 100, 10, 1 over three digits, the fourth added on top
-                                // (24-bit multiplies: v_mad_u32_u24 is full rate, the 32-bit multiplies are quarter rate)
-                                const uint32_t f3 = __umul24(__builtin_amdgcn_udot4(x3, 0x00010A64u, 0u, false), 10u) + (x3 >> 24);
-                                const uint32_t f4 = __umul24(__builtin_amdgcn_udot4(x4, 0x00010A64u, 0u, false), 10u) + (x4 >> 24);
-                                const uint32_t hi7 = __umul24(f3, 10000u) + f4;          // the first g - 3 digits (< 10^7)
-                                // positions past 2^32 - 1 cannot be in the site set: 4294966 * 1000 + 999 still fits 32 bits
-                                big = hi7 > 4294966u;
-                                pos = __umul24(hi7, 1000u) + __builtin_amdgcn_udot4(x5, 0x00010A64u, 0u, false);
+                                // the last four digits (window bytes 19..22) are the only ones that differ from line to line over long
+                                // stretches of a sorted pileup: SWAR digit test, v_dot4_u32_u8 with weights 100, 10, 1 and one 24-bit multiply-add
+                                const uint32_t xd = (__builtin_amdgcn_alignbyte(w[5], w[4], 3u) ^ 0x30303030u) & dmk4;
+                                bad = bad_name | (((xd + 0x76767676u) | xd) & 0x80808080u);
+                                pos = pos_base + __umul24(__builtin_amdgcn_udot4(xd, 0x00010A64u, 0u, false), 10u) + (xd >> 24);
+                                big = false;
                                 nd_seen = g;
-                                // Everything else only when some line of the round does not fit (one ballot in the steady state).
+                                // A round in which some line does not fit — other top digits (every 10 000 positions), another digit count,
+                                // another contig, a start that is none, odd separators — is done again in the general form, which sorts
+                                // out which it is and sets the layout for the rounds to come.
                                 if (__builtin_amdgcn_ballot_w64(bad != 0) & act_mask) {
-                                    // A start that does not follow '\n' (never in an LF file, every other one in a CR LF file): the
-                                    // '\n' of a "\r\n" pair and a byte after '\v' / '\f' start no line; after a lone '\r' one does
-                                    // start (universal newlines), and the exact parser takes it.
-                                    if (__ballot(active && bad_name != 0)) {
-                                        const uint32_t pv = tile[(int)s - 1], cv = tile[s];
-                                        const bool no_line = active && (pv == 13u ? cv == 10u : pv != 10u);
-                                        const uint64_t nl = __ballot(no_line);
-                                        if (nl) {
-                                            active = active && !no_line;
-                                            lines_seen -= (lane == 0) ? (uint32_t)__popcll(nl) : 0u;
-                                            if (__ballot(no_line && pv == 13u)) crlf_mode = true;
-                                        }
-                                    }
-                                    if (active && bad_name != 0) { mismatch_at = s; nd_seen = 0; }   // another contig, or another digit count
-                                    if (__ballot(active && bad != 0 && bad_name == 0)) { g = 0; mode = 0; }   // a digit count changed
-                                }
-                            } else {
+                                    fast_round = false;
+                                    nd_seen = 0;
+                                    if (++streak >= 4u) { streak = 0; cool = 64u; }      // (a file the layout keeps failing on: general rounds for a while)
+                                } else streak = 0;
+                            }
+                            if (!fast_round) {
                             bad = hint_bad;                                              // uniform: no usable hint
                             {                                                            // is this a line start at all? (as above)
                                 const uint32_t pv = tile[(int)s - 1];
@@ -807,9 +803,12 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                 ++hits;
                             }
                             if (!fast_round) {                                           // the general path calibrates the digit count
-                                const uint64_t okm = __ballot(active && nd_seen != 0 && tabs);   // lines separated otherwise never calibrate it
-                                const uint32_t g_new = okm ? __builtin_amdgcn_readlane(nd_seen, (uint32_t)__ffsll((long long)okm) - 1) : 0u;
-                                if (g_new != g) { g = g_new; relayout(); }
+                                const uint64_t okm = __ballot(active && nd_seen != 0 && tabs && !big);   // lines separated otherwise never calibrate it
+                                // the LAST such line of the round (lanes take their lines in file order): what comes next looks like it
+                                const uint32_t src = 63u - (uint32_t)__clzll((long long)(okm | 1ull));
+                                const uint32_t g_new = okm ? __builtin_amdgcn_readlane(nd_seen, src) : 0u;
+                                const uint32_t top_new = okm && g_new > 4u ? __builtin_amdgcn_readlane(pos, src) / 10000u : 0u;
+                                if (g_new != g || top_new != top) { g = g_new; top = top_new; relayout(); }
                             }
                         }
                     }
