@@ -808,7 +808,8 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                 const uint32_t src = 63u - (uint32_t)__clzll((long long)(okm | 1ull));
                                 const uint32_t g_new = okm ? __builtin_amdgcn_readlane(nd_seen, src) : 0u;
                                 const uint32_t top_new = okm && g_new > 4u ? __builtin_amdgcn_readlane(pos, src) / 10000u : 0u;
-                                if (g_new != g || top_new != top) { g = g_new; top = top_new; relayout(); }
+                                if (cool) { g = 0; mode = 0; }                           // (no new layout while the wave stays general: the first round after that sets it)
+                                else if (g_new != g || top_new != top) { g = g_new; top = top_new; relayout(); }
                             }
                         }
                     }

@@ -22,9 +22,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     (["distance_cli_time.py", "60", "900"], ""),
     (["scan_multi_contig.py", "5", "20000", "2"], ""),
     (["scan_crlf.py"], ""),
+    (["scan_sweep.py", "3", "20", "", "OVERSUB=1"], "GB/s"),
+    (["scan_realloc.py", "3", "20", "2"], "round 1:"),
 ])
 def test_tool_runs_at_toy_size(argv, expect, tmp_path):
-    env = dict(os.environ, TMPDIR=str(tmp_path))
+    env = dict(os.environ, TMPDIR=str(tmp_path), SWEEP_GENOME="60000")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", argv[0])] + argv[1:], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (argv, r.stdout[-1500:], r.stderr[-2500:])
     assert expect in r.stdout, (argv, r.stdout[-1500:])

@@ -20,7 +20,7 @@ def main():
     depth = float(sys.argv[2]) if len(sys.argv) > 2 else 30.0
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 6
     one_arena = os.environ.get("REALLOC_ARENA") == "1"
-    G = 5_000_000
+    G = int(os.environ.get("SWEEP_GENOME", "5000000"))              # (toy sizes for the test of this helper)
     S = G // 100
     contig = b"synth_chr1"
     d = dev.Device(0)

@@ -18,7 +18,7 @@ def main():
     from snp_pipeline_amd import device as dev
     B, depth = int(sys.argv[1]), float(sys.argv[2])
     settings = sys.argv[3:] or [""]
-    G = 5_000_000
+    G = int(os.environ.get("SWEEP_GENOME", "5000000"))              # (toy sizes for the test of this helper)
     S = G // 100
     contig = b"synth_chr1"
     os.environ["SNPGPU_SCAN_RELOAD"] = "1"
