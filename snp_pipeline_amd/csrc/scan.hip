@@ -109,8 +109,19 @@ struct TileView {
     }
 };
 
+// The contig table of a site set, handed to the helpers below BY VALUE: a reference to the kernel's site-set argument would make
+// every wave keep a copy of that argument in scratch memory (4.6 KB written per wave at its start).
+struct ContigTab {
+    const uint8_t *names;
+    const uint32_t *name_off;
+    const uint64_t *bit_off;
+    const uint32_t *max_pos;
+    uint32_t n_contigs;
+};
+__device__ __forceinline__ ContigTab contig_tab(const SiteSetDev &ss) { return ContigTab{ss.names, ss.name_off, ss.bit_off, ss.max_pos, ss.n_contigs}; }
+
 // Bytewise lexicographic compare of a line field with contig name c.
-__device__ int cmp_name(const SiteSetDev &ss, uint32_t c, const TileView &tv, int64_t p0, uint32_t len) {
+__device__ int cmp_name(const ContigTab &ss, uint32_t c, const TileView &tv, int64_t p0, uint32_t len) {
     uint32_t a = ss.name_off[c], nl = ss.name_off[c + 1] - a;
     uint32_t m = len < nl ? len : nl;
     for (uint32_t k = 0; k < m; ++k) {
@@ -120,7 +131,7 @@ __device__ int cmp_name(const SiteSetDev &ss, uint32_t c, const TileView &tv, in
     return (int)len - (int)nl;
 }
 
-__device__ __noinline__ uint32_t find_contig(const SiteSetDev &ss, TileView tv, int64_t f0, uint32_t f0len) {
+__device__ __noinline__ uint32_t find_contig(ContigTab ss, TileView tv, int64_t f0, uint32_t f0len) {
     int lo_i = 0, hi_i = (int)ss.n_contigs - 1;
     while (lo_i <= hi_i) {
         int mid = (lo_i + hi_i) >> 1;
@@ -247,7 +258,7 @@ struct Hint {                // the wave's current contig (all members wave-unif
     uint64_t bit_off;
 };
 
-__device__ __noinline__ Hint load_hint(const SiteSetDev &ss, uint32_t cid, uint32_t *hint_w, uint32_t lane) {
+__device__ __noinline__ Hint load_hint(ContigTab ss, uint32_t cid, uint32_t *hint_w, uint32_t lane) {
     Hint h;
     h.cid = 0xFFFFFFFFu; h.len = 0; h.max_pos = 0; h.bit_off = 0;
     if (cid < ss.n_contigs) {
@@ -418,7 +429,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
         for (int k = 0; k < 6; ++k) { nw[k] = ws.lay[k]; nm[k] = ws.lay[6 + k]; }
         dmk4 = ws.lay[12];
     };
-    if (!kExact) adopt(load_hint(ss, 0, ws.hint_w, lane));
+    if (!kExact) adopt(load_hint(contig_tab(ss), 0, ws.hint_w, lane));
 
     // Every wave takes one contiguous run of its sample's tiles: a pileup is sorted, so the contig hint and the bitmap
     // window survive from one tile to the next.  Shares are static and equal; the launcher makes sure every CU holds
@@ -822,7 +833,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             SlowLine sl = parse_line_slow(tv, s, a.want_depth);
                             if (sl.err) { report_scan_error(f.status, file_off, sl.err); continue; }
                             depth_acc += sl.depth;
-                            const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, sl.f0, sl.f0len) : 0xFFFFFFFFu;
+                            const uint32_t cid = ss.n_contigs ? find_contig(contig_tab(ss), tv, sl.f0, sl.f0len) : 0xFFFFFFFFu;
                             if (cid == 0xFFFFFFFFu || sl.pos > (uint64_t)ss.max_pos[cid]) continue;
                             const uint64_t bit = ss.bit_off[cid] + (uint32_t)sl.pos;
                             const uint32_t word = bitmap[bit >> 5];
@@ -854,9 +865,9 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                     if (same) { g = 0; mode = 0; }
                     else if (len >= 1 && len <= 4 * SCAN_HINT_WORDS - 4) {
                         TileView tv{tile, f.base, t0, f.hi, (int64_t)(SCAN_TILE + SCAN_HALO)};
-                        const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, (int64_t)s1, len) : 0xFFFFFFFFu;
+                        const uint32_t cid = ss.n_contigs ? find_contig(contig_tab(ss), tv, (int64_t)s1, len) : 0xFFFFFFFFu;
                         g = 0; mode = 0;                             // the next round calibrates against the new name
-                        if (cid != 0xFFFFFFFFu) adopt(load_hint(ss, cid, ws.hint_w, lane));
+                        if (cid != 0xFFFFFFFFu) adopt(load_hint(contig_tab(ss), cid, ws.hint_w, lane));
                         else {                                       // not a contig of the site set: remember the name itself
                             if (lane < SCAN_HINT_WORDS) {
                                 uint32_t w = 0;
@@ -907,7 +918,7 @@ __global__ __launch_bounds__(256) void k_scan_queue(ScanArgs a, SiteSetDev ss) {
         SlowLine sl = parse_line_slow(tv, (int64_t)off, a.want_depth);
         if (sl.err) { report_scan_error(f.status, off, sl.err); continue; }
         if (sl.depth) atomicAdd((unsigned long long *)&f.status[3], (unsigned long long)sl.depth);
-        const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, sl.f0, sl.f0len) : 0xFFFFFFFFu;
+        const uint32_t cid = ss.n_contigs ? find_contig(contig_tab(ss), tv, sl.f0, sl.f0len) : 0xFFFFFFFFu;
         if (cid == 0xFFFFFFFFu || sl.pos > (uint64_t)ss.max_pos[cid]) continue;
         const uint64_t bit = ss.bit_off[cid] + (uint32_t)sl.pos;
         const uint32_t word = ss.bitmap[bit >> 5];
@@ -1050,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_lines_flags(const uint8_t *buf, uint64_
         SlowLine sl = parse_line_slow(tv, (int64_t)off, 0);
         if (sl.err) report_scan_error(status, off, sl.err);
         else {
-            const uint32_t cid = ss.n_contigs ? find_contig(ss, tv, sl.f0, sl.f0len) : 0xFFFFFFFFu;
+            const uint32_t cid = ss.n_contigs ? find_contig(contig_tab(ss), tv, sl.f0, sl.f0len) : 0xFFFFFFFFu;
             if (cid != 0xFFFFFFFFu && sl.pos <= (uint64_t)ss.max_pos[cid]) {
                 const uint64_t bit = ss.bit_off[cid] + (uint32_t)sl.pos;
                 const uint32_t word = ss.bitmap[bit >> 5], shf = (uint32_t)(bit & 31);
