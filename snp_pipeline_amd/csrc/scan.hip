@@ -1211,6 +1211,10 @@ uint32_t snpgpu_scan_deal(const snpgpu_ctx *ctx, SampleDev *h, uint32_t n, uint3
     // 16 at 100x — 1 117 — four 74.0, one 72.9; from 800 down one workgroup per CU is as good or better: tools/scan_sweep.py)
     const uint64_t resident = (uint64_t)ctx->n_cu * c.blocks_per_cu * c.waves, per_wave = total_tiles / resident;
     const uint64_t max_waves = resident * (c.oversub ? (per_wave >= (uint64_t)c.oversub_min ? (uint64_t)c.oversub : 1) : per_wave >= 2500 ? 8 : per_wave >= 1000 ? 4 : 1);
+#ifdef SNPGPU_TUNING
+    const uint64_t max_waves_ = (c.mode == 8 || c.mode == 9) ? resident : max_waves;   // the per-wave records of these modes have room for the resident waves only
+#define max_waves max_waves_
+#endif
     uint64_t budget = total_tiles / min_tiles_per_wave, used = 0;
     if (budget > max_waves) budget = max_waves;
     if (budget < n) budget = n;
@@ -1235,6 +1239,9 @@ uint32_t snpgpu_scan_deal(const snpgpu_ctx *ctx, SampleDev *h, uint32_t n, uint3
     }
     uint32_t w0 = 0;
     for (uint32_t i = 0; i < n; ++i) { h[i].wave0 = w0; w0 += h[i].n_waves; }
+#ifdef SNPGPU_TUNING
+#undef max_waves
+#endif
     return w0;
 }
 
