@@ -752,67 +752,75 @@ def dump(name, obj):
     print(name, len(raw), "bytes raw")
 
 
+def _runs3(captured):
+    # line ends: the reference reads the pileup in text mode (universal newlines: "\n", "\r\n" and a lone "\r" end a line;
+    # '\v' / '\f' do not, they are whitespace to str.split()) — files of a few dozen scan tiles through its own driver
+    runs = []
+    for variant in ("crlf", "mixed", "vt_ff", "repeats"):
+        runs += gen_file_runs(captured, [(21, dict(genome_len=2600, n_sites=90, mean_depth=18), PARAM_SETS[1]),
+                                         (22, dict(genome_len=1800, n_sites=60, contigs=("NODE_1_length_419034_cov_23.1", "c")), PARAM_SETS[2])],
+                              line_ends=variant)
+    return {"runs": runs}
+
+
+def _utf8names(captured):
+    # contig names that are not plain ASCII (the reference reads the pileup as text: they are just names to it), one with a '~'
+    runs = gen_file_runs(captured, [(31, dict(genome_len=1500, n_sites=50, contigs=("chr\u00e4", "\u67d3\u8272\u4f531", "a~b")), PARAM_SETS[1]),
+                                    (32, dict(genome_len=2200, n_sites=70, mean_depth=14, contigs=("\u00e9coli_K12", "z")), PARAM_SETS[2])])
+    return {"runs": runs}
+
+
+def _runs2(captured):
+    # later additions: shapes the device kernels treat specially (512-byte lane window, long contig names,
+    # positions around the powers of ten), again through the reference's own driver
+    long_names = ("NODE_1_length_419034_cov_23.1", "scaffold_with_a_very_long_name_that_exceeds_44_bytes_000001", "c")
+    runs = gen_file_runs(captured, [
+        (15, dict(genome_len=900, n_sites=60, mean_depth=140), PARAM_SETS[0]),
+        (16, dict(genome_len=1500, n_sites=70, contigs=long_names), PARAM_SETS[1]),
+        (17, dict(genome_len=10400, n_sites=150), PARAM_SETS[2]),
+        (18, dict(genome_len=800, n_sites=50, mean_depth=220), PARAM_SETS[4]),
+    ], extra_sites=[p10 + d for p10 in (10, 100, 1000, 10000) for d in (-1, 0, 1)])
+    return {"runs": runs}
+
+
+# every committed vector file: slice name -> (file under tests/golden/, generator taking the captured-writes dict).
+# tests/test_golden_regen.py regenerates each one into a scratch directory and compares it with the committed file.
+SLICES = {
+    "pileup": ("pileup_vectors.json.gz", gen_pileup_vectors),
+    "steps": ("steps_vectors.json.gz", lambda captured: gen_steps_vectors()),
+    "cli": ("cli_vectors.json.gz", lambda captured: gen_cli_vectors()),
+    "metrics": ("metrics_vectors.json.gz", lambda captured: gen_metrics_vectors()),
+    "longref": ("longref_vectors.json.gz", lambda captured: gen_longref_vectors()),
+    "runs2": ("pileup_runs2.json.gz", _runs2),
+    "runs3": ("pileup_runs3.json.gz", _runs3),
+    "utf8names": ("pileup_runs_utf8.json.gz", _utf8names),
+    "distance": ("distance_runs.json.gz", lambda captured: {"runs": gen_distance_runs()}),
+    "merge": ("merge_runs.json.gz", lambda captured: {"runs": gen_merge_runs()}),
+    "filter": ("filter_runs.json.gz", lambda captured: {"runs": gen_filter_runs()}),
+    "badlines": ("badline_runs.json.gz", lambda captured: {"runs": gen_bad_line_runs(captured)}),
+}
+
+
 def main():
+    """``gen_golden.py`` writes every slice and the fixture trees; ``--only NAME`` one slice (or ``fixtures``); ``--out DIR``
+    writes there instead of tests/golden/ (what the regeneration test does)."""
+    global GOLD
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", choices=sorted(SLICES) + ["fixtures"])
+    ap.add_argument("--out")
+    opt = ap.parse_args()
+    if opt.out:
+        GOLD = os.path.abspath(opt.out)
     os.makedirs(GOLD, exist_ok=True)
     captured = install_stubs()
-    if sys.argv[1:] == ["--only", "cli"]:
-        dump("cli_vectors.json.gz", gen_cli_vectors())
-        return
-    if sys.argv[1:] == ["--only", "fixtures"]:
+    if opt.only == "fixtures":
         copy_fixtures()
         return
-    if sys.argv[1:] == ["--only", "metrics"]:
-        dump("metrics_vectors.json.gz", gen_metrics_vectors())
-        return
-    if sys.argv[1:] == ["--only", "runs3"]:
-        # line ends: the reference reads the pileup in text mode (universal newlines: "\n", "\r\n" and a lone "\r" end a line;
-        # '\v' / '\f' do not, they are whitespace to str.split()) — files of a few dozen scan tiles through its own driver
-        runs = []
-        for variant in ("crlf", "mixed", "vt_ff", "repeats"):
-            runs += gen_file_runs(captured, [(21, dict(genome_len=2600, n_sites=90, mean_depth=18), PARAM_SETS[1]),
-                                             (22, dict(genome_len=1800, n_sites=60, contigs=("NODE_1_length_419034_cov_23.1", "c")), PARAM_SETS[2])],
-                                  line_ends=variant)
-        dump("pileup_runs3.json.gz", {"runs": runs})
-        return
-    if sys.argv[1:] == ["--only", "utf8names"]:
-        # contig names that are not plain ASCII (the reference reads the pileup as text: they are just names to it), one with a '~'
-        runs = gen_file_runs(captured, [(31, dict(genome_len=1500, n_sites=50, contigs=("chr\u00e4", "\u67d3\u8272\u4f531", "a~b")), PARAM_SETS[1]),
-                                        (32, dict(genome_len=2200, n_sites=70, mean_depth=14, contigs=("\u00e9coli_K12", "z")), PARAM_SETS[2])])
-        dump("pileup_runs_utf8.json.gz", {"runs": runs})
-        return
-    if sys.argv[1:] == ["--only", "distance"]:
-        dump("distance_runs.json.gz", {"runs": gen_distance_runs()})
-        return
-    if sys.argv[1:] == ["--only", "merge"]:
-        dump("merge_runs.json.gz", {"runs": gen_merge_runs()})
-        return
-    if sys.argv[1:] == ["--only", "filter"]:
-        dump("filter_runs.json.gz", {"runs": gen_filter_runs()})
-        return
-    if sys.argv[1:] == ["--only", "badlines"]:
-        dump("badline_runs.json.gz", {"runs": gen_bad_line_runs(captured)})
-        return
-    if sys.argv[1:] == ["--only", "longref"]:
-        dump("longref_vectors.json.gz", gen_longref_vectors())
-        return
-    if sys.argv[1:] == ["--only", "runs2"]:
-        # later additions: shapes the device kernels treat specially (512-byte lane window, long contig names,
-        # positions around the powers of ten), again through the reference's own driver
-        long_names = ("NODE_1_length_419034_cov_23.1", "scaffold_with_a_very_long_name_that_exceeds_44_bytes_000001", "c")
-        runs = gen_file_runs(captured, [
-            (15, dict(genome_len=900, n_sites=60, mean_depth=140), PARAM_SETS[0]),
-            (16, dict(genome_len=1500, n_sites=70, contigs=long_names), PARAM_SETS[1]),
-            (17, dict(genome_len=10400, n_sites=150), PARAM_SETS[2]),
-            (18, dict(genome_len=800, n_sites=50, mean_depth=220), PARAM_SETS[4]),
-        ], extra_sites=[p10 + d for p10 in (10, 100, 1000, 10000) for d in (-1, 0, 1)])
-        dump("pileup_runs2.json.gz", {"runs": runs})
-        return
-    dump("pileup_vectors.json.gz", gen_pileup_vectors(captured))
-    dump("steps_vectors.json.gz", gen_steps_vectors())
-    dump("cli_vectors.json.gz", gen_cli_vectors())
-    dump("metrics_vectors.json.gz", gen_metrics_vectors())
-    dump("longref_vectors.json.gz", gen_longref_vectors())
-    copy_fixtures()
+    for name in ([opt.only] if opt.only else list(SLICES)):
+        fname, gen = SLICES[name]
+        dump(fname, gen(captured))
+    if not opt.only:
+        copy_fixtures()
 
 
 if __name__ == "__main__":

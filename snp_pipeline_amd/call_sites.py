@@ -49,6 +49,18 @@ def site_calling_mode(given=None):
     return mode
 
 
+DEVICE_PASS_NOTE = ("# site calling: device pass (parity unpinned) - no VarScan jar on CLASSPATH; the read counting and line selection of "
+                    "csrc/varscan.hip follow oracle/varscan_oracle.py, which no file of the reference pins.  Put the jar on CLASSPATH "
+                    "(mode varscan) or supply var.flt.vcf (mode existing) for the reference's own sites.")
+
+
+def log_site_calling_mode(mode):
+    """One line in the step log naming the route; whenever it is the device pass, say that its parity is unpinned."""
+    verbose_print("# site calling mode: %s" % mode)
+    if mode == "device":
+        verbose_print(DEVICE_PASS_NOTE)
+
+
 def _run(command_line, outfile=None):
     """command.run (command.py:17-88): a shell command with stdout captured or written to a file, stderr inherited;
     CalledProcessError for a non-zero exit when writing to a file."""
@@ -223,6 +235,7 @@ def call_sites(args):
         extra = os.environ.get("VarscanMpileup2snp_ExtraParams") or ""
         opts = varscan.Options(extra)
         verbose_print("# Create vcf file")
+        verbose_print(DEVICE_PASS_NOTE)
         verbose_print("# %s mpileup2snp (device) %s --output-vcf 1 %s" % (utils.timestamp(), pileup_file, extra))
         from .device import default_device
         open(vcf_file, "w").close()                          # as command.run does for its target: a failed pass leaves no stale var.flt.vcf behind
@@ -281,7 +294,7 @@ def call_sites_batch(args):
                     bad.add(sample_dir)
                     failed += 1
     mode = site_calling_mode(getattr(args, "siteCalling", None))
-    verbose_print("# site calling mode: %s" % mode)
+    log_site_calling_mode(mode)
     todo = [t for t in todo if t[0] not in bad]
     if mode == "existing":                                       # var.flt.vcf is an input: checked, never written
         for t in todo:

@@ -182,7 +182,10 @@ struct PyInt {
     bool neg = false, bad = false, last_digit = false;
     __device__ __forceinline__ void feed(uint32_t c) {
         if (n == 0 && (c == '+' || c == '-')) neg = c == '-';
-        else if (is_digit(c)) { v = v * 10 + (c - 48u); if (v > (1ull << 62)) v = 1ull << 62; last_digit = true; }
+        else if (is_digit(c)) {                                  // (saturate BEFORE the multiply: 2^62 * 10 wraps in 64 bits)
+            v = v > ((1ull << 62) - 9u) / 10u ? 1ull << 62 : v * 10 + (c - 48u);
+            last_digit = true;
+        }
         else if (c == '_' && last_digit) last_digit = false;     // an underscore sits between two digits
         else bad = true;
         ++n;

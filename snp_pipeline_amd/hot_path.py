@@ -448,7 +448,7 @@ def stage_ingest_and_sites(job):
     job.arena_thread = threading.Thread(target=_alloc_arenas, args=(job,))
     job.arena_thread.start()
     todo = [s for s in job.mine if s.ok]
-    verbose_print("# site calling mode: %s" % job.site_calling)
+    cs.log_site_calling_mode(job.site_calling)
     if job.site_calling == "device":
         _ingest_with_device_site_calling(job, todo)
     else:

@@ -562,6 +562,18 @@ def test_python_int_fields(d):
         assert int(res.spill[(int(c["n_symbols"]) >> 8) - 1]["depth64"]) == want and int(c["good_depth"]) == 3
     with pytest.raises(PileupFormatError):
         gpu_consensus(d, b"c1\t5\tA\t4611686018427387904\t...\tIII\n", keys, [], po.CallerParams())
+    # fields of 20 to 25 digits: int() takes them whole, so such a position is in no site set — 2^64 + 4 must not come out as 4
+    # (the accumulator saturates before its multiply) — and such a depth is refused like any other from 2^62 on
+    for pos in (b"18446744073709551620", b"18446744073709551621", b"184467440737095516165", b"9999999999999999999999999", b"46116860184273879045",
+                b"+18446744073709551620", b"18_446_744_073_709_551_620"):
+        data = b"c1\t7\tC\t2\tGG\tII\nc1\t" + pos + b"\tA\t3\t...\tIII\nc1\t10\tC\t2\tTT\tII\n"
+        res = check_against_oracle(d, data, [(b"c1", 4), (b"c1", 5), (b"c1", 7), (b"c1", 10)], [], po.CallerParams(0, 0.6, 1, 0, 0.0))
+        assert res.n_lines == 3 and res.n_matched == 2
+    for depth in (b"20000000000000000000", b"18446744073709551619", b"9999999999999999999999999"):
+        with pytest.raises(PileupFormatError):
+            gpu_consensus(d, b"c1\t5\tA\t" + depth + b"\t...\tIII\n", keys, [], po.CallerParams())
+        got = d.call_consensus(d.siteset(keys, [1] * len(keys)), b"c1\t9\tA\t" + depth + b"\t...\tIII\n", __import__("snp_pipeline_amd.device", fromlist=["x"]).make_params())
+        assert got.n_lines == 1 and got.n_matched == 0                  # (a line that is not listed is never converted: pileup.py:426-429)
 
 
 def test_the_first_malformed_line_in_file_order_decides_the_exception(d, tmp_path):
