@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SNPGPU_ABI_VERSION 5
+#define SNPGPU_ABI_VERSION 6
 
 /* ---- error codes ------------------------------------------------------- */
 #define SNPGPU_OK            0
@@ -293,6 +293,17 @@ int  snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_
 /* The same over a pileup that already is in device memory. */
 int  snpgpu_varscan_dev(snpgpu_ctx *ctx, const void *d_pileup, uint64_t nbytes, const snpgpu_varscan_params *params,
                         uint32_t capacity, snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status);
+
+/* The same over MANY pileups that are in device memory (the resident files of a snpgpu_pileups store, synthetic ones): one
+ * scan launch over all of them — every wave works inside one file, the waves are dealt to the files by size — so the ramp and
+ * the tail of a launch are paid once per call, not once per 0.1 ms file.  Arguments as snpgpu_varscan_files: out_sites is
+ * [n_files][capacity], out_n_sites [n_files], out_status [n_files][2], out_rc [n_files] (SNPGPU_OK or SNPGPU_E_PILEUP per
+ * file); a file with more records than `capacity` reports its count and leaves its out_sites undefined (repeat it with
+ * snpgpu_varscan_dev).  At most 65 535 files per call.  What the reference does per sample with one JVM each
+ * (call_sites.py:89-108, run.py:662 runs them as a job array). */
+int  snpgpu_varscan_batch_dev(snpgpu_ctx *ctx, const void *const *d_pileups, const uint64_t *nbytes, uint32_t n_files,
+                              const snpgpu_varscan_params *params, uint32_t capacity, snpgpu_varscan_site *out_sites,
+                              uint32_t *out_n_sites, uint64_t *out_status, int32_t *out_rc);
 
 /* ---- resident pileups: the input side of the one-job pipeline (`cfsan_snp_pipeline hot_path_batch`) ----------------------
  * The reference runs steps 4-11 as separate process arrays over a shared file system (run.py:662-784): call_sites

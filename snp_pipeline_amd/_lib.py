@@ -116,6 +116,7 @@ SIGNATURES = {
     "snpgpu_write_consensus_files": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.POINTER(C.c_char_p), C.c_int, C.c_char, _P, C.c_uint32,
                                                C.c_uint32]),
     "snpgpu_varscan_dev": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P, C.POINTER(C.c_uint32), _P]),
+    "snpgpu_varscan_batch_dev": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, _P, _P, _P]),
     "snpgpu_pileups_create": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
     "snpgpu_pileups_destroy": (None, [_P]),
     "snpgpu_pileups_ingest": (C.c_int, [_P, _P, C.POINTER(C.c_char_p), C.c_uint32, _P, C.c_uint32, _P, _P, _P, _P, _P]),

@@ -135,6 +135,12 @@ size_t snpgpu_varscan_scratch_bytes(uint64_t nbytes);
 int snpgpu_varscan_halo_class(const uint8_t *head, uint64_t n);
 int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, const snpgpu_varscan_params *prm, snpgpu_varscan_site *d_sites,
                            uint32_t capacity, uint32_t *d_ctl, uint64_t *d_status, void *d_scratch, int halo_class);
+// ... many resident pileups in one launch (see varscan.hip); h_table: snpgpu_varscan_table_bytes(n_files) bytes of host memory that stay valid
+// until the stream has passed the call
+size_t snpgpu_varscan_batch_scratch_bytes(uint64_t total_bytes, uint32_t n_files);
+size_t snpgpu_varscan_table_bytes(uint32_t n_files);
+int snpgpu_enqueue_varscan_batch(snpgpu_ctx *ctx, const uint8_t *const *d_bufs, const uint64_t *nbytes, uint32_t n_files, const snpgpu_varscan_params *prm,
+                                 snpgpu_varscan_site *d_sites, uint32_t capacity, uint32_t *d_ctl, uint64_t *d_status, void *d_scratch, void *h_table);
 // ... and the wave-per-site call kernel over such a list (consensus.hip): "site" i is line i
 int snpgpu_enqueue_call_lines(snpgpu_ctx *ctx, const SampleDev *d_sample, const uint64_t *d_line_off, const uint8_t *d_flags,
                               uint32_t n_lines, const snpgpu_caller_params *prm, uint8_t *d_out_base, uint8_t *d_out_filters,

@@ -843,12 +843,6 @@ int varscan_resident(snpgpu_ctx *ctx, const uint8_t *d_file, uint64_t nbytes, co
     *out_n_sites = 0;
     out_status[0] = ~0ull; out_status[1] = 0;
     if (nbytes == 0) return SNPGPU_OK;
-    // how long the lines are, from the file's first bytes: decides how much of the next tile a tile's LDS window takes along
-    uint8_t head[16384];
-    const uint64_t n_head = nbytes < sizeof head ? nbytes : sizeof head;
-    HIP_TRY(ctx, hipMemcpyAsync(head, d_file, n_head, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    const int halo_class = snpgpu_varscan_halo_class(head, n_head);
     size_t o = 0;
     const size_t o_ctl = o; o += 256;                          // [0] u64 status, then the kernels' eight control words
     const size_t o_rec = o; o += up(sizeof(snpgpu_varscan_site) * (size_t)capacity, 256);
@@ -860,13 +854,13 @@ int varscan_resident(snpgpu_ctx *ctx, const uint8_t *d_file, uint64_t nbytes, co
     uint64_t h_ctl[5] = {~0ull, 0, 0, 0, 0};                    // status; records found + candidates; long candidates + spare; lines; spare
     HIP_TRY(ctx, hipMemcpyAsync(b + o_ctl, h_ctl, sizeof h_ctl, hipMemcpyHostToDevice, st));
     rc = snpgpu_enqueue_varscan(ctx, d_file, nbytes, params, (snpgpu_varscan_site *)(b + o_rec), capacity, (uint32_t *)(b + o_ctl + 8), (uint64_t *)(b + o_ctl),
-                                b + o_var, halo_class);
+                                b + o_var, 0);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(h_ctl, b + o_ctl, sizeof h_ctl, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
 #ifdef SNPGPU_TUNING
     if (getenv("SNPGPU_VARSCAN_DEBUG"))
-        fprintf(stderr, "varscan: halo class %d, %llu lines, candidates %u, long %u\n", halo_class, (unsigned long long)h_ctl[3], (uint32_t)(h_ctl[1] >> 32), (uint32_t)h_ctl[2]);
+        fprintf(stderr, "varscan: %llu lines, %u candidates on the global list\n", (unsigned long long)h_ctl[3], (uint32_t)(h_ctl[1] >> 32));
 #endif
     out_status[0] = h_ctl[0];
     out_status[1] = h_ctl[3];
@@ -882,6 +876,60 @@ int varscan_resident(snpgpu_ctx *ctx, const uint8_t *d_file, uint64_t nbytes, co
             std::sort(out_sites, out_sites + got, [](const snpgpu_varscan_site &x, const snpgpu_varscan_site &y) {
                 return x.line_off != y.line_off ? x.line_off < y.line_off : x.alt_base < y.alt_base;
             });
+    }
+    return SNPGPU_OK;
+}
+
+// The same for many resident pileups at once: ONE scan launch over all of them (varscan.hip), one copy of the control words back,
+// then the records of every file.  Synchronous.  out_sites [n_files][capacity], out_n_sites [n_files], out_status [n_files][2],
+// out_rc [n_files].
+int varscan_resident_batch(snpgpu_ctx *ctx, const void *const *d_pileups, const uint64_t *nbytes, uint32_t n_files, const snpgpu_varscan_params *params,
+                           uint32_t capacity, snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status, int32_t *out_rc) {
+    hipStream_t st = ctx->stream;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_files; ++i) {
+        if (nbytes[i] && !d_pileups[i]) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null pileup %u", i);
+        total += nbytes[i];
+        out_n_sites[i] = 0; out_status[2 * i] = ~0ull; out_status[2 * i + 1] = 0; out_rc[i] = SNPGPU_OK;
+    }
+    size_t o = 0;
+    const size_t o_ctl = o; o += up(40 * (size_t)n_files, 256);                      // per file: u64 status, eight control words
+    const size_t o_rec = o; o += up(sizeof(snpgpu_varscan_site) * (size_t)capacity * n_files, 256);
+    const size_t o_var = o; o += up(snpgpu_varscan_batch_scratch_bytes(total, n_files), 256);
+    void *scr = nullptr;
+    int rc = snpgpu_scratch(ctx, o + 256, &scr);
+    if (rc) return rc;
+    char *b = (char *)scr;
+    // the status words first (n_files u64), then the control words (n_files x 8 u32)
+    std::vector<uint64_t> h_ctl(5 * (size_t)n_files, 0);
+    for (uint32_t i = 0; i < n_files; ++i) h_ctl[i] = ~0ull;
+    std::vector<char> h_table(snpgpu_varscan_table_bytes(n_files));
+    HIP_TRY(ctx, hipMemcpyAsync(b + o_ctl, h_ctl.data(), 40 * (size_t)n_files, hipMemcpyHostToDevice, st));
+    rc = snpgpu_enqueue_varscan_batch(ctx, (const uint8_t *const *)d_pileups, nbytes, n_files, params, (snpgpu_varscan_site *)(b + o_rec), capacity,
+                                      (uint32_t *)(b + o_ctl + 8 * (size_t)n_files), (uint64_t *)(b + o_ctl), b + o_var, h_table.data());
+    if (rc) { (void)hipStreamSynchronize(st); return rc; }
+    HIP_TRY(ctx, hipMemcpyAsync(h_ctl.data(), b + o_ctl, 40 * (size_t)n_files, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));                   // (h_table and h_ctl have been read by then)
+    const uint32_t *words = (const uint32_t *)(h_ctl.data() + n_files);
+    for (uint32_t i = 0; i < n_files; ++i) {
+        const uint32_t *w = words + 8 * (size_t)i;
+        uint64_t lines;
+        memcpy(&lines, w + 4, 8);
+        out_status[2 * i] = h_ctl[i];
+        out_status[2 * i + 1] = lines;
+        out_n_sites[i] = w[0];
+        if (h_ctl[i] != ~0ull) { out_rc[i] = SNPGPU_E_PILEUP; continue; }
+        const uint32_t got = w[0] < capacity ? w[0] : capacity;
+        if (got) HIP_TRY(ctx, hipMemcpyAsync(out_sites + (size_t)i * capacity, b + o_rec + sizeof(snpgpu_varscan_site) * (size_t)capacity * i,
+                                             sizeof(snpgpu_varscan_site) * (size_t)got, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (uint32_t i = 0; i < n_files; ++i) {
+        if (out_rc[i] != SNPGPU_OK || out_n_sites[i] > capacity) continue;           // (more records than the array holds: the caller repeats that file alone)
+        snpgpu_varscan_site *dst = out_sites + (size_t)i * capacity;
+        std::sort(dst, dst + out_n_sites[i], [](const snpgpu_varscan_site &x, const snpgpu_varscan_site &y) {
+            return x.line_off != y.line_off ? x.line_off < y.line_off : x.alt_base < y.alt_base;
+        });
     }
     return SNPGPU_OK;
 }
@@ -1424,6 +1472,16 @@ int snpgpu_varscan_dev(snpgpu_ctx *ctx, const void *d_pileup, uint64_t nbytes, c
     if (capacity && !out_sites) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
     HIP_TRY(ctx, snpgpu_enter(ctx));
     return varscan_resident(ctx, (const uint8_t *)d_pileup, nbytes, "the resident pileup", params, capacity, out_sites, out_n_sites, out_status);
+}
+
+// Many resident pileups, one launch.
+int snpgpu_varscan_batch_dev(snpgpu_ctx *ctx, const void *const *d_pileups, const uint64_t *nbytes, uint32_t n_files, const snpgpu_varscan_params *params,
+                             uint32_t capacity, snpgpu_varscan_site *out_sites, uint32_t *out_n_sites, uint64_t *out_status, int32_t *out_rc) {
+    if (!ctx || !params || !out_n_sites || !out_status || !out_rc || (n_files && (!d_pileups || !nbytes)) || (capacity && !out_sites))
+        return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (!n_files) return SNPGPU_OK;
+    HIP_TRY(ctx, snpgpu_enter(ctx));
+    return varscan_resident_batch(ctx, d_pileups, nbytes, n_files, params, capacity, out_sites, out_n_sites, out_status, out_rc);
 }
 
 int snpgpu_varscan_files(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, const snpgpu_varscan_params *params, uint32_t capacity,

@@ -7,11 +7,14 @@
 // min-avg-qual / min-var-freq.  Lines that pass leave one 48-byte record per passing allele; Fisher's exact test, the
 // strand filter and the VCF text are host work on those few records (snp_pipeline_amd/varscan.py).
 //
-// One lane per line over the line index of scan.hip (k_lines_index); a wave first copies the contiguous span of its 64
-// lines to LDS with 16-byte loads, so every byte of the file crosses HBM once and the byte-wise walk of the read-base
-// automaton runs out of LDS (a span over the wave's LDS — 64 very deep lines — is read from global memory instead).  The file arrives over PCIe at ~50 GB/s, so the pass as a whole is bounded by that
-// copy, not by this kernel.  The read-base automaton follows the restatement in oracle/varscan_oracle.py (which tests
-// compare it with); see its header for what the reference's fixtures pin.
+// k_varscan_scan reads the text once (one launch over any number of resident pileups; every wave a run of 4 KiB tiles of one file,
+// streamed through a ring of three LDS slots by LDS-DMA), decides per line in constant time whether it can call anything, and walks
+// the few lines that can with the exact read-base automaton when its tiles are done; k_varscan_finish takes what is left over and adds
+// up the line counts (see the comment above k_varscan_scan).  A file arrives over PCIe at ~50 GB/s, so from files the pass is bounded
+// by that copy; over resident pileups it is bounded by HBM and the VALU.  The read-base automaton follows the restatement in
+// oracle/varscan_oracle.py (which tests compare it with); see its header for what the reference's fixtures pin.
+#include <string.h>
+
 #include "internal.h"
 #include "prims.h"
 
@@ -21,11 +24,6 @@ struct Acc { uint32_t f, r, q; };
 
 __device__ __forceinline__ bool is_digit(uint32_t c) { return c - 0x30u < 10u; }
 
-constexpr uint32_t VS_CAND_LOCAL = 256;
-// A list entry: the line's index (bits 0-31), and for a line whose shape k_varscan_select has checked (VS_ENTRY_PLAIN) its depth
-// (bits 32-51) and where, counted from the line's first byte, its second and fourth TAB are (bits 52-56, 57-61)
-constexpr uint64_t VS_ENTRY_PLAIN = 1ull << 63;
-          // candidate lines a select wave collects in LDS before it takes a place on the list
 
 // Where a block reads its lines: the LDS copy of its span (32-bit offsets into it) or the file in global memory.
 struct LdsBytes {
@@ -318,566 +316,680 @@ __device__ __forceinline__ bool varscan_parse_lds(const uint32_t *lds32, uint32_
     return true;
 }
 
-// ---- two passes over what matters: scan + select every line, then walk the few that can call something ------------------------
+// ---- one pass over the text: scan + select every line, walk the few that can call something -----------------------------------
 // Nearly every line of a real pileup cannot reach min-reads2 for any allele, and the byte-wise walk over its read bases — 90 % of
-// this step's instructions in round 2 — computes nothing that is used.  So the step runs as two kernels, and since round 4 the
-// first of them needs NO line index and has no loop over the bytes of a line: k_varscan_scan reads the text once, in tiles, and
-// per tile
-//   A1  classifies every byte, 16 at a time, into three bit strings over the tile: line terminators, TABs, and "letters" — bytes
-//       with bit 6 set and bit 3 clear.  Every read-base letter (ACGTacgt: 0x41 43 47 54 and 0x20 more) is such a byte; N, n and
-//       '^' are not (bit 3), '$', digits, '.', ',' are not (bit 6); a mapping-quality character after '^' or a letter inside an
-//       indel may be, which only makes a count of them an upper bound of any allele's reads;
-//   A2  turns the terminator string into the list of line starts (a wave prefix sum) and the other two into running counts per
-//       32 bytes;
-//   B   gives every line one lane, which answers in constant time, from the bit strings alone: where are the first four TABs
-//       (find-first-set on 64 bits of the TAB string), the depth (one unaligned load, SWAR digits), is the fifth TAB where a
-//       quality column of exactly `depth` bytes puts it, are there five TABs in all (difference of two running counts), how many
-//       letters has the read-base column (another difference).
-// A line whose shape checks out ("plain") with fewer letters than min-reads2 cannot call anything and is done; with at least that
-// many it goes on the candidate list; a line the shortcut cannot vouch for goes on the list as it is and the walk parses it in
-// full (format errors included).  k_varscan_walk then gives every lane one candidate: the lane copies its line into its own strip
-// of LDS and runs the exact automaton over it.  Round 3 looked at every byte of every line in a lane-per-line loop (a third of the
-// lanes idle at 100x) and put every line with ANY letter on the list — 14 % of the lines at 30x, 39 % at 100x, which made the
-// walk grow 6.4 x for 2.6 x the bytes; now it is the variant sites and little else, at any depth.
+// this step's instructions in round 2 — computes nothing that is used.  So the scan (k_varscan_scan) reads the text once, has no
+// loop over the bytes of a line, and only the lines that might call something ("candidates") are walked with the exact automaton.
+// Round 5: the scan has no list of line starts and no window geometries any more (rounds 3-4 built the list with a wave prefix sum
+// in LDS and re-classified a halo of 6-100 % of every tile); a launch serves any number of pileups; a wave walks its own
+// candidates when its tiles are done, so a file costs one launch and a fixed-size epilogue, not three dependent ones.
+//
+// A wave owns a contiguous run of 4 KiB tiles of ONE file and a ring of three tile slots in LDS: tile k+1 streams into its slot with
+// LDS-DMA (global_load_lds_dwordx4, four wave instructions, no register round trip, counted s_waitcnt) while tile k is classified
+// and the lines that START in tile k-1 are looked at — by then their ends (in tile k-1 or k) are known, so nothing is classified
+// twice and a line of up to 4 KiB needs no special case.  Per tile:
+//   A  a lane owns 64 CONTIGUOUS bytes (four conflict-free ds_read_b128, chunk order i ^ ((lane >> 2) & 3)) and classifies them with
+//      SWAR adds on 8 bytes at a time into three 64-bit masks: terminators (bytes 0x0A..0x0D: w + 0x76 carries into bit 7, w + 0x72
+//      does not), TABs (w + 0x77 carries, w + 0x76 does not: the sums are shared), "letters" (bit 6 set, bit 3 clear: every
+//      ACGTacgt, no N / '^' / digit / '.' / ','), gathered with v_dot4_u32_u8.  The TAB and letter masks go to LDS as bit strings
+//      over the ring together with running counts per 32 bytes (one wave prefix sum of packed popcounts); the terminator mask
+//      stays in registers: the terminators a lane found are the lines it looks at.  Every flagged terminator is read back once:
+//      the first that is not LF (CR, VT, FF) switches the wave to exact LF / CR masks and Java's readLine() rules for good.
+//   B  one lane per line, one line per lane and round (30x: one round per tile): the line behind the lane's lowest terminator
+//      left; it ends at the lane's next terminator, else at the first one of the next lane that has any (one ballot, one
+//      ds_bpermute), else at the first one of tile k.  The lane answers in constant time from the strings: the first four TABs
+//      (find-first-set over 32, for long contig names 64, bits), the depth (one unaligned load, SWAR digit test, v_dot4 decimal),
+//      the fifth TAB where a quality column of exactly `depth` bytes puts it, five TABs in all and the letters of the read-base
+//      column (differences of running counts).  A well-formed ("plain") line with fewer letters than min-reads2 cannot call
+//      anything and is done; with at least that many it becomes a 16-byte candidate entry (file offset, length, depth, TAB
+//      places); a line the shortcut cannot vouch for becomes an entry as it is, and the walk parses it in full (format errors
+//      included).  A line that does not end by tile k (> 4 KiB) is left to the epilogue kernel with its end unknown.
+// Candidates collect in the wave's LDS.  When the wave's tiles are done its ring is free: the wave packs its candidates' lines back
+// to back into it (16-byte loads, mostly L2 hits) and every lane runs the exact read-base automaton over its own line
+// (varscan_core_lds).  What does not fit — or overflows the local list in mid-run — goes to a global list for k_varscan_finish,
+// which also adds up the line counts of the waves per file.
 
-// A list entry (16 bytes): x, y = file offset of the line's first byte; z = its length in bytes (terminator included; 0 for a
-// line that did not end inside the tile's LDS window: VS_W_LONG, the walk finds its end itself); w = what the walk need not find
-// out again for a line whose shape the scan has checked (VS_W_PLAIN): depth (bits 0-13), and where, counted from the line's
-// first byte, its second and fourth TAB are (bits 14-19, 20-25)
+// A list entry (16 bytes): x, y = file offset of the line's first byte (48 bits) and, in the upper half of y, the index of the file
+// in the launch; z = its length in bytes (terminator included; 0 for a line whose end the scan does not know: VS_W_LONG, the walk
+// finds it); w = what the walk need not find out again for a line whose shape the scan has checked (VS_W_PLAIN): depth (bits
+// 0-13), and where, counted from the line's first byte, its second and fourth TAB are (bits 14-19, 20-25)
 constexpr uint32_t VS_W_PLAIN = 1u << 31, VS_W_LONG = 1u << 30;
 
+#define VS_TILE 4096u
+#define VS_RING (3u * VS_TILE)
+#define VS_MIRROR 128u                        // the ring's first bytes again behind its end: short reads need no wrap-around
+#define VS_STR_WORDS (VS_RING / 32u)          // dwords of a bit string (and entries of the running counts) over the ring
+#define VS_STR_PAD 4u                         // ... and the first four again behind the end
+#define VS_CAND_LOCAL 128u                    // candidate entries a wave holds in LDS
+constexpr uint32_t VS_LDS_WAVE = VS_RING + VS_MIRROR + 3u * (VS_STR_WORDS + VS_STR_PAD) * 4u + VS_CAND_LOCAL * 16u;   // 19 120 bytes: eight waves per CU
+#define VS_NONE 0xFFFFFFFFu
+
+// One pileup of a launch: an entry of the device table, or (a launch over one file) a kernel argument.
+struct VsFile {
+    const uint8_t *abase;       // 16-byte aligned, 16..31 bytes below the file's first byte
+    uint64_t lo, hi;            // the file is abase[lo, hi); position lo - 1 and position hi count as '\n'
+    uint64_t n_tiles;           // tiles of VS_TILE bytes over abase[0, hi]
+    uint32_t wave0, n_waves;    // its waves in the launch
+    snpgpu_varscan_site *out;   // records
+    uint32_t capacity, pad;
+    uint32_t *ctl;              // [0] records found, [4..5] lines of the file (u64)
+    unsigned long long *status; // offset of the first malformed line (preset to UINT64_MAX)
+};
+// where the walk of one file's lines reads and writes
+struct VsOut {
+    const uint8_t *buf; uint64_t nbytes; snpgpu_varscan_site *out; uint32_t capacity; uint32_t *out_n; unsigned long long *status;
+};
+__device__ __forceinline__ VsOut vs_out(const VsFile &f) { return VsOut{f.abase + f.lo, f.hi - f.lo, f.out, f.capacity, f.ctl, f.status}; }
+
 // A candidate straight from global memory, byte by byte (the generic form of the walk; also what a full list falls back on).
-__device__ __noinline__ void walk_entry_global(const uint8_t *buf, uint64_t nbytes, uint4 e, const snpgpu_varscan_params &prm, snpgpu_varscan_site *out,
-                                               uint32_t capacity, uint32_t *out_n, unsigned long long *status) {
-    const uint64_t p0 = (uint64_t)e.x | ((uint64_t)e.y << 32);
+__device__ __noinline__ void walk_entry_global(VsOut o, uint4 e, const snpgpu_varscan_params &prm) {
+    const uint64_t p0 = (uint64_t)e.x | ((uint64_t)(e.y & 0xFFFFu) << 32);
     uint64_t end = p0 + e.z;
     if (e.w & VS_W_LONG) {                                                              // ends at the first line terminator
         end = p0;
-        while (end < nbytes && buf[end] != 10u && buf[end] != 13u) ++end;
+        while (end < o.nbytes && o.buf[end] != 10u && o.buf[end] != 13u) ++end;
     }
-    varscan_line<uint64_t>(GlobalBytes{buf}, p0, end < nbytes ? end : nbytes, 0, prm, out, capacity, out_n, status);
+    varscan_line<uint64_t>(GlobalBytes{o.buf}, p0, end < o.nbytes ? end : o.nbytes, 0, prm, o.out, o.capacity, o.out_n, o.status);
 }
 
-#define VS_LIST_CAP 256u          // line starts held in LDS per pass (a tile with more makes extra passes)
-#define VS_CAND_LOCAL 96u         // candidate entries a wave collects in LDS before it takes a place on the list
-
-// A1 for one chunk: the 16 bytes of v -> 16 bits of each string.  The SWAR tests run on 8 bytes at a time (one v_lshl_add_u64 per
-// add), and two dwords' flags are gathered into one register by a second v_dot4 that accumulates with weights 16 times the first's.
-__device__ __forceinline__ uint32_t gather16(uint64_t f_lo, uint64_t f_hi, uint32_t shift) {
-    // f: flag bit `shift` of every byte (7, or 6 for the letters); byte k of the chunk -> bit k
-    uint32_t a = __builtin_amdgcn_udot4((uint32_t)f_lo, 0x08040201u, 0u, false);
-    a = __builtin_amdgcn_udot4((uint32_t)(f_lo >> 32), 0x80402010u, a, false);
-    uint32_t b = __builtin_amdgcn_udot4((uint32_t)f_hi, 0x08040201u, 0u, false);
-    b = __builtin_amdgcn_udot4((uint32_t)(f_hi >> 32), 0x80402010u, b, false);
-    return ((a >> shift) & 0xFFu) | (((b >> shift) & 0xFFu) << 8);
+// The candidates of a wave's lanes (`have`: this lane has one) packed back to back into `strips` (16-byte chunks; a wave prefix sum
+// of the chunk counts gives every lane its place) and walked there, every lane its own.  Returns whether this lane's candidate has
+// been dealt with; false: it found no room this time (or has no known end: VS_W_LONG).
+__device__ __forceinline__ bool walk_in_strips(uint4 *strips, uint32_t strip_bytes, bool have, uint4 e, const VsOut &o, const snpgpu_varscan_params &prm) {
+    const bool is_long = have && (e.w & VS_W_LONG);
+    const uint64_t p0 = (uint64_t)e.x | ((uint64_t)(e.y & 0xFFFFu) << 32), end = p0 + e.z;
+    const uint64_t a0 = ((uintptr_t)o.buf + p0) & ~(uint64_t)15, a1 = (have && !is_long) ? (((uintptr_t)o.buf + end) + 15) & ~(uint64_t)15 : a0;
+    const uint32_t chunks = a1 - a0 > 0xFFFFFFull ? 0xFFFFFFu / 16u : (uint32_t)((a1 - a0) / 16);
+    const bool alone_fits = (uint64_t)chunks * 16 <= strip_bytes;
+    const uint32_t mine_chunks = alone_fits ? chunks : 0u;
+    const uint32_t incl = wave_inclusive_sum(mine_chunks);
+    const uint32_t first_chunk = incl - mine_chunks;
+    const bool fits = alone_fits && (uint64_t)incl * 16 <= strip_bytes;
+    if (!(have && !is_long && fits)) return false;
+    uint4 *mine = strips + first_chunk;
+    const uint4 *src = (const uint4 *)a0;
+    for (uint32_t c = 0; c < chunks; ++c) mine[c] = src[c];
+    const uint32_t lane0 = first_chunk * 16u;                                           // LDS offset of this lane's bytes
+    const uint64_t a0_off = a0 - (uintptr_t)o.buf;                                      // their file offset (may be "negative": the chunk starts below the file)
+    const uint32_t *lds32 = (const uint32_t *)strips;
+    const uint32_t l0 = lane0 + (uint32_t)(p0 - a0_off);
+    uint32_t l1 = lane0 + (uint32_t)(end - a0_off);
+    LineCols cols;
+    bool ok;
+    if (e.w & VS_W_PLAIN) {                                                             // the columns are where the scan found them
+        while (l1 > l0) { const uint32_t c = (lds32[(l1 - 1u) >> 2] >> (((l1 - 1u) & 3u) * 8u)) & 0xFFu; if (c != 10u && c != 13u) break; --l1; }
+        const uint32_t depth = e.w & 0x3FFFu, t1 = l0 + ((e.w >> 14) & 63u), t3 = l0 + ((e.w >> 20) & 63u);
+        const uint32_t t4 = l1 - depth - 1u;
+        cols = LineCols{t1 + 1u, depth, t3 + 1u, t4, t4 + 1u, l1};
+        ok = true;
+    } else {
+        ok = varscan_parse_lds(lds32, l0, l1, a0_off - lane0, o.status, cols);
+    }
+    if (ok) varscan_core_lds(lds32, l0, cols.ref_at, cols.depth, cols.b0, cols.b1, cols.q0, cols.q1, a0_off - lane0, prm, o.out, o.capacity, o.out_n);
+    return true;
 }
-template <bool kExact>
-__device__ __forceinline__ void classify_chunk(const uint4 v, uint32_t c, uint16_t *nl, uint16_t *cr, uint16_t *tab, uint16_t *let) {
-    constexpr uint64_t k7F = 0x7F7F7F7F7F7F7F7Full, k80 = 0x8080808080808080ull;
-    const uint64_t q[2] = {(uint64_t)v.x | ((uint64_t)v.y << 32), (uint64_t)v.z | ((uint64_t)v.w << 32)};
-    uint64_t ft[2], fl[2], fn[2], fc[2];
-    auto eq8 = [&](uint64_t w, uint64_t c8) -> uint64_t {      // 0x80 in every byte of w equal to the byte replicated in c8 (exact)
-        const uint64_t x = w ^ c8;
-        return ~(((x & k7F) + k7F) | x) & k80;
-    };
+
+// 16 byte flags (bit `shift` of every byte: 7, or 6 for the letters) of a 16-byte chunk -> 16 bits, byte k -> bit k
+__device__ __forceinline__ uint32_t gather16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3, uint32_t shift) {
+    uint32_t a = __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false);
+    a = __builtin_amdgcn_udot4(f1, 0x80402010u, a, false);
+    uint32_t b = __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false);
+    b = __builtin_amdgcn_udot4(f3, 0x80402010u, b, false);
+    return (a >> shift) | ((b >> shift) << 8);
+}
+// The 16-bit groups of a 64-bit mask from the order the lane read its chunks in (i ^ xq) into address order (and back: the same
+// exchange): neighbours swap where xq & 1 (both dwords rotate by 16), the dwords swap where xq & 2.
+__device__ __forceinline__ uint64_t regroup16(uint32_t lo, uint32_t hi, uint32_t xq) {
+    const uint32_t rot = (xq & 1u) << 4;
+    const uint32_t a_lo = __builtin_amdgcn_alignbit(lo, lo, rot), a_hi = __builtin_amdgcn_alignbit(hi, hi, rot);
+    return (xq & 2u) ? ((uint64_t)a_hi | ((uint64_t)a_lo << 32)) : ((uint64_t)a_lo | ((uint64_t)a_hi << 32));
+}
+// The exact, carry-safe masks of a lane's 64 bytes (any byte value): LF, CR, TAB, bytes 0x0A..0x0D, letters.  The slow side of
+// phase A: tiles with a byte >= 0x80 in them (the sums of the fast form would carry into the neighbour), and LF / CR of every tile
+// once a wave has seen a terminator that is not LF.
+struct SafeMasks { uint64_t lf, cr, tab, nl, let; };
+__device__ __noinline__ SafeMasks classify_safe(const uint4 *src, uint32_t xq) {
+    uint32_t b_lf[4], b_cr[4], b_tab[4], b_nl[4], b_let[4];
+#pragma unroll 1
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint4 v = src[i ^ xq];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t f_lf[4], f_cr[4], f_tab[4], f_nl[4], f_let[4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const uint64_t w = q[h];
-        ft[h] = eq8(w, 0x0909090909090909ull);
-        fl[h] = w & ~(w << 3) & 0x4040404040404040ull;           // bit 6 set, bit 3 clear (what crosses a byte in the shift is masked)
-        if (!kExact) {
-            const uint64_t m = w & k7F;                            // the adds run on seven bits: nothing carries between bytes
-            fn[h] = (m + 0x7676767676767676ull) & ~(m + 0x7272727272727272ull) & ~w & k80;
-            fc[h] = 0;
-        } else {
-            fn[h] = eq8(w, 0x0A0A0A0A0A0A0A0Aull);
-            fc[h] = eq8(w, 0x0D0D0D0D0D0D0D0Dull);
+        for (int k = 0; k < 4; ++k) {
+            f_lf[k] = eq4(w[k], 0x0A0A0A0Au);
+            f_cr[k] = eq4(w[k], 0x0D0D0D0Du);
+            f_tab[k] = eq4(w[k], 0x09090909u);
+            const uint32_t m = w[k] & 0x7F7F7F7Fu;
+            f_nl[k] = (m + 0x76767676u) & ~(m + 0x72727272u) & ~w[k] & 0x80808080u;
+            f_let[k] = w[k] & ~(w[k] << 3) & ~(w[k] >> 1) & 0x40404040u;                 // bit 6 set, bits 3 and 7 clear
         }
+        b_lf[i] = gather16(f_lf[0], f_lf[1], f_lf[2], f_lf[3], 7);
+        b_cr[i] = gather16(f_cr[0], f_cr[1], f_cr[2], f_cr[3], 7);
+        b_tab[i] = gather16(f_tab[0], f_tab[1], f_tab[2], f_tab[3], 7);
+        b_nl[i] = gather16(f_nl[0], f_nl[1], f_nl[2], f_nl[3], 7);
+        b_let[i] = gather16(f_let[0], f_let[1], f_let[2], f_let[3], 6);
     }
-    nl[c] = (uint16_t)gather16(fn[0], fn[1], 7);
-    tab[c] = (uint16_t)gather16(ft[0], ft[1], 7);
-    let[c] = (uint16_t)gather16(fl[0], fl[1], 6);
-    if (kExact) cr[c] = (uint16_t)gather16(fc[0], fc[1], 7);
+    SafeMasks r;
+    r.lf = regroup16(b_lf[0] | (b_lf[1] << 16), b_lf[2] | (b_lf[3] << 16), xq);
+    r.cr = regroup16(b_cr[0] | (b_cr[1] << 16), b_cr[2] | (b_cr[3] << 16), xq);
+    r.tab = regroup16(b_tab[0] | (b_tab[1] << 16), b_tab[2] | (b_tab[3] << 16), xq);
+    r.nl = regroup16(b_nl[0] | (b_nl[1] << 16), b_nl[2] | (b_nl[3] << 16), xq);
+    r.let = regroup16(b_let[0] | (b_let[1] << 16), b_let[2] | (b_let[3] << 16), xq);
+    return r;
 }
 
-// One wave per workgroup, every wave one contiguous run of tiles of the file.  A tile's slot in LDS holds the bytes
-// [t0 - 16, t0 + tile + halo) = 64 * kCPL chunks of 16 bytes: tile k+1 streams into the other slot with LDS-DMA
-// (global_load_lds_dwordx4, kCPL wave instructions, no register round trip) while tile k is looked at; the wave waits for its own
-// requests with a counted s_waitcnt, nothing else waits for anything.  A line that starts in the tile lies completely in the slot
-// when it is shorter than the halo; one that does not is left to the walk (VS_W_LONG).  The halo is fetched again with the next
-// tile (mostly from L2).  Geometries (chunks per lane, tile, halo): 4, 3840, 240 for lines of ~100 bytes (30x); 6, 5120, 1008 up
-// to ~480 bytes; 8, 4096, 4080 beyond.  Coordinates are "aligned": byte a of abase = file byte a - lo, abase 16-byte aligned, the
-// file at [lo, hi).
-// Line terminators are Java's readLine(): LF, CR, CR LF.  The fast form of A1 flags bytes 0x0A..0x0D with two adds and takes every
-// one for LF; phase B looks at the byte that ends each line, and the first that is not LF switches the wave to the exact form
-// (separate LF and CR strings, starts after LF, or after a CR that no LF follows) for this and all its later tiles.
-template <int kCPL>
-__global__ __launch_bounds__(1024) void k_varscan_scan(const uint8_t *__restrict__ abase, uint64_t lo, uint64_t hi, uint32_t tile_bytes, uint64_t n_tiles,
-                                                       snpgpu_varscan_params prm, uint4 *cand, uint32_t cand_cap, uint32_t *ctl, unsigned long long *status,
-                                                       snpgpu_varscan_site *out, uint32_t capacity, uint32_t *wave_lines, uint32_t lds_chunks_per_wave, uint4 share) {
-    constexpr uint32_t kChunks = 64u * kCPL;                                            // 16-byte chunks of a slot
-    constexpr uint32_t kSlotBytes = kChunks * 16u;
-    constexpr uint32_t kW = kSlotBytes / 32u;                                           // words of a bit string over the slot
-    constexpr uint32_t kMW = kW / 64u;                                                  // ... per lane in A2
+__device__ __forceinline__ uint32_t ffs64(uint64_t x) { return (uint32_t)__ffsll((long long)x) - 1u; }     // (x != 0)
+
+__global__ __launch_bounds__(512) void k_varscan_scan(const VsFile *__restrict__ files, uint32_t n_files, VsFile one, uint32_t n_waves_total,
+                                                      snpgpu_varscan_params prm, uint4 *cand, uint32_t cand_cap, uint32_t *cand_n, uint32_t *wave_lines,
+                                                      uint4 share) {
     extern __shared__ uint4 vs_lds_all[];
-    // the waves of a workgroup are independent (no barrier anywhere): each has its own stretch of the workgroup's LDS
-    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint4 *vs_lds = vs_lds_all + (size_t)wave_in_wg * lds_chunks_per_wave;
-    const uint32_t gwave = blockIdx.x * (blockDim.x >> 6) + wave_in_wg, n_gwaves = gridDim.x * (blockDim.x >> 6);
-    uint4 *slot0 = vs_lds, *slot1 = vs_lds + kChunks;
-    uint32_t *nlbits = (uint32_t *)(vs_lds + 2 * kChunks);                              // terminators (exact form: LF)
-    uint32_t *crbits = nlbits + kW + 4, *tabbits = crbits + kW + 4, *letbits = tabbits + kW + 4, *pre = letbits + kW + 4;   // (+4: the window reads run two words over)
-    uint4 *cand_local = (uint4 *)(pre + kW + 4);
-    uint16_t *lstart = (uint16_t *)(cand_local + VS_CAND_LOCAL);                        // VS_LIST_CAP + 2 entries
     const uint32_t lane = threadIdx.x & 63u;
-    const uint8_t *fbuf = abase + lo;                                                   // file byte 0
-    const uint64_t nbytes = hi - lo;
+    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+    const uint32_t gwave = blockIdx.x * wpb + wave_in_wg;
+    if (gwave >= n_waves_total) return;
+    // my file: the host dealt the waves of the launch to the files in proportion to their sizes
+    uint32_t fi = 0;
+    if (n_files > 1) {
+        uint32_t lo_i = 0, hi_i = n_files;                                              // the last file whose first wave is <= gwave
+        while (hi_i - lo_i > 1) { const uint32_t mid = (lo_i + hi_i) >> 1; if (files[mid].wave0 <= gwave) lo_i = mid; else hi_i = mid; }
+        fi = __builtin_amdgcn_readfirstlane(lo_i);
+    }
+    const VsFile f = n_files > 1 ? files[fi] : one;
+    const VsOut fo = vs_out(f);
+    // the waves of a workgroup are independent (no barrier anywhere): each has its own stretch of the workgroup's LDS
+    uint8_t *ring = (uint8_t *)vs_lds_all + (size_t)wave_in_wg * VS_LDS_WAVE;
+    const uint32_t *ring32 = (const uint32_t *)ring;
+    uint32_t *tabs32 = (uint32_t *)(ring + VS_RING + VS_MIRROR);
+    uint32_t *lets32 = tabs32 + VS_STR_WORDS + VS_STR_PAD;
+    uint32_t *pre = lets32 + VS_STR_WORDS + VS_STR_PAD;                                // (tabs before) | (letters before) << 16, per 32 bytes, modulo 2^16
+    uint4 *cand_local = (uint4 *)(pre + VS_STR_WORDS + VS_STR_PAD);
+    const uint32_t xq = (lane >> 2) & 3u;
     uint32_t n_local = 0, lines_seen = 0;
-    bool exact = false;                                                                 // wave-uniform: the exact form of A1 / A2
-    if (lane < 8) { nlbits[kW + (lane & 3)] = 0; crbits[kW + (lane & 3)] = 0; tabbits[kW + (lane & 3)] = 0; letbits[kW + (lane & 3)] = 0; pre[kW + (lane & 3)] = 0; }
-    auto flush = [&]() {
+    uint32_t exact = 0;                                                                 // wave-uniform (kept in a scalar), sticky: exact LF / CR masks, readLine() rules
+
+    // my run of tiles, in proportion to my share: wave w of a workgroup sits on SIMD w % 4 and is the (w / 4)-th oldest there; the
+    // SIMD issues oldest first, so with equal shares the oldest wave finishes early and the youngest runs on alone (share.x: oldest)
+    uint64_t t_first, t_end;
+    {
+        const uint32_t sh[4] = {share.x, share.y, share.z, share.w};
+        uint64_t blk = 0;
+        for (uint32_t w = 0; w < wpb; ++w) blk += sh[(w >> 2) & 3u];
+        auto cum = [&](uint64_t x) -> uint64_t {                                        // total weight of the launch's waves [0, x)
+            const uint32_t r = (uint32_t)(x % wpb);
+            uint64_t c = 0;
+            for (uint32_t w = 0; w < r; ++w) c += sh[(w >> 2) & 3u];
+            return (x / wpb) * blk + c;
+        };
+        const uint64_t c_lo = cum(f.wave0), c_span = cum((uint64_t)f.wave0 + f.n_waves) - c_lo;
+        t_first = (uint64_t)((unsigned __int128)f.n_tiles * (cum(gwave) - c_lo) / c_span);
+        t_end = (uint64_t)((unsigned __int128)f.n_tiles * (cum((uint64_t)gwave + 1) - c_lo) / c_span);
+    }
+    if (t_first >= t_end) { if (lane == 0) wave_lines[gwave] = 0; return; }
+    const uint64_t t_last = t_end < f.n_tiles ? t_end : f.n_tiles - 1;                  // the last tile I read: the one after my run (ends of my last lines)
+
+    auto flush = [&]() {                                                                // my candidates so far onto the global list
         if (n_local == 0) return;
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(ctl + 1, n_local);
+        if (lane == 0) base = atomicAdd(cand_n, n_local);
         base = __builtin_amdgcn_readfirstlane(base);
         for (uint32_t k = lane; k < n_local; k += 64) {
             const uint4 e = cand_local[k];
             if (base + k < cand_cap) cand[base + k] = e;
-            else walk_entry_global(fbuf, nbytes, e, prm, out, capacity, ctl, status);  // the list is full: looked at on the spot
+            else walk_entry_global(fo, e, prm);                                         // the list is full: looked at on the spot
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                // (the requests in flight are counted from zero again)
         n_local = 0;
     };
-    // my run of tiles
-    // ... in proportion to its share: wave w of a workgroup sits on SIMD w % 4 and is the (w / 4)-th oldest there; the SIMD issues
-    // oldest first, so with equal shares the oldest wave finishes early and the youngest runs on alone (share.x: oldest)
-    uint64_t t_first, t_end;
-    {
-        const uint32_t wpb = blockDim.x >> 6, sh[4] = {share.x, share.y, share.z, share.w};
-        uint64_t blk = 0, before = 0;
-        for (uint32_t w = 0; w < wpb; ++w) { const uint32_t x = sh[(w >> 2) & 3u]; blk += x; before += w < wave_in_wg ? x : 0u; }
-        const uint64_t total = blk * gridDim.x, c0 = (uint64_t)blockIdx.x * blk + before, c1 = c0 + sh[(wave_in_wg >> 2) & 3u];
-        t_first = (uint64_t)((unsigned __int128)n_tiles * c0 / total);
-        t_end = (uint64_t)((unsigned __int128)n_tiles * c1 / total);
-    }
-    auto interior = [&](uint64_t tt) { const uint64_t x0 = tt * tile_bytes; return x0 >= lo + 16 && x0 - 16 + kSlotBytes <= hi; };
-    // request tile tt into `slot`; returns whether it travels by DMA (else it has been staged synchronously)
-    auto request = [&](uint64_t tt, uint4 *slot) -> bool {
+    auto interior = [&](uint64_t tt) { const uint64_t x0 = tt * VS_TILE; return x0 >= f.lo && x0 + VS_TILE <= f.hi; };
+    // request tile tt into ring slot `slot`; returns whether it travels by DMA (else it has been staged synchronously)
+    auto request = [&](uint64_t tt, uint32_t slot) -> bool {
         if (interior(tt)) {
-            const uint8_t *gs = abase + tt * tile_bytes - 16;
+            const uint64_t ga = (uint64_t)(uintptr_t)(f.abase + tt * VS_TILE);
+            const uint64_t gr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ga >> 32)) << 32) |
+                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ga);
             const uint32_t voff = lane * 16u;
-            const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)slot);
-#pragma unroll
-            for (uint32_t r = 0; r < (uint32_t)kCPL; ++r) {
-                const uint64_t ga = (uint64_t)(uintptr_t)gs + (r >> 2) * 4096u;
-                const uint64_t gr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ga >> 32)) << 32) |
-                                    (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ga);
-                const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (r >> 2) * 4096u);
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(gr), "s"(m0v), "n"((r & 3u) * 1024u) : "memory");
-            }
+            const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)ring) + slot * VS_TILE);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %0, %1 offset:0\n\t"
+                         "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                         "global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(gr), "s"(m0v) : "memory");
             return true;
         }
-        // first / last tiles of the file: byte loads; the byte before the file reads as '\n' (byte 0 starts a line), the other
-        // bytes outside it as NUL (no line starts past the end)
-        const int64_t x0 = (int64_t)(tt * tile_bytes) - 16;
+        // first / last tiles of the file: byte loads; the byte before the file and the byte behind it read as '\n' (byte 0 starts a
+        // line, the last line ends with the file), the other bytes outside it as NUL
+        const int64_t x0 = (int64_t)(tt * VS_TILE);
+        uint4 *dst = (uint4 *)(ring + slot * VS_TILE);
 #pragma nounroll
-        for (uint32_t e = lane; e < kChunks; e += 64) {
+        for (uint32_t c = lane; c < VS_TILE / 16u; c += 64) {
             uint32_t d[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int64_t idx = x0 + (int64_t)e * 16 + 4 * k + j;
-                    const uint32_t bb = (idx >= (int64_t)lo && idx < (int64_t)hi) ? (uint32_t)abase[idx] : (idx + 1 == (int64_t)lo ? 10u : 0u);
+                    const int64_t idx = x0 + (int64_t)c * 16 + 4 * k + j;
+                    const uint32_t bb = (idx >= (int64_t)f.lo && idx < (int64_t)f.hi) ? (uint32_t)f.abase[idx]
+                                        : ((idx + 1 == (int64_t)f.lo || idx == (int64_t)f.hi) ? 10u : 0u);
                     d[k] |= bb << (8 * j);
                 }
-            slot[e] = make_uint4(d[0], d[1], d[2], d[3]);
+            dst[c] = make_uint4(d[0], d[1], d[2], d[3]);
         }
         return false;
     };
-    // the bits of a 32-bit word of a string (over the slot bytes from `b` on) that lie below slot offset x
-    auto below = [](uint32_t x, uint32_t b) -> uint32_t { return x <= b ? 0u : (x - b >= 32u ? 0xFFFFFFFFu : (1u << (x - b)) - 1u); };
-    // ... for this lane's words in A2: starts in [16, 16 + tile) are the tile's lines, in [16 + tile, slot end) end its last one
-    uint32_t own_mask[kMW], halo_mask[kMW];
-#pragma unroll
-    for (uint32_t k = 0; k < kMW; ++k) {
-        const uint32_t b = (lane * kMW + k) * 32u;
-        own_mask[k] = below(16u + tile_bytes, b) & ~below(16u, b);
-        halo_mask[k] = below(kSlotBytes, b) & ~below(16u + tile_bytes, b);
-    }
-    bool dma_next = false;
-    if (t_first < t_end) (void)request(t_first, slot0);
-    if (t_first + 1 < t_end) dma_next = request(t_first + 1, slot1);
-    uint4 *cur = slot0, *other = slot1;
-    for (uint64_t tt = t_first; tt < t_end; ++tt) {
-        // the current tile's request has landed when only the next tile's is outstanding
-        if (dma_next && tt + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kCPL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t *lds32 = (const uint32_t *)cur;
-        const uint64_t t0 = tt * tile_bytes;                                            // aligned coordinate of slot byte 16
-        // slot offset of the file's end (what a line without a terminator runs to), when that is inside the slot
-        const uint64_t hi_rel = hi - (t0 - 16);
-        const uint32_t hi_slot = hi_rel < kSlotBytes ? (uint32_t)hi_rel : 0xFFFFFFFFu;
-        const uint32_t own_end = 16u + tile_bytes < hi_slot ? 16u + tile_bytes : hi_slot;   // starts in [16, own_end) are this tile's lines
-        const uint32_t halo_end = hi_slot < kSlotBytes ? hi_slot : kSlotBytes;              // ... in [own_end, halo_end) end its last one
-        bool redo;
-        do {
-            redo = false;
+    auto wrap = [](uint32_t x) -> uint32_t { const uint32_t y = x - VS_RING; return x < y ? x : y; };   // x < 2 * VS_RING -> ring offset
+
+    uint32_t dma_mask = 0;                                                              // bit s: the tile now in slot s travels by DMA and has not been waited for
+    if (request(t_first, 0)) dma_mask |= 1u;
+    if (t_first + 1 <= t_last && request(t_first + 1, 1)) dma_mask |= 2u;
+    uint32_t slot = 0, pslot = 0;                                                       // ring slots of tile k and of tile k - 1
+    uint64_t prev_lf = 0, prev_cr = 0;                                                  // masks of tile k - 1 (fast form: cr == 0, lf = verified terminators)
+    uint32_t base_t = 0, base_l = 0;                                                    // running counts at the start of tile k (wave-uniform)
+    for (uint64_t k = t_first;; ++k) {
+        const bool have_cur = k <= t_last;
+        uint64_t cur_lf = 0, cur_cr = 0;
+        if (have_cur) {
+            // the current tile's request has landed when only the next tile's is outstanding
+            if (dma_mask & ~(1u << slot)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dma_mask = 0; }
+            dma_mask &= ~(1u << slot);
             __builtin_amdgcn_wave_barrier();
-            // ---- A1: chunk i * 64 + lane (conflict-free ds_read_b128) -> 16 bits of each string ------------------------------
-            if (!exact) {
+            // ---- A: my 64 bytes of tile k -> terminator / TAB / letter masks -----------------------------------------------
+            const uint4 *src = (const uint4 *)(ring + slot * VS_TILE) + 4u * lane;
+            uint64_t m_nl, m_tab, m_let;
+            {
+                uint32_t bn[4], bt[4], bl[4], hi_any = 0;
+                uint4 keepv[4];
 #pragma unroll
-                for (uint32_t i = 0; i < (uint32_t)kCPL; ++i)
-                    classify_chunk<false>(cur[i * 64u + lane], i * 64u + lane, (uint16_t *)nlbits, (uint16_t *)crbits, (uint16_t *)tabbits, (uint16_t *)letbits);
-            } else {
+                for (uint32_t i = 0; i < 4; ++i) {
+                    const uint4 v = src[i ^ xq];
+                    hi_any |= v.x | v.y | v.z | v.w;
+                    keepv[i] = v;
+                    const uint64_t q0 = (uint64_t)v.x | ((uint64_t)v.y << 32), q1 = (uint64_t)v.z | ((uint64_t)v.w << 32);
+                    const uint64_t a0 = q0 + 0x7777777777777777ull, b0 = q0 + 0x7676767676767676ull, c0 = q0 + 0x7272727272727272ull;
+                    const uint64_t a1 = q1 + 0x7777777777777777ull, b1 = q1 + 0x7676767676767676ull, c1 = q1 + 0x7272727272727272ull;
+                    bt[i] = gather16((uint32_t)a0 & ~(uint32_t)b0 & 0x80808080u, (uint32_t)(a0 >> 32) & ~(uint32_t)(b0 >> 32) & 0x80808080u,
+                                     (uint32_t)a1 & ~(uint32_t)b1 & 0x80808080u, (uint32_t)(a1 >> 32) & ~(uint32_t)(b1 >> 32) & 0x80808080u, 7);
+                    bn[i] = gather16((uint32_t)b0 & ~(uint32_t)c0 & 0x80808080u, (uint32_t)(b0 >> 32) & ~(uint32_t)(c0 >> 32) & 0x80808080u,
+                                     (uint32_t)b1 & ~(uint32_t)c1 & 0x80808080u, (uint32_t)(b1 >> 32) & ~(uint32_t)(c1 >> 32) & 0x80808080u, 7);
+                    // (x & ~(x << 3) & 0x40404040 as shift + one v_bitop3: left to itself the compiler moves the complement in front of the shift)
+                    bl[i] = gather16(__builtin_amdgcn_bitop3_b32(v.x, v.x << 3, 0x40404040u, 0x20), __builtin_amdgcn_bitop3_b32(v.y, v.y << 3, 0x40404040u, 0x20),
+                                     __builtin_amdgcn_bitop3_b32(v.z, v.z << 3, 0x40404040u, 0x20), __builtin_amdgcn_bitop3_b32(v.w, v.w << 3, 0x40404040u, 0x20), 6);
+                }
+                if (slot == 0) {                                                        // (wave-uniform) the mirror of the ring's first 128 bytes: lanes 0, 1 (xq == 0)
+                    if (lane < 2) {
 #pragma unroll
-                for (uint32_t i = 0; i < (uint32_t)kCPL; ++i)
-                    classify_chunk<true>(cur[i * 64u + lane], i * 64u + lane, (uint16_t *)nlbits, (uint16_t *)crbits, (uint16_t *)tabbits, (uint16_t *)letbits);
+                        for (uint32_t i = 0; i < 4; ++i) ((uint4 *)(ring + VS_RING))[lane * 4u + i] = keepv[i];
+                    }
+                }
+                m_nl = regroup16(bn[0] | (bn[1] << 16), bn[2] | (bn[3] << 16), xq);
+                m_tab = regroup16(bt[0] | (bt[1] << 16), bt[2] | (bt[3] << 16), xq);
+                m_let = regroup16(bl[0] | (bl[1] << 16), bl[2] | (bl[3] << 16), xq);
+                const bool high = __builtin_amdgcn_ballot_w64((hi_any & 0x80808080u) != 0u) != 0;
+                if (high || __builtin_amdgcn_readfirstlane(exact)) {                                                    // (wave-uniform) the slow, exact side
+                    const SafeMasks sm = classify_safe(src, xq);
+                    if (high) { m_nl = sm.nl; m_tab = sm.tab; m_let = sm.let; }
+                    cur_lf = sm.lf; cur_cr = sm.cr;
+                }
+            }
+            if (!__builtin_amdgcn_readfirstlane(exact)) {
+                // every byte the fast form flagged: is it LF?  The first that is not — CR, VT, FF — switches the wave to the exact form
+                // before anything of this tile has been used (the tiles before it hold nothing but LF: they keep their masks)
+                bool odd = false;
+                uint64_t v = m_nl;
+                const uint8_t *mine = ring + slot * VS_TILE + lane * 64u;
+                while (__builtin_amdgcn_ballot_w64(v != 0)) {
+                    if (v) { odd |= mine[ffs64(v)] != 10u; v &= v - 1; }
+                }
+                if (__builtin_amdgcn_ballot_w64(odd)) {
+                    exact = 1u;
+                    const SafeMasks sm = classify_safe(src, xq);
+                    cur_lf = sm.lf; cur_cr = sm.cr;
+                } else { cur_lf = m_nl; cur_cr = 0; }
+            }
+            // the strings and the running counts of this tile
+            {
+                const uint32_t ct0 = (uint32_t)__popc((uint32_t)m_tab), ct1 = (uint32_t)__popc((uint32_t)(m_tab >> 32));
+                const uint32_t cl0 = (uint32_t)__popc((uint32_t)m_let), cl1 = (uint32_t)__popc((uint32_t)(m_let >> 32));
+                const uint32_t mine = (ct0 + ct1) | ((cl0 + cl1) << 16);               // (<= 64 each: the fields of the sums stay apart, <= 4096)
+                const uint32_t incl = wave_inclusive_sum(mine), excl = incl - mine;
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                const uint32_t t_run = base_t + (excl & 0xFFFFu), l_run = base_l + (excl >> 16);
+                const uint32_t blk = slot * 64u + lane;                                 // my 64-byte block of the ring
+                ((uint2 *)tabs32)[blk] = make_uint2((uint32_t)m_tab, (uint32_t)(m_tab >> 32));
+                ((uint2 *)lets32)[blk] = make_uint2((uint32_t)m_let, (uint32_t)(m_let >> 32));
+                const uint2 pp = make_uint2((t_run & 0xFFFFu) | (l_run << 16), ((t_run + ct0) & 0xFFFFu) | ((l_run + cl0) << 16));
+                ((uint2 *)pre)[blk] = pp;
+                if (slot == 0 && lane < 2) {                                            // the mirror behind the ring's end
+                    ((uint2 *)tabs32)[VS_STR_WORDS / 2u + lane] = make_uint2((uint32_t)m_tab, (uint32_t)(m_tab >> 32));
+                    ((uint2 *)lets32)[VS_STR_WORDS / 2u + lane] = make_uint2((uint32_t)m_let, (uint32_t)(m_let >> 32));
+                    ((uint2 *)pre)[VS_STR_WORDS / 2u + lane] = pp;
+                }
+                base_t = (base_t + (tot & 0xFFFFu)) & 0xFFFFu;
+                base_l = (base_l + (tot >> 16)) & 0xFFFFu;
             }
             __builtin_amdgcn_wave_barrier();
-            // ---- A2: words lane * kMW .. of the strings: line starts, running counts ----------------------------------------
-            uint32_t S[kMW], tw[kMW], lw[kMW];
-            uint32_t c_nl = 0, c_tab = 0, c_let = 0, halo_first = 0xFFFFFFFFu;
+        }
+        if (k > t_first) {
+            // ---- B: the lines that start behind the terminators of tile k - 1 ----------------------------------------------
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t pbase = pslot * VS_TILE;                                     // ring offset of tile k - 1
+            const uint64_t t0p = (k - 1) * VS_TILE;                                     // its aligned coordinate
+            const uint64_t hi_rel64 = f.hi - t0p;                                       // (t0p < hi: the tile is one of the file's)
+            const uint32_t hi_rel = hi_rel64 < 0xFFFFFFFFull ? (uint32_t)hi_rel64 : 0xFFFFFFFFu;
+            // terminators: LF, and (exact form) a CR that no LF follows
+            uint64_t T = prev_lf, Tc = cur_lf;
+            if (__builtin_amdgcn_readfirstlane(exact)) {
+                uint32_t nb = (uint32_t)__shfl_down((int)(uint32_t)prev_lf, 1) & 1u;
+                const uint32_t first_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cur_lf) & 1u;
+                if (lane == 63) nb = first_cur;
+                T = prev_lf | (prev_cr & ~((prev_lf >> 1) | ((uint64_t)nb << 63)));
+                // (of tile k only the first terminator matters here; a CR in its last byte waits for tile k + 1: not taken for one)
+                uint32_t nc = (uint32_t)__shfl_down((int)(uint32_t)cur_lf, 1) & 1u;
+                if (lane == 63) nc = 1u;
+                Tc = cur_lf | (cur_cr & ~((cur_lf >> 1) | ((uint64_t)nc << 63)));
+            }
+            // where the first line after this tile's last terminator ends: the first terminator of tile k (VS_NONE: not in sight)
+            uint32_t next_first = VS_NONE;
             {
-                const uint32_t w0 = lane * kMW;
-                uint32_t carry_n = w0 ? nlbits[w0 - 1] >> 31 : 0u, carry_c = (exact && w0) ? crbits[w0 - 1] >> 31 : 0u;
-#pragma unroll
-                for (uint32_t k = 0; k < kMW; ++k) {
-                    const uint32_t n = nlbits[w0 + k];
-                    tw[k] = tabbits[w0 + k];
-                    lw[k] = letbits[w0 + k];
-                    uint32_t st = (n << 1) | carry_n;
-                    carry_n = n >> 31;
-                    if (exact) { const uint32_t cr = crbits[w0 + k]; st |= ((cr << 1) | carry_c) & ~n; carry_c = cr >> 31; }
-                    // bits of this word inside [16, own_end) / [own_end, halo_end)
-                    const uint32_t b = (w0 + k) * 32u;
-                    uint32_t m_own = own_mask[k], m_halo = halo_mask[k];
-                    if (hi_slot != 0xFFFFFFFFu) {                                       // (a tile the file ends in: its own limits)
-                        m_own = below(own_end, b) & ~below(16u, b);
-                        m_halo = below(halo_end, b) & ~below(own_end, b);
-                    }
-                    const uint32_t halo = st & m_halo;
-                    if (halo && halo_first == 0xFFFFFFFFu) halo_first = b + (uint32_t)__ffs((int)halo) - 1u;
-                    S[k] = st & m_own;
-                    c_nl += (uint32_t)__popc(S[k]);
-                    c_tab += (uint32_t)__popc(tw[k]);
-                    c_let += (uint32_t)__popc(lw[k]);
+                const uint64_t bm = __builtin_amdgcn_ballot_w64(Tc != 0);
+                if (bm) {
+                    const uint32_t j0 = ffs64(bm);
+                    next_first = VS_TILE + j0 * 64u + (uint32_t)__builtin_amdgcn_readlane((int)(Tc ? ffs64(Tc) : 0u), (int)j0);
                 }
             }
-            const uint32_t packed = c_nl | (c_tab << 13);
-            const uint32_t i1 = wave_inclusive_sum(packed), i2 = wave_inclusive_sum(c_let);
-            const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63) & 0x1FFFu;
-            uint32_t idx0 = (i1 - packed) & 0x1FFFu;
+            // ... and for every lane: the first terminator behind its own last one
+            uint32_t nxt = next_first;
             {
-                uint32_t ptab = (i1 - packed) >> 13, plet = i2 - c_let;
-#pragma unroll
-                for (uint32_t k = 0; k < kMW; ++k) {
-                    pre[lane * kMW + k] = (ptab & 0xFFFFu) | (plet << 16);
-                    ptab += (uint32_t)__popc(tw[k]);
-                    plet += (uint32_t)__popc(lw[k]);
+                const uint32_t first_t = T ? lane * 64u + ffs64(T) : VS_NONE;
+                const uint64_t bm = __builtin_amdgcn_ballot_w64(T != 0);
+                const uint64_t above = (bm >> 1) >> lane;                               // lanes lane + 1 ..
+                const uint32_t j = above ? lane + 1u + ffs64(above) : lane;
+                const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)first_t);
+                if (above) nxt = got;
+            }
+            uint64_t pend = T;
+            // One line per lane and round, in straight-line code: every test lands in a flag, every LDS read is issued whether its
+            // line needs it or not (a read outside the wave's LDS returns nothing and costs nothing), so a round is three LDS
+            // round trips — the TAB window; the depth and what hangs on the fourth TAB; what hangs on the depth — and no branch.
+            for (;;) {
+                if (!__builtin_amdgcn_ballot_w64(pend != 0)) break;
+                const bool active = pend != 0;
+                const uint32_t bpos = ffs64(pend);                                      // (no terminator left: 0xFFFFFFFF, the lane is not `valid`)
+                pend &= pend - 1;                                                       // (0 stays 0)
+                const uint32_t p0 = lane * 64u + bpos + 1u;                             // the line's first byte, counted from the start of tile k - 1
+                const uint32_t e = pend ? lane * 64u + ffs64(pend) : nxt;               // the terminator that ends it
+                const bool valid = active & (p0 < hi_rel);                              // (the virtual terminator behind the file starts no line)
+                lines_seen += valid ? 1u : 0u;
+                const uint32_t a0 = wrap(pbase + p0);                                   // ring offset of the line's first byte
+                uint32_t le = e;                                                        // the line without its terminator: [p0, le)
+                if (__builtin_amdgcn_readfirstlane(exact)) {                            // (wave-uniform) CR LF: both go
+                    const uint32_t ae = wrap(pbase + e);
+                    const bool pair = (e != VS_NONE) & (e > p0) & (ring[ae & 0x3FFFu] == 10u) & (ring[(ae ? ae - 1u : VS_RING - 1u) & 0x3FFFu] == 13u);
+                    le = pair ? e - 1u : e;
+                }
+                const uint32_t span = le - p0;
+                // the first four TABs out of the 64 bits of the TAB string from the line's first byte on
+                const uint32_t wq = (a0 >> 5) & 0x1FFu, sh = a0 & 31u;
+                const uint32_t w0 = tabs32[wq], w1 = tabs32[wq + 1u], w2 = tabs32[wq + 2u];
+                const uint32_t pre_p0 = pre[wq];
+                const uint32_t a_le = wrap(pbase + le) & 0x3FFFu;
+                const uint32_t tw_le = tabs32[a_le >> 5], pre_le = pre[a_le >> 5];
+                uint32_t m32 = __builtin_amdgcn_alignbit(w1, w0, sh);
+                m32 = span < 32u ? m32 & ((1u << (span & 31u)) - 1u) : m32;
+                bool four = __popc(m32) >= 4;
+                uint32_t r0 = (uint32_t)__ffs((int)m32) - 1u; m32 &= m32 - 1u;
+                uint32_t r1 = (uint32_t)__ffs((int)m32) - 1u; m32 &= m32 - 1u;
+                uint32_t r2 = (uint32_t)__ffs((int)m32) - 1u; m32 &= m32 - 1u;
+                uint32_t r3 = (uint32_t)__ffs((int)m32) - 1u;
+                if (__builtin_amdgcn_ballot_w64(valid & !four & (span > 32u) & (e != VS_NONE))) {   // (wave-uniform) long contig names: 64 bytes
+                    uint64_t M = (uint64_t)__builtin_amdgcn_alignbit(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32);
+                    M = span < 64u ? M & ((1ull << (span & 63u)) - 1ull) : M;
+                    four = __popcll(M) >= 4;
+                    r0 = ffs64(M); M &= M - 1ull;
+                    r1 = ffs64(M); M &= M - 1ull;
+                    r2 = ffs64(M); M &= M - 1ull;
+                    r3 = ffs64(M);
+                }
+                r0 &= 63u; r1 &= 63u; r2 &= 63u; r3 &= 63u;                            // (four == false: anything, but small)
+                const uint32_t nd = r3 - r2 - 1u;                                       // digits of the depth
+                const bool shape = four & (r0 > 0u) & (r1 > r0 + 1u) & (r2 == r1 + 2u) & (nd - 1u < 4u);
+                // the depth: four bytes from its first digit on, most significant first (up to 64 bytes behind a0: the mirror is there)
+                const uint32_t da = a0 + r2 + 1u;
+                const uint32_t a_b0 = a0 + r3 + 1u;
+                const uint32_t d_lo = ring32[da >> 2], d_hi = ring32[(da >> 2) + 1u];
+                const uint32_t lw_b0 = lets32[a_b0 >> 5], pre_b0 = pre[a_b0 >> 5];
+                const uint32_t x = __builtin_amdgcn_alignbyte(d_hi, d_lo, da & 3u);
+                const uint32_t keep = nd >= 4u ? 0xFFFFFFFFu : (1u << (8u * (nd & 3u))) - 1u;
+                const uint32_t z = (x & keep) | (0x30303030u & ~keep);                  // the bytes behind the digits read as '0'
+                // every byte in '0'..'9': bit 7 clear, z + 0x46 below 0x80, z + 0x50 at or above it
+                const bool digits = ((z | (z + 0x46464646u) | ~(z + 0x50505050u)) & 0x80808080u) == 0u;
+                const uint32_t ys = (z - 0x30303030u) << ((8u * (4u - nd)) & 31u);      // digit k in byte 4 - nd + k: weights 1000, 100, 10, 1 by byte
+                const uint32_t depth = (__builtin_amdgcn_udot4(ys, 0x010A6400u, 0u, false) + (ys & 0xFFu) * 1000u) & 0x3FFFu;
+                const uint32_t b0 = p0 + r3 + 1u;
+                const bool fits = digits & (depth >= 1u) & (b0 + 1u + depth < le);
+                const uint32_t t4 = le - depth - 1u;
+                const uint32_t a_t4 = wrap(pbase + t4) & 0x3FFFu;
+                const uint32_t tw_t4 = tabs32[a_t4 >> 5], lw_t4 = lets32[a_t4 >> 5], pre_t4 = pre[a_t4 >> 5];
+                // TABs in [p0, le), letters in [b0, t4): differences of running counts
+                const uint32_t tabs = ((pre_le & 0xFFFFu) + (uint32_t)__popc(tw_le & ((1u << (a_le & 31u)) - 1u)) -
+                                       (pre_p0 & 0xFFFFu) - (uint32_t)__popc(w0 & ((1u << sh) - 1u))) & 0xFFFFu;
+                const uint32_t letters = ((pre_t4 >> 16) + (uint32_t)__popc(lw_t4 & ((1u << (a_t4 & 31u)) - 1u)) -
+                                          (pre_b0 >> 16) - (uint32_t)__popc(lw_b0 & ((1u << (a_b0 & 31u)) - 1u))) & 0xFFFFu;
+                const bool plain = shape & fits & (((tw_t4 >> (a_t4 & 31u)) & 1u) != 0u) & (tabs == 5u);
+                // (min_reads2 0: an allele without reads is skipped by the walk, so one letter is still needed)
+                const bool calls = (depth >= prm.min_coverage) & (letters >= (prm.min_reads2 > 1u ? prm.min_reads2 : 1u));
+                // a line that runs past tile k: the walk finds its end; an empty line: nothing; a line the shortcut cannot vouch for: the
+                // walk looks at it in full (format errors included)
+                const bool is_long = e == VS_NONE;
+                const bool is_cand = valid & (is_long | ((le > p0) & (!plain | calls)));
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
+                if (mk) {
+                    const uint64_t off = t0p + p0 - f.lo;                               // file offset of the line
+                    uint4 ent;
+                    ent.x = (uint32_t)off; ent.y = (uint32_t)(off >> 32) | (fi << 16);
+                    ent.z = is_long ? 0u : (e + 1u < hi_rel ? e + 1u : hi_rel) - p0;    // (the virtual terminator behind the file is no byte of the line)
+                    ent.w = is_long ? VS_W_LONG : plain ? (VS_W_PLAIN | depth | (r1 << 14) | (r3 << 20)) : 0u;
+                    if (is_cand) cand_local[n_local + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = ent;
+                    n_local += (uint32_t)__popcll(mk);
+                    __builtin_amdgcn_wave_barrier();
+                    if (n_local + 64u > VS_CAND_LOCAL) { flush(); dma_mask = 0; __builtin_amdgcn_wave_barrier(); }
                 }
             }
-            // where the line after the tile's last one starts: the first start in the halo, else the end of the file, else unknown
-            uint32_t next = hi_slot;                                                    // 0xFFFFFFFF: not in the slot
-            {
-                const unsigned long long any = __ballot(halo_first != 0xFFFFFFFFu);
-                if (any) next = (uint32_t)__builtin_amdgcn_readlane((int)halo_first, (int)(__ffsll((long long)any) - 1));
-            }
-            // ---- passes of up to VS_LIST_CAP lines: the list, then one lane per line ---------------------------------------
-#pragma unroll 1
-            for (uint32_t base = 0; base < T; base += VS_LIST_CAP) {
-                {
-                    // The fast form took every byte in 0x0A..0x0D for LF: on the way through the starts (first pass), is the byte in
-                    // front of each one?  The first that is not — CR, VT, FF — switches the wave to the exact form, before anything
-                    // of this tile has been used.
-                    const bool check = !exact && base == 0;
-                    bool odd = check && halo_first != 0xFFFFFFFFu && halo_first == next && ((lds32[(next - 1u) >> 2] >> (((next - 1u) & 3u) * 8u)) & 0xFFu) != 10u;
-                    uint32_t idx = idx0;
-#pragma unroll
-                    for (uint32_t k = 0; k < kMW; ++k) {
-                        uint32_t mm = S[k];
-                        const uint32_t b = (lane * kMW + k) * 32u;
-                        while (mm) {
-                            const uint32_t q = b + (uint32_t)__ffs((int)mm) - 1u;
-                            mm &= mm - 1u;
-                            if (idx - base <= VS_LIST_CAP) lstart[idx - base] = (uint16_t)q;            // (unsigned: also false for idx < base)
-                            if (check) odd |= ((lds32[(q - 1u) >> 2] >> (((q - 1u) & 3u) * 8u)) & 0xFFu) != 10u;
-                            ++idx;
-                        }
-                    }
-                    if (check && __ballot(odd)) { exact = true; redo = true; break; }
-                }
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t n_here = T - base < VS_LIST_CAP ? T - base : VS_LIST_CAP;
-#pragma unroll 1
-                for (uint32_t r = 0; r < n_here; r += 64) {
-                    const uint32_t i = r + lane;
-                    bool is_cand = false;
-                    uint4 e = make_uint4(0, 0, 0, 0);
-                    if (i < n_here) {
-                        const uint32_t p0 = lstart[i];
-                        const uint32_t end = base + i + 1u < T ? (uint32_t)lstart[i + 1u] : next;
-                        const uint64_t off = t0 - 16 + p0 - lo;                         // file offset of the line
-                        e.x = (uint32_t)off; e.y = (uint32_t)(off >> 32);
-                        if (end == 0xFFFFFFFFu) { is_cand = true; e.w = VS_W_LONG; }    // runs past the slot: the walk finds its end
-                        else {
-                            e.z = end - p0;
-                            auto byte_at = [&](uint32_t p) -> uint32_t { return (lds32[p >> 2] >> ((p & 3u) * 8u)) & 0xFFu; };
-                            // the line without its terminator
-                            uint32_t le = end;
-                            if (!exact) {
-                                if (byte_at(end - 1u) == 10u) le = end - 1u;           // (else: the file's last line, without a terminator)
-                            } else {
-                                while (le > p0) { const uint32_t cb = byte_at(le - 1u); if (cb != 10u && cb != 13u) break; --le; }
-                            }
-                            if (le > p0) {
-                                bool plain = false;
-                                // the first four TABs out of the 64 bits of the TAB string from the line's first byte on
-                                const uint32_t wq = p0 >> 5, sh = p0 & 31u;
-                                const uint32_t a0 = tabbits[wq], a1 = tabbits[wq + 1u];
-                                const uint32_t span = le - p0;
-                                uint32_t m32 = __builtin_amdgcn_alignbit(a1, a0, sh);
-                                if (span < 32u) m32 &= (1u << span) - 1u;
-                                uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-                                bool four = false;
-                                if (__popc(m32) >= 4) {                                 // the usual case: all four within 32 bytes
-                                    four = true;
-                                    r0 = (uint32_t)__ffs((int)m32) - 1u; m32 &= m32 - 1u;
-                                    r1 = (uint32_t)__ffs((int)m32) - 1u; m32 &= m32 - 1u;
-                                    r2 = (uint32_t)__ffs((int)m32) - 1u; m32 &= m32 - 1u;
-                                    r3 = (uint32_t)__ffs((int)m32) - 1u;
-                                } else if (span > 32u) {                                // long contig names: 64 bytes
-                                    const uint32_t a2 = tabbits[wq + 2u];
-                                    uint64_t M = (uint64_t)m32 | ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, sh) << 32);
-                                    if (span < 64u) M &= (1ull << span) - 1ull;
-                                    if (__popcll(M) >= 4) {
-                                        four = true;
-                                        r0 = (uint32_t)__ffsll((long long)M) - 1u; M &= M - 1ull;
-                                        r1 = (uint32_t)__ffsll((long long)M) - 1u; M &= M - 1ull;
-                                        r2 = (uint32_t)__ffsll((long long)M) - 1u; M &= M - 1ull;
-                                        r3 = (uint32_t)__ffsll((long long)M) - 1u;
-                                    }
-                                }
-                                if (four) {
-                                    const uint32_t nd = r3 - r2 - 1u;                   // digits of the depth
-                                    if (r0 > 0u && r1 > r0 + 1u && r2 == r1 + 2u && nd >= 1u && nd <= 4u) {
-                                        // the depth: four bytes from its first digit on, most significant first
-                                        const uint32_t da = p0 + r2 + 1u;
-                                        const uint32_t x = __builtin_amdgcn_alignbyte(lds32[(da >> 2) + 1u], lds32[da >> 2], da & 3u);
-                                        const uint32_t keep = nd >= 4u ? 0xFFFFFFFFu : (1u << (8u * nd)) - 1u;
-                                        const uint32_t z = (x & keep) | (0x30303030u & ~keep);      // the bytes behind the digits read as '0'
-                                        // every byte in '0'..'9': bit 7 clear, z + 0x46 below 0x80, z + 0x50 at or above it
-                                        const bool digits = ((z | (z + 0x46464646u) | ~(z + 0x50505050u)) & 0x80808080u) == 0u;
-                                        const uint32_t ys = (z - 0x30303030u) << (8u * (4u - nd));  // digit k in byte 4 - nd + k: weights 1000, 100, 10, 1 by byte
-                                        const uint32_t depth = __builtin_amdgcn_udot4(ys, 0x010A6400u, 0u, false) + (ys & 0xFFu) * 1000u;
-                                        const uint32_t b0 = p0 + r3 + 1u;
-                                        if (digits && depth >= 1u && b0 + 1u + depth < le) {
-                                            const uint32_t t4 = le - depth - 1u;
-                                            const uint32_t t4w = tabbits[t4 >> 5];
-                                            // TABs in [p0, le), letters in [b0, t4): differences of running counts
-                                            auto upto = [&](uint32_t at, uint32_t word, uint32_t shift) -> uint32_t {
-                                                return ((pre[at >> 5] >> shift) & 0xFFFFu) + (uint32_t)__popc(word & ((1u << (at & 31u)) - 1u));
-                                            };
-                                            const uint32_t tabs = (upto(le, tabbits[le >> 5], 0) - upto(p0, a0, 0)) & 0xFFFFu;
-                                            const uint32_t letters = (upto(t4, letbits[t4 >> 5], 16) - upto(b0, letbits[b0 >> 5], 16)) & 0xFFFFu;
-                                            if (((t4w >> (t4 & 31u)) & 1u) && tabs == 5u) {
-                                                plain = true;
-                                                // (min_reads2 0: an allele without reads is skipped by the walk, so one letter is still needed)
-                                                is_cand = depth >= prm.min_coverage && letters >= (prm.min_reads2 > 1u ? prm.min_reads2 : 1u);
-                                                e.w = VS_W_PLAIN | depth | (r1 << 14) | (r3 << 20);
-                                            }
-                                        }
-                                    }
-                                }
-                                if (!plain) is_cand = true;                              // the walk looks at it in full (format errors included)
-                            }
-                        }
-                    }
-                    const unsigned long long mk = __ballot(is_cand);
-                    if (mk) {
-                        if (is_cand) cand_local[n_local + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = e;
-                        n_local += (uint32_t)__popcll(mk);
-                        __builtin_amdgcn_wave_barrier();
-                        if (n_local + 64u > VS_CAND_LOCAL) { flush(); __builtin_amdgcn_wave_barrier(); }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (!redo) lines_seen += T;
-        } while (redo);
-        // this slot is free: every LDS read of it has returned
+        }
+        if (k >= t_end) break;
+        // the slot of tile k - 1 is free: every LDS read of it has returned
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        dma_next = tt + 2 < t_end ? request(tt + 2, cur) : false;
-        uint4 *t_ = cur; cur = other; other = t_;
+        const uint32_t nslot = slot == 0 ? 2u : slot - 1u;                              // (slot + 2) % 3: where tile k - 1 was
+        if (k + 2 <= t_last && request(k + 2, nslot)) dma_mask |= 1u << nslot;
+        prev_lf = cur_lf; prev_cr = cur_cr;
+        pslot = slot;
+        slot = slot == 2 ? 0u : slot + 1u;
     }
+    // ---- my candidates: their lines into the ring (free now), every lane walks its own ------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    flush();
+    for (uint32_t r = 0; r < n_local; r += 64) {
+        bool have = r + lane < n_local;
+        const uint4 e = have ? cand_local[r + lane] : make_uint4(0, 0, 0, 0);
+        for (int round = 0; round < 4 && __builtin_amdgcn_ballot_w64(have); ++round) {
+            const bool done = walk_in_strips((uint4 *)ring, VS_RING + VS_MIRROR - 16u, have, e, fo, prm);   // (- one chunk: the walk may read the word after a line)
+            const bool progress = __builtin_amdgcn_ballot_w64(done && have) != 0;
+            have = have && !done;
+            __builtin_amdgcn_wave_barrier();
+            if (!progress) break;
+        }
+        // what found no room (a line longer than the ring, many deep ones, an unknown end): onto the global list
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(have);
+        if (mk) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(cand_n, (uint32_t)__popcll(mk));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (have) {
+                const uint32_t at = base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+                if (at < cand_cap) cand[at] = e;
+                else walk_entry_global(fo, e, prm);
+            }
+        }
+    }
+    for (int o = 32; o; o >>= 1) lines_seen += __shfl_xor(lines_seen, o);
     if (lane == 0) wave_lines[gwave] = lines_seen;
 }
 
-// One lane per candidate line: the 64 lines of a wave are copied into LDS back to back (16-byte chunks; a wave prefix sum of
-// the chunk counts gives every lane its place) and every lane walks its own there.  What does not fit the wave's LDS (a few
-// lines several times the mean length) and what the scan could not measure (VS_W_LONG) goes on a second list.  The entries are
-// fetched two rounds ahead of their use.
-__global__ __launch_bounds__(64) void k_varscan_walk(const uint8_t *__restrict__ buf, uint64_t nbytes, snpgpu_varscan_params prm, snpgpu_varscan_site *out,
-                                                     uint32_t capacity, uint32_t *out_n, unsigned long long *status, uint32_t lds_bytes,
-                                                     const uint4 *__restrict__ cand, const uint32_t *__restrict__ cand_n, uint32_t cand_cap,
-                                                     uint32_t *long_idx, uint32_t *long_n) {
-    extern __shared__ uint4 vs_lds[];
+// The epilogue of a launch: the candidates on the global list (a wave's overflow, lines that found no room in a ring, lines of
+// unknown end) — one lane per candidate, lines packed into LDS as the scan's waves do it, the rest byte-wise from global memory —
+// and the line counts of the scan's waves added up per file.
+__global__ __launch_bounds__(64) void k_varscan_finish(const VsFile *__restrict__ files, uint32_t n_files, VsFile one, snpgpu_varscan_params prm,
+                                                       const uint4 *__restrict__ cand, const uint32_t *__restrict__ cand_n, uint32_t cand_cap,
+                                                       const uint32_t *__restrict__ wave_lines, uint32_t strip_bytes) {
+    extern __shared__ uint4 vs_strips[];
     const uint32_t n = *cand_n < cand_cap ? *cand_n : cand_cap;
-    const uint64_t stride = (uint64_t)gridDim.x * 64;
-    uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-    const uint4 NONE = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
-    auto entry = [&](uint64_t k) -> uint4 { return k < n ? cand[k] : NONE; };
-    uint4 e = entry(i), e1 = entry(i + stride);
-    for (uint64_t i0 = (uint64_t)blockIdx.x * 64; i0 < n; i0 += stride, i += stride) {
-        const uint4 e2 = entry(i + 2 * stride);                      // two rounds ahead
-        const bool have = !(e.x == 0xFFFFFFFFu && e.y == 0xFFFFFFFFu);
-        const bool is_long = have && (e.w & VS_W_LONG);
-        const uint64_t p0 = (uint64_t)e.x | ((uint64_t)e.y << 32), end = p0 + e.z;
-        const uint64_t a0 = ((uintptr_t)buf + p0) & ~(uint64_t)15, a1 = (have && !is_long) ? (((uintptr_t)buf + end) + 15) & ~(uint64_t)15 : a0;
-        const uint32_t chunks = a1 - a0 > 0xFFFFFFull ? 0xFFFFFFu / 16u : (uint32_t)((a1 - a0) / 16);
-        // exclusive prefix sum of the chunk counts over the wave (a line that does not fit takes no room)
-        const bool alone_fits = (uint64_t)chunks * 16 <= lds_bytes;
-        const uint32_t mine_chunks = alone_fits ? chunks : 0u;
-        uint32_t incl = mine_chunks;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up_ = __shfl_up(incl, o);
-            if ((int)threadIdx.x >= o) incl += up_;
-        }
-        const uint32_t first_chunk = incl - mine_chunks;
-        const bool fits = alone_fits && (uint64_t)incl * 16 <= lds_bytes;
-        if (have && !is_long && fits) {
-            uint4 *mine = vs_lds + first_chunk;
-            const uint4 *src = (const uint4 *)a0;
-            for (uint32_t c = 0; c < chunks; ++c) mine[c] = src[c];
-            const uint32_t lane0 = first_chunk * 16u;                                   // LDS offset of this lane's bytes
-            const uint64_t a0_off = a0 - (uintptr_t)buf;                                // their file offset
-            const uint32_t *lds32 = (const uint32_t *)vs_lds;
-            const uint32_t l0 = lane0 + (uint32_t)(p0 - a0_off);
-            uint32_t l1 = lane0 + (uint32_t)(end - a0_off);
-            LineCols cols;
-            bool ok;
-            if (e.w & VS_W_PLAIN) {
-                // the columns are where k_varscan_scan found them
-                while (l1 > l0) { const uint32_t c = (lds32[(l1 - 1u) >> 2] >> (((l1 - 1u) & 3u) * 8u)) & 0xFFu; if (c != 10u && c != 13u) break; --l1; }
-                const uint32_t depth = e.w & 0x3FFFu, t1 = l0 + ((e.w >> 14) & 63u), t3 = l0 + ((e.w >> 20) & 63u);
-                const uint32_t t4 = l1 - depth - 1u;
-                cols = LineCols{t1 + 1u, depth, t3 + 1u, t4, t4 + 1u, l1};
-                ok = true;
-            } else {
-                ok = varscan_parse_lds(lds32, l0, l1, a0_off - lane0, status, cols);
-            }
-            if (ok) varscan_core_lds(lds32, l0, cols.ref_at, cols.depth, cols.b0, cols.b1, cols.q0, cols.q1, a0_off - lane0, prm, out, capacity, out_n);
-        } else if (have) {
-            long_idx[atomicAdd(long_n, 1u)] = (uint32_t)i;                              // (rare)
-        }
-        e = e1; e1 = e2;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * 64; i0 < n; i0 += (uint64_t)gridDim.x * 64) {
+        const uint64_t i = i0 + threadIdx.x;
+        const bool have = i < n;
+        const uint4 e = have ? cand[i] : make_uint4(0, 0, 0, 0);
+        const VsFile f = (n_files > 1 && have) ? files[e.y >> 16] : one;
+        const VsOut o = vs_out(f);
+        const bool done = walk_in_strips(vs_strips, strip_bytes, have, e, o, prm);
+        if (have && !done) walk_entry_global(o, e, prm);
+        __builtin_amdgcn_wave_barrier();
     }
-}
-
-// The candidates that did not fit a strip or have no known end: one lane per line, bytes straight from global memory.  The blocks
-// also add up the line counts of the scan's waves (the one number besides the records that the host is told; ctl[4..5] start at 0).
-__global__ __launch_bounds__(64) void k_varscan_walk_long(const uint8_t *__restrict__ buf, uint64_t nbytes, snpgpu_varscan_params prm, snpgpu_varscan_site *out,
-                                                          uint32_t capacity, uint32_t *ctl, unsigned long long *status, const uint4 *__restrict__ cand,
-                                                          const uint32_t *__restrict__ long_idx, const uint32_t *__restrict__ wave_lines, uint32_t n_waves) {
-    const uint32_t n = ctl[2];
-    for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 64)
-        walk_entry_global(buf, nbytes, cand[long_idx[i]], prm, out, capacity, ctl, status);
-    {   // every block a slice of the waves' line counts (up to 16 384 of them: one block alone would take longer than the scan's tail)
+    for (uint32_t fidx = blockIdx.x; fidx < n_files; fidx += gridDim.x) {
+        const VsFile f = n_files > 1 ? files[fidx] : one;
         unsigned long long s = 0;
-        for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < n_waves; k += gridDim.x * 64u) s += wave_lines[k];
+        for (uint32_t k = threadIdx.x; k < f.n_waves; k += 64) s += wave_lines[f.wave0 + k];
         for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
-        if (threadIdx.x == 0 && s) atomicAdd((unsigned long long *)(ctl + 4), s);
+        if (threadIdx.x == 0) *(unsigned long long *)(f.ctl + 4) = s;
     }
 }
 
 }  // namespace
 
-// Device scratch the site calling of one file needs besides its records: the candidate list (16 bytes per entry, one entry per 64
-// bytes of text: twelve times what a 30x pileup puts on it; a list that is full anyway costs speed, not answers), the indices of
-// the long candidates, one line count per scan wave.
-static inline uint32_t varscan_cand_cap(uint64_t nbytes) {
-    const uint64_t c = nbytes / 64 + 4096;
-    return (uint32_t)(c < 0x7FFFFFFFull ? c : 0x7FFFFFFFull);
-}
+// Device scratch the site calling of a launch needs besides its records: the global candidate list (16 bytes per entry; the scan's
+// waves walk their own candidates, so it only takes what overflows — a list that is full anyway costs speed, not answers) and one
+// line count per scan wave.
 static const uint32_t VARSCAN_MAX_WAVES = 256 * 64;
+static inline uint32_t varscan_cand_cap(uint64_t nbytes) {
+    const uint64_t c = nbytes / 256 + 4096;
+    return (uint32_t)(c < (1ull << 22) ? c : (1ull << 22));
+}
 size_t snpgpu_varscan_scratch_bytes(uint64_t nbytes) {
-    return (size_t)varscan_cand_cap(nbytes) * 20u + 4u * VARSCAN_MAX_WAVES + 1024;
+    return (size_t)varscan_cand_cap(nbytes) * 16u + 4u * VARSCAN_MAX_WAVES + 1024;
 }
+int snpgpu_varscan_halo_class(const uint8_t *, uint64_t) { return 0; }               // (rounds 3-4 chose a window geometry by the mean line length; one form serves all now)
 
-// d_ctl: 8 zeroed words — [0] records found, [1] candidate lines, [2] long candidates, [4..5] lines of the file (written by the
-// last kernel); d_status: one u64 preset to UINT64_MAX (becomes the offset of the first malformed line); d_scratch:
-// snpgpu_varscan_scratch_bytes(nbytes) bytes, 16-byte aligned.
-int snpgpu_varscan_halo_class(const uint8_t *head, uint64_t n) {
-    // from the first bytes of the file (on the host): 0 for lines of up to ~110 bytes on average, 1 up to ~480, else 2
-    uint64_t lines = 0;
-    for (uint64_t i = 0; i < n; ++i) lines += head[i] == '\n' || head[i] == '\r';
-    const uint64_t mean = n / (lines ? lines : 1);
-    return mean <= 110 ? 0 : mean <= 480 ? 1 : 2;
-}
-
-int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, const snpgpu_varscan_params *prm, snpgpu_varscan_site *d_sites,
-                           uint32_t capacity, uint32_t *d_ctl, uint64_t *d_status, void *d_scratch, int halo_class) {
-    if (nbytes == 0) return SNPGPU_OK;
-    const uint32_t cand_cap = varscan_cand_cap(nbytes);
-    uint4 *d_cand = (uint4 *)d_scratch;
-    uint32_t *d_long = (uint32_t *)((char *)d_scratch + (size_t)cand_cap * 16u);
-    uint32_t *d_wave_lines = d_long + cand_cap;
-    const uint64_t shift = (uintptr_t)d_buf & 15u;
-    const uint8_t *abase = d_buf - shift;
-    const uint64_t lo = shift, hi = shift + nbytes;
-    // (halo_class comes from snpgpu_varscan_halo_class over the file's first bytes: how long the lines are decides the geometry)
-    const uint32_t cpl = halo_class == 0 ? 4u : halo_class == 1 ? 6u : 8u;             // 16-byte chunks per lane: the slot is 64 of that
-    const uint32_t tile_bytes = halo_class == 0 ? 3840u : halo_class == 1 ? 5120u : 4096u;
-    const uint64_t n_tiles = (hi + tile_bytes - 1) / tile_bytes;
-    const uint32_t slot_bytes = cpl * 1024u, kw = slot_bytes / 32u;
-    const uint32_t lds = 2u * slot_bytes + 5u * (kw + 4u) * 4u + VS_CAND_LOCAL * 16u + (VS_LIST_CAP + 2u) * 2u + 12u;
-    const uint32_t lds_wave = (lds + 15u) / 16u * 16u;                                 // a wave's stretch of the workgroup's LDS
-    uint32_t waves_per_cu = 160u * 1024u / lds_wave;
-    if (waves_per_cu > 16u) waves_per_cu = 16u;                                        // (its registers allow 4 per SIMD)
-    // Eight workgroups (of one wave) for every place a CU has: the dispatcher hands out the next one when a wave ends, which evens
-    // out what a grid of exactly the resident size leaves to chance — how many waves share a SIMD, the oldest of them taking most
-    // issue slots (tools/vs_sweep.sh: 250 us for 432 MB with 12 waves per CU and one workgroup each, 174 us with eight each; 30x).
-    // One workgroup per CU, a multiple of four waves (the same number on every SIMD; 13 waves: 240 us where 12 take 170), every
-    // wave one contiguous run of tiles weighted by its age on its SIMD.  (Round 4's first form — one-wave workgroups, eight per
-    // resident place, balanced by the dispatcher — took 182 us in the same session, each short-lived wave paying its prologue.)
-    uint32_t wg_waves = waves_per_cu >= 4u ? waves_per_cu / 4u * 4u : 1u;
-    uint64_t grid = (uint64_t)ctx->n_cu * (wg_waves == 1u ? waves_per_cu : wg_waves);
-    if (grid > n_tiles / 4u) grid = n_tiles / 4u ? n_tiles / 4u : 1u;                   // (at least four tiles per wave)
-    uint32_t share[4] = {120, 100, 82, 70};                                             // tools/vs_share_sweep.sh: 181 -> 165 us at 30x, 513 -> 480 at 100x, 110 -> 100 at 8x
+// Deal the waves of a launch to its files in proportion to their sizes (every file at least one, every wave at least four tiles)
+// and launch the scan and its epilogue.  `h_files`: abase / lo / hi / out / capacity / ctl / status set by the caller; n_tiles,
+// wave0, n_waves are set here.  `d_files`: where the table is to go in device memory (n_files > 1; copied on the stream).
+// d_cand_n: one zeroed word.
+static int varscan_launch(snpgpu_ctx *ctx, VsFile *h_files, uint32_t n_files, VsFile *d_files, const snpgpu_varscan_params *prm, uint4 *d_cand,
+                          uint32_t cand_cap, uint32_t *d_cand_n, uint32_t *d_wave_lines) {
+    uint64_t total_tiles = 0;
+    for (uint32_t i = 0; i < n_files; ++i) {
+        h_files[i].n_tiles = h_files[i].hi / VS_TILE + 1;                               // (the tile of position hi, the virtual terminator, included)
+        total_tiles += h_files[i].n_tiles;
+    }
+    uint32_t wg_waves = 8;                                                              // 8 x 19 120 bytes of LDS: one workgroup per CU, two waves per SIMD
+    uint64_t resident = (uint64_t)ctx->n_cu * wg_waves;
+    uint32_t mult = total_tiles / resident >= 512 ? 4u : 1u;                            // long launches: four workgroups per CU in turn even out what one leaves to chance
+    uint32_t share[4] = {108, 92, 92, 92};
 #ifdef SNPGPU_TUNING                                            // development builds only (tools/)
-    if (const char *e = getenv("SNPGPU_VS_WAVES")) if (atoi(e) > 0) grid = (uint64_t)ctx->n_cu * (uint32_t)atoi(e);
-    if (const char *e = getenv("SNPGPU_VS_GRID_MUL")) if (atoi(e) > 0) grid *= (uint32_t)atoi(e);
-    if (const char *e = getenv("SNPGPU_VS_WG_WAVES")) if (atoi(e) > 0 && atoi(e) <= 16 && (uint32_t)atoi(e) * lds_wave <= 160u * 1024u) wg_waves = (uint32_t)atoi(e);
+    if (const char *e = getenv("SNPGPU_VS_GRID_MUL")) if (atoi(e) > 0) mult = (uint32_t)atoi(e);
+    uint32_t lds_waves = 8;                                     // (fewer waves per workgroup with the LDS of eight: that many waves per CU)
+    if (const char *e = getenv("SNPGPU_VS_WG_WAVES")) if (atoi(e) > 0 && atoi(e) <= 8) wg_waves = (uint32_t)atoi(e);
     if (const char *e = getenv("SNPGPU_VS_SHARE")) { int v[4]; if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4) for (int k = 0; k < 4; ++k) share[k] = v[k] > 0 ? (uint32_t)v[k] : 1u; }
 #endif
-    grid = (grid + wg_waves - 1) / wg_waves;                                            // (counted in waves so far; the launch counts workgroups)
-    if (grid * wg_waves > VARSCAN_MAX_WAVES) grid = VARSCAN_MAX_WAVES / wg_waves;
-    if (grid * wg_waves > n_tiles) grid = (n_tiles + wg_waves - 1) / wg_waves;
+#ifdef SNPGPU_TUNING
+    resident = (uint64_t)ctx->n_cu * wg_waves;
+    const uint32_t lds_bytes = VS_LDS_WAVE * (wg_waves < lds_waves ? lds_waves : wg_waves);
+#else
+    const uint32_t lds_bytes = VS_LDS_WAVE * wg_waves;
+#endif
+    uint64_t want = resident * mult;
+    if (want > VARSCAN_MAX_WAVES) want = VARSCAN_MAX_WAVES;
+    if (want > total_tiles / 4) want = total_tiles / 4 ? total_tiles / 4 : 1;
+    if (want < n_files) want = n_files;
+    uint32_t wave0 = 0;
+    for (uint32_t i = 0; i < n_files; ++i) {
+        uint64_t w = (uint64_t)((long double)want * (long double)h_files[i].n_tiles / (long double)total_tiles + 0.5L);
+        if (w < 1) w = 1;
+        if (w > h_files[i].n_tiles) w = h_files[i].n_tiles;
+        h_files[i].wave0 = wave0;
+        h_files[i].n_waves = (uint32_t)w;
+        wave0 += (uint32_t)w;
+    }
+    const uint32_t n_waves_total = wave0;
+    if (n_waves_total > 2 * VARSCAN_MAX_WAVES) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "too many pileups in one site-calling launch");
+    const uint32_t grid = (n_waves_total + wg_waves - 1) / wg_waves;
     if (!ctx->varscan_lds_attr) {                                                       // (more than 64 KiB of dynamic LDS needs the permission, per device)
-        for (auto f : {(const void *)k_varscan_scan<4>, (const void *)k_varscan_scan<6>, (const void *)k_varscan_scan<8>})
-            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_varscan_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_varscan_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         ctx->varscan_lds_attr = true;
     }
+    if (n_files > 1) HIP_TRY(ctx, hipMemcpyAsync(d_files, h_files, sizeof(VsFile) * n_files, hipMemcpyHostToDevice, ctx->stream));
     hipEvent_t ta = snpgpu_time_begin(ctx);
-#define VS_SCAN(C) k_varscan_scan<C><<<(unsigned)grid, 64u * wg_waves, lds_wave * wg_waves, ctx->stream>>>(abase, lo, hi, tile_bytes, n_tiles, *prm, d_cand, cand_cap, \
-                                                                            d_ctl, (unsigned long long *)d_status, d_sites, capacity, d_wave_lines, lds_wave / 16u, make_uint4(share[0], share[1], share[2], share[3]))
-    if (halo_class == 0) VS_SCAN(4); else if (halo_class == 1) VS_SCAN(6); else VS_SCAN(8);
-#undef VS_SCAN
-    // walk: LDS for 64 candidate lines — the deeper lines of the file — 2 .. 60 KiB
-    const uint32_t walk_bytes = halo_class == 0 ? 16u * 1024u : halo_class == 1 ? 32u * 1024u : 60u * 1024u;
-    const uint32_t walk_lds = walk_bytes + 16;                   // (+ one chunk: the walk may read the word after a line)
-    const uint32_t walk_waves_per_cu = 160 * 1024 / walk_lds < 16 ? 160 * 1024 / walk_lds : 16;
-    const unsigned walk_grid = (unsigned)((uint64_t)ctx->n_cu * (walk_waves_per_cu ? walk_waves_per_cu : 1));
-    k_varscan_walk<<<walk_grid, 64, walk_lds, ctx->stream>>>(d_buf, nbytes, *prm, d_sites, capacity, d_ctl, (unsigned long long *)d_status, walk_bytes, d_cand,
-                                                              d_ctl + 1, cand_cap, d_long, d_ctl + 2);
-    k_varscan_walk_long<<<ctx->n_cu, 64, 0, ctx->stream>>>(d_buf, nbytes, *prm, d_sites, capacity, d_ctl, (unsigned long long *)d_status, d_cand, d_long,
-                                                           d_wave_lines, (uint32_t)(grid * wg_waves));
+    k_varscan_scan<<<grid, 64u * wg_waves, lds_bytes, ctx->stream>>>(d_files, n_files, h_files[0], n_waves_total, *prm, d_cand, cand_cap, d_cand_n,
+                                                                                    d_wave_lines, make_uint4(share[0], share[1], share[2], share[3]));
+    const uint32_t strip_bytes = 32u * 1024u;
+    const uint32_t fin_grid = n_files > ctx->n_cu ? (uint32_t)ctx->n_cu * 4u : (uint32_t)ctx->n_cu;
+    k_varscan_finish<<<fin_grid, 64, strip_bytes + 16u, ctx->stream>>>(d_files, n_files, h_files[0], *prm, d_cand, d_cand_n, cand_cap, d_wave_lines, strip_bytes);
     snpgpu_time_end(ctx, SNPGPU_K_VARSCAN, ta);
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;
+}
+
+static inline void varscan_file_coords(VsFile &f, const uint8_t *d_buf, uint64_t nbytes) {
+    const uint64_t shift = ((uintptr_t)d_buf & 15u) + 16u;                              // the aligned coordinates start 16..31 bytes below the file
+    f.abase = d_buf - shift;
+    f.lo = shift;
+    f.hi = shift + nbytes;
+}
+
+// d_ctl: 8 zeroed words — [0] records found, [1] candidates on the global list, [4..5] lines of the file (written by the last
+// kernel); d_status: one u64 preset to UINT64_MAX (becomes the offset of the first malformed line); d_scratch:
+// snpgpu_varscan_scratch_bytes(nbytes) bytes, 16-byte aligned.
+int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, const snpgpu_varscan_params *prm, snpgpu_varscan_site *d_sites,
+                           uint32_t capacity, uint32_t *d_ctl, uint64_t *d_status, void *d_scratch, int /*halo_class*/) {
+    if (nbytes == 0) return SNPGPU_OK;
+    if (nbytes >> 47) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "pileup too large");
+    const uint32_t cand_cap = varscan_cand_cap(nbytes);
+    VsFile f;
+    memset(&f, 0, sizeof f);
+    varscan_file_coords(f, d_buf, nbytes);
+    f.out = d_sites; f.capacity = capacity; f.ctl = d_ctl; f.status = (unsigned long long *)d_status;
+    return varscan_launch(ctx, &f, 1, nullptr, prm, (uint4 *)d_scratch, cand_cap, d_ctl + 1, (uint32_t *)((char *)d_scratch + (size_t)cand_cap * 16u));
+}
+
+// Many resident pileups in ONE launch.  d_ctl: n_files x 8 zeroed words (as above, [1] of file 0 is the launch's list counter);
+// d_status: n_files u64 preset to UINT64_MAX; d_sites: n_files x capacity records; d_scratch: snpgpu_varscan_batch_scratch_bytes.
+size_t snpgpu_varscan_batch_scratch_bytes(uint64_t total_bytes, uint32_t n_files) {
+    return (size_t)varscan_cand_cap(total_bytes) * 16u + 4u * 2u * VARSCAN_MAX_WAVES + sizeof(VsFile) * (size_t)n_files + 1024;
+}
+size_t snpgpu_varscan_table_bytes(uint32_t n_files) { return sizeof(VsFile) * (size_t)(n_files ? n_files : 1); }
+int snpgpu_enqueue_varscan_batch(snpgpu_ctx *ctx, const uint8_t *const *d_bufs, const uint64_t *nbytes, uint32_t n_files, const snpgpu_varscan_params *prm,
+                                 snpgpu_varscan_site *d_sites, uint32_t capacity, uint32_t *d_ctl, uint64_t *d_status, void *d_scratch, void *h_table) {
+    // (h_table: sizeof(VsFile) * n_files bytes of host memory that stay valid until the stream has copied them)
+    if (n_files == 0) return SNPGPU_OK;
+    if (n_files > 0xFFFFu) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "too many pileups in one site-calling launch");
+    VsFile *h = (VsFile *)h_table;
+    uint64_t total = 0;
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < n_files; ++i) {
+        memset(&h[i], 0, sizeof h[i]);
+        if (nbytes[i] >> 47) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "pileup too large");
+        // (an empty file takes part with one tile: its only "line" starts behind its end and is not counted)
+        varscan_file_coords(h[i], d_bufs[i] ? d_bufs[i] : (const uint8_t *)d_scratch, nbytes[i]);
+        h[i].out = d_sites + (size_t)i * capacity; h[i].capacity = capacity; h[i].ctl = d_ctl + 8u * i; h[i].status = (unsigned long long *)(d_status + i);
+        total += nbytes[i];
+        ++n;
+    }
+    const uint32_t cand_cap = varscan_cand_cap(total);
+    char *s = (char *)d_scratch;
+    uint4 *d_cand = (uint4 *)s;
+    uint32_t *d_wave_lines = (uint32_t *)(s + (size_t)cand_cap * 16u);
+    VsFile *d_files = (VsFile *)(s + (size_t)cand_cap * 16u + 4u * 2u * VARSCAN_MAX_WAVES);
+    return varscan_launch(ctx, h, n, d_files, prm, d_cand, cand_cap, d_ctl + 1, d_wave_lines);
 }

@@ -595,6 +595,31 @@ class Device(object):
                 return sites[:n.value], int(status[1])
             capacity = max(n.value, 2 * cap)
 
+    def varscan_batch_dev(self, d_ptrs, sizes, params, capacity=32768):
+        """varscan_dev for many pileups in device memory with ONE scan launch (snpgpu_varscan_batch_dev).  Returns one
+        (records, n_lines) pair, or a PileupFormatError, per pileup; a pileup with more records than `capacity` is repeated alone."""
+        n = len(d_ptrs)
+        if n == 0:
+            return []
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(int(p)) if int(s) else None for p, s in zip(d_ptrs, sizes)])
+        nb = np.asarray([int(s) for s in sizes], dtype=np.uint64)
+        sites = np.zeros((n, max(int(capacity), 1)), dtype=VARSCAN_DTYPE)
+        counts = np.zeros(n, dtype=np.uint32)
+        status = np.zeros((n, 2), dtype=np.uint64)
+        rcs = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.snpgpu_varscan_batch_dev(self.ctx, ptrs, _ptr(nb), n, C.byref(params), int(capacity), _ptr(sites), _ptr(counts), _ptr(status), _ptr(rcs)))
+        out = []
+        for i in range(n):
+            if rcs[i] == L.E_PILEUP:
+                out.append(PileupFormatError("Invalid format for pileup at byte %d" % int(status[i, 0]), ValueError))
+            elif rcs[i] != 0:
+                out.append(RuntimeError("site calling failed for pileup %d (code %d)" % (i, int(rcs[i]))))
+            elif counts[i] > capacity:
+                out.append(self.varscan_dev(d_ptrs[i], sizes[i], params, capacity=int(counts[i])))
+            else:
+                out.append((sites[i, :counts[i]].copy(), int(status[i, 1])))
+        return out
+
     def pileups(self, budget_bytes=0):
         return Pileups(self, budget_bytes)
 

@@ -340,10 +340,10 @@ def test_empty_read_base_and_quality_columns_are_columns(d, tmp_path):
 
 
 def test_full_candidate_list_unaligned_text_and_lines_across_tiles(d, tmp_path):
-    """Round 4's index-free pass (k_varscan_scan): (1) more candidate lines than the list holds — depth-0 lines, which the
+    """The index-free pass (k_varscan_scan): (1) more candidate lines than the list holds — depth-0 lines, which the
     shortcut cannot vouch for, by the ten thousand — are looked at on the spot and the answer is the same; (2) text at every
     alignment mod 16 in device memory (snpgpu_varscan_dev); (3) line terminators, TABs and whole lines placed on the edges of the
-    4 KiB tiles and of the halo behind them, with LF / CR LF / lone CR ends."""
+    4 KiB tiles and of the ring of three tile slots, with LF / CR LF / lone CR ends."""
     import torch
     from snp_pipeline_amd import varscan
     opts = varscan.Options("--min-var-freq 0.2 --min-reads2 2")
@@ -381,7 +381,7 @@ def test_full_candidate_list_unaligned_text_and_lines_across_tiles(d, tmp_path):
     variant = b"c1\t7\tA\t12\tGGGGGGgggggg\tIIIIIIIIIIII"
     plainl = b"c1\t6\tA\t12\t......,,,,,,\tIIIIIIIIIIII"
     for eol in (b"\n", b"\r\n", b"\r"):
-        for edge in (4096, 8192, 4096 + 240, 4096 + 1008):
+        for edge in (4096, 8192, 12288, 16384):                  # (12288: where a wave's ring of three tile slots wraps around)
             for delta in range(-len(variant) - 3, 4):
                 pad_total = edge + delta
                 head = []
@@ -433,3 +433,47 @@ def test_bytes_above_0x89_next_to_terminators_and_tabs(d, tmp_path, eol):
     n_lines, n_rows = varscan.mpileup2snp(d, path, out, opts)
     want = vo.mpileup2snp(data, vo.Params(min_var_freq=0.2, min_reads2=2, min_avg_qual=0))
     assert open(out, "rb").read().decode("latin-1") == want and n_lines == len(lines) and n_rows > 400
+
+
+def test_many_resident_pileups_in_one_launch_equal_single_calls(d):
+    """snpgpu_varscan_batch_dev: one scan launch over pileups of very different sizes, line ends and depths, an empty one, a
+    malformed one, one with more records than the shared array holds, at odd alignments in device memory — every result equals
+    the single-pileup call's (and through it the restatement's: the tests above)."""
+    import torch
+    from snp_pipeline_amd import varscan
+    from snp_pipeline_amd.device import PileupFormatError
+    prm = varscan.Options("--min-var-freq 0.2 --min-reads2 2").device_params()
+    blobs = [fuzz.varscan_pileup(51, 9000), fuzz.varscan_pileup(52, 300), b"", fuzz.varscan_pileup(53, 30000, depths=(20, 30, 30, 45)),
+             b"c\t1\tA\t9\tGGGGGGGGG\n", fuzz.varscan_pileup(54, 2500, eol=b"\r\n"), fuzz.varscan_pileup(55, 1),
+             fuzz.varscan_pileup(56, 700, depths=(1500, 2500, 30, 0)), fuzz.varscan_pileup(57, 4000, eol=b"\r"), fuzz.varscan_adversarial(3, 2000)]
+    total = sum(len(b) + 64 for b in blobs)
+    buf = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+    ptrs, sizes, at = [], [], 3
+    for i, data in enumerate(blobs):
+        if data:
+            buf[at:at + len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        ptrs.append(buf.data_ptr() + at)
+        sizes.append(len(data))
+        at += len(data) + 17 + i                                   # every alignment class
+    torch.cuda.synchronize()
+    singles = []
+    for p, n in zip(ptrs, sizes):
+        try:
+            singles.append(d.varscan_dev(p, n, prm))
+        except PileupFormatError as e:
+            singles.append(e)
+    for capacity in (32768, 64):                                  # 64: most pileups overflow the shared array and are repeated alone
+        got = d.varscan_batch_dev(ptrs, sizes, prm, capacity=capacity)
+        assert len(got) == len(blobs)
+        for i, (g, w) in enumerate(zip(got, singles)):
+            if isinstance(w, Exception):
+                assert isinstance(g, PileupFormatError) and str(g) == str(w), i
+            else:
+                assert g[1] == w[1] and g[0].tobytes() == w[0].tobytes(), i
+    assert isinstance(singles[4], PileupFormatError) and singles[2][1] == 0 and len(singles[0][0]) > 50
+    # the same pileup many times over: more files than a launch has workgroups to spare, every copy the same answer
+    many = d.varscan_batch_dev([ptrs[1]] * 300 + [ptrs[0]] * 3, [sizes[1]] * 300 + [sizes[0]] * 3, prm)
+    for g in many[:300]:
+        assert g[1] == singles[1][1] and g[0].tobytes() == singles[1][0].tobytes()
+    for g in many[300:]:
+        assert g[0].tobytes() == singles[0][0].tobytes()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Phase-1 site calling on ONE synthetic sample that is already in device memory (snpgpu_varscan_dev): what the two kernels of
-csrc/varscan.hip and the line index cost without any file or copy.  Run it under rocprofv3 for the per-kernel numbers:
-    rocprofv3 --kernel-trace --stats -d gpurun_out/vs -- python tools/varscan_kernel_time.py [genome_len] [mean_depth] [reps]
+"""Phase-1 site calling on synthetic samples that already are in device memory: ONE sample per call (snpgpu_varscan_dev), then —
+with a fourth argument — that many distinct samples in one launch (snpgpu_varscan_batch_dev): what the kernels of csrc/varscan.hip
+cost without any file or copy.  HIP events around the launches on their stream; run it under rocprofv3 for the per-kernel numbers:
+    rocprofv3 --kernel-trace --stats -d gpurun_out/vs -- python tools/varscan_kernel_time.py [genome_len] [mean_depth] [reps] [batch]
 """
 import os
 import sys
@@ -19,6 +20,7 @@ def main():
     G = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
     depth = float(sys.argv[2]) if len(sys.argv) > 2 else 30.0
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    n_batch = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     d = dev.Device(0)
     d.use_torch_stream()
     ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda")
@@ -37,11 +39,38 @@ def main():
     torch.cuda.synchronize()
     prm = varscan.Options("--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5").device_params()
     recs, n_lines = d.varscan_dev(buf.data_ptr(), n, prm)
+    d.kernel_timing(True)
+    d.kernel_time_ms(3)
     t = time.perf_counter()
     for _ in range(reps):
         recs, n_lines = d.varscan_dev(buf.data_ptr(), n, prm)
     dt = (time.perf_counter() - t) / reps
-    print("%d bytes, %d lines, %d records: %.3f ms per call (two host round trips included) = %.2f TB/s" % (n, n_lines, len(recs), dt * 1e3, n / dt / 1e12))
+    k_ms, k_n = d.kernel_time_ms(3)
+    print("%d bytes, %d lines, %d records: %.3f ms per call (host round trips included) = %.2f TB/s; kernels %.1f us = %.2f TB/s (%.3f of 8 TB/s)"
+          % (n, n_lines, len(recs), dt * 1e3, n / dt / 1e12, k_ms / max(k_n, 1) * 1e3, n / (k_ms / max(k_n, 1) * 1e-3) / 1e12, n / (k_ms / max(k_n, 1) * 1e-3) / 8e12))
+    if n_batch:
+        bufs, sizes = [], []
+        for i in range(n_batch):
+            ni = d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), 0, 0, mean_depth=depth)
+            b = torch.empty(ni + 8192, dtype=torch.uint8, device="cuda")
+            d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), b.data_ptr(), ni, mean_depth=depth)
+            bufs.append(b)
+            sizes.append(ni)
+        torch.cuda.synchronize()
+        ptrs = [b.data_ptr() for b in bufs]
+        res = d.varscan_batch_dev(ptrs, sizes, prm)
+        assert res[0][0].tobytes() == recs.tobytes() and res[0][1] == n_lines           # (sample 0 again)
+        d.kernel_time_ms(3)
+        t = time.perf_counter()
+        for _ in range(max(reps // 2, 2)):
+            d.varscan_batch_dev(ptrs, sizes, prm)
+        dt = (time.perf_counter() - t) / max(reps // 2, 2)
+        k_ms, k_n = d.kernel_time_ms(3)
+        tot = sum(sizes)
+        print("batch of %d samples, %d bytes: %.3f ms per call; kernels %.1f us per call = %.1f us per sample = %.2f TB/s (%.3f of 8 TB/s)"
+              % (n_batch, tot, dt * 1e3, k_ms / max(k_n, 1) * 1e3, k_ms / max(k_n, 1) * 1e3 / n_batch, tot / (k_ms / max(k_n, 1) * 1e-3) / 1e12,
+                 tot / (k_ms / max(k_n, 1) * 1e-3) / 8e12))
+    d.kernel_timing(False)
 
 
 if __name__ == "__main__":
