@@ -356,12 +356,13 @@ __device__ __forceinline__ bool varscan_parse_lds(const uint32_t *lds32, uint32_
 constexpr uint32_t VS_W_PLAIN = 1u << 31, VS_W_LONG = 1u << 30;
 
 #define VS_TILE 4096u
-#define VS_RING (3u * VS_TILE)
-#define VS_MIRROR 128u                        // the ring's first bytes again behind its end: short reads need no wrap-around
+#define VS_RING (2u * VS_TILE)                // the two tile slots of a wave
+#define VS_PAD 64u                            // in front of each slot: the last bytes of the tile before the one in it
+#define VS_DATA (2u * (VS_PAD + VS_TILE))     // the slots with their pads
 #define VS_STR_WORDS (VS_RING / 32u)          // dwords of a bit string (and entries of the running counts) over the ring
-#define VS_STR_PAD 4u                         // ... and the first four again behind the end
-#define VS_CAND_LOCAL 128u                    // candidate entries a wave holds in LDS
-constexpr uint32_t VS_LDS_WAVE = VS_RING + VS_MIRROR + 3u * (VS_STR_WORDS + VS_STR_PAD) * 4u + VS_CAND_LOCAL * 16u;   // 19 120 bytes: eight waves per CU
+#define VS_STR_PAD 4u                         // ... and room for the reads that run over its end (their bits are masked away)
+#define VS_CAND_LOCAL 80u                     // candidate entries a wave holds in LDS
+constexpr uint32_t VS_LDS_WAVE = VS_DATA + 3u * (VS_STR_WORDS + VS_STR_PAD) * 4u + VS_CAND_LOCAL * 16u;   // 12 720 bytes: twelve waves per CU
 #define VS_NONE 0xFFFFFFFFu
 
 // One pileup of a launch: an entry of the device table, or (a launch over one file) a kernel argument.
@@ -481,7 +482,7 @@ __device__ __noinline__ SafeMasks classify_safe(const uint4 *src, uint32_t xq) {
 
 __device__ __forceinline__ uint32_t ffs64(uint64_t x) { return (uint32_t)__ffsll((long long)x) - 1u; }     // (x != 0)
 
-__global__ __launch_bounds__(512) void k_varscan_scan(const VsFile *__restrict__ files, uint32_t n_files, VsFile one, uint32_t n_waves_total,
+__global__ __launch_bounds__(768) void k_varscan_scan(const VsFile *__restrict__ files, uint32_t n_files, VsFile one, uint32_t n_waves_total,
                                                       snpgpu_varscan_params prm, uint4 *cand, uint32_t cand_cap, uint32_t *cand_n, uint32_t *wave_lines,
                                                       uint4 share) {
     extern __shared__ uint4 vs_lds_all[];
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(512) void k_varscan_scan(const VsFile *__restrict__
     // the waves of a workgroup are independent (no barrier anywhere): each has its own stretch of the workgroup's LDS
     uint8_t *ring = (uint8_t *)vs_lds_all + (size_t)wave_in_wg * VS_LDS_WAVE;
     const uint32_t *ring32 = (const uint32_t *)ring;
-    uint32_t *tabs32 = (uint32_t *)(ring + VS_RING + VS_MIRROR);
+    uint32_t *tabs32 = (uint32_t *)(ring + VS_DATA);
     uint32_t *lets32 = tabs32 + VS_STR_WORDS + VS_STR_PAD;
     uint32_t *pre = lets32 + VS_STR_WORDS + VS_STR_PAD;                                // (tabs before) | (letters before) << 16, per 32 bytes, modulo 2^16
     uint4 *cand_local = (uint4 *)(pre + VS_STR_WORDS + VS_STR_PAD);
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(512) void k_varscan_scan(const VsFile *__restrict__
         t_end = (uint64_t)((unsigned __int128)f.n_tiles * (cum((uint64_t)gwave + 1) - c_lo) / c_span);
     }
     if (t_first >= t_end) { if (lane == 0) wave_lines[gwave] = 0; return; }
-    const uint64_t t_last = t_end < f.n_tiles ? t_end : f.n_tiles - 1;                  // the last tile I read: the one after my run (ends of my last lines)
+    const uint64_t t_last = t_end < f.n_tiles ? t_end : f.n_tiles - 1;                  // the last tile I read: the one after my run (the end of my last line)
 
     auto flush = [&]() {                                                                // my candidates so far onto the global list
         if (n_local == 0) return;
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(512) void k_varscan_scan(const VsFile *__restrict__
             const uint64_t gr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ga >> 32)) << 32) |
                                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ga);
             const uint32_t voff = lane * 16u;
-            const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)ring) + slot * VS_TILE);
+            const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)ring) + VS_PAD + slot * (VS_PAD + VS_TILE));
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
                          "global_load_lds_dwordx4 %0, %1 offset:0\n\t"
                          "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(512) void k_varscan_scan(const VsFile *__restrict__
         // first / last tiles of the file: byte loads; the byte before the file and the byte behind it read as '\n' (byte 0 starts a
         // line, the last line ends with the file), the other bytes outside it as NUL
         const int64_t x0 = (int64_t)(tt * VS_TILE);
-        uint4 *dst = (uint4 *)(ring + slot * VS_TILE);
+        uint4 *dst = (uint4 *)(ring + VS_PAD + slot * (VS_PAD + VS_TILE));
 #pragma nounroll
         for (uint32_t c = lane; c < VS_TILE / 16u; c += 64) {
             uint32_t d[4] = {0, 0, 0, 0};
@@ -578,236 +579,254 @@ __global__ __launch_bounds__(512) void k_varscan_scan(const VsFile *__restrict__
         }
         return false;
     };
-    auto wrap = [](uint32_t x) -> uint32_t { const uint32_t y = x - VS_RING; return x < y ? x : y; };   // x < 2 * VS_RING -> ring offset
-
     uint32_t dma_mask = 0;                                                              // bit s: the tile now in slot s travels by DMA and has not been waited for
     if (request(t_first, 0)) dma_mask |= 1u;
     if (t_first + 1 <= t_last && request(t_first + 1, 1)) dma_mask |= 2u;
-    uint32_t slot = 0, pslot = 0;                                                       // ring slots of tile k and of tile k - 1
-    uint64_t prev_lf = 0, prev_cr = 0;                                                  // masks of tile k - 1 (fast form: cr == 0, lf = verified terminators)
+    uint32_t slot = 0;                                                                  // ring slot of tile k
     uint32_t base_t = 0, base_l = 0;                                                    // running counts at the start of tile k (wave-uniform)
-    for (uint64_t k = t_first;; ++k) {
-        const bool have_cur = k <= t_last;
-        uint64_t cur_lf = 0, cur_cr = 0;
-        if (have_cur) {
-            // the current tile's request has landed when only the next tile's is outstanding
-            if (dma_mask & ~(1u << slot)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            else { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dma_mask = 0; }
-            dma_mask &= ~(1u << slot);
-            __builtin_amdgcn_wave_barrier();
-            // ---- A: my 64 bytes of tile k -> terminator / TAB / letter masks -----------------------------------------------
-            const uint4 *src = (const uint4 *)(ring + slot * VS_TILE) + 4u * lane;
-            uint64_t m_nl, m_tab, m_let;
-            {
-                uint32_t bn[4], bt[4], bl[4], hi_any = 0;
-                uint4 keepv[4];
+    // the line that started in the tile before and had not ended there (all wave-uniform): where it starts, counted from the start of
+    // THAT tile, and what its first bytes said (bit 0: shape and depth vouched for; r1 << 1, r3 << 7, depth << 13)
+    uint32_t c_valid = 0, c_p0 = 0, c_pack = 0;
+    for (uint64_t k = t_first; k <= t_last; ++k) {
+        const bool own = k < t_end;                                                     // (wave-uniform) one of my tiles; else the one behind them: only the line carried into it
+        const uint32_t base = slot * VS_TILE;                                           // offset of tile k in the ring of the strings
+        const uint32_t dbase = VS_PAD + slot * (VS_PAD + VS_TILE);                      // ... and of its bytes in LDS (in front of them: the last 64 of tile k - 1)
+        const uint64_t t0k = k * VS_TILE;                                               // its aligned coordinate
+        // the current tile's request has landed when only the next tile's is outstanding
+        if (dma_mask & ~(1u << slot)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dma_mask = 0; }
+        dma_mask &= ~(1u << slot);
+        __builtin_amdgcn_wave_barrier();
+        // ---- A: my 64 bytes of tile k -> terminator / TAB / letter masks ---------------------------------------------------
+        const uint4 *src = (const uint4 *)(ring + dbase) + 4u * lane;
+        uint64_t m_nl, m_tab, m_let, cur_lf = 0, cur_cr = 0;
+        {
+            uint32_t bn[4], bt[4], bl[4], hi_any = 0;
+            uint4 keepv[4];
 #pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) {
-                    const uint4 v = src[i ^ xq];
-                    hi_any |= v.x | v.y | v.z | v.w;
-                    keepv[i] = v;
-                    const uint64_t q0 = (uint64_t)v.x | ((uint64_t)v.y << 32), q1 = (uint64_t)v.z | ((uint64_t)v.w << 32);
-                    const uint64_t a0 = q0 + 0x7777777777777777ull, b0 = q0 + 0x7676767676767676ull, c0 = q0 + 0x7272727272727272ull;
-                    const uint64_t a1 = q1 + 0x7777777777777777ull, b1 = q1 + 0x7676767676767676ull, c1 = q1 + 0x7272727272727272ull;
-                    bt[i] = gather16((uint32_t)a0 & ~(uint32_t)b0 & 0x80808080u, (uint32_t)(a0 >> 32) & ~(uint32_t)(b0 >> 32) & 0x80808080u,
-                                     (uint32_t)a1 & ~(uint32_t)b1 & 0x80808080u, (uint32_t)(a1 >> 32) & ~(uint32_t)(b1 >> 32) & 0x80808080u, 7);
-                    bn[i] = gather16((uint32_t)b0 & ~(uint32_t)c0 & 0x80808080u, (uint32_t)(b0 >> 32) & ~(uint32_t)(c0 >> 32) & 0x80808080u,
-                                     (uint32_t)b1 & ~(uint32_t)c1 & 0x80808080u, (uint32_t)(b1 >> 32) & ~(uint32_t)(c1 >> 32) & 0x80808080u, 7);
-                    // (x & ~(x << 3) & 0x40404040 as shift + one v_bitop3: left to itself the compiler moves the complement in front of the shift)
-                    bl[i] = gather16(__builtin_amdgcn_bitop3_b32(v.x, v.x << 3, 0x40404040u, 0x20), __builtin_amdgcn_bitop3_b32(v.y, v.y << 3, 0x40404040u, 0x20),
-                                     __builtin_amdgcn_bitop3_b32(v.z, v.z << 3, 0x40404040u, 0x20), __builtin_amdgcn_bitop3_b32(v.w, v.w << 3, 0x40404040u, 0x20), 6);
-                }
-                if (slot == 0) {                                                        // (wave-uniform) the mirror of the ring's first 128 bytes: lanes 0, 1 (xq == 0)
-                    if (lane < 2) {
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint4 v = src[i ^ xq];
+                keepv[i] = v;
+                hi_any |= v.x | v.y | v.z | v.w;
+                const uint64_t q0 = (uint64_t)v.x | ((uint64_t)v.y << 32), q1 = (uint64_t)v.z | ((uint64_t)v.w << 32);
+                const uint64_t a0 = q0 + 0x7777777777777777ull, b0 = q0 + 0x7676767676767676ull, c0 = q0 + 0x7272727272727272ull;
+                const uint64_t a1 = q1 + 0x7777777777777777ull, b1 = q1 + 0x7676767676767676ull, c1 = q1 + 0x7272727272727272ull;
+                bt[i] = gather16((uint32_t)a0 & ~(uint32_t)b0 & 0x80808080u, (uint32_t)(a0 >> 32) & ~(uint32_t)(b0 >> 32) & 0x80808080u,
+                                 (uint32_t)a1 & ~(uint32_t)b1 & 0x80808080u, (uint32_t)(a1 >> 32) & ~(uint32_t)(b1 >> 32) & 0x80808080u, 7);
+                bn[i] = gather16((uint32_t)b0 & ~(uint32_t)c0 & 0x80808080u, (uint32_t)(b0 >> 32) & ~(uint32_t)(c0 >> 32) & 0x80808080u,
+                                 (uint32_t)b1 & ~(uint32_t)c1 & 0x80808080u, (uint32_t)(b1 >> 32) & ~(uint32_t)(c1 >> 32) & 0x80808080u, 7);
+                // (x & ~(x << 3) & 0x40404040 as shift + one v_bitop3: left to itself the compiler moves the complement in front of the shift)
+                bl[i] = gather16(__builtin_amdgcn_bitop3_b32(v.x, v.x << 3, 0x40404040u, 0x20), __builtin_amdgcn_bitop3_b32(v.y, v.y << 3, 0x40404040u, 0x20),
+                                 __builtin_amdgcn_bitop3_b32(v.z, v.z << 3, 0x40404040u, 0x20), __builtin_amdgcn_bitop3_b32(v.w, v.w << 3, 0x40404040u, 0x20), 6);
+            }
+            if (lane == 63) {                                                           // the tile's last 64 bytes in front of the other slot (lane 63 read chunk i ^ 3 in turn i)
+                uint4 *pad = (uint4 *)(ring + (slot ? 0u : VS_PAD + VS_TILE));
 #pragma unroll
-                        for (uint32_t i = 0; i < 4; ++i) ((uint4 *)(ring + VS_RING))[lane * 4u + i] = keepv[i];
-                    }
-                }
-                m_nl = regroup16(bn[0] | (bn[1] << 16), bn[2] | (bn[3] << 16), xq);
-                m_tab = regroup16(bt[0] | (bt[1] << 16), bt[2] | (bt[3] << 16), xq);
-                m_let = regroup16(bl[0] | (bl[1] << 16), bl[2] | (bl[3] << 16), xq);
-                const bool high = __builtin_amdgcn_ballot_w64((hi_any & 0x80808080u) != 0u) != 0;
-                if (high || __builtin_amdgcn_readfirstlane(exact)) {                                                    // (wave-uniform) the slow, exact side
-                    const SafeMasks sm = classify_safe(src, xq);
-                    if (high) { m_nl = sm.nl; m_tab = sm.tab; m_let = sm.let; }
-                    cur_lf = sm.lf; cur_cr = sm.cr;
-                }
+                for (uint32_t i = 0; i < 4; ++i) pad[i ^ 3u] = keepv[i];
             }
-            if (!__builtin_amdgcn_readfirstlane(exact)) {
-                // every byte the fast form flagged: is it LF?  The first that is not — CR, VT, FF — switches the wave to the exact form
-                // before anything of this tile has been used (the tiles before it hold nothing but LF: they keep their masks)
-                bool odd = false;
-                uint64_t v = m_nl;
-                const uint8_t *mine = ring + slot * VS_TILE + lane * 64u;
-                while (__builtin_amdgcn_ballot_w64(v != 0)) {
-                    if (v) { odd |= mine[ffs64(v)] != 10u; v &= v - 1; }
-                }
-                if (__builtin_amdgcn_ballot_w64(odd)) {
-                    exact = 1u;
-                    const SafeMasks sm = classify_safe(src, xq);
-                    cur_lf = sm.lf; cur_cr = sm.cr;
-                } else { cur_lf = m_nl; cur_cr = 0; }
-            }
-            // the strings and the running counts of this tile
-            {
-                const uint32_t ct0 = (uint32_t)__popc((uint32_t)m_tab), ct1 = (uint32_t)__popc((uint32_t)(m_tab >> 32));
-                const uint32_t cl0 = (uint32_t)__popc((uint32_t)m_let), cl1 = (uint32_t)__popc((uint32_t)(m_let >> 32));
-                const uint32_t mine = (ct0 + ct1) | ((cl0 + cl1) << 16);               // (<= 64 each: the fields of the sums stay apart, <= 4096)
-                const uint32_t incl = wave_inclusive_sum(mine), excl = incl - mine;
-                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                const uint32_t t_run = base_t + (excl & 0xFFFFu), l_run = base_l + (excl >> 16);
-                const uint32_t blk = slot * 64u + lane;                                 // my 64-byte block of the ring
-                ((uint2 *)tabs32)[blk] = make_uint2((uint32_t)m_tab, (uint32_t)(m_tab >> 32));
-                ((uint2 *)lets32)[blk] = make_uint2((uint32_t)m_let, (uint32_t)(m_let >> 32));
-                const uint2 pp = make_uint2((t_run & 0xFFFFu) | (l_run << 16), ((t_run + ct0) & 0xFFFFu) | ((l_run + cl0) << 16));
-                ((uint2 *)pre)[blk] = pp;
-                if (slot == 0 && lane < 2) {                                            // the mirror behind the ring's end
-                    ((uint2 *)tabs32)[VS_STR_WORDS / 2u + lane] = make_uint2((uint32_t)m_tab, (uint32_t)(m_tab >> 32));
-                    ((uint2 *)lets32)[VS_STR_WORDS / 2u + lane] = make_uint2((uint32_t)m_let, (uint32_t)(m_let >> 32));
-                    ((uint2 *)pre)[VS_STR_WORDS / 2u + lane] = pp;
-                }
-                base_t = (base_t + (tot & 0xFFFFu)) & 0xFFFFu;
-                base_l = (base_l + (tot >> 16)) & 0xFFFFu;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (k > t_first) {
-            // ---- B: the lines that start behind the terminators of tile k - 1 ----------------------------------------------
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t pbase = pslot * VS_TILE;                                     // ring offset of tile k - 1
-            const uint64_t t0p = (k - 1) * VS_TILE;                                     // its aligned coordinate
-            const uint64_t hi_rel64 = f.hi - t0p;                                       // (t0p < hi: the tile is one of the file's)
-            const uint32_t hi_rel = hi_rel64 < 0xFFFFFFFFull ? (uint32_t)hi_rel64 : 0xFFFFFFFFu;
-            // terminators: LF, and (exact form) a CR that no LF follows
-            uint64_t T = prev_lf, Tc = cur_lf;
-            if (__builtin_amdgcn_readfirstlane(exact)) {
-                uint32_t nb = (uint32_t)__shfl_down((int)(uint32_t)prev_lf, 1) & 1u;
-                const uint32_t first_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cur_lf) & 1u;
-                if (lane == 63) nb = first_cur;
-                T = prev_lf | (prev_cr & ~((prev_lf >> 1) | ((uint64_t)nb << 63)));
-                // (of tile k only the first terminator matters here; a CR in its last byte waits for tile k + 1: not taken for one)
-                uint32_t nc = (uint32_t)__shfl_down((int)(uint32_t)cur_lf, 1) & 1u;
-                if (lane == 63) nc = 1u;
-                Tc = cur_lf | (cur_cr & ~((cur_lf >> 1) | ((uint64_t)nc << 63)));
-            }
-            // where the first line after this tile's last terminator ends: the first terminator of tile k (VS_NONE: not in sight)
-            uint32_t next_first = VS_NONE;
-            {
-                const uint64_t bm = __builtin_amdgcn_ballot_w64(Tc != 0);
-                if (bm) {
-                    const uint32_t j0 = ffs64(bm);
-                    next_first = VS_TILE + j0 * 64u + (uint32_t)__builtin_amdgcn_readlane((int)(Tc ? ffs64(Tc) : 0u), (int)j0);
-                }
-            }
-            // ... and for every lane: the first terminator behind its own last one
-            uint32_t nxt = next_first;
-            {
-                const uint32_t first_t = T ? lane * 64u + ffs64(T) : VS_NONE;
-                const uint64_t bm = __builtin_amdgcn_ballot_w64(T != 0);
-                const uint64_t above = (bm >> 1) >> lane;                               // lanes lane + 1 ..
-                const uint32_t j = above ? lane + 1u + ffs64(above) : lane;
-                const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)first_t);
-                if (above) nxt = got;
-            }
-            uint64_t pend = T;
-            // One line per lane and round, in straight-line code: every test lands in a flag, every LDS read is issued whether its
-            // line needs it or not (a read outside the wave's LDS returns nothing and costs nothing), so a round is three LDS
-            // round trips — the TAB window; the depth and what hangs on the fourth TAB; what hangs on the depth — and no branch.
-            for (;;) {
-                if (!__builtin_amdgcn_ballot_w64(pend != 0)) break;
-                const bool active = pend != 0;
-                const uint32_t bpos = ffs64(pend);                                      // (no terminator left: 0xFFFFFFFF, the lane is not `valid`)
-                pend &= pend - 1;                                                       // (0 stays 0)
-                const uint32_t p0 = lane * 64u + bpos + 1u;                             // the line's first byte, counted from the start of tile k - 1
-                const uint32_t e = pend ? lane * 64u + ffs64(pend) : nxt;               // the terminator that ends it
-                const bool valid = active & (p0 < hi_rel);                              // (the virtual terminator behind the file starts no line)
-                lines_seen += valid ? 1u : 0u;
-                const uint32_t a0 = wrap(pbase + p0);                                   // ring offset of the line's first byte
-                uint32_t le = e;                                                        // the line without its terminator: [p0, le)
-                if (__builtin_amdgcn_readfirstlane(exact)) {                            // (wave-uniform) CR LF: both go
-                    const uint32_t ae = wrap(pbase + e);
-                    const bool pair = (e != VS_NONE) & (e > p0) & (ring[ae & 0x3FFFu] == 10u) & (ring[(ae ? ae - 1u : VS_RING - 1u) & 0x3FFFu] == 13u);
-                    le = pair ? e - 1u : e;
-                }
-                const uint32_t span = le - p0;
-                // the first four TABs out of the 64 bits of the TAB string from the line's first byte on
-                const uint32_t wq = (a0 >> 5) & 0x1FFu, sh = a0 & 31u;
-                const uint32_t w0 = tabs32[wq], w1 = tabs32[wq + 1u], w2 = tabs32[wq + 2u];
-                const uint32_t pre_p0 = pre[wq];
-                const uint32_t a_le = wrap(pbase + le) & 0x3FFFu;
-                const uint32_t tw_le = tabs32[a_le >> 5], pre_le = pre[a_le >> 5];
-                uint32_t m32 = __builtin_amdgcn_alignbit(w1, w0, sh);
-                m32 = span < 32u ? m32 & ((1u << (span & 31u)) - 1u) : m32;
-                bool four = __popc(m32) >= 4;
-                uint32_t r0 = (uint32_t)__ffs((int)m32) - 1u; m32 &= m32 - 1u;
-                uint32_t r1 = (uint32_t)__ffs((int)m32) - 1u; m32 &= m32 - 1u;
-                uint32_t r2 = (uint32_t)__ffs((int)m32) - 1u; m32 &= m32 - 1u;
-                uint32_t r3 = (uint32_t)__ffs((int)m32) - 1u;
-                if (__builtin_amdgcn_ballot_w64(valid & !four & (span > 32u) & (e != VS_NONE))) {   // (wave-uniform) long contig names: 64 bytes
-                    uint64_t M = (uint64_t)__builtin_amdgcn_alignbit(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32);
-                    M = span < 64u ? M & ((1ull << (span & 63u)) - 1ull) : M;
-                    four = __popcll(M) >= 4;
-                    r0 = ffs64(M); M &= M - 1ull;
-                    r1 = ffs64(M); M &= M - 1ull;
-                    r2 = ffs64(M); M &= M - 1ull;
-                    r3 = ffs64(M);
-                }
-                r0 &= 63u; r1 &= 63u; r2 &= 63u; r3 &= 63u;                            // (four == false: anything, but small)
-                const uint32_t nd = r3 - r2 - 1u;                                       // digits of the depth
-                const bool shape = four & (r0 > 0u) & (r1 > r0 + 1u) & (r2 == r1 + 2u) & (nd - 1u < 4u);
-                // the depth: four bytes from its first digit on, most significant first (up to 64 bytes behind a0: the mirror is there)
-                const uint32_t da = a0 + r2 + 1u;
-                const uint32_t a_b0 = a0 + r3 + 1u;
-                const uint32_t d_lo = ring32[da >> 2], d_hi = ring32[(da >> 2) + 1u];
-                const uint32_t lw_b0 = lets32[a_b0 >> 5], pre_b0 = pre[a_b0 >> 5];
-                const uint32_t x = __builtin_amdgcn_alignbyte(d_hi, d_lo, da & 3u);
-                const uint32_t keep = nd >= 4u ? 0xFFFFFFFFu : (1u << (8u * (nd & 3u))) - 1u;
-                const uint32_t z = (x & keep) | (0x30303030u & ~keep);                  // the bytes behind the digits read as '0'
-                // every byte in '0'..'9': bit 7 clear, z + 0x46 below 0x80, z + 0x50 at or above it
-                const bool digits = ((z | (z + 0x46464646u) | ~(z + 0x50505050u)) & 0x80808080u) == 0u;
-                const uint32_t ys = (z - 0x30303030u) << ((8u * (4u - nd)) & 31u);      // digit k in byte 4 - nd + k: weights 1000, 100, 10, 1 by byte
-                const uint32_t depth = (__builtin_amdgcn_udot4(ys, 0x010A6400u, 0u, false) + (ys & 0xFFu) * 1000u) & 0x3FFFu;
-                const uint32_t b0 = p0 + r3 + 1u;
-                const bool fits = digits & (depth >= 1u) & (b0 + 1u + depth < le);
-                const uint32_t t4 = le - depth - 1u;
-                const uint32_t a_t4 = wrap(pbase + t4) & 0x3FFFu;
-                const uint32_t tw_t4 = tabs32[a_t4 >> 5], lw_t4 = lets32[a_t4 >> 5], pre_t4 = pre[a_t4 >> 5];
-                // TABs in [p0, le), letters in [b0, t4): differences of running counts
-                const uint32_t tabs = ((pre_le & 0xFFFFu) + (uint32_t)__popc(tw_le & ((1u << (a_le & 31u)) - 1u)) -
-                                       (pre_p0 & 0xFFFFu) - (uint32_t)__popc(w0 & ((1u << sh) - 1u))) & 0xFFFFu;
-                const uint32_t letters = ((pre_t4 >> 16) + (uint32_t)__popc(lw_t4 & ((1u << (a_t4 & 31u)) - 1u)) -
-                                          (pre_b0 >> 16) - (uint32_t)__popc(lw_b0 & ((1u << (a_b0 & 31u)) - 1u))) & 0xFFFFu;
-                const bool plain = shape & fits & (((tw_t4 >> (a_t4 & 31u)) & 1u) != 0u) & (tabs == 5u);
-                // (min_reads2 0: an allele without reads is skipped by the walk, so one letter is still needed)
-                const bool calls = (depth >= prm.min_coverage) & (letters >= (prm.min_reads2 > 1u ? prm.min_reads2 : 1u));
-                // a line that runs past tile k: the walk finds its end; an empty line: nothing; a line the shortcut cannot vouch for: the
-                // walk looks at it in full (format errors included)
-                const bool is_long = e == VS_NONE;
-                const bool is_cand = valid & (is_long | ((le > p0) & (!plain | calls)));
-                const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
-                if (mk) {
-                    const uint64_t off = t0p + p0 - f.lo;                               // file offset of the line
-                    uint4 ent;
-                    ent.x = (uint32_t)off; ent.y = (uint32_t)(off >> 32) | (fi << 16);
-                    ent.z = is_long ? 0u : (e + 1u < hi_rel ? e + 1u : hi_rel) - p0;    // (the virtual terminator behind the file is no byte of the line)
-                    ent.w = is_long ? VS_W_LONG : plain ? (VS_W_PLAIN | depth | (r1 << 14) | (r3 << 20)) : 0u;
-                    if (is_cand) cand_local[n_local + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = ent;
-                    n_local += (uint32_t)__popcll(mk);
-                    __builtin_amdgcn_wave_barrier();
-                    if (n_local + 64u > VS_CAND_LOCAL) { flush(); dma_mask = 0; __builtin_amdgcn_wave_barrier(); }
-                }
+            m_nl = regroup16(bn[0] | (bn[1] << 16), bn[2] | (bn[3] << 16), xq);
+            m_tab = regroup16(bt[0] | (bt[1] << 16), bt[2] | (bt[3] << 16), xq);
+            m_let = regroup16(bl[0] | (bl[1] << 16), bl[2] | (bl[3] << 16), xq);
+            const bool high = __builtin_amdgcn_ballot_w64((hi_any & 0x80808080u) != 0u) != 0;
+            if (high || __builtin_amdgcn_readfirstlane(exact)) {                        // (wave-uniform) the slow, exact side
+                const SafeMasks sm = classify_safe(src, xq);
+                if (high) { m_nl = sm.nl; m_tab = sm.tab; m_let = sm.let; }
+                cur_lf = sm.lf; cur_cr = sm.cr;
             }
         }
-        if (k >= t_end) break;
-        // the slot of tile k - 1 is free: every LDS read of it has returned
+        if (!__builtin_amdgcn_readfirstlane(exact)) {
+            // every byte the fast form flagged: is it LF?  The first that is not — CR, VT, FF — switches the wave to the exact form
+            // before anything of this tile has been used (the tiles before it hold nothing but LF)
+            bool odd = false;
+            uint64_t v = m_nl;
+            const uint8_t *mine = ring + dbase + lane * 64u;
+            while (__builtin_amdgcn_ballot_w64(v != 0)) {
+                if (v) { odd |= mine[ffs64(v)] != 10u; v &= v - 1; }
+            }
+            if (__builtin_amdgcn_ballot_w64(odd)) {
+                exact = 1u;
+                const SafeMasks sm = classify_safe(src, xq);
+                cur_lf = sm.lf; cur_cr = sm.cr;
+            } else { cur_lf = m_nl; cur_cr = 0; }
+        }
+        // the strings and the running counts of this tile
+        {
+            const uint32_t ct0 = (uint32_t)__popc((uint32_t)m_tab), ct1 = (uint32_t)__popc((uint32_t)(m_tab >> 32));
+            const uint32_t cl0 = (uint32_t)__popc((uint32_t)m_let), cl1 = (uint32_t)__popc((uint32_t)(m_let >> 32));
+            const uint32_t mine = (ct0 + ct1) | ((cl0 + cl1) << 16);                   // (<= 64 each: the fields of the sums stay apart, <= 4096)
+            const uint32_t incl = wave_inclusive_sum(mine), excl = incl - mine;
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t t_run = base_t + (excl & 0xFFFFu), l_run = base_l + (excl >> 16);
+            const uint32_t blk = slot * 64u + lane;                                     // my 64-byte block of the ring
+            ((uint2 *)tabs32)[blk] = make_uint2((uint32_t)m_tab, (uint32_t)(m_tab >> 32));
+            ((uint2 *)lets32)[blk] = make_uint2((uint32_t)m_let, (uint32_t)(m_let >> 32));
+            ((uint2 *)pre)[blk] = make_uint2((t_run & 0xFFFFu) | (l_run << 16), ((t_run + ct0) & 0xFFFFu) | ((l_run + cl0) << 16));
+            base_t = (base_t + (tot & 0xFFFFu)) & 0xFFFFu;
+            base_l = (base_l + (tot >> 16)) & 0xFFFFu;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        const uint32_t nslot = slot == 0 ? 2u : slot - 1u;                              // (slot + 2) % 3: where tile k - 1 was
-        if (k + 2 <= t_last && request(k + 2, nslot)) dma_mask |= 1u << nslot;
-        prev_lf = cur_lf; prev_cr = cur_cr;
-        pslot = slot;
-        slot = slot == 2 ? 0u : slot + 1u;
+        // ---- B: the lines that start behind the terminators of tile k, and the one carried into it --------------------------------
+        const uint64_t hi_rel64 = f.hi - t0k;                                           // (t0k <= hi: the tile is one of the file's)
+        const uint32_t hi_rel = hi_rel64 < 0x7FFFFFFFull ? (uint32_t)hi_rel64 : 0x7FFFFFFFu;
+        // terminators: LF, and (exact form) a CR that no LF follows
+        uint64_t T = cur_lf;
+        const uint32_t is_exact = __builtin_amdgcn_readfirstlane(exact);
+        if (is_exact) {
+            uint32_t nb = (uint32_t)__shfl_down((int)(uint32_t)cur_lf, 1) & 1u;
+            if ((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur_cr >> 32), 63) >> 31) {                                                              // (rare) a CR in the tile's last byte: what follows it is in the next tile
+                const uint64_t at = t0k + VS_TILE;
+                const uint32_t nx = at < f.hi ? (uint32_t)f.abase[at] : (at == f.hi ? 10u : 0u);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                dma_mask = 0;
+                if (lane == 63) nb = nx == 10u ? 1u : 0u;
+            }
+            T = cur_lf | (cur_cr & ~((cur_lf >> 1) | ((uint64_t)nb << 63)));
+        }
+        // the first terminator of the tile: where the carried line ends
+        uint32_t first_cur = VS_NONE;
+        const uint64_t t_lanes = __builtin_amdgcn_ballot_w64(T != 0);
+        {
+            if (t_lanes) {
+                const uint32_t j0 = ffs64(t_lanes);
+                first_cur = j0 * 64u + (uint32_t)__builtin_amdgcn_readlane((int)(T ? ffs64(T) : 0u), (int)j0);
+            }
+        }
+        if (c_valid && first_cur == VS_NONE) {                                          // the carried line runs on past this tile (> 4 KiB): the walk finds its end
+            if (lane == 0) {
+                const uint64_t off = t0k - VS_TILE + c_p0 - f.lo;
+                cand_local[n_local] = make_uint4((uint32_t)off, (uint32_t)(off >> 32) | (fi << 16), 0u, VS_W_LONG);
+            }
+            ++n_local;
+            c_valid = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (n_local + 64u > VS_CAND_LOCAL) { flush(); dma_mask = 0; __builtin_amdgcn_wave_barrier(); }
+        }
+        // for every lane: the first terminator behind its own last one (VS_NONE: none in this tile)
+        uint32_t nxt = VS_NONE;
+        {
+            const uint32_t first_t = T ? lane * 64u + ffs64(T) : VS_NONE;
+            const uint64_t above = (t_lanes >> 1) >> lane;                              // lanes lane + 1 ..
+            const uint32_t j = above ? lane + 1u + ffs64(above) : lane;
+            const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)first_t);
+            if (above) nxt = got;
+        }
+        uint64_t pend = own ? T : 0ull;
+        uint32_t n_valid = 0, n_pack = 0, n_p0 = 0;                                     // the line this tile hands on
+        // One line per lane and round, in straight-line code: every test lands in a flag, every LDS read is issued whether its
+        // line needs it or not (a read outside the wave's LDS returns nothing and costs nothing), so a round is three LDS
+        // round trips — the TAB window; the depth and what hangs on the fourth TAB; what hangs on the depth — and no branch.  The
+        // carried line takes the first lane that has no line of its own in a round.
+        for (;;) {
+            const uint64_t busy = __builtin_amdgcn_ballot_w64(pend != 0);
+            if (!busy && !c_valid) break;
+            uint32_t taker = 64u;
+            if (c_valid && ~busy) { taker = ffs64(~busy); c_valid = 0; }
+            const bool take = lane == taker;
+            const bool active = (pend != 0) | take;
+            const uint32_t bpos = ffs64(pend);                                          // (no terminator left: 0xFFFFFFFF)
+            pend &= pend - 1;                                                           // (0 stays 0)
+            // the line's first byte and the terminator that ends it, counted from the start of tile k (the carried line: p0 < 0)
+            const uint32_t p0 = take ? c_p0 - VS_TILE : lane * 64u + bpos + 1u;
+            const uint32_t e = take ? first_cur : (pend ? lane * 64u + ffs64(pend) : nxt);
+            const bool starts = active & (take | (p0 < hi_rel));                        // (the virtual terminator behind the file starts no line)
+            lines_seen += (starts & !take) ? 1u : 0u;                                   // (the carried line was counted where it started)
+            const bool defer = starts & (e == VS_NONE);                                 // the last terminator of the tile: its line ends in a later one
+            const uint32_t a0 = (base + p0) & (VS_RING - 1u);                           // ring offset of the line's first byte
+            uint32_t le = e;                                                            // the line without its terminator: [p0, le)
+            if (is_exact) {                                                             // (wave-uniform) CR LF: both go
+                const uint32_t ae = (dbase + e) & 0x3FFFu;                              // (e == VS_NONE: anywhere, but inside the wave's LDS)
+                const bool pair = (e != VS_NONE) & ((int32_t)(e - p0) > 0) & (ring[ae] == 10u) & (ring[(ae - 1u) & 0x3FFFu] == 13u);
+                le = pair ? e - 1u : e;
+            }
+            const uint32_t span = le - p0;
+            // the first four TABs out of the 64 bits of the TAB string from the line's first byte on
+            const uint32_t wq = a0 >> 5, sh = a0 & 31u;
+            const uint32_t w0 = tabs32[wq], w1 = tabs32[(wq + 1u) & (VS_STR_WORDS - 1u)], w2 = tabs32[(wq + 2u) & (VS_STR_WORDS - 1u)];
+            const uint32_t pre_p0 = pre[wq];
+            const uint32_t a_le = (base + le) & (VS_RING - 1u);
+            const uint32_t tw_le = tabs32[a_le >> 5], pre_le = pre[a_le >> 5];
+            uint32_t m32 = __builtin_amdgcn_alignbit(w1, w0, sh);
+            m32 = span < 32u ? m32 & ((1u << (span & 31u)) - 1u) : m32;
+            bool four = __popc(m32) >= 4;
+            uint32_t r0 = (uint32_t)__ffs((int)m32) - 1u; m32 &= m32 - 1u;
+            uint32_t r1 = (uint32_t)__ffs((int)m32) - 1u; m32 &= m32 - 1u;
+            uint32_t r2 = (uint32_t)__ffs((int)m32) - 1u; m32 &= m32 - 1u;
+            uint32_t r3 = (uint32_t)__ffs((int)m32) - 1u;
+            if (__builtin_amdgcn_ballot_w64(starts & !four & ((span > 32u) | defer))) {   // (wave-uniform) long contig names: 64 bytes
+                uint64_t M = (uint64_t)__builtin_amdgcn_alignbit(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32);
+                M = span < 64u ? M & ((1ull << (span & 63u)) - 1ull) : M;
+                four = __popcll(M) >= 4;
+                r0 = ffs64(M); M &= M - 1ull;
+                r1 = ffs64(M); M &= M - 1ull;
+                r2 = ffs64(M); M &= M - 1ull;
+                r3 = ffs64(M);
+            }
+            r0 &= 63u; r1 &= 63u; r2 &= 63u; r3 &= 63u;                                // (four == false: anything, but small)
+            const uint32_t nd = r3 - r2 - 1u;                                           // digits of the depth
+            // the depth: four bytes from its first digit on, most significant first
+            const uint32_t da = (dbase + p0 + r2 + 1u) & 0x3FFFu;                       // (the carried line: p0 >= -63 where its first bytes matter, they are in the pad)
+            const uint32_t d_lo = ring32[da >> 2], d_hi = ring32[(da >> 2) + 1u];
+            const uint32_t x = __builtin_amdgcn_alignbyte(d_hi, d_lo, da & 3u);
+            const uint32_t keep = nd >= 4u ? 0xFFFFFFFFu : (1u << (8u * (nd & 3u))) - 1u;
+            const uint32_t z = (x & keep) | (0x30303030u & ~keep);                      // the bytes behind the digits read as '0'
+            // every byte in '0'..'9': bit 7 clear, z + 0x46 below 0x80, z + 0x50 at or above it
+            const bool digits = ((z | (z + 0x46464646u) | ~(z + 0x50505050u)) & 0x80808080u) == 0u;
+            const uint32_t ys = (z - 0x30303030u) << ((8u * (4u - nd)) & 31u);          // digit k in byte 4 - nd + k: weights 1000, 100, 10, 1 by byte
+            uint32_t depth = (__builtin_amdgcn_udot4(ys, 0x010A6400u, 0u, false) + (ys & 0xFFu) * 1000u) & 0x3FFFu;
+            // what the line's first bytes say: four TABs where chrom / position / a one-byte reference / 1-4 digits of depth >= 1 put them.
+            // A line that is handed on is vouched for here when all four lie in this tile (the strings of the next one are not there
+            // yet); else the lane that takes it in the next tile looks again: the tile's last 64 bytes are in front of the next one.
+            bool head = four & (r0 > 0u) & (r1 > r0 + 1u) & (r2 == r1 + 2u) & (nd - 1u < 4u) & digits & (depth >= 1u) & (!defer | (p0 + r3 < VS_TILE));
+            // hand the line on ...
+            const uint64_t dm = __builtin_amdgcn_ballot_w64(defer);
+            if (dm) {
+                const uint32_t dl = ffs64(dm);
+                n_valid = 1u;
+                n_p0 = (uint32_t)__builtin_amdgcn_readlane((int)p0, (int)dl);
+                n_pack = (uint32_t)__builtin_amdgcn_readlane((int)((head ? 1u : 0u) | (r1 << 1) | (r3 << 7) | (depth << 13)), (int)dl);
+            }
+            // ... or take the one handed to this tile
+            const bool taken = take & ((c_pack & 1u) != 0u);                            // (else: what this lane has just read itself, ...
+            head = taken | (head & (!take | (c_p0 + 63u >= VS_TILE)));                  //  which is the line's when it starts in the pad)
+            r1 = taken ? (c_pack >> 1) & 63u : r1;
+            r3 = taken ? (c_pack >> 7) & 63u : r3;
+            depth = taken ? c_pack >> 13 : depth;
+            const uint32_t a_b0 = (a0 + r3 + 1u) & (VS_RING - 1u);
+            const uint32_t lw_b0 = lets32[a_b0 >> 5], pre_b0 = pre[a_b0 >> 5];
+            const bool fits = r3 + 2u + depth < span;                                   // (b0 + 1 + depth < le)
+            const uint32_t t4 = le - depth - 1u;
+            const uint32_t a_t4 = (base + t4) & (VS_RING - 1u);
+            const uint32_t tw_t4 = tabs32[a_t4 >> 5], lw_t4 = lets32[a_t4 >> 5], pre_t4 = pre[a_t4 >> 5];
+            // TABs in [p0, le), letters in [b0, t4): differences of running counts
+            const uint32_t tabs = ((pre_le & 0xFFFFu) + (uint32_t)__popc(tw_le & ((1u << (a_le & 31u)) - 1u)) -
+                                   (pre_p0 & 0xFFFFu) - (uint32_t)__popc(w0 & ((1u << sh) - 1u))) & 0xFFFFu;
+            const uint32_t letters = ((pre_t4 >> 16) + (uint32_t)__popc(lw_t4 & ((1u << (a_t4 & 31u)) - 1u)) -
+                                      (pre_b0 >> 16) - (uint32_t)__popc(lw_b0 & ((1u << (a_b0 & 31u)) - 1u))) & 0xFFFFu;
+            const bool plain = head & fits & (((tw_t4 >> (a_t4 & 31u)) & 1u) != 0u) & (tabs == 5u);
+            // (min_reads2 0: an allele without reads is skipped by the walk, so one letter is still needed)
+            const bool calls = (depth >= prm.min_coverage) & (letters >= (prm.min_reads2 > 1u ? prm.min_reads2 : 1u));
+            // an empty line: nothing; a line the shortcut cannot vouch for: the walk looks at it in full (format errors included)
+            const bool is_cand = starts & !defer & ((int32_t)span > 0) & (!plain | calls);
+            const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
+            if (mk) {
+                const uint64_t off = t0k + (uint64_t)(int64_t)(int32_t)p0 - f.lo;      // file offset of the line
+                uint4 ent;
+                ent.x = (uint32_t)off; ent.y = (uint32_t)(off >> 32) | (fi << 16);
+                ent.z = (e + 1u < hi_rel ? e + 1u : hi_rel) - p0;                       // (the virtual terminator behind the file is no byte of the line)
+                ent.w = plain ? (VS_W_PLAIN | depth | (r1 << 14) | (r3 << 20)) : 0u;
+                if (is_cand) cand_local[n_local + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = ent;
+                n_local += (uint32_t)__popcll(mk);
+                __builtin_amdgcn_wave_barrier();
+                if (n_local + 64u > VS_CAND_LOCAL) { flush(); dma_mask = 0; __builtin_amdgcn_wave_barrier(); }
+            }
+        }
+        c_valid = n_valid; c_p0 = n_p0; c_pack = n_pack;
+        // this slot is free: every LDS read of it has returned (the line handed on travels in registers)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (k + 2 <= t_last && request(k + 2, slot)) dma_mask |= 1u << slot;
+        slot ^= 1u;
     }
     // ---- my candidates: their lines into the ring (free now), every lane walks its own ------------------------------------------
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -816,7 +835,7 @@ __global__ __launch_bounds__(512) void k_varscan_scan(const VsFile *__restrict__
         bool have = r + lane < n_local;
         const uint4 e = have ? cand_local[r + lane] : make_uint4(0, 0, 0, 0);
         for (int round = 0; round < 4 && __builtin_amdgcn_ballot_w64(have); ++round) {
-            const bool done = walk_in_strips((uint4 *)ring, VS_RING + VS_MIRROR - 16u, have, e, fo, prm);   // (- one chunk: the walk may read the word after a line)
+            const bool done = walk_in_strips((uint4 *)ring, VS_DATA + 3u * (VS_STR_WORDS + VS_STR_PAD) * 4u - 16u, have, e, fo, prm);   // (- one chunk: the walk may read the word after a line)
             const bool progress = __builtin_amdgcn_ballot_w64(done && have) != 0;
             have = have && !done;
             __builtin_amdgcn_wave_barrier();
@@ -892,14 +911,14 @@ static int varscan_launch(snpgpu_ctx *ctx, VsFile *h_files, uint32_t n_files, Vs
         h_files[i].n_tiles = h_files[i].hi / VS_TILE + 1;                               // (the tile of position hi, the virtual terminator, included)
         total_tiles += h_files[i].n_tiles;
     }
-    uint32_t wg_waves = 8;                                                              // 8 x 19 120 bytes of LDS: one workgroup per CU, two waves per SIMD
+    uint32_t wg_waves = 12;                                                             // 12 x 12 720 bytes of LDS: one workgroup per CU, three waves per SIMD
     uint64_t resident = (uint64_t)ctx->n_cu * wg_waves;
     uint32_t mult = total_tiles / resident >= 512 ? 4u : 1u;                            // long launches: four workgroups per CU in turn even out what one leaves to chance
-    uint32_t share[4] = {108, 92, 92, 92};
+    uint32_t share[4] = {118, 100, 84, 84};
 #ifdef SNPGPU_TUNING                                            // development builds only (tools/)
     if (const char *e = getenv("SNPGPU_VS_GRID_MUL")) if (atoi(e) > 0) mult = (uint32_t)atoi(e);
-    uint32_t lds_waves = 8;                                     // (fewer waves per workgroup with the LDS of eight: that many waves per CU)
-    if (const char *e = getenv("SNPGPU_VS_WG_WAVES")) if (atoi(e) > 0 && atoi(e) <= 8) wg_waves = (uint32_t)atoi(e);
+    uint32_t lds_waves = 12;                                    // (fewer waves per workgroup with the LDS of twelve: that many waves per CU)
+    if (const char *e = getenv("SNPGPU_VS_WG_WAVES")) if (atoi(e) > 0 && atoi(e) <= 12) wg_waves = (uint32_t)atoi(e);
     if (const char *e = getenv("SNPGPU_VS_SHARE")) { int v[4]; if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4) for (int k = 0; k < 4; ++k) share[k] = v[k] > 0 ? (uint32_t)v[k] : 1u; }
 #endif
 #ifdef SNPGPU_TUNING
