@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-PROFILE_ROUND = "r4"
+PROFILE_ROUND = "r5"
 
 
 def parse_args():
@@ -203,7 +203,7 @@ def end_to_end(d, ss, prm, pile, offs, sizes, bases, n_files, S):
 
 def site_calling(d, pile, offs, sizes, n_files):
     """Phase-1 site calling on pileup FILES in the page cache: file -> var.flt.vcf through
-    varscan.mpileup2snp (reader threads + copy, k_varscan_scan + k_varscan_walk, host finish), best of two passes; every
+    varscan.mpileup2snp (reader threads + copy, k_varscan_scan + k_varscan_finish, host finish), best of two passes; every
     record of the first file is checked against the CPU restatement (oracle/varscan_oracle.py) on the record's own line,
     and the restatement is timed on the first lines of that file for the CPU column."""
     import shutil
@@ -258,20 +258,35 @@ def site_calling(d, pile, offs, sizes, n_files):
         vo.mpileup2snp(first[:cut], prm)
         cpu_s = time.perf_counter() - t0
         nbytes = int(sum(sizes[:n_files]))
-        # the kernels alone, on one sample that already is in device memory: everything site calling launches for a file
-        # (k_varscan_scan: one pass over the text; k_varscan_walk: the candidate lines again; k_varscan_walk_long), HIP events
-        # on the launch stream around them.  Algorithmic bytes = the text, once.
+        # the kernels alone, over ALL resident samples of the shard in ONE launch (snpgpu_varscan_batch_dev: k_varscan_scan — one pass over
+        # the text, every wave walks its own candidate lines — and k_varscan_finish), HIP events on the launch stream around them.
+        # Algorithmic bytes = the text, once.  Beside it: the same for one sample per launch (a 0.15 ms grid pays its ramp and tail).
         dprm = opts.device_params()
-        d.varscan_dev(pile.data_ptr() + int(offs[0]), sizes[0], dprm)
+        n_res = len(sizes)
+        ptrs = [pile.data_ptr() + int(offs[i]) for i in range(n_res)]
+        lens = [int(sizes[i]) for i in range(n_res)]
+        res_b = d.varscan_batch_dev(ptrs, lens, dprm, capacity=8192)                   # warm-up, and the answer of sample 0 against the file route's
+        if isinstance(res_b[0], Exception) or res_b[0][0].tobytes() != recs.tobytes():
+            raise SystemExit("site calling over resident samples differs from the file route")
         d.kernel_timing(True)
         d.kernel_time_ms(3)
-        reps = 10
-        for _ in range(reps):
-            d.varscan_dev(pile.data_ptr() + int(offs[0]), sizes[0], dprm)
-        k_ms, k_n = d.kernel_time_ms(3)
+        reps_b = 5
+        for _ in range(reps_b):
+            d.varscan_batch_dev(ptrs, lens, dprm, capacity=8192)
+        kb_ms, kb_n = d.kernel_time_ms(3)
+        kb_avg = kb_ms / max(kb_n, 1)
+        tot_b = int(sum(lens))
+        k_gbs = tot_b / (kb_avg * 1e-3) / 1e9 if kb_avg > 0 else 0.0
+        k_avg = kb_avg / max(n_res, 1)
+        k_n = kb_n
+        d.varscan_dev(ptrs[0], lens[0], dprm)
+        d.kernel_time_ms(3)
+        for _ in range(10):
+            d.varscan_dev(ptrs[0], lens[0], dprm)
+        k1_ms, k1_n = d.kernel_time_ms(3)
         d.kernel_timing(False)
-        k_avg = k_ms / max(k_n, 1)
-        k_gbs = sizes[0] / (k_avg * 1e-3) / 1e9 if k_avg > 0 else 0.0
+        k1_avg = k1_ms / max(k1_n, 1)
+        k1_gbs = lens[0] / (k1_avg * 1e-3) / 1e9 if k1_avg > 0 else 0.0
         vs_traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "varscan_traffic.json")) as f:
@@ -281,13 +296,15 @@ def site_calling(d, pile, offs, sizes, n_files):
         except (OSError, ValueError):
             pass
         return {
-            "roofline": {"kernels": "k_varscan_scan + k_varscan_walk + k_varscan_walk_long (all launches of one file)", "bound": "hbm",
+            "roofline": {"kernels": "k_varscan_scan + k_varscan_finish (one launch over the shard's %d resident samples)" % n_res, "bound": "hbm",
                          "achieved": k_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k_gbs / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_file": int(sizes[0]), "avg_ms_per_file": k_avg, "files_timed": int(k_n),
+                         "algorithmic_bytes_per_launch": tot_b, "samples_per_launch": n_res, "avg_ms_per_launch": kb_avg, "launches_timed": int(k_n),
+                         "algorithmic_bytes_per_file": int(sizes[0]), "avg_ms_per_file": k_avg,
+                         "one_sample_per_launch": {"achieved": k1_gbs, "frac": k1_gbs / HBM_PEAK_GBS, "avg_ms_per_file": k1_avg, "files_timed": int(k1_n)},
                          "traffic": (vs_traffic or {}).get("traffic_bytes_per_file"), "traffic_measured_on_bytes": (vs_traffic or {}).get("bytes"),
                          "traffic_over_algorithmic": (vs_traffic or {}).get("traffic_over_algorithmic"),
                          "traffic_source": ("profiles/%s/varscan_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % PROFILE_ROUND) if vs_traffic else None,
-                         "note": "one resident sample, HIP events around the launches on their stream; the files -> var.flt.vcf rate above is bound by the host link"},
+                         "note": "resident samples, HIP events around the launches on their stream; the files -> var.flt.vcf rate above is bound by the host link"},
             "what": "%d pileup files in the page cache -> var.flt.vcf each (VarScan mpileup2snp's job, %s), one snpgpu_varscan_files call" % (n_files, extra),
             "files": n_files, "bytes": nbytes, "seconds": best, "pileup_gb_per_sec": nbytes / best / 1e9, "samples_per_sec": n_files / best,
             "pileup_lines_per_sec": lines / best, "sites_written": rows, "rows_equal_cpu_restatement": True,

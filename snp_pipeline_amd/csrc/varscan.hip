@@ -361,8 +361,8 @@ constexpr uint32_t VS_W_PLAIN = 1u << 31, VS_W_LONG = 1u << 30;
 #define VS_DATA (2u * (VS_PAD + VS_TILE))     // the slots with their pads
 #define VS_STR_WORDS (VS_RING / 32u)          // dwords of a bit string (and entries of the running counts) over the ring
 #define VS_STR_PAD 4u                         // ... and room for the reads that run over its end (their bits are masked away)
-#define VS_CAND_LOCAL 80u                     // candidate entries a wave holds in LDS
-constexpr uint32_t VS_LDS_WAVE = VS_DATA + 3u * (VS_STR_WORDS + VS_STR_PAD) * 4u + VS_CAND_LOCAL * 16u;   // 12 720 bytes: twelve waves per CU
+#define VS_CAND_LOCAL 136u                    // candidate entries a wave holds in LDS (100x: a dozen per wave; what LDS is left at twelve waves per CU)
+constexpr uint32_t VS_LDS_WAVE = VS_DATA + 3u * (VS_STR_WORDS + VS_STR_PAD) * 4u + VS_CAND_LOCAL * 16u;   // 13 616 bytes: twelve waves per CU (163 392 of 163 840 bytes)
 #define VS_NONE 0xFFFFFFFFu
 
 // One pileup of a launch: an entry of the device table, or (a launch over one file) a kernel argument.
@@ -406,10 +406,32 @@ __device__ __forceinline__ bool walk_in_strips(uint4 *strips, uint32_t strip_byt
     const uint32_t incl = wave_inclusive_sum(mine_chunks);
     const uint32_t first_chunk = incl - mine_chunks;
     const bool fits = alone_fits && (uint64_t)incl * 16 <= strip_bytes;
-    if (!(have && !is_long && fits)) return false;
-    uint4 *mine = strips + first_chunk;
-    const uint4 *src = (const uint4 *)a0;
-    for (uint32_t c = 0; c < chunks; ++c) mine[c] = src[c];
+    const bool mine_fits = have && !is_long && fits;
+    // the lines that fit, one after the other, each by LDS-DMA (64 lanes x 16 bytes per instruction, nothing waits before the last one
+    // is under way: a lane copying its own line chunk by chunk pays the memory latency once per chunk)
+    {
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)strips);
+        const uint32_t voff = lane * 16u;
+        uint64_t todo = __builtin_amdgcn_ballot_w64(mine_fits);
+        while (todo) {
+            const uint32_t c = (uint32_t)__ffsll((long long)todo) - 1u;
+            todo &= todo - 1;
+            const uint32_t a_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a0, (int)c), a_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(a0 >> 32), (int)c);
+            const uint32_t nch = (uint32_t)__builtin_amdgcn_readlane((int)chunks, (int)c), dst = (uint32_t)__builtin_amdgcn_readlane((int)first_chunk, (int)c);
+            for (uint32_t o = 0; o < nch; o += 64) {
+                const uint64_t ga = (((uint64_t)a_hi << 32) | a_lo) + (uint64_t)o * 16u;
+                const uint64_t gr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ga >> 32)) << 32) |
+                                    (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ga);
+                const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (dst + o) * 16u);
+                if (o + lane < nch)
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gr), "s"(m0v) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!mine_fits) return false;
     const uint32_t lane0 = first_chunk * 16u;                                           // LDS offset of this lane's bytes
     const uint64_t a0_off = a0 - (uintptr_t)o.buf;                                      // their file offset (may be "negative": the chunk starts below the file)
     const uint32_t *lds32 = (const uint32_t *)strips;
@@ -863,7 +885,7 @@ __global__ __launch_bounds__(768) void k_varscan_scan(const VsFile *__restrict__
 // and the line counts of the scan's waves added up per file.
 __global__ __launch_bounds__(64) void k_varscan_finish(const VsFile *__restrict__ files, uint32_t n_files, VsFile one, snpgpu_varscan_params prm,
                                                        const uint4 *__restrict__ cand, const uint32_t *__restrict__ cand_n, uint32_t cand_cap,
-                                                       const uint32_t *__restrict__ wave_lines, uint32_t strip_bytes) {
+                                                       const uint32_t *__restrict__ wave_lines, uint32_t n_waves_total, uint32_t strip_bytes) {
     extern __shared__ uint4 vs_strips[];
     const uint32_t n = *cand_n < cand_cap ? *cand_n : cand_cap;
     for (uint64_t i0 = (uint64_t)blockIdx.x * 64; i0 < n; i0 += (uint64_t)gridDim.x * 64) {
@@ -876,12 +898,25 @@ __global__ __launch_bounds__(64) void k_varscan_finish(const VsFile *__restrict_
         if (have && !done) walk_entry_global(o, e, prm);
         __builtin_amdgcn_wave_barrier();
     }
-    for (uint32_t fidx = blockIdx.x; fidx < n_files; fidx += gridDim.x) {
-        const VsFile f = n_files > 1 ? files[fidx] : one;
-        unsigned long long s = 0;
-        for (uint32_t k = threadIdx.x; k < f.n_waves; k += 64) s += wave_lines[f.wave0 + k];
-        for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
-        if (threadIdx.x == 0) *(unsigned long long *)(f.ctl + 4) = s;
+    // the line counts: 64 waves of the scan per block and turn; a file's waves are neighbours, so nearly always the 64 belong to one
+    // file and the block adds one sum to that file's count (ctl[4..5] start at 0)
+    for (uint32_t w0 = blockIdx.x * 64u; w0 < n_waves_total; w0 += gridDim.x * 64u) {
+        const uint32_t w = w0 + threadIdx.x;
+        const bool in = w < n_waves_total;
+        unsigned long long v = in ? wave_lines[w] : 0ull;
+        uint32_t fidx = 0;
+        if (n_files > 1 && in) {
+            uint32_t lo_i = 0, hi_i = n_files;
+            while (hi_i - lo_i > 1) { const uint32_t mid = (lo_i + hi_i) >> 1; if (files[mid].wave0 <= w) lo_i = mid; else hi_i = mid; }
+            fidx = lo_i;
+        }
+        const uint32_t f_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)fidx);
+        if (__builtin_amdgcn_ballot_w64(in && fidx != f_first) == 0) {                  // one file
+            for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+            if (threadIdx.x == 0 && v) atomicAdd((unsigned long long *)((n_files > 1 ? files[f_first].ctl : one.ctl) + 4), v);
+        } else if (in && v) {
+            atomicAdd((unsigned long long *)(files[fidx].ctl + 4), v);
+        }
     }
 }
 
@@ -911,10 +946,10 @@ static int varscan_launch(snpgpu_ctx *ctx, VsFile *h_files, uint32_t n_files, Vs
         h_files[i].n_tiles = h_files[i].hi / VS_TILE + 1;                               // (the tile of position hi, the virtual terminator, included)
         total_tiles += h_files[i].n_tiles;
     }
-    uint32_t wg_waves = 12;                                                             // 12 x 12 720 bytes of LDS: one workgroup per CU, three waves per SIMD
+    uint32_t wg_waves = 12;                                                             // 12 x 13 616 bytes of LDS: one workgroup per CU, three waves per SIMD
     uint64_t resident = (uint64_t)ctx->n_cu * wg_waves;
     uint32_t mult = total_tiles / resident >= 512 ? 4u : 1u;                            // long launches: four workgroups per CU in turn even out what one leaves to chance
-    uint32_t share[4] = {118, 100, 84, 84};
+    uint32_t share[4] = {140, 100, 66, 66};                                             // tools/vs_share_sweep.sh: 123 -> 111 us per 30x sample from 118 : 100 : 84; steeper loses again
 #ifdef SNPGPU_TUNING                                            // development builds only (tools/)
     if (const char *e = getenv("SNPGPU_VS_GRID_MUL")) if (atoi(e) > 0) mult = (uint32_t)atoi(e);
     uint32_t lds_waves = 12;                                    // (fewer waves per workgroup with the LDS of twelve: that many waves per CU)
@@ -954,7 +989,7 @@ static int varscan_launch(snpgpu_ctx *ctx, VsFile *h_files, uint32_t n_files, Vs
                                                                                     d_wave_lines, make_uint4(share[0], share[1], share[2], share[3]));
     const uint32_t strip_bytes = 32u * 1024u;
     const uint32_t fin_grid = n_files > ctx->n_cu ? (uint32_t)ctx->n_cu * 4u : (uint32_t)ctx->n_cu;
-    k_varscan_finish<<<fin_grid, 64, strip_bytes + 16u, ctx->stream>>>(d_files, n_files, h_files[0], *prm, d_cand, d_cand_n, cand_cap, d_wave_lines, strip_bytes);
+    k_varscan_finish<<<fin_grid, 64, strip_bytes + 16u, ctx->stream>>>(d_files, n_files, h_files[0], *prm, d_cand, d_cand_n, cand_cap, d_wave_lines, n_waves_total, strip_bytes);
     snpgpu_time_end(ctx, SNPGPU_K_VARSCAN, ta);
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;

@@ -7,7 +7,8 @@ for dp in ${@:-30 100 8}; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/vs$dp -- python $root/tools/varscan_kernel_time.py 5000000 $dp 10 2>&1 | grep "per call"
     find $root/gpurun_out/vs$dp -name "*kernel_stats.csv" -exec cp {} $root/gpurun_out/vs_stats_$dp.csv \;
     rm -rf $root/gpurun_out/vs$dp
-    echo "== depth $dp"
+    python $root/tools/varscan_kernel_time.py 5000000 $dp 6 12 2>&1 | grep "^batch"     # (no profiler attached: HIP events, twelve samples per launch)
+    echo "== depth $dp, one sample per launch (rocprofv3 --kernel-trace --stats)"
     python - <<PY
 import csv
 for r in csv.reader(open('$root/gpurun_out/vs_stats_$dp.csv')):
