@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--cpu-procs", type=int, default=0, help="one-process-per-sample CPU leg: processes (0 = min(cores, 32))")
     ap.add_argument("--cpu-dist-samples", type=int, default=200, help="rows of the CPU distance leg (x 50 000 sites; BASELINE.md 3: >= 200)")
     ap.add_argument("--skip-secondary", action="store_true")
+    ap.add_argument("--skip-call-variants", action="store_true", help="leave out the with-counts / strict / --vcfAllPos rows")
     ap.add_argument("--site-files", type=int, default=16, help="pileup files for the site_calling row (0 = skip)")
     ap.add_argument("--skip-aux", action="store_true", help="skip the device-copy ceiling and the K3/K4 timings")
     ap.add_argument("--shape-samples", type=int, default=64, help="samples per launch of the scan_shapes rows (0 = skip)")
@@ -136,18 +137,8 @@ def end_to_end(d, ss, prm, pile, offs, sizes, bases, n_files, S):
             with open(path, "wb") as f:
                 f.write(pile[int(offs[i]):int(offs[i]) + sizes[i]].cpu().numpy().tobytes())
             paths.append(path)
-        # pinned host -> device copy rate (the ceiling of this path)
-        n = 256 << 20
-        src = torch.empty(n, dtype=torch.uint8).pin_memory()
-        dst = torch.empty(n, dtype=torch.uint8, device="cuda")
-        dst.copy_(src, non_blocking=True)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(8):
-            dst.copy_(src, non_blocking=True)
-        torch.cuda.synchronize()
-        h2d = 8 * n / (time.perf_counter() - t1) / 1e9
-        del src, dst
+        # pinned host -> device copy rate (the ceiling of this path): the best of several shapes of the copy, see pinned_h2d_gbps
+        h2d = pinned_h2d_gbps(torch)
         d.call_consensus_files(ss, paths[:1], prm)                                  # warm-up: pinned staging, device slots
         # two passes over the same files, the better one reported (both listed): single passes spread between 42 and 56 GB/s
         # on the bench box whatever the reader count (>= 8) and whichever socket wrote the files (tools/e2e_readers.py)
@@ -192,7 +183,8 @@ def end_to_end(d, ss, prm, pile, offs, sizes, bases, n_files, S):
                                             "excluded_positions_per_file": int(len(excl[0])), "passes_gb_per_sec": passes_e, "checked": True},
             "files": n_files, "bytes": int(st.bytes), "seconds": st.seconds, "pileup_gb_per_sec": gbps,
             "consensus_bases_per_sec": n_files * S / st.seconds, "samples_per_sec": n_files / st.seconds,
-            "pinned_h2d_gb_per_sec": h2d, "frac_of_pinned_h2d": gbps / h2d, "passes_gb_per_sec": passes,
+            "pinned_h2d_gb_per_sec": h2d, "frac_of_pinned_h2d": over_link(gbps, h2d), "pinned_h2d_probe_is_a_ceiling_here": over_link(gbps, h2d) is not None,
+            "pinned_h2d_probe": pinned_h2d_probe(), "passes_gb_per_sec": passes,
             "chunk_bytes": int(st.chunk_bytes), "reader_threads": int(st.n_readers), "staging_buffers": int(st.n_staging),
             "seconds_waiting_for_readers": st.seconds_waiting_for_readers,
             "seconds_waiting_for_device": st.seconds_waiting_for_device, "matches_resident": True,
@@ -327,6 +319,139 @@ PER_SAMPLE_FILES = ("var.flt.vcf", "var.flt_preserved.vcf", "var.flt_removed.vcf
                     "consensus_preserved.fasta", "consensus_preserved.vcf")
 
 
+def call_variants(d, ss, prm, pile, offs, sizes, S, dev, torch, pos):
+    """The call paths the headline does not time, on the same resident shard, HIP events of the context around the
+    scan and the call kernels:
+      call_with_counts  per-site counts for consensus.vcf — the reference's default configuration writes it (snppipeline.conf:249,
+                        run.py:709): k_call_lanes<..., true> + k_call_sites, one 128-byte record per (sample, site);
+      strict            the strict caller set of SURVEY 8(d): -q 15 -c 0.9 -D 5 -d 2 -b 0.1, no counts;
+      all_positions     --vcfAllPos (call_consensus.py:148, pileup.py:418-421): a Record from EVERY line of one sample (5 M), from
+                        its file in the page cache through snpgpu_call_all_lines_file (line index + k_call_sites + the records back).
+    K2 roofline: algorithmic bytes = the bytes of the lines that are looked at (matched lines x the batch's mean line length; every
+    line of the file for all_positions) + the records / bytes written."""
+    import shutil
+    import tempfile
+    from oracle import pileup_oracle as po
+    B = len(sizes)
+    ptrs = [pile.data_ptr() + int(offs[i]) for i in range(B)]
+    lens = [int(x) for x in sizes]
+    pile_bytes = int(sum(lens))
+    out = {}
+    bases = torch.empty((B, S), dtype=torch.uint8, device="cuda")
+    filt = torch.empty((B, S), dtype=torch.uint8, device="cuda")
+    status = torch.empty((B, 4), dtype=torch.int64, device="cuda")
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        d.kernel_timing(True)
+        d.kernel_time_ms(0), d.kernel_time_ms(1)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        scan_ms, scan_n = d.kernel_time_ms(0)
+        call_ms, call_n = d.kernel_time_ms(1)
+        d.kernel_timing(False)
+        return a.elapsed_time(b) / reps, scan_ms / max(scan_n, 1), call_ms / max(call_n, 1)
+
+    def row(ms, scan_ms, call_ms, positions, matched, looked_bytes, written_bytes, what):
+        algo = looked_bytes + written_bytes
+        gbs = algo / (call_ms * 1e-3) / 1e9 if call_ms > 0 else 0.0
+        return {"what": what, "ms_per_step": ms, "positions_per_sec": positions / (ms * 1e-3), "positions": positions, "matched_lines": matched,
+                "k_scan_wave_ms": scan_ms, "call_kernels_ms": call_ms,
+                "roofline": {"kernels": "K2: k_call_lanes x3 + k_call_sites (everything between the scan and the results)", "bound": "hbm", "achieved": gbs,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": algo,
+                             "of_which_line_bytes": looked_bytes, "of_which_written": written_bytes, "traffic": None}}
+
+    # ---- per-site counts --------------------------------------------------------------------------------------------
+    counts = torch.empty((B, S, dev.COUNTS_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+
+    def with_counts():
+        d.call_consensus_many_dev(ss, ptrs, lens, prm, bases.data_ptr(), filt.data_ptr(), status.data_ptr(), d_counts=counts.data_ptr())
+    ms, scan_ms, call_ms = timed(with_counts, 3)
+    st = status.cpu().numpy()
+    n_lines, matched = int(st[:, 1].sum()), int(st[:, 2].sum())
+    mean_line = pile_bytes / max(n_lines, 1)
+    # check: the records of sample 0 at 200 sites against the oracle on their own lines
+    rec = np.frombuffer(counts[0].cpu().numpy().tobytes(), dtype=dev.COUNTS_DTYPE)
+    text = pile[int(offs[0]):int(offs[0]) + lens[0]].cpu().numpy().tobytes()
+    p0 = po.CallerParams(0, 0.6, 3, 0, 0.0)
+    cut = text.rfind(b"\n", 0, 24 << 20) + 1                  # the oracle on the sample's first 24 MB (whole lines), and the sites that lie in them
+    last_pos = int(text[text.rfind(b"\n", 0, cut - 1) + 1:cut].split(b"\t")[1])
+    inside = pos[pos < last_pos]
+    sub = [(b"synth_chr1", int(p)) for p in inside[::max(len(inside) // 200, 1)]]
+    _, detail = po.call_consensus_sites(text[:cut], sub, set(), p0)
+    slot = {k: i for i, k in enumerate(ss.key_tuples())}
+    for key, (r, base, mask) in detail.items():
+        c = rec[slot[key]]
+        if (int(c["raw_depth"]), int(c["good_depth"]), int(c["fwd_good_depth"]), int(c["rev_good_depth"]), int(c["cons_base"]), int(c["filters"])) != \
+                (r.raw_depth, r.good_depth, r.forward_good_depth, r.reverse_good_depth, base, mask):
+            raise SystemExit("per-site counts differ from the oracle at %r" % (key,))
+    out["call_with_counts"] = row(ms, scan_ms, call_ms, B * S, matched, int(matched * mean_line), matched * dev.COUNTS_DTYPE.itemsize + 2 * B * S,
+                                  "%d samples x %d sites with per-site count records (consensus.vcf's input): scan + call, one group per launch" % (B, S))
+    out["call_with_counts"]["records_checked_against_oracle"] = len(detail)
+    del counts, rec
+
+    # ---- the strict caller ------------------------------------------------------------------------------------------------
+    strict = dev.make_params(15, 0.9, 5, 2, 0.1)
+    sizes_np = np.asarray(lens, dtype=np.uint64)
+
+    def strict_call():
+        d.call_consensus_batch_dev(ss, pile.data_ptr(), offs[:B], strict, bases.data_ptr(), filt.data_ptr(), status.data_ptr(), sizes=sizes_np)
+    ms, scan_ms, call_ms = timed(strict_call, 5)
+    ps = po.CallerParams(15, 0.9, 5, 2, 0.1)
+    want, _ = po.call_consensus_sites(text[:cut], sub, set(), ps)
+    got = bytes(int(x) for x in bases[0].cpu().numpy()[[slot[k] for k in sub]])
+    if got != want:
+        raise SystemExit("the strict caller differs from the oracle")
+    out["strict"] = row(ms, scan_ms, call_ms, B * S, matched, int(matched * mean_line), 2 * B * S,
+                        "%d samples x %d sites, caller -q 15 -c 0.9 -D 5 -d 2 -b 0.1 (SURVEY 8d), no count records" % (B, S))
+    out["strict"]["sites_checked_against_oracle"] = len(sub)
+
+    # ---- every line of one sample ---------------------------------------------------------------------------------------------
+    base_dir = _scratch_dir(lens[0] + (64 << 20))
+    if base_dir is None:
+        out["all_positions"] = {"skipped": "no room for one pileup file"}
+        return out
+    tmpdir = tempfile.mkdtemp(prefix="snpbench_allpos_", dir=base_dir)
+    try:
+        path = os.path.join(tmpdir, "reads.all.pileup")
+        with open(path, "wb") as f:
+            f.write(text)
+        lines0 = int(st[0, 1])
+        d.call_all_lines(ss, path, prm, capacity=lines0, check=False)            # warm-up: scratch, pinned staging
+        d.kernel_timing(True)
+        d.kernel_time_ms(1)
+        t0 = time.perf_counter()
+        off, flags, recs = d.call_all_lines(ss, path, prm, capacity=lines0, check=False)
+        wall = time.perf_counter() - t0
+        call_ms, call_n = d.kernel_time_ms(1)
+        d.kernel_timing(False)
+        call_ms = call_ms / max(call_n, 1)
+        # check: 300 lines spread over the file, each against the oracle's Record of that very line
+        for k in range(0, len(off), max(len(off) // 300, 1)):
+            o = int(off[k]) - 1
+            ln = text[o:text.index(b"\n", o)]
+            r = po.parse_record(po.split_fields(ln), 0)
+            if (int(recs[k]["raw_depth"]), int(recs[k]["good_depth"]), int(recs[k]["fwd_good_depth"])) != (r.raw_depth, r.good_depth, r.forward_good_depth):
+                raise SystemExit("--vcfAllPos record %d differs from the oracle" % k)
+        written = len(off) * (dev.COUNTS_DTYPE.itemsize + 8 + 1)
+        gbs = (lens[0] + written) / (call_ms * 1e-3) / 1e9 if call_ms > 0 else 0.0
+        out["all_positions"] = {
+            "what": "one sample, a record from every one of its %d lines (--vcfAllPos): file in the page cache -> records on the host" % len(off),
+            "ms_per_step": wall * 1e3, "positions_per_sec": len(off) / wall, "positions": int(len(off)), "call_kernel_ms": call_ms,
+            "roofline": {"kernels": "K2 over a line list: k_call_sites, one wave per line", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": lens[0] + written, "of_which_line_bytes": lens[0],
+                         "of_which_written": written, "traffic": None},
+            "note": "the wall time holds the file read, its copy to the device, the line index, the call and %.0f MB of records back over the host link" % (written / 1e6)}
+    finally:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    return out
+
+
 def run_cli(line, verbose=0):
     """One subcommand in this process (\\x00 stands for a blank inside an argument).  Returns its wall time."""
     from snp_pipeline_amd import cfsan_snp_pipeline as cli
@@ -421,16 +546,57 @@ def write_sample_tree(base_dir, refh, G, sample_bytes, n, contig="synth_chr1"):
     return tmpdir, ref_path, dirs_file, dirs, total
 
 
+_H2D_PROBE = {}
+
+
 def pinned_h2d_gbps(torch, n=256 << 20, reps=8):
-    src = torch.empty(n, dtype=torch.uint8, pin_memory=True)
-    dst = torch.empty(n, dtype=torch.uint8, device="cuda")
-    dst.copy_(src, non_blocking=True)
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(reps):
-        dst.copy_(src, non_blocking=True)
-    torch.cuda.synchronize()
-    return reps * n / (time.perf_counter() - t) / 1e9
+    """What the host link gives pinned memory on THIS box: the best of several shapes of the copy — one, two and four streams each
+    with its own pinned buffer (the streamed ingestion keeps several copies in flight; a single stream was measured at HALF the link
+    rate on one of the driver's boxes, so a single-stream probe is no ceiling), buffers of 16 MiB to 256 MiB, allocated by this
+    thread as the library's staging buffers are.  Measured once per process; `pinned_h2d_probe()` says which shape won."""
+    if "best" in _H2D_PROBE:
+        return _H2D_PROBE["best"]
+    best, shapes = 0.0, []
+    for streams in (1, 2, 4):
+        for size in (16 << 20, 64 << 20, n):
+            try:
+                srcs = [torch.empty(size, dtype=torch.uint8, pin_memory=True) for _ in range(streams)]
+                dsts = [torch.empty(size, dtype=torch.uint8, device="cuda") for _ in range(streams)]
+                qs = [torch.cuda.Stream() for _ in range(streams)]
+            except RuntimeError:
+                continue
+            rounds = max(2, min(reps * n // size // streams, 64))
+            for k in range(streams):                                           # warm-up: the mappings, the engines
+                with torch.cuda.stream(qs[k]):
+                    dsts[k].copy_(srcs[k], non_blocking=True)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(rounds):
+                for k in range(streams):
+                    with torch.cuda.stream(qs[k]):
+                        dsts[k].copy_(srcs[k], non_blocking=True)
+            torch.cuda.synchronize()
+            rate = rounds * streams * size / (time.perf_counter() - t) / 1e9
+            shapes.append({"streams": streams, "buffer_bytes": size, "gb_per_sec": rate})
+            if rate > best:
+                best = rate
+                _H2D_PROBE["shape"] = shapes[-1]
+            del srcs, dsts, qs
+    _H2D_PROBE["best"] = best
+    _H2D_PROBE["shapes"] = shapes
+    return best
+
+
+def pinned_h2d_probe():
+    return {"best": _H2D_PROBE.get("shape"), "all": _H2D_PROBE.get("shapes")}
+
+
+def over_link(rate_gbps, h2d):
+    """A path's rate as a fraction of the probed link rate — or None (and a flag) when the path beat the probe by more than 5 %:
+    then the probe was no ceiling on this box and the ratio would say nothing."""
+    if not h2d or rate_gbps > 1.05 * h2d:
+        return None
+    return rate_gbps / h2d
 
 
 def pipeline_from_files(pile, offs, sizes, refh, G, n_files, with_separate=True):
@@ -486,7 +652,9 @@ def pipeline_from_files(pile, offs, sizes, refh, G, n_files, with_separate=True)
                     "consensus(.fasta|.vcf) x 2 flows, snpma x 2, referenceSNP x 2, distance TSVs x 4 — one hot_path_batch job" % (n_files, base_dir),
             "samples": n_files, "pileup_bytes": total, "seconds": st["seconds"], "cli_seconds": wall,
             "h2d_bytes": st["h2d_bytes"], "each_pileup_crossed_the_link_once": st["h2d_bytes"] == total,
-            "pinned_h2d_gb_per_sec": h2d, "bytes_over_pinned_h2d_seconds": ideal, "wall_over_copy_time": st["seconds"] / ideal,
+            "pinned_h2d_gb_per_sec": h2d, "bytes_over_pinned_h2d_seconds": ideal,
+            "wall_over_copy_time": (st["seconds"] / ideal) if st["seconds"] >= ideal / 1.05 else None,
+            "pinned_h2d_probe_is_a_ceiling_here": st["seconds"] >= ideal / 1.05, "pinned_h2d_probe": pinned_h2d_probe(),
             "samples_per_sec": n_files / st["seconds"], "pileup_gb_per_sec": total / st["seconds"] / 1e9,
             "phases_seconds": st["phases"], "ingest": st["ingest"], "snp_sites": st["sites"], "snp_sites_preserved": st["sites_preserved"],
             "tree_written_in_seconds": t_tree, "tree_synced_in_seconds": t_sync,
@@ -819,6 +987,34 @@ def cpu_baseline(args, d, pile, offs, sizes, bases, pos, G, S, gpu_value, second
     return res
 
 
+class StepWatch(object):
+    """A daemon thread that ends the process when one phase of a step takes longer than `limit` seconds: with a rank missing a
+    collective never returns, and a run that hangs tells nobody where.  phase(None) disarms it."""
+
+    def __init__(self, rank, limit):
+        import threading
+        self.rank, self.limit = rank, limit
+        self.name, self.since = None, 0.0
+        self.lock = threading.Lock()
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def phase(self, name):
+        with self.lock:
+            self.name, self.since = name, time.monotonic()
+
+    def _run(self):
+        while True:
+            time.sleep(1.0)
+            with self.lock:
+                name, since = self.name, self.since
+            if name is not None and time.monotonic() - since > self.limit:
+                sys.stderr.write("bench.py rank %d: phase '%s' did not finish within %.0f s (a rank that never arrived?); giving up\n"
+                                 % (self.rank, name, self.limit))
+                sys.stderr.flush()
+                os._exit(3)
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher around it: start N ranks of this very command line on this node (one per GPU,
     rendezvous on 127.0.0.1 — the fan-out the reference does with its per-sample job arrays, run.py:613-627) and pass on what
@@ -871,6 +1067,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     d = dev.Device(local_rank)
     d.use_torch_stream()
+    # over RCCL the exchanges of the step are calls into libsnpgpu.so on the context's stream (csrc/comm.hip: ncclAllGather, grouped
+    # ncclSend / ncclRecv, hand-written tile kernels); torch.distributed stays for the barrier and for adding up the timings.  The
+    # gloo hook (all ranks on one GPU) and SNPGPU_COMM=torch keep the torch.distributed route for the exchanges too.
+    abi_route = bool(multi and not one_gpu and os.environ.get("SNPGPU_COMM") != "torch" and sharding.use_abi_comm(d))
+    comm_info = d.comm_info() if abi_route else None
+    # a rank that never arrives must end the run, not hang it: every step is watched (the phase it was in goes to stderr, exit code 3)
+    watch = StepWatch(rank, float(os.environ.get("SNPGPU_BENCH_STEP_TIMEOUT", "600")))
 
     G, S = args.genome, args.sites
     if args.scaling == "weak":
@@ -949,7 +1152,11 @@ def main():
 
     def step(timed=False):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(PHASES) + 1)] if timed else None
-        mark = (lambda k: ev[k].record()) if timed else (lambda k: None)
+
+        def mark(k):
+            watch.phase(PHASES[k] if k < len(PHASES) else "end of step")
+            if timed:
+                ev[k].record()
         mark(0)
         # C1: every rank's SNP records -> the same site union on every rank (the snplist)
         keys_all, _ = sharding.all_gather_varlen(local_keys)
@@ -975,10 +1182,12 @@ def main():
             phase_events.append(ev)
 
     def barrier():
+        watch.phase("barrier")
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
+        watch.phase(None)
 
     for _ in range(args.warmup):
         step()
@@ -994,10 +1203,13 @@ def main():
     # them), and the slowest rank per phase
     phase_ms = [sum(ev[k].elapsed_time(ev[k + 1]) for ev in phase_events) / max(len(phase_events), 1) for k in range(len(PHASES))]
     phase_max = list(phase_ms)
+    phase_all = [list(phase_ms)]
     if multi:
         pt = torch.tensor(phase_ms, dtype=torch.float64, device="cpu" if one_gpu else "cuda")
-        dist.all_reduce(pt, op=dist.ReduceOp.MAX)
-        phase_max = [float(x) for x in pt.tolist()]
+        every = [torch.zeros_like(pt) for _ in range(world)]
+        dist.all_gather(every, pt)
+        phase_all = [[float(x) for x in t.tolist()] for t in every]
+        phase_max = [max(r[k] for r in phase_all) for k in range(len(PHASES))]
     scan_ms, scan_n = d.kernel_time_ms(0)
     call_ms, call_n = d.kernel_time_ms(1)
     dist_ms, dist_n = d.kernel_time_ms(2)
@@ -1062,6 +1274,9 @@ def main():
                  "launcher": "bench.py started its own ranks (torch.distributed.run, 127.0.0.1)" if os.environ.get("SNPGPU_BENCH_LAUNCHER") == "self"
                  else ("torch.distributed.run around bench.py" if multi else "none (one process)"),
                  "collectives_per_step": "C1 variable-length all-gather of site records, C2 all-gather of packed rows, one all-to-all of distance tiles" if multi else "none"},
+        "comm_route": ({"exchanges": "libsnpgpu.so (snpgpu_allgather / snpgpu_allgatherv / snpgpu_alltoallv on the context's stream, csrc/comm.hip)",
+                        "rccl_version": comm_info["rccl_version"], "world_size_rccl_reports": comm_info["rccl_comm_count"], "rank": comm_info["rank"]}
+                       if abi_route else ({"exchanges": "torch.distributed (%s)" % backend} if multi else None)),
         "genome_bp_per_sec": n_total * G / (elapsed / args.steps),
         "pileup_gb_per_sec": (pile_bytes * n_total / max(B, 1)) / (elapsed / args.steps) / 1e9,
         "roofline": {"kernel": "k_scan_wave", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1071,6 +1286,7 @@ def main():
                                 "k_distance": dist_ms / args.steps},
         "site_union": {"records": n_records, "unique_sites": int(u_n[0]), "carriers": int(u_n[1])},
         "phases_ms_per_step": {"rank0": dict(zip(PHASES, phase_ms)), "max_over_ranks": dict(zip(PHASES, phase_max)),
+                               "per_rank": [dict(zip(PHASES, r)) for r in phase_all],
                                "note": "device time between events on the kernels' stream, averaged over the timed steps"},
     }
 
@@ -1103,11 +1319,13 @@ def main():
             d.distance_packed_dev(pk.data_ptr(), b2.n_padded, s2, dm.data_ptr(), rank, world)
             return b2.exchange(dm, rank) if multi else dm
 
+        watch.phase("secondary: distance tiles + row-band exchange (warm-up)")
         dstep()                                                  # warm-up
         barrier()
         d.kernel_timing(True)
         d.kernel_time_ms(2)
         t1 = time.perf_counter()
+        watch.phase("secondary: distance tiles + row-band exchange")
         for _ in range(args.dist_reps):
             band2 = dstep()
         barrier()
@@ -1169,6 +1387,11 @@ def main():
     # ---- end to end: pileup FILES in the page cache -> consensus bytes on the host, through the streamed ingestion ----
     if rank == 0 and world == 1 and args.e2e_files > 0 and B:
         out["end_to_end"] = side_row(end_to_end, d, ss, prm, pile, offs, sizes, bases, min(args.e2e_files, B), S)
+
+    # ---- the call paths the headline leaves out: per-site counts (the default configuration's consensus.vcf), the strict caller,
+    #      --vcfAllPos --------------------------------------------------------------------------------------------------------
+    if rank == 0 and world == 1 and not args.skip_call_variants and B:
+        out["call_variants"] = side_row(call_variants, d, ss, prm, pile, offs, sizes, S, dev, torch, pos)
 
     # ---- phase-1 site calling on files -----------------------------------------------------------------
     if rank == 0 and world == 1 and args.site_files > 0 and B:

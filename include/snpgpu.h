@@ -35,6 +35,7 @@ extern "C" {
 #define SNPGPU_E_PILEUP     -4   /* malformed pileup text; see snpgpu_scan_status */
 #define SNPGPU_E_UNSUPPORTED -5  /* input the reference accepts but this build refuses (reported loudly) */
 #define SNPGPU_E_IO         -6   /* a file could not be opened, read or written */
+#define SNPGPU_E_TIMEOUT    -7   /* snpgpu_stream_wait: the stream was still busy when the time was up */
 
 /* ---- failed-filter bits, in the order pileup.py:564-584 appends them and
  *      call_consensus.py:165-168 appends "Region" ------------------------- */
@@ -479,6 +480,49 @@ int  snpgpu_fasta_load(const char *path, uint64_t n_records, uint64_t row_stride
 #define SNPGPU_TSV_MATRIX   1
 int  snpgpu_write_distance_tsv(const char *path, int layout, const char *ids, const uint64_t *id_off, uint32_t n,
                                const int32_t *matrix, uint64_t row_stride);
+
+/* ---- the exchange steps of the sharded path: RCCL over xGMI, one process per GPU ------------------------
+ * The reference fans out one process per sample (run.py:704-718, `run_array` with `max_processes`) over a shared file system
+ * and has no exchange step; sharded over GPUs the hot path has three: C1, the all-gather of the per-rank SNP site keys
+ * (variable length: snpgpu_allgatherv); C2, the all-gather of the per-rank rows of the packed consensus matrix
+ * (snpgpu_allgather, or snpgpu_allgatherv when the last rank holds fewer rows); the row-band exchange of the 128 x 128
+ * distance tiles (snpgpu_tiles_gather_dev -> snpgpu_alltoallv -> snpgpu_tiles_scatter_dev).  librccl.so is loaded on first
+ * use (snpgpu_comm_available() == 0: not found; single-GPU work is not affected).  Rank 0 makes a 128-byte id and hands it
+ * to the other ranks by any means the host program has; every rank then calls snpgpu_comm_init on its own context (its own
+ * device).  The collectives are ENQUEUED on the context's stream, like kernels: they return at once, results are valid when
+ * the stream has passed them (snpgpu_ctx_sync, or snpgpu_stream_wait with a time limit: a rank that never arrives shows as
+ * SNPGPU_E_TIMEOUT instead of a process that hangs).  All ranks must make the same calls in the same order. */
+#define SNPGPU_COMM_ID_BYTES 128
+int  snpgpu_comm_available(void);
+int  snpgpu_comm_version(int *out_version);                    /* ncclGetVersion of the library that was loaded */
+int  snpgpu_comm_unique_id(void *out_id);                      /* SNPGPU_COMM_ID_BYTES bytes; rank 0 */
+int  snpgpu_comm_init(snpgpu_ctx *ctx, int rank, int nranks, const void *unique_id);
+void snpgpu_comm_destroy(snpgpu_ctx *ctx);                     /* (also done by snpgpu_ctx_destroy) */
+/* this rank, the number of ranks, and what ncclCommCount says (0 without a communicator) */
+int  snpgpu_comm_info(const snpgpu_ctx *ctx, int *out_rank, int *out_nranks, int *out_count_from_rccl);
+/* block r of d_recv (bytes_per_rank bytes) comes from rank r's d_send */
+int  snpgpu_allgather(snpgpu_ctx *ctx, const void *d_send, void *d_recv, size_t bytes_per_rank);
+/* rank r contributes bytes[r] bytes, which land at d_recv + offsets[r] on every rank; bytes / offsets: HOST arrays of nranks
+ * entries, the same on every rank (sizes are exchanged first, e.g. with snpgpu_allgather of one word) */
+int  snpgpu_allgatherv(snpgpu_ctx *ctx, const void *d_send, void *d_recv, const uint64_t *bytes, const uint64_t *offsets);
+/* send_bytes[p] bytes of d_send (blocks packed in rank order) go to rank p; recv_bytes[p] bytes from rank p arrive in d_recv
+ * (blocks packed in rank order); HOST arrays */
+int  snpgpu_alltoallv(snpgpu_ctx *ctx, const void *d_send, const uint64_t *send_bytes, void *d_recv, const uint64_t *recv_bytes);
+int  snpgpu_stream_wait(snpgpu_ctx *ctx, uint32_t timeout_ms);
+/* 128 x 128 tiles of an n_padded x n_padded int32 matrix (n_padded a multiple of 128) to and from a packed list: tile t is the
+ * block at tile row d_tile_rows[t], tile column d_tile_cols[t]; d_out / d_tiles hold 128 * 128 values per tile */
+int  snpgpu_tiles_gather_dev(snpgpu_ctx *ctx, const int32_t *d_matrix, uint32_t n_padded, const uint32_t *d_tile_rows,
+                             const uint32_t *d_tile_cols, uint32_t n_tiles, int32_t *d_out);
+int  snpgpu_tiles_scatter_dev(snpgpu_ctx *ctx, const int32_t *d_tiles, const uint32_t *d_tile_rows, const uint32_t *d_tile_cols,
+                              uint32_t n_tiles, int32_t *d_matrix, uint32_t n_padded);
+/* What the one-job pipeline asks about a group of samples after scan + call, per sample s -> d_out[s][3] (int64): [0] 1 when a
+ * position the sample is asked about is malformed (d_wanted[n_sites]: 1 = every sample is asked about it; plus the sample's
+ * own stretch d_excl_slots[d_excl_off[s] .. d_excl_off[s + 1]), both nullable), judged by the records' status bytes when
+ * d_counts is given, else by bit 7 of the filter bytes; [1] positions of the set that have a pileup line (d_line_off != 0);
+ * [2] positions with a record in the context's spill (d_counts only).  Inputs [n_samples][n_sites]. */
+int  snpgpu_group_check_dev(snpgpu_ctx *ctx, const uint8_t *d_filters, const snpgpu_site_counts *d_counts, const uint64_t *d_line_off,
+                            const uint8_t *d_wanted, const uint32_t *d_excl_off, const uint32_t *d_excl_slots,
+                            uint32_t n_samples, uint32_t n_sites, int64_t *d_out);
 
 /* ---- filter_regions: find_dense_regions (filter_regions.py:17-71) + utils.merge_regions
  *      (utils.py:1267-1282) + utils.in_region (utils.py:1314-1318); merge_sites (merge_sites.py:91-117) ---------

@@ -12,7 +12,7 @@ SCAN_STATUS_WORDS = 4
 F_RAWDPTH, F_VARFREQ, F_DEPTH, F_STRDPTH, F_STRBIAS, F_REGION = 1, 2, 4, 8, 16, 32
 SITE_IN_SNPLIST, SITE_EXCLUDED = 1, 2
 ST_NO_LINE, ST_OK, ST_SHORT_LINE, ST_BAD_DEPTH, ST_NO_QUALS, ST_MULTI_REF = 0, 1, 2, 3, 4, 5
-E_HIP, E_ARG, E_NOMEM, E_PILEUP, E_UNSUPPORTED, E_IO = -1, -2, -3, -4, -5, -6
+E_HIP, E_ARG, E_NOMEM, E_PILEUP, E_UNSUPPORTED, E_IO, E_TIMEOUT = -1, -2, -3, -4, -5, -6, -7
 
 
 class CallerParams(C.Structure):
@@ -151,6 +151,19 @@ SIGNATURES = {
     "snpgpu_merge_regions_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, _P, _P, _P]),
     "snpgpu_in_regions_dev": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, _P, C.c_uint32, _P]),
     "snpgpu_merge_sites_dev": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, _P, _P]),
+    "snpgpu_comm_available": (C.c_int, []),
+    "snpgpu_comm_version": (C.c_int, [C.POINTER(C.c_int)]),
+    "snpgpu_comm_unique_id": (C.c_int, [_P]),
+    "snpgpu_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "snpgpu_comm_destroy": (None, [_P]),
+    "snpgpu_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "snpgpu_allgather": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "snpgpu_allgatherv": (C.c_int, [_P, _P, _P, _P, _P]),
+    "snpgpu_alltoallv": (C.c_int, [_P, _P, _P, _P, _P]),
+    "snpgpu_stream_wait": (C.c_int, [_P, C.c_uint32]),
+    "snpgpu_tiles_gather_dev": (C.c_int, [_P, _P, C.c_uint32, _P, _P, C.c_uint32, _P]),
+    "snpgpu_tiles_scatter_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, C.c_uint32]),
+    "snpgpu_group_check_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P]),
     "snpgpu_synth_reference_dev": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P]),
     "snpgpu_synth_pileup_dev": (C.c_int, [_P, C.POINTER(SynthParams), _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
 }

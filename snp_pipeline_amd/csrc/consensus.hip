@@ -1041,7 +1041,9 @@ int snpgpu_enqueue_call_lines(snpgpu_ctx *ctx, const SampleDev *d_sample, const 
     ca.spill_cap = ctx->spill_cap;
     ca.todo = nullptr; ca.todo_n = nullptr; ca.in_todo = nullptr; ca.in_todo_n = nullptr; ca.deep = nullptr;
     const uint64_t blocks = ((uint64_t)n_lines + CALL_WAVES - 1) / CALL_WAVES, max_blocks = (uint64_t)ctx->n_cu * 16;
+    hipEvent_t ta = snpgpu_time_begin(ctx);
     k_call_sites<<<(unsigned)(blocks < max_blocks ? blocks : max_blocks), CALL_WAVES * 64, 0, ctx->stream>>>(ca);
+    snpgpu_time_end(ctx, SNPGPU_K_CALL, ta);
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;
 }

@@ -114,6 +114,7 @@ void snpgpu_ctx_destroy(snpgpu_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    snpgpu_comm_release(ctx);
     snpgpu_stream_pool_destroy(ctx);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->d_spill) hipFree(ctx->d_spill);

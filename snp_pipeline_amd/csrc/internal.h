@@ -11,6 +11,7 @@
 
 struct snpgpu_stream_pool;          // stream.hip: pinned staging ring, device file slots, copy stream
 void snpgpu_stream_pool_destroy(struct snpgpu_ctx *ctx);
+void snpgpu_comm_release(struct snpgpu_ctx *ctx);       // comm.hip: the communicator goes with the context
 
 struct snpgpu_ctx {
     int device = 0;
@@ -25,6 +26,7 @@ struct snpgpu_ctx {
     int n_cu = 256;
     bool scan_lds_attr = false;         // hipFuncSetAttribute is per device: done once per context
     bool varscan_lds_attr = false;
+    void *comm = nullptr;               // comm.hip: the RCCL communicator of this rank (snpgpu_comm_init), or none
     // positions with more than SNPGPU_MAX_SYMS symbols: [SNPGPU_SPILL_CAP] records + one counter word (allocated on first use)
     snpgpu_symbol_spill *d_spill = nullptr;
     uint32_t *d_spill_n = nullptr;
@@ -189,7 +191,8 @@ struct PyInt {
     __device__ __forceinline__ void feed(uint32_t c) {
         if (n == 0 && (c == '+' || c == '-')) neg = c == '-';
         else if (is_digit(c)) {                                  // (saturate BEFORE the multiply: 2^62 * 10 wraps in 64 bits)
-            v = v > ((1ull << 62) - 9u) / 10u ? 1ull << 62 : v * 10 + (c - 48u);
+            const uint64_t dgt = c - 48u;
+            v = v > ((1ull << 62) - dgt) / 10u ? 1ull << 62 : v * 10 + dgt;
             last_digit = true;
         }
         else if (c == '_' && last_digit) last_digit = false;     // an underscore sits between two digits

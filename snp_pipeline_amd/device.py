@@ -620,6 +620,70 @@ class Device(object):
                 out.append((sites[i, :counts[i]].copy(), int(status[i, 1])))
         return out
 
+    # ---- the exchange steps of the sharded path: RCCL behind the C ABI (csrc/comm.hip) --------------------------------------
+    def comm_available(self):
+        return bool(self.lib.snpgpu_comm_available())
+
+    def comm_version(self):
+        v = C.c_int()
+        return v.value if self.lib.snpgpu_comm_version(C.byref(v)) == 0 else None
+
+    def comm_unique_id(self):
+        """128 bytes that name a communicator: rank 0 makes them and hands them to the other ranks."""
+        buf = C.create_string_buffer(128)
+        rc = self.lib.snpgpu_comm_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError("RCCL is not available (snpgpu_comm_unique_id: %d)" % rc)
+        return buf.raw
+
+    def comm_init(self, rank, nranks, unique_id):
+        self._check(self.lib.snpgpu_comm_init(self.ctx, int(rank), int(nranks), C.c_char_p(bytes(unique_id))))
+        self.comm_rank, self.comm_nranks = int(rank), int(nranks)
+
+    def comm_destroy(self):
+        if self.ctx:
+            self.lib.snpgpu_comm_destroy(self.ctx)
+        self.comm_rank, self.comm_nranks = 0, 0
+
+    def comm_info(self):
+        r, n, c = C.c_int(), C.c_int(), C.c_int()
+        self._check(self.lib.snpgpu_comm_info(self.ctx, C.byref(r), C.byref(n), C.byref(c)))
+        return {"rank": r.value, "nranks": n.value, "rccl_comm_count": c.value, "rccl_version": self.comm_version()}
+
+    def allgather_dev(self, d_send, d_recv, bytes_per_rank):
+        self._check(self.lib.snpgpu_allgather(self.ctx, C.c_void_p(int(d_send)), C.c_void_p(int(d_recv)), int(bytes_per_rank)))
+
+    def allgatherv_dev(self, d_send, d_recv, nbytes, offsets):
+        b = np.ascontiguousarray(nbytes, dtype=np.uint64)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._check(self.lib.snpgpu_allgatherv(self.ctx, C.c_void_p(int(d_send)) if int(d_send) else None, C.c_void_p(int(d_recv)), _ptr(b), _ptr(o)))
+
+    def alltoallv_dev(self, d_send, send_bytes, d_recv, recv_bytes):
+        sb = np.ascontiguousarray(send_bytes, dtype=np.uint64)
+        rb = np.ascontiguousarray(recv_bytes, dtype=np.uint64)
+        self._check(self.lib.snpgpu_alltoallv(self.ctx, C.c_void_p(int(d_send)) if int(d_send) else None, _ptr(sb),
+                                              C.c_void_p(int(d_recv)) if int(d_recv) else None, _ptr(rb)))
+
+    def stream_wait(self, timeout_ms):
+        """Wait for the context's stream, at most timeout_ms; raises TimeoutError when it is still busy then."""
+        rc = self.lib.snpgpu_stream_wait(self.ctx, int(timeout_ms))
+        if rc == L.E_TIMEOUT:
+            raise TimeoutError("the device stream was still busy after %d ms" % int(timeout_ms))
+        self._check(rc)
+
+    def tiles_gather_dev(self, d_matrix, n_padded, d_rows, d_cols, n_tiles, d_out):
+        self._check(self.lib.snpgpu_tiles_gather_dev(self.ctx, C.c_void_p(int(d_matrix)), int(n_padded), C.c_void_p(int(d_rows)), C.c_void_p(int(d_cols)),
+                                                     int(n_tiles), C.c_void_p(int(d_out))))
+
+    def tiles_scatter_dev(self, d_tiles, d_rows, d_cols, n_tiles, d_matrix, n_padded):
+        self._check(self.lib.snpgpu_tiles_scatter_dev(self.ctx, C.c_void_p(int(d_tiles)), C.c_void_p(int(d_rows)), C.c_void_p(int(d_cols)), int(n_tiles),
+                                                      C.c_void_p(int(d_matrix)), int(n_padded)))
+
+    def group_check_dev(self, d_filters, d_counts, d_line_off, d_wanted, d_excl_off, d_excl_slots, n_samples, n_sites, d_out):
+        opt = lambda v: C.c_void_p(int(v)) if v else None     # noqa: E731
+        self._check(self.lib.snpgpu_group_check_dev(self.ctx, opt(d_filters), opt(d_counts), opt(d_line_off), opt(d_wanted), opt(d_excl_off),
+                                                    opt(d_excl_slots), int(n_samples), int(n_sites), C.c_void_p(int(d_out))))
+
     def pileups(self, budget_bytes=0):
         return Pileups(self, budget_bytes)
 

@@ -213,12 +213,19 @@ class _Job(object):
         self.dev = devmod.Device(self.comm.local_rank)
         self.dev.use_torch_stream()
         torch.cuda.set_device(self.comm.local_rank)
+        # sharded over RCCL: the exchanges of the job are library calls on this context's stream (csrc/comm.hip); the gloo route of
+        # the one-GPU tests, and a host whose librccl.so cannot be loaded, keep torch.distributed
+        if self.comm.dist and not self.comm.one_gpu and os.environ.get("SNPGPU_COMM") != "torch":
+            self.abi_comm = sharding.use_abi_comm(self.dev)
         self.store = self.dev.pileups(int(self.args.residentBytes or 0))
 
     def close_device(self):
         if self.store is not None:
             self.store.close()
         if self.dev is not None:
+            if getattr(self, "abi_comm", False):
+                sharding.drop_abi_comm()
+                self.abi_comm = False
             self.dev.close()
         self.store = self.dev = None
 
@@ -642,7 +649,7 @@ def _prepare_flows(job):
     fl.d_cols1, fl.d_cols2 = torch.from_numpy(cols1.astype(np.int32)).cuda(), torch.from_numpy(cols2.astype(np.int32)).cuda()
     fl.d_col_of2 = torch.from_numpy(col_of2).cuda()
     fl.d_col_of1 = torch.from_numpy(np.where(in1 != 0, np.cumsum(in1, dtype=np.int64) - 1, -1).astype(np.int32)).cuda()
-    fl.d_in12 = torch.from_numpy((in1 | in2).astype(bool)).cuda()     # the positions every sample of the job is asked about
+    fl.d_in12_u8 = torch.from_numpy((in1 | in2).astype(np.uint8)).cuda()     # 1: a position every sample of the job is asked about
     fl.d_err = torch.zeros(4, dtype=torch.int32, device="cuda")
     job.callable_ = callable_ = [s for s in mine if s.ok]
     fl.n_local = n_local = len(callable_)
@@ -833,17 +840,11 @@ def _consensus_group(job, fl, g0, part, hs, vcf_again, vcf_later):
     # a malformed line at one of them?  how many of the set's positions have a line?  how many have a spill record?
     d_chk = None
     if S:
-        d_wanted = fl.d_in12.unsqueeze(0).expand(g, S)
-        if eoff[-1] and not fl.identity1:                    # (with the set == snplist.txt every own position is in it already)
-            d_wanted = d_wanted.clone()
-            rows = torch.repeat_interleave(torch.arange(g, device="cuda"), torch.from_numpy(np.diff(eoff).astype(np.int64)).cuda())
-            d_wanted[rows, d_eslots[:int(eoff[-1])].to(torch.int64)] = True
-        d_badmask = (d_counts[:g, :S, 23] > L.ST_OK) if want_vcf else ((d_filt[:g, :S] & 0x80) != 0)
-        d_bad = (d_badmask & d_wanted).any(dim=1)
-        # (bytes 17-19 of a record: nonzero = the position has a record in the context's spill — more than 8 symbols, or a
-        # reference field of several bytes)
-        d_ovf = (d_counts[:g, :S, 17:20] != 0).any(dim=2).sum(dim=1) if want_vcf else torch.zeros(g, dtype=torch.int64, device="cuda")
-        d_chk = torch.stack([d_bad.to(torch.int64), (d_line[:g, :S] != 0).sum(dim=1), d_ovf], dim=1)
+        # (k_group_check, csrc/comm.hip: one workgroup per sample; rounds 2-4 did this with half a dozen ATen kernels per group)
+        d_chk = torch.empty((g, 3), dtype=torch.int64, device="cuda")
+        own = bool(eoff[-1]) and not fl.identity1             # (with the set == snplist.txt every own position is in it already)
+        dev.group_check_dev(0 if want_vcf else d_filt.data_ptr(), d_counts.data_ptr() if want_vcf else 0, d_line.data_ptr(), fl.d_in12_u8.data_ptr(),
+                            d_eoff.data_ptr() if own else 0, d_eslots.data_ptr() if own else 0, g, S, d_chk.data_ptr())
     hs["status"][:g].copy_(d_status[:g], non_blocking=True)
     if S1:
         hs["base1"][:g, :S1].copy_(job.rows1[g0:g0 + g, :S1], non_blocking=True)

@@ -18,6 +18,45 @@ import torch.distributed as dist
 
 DIST_TILE = 128          # csrc/distance.hip
 
+# The device whose context holds this rank's RCCL communicator behind the C ABI (csrc/comm.hip), once use_abi_comm() has set it
+# up.  With it every exchange of the step is a library call on the context's stream — ncclAllGather / grouped ncclSend + ncclRecv
+# and the hand-written tile kernels — and no ATen kernel runs between the step's own kernels; without it (the gloo route of the
+# CPU tests, a host without librccl.so) the exchanges go through torch.distributed as before.
+_abi = {"dev": None, "rank": 0, "world": 1, "counts": None}
+
+
+def use_abi_comm(device, rank=None, world=None, unique_id=None):
+    """Make the exchanges of this process library calls on `device`'s context.  With torch.distributed initialised, rank 0's id
+    travels through its object broadcast; a host program without PyTorch passes rank / world / the 128-byte id itself (rank 0:
+    device.comm_unique_id(); INTEGRATION.md shows the ctypes form).  Returns False when RCCL cannot be loaded."""
+    if not device.comm_available():
+        return False
+    if unique_id is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        box = [device.comm_unique_id() if rank == 0 else None]
+        if dist.is_initialized() and world > 1:
+            dist.broadcast_object_list(box, src=0)
+        unique_id = box[0]
+    device.comm_init(rank, world, unique_id)
+    _abi.update(dev=device, rank=int(rank), world=int(world), counts=None)
+    return True
+
+
+def drop_abi_comm():
+    if _abi["dev"] is not None:
+        _abi["dev"].comm_destroy()
+    _abi.update(dev=None, rank=0, world=1, counts=None)
+
+
+def abi_comm():
+    """The device of use_abi_comm(), or None."""
+    return _abi["dev"]
+
+
+def _abi_for(t):
+    return _abi["dev"] if (_abi["dev"] is not None and t.is_cuda) else None
+
 
 def group_of_one_exchanges():
     """SNPGPU_DIST_AT_WORLD_1=1 (functional tests on a one-GPU box): a process group of ONE rank still makes every collective
@@ -28,9 +67,15 @@ def group_of_one_exchanges():
 
 def _alone():
     """Nothing to exchange: no process group, or a group of one (unless the test hook above asks for the calls anyway)."""
+    if _abi["dev"] is not None:
+        return _abi["world"] == 1 and not group_of_one_exchanges()
     if not dist.is_initialized():
         return True
     return dist.get_world_size() == 1 and not group_of_one_exchanges()
+
+
+def _world():
+    return _abi["world"] if _abi["dev"] is not None else dist.get_world_size()
 
 
 def shard_bounds(n_items, rank, world):
@@ -49,6 +94,29 @@ def all_gather_varlen(t):
     """All-gather of 1-D tensors whose lengths differ per rank.  Returns (concatenation in rank order, lengths)."""
     if _alone():
         return t, [int(t.numel())]
+    dev = _abi_for(t)
+    if dev is not None:
+        # the lengths first (one word per rank through the same library; the host needs them to size the result), then every
+        # rank's block straight to its place: no padding, no concatenation
+        world = _abi["world"]
+        if _abi["counts"] is None:
+            _abi["counts"] = (torch.zeros(1, dtype=torch.int64, device=t.device), torch.zeros(world, dtype=torch.int64, device=t.device),
+                              torch.zeros(1, dtype=torch.int64).pin_memory(), torch.zeros(world, dtype=torch.int64).pin_memory())
+        d_n, d_counts, h_n, h_counts = _abi["counts"]
+        h_n[0] = t.numel()
+        d_n.copy_(h_n, non_blocking=True)
+        dev.allgather_dev(d_n.data_ptr(), d_counts.data_ptr(), 8)
+        h_counts.copy_(d_counts, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        counts = [int(c) for c in h_counts.tolist()]
+        item = t.element_size()
+        out = torch.empty(sum(counts), dtype=t.dtype, device=t.device)
+        offs = [0]
+        for c in counts[:-1]:
+            offs.append(offs[-1] + c * item)
+        tc = t.contiguous()
+        dev.allgatherv_dev(tc.data_ptr() if tc.numel() else 0, out.data_ptr() if out.numel() else tc.data_ptr(), [c * item for c in counts], offs)
+        return out, counts
     if _via_host(t):
         out, counts = all_gather_varlen(t.cpu())
         return out.to(t.device), counts
@@ -72,6 +140,9 @@ def all_gather_rows(rows, n_total):
     Returns the (n_total, row_bytes) matrix on every rank."""
     if _alone():
         return rows
+    if _abi_for(rows) is not None:
+        out = torch.zeros((n_total, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        return all_gather_rows_into(rows, n_total, out)[:n_total]
     if _via_host(rows):
         return all_gather_rows(rows.cpu(), n_total).to(rows.device)
     world = dist.get_world_size()
@@ -89,6 +160,15 @@ def all_gather_rows_into(rows, n_total, out):
     rows; the distance kernel wants the matrix padded to whole 128-row tiles, the padding rows stay zero)."""
     if _alone():
         out[:rows.shape[0]].copy_(rows)
+        return out
+    dev = _abi_for(rows)
+    if dev is not None:
+        # every rank's block of rows straight to its place in `out` (rows past n_total are not written: they stay what they were)
+        world = _abi["world"]
+        width = rows.shape[1] * rows.element_size()
+        bounds = [shard_bounds(n_total, r, world) for r in range(world)]
+        rc = rows.contiguous()
+        dev.allgatherv_dev(rc.data_ptr() if rc.numel() else 0, out.data_ptr(), [(hi - lo) * width for lo, hi in bounds], [lo * width for lo, _ in bounds])
         return out
     world = dist.get_world_size()
     per = (n_total + world - 1) // world
@@ -118,7 +198,7 @@ def tiles_of_rank(n, rank, world):
 
 def sum_partial_distances(partial):
     """Every rank filled only its own tiles (and their mirror images) of an n x n int32 matrix of zeros."""
-    if not _alone():
+    if not _alone() and dist.is_initialized():
         dist.all_reduce(partial, op=dist.ReduceOp.SUM)
     return partial
 
@@ -158,6 +238,11 @@ class RowBands(object):
         Returns the (band tile rows * 128, n_padded) band of complete rows this rank owns."""
         nt, T, world = self.nt, DIST_TILE, self.world
         lo, hi = self.bands[rank]
+        if world == 1 and not group_of_one_exchanges():                   # one rank owns every row: the matrix it computed is the band
+            return partial[:(hi - lo) * T]
+        dev_abi = _abi_for(partial)
+        if dev_abi is not None:
+            return self._exchange_abi(dev_abi, partial, rank)
         band = torch.zeros(((hi - lo) * T, self.n_padded), dtype=partial.dtype, device=partial.device)
         p4 = partial.view(nt, T, nt, T)
         b4 = band.view(max(hi - lo, 0), T, nt, T) if hi > lo else None
@@ -189,3 +274,36 @@ class RowBands(object):
         if rrows.numel():
             b4[rrows, :, rcols, :] = recv
         return band
+
+    def _exchange_abi(self, dev, partial, rank):
+        """The same exchange as library calls on the context's stream: k_tiles_gather packs this rank's tiles in destination order,
+        one group of ncclSend / ncclRecv moves them, k_tiles_scatter puts what arrived into the band.  The buffers and the index
+        arrays are made once per (rank, device); a band is written completely every time (every tile of its rows arrives exactly
+        once), so it needs no clearing.  One rank alone owns every row: the matrix it computed is the band."""
+        nt, T, world = self.nt, DIST_TILE, self.world
+        lo, hi = self.bands[rank]
+        key = ("abi", rank, str(partial.device))
+        plan = self._index.get(key)
+        if plan is None:
+            send_list = [blk for dst in range(world) for blk in self.blocks[rank][dst]]
+            recv_list = [blk for src in range(world) for blk in self.blocks[src][rank]]
+            as_u32 = lambda v: torch.tensor(v, dtype=torch.int32, device=partial.device)     # noqa: E731  (tile indices: far below 2^31)
+            plan = {
+                "s_rows": as_u32([b[0] for b in send_list]), "s_cols": as_u32([b[1] for b in send_list]),
+                "r_rows": as_u32([b[0] - lo for b in recv_list]), "r_cols": as_u32([b[1] for b in recv_list]),
+                "n_send": len(send_list), "n_recv": len(recv_list),
+                "send": torch.empty((max(len(send_list), 1), T, T), dtype=torch.int32, device=partial.device),
+                "recv": torch.empty((max(len(recv_list), 1), T, T), dtype=torch.int32, device=partial.device),
+                "band": torch.zeros((max(hi - lo, 0) * T, self.n_padded), dtype=torch.int32, device=partial.device),
+                "send_bytes": [len(self.blocks[rank][dst]) * T * T * 4 for dst in range(world)],
+                "recv_bytes": [len(self.blocks[src][rank]) * T * T * 4 for src in range(world)],
+            }
+            self._index[key] = plan
+        if partial.dtype != torch.int32 or not partial.is_contiguous():
+            raise ValueError("the distance matrix must be a contiguous int32 tensor")
+        dev.tiles_gather_dev(partial.data_ptr(), self.n_padded, plan["s_rows"].data_ptr(), plan["s_cols"].data_ptr(), plan["n_send"], plan["send"].data_ptr())
+        dev.alltoallv_dev(plan["send"].data_ptr(), plan["send_bytes"], plan["recv"].data_ptr(), plan["recv_bytes"])
+        if hi > lo:
+            dev.tiles_scatter_dev(plan["recv"].data_ptr(), plan["r_rows"].data_ptr(), plan["r_cols"].data_ptr(), plan["n_recv"], plan["band"].data_ptr(),
+                                  self.n_padded)
+        return plan["band"]

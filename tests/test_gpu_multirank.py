@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _run_bench(world, dump, extra, launcher=False, rccl_group_of_one=False):
+def _run_bench(world, dump, extra, launcher=False, rccl_group_of_one=False, comm=None):
     args = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--scaling", "strong", "--skip-aux", "--e2e-files", "0", "--site-files", "0",
             "--cpu-samples", "0", "--pipeline-files", "0", "--shape-samples", "0", "--dump", dump] + extra
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
@@ -33,6 +33,8 @@ def _run_bench(world, dump, extra, launcher=False, rccl_group_of_one=False):
     if rccl_group_of_one:                                               # one rank, one GPU, backend nccl, every collective of the step made
         del env["SNPGPU_BENCH_TEST_ONE_GPU"]
         env.update(SNPGPU_DIST_AT_WORLD_1="1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+        if comm:
+            env["SNPGPU_COMM"] = comm
     if world == 1 or not launcher:
         cmd = [sys.executable] + args                                   # plain `python bench.py --gpus N`: bench.py starts its own ranks
     else:
@@ -44,7 +46,7 @@ def _run_bench(world, dump, extra, launcher=False, rccl_group_of_one=False):
     return json.loads(line)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_step_equals_single_rank(tmp_path, world):
     n_total = 300                                                       # 3 x 3 distance tiles, uneven sample shards for 3 ranks
     extra = ["--samples", str(n_total), "--genome", "40000", "--sites", "400", "--vcf-records", "60", "--dist-samples", "700",
@@ -53,7 +55,8 @@ def test_sharded_step_equals_single_rank(tmp_path, world):
     many = _run_bench(world, str(tmp_path / "many"), extra, launcher=(world == 3))      # 2 ranks: self-launched; 3: the driver's way
     assert many["n_gpus"] == world and many["scaling"] == "strong" and "world size %d" % world in many["config"]["parallelism"]
     assert many["comm"]["world_size"] == world and many["comm"]["backend"] == "gloo"
-    assert ("started its own ranks" in many["comm"]["launcher"]) == (world == 2)
+    assert ("started its own ranks" in many["comm"]["launcher"]) == (world != 3)      # (8 ranks: six distance tiles, two ranks without one)
+    assert len(many["phases_ms_per_step"]["per_rank"]) == world and many["comm_route"] == {"exchanges": "torch.distributed (gloo)"}
     assert one["comm"] == {"backend": None, "world_size": 1, "launcher": "none (one process)", "collectives_per_step": "none"}
     assert many["site_union"] == one["site_union"]
     assert many["secondary"]["value"] > 0
@@ -95,17 +98,23 @@ def test_strong_scaling_of_the_distance_step_at_configs4_shape(tmp_path):
         assert set(ph["rank0"]) == set(ph["max_over_ranks"]) and all(v >= 0 for v in ph["max_over_ranks"].values())
 
 
-def test_the_step_in_an_rccl_group_of_one(tmp_path):
+@pytest.mark.parametrize("route", ["abi", "torch"])
+def test_the_step_in_an_rccl_group_of_one(tmp_path, route):
     """RCCL needs a GPU per rank and the test box has one: so the N > 1 step runs over gloo above, and RCCL runs here in a group of
-    ONE rank that still makes every collective call of the step on device tensors (SNPGPU_DIST_AT_WORLD_1: all_gather_into_tensor
-    of counts, padded keys and packed rows — the last straight into a slice of the padded matrix —, all_to_all_single with split
-    lists, all_reduce, barrier).  Same answers as the plain one-process run, array for array."""
+    ONE rank that still makes every collective call of the step on device tensors (SNPGPU_DIST_AT_WORLD_1) — through the library's
+    own entry points (csrc/comm.hip: the default over RCCL), and through torch.distributed (SNPGPU_COMM=torch: all_gather_into_tensor
+    of counts, padded keys and packed rows, all_to_all_single with split lists).  Same answers as the plain one-process run, array
+    for array."""
     n_total = 300
     extra = ["--samples", str(n_total), "--genome", "40000", "--sites", "400", "--vcf-records", "60", "--dist-samples", "700",
              "--dist-sites", "3000", "--dist-reps", "1"]
     one = _run_bench(1, str(tmp_path / "one"), extra)
-    grp = _run_bench(1, str(tmp_path / "grp"), extra, rccl_group_of_one=True)
+    grp = _run_bench(1, str(tmp_path / "grp"), extra, rccl_group_of_one=True, comm=route)
     assert grp["comm"]["backend"] == "nccl" and grp["comm"]["world_size"] == 1 and grp["n_gpus"] == 1
+    if route == "abi":
+        assert "libsnpgpu.so" in grp["comm_route"]["exchanges"] and grp["comm_route"]["world_size_rccl_reports"] == 1 and grp["comm_route"]["rccl_version"] >= 20000
+    else:
+        assert grp["comm_route"] == {"exchanges": "torch.distributed (nccl)"}
     assert "all-to-all" in grp["comm"]["collectives_per_step"]
     assert grp["site_union"] == one["site_union"]
     assert grp["secondary"]["band_checksum"] == one["secondary"]["band_checksum"] and "row-band exchange included" in grp["secondary"]["config"]["workload"]
