@@ -240,9 +240,13 @@ int snpgpu_allgather(snpgpu_ctx *ctx, const void *d_send, void *d_recv, size_t b
 // point-to-point transfers: xGMI is point-to-point, every pair has its own link.
 int snpgpu_allgatherv(snpgpu_ctx *ctx, const void *d_send, void *d_recv, const uint64_t *bytes, const uint64_t *offsets) {
     if (!ctx || !ctx->comm) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "no communicator: snpgpu_comm_init first");
-    if (!bytes || !offsets || !d_recv) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (!bytes || !offsets) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
     Rccl *R = rccl();
     Comm *c = (Comm *)ctx->comm;
+    uint64_t total = 0;
+    for (int p = 0; p < c->nranks; ++p) total += bytes[p];
+    if (!total) return SNPGPU_OK;                                // (every rank sees the same sizes: nobody has anything)
+    if (!d_recv) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
     HIP_TRY(ctx, snpgpu_enter(ctx));
     const uint64_t mine = bytes[c->rank];
     if (mine && !d_send) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
@@ -266,8 +270,10 @@ int snpgpu_alltoallv(snpgpu_ctx *ctx, const void *d_send, const uint64_t *send_b
     Rccl *R = rccl();
     Comm *c = (Comm *)ctx->comm;
     HIP_TRY(ctx, snpgpu_enter(ctx));
-    uint64_t so = 0, ro = 0, my_so = 0, my_ro = 0;
+    uint64_t so = 0, ro = 0, my_so = 0, my_ro = 0, total_s = 0, total_r = 0;
     for (int p = 0; p < c->rank; ++p) { my_so += send_bytes[p]; my_ro += recv_bytes[p]; }
+    for (int p = 0; p < c->nranks; ++p) { total_s += send_bytes[p]; total_r += recv_bytes[p]; }
+    if ((total_s && !d_send) || (total_r && !d_recv)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
     if (send_bytes[c->rank] != recv_bytes[c->rank]) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "a rank's block for itself has two sizes");
     if (send_bytes[c->rank])
         HIP_TRY(ctx, hipMemcpyAsync((char *)d_recv + my_ro, (const char *)d_send + my_so, send_bytes[c->rank], hipMemcpyDeviceToDevice, ctx->stream));

@@ -954,19 +954,19 @@ __global__ __launch_bounds__(256) void k_call_mode(const SampleDev *samples, uin
 // ------------------------------------------------------------------------------------------------
 struct SampleIO { const uint8_t *d_pileup; size_t nbytes; uint64_t *d_status; };
 
-// The call kernels over a scanned batch: d_table describes the (complete) files, d_site_line the scan's result.
-int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n,
-                        const snpgpu_caller_params *prm, const uint64_t *d_site_line, uint8_t *d_out_base,
-                        uint8_t *d_out_filters, snpgpu_site_counts *d_out_counts, uint32_t *d_todo_n, uint64_t *d_todo,
-                        uint64_t *d_todo2, const uint8_t *d_site_flags, uint32_t flags_stride) {
+// The call kernels over n_sites "sites" of n samples: d_table describes the (complete) files, d_site_line the line of every
+// (sample, site); default_flags [n_sites] unless d_site_flags gives every sample its own row.
+static int enqueue_call_n(snpgpu_ctx *ctx, uint32_t n_sites, const uint8_t *default_flags, const SampleDev *d_table, uint32_t n,
+                          const snpgpu_caller_params *prm, const uint64_t *d_site_line, uint8_t *d_out_base,
+                          uint8_t *d_out_filters, snpgpu_site_counts *d_out_counts, uint32_t *d_todo_n, uint64_t *d_todo,
+                          uint64_t *d_todo2, const uint8_t *d_site_flags, uint32_t flags_stride) {
     hipStream_t st = ctx->stream;
-    const uint32_t n_sites = ss->n_sites;
     if (!n_sites || !n) return SNPGPU_OK;
     CallArgs ca;
     ca.samples = d_table;
     ca.n_samples = n;
     ca.site_line = d_site_line;
-    ca.site_flags = d_site_flags ? d_site_flags : ss->dev.flags;
+    ca.site_flags = d_site_flags ? d_site_flags : default_flags;
     ca.flags_stride = d_site_flags ? flags_stride : 0;
     ca.n_sites = n_sites;
     ca.prm = *prm;
@@ -1020,11 +1020,26 @@ int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleD
     return SNPGPU_OK;
 }
 
-// Every line of one pileup as a "site" (--vcfAllPos): the complete caller over a list of line offsets.
+// The call kernels over a scanned batch: d_table describes the (complete) files, d_site_line the scan's result.
+int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n,
+                        const snpgpu_caller_params *prm, const uint64_t *d_site_line, uint8_t *d_out_base,
+                        uint8_t *d_out_filters, snpgpu_site_counts *d_out_counts, uint32_t *d_todo_n, uint64_t *d_todo,
+                        uint64_t *d_todo2, const uint8_t *d_site_flags, uint32_t flags_stride) {
+    return enqueue_call_n(ctx, ss->n_sites, ss->dev.flags, d_table, n, prm, d_site_line, d_out_base, d_out_filters, d_out_counts, d_todo_n, d_todo, d_todo2,
+                          d_site_flags, flags_stride);
+}
+
+// Every line of one pileup as a "site" (--vcfAllPos, call_consensus.py:148 / pileup.py:418-421): the caller over a list of line
+// offsets — the same chain as over a site list (one lane per line in three window sizes, one wave per line for what is left; up to
+// round 4 every line took a wave of its own: 9.9 ms for 5 M lines).  d_todo / d_todo2: 8 * n_lines bytes each; d_todo_n: four words.
 int snpgpu_enqueue_call_lines(snpgpu_ctx *ctx, const SampleDev *d_sample, const uint64_t *d_line_off, const uint8_t *d_flags,
                               uint32_t n_lines, const snpgpu_caller_params *prm, uint8_t *d_out_base, uint8_t *d_out_filters,
-                              snpgpu_site_counts *d_out_counts) {
+                              snpgpu_site_counts *d_out_counts, uint32_t *d_todo_n, uint64_t *d_todo, uint64_t *d_todo2) {
     if (!n_lines) return SNPGPU_OK;
+    if (d_todo_n && d_todo && d_todo2) {
+        HIP_TRY(ctx, hipMemsetAsync(d_todo_n, 0, 16, ctx->stream));
+        return enqueue_call_n(ctx, n_lines, d_flags, d_sample, 1, prm, d_line_off, d_out_base, d_out_filters, d_out_counts, d_todo_n, d_todo, d_todo2, nullptr, 0);
+    }
     CallArgs ca;
     ca.samples = d_sample;
     ca.n_samples = 1;

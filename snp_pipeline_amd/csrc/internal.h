@@ -146,7 +146,7 @@ int snpgpu_enqueue_varscan_batch(snpgpu_ctx *ctx, const uint8_t *const *d_bufs, 
 // ... and the wave-per-site call kernel over such a list (consensus.hip): "site" i is line i
 int snpgpu_enqueue_call_lines(snpgpu_ctx *ctx, const SampleDev *d_sample, const uint64_t *d_line_off, const uint8_t *d_flags,
                               uint32_t n_lines, const snpgpu_caller_params *prm, uint8_t *d_out_base, uint8_t *d_out_filters,
-                              snpgpu_site_counts *d_out_counts);
+                              snpgpu_site_counts *d_out_counts, uint32_t *d_todo_n = nullptr, uint64_t *d_todo = nullptr, uint64_t *d_todo2 = nullptr);
 // the call kernels over a scanned batch (consensus.hip); d_todo_n: 4 words (3 zeroed), d_todo / d_todo2: n * n_sites entries each;
 // d_site_flags: nullptr = the site set's flags for every sample, else flags of sample i at d_site_flags + i * flags_stride
 int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n,

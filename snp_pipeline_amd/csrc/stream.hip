@@ -802,7 +802,8 @@ int snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const 
     const size_t o_filt = o; o += up(n_lines, 256);
     const size_t o_stat = o; o += 256;
     const size_t o_samp = o; o += 256;
-    const size_t o_cnt = o; o += sizeof(snpgpu_site_counts) * (size_t)n_lines;
+    const size_t o_cnt = o; o += up(sizeof(snpgpu_site_counts) * (size_t)n_lines, 256);
+    const size_t o_todo = o; o += 2 * up(8ull * n_lines, 256) + 256;           // the lane kernels' leftover lists and their counts
     rc = snpgpu_scratch(ctx, o + 256, &scr);
     if (rc) return rc;
     char *b = (char *)scr;
@@ -819,7 +820,8 @@ int snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const 
                                    (uint64_t *)(b + o_stat));
     if (rc == SNPGPU_OK)
         rc = snpgpu_enqueue_call_lines(ctx, (const SampleDev *)(b + o_samp), (const uint64_t *)(b + o_off), (const uint8_t *)(b + o_flag),
-                                       n_lines, params, (uint8_t *)(b + o_base), (uint8_t *)(b + o_filt), (snpgpu_site_counts *)(b + o_cnt));
+                                       n_lines, params, (uint8_t *)(b + o_base), (uint8_t *)(b + o_filt), (snpgpu_site_counts *)(b + o_cnt),
+                                       (uint32_t *)(b + o_todo), (uint64_t *)(b + o_todo + 256), (uint64_t *)(b + o_todo + 256 + up(8ull * n_lines, 256)));
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out_line_off, b + o_off, 8ull * n_lines, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(out_line_flags, b + o_flag, n_lines, hipMemcpyDeviceToHost, st));

@@ -15,6 +15,9 @@
 // oracle/varscan_oracle.py (which tests compare it with); see its header for what the reference's fixtures pin.
 #include <string.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "internal.h"
 #include "prims.h"
 
@@ -948,7 +951,7 @@ static int varscan_launch(snpgpu_ctx *ctx, VsFile *h_files, uint32_t n_files, Vs
     }
     uint32_t wg_waves = 12;                                                             // 12 x 13 616 bytes of LDS: one workgroup per CU, three waves per SIMD
     uint64_t resident = (uint64_t)ctx->n_cu * wg_waves;
-    uint32_t mult = total_tiles / resident >= 512 ? 4u : 1u;                            // long launches: four workgroups per CU in turn even out what one leaves to chance
+    uint32_t mult = 1;                                                                  // (more workgroups than the CUs hold at once were measured and lose: every wave pays its prologue and a tile behind its run)
     uint32_t share[4] = {140, 100, 66, 66};                                             // tools/vs_share_sweep.sh: 123 -> 111 us per 30x sample from 118 : 100 : 84; steeper loses again
 #ifdef SNPGPU_TUNING                                            // development builds only (tools/)
     if (const char *e = getenv("SNPGPU_VS_GRID_MUL")) if (atoi(e) > 0) mult = (uint32_t)atoi(e);
@@ -966,15 +969,30 @@ static int varscan_launch(snpgpu_ctx *ctx, VsFile *h_files, uint32_t n_files, Vs
     if (want > VARSCAN_MAX_WAVES) want = VARSCAN_MAX_WAVES;
     if (want > total_tiles / 4) want = total_tiles / 4 ? total_tiles / 4 : 1;
     if (want < n_files) want = n_files;
-    uint32_t wave0 = 0;
-    for (uint32_t i = 0; i < n_files; ++i) {
-        uint64_t w = (uint64_t)((long double)want * (long double)h_files[i].n_tiles / (long double)total_tiles + 0.5L);
-        if (w < 1) w = 1;
-        if (w > h_files[i].n_tiles) w = h_files[i].n_tiles;
-        h_files[i].wave0 = wave0;
-        h_files[i].n_waves = (uint32_t)w;
-        wave0 += (uint32_t)w;
+    // Exactly `want` waves in all (a launch of one workgroup more than the CUs hold runs twice as long): every file the whole part
+    // of its share, at least one; what is left over goes, one each, to the files in the order of their fractional parts.
+    {
+        std::vector<std::pair<long double, uint32_t>> frac(n_files);
+        uint64_t given = 0;
+        for (uint32_t i = 0; i < n_files; ++i) {
+            const long double sh = (long double)want * (long double)h_files[i].n_tiles / (long double)total_tiles;
+            uint64_t w = (uint64_t)sh;
+            frac[i] = {sh - (long double)w, i};
+            if (w < 1) { w = 1; frac[i].first = 0; }
+            if (w > h_files[i].n_tiles) { w = h_files[i].n_tiles; frac[i].first = 0; }
+            h_files[i].n_waves = (uint32_t)w;
+            given += w;
+        }
+        std::sort(frac.begin(), frac.end(), [](const std::pair<long double, uint32_t> &a, const std::pair<long double, uint32_t> &b) {
+            return a.first != b.first ? a.first > b.first : a.second < b.second;
+        });
+        for (uint32_t k = 0; k < n_files && given < want; ++k) {
+            VsFile &f = h_files[frac[k].second];
+            if (frac[k].first > 0 && f.n_waves < f.n_tiles) { ++f.n_waves; ++given; }
+        }
     }
+    uint32_t wave0 = 0;
+    for (uint32_t i = 0; i < n_files; ++i) { h_files[i].wave0 = wave0; wave0 += h_files[i].n_waves; }
     const uint32_t n_waves_total = wave0;
     if (n_waves_total > 2 * VARSCAN_MAX_WAVES) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "too many pileups in one site-calling launch");
     const uint32_t grid = (n_waves_total + wg_waves - 1) / wg_waves;
@@ -1045,5 +1063,22 @@ int snpgpu_enqueue_varscan_batch(snpgpu_ctx *ctx, const uint8_t *const *d_bufs, 
     uint4 *d_cand = (uint4 *)s;
     uint32_t *d_wave_lines = (uint32_t *)(s + (size_t)cand_cap * 16u);
     VsFile *d_files = (VsFile *)(s + (size_t)cand_cap * 16u + 4u * 2u * VARSCAN_MAX_WAVES);
-    return varscan_launch(ctx, h, n, d_files, prm, d_cand, cand_cap, d_ctl + 1, d_wave_lines);
+    // One launch per stretch of files of about 400 tiles per wave (twelve 30x samples of 5 Mbp): measured per sample, 110 us at 12
+    // files per launch, 121 at 30, 135 at 100 — the longer a wave's run, the further the static shares of the waves drift from what
+    // the SIMDs give them.  The launches follow each other on the stream and share the list and the line counts (a stretch's
+    // epilogue has run before the next scan starts); each has its own list counter (word 1 of its first file's control words).
+    uint64_t per_wave = 400;
+#ifdef SNPGPU_TUNING
+    if (const char *e = getenv("SNPGPU_VS_TILES_PER_WAVE")) if (atoi(e) > 0) per_wave = (uint64_t)atoi(e);
+#endif
+    const uint64_t per_launch = per_wave * (uint64_t)ctx->n_cu * 12ull;
+    for (uint32_t i0 = 0; i0 < n;) {
+        uint64_t tiles = 0;
+        uint32_t i1 = i0;
+        while (i1 < n && (i1 == i0 || tiles + h[i1].hi / VS_TILE + 1 <= per_launch + per_launch / 8)) { tiles += h[i1].hi / VS_TILE + 1; ++i1; }
+        const int rc = varscan_launch(ctx, h + i0, i1 - i0, d_files + i0, prm, d_cand, cand_cap, d_ctl + 8u * i0 + 1, d_wave_lines);
+        if (rc) return rc;
+        i0 = i1;
+    }
+    return SNPGPU_OK;
 }

@@ -216,7 +216,7 @@ class _Job(object):
         # sharded over RCCL: the exchanges of the job are library calls on this context's stream (csrc/comm.hip); the gloo route of
         # the one-GPU tests, and a host whose librccl.so cannot be loaded, keep torch.distributed
         if self.comm.dist and not self.comm.one_gpu and os.environ.get("SNPGPU_COMM") != "torch":
-            self.abi_comm = sharding.use_abi_comm(self.dev)
+            self.abi_comm = self.sharding.use_abi_comm(self.dev)
         self.store = self.dev.pileups(int(self.args.residentBytes or 0))
 
     def close_device(self):
@@ -224,7 +224,7 @@ class _Job(object):
             self.store.close()
         if self.dev is not None:
             if getattr(self, "abi_comm", False):
-                sharding.drop_abi_comm()
+                self.sharding.drop_abi_comm()
                 self.abi_comm = False
             self.dev.close()
         self.store = self.dev = None

@@ -62,14 +62,15 @@ def main():
         assert res[0][0].tobytes() == recs.tobytes() and res[0][1] == n_lines           # (sample 0 again)
         d.kernel_time_ms(3)
         t = time.perf_counter()
-        for _ in range(max(reps // 2, 2)):
+        calls = max(reps // 2, 2)
+        for _ in range(calls):
             d.varscan_batch_dev(ptrs, sizes, prm)
-        dt = (time.perf_counter() - t) / max(reps // 2, 2)
-        k_ms, k_n = d.kernel_time_ms(3)
+        dt = (time.perf_counter() - t) / calls
+        k_ms, k_n = d.kernel_time_ms(3)                       # (a call makes one launch per dozen 30x samples: k_n launches in all)
         tot = sum(sizes)
-        print("batch of %d samples, %d bytes: %.3f ms per call; kernels %.1f us per call = %.1f us per sample = %.2f TB/s (%.3f of 8 TB/s)"
-              % (n_batch, tot, dt * 1e3, k_ms / max(k_n, 1) * 1e3, k_ms / max(k_n, 1) * 1e3 / n_batch, tot / (k_ms / max(k_n, 1) * 1e-3) / 1e12,
-                 tot / (k_ms / max(k_n, 1) * 1e-3) / 8e12))
+        per_call = k_ms / calls
+        print("batch of %d samples, %d bytes: %.3f ms per call; kernels %.1f us per call (%d launches) = %.1f us per sample = %.2f TB/s (%.3f of 8 TB/s)"
+              % (n_batch, tot, dt * 1e3, per_call * 1e3, k_n // calls, per_call * 1e3 / n_batch, tot / (per_call * 1e-3) / 1e12, tot / (per_call * 1e-3) / 8e12))
     d.kernel_timing(False)
 
 
