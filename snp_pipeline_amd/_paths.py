@@ -37,21 +37,14 @@ def ensure_private_dir(path, allow_group_read=False):
 
 
 def private_dir(*sub):
-    """This user's private directory of the build, plus sub-directories (each checked the same way): under
-    ``$XDG_RUNTIME_DIR`` when the session has one that is ours (a per-user tmpfs nobody else can write to), else
-    ``<tmp>/snpgpu-<uid>`` — created 0700 and refused when somebody else got there first."""
-    base = None
-    xdg = os.environ.get("XDG_RUNTIME_DIR")
-    if xdg and os.path.isabs(xdg):
-        try:
-            st = os.lstat(xdg)
-            if stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & 0o077):
-                base = os.path.join(xdg, "snpgpu")
-        except OSError:
-            pass
-    if base is None:
-        base = os.path.join(tempfile.gettempdir(), "snpgpu-%d" % os.getuid())
-    path = ensure_private_dir(base)
+    """This user's private directory of the build, plus sub-directories (each checked the same way): ALWAYS
+    ``<tmp>/snpgpu-<uid>`` — created 0700 and refused when somebody else got there first.  One place whatever the process was
+    started from: rounds 3-4 preferred ``$XDG_RUNTIME_DIR``, so an interactive shell (which has one) and a scheduler job or a
+    service started at boot (which have none) did not see each other's device-slot locks and service sockets
+    (SNPGPU_MAX_PROCS_PER_DEVICE silently not enforced, a second service spawned).  Processes that are to share across users or
+    with another temporary directory name a common one themselves: SNPGPU_LOCK_DIR (device slots, device.py) and
+    SNPGPU_SERVICE=<dir> (sockets, service.py)."""
+    path = ensure_private_dir(os.path.join(tempfile.gettempdir(), "snpgpu-%d" % os.getuid()))
     for name in sub:
         path = ensure_private_dir(os.path.join(path, name))
     return path

@@ -213,6 +213,8 @@ def _call_one_with_escaped_names(plan, dev, params, snp_arrays, err):
         plan.read_path = utf8_names.escaped_copy(plan.pileup_path)
     except utf8_names.Refused as why:
         raise devmod.PileupFormatError("%s (%s)" % (err, why), None)
+    except OSError as why:                       # no room for the copy (it is as large as the pileup): this sample's error, said plainly
+        raise devmod.PileupIOError("cannot write the copy of %s with escaped contig names: %s (TMPDIR names another place)" % (plan.pileup_path, why))
     kept = plan.excluded
     try:
         if plan.excluded is not None:
@@ -229,6 +231,14 @@ def _call_one(plan, dev, params, snp_arrays):
     """The device part of call_consensus for one sample: site set, streamed call, the checks the reference's loop makes, outputs."""
     args = plan.args
     ss, snp_slots, _ = build_siteset(dev, snp_arrays, plan.excluded)
+    try:
+        _call_one_on(plan, dev, params, ss, snp_slots)
+    finally:
+        ss.close()                                # (the batch command comes here once per sample with non-ASCII names: no site set left behind)
+
+
+def _call_one_on(plan, dev, params, ss, snp_slots):
+    args = plan.args
     timing.mark("site set")
     results, rcs, _ = dev.call_consensus_files(ss, [plan.read_path], params, want_counts=True, want_line_offsets=True,
                                                want_depth_sum=bool(getattr(args, "amdMetricsRefFasta", None)))

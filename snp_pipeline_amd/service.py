@@ -17,7 +17,7 @@ exit codes, same log text), one at a time per GPU.
 cannot reach a server does the work in-process.
 
 Whom the client trusts: the socket directory must be a real directory of this user that nobody else can write to (the default
-one lives under ``$XDG_RUNTIME_DIR``, or ``<tmp>/snpgpu-<uid>`` created 0700 and refused when another user made it first:
+one is ``<tmp>/snpgpu-<uid>`` (the same with or without a login session), created 0700 and refused when another user made it first:
 _paths.py), the process at the other end of the socket must run under this user's uid (SO_PEERCRED), and what it is sent of
 the environment is the list of variables the steps read (``_forwarded``) — not the whole of ``os.environ``.
 """
@@ -163,6 +163,16 @@ def try_client(argv):
     request was not served (service off, subcommand not served, no server reachable): the caller then works in-process."""
     if not argv or argv[0] not in SERVED:
         return None
+    if argv[0] == "call_sites":
+        # Only the device pass belongs in the per-GPU worker.  With a VarScan jar on CLASSPATH (mode varscan) the step runs samtools
+        # and a JVM, touches no device, and would queue behind the worker's one-request-at-a-time loop with its programs' stderr
+        # going to the detached server instead of this command's: it runs in-process, as the reference runs it.
+        try:
+            from . import call_sites as _cs
+            if _cs.site_calling_mode() != "device":
+                return None
+        except SystemExit:
+            return None                                         # (a mode that does not exist: the in-process command reports it)
     try:
         directory = service_dir()
     except OSError as e:                                      # the directory is not provably ours: nothing in it is trusted

@@ -99,10 +99,20 @@ def _escape_chunk(raw):
     return out.tobytes()
 
 
+def _copy_directory(pileup_path):
+    """Where the escaped copy goes: $TMPDIR when the user names one, else beside the pileup (the copy is as large as the file —
+    many GB — and the default /tmp is often a small tmpfs), else wherever tempfile puts things."""
+    if os.environ.get("TMPDIR"):
+        return None                                              # tempfile honours it
+    beside = os.path.dirname(os.path.abspath(pileup_path))
+    return beside if os.access(beside, os.W_OK | os.X_OK) else None
+
+
 def escaped_copy(pileup_path, directory=None):
     """Write the pileup with escaped contig names to a temporary file and return its path.  Raises UnicodeDecodeError for a
-    file that is not valid UTF-8 (as the reference's read does) and Refused for one this bridge cannot carry."""
-    fd, tmp = tempfile.mkstemp(prefix="snpgpu_names_", suffix=".pileup", dir=directory)
+    file that is not valid UTF-8 (as the reference's read does), Refused for one this bridge cannot carry, OSError (ENOSPC ...)
+    when the copy cannot be written."""
+    fd, tmp = tempfile.mkstemp(prefix=".snpgpu_names_", suffix=".pileup", dir=directory or _copy_directory(pileup_path))
     ok = False
     try:
         with os.fdopen(fd, "wb") as out, open(pileup_path, "rb") as f:
@@ -133,15 +143,22 @@ def escaped_copy(pileup_path, directory=None):
 
 
 def unescape_vcf_chrom(vcf_path):
-    """Spell the CHROM column of the data lines back (the file was written from escaped names)."""
-    with open(vcf_path, "rb") as f:
-        lines = f.read().split(b"\n")
+    """Spell the CHROM column of the data lines back (the file was written from escaped names): line by line into a temporary
+    file beside it, which then takes its place in one step — with --vcfAllPos the file has a row per pileup line, and a crash in the
+    middle must not leave half a consensus.vcf that is newer than its inputs."""
+    tmp = "%s.names.%d" % (vcf_path, os.getpid())
     changed = False
-    for i, ln in enumerate(lines):
-        if ln and not ln.startswith(b"#") and b"~" in ln.split(b"\t", 1)[0]:
-            chrom, rest = ln.split(b"\t", 1)
-            lines[i] = unescape_name(chrom) + b"\t" + rest
-            changed = True
-    if changed:
-        with open(vcf_path, "wb") as f:
-            f.write(b"\n".join(lines))
+    try:
+        with open(vcf_path, "rb") as f, open(tmp, "wb") as out:
+            for ln in f:
+                if ln[:1] != b"#" and b"\t" in ln:
+                    chrom, rest = ln.split(b"\t", 1)
+                    if b"~" in chrom:
+                        ln = unescape_name(chrom) + b"\t" + rest
+                        changed = True
+                out.write(ln)
+        if changed:
+            os.replace(tmp, vcf_path)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)

@@ -388,25 +388,48 @@ def private_temp_dir():
 
 # ---- the per-sample metrics file (name=value properties, utils.py:323-380 of the reference reads it back) ---------------
 def update_properties(prop_file_path, updates, keep_mtime=False):
-    """Set ``name=value`` lines in a properties file, keeping every other line; the file is created when missing.  The
-    read-modify-write runs under an exclusive lock (the regular and the preserved call_consensus job of one sample may get here
-    at the same time).  The lock file lives in the per-user temporary directory, named after the metrics file's real path: the
-    sample directory gets no file the reference's tools do not write, and a shared file system without a lock daemon is not
-    asked to lock anything; when even that lock cannot be had the update goes ahead unlocked — these are optional by-products,
-    never a reason for the step to fail.  keep_mtime: an existing file keeps its modification time, so that make-style
-    consumers (collect_metrics decides per metric with target_needs_rebuild) do not take its OTHER values for fresh."""
+    """Set ``name=value`` lines in a properties file, keeping every other line; the file is created when missing.  The regular and
+    the preserved call_consensus job of one sample may get here at the same time — on one host or, in an HPC job array, on two —
+    so the read-modify-write is made safe in two ways that need nothing but the file system the metrics file is on:
+      * the new content goes to a temporary file beside it and takes its place with os.replace: a reader never sees half a file,
+        and a crash leaves the old one;
+      * the update runs under an exclusive flock ON THE METRICS FILE'S DIRECTORY ENTRY (a lock file named after it, beside it,
+        removed afterwards — the sample directory keeps no file the reference's tools do not write), which two hosts sharing the
+        file system both see; where that cannot be had (a read-only or lock-less file system) the per-user lock directory of this
+        host serves (`_paths.private_dir`), and without any lock the update goes ahead: these are optional by-products, never a
+        reason for the step to fail.
+    keep_mtime: an existing file keeps its modification time, so that make-style consumers (collect_metrics decides per metric
+    with target_needs_rebuild) do not take its OTHER values for fresh."""
     import fcntl
     import hashlib
-    lock = None
+    lock, beside = None, None
     try:
-        lock_dir = private_temp_dir()
-        digest = hashlib.sha1(os.path.realpath(prop_file_path).encode("utf-8", "surrogateescape")).hexdigest()
-        lock = open(os.path.join(lock_dir, "metrics-%s.lock" % digest), "a")
-        fcntl.flock(lock, fcntl.LOCK_EX)
+        beside = prop_file_path + ".lock"
+        for _ in range(50):
+            lock = open(beside, "a")
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:                                                # the holder before us removed the name: our lock is on a file nobody else will find
+                same = os.fstat(lock.fileno()).st_ino == os.stat(beside).st_ino
+            except OSError:
+                same = False
+            if same:
+                break
+            lock.close()
+            lock = None
+        if lock is None:
+            raise OSError("the lock file keeps changing")
     except (OSError, IOError):
         if lock is not None:
             lock.close()
-        lock = None
+        lock, beside = None, None
+        try:
+            digest = hashlib.sha1(os.path.realpath(prop_file_path).encode("utf-8", "surrogateescape")).hexdigest()
+            lock = open(os.path.join(private_temp_dir(), "metrics-%s.lock" % digest), "a")
+            fcntl.flock(lock, fcntl.LOCK_EX)
+        except (OSError, IOError):
+            if lock is not None:
+                lock.close()
+            lock = None
     try:
         before = os.stat(prop_file_path) if (keep_mtime and os.path.isfile(prop_file_path)) else None
         _update_properties_unlocked(prop_file_path, updates)
@@ -415,6 +438,11 @@ def update_properties(prop_file_path, updates, keep_mtime=False):
     finally:
         if lock is not None:
             try:
+                if beside is not None:                          # (while the lock is held: whoever waits on it opens a new one afterwards)
+                    try:
+                        os.unlink(beside)
+                    except OSError:
+                        pass
                 fcntl.flock(lock, fcntl.LOCK_UN)
             finally:
                 lock.close()
@@ -436,5 +464,16 @@ def _update_properties_unlocked(prop_file_path, updates):
         else:
             out.append(line)
     out.extend("%s=%s" % kv for kv in left.items())
-    with open(prop_file_path, "w") as f:
-        f.write("\n".join(out) + "\n")
+    text = "\n".join(out) + "\n"
+    tmp = "%s.tmp.%d" % (prop_file_path, os.getpid())
+    try:                                                        # the new content beside the file, then in its place in one step
+        with open(tmp, "w") as f:
+            f.write(text)
+        os.replace(tmp, prop_file_path)
+    except (OSError, IOError):
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        with open(prop_file_path, "w") as f:                    # (a directory that takes no new file: in place, as the reference writes it)
+            f.write(text)

@@ -1280,7 +1280,7 @@ def test_site_calling_mode_existing_never_writes_and_batch_modes(tmp_path, monke
 def test_private_directories_and_what_the_service_client_sends(tmp_path, monkeypatch):
     """the per-user directory under a world-writable place is used only when it is provably ours (a real directory,
     owned by this uid, closed to others); the service client sends the variables the steps read, not the whole environment, and
-    only to a server of the same uid; the metrics lock file does not land in the sample directory."""
+    only to a server of the same uid; the metrics update leaves no lock or temporary file in the sample directory."""
     import socket
     from snp_pipeline_amd import _paths, service, utils
     monkeypatch.delenv("XDG_RUNTIME_DIR", raising=False)
@@ -1300,8 +1300,8 @@ def test_private_directories_and_what_the_service_client_sends(tmp_path, monkeyp
     os.unlink(d)
     xdg = tmp_path / "xdg"
     xdg.mkdir(mode=0o700)
-    monkeypatch.setenv("XDG_RUNTIME_DIR", str(xdg))
-    assert _paths.private_dir() == str(xdg / "snpgpu")
+    monkeypatch.setenv("XDG_RUNTIME_DIR", str(xdg))             # (one place with or without a session — a shell and a
+    assert _paths.private_dir() == os.path.join(str(tmp_path), "snpgpu-%d" % os.getuid())      # scheduler job must see each other's locks)
     # what travels
     monkeypatch.setenv("AWS_SECRET_ACCESS_KEY", "hunter2")
     monkeypatch.setenv("CallConsensus_ExtraParams", "-q 15")
@@ -1315,7 +1315,8 @@ def test_private_directories_and_what_the_service_client_sends(tmp_path, monkeyp
     finally:
         a.close()
         b.close()
-    # the metrics by-product: no lock file beside it
+    # the metrics by-product: locked beside the file (two hosts of a job array both see that lock), replaced in one step,
+    # nothing left behind
     sample = tmp_path / "sampleX"
     sample.mkdir()
     utils.update_properties(str(sample / "metrics"), {"missingPos": "3"})
