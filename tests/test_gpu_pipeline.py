@@ -228,11 +228,12 @@ def test_hot_path_batch_equals_the_separate_steps(tmp_path, monkeypatch, filter_
         assert 0 < st["resident_files"] < len(piles) and st["h2d_bytes"] > total
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_hot_path_batch_sharded_over_ranks_writes_the_same_files(tmp_path, monkeypatch, world):
     """torchrun, one rank per GPU in production (RCCL); here all ranks on the one GPU of the test box with gloo moving the
     bytes: contiguous blocks of the sorted samples per rank, C1 / C2 / row bands between them — every file as the one-rank job
-    writes it (which the test above compares with the separate subcommands)."""
+    writes it (which the test above compares with the separate subcommands).  Eight ranks (the driver's scaling run) over seven
+    samples: one block per rank and a rank with nothing at all, one distance tile for eight ranks."""
     import socket
     import subprocess
     import sys
@@ -294,6 +295,11 @@ def test_hot_path_batch_in_an_rccl_group_of_one_writes_the_same_files(tmp_path, 
              "print('backend', seen[0])\n")
     cmd = [sys.executable, "-c", probe] + [w.replace("\x00", " ") for w in line.split()] + ["-v", "0"]
     r = subprocess.run(cmd, cwd=str(work), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "backend nccl" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    _compare(_snapshot(work, dirs, remove=False), want)
+    # ... and with the exchanges left to torch.distributed (SNPGPU_COMM=torch) instead of the library's own communicator
+    r = subprocess.run(cmd, cwd=str(work), env=dict(env, SNPGPU_COMM="torch", MASTER_PORT=str(port + 1 if port < 65000 else port - 1)),
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "backend nccl" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
     _compare(_snapshot(work, dirs, remove=False), want)
 
