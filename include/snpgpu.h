@@ -498,6 +498,7 @@ int  snpgpu_comm_version(int *out_version);                    /* ncclGetVersion
 int  snpgpu_comm_unique_id(void *out_id);                      /* SNPGPU_COMM_ID_BYTES bytes; rank 0 */
 int  snpgpu_comm_init(snpgpu_ctx *ctx, int rank, int nranks, const void *unique_id);
 void snpgpu_comm_destroy(snpgpu_ctx *ctx);                     /* (also done by snpgpu_ctx_destroy) */
+void snpgpu_comm_abort(snpgpu_ctx *ctx);                       /* without waiting for the stream: cancels what never completed (ncclCommAbort) */
 /* this rank, the number of ranks, and what ncclCommCount says (0 without a communicator) */
 int  snpgpu_comm_info(const snpgpu_ctx *ctx, int *out_rank, int *out_nranks, int *out_count_from_rccl);
 /* block r of d_recv (bytes_per_rank bytes) comes from rank r's d_send */

@@ -156,6 +156,7 @@ SIGNATURES = {
     "snpgpu_comm_unique_id": (C.c_int, [_P]),
     "snpgpu_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "snpgpu_comm_destroy": (None, [_P]),
+    "snpgpu_comm_abort": (None, [_P]),
     "snpgpu_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "snpgpu_allgather": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "snpgpu_allgatherv": (C.c_int, [_P, _P, _P, _P, _P]),

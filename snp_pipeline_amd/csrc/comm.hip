@@ -210,6 +210,18 @@ void snpgpu_comm_destroy(snpgpu_ctx *ctx) {
     snpgpu_comm_release(ctx);
 }
 
+// Give the communicator up WITHOUT waiting for the stream: what a collective that never completes leaves behind is cancelled
+// (ncclCommAbort), so that the process can go on by another route or end with a message instead of hanging in a synchronize.
+void snpgpu_comm_abort(snpgpu_ctx *ctx) {
+    if (!ctx || !ctx->comm) return;
+    Comm *c = (Comm *)ctx->comm;
+    Rccl *R = rccl();
+    (void)hipSetDevice(ctx->device);
+    if (R && c->comm) (void)R->CommAbort(c->comm);
+    delete c;
+    ctx->comm = nullptr;
+}
+
 int snpgpu_comm_info(const snpgpu_ctx *ctx, int *out_rank, int *out_nranks, int *out_count_from_rccl) {
     if (!ctx) return SNPGPU_E_ARG;
     const Comm *c = (const Comm *)ctx->comm;

@@ -347,10 +347,10 @@ __device__ __forceinline__ bool varscan_parse_lds(const uint32_t *lds32, uint32_
 //      anything and is done; with at least that many it becomes a 16-byte candidate entry (file offset, length, depth, TAB
 //      places); a line the shortcut cannot vouch for becomes an entry as it is, and the walk parses it in full (format errors
 //      included).  A line that does not end by tile k (> 4 KiB) is left to the epilogue kernel with its end unknown.
-// Candidates collect in the wave's LDS.  When the wave's tiles are done its ring is free: the wave packs its candidates' lines back
-// to back into it (16-byte loads, mostly L2 hits) and every lane runs the exact read-base automaton over its own line
-// (varscan_core_lds).  What does not fit — or overflows the local list in mid-run — goes to a global list for k_varscan_finish,
-// which also adds up the line counts of the waves per file.
+// Candidates collect in the wave's LDS (what does not fit there until the end: in the wave's own stretch of a spill list in global
+// memory).  When the wave's tiles are done its slots are free: the wave packs its candidates' lines back to back into them (LDS-DMA,
+// mostly L2 hits) and every lane runs the exact read-base automaton over its own line (varscan_core_lds).  Lines that fit no strip
+// or have no known end go to a shared list for k_varscan_finish, which also adds up the line counts of the waves per file.
 
 // A list entry (16 bytes): x, y = file offset of the line's first byte (48 bits) and, in the upper half of y, the index of the file
 // in the launch; z = its length in bytes (terminator included; 0 for a line whose end the scan does not know: VS_W_LONG, the walk
@@ -509,7 +509,7 @@ __device__ __forceinline__ uint32_t ffs64(uint64_t x) { return (uint32_t)__ffsll
 
 __global__ __launch_bounds__(768) void k_varscan_scan(const VsFile *__restrict__ files, uint32_t n_files, VsFile one, uint32_t n_waves_total,
                                                       snpgpu_varscan_params prm, uint4 *cand, uint32_t cand_cap, uint32_t *cand_n, uint32_t *wave_lines,
-                                                      uint4 share) {
+                                                      uint4 share, uint4 *spill, uint32_t spill_per_wave) {
     extern __shared__ uint4 vs_lds_all[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
@@ -555,8 +555,19 @@ __global__ __launch_bounds__(768) void k_varscan_scan(const VsFile *__restrict__
     if (t_first >= t_end) { if (lane == 0) wave_lines[gwave] = 0; return; }
     const uint64_t t_last = t_end < f.n_tiles ? t_end : f.n_tiles - 1;                  // the last tile I read: the one after my run (the end of my last line)
 
-    auto flush = [&]() {                                                                // my candidates so far onto the global list
+    // My candidates so far out of LDS: into my own stretch of the spill (no atomics, nobody else writes there; I walk them myself
+    // when my tiles are done), and only when that is full onto the shared list for the epilogue kernel.
+    uint32_t n_spilled = 0;
+    uint4 *my_spill = spill + (size_t)gwave * spill_per_wave;
+    auto flush = [&]() {
         if (n_local == 0) return;
+        if (n_spilled + n_local <= spill_per_wave) {
+            for (uint32_t k = lane; k < n_local; k += 64) my_spill[n_spilled + k] = cand_local[k];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // (the requests in flight are counted from zero again)
+            n_spilled += n_local;
+            n_local = 0;
+            return;
+        }
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(cand_n, n_local);
         base = __builtin_amdgcn_readfirstlane(base);
@@ -856,9 +867,10 @@ __global__ __launch_bounds__(768) void k_varscan_scan(const VsFile *__restrict__
     // ---- my candidates: their lines into the ring (free now), every lane walks its own ------------------------------------------
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t r = 0; r < n_local; r += 64) {
-        bool have = r + lane < n_local;
-        const uint4 e = have ? cand_local[r + lane] : make_uint4(0, 0, 0, 0);
+    const uint32_t n_mine = n_local + n_spilled;                                        // first what is still in LDS, then what went to my spill
+    for (uint32_t r = 0; r < n_mine; r += 64) {
+        bool have = r + lane < n_mine;
+        const uint4 e = have ? (r + lane < n_local ? cand_local[r + lane] : my_spill[r + lane - n_local]) : make_uint4(0, 0, 0, 0);
         for (int round = 0; round < 4 && __builtin_amdgcn_ballot_w64(have); ++round) {
             const bool done = walk_in_strips((uint4 *)ring, VS_DATA + 3u * (VS_STR_WORDS + VS_STR_PAD) * 4u - 16u, have, e, fo, prm);   // (- one chunk: the walk may read the word after a line)
             const bool progress = __builtin_amdgcn_ballot_w64(done && have) != 0;
@@ -925,13 +937,13 @@ __global__ __launch_bounds__(64) void k_varscan_finish(const VsFile *__restrict_
 
 }  // namespace
 
-// Device scratch the site calling of a launch needs besides its records: the global candidate list (16 bytes per entry; the scan's
-// waves walk their own candidates, so it only takes what overflows — a list that is full anyway costs speed, not answers) and one
-// line count per scan wave.
+// Device scratch the site calling of a launch needs besides its records: the candidate list (16 bytes per entry: a shared half for
+// the epilogue kernel and a stretch per wave for what a wave's LDS cannot hold until its tiles are done — a list that is full costs
+// speed, not answers) and one line count per scan wave.
 static const uint32_t VARSCAN_MAX_WAVES = 256 * 64;
 static inline uint32_t varscan_cand_cap(uint64_t nbytes) {
-    const uint64_t c = nbytes / 256 + 4096;
-    return (uint32_t)(c < (1ull << 22) ? c : (1ull << 22));
+    const uint64_t c = nbytes / 128 + 2 * VARSCAN_MAX_WAVES * 64;                      // (a shared half, and a stretch of >= 64 per wave)
+    return (uint32_t)(c < (1ull << 23) ? c : (1ull << 23));
 }
 size_t snpgpu_varscan_scratch_bytes(uint64_t nbytes) {
     return (size_t)varscan_cand_cap(nbytes) * 16u + 4u * VARSCAN_MAX_WAVES + 1024;
@@ -1003,11 +1015,14 @@ static int varscan_launch(snpgpu_ctx *ctx, VsFile *h_files, uint32_t n_files, Vs
     }
     if (n_files > 1) HIP_TRY(ctx, hipMemcpyAsync(d_files, h_files, sizeof(VsFile) * n_files, hipMemcpyHostToDevice, ctx->stream));
     hipEvent_t ta = snpgpu_time_begin(ctx);
-    k_varscan_scan<<<grid, 64u * wg_waves, lds_bytes, ctx->stream>>>(d_files, n_files, h_files[0], n_waves_total, *prm, d_cand, cand_cap, d_cand_n,
-                                                                                    d_wave_lines, make_uint4(share[0], share[1], share[2], share[3]));
+    // the list: its first half shared (the epilogue's), its second half one stretch per wave of this launch
+    const uint32_t shared_cap = cand_cap / 2, spill_per_wave = (cand_cap - shared_cap) / n_waves_total;
+    k_varscan_scan<<<grid, 64u * wg_waves, lds_bytes, ctx->stream>>>(d_files, n_files, h_files[0], n_waves_total, *prm, d_cand, shared_cap, d_cand_n,
+                                                                      d_wave_lines, make_uint4(share[0], share[1], share[2], share[3]), d_cand + shared_cap,
+                                                                      spill_per_wave);
     const uint32_t strip_bytes = 32u * 1024u;
-    const uint32_t fin_grid = n_files > ctx->n_cu ? (uint32_t)ctx->n_cu * 4u : (uint32_t)ctx->n_cu;
-    k_varscan_finish<<<fin_grid, 64, strip_bytes + 16u, ctx->stream>>>(d_files, n_files, h_files[0], *prm, d_cand, d_cand_n, cand_cap, d_wave_lines, n_waves_total, strip_bytes);
+    const uint32_t fin_grid = (uint32_t)ctx->n_cu * 4u;
+    k_varscan_finish<<<fin_grid, 64, strip_bytes + 16u, ctx->stream>>>(d_files, n_files, h_files[0], *prm, d_cand, d_cand_n, shared_cap, d_wave_lines, n_waves_total, strip_bytes);
     snpgpu_time_end(ctx, SNPGPU_K_VARSCAN, ta);
     HIP_TRY(ctx, hipGetLastError());
     return SNPGPU_OK;

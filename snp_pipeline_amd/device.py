@@ -645,6 +645,11 @@ class Device(object):
             self.lib.snpgpu_comm_destroy(self.ctx)
         self.comm_rank, self.comm_nranks = 0, 0
 
+    def comm_abort(self):
+        if self.ctx:
+            self.lib.snpgpu_comm_abort(self.ctx)
+        self.comm_rank, self.comm_nranks = 0, 0
+
     def comm_info(self):
         r, n, c = C.c_int(), C.c_int(), C.c_int()
         self._check(self.lib.snpgpu_comm_info(self.ctx, C.byref(r), C.byref(n), C.byref(c)))

@@ -12,6 +12,7 @@ complete rows of its contiguous band of tile rows, and every computed tile trave
 links, where summing the partial matrices with an all-reduce would move the whole N x N through every rank.
 """
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -25,10 +26,11 @@ DIST_TILE = 128          # csrc/distance.hip
 _abi = {"dev": None, "rank": 0, "world": 1, "counts": None}
 
 
-def use_abi_comm(device, rank=None, world=None, unique_id=None):
+def use_abi_comm(device, rank=None, world=None, unique_id=None, selftest=True):
     """Make the exchanges of this process library calls on `device`'s context.  With torch.distributed initialised, rank 0's id
     travels through its object broadcast; a host program without PyTorch passes rank / world / the 128-byte id itself (rank 0:
-    device.comm_unique_id(); INTEGRATION.md shows the ctypes form).  Returns False when RCCL cannot be loaded."""
+    device.comm_unique_id(); INTEGRATION.md shows the ctypes form).  Returns False when RCCL cannot be loaded, or when the
+    communicator's self-test fails on some rank (see _selftest): the exchanges then stay with torch.distributed."""
     if not device.comm_available():
         return False
     if unique_id is None:
@@ -39,8 +41,62 @@ def use_abi_comm(device, rank=None, world=None, unique_id=None):
             dist.broadcast_object_list(box, src=0)
         unique_id = box[0]
     device.comm_init(rank, world, unique_id)
+    if selftest and world > 1:
+        why = _selftest(device, int(rank), int(world))
+        every_ok = why is None
+        if dist.is_initialized():
+            flag = torch.tensor([1 if every_ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            every_ok = bool(int(flag.item()))
+        if not every_ok:
+            sys.stderr.write("snpgpu rank %d: the exchanges stay with torch.distributed (%s)\n"
+                             % (rank, why or "another rank's self-test of the library's communicator failed"))
+            device.comm_abort()
+            return False
     _abi.update(dev=device, rank=int(rank), world=int(world), counts=None)
     return True
+
+
+def _selftest(device, rank, world, timeout_ms=120000):
+    """Before the first real exchange, on a stream of its own: one all-gather, one all-gather of blocks of different sizes and one
+    all-to-all with a different size for every pair, checked byte for byte.  The first time ranks of a job meet on hardware this
+    takes the place of a hang in the middle of a step: a failure (or no completion within the time limit) is reported, the
+    communicator is given up and the job goes on over torch.distributed.  Returns None, or what went wrong."""
+    import numpy as np
+    side = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(side):
+            device.use_torch_stream()
+            mark = lambda a, b, n: ((torch.arange(n, dtype=torch.int64, device="cuda") * 31 + a * 7919 + b * 104729) & 0xFF).to(torch.uint8)  # noqa: E731
+            # 1: equal blocks
+            src = mark(rank, 0, 4096)
+            dst = torch.zeros(4096 * world, dtype=torch.uint8, device="cuda")
+            device.allgather_dev(src.data_ptr(), dst.data_ptr(), 4096)
+            # 2: rank r contributes (r + 1) * 1000 bytes
+            sizes = [(r + 1) * 1000 for r in range(world)]
+            offs = [sum(sizes[:r]) for r in range(world)]
+            src2 = mark(rank, 1, sizes[rank])
+            dst2 = torch.zeros(sum(sizes), dtype=torch.uint8, device="cuda")
+            device.allgatherv_dev(src2.data_ptr(), dst2.data_ptr(), sizes, offs)
+            # 3: rank a sends (a * world + b + 1) * 100 bytes to rank b
+            sb = [(rank * world + b + 1) * 100 for b in range(world)]
+            rb = [(a * world + rank + 1) * 100 for a in range(world)]
+            src3 = torch.cat([mark(rank, 2 + b, sb[b]) for b in range(world)])
+            dst3 = torch.zeros(sum(rb), dtype=torch.uint8, device="cuda")
+            device.alltoallv_dev(src3.data_ptr(), sb, dst3.data_ptr(), rb)
+            device.stream_wait(timeout_ms)
+            want1 = torch.cat([mark(r, 0, 4096) for r in range(world)])
+            want2 = torch.cat([mark(r, 1, sizes[r]) for r in range(world)])
+            want3 = torch.cat([mark(a, 2 + rank, rb[a]) for a in range(world)])
+            side.synchronize()
+            for k, (got, want) in enumerate(((dst, want1), (dst2, want2), (dst3, want3)), 1):
+                if not torch.equal(got, want):
+                    return "self-test %d of the library's communicator: wrong bytes arrived" % k
+        return None
+    except Exception as err:                                  # noqa: B902 — whatever it is, the other route is there
+        return "%s: %s" % (type(err).__name__, err)
+    finally:
+        device.use_torch_stream()                             # back to the stream the caller works on
 
 
 def drop_abi_comm():

@@ -46,7 +46,7 @@ try:
     m = re.search(r"^(\d+) bytes, (\d+) lines", txt, re.M)
     nbytes = int(m.group(1))
     fetch = write = 0.0
-    for kern in ("k_varscan_scan", "k_varscan_walk\n", "k_varscan_walk_long"):
+    for kern in ("k_varscan_scan", "k_varscan_finish"):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             mm = re.search(r"%s[^\n]*\n\s+%s\s+n=\d+\s+mean=(\S+)" % (kern.replace("\n", "(?=\n)"), counter), txt)
             if mm:
@@ -54,7 +54,7 @@ try:
                     fetch += float(mm.group(1))
                 else:
                     write += float(mm.group(1))
-    vs = {"kernels": "k_varscan_scan + k_varscan_walk + k_varscan_walk_long, one resident 5 Mbp x 30x sample", "bytes": nbytes,
+    vs = {"kernels": "k_varscan_scan + k_varscan_finish, one resident 5 Mbp x 30x sample per launch", "bytes": nbytes,
           "FETCH_SIZE_kb_per_file": fetch, "WRITE_SIZE_kb_per_file": write, "corrections": out["corrections"],
           "traffic_bytes_per_file": fetch * 1024 * 2 + write * 1024, "traffic_over_algorithmic": (fetch * 1024 * 2 + write * 1024) / nbytes}
     json.dump(vs, open(base + "varscan_traffic.json", "w"), indent=1)

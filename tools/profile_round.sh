@@ -1,15 +1,15 @@
 #!/bin/sh
 # Round profile on the GPU box: the bench line, the rocprofv3 kernel trace of the same command, and the PMC passes
 # (FETCH_SIZE / WRITE_SIZE / SQ counters, separate runs) -> gpurun_out/<round>/ ; copy what is to be judged into profiles/<round>/.
-# Usage: sh tools/profile_round.sh r4
-round=${1:-r4}
+# Usage: sh tools/profile_round.sh r5
+round=${1:-r5}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$round
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-short="--cpu-samples 0 --skip-aux --e2e-files 0 --site-files 0 --pipeline-files 0 --shape-samples 0"      # the timed step only (20 steps + 3 warm-up launches): every k_scan_wave<false,0> launch in this trace is a headline launch, so its average is the roofline's
+short="--cpu-samples 0 --skip-aux --e2e-files 0 --site-files 0 --pipeline-files 0 --shape-samples 0 --skip-call-variants"      # the timed step only (20 steps + 3 warm-up launches): every k_scan_wave<false,0> launch in this trace is a headline launch, so its average is the roofline's
 rows="--steps 2 --warmup 1 --cpu-samples 0 --skip-aux --skip-separate-steps"                         # the side rows (pipeline from files, end to end, site calling, scan shapes): which kernels they spend their device time in
-pmc="--steps 3 --warmup 1 --cpu-samples 0 --skip-secondary --skip-aux --e2e-files 0 --site-files 0 --pipeline-files 0 --shape-samples 0"
+pmc="--steps 3 --warmup 1 --cpu-samples 0 --skip-secondary --skip-aux --e2e-files 0 --site-files 0 --pipeline-files 0 --shape-samples 0 --skip-call-variants"
 python $root/bench.py > "$out/bench_n1.json" 2> "$out/bench_n1.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python $root/bench.py $short > "$out/trace_bench.json" 2> "$out/trace.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_rows" -- python $root/bench.py $rows > "$out/trace_rows_bench.json" 2> "$out/trace_rows.err"
