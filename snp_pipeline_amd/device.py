@@ -87,12 +87,15 @@ class SiteSet(object):
         self._create()
 
     @classmethod
-    def from_arrays(cls, device, contigs, keys, flags):
+    def from_arrays(cls, device, contigs, keys, flags, device_contigs=None):
         """contigs: bytewise sorted, unique list of contig names (bytes); keys: uint64 (contig index << 32 | pos), strictly
-        increasing; flags: SITE_* per key.  No Python loop per key (``index_of`` is the identity and is not materialised)."""
+        increasing; flags: SITE_* per key.  No Python loop per key (``index_of`` is the identity and is not materialised).
+        device_contigs: the names as the pileups the DEVICE reads spell them (utf8_names.escape_name of names that are not
+        plain ASCII: same order, same equalities); the writers that take this site set keep printing ``contigs``."""
         self = cls.__new__(cls)
         self.device = device
         self.contigs = list(contigs)
+        self.device_contigs = list(device_contigs) if device_contigs is not None else None
         self.keys = np.ascontiguousarray(keys, dtype=np.uint64)
         self.flags = np.ascontiguousarray(flags, dtype=np.uint8)
         self.index_of = None
@@ -132,15 +135,18 @@ class SiteSet(object):
 
     def _create(self):
         device, contigs = self.device, self.contigs
-        names = b"".join(contigs)
-        offs = np.zeros(len(contigs) + 1, dtype=np.uint32)
-        if contigs:
-            offs[1:] = np.cumsum([len(c) for c in contigs])
-        self._names = np.frombuffer(names, dtype=np.uint8) if names else np.zeros(0, np.uint8)
-        self._offs = offs
+
+        def table(names_list):
+            names = b"".join(names_list)
+            offs = np.zeros(len(names_list) + 1, dtype=np.uint32)
+            if names_list:
+                offs[1:] = np.cumsum([len(c) for c in names_list])
+            return (np.frombuffer(names, dtype=np.uint8) if names else np.zeros(0, np.uint8)), offs
+        self._names, self._offs = table(contigs)               # what the host writers print
+        dev_names, dev_offs = table(self.device_contigs) if getattr(self, "device_contigs", None) is not None else (self._names, self._offs)
         h = C.c_void_p()
         device._check(device.lib.snpgpu_siteset_create(
-            device.ctx, _ptr(self._names), _ptr(self._offs), len(contigs), _ptr(self.keys), _ptr(self.flags),
+            device.ctx, _ptr(dev_names), _ptr(dev_offs), len(contigs), _ptr(self.keys), _ptr(self.flags),
             len(self.keys), C.byref(h)))
         self.handle = h
         device._children.add(self)                         # the library object points at the context: it must go first

@@ -67,7 +67,7 @@ VARSCAN_CAPACITY = 16384    # records per file in those arrays; a file with more
 
 class _Sample(object):
     __slots__ = ("index", "dir", "name", "pileup", "ok", "error", "store_index", "vcf_lines", "header", "sites", "removed",
-                 "n_lines", "n_rows")
+                 "n_lines", "n_rows", "names_escaped")
 
     def __init__(self, index, sample_dir, pileup_name):
         self.index = index                      # position in the sorted list of sample directories
@@ -79,6 +79,7 @@ class _Sample(object):
         self.store_index = -1
         self.vcf_lines = self.header = self.sites = self.removed = None
         self.n_lines = self.n_rows = 0
+        self.names_escaped = False              # its pileup spells contig names that are not plain ASCII: the device reads an escaped copy
 
     def fail(self, message):
         self.ok, self.error = False, message
@@ -637,7 +638,15 @@ def _prepare_flows(job):
     col_of2 = np.full(S, -1, dtype=np.int32)
     col_of2[cols2] = np.arange(len(cols2), dtype=np.int32)
     fl.contig_bytes = [c.encode("utf-8") for c in job.contigs]
-    fl.ss = devmod.SiteSet.from_arrays(dev, fl.contig_bytes, set_keys.astype(np.uint64), in1 * np.uint8(L.SITE_IN_SNPLIST))
+    # Contig names that are not plain ASCII (just names to the reference, which reads its files as text): the scan's byte tests are
+    # ASCII-only, so the device sees every name escaped (utf8_names: injective, order-preserving, plain names unchanged) — in the
+    # site set here, and in a copy of the pileups that spell such names (made when the scan meets one, _consensus_group) — while
+    # everything that is written keeps the names as they are.
+    from . import utf8_names
+    fl.device_contigs = [utf8_names.escape_name(c) for c in fl.contig_bytes]
+    fl.escaped = fl.device_contigs != fl.contig_bytes
+    fl.ss = devmod.SiteSet.from_arrays(dev, fl.contig_bytes, set_keys.astype(np.uint64), in1 * np.uint8(L.SITE_IN_SNPLIST),
+                                       device_contigs=fl.device_contigs if fl.escaped else None)
     fl.identity1 = len(set_keys) == len(list1)
     fl.prm = devmod.make_params(cc_args.minBaseQual, cc_args.minConsFreq, cc_args.minConsDpth, cc_args.minConsStrdDpth, cc_args.minConsStrdBias)
     # collect_metrics by-products (call_consensus --amdMetricsRefFasta, given through CallConsensus_ExtraParams): the depth
@@ -761,14 +770,21 @@ def _check_repeated_lines(job, fl, s, status_row):
     it ends at the first it cannot build — and writes a consensus.vcf row for each.  The all-lines pass looks at them now,
     with the sample's OWN positions flagged as listed.  Returns the exception the reference would end with, or None."""
     wanted = _wanted_mask(fl, s)
-    own_set = devmod.SiteSet.from_arrays(job.dev, fl.contig_bytes, fl.set_keys.astype(np.uint64), wanted.astype(np.uint8) * np.uint8(L.SITE_IN_SNPLIST))
+    own_set = devmod.SiteSet.from_arrays(job.dev, fl.contig_bytes, fl.set_keys.astype(np.uint64), wanted.astype(np.uint8) * np.uint8(L.SITE_IN_SNPLIST),
+                                         device_contigs=fl.device_contigs if fl.escaped else None)
+    copy = None
     try:
-        _, line_flags, line_counts = job.dev.call_all_lines(own_set, s.pileup, fl.prm, check=False)
+        if getattr(s, "names_escaped", False):                 # (the file the device can read: its names escaped)
+            from . import utf8_names
+            copy = utf8_names.escaped_copy(s.pileup)
+        _, line_flags, line_counts = job.dev.call_all_lines(own_set, copy or s.pileup, fl.prm, check=False)
         err, _ = devmod.Device.site_error(devmod.ConsensusResult(None, None, line_counts[line_flags != 0], status_row))
     except (devmod.PileupFormatError, devmod.PileupIOError) as e:
         err = e
     finally:
         own_set.close()
+        if copy:
+            os.unlink(copy)
     return err
 
 
@@ -798,6 +814,15 @@ def _consensus_group(job, fl, g0, part, hs, vcf_again, vcf_later):
     elif res_idx:
         d_status[:g] = torch.tensor([-1, 0, 0, 0], dtype=torch.int64, device="cuda")
     rest = [(k, s) for k, s, ptr, _ in resident if not ptr]
+
+    def put_rows(k, r):                                       # the result of a streamed sample into row k of the group's arrays
+        d_status[k] = torch.from_numpy(r.status.astype(np.int64)).cuda()
+        if S:
+            d_base[k, :S] = torch.from_numpy(r.bases).cuda()
+            d_filt[k, :S] = torch.from_numpy(r.filters).cuda()
+            d_line[k, :S] = torch.from_numpy(r.line_offsets.astype(np.int64)).cuda()
+            if want_vcf:
+                d_counts[k, :S] = torch.from_numpy(r.counts.view(np.uint8).reshape(S, 128)).cuda()
     if rest:
         # files that did not fit the memory budget: streamed again (the only pileups that cross the link twice)
         results, rcs, st = dev.call_consensus_files(ss, [s.pileup for _, s in rest], prm, want_counts=want_vcf, want_line_offsets=True,
@@ -806,13 +831,37 @@ def _consensus_group(job, fl, g0, part, hs, vcf_again, vcf_later):
         for (k, s), rc, r in zip(rest, rcs, results):
             if int(rc) == L.E_IO:
                 s.fail("Error: cannot open or read the pileup file %s" % s.pileup)
-            d_status[k] = torch.from_numpy(r.status.astype(np.int64)).cuda()
-            if S:
-                d_base[k, :S] = torch.from_numpy(r.bases).cuda()
-                d_filt[k, :S] = torch.from_numpy(r.filters).cuda()
-                d_line[k, :S] = torch.from_numpy(r.line_offsets.astype(np.int64)).cuda()
-                if want_vcf:
-                    d_counts[k, :S] = torch.from_numpy(r.counts.view(np.uint8).reshape(S, 128)).cuda()
+            put_rows(k, r)
+    if fl.escaped and S:
+        # Some contig name of the job is not plain ASCII.  A pileup that spells such a name stops the scan at its first byte >= 0x80
+        # (scan code 3); the device gets a copy of that file with every name escaped, as the site set has them, and the sample's
+        # rows come from there (call_consensus does the same for one sample).  Characters >= 0x80 outside the name column stay
+        # refused (utf8_names.Refused: the sample keeps its scan error), a file that is not valid UTF-8 too.
+        from . import utf8_names
+        st_now = d_status[:g].cpu().numpy()
+        again = [(k, s) for k, s in enumerate(part) if s.ok and (int(st_now[k, 0]) & 0xFF) == 3 and (int(st_now[k, 0]) & 0xFFFFFFFFFFFFFFFF) != 0xFFFFFFFFFFFFFFFF]
+        copies = []
+        try:
+            for k, s in again:
+                try:
+                    copies.append((k, s, utf8_names.escaped_copy(s.pileup)))
+                except (utf8_names.Refused, UnicodeDecodeError, OSError):
+                    pass                                      # (its scan error stands)
+            if copies:
+                results, rcs, st = dev.call_consensus_files(ss, [c for _, _, c in copies], prm, want_counts=want_vcf, want_line_offsets=True,
+                                                            want_depth_sum=bool(fl.metrics_ref))
+                job.h2d_extra += int(st.bytes)
+                for (k, s, _), rc, r in zip(copies, rcs, results):
+                    if int(rc) == L.E_IO:
+                        continue
+                    s.names_escaped = True
+                    put_rows(k, r)
+        finally:
+            for _, _, c in copies:
+                try:
+                    os.unlink(c)
+                except OSError:
+                    pass
     # the preserved flow (and, when the set is wider than snplist.txt, the columns of the full flow) on the device
     excl = [np.searchsorted(fl.set_keys, fl.own_removed[s.index]).astype(np.uint32) for s in part]
     eoff = np.zeros(g + 1, dtype=np.int32)

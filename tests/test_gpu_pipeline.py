@@ -127,8 +127,8 @@ VARSCAN_EXTRA = "--min-avg-qual 15 --min-var-freq 0.90 --min-reads2 5"
 CONSENSUS_EXTRA = "-q 15 -c 0.9 -D 5 -d 2 -b 0.1"
 
 
-def _outbreak_tree(work, seed=7, n_samples=6, genome_len=12000):
-    refs, piles = fuzz.cohort_pileups(seed, n_samples=n_samples, genome_len=genome_len, mean_depth=22, n_scattered=9)
+def _outbreak_tree(work, seed=7, n_samples=6, genome_len=12000, contigs=("ctg1", "ctg2")):
+    refs, piles = fuzz.cohort_pileups(seed, n_samples=n_samples, genome_len=genome_len, mean_depth=22, n_scattered=9, contigs=contigs)
     names = ["iso%02d" % i for i in range(len(piles))]
     ref_path = work / "reference" / "ref.fasta"
     ref_path.parent.mkdir()
@@ -148,6 +148,33 @@ def _outbreak_tree(work, seed=7, n_samples=6, genome_len=12000):
     with open(dirs_file, "w") as f:
         f.write("\n".join(reversed(dirs)) + "\n")
     return str(ref_path), dirs, dirs_file, piles
+
+
+def test_hot_path_batch_with_contig_names_that_are_not_ascii(tmp_path, monkeypatch):
+    """Contig names are just names to the reference (it reads its files as text): `chr\u00e4`, `\u67d3\u8272\u4f531`, a name with a `~` in it.
+    The one job must write what the separate subcommands write (which take such names sample by sample since round 4) — refused up
+    to round 4, now carried the same way: the device sees every name escaped, what is written keeps the names as they are.  Half
+    of the samples resident, half streamed."""
+    work = tmp_path
+    ref_path, dirs, dirs_file, piles = _outbreak_tree(work, seed=11, contigs=("a~b", "chr\u00e4", "\u67d3\u8272\u4f531"), genome_len=7000)
+    monkeypatch.setenv("VarscanMpileup2snp_ExtraParams", VARSCAN_EXTRA)
+    monkeypatch.chdir(work)
+    filter_extra = "--edge_length 100 --window_size 1000 125 15 --max_snp 3 2 1 --mode all"
+    _separate_steps(work, ref_path, dirs, dirs_file, filter_extra, "")
+    want = _snapshot(work, dirs)
+    lists = want["snplist.txt"].decode("utf-8"), want["snplist_preserved.txt"].decode("utf-8")
+    assert "chr\u00e4" in lists[0] and "\u67d3\u8272\u4f531" in lists[1] and "a~b" in lists[0]
+    for resident in (0, int(2.5 * max(len(p) for p in piles))):
+        _run("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s%s"
+             % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), CONSENSUS_EXTRA.replace(" ", "\x00"),
+                " --residentBytes %d" % resident if resident else ""))
+        _compare(_snapshot(work, dirs, remove=False), want)
+    # the batch form of step 4 alone (its device pass works on bytes: a name is whatever stands in front of the first TAB)
+    for sdir in dirs:
+        os.remove(os.path.join(sdir, "var.flt.vcf"))
+    _run("call_sites_batch %s %s" % (ref_path, dirs_file))
+    for sdir in dirs:
+        assert open(os.path.join(sdir, "var.flt.vcf"), "rb").read() == want[os.path.join(os.path.basename(sdir), "var.flt.vcf")], sdir
 
 
 def _separate_steps(work, ref_path, dirs, dirs_file, filter_extra, merge_extra, consensus_extra=None):
