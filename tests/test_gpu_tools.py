@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     (["scan_tune.py", "3", "60000", "batch", "20"], "scan "),
     (["scan_tune.py", "2", "60000", "single", "20"], "scan "),
     (["varscan_kernel_time.py", "200000", "30", "2"], "records:"),
+    (["varscan_kernel_time.py", "200000", "30", "2", "3"], "batch of 3 samples"),
     (["varscan_time.py", "200000", "30", "1"], ""),
     (["varscan_files_time.py", "3", "1"], ""),
     (["pipeline_time.py", "--samples", "4", "--genome", "60000", "--sites", "600", "--separate", "--resident-frac", "0.5"], "outputs_identical_to_fully_resident\": true"),
