@@ -150,6 +150,56 @@ def _outbreak_tree(work, seed=7, n_samples=6, genome_len=12000, contigs=("ctg1",
     return str(ref_path), dirs, dirs_file, piles
 
 
+def test_hot_path_batch_without_consensus_vcf_writes_the_other_files_alike(tmp_path, monkeypatch):
+    """--noConsensusVcf: no per-site count records are made (the lane kernels without them, the group check on the filter bytes
+    instead of the records' status bytes) — every other file as the full job writes it, and a malformed line at a listed
+    position is the same sample error."""
+    work = tmp_path
+    ref_path, dirs, dirs_file, piles = _outbreak_tree(work, seed=13, n_samples=5, genome_len=6000)
+    monkeypatch.setenv("VarscanMpileup2snp_ExtraParams", VARSCAN_EXTRA)
+    monkeypatch.setenv("StopOnSampleError", "false")
+    monkeypatch.setenv("errorOutputFile", str(work / "error.log"))
+    monkeypatch.chdir(work)
+    filter_extra = "--edge_length 100 --window_size 1000 125 15 --max_snp 3 2 1 --mode all"
+    line = ("hot_path_batch -f %s %s --filterRegionsExtraParams=%s --callConsensusExtraParams=%s"
+            % (dirs_file, ref_path, filter_extra.replace(" ", "\x00"), CONSENSUS_EXTRA.replace(" ", "\x00")))
+    _run(line)
+    want = _snapshot(work, dirs)
+    _run(line + " --noConsensusVcf")
+    for sdir in dirs:
+        for name in PER_SAMPLE:
+            path = os.path.join(sdir, name)
+            if name.endswith("consensus.vcf") or name.endswith("consensus_preserved.vcf"):
+                assert not os.path.exists(path), path
+            else:
+                assert open(path, "rb").read() == want[os.path.join(os.path.basename(sdir), name)], path
+    for name in TOP_LEVEL:
+        assert open(os.path.join(str(work), name), "rb").read() == want[name], name
+    # a line no Record can be built from, at a listed position of one sample: that sample fails either way, the others go on
+    snplist = [ln.split("\t") for ln in want["snplist.txt"].decode().splitlines()]
+    chrom, pos = snplist[len(snplist) // 2][0], snplist[len(snplist) // 2][1]
+    p = os.path.join(dirs[1], "reads.all.pileup")
+    stamp = os.stat(p)
+    data = open(p, "rb").read().split(b"\n")
+    for i, ln in enumerate(data):
+        f = ln.split(b"\t")
+        if len(f) > 3 and f[0] == chrom.encode() and f[1] == pos.encode():
+            data[i] = b"\t".join(f[:3] + [b"notanumber"] + f[4:])
+            break
+    else:
+        raise AssertionError("the listed position has no line in sample 1")
+    open(p, "wb").write(b"\n".join(data))
+    os.utime(p, ns=(stamp.st_atime_ns, stamp.st_mtime_ns))     # (its var.flt.vcf stays the newer file: --siteCalling existing takes it)
+    logs = []
+    for extra in ("", " --noConsensusVcf"):
+        if os.path.exists(str(work / "error.log")):
+            os.remove(str(work / "error.log"))
+        _run(line + extra + " --siteCalling existing")
+        logs.append(open(str(work / "error.log")).read())
+        assert "call_consensus failed for sample %s" % os.path.basename(dirs[1]) in logs[-1]
+    assert logs[0] == logs[1]
+
+
 def test_hot_path_batch_with_contig_names_that_are_not_ascii(tmp_path, monkeypatch):
     """Contig names are just names to the reference (it reads its files as text): `chr\u00e4`, `\u67d3\u8272\u4f531`, a name with a `~` in it.
     The one job must write what the separate subcommands write (which take such names sample by sample since round 4) — refused up
