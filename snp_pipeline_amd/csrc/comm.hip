@@ -36,7 +36,6 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    std::string why;
 };
 
 Rccl *rccl() {
@@ -48,13 +47,13 @@ Rccl *rccl() {
             if (!n || !*n) continue;
             r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (r.handle) break;
-            r.why = dlerror() ? dlerror() : "";
+            (void)dlerror();
         }
-        if (!r.handle) { if (r.why.empty()) r.why = "librccl.so not found"; return; }
+        if (!r.handle) return;
 #define RCCL_SYM(field, name)                                                              \
     do {                                                                                   \
         *(void **)(&r.field) = dlsym(r.handle, name);                                      \
-        if (!r.field) { r.why = std::string("librccl.so lacks ") + name; r.handle = nullptr; return; } \
+        if (!r.field) { r.handle = nullptr; return; }                                      \
     } while (0)
         RCCL_SYM(GetVersion, "ncclGetVersion");
         RCCL_SYM(GetUniqueId, "ncclGetUniqueId");

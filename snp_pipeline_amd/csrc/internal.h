@@ -134,9 +134,8 @@ int snpgpu_enqueue_lines_emit(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const u
 int snpgpu_enqueue_lines_offsets(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, uint32_t *ws, uint64_t *d_line_off, uint64_t n_lines);
 // phase-1 site calling straight over the text, no line index (varscan.hip): see snpgpu_enqueue_varscan there for the arguments
 size_t snpgpu_varscan_scratch_bytes(uint64_t nbytes);
-int snpgpu_varscan_halo_class(const uint8_t *head, uint64_t n);
 int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, const snpgpu_varscan_params *prm, snpgpu_varscan_site *d_sites,
-                           uint32_t capacity, uint32_t *d_ctl, uint64_t *d_status, void *d_scratch, int halo_class);
+                           uint32_t capacity, uint32_t *d_ctl, uint64_t *d_status, void *d_scratch);
 // ... many resident pileups in one launch (see varscan.hip); h_table: snpgpu_varscan_table_bytes(n_files) bytes of host memory that stay valid
 // until the stream has passed the call
 size_t snpgpu_varscan_batch_scratch_bytes(uint64_t total_bytes, uint32_t n_files);

@@ -856,7 +856,7 @@ int varscan_resident(snpgpu_ctx *ctx, const uint8_t *d_file, uint64_t nbytes, co
     uint64_t h_ctl[5] = {~0ull, 0, 0, 0, 0};                    // status; records found + candidates; long candidates + spare; lines; spare
     HIP_TRY(ctx, hipMemcpyAsync(b + o_ctl, h_ctl, sizeof h_ctl, hipMemcpyHostToDevice, st));
     rc = snpgpu_enqueue_varscan(ctx, d_file, nbytes, params, (snpgpu_varscan_site *)(b + o_rec), capacity, (uint32_t *)(b + o_ctl + 8), (uint64_t *)(b + o_ctl),
-                                b + o_var, 0);
+                                b + o_var);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(h_ctl, b + o_ctl, sizeof h_ctl, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -1166,7 +1166,6 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
     };
     // The work on a complete file: one pass over its text, the walk over the candidates, results into the slot's pinned block.
     // Nothing here waits for the device (round 3 needed the file's line count on the host between two halves of this).
-    std::vector<int8_t> halo_cls(n_files, 1);                   // set from the file's first piece as it passes through the staging ring
 #define VS_RET(expr)                                                                                                \
     do {                                                                                                            \
         hipError_t e_ = (expr);                                                                                     \
@@ -1190,7 +1189,7 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
         memcpy(res + 64, h_ctl, sizeof h_ctl);                  // (a pinned source that stays valid until the copy has run)
         VS_RET(hipMemcpyAsync(b + o_ctl, res + 64, sizeof h_ctl, hipMemcpyHostToDevice, st));
         r = snpgpu_enqueue_varscan(ctx, d_file, nbytes, params, (snpgpu_varscan_site *)(b + o_rec), capacity, (uint32_t *)(b + o_ctl + 8), (uint64_t *)(b + o_ctl),
-                                   b + o_var, halo_cls[f]);
+                                   b + o_var);
         if (r) return r;
         VS_RET(hipMemcpyAsync(res, b + o_ctl, 32, hipMemcpyDeviceToHost, st));
         if (capacity) VS_RET(hipMemcpyAsync(res + r_rec, b + o_rec, sizeof(snpgpu_varscan_site) * (size_t)capacity, hipMemcpyDeviceToHost, st));
@@ -1321,7 +1320,6 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
                 }
                 if (place[f].block != ~0u) store->files[first + f].d = dest(f);
                 if (jb.len) {
-                    if (jb.off == 0 && params) halo_cls[f] = (int8_t)snpgpu_varscan_halo_class((const uint8_t *)p->staging[rd.buf], jb.len < 16384 ? jb.len : 16384);
                     hipStream_t cs = (issued & 1) ? p->copy_stream2 : p->copy_stream;
                     hipError_t e = hipMemcpyAsync(dest(f) + jb.off, p->staging[rd.buf], jb.len, hipMemcpyHostToDevice, cs);
                     if (e == hipSuccess) e = hipEventRecord(p->ev_copy[rd.buf], cs);
@@ -1404,7 +1402,6 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
                 if (sh.job_err[j] && s.rc == SNPGPU_OK) s.rc = SNPGPU_E_IO;
                 hipStream_t cs = (j & 1) ? p->copy_stream2 : p->copy_stream;
                 hipError_t e = hipSuccess;
-                if (jb.len && jb.off == 0 && params) halo_cls[f] = (int8_t)snpgpu_varscan_halo_class((const uint8_t *)p->staging[(j - JA) % R], jb.len < 16384 ? jb.len : 16384);
                 if (jb.len) e = hipMemcpyAsync(d_file + jb.off, p->staging[(j - JA) % R], jb.len, hipMemcpyHostToDevice, cs);
                 if (store) store->h2d_bytes += jb.len;
                 if (e == hipSuccess) e = hipEventRecord(p->ev_copy[(j - JA) % R], cs);

@@ -948,7 +948,6 @@ static inline uint32_t varscan_cand_cap(uint64_t nbytes) {
 size_t snpgpu_varscan_scratch_bytes(uint64_t nbytes) {
     return (size_t)varscan_cand_cap(nbytes) * 16u + 4u * VARSCAN_MAX_WAVES + 1024;
 }
-int snpgpu_varscan_halo_class(const uint8_t *, uint64_t) { return 0; }               // (rounds 3-4 chose a window geometry by the mean line length; one form serves all now)
 
 // Deal the waves of a launch to its files in proportion to their sizes (every file at least one, every wave at least four tiles)
 // and launch the scan and its epilogue.  `h_files`: abase / lo / hi / out / capacity / ctl / status set by the caller; n_tiles,
@@ -1039,7 +1038,7 @@ static inline void varscan_file_coords(VsFile &f, const uint8_t *d_buf, uint64_t
 // kernel); d_status: one u64 preset to UINT64_MAX (becomes the offset of the first malformed line); d_scratch:
 // snpgpu_varscan_scratch_bytes(nbytes) bytes, 16-byte aligned.
 int snpgpu_enqueue_varscan(snpgpu_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, const snpgpu_varscan_params *prm, snpgpu_varscan_site *d_sites,
-                           uint32_t capacity, uint32_t *d_ctl, uint64_t *d_status, void *d_scratch, int /*halo_class*/) {
+                           uint32_t capacity, uint32_t *d_ctl, uint64_t *d_status, void *d_scratch) {
     if (nbytes == 0) return SNPGPU_OK;
     if (nbytes >> 47) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "pileup too large");
     const uint32_t cand_cap = varscan_cand_cap(nbytes);
