@@ -633,6 +633,16 @@ __global__ __launch_bounds__(768) void k_varscan_scan(const VsFile *__restrict__
         else { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dma_mask = 0; }
         dma_mask &= ~(1u << slot);
         __builtin_amdgcn_wave_barrier();
+#if defined(SNPGPU_TUNING) && defined(VS_EXP) && VS_EXP >= 2         // (experiment builds: the stream alone — wait, touch, request)
+        {
+            lines_seen += ((const uint32_t *)(ring + dbase))[lane] & 1u;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (k + 2 <= t_last && request(k + 2, slot)) dma_mask |= 1u << slot;
+            slot ^= 1u;
+            continue;
+        }
+#endif
         // ---- A: my 64 bytes of tile k -> terminator / TAB / letter masks ---------------------------------------------------
         const uint4 *src = (const uint4 *)(ring + dbase) + 4u * lane;
         uint64_t m_nl, m_tab, m_let, cur_lf = 0, cur_cr = 0;
@@ -748,6 +758,9 @@ __global__ __launch_bounds__(768) void k_varscan_scan(const VsFile *__restrict__
             if (above) nxt = got;
         }
         uint64_t pend = own ? T : 0ull;
+#if defined(SNPGPU_TUNING) && defined(VS_EXP) && VS_EXP >= 1         // (experiment builds: what the rounds of phase B cost — they are left out)
+        pend = 0; c_valid = 0; lines_seen += (uint32_t)__popcll(T);
+#endif
         uint32_t n_valid = 0, n_pack = 0, n_p0 = 0;                                     // the line this tile hands on
         // One line per lane and round, in straight-line code: every test lands in a flag, every LDS read is issued whether its
         // line needs it or not (a read outside the wave's LDS returns nothing and costs nothing), so a round is three LDS
