@@ -1,6 +1,7 @@
 """call_sites subcommand: reads.all.pileup and var.flt.vcf for one sample.
 
-Host mirror of snppipeline/call_sites.py:15-111.  The pileup is still made by ``samtools mpileup`` (an external tool on both
+Host side of snppipeline/call_sites.py:15-111; the prologue of ``call_sites`` (input checks, the BAM's name, the samtools command
+line, the freshness tests and every message) is the CLI contract and follows call_sites.py:40-92 statement by statement.  The pileup is still made by ``samtools mpileup`` (an external tool on both
 sides, untouched).  The site calling has two routes, chosen by ``SNPGPU_SITE_CALLING`` (or ``--siteCalling`` of the batch
 subcommands):
 

@@ -1,6 +1,8 @@
 """snp_matrix subcommand: concatenate the per-sample consensus FASTA files into snpma.fasta.
 
-Host mirror of snppipeline/snp_matrix.py:13-119 (a byte copy in sorted sample-directory order; no arithmetic).
+Host side of snppipeline/snp_matrix.py:13-119 (a byte copy in sorted sample-directory order; no arithmetic).
+``create_snp_matrix`` is the CLI contract of the step: its input checks, their order, the messages and the freshness test are
+those of snp_matrix.py:68-110, said the same way; the copy (whole files, bytes) is this build's own.
 ``read_matrix`` additionally returns the sequences as a samples x sites byte matrix for the distance kernel.
 """
 from __future__ import print_function

@@ -1,8 +1,12 @@
 """snp_reference subcommand: the reference bases at the snplist positions as a FASTA file.
 
-Host mirror of snppipeline/snp_reference.py:12-77 and utils.write_reference_snp_file (utils.py:1091-1110).  There is
+Host side of snppipeline/snp_reference.py:12-77 and utils.write_reference_snp_file (utils.py:1091-1110).  There is
 no arithmetic in this step — one byte gathered per site — so it stays on the host; it is here because
 referenceSNP.fasta is one of the top-level outputs the regression suite diffs.
+
+``create_snp_reference_seq`` is the CLI contract of the step — which inputs are checked, in which order, with which messages, and
+the freshness test — and therefore says the same things in the same order as snp_reference.py:50-77 does; the gather itself
+(``_gather_plain``, ``read_fasta_sequences``) is this build's own.
 """
 from __future__ import absolute_import
 
@@ -89,19 +93,14 @@ def create_snp_reference_seq(args):
     """args: referenceFile, snpListFile, snpRefFile, forceFlag (snp_reference.py:12-77)."""
     utils.print_log_header()
     utils.print_arguments(args)
-    reference_file = args.referenceFile
-    snp_list_file_path = args.snpListFile
-    snp_ref_seq_path = args.snpRefFile
-
-    bad_file_count = utils.verify_existing_input_files("Snplist file", [snp_list_file_path])
-    if bad_file_count > 0:
-        utils.global_error("Error: cannot create the snp reference sequence without the snplist file.")
-    bad_file_count = utils.verify_non_empty_input_files("Reference file", [reference_file])
-    if bad_file_count > 0:
-        utils.global_error("Error: cannot create the snp reference sequence without the reference fasta file.")
-
-    source_files = [reference_file, snp_list_file_path]
-    if args.forceFlag or utils.target_needs_rebuild(source_files, snp_ref_seq_path):
-        write_reference_snp_file(reference_file, snp_list_file_path, snp_ref_seq_path)
-    else:
-        verbose_print("SNP reference sequence %s has already been freshly built.  Use the -f option to force a rebuild." % snp_ref_seq_path)
+    # the step's inputs in the order the reference checks them: (how, label in the log, path, what the step says when it is bad)
+    inputs = ((utils.verify_existing_input_files, "Snplist file", args.snpListFile, "snplist file"),
+              (utils.verify_non_empty_input_files, "Reference file", args.referenceFile, "reference fasta file"))
+    for verify, label, path, what in inputs:
+        if verify(label, [path]) > 0:
+            utils.global_error("Error: cannot create the snp reference sequence without the %s." % what)
+    target = args.snpRefFile
+    if not args.forceFlag and not utils.target_needs_rebuild([args.referenceFile, args.snpListFile], target):
+        verbose_print("SNP reference sequence %s has already been freshly built.  Use the -f option to force a rebuild." % target)
+        return
+    write_reference_snp_file(args.referenceFile, args.snpListFile, target)
