@@ -327,10 +327,11 @@ __device__ __forceinline__ bool varscan_parse_lds(const uint32_t *lds32, uint32_
 // in LDS and re-classified a halo of 6-100 % of every tile); a launch serves any number of pileups; a wave walks its own
 // candidates when its tiles are done, so a file costs one launch and a fixed-size epilogue, not three dependent ones.
 //
-// A wave owns a contiguous run of 4 KiB tiles of ONE file and a ring of three tile slots in LDS: tile k+1 streams into its slot with
-// LDS-DMA (global_load_lds_dwordx4, four wave instructions, no register round trip, counted s_waitcnt) while tile k is classified
-// and the lines that START in tile k-1 are looked at — by then their ends (in tile k-1 or k) are known, so nothing is classified
-// twice and a line of up to 4 KiB needs no special case.  Per tile:
+// A wave owns a contiguous run of 4 KiB tiles of ONE file and two tile slots in LDS: tile k+1 streams into its slot with LDS-DMA
+// (global_load_lds_dwordx4, four wave instructions, no register round trip, counted s_waitcnt) while tile k is classified and its lines
+// are looked at.  In front of each slot lie the last 64 bytes of the tile before it (a line whose first columns straddle the tile
+// edge is read in one piece); the bit strings and running counts below cover both slots, so a line that started in tile k-1 and ends
+// in tile k is answered from them and nothing is classified twice.  Per tile:
 //   A  a lane owns 64 CONTIGUOUS bytes (four conflict-free ds_read_b128, chunk order i ^ ((lane >> 2) & 3)) and classifies them with
 //      SWAR adds on 8 bytes at a time into three 64-bit masks: terminators (bytes 0x0A..0x0D: w + 0x76 carries into bit 7, w + 0x72
 //      does not), TABs (w + 0x77 carries, w + 0x76 does not: the sums are shared), "letters" (bit 6 set, bit 3 clear: every
@@ -340,7 +341,8 @@ __device__ __forceinline__ bool varscan_parse_lds(const uint32_t *lds32, uint32_
 //      the first that is not LF (CR, VT, FF) switches the wave to exact LF / CR masks and Java's readLine() rules for good.
 //   B  one lane per line, one line per lane and round (30x: one round per tile): the line behind the lane's lowest terminator
 //      left; it ends at the lane's next terminator, else at the first one of the next lane that has any (one ballot, one
-//      ds_bpermute), else at the first one of tile k.  The lane answers in constant time from the strings: the first four TABs
+//      ds_bpermute), else in the next tile: then what its first columns said travels there in scalars, and the first lane without
+//      a line of its own takes it.  The lane answers in constant time from the strings: the first four TABs
 //      (find-first-set over 32, for long contig names 64, bits), the depth (one unaligned load, SWAR digit test, v_dot4 decimal),
 //      the fifth TAB where a quality column of exactly `depth` bytes puts it, five TABs in all and the letters of the read-base
 //      column (differences of running counts).  A well-formed ("plain") line with fewer letters than min-reads2 cannot call
