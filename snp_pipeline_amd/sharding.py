@@ -40,9 +40,16 @@ def use_abi_comm(device, rank=None, world=None, unique_id=None, selftest=True):
         if dist.is_initialized() and world > 1:
             dist.broadcast_object_list(box, src=0)
         unique_id = box[0]
-    device.comm_init(rank, world, unique_id)
-    if selftest and world > 1:
-        why = _selftest(device, int(rank), int(world))
+    why = None
+    try:
+        device.comm_init(rank, world, unique_id)
+    except Exception as exc:                                     # (RCCL said no on this rank: the others must hear of it)
+        if world <= 1 or not dist.is_initialized():
+            raise
+        why = "snpgpu_comm_init: %s" % exc
+    if world > 1 and (selftest or why is not None):
+        if why is None:
+            why = _selftest(device, int(rank), int(world))
         every_ok = why is None
         if dist.is_initialized():
             flag = torch.tensor([1 if every_ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
