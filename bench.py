@@ -60,7 +60,7 @@ def parse_args():
     ap.add_argument("--skip-call-variants", action="store_true", help="leave out the with-counts / strict / --vcfAllPos rows")
     ap.add_argument("--site-files", type=int, default=16, help="pileup files for the site_calling row (0 = skip)")
     ap.add_argument("--skip-aux", action="store_true", help="skip the device-copy ceiling and the K3/K4 timings")
-    ap.add_argument("--shape-samples", type=int, default=64, help="samples per launch of the scan_shapes rows (0 = skip)")
+    ap.add_argument("--shape-samples", type=int, default=125, help="samples per launch of the scan_shapes rows, as in the headline's shard (0 = skip)")
     ap.add_argument("--skip-cpu-parallel", action="store_true", help="skip the one-process-per-sample CPU baseline")
     ap.add_argument("--e2e-files", type=int, default=16, help="pileup files streamed from the page cache for the end_to_end row (0 = skip)")
     ap.add_argument("--pipeline-files", type=int, default=125, help="samples of the pipeline_from_files row (0 = skip)")
@@ -709,7 +709,8 @@ def side_row(fn, *a):
 
 def scan_shapes(d, L, dev, ref, alt, G, pos, n_samples):
     """The pileup-scan kernel on the shapes where it is weakest, measured the same way as the headline
-    (HIP events around the launches of one batched call, 3 launches after a warm-up): shallow pileups (more, shorter lines per
+    (HIP events around the launches of one batched call, 3 launches after a warm-up, as many samples per launch as the headline's
+    shard has — a launch of a quarter of the bytes pays the same ramp and tail and reads 2-3 points lower): shallow pileups (more, shorter lines per
     tile), a deep one, CR LF line ends, and samples of many short contigs with long names.  Each entry: bytes per launch,
     GB/s, fraction of the HBM peak."""
     import torch
@@ -742,7 +743,7 @@ def scan_shapes(d, L, dev, ref, alt, G, pos, n_samples):
                 "lines_per_sample": int(st[0, 1]), "bases": bases}
 
     ss1 = d.siteset([(b"synth_chr1", int(p)) for p in pos], [L.SITE_IN_SNPLIST] * S)
-    for label, depth, B in (("depth_8x", 8.0, n_samples), ("depth_15x", 15.0, n_samples), ("depth_100x", 100.0, max(1, n_samples // 4))):
+    for label, depth, B in (("depth_8x", 8.0, n_samples), ("depth_15x", 15.0, n_samples), ("depth_100x", 100.0, max(1, n_samples * 3 // 8))):   # (100x: the headline's bytes)
         sizes = [d.synth_pileup_dev(3, i, G, ref.data_ptr(), alt.data_ptr(), 0, 0, mean_depth=depth) for i in range(B)]
         offs = np.concatenate(([0], np.cumsum([(n + 255) // 256 * 256 for n in sizes])))
         buf = torch.empty(int(offs[-1]) + 8192, dtype=torch.uint8, device="cuda")
@@ -764,7 +765,7 @@ def scan_shapes(d, L, dev, ref, alt, G, pos, n_samples):
     crlf = torch.full((n + int(before[-1]),), 13, dtype=torch.uint8, device="cuda")
     crlf[torch.arange(n, device="cuda") + before] = lf                           # byte i moves behind the '\r's of the '\n's up to and including it
     del before, is_nl
-    B = max(1, n_samples // 2)
+    B = n_samples
     res = {}
     for label, one in (("lf_same_sample", lf), ("cr_lf", crlf)):
         step = (one.numel() + 255) // 256 * 256
@@ -790,7 +791,7 @@ def scan_shapes(d, L, dev, ref, alt, G, pos, n_samples):
     altc = torch.from_numpy(alt_h).cuda()
     names = [("NODE_%d_len_%d" % (c + 1, Gc)).encode() if c % 2 else ("ctg%03d" % c).encode() for c in range(C)]
     keys = [(names[c], int(p)) for c in range(C) if c % 5 != 3 for p in posc]
-    B = max(1, n_samples // 2)
+    B = n_samples
     piece = [[d.synth_pileup_dev(3, s * C + c, Gc, refc.data_ptr(), altc.data_ptr(), 0, 0, contig=names[c]) for c in range(C)] for s in range(B)]
     total = sum(sum(x) for x in piece)
     buf = torch.empty(total + 8192, dtype=torch.uint8, device="cuda")

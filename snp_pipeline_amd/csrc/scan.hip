@@ -44,6 +44,8 @@
 #define SCAN_DMA_PER_TILE ((SCAN_WTILE_CHUNKS + 63) / 64)       // global_load_lds wave-instructions per tile
 #define SCAN_LIST_CAP 192                    // line starts held in LDS per pass (a tile with more makes extra passes)
 #define SCAN_HINT_WORDS 12                   // contig names up to 44 bytes take the fast compare
+#define SCAN_HIT_CAP 128                     // matched lines a wave collects in LDS before it publishes them (what LDS is left at sixteen waves per CU)
+#define SCAN_HIT_FLUSH 48                    // ... published at the top of the next tile once there are this many
 
 struct ScanArgs {
     const SampleDev *samples; // one launch covers a batch of pileups; each wave works inside exactly one of them
@@ -87,6 +89,8 @@ struct WaveSlots {
     uint32_t hint_w[SCAN_HINT_WORDS];        // the wave's current contig name, zero padded
     uint32_t hint_m[SCAN_HINT_WORDS];        // byte masks of the name (zero past its end)
     uint32_t lay[16];                        // scan_layout() of the current (name, digit count)
+    uint32_t hit_site[SCAN_HIT_CAP];         // matched lines not yet published: the site ...
+    uint32_t hit_off[SCAN_HIT_CAP];          // ... and the line's file offset + 1, counted from hit_base
 };
 struct ScanShared {                          // dynamic LDS: the table, then one WaveSlots per wave of the workgroup
     uint4 digit_mask[16];                    // [nd]: keeps the last nd bytes of window bytes 4..14
@@ -305,6 +309,13 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     bool crlf_mode = false;                                   // (wave-uniform, sticky) the file has "\r\n" line ends
     const uint32_t *bitmap = ss.bitmap, *rank = ss.rank;
     uint32_t hits = 0, lines_seen = 0, any_hi = 0;
+    // Matched lines are published with atomicMax (the last duplicate of a position wins, whichever wave sees it).  An atomic issued
+    // while a tile is parsed sits between the DMA requests of the next two tiles in the wave's memory queue, and the counted wait at
+    // the top of the next tile cannot tell it from a request: the wave stood there until the atomic had been to memory and back —
+    // 4-7 % of the launch, more or less by where site_line happened to lie (round 5: the "placement modes").  So the matches collect
+    // in LDS and go out together right AFTER a top-of-tile wait: by the next one they have had a whole tile's time.
+    uint32_t n_hit = 0;                                       // (wave-uniform) entries of ws.hit_site / ws.hit_off
+    uint64_t hit_base = 0;                                    // (wave-uniform) what their offsets are counted from
     unsigned long long depth_acc = 0;
     unsigned long long t_a = 0, t_b = 0, t_c = 0, t_s = 0, t_i = 0, t_mark = kTime == 2 ? __builtin_readcyclecounter() : 0;
     constexpr bool kStamp = kTime == 1 || kTime == 2;
@@ -337,6 +348,11 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
     const uint64_t r_lo = __builtin_amdgcn_readfirstlane(a.samples[si].tile_lo);
     const uint64_t n_tiles = __builtin_amdgcn_readfirstlane(a.samples[si].tile_hi) - r_lo;
     auto interior = [&](uint64_t tt) { uint64_t x0 = tt * SCAN_TILE; return x0 >= f.lo + 16 && x0 + SCAN_TILE + SCAN_HALO <= f.hi; };
+    auto flush_hits = [&]() {
+        for (uint32_t i = lane; i < n_hit; i += 64)
+            atomicMax((unsigned long long *)&f.site_line[ws.hit_site[i]], (unsigned long long)(hit_base + ws.hit_off[i]));
+        n_hit = 0;
+    };
     // request tile tt into slot `buf`; returns the number of DMA wave-instructions now in flight for it (0: staged synchronously)
     auto request = [&](uint64_t tt, int buf) -> uint32_t {
         if (interior(tt)) {
@@ -487,6 +503,8 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
         else if (later == 2 || SCAN_NBUF < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * SCAN_DMA_PER_TILE) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * SCAN_DMA_PER_TILE) : "memory");
         __builtin_amdgcn_wave_barrier();
+        // the matches so far go out here, a whole tile's time before the next counted wait (and before their offsets outgrow 32 bits)
+        if (n_hit >= SCAN_HIT_FLUSH || (n_hit && tt * SCAN_TILE - f.lo - hit_base > 0x7FFFFFFFull)) flush_hits();
         WTICK(t_a);
         {
             const uint64_t t0 = tt * SCAN_TILE;
@@ -809,9 +827,21 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             if (!got) word = 0;
                             const uint32_t shf = (uint32_t)(bit & 31);
                             if ((word >> shf) & 1u) {
-                                const uint32_t site = rk + __popc(word & ((1u << shf) - 1u));
-                                atomicMax((unsigned long long *)&f.site_line[site], (unsigned long long)off1);
                                 ++hits;
+                            }
+                            {
+                                const bool hit = ((word >> shf) & 1u) != 0;
+                                const uint64_t hm = __ballot(hit);
+                                if (hm) {                                                // (wave-uniform)
+                                    if (n_hit + 64u > SCAN_HIT_CAP) flush_hits();       // (only where nearly every line is a site)
+                                    if (n_hit == 0) hit_base = t0 - f.lo - 2 * SCAN_TILE;   // (modulo 2^64; every offset of this tile and the later ones lies above it)
+                                    const uint32_t idx = n_hit + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+                                    if (hit) {
+                                        ws.hit_site[idx] = rk + __popc(word & ((1u << shf) - 1u));
+                                        ws.hit_off[idx] = (uint32_t)(off1 - hit_base);
+                                    }
+                                    n_hit += (uint32_t)__popcll(hm);
+                                }
                             }
                             if (!fast_round) {                                           // the general path calibrates the digit count
                                 const uint64_t okm = __ballot(active && nd_seen != 0 && tabs && !big);   // lines separated otherwise never calibrate it
@@ -899,6 +929,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
         rec[3] = t_a; rec[4] = t_b; rec[5] = t_c; rec[6] = kTime == 2 ? t_s : rt_prologue; rec[7] = kTime == 2 ? t_i : rt_first;
     }
 #undef WTICK
+    flush_hits();
     // a byte >= 0x80 anywhere in this wave's share of the file (checked once: the answers are void anyway)
     if (__ballot((any_hi & 0x80808080u) != 0) && lane == 0) report_scan_error(f.status, 0, SCAN_ERR_NON_ASCII);
     for (int o = 32; o; o >>= 1) { hits += __shfl_xor(hits, o); lines_seen += __shfl_xor(lines_seen, o); }

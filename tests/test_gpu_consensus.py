@@ -750,6 +750,30 @@ def test_many_short_lines_per_lane_of_the_scan(d, seed):
     assert res.n_lines == len(out) and res.n_matched == len(set(sites))
 
 
+@pytest.mark.parametrize("seed", [5, 6])
+def test_every_line_a_site_and_positions_repeated_far_apart(d, seed):
+    """The scan collects its matched lines in LDS (128 per wave) and publishes them with atomicMax a tile later.  A file whose
+    every line is a site fills that buffer inside one tile (it is emptied in the middle of a round then), and a position that
+    comes back tens of tiles later — in another wave's run — must still end with its LAST line (pileup.py:422-429 keeps the last
+    record of a position): whatever the order in which the waves publish."""
+    from tests.gpu_util import check_against_oracle
+    rng = random.Random(seed)
+    out, pos = [], 0
+    while sum(len(x) for x in out) < 40 * 4096:
+        pos += 1
+        dp = rng.randrange(1, 4) if rng.random() < 0.8 else rng.randrange(10, 60)
+        out.append(b"c\t%d\t%s\t%d\t%s\t%s\n" % (pos, bytes([rng.choice(b"ACGT")]), dp, bytes(rng.choice(b".,ACgt") for _ in range(dp)), b"I" * dp))
+    n_first = len(out)
+    for _ in range(300):                                         # old positions again, with other bases, far behind their first lines
+        q = rng.randrange(1, pos + 1)
+        dp = rng.randrange(3, 9)
+        out.append(b"c\t%d\tA\t%d\t%s\t%s\n" % (q, dp, bytes(rng.choice(b"CGT") for _ in range(dp)), b"I" * dp))
+    data = b"".join(out)
+    sites = [(b"c", q) for q in range(1, pos + 1)]
+    res = check_against_oracle(d, data, sites, rng.sample(sites, 50), po.CallerParams(0, 0.6, 1, 0, 0.0))
+    assert res.n_lines == len(out) and res.n_matched == len(out) and n_first == pos
+
+
 @pytest.mark.parametrize("order", ["shuffled", "blocks", "zero_padded"])
 def test_positions_whose_top_digits_keep_changing(d, order):
     """The one-window parse of the scan knows all but the last four digits of a position in advance; a round with a line that differs
