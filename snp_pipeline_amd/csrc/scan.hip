@@ -10,8 +10,10 @@
 // requests tile k+2 with LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B straight into LDS, no VGPR round trip) as
 // soon as tile k is parsed, and waits for its own DMA with a counted s_waitcnt — no workgroup barrier, no flags, no
 // polling.  The DMA goes through inline asm on purpose: hipcc orders every LDS read behind a *tracked* LDS-DMA with
-// vmcnt(0), which would serialise fetch and parse; the steady-state parse issues no other vector-memory load (the
-// site bitmap is probed through a register window), so the explicit counted wait is the only one on the path.
+// vmcnt(0), which would serialise fetch and parse; the steady-state parse issues no other vector-memory operation (the
+// site bitmap is probed through a register window; matched lines collect in LDS and their atomics go out right after a
+// top-of-tile wait — vmcnt counts loads and atomics alike, and an atomic issued in the middle of a tile made the next counted wait
+// stand until it had been to memory and back), so the explicit counted wait is the only one on the path.
 // Per tile:
 //   B  each lane scans the four 16-byte chunks of ITS 64 contiguous bytes for bytes in 0x0A..0x0D (SWAR, v_dot4_u32_u8 gathers byte
 //      flags into bits; the chunks are read in an order that keeps ds_read_b128 free of bank conflicts); two flagged neighbours
