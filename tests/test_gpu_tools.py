@@ -25,6 +25,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     (["scan_crlf.py"], ""),
     (["scan_sweep.py", "3", "20", "", "OVERSUB=1"], "GB/s"),
     (["scan_realloc.py", "3", "20", "2"], "round 1:"),
+    (["scan_placement.py", "20", "3"], "ctx 0, input 6"),
+    (["scan_batch_sizes.py", "20", "5"], "all again"),
 ])
 def test_tool_runs_at_toy_size(argv, expect, tmp_path):
     env = dict(os.environ, TMPDIR=str(tmp_path), SWEEP_GENOME="60000")
