@@ -505,8 +505,8 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
         else if (later == 2 || SCAN_NBUF < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * SCAN_DMA_PER_TILE) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * SCAN_DMA_PER_TILE) : "memory");
         __builtin_amdgcn_wave_barrier();
-        // the matches so far go out here, a whole tile's time before the next counted wait (and before their offsets outgrow 32 bits)
-        if (n_hit >= SCAN_HIT_FLUSH || (n_hit && tt * SCAN_TILE - f.lo - hit_base > 0x7FFFFFFFull)) flush_hits();
+        // the matches so far go out here, a whole tile's time before the next counted wait (and long before their offsets outgrow 32 bits)
+        if (n_hit >= SCAN_HIT_FLUSH || ((uint32_t)tt & 0xFFFFu) == 0u) flush_hits();    // (every 65 536 tiles at the latest: 256 MiB of offsets)
         WTICK(t_a);
         {
             const uint64_t t0 = tt * SCAN_TILE;
@@ -828,11 +828,9 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             }
                             if (!got) word = 0;
                             const uint32_t shf = (uint32_t)(bit & 31);
-                            if ((word >> shf) & 1u) {
-                                ++hits;
-                            }
                             {
                                 const bool hit = ((word >> shf) & 1u) != 0;
+                                hits += hit ? 1u : 0u;
                                 const uint64_t hm = __ballot(hit);
                                 if (hm) {                                                // (wave-uniform)
                                     if (n_hit + 64u > SCAN_HIT_CAP) flush_hits();       // (only where nearly every line is a site)
