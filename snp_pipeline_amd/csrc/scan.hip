@@ -47,7 +47,9 @@
 #define SCAN_LIST_CAP 192                    // line starts held in LDS per pass (a tile with more makes extra passes)
 #define SCAN_HINT_WORDS 12                   // contig names up to 44 bytes take the fast compare
 #define SCAN_HIT_CAP 128                     // matched lines a wave collects in LDS before it publishes them (what LDS is left at sixteen waves per CU)
+#ifndef SCAN_HIT_FLUSH
 #define SCAN_HIT_FLUSH 48                    // ... published at the top of the next tile once there are this many
+#endif
 
 struct ScanArgs {
     const SampleDev *samples; // one launch covers a batch of pileups; each wave works inside exactly one of them
@@ -1152,7 +1154,7 @@ struct ScanConfig {
     int blocks_per_cu = 1, mode = 0, waves = SCAN_NBUF == 2 ? 16 : 12, oversub = 0;   // oversub 0: chosen by the launch's length
     int oversub_min = 1500;                                 // (tuning) tiles per resident wave from which a forced oversub applies
     int share[4] = {329, 282, 223, 169};                    // measured: 1 / (finish time with equal shares), oldest first (30x)
-    int share_dense[4] = {290, 266, 238, 206};              // ... at 8x (tools/scan_sweep.py)
+    int share_dense[4] = {320, 280, 225, 175};              // ... at 8x (tools/scan_sweep.py; {290, 266, 238, 206} while the atomics of the matches still stood in the waves' way: round 5)
     bool ready = false;
 };
 ScanConfig &scan_config() {
