@@ -100,6 +100,9 @@ struct ScanShared {                          // dynamic LDS: the table, then one
     uint4 digit_mask[16];                    // [nd]: keeps the last nd bytes of window bytes 4..14
     WaveSlots w[1];
 };
+#if SCAN_NBUF == 2
+static_assert(sizeof(ScanShared) + 15 * sizeof(WaveSlots) <= 160 * 1024, "sixteen waves of k_scan_wave no longer fit a CU's LDS");
+#endif
 
 __device__ __forceinline__ void report_scan_error(uint64_t *status, uint64_t file_off, uint32_t code) {
     atomicMin((unsigned long long *)&status[0], (unsigned long long)(((file_off + 1) << 8) | code));

@@ -368,6 +368,7 @@ constexpr uint32_t VS_W_PLAIN = 1u << 31, VS_W_LONG = 1u << 30;
 #define VS_STR_PAD 4u                         // ... and room for the reads that run over its end (their bits are masked away)
 #define VS_CAND_LOCAL 136u                    // candidate entries a wave holds in LDS (100x: a dozen per wave; what LDS is left at twelve waves per CU)
 constexpr uint32_t VS_LDS_WAVE = VS_DATA + 3u * (VS_STR_WORDS + VS_STR_PAD) * 4u + VS_CAND_LOCAL * 16u;   // 13 616 bytes: twelve waves per CU (163 392 of 163 840 bytes)
+static_assert(12u * VS_LDS_WAVE <= 160u * 1024u && VS_LDS_WAVE % 16u == 0u, "twelve waves of k_varscan_scan no longer fit a CU's LDS");
 #define VS_NONE 0xFFFFFFFFu
 
 // One pileup of a launch: an entry of the device table, or (a launch over one file) a kernel argument.
