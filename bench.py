@@ -411,6 +411,19 @@ def call_variants(d, ss, prm, pile, offs, sizes, S, dev, torch, pos):
     out["strict"] = row(ms, scan_ms, call_ms, B * S, matched, int(matched * mean_line), 2 * B * S,
                         "%d samples x %d sites, caller -q 15 -c 0.9 -D 5 -d 2 -b 0.1 (SURVEY 8d), no count records" % (B, S))
     out["strict"]["sites_checked_against_oracle"] = len(sub)
+    # HBM traffic of the call kernels from the committed PMC passes of the same shape (rocprofv3 cannot run inside this process)
+    try:
+        with open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "call_traffic.json")) as f:
+            ct = json.load(f)
+        for key in ("call_with_counts", "strict"):
+            t, r = ct.get(key) or {}, out[key]["roofline"]
+            if t.get("algorithmic_bytes") and abs(t["algorithmic_bytes"] - r["algorithmic_bytes"]) <= r["algorithmic_bytes"] // 50:
+                r["traffic"] = t["traffic_bytes_per_step"]
+                r["traffic_over_algorithmic"] = t["traffic_over_algorithmic"]
+                r["traffic_source"] = "profiles/%s/call_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % PROFILE_ROUND
+                r["traffic_note"] = ct.get("note")
+    except (OSError, ValueError):
+        pass
 
     # ---- every line of one sample ---------------------------------------------------------------------------------------------
     base_dir = _scratch_dir(lens[0] + (64 << 20))

@@ -17,7 +17,14 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python $ro
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python $root/bench.py $pmc > /dev/null 2> "$out/pmc_write.err"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d "$out/pmc_sq" -- python $root/bench.py $pmc > /dev/null 2> "$out/pmc_sq.err"
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d "$out/pmc_sq2" -- python $root/bench.py $pmc > /dev/null 2> "$out/pmc_sq2.err"
+# K2 with per-site count records (the call_variants rows): FETCH_SIZE / WRITE_SIZE of k_call_lanes<..., true>
+pmc_cv="--steps 1 --warmup 1 --cpu-samples 0 --skip-secondary --skip-aux --e2e-files 0 --site-files 0 --pipeline-files 0 --shape-samples 0"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch_cv" -- python $root/bench.py $pmc_cv > /dev/null 2> "$out/pmc_fetch_cv.err"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write_cv" -- python $root/bench.py $pmc_cv > /dev/null 2> "$out/pmc_write_cv.err"
 cd "$root"
+python tools/pmc_summary.py "$out/pmc_fetch_cv" | grep -A1 "k_call" > "$out/pmc_fetch_size_call_variants_summary.txt"
+python tools/pmc_summary.py "$out/pmc_write_cv" | grep -A1 "k_call" > "$out/pmc_write_size_call_variants_summary.txt"
+rm -rf "$out/pmc_fetch_cv" "$out/pmc_write_cv"
 # phase-1 site calling on a resident sample (the kernels of the pipeline row's ingest): trace averages at three depths + SQ counters at 30x
 VS_PMC=30 bash tools/varscan_profile.sh 30 100 8 > "$out/varscan_kernels.txt" 2>&1
 python tools/pmc_summary.py "$out/pmc_fetch" > "$out/pmc_fetch_size_summary.txt"
