@@ -612,6 +612,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_call_lanes(CallArgs a) {
         };
         stage_half(0, has);
         __builtin_amdgcn_wave_barrier();                       // LDS operations of a wave execute in order
+#if defined(SNPGPU_TUNING) && defined(CALL_EXP) && CALL_EXP >= 2      // (... the staging alone)
+        if (valid) a.out_filters[site] = (uint8_t)slot[0];
+        continue;
+#endif
 
         // ---- tokenise (pileup.py:206): per-lane 256-bit masks of the str.split() separators and of the terminator
         //      candidates, built 4 bytes per step with SWAR compares; the field boundaries are bit scans on the masks ----
@@ -816,7 +820,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_call_lanes(CallArgs a) {
                 uint32_t kept = 0;
                 uint32_t qd = qs >> 2, qw = 0, qw_next = 0;
                 if (pair_any) { qw = slot[qd & (LANES_WIN / 4 - 1u)]; qw_next = slot[(qd + 1) & (LANES_WIN / 4 - 1u)]; }
+#if defined(SNPGPU_TUNING) && defined(CALL_EXP) && CALL_EXP >= 1      // (experiment builds: what the phases of the lane kernel cost; the results are wrong)
+                for (uint32_t j = nd; j < nd; ++j) {
+#else
                 for (uint32_t j = 0; j < nd; ++j) {
+#endif
                     const uint32_t hi = slot[(bs >> 2) + j + 1];
                     const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
                     lo = hi;
