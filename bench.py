@@ -271,6 +271,15 @@ def site_calling(d, pile, offs, sizes, n_files):
         k_gbs = tot_b / (kb_avg * 1e-3) / 1e9 if kb_avg > 0 else 0.0
         k_avg = kb_avg / max(n_res, 1)
         k_n = kb_n
+        # a dozen samples per call (one launch each), the host's read-back between the calls: what the launches of the long call settle at
+        # once the clocks have (a VALU-bound kernel is clocked down a few milliseconds into a sustained run that follows an idle stretch)
+        n12 = min(12, n_res)
+        d.kernel_time_ms(3)
+        for _ in range(6):
+            d.varscan_batch_dev(ptrs[:n12], lens[:n12], dprm, capacity=8192)
+        k12_ms, _k12_n = d.kernel_time_ms(3)
+        k12_avg = k12_ms / 6.0 / max(n12, 1)
+        k12_gbs = (sum(lens[:n12]) / n12) / (k12_avg * 1e-3) / 1e9 if k12_avg > 0 else 0.0
         d.varscan_dev(ptrs[0], lens[0], dprm)
         d.kernel_time_ms(3)
         for _ in range(10):
@@ -294,6 +303,9 @@ def site_calling(d, pile, offs, sizes, n_files):
                          "launches_per_call": int(kb_n) // reps_b,
                          "algorithmic_bytes_per_file": int(sizes[0]), "avg_ms_per_file": k_avg,
                          "one_sample_per_launch": {"achieved": k1_gbs, "frac": k1_gbs / HBM_PEAK_GBS, "avg_ms_per_file": k1_avg, "files_timed": int(k1_n)},
+                         "twelve_samples_per_call": {"achieved": k12_gbs, "frac": k12_gbs / HBM_PEAK_GBS, "avg_ms_per_file": k12_avg, "calls_timed": 6,
+                                                     "note": "the same kernels, a dozen resident samples per call with the host's read-back in between: the launches of the "
+                                                             "long call slow down by up to a fifth a few milliseconds in and recover (profiles/r5/varscan_launch_trace.txt)"},
                          "traffic": (vs_traffic or {}).get("traffic_bytes_per_file"), "traffic_measured_on_bytes": (vs_traffic or {}).get("bytes"),
                          "traffic_over_algorithmic": (vs_traffic or {}).get("traffic_over_algorithmic"),
                          "traffic_source": ("profiles/%s/varscan_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % PROFILE_ROUND) if vs_traffic else None,
