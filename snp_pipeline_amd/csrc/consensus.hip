@@ -494,6 +494,7 @@ template <int kWin, int kWaves>
 struct LanesLds {
     uint32_t slot[kWaves][64 * (kWin / 4 + 1)];   // slot stride kWin/4 + 1 dwords: odd, conflict free
     uint8_t cls[256];           // byte -> rank of its symbol among "*ACGNT" (6: '.' / ',') | reverse << 3; 0xFF: other
+    uint4 hist[kWaves][64];     // per lane: sixteen byte counters, one per symbol class (bytes 0-7: forward strand, 8-15: reverse)
 };
 
 template <int kWin, int kWords, int kWaves, bool kCounts>
@@ -820,6 +821,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_call_lanes(CallArgs a) {
                 uint32_t kept = 0;
                 uint32_t qd = qs >> 2, qw = 0, qw_next = 0;
                 if (pair_any) { qw = slot[qd & (LANES_WIN / 4 - 1u)]; qw_next = slot[(qd + 1) & (LANES_WIN / 4 - 1u)]; }
+                // The counts live in LDS while the bases are walked: byte `cl` of the lane's sixteen takes one ds_add per read base
+                // (a lane only ever touches its own sixteen bytes; <= 255 bases per field: no carry between them) instead of two
+                // 64-bit shift-and-add pairs in registers — the loop is the kernel's largest block of vector instructions.
+                uint32_t *my_hist = (uint32_t *)&S.hist[wave][lane];
+                S.hist[wave][lane] = make_uint4(0u, 0u, 0u, 0u);
 #if defined(SNPGPU_TUNING) && defined(CALL_EXP) && CALL_EXP >= 1      // (experiment builds: what the phases of the lane kernel cost; the results are wrong)
                 for (uint32_t j = nd; j < nd; ++j) {
 #else
@@ -849,13 +855,17 @@ __global__ __launch_bounds__(kWaves * 64) void k_call_lanes(CallArgs a) {
                             kept += emit ? 1u : 0u;
                         }
                         const uint32_t cl = cl4[k];
-                        good += goodb ? 1u : 0u;
-                        punt = punt || (goodb && cl == 0xFFu);
-                        const uint32_t shf = 8u * (cl & 7u);
-                        cnt_f += (uint64_t)((goodb && cl < 8u) ? 1u : 0u) << shf;
-                        cnt_r += (uint64_t)((goodb && (cl & 0xF8u) == 8u) ? 1u : 0u) << shf;
+                        // (cl 0xFF — any other symbol — lands in byte 15, which no class uses: such a site is handed on below)
+                        (void)__hip_atomic_fetch_add(my_hist + ((cl >> 2) & 3u), (goodb ? 1u : 0u) << (8u * (cl & 3u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
                 }
+                const uint4 h = S.hist[wave][lane];
+                punt = punt || (h.w >> 24) != 0u;
+                cnt_f = (uint64_t)h.x | ((uint64_t)h.y << 32);
+                cnt_r = (uint64_t)h.z | ((uint64_t)(h.w & 0x00FFFFFFu) << 32);
+                // good bases = all that were counted (pileup.py:252)
+                good = __builtin_amdgcn_udot4(h.x, 0x01010101u, __builtin_amdgcn_udot4(h.y, 0x01010101u, 0u, false), false) +
+                       __builtin_amdgcn_udot4(h.z, 0x01010101u, __builtin_amdgcn_udot4(h.w, 0x00010101u, 0u, false), false);
             }
             // '.' and ',' stand for the reference base on the forward / reverse strand (pileup.py:255-258)
             const uint32_t ndot = (uint32_t)(cnt_f >> 48) & 0xFFu, ncom = (uint32_t)(cnt_r >> 48) & 0xFFu;
