@@ -498,7 +498,7 @@ struct LanesLds {
 };
 
 template <int kWin, int kWords, int kWaves, bool kCounts>
-__global__ __launch_bounds__(kWaves * 64) void k_call_lanes(CallArgs a) {
+__global__ __launch_bounds__(kWaves * 64, kWin == 128 ? 3 : 1) void k_call_lanes(CallArgs a) {
     constexpr int LANES_WIN = kWin;               // bytes staged per site, from the 16-byte aligned address at or below the line start
     constexpr int LANES_STRIDE = kWin / 4 + 1;    // dwords between slots
     constexpr int LANES_WAVES = kWaves;
