@@ -210,7 +210,9 @@ static inline void prim_inclusive_scan(hipStream_t st, const T *in, T *out, uint
 // A pre-pass notes whether the input is already sorted (VCF records usually are): the tile sort then copies straight
 // into the final buffer and the merge passes return at once.
 #define PRIM_SORT_TILE 2048
-#define PRIM_SORT_THREADS 256
+#ifndef PRIM_SORT_THREADS
+#define PRIM_SORT_THREADS 1024               // (a thread per compare-exchange of a bitonic stage; 256: the site union of a bench step 0.26 ms, 1024: 0.17)
+#endif
 
 template <typename T, typename Less>
 __global__ __launch_bounds__(PRIM_SORT_THREADS) static void k_prim_sort_check(const T *in, uint64_t n, uint32_t *unsorted, Less less) {
