@@ -27,7 +27,7 @@ def _free_port():
 
 def _run_bench(world, dump, extra, launcher=False, rccl_group_of_one=False, comm=None):
     args = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--scaling", "strong", "--skip-aux", "--e2e-files", "0", "--site-files", "0",
-            "--cpu-samples", "0", "--pipeline-files", "0", "--shape-samples", "0", "--dump", dump] + extra
+            "--cpu-samples", "0", "--pipeline-files", "0", "--shape-samples", "0", "--dump", dump, "--detail", dump + ".detail.json"] + extra
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(SNPGPU_BENCH_TEST_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
     if rccl_group_of_one:                                               # one rank, one GPU, backend nccl, every collective of the step made
@@ -42,8 +42,17 @@ def _run_bench(world, dump, extra, launcher=False, rccl_group_of_one=False, comm
                "--master-port", str(_free_port())] + args
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    return json.loads(line)
+    # the LAST line of stdout is the compact object the driver parses (< 4 KB); the full result is in the detail file, and what the
+    # compact line says is what the detail file says
+    line = r.stdout.splitlines()[-1]
+    assert len(line) < 4096
+    compact = json.loads(line)
+    with open(dump + ".detail.json") as f:
+        detail = json.load(f)
+    for key in ("value", "ms_per_step", "n_gpus", "scaling", "steps", "warmup"):
+        assert compact[key] == pytest.approx(detail[key], rel=1e-5), key
+    assert compact["roofline"]["frac"] == pytest.approx(detail["roofline"]["frac"], rel=1e-5) and compact["comm"]["world_size"] == world
+    return detail
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])

@@ -33,3 +33,38 @@ def test_tool_runs_at_toy_size(argv, expect, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", argv[0])] + argv[1:], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (argv, r.stdout[-1500:], r.stderr[-2500:])
     assert expect in r.stdout, (argv, r.stdout[-1500:])
+
+
+def test_bench_prints_one_compact_line_last(tmp_path):
+    """The driver parses a bounded tail of bench.py's stdout (BENCH_r05: a 20 KB line came back as `parsed: null`).  With every side
+    row switched on, at toy sizes: the LAST stdout line is one JSON object under 4 KB that carries the contract's keys, `roofline`
+    and `cpu_baseline`; the detail file holds the side rows the compact line quotes from."""
+    import json
+    detail = str(tmp_path / "detail.json")
+    argv = ["--steps", "2", "--warmup", "1", "--samples", "4", "--genome", "60000", "--sites", "600", "--vcf-records", "60", "--dist-samples", "300",
+            "--dist-sites", "2000", "--dist-reps", "1", "--cpu-samples", "2", "--cpu-procs", "2", "--cpu-dist-samples", "20", "--site-files", "2", "--e2e-files", "2",
+            "--pipeline-files", "4", "--shape-samples", "2", "--detail", detail]
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    lines = r.stdout.splitlines()
+    assert len(lines[-1].encode()) < 4096
+    line = json.loads(lines[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0 and line["vs_baseline"] is None
+    assert "workload" in line["config"] and "model" not in line["config"]
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0 and roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-4)
+    assert roof["launches"] == 2 and roof["avg_launch_ms"] > 0
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["matches_gpu"] is True and cb["sample"]
+    assert cb["parallel"]["matches_gpu"] is True and cb["distance"]["matches_gpu"] is True
+    assert "side_rows_with_errors" not in line, line["side_rows_with_errors"]
+    with open(detail) as f:
+        full = json.load(f)
+    for row in ("pipeline_from_files", "secondary", "aux_steps_ms", "scan_shapes", "end_to_end", "call_variants", "site_calling", "cpu_baseline", "north_star"):
+        assert row in full and "error" not in full[row], (row, full.get(row))
+    assert line["value"] == pytest.approx(full["value"], rel=1e-5) and line["k2_frac"] == pytest.approx(full["call_variants"]["strict"]["roofline"]["frac"], rel=1e-5)
+    assert line["site_calling_frac"] == pytest.approx(full["site_calling"]["roofline"]["frac"], rel=1e-5)

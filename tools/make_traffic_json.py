@@ -19,7 +19,7 @@ def mean_of(path, kernel, counter):
     raise SystemExit("no %s for %s in %s" % (counter, kernel, path))
 
 
-bench = json.loads(open(base + "bench_n1.json").read().strip().split("\n")[-1])
+bench = json.load(open(base + "bench_n1_detail.json"))          # bench.py --detail: the full result (the stdout line is an extract)
 k = "void k_scan_wave<false, 0>"
 fetch_kb = mean_of(base + "pmc_fetch_size_summary.txt", k, "FETCH_SIZE")
 write_kb = mean_of(base + "pmc_write_size_summary.txt", k, "WRITE_SIZE")
