@@ -115,10 +115,21 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def claim_stdout():
+    """stdout carries the result line and nothing else: file descriptor 1 is pointed at stderr for the life of the process — RCCL
+    prints "Librccl path : ..." on C stdio's stdout, which a pipe holds back until the process EXITS, i.e. after the JSON line, and
+    every rank of a launch shares the pipe — and the returned descriptor is the real stdout, written once by rank 0 at the end."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
+    real_stdout = claim_stdout()
     import torch
     import torch.distributed as dist
     from snp_pipeline_amd import _lib as L
@@ -398,11 +409,11 @@ def main():
         if len(line) >= COMPACT_LIMIT:                          # never lose the headline to its own length again (BENCH_r05: parsed = null)
             line = json.dumps(compact(out, minimal=True), separators=(",", ":"))
         write_detail(args.detail, out)
-        sys.stdout.flush()
-        print(line)
-        sys.stdout.flush()
     if multi:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(real_stdout, (line + "\n").encode())
 
 
 def write_detail(path, out):

@@ -799,7 +799,7 @@ def aux_steps(d, pos, G):
     host synchronisation inside) and wall time of the host-pointer forms (staging + kernels + read-back)."""
     import torch
     arng = np.random.default_rng(5)
-    n_s, per = 1000, 1500
+    n_s, per = 1000, min(1500, len(pos))
     samp_pos = [np.sort(arng.choice(pos, size=per, replace=False)) for _ in range(n_s)]
     keys = np.concatenate(samp_pos).astype(np.int64)                # contig 0
     who = np.repeat(np.arange(n_s, dtype=np.int32), per)

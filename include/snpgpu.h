@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SNPGPU_ABI_VERSION 6
+#define SNPGPU_ABI_VERSION 7
 
 /* ---- error codes ------------------------------------------------------- */
 #define SNPGPU_OK            0
@@ -138,6 +138,29 @@ const char *snpgpu_last_error(const snpgpu_ctx *ctx);
 int  snpgpu_ctx_set_stream(snpgpu_ctx *ctx, void *hip_stream);
 int  snpgpu_ctx_reset_stream(snpgpu_ctx *ctx);
 int  snpgpu_ctx_sync(snpgpu_ctx *ctx);
+
+/* ---- the CPU budget of the host side (ABI 7) ------------------------------------------------------------------------------
+ * Replaces run.py:387-400 (MaxCpuCores: min(psutil.cpu_count(), MaxCpuCores) caps the reference's per-sample process fan-out).
+ * Here one process per GPU does its shard's host work on threads (file readers, text writers), so the cap is divided among the
+ * processes that share the node:
+ *   usable_cpus = min(CPUs in the affinity mask, the cgroup's CPU quota (v2 cpu.max / v1 cfs quota), max_cpu_cores)
+ *   budget      = max(1, usable_cpus / local_ranks)        -> readers, writers (what the entry points start by default)
+ * max_cpu_cores: snpgpu_set_max_cpu_cores, else the environment variable SNPGPU_MAX_CPU_CORES, else no cap.
+ * local_ranks:   snpgpu_set_local_ranks, else SNPGPU_LOCAL_RANKS, else LOCAL_WORLD_SIZE (torch.distributed.run), else 1.
+ * An explicit thread count in a call's options (snpgpu_stream_opts.n_readers, n_threads arguments) still wins. */
+typedef struct snpgpu_cpu_budget_info {
+    uint32_t affinity_cpus;              /* sched_getaffinity */
+    uint32_t quota_cpus;                 /* cgroup quota / period, rounded down, at least 1; 0 = no quota */
+    uint32_t max_cpu_cores;              /* the cap in force; 0 = none */
+    uint32_t usable_cpus;
+    uint32_t local_ranks;
+    uint32_t budget;                     /* CPUs this process plans with */
+    uint32_t readers;                    /* default reader threads of the file entry points */
+    uint32_t writers;                    /* default formatting threads of the text writers / the FASTA survey */
+} snpgpu_cpu_budget_info;
+int  snpgpu_cpu_budget(snpgpu_cpu_budget_info *out);
+void snpgpu_set_max_cpu_cores(uint32_t cores);   /* 0 = back to the environment / no cap */
+void snpgpu_set_local_ranks(uint32_t ranks);     /* 0 = back to the environment / 1 */
 /* Kernel-only elapsed time helpers (HIP events recorded on the context's stream). */
 int  snpgpu_timer_start(snpgpu_ctx *ctx);
 int  snpgpu_timer_stop_ms(snpgpu_ctx *ctx, float *out_ms);   /* synchronises on the stop event */
@@ -216,7 +239,7 @@ int  snpgpu_call_consensus(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint
 typedef struct snpgpu_stream_opts {      /* 0 = default everywhere */
     uint32_t chunk_bytes;                /* bytes per host->device copy (default 8 MiB; rounded up to 4 KiB) */
     uint32_t n_staging;                  /* pinned staging buffers (default: readers + 4) */
-    uint32_t n_readers;                  /* reader threads (default: 12 on a big host, fewer on a small one) */
+    uint32_t n_readers;                  /* reader threads (default: snpgpu_cpu_budget().readers — 8 on a big host, fewer on a small one or beside other ranks) */
     uint32_t n_slots;                    /* device file buffers = files in flight (default 2) */
     uint32_t want_depth_sum;             /* also accumulate status[3] (collect_metrics.py:325-340 by-product) */
     uint32_t reserved[3];
@@ -330,6 +353,8 @@ typedef struct snpgpu_pileups_stats {
     double   reader_seconds_reading;        /* summed over the reader threads: inside pread */
     double   reader_seconds_waiting;        /* ... waiting for a staging buffer to be copied out */
     double   seconds_preparing;             /* part of `seconds` before the first read starts: files opened and placed, staging memory */
+    uint32_t n_readers;                     /* reader threads of the last ingest call (ABI 7: from snpgpu_cpu_budget) */
+    uint32_t reserved;
 } snpgpu_pileups_stats;
 int  snpgpu_pileups_create(snpgpu_ctx *ctx, uint64_t budget_bytes, snpgpu_pileups **out);
 void snpgpu_pileups_destroy(snpgpu_pileups *store);

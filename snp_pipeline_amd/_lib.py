@@ -77,7 +77,13 @@ class PileupsStats(C.Structure):
     _fields_ = [("h2d_bytes", C.c_uint64), ("file_bytes", C.c_uint64), ("resident_bytes", C.c_uint64), ("budget_bytes", C.c_uint64),
                 ("n_files", C.c_uint32), ("n_resident", C.c_uint32), ("seconds", C.c_double), ("seconds_allocating", C.c_double),
                 ("seconds_waiting_for_readers", C.c_double), ("seconds_waiting_for_device", C.c_double),
-                ("reader_seconds_reading", C.c_double), ("reader_seconds_waiting", C.c_double), ("seconds_preparing", C.c_double)]
+                ("reader_seconds_reading", C.c_double), ("reader_seconds_waiting", C.c_double), ("seconds_preparing", C.c_double),
+                ("n_readers", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class CpuBudget(C.Structure):
+    _fields_ = [("affinity_cpus", C.c_uint32), ("quota_cpus", C.c_uint32), ("max_cpu_cores", C.c_uint32), ("usable_cpus", C.c_uint32),
+                ("local_ranks", C.c_uint32), ("budget", C.c_uint32), ("readers", C.c_uint32), ("writers", C.c_uint32)]
 
 
 class ConsensusJob(C.Structure):
@@ -99,6 +105,9 @@ SIGNATURES = {
     "snpgpu_ctx_set_stream": (C.c_int, [_P, _P]),
     "snpgpu_ctx_reset_stream": (C.c_int, [_P]),
     "snpgpu_ctx_sync": (C.c_int, [_P]),
+    "snpgpu_cpu_budget": (C.c_int, [C.POINTER(CpuBudget)]),
+    "snpgpu_set_max_cpu_cores": (None, [C.c_uint32]),
+    "snpgpu_set_local_ranks": (None, [C.c_uint32]),
     "snpgpu_timer_start": (C.c_int, [_P]),
     "snpgpu_timer_stop_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "snpgpu_ctx_kernel_timing": (C.c_int, [_P, C.c_int]),

@@ -146,7 +146,8 @@ def run_varscan_jar_many(items, max_workers=None):
 
     if not items:
         return []
-    workers = max_workers or max(1, min(len(items), (os.cpu_count() or 2) // 2))
+    from . import device as devmod
+    workers = max_workers or devmod.host_threads(len(items), share=2)     # (a JVM per worker: half of this process's CPU budget)
     with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as ex:
         return list(ex.map(one, items))
 
@@ -288,7 +289,8 @@ def call_sites_batch(args):
     bad = set()
     if stale:
         verbose_print("# %s samtools mpileup for %d samples" % (utils.timestamp(), len(stale)))
-        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        from . import device as devmod
+        with concurrent.futures.ThreadPoolExecutor(max_workers=devmod.host_threads(8)) as ex:
             for (sample_dir, _, pileup_file), rc in zip(stale, ex.map(make_pileup, stale)):
                 if rc != 0 or not os.path.isfile(pileup_file) or os.path.getsize(pileup_file) == 0:
                     utils.sample_error("Error: %s is missing or empty after running samtools mpileup." % pileup_file, continue_possible=True)

@@ -100,8 +100,7 @@ struct RangeInfo {
 };
 
 unsigned fasta_threads(size_t n) {
-    unsigned hc = std::thread::hardware_concurrency();
-    unsigned t = hc >= 32 ? 16 : (hc >= 4 ? hc / 2 : 1);
+    unsigned t = snpgpu_writer_threads(0);
     const size_t per = (size_t)16 << 20;                        // not worth a thread below 16 MB each
     if (n / per < t) t = (unsigned)(n / per);
     return t < 1 ? 1 : t;

@@ -62,6 +62,7 @@ struct snpgpu_pileups {
     uint64_t file_bytes = 0;            // sizes of the files that were ingested
     double seconds = 0, seconds_allocating = 0, seconds_waiting_for_readers = 0, seconds_waiting_for_device = 0;   // summed over the ingest calls
     double reader_seconds_reading = 0, reader_seconds_waiting = 0, seconds_preparing = 0;
+    uint32_t n_readers = 0;             // reader threads of the last ingest call
 };
 
 // Device-side view of a site set.
@@ -158,6 +159,11 @@ int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleD
 #define SNPGPU_SCAN_MAX_BATCH 256   // samples per scan launch (each gets at least ~16 of the 4096 waves)
 
 int snpgpu_set_error(snpgpu_ctx *ctx, int code, const char *fmt, ...);
+// host_budget.hip: the host threads this process may start (affinity mask, cgroup quota, MaxCpuCores, ranks sharing the node)
+void snpgpu_host_budget(snpgpu_cpu_budget_info *out);
+uint32_t snpgpu_reader_threads();                       // file readers of the streamed entry points
+uint32_t snpgpu_writer_threads(uint32_t at_most);       // formatting threads (0 = no other bound)
+uint32_t snpgpu_cpu_threads(uint32_t at_most);          // the whole budget, for pools of one job per thread
 // Start of an entry point: make the context's device current and drop whatever error an EARLIER runtime call of this thread left
 // behind — other users of the HIP runtime in the process (torch probes devices and pointers) leave sticky errors that the launch
 // checks (hipGetLastError after a kernel launch) would otherwise report as ours.

@@ -397,8 +397,7 @@ int run_stream(snpgpu_ctx *ctx, const snpgpu_siteset *ss, std::vector<Source> &s
     // ---- resources ----------------------------------------------------------------------------------------------
     uint32_t n_readers = opts && opts->n_readers ? opts->n_readers : 0;
     if (!n_readers) {
-        unsigned hc = std::thread::hardware_concurrency();
-        n_readers = hc >= 32 ? 8 : (hc >= 8 ? hc / 2 : (hc > 1 ? hc - 1 : 1));
+        n_readers = snpgpu_reader_threads();                     // the CPU budget of this process, not the box's CPU count
     }
     if (n_readers > J) n_readers = (uint32_t)J;
     uint32_t n_staging = opts && opts->n_staging ? opts->n_staging : n_readers + 4;
@@ -654,8 +653,7 @@ int load_file(snpgpu_ctx *ctx, const char *path, uint8_t **d_file, uint64_t *siz
         off += len;
     }
     const uint64_t J = jobs.size();
-    unsigned hc = std::thread::hardware_concurrency();
-    uint32_t n_readers = hc >= 32 ? 8 : (hc >= 8 ? hc / 2 : (hc > 1 ? hc - 1 : 1));
+    uint32_t n_readers = snpgpu_reader_threads();
     if (n_readers > J) n_readers = (uint32_t)J;
     uint32_t n_staging = n_readers + 4;
     if (n_staging > J) n_staging = (uint32_t)J;
@@ -1088,14 +1086,14 @@ int varscan_stream(snpgpu_ctx *ctx, const char *const *paths, uint32_t n_files, 
     }
     const uint64_t J = jobs.size();
     if (n_prefix == n_files) JA = J;
-    unsigned hc = std::thread::hardware_concurrency();
-    uint32_t n_readers = hc >= 32 ? 8 : (hc >= 8 ? hc / 2 : (hc > 1 ? hc - 1 : 1));
+    uint32_t n_readers = snpgpu_reader_threads();
     uint32_t extra_staging = 4;
 #ifdef SNPGPU_TUNING                                            // development builds only (tools/)
     if (const char *e = getenv("SNPGPU_INGEST_READERS")) if (atoi(e) > 0) n_readers = (uint32_t)atoi(e);
     if (const char *e = getenv("SNPGPU_INGEST_EXTRA_STAGING")) if (atoi(e) >= 0) extra_staging = (uint32_t)atoi(e);
 #endif
     if (n_readers > J) n_readers = (uint32_t)J;
+    if (store) store->n_readers = n_readers;
     uint32_t n_staging = n_readers + extra_staging;
     if (n_staging > J) n_staging = (uint32_t)J;
     if (n_staging < 1) n_staging = 1;
@@ -1554,6 +1552,7 @@ int snpgpu_pileups_get_stats(const snpgpu_pileups *store, snpgpu_pileups_stats *
     out->reader_seconds_reading = store->reader_seconds_reading;
     out->reader_seconds_waiting = store->reader_seconds_waiting;
     out->seconds_preparing = store->seconds_preparing;
+    out->n_readers = store->n_readers;
     return SNPGPU_OK;
 }
 

@@ -132,8 +132,7 @@ extern "C" int snpgpu_write_distance_tsv(const char *path, int layout, const cha
                                          const int32_t *matrix, uint64_t row_stride) {
     if (!path || (layout != SNPGPU_TSV_PAIRWISE && layout != SNPGPU_TSV_MATRIX) || (n && (!ids || !id_off || !matrix)) || row_stride < n)
         return SNPGPU_E_ARG;
-    unsigned hc = std::thread::hardware_concurrency();
-    unsigned T = hc >= 32 ? 16 : (hc >= 4 ? hc / 2 : 1);
+    unsigned T = snpgpu_writer_threads(0);
     if ((uint64_t)n * n < ((uint64_t)1 << 22)) T = 1;            // small matrices: one thread, one stream of write() calls
     if (T > n) T = n ? n : 1;
     if (T <= 1) {

@@ -212,8 +212,7 @@ extern "C" int snpgpu_write_consensus_files(snpgpu_consensus_job *jobs, uint32_t
                                             uint32_t n_threads) {
     if (n_jobs && !jobs) return SNPGPU_E_ARG;
     if (!n_threads) {
-        n_threads = std::thread::hardware_concurrency();
-        if (n_threads > 64) n_threads = 64;
+        n_threads = snpgpu_cpu_threads(64);                       // one job per thread, within this process's CPU budget
     }
     if (n_threads > n_jobs) n_threads = n_jobs;
     if (n_threads < 1) n_threads = 1;

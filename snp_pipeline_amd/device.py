@@ -922,6 +922,32 @@ def device_count():
     return int(L.load().snpgpu_device_count())
 
 
+def cpu_budget():
+    """The host threads this process plans with (snpgpu_cpu_budget: affinity mask, cgroup quota, SNPGPU_MAX_CPU_CORES — the MaxCpuCores
+    of run.py:387-400 — divided by the ranks that share the node) as a dict; `budget` is the figure for Python-side pools, `readers`
+    and `writers` are what the library's file entry points start by default."""
+    b = L.CpuBudget()
+    rc = L.load().snpgpu_cpu_budget(C.byref(b))
+    if rc != 0:
+        raise RuntimeError("snpgpu_cpu_budget failed (%d)" % rc)
+    return {name: int(getattr(b, name)) for name, _ in L.CpuBudget._fields_}
+
+
+def set_local_ranks(n):
+    """How many processes of this job share the node (0: back to SNPGPU_LOCAL_RANKS / LOCAL_WORLD_SIZE / 1)."""
+    L.load().snpgpu_set_local_ranks(int(n))
+
+
+def set_max_cpu_cores(n):
+    """The MaxCpuCores of this process's node (0: back to SNPGPU_MAX_CPU_CORES / no cap)."""
+    L.load().snpgpu_set_max_cpu_cores(int(n))
+
+
+def host_threads(at_most, share=1):
+    """Workers for a Python-side pool: the budget divided by `share`, between 1 and at_most."""
+    return max(1, min(int(at_most), cpu_budget()["budget"] // max(1, share)))
+
+
 def acquire_device_slot(n_devices, max_per_device=None, lock_dir=None, poll_seconds=0.05):
     """Device assignment for the reference's per-sample process array (run.py:709-710 starts up to max_cpu_cores
     ``cfsan_snp_pipeline call_consensus`` processes at once, none of which knows about the others).  Every process

@@ -213,6 +213,11 @@ class _Job(object):
         torch = self.torch
         self.dev = devmod.Device(self.comm.local_rank)
         self.dev.use_torch_stream()
+        # the host side's CPU budget (run.py:387-400, MaxCpuCores): the ranks of this job share the node's cores — a launcher that
+        # does not export LOCAL_WORLD_SIZE still has WORLD_SIZE ranks on this one node (hot_path_batch is a single-node job)
+        if self.comm.world > 1 and not os.environ.get("LOCAL_WORLD_SIZE") and not os.environ.get("SNPGPU_LOCAL_RANKS"):
+            devmod.set_local_ranks(self.comm.world)
+        self.cpu = devmod.cpu_budget()
         torch.cuda.set_device(self.comm.local_rank)
         # sharded over RCCL: the exchanges of the job are library calls on this context's stream (csrc/comm.hip); the gloo route of
         # the one-GPU tests, and a host whose librccl.so cannot be loaded, keep torch.distributed
@@ -321,7 +326,7 @@ def _ingest_with_device_site_calling(job, todo):
     """Mode ``device``: site calling on each file while the next arrives; var.flt.vcf written by host threads as records return."""
     dev, store = job.dev, job.store
     vparams = job.vs_opts.device_params()
-    pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // 4)))
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(2, devmod.host_threads(16, share=4)))
     redo = []
     for b0 in range(0, len(todo), INGEST_BATCH):
         batch = todo[b0:b0 + INGEST_BATCH]
@@ -420,7 +425,7 @@ def _ingest_only(job, todo):
             for s, message in zip(stale, cs.run_varscan_jar_many([(s.pileup, os.path.join(s.dir, "var.flt.vcf")) for s in stale])):
                 if message:
                     s.fail(message)
-        with concurrent.futures.ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // 4))) as pool:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=max(2, devmod.host_threads(16, share=4))) as pool:
             list(pool.map(_read_sample_vcf, [s for s in todo if s.ok]))
         job.lap("1c   of which: var.flt.vcf files (%s) beside the ingest" % job.site_calling, t_sites)
     finally:
@@ -589,7 +594,7 @@ def stage_site_union_and_regions(job):
     job.lap("2e   of which: preserved site union + snplist_preserved.txt", t2)
     t2 = time.perf_counter()
     # the split VCF files of this rank's samples: written by host threads while the consensus stage keeps the device busy
-    job.split_pool = concurrent.futures.ThreadPoolExecutor(max_workers=4)
+    job.split_pool = concurrent.futures.ThreadPoolExecutor(max_workers=devmod.host_threads(4))
     job.split_files = []
     for s in mine:
         if not s.ok:
@@ -1128,7 +1133,8 @@ def _job_stats(job):
             "ingest": {"seconds": st.seconds, "allocating": st.seconds_allocating, "waiting_for_readers": st.seconds_waiting_for_readers,
                        "waiting_for_device": st.seconds_waiting_for_device, "reader_seconds_reading": st.reader_seconds_reading,
                        "reader_seconds_waiting": st.reader_seconds_waiting, "preparing": st.seconds_preparing},
-            "phases": job.timings, "sites": fl.S1, "sites_preserved": fl.S2, "samples": job.hi - job.lo}
+            "phases": job.timings, "sites": fl.S1, "sites_preserved": fl.S2, "samples": job.hi - job.lo,
+            "readers": int(st.n_readers), "usable_cores": job.cpu["usable_cpus"], "local_world": job.cpu["local_ranks"], "cpu_budget": job.cpu}
 
 
 def hot_path_batch(args):
@@ -1147,6 +1153,10 @@ def hot_path_batch(args):
             job.run_stage(stage)
         stats = _job_stats(job)
         hot_path_batch.last_stats = stats
+        if os.environ.get("SNPGPU_HOT_PATH_STATS"):             # a directory: every rank leaves its figures there (tests, bench tooling)
+            import json
+            with open(os.path.join(os.environ["SNPGPU_HOT_PATH_STATS"], "rank%d.json" % job.rank), "w") as f:
+                json.dump(stats, f)
         verbose_print("# hot_path_batch rank %d: %d samples, %d pileup bytes, %d bytes copied to the device (%d files resident), %.3f s"
                       % (job.rank, job.hi - job.lo, stats["file_bytes"], stats["h2d_bytes"], stats["resident_files"], stats["seconds"]))
         for k in sorted(job.timings):

@@ -26,7 +26,7 @@ def test_library_builds_loads_and_exports_everything():
     lib = _lib.load()
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.snpgpu_abi_version() == 6
+    assert lib.snpgpu_abi_version() == 7
     assert lib.snpgpu_packed_row_bytes(33) == 64 and lib.snpgpu_packed_row_bytes(128) == 64 and lib.snpgpu_packed_row_bytes(129) == 128   # rows padded to 4 words
     assert ctypes.sizeof(_lib.SiteCounts) == 128
 

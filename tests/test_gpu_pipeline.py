@@ -327,12 +327,25 @@ def test_hot_path_batch_sharded_over_ranks_writes_the_same_files(tmp_path, monke
     port = s.getsockname()[1]
     s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SNPGPU_PIPELINE_ONE_GPU="1", MASTER_ADDR="127.0.0.1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    # the host side's CPU budget: a node whose cgroup grants 16 CPUs (whatever the box shows), shared by the ranks of the launch
+    cgroup, stats_dir = work / "cgroup", work / "stats"
+    cgroup.mkdir()
+    stats_dir.mkdir()
+    (cgroup / "cpu.max").write_text("1600000 100000\n")
+    env = dict(os.environ, SNPGPU_PIPELINE_ONE_GPU="1", MASTER_ADDR="127.0.0.1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""),
+               SNPGPU_CGROUP_ROOT=str(cgroup), SNPGPU_HOT_PATH_STATS=str(stats_dir))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bin", "cfsan_snp_pipeline")] + [w.replace("\x00", " ") for w in line.split()] + ["-v", "0"]
     r = subprocess.run(cmd, cwd=str(work), env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     _compare(_snapshot(work, dirs, remove=False), want)
+    import json
+    per_rank = [json.load(open(str(stats_dir / ("rank%d.json" % k)))) for k in range(world)]
+    usable = min(16, len(os.sched_getaffinity(0)))
+    for st in per_rank:
+        assert st["local_world"] == world and st["usable_cores"] == usable and st["cpu_budget"]["budget"] == max(1, usable // world)
+        assert st["readers"] <= st["cpu_budget"]["readers"] <= max(1, usable // world)
+    assert sum(st["readers"] for st in per_rank) <= max(usable, world)        # 8 ranks on 16 CPUs: at most 2 readers each (r5: 8 each)
 
 
 def test_hot_path_batch_in_an_rccl_group_of_one_writes_the_same_files(tmp_path, monkeypatch):
