@@ -477,7 +477,8 @@ def compact(out, minimal=False):
         c["all_positions_ms"] = cv["all_positions"]["ms_per_step"]
     sc = out.get("site_calling") or {}
     if "roofline" in sc:
-        c["site_calling_frac"] = sc["roofline"]["frac"]
+        c["site_calling_frac"] = sc["roofline"]["frac"]                # one sample per launch: what the pipeline runs
+        c["site_calling_batch_frac"] = (sc["roofline"].get("batch_over_the_shard_not_used_by_the_pipeline") or {}).get("frac")
     shapes = out.get("scan_shapes") or {}
     if shapes and "error" not in shapes:
         c["scan_shapes_frac"] = {k: v["frac_of_hbm_peak"] for k, v in shapes.items() if isinstance(v, dict) and "frac_of_hbm_peak" in v}

@@ -248,19 +248,21 @@ def site_calling(d, pile, offs, sizes, n_files):
         # the same shape (5 Mbp x 30x): sample 0 of the profile's generator
         vs_traffic, vs_src = committed_traffic("varscan_traffic.json", lambda vt: abs(vt.get("bytes", 0) - int(sizes[0])) <= int(sizes[0]) // 100)
         return {
-            "roofline": {"kernels": "k_varscan_scan + k_varscan_finish (one call over the shard's %d resident samples: a launch per dozen of them)" % n_res, "bound": "hbm",
-                         "achieved": k_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k_gbs / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_call": tot_b, "samples_per_call": n_res, "avg_ms_per_call": kb_avg, "calls_timed": reps_b,
-                         "launches_per_call": int(kb_n) // reps_b,
-                         "algorithmic_bytes_per_file": int(sizes[0]), "avg_ms_per_file": k_avg,
-                         "one_sample_per_launch": {"achieved": k1_gbs, "frac": k1_gbs / HBM_PEAK_GBS, "avg_ms_per_file": k1_avg, "files_timed": int(k1_n)},
-                         "twelve_samples_per_call": {"achieved": k12_gbs, "frac": k12_gbs / HBM_PEAK_GBS, "avg_ms_per_file": k12_avg, "calls_timed": 6,
-                                                     "note": "the same kernels, a dozen resident samples per call with the host's read-back in between: the launches of the "
-                                                             "long call slow down by up to a fifth a few milliseconds in and recover (profiles/r5/varscan_launch_trace.txt)"},
+            # headline = the shape the pipeline runs: snpgpu_pileups_ingest / snpgpu_varscan_files launch the kernels once per FILE as it
+            # arrives (hot_path.py stage 1, call_sites_batch); snpgpu_varscan_batch_dev (many resident samples per launch) is an entry
+            # point of the ABI that no subcommand calls — its figure is listed beside it and labelled so
+            "roofline": {"kernels": "k_varscan_scan + k_varscan_finish, one resident sample per launch (what the ingest of hot_path_batch and call_sites_batch do)",
+                         "bound": "hbm", "achieved": k1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_file": int(lens[0]), "avg_ms_per_file": k1_avg, "files_timed": int(k1_n),
+                         "batch_over_the_shard_not_used_by_the_pipeline": {
+                             "entry_point": "snpgpu_varscan_batch_dev: one call over the shard's %d resident samples, a launch per dozen of them" % n_res,
+                             "achieved": k_gbs, "frac": k_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_call": tot_b, "samples_per_call": n_res,
+                             "avg_ms_per_call": kb_avg, "calls_timed": reps_b, "launches_per_call": int(kb_n) // reps_b, "avg_ms_per_file": k_avg},
+                         "twelve_samples_per_call_not_used_by_the_pipeline": {"achieved": k12_gbs, "frac": k12_gbs / HBM_PEAK_GBS, "avg_ms_per_file": k12_avg, "calls_timed": 6},
                          "traffic": (vs_traffic or {}).get("traffic_bytes_per_file"), "traffic_measured_on_bytes": (vs_traffic or {}).get("bytes"),
                          "traffic_over_algorithmic": (vs_traffic or {}).get("traffic_over_algorithmic"),
                          "traffic_source": ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % vs_src) if vs_traffic else None,
-                         "note": "resident samples, HIP events around the launches on their stream; the files -> var.flt.vcf rate above is bound by the host link"},
+                         "note": "resident samples, HIP events around the launches on their stream; the files -> var.flt.vcf rate below is bound by the host link"},
             "what": "%d pileup files in the page cache -> var.flt.vcf each (VarScan mpileup2snp's job, %s), one snpgpu_varscan_files call" % (n_files, extra),
             "files": n_files, "bytes": nbytes, "seconds": best, "pileup_gb_per_sec": nbytes / best / 1e9, "samples_per_sec": n_files / best,
             "pileup_lines_per_sec": lines / best, "sites_written": rows, "rows_equal_cpu_restatement": True,
@@ -629,7 +631,8 @@ def pipeline_from_files(pile, offs, sizes, refh, G, n_files, with_separate=True)
             "wall_over_copy_time": (st["seconds"] / ideal) if st["seconds"] >= ideal / 1.05 else None,
             "pinned_h2d_probe_is_a_ceiling_here": st["seconds"] >= ideal / 1.05, "pinned_h2d_probe": pinned_h2d_probe(),
             "samples_per_sec": n_files / st["seconds"], "pileup_gb_per_sec": total / st["seconds"] / 1e9,
-            "phases_seconds": st["phases"], "ingest": st["ingest"], "snp_sites": st["sites"], "snp_sites_preserved": st["sites_preserved"],
+            "phases_seconds": st["phases"], "ingest": st["ingest"], "readers": st.get("readers"), "usable_cores": st.get("usable_cores"),
+            "local_world": st.get("local_world"), "snp_sites": st["sites"], "snp_sites_preserved": st["sites_preserved"],
             "tree_written_in_seconds": t_tree, "tree_synced_in_seconds": t_sync,
             "device_memory_recycled_first": {"bytes": n_recycled, "first_allocation_seconds": t_recycle,
                                              "note": "allocated and freed once before the tree was written: the job's own allocations "

@@ -80,6 +80,23 @@ const char *rccl_why() { return "RCCL is not available (librccl.so could not be 
         if (r_ != ncclSuccess) return snpgpu_set_error((ctx), SNPGPU_E_HIP, "%s failed: %s", #expr, (R)->GetErrorString(r_)); \
     } while (0)
 
+// Inside a ncclGroupStart / ncclGroupEnd bracket: remember the first failure and go on to the bracket's end — returning from inside
+// would leave the thread's group open, every later collective of the thread would be queued into it and never launch (a hang where
+// an error belongs).  RCCL_GROUP_END closes the bracket whatever happened and returns the first failure.
+#define RCCL_IN_GROUP(first, what, expr)                                                                                    \
+    do {                                                                                                                    \
+        if ((first) == ncclSuccess) {                                                                                       \
+            (first) = (expr);                                                                                               \
+            if ((first) != ncclSuccess) (what) = #expr;                                                                     \
+        }                                                                                                                   \
+    } while (0)
+#define RCCL_GROUP_END(ctx, R, first, what)                                                                                 \
+    do {                                                                                                                    \
+        const ncclResult_t end_ = (R)->GroupEnd();                                                                          \
+        if ((first) != ncclSuccess) return snpgpu_set_error((ctx), SNPGPU_E_HIP, "%s failed: %s", (what), (R)->GetErrorString(first)); \
+        if (end_ != ncclSuccess) return snpgpu_set_error((ctx), SNPGPU_E_HIP, "ncclGroupEnd failed: %s", (R)->GetErrorString(end_));  \
+    } while (0)
+
 struct Comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
@@ -264,12 +281,14 @@ int snpgpu_allgatherv(snpgpu_ctx *ctx, const void *d_send, void *d_recv, const u
     if (mine && (const char *)d_send != (const char *)d_recv + offsets[c->rank])
         HIP_TRY(ctx, hipMemcpyAsync((char *)d_recv + offsets[c->rank], d_send, mine, hipMemcpyDeviceToDevice, ctx->stream));
     RCCL_TRY(ctx, R, R->GroupStart());
+    ncclResult_t first = ncclSuccess;
+    const char *what = "";
     for (int p = 0; p < c->nranks; ++p) {
         if (p == c->rank) continue;
-        if (mine) RCCL_TRY(ctx, R, R->Send(d_send, mine, ncclUint8, p, c->comm, ctx->stream));
-        if (bytes[p]) RCCL_TRY(ctx, R, R->Recv((char *)d_recv + offsets[p], bytes[p], ncclUint8, p, c->comm, ctx->stream));
+        if (mine) RCCL_IN_GROUP(first, what, R->Send(d_send, mine, ncclUint8, p, c->comm, ctx->stream));
+        if (bytes[p]) RCCL_IN_GROUP(first, what, R->Recv((char *)d_recv + offsets[p], bytes[p], ncclUint8, p, c->comm, ctx->stream));
     }
-    RCCL_TRY(ctx, R, R->GroupEnd());
+    RCCL_GROUP_END(ctx, R, first, what);
     return SNPGPU_OK;
 }
 
@@ -289,15 +308,17 @@ int snpgpu_alltoallv(snpgpu_ctx *ctx, const void *d_send, const uint64_t *send_b
     if (send_bytes[c->rank])
         HIP_TRY(ctx, hipMemcpyAsync((char *)d_recv + my_ro, (const char *)d_send + my_so, send_bytes[c->rank], hipMemcpyDeviceToDevice, ctx->stream));
     RCCL_TRY(ctx, R, R->GroupStart());
+    ncclResult_t first = ncclSuccess;
+    const char *what = "";
     for (int p = 0; p < c->nranks; ++p) {
         if (p != c->rank) {
-            if (send_bytes[p]) RCCL_TRY(ctx, R, R->Send((const char *)d_send + so, send_bytes[p], ncclUint8, p, c->comm, ctx->stream));
-            if (recv_bytes[p]) RCCL_TRY(ctx, R, R->Recv((char *)d_recv + ro, recv_bytes[p], ncclUint8, p, c->comm, ctx->stream));
+            if (send_bytes[p]) RCCL_IN_GROUP(first, what, R->Send((const char *)d_send + so, send_bytes[p], ncclUint8, p, c->comm, ctx->stream));
+            if (recv_bytes[p]) RCCL_IN_GROUP(first, what, R->Recv((char *)d_recv + ro, recv_bytes[p], ncclUint8, p, c->comm, ctx->stream));
         }
         so += send_bytes[p];
         ro += recv_bytes[p];
     }
-    RCCL_TRY(ctx, R, R->GroupEnd());
+    RCCL_GROUP_END(ctx, R, first, what);
     return SNPGPU_OK;
 }
 

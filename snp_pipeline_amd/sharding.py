@@ -31,7 +31,12 @@ def use_abi_comm(device, rank=None, world=None, unique_id=None, selftest=True):
     travels through its object broadcast; a host program without PyTorch passes rank / world / the 128-byte id itself (rank 0:
     device.comm_unique_id(); INTEGRATION.md shows the ctypes form).  Returns False when RCCL cannot be loaded, or when the
     communicator's self-test fails on some rank (see _selftest): the exchanges then stay with torch.distributed."""
-    if not device.comm_available():
+    via_dist = unique_id is None and dist.is_initialized() and dist.get_world_size() > 1
+    available = device.comm_available()
+    if via_dist:
+        # ncclCommInitRank is itself a collective: a rank that cannot even load librccl.so must say so BEFORE the others walk into it
+        available = _all_agree(available)
+    if not available:
         return False
     if unique_id is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
@@ -40,13 +45,13 @@ def use_abi_comm(device, rank=None, world=None, unique_id=None, selftest=True):
         if dist.is_initialized() and world > 1:
             dist.broadcast_object_list(box, src=0)
         unique_id = box[0]
-    why = None
-    try:
+    if world > 1 and dist.is_initialized():
+        # ... and under a watchdog: where one rank fails inside the call the others would wait in it for good, and never reach the
+        # agreement below that sends every rank back to torch.distributed
+        why = _comm_init_watched(device, rank, world, unique_id, float(os.environ.get("SNPGPU_COMM_INIT_TIMEOUT", "180")))
+    else:
+        why = None
         device.comm_init(rank, world, unique_id)
-    except Exception as exc:                                     # (RCCL said no on this rank: the others must hear of it)
-        if world <= 1 or not dist.is_initialized():
-            raise
-        why = "snpgpu_comm_init: %s" % exc
     if world > 1 and (selftest or why is not None):
         if why is None:
             why = _selftest(device, int(rank), int(world))
@@ -58,10 +63,41 @@ def use_abi_comm(device, rank=None, world=None, unique_id=None, selftest=True):
         if not every_ok:
             sys.stderr.write("snpgpu rank %d: the exchanges stay with torch.distributed (%s)\n"
                              % (rank, why or "another rank's self-test of the library's communicator failed"))
-            device.comm_abort()
+            if why is None or not why.startswith("snpgpu_comm_init"):
+                device.comm_abort()                              # (a communicator that never came to be has nothing to abort)
             return False
     _abi.update(dev=device, rank=int(rank), world=int(world), counts=None)
     return True
+
+
+def _all_agree(flag):
+    """True where `flag` is true on every rank of the process group (an all-reduce with MIN on the group's own device kind)."""
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def _comm_init_watched(device, rank, world, unique_id, timeout_s):
+    """snpgpu_comm_init in a helper thread that this one waits for at most timeout_s.  Returns None, or what went wrong (the call
+    raised, or did not come back: its thread is then left behind as a daemon and the communicator is never used)."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            device.comm_init(rank, world, unique_id)
+            box["ok"] = True
+        except Exception as exc:                                  # noqa: B902 — reported to the other ranks by the caller
+            box["err"] = exc
+
+    th = threading.Thread(target=run, name="snpgpu-comm-init", daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return "snpgpu_comm_init did not return within %g s" % timeout_s
+    if "err" in box:
+        return "snpgpu_comm_init: %s" % box["err"]
+    return None
 
 
 def _selftest(device, rank, world, timeout_ms=120000):
@@ -260,9 +296,15 @@ def tiles_of_rank(n, rank, world):
 
 
 def sum_partial_distances(partial):
-    """Every rank filled only its own tiles (and their mirror images) of an n x n int32 matrix of zeros."""
-    if not _alone() and dist.is_initialized():
-        dist.all_reduce(partial, op=dist.ReduceOp.SUM)
+    """Every rank filled only its own tiles (and their mirror images) of an n x n int32 matrix of zeros.  The sum goes through
+    torch.distributed; a host that drives the library's communicator without a process group has the row-band
+    exchange (RowBands.exchange) for this and must not get a partial matrix back in silence."""
+    if _alone():
+        return partial
+    if not dist.is_initialized():
+        raise RuntimeError("sum_partial_distances needs torch.distributed (the library's communicator has no all-reduce): "
+                           "use RowBands.exchange, which moves every tile once to the owner of its row")
+    dist.all_reduce(partial, op=dist.ReduceOp.SUM)
     return partial
 
 
@@ -298,7 +340,12 @@ class RowBands(object):
 
     def exchange(self, partial, rank):
         """partial: this rank's (n_padded, n_padded) int32 matrix holding the tiles it computed (and their mirror images).
-        Returns the (band tile rows * 128, n_padded) band of complete rows this rank owns."""
+        Returns the (band tile rows * 128, n_padded) band of complete rows this rank owns.
+
+        ALIASING: over the library's communicator the returned band is this object's own buffer (made once per rank and device, so
+        that a step allocates nothing) and the NEXT exchange() of the same RowBands overwrites it; with one rank it is a view of
+        `partial`.  A caller that keeps band k while band k + 1 is computed must .clone() it; the torch.distributed route returns a
+        fresh tensor every time."""
         nt, T, world = self.nt, DIST_TILE, self.world
         lo, hi = self.bands[rank]
         if world == 1 and not group_of_one_exchanges():                   # one rank owns every row: the matrix it computed is the band

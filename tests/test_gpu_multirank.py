@@ -132,3 +132,39 @@ def test_the_step_in_an_rccl_group_of_one(tmp_path, route):
     assert sorted(ref.files) == sorted(got.files)
     for k in ref.files:
         assert np.array_equal(got[k], ref[k]), k
+
+
+def _n_devices():
+    from snp_pipeline_amd import device as dev
+    return dev.device_count()
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="RCCL between two ranks needs two GPUs (the test box of this build has one)")
+@pytest.mark.parametrize("comm", ["abi", "torch"])
+def test_two_ranks_over_rccl_when_two_gpus_are_there(tmp_path, comm):
+    """the real inter-rank ncclSend / ncclRecv path.  Skipped on a one-GPU box; on a node with two or more GPUs two ranks
+    run the step over RCCL — through the library's communicator, and through torch.distributed — and must reproduce the one-rank
+    arrays (uneven sample shards: 301 samples over two ranks)."""
+    n_total = 301
+    extra = ["--samples", str(n_total), "--genome", "40000", "--sites", "400", "--vcf-records", "60", "--dist-samples", "700",
+             "--dist-sites", "3000", "--dist-reps", "1"]
+    one = _run_bench(1, str(tmp_path / "one"), extra)
+    args = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--scaling", "strong", "--skip-aux", "--e2e-files", "0", "--site-files", "0", "--cpu-samples", "0",
+            "--pipeline-files", "0", "--shape-samples", "0", "--dump", str(tmp_path / "two"), "--detail", str(tmp_path / "two.detail.json")] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SNPGPU_BENCH_TEST_ONE_GPU")}
+    env.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", SNPGPU_COMM=comm)
+    r = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads(r.stdout.splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["comm"] == {"backend": "nccl", "world_size": 2}
+    assert ("libsnpgpu.so" in line["comm_route"]) == (comm == "abi")
+    two = json.load(open(str(tmp_path / "two.detail.json")))
+    assert two["site_union"] == one["site_union"] and two["secondary"]["band_checksum"] == one["secondary"]["band_checksum"]
+    ref = np.load(str(tmp_path / "one.rank0.npz"))
+    for r_ in range(2):
+        got = np.load(str(tmp_path / ("two.rank%d.npz" % r_)))
+        for k in ("union", "union_off", "carriers", "packed"):
+            assert np.array_equal(got[k], ref[k]), (r_, k)
+        g0, g1 = got["first_sample"]
+        lo, hi = got["band_rows"]
+        assert np.array_equal(got["bases"], ref["bases"][g0:g1]) and np.array_equal(got["band"], ref["band"][lo:hi])
