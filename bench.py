@@ -475,6 +475,7 @@ def compact(out, minimal=False):
             c[name] = cv[key]["roofline"]["frac"]
     if isinstance(cv.get("all_positions"), dict) and "ms_per_step" in cv["all_positions"]:
         c["all_positions_ms"] = cv["all_positions"]["ms_per_step"]
+        c["all_positions_file_to_vcf_ms"] = (cv["all_positions"].get("file_to_vcf_file") or {}).get("ms")
     sc = out.get("site_calling") or {}
     if "roofline" in sc:
         c["site_calling_frac"] = sc["roofline"]["frac"]                # one sample per launch: what the pipeline runs

@@ -397,15 +397,24 @@ def call_variants(d, ss, prm, pile, offs, sizes, S, dev, torch, pos):
         with open(path, "wb") as f:
             f.write(text)
         lines0 = int(st[0, 1])
-        d.call_all_lines(ss, path, prm, capacity=lines0, check=False)            # warm-up: scratch, pinned staging
+        # records back: the 32-byte line records (snpgpu_call_all_lines_compact_file), which is what crosses the host link since round 6; the
+        # 128-byte form (snpgpu_call_all_lines_file, round 5's row) timed beside it
+        d.call_all_lines_compact(ss, path, prm, capacity=lines0)                  # warm-up: scratch, pinned staging
         d.kernel_timing(True)
         d.kernel_time_ms(1)
         t0 = time.perf_counter()
-        off, flags, recs = d.call_all_lines(ss, path, prm, capacity=lines0, check=False)
+        off, lrec, widx, wide = d.call_all_lines_compact(ss, path, prm, capacity=lines0, wide_capacity=max(lines0 // 16, 4096))
         wall = time.perf_counter() - t0
         call_ms, call_n = d.kernel_time_ms(1)
         d.kernel_timing(False)
         call_ms = call_ms / max(call_n, 1)
+        _, recs = dev.expand_line_records(lrec, widx, wide)
+        t0 = time.perf_counter()
+        off_full, _, recs_full = d.call_all_lines(ss, path, prm, capacity=lines0, check=False)
+        wall_full = time.perf_counter() - t0
+        if not np.array_equal(off, off_full) or recs.tobytes() != recs_full.tobytes():
+            raise SystemExit("--vcfAllPos: the 32-byte line records differ from the full ones")
+        del recs_full, off_full
         # check: 300 lines spread over the file, each against the oracle's Record of that very line
         for k in range(0, len(off), max(len(off) // 300, 1)):
             o = int(off[k]) - 1
@@ -413,15 +422,43 @@ def call_variants(d, ss, prm, pile, offs, sizes, S, dev, torch, pos):
             r = po.parse_record(po.split_fields(ln), 0)
             if (int(recs[k]["raw_depth"]), int(recs[k]["good_depth"]), int(recs[k]["fwd_good_depth"])) != (r.raw_depth, r.good_depth, r.forward_good_depth):
                 raise SystemExit("--vcfAllPos record %d differs from the oracle" % k)
-        written = len(off) * (dev.COUNTS_DTYPE.itemsize + 8 + 1)
-        gbs = (lens[0] + written) / (call_ms * 1e-3) / 1e9 if call_ms > 0 else 0.0
+        # file to file: reads.all.pileup -> consensus.vcf with a row per line (what `call_consensus --vcfAllPos` does with the records)
+        import argparse
+        from snp_pipeline_amd import vcf_writer
+        cc = argparse.Namespace(minBaseQual=0, minConsFreq=0.6, minConsDpth=3, minConsStrdDpth=0, minConsStrdBias=0.0, vcfRefName="ref.fasta",
+                                vcfPreserveRefCase=False, vcfFailedSnpGt=".")
+        vcf = os.path.join(tmpdir, "consensus.vcf")
+        vcf_writer.write_all_positions_vcf_from_pileup(d, ss, vcf, "s0", cc, path, prm)                  # warm-up: page cache of the output
+        t0 = time.perf_counter()
+        n_l, n_rows = vcf_writer.write_all_positions_vcf_from_pileup(d, ss, vcf, "s0", cc, path, prm)
+        wall_vcf = time.perf_counter() - t0
+        vcf_bytes = os.path.getsize(vcf)
+        # its rows against the row-by-row writer on the first 2 000 and the last 2 000 lines
+        filt = [n for n, _ in vcf_writer.filter_descriptions(0.6, 3, 0, 0.0)]
+        with open(vcf, "rb") as f:
+            rows = [ln for ln in f.read().split(b"\n") if ln and not ln.startswith(b"#")]
+        if n_rows != len(off) or len(rows) != len(off):
+            raise SystemExit("--vcfAllPos: %d rows for %d lines" % (len(rows), len(off)))
+        for k in list(range(0, min(2000, len(off)))) + list(range(max(0, len(off) - 2000), len(off))):
+            o = int(off[k]) - 1
+            f0, f1 = text[o:o + 256].split(None, 2)[:2]
+            if rows[k].decode() != vcf_writer.row_from_counts(f0.decode(), int(f1), recs[k], filt, False, ".", spill=d.last_spill):
+                raise SystemExit("--vcfAllPos row %d differs from the row-by-row writer" % k)
+        written = len(off) * (dev.LINE_DTYPE.itemsize + 8) + len(widx) * (dev.COUNTS_DTYPE.itemsize + 4)
+        gbs = (lens[0] + len(off) * (dev.COUNTS_DTYPE.itemsize + 8 + 1)) / (call_ms * 1e-3) / 1e9 if call_ms > 0 else 0.0
         out["all_positions"] = {
-            "what": "one sample, a record from every one of its %d lines (--vcfAllPos): file in the page cache -> records on the host" % len(off),
+            "what": "one sample, a record from every one of its %d lines (--vcfAllPos): file in the page cache -> 32-byte records on the host" % len(off),
             "ms_per_step": wall * 1e3, "positions_per_sec": len(off) / wall, "positions": int(len(off)), "call_kernel_ms": call_ms,
-            "roofline": {"kernels": "K2 over a line list: k_call_sites, one wave per line", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": lens[0] + written, "of_which_line_bytes": lens[0],
-                         "of_which_written": written, "traffic": None},
-            "note": "the wall time holds the file read, its copy to the device, the line index, the call and %.0f MB of records back over the host link" % (written / 1e6)}
+            "bytes_back_over_the_host_link": written, "wide_lines": int(len(widx)),
+            "with_128_byte_records_ms": wall_full * 1e3, "with_128_byte_records_bytes_back": len(off) * (dev.COUNTS_DTYPE.itemsize + 8 + 1),
+            "file_to_vcf_file": {"ms": wall_vcf * 1e3, "rows": int(n_rows), "vcf_bytes": vcf_bytes, "rows_per_sec": n_rows / wall_vcf,
+                                 "rows_checked_against_the_row_by_row_writer": min(4000, len(off)),
+                                 "what": "reads.all.pileup (page cache) -> consensus.vcf with a row per line, snpgpu_write_all_positions_vcf: records back in pieces, "
+                                         "rows formatted and written by the library's host threads"},
+            "roofline": {"kernels": "K2 over a line list: k_call_lanes x3 + k_call_sites", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": lens[0] + len(off) * (dev.COUNTS_DTYPE.itemsize + 8 + 1), "of_which_line_bytes": lens[0],
+                         "traffic": None},
+            "note": "the wall time holds the file read, its copy to the device, the line index, the call, the packing and %.0f MB of records back over the host link" % (written / 1e6)}
     finally:
         shutil.rmtree(tmpdir, ignore_errors=True)
     return out

@@ -272,6 +272,50 @@ int  snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const
                                 uint64_t *out_line_off, uint8_t *out_line_flags, snpgpu_site_counts *out_counts,
                                 uint64_t *out_status);
 
+/* The same pass with 32-byte records (ABI 7).  Nearly every line of a pileup has at most three distinct symbols and depths far
+ * below 65 536: such a line's record is packed into a snpgpu_line_record — everything consensus.vcf prints for it
+ * (vcf_writer.py:295-379) — and only the others ("wide": more symbols, a count above 65 535, a spill record, a Record-level error)
+ * come back as the full 128-byte record, with their line index.  5 M lines: 200 MB over the host link instead of 685 MB.
+ *   good_depth = total[0] + total[1] + total[2], forward_good_depth = sum of fwd[], reverse_good_depth = sum of rev[]
+ * (each kept read base counts for exactly one symbol; a line is only packed when these sums hold).
+ * out_records[i] is line i of the file (n_symbols == SNPGPU_LINE_WIDE: look the line up in out_wide_index, ascending, and take
+ * out_wide[k]).  *out_n_wide is always set; when it exceeds wide_capacity (or *out_n_lines exceeds capacity) nothing else is
+ * written and the caller comes back with larger arrays.  Other arguments and the status words as snpgpu_call_all_lines_file. */
+#define SNPGPU_LINE_WIDE 0xFF
+#define SNPGPU_LINE_SYMS 3
+typedef struct snpgpu_line_record {
+    uint32_t raw_depth;                     /* Record.raw_depth */
+    uint16_t total[SNPGPU_LINE_SYMS];       /* base_good_depth of the ranked symbols */
+    uint16_t fwd[SNPGPU_LINE_SYMS];
+    uint16_t rev[SNPGPU_LINE_SYMS];
+    uint8_t  sym[SNPGPU_LINE_SYMS];         /* most_common_good_bases[0..3) */
+    uint8_t  ref_base, cons_base, filters, status;      /* as in snpgpu_site_counts */
+    uint8_t  n_symbols;                     /* 0 .. 3, or SNPGPU_LINE_WIDE */
+    uint8_t  site_flags;                    /* SNPGPU_SITE_* of the line's position (0: not in the site set) */
+    uint8_t  reserved;
+} snpgpu_line_record;
+int  snpgpu_call_all_lines_compact_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const char *path,
+                                        const snpgpu_caller_params *params, uint64_t capacity, uint64_t *out_n_lines,
+                                        uint64_t *out_line_off, snpgpu_line_record *out_records,
+                                        uint32_t wide_capacity, uint32_t *out_n_wide, uint32_t *out_wide_index,
+                                        snpgpu_site_counts *out_wide, uint64_t *out_status);
+
+/* call_consensus --vcfAllPos from file to file: every row of consensus.vcf (call_consensus.py:148-151, vcf_writer.py:381-435: one
+ * row per pileup LINE, in file order; CHROM and POS are the line's own first two fields, POS as int() prints it) formatted by the
+ * library's host threads from the 32-byte records, straight into vcf_path behind `header` (the text of the header lines).
+ * only_listed != 0: rows for the lines whose position is in the site set only (a pileup that repeats positions: the reference
+ * writes a row for every matching line, call_consensus.py:178-180).  The file is written only when no line stops the reference:
+ *   returns SNPGPU_E_PILEUP / SNPGPU_E_UNSUPPORTED with out_status as snpgpu_call_all_lines_file for a malformed chrom / position
+ *   column; returns SNPGPU_OK with *out_first_bad_line != UINT64_MAX (and that line's record and offset + 1) when `check` is set
+ *   and a Record cannot be built from some line (status > SNPGPU_ST_OK) — the caller raises what the reference raises.
+ * *out_n_rows: rows written.  filter_names, preserve_ref_case, failed_snp_gt as snpgpu_format_vcf_rows. */
+int  snpgpu_write_all_positions_vcf(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const char *pileup_path,
+                                    const snpgpu_caller_params *params, const char *vcf_path, const char *header,
+                                    const char *const *filter_names, int preserve_ref_case, char failed_snp_gt,
+                                    int only_listed, int check, uint64_t *out_n_lines, uint64_t *out_n_rows,
+                                    uint64_t *out_first_bad_line, uint64_t *out_first_bad_off, snpgpu_site_counts *out_first_bad,
+                                    uint64_t *out_status);
+
 /* ---- phase-1 site calling: the counting + selection half of `VarScan mpileup2snp` -------------------------------
  * Replaces what call_sites.py:89-108 gets from the VarScan v2.3.9 jar (a third-party dependency that is not in the
  * reference tree): VarScan.qualityDepth, VarScan.getReadCounts and the min-coverage / min-reads2 / min-avg-qual /

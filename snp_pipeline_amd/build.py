@@ -19,7 +19,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libsnpgpu.so")
-SOURCES = ["ctx.hip", "host_budget.hip", "scan.hip", "consensus.hip", "stream.hip", "varscan.hip", "varscan_rows.hip", "vcf_rows.hip", "tsv_out.hip", "fasta_in.hip", "vcf_in.hip", "distance.hip", "regions.hip", "synth.hip", "flows.hip", "comm.hip"]
+SOURCES = ["ctx.hip", "host_budget.hip", "scan.hip", "consensus.hip", "stream.hip", "varscan.hip", "varscan_rows.hip", "vcf_rows.hip", "tsv_out.hip", "fasta_in.hip", "vcf_in.hip", "distance.hip", "regions.hip", "synth.hip", "flows.hip", "lines_out.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
          "-Wno-unused-result"]
 

@@ -119,16 +119,13 @@ def _write_outputs(plan, dev, ss, snp_slots, res, file_flags=None):
             params = devmod.make_params(args.minBaseQual, args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
             own = ss if file_flags is ss.flags else devmod.SiteSet.from_arrays(dev, ss.contigs, ss.keys[file_flags != 0], file_flags[file_flags != 0])
             try:
-                line_off, line_flags, counts = dev.call_all_lines(own, plan.read_path, params, capacity=res.n_lines, check=bool(args.vcfAllPos))
+                vcf_writer.write_all_positions_vcf_from_pileup(dev, own, plan.vcf_path, plan.sample_name, args, plan.read_path, params,
+                                                               only_listed=not args.vcfAllPos, check=bool(args.vcfAllPos))
             except devmod.PileupFormatError as err:
                 _raise_as_reference(err, plan.read_path, bool(args.vcfAllPos))
             finally:
                 if own is not ss:
                     own.close()
-            if not args.vcfAllPos:
-                keep = np.nonzero(line_flags)[0]                # listed positions only
-                line_off, counts = line_off[keep], counts[keep]
-            vcf_writer.write_all_positions_vcf(plan.vcf_path, plan.sample_name, args, plan.read_path, line_off, counts, spill=dev.last_spill)
         else:
             vcf_writer.write_consensus_vcf(plan.vcf_path, plan.sample_name, args, ss, res, res.line_offsets, parsed=file_flags != 0)
     consensus = consensus_string(snp_slots, res).tobytes().decode("ascii")

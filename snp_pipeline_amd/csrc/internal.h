@@ -148,6 +148,19 @@ int snpgpu_enqueue_call_lines(snpgpu_ctx *ctx, const SampleDev *d_sample, const 
                               uint32_t n_lines, const snpgpu_caller_params *prm, uint8_t *d_out_base, uint8_t *d_out_filters,
                               snpgpu_site_counts *d_out_counts, uint32_t *d_todo_n = nullptr, uint64_t *d_todo = nullptr, uint64_t *d_todo2 = nullptr);
 // the call kernels over a scanned batch (consensus.hip); d_todo_n: 4 words (3 zeroed), d_todo / d_todo2: n * n_sites entries each;
+// lines_out.hip: the per-line records of --vcfAllPos packed into 24 bytes where they fit, the others gathered as they are
+size_t snpgpu_compact_lines_workspace_words(uint64_t n_lines);
+int snpgpu_enqueue_compact_lines(snpgpu_ctx *ctx, const snpgpu_site_counts *d_counts, const uint8_t *d_flags, uint64_t n_lines, snpgpu_line_record *d_recs,
+                                 uint32_t *ws, uint32_t **d_n_wide);
+int snpgpu_enqueue_gather_wide(snpgpu_ctx *ctx, const snpgpu_site_counts *d_counts, const snpgpu_line_record *d_recs, uint64_t n_lines, const uint32_t *ws,
+                               uint32_t capacity, uint32_t *d_wide_index, snpgpu_site_counts *d_wide);
+void snpgpu_expand_line_record(const snpgpu_line_record &r, snpgpu_site_counts *out);
+// vcf_rows.hip: consensus.vcf rows of the lines [lo, hi) from those records (host)
+bool snpgpu_format_line_rows(const uint8_t *text, uint64_t nbytes, const uint64_t *line_off, const snpgpu_line_record *recs, uint64_t first, uint64_t lo, uint64_t hi,
+                             const uint32_t *wide_index, const snpgpu_site_counts *wide, uint32_t n_wide, const char *const *filter_names,
+                             int preserve_ref_case, char failed_snp_gt, const snpgpu_symbol_spill *spill, uint32_t n_spill, int only_listed,
+                             std::vector<char> &out, uint64_t *n_rows, uint64_t *bad_line);
+
 // d_site_flags: nullptr = the site set's flags for every sample, else flags of sample i at d_site_flags + i * flags_stride
 int snpgpu_enqueue_call(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const SampleDev *d_table, uint32_t n,
                         const snpgpu_caller_params *prm, const uint64_t *d_site_line, uint8_t *d_out_base,

@@ -22,6 +22,7 @@
 #include <sched.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -760,24 +761,37 @@ int snpgpu_call_consensus(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const uint8
     return SNPGPU_OK;
 }
 
-// call_consensus --vcfAllPos (call_consensus.py:148-151, pileup.py:418-421): a Record for EVERY line of the pileup.
-// Synchronous, host outputs in file order: out_line_off[i] = 1 + byte offset of line i, out_line_flags[i] = SNPGPU_SITE_*
-// of its position (0 when it is not in the site set), out_counts[i] its record.  *out_n_lines is always set; when it
-// exceeds `capacity` nothing else is written and the caller comes back with larger arrays.  out_status: scan status words
-// ([0] = first line whose chrom / position columns are malformed, [1] = number of lines).
-int snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const char *path, const snpgpu_caller_params *params,
-                               uint64_t capacity, uint64_t *out_n_lines, uint64_t *out_line_off, uint8_t *out_line_flags,
-                               snpgpu_site_counts *out_counts, uint64_t *out_status) {
-    if (!ctx || !ss || !path || !params || !out_n_lines || !out_status) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
-    if (capacity && (!out_line_off || !out_line_flags || !out_counts)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
-    HIP_TRY(ctx, snpgpu_enter(ctx));
+}  // extern "C"
+
+namespace {
+
+// The all-lines pass on the device (--vcfAllPos): the file into device memory, its line index, a record per line.  What it leaves
+// behind lives in the context's scratch (valid until the next call that takes scratch); nothing has been copied back but the number
+// of lines.  With `compact`: also the 24-byte records and the count of the wide ones (lines_out.hip).
+struct AllLines {
     uint8_t *d_file = nullptr;
     uint64_t nbytes = 0;
+    uint32_t n_lines = 0;
+    uint64_t *d_off = nullptr;
+    uint8_t *d_flags = nullptr;
+    snpgpu_site_counts *d_counts = nullptr;
+    uint64_t *d_status = nullptr;
+    snpgpu_line_record *d_recs = nullptr;       // compact only
+    uint32_t *d_compact_ws = nullptr, *d_n_wide = nullptr;
+    uint32_t *d_wide_index = nullptr;           // room for n_lines of each: the gather's targets
+    snpgpu_site_counts *d_wide = nullptr;
+};
+
+// Returns SNPGPU_OK with al.n_lines set; when n_lines == 0 or n_lines > capacity nothing else has been done (al.d_counts == nullptr).
+int all_lines_pass(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const char *path, const snpgpu_caller_params *params, uint64_t capacity, bool compact,
+                   AllLines &al) {
     int rc = snpgpu_spill_begin(ctx);
     if (rc) return rc;
-    rc = load_file(ctx, path, &d_file, &nbytes);
+    rc = load_file(ctx, path, &al.d_file, &al.nbytes);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
+    const uint8_t *d_file = al.d_file;
+    const uint64_t nbytes = al.nbytes;
     const size_t ws_words = snpgpu_lines_workspace_words(nbytes);
     // first the count alone (its workspace is all the scratch it needs) ...
     void *scr = nullptr;
@@ -789,8 +803,7 @@ int snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const 
     uint32_t n_lines = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&n_lines, d_total, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    *out_n_lines = n_lines;
-    out_status[0] = ~0ull; out_status[1] = n_lines; out_status[2] = out_status[3] = 0;
+    al.n_lines = n_lines;
     if (n_lines > capacity || n_lines == 0) return SNPGPU_OK;
     // ... then everything: the scratch may move, so the count is redone in the new place (cheap next to the call step)
     size_t o = up(4 * ws_words, 256);
@@ -802,6 +815,10 @@ int snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const 
     const size_t o_samp = o; o += 256;
     const size_t o_cnt = o; o += up(sizeof(snpgpu_site_counts) * (size_t)n_lines, 256);
     const size_t o_todo = o; o += 2 * up(8ull * n_lines, 256) + 256;           // the lane kernels' leftover lists and their counts
+    const size_t o_rec = o; if (compact) o += up(sizeof(snpgpu_line_record) * (size_t)n_lines, 256);
+    const size_t o_cws = o; if (compact) o += up(4 * snpgpu_compact_lines_workspace_words(n_lines), 256);
+    const size_t o_widx = o; if (compact) o += up(4ull * n_lines, 256);
+    const size_t o_wide = o; if (compact) o += up(sizeof(snpgpu_site_counts) * (size_t)n_lines, 256);     // (every line may be wide; 288 GB of HBM)
     rc = snpgpu_scratch(ctx, o + 256, &scr);
     if (rc) return rc;
     char *b = (char *)scr;
@@ -821,13 +838,266 @@ int snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const 
                                        n_lines, params, (uint8_t *)(b + o_base), (uint8_t *)(b + o_filt), (snpgpu_site_counts *)(b + o_cnt),
                                        (uint32_t *)(b + o_todo), (uint64_t *)(b + o_todo + 256), (uint64_t *)(b + o_todo + 256 + up(8ull * n_lines, 256)));
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(out_line_off, b + o_off, 8ull * n_lines, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(out_line_flags, b + o_flag, n_lines, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(out_counts, b + o_cnt, sizeof(snpgpu_site_counts) * (size_t)n_lines, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(out_status, b + o_stat, 8 * SNPGPU_SCAN_STATUS_WORDS, hipMemcpyDeviceToHost, st));
+    al.d_off = (uint64_t *)(b + o_off);
+    al.d_flags = (uint8_t *)(b + o_flag);
+    al.d_counts = (snpgpu_site_counts *)(b + o_cnt);
+    al.d_status = (uint64_t *)(b + o_stat);
+    if (compact) {
+        al.d_recs = (snpgpu_line_record *)(b + o_rec);
+        al.d_compact_ws = (uint32_t *)(b + o_cws);
+        al.d_wide_index = (uint32_t *)(b + o_widx);
+        al.d_wide = (snpgpu_site_counts *)(b + o_wide);
+        rc = snpgpu_enqueue_compact_lines(ctx, al.d_counts, al.d_flags, n_lines, al.d_recs, al.d_compact_ws, &al.d_n_wide);
+    }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+// call_consensus --vcfAllPos (call_consensus.py:148-151, pileup.py:418-421): a Record for EVERY line of the pileup.
+// Synchronous, host outputs in file order: out_line_off[i] = 1 + byte offset of line i, out_line_flags[i] = SNPGPU_SITE_*
+// of its position (0 when it is not in the site set), out_counts[i] its record.  *out_n_lines is always set; when it
+// exceeds `capacity` nothing else is written and the caller comes back with larger arrays.  out_status: scan status words
+// ([0] = first line whose chrom / position columns are malformed, [1] = number of lines).
+int snpgpu_call_all_lines_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const char *path, const snpgpu_caller_params *params,
+                               uint64_t capacity, uint64_t *out_n_lines, uint64_t *out_line_off, uint8_t *out_line_flags,
+                               snpgpu_site_counts *out_counts, uint64_t *out_status) {
+    if (!ctx || !ss || !path || !params || !out_n_lines || !out_status) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (capacity && (!out_line_off || !out_line_flags || !out_counts)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
+    HIP_TRY(ctx, snpgpu_enter(ctx));
+    AllLines al;
+    int rc = all_lines_pass(ctx, ss, path, params, capacity, false, al);
+    if (rc) return rc;
+    const uint32_t n_lines = al.n_lines;
+    *out_n_lines = n_lines;
+    out_status[0] = ~0ull; out_status[1] = n_lines; out_status[2] = out_status[3] = 0;
+    if (!al.d_counts) return SNPGPU_OK;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(out_line_off, al.d_off, 8ull * n_lines, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(out_line_flags, al.d_flags, n_lines, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(out_counts, al.d_counts, sizeof(snpgpu_site_counts) * (size_t)n_lines, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(out_status, al.d_status, 8 * SNPGPU_SCAN_STATUS_WORDS, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     out_status[1] = n_lines;
     if (out_status[0] != ~0ull) return scan_status_error(ctx, out_status, path);
+    return SNPGPU_OK;
+}
+
+// The same with 24-byte records: see include/snpgpu.h.
+int snpgpu_call_all_lines_compact_file(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const char *path, const snpgpu_caller_params *params,
+                                       uint64_t capacity, uint64_t *out_n_lines, uint64_t *out_line_off, snpgpu_line_record *out_records,
+                                       uint32_t wide_capacity, uint32_t *out_n_wide, uint32_t *out_wide_index, snpgpu_site_counts *out_wide,
+                                       uint64_t *out_status) {
+    if (!ctx || !ss || !path || !params || !out_n_lines || !out_n_wide || !out_status) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    if (capacity && (!out_line_off || !out_records)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
+    if (wide_capacity && (!out_wide_index || !out_wide)) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null output");
+    HIP_TRY(ctx, snpgpu_enter(ctx));
+    AllLines al;
+    int rc = all_lines_pass(ctx, ss, path, params, capacity, true, al);
+    if (rc) return rc;
+    const uint32_t n_lines = al.n_lines;
+    *out_n_lines = n_lines;
+    *out_n_wide = 0;
+    out_status[0] = ~0ull; out_status[1] = n_lines; out_status[2] = out_status[3] = 0;
+    if (!al.d_counts) return SNPGPU_OK;
+    hipStream_t st = ctx->stream;
+    uint32_t n_wide = 0;
+    // the bulk goes while the host learns how many wide lines there are
+    HIP_TRY(ctx, hipMemcpyAsync(&n_wide, al.d_n_wide, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(out_status, al.d_status, 8 * SNPGPU_SCAN_STATUS_WORDS, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    *out_n_wide = n_wide;
+    out_status[1] = n_lines;
+    if (out_status[0] != ~0ull) return scan_status_error(ctx, out_status, path);
+    if (n_wide > wide_capacity) return SNPGPU_OK;                 // the caller comes back with room for them
+    HIP_TRY(ctx, hipMemcpyAsync(out_line_off, al.d_off, 8ull * n_lines, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(out_records, al.d_recs, sizeof(snpgpu_line_record) * (size_t)n_lines, hipMemcpyDeviceToHost, st));
+    if (n_wide) {
+        rc = snpgpu_enqueue_gather_wide(ctx, al.d_counts, al.d_recs, n_lines, al.d_compact_ws, n_wide, al.d_wide_index, al.d_wide);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(out_wide_index, al.d_wide_index, 4ull * n_wide, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(out_wide, al.d_wide, sizeof(snpgpu_site_counts) * (size_t)n_wide, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return SNPGPU_OK;
+}
+
+// --vcfAllPos from file to file: see include/snpgpu.h.  The records come back in pieces into pinned memory while host threads format the
+// rows of the pieces that have landed; the pileup's own text (CHROM and POS of every row) is read through a private mapping of the file,
+// which the load has just pulled into the page cache.
+int snpgpu_write_all_positions_vcf(snpgpu_ctx *ctx, const snpgpu_siteset *ss, const char *pileup_path, const snpgpu_caller_params *params,
+                                   const char *vcf_path, const char *header, const char *const *filter_names, int preserve_ref_case,
+                                   char failed_snp_gt, int only_listed, int check, uint64_t *out_n_lines, uint64_t *out_n_rows,
+                                   uint64_t *out_first_bad_line, uint64_t *out_first_bad_off, snpgpu_site_counts *out_first_bad, uint64_t *out_status) {
+    if (!ctx || !ss || !pileup_path || !params || !vcf_path || !header || !filter_names || !out_n_lines || !out_n_rows || !out_first_bad_line ||
+        !out_first_bad_off || !out_first_bad || !out_status)
+        return snpgpu_set_error(ctx, SNPGPU_E_ARG, "null argument");
+    HIP_TRY(ctx, snpgpu_enter(ctx));
+    *out_n_lines = *out_n_rows = 0;
+    *out_first_bad_line = ~0ull;
+    *out_first_bad_off = 0;
+    hipStream_t st = ctx->stream;
+    AllLines al;
+    uint32_t n_lines = 0, n_wide = 0, n_spill = 0;
+    bool scan_bad = false;
+    std::vector<snpgpu_symbol_spill> spill;
+    for (int attempt = 0;; ++attempt) {                          // (again when the positions asked for more spill records than the arena held)
+        al = AllLines();
+        int rc = all_lines_pass(ctx, ss, pileup_path, params, ~0ull, true, al);
+        if (rc) return rc;
+        n_lines = al.n_lines;
+        *out_n_lines = n_lines;
+        out_status[0] = ~0ull; out_status[1] = n_lines; out_status[2] = out_status[3] = 0;
+        if (!al.d_counts) break;                                 // an empty file: the header alone
+        HIP_TRY(ctx, hipMemcpyAsync(&n_wide, al.d_n_wide, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(&n_spill, ctx->d_spill_n, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(out_status, al.d_status, 8 * SNPGPU_SCAN_STATUS_WORDS, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        out_status[1] = n_lines;
+        scan_bad = out_status[0] != ~0ull;       // (reported below, after a look for an earlier line that a Record cannot be built from)
+        if (scan_bad || n_spill <= ctx->spill_cap) break;
+        if (attempt >= 4 || n_spill > 0xFFFFFEu) return snpgpu_set_error(ctx, SNPGPU_E_UNSUPPORTED, "%u lines of %s need a spill record", n_spill, pileup_path);
+        const uint64_t want = (uint64_t)n_spill + n_spill / 4 + 64;
+        ctx->spill_want = want > 0xFFFFFEull ? 0xFFFFFEu : (uint32_t)want;
+    }
+    // the wide lines (few) and the spill records they point at: all at once
+    std::vector<uint32_t> wide_index(n_wide);
+    std::vector<snpgpu_site_counts> wide(n_wide);
+    if (al.d_counts && n_wide) {
+        int rc = snpgpu_enqueue_gather_wide(ctx, al.d_counts, al.d_recs, n_lines, al.d_compact_ws, n_wide, al.d_wide_index, al.d_wide);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(wide_index.data(), al.d_wide_index, 4ull * n_wide, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(wide.data(), al.d_wide, sizeof(snpgpu_site_counts) * (size_t)n_wide, hipMemcpyDeviceToHost, st));
+        if (n_spill > ctx->spill_cap) n_spill = ctx->spill_cap;
+        spill.resize(n_spill);
+        if (n_spill) HIP_TRY(ctx, hipMemcpyAsync(spill.data(), ctx->d_spill, sizeof(snpgpu_symbol_spill) * (size_t)n_spill, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (check)
+            for (uint32_t k = 0; k < n_wide; ++k)
+                if (wide[k].status > SNPGPU_ST_OK) {             // the first line a Record cannot be built from: the caller raises, nothing is written
+                    *out_first_bad_line = wide_index[k];
+                    *out_first_bad = wide[k];
+                    HIP_TRY(ctx, hipMemcpy(out_first_bad_off, al.d_off + wide_index[k], 8, hipMemcpyDeviceToHost));
+                    break;
+                }
+    }
+    if (scan_bad) return scan_status_error(ctx, out_status, pileup_path);
+    if (*out_first_bad_line != ~0ull) return SNPGPU_OK;
+    // the pileup's text for CHROM / POS
+    const uint8_t *text = nullptr;
+    int pfd = -1;
+    if (n_lines) {
+        pfd = open(pileup_path, O_RDONLY | O_CLOEXEC);
+        void *m = pfd >= 0 ? mmap(nullptr, al.nbytes, PROT_READ, MAP_PRIVATE, pfd, 0) : MAP_FAILED;
+        if (m == MAP_FAILED) { if (pfd >= 0) close(pfd); return snpgpu_set_error(ctx, SNPGPU_E_IO, "cannot map the pileup file %s", pileup_path); }
+        text = (const uint8_t *)m;
+    }
+    const int vfd = open(vcf_path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+    std::atomic<bool> io_ok{vfd >= 0};
+    const size_t header_len = strlen(header);
+    // pieces of lines: offsets + records of a piece come back into one pinned buffer each (two copies on the stream, an event behind
+    // them); a pool of threads takes the pieces in order, formats, and writes its text at the offset the pieces before it end at
+    const uint64_t piece = 1u << 16;                              // 65 536 lines: 2.5 MiB of offsets and records
+    const uint64_t n_pieces = (n_lines + piece - 1) / piece;
+    const size_t part_bytes = (size_t)4 << 20;                    // the load's pinned staging ring (16 MiB buffers), in parts of 4 MiB
+    static_assert((size_t)(1u << 16) * (8 + sizeof(snpgpu_line_record)) <= ((size_t)4 << 20), "a piece fits a part");
+    snpgpu_stream_pool *pool_ = ctx->pool;
+    const uint32_t parts_per = pool_ ? (uint32_t)(pool_->chunk_bytes / part_bytes) : 0;
+    const uint32_t parts = pool_ ? (uint32_t)pool_->staging.size() * parts_per : 0;
+    if (n_pieces && parts < 2) return snpgpu_set_error(ctx, SNPGPU_E_NOMEM, "no pinned staging memory for the records");
+    const uint32_t T = n_pieces ? (uint32_t)std::min<uint64_t>(std::min<uint32_t>(snpgpu_cpu_threads(64), parts - 1), n_pieces) : 0;
+    const uint32_t R = n_pieces ? (uint32_t)std::min<uint64_t>(std::min<uint32_t>(T + 2, parts), n_pieces) : 0;          // parts in flight
+    std::vector<void *> pinned(R, nullptr);
+    std::vector<hipEvent_t> ev(R, nullptr);
+    hipError_t he = hipSuccess;
+    for (uint32_t k = 0; k < R && he == hipSuccess; ++k) {
+        pinned[k] = (char *)pool_->staging[k / parts_per] + (size_t)(k % parts_per) * part_bytes;
+        he = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+    }
+    struct Piece { std::vector<char> text; uint64_t rows = 0; bool done = false, bad = false; uint64_t bad_line = 0; };
+    std::vector<Piece> out(n_pieces);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int> landed(n_pieces, 0);                       // 1: its copies were enqueued (the event tells when they are done)
+    std::vector<int> buffer_free(R, 1);
+    std::atomic<uint64_t> next_piece{0};
+    uint64_t written_upto = 0, file_off = header_len;           // (under mu) pieces whose text is in the file
+    bool abort_all = he != hipSuccess;
+    auto worker = [&]() {
+        (void)hipSetDevice(ctx->device);
+        for (;;) {
+            const uint64_t pi = next_piece.fetch_add(1);
+            if (pi >= n_pieces) return;
+            const uint32_t k = (uint32_t)(pi % R);
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return landed[pi] || abort_all; }); if (abort_all) return; }
+            if (hipEventSynchronize(ev[k]) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); abort_all = true; cv.notify_all(); return; }
+            const uint64_t lo = pi * piece, hi = std::min<uint64_t>(n_lines, lo + piece);
+            const uint64_t *off = (const uint64_t *)pinned[k];
+            const snpgpu_line_record *recs = (const snpgpu_line_record *)((const char *)pinned[k] + 8 * piece);
+            Piece &pc = out[pi];
+            pc.text.reserve((size_t)(hi - lo) * 96);
+            pc.bad = !snpgpu_format_line_rows(text, al.nbytes, off, recs, lo, lo, hi, wide_index.data(), wide.data(), n_wide, filter_names, preserve_ref_case,
+                                              failed_snp_gt, spill.data(), n_spill, only_listed, pc.text, &pc.rows, &pc.bad_line);
+            std::unique_lock<std::mutex> lk(mu);
+            buffer_free[k] = 1;
+            pc.done = true;
+            cv.notify_all();
+            // the file is written in piece order by whoever finishes the piece that is next in line
+            while (written_upto < n_pieces && out[written_upto].done && !abort_all) {
+                Piece &w = out[written_upto];
+                const uint64_t at = file_off;
+                file_off += w.text.size();
+                const uint64_t me = written_upto++;
+                lk.unlock();
+                if (io_ok && !w.bad) {
+                    const char *p = w.text.data();
+                    size_t left = w.text.size();
+                    uint64_t pos = at;
+                    while (left) {
+                        const ssize_t wr = pwrite(vfd, p, left, (off_t)pos);
+                        if (wr < 0) { if (errno == EINTR) continue; io_ok = false; break; }
+                        p += wr; left -= (size_t)wr; pos += (uint64_t)wr;
+                    }
+                }
+                std::vector<char>().swap(out[me].text);
+                lk.lock();
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    if (!abort_all) for (uint32_t t = 0; t < T; ++t) pool.emplace_back(worker);
+    if (io_ok && header_len) {
+        size_t left = header_len; const char *p = header; uint64_t pos = 0;
+        while (left) { const ssize_t wr = pwrite(vfd, p, left, (off_t)pos); if (wr < 0) { if (errno == EINTR) continue; io_ok = false; break; } p += wr; left -= (size_t)wr; pos += (uint64_t)wr; }
+    }
+    for (uint64_t pi = 0; pi < n_pieces && !abort_all; ++pi) {
+        const uint32_t k = (uint32_t)(pi % R);
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return buffer_free[k] || abort_all; }); if (abort_all) break; buffer_free[k] = 0; }
+        const uint64_t lo = pi * piece, hi = std::min<uint64_t>(n_lines, lo + piece);
+        he = hipMemcpyAsync(pinned[k], al.d_off + lo, 8 * (hi - lo), hipMemcpyDeviceToHost, st);
+        if (he == hipSuccess) he = hipMemcpyAsync((char *)pinned[k] + 8 * piece, al.d_recs + lo, sizeof(snpgpu_line_record) * (hi - lo), hipMemcpyDeviceToHost, st);
+        if (he == hipSuccess) he = hipEventRecord(ev[k], st);
+        std::lock_guard<std::mutex> lk(mu);
+        if (he != hipSuccess) abort_all = true; else landed[pi] = 1;
+        cv.notify_all();
+    }
+    { std::lock_guard<std::mutex> lk(mu); cv.notify_all(); }
+    for (auto &t : pool) t.join();
+    (void)hipStreamSynchronize(st);
+    for (uint32_t k = 0; k < R; ++k) if (ev[k]) (void)hipEventDestroy(ev[k]);
+    if (text) { munmap((void *)text, al.nbytes); close(pfd); }
+    uint64_t rows = 0, bad_line = ~0ull;
+    for (auto &pc : out) { rows += pc.rows; if (pc.bad && bad_line == ~0ull) bad_line = pc.bad_line; }
+    if (vfd >= 0) {
+        if (io_ok && ftruncate(vfd, (off_t)file_off) != 0) io_ok = false;
+        if (close(vfd) != 0) io_ok = false;
+    }
+    if (he != hipSuccess || abort_all) return snpgpu_set_error(ctx, SNPGPU_E_HIP, "reading the records of %s back failed: %s", pileup_path, hipGetErrorString(he));
+    if (bad_line != ~0ull) return snpgpu_set_error(ctx, SNPGPU_E_UNSUPPORTED, "line %llu of %s has more symbols than a record keeps and no spill record", (unsigned long long)bad_line, pileup_path);
+    if (!io_ok) return snpgpu_set_error(ctx, SNPGPU_E_IO, "cannot write %s", vcf_path);
+    *out_n_rows = rows;
     return SNPGPU_OK;
 }
 

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <vector>
 
 #include "internal.h"
 
@@ -34,8 +35,10 @@ struct Out {
 
 // One data line.  `mask`: the failed-filter bits of the row (the record's own, or — for the preserved flow of the pipeline —
 // the record's plus Region).  Returns false for a record with more symbols than it keeps.
+// head / head_len (nullable): "CHROM\tPOS" as text, for rows whose position is the pileup line's own (--vcfAllPos) instead of a site key.
 bool put_row(Out &o, const snpgpu_site_counts &c, uint32_t mask, uint64_t key, const uint8_t *contig_names, const uint32_t *contig_name_off,
-             const char *const *filter_names, int preserve_ref_case, char failed_snp_gt, const snpgpu_symbol_spill *spill, uint32_t n_spill) {
+             const char *const *filter_names, int preserve_ref_case, char failed_snp_gt, const snpgpu_symbol_spill *spill, uint32_t n_spill,
+             const char *head = nullptr, size_t head_len = 0) {
     // the ranked symbols: eight in the record, the rest (rare) in the position's spill record
     const uint32_t n_symbols = c.n_symbols & 0xFFu, spill_code = c.n_symbols >> 8;
     const snpgpu_symbol_spill *more = nullptr;
@@ -82,9 +85,12 @@ bool put_row(Out &o, const snpgpu_site_counts &c, uint32_t mask, uint64_t key, c
         gt = n_alt == 0 ? '0' : (!long_ref && sym_of(0) == upper_ref ? '0' : '1');
         if (failed) gt = failed_snp_gt == '.' ? '.' : (failed_snp_gt == '0' ? '0' : '1');
     }
-    const uint32_t cid = (uint32_t)(key >> 32);
-    o.putn((const char *)contig_names + contig_name_off[cid], contig_name_off[cid + 1] - contig_name_off[cid]);
-    o.put('\t'); o.putu(key & 0xFFFFFFFFull);
+    if (head) o.putn(head, head_len);
+    else {
+        const uint32_t cid = (uint32_t)(key >> 32);
+        o.putn((const char *)contig_names + contig_name_off[cid], contig_name_off[cid + 1] - contig_name_off[cid]);
+        o.put('\t'); o.putu(key & 0xFFFFFFFFull);
+    }
     o.puts_("\t.\t");
     if (long_ref) {
         const uint8_t *field = (const uint8_t *)(more + 1) - SNPGPU_SPILL_REF;        // = more->ref, and on into the next records
@@ -112,6 +118,85 @@ bool put_row(Out &o, const snpgpu_site_counts &c, uint32_t mask, uint64_t key, c
     if (n_alt == 0) o.put('0'); else for (int k = 0; k < n_alt; ++k) { if (k) o.put(','); o.putu(rev_of(alt[k])); }
     o.put(':'); o.putn(ft, ftn); o.put('\n');
     return true;
+}
+
+// ---- rows of --vcfAllPos: one per pileup line, CHROM and POS from the line's own text ---------------------------------------------
+__host__ inline bool host_is_ws(uint8_t c) { return (uint8_t)(c - 9u) <= 4u || (uint8_t)(c - 28u) <= 4u; }     // str.split() on ASCII (pileup.py:424)
+
+inline char *put_u32(char *p, uint32_t v) {
+    char tmp[10];
+    int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10u); v /= 10u; } while (v);
+    while (k) *p++ = tmp[--k];
+    return p;
+}
+
+// "CHROM\tPOS" of the line that starts at text[at]: the first two whitespace-separated fields (fields = line.split(), pileup.py:424),
+// POS the way str(int(field)) prints it (sign, leading zeros and underscores gone: pileup.py:426, vcf_writer.py:406).  The scan has
+// already refused lines without two fields or with a position int() does not take.  Returns the bytes written to `out` (cap bytes), or
+// 0 when they do not fit.
+size_t line_head(const uint8_t *text, uint64_t n, uint64_t at, char *out, size_t cap) {
+    uint64_t p = at;
+    while (p < n && host_is_ws(text[p]) && text[p] != '\n' && text[p] != '\r') ++p;
+    const uint64_t c0 = p;
+    while (p < n && !host_is_ws(text[p])) ++p;
+    const uint64_t c1 = p;
+    while (p < n && host_is_ws(text[p]) && text[p] != '\n' && text[p] != '\r') ++p;
+    const uint64_t p0 = p;
+    while (p < n && !host_is_ws(text[p])) ++p;
+    const uint64_t p1 = p;
+    if (c1 - c0 + (p1 - p0) + 3 > cap) return 0;
+    size_t k = 0;
+    memcpy(out, text + c0, c1 - c0); k += c1 - c0;
+    out[k++] = '\t';
+    uint64_t q = p0;
+    bool neg = false;
+    if (q < p1 && (text[q] == '+' || text[q] == '-')) { neg = text[q] == '-'; ++q; }
+    while (q < p1 && (text[q] == '0' || text[q] == '_')) ++q;            // leading zeros (and the underscores between them)
+    if (q == p1) { out[k++] = '0'; return k; }                            // int("-0") prints 0
+    if (neg) out[k++] = '-';
+    for (; q < p1; ++q) if (text[q] != '_') out[k++] = (char)text[q];
+    return k;
+}
+
+// The row of a packed record (at most three symbols: vcf_writer.py:295-379 with every list up to three long), written with plain
+// pointer stores: `p` has room for SNPGPU_PACKED_ROW_MAX bytes beside the head.
+constexpr size_t PACKED_ROW_TAIL_MAX = 192;
+char *put_packed_row(char *p, const snpgpu_line_record &r, const char *ft, size_t ftn, bool failed, int preserve_ref_case, char failed_snp_gt) {
+    char ref = (char)r.ref_base, upper_ref = ref;
+    if (upper_ref >= 'a' && upper_ref <= 'z') upper_ref = (char)(upper_ref - 32);
+    if (!preserve_ref_case) ref = upper_ref;
+    const uint32_t nsym = r.n_symbols;
+    const bool none = (uint32_t)r.total[0] + r.total[1] + r.total[2] == 0;
+    int ref_at = -1, alt[SNPGPU_LINE_SYMS], n_alt = 0;
+    for (uint32_t k = 0; k < nsym; ++k) { if ((char)r.sym[k] == upper_ref) ref_at = (int)k; else alt[n_alt++] = (int)k; }
+    char gt;
+    if (none) { gt = '.'; n_alt = 0; }
+    else {
+        gt = n_alt == 0 ? '0' : ((char)r.sym[0] == upper_ref ? '0' : '1');
+        if (failed) gt = failed_snp_gt == '.' ? '.' : (failed_snp_gt == '0' ? '0' : '1');
+    }
+    memcpy(p, "\t.\t", 3); p += 3;
+    *p++ = ref; *p++ = '\t';
+    if (n_alt == 0) *p++ = '.';
+    else for (int k = 0; k < n_alt; ++k) { if (k) *p++ = ','; *p++ = (char)r.sym[alt[k]]; }
+    memcpy(p, "\t.\t", 3); p += 3;
+    memcpy(p, ft, ftn); p += ftn;
+    static const char mid[] = "\tNS=1\tGT:SDP:RD:AD:RDF:RDR:ADF:ADR:FT\t";
+    memcpy(p, mid, sizeof mid - 1); p += sizeof mid - 1;
+    *p++ = gt; *p++ = ':';
+    p = put_u32(p, r.raw_depth); *p++ = ':';
+    const bool have_ref = ref_at >= 0 && !none;
+    p = put_u32(p, have_ref ? r.total[ref_at] : 0u); *p++ = ':';
+    if (n_alt == 0) *p++ = '0'; else for (int k = 0; k < n_alt; ++k) { if (k) *p++ = ','; p = put_u32(p, r.total[alt[k]]); }
+    *p++ = ':'; p = put_u32(p, have_ref ? r.fwd[ref_at] : 0u);
+    *p++ = ':'; p = put_u32(p, have_ref ? r.rev[ref_at] : 0u); *p++ = ':';
+    if (n_alt == 0) *p++ = '0'; else for (int k = 0; k < n_alt; ++k) { if (k) *p++ = ','; p = put_u32(p, r.fwd[alt[k]]); }
+    *p++ = ':';
+    if (n_alt == 0) *p++ = '0'; else for (int k = 0; k < n_alt; ++k) { if (k) *p++ = ','; p = put_u32(p, r.rev[alt[k]]); }
+    *p++ = ':'; memcpy(p, ft, ftn); p += ftn;
+    *p++ = '\n';
+    return p;
 }
 
 bool write_all(const char *path, const char *a, size_t na, const char *b, size_t nb) {
@@ -185,6 +270,77 @@ void write_consensus_job(snpgpu_consensus_job &job, uint32_t n_sites, const uint
 }
 
 }  // namespace
+
+// Rows of the lines [lo, hi) of a pileup whose bytes are text[0, nbytes): appended to `out`.  recs[i - first] / line_off[i - first] belong to line i;
+// wide lines (recs[i].n_symbols == SNPGPU_LINE_WIDE) take their full record from wide[] — wide_index is ascending, so a range walks
+// it from its first entry on.  only_listed: rows for the lines whose position is in the site set only.  Returns false for a record
+// the writer refuses (more symbols than it keeps and no spill record): *bad_line says which.
+bool snpgpu_format_line_rows(const uint8_t *text, uint64_t nbytes, const uint64_t *line_off, const snpgpu_line_record *recs, uint64_t first, uint64_t lo, uint64_t hi,
+                             const uint32_t *wide_index, const snpgpu_site_counts *wide, uint32_t n_wide, const char *const *filter_names,
+                             int preserve_ref_case, char failed_snp_gt, const snpgpu_symbol_spill *spill, uint32_t n_spill, int only_listed,
+                             std::vector<char> &out, uint64_t *n_rows, uint64_t *bad_line) {
+    // the FT text of every filter mask (64 of them), once
+    char ft_text[64][256];
+    size_t ft_len[64];
+    for (uint32_t mask = 0; mask < 64; ++mask) {
+        size_t ftn = 0;
+        for (int b = 0; b < 6; ++b)
+            if (mask >> b & 1) {
+                const size_t len = strlen(filter_names[b]);
+                if (ftn + len + 2 < sizeof ft_text[0]) {
+                    if (ftn) ft_text[mask][ftn++] = ';';
+                    memcpy(ft_text[mask] + ftn, filter_names[b], len);
+                    ftn += len;
+                }
+            }
+        if (!ftn) { memcpy(ft_text[mask], "PASS", 4); ftn = 4; }
+        ft_len[mask] = ftn;
+    }
+    uint32_t w = (uint32_t)(std::lower_bound(wide_index, wide_index + n_wide, (uint32_t)lo) - wide_index);
+    size_t used = out.size();
+    uint64_t rows = 0;
+    char head[512];
+    std::vector<char> long_head;
+    for (uint64_t i = lo; i < hi; ++i) {
+        const snpgpu_line_record &r = recs[i - first];
+        const bool is_wide = r.n_symbols == SNPGPU_LINE_WIDE;
+        const uint32_t wi = is_wide ? w++ : 0u;
+        if (only_listed && !r.site_flags) continue;
+        const uint64_t at = line_off[i - first] - 1;
+        const char *hp = head;
+        size_t hn = line_head(text, nbytes, at, head, sizeof head);
+        if (!hn) {                                               // a contig name of hundreds of bytes
+            uint64_t e = at;
+            while (e < nbytes && text[e] != '\n' && text[e] != '\r') ++e;
+            long_head.resize((size_t)(e - at) + 8);
+            hn = line_head(text, nbytes, at, long_head.data(), long_head.size());
+            hp = long_head.data();
+        }
+        if (!is_wide) {
+            const uint32_t mask = r.filters & 0x3Fu;
+            const size_t need = hn + PACKED_ROW_TAIL_MAX + 2 * ft_len[mask];
+            if (out.size() < used + need) out.resize((used + need) * 2);
+            char *p = out.data() + used;
+            memcpy(p, hp, hn);
+            p = put_packed_row(p + hn, r, ft_text[mask], ft_len[mask], mask != 0, preserve_ref_case, failed_snp_gt);
+            used = (size_t)(p - out.data());
+        } else {
+            if (wi >= n_wide || wide_index[wi] != (uint32_t)i) { *bad_line = i; return false; }
+            const snpgpu_site_counts &c = wide[wi];
+            for (;;) {
+                Out o{out.data() + used, out.size() - used, 0};
+                if (!put_row(o, c, c.filters & 0x3Fu, 0, nullptr, nullptr, filter_names, preserve_ref_case, failed_snp_gt, spill, n_spill, hp, hn)) { *bad_line = i; return false; }
+                if (o.n > o.cap) { out.resize((used + o.n) * 2 + 4096); continue; }
+                used += o.n;
+                break;
+            }
+        }
+        ++rows;
+    }
+    out.resize(used);
+    *n_rows = rows;
+    return true;
+}
 
 extern "C" size_t snpgpu_format_vcf_rows(const snpgpu_site_counts *counts, const uint32_t *order, uint32_t n_rows,
                                          const uint8_t *contig_names, const uint32_t *contig_name_off, const uint64_t *site_keys,

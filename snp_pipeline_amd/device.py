@@ -17,6 +17,11 @@ COUNTS_DTYPE = np.dtype([
     ("sym", "u1", (L.MAX_SYMS,)), ("total", "<u4", (L.MAX_SYMS,)), ("fwd", "<u4", (L.MAX_SYMS,)),
     ("rev", "<u4", (L.MAX_SYMS,))])
 assert COUNTS_DTYPE.itemsize == 128
+LINE_WIDE, LINE_SYMS = 0xFF, 3
+LINE_DTYPE = np.dtype([("raw_depth", "<u4"), ("total", "<u2", (LINE_SYMS,)), ("fwd", "<u2", (LINE_SYMS,)), ("rev", "<u2", (LINE_SYMS,)),
+                       ("sym", "u1", (LINE_SYMS,)), ("ref_base", "u1"), ("cons_base", "u1"), ("filters", "u1"), ("status", "u1"),
+                       ("n_symbols", "u1"), ("site_flags", "u1"), ("reserved", "u1")])
+assert LINE_DTYPE.itemsize == 32
 VARSCAN_DTYPE = np.dtype([("line_off", "<u8"), ("sdp", "<u4"), ("dp", "<u4"), ("total", "<u4"), ("rdf", "<u4"), ("rdr", "<u4"),
                           ("ref_qual_sum", "<u4"), ("adf", "<u4"), ("adr", "<u4"), ("alt_qual_sum", "<u4"), ("ref_base", "u1"),
                           ("alt_base", "u1"), ("reserved", "u1", (2,))])
@@ -188,6 +193,25 @@ SPILL_DTYPE = np.dtype([("n", "<u4"), ("ref_len", "<u4"), ("depth64", "<i8"), ("
                         ("total", "<u4", (L.SPILL_SYMS,)), ("fwd", "<u4", (L.SPILL_SYMS,)), ("rev", "<u4", (L.SPILL_SYMS,)),
                         ("ref", "u1", (L.SPILL_REF,))])
 assert SPILL_DTYPE.itemsize == C.sizeof(L.SymbolSpill)
+
+
+def expand_line_records(recs, wide_index, wide):
+    """(site flags, COUNTS_DTYPE records) of every line from the 32-byte records and the wide lines' full ones — what call_all_lines
+    returns, rebuilt on the host (tests, and callers that want the per-line numbers rather than rows)."""
+    n = len(recs)
+    out = np.zeros(n, dtype=COUNTS_DTYPE)
+    for name in ("raw_depth", "ref_base", "cons_base", "filters", "status"):
+        out[name] = recs[name]
+    out["n_symbols"] = recs["n_symbols"]
+    for name, total in (("total", "good_depth"), ("fwd", "fwd_good_depth"), ("rev", "rev_good_depth")):
+        out[name][:, :LINE_SYMS] = recs[name]
+        out[total] = recs[name].astype(np.uint32).sum(axis=1)
+    out["sym"][:, :LINE_SYMS] = recs["sym"]
+    if len(wide_index):
+        if not (recs["n_symbols"][wide_index] == LINE_WIDE).all() or int((recs["n_symbols"] == LINE_WIDE).sum()) != len(wide_index):
+            raise ValueError("the wide list does not match the records marked wide")
+        out[wide_index] = wide
+    return recs["site_flags"].copy(), out
 
 
 def symbol_count(counts):
@@ -462,6 +486,68 @@ class Device(object):
             self.raise_site_status(ConsensusResult(None, None, counts[:n], status))
         self.last_spill = self.read_symbol_spill(counts[:n])     # (for the rows of these records: vcf_writer.write_all_positions_vcf)
         return off[:n], flags[:n], counts[:n]
+
+    def call_all_lines_compact(self, siteset, path, params, capacity=0, wide_capacity=4096):
+        """call_all_lines with 32-byte records (snpgpu_call_all_lines_compact_file): a fifth of the bytes over the host link.
+        Returns (line_offsets + 1, LINE_DTYPE records — site_flags inside —, indices of the wide lines (ascending), their COUNTS_DTYPE
+        records); ``expand_line_records`` turns that into what call_all_lines returns.  Raises for a malformed chrom / position
+        column only; the Record-level failures are in the wide records' status (the caller looks at the lines it uses)."""
+        n_lines, n_wide = C.c_uint64(), C.c_uint32()
+        status = np.zeros(L.SCAN_STATUS_WORDS, dtype=np.uint64)
+        cap, wcap = int(capacity), int(wide_capacity)
+        while True:
+            off = np.empty(max(cap, 1), dtype=np.uint64)
+            recs = np.empty(max(cap, 1), dtype=LINE_DTYPE)
+            widx = np.empty(max(wcap, 1), dtype=np.uint32)
+            wide = np.empty(max(wcap, 1), dtype=COUNTS_DTYPE)
+            rc = self.lib.snpgpu_call_all_lines_compact_file(self.ctx, siteset.handle, os.fsencode(path), C.byref(params), cap, C.byref(n_lines), _ptr(off),
+                                                             _ptr(recs), wcap, C.byref(n_wide), _ptr(widx), _ptr(wide), _ptr(status))
+            if rc == L.E_IO:
+                raise PileupIOError("cannot open or read the pileup file %s" % path)
+            if rc in (L.E_PILEUP, L.E_UNSUPPORTED) and int(status[0]) != 0xFFFFFFFFFFFFFFFF:
+                self.raise_scan_status(status)
+            self._check(rc)
+            if n_lines.value <= cap and n_wide.value <= wcap:
+                break
+            cap, wcap = max(cap, n_lines.value), max(wcap, n_wide.value)
+        n, w = n_lines.value, n_wide.value
+        if (wide[:w]["n_symbols"] >> 8).any():
+            spill = self.read_symbol_spill()
+            if ((wide[:w]["n_symbols"] >> 8) == 0xFFFFFF).any():
+                raise SpillOverflow(len(spill))
+            self.last_spill = spill
+        else:
+            self.last_spill = None
+        return off[:n], recs[:n], widx[:w], wide[:w]
+
+    def write_all_positions_vcf(self, siteset, pileup_path, params, vcf_path, header_text, filter_names, preserve_ref_case, failed_snp_gt,
+                                only_listed=False, check=True):
+        """call_consensus --vcfAllPos from file to file (snpgpu_write_all_positions_vcf): the pileup through the device, a row per line
+        formatted by the library's host threads straight into vcf_path behind header_text.  Returns (lines, rows written).  Raises what
+        the reference raises for the first line it cannot take (nothing is written then)."""
+        n_lines, n_rows, bad_line, bad_off = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        bad = np.zeros(1, dtype=COUNTS_DTYPE)
+        status = np.zeros(L.SCAN_STATUS_WORDS, dtype=np.uint64)
+        fn = (C.c_char_p * 6)(*[n.encode("ascii") for n in filter_names])
+        rc = self.lib.snpgpu_write_all_positions_vcf(self.ctx, siteset.handle, os.fsencode(pileup_path), C.byref(params), os.fsencode(vcf_path),
+                                                     header_text.encode("utf-8"), fn, 1 if preserve_ref_case else 0, failed_snp_gt.encode("ascii"),
+                                                     1 if only_listed else 0, 1 if check else 0, C.byref(n_lines), C.byref(n_rows), C.byref(bad_line),
+                                                     C.byref(bad_off), _ptr(bad), _ptr(status))
+        if rc == L.E_IO and not os.access(pileup_path, os.R_OK):
+            raise PileupIOError("cannot open or read the pileup file %s" % pileup_path)
+        has_bad = bad_line.value != 0xFFFFFFFFFFFFFFFF
+        if rc in (L.E_PILEUP, L.E_UNSUPPORTED) and int(status[0]) != 0xFFFFFFFFFFFFFFFF:
+            if check and has_bad:                                 # a Record-level failure earlier in the file goes first
+                res = ConsensusResult(None, None, bad, status)
+                res.line_offsets = np.array([bad_off.value], dtype=np.uint64)
+                self.raise_first_error(status, res, True)
+            self.raise_scan_status(status)
+        self._check(rc)
+        if has_bad:
+            res = ConsensusResult(None, None, bad, status)
+            res.line_offsets = np.array([bad_off.value], dtype=np.uint64)
+            self.raise_site_status(res)
+        return int(n_lines.value), int(n_rows.value)
 
     def varscan_file(self, path, params, capacity=65536):
         """Phase-1 site calling over a pileup file: numpy records (VARSCAN_DTYPE) of every (line, allele) that passes the

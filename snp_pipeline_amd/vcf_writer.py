@@ -148,9 +148,21 @@ def write_consensus_vcf(path, sample_id, args, siteset, result, line_offsets, pa
         f.write(rows)
 
 
+def write_all_positions_vcf_from_pileup(dev, siteset, path, sample_id, args, pileup_path, params, only_listed=False, check=True):
+    """--vcfAllPos (call_consensus.py:148-151, vcf_writer.py:381-435): one row per pileup LINE, in file order — or, only_listed, per
+    line at a listed position (a pileup that repeats positions, call_consensus.py:178-180) — from file to file inside the library
+    (snpgpu_write_all_positions_vcf: 32-byte records back over the host link, rows formatted by its host threads; a 5 Mbp sample's
+    5 M rows in tens of milliseconds where the row-by-row form below takes a minute).  Raises what the reference raises for the
+    first line it cannot take; the file is not written then.  Returns (lines, rows)."""
+    filters = filter_descriptions(args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
+    header = "\n".join(header_lines(sample_id, filters, args.vcfRefName)) + "\n"
+    return dev.write_all_positions_vcf(siteset, pileup_path, params, path, header, [n for n, _ in filters], args.vcfPreserveRefCase,
+                                       args.vcfFailedSnpGt, only_listed=only_listed, check=check)
+
+
 def write_all_positions_vcf(path, sample_id, args, pileup_path, line_offsets, counts, spill=None):
-    """--vcfAllPos (call_consensus.py:148-151): one row per pileup LINE, in file order.  The numbers come from the
-    per-line records of ``Device.call_all_lines``; CHROM and POS are the first two fields of the line itself."""
+    """The same file row by row in Python, from the per-line records of ``Device.call_all_lines``; CHROM and POS are the first two
+    fields of the line itself.  The readable statement of the layout: the tests hold the library's rows against it."""
     import mmap
     filters = filter_descriptions(args.minConsFreq, args.minConsDpth, args.minConsStrdDpth, args.minConsStrdBias)
     names = [n for n, _ in filters]
