@@ -485,6 +485,14 @@ int  snpgpu_region_flow_dev(snpgpu_ctx *ctx, const uint8_t *d_base, const uint8_
                             const uint32_t *d_excl_off, const uint32_t *d_excl_slots, uint8_t *d_out_base, uint8_t *d_out_filters,
                             uint32_t *d_err);
 
+/* Whole rows from one device matrix to another by index lists (ABI 7): dst row dst_index[r] <- src row src_index[r], r < n_rows; a null
+ * list stands for r itself; strides and row_bytes in bytes; destination rows distinct; asynchronous on the context's stream.  The
+ * one-job pipeline's gathers between its steps — the rows of a group's resident samples to their places (run.py:704-718 runs the
+ * samples in any order), the packed rows into sorted-id order for the distance step (distance.py:76-84) — without leaving the
+ * library's kernels. */
+int  snpgpu_rows_copy_dev(snpgpu_ctx *ctx, const void *d_src, uint64_t src_stride, const uint32_t *d_src_index,
+                          void *d_dst, uint64_t dst_stride, const uint32_t *d_dst_index, uint32_t n_rows, uint64_t row_bytes);
+
 /* After a call_consensus on `ss`: for every site, 1 + the byte offset of the pileup line that was used (0 = no
  * line).  consensus.vcf rows are written in pileup order (call_consensus.py:161-180), which this recovers.
  * out_line_off[n_sites] is a HOST pointer; synchronous. */

@@ -122,6 +122,7 @@ SIGNATURES = {
                                               _P, _P, _P, _P, C.POINTER(StreamOpts), C.POINTER(StreamStats)]),
     "snpgpu_call_consensus_many_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(CallerParams), _P, _P, _P, _P, _P, _P, C.c_int]),
     "snpgpu_region_flow_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, C.c_uint32, _P, _P, _P, _P, _P]),
+    "snpgpu_rows_copy_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint64, _P, C.c_uint32, C.c_uint64]),
     "snpgpu_write_consensus_files": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.POINTER(C.c_char_p), C.c_int, C.c_char, _P, C.c_uint32,
                                                C.c_uint32]),
     "snpgpu_varscan_dev": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P, C.POINTER(C.c_uint32), _P]),

@@ -557,7 +557,11 @@ __global__ __launch_bounds__(kWaves * 64, kWin == 128 ? 3 : 1) void k_call_lanes
         // ---- stage the line: bytes [al, al + 128) of every lane first, [al + 128, al + 256) only for the lanes whose line
         //      does not end in the first half (a 30x line is ~100 bytes; the fetch is random 128-byte DRAM accesses, so
         //      bytes matter).  Bytes at or past the end of the file read as '\n'. ------------------------------------
+#if defined(SNPGPU_TUNING) && defined(CALL_EXP_ALIGN128)       // (experiment build: every window inside ONE 128-byte cache line — what K2 would cost if
+        const uintptr_t al = addr & ~(uintptr_t)127;           //  the matched lines lay in aligned compact slots; the results are wrong)
+#else
         const uintptr_t al = addr & ~(uintptr_t)15;
+#endif
         const uint32_t o = (uint32_t)(addr & 15);              // the line starts at byte o of the slot
         auto stage_half = [&](int half, bool want) {
             if (!__ballot(want && end - al < (uintptr_t)LANES_WIN + 16)) {

@@ -42,7 +42,41 @@ __global__ __launch_bounds__(256) void k_flow_exclude(const uint64_t *__restrict
     }
 }
 
+// Rows of one matrix into rows of another, picked and placed by index lists: dst[dst_index[r]] = src[src_index[r]] (an absent list: r).
+// One workgroup per row at a time; 16-byte lanes where both rows and the length allow, bytes otherwise.
+__global__ __launch_bounds__(256) void k_rows_copy(const uint8_t *__restrict__ src, uint64_t src_stride, const uint32_t *__restrict__ src_index,
+                                                   uint8_t *__restrict__ dst, uint64_t dst_stride, const uint32_t *__restrict__ dst_index,
+                                                   uint32_t n_rows, uint64_t row_bytes) {
+    for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const uint8_t *s = src + (uint64_t)(src_index ? src_index[r] : r) * src_stride;
+        uint8_t *d = dst + (uint64_t)(dst_index ? dst_index[r] : r) * dst_stride;
+        if ((((uintptr_t)s | (uintptr_t)d) & 15u) == 0) {
+            const uint64_t n16 = row_bytes >> 4;
+            for (uint64_t i = threadIdx.x; i < n16; i += blockDim.x) ((uint4 *)d)[i] = ((const uint4 *)s)[i];
+            for (uint64_t i = (n16 << 4) + threadIdx.x; i < row_bytes; i += blockDim.x) d[i] = s[i];
+        } else {
+            for (uint64_t i = threadIdx.x; i < row_bytes; i += blockDim.x) d[i] = s[i];
+        }
+    }
+}
+
 }  // namespace
+
+// The gathers and scatters of whole rows the one-job pipeline needs between its steps (rows of a group's resident samples to their
+// places; packed rows into sorted-id order, distance.py:76-84): device pointers, strides in bytes, index lists of n_rows entries or
+// null, asynchronous on the context's stream.  The destination rows must be distinct.
+extern "C" int snpgpu_rows_copy_dev(snpgpu_ctx *ctx, const void *d_src, uint64_t src_stride, const uint32_t *d_src_index, void *d_dst, uint64_t dst_stride,
+                                    const uint32_t *d_dst_index, uint32_t n_rows, uint64_t row_bytes) {
+    if (!ctx) return SNPGPU_E_ARG;
+    if (!n_rows || !row_bytes) return SNPGPU_OK;
+    if (!d_src || !d_dst || row_bytes > src_stride || row_bytes > dst_stride) return snpgpu_set_error(ctx, SNPGPU_E_ARG, "bad row copy arguments");
+    HIP_TRY(ctx, snpgpu_enter(ctx));
+    const unsigned cap = (unsigned)ctx->n_cu * 16;
+    k_rows_copy<<<n_rows < cap ? n_rows : cap, 256, 0, ctx->stream>>>((const uint8_t *)d_src, src_stride, d_src_index, (uint8_t *)d_dst, dst_stride, d_dst_index,
+                                                                       n_rows, row_bytes);
+    HIP_TRY(ctx, hipGetLastError());
+    return SNPGPU_OK;
+}
 
 extern "C" int snpgpu_region_flow_dev(snpgpu_ctx *ctx, const uint8_t *d_base, const uint8_t *d_filters, const uint64_t *d_line_off,
                                       uint32_t n_samples, uint32_t n_sites, const uint32_t *d_cols, const int32_t *d_col_of, uint32_t n_cols,

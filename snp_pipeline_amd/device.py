@@ -672,6 +672,13 @@ class Device(object):
                                                     opt(d_col_of), n_cols, opt(d_excl_off), opt(d_excl_slots), opt(d_out_base),
                                                     opt(d_out_filters), C.c_void_p(d_err)))
 
+    def rows_copy_dev(self, d_src, src_stride, d_dst, dst_stride, n_rows, row_bytes, d_src_index=0, d_dst_index=0):
+        """dst row dst_index[r] <- src row src_index[r] (snpgpu_rows_copy_dev); device pointers, strides in bytes, index lists of uint32 or 0
+        for "row r itself"; asynchronous on the context's stream."""
+        opt = lambda v: C.c_void_p(v) if v else None     # noqa: E731
+        self._check(self.lib.snpgpu_rows_copy_dev(self.ctx, opt(d_src), int(src_stride), opt(d_src_index), opt(d_dst), int(dst_stride), opt(d_dst_index),
+                                                  int(n_rows), int(row_bytes)))
+
     def varscan_dev(self, d_ptr, nbytes, params, capacity=65536):
         """varscan_file for a pileup that is in device memory."""
         n = C.c_uint32()

@@ -48,7 +48,7 @@ def _odd_lines(rng):
         if len(ref) > 1:
             bases = bases.replace("*", ".")
         depth = "-%d" % len(reads) if i % 9 == 4 else ("%d" % (5_000_000_000 + i) if i % 9 == 7 else "%d" % len(reads))
-        out.append("%s\t%s\t%s\t%s\t%s" % (ref, depth, bases, "".join(chr(33 + rng.randint(0, 40)) for _ in reads)))
+        out.append("%s\t%s\t%s\t%s" % (ref, depth, bases, "".join(chr(33 + rng.randint(0, 40)) for _ in reads)))
     return out
 
 
