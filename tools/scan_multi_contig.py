@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Development helper: scan rate on samples made of many contigs (device-generated pieces with different contig names
-laid back to back), some of them without any site.  Usage: python tools/scan_multi_contig.py [n_contigs] [contig_len] [n_samples]"""
+laid back to back), some of them without any site.  Usage: python tools/scan_multi_contig.py [n_contigs] [contig_len] [n_samples] [names]
+names: mixed (default: every other contig "NODE_<k>_len_<G>", the others "ctg<kkk>"), short (all "ctg<kkk>"), long (all "NODE_<k>_len_<G>"),
+draft (SPAdes style: "NODE_<k>_length_<G>_cov_<x.y>", 27-30 bytes) — which of name length and contig changes costs what."""
 import os
 import sys
 
@@ -26,7 +28,11 @@ def main():
     alt_h = np.zeros(G + 1, dtype=np.uint8)
     alt_h[pos] = ord("A")
     alt = torch.from_numpy(alt_h).cuda()
-    names = [("NODE_%d_len_%d" % (c + 1, G)).encode() if c % 2 else ("ctg%03d" % c).encode() for c in range(C)]
+    style = sys.argv[4] if len(sys.argv) > 4 else "mixed"
+    long_name = lambda c: ("NODE_%d_len_%d" % (c + 1, G)).encode()      # noqa: E731
+    short_name = lambda c: ("ctg%03d" % c).encode()                     # noqa: E731
+    names = [{"mixed": long_name(c) if c % 2 else short_name(c), "short": short_name(c), "long": long_name(c),
+              "draft": ("NODE_%d_length_%d_cov_%.1f" % (c + 1, G, 10 + (c * 37 % 400) / 10.0)).encode()}[style] for c in range(C)]
     keys = [(names[c], int(p)) for c in range(C) if c % 5 != 3 for p in pos]          # every fifth contig has no site
     sizes = [[d.synth_pileup_dev(3, s * C + c, G, ref.data_ptr(), alt.data_ptr(), 0, 0, contig=names[c]) for c in range(C)] for s in range(B)]
     total = sum(sum(x) for x in sizes)
@@ -58,6 +64,7 @@ def main():
     sm, sn = d.kernel_time_ms(0)
     cm, cn = d.kernel_time_ms(1)
     st = status.cpu().numpy()
+    print("names %s (%d-%d bytes): " % (style, min(len(x) for x in names), max(len(x) for x in names)), end="")
     print("%d samples x %d contigs x %d bp (%.2f GB): scan %.3f ms  %.0f GB/s | call %.3f ms | lines %d matched %d of %d sites, err %s"
           % (B, C, G, total / 1e9, sm / sn, total / (sm / sn * 1e-3) / 1e9, cm / cn, st[0, 1], st[0, 2], S, (st[:, 0] != -1).any()))
 
