@@ -85,8 +85,12 @@ def _same_records(a, spill_a, b, spill_b):
     size = dev.SPILL_DTYPE.itemsize
     for i in np.nonzero(code_a)[0]:
         ra, rb = spill_a[int(code_a[i]) - 1], spill_b[int(code_b[i]) - 1]
-        assert ra.tobytes() == rb.tobytes(), i
-        more = max(0, (int(ra["ref_len"]) - L.SPILL_REF + size - 1) // size) if int(ra["ref_len"]) > L.SPILL_REF else 0
+        n, ref_len = int(ra["n"]), int(ra["ref_len"])
+        assert (n, ref_len, int(ra["depth64"])) == (int(rb["n"]), int(rb["ref_len"]), int(rb["depth64"])), i
+        for name in ("sym", "total", "fwd", "rev"):                  # (what lies past the entries in use is whatever the arena held before)
+            assert np.array_equal(ra[name][:n], rb[name][:n]), (i, name)
+        assert ra["ref"][:min(ref_len, L.SPILL_REF)].tobytes() == rb["ref"][:min(ref_len, L.SPILL_REF)].tobytes(), i
+        more = (ref_len - L.SPILL_REF + size - 1) // size if ref_len > L.SPILL_REF else 0
         for k in range(1, more + 1):                                 # a reference field longer than one record goes on in the next ones
             assert spill_a[int(code_a[i]) - 1 + k].tobytes() == spill_b[int(code_b[i]) - 1 + k].tobytes()
     assert int((code_a != 0).sum()) > 0

@@ -22,11 +22,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     (["merge_scale.py", "50", "60", "2000"], ""),
     (["distance_cli_time.py", "60", "900"], ""),
     (["scan_multi_contig.py", "5", "20000", "2"], ""),
+    (["scan_multi_contig.py", "6", "20000", "2", "draft", "all"], "names draft"),
+    (["k2_exp.py"], "call kernels"),
     (["scan_crlf.py"], ""),
     (["scan_sweep.py", "3", "20", "", "OVERSUB=1"], "GB/s"),
-    (["scan_realloc.py", "3", "20", "2"], "round 1:"),
-    (["scan_placement.py", "20", "3"], "ctx 0, input 6"),
-    (["scan_batch_sizes.py", "20", "5"], "all again"),
 ])
 def test_tool_runs_at_toy_size(argv, expect, tmp_path):
     env = dict(os.environ, TMPDIR=str(tmp_path), SWEEP_GENOME="60000")

@@ -6,7 +6,7 @@ import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.getcwd()))
 import numpy as np, torch
 from snp_pipeline_amd import device as dev, _lib as L
-G = 5_000_000; NB = 125; depth = 30.0
+G = int(os.environ.get("SWEEP_GENOME", "5000000")); NB = int(os.environ.get("K2_SAMPLES", "125")); depth = 30.0
 d = dev.Device(0); d.use_torch_stream()
 ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda"); d.synth_reference_dev(1, G, ref.data_ptr())
 pos = np.sort(np.random.default_rng(2).choice(np.arange(501, G - 499), size=G // 100, replace=False))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development helper: scan rate on samples made of many contigs (device-generated pieces with different contig names
-laid back to back), some of them without any site.  Usage: python tools/scan_multi_contig.py [n_contigs] [contig_len] [n_samples] [names]
+laid back to back), some of them without any site.  Usage: python tools/scan_multi_contig.py [n_contigs] [contig_len] [n_samples] [names] [all]
 names: mixed (default: every other contig "NODE_<k>_len_<G>", the others "ctg<kkk>"), short (all "ctg<kkk>"), long (all "NODE_<k>_len_<G>"),
 draft (SPAdes style: "NODE_<k>_length_<G>_cov_<x.y>", 27-30 bytes) — which of name length and contig changes costs what."""
 import os
@@ -33,7 +33,8 @@ def main():
     short_name = lambda c: ("ctg%03d" % c).encode()                     # noqa: E731
     names = [{"mixed": long_name(c) if c % 2 else short_name(c), "short": short_name(c), "long": long_name(c),
               "draft": ("NODE_%d_length_%d_cov_%.1f" % (c + 1, G, 10 + (c * 37 % 400) / 10.0)).encode()}[style] for c in range(C)]
-    keys = [(names[c], int(p)) for c in range(C) if c % 5 != 3 for p in pos]          # every fifth contig has no site
+    every = len(sys.argv) > 5 and sys.argv[5] == "all"                               # 5th argument "all": every contig has sites
+    keys = [(names[c], int(p)) for c in range(C) if every or c % 5 != 3 for p in pos]          # (default) every fifth contig has no site
     sizes = [[d.synth_pileup_dev(3, s * C + c, G, ref.data_ptr(), alt.data_ptr(), 0, 0, contig=names[c]) for c in range(C)] for s in range(B)]
     total = sum(sum(x) for x in sizes)
     buf = torch.empty(total + 64, dtype=torch.uint8, device="cuda")
