@@ -519,39 +519,6 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
             const uint8_t *tile = (const uint8_t *)&ws.slot[cur][1];   // tile[-16 .. SCAN_TILE+SCAN_HALO)
             const uint4 *tile16 = &ws.slot[cur][1];
             uint32_t mismatch_at = 0xFFFFFFFFu;                      // line start of a lane whose name did not match the hint
-            // Make the contig of the first line whose name did not match the wave's hint (rare: once per contig change).
-            auto adopt_mismatch = [&]() {
-                const uint64_t mm = __ballot(mismatch_at != 0xFFFFFFFFu);
-                if (mm) {
-                    const uint32_t s1 = __builtin_amdgcn_readlane(mismatch_at, (uint32_t)__ffsll((long long)mm) - 1);
-                    uint32_t len = 0;
-                    while (len < 4 * SCAN_HINT_WORDS && __builtin_amdgcn_readfirstlane((uint32_t)tile[s1 + len]) > 0x20u) ++len;
-                    // the same name as the hint's? then only the digit count (or a separator) differed: recalibrate, no look-up
-                    bool same = hint_bad == 0 && len == L;
-                    if (same) {
-                        bool diff = false;
-                        for (uint32_t i = lane; i < len; i += 64) diff = diff || tile[s1 + i] != ((ws.hint_w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-                        same = __ballot(diff) == 0;
-                    }
-                    if (same) { g = 0; mode = 0; }
-                    else if (len >= 1 && len <= 4 * SCAN_HINT_WORDS - 4) {
-                        TileView tv{tile, f.base, t0, f.hi, (int64_t)(SCAN_TILE + SCAN_HALO)};
-                        const uint32_t cid = ss.n_contigs ? find_contig(contig_tab(ss), tv, (int64_t)s1, len) : 0xFFFFFFFFu;
-                        g = 0; mode = 0;                             // the next round calibrates against the new name
-                        if (cid != 0xFFFFFFFFu) adopt(load_hint(contig_tab(ss), cid, ws.hint_w, lane));
-                        else {                                       // not a contig of the site set: remember the name itself
-                            if (lane < SCAN_HINT_WORDS) {
-                                uint32_t w = 0;
-                                for (uint32_t j = 0; j < 4; ++j) { uint32_t i = lane * 4 + j; if (i < len) w |= (uint32_t)tile[s1 + i] << (8 * j); }
-                                ws.hint_w[lane] = w;
-                            }
-                            Hint h;
-                            h.len = len; h.cid = SCAN_HINT_ABSENT; h.max_pos = 0; h.bit_off = 0;
-                            adopt(h);
-                        }
-                    }
-                }
-            };
             do {                                                // one pass; `break` leaves the tile early
                 if (kTime == 3) { any_hi |= tile16[lane].x; break; }   // tuning: stream only, no parsing
                 // ---- B: terminator flags of four 16-byte chunks per lane (chunk i*64+lane: conflict-free LDS reads) ----
@@ -715,26 +682,16 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                         uint64_t pend = S;
                         bool extra = s0;
                         uint64_t extra_mask = __ballot(extra);          // (a ballot of a plain compare is one v_cmp; of anything else the
-                        // Lines of ANOTHER contig than the wave's hint are put aside (their terminator bits in `defer`); when the tile's rounds
-                        // are through, that contig becomes the hint and they are taken in a second pass over the same slot.  (Up to round 5
-                        // they went to the exact parser's queue with a same-address atomic per line: a sample of 200 contigs queued 6 000
-                        // lines, and the launch ran 14 % slower than over one contig.)
+                        // Lines of ANOTHER contig than the wave's hint are put aside (their terminator bits in `defer`); when the tile's rounds are
+                        // through, that contig becomes the hint and they are taken in a second trip through the rounds, over the same slot.  (Up to
+                        // round 5 they went to the exact parser's queue: 6 000 lines of every 200-contig sample.)
                         uint64_t defer = 0;
-                        bool defer_extra = false, second_pass = false;  // (second_pass: wave-uniform)
+                        for (uint32_t second = 0;; second = 1u) {
                         for (;;) {                                      //  compiler first makes a 0 / 1 register: lane masks are kept in scalars)
                             bool active = extra || pend != 0;
                             uint64_t act_mask = __builtin_amdgcn_ballot_w64(pend != 0) | extra_mask;
                             extra_mask = 0;
-                            if (!act_mask) {
-                                if (second_pass || !__ballot(defer != 0 || defer_extra)) break;
-                                second_pass = true;
-                                adopt_mismatch();
-                                mismatch_at = 0xFFFFFFFFu;
-                                pend = defer;
-                                extra = defer_extra;
-                                extra_mask = __ballot(extra);
-                                continue;
-                            }
+                            if (!act_mask) break;
                             const uint32_t bpos = extra ? 0xFFFFFFFFu : (uint32_t)__ffsll((long long)pend) - 1u;
                             const uint32_t s = extra ? 0u : byte_of(bpos & 63u) + 1u;
                             if (!extra) pend &= pend - 1;
@@ -743,7 +700,6 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                             bool big;
                             uint32_t nd_seen = 0;                                        // digits of this line's position (0: unknown)
                             bool tabs = true;
-                            bool name_miss = false;                                      // (general form) the line's name is not the hint's
                             const uint32_t mode_now = __builtin_amdgcn_readfirstlane(mode);
                             bool fast_round = (mode_now & 1u) != 0 && cool == 0;         // wave-uniform: a scalar branch
                             if (!fast_round && cool) --cool;
@@ -802,8 +758,7 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                 bad |= ((v0 ^ hint_w[8]) & hint_m[8]) | ((v1 ^ hint_w[9]) & hint_m[9]) | ((v2 ^ hint_w[10]) & hint_m[10]) | ((v3 ^ hint_w[11]) & hint_m[11]);
                             }
                             const uint32_t c1 = tile[s + L];                             // the separator after the name
-                            name_miss = active && (bad | min(c1 ^ 9u, c1 ^ 32u)) != 0;             // another contig?
-                            if (name_miss) mismatch_at = s;
+                            if (active && (bad | min(c1 ^ 9u, c1 ^ 32u)) != 0) mismatch_at = s;    // another contig?
                             uint4 q1;
                             lds_window16(tile, (int)(s + L + 1), q1.x, q1.y, q1.z, q1.w);       // digits + separator
                             // first byte <= 0x20 in the 16-byte window = number of digits (1..10 on the fast path)
@@ -848,12 +803,24 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                 }
                             }
                             const uint64_t off1 = t0 + (uint64_t)s - f.lo + 1;
-                            if (active && bad != 0) {
-                                if (name_miss && !second_pass) {                         // put aside for the pass after the contig change
-                                    if (bpos == 0xFFFFFFFFu) defer_extra = true; else defer |= 1ull << (bpos & 63u);
-                                } else {                                                 // rare: leave it to k_scan_queue
-                                    const uint32_t qi = atomicAdd(&a.ctl[0], 1u);
-                                    if (qi < a.q_cap) a.queue[qi] = f.sample | (off1 - 1); else a.ctl[1] = 1u;
+                            // rare: leave the line to k_scan_queue — with ONE atomic for all such lines of the round — unless it is a line of another
+                            // contig on the first trip through the tile: that one is put aside for the trip after the contig change.
+                            uint64_t qm = __builtin_amdgcn_ballot_w64(active && bad != 0);
+                            if (qm) {
+                                if (!second) {
+                                    const bool aside = active && bad != 0 && mismatch_at == s && bpos != 0xFFFFFFFFu;
+                                    if (aside) { defer |= 1ull << (bpos & 63u); bad = 0; active = false; }
+                                    qm = __builtin_amdgcn_ballot_w64(active && bad != 0);
+                                }
+                                if (qm) {
+                                    const uint32_t leader = (uint32_t)__ffsll((long long)qm) - 1u;
+                                    uint32_t q0 = 0;
+                                    if (lane == leader) q0 = atomicAdd(&a.ctl[0], (uint32_t)__popcll(qm));
+                                    q0 = __builtin_amdgcn_readlane(q0, leader);
+                                    if (active && bad != 0) {
+                                        const uint32_t qi = q0 + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull));
+                                        if (qi < a.q_cap) a.queue[qi] = f.sample | (off1 - 1); else a.ctl[1] = 1u;
+                                    }
                                 }
                             }
                             const bool probe = active && bad == 0 && hint_present && !big && pos <= h_max;
@@ -912,6 +879,46 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                                 else if (g_new != g || top_new != top) { g = g_new; top = top_new; relayout(); }
                             }
                         }
+                        // A line of another contig was seen: make that contig the wave's hint (rare: once per contig change), then take the
+                        // lines that were put aside for it, once per tile.  (On that second trip a line that still does not match — a second
+                        // contig change in the tile, a name the hint cannot hold, the hint's own name with something odd behind it — is queued.)
+                        {
+                            const uint64_t mm = __ballot(mismatch_at != 0xFFFFFFFFu);
+                            if (mm) {
+                                const uint32_t s1 = __builtin_amdgcn_readlane(mismatch_at, (uint32_t)__ffsll((long long)mm) - 1);
+                                uint32_t len = 0;
+                                while (len < 4 * SCAN_HINT_WORDS && __builtin_amdgcn_readfirstlane((uint32_t)tile[s1 + len]) > 0x20u) ++len;
+                                // the same name as the hint's? then only the digit count (or a separator) differed: recalibrate, no look-up
+                                bool same = hint_bad == 0 && len == L;
+                                if (same) {
+                                    bool diff = false;
+                                    for (uint32_t i = lane; i < len; i += 64) diff = diff || tile[s1 + i] != ((ws.hint_w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+                                    same = __ballot(diff) == 0;
+                                }
+                                if (same) { g = 0; mode = 0; }
+                                else if (len >= 1 && len <= 4 * SCAN_HINT_WORDS - 4) {
+                                    TileView tv{tile, f.base, t0, f.hi, (int64_t)(SCAN_TILE + SCAN_HALO)};
+                                    const uint32_t cid = ss.n_contigs ? find_contig(contig_tab(ss), tv, (int64_t)s1, len) : 0xFFFFFFFFu;
+                                    g = 0; mode = 0;                             // the next round calibrates against the new name
+                                    if (cid != 0xFFFFFFFFu) adopt(load_hint(contig_tab(ss), cid, ws.hint_w, lane));
+                                    else {                                       // not a contig of the site set: remember the name itself
+                                        if (lane < SCAN_HINT_WORDS) {
+                                            uint32_t w = 0;
+                                            for (uint32_t j = 0; j < 4; ++j) { uint32_t i = lane * 4 + j; if (i < len) w |= (uint32_t)tile[s1 + i] << (8 * j); }
+                                            ws.hint_w[lane] = w;
+                                        }
+                                        Hint h;
+                                        h.len = len; h.cid = SCAN_HINT_ABSENT; h.max_pos = 0; h.bit_off = 0;
+                                        adopt(h);
+                                    }
+                                }
+                            }
+                        }
+                        if (second || !__ballot(defer != 0)) break;
+                        mismatch_at = 0xFFFFFFFFu;
+                        pend = defer;
+                        defer = 0;
+                        }
                     }
                     } else {
                         TileView tv{tile, f.base, t0, f.hi, (int64_t)(SCAN_TILE + SCAN_HALO)};
@@ -936,9 +943,6 @@ __global__ __launch_bounds__(1024) void k_scan_wave(ScanArgs a, SiteSetDev ss) {
                     __builtin_amdgcn_wave_barrier();
                 }
             } while (false);
-            // A line of another contig was seen (and not taken care of inside the rounds: a second contig change in one tile, a name
-            // the hint cannot hold): make that contig the wave's hint.  The lines that failed meanwhile are in the queue.
-            if (!kExact) adopt_mismatch();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this slot has returned: it can be refilled
         __builtin_amdgcn_wave_barrier();

@@ -804,3 +804,39 @@ def test_positions_whose_top_digits_keep_changing(d, order):
     snps = sorted(set(sites))
     res = check_against_oracle(d, data, snps, rng.sample(snps, 10), po.CallerParams(0, 0.6, 1, 0, 0.0))
     assert res.n_lines == len(lines)
+
+
+@pytest.mark.parametrize("depth_sum", [False, True])
+def test_many_contig_changes_inside_one_scan_tile(d, depth_sum):
+    """Round 6: the scan puts the lines of another contig than its hint aside and takes them in another trip through the tile after
+    the contig change, as often as the tile changes contig (up to round 5 they went to the exact parser).  Contigs of five to forty
+    lines — a dozen changes per 4 KiB tile — with names the hint cannot hold (50 bytes: those lines do go to the exact parser), names
+    that are not in the site set, the same name coming back later (an unsorted file), a name followed by two blanks, and a contig whose
+    lines fill several tiles in between; consensus, line counts and the depth-column sum as the oracle's."""
+    from snp_pipeline_amd import _lib as L
+    from tests.gpu_util import check_against_oracle
+    rng = random.Random(77)
+    names = ["c%02d" % i for i in range(30)] + ["NODE_%d_length_%d_cov_%.1f" % (i, 1000 + i, 3.5 + i) for i in range(12)] + ["L" * 50, "absent_1", "absent_2"]
+    lines, keys = [], []
+    order = names + ["c03", "bulk", "c07", "L" * 50, "c01"]                     # (names that come a second time)
+    for k, name in enumerate(order):
+        n_lines = 400 if name == "bulk" else rng.choice((3, 5, 9, 17, 40))
+        first = 100 * k + 1 if name != "bulk" else 1
+        for j in range(n_lines):
+            pos = first + j
+            depth = rng.randint(3, 25)
+            reads = "".join(rng.choice("..,,..,,AaCcGgTt") for _ in range(depth))
+            sep = "  " if (name == "c05" and j == 2) else "\t"               # the hint's own name with something odd behind it
+            lines.append("%s%s%d\t%s\t%d\t%s\t%s" % (name, sep, pos, rng.choice("ACGT"), depth, reads, "I" * depth))
+            if not name.startswith("absent") and j % 3 == 0:
+                keys.append((name.encode(), pos))
+    data = ("\n".join(lines) + "\n").encode()
+    assert len(order) > 3 * (len(data) // 4096)                               # several contig changes per 4 KiB tile
+    snps = sorted(set(keys))
+    p = po.CallerParams(0, 0.6, 3, 0, 0.0)
+    res = check_against_oracle(d, data, snps, snps[::11], p)
+    assert res.n_lines == len(lines)
+    if depth_sum:
+        ss = d.siteset(snps, [L.SITE_IN_SNPLIST] * len(snps))
+        r2 = d.call_consensus(ss, data, devmod_params(p), want_counts=False, want_depth_sum=True)
+        assert r2.depth_sum == po.depth_sum(data)

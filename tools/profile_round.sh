@@ -21,6 +21,13 @@ rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES S
 pmc_cv="--steps 1 --warmup 1 --cpu-samples 0 --skip-secondary --skip-aux --e2e-files 0 --site-files 0 --pipeline-files 0 --shape-samples 0"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch_cv" -- python $root/bench.py $pmc_cv --detail "" > /dev/null 2> "$out/pmc_fetch_cv.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write_cv" -- python $root/bench.py $pmc_cv --detail "" > /dev/null 2> "$out/pmc_write_cv.err"
+# the one job (hot_path_batch) on 32 samples, half of them resident (the scattered-rows path too): which kernels it launches — no at::native::index* among them
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_job" -- python $root/tools/pipeline_time.py --samples 32 --resident-frac 0.5 > "$out/hot_path_batch_trace.json" 2> "$out/trace_job.err"
+find "$out/trace_job" -name "*kernel_stats.csv" -exec cp {} "$out/rocprofv3_kernel_stats_hot_path_batch.csv" \;
+( echo "kernels of the hot_path_batch trace whose name contains 'index' (ATen's advanced-indexing kernels are at::native::index_*):"; grep -i "index" "$out/rocprofv3_kernel_stats_hot_path_batch.csv" | cut -d, -f1 | sed 's/^/  /'; echo "(k_lines_index is the library's own line index; no at::native::index* line above = none was launched)"; echo "ATen kernels of any kind in the trace:"; grep -c "at::native" "$out/rocprofv3_kernel_stats_hot_path_batch.csv" ) > "$out/hot_path_batch_aten_kernels.txt" 2>&1
+rm -rf "$out/trace_job"
+# FETCH_SIZE / WRITE_SIZE on known byte counts
+sh $root/tools/fetch_calib.sh 8 > "$out/fetch_calibration_raw.txt" 2>&1
 cd "$root"
 python tools/pmc_summary.py "$out/pmc_fetch_cv" | grep -A1 "k_call" > "$out/pmc_fetch_size_call_variants_summary.txt"
 python tools/pmc_summary.py "$out/pmc_write_cv" | grep -A1 "k_call" > "$out/pmc_write_size_call_variants_summary.txt"

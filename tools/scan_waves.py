@@ -46,7 +46,7 @@ print(" ".join("%.0f" % life[i * n // 32:(i + 1) * n // 32].mean() for i in rang
 print("life by wave-in-block:", " ".join("%.0f" % life[w::8].mean() for w in range(8)))
 slow = life > 1.5 * np.median(life)
 print("slow waves: %d; per block counts of slow waves: %s" % (slow.sum(), dict(zip(*np.unique(slow[:n // 8 * 8].reshape(-1, 8).sum(1), return_counts=True)))))
-wpb = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+wpb = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 16
 print("life by wave-in-block (%d waves/block):" % wpb, " ".join("%.0f" % life[w::wpb].mean() for w in range(wpb)))
 print("simd of wave-in-block:", " ".join("%.1f" % simd[w::wpb].mean() for w in range(wpb)))
 # life by age rank on the SIMD (wave-in-block / 4: the host's shares are per rank) — equal lives = balanced shares
