@@ -27,7 +27,10 @@
 //      looked at bytewise: after "\r\n" split over two chunks, '\v' or '\f' there is no line; after a lone '\r' there is.  General form (calibrates g, handles long names): name
 //      window, digit window, SWAR "<= 0x20" mask + ffs for the digit count.  Then the site probe by ds_bpermute into a
 //      64-dword register window of the bitmap / rank directory.
-// A line that fits neither (other contig, another digit count, odd whitespace, > 10 digits, names > 44 bytes) is
+// A line of ANOTHER CONTIG than the wave's hint waits (one 64-bit mask per lane) until the tile's rounds are through; then the hint
+// moves to that contig and a second trip through the same LDS slot takes the lines that waited (round 6: up to then they went to the
+// queue below, 6 000 lines of every 200-contig sample).
+// A line that fits neither form (odd whitespace, > 10 digits, names > 44 bytes, a second contig change in one tile) is
 // pushed on a device queue and finished by k_scan_queue with an exact byte-wise parser; if the queue overflows, the
 // kExact instantiation (every line through the exact parser) redoes the batch.  kExact also serves the depth-column
 // sum.  Line and match counts leave the kernel through per-wave slots (k_scan_finish adds them up per sample):
