@@ -62,6 +62,7 @@ def parse_args():
     ap.add_argument("--e2e-files", type=int, default=16, help="pileup files streamed from the page cache for the end_to_end row (0 = skip)")
     ap.add_argument("--pipeline-files", type=int, default=125, help="samples of the pipeline_from_files row (0 = skip)")
     ap.add_argument("--skip-separate-steps", action="store_true", help="pipeline_from_files: do not time the separate subcommands beside it")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not measure the scan's HBM traffic with rocprofv3 child runs (the committed result of the same workload stands in)")
     ap.add_argument("--detail", type=str, default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
                     help="where rank 0 writes the full result (side rows, per-rank phases, notes); '' = nowhere")
     ap.add_argument("--dump", type=str, default=None, help="write this rank's results (site union, packed matrix, distance band) to DUMP.rankN.npz")
@@ -403,6 +404,14 @@ def main():
     if on_rank0_alone and args.cpu_samples > 0:
         out["cpu_baseline"] = rows.cpu_baseline(args, d, pile, offs, sizes, bases, pos, G, S, value, out.get("secondary"))
         rows.from_files_ratios(out, S)
+    # ---- the scan's HBM traffic, measured now (two short child runs under rocprofv3 --pmc); N = 1 only ------------------------------
+    if on_rank0_alone and not args.no_live_traffic:
+        watch.phase(None)
+        live = rows.live_traffic(args, algo_bytes)
+        if "error" in live:
+            out["roofline"]["traffic_live_error"] = live["error"]
+        else:
+            out["roofline"].update(live)
     if rank == 0:
         out["north_star"] = rows.north_star(out, args, world, S)
         line = json.dumps(compact(out), separators=(",", ":"))
@@ -454,6 +463,8 @@ def compact(out, minimal=False):
     c["comm_route"] = None if not cr else ("libsnpgpu.so over rccl %s" % cr["rccl_version"] if "rccl_version" in cr else cr["exchanges"])
     c["roofline"] = _pick(out["roofline"], "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic",
                           "algorithmic_bytes_per_launch", "avg_launch_ms", "launches", "measured_copy_gbps_read_plus_write")
+    src = out["roofline"].get("traffic_source") or ""
+    c["roofline"]["traffic_is"] = "measured in this run" if src.startswith("measured in this run") else ("committed profile of this workload" if src else None)
     cb = out.get("cpu_baseline")
     if cb:
         c["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind", "sample", "matches_gpu", "gpu_over_cpu_1core")

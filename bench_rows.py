@@ -1104,6 +1104,53 @@ def committed_traffic(name, match):
     return None, None
 
 
+def live_traffic(args, algorithmic_bytes, timeout_s=240):
+    """HBM traffic of one scan launch of THIS workload on THIS box, measured now: the timed step alone (a warm-up and three launches, no
+    side rows) in two child processes under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, as
+    MI355X_MICROARCH.md prescribes; counter collection cannot be switched on inside a running process).  FETCH_SIZE x 1024 x 2 (a
+    128-byte line is tallied at 64 bytes: profiles/r6/fetch_calibration.md), WRITE_SIZE x 1024.  Returns the roofline's traffic fields,
+    or {"error": ...} — the committed result of the same workload then stands in, and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--samples", str(args.samples), "--genome", str(args.genome),
+             "--sites", str(args.sites), "--depth", repr(args.depth), "--vcf-records", str(args.vcf_records), "--cpu-samples", "0", "--skip-secondary", "--skip-aux",
+             "--e2e-files", "0", "--site-files", "0", "--pipeline-files", "0", "--shape-samples", "0", "--skip-call-variants", "--detail", "", "--no-live-traffic"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env["TMPDIR"] = "/tmp"
+    got = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="snpbench_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--"] + child, cwd="/tmp", env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=timeout_s)
+            vals = []
+            for path in glob.glob(tmp + "/**/*counter_collection.csv", recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if row.get("Counter_Name") == counter and row.get("Kernel_Name", "").replace("(anonymous namespace)::", "").startswith("void k_scan_wave<false, 0>"):
+                            vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                return {"error": "%s pass: exit code %d, %d launches seen; %s" % (counter, r.returncode, len(vals), r.stderr.decode("utf-8", "replace")[-300:])}
+            got[counter] = (sum(vals) / len(vals), len(vals))
+        except (OSError, subprocess.TimeoutExpired, ValueError, KeyError) as err:
+            return {"error": "%s pass: %s: %s" % (counter, type(err).__name__, err)}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    fetch_b, write_b = got["FETCH_SIZE"][0] * 1024 * 2, got["WRITE_SIZE"][0] * 1024
+    return {"traffic": fetch_b + write_b, "traffic_over_algorithmic": (fetch_b + write_b) / algorithmic_bytes if algorithmic_bytes else None,
+            "traffic_fetch_bytes": fetch_b, "traffic_write_bytes": write_b, "traffic_launches_measured": got["FETCH_SIZE"][1],
+            "traffic_source": "measured in this run: two child processes of the timed step under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; "
+                              "FETCH_SIZE x 2 as calibrated in profiles/r6/fetch_calibration.md), %.0f s" % (time.perf_counter() - t0)}
+
+
 def north_star(out, args, world, S):
     """The target of BASELINE.json's north_star, written down as numbers: 10 000 samples x 5 Mbp, call_consensus -> snp_matrix ->
     distance, reference CPU seconds over GPU seconds; >= 50 % of HBM peak on the scan; >= 6x at 8 GPUs."""

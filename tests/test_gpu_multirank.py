@@ -27,7 +27,7 @@ def _free_port():
 
 def _run_bench(world, dump, extra, launcher=False, rccl_group_of_one=False, comm=None):
     args = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--scaling", "strong", "--skip-aux", "--e2e-files", "0", "--site-files", "0",
-            "--cpu-samples", "0", "--pipeline-files", "0", "--shape-samples", "0", "--dump", dump, "--detail", dump + ".detail.json"] + extra
+            "--cpu-samples", "0", "--pipeline-files", "0", "--shape-samples", "0", "--no-live-traffic", "--dump", dump, "--detail", dump + ".detail.json"] + extra
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(SNPGPU_BENCH_TEST_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
     if rccl_group_of_one:                                               # one rank, one GPU, backend nccl, every collective of the step made
@@ -150,7 +150,7 @@ def test_two_ranks_over_rccl_when_two_gpus_are_there(tmp_path, comm):
              "--dist-sites", "3000", "--dist-reps", "1"]
     one = _run_bench(1, str(tmp_path / "one"), extra)
     args = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--scaling", "strong", "--skip-aux", "--e2e-files", "0", "--site-files", "0", "--cpu-samples", "0",
-            "--pipeline-files", "0", "--shape-samples", "0", "--dump", str(tmp_path / "two"), "--detail", str(tmp_path / "two.detail.json")] + extra
+            "--pipeline-files", "0", "--shape-samples", "0", "--no-live-traffic", "--dump", str(tmp_path / "two"), "--detail", str(tmp_path / "two.detail.json")] + extra
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SNPGPU_BENCH_TEST_ONE_GPU")}
     env.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", SNPGPU_COMM=comm)
     r = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)

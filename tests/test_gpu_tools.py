@@ -57,6 +57,16 @@ def test_bench_prints_one_compact_line_last(tmp_path):
     roof = line["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0 and roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-4)
     assert roof["launches"] == 2 and roof["avg_launch_ms"] > 0
+    # the scan's HBM traffic is measured in the run itself (two child runs under rocprofv3 --pmc): at least the bytes of the text, and not
+    # the multiple a re-reading kernel would show; where rocprofv3 cannot run the line says why and carries no live figure
+    with open(detail) as f:
+        roof_full = json.load(f)["roofline"]
+    if "traffic_live_error" in roof_full:
+        print("live traffic not measured here:", roof_full["traffic_live_error"])
+        assert roof.get("traffic_is") != "measured in this run"
+    else:
+        assert roof["traffic_is"] == "measured in this run" and roof_full["traffic_launches_measured"] == 4
+        assert 0.9 < roof["traffic_over_algorithmic"] < 3.0           # (toy samples: the edge tiles and the site set weigh more than at full size)
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["matches_gpu"] is True and cb["sample"]
     assert cb["parallel"]["matches_gpu"] is True and cb["distance"]["matches_gpu"] is True

@@ -7,9 +7,9 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$round
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-short="--cpu-samples 0 --skip-aux --e2e-files 0 --site-files 0 --pipeline-files 0 --shape-samples 0 --skip-call-variants"      # the timed step only (20 steps + 3 warm-up launches): every k_scan_wave<false,0> launch in this trace is a headline launch, so its average is the roofline's
-rows="--steps 2 --warmup 1 --cpu-samples 0 --skip-aux --skip-separate-steps"                         # the side rows (pipeline from files, end to end, site calling, scan shapes): which kernels they spend their device time in
-pmc="--steps 3 --warmup 1 --cpu-samples 0 --skip-secondary --skip-aux --e2e-files 0 --site-files 0 --pipeline-files 0 --shape-samples 0 --skip-call-variants"
+short="--no-live-traffic --cpu-samples 0 --skip-aux --e2e-files 0 --site-files 0 --pipeline-files 0 --shape-samples 0 --skip-call-variants"      # the timed step only (20 steps + 3 warm-up launches): every k_scan_wave<false,0> launch in this trace is a headline launch, so its average is the roofline's
+rows="--no-live-traffic --steps 2 --warmup 1 --cpu-samples 0 --skip-aux --skip-separate-steps"                         # the side rows (pipeline from files, end to end, site calling, scan shapes): which kernels they spend their device time in
+pmc="--no-live-traffic --steps 3 --warmup 1 --cpu-samples 0 --skip-secondary --skip-aux --e2e-files 0 --site-files 0 --pipeline-files 0 --shape-samples 0 --skip-call-variants"
 python $root/bench.py --detail "$out/bench_n1_detail.json" > "$out/bench_n1.json" 2> "$out/bench_n1.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python $root/bench.py $short --detail "$out/trace_bench_detail.json" > "$out/trace_bench.json" 2> "$out/trace.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_rows" -- python $root/bench.py $rows --detail "" > "$out/trace_rows_bench.json" 2> "$out/trace_rows.err"
@@ -18,7 +18,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python $ro
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d "$out/pmc_sq" -- python $root/bench.py $pmc --detail "" > /dev/null 2> "$out/pmc_sq.err"
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d "$out/pmc_sq2" -- python $root/bench.py $pmc --detail "" > /dev/null 2> "$out/pmc_sq2.err"
 # K2 with per-site count records (the call_variants rows): FETCH_SIZE / WRITE_SIZE of k_call_lanes<..., true>
-pmc_cv="--steps 1 --warmup 1 --cpu-samples 0 --skip-secondary --skip-aux --e2e-files 0 --site-files 0 --pipeline-files 0 --shape-samples 0"
+pmc_cv="--no-live-traffic --steps 1 --warmup 1 --cpu-samples 0 --skip-secondary --skip-aux --e2e-files 0 --site-files 0 --pipeline-files 0 --shape-samples 0"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch_cv" -- python $root/bench.py $pmc_cv --detail "" > /dev/null 2> "$out/pmc_fetch_cv.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write_cv" -- python $root/bench.py $pmc_cv --detail "" > /dev/null 2> "$out/pmc_write_cv.err"
 # the one job (hot_path_batch) on 32 samples, half of them resident (the scattered-rows path too): which kernels it launches — no at::native::index* among them
