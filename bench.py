@@ -407,6 +407,7 @@ def main():
     # ---- the scan's HBM traffic, measured now (two short child runs under rocprofv3 --pmc); N = 1 only ------------------------------
     if on_rank0_alone and not args.no_live_traffic:
         watch.phase(None)
+        torch.cuda.empty_cache()                                 # (the child generates the same 54 GB beside this process's)
         live = rows.live_traffic(args, algo_bytes)
         if "error" in live:
             out["roofline"]["traffic_live_error"] = live["error"]

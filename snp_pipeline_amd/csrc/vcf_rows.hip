@@ -298,6 +298,7 @@ bool snpgpu_format_line_rows(const uint8_t *text, uint64_t nbytes, const uint64_
     }
     uint32_t w = (uint32_t)(std::lower_bound(wide_index, wide_index + n_wide, (uint32_t)lo) - wide_index);
     size_t used = out.size();
+    out.resize(used + (size_t)(hi - lo) * 128 + 4096);          // a row of a 30x line is ~95 bytes: one allocation for nearly every range
     uint64_t rows = 0;
     char head[512];
     std::vector<char> long_head;
