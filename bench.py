@@ -126,58 +126,73 @@ def claim_stdout():
     return real
 
 
-def main():
-    args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
-        sys.exit(launch_ranks(args.gpus))
-    real_stdout = claim_stdout()
+def open_rank(args):
+    """This process as a rank of the job: device, process group (RCCL, or gloo in the one-GPU test hook), the library's context and —
+    over RCCL — its communicator, the step watchdog.  Returns a namespace."""
+    import types
     import torch
     import torch.distributed as dist
-    from snp_pipeline_amd import _lib as L
     from snp_pipeline_amd import device as dev
     from snp_pipeline_amd import sharding
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
+    r = types.SimpleNamespace(torch=torch, dist=dist, dev=dev, sharding=sharding)
+    r.rank = int(os.environ.get("RANK", "0"))
+    r.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    r.world = int(os.environ.get("WORLD_SIZE", "1"))
+    if r.world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch %d ranks with torch.distributed.run, or run plain "
-                         "`python bench.py --gpus %d` and let it start them" % (world, args.gpus, args.gpus, args.gpus))
+                         "`python bench.py --gpus %d` and let it start them" % (r.world, args.gpus, args.gpus, args.gpus))
     # functional test hook (not a measurement mode): all ranks on one GPU over gloo, to exercise the N > 1 code path on
     # a single-GPU box
-    one_gpu = os.environ.get("SNPGPU_BENCH_TEST_ONE_GPU") == "1"
-    if one_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    backend = None
+    r.one_gpu = os.environ.get("SNPGPU_BENCH_TEST_ONE_GPU") == "1"
+    if r.one_gpu:
+        r.local_rank = 0
+    torch.cuda.set_device(r.local_rank)
+    r.backend = None
     # (a second functional hook: SNPGPU_DIST_AT_WORLD_1=1 makes a group of one rank and still runs every collective of the
     # N > 1 step — the RCCL calls on device tensors — on a box with one GPU)
-    multi = world > 1 or sharding.group_of_one_exchanges()
-    if multi:
-        backend = "gloo" if one_gpu else "nccl"
-        if one_gpu:
+    r.multi = r.world > 1 or sharding.group_of_one_exchanges()
+    if r.multi:
+        r.backend = "gloo" if r.one_gpu else "nccl"
+        if r.one_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    d = dev.Device(local_rank)
-    d.use_torch_stream()
+            dist.init_process_group("nccl", device_id=torch.device("cuda", r.local_rank))
+    r.d = dev.Device(r.local_rank)
+    r.d.use_torch_stream()
     # over RCCL the exchanges of the step are calls into libsnpgpu.so on the context's stream (csrc/comm.hip: ncclAllGather, grouped
     # ncclSend / ncclRecv, hand-written tile kernels); torch.distributed stays for the barrier and for adding up the timings.  The
     # gloo hook (all ranks on one GPU) and SNPGPU_COMM=torch keep the torch.distributed route for the exchanges too.
-    abi_route = bool(multi and not one_gpu and os.environ.get("SNPGPU_COMM") != "torch" and sharding.use_abi_comm(d))
-    comm_info = d.comm_info() if abi_route else None
+    r.abi_route = bool(r.multi and not r.one_gpu and os.environ.get("SNPGPU_COMM") != "torch" and sharding.use_abi_comm(r.d))
+    r.comm_info = r.d.comm_info() if r.abi_route else None
     # a rank that never arrives must end the run, not hang it: every step is watched (the phase it was in goes to stderr, exit code 3)
-    watch = StepWatch(rank, float(os.environ.get("SNPGPU_BENCH_STEP_TIMEOUT", "600")))
+    r.watch = StepWatch(r.rank, float(os.environ.get("SNPGPU_BENCH_STEP_TIMEOUT", "600")))
 
+    def barrier():
+        r.watch.phase("barrier")
+        torch.cuda.synchronize()
+        if r.multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        r.watch.phase(None)
+    r.barrier = barrier
+    return r
+
+
+def synthetic_inputs(args, r):
+    """The rank's batch: reference seed 1, sites seed 2, pileups seed 3, generated on the device and resident in HBM; the
+    site set; the phase-1 SNP records of its samples.  Returns a namespace."""
+    import types
+    from snp_pipeline_amd import _lib as L
+    torch, d = r.torch, r.d
+    x = types.SimpleNamespace()
     G, S = args.genome, args.sites
     if args.scaling == "weak":
-        n_total = world * args.samples
-        g0, g1 = rank * args.samples, (rank + 1) * args.samples
+        x.n_total = r.world * args.samples
+        x.g0, x.g1 = r.rank * args.samples, (r.rank + 1) * args.samples
     else:
-        n_total = args.samples
-        g0, g1 = sharding.shard_bounds(n_total, rank, world)
-    B = g1 - g0                                               # this rank's samples: global indices [g0, g1)
-    # ---- synthetic inputs: reference seed 1, sites seed 2, pileups seed 3 -----------------------
+        x.n_total = args.samples
+        x.g0, x.g1 = r.sharding.shard_bounds(x.n_total, r.rank, r.world)
+    B = x.B = x.g1 - x.g0                                     # this rank's samples: global indices [g0, g1)
     ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda")
     d.synth_reference_dev(1, G, ref.data_ptr())
     torch.cuda.synchronize()
@@ -195,41 +210,46 @@ def main():
     alt_host = np.zeros(G + 1, dtype=np.uint8)
     alt_host[pos] = acgt[(code + 1 + rng.integers(0, 3, size=S)) % 4]
     alt = torch.from_numpy(alt_host).cuda()
-
     sizes = []
     for i in range(B):
-        sizes.append(d.synth_pileup_dev(3, g0 + i, G, ref.data_ptr(), alt.data_ptr(), 0, 0, mean_depth=args.depth))
+        sizes.append(d.synth_pileup_dev(3, x.g0 + i, G, ref.data_ptr(), alt.data_ptr(), 0, 0, mean_depth=args.depth))
     offs = np.zeros(B + 1, dtype=np.uint64)
     for i, n in enumerate(sizes):
         offs[i + 1] = offs[i] + ((n + 255) // 256) * 256
     pile = torch.empty(int(offs[-1]) + 256, dtype=torch.uint8, device="cuda")
     for i in range(B):
-        n = d.synth_pileup_dev(3, g0 + i, G, ref.data_ptr(), alt.data_ptr(), pile.data_ptr() + int(offs[i]),
+        n = d.synth_pileup_dev(3, x.g0 + i, G, ref.data_ptr(), alt.data_ptr(), pile.data_ptr() + int(offs[i]),
                                sizes[i], mean_depth=args.depth)
         assert n == sizes[i]
     torch.cuda.synchronize()
-    pile_bytes = int(sum(sizes))
-
-    keys = [(b"synth_chr1", int(p)) for p in pos]
-    ss = d.siteset(keys, [L.SITE_IN_SNPLIST] * S)
-    prm = dev.make_params(0, 0.6, 3, 0, 0.0)                  # pipeline defaults (snppipeline.conf:249)
-
+    x.G, x.S, x.ref, x.refh, x.pos, x.alt, x.sizes, x.offs, x.pile = G, S, ref, refh, pos, alt, sizes, offs, pile
+    x.pile_bytes = int(sum(sizes))
+    x.ss = d.siteset([(b"synth_chr1", int(p)) for p in pos], [L.SITE_IN_SNPLIST] * S)
+    x.prm = r.dev.make_params(0, 0.6, 3, 0, 0.0)              # pipeline defaults (snppipeline.conf:249)
     # phase-1 SNP records of every sample (what merge_sites reads from var.flt.vcf): a fixed subset of the sites per
     # sample, keyed by the global sample index so that every rank can also tell what the union must be
-    recs = min(args.vcf_records, S)
+    x.recs = min(args.vcf_records, S)
+    x.sample_records = lambda g: np.sort(np.random.default_rng(1000 + g).choice(pos, size=x.recs, replace=False))     # noqa: E731
+    x.local_keys = torch.from_numpy(np.concatenate([x.sample_records(g) for g in range(x.g0, x.g1)] + [np.zeros(0, np.int64)]).astype(np.int64)).cuda()
+    x.local_samp = torch.from_numpy(np.repeat(np.arange(x.g0, x.g1, dtype=np.int32), x.recs)).cuda()
+    return x
 
-    def sample_records(g):
-        return np.sort(np.random.default_rng(1000 + g).choice(pos, size=recs, replace=False))
 
-    local_keys = torch.from_numpy(np.concatenate([sample_records(g) for g in range(g0, g1)] + [np.zeros(0, np.int64)]).astype(np.int64)).cuda()
-    local_samp = torch.from_numpy(np.repeat(np.arange(g0, g1, dtype=np.int32), recs)).cuda()
-    n_records = n_total * recs
+PHASES = ("c1_gather_and_site_union", "scan_and_call", "pack_and_c2_row_gather", "distance_tiles", "row_band_exchange")
+
+
+def timed_steps(args, r, x):
+    """W warm-up steps, then exactly K steps between barriers; checks of what they left.  Returns a namespace of timings and buffers."""
+    import types
+    torch, dist, d, sharding, watch = r.torch, r.dist, r.d, r.sharding, r.watch
+    B, S, n_total, rank, world = x.B, x.S, x.n_total, r.rank, r.world
+    t = types.SimpleNamespace()
+    n_records = t.n_records = n_total * x.recs
     u_keys = torch.zeros(max(n_records, 1), dtype=torch.int64, device="cuda")
     u_off = torch.zeros(n_records + 1, dtype=torch.int32, device="cuda")
     u_car = torch.zeros(max(n_records, 1), dtype=torch.int32, device="cuda")
     u_n = torch.zeros(4, dtype=torch.int32, device="cuda")
-
-    bases = torch.empty((B, S), dtype=torch.uint8, device="cuda")
+    bases = t.bases = torch.empty((B, S), dtype=torch.uint8, device="cuda")
     filt = torch.empty((B, S), dtype=torch.uint8, device="cuda")
     status = torch.empty((max(B, 1), 4), dtype=torch.int64, device="cuda")
     row_bytes = d.packed_row_bytes(S)
@@ -238,10 +258,8 @@ def main():
     per = (n_total + world - 1) // world
     packed_pad = torch.zeros((max(bands.n_padded, world * per), row_bytes), dtype=torch.uint8, device="cuda")
     dmat = torch.zeros((bands.n_padded, bands.n_padded), dtype=torch.int32, device="cuda")
-    sizes_np = np.asarray(sizes, dtype=np.uint64)
+    sizes_np = np.asarray(x.sizes, dtype=np.uint64)
     band_holder = [None]
-
-    PHASES = ("c1_gather_and_site_union", "scan_and_call", "pack_and_c2_row_gather", "distance_tiles", "row_band_exchange")
     phase_events = []                                         # per timed step: len(PHASES) + 1 events on the stream the kernels run on
 
     def step(timed=False):
@@ -253,14 +271,14 @@ def main():
                 ev[k].record()
         mark(0)
         # C1: every rank's SNP records -> the same site union on every rank (the snplist)
-        keys_all, _ = sharding.all_gather_varlen(local_keys)
-        samp_all, _ = sharding.all_gather_varlen(local_samp)
+        keys_all, _ = sharding.all_gather_varlen(x.local_keys)
+        samp_all, _ = sharding.all_gather_varlen(x.local_samp)
         d.merge_sites_dev(keys_all.data_ptr(), samp_all.data_ptr(), keys_all.numel(), u_keys.data_ptr(), u_off.data_ptr(),
                           u_car.data_ptr(), u_n.data_ptr())
         mark(1)
         # one scan launch and one call launch for the rank's whole batch; sample i is bytes [offs[i], offs[i] + sizes[i])
         if B:
-            d.call_consensus_batch_dev(ss, pile.data_ptr(), offs[:B], prm, bases.data_ptr(), filt.data_ptr(), status.data_ptr(),
+            d.call_consensus_batch_dev(x.ss, x.pile.data_ptr(), x.offs[:B], x.prm, bases.data_ptr(), filt.data_ptr(), status.data_ptr(),
                                        sizes=sizes_np)
         mark(2)
         if B:
@@ -275,153 +293,166 @@ def main():
         if timed:
             phase_events.append(ev)
 
-    def barrier():
-        watch.phase("barrier")
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-        watch.phase(None)
-
     for _ in range(args.warmup):
         step()
-    barrier()
+    r.barrier()
     d.kernel_timing(True)
     d.kernel_time_ms(0), d.kernel_time_ms(1), d.kernel_time_ms(2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(timed=True)
-    barrier()
+    r.barrier()
     elapsed = time.perf_counter() - t0
     # where the step's time goes on this rank (events on the kernels' stream; with gloo the collectives are host work between
     # them), and the slowest rank per phase
     phase_ms = [sum(ev[k].elapsed_time(ev[k + 1]) for ev in phase_events) / max(len(phase_events), 1) for k in range(len(PHASES))]
     phase_max = list(phase_ms)
     phase_all = [list(phase_ms)]
-    if multi:
-        pt = torch.tensor(phase_ms, dtype=torch.float64, device="cpu" if one_gpu else "cuda")
+    if r.multi:
+        pt = torch.tensor(phase_ms, dtype=torch.float64, device="cpu" if r.one_gpu else "cuda")
         every = [torch.zeros_like(pt) for _ in range(world)]
         dist.all_gather(every, pt)
-        phase_all = [[float(x) for x in t.tolist()] for t in every]
-        phase_max = [max(r[k] for r in phase_all) for k in range(len(PHASES))]
-    scan_ms, scan_n = d.kernel_time_ms(0)
-    call_ms, call_n = d.kernel_time_ms(1)
-    dist_ms, dist_n = d.kernel_time_ms(2)
+        phase_all = [[float(v) for v in e.tolist()] for e in every]
+        phase_max = [max(p[k] for p in phase_all) for k in range(len(PHASES))]
+    t.phase_ms, t.phase_max, t.phase_all = phase_ms, phase_max, phase_all
+    t.scan_ms, t.scan_n = d.kernel_time_ms(0)
+    t.call_ms, _ = d.kernel_time_ms(1)
+    t.dist_ms, _ = d.kernel_time_ms(2)
     d.kernel_timing(False)
-    if multi:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
+    if r.multi:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if r.one_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-
+    t.elapsed = elapsed
+    # ---- what the steps left ------------------------------------------------------------------------------------------------------
     if B:
         st = status[:B].cpu().numpy()
         if (st[:, 0] != -1).any():
             raise SystemExit("scan reported a malformed pileup: %r" % st[:, 0])
         if (filt.cpu().numpy() & 0x80).any():
             raise SystemExit("caller reported a malformed line")
-    want_union = len(np.unique(np.concatenate([sample_records(g) for g in range(n_total)]))) if n_total * recs <= 4_000_000 else None
+    want_union = len(np.unique(np.concatenate([x.sample_records(g) for g in range(n_total)]))) if n_total * x.recs <= 4_000_000 else None
     if want_union is not None and int(u_n[0]) != want_union:
         raise SystemExit("site union has %d keys, expected %d" % (int(u_n[0]), want_union))
+    t.unique_sites, t.carriers = int(u_n[0]), int(u_n[1])
     if args.dump:
         lo, hi = bands.band_rows(rank)
-        nu = int(u_n[0])
-        np.savez(args.dump + ".rank%d.npz" % rank, union=u_keys[:nu].cpu().numpy(), union_off=u_off[:nu + 1].cpu().numpy(),
-                 carriers=u_car[:int(u_n[1])].cpu().numpy(), packed=packed_pad[:n_total].cpu().numpy(),
+        np.savez(args.dump + ".rank%d.npz" % rank, union=u_keys[:t.unique_sites].cpu().numpy(), union_off=u_off[:t.unique_sites + 1].cpu().numpy(),
+                 carriers=u_car[:t.carriers].cpu().numpy(), packed=packed_pad[:n_total].cpu().numpy(),
                  band=band_holder[0][:hi - lo, :n_total].cpu().numpy(), band_rows=np.array([lo, hi]), bases=bases.cpu().numpy(),
-                 first_sample=np.array([g0, g1]))
+                 first_sample=np.array([x.g0, x.g1]))
+    return t
 
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = n_total * S / (elapsed / args.steps)
-    scan_avg_ms = scan_ms / max(scan_n, 1)
-    algo_bytes = pile_bytes * args.steps / max(scan_n, 1)       # per launch: the rank's whole batch of pileup text
+
+def headline(args, r, x, t):
+    """The result object of the timed steps: the contract's keys, the workload, who made the exchanges, K1's roofline, the phases."""
+    dist, world, multi = r.dist, r.world, r.multi
+    per_step = t.elapsed / args.steps
+    scan_avg_ms = t.scan_ms / max(t.scan_n, 1)
+    algo_bytes = x.pile_bytes * args.steps / max(t.scan_n, 1)   # per launch: the rank's whole batch of pileup text
     achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
-
-    # HBM traffic of one scan launch from the committed PMC passes (rocprofv3 cannot run inside this process); only
-    # quoted when it was measured on this very workload
+    # HBM traffic of one scan launch from the committed PMC passes of this very workload: what stands in where the run cannot measure it
+    # itself (N > 1, --no-live-traffic, no rocprofv3)
     pt, pt_src = rows.committed_traffic("pmc_traffic.json", lambda p: (p["workload"]["samples_per_gpu"], p["workload"]["genome_bp"], p["workload"]["mean_depth"],
-                                                                       p["workload"]["snp_sites"]) == (B, G, args.depth, S))
+                                                                       p["workload"]["snp_sites"]) == (x.B, x.G, args.depth, x.S))
     traffic = pt["traffic_bytes_per_launch"] if pt else None
     traffic_note = ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this workload; not of this very run)" % pt_src) if pt else None
-
-    out = {
-        "metric": "consensus_bases_called_per_sec", "value": value, "unit": "bases/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+    return {
+        "metric": "consensus_bases_called_per_sec", "value": x.n_total * x.S / per_step, "unit": "bases/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_step * 1e3, "higher_is_better": True,
         "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "BASELINE configs[3] shard (%d samples%s x %d bp x %gx synthetic pileups, %d SNP sites, %d SNP records "
                                "per sample; the reference bundles no pileups); step = site-record gather + site union, one batched "
                                "scan launch + one call launch, 4-bit pack, row all-gather, all-pairs distance tiles, row-band exchange"
-                               % (args.samples, "/GPU" if args.scaling == "weak" else " in total", G, args.depth, S, recs),
-                   "samples_total": n_total, "samples_this_rank": B, "genome_bp": G, "mean_depth": args.depth, "snp_sites": S,
-                   "pileup_bytes_this_rank": pile_bytes, "caller": "q0 c0.6 D3 d0 b0",
+                               % (args.samples, "/GPU" if args.scaling == "weak" else " in total", x.G, args.depth, x.S, x.recs),
+                   "samples_total": x.n_total, "samples_this_rank": x.B, "genome_bp": x.G, "mean_depth": args.depth, "snp_sites": x.S,
+                   "pileup_bytes_this_rank": x.pile_bytes, "caller": "q0 c0.6 D3 d0 b0",
                    "parallelism": "samples sharded over %d rank(s)%s"
-                                  % (world, (", backend %s, world size %d" % (backend, dist.get_world_size())) if multi else "")},
+                                  % (world, (", backend %s, world size %d" % (r.backend, dist.get_world_size())) if multi else "")},
         "comm": {"backend": (dist.get_backend() if multi else None), "world_size": (dist.get_world_size() if multi else 1),
                  "launcher": "bench.py started its own ranks (torch.distributed.run, 127.0.0.1)" if os.environ.get("SNPGPU_BENCH_LAUNCHER") == "self"
                  else ("torch.distributed.run around bench.py" if multi else "none (one process)"),
                  "collectives_per_step": "C1 variable-length all-gather of site records, C2 all-gather of packed rows, one all-to-all of distance tiles" if multi else "none"},
         "comm_route": ({"exchanges": "libsnpgpu.so (snpgpu_allgather / snpgpu_allgatherv / snpgpu_alltoallv on the context's stream, csrc/comm.hip)",
-                        "rccl_version": comm_info["rccl_version"], "world_size_rccl_reports": comm_info["rccl_comm_count"], "rank": comm_info["rank"]}
-                       if abi_route else ({"exchanges": "torch.distributed (%s)" % backend} if multi else None)),
-        "genome_bp_per_sec": n_total * G / (elapsed / args.steps),
-        "pileup_gb_per_sec": (pile_bytes * n_total / max(B, 1)) / (elapsed / args.steps) / 1e9,
+                        "rccl_version": r.comm_info["rccl_version"], "world_size_rccl_reports": r.comm_info["rccl_comm_count"], "rank": r.comm_info["rank"]}
+                       if r.abi_route else ({"exchanges": "torch.distributed (%s)" % r.backend} if multi else None)),
+        "genome_bp_per_sec": x.n_total * x.G / per_step,
+        "pileup_gb_per_sec": (x.pile_bytes * x.n_total / max(x.B, 1)) / per_step / 1e9,
         "roofline": {"kernel": "k_scan_wave", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_over_algorithmic": (traffic / algo_bytes) if traffic and algo_bytes else None, "traffic_source": traffic_note,
-                     "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},
-        "kernels_ms_per_step": {"k_scan_wave": scan_ms / args.steps, "k_call_sites": call_ms / args.steps,
-                                "k_distance": dist_ms / args.steps},
-        "site_union": {"records": n_records, "unique_sites": int(u_n[0]), "carriers": int(u_n[1])},
-        "phases_ms_per_step": {"rank0": dict(zip(PHASES, phase_ms)), "max_over_ranks": dict(zip(PHASES, phase_max)),
-                               "per_rank": [dict(zip(PHASES, r)) for r in phase_all],
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_over_algorithmic": (traffic / algo_bytes) if traffic and algo_bytes else None,
+                     "traffic_source": traffic_note, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms, "launches": t.scan_n},
+        "kernels_ms_per_step": {"k_scan_wave": t.scan_ms / args.steps, "k_call_sites": t.call_ms / args.steps, "k_distance": t.dist_ms / args.steps},
+        "site_union": {"records": t.n_records, "unique_sites": t.unique_sites, "carriers": t.carriers},
+        "phases_ms_per_step": {"rank0": dict(zip(PHASES, t.phase_ms)), "max_over_ranks": dict(zip(PHASES, t.phase_max)),
+                               "per_rank": [dict(zip(PHASES, p)) for p in t.phase_all],
                                "note": "device time between events on the kernels' stream, averaged over the timed steps"},
     }
 
-    on_rank0_alone = rank == 0 and world == 1 and B > 0
-    # ---- the shard as ONE job from files to files (hot_path_batch); first of the side rows: the device memory it takes has not
-    #      been through the other rows' allocations and frees, as in a job of its own -------------------------------------
-    if on_rank0_alone and args.pipeline_files > 0:
-        out["pipeline_from_files"] = rows.side_row(rows.pipeline_from_files, pile, offs, sizes, refh, G, min(args.pipeline_files, B), not args.skip_separate_steps)
-    # ---- secondary metric: the distance step alone at configs[4] shape (kernel + row-band exchange) ------------------
+
+def side_rows(args, r, x, t, out):
+    """Everything measured after the timed region (bench_rows.py), into `out`; most of it on rank 0 at N = 1 only."""
+    from snp_pipeline_amd import _lib as L
+    torch, d, dev = r.torch, r.d, r.dev
+    B, G, S = x.B, x.G, x.S
+    alone = r.rank == 0 and r.world == 1 and B > 0
+    # the shard as ONE job from files to files (hot_path_batch); first: the device memory it takes has not been through the other rows'
+    # allocations and frees, as in a job of its own
+    if alone and args.pipeline_files > 0:
+        out["pipeline_from_files"] = rows.side_row(rows.pipeline_from_files, x.pile, x.offs, x.sizes, x.refh, G, min(args.pipeline_files, B), not args.skip_separate_steps)
+    # secondary metric: the distance step alone at configs[4] shape (kernel + row-band exchange)
     if not args.skip_secondary:
-        out["secondary"] = rows.secondary_distance(d, sharding, args, rank, world, multi, one_gpu, barrier, watch)
-    # ---- context figures (rank 0, N = 1): a measured device-copy ceiling and the small latency-bound steps ------------
-    if rank == 0 and world == 1 and not args.skip_aux:
+        out["secondary"] = rows.secondary_distance(d, r.sharding, args, r.rank, r.world, r.multi, r.one_gpu, r.barrier, r.watch)
+    # context figures: a measured device-copy ceiling and the small latency-bound steps
+    if r.rank == 0 and r.world == 1 and not args.skip_aux:
         out["roofline"]["measured_copy_gbps_read_plus_write"] = rows.device_copy_gbps(torch)
-        out["aux_steps_ms"] = rows.aux_steps(d, pos, G)
-    # ---- the scan kernel on its weak shapes (shallow / deep pileups, CR LF, many contigs) -------------------------------
-    if on_rank0_alone and args.shape_samples > 0:
-        out["scan_shapes"] = rows.side_row(rows.scan_shapes, d, L, dev, ref, alt, G, pos, args.shape_samples)
-    # ---- end to end: pileup FILES in the page cache -> consensus bytes on the host, through the streamed ingestion ----
-    if on_rank0_alone and args.e2e_files > 0:
-        out["end_to_end"] = rows.side_row(rows.end_to_end, d, ss, prm, pile, offs, sizes, bases, min(args.e2e_files, B), S)
-    # ---- the call paths the headline leaves out: per-site counts (the default configuration's consensus.vcf), the strict caller,
-    #      --vcfAllPos --------------------------------------------------------------------------------------------------------
-    if on_rank0_alone and not args.skip_call_variants:
-        out["call_variants"] = rows.side_row(rows.call_variants, d, ss, prm, pile, offs, sizes, S, dev, torch, pos)
-    # ---- phase-1 site calling on files -----------------------------------------------------------------
-    if on_rank0_alone and args.site_files > 0:
-        out["site_calling"] = rows.side_row(rows.site_calling, d, pile, offs, sizes, min(args.site_files, B))
-    # ---- CPU baseline: the oracle on samples of the batch; rank 0, N = 1 -----------------------------
-    if on_rank0_alone and args.cpu_samples > 0:
-        out["cpu_baseline"] = rows.cpu_baseline(args, d, pile, offs, sizes, bases, pos, G, S, value, out.get("secondary"))
+        out["aux_steps_ms"] = rows.aux_steps(d, x.pos, G)
+    # the scan kernel on its weak shapes (shallow / deep pileups, CR LF, many contigs)
+    if alone and args.shape_samples > 0:
+        out["scan_shapes"] = rows.side_row(rows.scan_shapes, d, L, dev, x.ref, x.alt, G, x.pos, args.shape_samples)
+    # end to end: pileup FILES in the page cache -> consensus bytes on the host, through the streamed ingestion
+    if alone and args.e2e_files > 0:
+        out["end_to_end"] = rows.side_row(rows.end_to_end, d, x.ss, x.prm, x.pile, x.offs, x.sizes, t.bases, min(args.e2e_files, B), S)
+    # the call paths the headline leaves out: per-site counts (the default configuration's consensus.vcf), the strict caller, --vcfAllPos
+    if alone and not args.skip_call_variants:
+        out["call_variants"] = rows.side_row(rows.call_variants, d, x.ss, x.prm, x.pile, x.offs, x.sizes, S, dev, torch, x.pos)
+    # phase-1 site calling on files (SURVEY 8f #4)
+    if alone and args.site_files > 0:
+        out["site_calling"] = rows.side_row(rows.site_calling, d, x.pile, x.offs, x.sizes, min(args.site_files, B))
+    # CPU baseline (BASELINE.md 3): the oracle on samples of the batch
+    if alone and args.cpu_samples > 0:
+        out["cpu_baseline"] = rows.cpu_baseline(args, d, x.pile, x.offs, x.sizes, t.bases, x.pos, G, S, out["value"], out.get("secondary"))
         rows.from_files_ratios(out, S)
-    # ---- the scan's HBM traffic, measured now (two short child runs under rocprofv3 --pmc); N = 1 only ------------------------------
-    if on_rank0_alone and not args.no_live_traffic:
-        watch.phase(None)
+    # the scan's HBM traffic, measured now (two short child runs under rocprofv3 --pmc)
+    if alone and not args.no_live_traffic:
+        r.watch.phase(None)
         torch.cuda.empty_cache()                                 # (the child generates the same 54 GB beside this process's)
-        live = rows.live_traffic(args, algo_bytes)
+        live = rows.live_traffic(args, out["roofline"]["algorithmic_bytes_per_launch"])
         if "error" in live:
             out["roofline"]["traffic_live_error"] = live["error"]
         else:
             out["roofline"].update(live)
-    if rank == 0:
-        out["north_star"] = rows.north_star(out, args, world, S)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    real_stdout = claim_stdout()
+    r = open_rank(args)
+    x = synthetic_inputs(args, r)
+    t = timed_steps(args, r, x)
+    out = headline(args, r, x, t)
+    side_rows(args, r, x, t, out)
+    line = None
+    if r.rank == 0:
+        out["north_star"] = rows.north_star(out, args, r.world, x.S)
         line = json.dumps(compact(out), separators=(",", ":"))
         if len(line) >= COMPACT_LIMIT:                          # never lose the headline to its own length again (BENCH_r05: parsed = null)
             line = json.dumps(compact(out, minimal=True), separators=(",", ":"))
         write_detail(args.detail, out)
-    if multi:
-        dist.destroy_process_group()
-    if rank == 0:
+    if r.multi:
+        r.dist.destroy_process_group()
+    if r.rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (line + "\n").encode())
 
