@@ -300,6 +300,18 @@ int  snpgpu_call_all_lines_compact_file(snpgpu_ctx *ctx, const snpgpu_siteset *s
                                         uint32_t wide_capacity, uint32_t *out_n_wide, uint32_t *out_wide_index,
                                         snpgpu_site_counts *out_wide, uint64_t *out_status);
 
+/* Rows of consensus.vcf from such records, host code (no device): the lines [0, n_lines) of the pileup text `pileup[0, nbytes)`, CHROM and
+ * POS of a row from the line's own first two fields (POS as int() prints it), the numbers from records[i] — or, where that says
+ * SNPGPU_LINE_WIDE, from the entry of wide[] whose wide_index equals i (ascending) — laid out as vcf_writer.py:295-379 does.
+ * only_listed: rows for lines with site_flags != 0 only.  Returns the bytes the rows take and writes at most `capacity` of them to out
+ * (capacity 0: just the size); *out_n_rows rows; *out_bad_line: -1, or the line whose record the writer refuses (more symbols than it
+ * keeps and no spill record; an offset outside the text) — nothing is returned then. */
+size_t snpgpu_format_line_rows(const uint8_t *pileup, uint64_t nbytes, const uint64_t *line_off, const snpgpu_line_record *records,
+                               uint64_t n_lines, const uint32_t *wide_index, const snpgpu_site_counts *wide, uint32_t n_wide,
+                               const char *const *filter_names, int preserve_ref_case, char failed_snp_gt,
+                               const snpgpu_symbol_spill *spill, uint32_t n_spill, int only_listed, char *out, size_t capacity,
+                               uint64_t *out_n_rows, int64_t *out_bad_line);
+
 /* call_consensus --vcfAllPos from file to file: every row of consensus.vcf (call_consensus.py:148-151, vcf_writer.py:381-435: one
  * row per pileup LINE, in file order; CHROM and POS are the line's own first two fields, POS as int() prints it) formatted by the
  * library's host threads from the 32-byte records, straight into vcf_path behind `header` (the text of the header lines).

@@ -137,6 +137,8 @@ SIGNATURES = {
                                              _P, _P, _P, _P]),
     "snpgpu_call_all_lines_compact_file": (C.c_int, [_P, _P, C.c_char_p, C.POINTER(CallerParams), C.c_uint64, C.POINTER(C.c_uint64), _P, _P,
                                                      C.c_uint32, C.POINTER(C.c_uint32), _P, _P, _P]),
+    "snpgpu_format_line_rows": (C.c_size_t, [_P, C.c_uint64, _P, _P, C.c_uint64, _P, _P, C.c_uint32, C.POINTER(C.c_char_p), C.c_int, C.c_char, _P, C.c_uint32,
+                                             C.c_int, _P, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]),
     "snpgpu_write_all_positions_vcf": (C.c_int, [_P, _P, C.c_char_p, C.POINTER(CallerParams), C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_char,
                                                  C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _P, _P]),
     "snpgpu_format_vcf_rows": (C.c_size_t, [_P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_char_p), C.c_int, C.c_char, _P, C.c_uint32, _P,

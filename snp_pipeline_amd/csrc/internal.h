@@ -156,7 +156,7 @@ int snpgpu_enqueue_gather_wide(snpgpu_ctx *ctx, const snpgpu_site_counts *d_coun
                                uint32_t capacity, uint32_t *d_wide_index, snpgpu_site_counts *d_wide);
 void snpgpu_expand_line_record(const snpgpu_line_record &r, snpgpu_site_counts *out);
 // vcf_rows.hip: consensus.vcf rows of the lines [lo, hi) from those records (host)
-bool snpgpu_format_line_rows(const uint8_t *text, uint64_t nbytes, const uint64_t *line_off, const snpgpu_line_record *recs, uint64_t first, uint64_t lo, uint64_t hi,
+bool snpgpu_line_rows_into(const uint8_t *text, uint64_t nbytes, const uint64_t *line_off, const snpgpu_line_record *recs, uint64_t first, uint64_t lo, uint64_t hi,
                              const uint32_t *wide_index, const snpgpu_site_counts *wide, uint32_t n_wide, const char *const *filter_names,
                              int preserve_ref_case, char failed_snp_gt, const snpgpu_symbol_spill *spill, uint32_t n_spill, int only_listed,
                              std::vector<char> &out, uint64_t *n_rows, uint64_t *bad_line);

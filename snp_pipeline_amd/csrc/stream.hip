@@ -1037,7 +1037,7 @@ int snpgpu_write_all_positions_vcf(snpgpu_ctx *ctx, const snpgpu_siteset *ss, co
             const uint64_t *off = (const uint64_t *)pinned[k];
             const snpgpu_line_record *recs = (const snpgpu_line_record *)((const char *)pinned[k] + 8 * piece);
             Piece &pc = out[pi];
-            pc.bad = !snpgpu_format_line_rows(text, al.nbytes, off, recs, lo, lo, hi, wide_index.data(), wide.data(), n_wide, filter_names, preserve_ref_case,
+            pc.bad = !snpgpu_line_rows_into(text, al.nbytes, off, recs, lo, lo, hi, wide_index.data(), wide.data(), n_wide, filter_names, preserve_ref_case,
                                               failed_snp_gt, spill.data(), n_spill, only_listed, pc.text, &pc.rows, &pc.bad_line);
             std::unique_lock<std::mutex> lk(mu);
             buffer_free[k] = 1;

@@ -275,7 +275,7 @@ void write_consensus_job(snpgpu_consensus_job &job, uint32_t n_sites, const uint
 // wide lines (recs[i].n_symbols == SNPGPU_LINE_WIDE) take their full record from wide[] — wide_index is ascending, so a range walks
 // it from its first entry on.  only_listed: rows for the lines whose position is in the site set only.  Returns false for a record
 // the writer refuses (more symbols than it keeps and no spill record): *bad_line says which.
-bool snpgpu_format_line_rows(const uint8_t *text, uint64_t nbytes, const uint64_t *line_off, const snpgpu_line_record *recs, uint64_t first, uint64_t lo, uint64_t hi,
+bool snpgpu_line_rows_into(const uint8_t *text, uint64_t nbytes, const uint64_t *line_off, const snpgpu_line_record *recs, uint64_t first, uint64_t lo, uint64_t hi,
                              const uint32_t *wide_index, const snpgpu_site_counts *wide, uint32_t n_wide, const char *const *filter_names,
                              int preserve_ref_case, char failed_snp_gt, const snpgpu_symbol_spill *spill, uint32_t n_spill, int only_listed,
                              std::vector<char> &out, uint64_t *n_rows, uint64_t *bad_line) {
@@ -341,6 +341,33 @@ bool snpgpu_format_line_rows(const uint8_t *text, uint64_t nbytes, const uint64_
     out.resize(used);
     *n_rows = rows;
     return true;
+}
+
+// The same as a plain function of host arrays (a host that took the records of snpgpu_call_all_lines_compact_file and wants rows; the
+// CPU tests and the sanitizer runs of this text-parsing code): rows of lines [0, n_lines) into out[0, capacity); returns the bytes the
+// rows take (call with capacity 0 to size the buffer).
+extern "C" size_t snpgpu_format_line_rows(const uint8_t *pileup, uint64_t nbytes, const uint64_t *line_off, const snpgpu_line_record *records,
+                                          uint64_t n_lines, const uint32_t *wide_index, const snpgpu_site_counts *wide, uint32_t n_wide,
+                                          const char *const *filter_names, int preserve_ref_case, char failed_snp_gt,
+                                          const snpgpu_symbol_spill *spill, uint32_t n_spill, int only_listed, char *out, size_t capacity,
+                                          uint64_t *out_n_rows, int64_t *out_bad_line) {
+    if (out_n_rows) *out_n_rows = 0;
+    if (out_bad_line) *out_bad_line = -1;
+    if (n_lines && (!pileup || !line_off || !records || !filter_names)) return 0;
+    for (uint64_t i = 0; i < n_lines; ++i)
+        if (line_off[i] == 0 || line_off[i] > nbytes) { if (out_bad_line) *out_bad_line = (int64_t)i; return 0; }     // (offsets are 1 + byte offset)
+    std::vector<char> text;
+    uint64_t rows = 0, bad = 0;
+    static const uint32_t no_index = 0;
+    static const snpgpu_site_counts no_wide = {};
+    if (!snpgpu_line_rows_into(pileup, nbytes, line_off, records, 0, 0, n_lines, n_wide ? wide_index : &no_index, n_wide ? wide : &no_wide, n_wide, filter_names,
+                               preserve_ref_case, failed_snp_gt, spill, n_spill, only_listed, text, &rows, &bad)) {
+        if (out_bad_line) *out_bad_line = (int64_t)bad;
+        return 0;
+    }
+    if (out_n_rows) *out_n_rows = rows;
+    if (out && capacity) memcpy(out, text.data(), text.size() < capacity ? text.size() : capacity);
+    return text.size();
 }
 
 extern "C" size_t snpgpu_format_vcf_rows(const snpgpu_site_counts *counts, const uint32_t *order, uint32_t n_rows,

@@ -195,6 +195,35 @@ SPILL_DTYPE = np.dtype([("n", "<u4"), ("ref_len", "<u4"), ("depth64", "<i8"), ("
 assert SPILL_DTYPE.itemsize == C.sizeof(L.SymbolSpill)
 
 
+def pack_line_records(counts, flags):
+    """What k_compact_lines does, in numpy: (LINE_DTYPE records, indices of the wide lines, their COUNTS_DTYPE records) of per-line
+    COUNTS_DTYPE records and site flags.  A line is packed when its record is well-formed (status <= ST_OK), has at most three symbols
+    and no spill record, every count of the three fits 16 bits, nothing is counted past the symbols it says it has, and its depths are
+    the sums of the symbols' counts.  The tests hold the device's packing against this; a host without a device can make the
+    records snpgpu_format_line_rows takes."""
+    n = len(counts)
+    tot, fwd, rev = (counts[k].astype(np.int64) for k in ("total", "fwd", "rev"))
+    nsym = counts["n_symbols"].astype(np.int64)
+    ok = (counts["status"] <= L.ST_OK) & (nsym <= LINE_SYMS)
+    for a in (tot, fwd, rev):
+        ok &= (a[:, :LINE_SYMS] < 65536).all(axis=1)
+    ok &= (counts["good_depth"] == tot[:, :LINE_SYMS].sum(axis=1)) & (counts["fwd_good_depth"] == fwd[:, :LINE_SYMS].sum(axis=1)) & \
+          (counts["rev_good_depth"] == rev[:, :LINE_SYMS].sum(axis=1))
+    for k in range(LINE_SYMS):
+        ok &= (nsym > k) | (tot[:, k] == 0)
+    recs = np.zeros(n, dtype=LINE_DTYPE)
+    recs["raw_depth"] = counts["raw_depth"]
+    for name in ("total", "fwd", "rev"):
+        recs[name] = (counts[name][:, :LINE_SYMS] & 0xFFFF).astype(np.uint16)
+    recs["sym"] = counts["sym"][:, :LINE_SYMS]
+    for name in ("ref_base", "cons_base", "filters", "status"):
+        recs[name] = counts[name]
+    recs["n_symbols"] = np.where(ok, nsym & 0xFF, LINE_WIDE).astype(np.uint8)
+    recs["site_flags"] = flags
+    wide_index = np.nonzero(~ok)[0].astype(np.uint32)
+    return recs, wide_index, counts[wide_index].copy()
+
+
 def expand_line_records(recs, wide_index, wide):
     """(site flags, COUNTS_DTYPE records) of every line from the 32-byte records and the wide lines' full ones — what call_all_lines
     returns, rebuilt on the host (tests, and callers that want the per-line numbers rather than rows)."""

@@ -160,6 +160,30 @@ def write_all_positions_vcf_from_pileup(dev, siteset, path, sample_id, args, pil
                                        args.vcfFailedSnpGt, only_listed=only_listed, check=check)
 
 
+def format_line_rows(pileup, line_offsets, recs, wide_index, wide, filter_names, preserve_ref_case, failed_snp_gt, only_listed=False, spill=None):
+    """consensus.vcf rows (bytes) of the lines whose 32-byte records are `recs` (device.LINE_DTYPE; the wide ones in `wide`), CHROM and POS
+    from the pileup text itself: snpgpu_format_line_rows, the library's host formatter behind the file-to-file writer."""
+    import ctypes as C
+    lib = L.load()
+    text = np.frombuffer(pileup, dtype=np.uint8)
+    off = np.ascontiguousarray(line_offsets, dtype=np.uint64)
+    recs = np.ascontiguousarray(recs)
+    widx = np.ascontiguousarray(wide_index, dtype=np.uint32)
+    wide = np.ascontiguousarray(wide)
+    fn = (C.c_char_p * 6)(*[n.encode("ascii") for n in filter_names])
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None and len(a) else None      # noqa: E731
+    sp = np.ascontiguousarray(spill) if spill is not None and len(spill) else None
+    n_rows, bad = C.c_uint64(), C.c_int64(-1)
+    args = (ptr(text), len(text), ptr(off), ptr(recs), len(recs), ptr(widx), ptr(wide), len(widx), fn, 1 if preserve_ref_case else 0,
+            failed_snp_gt.encode("ascii"), ptr(sp), len(sp) if sp is not None else 0, 1 if only_listed else 0)
+    need = lib.snpgpu_format_line_rows(*args, None, 0, C.byref(n_rows), C.byref(bad))
+    if bad.value >= 0:
+        raise ValueError("line #%d: its record cannot be written (more symbols than a record keeps and no spill record, or an offset outside the text)" % bad.value)
+    buf = C.create_string_buffer(max(int(need), 1))
+    lib.snpgpu_format_line_rows(*args, buf, int(need), C.byref(n_rows), C.byref(bad))
+    return buf.raw[:int(need)], int(n_rows.value)
+
+
 def write_all_positions_vcf(path, sample_id, args, pileup_path, line_offsets, counts, spill=None):
     """The same file row by row in Python, from the per-line records of ``Device.call_all_lines``; CHROM and POS are the first two
     fields of the line itself.  The readable statement of the layout: the tests hold the library's rows against it."""

@@ -117,6 +117,9 @@ def test_line_records_of_32_bytes_equal_the_full_ones(d, tmp_path, seed, genome_
     assert 0 < n_wide < len(off) // 20 and np.all(np.diff(widx.astype(np.int64)) > 0)
     assert n_wide >= len(off) // 97 - 1
     assert (recs["n_symbols"][recs["n_symbols"] != dev.LINE_WIDE] <= dev.LINE_SYMS).all()
+    # the device's packing (k_compact_lines, k_gather_wide) is device.pack_line_records', record for record
+    recs_np, widx_np, _ = dev.pack_line_records(counts, flags)
+    assert np.array_equal(widx, widx_np) and recs.tobytes() == recs_np.tobytes()
 
 
 @pytest.mark.parametrize("seed, genome_len, kw", [

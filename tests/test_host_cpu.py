@@ -1381,3 +1381,81 @@ def test_contig_names_escape_to_ascii_in_order_and_back(tmp_path, monkeypatch):
     vcf.write_bytes(b"##x\n#CHROM\tPOS\nchr~45~26\t5\t.\tA~\n~00\t6\t.\tC\n")
     u.unescape_vcf_chrom(str(vcf))
     assert vcf.read_bytes() == "##x\n#CHROM\tPOS\nchrä\t5\t.\tA~\n~\t6\t.\tC\n".encode("utf-8")
+
+
+def test_library_line_rows_equal_python_rows():
+    """snpgpu_format_line_rows (the host formatter behind `call_consensus --vcfAllPos`: CHROM and POS from the pileup line itself, the
+    numbers from 32-byte line records, the full record where a line is wide) against the row-by-row Python statement of the same layout
+    (vcf_writer.row_from_counts <- vcf_writer.py:295-379) on random records and on pileup text with the first two columns in every
+    spelling split() and int() take: leading blanks, several blanks between the fields, '+7', '007', '1_000', '-12', '-0', names of one
+    byte and of 900, CR LF ends.  Also device.pack_line_records / expand_line_records there and back."""
+    import random
+    import numpy as np
+    from snp_pipeline_amd import _lib as L
+    from snp_pipeline_amd import device as dev
+    from snp_pipeline_amd import vcf_writer
+    rng = random.Random(11)
+    names = ["RawDpth", "VarFreq60", "Depth3", "StrDpth0", "StrBias0", "Region"]
+    n = 600
+    counts = np.zeros(n, dtype=dev.COUNTS_DTYPE)
+    flags = np.zeros(n, dtype=np.uint8)
+    lines, offs, heads = [], [], []
+    at = 0
+    for i in range(n):
+        c = counts[i]
+        k = rng.choice([0, 0, 1, 1, 2, 2, 3, 3, 4, 6, 8])
+        syms = rng.sample(list(b"*ACGTN#<"), k)
+        big = rng.random() < 0.05                                       # a count past 16 bits: wide
+        tot = sorted((rng.randint(1, 70000 if big else 300) for _ in range(k)), reverse=True)
+        c["ref_base"] = rng.choice(list(b"ACGTNacgtn"))
+        c["raw_depth"] = rng.randint(0, 4_000_000_000) if rng.random() < 0.1 else rng.randint(0, 400)
+        c["n_symbols"] = k
+        c["status"] = L.ST_OK
+        c["cons_base"] = syms[0] if k else ord("-")
+        c["filters"] = rng.randint(0, 63) if rng.random() < 0.5 else 0
+        for r in range(k):
+            f = rng.randint(0, tot[r])
+            # (a symbol between 'Z' and 'a' is on neither strand, pileup.py:269-274: forward + reverse may stay below the total)
+            c["sym"][r], c["total"][r], c["fwd"][r], c["rev"][r] = syms[r], tot[r], f, tot[r] - f - (1 if tot[r] - f > 0 and rng.random() < 0.05 else 0)
+        c["good_depth"] = int(c["total"].sum())
+        c["fwd_good_depth"], c["rev_good_depth"] = int(c["fwd"].sum()), int(c["rev"].sum())
+        flags[i] = rng.choice([0, 0, 1, 3])
+        name = rng.choice(["c", "ctg_7", "gi|9626243|ref|NC_001416.1|", "NODE_1_length_419034_cov_23.1", "n" * 900])
+        value = rng.choice([0, 5, 17, 99_999, 4_000_000_000, 12_345_678_901_234_567_890])
+        pos_text, pos_int = rng.choice([("%d" % value, value), ("+%d" % value, value), ("00%d" % value, value), ("-%d" % value, -value),
+                                        ("1_000" if value else "0_0", 1000 if value else 0)])
+        lead = rng.choice(["", "", " ", "\t "])
+        sep = rng.choice(["\t", "\t", "  ", " \t"])
+        end = rng.choice(["\n", "\n", "\r\n"])
+        text = "%s%s%s%s\tA\t3\t.,.\tIII%s" % (lead, name, sep, pos_text, end)
+        lines.append(text)
+        offs.append(at + 1)
+        heads.append((name, pos_int))
+        at += len(text)
+    pileup = "".join(lines).encode()
+    offs = np.array(offs, dtype=np.uint64)
+    recs, widx, wide = dev.pack_line_records(counts, flags)
+    assert 0 < len(widx) < n // 2 and (recs["n_symbols"][widx] == dev.LINE_WIDE).all()
+    assert set(widx.tolist()) == {i for i in range(n) if int(counts[i]["n_symbols"]) > 3 or int(counts[i]["total"].max()) > 65535}
+    flags2, back = dev.expand_line_records(recs, widx, wide)
+    assert np.array_equal(flags2, flags) and back.tobytes() == counts.tobytes()
+    for gt, preserve, only_listed in ((".", False, False), ("0", True, False), ("1", False, True)):
+        got, n_rows = vcf_writer.format_line_rows(pileup, offs, recs, widx, wide, names, preserve, gt, only_listed=only_listed)
+        keep = [i for i in range(n) if flags[i] or not only_listed]
+        want = "".join(vcf_writer.row_from_counts(heads[i][0], heads[i][1], counts[i], names, preserve, gt) + "\n" for i in keep)
+        assert n_rows == len(keep)
+        if got.decode() != want:
+            g, w = got.decode().split("\n"), want.split("\n")
+            k = next(j for j in range(len(w)) if j >= len(g) or g[j] != w[j])
+            raise AssertionError("row %d:\n%r\n%r" % (k, g[k] if k < len(g) else None, w[k]))
+    # a range of the file on its own (what a piece of the file-to-file writer is), and nothing at all
+    part, n_part = vcf_writer.format_line_rows(pileup, offs[100:250], recs[100:250], [w - 100 for w in widx if 100 <= w < 250],
+                                               wide[[k for k, w in enumerate(widx) if 100 <= w < 250]], names, False, ".")
+    assert n_part == 150 and part.decode() == "".join(vcf_writer.row_from_counts(heads[i][0], heads[i][1], counts[i], names, False, ".") + "\n" for i in range(100, 250))
+    assert vcf_writer.format_line_rows(pileup, offs[:0], recs[:0], widx[:0], wide[:0], names, False, ".") == (b"", 0)
+    # an offset outside the text, a wide line without its record: refused
+    with pytest.raises(ValueError):
+        vcf_writer.format_line_rows(pileup, np.array([len(pileup) + 5], dtype=np.uint64), recs[:1], widx[:0], wide[:0], names, False, ".")
+    k = int(widx[0])
+    with pytest.raises(ValueError):
+        vcf_writer.format_line_rows(pileup, offs[k:k + 1], recs[k:k + 1], widx[:0], wide[:0], names, False, ".")
