@@ -4,7 +4,7 @@ fixed ones).  Usage: python tools/fuzz_campaign.py [seconds] [first seed]   -> o
 agreed; the first disagreement is written to gpurun_out/fuzz/ (input bytes + what differed) and ends the run with exit code 1.
 
 Kinds: fuzz.fuzz_line files (adversarial read-base columns, odd separators) with three caller parameter sets; synthetic pileups of
-random shape (depth 2-300, 1-3 contigs with names of 1-50 bytes, CR LF / mixed / VT FF line ends, repeated positions) through the
+random shape (depth 2-300, 1-12 contigs with names of 1-50 bytes, CR LF / mixed / VT FF line ends, repeated positions) through the
 file-level scan + call; site calling (fuzz.varscan_pileup / varscan_adversarial) with two option sets against the VarScan
 restatement."""
 import os
@@ -129,7 +129,7 @@ def main():
                 check_against_oracle(d, data, keys[::step] if step > 1 else keys, keys[::13], rng.choice(param_sets))
             elif kind == "shapes":
                 contigs = tuple(rng.choice(["c", "ctg%d" % rng.randint(1, 99), "NODE_%d_length_%d_cov_1.5" % (rng.randint(1, 999), rng.randint(100, 99999)),
-                                            "n" * rng.randint(17, 50)]) + ("_%d" % k) for k in range(rng.randint(1, 3)))
+                                            "n" * rng.randint(17, 50)]) + ("_%d" % k) for k in range(rng.choice([1, 1, 2, 3, 3, 6, 12])))      # (6, 12: several contig changes per scan tile)
                 depth = rng.choice([2, 8, 15, 30, 30, 100, 300])
                 glen = rng.choice([g for g in (300, 2000, 9000, 30000) if g * depth * len(contigs) <= 600000])
                 data, _, sites = fuzz.synth_pileup(seed, genome_len=glen, contigs=contigs, mean_depth=depth, n_sites=rng.choice([5, 60, 250]))
