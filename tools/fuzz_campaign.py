@@ -131,7 +131,7 @@ def main():
                 contigs = tuple(rng.choice(["c", "ctg%d" % rng.randint(1, 99), "NODE_%d_length_%d_cov_1.5" % (rng.randint(1, 999), rng.randint(100, 99999)),
                                             "n" * rng.randint(17, 50)]) + ("_%d" % k) for k in range(rng.choice([1, 1, 2, 3, 3, 6, 12])))      # (6, 12: several contig changes per scan tile)
                 depth = rng.choice([2, 8, 15, 30, 30, 100, 300])
-                glen = rng.choice([g for g in (300, 2000, 9000, 30000) if g * depth * len(contigs) <= 600000])
+                glen = rng.choice([g for g in (40, 300, 2000, 9000, 30000) if g * depth * len(contigs) <= 600000 and (g > 40 or len(contigs) > 3)])   # (40: a contig of less than a tile)
                 data, _, sites = fuzz.synth_pileup(seed, genome_len=glen, contigs=contigs, mean_depth=depth, n_sites=rng.choice([5, 60, 250]))
                 variant = rng.choice([None, None, "crlf", "mixed", "vt_ff", "repeats", "shuffle", "interleave", "blanks"])
                 if variant in ("shuffle", "interleave", "blanks"):
