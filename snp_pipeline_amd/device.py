@@ -564,6 +564,12 @@ class Device(object):
                                                      C.byref(bad_off), _ptr(bad), _ptr(status))
         if rc == L.E_IO and not os.access(pileup_path, os.R_OK):
             raise PileupIOError("cannot open or read the pileup file %s" % pileup_path)
+        if rc == L.E_IO:
+            # the output could not be written: end as `open(vcf_path, "w")` of the reference's writer does (vcf_writer.py:92-99) —
+            # IOError / PermissionError / FileNotFoundError with the path in it
+            with open(vcf_path, "ab"):
+                pass
+            raise IOError("cannot write %s" % vcf_path)
         has_bad = bad_line.value != 0xFFFFFFFFFFFFFFFF
         if rc in (L.E_PILEUP, L.E_UNSUPPORTED) and int(status[0]) != 0xFFFFFFFFFFFFFFFF:
             if check and has_bad:                                 # a Record-level failure earlier in the file goes first

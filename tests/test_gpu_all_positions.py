@@ -183,6 +183,10 @@ def test_the_first_line_the_reference_cannot_take_ends_the_file_to_file_writer_t
     path, out = str(tmp_path / "p0.pileup"), str(tmp_path / "unchecked.vcf")
     n_lines, n_rows = vcf_writer.write_all_positions_vcf_from_pileup(d, ss, out, "s", args, path, prm, only_listed=True, check=False)
     assert (n_lines, n_rows) == (2 * 399 + 1, 2)
+    # an output that cannot be written ends as open(path, "w") of the reference's writer does (vcf_writer.py:92-99): an OSError with the path
+    with pytest.raises(OSError) as info:
+        vcf_writer.write_all_positions_vcf_from_pileup(d, ss, str(tmp_path / "no_such_dir" / "x.vcf"), "s", args, path, prm, only_listed=True, check=False)
+    assert "no_such_dir" in str(info.value)
     # an empty pileup: the header alone
     empty = str(tmp_path / "empty.pileup")
     open(empty, "wb").close()
