@@ -31,8 +31,9 @@ out = {
                  "mean_depth": bench["config"]["mean_depth"], "snp_sites": bench["config"]["snp_sites"]},
     "FETCH_SIZE_kb_per_launch": fetch_kb, "WRITE_SIZE_kb_per_launch": write_kb,
     "corrections": "FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes (rocprofv3, gfx950); unit KB (x1024); FETCH_SIZE "
-                   "doubled as MI355X_MICROARCH.md prescribes for wide coalesced streaming reads (128-B requests tallied at 64 B); "
-                   "WRITE_SIZE uncalibrated, taken as reported",
+                   "doubled as MI355X_MICROARCH.md prescribes (128-B requests tallied at 64 B) — calibrated on known byte counts for wide "
+                   "coalesced streams AND for scattered 16-byte-per-lane reads in profiles/r6/fetch_calibration.md; WRITE_SIZE taken as "
+                   "reported (exact on a known byte count, same file)",
     "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b, "traffic_bytes_per_launch": fetch_b + write_b,
     "algorithmic_bytes_per_launch": algo, "traffic_over_algorithmic": (fetch_b + write_b) / algo,
 }
