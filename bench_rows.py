@@ -22,7 +22,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-PROFILE_ROUND = "r6"
 PROFILE_ROUNDS = ("r6", "r5", "r3", "r2", "r1")   # where a committed PMC pass of the same workload may be found, newest first
 
 

@@ -105,7 +105,6 @@ def _selftest(device, rank, world, timeout_ms=120000):
     all-to-all with a different size for every pair, checked byte for byte.  The first time ranks of a job meet on hardware this
     takes the place of a hang in the middle of a step: a failure (or no completion within the time limit) is reported, the
     communicator is given up and the job goes on over torch.distributed.  Returns None, or what went wrong."""
-    import numpy as np
     side = torch.cuda.Stream()
     try:
         with torch.cuda.stream(side):
