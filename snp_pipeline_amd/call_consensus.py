@@ -246,9 +246,10 @@ def _call_one_on(plan, dev, params, ss, snp_slots):
         # when the scan has already met a line it cannot take: which line ends the run is decided among all of them)
         if all_pos and int(rcs[0]) in (L.E_PILEUP, L.E_UNSUPPORTED):
             dev.call_all_lines(ss, plan.read_path, params, capacity=results[0].n_lines, check=True)
-        dev.raise_file_status(plan.read_path, int(rcs[0]), results[0], check=not all_pos)
-        if not all_pos:
-            dev.check_repeated_positions(ss, plan.read_path, params, results[0])
+        if all_pos:
+            dev.raise_file_status(plan.read_path, int(rcs[0]), results[0], check=False)
+        else:
+            dev.raise_file_errors(ss, plan.read_path, params, int(rcs[0]), results[0])
     except devmod.PileupFormatError as err:
         _raise_as_reference(err, plan.read_path, bool(args.vcfAllPos))
     _write_outputs(plan, dev, ss, snp_slots, results[0])
@@ -357,8 +358,7 @@ def call_consensus_batch(args):
                             if mine is not None:
                                 flags[mine[mine >= 0]] |= L.SITE_EXCLUDED
                         # (positions that are only on OTHER samples' exclude lists are nothing this sample is asked about)
-                        dev.raise_file_status(plan.pileup_path, int(rc), res, wanted=(flags != 0) if with_excl else None)
-                        dev.check_repeated_positions(ss, plan.pileup_path, params, res)
+                        dev.raise_file_errors(ss, plan.pileup_path, params, int(rc), res, wanted=(flags != 0) if with_excl else None)
                         needs_device = bool(plan.vcf_path) and (args.vcfAllPos or res.n_matched > int(np.count_nonzero(res.line_offsets)))
                         if needs_device:      # (the all-lines pass: a device call, so here and now)
                             with lock:

@@ -485,10 +485,12 @@ class Device(object):
         return results, rcs[:n_files], stats
 
     @_again_on_spill_overflow
-    def call_all_lines(self, siteset, path, params, capacity=0, check=True):
+    def call_all_lines(self, siteset, path, params, capacity=0, check=True, listed_only=False):
         """call_consensus --vcfAllPos: a record for EVERY line of the pileup file, in file order.
         Returns (line_offsets + 1, line site flags, counts records).  Raises like the reference for malformed lines
-        (check=False: only for malformed chrom / position columns; the caller looks at the records it uses)."""
+        (check=False: only for malformed chrom / position columns; the caller looks at the records it uses; listed_only: the
+        Record-level failures that count are those of lines at positions of the site set — the reader with a position set builds no
+        Record from the others, pileup.py:427-429 — and the first line the reference cannot take, of either kind, decides)."""
         n_lines = C.c_uint64()
         status = np.zeros(L.SCAN_STATUS_WORDS, dtype=np.uint64)
         while True:
@@ -502,8 +504,9 @@ class Device(object):
                 raise PileupIOError("cannot open or read the pileup file %s" % path)
             if rc in (L.E_PILEUP, L.E_UNSUPPORTED) and int(status[0]) != 0xFFFFFFFFFFFFFFFF:
                 if check and 0 < n_lines.value <= cap:          # the records are there: a Record-level failure earlier in the file goes first
-                    res = ConsensusResult(None, None, counts[:n_lines.value], status)
-                    res.line_offsets = off[:n_lines.value]
+                    keep = np.nonzero(flags[:n_lines.value])[0] if listed_only else slice(0, n_lines.value)
+                    res = ConsensusResult(None, None, counts[:n_lines.value][keep], status)
+                    res.line_offsets = off[:n_lines.value][keep]
                     self.raise_first_error(status, res, True)
                 self.raise_scan_status(status)
             self._check(rc)
@@ -512,7 +515,7 @@ class Device(object):
             capacity = n_lines.value
         n = n_lines.value
         if check:
-            self.raise_site_status(ConsensusResult(None, None, counts[:n], status))
+            self.raise_site_status(ConsensusResult(None, None, counts[:n][flags[:n] != 0] if listed_only else counts[:n], status))
         self.last_spill = self.read_symbol_spill(counts[:n])     # (for the rows of these records: vcf_writer.write_all_positions_vcf)
         return off[:n], flags[:n], counts[:n]
 
@@ -644,6 +647,21 @@ class Device(object):
             err, _ = self.site_error(res, wanted)
             if err is not None:
                 raise err
+
+    def raise_file_errors(self, siteset, path, params, rc, res, wanted=None):
+        """raise_file_status and check_repeated_positions as ONE decision, which is what the reference's single pass is: it ends at
+        the first line it cannot take.  Where no listed position comes twice the per-site result knows every matching line and
+        raise_file_status decides; where one does, it knows only the LAST line of that position — an earlier malformed line of the same
+        position is hidden behind a later one, which may lie behind a reader-level error (found by the fuzz campaign of round 6: a
+        position three times, two of its lines malformed, a bad position column between them) — so every line at a listed position is
+        looked at in file order by the all-lines pass, beside the reader-level error."""
+        repeats = res.line_offsets is not None and res.n_matched > int(np.count_nonzero(res.line_offsets))
+        if not repeats or rc == L.E_IO:
+            self.raise_file_status(path, rc, res, True, wanted)
+            return
+        self.call_all_lines(siteset, path, params, capacity=res.n_lines, check=True, listed_only=True)
+        if rc != 0 and rc not in (L.E_PILEUP, L.E_UNSUPPORTED):
+            raise SnpGpuError(int(rc), "pileup %s" % path)
 
     def check_repeated_positions(self, siteset, path, params, res):
         """A pileup that repeats a listed position: the per-site result knows the LAST line of a position, the reference builds a

@@ -840,3 +840,45 @@ def test_many_contig_changes_inside_one_scan_tile(d, depth_sum):
         ss = d.siteset(snps, [L.SITE_IN_SNPLIST] * len(snps))
         r2 = d.call_consensus(ss, data, devmod_params(p), want_counts=False, want_depth_sum=True)
         assert r2.depth_sum == po.depth_sum(data)
+
+
+def test_an_earlier_malformed_line_hidden_behind_a_later_line_of_its_position(d, tmp_path):
+    """Found by tools/fuzz_campaign.py in round 6 (seed 867783): a listed position that comes three times — well-formed, then with
+    three fields (IndexError), then with a depth of 'C' (ValueError) — and a line with a bad position column between the last two.
+    The per-site result knows only the LAST line of the position (ValueError, behind the reader-level ValueError), the reference ends
+    at the first of them all (IndexError): Device.raise_file_errors lets the all-lines pass decide whenever a listed position repeats."""
+    from snp_pipeline_amd.device import PileupFormatError
+    good = b"".join(b"c1\t%d\tA\t3\t...\tIII\n" % k for k in range(1, 60))
+    tail = b"".join(b"c1\t%d\tA\t3\t...\tIII\n" % k for k in range(61, 90))
+    three = b"c1\t5\tA\n"                      # position 5 again: IndexError when listed
+    bad_depth = b"c1\t5\t8\tC\t1\tg\tJ\n"      # ... and again: ValueError when listed
+    bad_pos = b"12\tT\t9\t,,,,....,\tDJH@ED?BC\n"
+    again = b"c1\t5\tG\t2\t..\tII\n"           # ... and a well-formed last one
+    p = po.CallerParams()
+    cases = [(good + three + bad_pos + bad_depth + tail, [(b"c1", 5)], IndexError),
+             (good + bad_depth + bad_pos + three + tail, [(b"c1", 5)], ValueError),
+             (good + bad_pos + three + bad_depth + tail, [(b"c1", 5)], ValueError),       # the reader-level line first
+             (good + three + bad_depth + again + tail, [(b"c1", 5)], IndexError),         # no reader-level error, the last line of the position is fine
+             (good + three + bad_pos + bad_depth + tail, [(b"c1", 7)], ValueError),       # position 5 not listed: only the reader-level line counts
+             (good + three + again + tail, [(b"c1", 5), (b"c1", 9)], IndexError)]
+    for k, (data, keys, exc) in enumerate(cases):
+        with pytest.raises(exc):
+            po.call_consensus_sites(data, keys, set(), p)
+        path = str(tmp_path / ("f%d.pileup" % k))
+        with open(path, "wb") as f:
+            f.write(data)
+        ss = d.siteset(keys, [1] * len(keys))
+        results, rcs, _ = d.call_consensus_files(ss, [path], devmod_params(p), want_counts=True, want_line_offsets=True)
+        with pytest.raises(PileupFormatError) as ei:
+            d.raise_file_errors(ss, path, devmod_params(p), int(rcs[0]), results[0])
+        assert ei.value.reference_exception is exc, (k, exc, ei.value)
+    # ... and the same through the console script's function: the exception class the reference ends with
+    from snp_pipeline_amd import cfsan_snp_pipeline as cli
+    data, keys, exc = cases[0]
+    sdir = tmp_path / "s"
+    sdir.mkdir()
+    (sdir / "reads.all.pileup").write_bytes(data)
+    (tmp_path / "snplist.txt").write_text("c1\t5\t1\ts\n")
+    a = cli.parse_argument_list(("call_consensus -v 0 -f -l %s/snplist.txt -o %s/consensus.fasta %s/reads.all.pileup" % (tmp_path, sdir, sdir)).split())
+    with pytest.raises(exc):
+        a.func(a)

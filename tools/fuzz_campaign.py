@@ -79,8 +79,7 @@ def main():
         try:
             prm = devmod.make_params(p.min_base_quality, p.min_cons_freq, p.min_cons_depth, p.min_cons_strand_depth, p.min_cons_strand_bias)
             results, rcs, _ = d.call_consensus_files(ss, [path], prm, want_counts=True, want_line_offsets=True)
-            d.raise_file_status(path, int(rcs[0]), results[0])
-            d.check_repeated_positions(ss, path, prm, results[0])
+            d.raise_file_errors(ss, path, prm, int(rcs[0]), results[0])
             idx = ss.index_of[:len(keys)]
             return bytes(int(results[0].bases[i]) if i >= 0 else 0x2D for i in idx)
         finally:
