@@ -389,7 +389,8 @@ class Device(object):
     def call_consensus(self, siteset, pileup, params, want_counts=False, want_depth_sum=False, check=True):
         """pileup: bytes-like (host).  Returns ConsensusResult over siteset.keys order.  check=False: do not raise for
         the per-site failures the reference raises on (malformed line at a listed position); the scan-level errors
-        (malformed chrom / position column anywhere in the file) always raise."""
+        (malformed chrom / position column anywhere in the file) always raise.  (A buffer that repeats a listed position: the result
+        knows the last line of the position only; the commands go through files and raise_file_errors, which looks at every line.)"""
         buf = np.frombuffer(pileup, dtype=np.uint8)
         n = len(siteset)
         bases = np.empty(n, dtype=np.uint8)
