@@ -434,13 +434,14 @@ def call_variants(d, ss, prm, pile, offs, sizes, S, dev, torch, pos):
         n_l, n_rows = vcf_writer.write_all_positions_vcf_from_pileup(d, ss, vcf, "s0", cc, path, prm)
         wall_vcf = time.perf_counter() - t0
         vcf_bytes = os.path.getsize(vcf)
-        # its rows against the row-by-row writer on the first 2 000 and the last 2 000 lines
+        # its rows against the row-by-row writer: the ends of the file and a sample spread over all of it
         filt = [n for n, _ in vcf_writer.filter_descriptions(0.6, 3, 0, 0.0)]
         with open(vcf, "rb") as f:
             rows = [ln for ln in f.read().split(b"\n") if ln and not ln.startswith(b"#")]
         if n_rows != len(off) or len(rows) != len(off):
             raise SystemExit("--vcfAllPos: %d rows for %d lines" % (len(rows), len(off)))
-        for k in list(range(0, min(2000, len(off)))) + list(range(max(0, len(off) - 2000), len(off))):
+        stride = max(len(off) // 4000, 1)                                        # the first and the last 1 000 rows and 4 000 spread over every piece of the read-back
+        for k in sorted(set(list(range(0, min(1000, len(off)))) + list(range(0, len(off), stride)) + list(range(max(0, len(off) - 1000), len(off))))):
             o = int(off[k]) - 1
             f0, f1 = text[o:o + 256].split(None, 2)[:2]
             if rows[k].decode() != vcf_writer.row_from_counts(f0.decode(), int(f1), recs[k], filt, False, ".", spill=d.last_spill):
@@ -453,7 +454,7 @@ def call_variants(d, ss, prm, pile, offs, sizes, S, dev, torch, pos):
             "bytes_back_over_the_host_link": written, "wide_lines": int(len(widx)),
             "with_128_byte_records_ms": wall_full * 1e3, "with_128_byte_records_bytes_back": len(off) * (dev.COUNTS_DTYPE.itemsize + 8 + 1),
             "file_to_vcf_file": {"ms": wall_vcf * 1e3, "rows": int(n_rows), "vcf_bytes": vcf_bytes, "rows_per_sec": n_rows / wall_vcf,
-                                 "rows_checked_against_the_row_by_row_writer": min(4000, len(off)),
+                                 "rows_checked_against_the_row_by_row_writer": min(6000, len(off)),
                                  "what": "reads.all.pileup (page cache) -> consensus.vcf with a row per line, snpgpu_write_all_positions_vcf: records back in pieces, "
                                          "rows formatted and written by the library's host threads"},
             "roofline": {"kernels": "K2 over a line list: k_call_lanes x3 + k_call_sites", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
