@@ -222,3 +222,80 @@ def test_region_steps_at_configs4_scale(d):
     idx = np.searchsorted(key_s, p + pos_group.astype(np.int64) * (1 << 40), side="right") - 1
     inside = (idx >= 0) & (want_g[np.maximum(idx, 0)] == pos_group) & (p <= want_e[np.maximum(idx, 0)])
     assert np.array_equal(flags, inside) and 0.01 < inside.mean() < 0.99
+
+
+def test_all_positions_vcf_of_a_full_size_sample(d, tmp_path):
+    """`call_consensus --vcfAllPos` at BASELINE's sample shape (5 Mbp x 30x: 5 M lines, 76 pieces of the read-back, 470 MB of rows),
+    through the file-to-file writer.  Size-independent properties: a row per line, in file order (POS strictly ascending, CHROM the
+    one contig), the SDP column adds up to the depth-column sum of the scan (collect_metrics.py:325-340), RD + sum(AD) of every row is
+    the good depth the 32-byte records carry; the records equal the 128-byte ones; a sample of rows spread over the file equals the
+    row-by-row Python writer."""
+    import argparse
+    import torch
+    from snp_pipeline_amd import device as dev
+    from snp_pipeline_amd import _lib as L
+    from snp_pipeline_amd import vcf_writer
+    G, S = 5_000_000, 50_000
+    d.use_torch_stream()
+    ref = torch.empty(G + 1, dtype=torch.uint8, device="cuda")
+    d.synth_reference_dev(1, G, ref.data_ptr())
+    refh = ref.cpu().numpy()
+    rng = np.random.default_rng(2)
+    pos = np.sort(rng.choice(np.arange(501, G - 499), size=S, replace=False))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    alt_h = np.zeros(G + 1, dtype=np.uint8)
+    alt_h[pos] = acgt[(np.searchsorted(acgt, refh[pos]) + 1 + rng.integers(0, 3, size=S)) % 4]
+    alt = torch.from_numpy(alt_h).cuda()
+    n = d.synth_pileup_dev(3, 0, G, ref.data_ptr(), alt.data_ptr(), 0, 0)
+    buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    assert d.synth_pileup_dev(3, 0, G, ref.data_ptr(), alt.data_ptr(), buf.data_ptr(), n) == n
+    text = buf[:n].cpu().numpy().tobytes()
+    del buf
+    path, out = str(tmp_path / "reads.all.pileup"), str(tmp_path / "consensus.vcf")
+    with open(path, "wb") as f:
+        f.write(text)
+    args = argparse.Namespace(minBaseQual=0, minConsFreq=0.6, minConsDpth=3, minConsStrdDpth=0, minConsStrdBias=0.0, vcfRefName="ref.fasta",
+                              vcfPreserveRefCase=False, vcfFailedSnpGt=".")
+    prm = dev.make_params(0, 0.6, 3, 0, 0.0)
+    ss = d.siteset([(b"synth_chr1", int(p_)) for p_ in pos], [L.SITE_IN_SNPLIST] * S)
+    n_lines, n_rows = vcf_writer.write_all_positions_vcf_from_pileup(d, ss, out, "s0", args, path, prm)
+    assert n_lines == n_rows == text.count(b"\n") > 4_900_000
+    off, recs, widx, wide = d.call_all_lines_compact(ss, path, prm, capacity=n_lines, wide_capacity=n_lines // 100)
+    off_full, flags_full, counts_full = d.call_all_lines(ss, path, prm, capacity=n_lines, check=True)
+    flags, counts = dev.expand_line_records(recs, widx, wide)
+    assert np.array_equal(off, off_full) and np.array_equal(flags, flags_full) and counts.tobytes() == counts_full.tobytes()     # (no spill records in this file)
+    assert int(flags.astype(bool).sum()) >= 0.97 * S and len(widx) < n_lines // 1000
+    del counts_full, off_full, flags_full
+    # the file: the scan's depth-column sum, one row per line in order
+    res = d.call_consensus_files(ss, [path], prm, want_depth_sum=True)[0][0]
+    sdp_sum, good_sum, prev, rows = 0, 0, 0, 0
+    with open(out, "rb") as f:
+        for ln in f:
+            if ln[0] == 35:                                             # '#'
+                continue
+            c = ln.split(b"\t")
+            p_ = int(c[1])
+            assert c[0] == b"synth_chr1" and p_ > prev
+            prev = p_
+            v = c[9].split(b":")
+            sdp_sum += int(v[1])
+            good_sum += int(v[2]) + (0 if v[3] == b"0" and c[4] == b"." else sum(int(x) for x in v[3].split(b",")))
+            rows += 1
+    assert rows == n_lines and sdp_sum == res.depth_sum == int(counts["raw_depth"].astype(np.int64).sum())
+    assert good_sum == int(counts["good_depth"].astype(np.int64).sum())
+    # rows spread over the file against the Python writer
+    names = [nm for nm, _ in vcf_writer.filter_descriptions(0.6, 3, 0, 0.0)]
+    pick = np.unique(np.concatenate([np.arange(0, n_lines, 997), widx[:200].astype(np.int64), np.arange(n_lines - 50, n_lines)]))
+    want = {}
+    for k in pick:
+        o = int(off[k]) - 1
+        f0, f1 = text[o:o + 64].split(None, 2)[:2]
+        want[int(k)] = vcf_writer.row_from_counts(f0.decode(), int(f1), counts[k], names, False, ".").encode() + b"\n"
+    with open(out, "rb") as f:
+        k = 0
+        for ln in f:
+            if ln[0] == 35:
+                continue
+            if k in want:
+                assert ln == want[k], k
+            k += 1
